@@ -1,0 +1,207 @@
+/*
+ * refenc.c -- TEST INFRASTRUCTURE: in-memory driver around the REAL reference
+ * library (mozjpeg compiled from /root/reference into oracle/_ref/libjpeg.so.62).
+ *
+ * Why it exists: (1) tjbench / TurboJPEG force JCP_FASTEST (turbojpeg.c:336) and so can
+ * never reach the trellis path; cjpeg reaches it but only file->file.  This driver makes
+ * the same libjpeg API calls cjpeg makes (cjpeg.c:813-1023) with jpeg_mem_dest, so the
+ * reference CPU path can be timed in memory ("cpu_baseline.kind = reference") and its
+ * bytes used as goldens.  (2) -dumpcoef re-reads the produced file with
+ * jpeg_read_coefficients (jpeglib.h:1177) to give the post-trellis quantized
+ * coefficients as a stage-level oracle.
+ *
+ * usage: refenc [switches] in.(ppm|rgb) out.jpg
+ *   -raw W H        input is headerless interleaved RGB (or gray with -grayin), 8-bit
+ *   -grayin         raw input has 1 component
+ *   -quality N  -baseline  -revert  -optimize  -progressive  -fastcrush
+ *   -notrellis  -notrellis-dc  -noovershoot  -sample HxV  -restart N[B]  -gray
+ *   -quant-table N  -lambda1 F -lambda2 F
+ *   -reps N         encode N times, report best and mean wall time
+ *   -dumpcoef FILE  dump quantized coefficients of the output
+ * Not part of the product; nothing under mozjpeg_amd/ links to or executes it.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "jpeglib.h"
+
+static double now(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static unsigned char *read_ppm(const char *fn, int *w, int *h, int *nc)
+{
+  FILE *f = fopen(fn, "rb");
+  char magic[3] = { 0 };
+  int maxv, c;
+  unsigned char *buf;
+  if (!f) { perror(fn); exit(2); }
+  if (fscanf(f, "%2s", magic) != 1) exit(2);
+  *nc = (magic[1] == '6') ? 3 : 1;
+  /* skip comments */
+  for (;;) {
+    c = fgetc(f);
+    if (c == '#') { while ((c = fgetc(f)) != '\n' && c != EOF) {} }
+    else if (c == ' ' || c == '\n' || c == '\r' || c == '\t') continue;
+    else { ungetc(c, f); break; }
+  }
+  if (fscanf(f, "%d %d %d", w, h, &maxv) != 3 || maxv != 255) { fprintf(stderr, "bad ppm\n"); exit(2); }
+  fgetc(f);
+  buf = malloc((size_t)(*w) * (*h) * (*nc));
+  if (fread(buf, 1, (size_t)(*w) * (*h) * (*nc), f) != (size_t)(*w) * (*h) * (*nc)) { fprintf(stderr, "short ppm\n"); exit(2); }
+  fclose(f);
+  return buf;
+}
+
+int main(int argc, char **argv)
+{
+  int quality = 75, baseline = 0, revert = 0, optimize = 0, progressive = 0, fastcrush = 0;
+  int notrellis = 0, notrellis_dc = 0, noovershoot = 0, gray = 0, grayin = 0, qtbl = -1;
+  int hs = 2, vs = 2, restart = 0, restart_blocks = 0, reps = 1, rawW = 0, rawH = 0;
+  double l1 = -1e9, l2 = -1e9;
+  const char *dump = NULL, *in = NULL, *out = NULL;
+  int i, w, h, nc;
+  unsigned char *img;
+  unsigned char *jbuf = NULL;
+  unsigned long jsize = 0;
+  double best = 1e30, total = 0;
+
+  for (i = 1; i < argc; i++) {
+    const char *a = argv[i];
+    if (!strcmp(a, "-quality")) quality = atoi(argv[++i]);
+    else if (!strcmp(a, "-baseline")) baseline = 1;
+    else if (!strcmp(a, "-revert")) revert = 1;
+    else if (!strcmp(a, "-optimize")) optimize = 1;
+    else if (!strcmp(a, "-progressive")) progressive = 1;
+    else if (!strcmp(a, "-fastcrush")) fastcrush = 1;
+    else if (!strcmp(a, "-notrellis")) notrellis = 1;
+    else if (!strcmp(a, "-notrellis-dc")) notrellis_dc = 1;
+    else if (!strcmp(a, "-noovershoot")) noovershoot = 1;
+    else if (!strcmp(a, "-gray")) gray = 1;
+    else if (!strcmp(a, "-grayin")) grayin = 1;
+    else if (!strcmp(a, "-quant-table")) qtbl = atoi(argv[++i]);
+    else if (!strcmp(a, "-lambda1")) l1 = atof(argv[++i]);
+    else if (!strcmp(a, "-lambda2")) l2 = atof(argv[++i]);
+    else if (!strcmp(a, "-sample")) { sscanf(argv[++i], "%dx%d", &hs, &vs); }
+    else if (!strcmp(a, "-restart")) {
+      char ch = 'x'; long v = 0;
+      sscanf(argv[++i], "%ld%c", &v, &ch);
+      restart = (int)v; restart_blocks = (ch == 'b' || ch == 'B');
+    }
+    else if (!strcmp(a, "-reps")) reps = atoi(argv[++i]);
+    else if (!strcmp(a, "-raw")) { rawW = atoi(argv[++i]); rawH = atoi(argv[++i]); }
+    else if (!strcmp(a, "-dumpcoef")) dump = argv[++i];
+    else if (!in) in = a;
+    else out = a;
+  }
+  if (!in || !out) { fprintf(stderr, "usage: refenc [switches] in out.jpg\n"); return 2; }
+
+  if (rawW) {
+    FILE *f = fopen(in, "rb");
+    size_t n;
+    if (!f) { perror(in); return 2; }
+    w = rawW; h = rawH; nc = grayin ? 1 : 3;
+    n = (size_t)w * h * nc;
+    img = malloc(n);
+    if (fread(img, 1, n, f) != n) { fprintf(stderr, "short raw\n"); return 2; }
+    fclose(f);
+  } else
+    img = read_ppm(in, &w, &h, &nc);
+
+  for (i = 0; i < reps; i++) {
+    struct jpeg_compress_struct cinfo;
+    struct jpeg_error_mgr jerr;
+    JSAMPROW *rows;
+    int y;
+    double t0, t1;
+
+    if (jbuf) { free(jbuf); jbuf = NULL; jsize = 0; }
+    t0 = now();
+    cinfo.err = jpeg_std_error(&jerr);
+    jpeg_create_compress(&cinfo);
+    cinfo.in_color_space = (nc == 3) ? JCS_RGB : JCS_GRAYSCALE;
+    cinfo.input_components = nc;
+    if (revert)
+      jpeg_c_set_int_param(&cinfo, JINT_COMPRESS_PROFILE, JCP_FASTEST);
+    jpeg_set_defaults(&cinfo);
+    cinfo.image_width = w;
+    cinfo.image_height = h;
+    cinfo.dct_method = JDCT_ISLOW;
+    if (qtbl >= 0) jpeg_c_set_int_param(&cinfo, JINT_BASE_QUANT_TBL_IDX, qtbl);
+    if (l1 > -1e8) jpeg_c_set_float_param(&cinfo, JFLOAT_LAMBDA_LOG_SCALE1, (float)l1);
+    if (l2 > -1e8) jpeg_c_set_float_param(&cinfo, JFLOAT_LAMBDA_LOG_SCALE2, (float)l2);
+    if (gray) jpeg_set_colorspace(&cinfo, JCS_GRAYSCALE);
+    jpeg_set_quality(&cinfo, quality, baseline ? TRUE : FALSE);
+    if (baseline) { cinfo.num_scans = 0; cinfo.scan_info = NULL; }
+    if (optimize) cinfo.optimize_coding = TRUE;
+    if (fastcrush) { jpeg_c_set_bool_param(&cinfo, JBOOLEAN_OPTIMIZE_SCANS, FALSE); progressive = 1; }
+    if (progressive) jpeg_simple_progression(&cinfo);
+    if (notrellis) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_TRELLIS_QUANT, FALSE);
+    if (notrellis_dc) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_TRELLIS_QUANT_DC, FALSE);
+    if (noovershoot) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_OVERSHOOT_DERINGING, FALSE);
+    if (cinfo.num_components == 3) {
+      cinfo.comp_info[0].h_samp_factor = hs;
+      cinfo.comp_info[0].v_samp_factor = vs;
+      cinfo.comp_info[1].h_samp_factor = cinfo.comp_info[1].v_samp_factor = 1;
+      cinfo.comp_info[2].h_samp_factor = cinfo.comp_info[2].v_samp_factor = 1;
+    }
+    if (restart) {
+      if (restart_blocks) { cinfo.restart_interval = restart; cinfo.restart_in_rows = 0; }
+      else cinfo.restart_in_rows = restart;
+    }
+    jpeg_mem_dest(&cinfo, &jbuf, &jsize);
+    jpeg_start_compress(&cinfo, TRUE);
+    rows = malloc(sizeof(JSAMPROW) * h);
+    for (y = 0; y < h; y++) rows[y] = img + (size_t)y * w * nc;
+    while (cinfo.next_scanline < cinfo.image_height)
+      jpeg_write_scanlines(&cinfo, rows + cinfo.next_scanline, cinfo.image_height - cinfo.next_scanline);
+    jpeg_finish_compress(&cinfo);
+    jpeg_destroy_compress(&cinfo);
+    free(rows);
+    t1 = now();
+    if (t1 - t0 < best) best = t1 - t0;
+    total += t1 - t0;
+  }
+  {
+    FILE *f = fopen(out, "wb");
+    if (!f) { perror(out); return 2; }
+    fwrite(jbuf, 1, jsize, f);
+    fclose(f);
+  }
+  printf("{\"width\": %d, \"height\": %d, \"bytes\": %lu, \"reps\": %d, \"best_s\": %.6f, \"mean_s\": %.6f, \"mpix_per_s_best\": %.3f}\n",
+         w, h, jsize, reps, best, total / reps, (double)w * h / best / 1e6);
+
+  if (dump) {
+    struct jpeg_decompress_struct d;
+    struct jpeg_error_mgr jerr;
+    jvirt_barray_ptr *arrs;
+    FILE *f = fopen(dump, "wb");
+    int ci;
+    d.err = jpeg_std_error(&jerr);
+    jpeg_create_decompress(&d);
+    jpeg_mem_src(&d, jbuf, jsize);
+    jpeg_read_header(&d, TRUE);
+    arrs = jpeg_read_coefficients(&d);
+    for (ci = 0; ci < d.num_components; ci++) {
+      jpeg_component_info *c = &d.comp_info[ci];
+      int hdr[2];
+      JDIMENSION r;
+      hdr[0] = c->height_in_blocks; hdr[1] = c->width_in_blocks;
+      fwrite(hdr, sizeof(int), 2, f);
+      for (r = 0; r < c->height_in_blocks; r++) {
+        JBLOCKARRAY ba = (*d.mem->access_virt_barray)((j_common_ptr)&d, arrs[ci], r, 1, FALSE);
+        fwrite(ba[0], sizeof(JBLOCK), c->width_in_blocks, f);
+      }
+    }
+    fclose(f);
+    jpeg_finish_decompress(&d);
+    jpeg_destroy_decompress(&d);
+  }
+  free(jbuf);
+  free(img);
+  return 0;
+}
