@@ -1,0 +1,1495 @@
+/*
+ * mjoracle.c -- TEST INFRASTRUCTURE ONLY (see mjoracle.h for the parity pin statement).
+ *
+ * Plain-C restatement of the mozjpeg encode hot path as a whole-image planar encoder.
+ * Every function names the reference file:line whose behaviour it follows
+ * (paths relative to /root/reference).  Nothing here is used by the product.
+ *
+ * Float discipline: built with -ffp-contract=off; every float expression of
+ * the reference is spelled out one IEEE operation at a time in the reference's
+ * evaluation order, including the float/double promotion points.
+ */
+#include "mjoracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* zig-zag -> natural order, jutils.c:59 (the standard JPEG zig-zag sequence) */
+static const int ZZ[64] = {
+  0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
+  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
+  35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+  58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63
+};
+
+static int nbits_of(unsigned v) /* JPEG_NBITS, jpeg_nbits.h:34-38 */
+{
+  int n = 0;
+  while (v) { n++; v >>= 1; }
+  return n;
+}
+
+static long div_round_up(long a, long b) { return (a + b - 1) / b; } /* jutils.c:79 */
+
+/* ------------------------------------------------------------------------------------------
+ * Parameters: jpeg_set_defaults (jcparam.c:386-519), jpeg_set_quality (jcparam.c:360-380),
+ * jpeg_add_quant_table (jcparam.c:30-68), jpeg_set_colorspace (jcparam.c:573-650).
+ * Base tables: index 0 = Annex K (jcparam.c:76-99 luma, :180-190 chroma),
+ *              index 3 = the max-compression default (jcparam.c:111-122 == :218-229).
+ * ------------------------------------------------------------------------------------------ */
+static const unsigned BASE_LUMA0[64] = {
+  16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55,
+  14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+  18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+  49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99
+};
+static const unsigned BASE_CHROMA0[64] = {
+  17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99,
+  24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+  99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+  99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99
+};
+static const unsigned BASE_3[64] = {
+  16, 16, 16, 18, 25, 37, 56, 85, 16, 17, 20, 27, 34, 40, 53, 75,
+  16, 20, 24, 31, 43, 62, 91, 135, 18, 27, 31, 40, 53, 74, 106, 156,
+  25, 34, 43, 53, 69, 94, 131, 189, 37, 40, 62, 74, 94, 124, 169, 238,
+  56, 53, 91, 106, 131, 169, 226, 311, 85, 75, 135, 156, 189, 238, 311, 418
+};
+
+static void add_quant_table(uint16_t *dst, const unsigned *base, int scale, int force_baseline)
+{
+  int i;
+  for (i = 0; i < 64; i++) {
+    long t = ((long)base[i] * scale + 50L) / 100L;
+    if (t <= 0) t = 1;
+    if (t > 32767) t = 32767;
+    if (force_baseline && t > 255) t = 255;
+    dst[i] = (uint16_t)t;
+  }
+}
+
+void mjo_default_params(mjo_params *p, int width, int height, int input_components,
+                        int gray_output, int quality, int force_baseline, int profile_fastest,
+                        int hsamp, int vsamp, int base_quant_tbl_idx)
+{
+  float q = (float)quality;
+  int scale, i;
+  memset(p, 0, sizeof(*p));
+  p->width = width;
+  p->height = height;
+  p->input_components = input_components;
+  p->fastest_profile = profile_fastest;
+  /* jpeg_float_quality_scaling, jcparam.c:340-357, truncated to int (rdswitch.c:545) */
+  if (q <= 0.f) q = 1.f;
+  if (q > 100.f) q = 100.f;
+  if (q < 50.f) q = 5000.f / q; else q = 200.f - q * 2.f;
+  scale = (int)q;
+  if (base_quant_tbl_idx < 0) base_quant_tbl_idx = profile_fastest ? 0 : 3;
+  if (base_quant_tbl_idx == 3) {
+    add_quant_table(p->qtbl[0], BASE_3, scale, force_baseline);
+    add_quant_table(p->qtbl[1], BASE_3, scale, force_baseline);
+  } else {
+    add_quant_table(p->qtbl[0], BASE_LUMA0, scale, force_baseline);
+    add_quant_table(p->qtbl[1], BASE_CHROMA0, scale, force_baseline);
+  }
+  if (input_components == 1 || gray_output) {
+    p->num_components = 1;
+    p->component_id[0] = 1;
+    p->h_samp[0] = p->v_samp[0] = 1;
+  } else {
+    p->num_components = 3;
+    for (i = 0; i < 3; i++) {
+      p->component_id[i] = i + 1;
+      p->h_samp[i] = p->v_samp[i] = 1;
+      p->quant_tbl_no[i] = p->dc_tbl_no[i] = p->ac_tbl_no[i] = (i > 0);
+    }
+    p->h_samp[0] = hsamp;
+    p->v_samp[0] = vsamp;
+  }
+  p->write_jfif = 1;
+  p->optimize_coding = !profile_fastest;
+  p->trellis_quant = !profile_fastest;
+  p->trellis_quant_dc = 1;
+  p->overshoot_deringing = !profile_fastest;
+  p->lambda_log_scale1 = 14.75f;
+  p->lambda_log_scale2 = 16.5f;
+  p->num_scans = 0;
+  p->optimize_scans = 0;
+}
+
+static mjo_scan *fill_a_scan(mjo_scan *s, int ci, int Ss, int Se, int Ah, int Al)
+{
+  s->comps_in_scan = 1; s->component_index[0] = ci;
+  s->Ss = Ss; s->Se = Se; s->Ah = Ah; s->Al = Al;
+  return s + 1;
+}
+static mjo_scan *fill_dc_scans(mjo_scan *s, int ncomps, int Ah, int Al)
+{ /* jcparam.c:700-725 (ncomps <= MAX_COMPS_IN_SCAN: one interleaved DC scan) */
+  int ci;
+  s->comps_in_scan = ncomps;
+  for (ci = 0; ci < ncomps; ci++) s->component_index[ci] = ci;
+  s->Ss = s->Se = 0; s->Ah = Ah; s->Al = Al;
+  return s + 1;
+}
+
+/* jpeg_simple_progression, jcparam.c:859-1004, max-compression profile, dc_scan_opt_mode 0 */
+void mjo_simple_progression(mjo_params *p)
+{
+  mjo_scan *s = p->scans;
+  int ci, nc = p->num_components;
+  p->optimize_scans = 0;
+  if (nc == 3) {
+    if (!p->fastest_profile) {
+      s = fill_dc_scans(s, nc, 0, 0);
+      s = fill_a_scan(s, 0, 1, 8, 0, 2);
+      s = fill_a_scan(s, 1, 1, 8, 0, 0);
+      s = fill_a_scan(s, 2, 1, 8, 0, 0);
+      s = fill_a_scan(s, 0, 9, 63, 0, 2);
+      s = fill_a_scan(s, 0, 1, 63, 2, 1);
+      s = fill_a_scan(s, 0, 1, 63, 1, 0);
+      s = fill_a_scan(s, 1, 9, 63, 0, 0);
+      s = fill_a_scan(s, 2, 9, 63, 0, 0);
+    } else {
+      s = fill_dc_scans(s, nc, 0, 1);
+      s = fill_a_scan(s, 0, 1, 5, 0, 2);
+      s = fill_a_scan(s, 2, 1, 63, 0, 1);
+      s = fill_a_scan(s, 1, 1, 63, 0, 1);
+      s = fill_a_scan(s, 0, 6, 63, 0, 2);
+      s = fill_a_scan(s, 0, 1, 63, 2, 1);
+      s = fill_dc_scans(s, nc, 1, 0);
+      s = fill_a_scan(s, 2, 1, 63, 1, 0);
+      s = fill_a_scan(s, 1, 1, 63, 1, 0);
+      s = fill_a_scan(s, 0, 1, 63, 1, 0);
+    }
+  } else {
+    if (!p->fastest_profile) {
+      s = fill_dc_scans(s, nc, 0, 0);
+      for (ci = 0; ci < nc; ci++) s = fill_a_scan(s, ci, 1, 8, 0, 2);
+      for (ci = 0; ci < nc; ci++) s = fill_a_scan(s, ci, 9, 63, 0, 2);
+      for (ci = 0; ci < nc; ci++) s = fill_a_scan(s, ci, 1, 63, 2, 1);
+      for (ci = 0; ci < nc; ci++) s = fill_a_scan(s, ci, 1, 63, 1, 0);
+    } else {
+      s = fill_dc_scans(s, nc, 0, 1);
+      for (ci = 0; ci < nc; ci++) s = fill_a_scan(s, ci, 1, 5, 0, 2);
+      for (ci = 0; ci < nc; ci++) s = fill_a_scan(s, ci, 6, 63, 0, 2);
+      for (ci = 0; ci < nc; ci++) s = fill_a_scan(s, ci, 1, 63, 2, 1);
+      s = fill_dc_scans(s, nc, 1, 0);
+      for (ci = 0; ci < nc; ci++) s = fill_a_scan(s, ci, 1, 63, 1, 0);
+    }
+  }
+  p->num_scans = (int)(s - p->scans);
+}
+
+/* jpeg_search_progression, jcparam.c:733-852 (dc_scan_opt_mode 0) */
+void mjo_search_progression(mjo_params *p)
+{
+  static const int fs[5] = { 2, 8, 5, 12, 18 };
+  mjo_scan *s = p->scans;
+  int Al, i, nc = p->num_components;
+  p->optimize_scans = 1;
+  s = fill_dc_scans(s, nc, 0, 0);
+  s = fill_a_scan(s, 0, 1, 8, 0, 0);
+  s = fill_a_scan(s, 0, 9, 63, 0, 0);
+  for (Al = 0; Al < 3; Al++) {
+    s = fill_a_scan(s, 0, 1, 63, Al + 1, Al);
+    s = fill_a_scan(s, 0, 1, 8, 0, Al + 1);
+    s = fill_a_scan(s, 0, 9, 63, 0, Al + 1);
+  }
+  s = fill_a_scan(s, 0, 1, 63, 0, 0);
+  for (i = 0; i < 5; i++) {
+    s = fill_a_scan(s, 0, 1, fs[i], 0, 0);
+    s = fill_a_scan(s, 0, fs[i] + 1, 63, 0, 0);
+  }
+  if (nc == 3) {
+    s->comps_in_scan = 2; s->component_index[0] = 1; s->component_index[1] = 2;
+    s->Ss = s->Se = s->Ah = s->Al = 0; s++;
+    s = fill_a_scan(s, 1, 0, 0, 0, 0);
+    s = fill_a_scan(s, 2, 0, 0, 0, 0);
+    s = fill_a_scan(s, 1, 1, 8, 0, 0);
+    s = fill_a_scan(s, 1, 9, 63, 0, 0);
+    s = fill_a_scan(s, 2, 1, 8, 0, 0);
+    s = fill_a_scan(s, 2, 9, 63, 0, 0);
+    for (Al = 0; Al < 2; Al++) {
+      s = fill_a_scan(s, 1, 1, 63, Al + 1, Al);
+      s = fill_a_scan(s, 2, 1, 63, Al + 1, Al);
+      s = fill_a_scan(s, 1, 1, 8, 0, Al + 1);
+      s = fill_a_scan(s, 1, 9, 63, 0, Al + 1);
+      s = fill_a_scan(s, 2, 1, 8, 0, Al + 1);
+      s = fill_a_scan(s, 2, 9, 63, 0, Al + 1);
+    }
+    s = fill_a_scan(s, 1, 1, 63, 0, 0);
+    s = fill_a_scan(s, 2, 1, 63, 0, 0);
+    for (i = 0; i < 5; i++) {
+      s = fill_a_scan(s, 1, 1, fs[i], 0, 0);
+      s = fill_a_scan(s, 1, fs[i] + 1, 63, 0, 0);
+      s = fill_a_scan(s, 2, 1, fs[i], 0, 0);
+      s = fill_a_scan(s, 2, fs[i] + 1, 63, 0, 0);
+    }
+  }
+  p->num_scans = (int)(s - p->scans);
+}
+
+/* initial_setup, jcmaster.c:163-259; per_scan_setup :561-566; jccoefct.c:587-601 (padding) */
+void mjo_geometry(const mjo_params *p, mjo_geom g[MJO_MAX_COMPS], int *mcus_per_row, int *mcu_rows)
+{
+  int ci, maxh = 1, maxv = 1;
+  for (ci = 0; ci < p->num_components; ci++) {
+    if (p->h_samp[ci] > maxh) maxh = p->h_samp[ci];
+    if (p->v_samp[ci] > maxv) maxv = p->v_samp[ci];
+  }
+  for (ci = 0; ci < p->num_components; ci++) {
+    g[ci].wib = (int)div_round_up((long)p->width * p->h_samp[ci], (long)maxh * 8);
+    g[ci].hib = (int)div_round_up((long)p->height * p->v_samp[ci], (long)maxv * 8);
+    g[ci].wpad = (int)(div_round_up(g[ci].wib, p->h_samp[ci]) * p->h_samp[ci]);
+    g[ci].hpad = (int)(div_round_up(g[ci].hib, p->v_samp[ci]) * p->v_samp[ci]);
+    g[ci].pw = g[ci].wib * 8;
+    g[ci].ph = g[ci].hib * 8;
+  }
+  if (mcus_per_row) *mcus_per_row = (int)div_round_up(p->width, (long)maxh * 8);
+  if (mcu_rows) *mcu_rows = (int)div_round_up(p->height, (long)maxv * 8);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a1-a3  Colour conversion + downsampling + edge replication.
+ *   rgb_ycc_convert  jccolext.c:30-75, tables jccolor.c:213-246 (FIX(x) = (int)(x*65536+0.5))
+ *   rgb_gray_convert jccolext.c:88-118 (same Y row of the table)
+ *   downsampling     jcsample.c:151-295 (int_downsample covers every ratio; h2v1/h2v2 are the
+ *                    special cases with the alternating bias :247,:286)
+ *   edges            expand_right_edge jcsample.c:98; expand_bottom_edge jcprepct.c:113,
+ *                    call sites :161-168 (input rows, BEFORE downsampling) and :180-190
+ *                    (downsampled rows, to the iMCU height)
+ * Whole-image formulation: every replicated sample is an index clamp.
+ * ------------------------------------------------------------------------------------------ */
+#define FIXC(x) ((int)((x) * 65536.0 + 0.5))
+
+static void convert_pixel(const mjo_params *p, const uint8_t *px, int out[3])
+{
+  if (p->input_components == 1) {
+    out[0] = px[0];
+    return;
+  }
+  {
+    int r = px[0], g = px[1], b = px[2];
+    out[0] = (FIXC(0.29900) * r + FIXC(0.58700) * g + FIXC(0.11400) * b + 32768) >> 16;
+    if (p->num_components == 3) {
+      out[1] = (-FIXC(0.16874) * r - FIXC(0.33126) * g + FIXC(0.50000) * b + (128 << 16) + 32767) >> 16;
+      out[2] = (FIXC(0.50000) * r - FIXC(0.41869) * g - FIXC(0.08131) * b + (128 << 16) + 32767) >> 16;
+    }
+  }
+}
+
+void mjo_color_downsample(const mjo_params *p, const uint8_t *pixels, size_t row_stride, uint8_t *planes[MJO_MAX_COMPS])
+{
+  mjo_geom g[MJO_MAX_COMPS];
+  int ci, maxh = 1, maxv = 1, W = p->width, H = p->height;
+  int groups; /* number of input row groups, jcprepct.c:135-192 */
+  uint8_t *full[3] = { 0, 0, 0 };
+  int x, y;
+  mjo_geometry(p, g, NULL, NULL);
+  for (ci = 0; ci < p->num_components; ci++) {
+    if (p->h_samp[ci] > maxh) maxh = p->h_samp[ci];
+    if (p->v_samp[ci] > maxv) maxv = p->v_samp[ci];
+  }
+  groups = (int)div_round_up(H, maxv);
+  /* full-resolution converted planes (the colour buffer of jcprepct.c, whole image) */
+  for (ci = 0; ci < p->num_components; ci++) full[ci] = (uint8_t *)malloc((size_t)W * H);
+  for (y = 0; y < H; y++) {
+    const uint8_t *row = pixels + (size_t)y * row_stride;
+    for (x = 0; x < W; x++) {
+      int v[3];
+      convert_pixel(p, row + (size_t)x * p->input_components, v);
+      for (ci = 0; ci < p->num_components; ci++) full[ci][(size_t)y * W + x] = (uint8_t)v[ci];
+    }
+  }
+  for (ci = 0; ci < p->num_components; ci++) {
+    int hexp = maxh / p->h_samp[ci], vexp = maxv / p->v_samp[ci];
+    int v = p->v_samp[ci];
+    int real_rows = groups * v; /* downsampled rows that exist before the iMCU padding */
+    int numpix = hexp * vexp;
+    int r, c;
+    for (r = 0; r < g[ci].ph; r++) {
+      int rr = r < real_rows ? r : real_rows - 1; /* jcprepct.c:180-190 */
+      int grp = rr / v, sub = rr % v;
+      int in_row0 = grp * maxv + sub * vexp;
+      for (c = 0; c < g[ci].pw; c++) {
+        int sum = 0, hh, vv, val;
+        for (vv = 0; vv < vexp; vv++) {
+          int iy = in_row0 + vv;
+          if (iy > H - 1) iy = H - 1; /* jcprepct.c:161-168 */
+          for (hh = 0; hh < hexp; hh++) {
+            int ix = c * hexp + hh;
+            if (ix > W - 1) ix = W - 1; /* jcsample.c:98-116 */
+            sum += full[ci][(size_t)iy * W + ix];
+          }
+        }
+        if (hexp == 1 && vexp == 1) val = sum;                       /* fullsize_downsample :199 */
+        else if (hexp == 2 && vexp == 1) val = (sum + (c & 1)) >> 1; /* h2v1 :226, bias 0,1,0,1 */
+        else if (hexp == 2 && vexp == 2) val = (sum + 1 + (c & 1)) >> 2; /* h2v2 :263, bias 1,2,1,2 */
+        else val = (sum + numpix / 2) / numpix;                      /* int_downsample :151 */
+        planes[ci][(size_t)r * g[ci].pw + c] = (uint8_t)val;
+      }
+    }
+  }
+  for (ci = 0; ci < p->num_components; ci++) free(full[ci]);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a5  preprocess_deringing jcdctmgr.c:416-498, catmull_rom :387-403
+ * ------------------------------------------------------------------------------------------ */
+static float catmull_rom(int v1, int v2, int v3, int v4, float t, int size)
+{
+  const int tan1 = (v3 - v1) * size;
+  const int tan2 = (v4 - v2) * size;
+  const float t2 = t * t;
+  const float t3 = t2 * t;
+  const float f1 = ((2.f * t3) - (3.f * t2)) + 1.f;
+  const float f2 = (-2.f * t3) + (3.f * t2);
+  const float f3 = (t3 - (2.f * t2)) + t;
+  const float f4 = t3 - t2;
+  float r = (float)v2 * f1;
+  r = r + (float)tan1 * f3;
+  r = r + (float)v3 * f2;
+  r = r + (float)tan2 * f4;
+  return r;
+}
+
+void mjo_deringing(int data[64], int q0)
+{
+  const int maxsample = 255 - 128;
+  const int size = 64;
+  int sum = 0, cnt = 0, i, n, maxovershoot, a, b;
+  for (i = 0; i < size; i++) {
+    sum += data[i];
+    if (data[i] >= maxsample) cnt++;
+  }
+  if (!cnt || cnt == size) return;
+  a = 2 * q0 < 31 ? 2 * q0 : 31;
+  b = (maxsample * size - sum) / cnt;
+  maxovershoot = maxsample + (a < b ? a : b);
+  n = 0;
+  do {
+    int start, end, length, f1, f2, l1, l2, fslope, lslope;
+    float step, position;
+    if (data[ZZ[n]] < maxsample) { n++; continue; }
+    start = n;
+    while (++n < size && data[ZZ[n]] >= maxsample) {}
+    end = n;
+    f1 = data[ZZ[start >= 1 ? start - 1 : 0]];
+    f2 = data[ZZ[start >= 2 ? start - 2 : 0]];
+    l1 = data[ZZ[end < size - 1 ? end : size - 1]];
+    l2 = data[ZZ[end < size - 2 ? end + 1 : size - 1]];
+    fslope = (f1 - f2) > (maxsample - f1) ? (f1 - f2) : (maxsample - f1);
+    lslope = (l1 - l2) > (maxsample - l1) ? (l1 - l2) : (maxsample - l1);
+    if (start == 0) fslope = lslope;
+    if (end == size) lslope = fslope;
+    length = end - start;
+    step = 1.f / (float)(length + 1);
+    position = step;
+    for (i = start; i < end; i++, position += step) {
+      int tmp = (int)ceilf(catmull_rom(maxsample - fslope, maxsample, maxsample, maxsample - lslope, position, length));
+      data[ZZ[i]] = tmp < maxovershoot ? tmp : maxovershoot;
+    }
+    n++;
+  } while (n < size);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a6  jpeg_fdct_islow jfdctint.c:142-286 (8-bit: CONST_BITS 13, PASS1_BITS 2)
+ * ------------------------------------------------------------------------------------------ */
+#define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
+static void fdct_1d(int *d, int stride, int pass)
+{
+  int t0 = d[0] + d[7 * stride], t7 = d[0] - d[7 * stride];
+  int t1 = d[stride] + d[6 * stride], t6 = d[stride] - d[6 * stride];
+  int t2 = d[2 * stride] + d[5 * stride], t5 = d[2 * stride] - d[5 * stride];
+  int t3 = d[3 * stride] + d[4 * stride], t4 = d[3 * stride] - d[4 * stride];
+  int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+  int z1, z2, z3, z4, z5;
+  int sh = pass == 0 ? 13 - 2 : 13 + 2;
+  if (pass == 0) {
+    d[0] = (t10 + t11) * 4;
+    d[4 * stride] = (t10 - t11) * 4;
+  } else {
+    d[0] = DESCALE(t10 + t11, 2);
+    d[4 * stride] = DESCALE(t10 - t11, 2);
+  }
+  z1 = (t12 + t13) * 4433;
+  d[2 * stride] = DESCALE(z1 + t13 * 6270, sh);
+  d[6 * stride] = DESCALE(z1 + t12 * (-15137), sh);
+  z1 = t4 + t7; z2 = t5 + t6; z3 = t4 + t6; z4 = t5 + t7;
+  z5 = (z3 + z4) * 9633;
+  t4 *= 2446; t5 *= 16819; t6 *= 25172; t7 *= 12299;
+  z1 *= -7373; z2 *= -20995; z3 *= -16069; z4 *= -3196;
+  z3 += z5; z4 += z5;
+  d[7 * stride] = DESCALE(t4 + z1 + z3, sh);
+  d[5 * stride] = DESCALE(t5 + z2 + z4, sh);
+  d[3 * stride] = DESCALE(t6 + z2 + z3, sh);
+  d[stride] = DESCALE(t7 + z1 + z4, sh);
+}
+
+void mjo_fdct_islow(int data[64])
+{
+  int i;
+  for (i = 0; i < 8; i++) fdct_1d(data + 8 * i, 1, 0);
+  for (i = 0; i < 8; i++) fdct_1d(data + i, 8, 1);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a4,a7,a8  convsamp jcdctmgr.c:576, quantize :611 (the reciprocal form there is, for d = 8*q,
+ * identical to sign(x)*((|x| + d/2) / d): SURVEY 8a row a7), forward_DCT :693-772,
+ * compress_first_pass jccoefct.c:262-353 (dummy blocks :312-345).
+ * ------------------------------------------------------------------------------------------ */
+static void build_dummies(const mjo_params *p, const mjo_geom *g, int ci, int16_t *coef)
+{
+  int h = p->h_samp[ci];
+  int r, c;
+  for (r = 0; r < g->hib; r++) {
+    for (c = g->wib; c < g->wpad; c++) {
+      int16_t *b = coef + ((size_t)r * g->wpad + c) * 64;
+      memset(b, 0, 128);
+      b[0] = coef[((size_t)r * g->wpad + g->wib - 1) * 64];
+    }
+  }
+  for (r = g->hib; r < g->hpad; r++) {
+    for (c = 0; c < g->wpad; c++) {
+      int16_t *b = coef + ((size_t)r * g->wpad + c) * 64;
+      int src = (c / h) * h + h - 1;
+      memset(b, 0, 128);
+      b[0] = coef[((size_t)(r - 1) * g->wpad + src) * 64];
+    }
+  }
+}
+
+void mjo_forward(const mjo_params *p, uint8_t *const planes[MJO_MAX_COMPS],
+                 int16_t *coef_uq[MJO_MAX_COMPS], int16_t *coef_q[MJO_MAX_COMPS])
+{
+  mjo_geom g[MJO_MAX_COMPS];
+  int ci;
+  mjo_geometry(p, g, NULL, NULL);
+  for (ci = 0; ci < p->num_components; ci++) {
+    const uint16_t *qt = p->qtbl[p->quant_tbl_no[ci]];
+    int br, bc, i;
+    memset(coef_uq[ci], 0, (size_t)g[ci].hpad * g[ci].wpad * 128);
+    for (br = 0; br < g[ci].hib; br++) {
+      for (bc = 0; bc < g[ci].wib; bc++) {
+        int ws[64];
+        int16_t *uq = coef_uq[ci] + ((size_t)br * g[ci].wpad + bc) * 64;
+        int16_t *q = coef_q[ci] + ((size_t)br * g[ci].wpad + bc) * 64;
+        for (i = 0; i < 64; i++)
+          ws[i] = planes[ci][(size_t)(br * 8 + i / 8) * g[ci].pw + bc * 8 + (i & 7)] - 128;
+        if (p->overshoot_deringing) mjo_deringing(ws, qt[0]);
+        mjo_fdct_islow(ws);
+        for (i = 0; i < 64; i++) {
+          int d = 8 * qt[i], x = ws[i], v;
+          uq[i] = (int16_t)x;
+          v = ((x < 0 ? -x : x) + d / 2) / d;
+          if (x < 0) v = -v;
+          if (p->overshoot_deringing) { /* jcdctmgr.c:761-770 */
+            if (v < -1023) v = -1023;
+            if (v > 1023) v = 1023;
+          }
+          q[i] = (int16_t)v;
+        }
+      }
+    }
+    build_dummies(p, &g[ci], ci, coef_q[ci]);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a11  jpeg_gen_optimal_table jchuff.c:947-1106; jpeg_make_c_derived_tbl :231-318
+ * ------------------------------------------------------------------------------------------ */
+void mjo_gen_optimal_table(long freq_in[257], uint8_t bits_out[17], uint8_t huffval[256])
+{
+  uint8_t bits[33];
+  int bit_pos[33];
+  int codesize[257], nz_index[257], others[257];
+  long freq[257];
+  int c1, c2, p, i, j, nnz = 0;
+  long v, v2;
+  memset(bits, 0, sizeof(bits));
+  memset(codesize, 0, sizeof(codesize));
+  for (i = 0; i < 257; i++) others[i] = -1;
+  freq_in[256] = 1;
+  for (i = 0; i < 257; i++) {
+    if (freq_in[i]) {
+      nz_index[nnz] = i;
+      freq[nnz] = freq_in[i];
+      nnz++;
+    }
+  }
+  for (;;) {
+    c1 = -1; c2 = -1;
+    v = 1000000000L; v2 = 1000000000L;
+    for (i = 0; i < nnz; i++) {
+      if (freq[i] <= v2) {
+        if (freq[i] <= v) { c2 = c1; v2 = v; v = freq[i]; c1 = i; }
+        else { v2 = freq[i]; c2 = i; }
+      }
+    }
+    if (c2 < 0) break;
+    freq[c1] += freq[c2];
+    freq[c2] = 1000000001L;
+    codesize[c1]++;
+    while (others[c1] >= 0) { c1 = others[c1]; codesize[c1]++; }
+    others[c1] = c2;
+    codesize[c2]++;
+    while (others[c2] >= 0) { c2 = others[c2]; codesize[c2]++; }
+  }
+  for (i = 0; i < nnz; i++) bits[codesize[i]]++;
+  p = 0;
+  for (i = 1; i <= 32; i++) { bit_pos[i] = p; p += bits[i]; }
+  for (i = 32; i > 16; i--) {
+    while (bits[i] > 0) {
+      j = i - 2;
+      while (bits[j] == 0) j--;
+      bits[i] -= 2; bits[i - 1]++; bits[j + 1] += 2; bits[j]--;
+    }
+  }
+  while (bits[i] == 0) i--;
+  bits[i]--;
+  memcpy(bits_out, bits, 17);
+  for (i = 0; i < nnz - 1; i++) {
+    huffval[bit_pos[codesize[i]]] = (uint8_t)nz_index[i];
+    bit_pos[codesize[i]]++;
+  }
+}
+
+typedef struct { uint8_t bits[17]; uint8_t huffval[256]; int sent; } htbl;
+typedef struct { unsigned code[256]; uint8_t size[256]; } dtbl;
+
+static void make_derived(const htbl *h, dtbl *d)
+{
+  char huffsize[257];
+  unsigned huffcode[257], code = 0;
+  int p = 0, l, i, si, lastp;
+  for (l = 1; l <= 16; l++) { i = h->bits[l]; while (i--) huffsize[p++] = (char)l; }
+  huffsize[p] = 0; lastp = p;
+  si = huffsize[0]; p = 0;
+  while (huffsize[p]) {
+    while ((int)huffsize[p] == si) { huffcode[p++] = code; code++; }
+    code <<= 1; si++;
+  }
+  memset(d, 0, sizeof(*d));
+  for (p = 0; p < lastp; p++) {
+    d->code[h->huffval[p]] = huffcode[p];
+    d->size[h->huffval[p]] = (uint8_t)huffsize[p];
+  }
+}
+
+/* Annex K.3 tables, jstdhuff.c:54-131 */
+static const uint8_t STD_DC_L_BITS[17] = { 0, 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0 };
+static const uint8_t STD_DC_C_BITS[17] = { 0, 0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0 };
+static const uint8_t STD_DC_VAL[12] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11 };
+static const uint8_t STD_AC_L_BITS[17] = { 0, 0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d };
+static const uint8_t STD_AC_L_VAL[162] = {
+  0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07,
+  0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0,
+  0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28,
+  0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49,
+  0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69,
+  0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89,
+  0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7,
+  0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5,
+  0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
+  0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8,
+  0xf9, 0xfa
+};
+static const uint8_t STD_AC_C_BITS[17] = { 0, 0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77 };
+static const uint8_t STD_AC_C_VAL[162] = {
+  0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71,
+  0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0,
+  0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26,
+  0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48,
+  0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68,
+  0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87,
+  0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5,
+  0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+  0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda,
+  0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8,
+  0xf9, 0xfa
+};
+
+/* ------------------------------------------------------------------------------------------
+ * Encoder state
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  uint8_t *buf;
+  size_t len, cap;
+} bytebuf;
+
+static void bb_put(bytebuf *b, int v)
+{
+  if (b->len == b->cap) {
+    b->cap = b->cap ? b->cap * 2 : 4096;
+    b->buf = (uint8_t *)realloc(b->buf, b->cap);
+  }
+  b->buf[b->len++] = (uint8_t)v;
+}
+static void bb_put2(bytebuf *b, int v) { bb_put(b, (v >> 8) & 0xFF); bb_put(b, v & 0xFF); }
+
+typedef struct {
+  const mjo_params *p;
+  mjo_geom g[MJO_MAX_COMPS];
+  int mcus_per_row, mcu_rows;
+  int16_t *uq[MJO_MAX_COMPS], *q[MJO_MAX_COMPS];
+  htbl dc[4], ac[4];
+  int qsent[4];
+  int last_restart_interval; /* jcmarker.c:660 */
+  int progressive;
+} enc_t;
+
+/* an entropy sink: counts (gather) or bits (emit) */
+typedef struct {
+  int gather;
+  long *dc_count[4], *ac_count[4]; /* gather */
+  const dtbl *dcd[4], *acd[4];     /* emit */
+  bytebuf *out;
+  uint64_t acc; /* bit accumulator, msb first */
+  int nacc;
+} sink_t;
+
+static void put_bits(sink_t *s, unsigned code, int size)
+{
+  if (s->gather || size == 0) return;
+  s->acc = (s->acc << size) | (code & ((1u << size) - 1));
+  s->nacc += size;
+  while (s->nacc >= 8) {
+    int c = (int)((s->acc >> (s->nacc - 8)) & 0xFF);
+    bb_put(s->out, c);
+    if (c == 0xFF) bb_put(s->out, 0); /* jchuff.c:354-358 / jcphuff.c:347-352 */
+    s->nacc -= 8;
+  }
+}
+static void flush_bits(sink_t *s)
+{ /* jchuff.c:505-514 and jcphuff.c:362-367: pad the partial byte with one-bits */
+  if (s->gather) return;
+  put_bits(s, 0x7F, 7);
+  s->acc = 0;
+  s->nacc = 0;
+}
+
+/* The scan being coded: per_scan_setup jcmaster.c:518-601 */
+typedef struct {
+  int ncomp;
+  int comp[MJO_MAX_COMPS];
+  int Ss, Se, Ah, Al;
+  int mcus_per_row, mcu_rows;
+  int restart_interval;
+} scan_t;
+
+static void setup_scan(const enc_t *e, scan_t *sc, const mjo_scan *ms)
+{
+  const mjo_params *p = e->p;
+  int i;
+  sc->ncomp = ms->comps_in_scan;
+  for (i = 0; i < sc->ncomp; i++) sc->comp[i] = ms->component_index[i];
+  sc->Ss = ms->Ss; sc->Se = ms->Se; sc->Ah = ms->Ah; sc->Al = ms->Al;
+  if (sc->ncomp == 1) {
+    sc->mcus_per_row = e->g[sc->comp[0]].wib;
+    sc->mcu_rows = e->g[sc->comp[0]].hib;
+  } else {
+    sc->mcus_per_row = e->mcus_per_row;
+    sc->mcu_rows = e->mcu_rows;
+  }
+  sc->restart_interval = p->restart_interval;
+  if (p->restart_in_rows > 0) { /* jcmaster.c:595-600 */
+    long nominal = (long)p->restart_in_rows * sc->mcus_per_row;
+    sc->restart_interval = (int)(nominal < 65535L ? nominal : 65535L);
+  }
+}
+
+/* ---- sequential Huffman coder: jchuff.c encode_one_block :563, htest_one_block :812,
+ *      encode_mcu_huff :693, encode_mcu_gather :886, emit_restart :668 ---------------------- */
+static void seq_block(sink_t *s, const int16_t *blk, int last_dc, int dctbl, int actbl)
+{
+  int temp = blk[0] - last_dc, temp2 = temp, nb, k, r;
+  if (temp < 0) { temp = -temp; temp2--; }
+  nb = nbits_of((unsigned)temp);
+  if (s->gather) s->dc_count[dctbl][nb]++;
+  else {
+    put_bits(s, s->dcd[dctbl]->code[nb], s->dcd[dctbl]->size[nb]);
+    put_bits(s, (unsigned)temp2, nb);
+  }
+  r = 0;
+  for (k = 1; k < 64; k++) {
+    temp = blk[ZZ[k]];
+    if (temp == 0) { r++; continue; }
+    while (r > 15) {
+      if (s->gather) s->ac_count[actbl][0xF0]++;
+      else put_bits(s, s->acd[actbl]->code[0xF0], s->acd[actbl]->size[0xF0]);
+      r -= 16;
+    }
+    temp2 = temp;
+    if (temp < 0) { temp = -temp; temp2--; }
+    nb = nbits_of((unsigned)temp);
+    if (s->gather) s->ac_count[actbl][(r << 4) + nb]++;
+    else {
+      put_bits(s, s->acd[actbl]->code[(r << 4) + nb], s->acd[actbl]->size[(r << 4) + nb]);
+      put_bits(s, (unsigned)temp2, nb);
+    }
+    r = 0;
+  }
+  if (r > 0) {
+    if (s->gather) s->ac_count[actbl][0]++;
+    else put_bits(s, s->acd[actbl]->code[0], s->acd[actbl]->size[0]);
+  }
+}
+
+/* ---- progressive coder state, jcphuff.c:90-130 -------------------------------------------- */
+typedef struct {
+  unsigned EOBRUN;
+  unsigned BE;
+  char bit_buffer[1000]; /* MAX_CORR_BITS jcphuff.c:108 */
+  int ac_tbl;
+} prog_t;
+
+static void prog_symbol(sink_t *s, int isdc, int tbl, int sym)
+{
+  if (s->gather) { if (isdc) s->dc_count[tbl][sym]++; else s->ac_count[tbl][sym]++; }
+  else {
+    const dtbl *d = isdc ? s->dcd[tbl] : s->acd[tbl];
+    put_bits(s, d->code[sym], d->size[sym]);
+  }
+}
+static void prog_emit_eobrun(sink_t *s, prog_t *pg)
+{ /* jcphuff.c:409-431 */
+  if (pg->EOBRUN > 0) {
+    int nb = nbits_of(pg->EOBRUN) - 1;
+    unsigned i;
+    prog_symbol(s, 0, pg->ac_tbl, nb << 4);
+    if (nb) put_bits(s, pg->EOBRUN, nb);
+    pg->EOBRUN = 0;
+    for (i = 0; i < pg->BE; i++) put_bits(s, (unsigned)pg->bit_buffer[i], 1);
+    pg->BE = 0;
+  }
+}
+
+/* iterate over the MCUs of a scan in coding order: compress_output jccoefct.c:498-553 */
+static void code_scan(enc_t *e, const scan_t *sc, sink_t *s)
+{
+  const mjo_params *p = e->p;
+  int last_dc[MJO_MAX_COMPS] = { 0, 0, 0, 0 };
+  int restarts_to_go = sc->restart_interval, next_restart = 0;
+  prog_t pg;
+  int mr, mc, ci;
+  memset(&pg, 0, sizeof(pg));
+  if (sc->ncomp == 1) pg.ac_tbl = p->ac_tbl_no[sc->comp[0]];
+
+  for (mr = 0; mr < sc->mcu_rows; mr++) {
+    for (mc = 0; mc < sc->mcus_per_row; mc++) {
+      /* restart handling: jchuff.c:710-714,:894-903 / jcphuff.c:485-488, emit_restart :438 */
+      if (sc->restart_interval && restarts_to_go == 0) {
+        if (e->progressive) prog_emit_eobrun(s, &pg);
+        if (!s->gather) {
+          flush_bits(s);
+          bb_put(s->out, 0xFF);
+          bb_put(s->out, 0xD0 + next_restart);
+        }
+        if (!e->progressive || sc->Ss == 0) for (ci = 0; ci < sc->ncomp; ci++) last_dc[ci] = 0;
+        if (e->progressive && sc->Ss != 0) { pg.EOBRUN = 0; pg.BE = 0; }
+        restarts_to_go = sc->restart_interval;
+        next_restart = (next_restart + 1) & 7;
+      }
+      for (ci = 0; ci < sc->ncomp; ci++) {
+        int c = sc->comp[ci];
+        int mw = sc->ncomp == 1 ? 1 : p->h_samp[c];
+        int mh = sc->ncomp == 1 ? 1 : p->v_samp[c];
+        int yi, xi;
+        for (yi = 0; yi < mh; yi++) {
+          for (xi = 0; xi < mw; xi++) {
+            const int16_t *blk = e->q[c] + ((size_t)(mr * mh + yi) * e->g[c].wpad + (mc * mw + xi)) * 64;
+            if (!e->progressive) {
+              seq_block(s, blk, last_dc[ci], p->dc_tbl_no[c], p->ac_tbl_no[c]);
+              last_dc[ci] = blk[0];
+            } else if (sc->Ss == 0 && sc->Ah == 0) {
+              /* encode_mcu_DC_first jcphuff.c:468-552 */
+              int t2 = blk[0] >> sc->Al, t = t2 - last_dc[ci], nb;
+              last_dc[ci] = t2;
+              t2 = t;
+              if (t < 0) { t = -t; t2--; }
+              nb = nbits_of((unsigned)t);
+              prog_symbol(s, 1, p->dc_tbl_no[c], nb);
+              if (nb) put_bits(s, (unsigned)t2, nb);
+            } else if (sc->Ss == 0) {
+              /* encode_mcu_DC_refine jcphuff.c:746-790 */
+              put_bits(s, (unsigned)(blk[0] >> sc->Al), 1);
+            } else if (sc->Ah == 0) {
+              /* encode_mcu_AC_first jcphuff.c:648-737 (+prepare :580-625) */
+              int k, r = 0, any = 0;
+              for (k = sc->Ss; k <= sc->Se; k++) {
+                int t = blk[ZZ[k]], t2, nb;
+                if (t == 0) { r++; continue; }
+                if (t < 0) { t = -t; t >>= sc->Al; t2 = ~t; } else { t >>= sc->Al; t2 = t; }
+                if (t == 0) { r++; continue; }
+                if (!any && pg.EOBRUN > 0) prog_emit_eobrun(s, &pg);
+                any = 1;
+                while (r > 15) { prog_symbol(s, 0, pg.ac_tbl, 0xF0); r -= 16; }
+                nb = nbits_of((unsigned)t);
+                prog_symbol(s, 0, pg.ac_tbl, (r << 4) + nb);
+                put_bits(s, (unsigned)t2, nb);
+                r = 0;
+              }
+              if (r > 0) {
+                pg.EOBRUN++;
+                if (pg.EOBRUN == 0x7FFF) prog_emit_eobrun(s, &pg);
+              }
+            } else {
+              /* encode_mcu_AC_refine jcphuff.c:918-1025 (+prepare :817-870) */
+              int absv[64], k, EOB = 0, r = 0;
+              unsigned BR = 0;
+              char *BR_buffer = pg.bit_buffer + pg.BE;
+              for (k = sc->Ss; k <= sc->Se; k++) {
+                int t = blk[ZZ[k]];
+                if (t < 0) t = -t;
+                t >>= sc->Al;
+                absv[k] = t;
+                if (t == 1) EOB = k;
+              }
+              for (k = sc->Ss; k <= sc->Se; k++) {
+                int t = absv[k];
+                if (t == 0) { r++; continue; }
+                while (r > 15 && k <= EOB) {
+                  unsigned i;
+                  prog_emit_eobrun(s, &pg);
+                  prog_symbol(s, 0, pg.ac_tbl, 0xF0);
+                  r -= 16;
+                  for (i = 0; i < BR; i++) put_bits(s, (unsigned)BR_buffer[i], 1);
+                  BR_buffer = pg.bit_buffer;
+                  BR = 0;
+                }
+                if (t > 1) { BR_buffer[BR++] = (char)(t & 1); continue; }
+                prog_emit_eobrun(s, &pg);
+                prog_symbol(s, 0, pg.ac_tbl, (r << 4) + 1);
+                put_bits(s, blk[ZZ[k]] < 0 ? 0u : 1u, 1);
+                {
+                  unsigned i;
+                  for (i = 0; i < BR; i++) put_bits(s, (unsigned)BR_buffer[i], 1);
+                }
+                BR_buffer = pg.bit_buffer;
+                BR = 0;
+                r = 0;
+              }
+              if (r > 0 || BR > 0) {
+                pg.EOBRUN++;
+                pg.BE += BR;
+                if (pg.EOBRUN == 0x7FFF || pg.BE > (1000 - 64 + 1)) prog_emit_eobrun(s, &pg);
+              }
+            }
+          }
+        }
+      }
+      if (sc->restart_interval) restarts_to_go--;
+    }
+  }
+  /* finish_pass: jchuff.c:772-800 / jcphuff.c:1033-1048,:1060 */
+  if (e->progressive) prog_emit_eobrun(s, &pg);
+  flush_bits(s);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a9  quantize_trellis jcdctmgr.c:936-1329 driven by compress_trellis_pass jccoefct.c:356-486.
+ * One component; dctbl/actbl are the code LENGTHS of the component's current tables (T7).
+ * ------------------------------------------------------------------------------------------ */
+static void trellis_component(enc_t *e, int ci, const dtbl *dctbl, const dtbl *actbl)
+{
+  const mjo_params *p = e->p;
+  const mjo_geom *g = &e->g[ci];
+  const uint16_t *qt = p->qtbl[p->quant_tbl_no[ci]];
+  const int Ss = 1, Se = 63; /* select_scan_parameters jcmaster.c:462-466 */
+  const int v = p->v_samp[ci];
+  int ncand = 2 + 60 / qt[0]; /* get_num_dc_trellis_candidates :930-933 */
+  float lambda_tbl[64];
+  float *acc_dc[9];
+  int *back_dc[9];
+  int16_t *cand_dc[9];
+  int i, j, k, l, br, bi;
+  int last_dc = 0;
+  int run_start[64];
+  ncand |= 1;
+  if (ncand > 9) ncand = 9;
+  for (i = 0; i < 64; i++) lambda_tbl[i] = (float)(1.0 / (double)((int)qt[i] * (int)qt[i])); /* :1017-1021 */
+  for (i = 0; i < 9; i++) {
+    acc_dc[i] = (float *)malloc(sizeof(float) * g->wib);
+    back_dc[i] = (int *)malloc(sizeof(int) * g->wib);
+    cand_dc[i] = (int16_t *)malloc(sizeof(int16_t) * g->wib);
+  }
+  memset(run_start, 0, sizeof(run_start));
+
+  for (br = 0; br < g->hib; br++) {
+    if (br % v == 0) last_dc = 0; /* jccoefct.c:418: per iMCU row */
+    for (bi = 0; bi < g->wib; bi++) {
+      const int16_t *src = e->uq[ci] + ((size_t)br * g->wpad + bi) * 64;
+      int16_t *coef = e->q[ci] + ((size_t)br * g->wpad + bi) * 64;
+      float azd[64], acost[64];
+      float norm = 0.0f, lambda, lambda_dc, best_cost;
+      int last_coeff_idx;
+      for (i = 1; i < 64; i++) norm = norm + (float)((int)src[i] * (int)src[i]); /* :1027-1031 */
+      norm = (float)((double)norm / 63.0);
+      if (p->lambda_log_scale2 > 0.0f)
+        lambda = (float)(pow(2.0, (double)p->lambda_log_scale1) * (double)1.0f /
+                         (pow(2.0, (double)p->lambda_log_scale2) + (double)norm));
+      else
+        lambda = (float)(pow(2.0, (double)p->lambda_log_scale1 - 12.0) * (double)1.0f);
+      lambda_dc = lambda * lambda_tbl[0];
+      azd[Ss - 1] = 0.0f;
+      acost[Ss - 1] = 0.0f;
+
+      if (p->trellis_quant_dc) { /* :1044-1118 */
+        int sign = src[0] >> 15 ? -1 : 0; /* src[bi][0] >> 31 on the promoted int */
+        int x = src[0] < 0 ? -src[0] : src[0];
+        int q = 8 * qt[0];
+        int qval = (x + q / 2) / q;
+        for (k = 0; k < ncand; k++) {
+          int delta, dc_delta, bits;
+          float dist, cost;
+          int cnd = qval - ncand / 2 + k;
+          if (cnd >= 1024) cnd = 1023;
+          if (cnd <= -1024) cnd = -1023;
+          delta = cnd * q - x;
+          dist = (float)(delta * delta) * lambda_dc;
+          cnd *= 1 + 2 * sign;
+          cand_dc[k][bi] = (int16_t)cnd;
+          if (bi == 0) {
+            dc_delta = cnd - last_dc;
+            bits = nbits_of((unsigned)(dc_delta < 0 ? -dc_delta : dc_delta));
+            cost = (float)(bits + dctbl->size[bits]) + dist;
+            acc_dc[k][0] = cost;
+            back_dc[k][0] = -1;
+          } else {
+            for (l = 0; l < ncand; l++) {
+              dc_delta = cnd - cand_dc[l][bi - 1];
+              bits = nbits_of((unsigned)(dc_delta < 0 ? -dc_delta : dc_delta));
+              cost = (float)(bits + dctbl->size[bits]) + dist;
+              cost = cost + acc_dc[l][bi - 1];
+              if (l == 0 || cost < acc_dc[k][bi]) {
+                acc_dc[k][bi] = cost;
+                back_dc[k][bi] = l;
+              }
+            }
+          }
+        }
+      }
+
+      /* AC, :1120-1185 */
+      for (i = Ss; i <= Se; i++) {
+        int z = ZZ[i];
+        int sign = src[z] < 0 ? -1 : 0;
+        int x = src[z] < 0 ? -src[z] : src[z];
+        int q = 8 * qt[z];
+        int cand[16], cbits[16], ncd, qval;
+        float cdist[16], t;
+        t = (float)(x * x) * lambda;
+        t = t * lambda_tbl[z];
+        azd[i] = t + azd[i - 1];
+        qval = (x + q / 2) / q;
+        if (qval == 0) {
+          coef[z] = 0;
+          acost[i] = 1e38f;
+          continue;
+        }
+        if (qval >= 1024) qval = 1023;
+        ncd = nbits_of((unsigned)qval);
+        for (k = 0; k < ncd; k++) {
+          int delta;
+          cand[k] = (k < ncd - 1) ? (2 << k) - 1 : qval;
+          delta = cand[k] * q - x;
+          cbits[k] = k + 1;
+          t = (float)(delta * delta) * lambda;
+          cdist[k] = t * lambda_tbl[z];
+        }
+        acost[i] = 1e38f;
+        for (j = Ss - 1; j < i; j++) {
+          int zz = ZZ[j], zero_run, run_bits;
+          if (j != Ss - 1 && coef[zz] == 0) continue;
+          zero_run = i - 1 - j;
+          if ((zero_run >> 4) && actbl->size[0xF0] == 0) continue;
+          run_bits = (zero_run >> 4) * actbl->size[0xF0];
+          zero_run &= 15;
+          for (k = 0; k < ncd; k++) {
+            int coef_bits = actbl->size[16 * zero_run + cbits[k]];
+            int rate;
+            float cost, rhs;
+            if (coef_bits == 0) continue;
+            rate = coef_bits + cbits[k] + run_bits;
+            cost = (float)rate + cdist[k];
+            rhs = azd[i - 1] - azd[j];
+            rhs = rhs + acost[j];
+            cost = cost + rhs;
+            if (cost < acost[i]) {
+              coef[z] = (int16_t)((cand[k] ^ sign) - sign);
+              acost[i] = cost;
+              run_start[i] = j;
+            }
+          }
+        }
+      }
+      /* EOB choice :1187-1207 */
+      last_coeff_idx = Ss - 1;
+      best_cost = azd[Se] + (float)actbl->size[0];
+      for (i = Ss; i <= Se; i++) {
+        int z = ZZ[i];
+        if (coef[z] != 0) {
+          float cost = acost[i] + azd[Se];
+          cost = cost - azd[i];
+          if (i < Se) cost = cost + (float)actbl->size[0];
+          if (cost < best_cost) { best_cost = cost; last_coeff_idx = i; }
+        }
+      }
+      /* back-track :1211-1222 */
+      i = Se;
+      while (i >= Ss) {
+        while (i > last_coeff_idx) { coef[ZZ[i]] = 0; i--; }
+        last_coeff_idx = run_start[i];
+        i--;
+      }
+    }
+    if (p->trellis_quant_dc) { /* :1308-1327 */
+      j = 0;
+      for (i = 1; i < ncand; i++)
+        if (acc_dc[i][g->wib - 1] < acc_dc[j][g->wib - 1]) j = i;
+      for (bi = g->wib - 1; bi >= 0; bi--) {
+        e->q[ci][((size_t)br * g->wpad + bi) * 64] = cand_dc[j][bi];
+        j = back_dc[j][bi];
+      }
+      last_dc = e->q[ci][((size_t)br * g->wpad + g->wib - 1) * 64];
+    }
+  }
+  build_dummies(p, g, ci, e->q[ci]); /* jccoefct.c:443-476 */
+  for (i = 0; i < 9; i++) { free(acc_dc[i]); free(back_dc[i]); free(cand_dc[i]); }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a15  markers: jcmarker.c
+ * ------------------------------------------------------------------------------------------ */
+static void emit_file_header(const enc_t *e, bytebuf *o)
+{ /* write_file_header :649-666, emit_jfif_app0 :534-565 */
+  bb_put(o, 0xFF); bb_put(o, 0xD8);
+  if (e->p->write_jfif) {
+    bb_put(o, 0xFF); bb_put(o, 0xE0);
+    bb_put2(o, 16);
+    bb_put(o, 'J'); bb_put(o, 'F'); bb_put(o, 'I'); bb_put(o, 'F'); bb_put(o, 0);
+    bb_put(o, 1); bb_put(o, 1);
+    bb_put(o, 0);
+    bb_put2(o, 1); bb_put2(o, 1);
+    bb_put(o, 0); bb_put(o, 0);
+  }
+}
+
+static void emit_frame_header(enc_t *e, bytebuf *o)
+{ /* write_frame_header :674-734, emit_multi_dqt :189-254, emit_dqt :140-186, emit_sof :464-490 */
+  const mjo_params *p = e->p;
+  int ci, i, prec_any = 0, is_baseline;
+  int prec[MJO_MAX_COMPS];
+  int multi = !p->fastest_profile;
+  for (ci = 0; ci < p->num_components; ci++) {
+    const uint16_t *qt = p->qtbl[p->quant_tbl_no[ci]];
+    prec[ci] = 0;
+    for (i = 0; i < 64; i++) if (qt[i] > 255) prec[ci] = 1;
+    if (e->qsent[p->quant_tbl_no[ci]]) multi = 0;
+  }
+  if (multi) {
+    int seen[4] = { 0, 0, 0, 0 }, size = 2;
+    bb_put(o, 0xFF); bb_put(o, 0xDB);
+    for (ci = 0; ci < p->num_components; ci++) {
+      int t = p->quant_tbl_no[ci];
+      if (!seen[t]) { size += 64 * (prec[ci] + 1) + 1; seen[t] = 1; }
+      prec_any += prec[ci];
+    }
+    bb_put2(o, size);
+    for (ci = 0; ci < p->num_components; ci++) {
+      int t = p->quant_tbl_no[ci];
+      if (e->qsent[t]) continue;
+      bb_put(o, t + (prec[ci] << 4));
+      for (i = 0; i < 64; i++) {
+        unsigned qv = p->qtbl[t][ZZ[i]];
+        if (prec[ci]) bb_put(o, (int)(qv >> 8));
+        bb_put(o, (int)(qv & 0xFF));
+      }
+      e->qsent[t] = 1;
+    }
+  } else {
+    for (ci = 0; ci < p->num_components; ci++) {
+      int t = p->quant_tbl_no[ci];
+      prec_any += prec[ci];
+      if (e->qsent[t]) continue;
+      bb_put(o, 0xFF); bb_put(o, 0xDB);
+      bb_put2(o, prec[ci] ? 64 * 2 + 1 + 2 : 64 + 1 + 2);
+      bb_put(o, t + (prec[ci] << 4));
+      for (i = 0; i < 64; i++) {
+        unsigned qv = p->qtbl[t][ZZ[i]];
+        if (prec[ci]) bb_put(o, (int)(qv >> 8));
+        bb_put(o, (int)(qv & 0xFF));
+      }
+      e->qsent[t] = 1;
+    }
+  }
+  is_baseline = !e->progressive;
+  if (is_baseline) {
+    for (ci = 0; ci < p->num_components; ci++)
+      if (p->dc_tbl_no[ci] > 1 || p->ac_tbl_no[ci] > 1) is_baseline = 0;
+    if (prec_any) is_baseline = 0;
+  }
+  bb_put(o, 0xFF);
+  bb_put(o, e->progressive ? 0xC2 : (is_baseline ? 0xC0 : 0xC1));
+  bb_put2(o, 3 * p->num_components + 2 + 5 + 1);
+  bb_put(o, 8);
+  bb_put2(o, p->height);
+  bb_put2(o, p->width);
+  bb_put(o, p->num_components);
+  for (ci = 0; ci < p->num_components; ci++) {
+    bb_put(o, p->component_id[ci]);
+    bb_put(o, (p->h_samp[ci] << 4) + p->v_samp[ci]);
+    bb_put(o, p->quant_tbl_no[ci]);
+  }
+}
+
+static void emit_one_dht(bytebuf *o, htbl *h, int index)
+{ /* emit_dht :257-290 */
+  int length = 0, i;
+  if (h->sent) return;
+  bb_put(o, 0xFF); bb_put(o, 0xC4);
+  for (i = 1; i <= 16; i++) length += h->bits[i];
+  bb_put2(o, length + 2 + 1 + 16);
+  bb_put(o, index);
+  for (i = 1; i <= 16; i++) bb_put(o, h->bits[i]);
+  for (i = 0; i < length; i++) bb_put(o, h->huffval[i]);
+  h->sent = 1;
+}
+
+static void emit_scan_header(enc_t *e, const scan_t *sc, bytebuf *o)
+{ /* write_scan_header :744-784, emit_multi_dht :293-401, emit_dri :452, emit_sos :494-531 */
+  const mjo_params *p = e->p;
+  int i, j;
+  if (!p->fastest_profile) {
+    int length = 2, dclens[4] = { 0, 0, 0, 0 }, aclens[4] = { 0, 0, 0, 0 };
+    htbl *dcseen[4] = { 0, 0, 0, 0 }, *acseen[4] = { 0, 0, 0, 0 };
+    for (i = 0; i < sc->ncomp; i++) {
+      htbl *d = &e->dc[p->dc_tbl_no[sc->comp[i]]], *a = &e->ac[p->ac_tbl_no[sc->comp[i]]];
+      int seen = 0;
+      if (sc->Ss == 0 && sc->Ah == 0) {
+        if (d->sent) continue;
+        for (j = 0; j < 4; j++) seen += (d == dcseen[j]);
+        if (seen) continue;
+        dcseen[i] = d;
+        for (j = 1; j <= 16; j++) dclens[i] += d->bits[j];
+        length += dclens[i] + 16 + 1;
+      }
+      if (sc->Se) {
+        if (a->sent) continue;
+        seen = 0;
+        for (j = 0; j < 4; j++) seen += (a == acseen[j]);
+        if (seen) continue;
+        acseen[i] = a;
+        for (j = 1; j <= 16; j++) aclens[i] += a->bits[j];
+        length += aclens[i] + 16 + 1;
+      }
+    }
+    bb_put(o, 0xFF); bb_put(o, 0xC4);
+    bb_put2(o, length);
+    for (i = 0; i < sc->ncomp; i++) {
+      int dcidx = p->dc_tbl_no[sc->comp[i]], acidx = p->ac_tbl_no[sc->comp[i]];
+      htbl *d = &e->dc[dcidx], *a = &e->ac[acidx];
+      if (sc->Ss == 0 && sc->Ah == 0 && !d->sent) {
+        bb_put(o, dcidx);
+        for (j = 1; j <= 16; j++) bb_put(o, d->bits[j]);
+        for (j = 0; j < dclens[i]; j++) bb_put(o, d->huffval[j]);
+        d->sent = 1;
+      }
+      if (sc->Se && !a->sent) {
+        bb_put(o, acidx + 0x10);
+        for (j = 1; j <= 16; j++) bb_put(o, a->bits[j]);
+        for (j = 0; j < aclens[i]; j++) bb_put(o, a->huffval[j]);
+        a->sent = 1;
+      }
+    }
+  } else {
+    for (i = 0; i < sc->ncomp; i++) {
+      int c = sc->comp[i];
+      if (sc->Ss == 0 && sc->Ah == 0) emit_one_dht(o, &e->dc[p->dc_tbl_no[c]], p->dc_tbl_no[c]);
+      if (sc->Se) emit_one_dht(o, &e->ac[p->ac_tbl_no[c]], p->ac_tbl_no[c] + 0x10);
+    }
+  }
+  if (sc->restart_interval != e->last_restart_interval) {
+    bb_put(o, 0xFF); bb_put(o, 0xDD);
+    bb_put2(o, 4);
+    bb_put2(o, sc->restart_interval);
+    e->last_restart_interval = sc->restart_interval;
+  }
+  bb_put(o, 0xFF); bb_put(o, 0xDA);
+  bb_put2(o, 2 * sc->ncomp + 2 + 1 + 3);
+  bb_put(o, sc->ncomp);
+  for (i = 0; i < sc->ncomp; i++) {
+    int c = sc->comp[i];
+    int td = (sc->Ss == 0 && sc->Ah == 0) ? p->dc_tbl_no[c] : 0;
+    int ta = sc->Se ? p->ac_tbl_no[c] : 0;
+    bb_put(o, p->component_id[c]);
+    bb_put(o, (td << 4) + ta);
+  }
+  bb_put(o, sc->Ss);
+  bb_put(o, sc->Se);
+  bb_put(o, (sc->Ah << 4) + sc->Al);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a16  pass control: jcmaster.c prepare_for_pass :612, finish_pass_master :968,
+ *      select_scan_parameters :443, select_scans :773; gather -> table: finish_pass_gather
+ *      jchuff.c:1113 / finish_pass_gather_phuff jcphuff.c:1055.
+ * ------------------------------------------------------------------------------------------ */
+static void gather_and_build(enc_t *e, const scan_t *sc, int trellis_pass)
+{
+  const mjo_params *p = e->p;
+  long dcc[4][257], acc[4][257];
+  sink_t s;
+  int t, i, j, ci;
+  int did_dc[4] = { 0, 0, 0, 0 }, did_ac[4] = { 0, 0, 0, 0 };
+  memset(&s, 0, sizeof(s));
+  memset(dcc, 0, sizeof(dcc));
+  memset(acc, 0, sizeof(acc));
+  s.gather = 1;
+  for (t = 0; t < 4; t++) { s.dc_count[t] = dcc[t]; s.ac_count[t] = acc[t]; }
+  if (e->progressive && trellis_pass) { /* jcphuff.c:257-264 */
+    for (ci = 0; ci < sc->ncomp; ci++) {
+      long *c = sc->Ss == 0 ? dcc[p->dc_tbl_no[sc->comp[ci]]] : acc[p->ac_tbl_no[sc->comp[ci]]];
+      for (i = 0; i < 16; i++) for (j = 0; j < 12; j++) c[16 * i + j] = 1;
+    }
+  }
+  code_scan(e, sc, &s);
+  for (ci = 0; ci < sc->ncomp; ci++) {
+    int c = sc->comp[ci];
+    int d = p->dc_tbl_no[c], a = p->ac_tbl_no[c];
+    int want_dc = !e->progressive || (sc->Ss == 0 && sc->Ah == 0);
+    int want_ac = !e->progressive || sc->Ss != 0;
+    if (want_dc && !did_dc[d]) {
+      mjo_gen_optimal_table(dcc[d], e->dc[d].bits, e->dc[d].huffval);
+      e->dc[d].sent = 0;
+      did_dc[d] = 1;
+    }
+    if (want_ac && !did_ac[a]) {
+      mjo_gen_optimal_table(acc[a], e->ac[a].bits, e->ac[a].huffval);
+      e->ac[a].sent = 0;
+      did_ac[a] = 1;
+    }
+  }
+}
+
+static void output_scan(enc_t *e, const scan_t *sc, int first_scan, bytebuf *o)
+{
+  const mjo_params *p = e->p;
+  dtbl dcd[4], acd[4];
+  sink_t s;
+  int ci;
+  memset(&s, 0, sizeof(s));
+  for (ci = 0; ci < sc->ncomp; ci++) {
+    int c = sc->comp[ci];
+    make_derived(&e->dc[p->dc_tbl_no[c]], &dcd[p->dc_tbl_no[c]]);
+    make_derived(&e->ac[p->ac_tbl_no[c]], &acd[p->ac_tbl_no[c]]);
+    s.dcd[p->dc_tbl_no[c]] = &dcd[p->dc_tbl_no[c]];
+    s.acd[p->ac_tbl_no[c]] = &acd[p->ac_tbl_no[c]];
+  }
+  s.out = o;
+  if (first_scan) emit_frame_header(e, o);
+  emit_scan_header(e, sc, o);
+  code_scan(e, sc, &s);
+}
+
+static void bb_append(bytebuf *dst, const bytebuf *src)
+{
+  size_t i;
+  for (i = 0; i < src->len; i++) bb_put(dst, src->buf[i]);
+}
+
+size_t mjo_encode(const mjo_params *p, const uint8_t *pixels, size_t row_stride,
+                  uint8_t *out, size_t cap, mjo_taps *taps)
+{
+  enc_t e;
+  bytebuf o = { 0, 0, 0 };
+  uint8_t *planes[MJO_MAX_COMPS] = { 0, 0, 0, 0 };
+  int ci, t;
+  size_t n;
+
+  memset(&e, 0, sizeof(e));
+  e.p = p;
+  e.progressive = p->num_scans > 0;
+  mjo_geometry(p, e.g, &e.mcus_per_row, &e.mcu_rows);
+  for (ci = 0; ci < p->num_components; ci++) {
+    planes[ci] = (uint8_t *)malloc((size_t)e.g[ci].pw * e.g[ci].ph);
+    e.uq[ci] = (int16_t *)calloc((size_t)e.g[ci].hpad * e.g[ci].wpad * 64, 2);
+    e.q[ci] = (int16_t *)calloc((size_t)e.g[ci].hpad * e.g[ci].wpad * 64, 2);
+  }
+  /* std_huff_tables, jstdhuff.c:54 */
+  memcpy(e.dc[0].bits, STD_DC_L_BITS, 17); memcpy(e.dc[0].huffval, STD_DC_VAL, 12);
+  memcpy(e.dc[1].bits, STD_DC_C_BITS, 17); memcpy(e.dc[1].huffval, STD_DC_VAL, 12);
+  memcpy(e.ac[0].bits, STD_AC_L_BITS, 17); memcpy(e.ac[0].huffval, STD_AC_L_VAL, 162);
+  memcpy(e.ac[1].bits, STD_AC_C_BITS, 17); memcpy(e.ac[1].huffval, STD_AC_C_VAL, 162);
+
+  mjo_color_downsample(p, pixels, row_stride, planes);
+  mjo_forward(p, planes, e.uq, e.q);
+  if (taps) {
+    for (ci = 0; ci < p->num_components; ci++) {
+      size_t nb = (size_t)e.g[ci].hpad * e.g[ci].wpad * 128;
+      if (taps->planes[ci]) memcpy(taps->planes[ci], planes[ci], (size_t)e.g[ci].pw * e.g[ci].ph);
+      if (taps->coef_uq[ci]) memcpy(taps->coef_uq[ci], e.uq[ci], nb);
+      if (taps->coef_q0[ci]) memcpy(taps->coef_q0[ci], e.q[ci], nb);
+    }
+  }
+
+  emit_file_header(&e, &o);
+
+  /* trellis passes (pass numbers < pass_number_scan_opt_base): SURVEY 3.3 table */
+  if (p->trellis_quant) {
+    for (ci = 0; ci < p->num_components; ci++) {
+      mjo_scan ms;
+      scan_t sc;
+      dtbl dcd, acd;
+      memset(&ms, 0, sizeof(ms));
+      ms.comps_in_scan = 1; ms.component_index[0] = ci;
+      ms.Ss = 1; ms.Se = 63; ms.Ah = 0; ms.Al = 0;
+      setup_scan(&e, &sc, &ms);
+      gather_and_build(&e, &sc, 1);
+      make_derived(&e.dc[p->dc_tbl_no[ci]], &dcd);
+      make_derived(&e.ac[p->ac_tbl_no[ci]], &acd);
+      trellis_component(&e, ci, &dcd, &acd);
+      gather_and_build(&e, &sc, 1);
+    }
+  }
+  if (taps)
+    for (ci = 0; ci < p->num_components; ci++)
+      if (taps->coef_q[ci]) memcpy(taps->coef_q[ci], e.q[ci], (size_t)e.g[ci].hpad * e.g[ci].wpad * 128);
+
+  if (!e.progressive) {
+    mjo_scan ms;
+    scan_t sc;
+    memset(&ms, 0, sizeof(ms));
+    ms.comps_in_scan = p->num_components;
+    for (ci = 0; ci < p->num_components; ci++) ms.component_index[ci] = ci;
+    ms.Ss = 0; ms.Se = 63;
+    setup_scan(&e, &sc, &ms);
+    if (p->optimize_coding) gather_and_build(&e, &sc, 0);
+    output_scan(&e, &sc, 1, &o);
+  } else if (!p->optimize_scans) {
+    int si;
+    for (si = 0; si < p->num_scans; si++) {
+      scan_t sc;
+      setup_scan(&e, &sc, &p->scans[si]);
+      if (sc.Ss != 0 || sc.Ah == 0) gather_and_build(&e, &sc, 0);
+      output_scan(&e, &sc, si == 0, &o);
+    }
+  } else {
+    /* scan search: select_scans jcmaster.c:773-962; constants from jpeg_search_progression */
+    bytebuf sb[MJO_MAX_SCANS];
+    unsigned long size[MJO_MAX_SCANS];
+    const int nsl_dc = 1, Al_max_luma = 3, nfs = 5;
+    const int nsl = nsl_dc + (3 * Al_max_luma + 2) + (2 * nfs + 1); /* 23 */
+    const int Al_max_chroma = p->num_components == 3 ? 2 : 0;
+    const int nsc_dc = p->num_components == 3 ? 3 : 0;
+    const int luma_fs_start = nsl_dc + 3 * Al_max_luma + 2;            /* 12 */
+    const int chroma_fs_start = nsl + nsc_dc + (6 * Al_max_chroma + 4); /* 42 */
+    unsigned long best_cost = 0;
+    int best_Al_luma = 0, best_Al_chroma = 0, best_fs_luma = 0, best_fs_chroma = 0;
+    int sn = 0, i, Al, min_Al, base;
+    memset(sb, 0, sizeof(sb));
+    memset(size, 0, sizeof(size));
+    while (sn < p->num_scans) {
+      mjo_scan ms = p->scans[sn];
+      scan_t sc;
+      int next;
+      if (sn >= luma_fs_start && sn < nsl) ms.Al = best_Al_luma;             /* jcmaster.c:487-491 */
+      if (sn >= chroma_fs_start && sn < p->num_scans) ms.Al = best_Al_chroma; /* :492-497 */
+      setup_scan(&e, &sc, &ms);
+      if (sc.Ss != 0 || sc.Ah == 0) gather_and_build(&e, &sc, 0);
+      output_scan(&e, &sc, sn == 0, &sb[sn]);
+      size[sn] = (unsigned long)sb[sn].len;
+      next = sn + 1;
+      if (next > 1 && next <= luma_fs_start) {
+        if ((next - 1) % 3 == 2) {
+          unsigned long cost = size[next - 2] + size[next - 1];
+          Al = (next - 1) / 3;
+          for (i = 0; i < Al; i++) cost += size[3 + 3 * i];
+          if (Al == 0 || cost < best_cost) { best_cost = cost; best_Al_luma = Al; }
+          else sn = luma_fs_start - 1;
+        }
+      } else if (next > luma_fs_start && next <= nsl) {
+        if (next == luma_fs_start + 1) { best_fs_luma = 0; best_cost = size[next - 1]; }
+        else if ((next - luma_fs_start) % 2 == 1) {
+          int idx = (next - luma_fs_start) >> 1;
+          unsigned long cost = size[next - 2] + size[next - 1];
+          if (cost < best_cost) { best_cost = cost; best_fs_luma = idx; }
+          if ((idx == 2 && best_fs_luma == 0) || (idx == 3 && best_fs_luma != 2) ||
+              (idx == 4 && best_fs_luma != 4))
+            sn = nsl - 1;
+        }
+      } else if (p->num_scans > nsl) {
+        if (next == nsl + nsc_dc) {
+          /* interleave_chroma_dc decision only matters for dc_scan_opt_mode != 0 */
+        } else if (next > nsl + nsc_dc && next <= chroma_fs_start) {
+          base = nsl + nsc_dc;
+          if ((next - base) % 6 == 4) {
+            unsigned long cost = size[next - 4] + size[next - 3] + size[next - 2] + size[next - 1];
+            Al = (next - base) / 6;
+            for (i = 0; i < Al; i++) cost += size[base + 4 + 6 * i] + size[base + 5 + 6 * i];
+            if (Al == 0 || cost < best_cost) { best_cost = cost; best_Al_chroma = Al; }
+            else sn = chroma_fs_start - 1;
+          }
+        } else if (next > chroma_fs_start && next <= p->num_scans) {
+          if (next == chroma_fs_start + 2) {
+            best_fs_chroma = 0;
+            best_cost = size[next - 2] + size[next - 1];
+          } else if ((next - chroma_fs_start) % 4 == 2) {
+            int idx = (next - chroma_fs_start) >> 2;
+            unsigned long cost = size[next - 4] + size[next - 3] + size[next - 2] + size[next - 1];
+            if (cost < best_cost) { best_cost = cost; best_fs_chroma = idx; }
+            if ((idx == 2 && best_fs_chroma == 0) || (idx == 3 && best_fs_chroma != 2) ||
+                (idx == 4 && best_fs_chroma != 4))
+              sn = p->num_scans - 1;
+          }
+        }
+      }
+      sn++;
+    }
+    /* final assembly, jcmaster.c:898-956 */
+    min_Al = best_Al_luma < best_Al_chroma ? best_Al_luma : best_Al_chroma;
+    bb_append(&o, &sb[0]);
+    if (best_fs_luma == 0) bb_append(&o, &sb[luma_fs_start]);
+    else {
+      bb_append(&o, &sb[luma_fs_start + 2 * (best_fs_luma - 1) + 1]);
+      bb_append(&o, &sb[luma_fs_start + 2 * (best_fs_luma - 1) + 2]);
+    }
+    for (Al = best_Al_luma - 1; Al >= min_Al; Al--) bb_append(&o, &sb[3 + 3 * Al]);
+    base = nsl + nsc_dc;
+    if (p->num_scans > nsl) {
+      if (best_fs_chroma == 0) {
+        bb_append(&o, &sb[chroma_fs_start]);
+        bb_append(&o, &sb[chroma_fs_start + 1]);
+      } else {
+        for (i = 2; i <= 5; i++) bb_append(&o, &sb[chroma_fs_start + 4 * (best_fs_chroma - 1) + i]);
+      }
+      for (Al = best_Al_chroma - 1; Al >= min_Al; Al--) {
+        bb_append(&o, &sb[base + 6 * Al + 4]);
+        bb_append(&o, &sb[base + 6 * Al + 5]);
+      }
+    }
+    for (Al = min_Al - 1; Al >= 0; Al--) {
+      bb_append(&o, &sb[3 + 3 * Al]);
+      if (p->num_scans > nsl) {
+        bb_append(&o, &sb[base + 6 * Al + 4]);
+        bb_append(&o, &sb[base + 6 * Al + 5]);
+      }
+    }
+    for (i = 0; i < p->num_scans; i++) free(sb[i].buf);
+  }
+  bb_put(&o, 0xFF); bb_put(&o, 0xD9); /* write_file_trailer jcmarker.c:791 */
+
+  if (taps) {
+    for (t = 0; t < 4; t++) {
+      memcpy(taps->dc_bits[t], e.dc[t].bits, 17); memcpy(taps->dc_vals[t], e.dc[t].huffval, 256);
+      memcpy(taps->ac_bits[t], e.ac[t].bits, 17); memcpy(taps->ac_vals[t], e.ac[t].huffval, 256);
+    }
+  }
+  n = o.len;
+  if (n <= cap) memcpy(out, o.buf, n); else n = 0;
+  free(o.buf);
+  for (ci = 0; ci < p->num_components; ci++) { free(planes[ci]); free(e.uq[ci]); free(e.q[ci]); }
+  return n;
+}

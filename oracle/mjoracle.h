@@ -1,0 +1,106 @@
+/*
+ * mjoracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the mozjpeg encode hot path,
+ * written from the reference's behaviour as a whole-image, planar encoder.  It exists so the
+ * HIP path can be checked stage by stage (planes, raw DCT, quantized, trellised
+ * coefficients, histograms, Huffman tables, final bytes) and byte for byte.
+ *
+ * PARITY PIN: this restatement is itself pinned against (i) the reference's own golden
+ * MD5_JPEG_420_ISLOW = 9a68f56bc76e466aa7e52f415d0f4a5f (CMakeLists.txt:1391) and the other
+ * cjpeg -revert bittest constants usable on this path, and (ii) the REAL reference compiled
+ * from /root/reference into oracle/_ref (oracle/Makefile), byte for byte, on the fixture set
+ * under tests/golden/ (tests/test_oracle_vs_reference.py, tests/golden/make_goldens.py).
+ * The reference has no test that pins trellis / deringing / scan search; for
+ * those modes the compiled reference is the only authority.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this code.
+ * The product (mozjpeg_amd/) never links, imports or executes anything in oracle/.
+ */
+#ifndef MJORACLE_H
+#define MJORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MJO_MAX_COMPS 4
+#define MJO_MAX_SCANS 64
+
+typedef struct {
+  int comps_in_scan;
+  int component_index[MJO_MAX_COMPS];
+  int Ss, Se, Ah, Al;
+} mjo_scan;
+
+/* Everything jpeg_start_compress would read from cinfo (SURVEY 8b "Inputs read from cinfo"). */
+typedef struct {
+  int width, height;
+  int input_components;           /* 3: interleaved RGB, 1: gray */
+  int num_components;             /* 3: YCbCr, 1: gray (RGB->gray if input is RGB) */
+  int h_samp[MJO_MAX_COMPS], v_samp[MJO_MAX_COMPS];
+  int quant_tbl_no[MJO_MAX_COMPS], dc_tbl_no[MJO_MAX_COMPS], ac_tbl_no[MJO_MAX_COMPS];
+  int component_id[MJO_MAX_COMPS];
+  uint16_t qtbl[4][64];           /* natural (row-major) order, like JQUANT_TBL.quantval */
+  int fastest_profile;            /* 1: JCP_FASTEST marker layout (one DQT/DHT marker per table) */
+  int optimize_coding;
+  int trellis_quant, trellis_quant_dc, overshoot_deringing;
+  float lambda_log_scale1, lambda_log_scale2;
+  int restart_interval, restart_in_rows;
+  int num_scans;                  /* 0: single sequential scan */
+  mjo_scan scans[MJO_MAX_SCANS];
+  int optimize_scans;
+  int write_jfif;
+} mjo_params;
+
+/* jpeg_set_defaults + jpeg_set_quality + colorspace defaults, as cjpeg would leave them:
+ * profile_fastest=0 is the max-compression profile (jcparam.c:386-519).
+ * subsampling h x v applies to component 0 (the others are 1x1). */
+void mjo_default_params(mjo_params *p, int width, int height, int input_components,
+                        int gray_output, int quality, int force_baseline, int profile_fastest,
+                        int hsamp, int vsamp, int base_quant_tbl_idx);
+/* the two scan scripts of jcparam.c */
+void mjo_simple_progression(mjo_params *p);   /* jpeg_simple_progression, optimize_scans off */
+void mjo_search_progression(mjo_params *p);   /* jpeg_search_progression (64 scans, YCbCr) */
+
+/* geometry helpers (jcmaster.c:237-259) */
+typedef struct {
+  int wib, hib;        /* width/height in blocks (real blocks) */
+  int wpad, hpad;      /* rounded up to the sampling factors (dummy blocks included) */
+  int pw, ph;          /* sample plane size: wib*8 x hib*8 */
+} mjo_geom;
+void mjo_geometry(const mjo_params *p, mjo_geom g[MJO_MAX_COMPS], int *mcus_per_row, int *mcu_rows);
+
+/* Stage taps.  All buffers are caller-allocated. */
+/* a1-a3: colour conversion + downsampling + edge replication -> planes[c] (g[c].pw x g[c].ph) */
+void mjo_color_downsample(const mjo_params *p, const uint8_t *pixels, size_t row_stride, uint8_t *planes[MJO_MAX_COMPS]);
+/* a4-a8: deringing + FDCT + quantize -> coef_uq/coef_q [hpad*wpad][64] natural order, dummies built */
+void mjo_forward(const mjo_params *p, uint8_t *const planes[MJO_MAX_COMPS],
+                 int16_t *coef_uq[MJO_MAX_COMPS], int16_t *coef_q[MJO_MAX_COMPS]);
+/* a11 */
+void mjo_gen_optimal_table(long freq[257], uint8_t bits[17], uint8_t huffval[256]);
+/* one block: used by unit tests */
+void mjo_fdct_islow(int data[64]);
+void mjo_deringing(int data[64], int q0);
+
+/* Whole encode.  Returns number of bytes written to out (0 on error / insufficient cap).
+ * If taps != NULL the post-trellis quantized coefficients etc. are copied out. */
+typedef struct {
+  int16_t *coef_uq[MJO_MAX_COMPS];    /* optional, [hpad*wpad*64] */
+  int16_t *coef_q0[MJO_MAX_COMPS];    /* optional, quantized before trellis */
+  int16_t *coef_q[MJO_MAX_COMPS];     /* optional, final (after trellis) */
+  uint8_t *planes[MJO_MAX_COMPS];     /* optional */
+  /* final tables: [tbl][17] bits, [tbl][256] vals for the LAST sequential scan */
+  uint8_t dc_bits[4][17], dc_vals[4][256], ac_bits[4][17], ac_vals[4][256];
+} mjo_taps;
+
+size_t mjo_encode(const mjo_params *p, const uint8_t *pixels, size_t row_stride,
+                  uint8_t *out, size_t cap, mjo_taps *taps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

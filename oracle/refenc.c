@@ -138,8 +138,10 @@ int main(int argc, char **argv)
     jpeg_set_quality(&cinfo, quality, baseline ? TRUE : FALSE);
     if (baseline) { cinfo.num_scans = 0; cinfo.scan_info = NULL; }
     if (optimize) cinfo.optimize_coding = TRUE;
-    if (fastcrush) { jpeg_c_set_bool_param(&cinfo, JBOOLEAN_OPTIMIZE_SCANS, FALSE); progressive = 1; }
-    if (progressive) jpeg_simple_progression(&cinfo);
+    if (fastcrush) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_OPTIMIZE_SCANS, FALSE);
+    /* cjpeg.c re-runs jpeg_simple_progression after all colourspace switches (simple_progressive
+     * is TRUE by default in the max-compression profile, cjpeg.c:345-347,:767-768) */
+    if (progressive || fastcrush || (!revert && !baseline)) jpeg_simple_progression(&cinfo);
     if (notrellis) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_TRELLIS_QUANT, FALSE);
     if (notrellis_dc) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_TRELLIS_QUANT_DC, FALSE);
     if (noovershoot) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_OVERSHOOT_DERINGING, FALSE);

@@ -1,0 +1,242 @@
+"""ctypes binding of the CPU oracle (oracle/libmjoracle.so) and helpers around the compiled
+reference (oracle/_ref).  TEST INFRASTRUCTURE: imported only by tests/, bench.py's cpu_baseline
+leg and __graft_entry__.smoke() -- never by the product package."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+REF_DIR = os.path.join(ORACLE_DIR, "_ref")
+MAXC, MAXS = 4, 64
+
+
+class Scan(C.Structure):
+    _fields_ = [("comps_in_scan", C.c_int), ("component_index", C.c_int * MAXC),
+                ("Ss", C.c_int), ("Se", C.c_int), ("Ah", C.c_int), ("Al", C.c_int)]
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("input_components", C.c_int),
+                ("num_components", C.c_int), ("h_samp", C.c_int * MAXC), ("v_samp", C.c_int * MAXC),
+                ("quant_tbl_no", C.c_int * MAXC), ("dc_tbl_no", C.c_int * MAXC),
+                ("ac_tbl_no", C.c_int * MAXC), ("component_id", C.c_int * MAXC),
+                ("qtbl", (C.c_uint16 * 64) * 4), ("fastest_profile", C.c_int),
+                ("optimize_coding", C.c_int), ("trellis_quant", C.c_int),
+                ("trellis_quant_dc", C.c_int), ("overshoot_deringing", C.c_int),
+                ("lambda_log_scale1", C.c_float), ("lambda_log_scale2", C.c_float),
+                ("restart_interval", C.c_int), ("restart_in_rows", C.c_int),
+                ("num_scans", C.c_int), ("scans", Scan * MAXS), ("optimize_scans", C.c_int),
+                ("write_jfif", C.c_int)]
+
+
+class Geom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("wib", "hib", "wpad", "hpad", "pw", "ph")]
+
+
+class Taps(C.Structure):
+    _fields_ = [("coef_uq", C.c_void_p * MAXC), ("coef_q0", C.c_void_p * MAXC),
+                ("coef_q", C.c_void_p * MAXC), ("planes", C.c_void_p * MAXC),
+                ("dc_bits", (C.c_uint8 * 17) * 4), ("dc_vals", (C.c_uint8 * 256) * 4),
+                ("ac_bits", (C.c_uint8 * 17) * 4), ("ac_vals", (C.c_uint8 * 256) * 4)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ORACLE_DIR, "libmjoracle.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "port"])
+        _lib = C.CDLL(path)
+        _lib.mjo_encode.restype = C.c_size_t
+        _lib.mjo_encode.argtypes = [C.POINTER(Params), C.c_void_p, C.c_size_t, C.c_void_p,
+                                    C.c_size_t, C.POINTER(Taps)]
+        _lib.mjo_default_params.argtypes = [C.POINTER(Params)] + [C.c_int] * 10
+        _lib.mjo_geometry.argtypes = [C.POINTER(Params), C.POINTER(Geom), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int)]
+        _lib.mjo_gen_optimal_table.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_uint8),
+                                               C.POINTER(C.c_uint8)]
+    return _lib
+
+
+def make_params(width, height, *, quality=75, baseline=False, revert=False, optimize=False,
+                progressive=False, fastcrush=False, notrellis=False, notrellis_dc=False,
+                noovershoot=False, sample=(2, 2), restart=None, gray=False, grayin=False,
+                quant_table=-1, lambda1=None, lambda2=None):
+    """Same switch vocabulary as cjpeg / oracle/refenc.c.  Default (no switch) is cjpeg's default:
+    max-compression profile, progressive with scan search."""
+    p = Params()
+    L = lib()
+    L.mjo_default_params(C.byref(p), width, height, 1 if grayin else 3, 1 if gray else 0, quality,
+                         1 if baseline else 0, 1 if revert else 0, sample[0], sample[1], quant_table)
+    if optimize:
+        p.optimize_coding = 1
+    if notrellis:
+        p.trellis_quant = 0
+    if notrellis_dc:
+        p.trellis_quant_dc = 0
+    if noovershoot:
+        p.overshoot_deringing = 0
+    if lambda1 is not None:
+        p.lambda_log_scale1 = lambda1
+    if lambda2 is not None:
+        p.lambda_log_scale2 = lambda2
+    if restart is not None:
+        if isinstance(restart, str) and restart.lower().endswith("b"):
+            p.restart_interval = int(restart[:-1])
+        else:
+            p.restart_in_rows = int(restart)
+    if revert:
+        if progressive:
+            L.mjo_simple_progression(C.byref(p))
+            p.optimize_coding = 1
+    elif not baseline:
+        if fastcrush or progressive:
+            L.mjo_simple_progression(C.byref(p))
+        else:
+            L.mjo_search_progression(C.byref(p))
+        p.optimize_coding = 1
+    return p
+
+
+def geometry(p):
+    g = (Geom * MAXC)()
+    mpr, mr = C.c_int(), C.c_int()
+    lib().mjo_geometry(C.byref(p), g, C.byref(mpr), C.byref(mr))
+    return [g[i] for i in range(p.num_components)], mpr.value, mr.value
+
+
+def encode(p, pixels, want_taps=False):
+    """pixels: uint8 array [H, W, C] (C contiguous).  Returns bytes (and taps dict)."""
+    pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
+    h, w = pixels.shape[:2]
+    assert (w, h) == (p.width, p.height)
+    cap = w * h * 4 + 65536
+    out = np.empty(cap, np.uint8)
+    taps = None
+    keep = {}
+    if want_taps:
+        taps = Taps()
+        gs, _, _ = geometry(p)
+        for ci, g in enumerate(gs):
+            nb = g.hpad * g.wpad * 64
+            for name in ("coef_uq", "coef_q0", "coef_q"):
+                a = np.zeros(nb, np.int16)
+                keep[(name, ci)] = a
+                getattr(taps, name)[ci] = a.ctypes.data
+            a = np.zeros(g.pw * g.ph, np.uint8)
+            keep[("planes", ci)] = a
+            taps.planes[ci] = a.ctypes.data
+    n = lib().mjo_encode(C.byref(p), pixels.ctypes.data, pixels.strides[0], out.ctypes.data, cap,
+                         C.byref(taps) if taps is not None else None)
+    assert n > 0, "oracle encode failed"
+    data = out[:n].tobytes()
+    if not want_taps:
+        return data
+    res = {}
+    gs, _, _ = geometry(p)
+    for ci, g in enumerate(gs):
+        for name in ("coef_uq", "coef_q0", "coef_q"):
+            res[(name, ci)] = keep[(name, ci)].reshape(g.hpad, g.wpad, 64)
+        res[("planes", ci)] = keep[("planes", ci)].reshape(g.ph, g.pw)
+    res["dc_bits"] = np.ctypeslib.as_array(taps.dc_bits).copy()
+    res["dc_vals"] = np.ctypeslib.as_array(taps.dc_vals).copy()
+    res["ac_bits"] = np.ctypeslib.as_array(taps.ac_bits).copy()
+    res["ac_vals"] = np.ctypeslib.as_array(taps.ac_vals).copy()
+    return data, res
+
+
+# ---- the compiled reference (oracle/_ref), where present -------------------------------------
+def have_ref():
+    return os.path.exists(os.path.join(REF_DIR, "refenc"))
+
+
+def ref_switches(**kw):
+    """Translate make_params keywords into refenc/cjpeg switches."""
+    sw = ["-quality", str(kw.get("quality", 75))]
+    for k in ("baseline", "revert", "optimize", "progressive", "fastcrush", "notrellis",
+              "noovershoot", "gray", "grayin"):
+        if kw.get(k):
+            sw.append("-" + k)
+    if kw.get("notrellis_dc"):
+        sw.append("-notrellis-dc")
+    s = kw.get("sample", (2, 2))
+    sw += ["-sample", "%dx%d" % s]
+    if kw.get("restart") is not None:
+        sw += ["-restart", str(kw["restart"])]
+    if kw.get("quant_table", -1) >= 0:
+        sw += ["-quant-table", str(kw["quant_table"])]
+    if kw.get("lambda1") is not None:
+        sw += ["-lambda1", str(kw["lambda1"])]
+    if kw.get("lambda2") is not None:
+        sw += ["-lambda2", str(kw["lambda2"])]
+    return sw
+
+
+def ref_encode(pixels, reps=1, dumpcoef=False, **kw):
+    """Encode with the REAL reference library through oracle/_ref/refenc."""
+    pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
+    h, w = pixels.shape[:2]
+    with tempfile.TemporaryDirectory() as td:
+        raw = os.path.join(td, "in.rgb")
+        outp = os.path.join(td, "out.jpg")
+        pixels.tofile(raw)
+        cmd = [os.path.join(REF_DIR, "refenc")] + ref_switches(**kw) + ["-raw", str(w), str(h),
+                                                                        "-reps", str(reps)]
+        if pixels.ndim == 2 or pixels.shape[2] == 1:
+            cmd.append("-grayin")
+        if dumpcoef:
+            cmd += ["-dumpcoef", os.path.join(td, "coef.bin")]
+        cmd += [raw, outp]
+        info = subprocess.check_output(cmd).decode()
+        data = open(outp, "rb").read()
+        if dumpcoef:
+            blob = open(os.path.join(td, "coef.bin"), "rb").read()
+            coefs, off = [], 0
+            while off < len(blob):
+                hb, wb = np.frombuffer(blob, np.int32, 2, off)
+                off += 8
+                n = int(hb) * int(wb) * 64
+                coefs.append(np.frombuffer(blob, np.int16, n, off).reshape(hb, wb, 64).copy())
+                off += 2 * n
+            return data, info, coefs
+        return data, info
+
+
+def md5(b):
+    return hashlib.md5(b).hexdigest()
+
+
+def read_ppm(path):
+    with open(path, "rb") as f:
+        blob = f.read()
+    # P6\n W H\n 255\n
+    parts = blob.split(None, 4)
+    assert parts[0] == b"P6"
+    w, h = int(parts[1]), int(parts[2])
+    data = blob[len(blob) - w * h * 3:]
+    return np.frombuffer(data, np.uint8).reshape(h, w, 3).copy()
+
+
+def synthetic_frame(width, height, seed=1234):
+    """SURVEY 8d synthetic input: smooth colour fields + Gaussian noise + saturated 64x64 tiles
+    (exercise deringing/clipping).  Deterministic (PCG64)."""
+    y, x = np.mgrid[0:height, 0:width].astype(np.float64)
+    s = float(seed)
+    f = [np.sin(x / 97 + s) * np.cos(y / 71), np.sin((x + y) / 53), np.cos(x / 31 - y / 43)]
+    amp = (100, 90, 80)
+    rng = np.random.default_rng(seed)
+    img = np.empty((height, width, 3), np.float64)
+    for c in range(3):
+        img[..., c] = 128 + amp[c] * f[c] + rng.normal(0, 12, (height, width))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    tiles = ((x.astype(np.int64) // 64 + y.astype(np.int64) // 64) % 7) == 0
+    img[tiles] = 255
+    return img
