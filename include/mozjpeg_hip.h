@@ -1,0 +1,143 @@
+/*
+ * mozjpeg_hip.h -- C ABI of libmozjpeg_hip.so, the MI355X-native JPEG encode hot path.
+ *
+ * Two layers are exported (plain pointers and sizes only; no C++/torch types):
+ *
+ *  (1) The batch encoder (mjh_*): the native interface of the GPU pipeline.  One encoder =
+ *      one parameter set + one GPU + device-resident working buffers for up to max_batch
+ *      equally sized images.  It replaces, for a whole image at a time, the reference's
+ *      pixel->bytes path:
+ *        jpeg_start_compress      jcapistd.c:44   (parameter capture  -> mjh_encoder_create)
+ *        jpeg_write_scanlines     jcapistd.c:90   (pixel hand-over    -> mjh_encode_*)
+ *        jpeg_finish_compress     jcapimin.c:176  (passes 1..N + bytes-> mjh_encode_*, mjh_get_jpeg)
+ *      and the parameter helpers a caller needs to fill mjh_params:
+ *        jpeg_set_defaults        jcparam.c:386   -> mjh_params_defaults
+ *        jpeg_set_quality         jcparam.c:360   -> mjh_params_set_quality
+ *        jpeg_simple_progression  jcparam.c:859   -> (later rounds)
+ *
+ *  (2) The libjpeg drop-in symbols (declared in mozjpeg_hip_jpeglib.h, built into
+ *      libmozjpeg_hip_jpeg62.so): jpeg_start_compress / jpeg_write_scanlines /
+ *      jpeg_finish_compress with the reference's exact signatures (jpeglib.h:1065-1076),
+ *      implemented on top of layer (1).
+ *
+ * Error convention: functions return 0 on success or a negative MJH_E* code;
+ * mjh_last_error() returns a thread-local message.  Nothing here falls back to a CPU
+ * implementation: an unsupported configuration is an error (MJH_EUNSUPPORTED).
+ */
+#ifndef MOZJPEG_HIP_H
+#define MOZJPEG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MJH_MAX_COMPS 4
+#define MJH_MAX_SCANS 64
+
+#define MJH_OK            0
+#define MJH_EINVAL       -1   /* bad argument */
+#define MJH_EUNSUPPORTED -2   /* configuration outside the GPU hot path (no CPU fallback) */
+#define MJH_EHIP         -3   /* HIP runtime error (message has the hipError string) */
+#define MJH_ENOMEM       -4
+#define MJH_ETOOSMALL    -5   /* output buffer too small */
+
+/* profile values = the reference's JINT_COMPRESS_PROFILE GUIDs (jpeglib.h:353-356) */
+#define MJH_PROFILE_MAX_COMPRESSION 0x5D083AAD
+#define MJH_PROFILE_FASTEST         0x2AEA5CB4
+
+/* one entry of a progressive scan script (jpeg_scan_info, jpeglib.h:196-201) */
+typedef struct {
+  int comps_in_scan;
+  int component_index[MJH_MAX_COMPS];
+  int Ss, Se, Ah, Al;
+} mjh_scan;
+
+/* Everything the hot path reads from a jpeg_compress_struct at jpeg_start_compress
+ * (SURVEY 8b "Inputs read from cinfo"; field names follow jpeglib.h:399-488 and the
+ * extension parameters of jpeglib.h:321-356). */
+typedef struct {
+  int image_width, image_height;
+  int input_components;            /* 3 = interleaved RGB, 1 = grayscale */
+  int num_components;              /* 3 = YCbCr output, 1 = grayscale output */
+  int h_samp_factor[MJH_MAX_COMPS], v_samp_factor[MJH_MAX_COMPS];
+  int quant_tbl_no[MJH_MAX_COMPS], dc_tbl_no[MJH_MAX_COMPS], ac_tbl_no[MJH_MAX_COMPS];
+  int component_id[MJH_MAX_COMPS];
+  uint16_t quantval[4][64];        /* natural order, = quant_tbl_ptrs[i]->quantval */
+  int compress_profile;            /* MJH_PROFILE_* : marker layout (jcmarker.c:189,293) */
+  int optimize_coding;
+  int trellis_quant, trellis_quant_dc, overshoot_deringing;
+  float lambda_log_scale1, lambda_log_scale2;
+  unsigned restart_interval;
+  int restart_in_rows;
+  int num_scans;                   /* 0 = one sequential scan (baseline) */
+  mjh_scan scan_info[MJH_MAX_SCANS];
+  int optimize_scans;
+  int write_JFIF_header;
+} mjh_params;
+
+typedef struct mjh_encoder mjh_encoder;
+
+/* ---- parameter helpers (host only) ---------------------------------------------------- */
+/* jpeg_set_defaults (jcparam.c:386-519) for an RGB->YCbCr (or ->gray) encode of the given size
+ * and profile, plus the sampling factors of component 0 (others 1x1). */
+int mjh_params_defaults(mjh_params *p, int width, int height, int input_components,
+                        int gray_output, int compress_profile, int hsamp, int vsamp);
+/* jpeg_set_quality (jcparam.c:360-380) with the base table selected by base_quant_tbl_idx
+ * (-1 = the profile's default: 3 for max compression, 0 for fastest; jcparam.c:509-510). */
+int mjh_params_set_quality(mjh_params *p, int quality, int force_baseline, int base_quant_tbl_idx);
+
+/* ---- encoder lifetime ----------------------------------------------------------------- */
+/* Creates the device-resident state for up to max_batch images of p's geometry on HIP device
+ * `device`.  Returns MJH_EUNSUPPORTED for configurations the GPU path does not cover. */
+int mjh_encoder_create(const mjh_params *p, int max_batch, int device, mjh_encoder **out);
+void mjh_encoder_destroy(mjh_encoder *e);
+
+/* ---- encode ---------------------------------------------------------------------------- */
+/* Encode n images that are ALREADY in device memory (interleaved samples, row_pitch bytes per
+ * row, image_stride bytes between images).  `stream` is a hipStream_t passed as void*
+ * (NULL = the encoder's own stream).  Asynchronous: results are valid after
+ * mjh_encoder_sync() or any later synchronising call. */
+int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t row_pitch, size_t image_stride,
+                      int n, void *stream);
+/* Same with host pixels: staged through pinned memory and a side stream (H2D), then encoded. */
+int mjh_encode_host(mjh_encoder *e, const void *pixels, size_t row_pitch, size_t image_stride, int n);
+int mjh_encoder_sync(mjh_encoder *e);
+
+/* Size in bytes of JPEG i of the last batch (synchronises). */
+int mjh_get_jpeg_size(mjh_encoder *e, int i, size_t *size);
+/* Copy JPEG i of the last batch to host memory (synchronises). */
+int mjh_get_jpeg(mjh_encoder *e, int i, void *dst, size_t cap, size_t *size);
+/* Device-side view of the outputs of the last batch: file i starts at base + i*stride and is
+ * sizes[i] bytes long (sizes is a device pointer to uint32). */
+int mjh_get_output_device(mjh_encoder *e, void **d_base, size_t *stride, void **d_sizes);
+
+/* ---- introspection for parity tests and profiling ------------------------------------- */
+enum {
+  MJH_TAP_PLANE = 1,     /* uint8  [ph][pw] downsampled samples of one component            */
+  MJH_TAP_COEF_UQ = 2,   /* int16  [64 zig-zag][nblk] raw DCT (x8) coefficients             */
+  MJH_TAP_COEF_Q = 3,    /* int16  [64 zig-zag][nblk] quantized (after trellis if enabled)  */
+  MJH_TAP_COEF_Q0 = 4,   /* int16  quantized before trellis (kept only when debug taps on)  */
+  MJH_TAP_HUFF_BITS = 5, /* uint8  [4 slots: DC0,AC0,DC1,AC1][17] final tables               */
+  MJH_TAP_HUFF_VALS = 6  /* uint8  [4][256]                                                  */
+};
+int mjh_set_debug_taps(mjh_encoder *e, int on);
+int mjh_read_tap(mjh_encoder *e, int what, int image, int component, void *dst, size_t cap, size_t *size);
+/* geometry of component c: blocks across/down (real blocks) and plane size */
+int mjh_component_geometry(const mjh_encoder *e, int c, int *width_in_blocks, int *height_in_blocks,
+                           int *plane_width, int *plane_height);
+
+/* Per-kernel HIP-event timing of the last mjh_encode_* call when profiling is on
+ * (names/ms arrays are owned by the encoder; *count entries). */
+int mjh_set_profiling(mjh_encoder *e, int on);
+int mjh_get_kernel_times(mjh_encoder *e, const char *const **names, const float **ms, int *count);
+
+const char *mjh_last_error(void);
+const char *mjh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOZJPEG_HIP_H */

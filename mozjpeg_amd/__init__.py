@@ -1,0 +1,205 @@
+"""mozjpeg_amd -- ctypes binding of libmozjpeg_hip.so (the MI355X-native JPEG encode hot path).
+
+This package is only a thin binding: the product is the shared library built from
+mozjpeg_amd/csrc (HIP kernels for gfx950 + C++ host pipeline + C ABI, see include/mozjpeg_hip.h).
+There is deliberately NO CPU fallback anywhere: if the library is missing or no GPU is visible the
+calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmozjpeg_hip.so")
+
+MAX_COMPS, MAX_SCANS = 4, 64
+PROFILE_MAX_COMPRESSION = 0x5D083AAD
+PROFILE_FASTEST = 0x2AEA5CB4
+OK, EINVAL, EUNSUPPORTED, EHIP, ENOMEM, ETOOSMALL = 0, -1, -2, -3, -4, -5
+TAP_PLANE, TAP_COEF_UQ, TAP_COEF_Q, TAP_COEF_Q0, TAP_HUFF_BITS, TAP_HUFF_VALS = 1, 2, 3, 4, 5, 6
+
+
+class MjhError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mozjpeg_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Scan(C.Structure):
+    _fields_ = [("comps_in_scan", C.c_int), ("component_index", C.c_int * MAX_COMPS),
+                ("Ss", C.c_int), ("Se", C.c_int), ("Ah", C.c_int), ("Al", C.c_int)]
+
+
+class Params(C.Structure):
+    """Mirror of mjh_params (include/mozjpeg_hip.h) = the cinfo fields the hot path reads."""
+    _fields_ = [("image_width", C.c_int), ("image_height", C.c_int), ("input_components", C.c_int),
+                ("num_components", C.c_int), ("h_samp_factor", C.c_int * MAX_COMPS),
+                ("v_samp_factor", C.c_int * MAX_COMPS), ("quant_tbl_no", C.c_int * MAX_COMPS),
+                ("dc_tbl_no", C.c_int * MAX_COMPS), ("ac_tbl_no", C.c_int * MAX_COMPS),
+                ("component_id", C.c_int * MAX_COMPS), ("quantval", (C.c_uint16 * 64) * 4),
+                ("compress_profile", C.c_int), ("optimize_coding", C.c_int), ("trellis_quant", C.c_int),
+                ("trellis_quant_dc", C.c_int), ("overshoot_deringing", C.c_int),
+                ("lambda_log_scale1", C.c_float), ("lambda_log_scale2", C.c_float),
+                ("restart_interval", C.c_uint), ("restart_in_rows", C.c_int), ("num_scans", C.c_int),
+                ("scan_info", Scan * MAX_SCANS), ("optimize_scans", C.c_int), ("write_JFIF_header", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libmozjpeg_hip.so; raises if it has not been built (python -m mozjpeg_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MjhError(EHIP, "%s not built: run `python -m mozjpeg_amd.build` (needs hipcc)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.mjh_last_error.restype = C.c_char_p
+        L.mjh_version.restype = C.c_char_p
+        L.mjh_params_defaults.argtypes = [C.POINTER(Params)] + [C.c_int] * 7
+        L.mjh_params_set_quality.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int]
+        L.mjh_encoder_create.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.mjh_encoder_destroy.argtypes = [C.c_void_p]
+        L.mjh_encoder_destroy.restype = None
+        L.mjh_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
+        L.mjh_encode_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+        L.mjh_encoder_sync.argtypes = [C.c_void_p]
+        L.mjh_get_jpeg_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
+        L.mjh_get_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.mjh_get_output_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                            C.POINTER(C.c_void_p)]
+        L.mjh_set_debug_taps.argtypes = [C.c_void_p, C.c_int]
+        L.mjh_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.mjh_read_tap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                   C.POINTER(C.c_size_t)]
+        L.mjh_component_geometry.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_int)] * 4
+        L.mjh_get_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_char_p)),
+                                           C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise MjhError(rc, lib().mjh_last_error().decode())
+
+
+def make_params(width, height, *, quality=75, baseline=False, revert=False, optimize=False,
+                notrellis=False, notrellis_dc=False, noovershoot=False, sample=(2, 2), gray=False,
+                grayin=False, quant_table=-1, lambda1=None, lambda2=None, restart=None,
+                progressive=False, fastcrush=False):
+    """Parameters with cjpeg's switch vocabulary (cjpeg.c:371-714).  Without `baseline` or
+    `revert` cjpeg would select progressive + scan search, which the GPU path rejects for now."""
+    p = Params()
+    L = lib()
+    _chk(L.mjh_params_defaults(C.byref(p), width, height, 1 if grayin else 3, 1 if gray else 0,
+                               PROFILE_FASTEST if revert else PROFILE_MAX_COMPRESSION, sample[0], sample[1]))
+    _chk(L.mjh_params_set_quality(C.byref(p), quality, 1 if baseline else 0, quant_table))
+    if optimize:
+        p.optimize_coding = 1
+    if notrellis:
+        p.trellis_quant = 0
+    if notrellis_dc:
+        p.trellis_quant_dc = 0
+    if noovershoot:
+        p.overshoot_deringing = 0
+    if lambda1 is not None:
+        p.lambda_log_scale1 = lambda1
+    if lambda2 is not None:
+        p.lambda_log_scale2 = lambda2
+    if restart is not None:
+        if isinstance(restart, str) and restart.lower().endswith("b"):
+            p.restart_interval = int(restart[:-1])
+        else:
+            p.restart_in_rows = int(restart)
+    if progressive or fastcrush or not (baseline or revert):
+        p.num_scans = -1  # marks "a progressive script is required": rejected by mjh_encoder_create
+    return p
+
+
+class Encoder:
+    """One parameter set + one GPU + device buffers for up to max_batch images."""
+
+    def __init__(self, params, max_batch=1, device=0):
+        self._h = C.c_void_p()
+        self.params = params
+        self.max_batch = max_batch
+        _chk(lib().mjh_encoder_create(C.byref(params), max_batch, device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().mjh_encoder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- encode -------------------------------------------------------------------------------
+    def encode_host(self, images):
+        """images: uint8 ndarray [n, H, W, C] (or [H, W, C]); returns list of bytes."""
+        a = np.ascontiguousarray(images, dtype=np.uint8)
+        if a.ndim == 3:
+            a = a[None]
+        n = a.shape[0]
+        _chk(lib().mjh_encode_host(self._h, a.ctypes.data, a.strides[1], a.strides[0], n))
+        return [self.get_jpeg(i) for i in range(n)]
+
+    def encode_device_ptr(self, ptr, row_pitch, image_stride, n, stream=None):
+        _chk(lib().mjh_encode_device(self._h, ptr, row_pitch, image_stride, n, stream))
+
+    def encode_tensor(self, t, stream=None):
+        """t: torch uint8 CUDA tensor [n, H, W, C], contiguous.  Asynchronous."""
+        assert t.is_cuda and t.is_contiguous() and t.dim() == 4
+        self.encode_device_ptr(t.data_ptr(), t.stride(1), t.stride(0), t.shape[0], stream)
+
+    def sync(self):
+        _chk(lib().mjh_encoder_sync(self._h))
+
+    def get_jpeg(self, i):
+        n = C.c_size_t()
+        _chk(lib().mjh_get_jpeg_size(self._h, i, C.byref(n)))
+        buf = np.empty(n.value, np.uint8)
+        _chk(lib().mjh_get_jpeg(self._h, i, buf.ctypes.data, n.value, C.byref(n)))
+        return buf.tobytes()
+
+    def jpeg_size(self, i):
+        n = C.c_size_t()
+        _chk(lib().mjh_get_jpeg_size(self._h, i, C.byref(n)))
+        return n.value
+
+    # -- introspection ------------------------------------------------------------------------
+    def set_debug_taps(self, on=True):
+        _chk(lib().mjh_set_debug_taps(self._h, int(on)))
+
+    def set_profiling(self, on=True):
+        _chk(lib().mjh_set_profiling(self._h, int(on)))
+
+    def geometry(self, c):
+        v = [C.c_int() for _ in range(4)]
+        _chk(lib().mjh_component_geometry(self._h, c, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)  # wib, hib, pw, ph
+
+    def read_tap(self, what, image=0, comp=0):
+        wib, hib, pw, ph = self.geometry(comp if what not in (TAP_HUFF_BITS, TAP_HUFF_VALS) else 0)
+        if what == TAP_PLANE:
+            out = np.empty((ph, pw), np.uint8)
+        elif what == TAP_HUFF_BITS:
+            out = np.empty((4, 17), np.uint8)
+        elif what == TAP_HUFF_VALS:
+            out = np.empty((4, 256), np.uint8)
+        else:
+            out = np.empty((64, wib * hib), np.int16)
+        n = C.c_size_t()
+        _chk(lib().mjh_read_tap(self._h, what, image, comp, out.ctypes.data, out.nbytes, C.byref(n)))
+        return out
+
+    def kernel_times(self):
+        names = C.POINTER(C.c_char_p)()
+        ms = C.POINTER(C.c_float)()
+        cnt = C.c_int()
+        _chk(lib().mjh_get_kernel_times(self._h, C.byref(names), C.byref(ms), C.byref(cnt)))
+        return [(names[i].decode(), float(ms[i])) for i in range(cnt.value)]

@@ -1,0 +1,49 @@
+"""Build libmozjpeg_hip.so (HIP kernels + host pipeline + C ABI) for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so is
+git-ignored but travels to the GPU box with the repo snapshot."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmozjpeg_hip.so")
+SHIM = os.path.join(HERE, "libmozjpeg_hip_jpeg62.so")
+SOURCES = ["mjh_kernels.hip", "mjh_encoder.cpp"]
+# -ffp-contract=off: the trellis / deringing float recipes must not be fused into FMAs
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + \
+        [os.path.join(HERE, "..", "include", "mozjpeg_hip.h")]
+    if force or _newer(LIB, deps):
+        objs = []
+        for s in srcs:
+            o = os.path.join(CSRC, os.path.splitext(os.path.basename(s))[0] + ".o")
+            cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            objs.append(o)
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

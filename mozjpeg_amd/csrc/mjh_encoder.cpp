@@ -1,0 +1,723 @@
+// mjh_encoder.cpp -- host side of libmozjpeg_hip.so: parameter capture, geometry, marker
+// bytes, device buffers and the kernel schedule.  Everything the reference does on the host
+// between its passes (pass scheduling jcmaster.c:612-1035, Huffman table construction, marker
+// writing) is either a kernel here (tables, headers) or a fixed launch sequence, so an encode
+// of a whole batch never synchronises with the host until the JPEG bytes are fetched.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mozjpeg_hip.h"
+#include "mjh_internal.h"
+#include "mjh_launch.h"
+
+// ---- error plumbing ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MJH_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+extern "C" const char *mjh_last_error(void) { return g_err; }
+extern "C" const char *mjh_version(void) { return "mozjpeg_hip 0.1 (gfx950)"; }
+
+// zig-zag (jutils.c:59)
+static const int kZZ[64] = {
+  0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
+  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
+  35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+  58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
+
+// ---- parameter helpers --------------------------------------------------------------------------
+// Base quantization tables the two profiles use: index 0 = Annex K.1 (jcparam.c:76-99,:180-190),
+// index 3 = the max-compression default (jcparam.c:111-122 == :218-229, same table for chroma).
+static const unsigned kBaseLuma0[64] = {
+  16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55,
+  14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+  18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+  49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99 };
+static const unsigned kBaseChroma0[64] = {
+  17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99,
+  24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+  99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+  99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99 };
+static const unsigned kBase3[64] = {
+  16, 16, 16, 18, 25, 37, 56, 85, 16, 17, 20, 27, 34, 40, 53, 75,
+  16, 20, 24, 31, 43, 62, 91, 135, 18, 27, 31, 40, 53, 74, 106, 156,
+  25, 34, 43, 53, 69, 94, 131, 189, 37, 40, 62, 74, 94, 124, 169, 238,
+  56, 53, 91, 106, 131, 169, 226, 311, 85, 75, 135, 156, 189, 238, 311, 418 };
+
+extern "C" int mjh_params_set_quality(mjh_params *p, int quality, int force_baseline, int base_idx)
+{
+  if (!p) return fail(MJH_EINVAL, "null params");
+  // jpeg_float_quality_scaling jcparam.c:340-357, truncated to int as jpeg_quality_scaling does
+  float q = (float)quality;
+  if (q <= 0.f) q = 1.f;
+  if (q > 100.f) q = 100.f;
+  q = q < 50.f ? 5000.f / q : 200.f - q * 2.f;
+  const int scale = (int)q;
+  if (base_idx < 0) base_idx = p->compress_profile == MJH_PROFILE_FASTEST ? 0 : 3;
+  if (base_idx != 0 && base_idx != 3) return fail(MJH_EUNSUPPORTED, "base quant table index %d: pass the table in quantval[] instead", base_idx);
+  const unsigned *bl = base_idx == 3 ? kBase3 : kBaseLuma0;
+  const unsigned *bc = base_idx == 3 ? kBase3 : kBaseChroma0;
+  for (int t = 0; t < 2; t++) {
+    const unsigned *b = t ? bc : bl;
+    for (int i = 0; i < 64; i++) {  // jpeg_add_quant_table jcparam.c:55-64
+      long v = ((long)b[i] * scale + 50L) / 100L;
+      if (v <= 0) v = 1;
+      if (v > 32767) v = 32767;
+      if (force_baseline && v > 255) v = 255;
+      p->quantval[t][i] = (uint16_t)v;
+    }
+  }
+  return MJH_OK;
+}
+
+extern "C" int mjh_params_defaults(mjh_params *p, int width, int height, int input_components,
+                                   int gray_output, int profile, int hsamp, int vsamp)
+{
+  if (!p) return fail(MJH_EINVAL, "null params");
+  memset(p, 0, sizeof(*p));
+  const bool maxc = profile != MJH_PROFILE_FASTEST;
+  p->image_width = width;
+  p->image_height = height;
+  p->input_components = input_components;
+  p->compress_profile = maxc ? MJH_PROFILE_MAX_COMPRESSION : MJH_PROFILE_FASTEST;
+  if (input_components == 1 || gray_output) {  // jpeg_set_colorspace jcparam.c:597-602
+    p->num_components = 1;
+    p->component_id[0] = 1;
+    p->h_samp_factor[0] = p->v_samp_factor[0] = 1;
+  } else {                                      // :611-619
+    p->num_components = 3;
+    for (int i = 0; i < 3; i++) {
+      p->component_id[i] = i + 1;
+      p->h_samp_factor[i] = p->v_samp_factor[i] = 1;
+      p->quant_tbl_no[i] = p->dc_tbl_no[i] = p->ac_tbl_no[i] = i > 0;
+    }
+    p->h_samp_factor[0] = hsamp;
+    p->v_samp_factor[0] = vsamp;
+  }
+  p->optimize_coding = maxc;        // jcparam.c:436-444
+  p->trellis_quant = maxc;          // :505
+  p->trellis_quant_dc = 1;          // :516
+  p->overshoot_deringing = maxc;    // :463
+  p->lambda_log_scale1 = 14.75f;    // :507-508
+  p->lambda_log_scale2 = 16.5f;
+  p->write_JFIF_header = 1;
+  return mjh_params_set_quality(p, 75, 1, -1);
+}
+
+// ---- encoder object -------------------------------------------------------------------------------
+enum { SLOTS_PER_IMAGE = 16, SLOT_FINAL = 8 };   // 0..7: per-component trellis-pass tables (DC,AC); 8..15: final DC t / AC t
+
+
+struct mjh_encoder {
+  mjh_params p;
+  MjhConst C;
+  int device = 0;
+  int max_batch = 0;
+  int last_n = 0;
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  hipEvent_t copy_done = nullptr;
+  // device buffers
+  uint8_t *d_pix = nullptr;        // staging for mjh_encode_host
+  uint8_t *h_pix = nullptr;        // pinned host staging
+  size_t pix_image_bytes = 0;
+  uint8_t *d_planes = nullptr;
+  int16_t *d_uq = nullptr, *d_q = nullptr, *d_q0 = nullptr;
+  MjhQuant *d_quant = nullptr;
+  MjhHuffTable *d_tabs = nullptr, *d_tabs_init = nullptr;
+  float *d_lambda = nullptr;
+  uint8_t *d_back = nullptr;
+  uint16_t *d_len16 = nullptr;
+  unsigned *d_off32 = nullptr, *d_sums = nullptr, *d_totals = nullptr, *d_ffsums = nullptr, *d_fftotals = nullptr;
+  unsigned *d_stream = nullptr;
+  size_t stream_words = 0;         // per image
+  int chunks = 0, ff_chunks = 0;
+  uint8_t *d_out = nullptr;
+  size_t out_stride = 0;
+  unsigned *d_sizes = nullptr;
+  void *d_meta = nullptr;
+  uint8_t *d_prefix = nullptr, *d_sos = nullptr;
+  int prefix_len = 0, sos_len = 0;
+  int dht_slots[4] = { 0, 0, 0, 0 }, dht_ids[4] = { 0, 0, 0, 0 }, ndht = 0;
+  bool debug_taps = false, profiling = false;
+  // profiling
+  std::vector<std::string> prof_names;
+  std::vector<const char *> prof_cnames;
+  std::vector<float> prof_ms;
+  std::vector<hipEvent_t> prof_events;
+  std::vector<unsigned> h_sizes;
+  bool sizes_valid = false;
+};
+
+static long div_round_up(long a, long b) { return (a + b - 1) / b; }
+
+static int check_supported(const mjh_params *p)
+{
+  if (p->image_width <= 0 || p->image_height <= 0 || p->image_width > 65500 || p->image_height > 65500)
+    return fail(MJH_EINVAL, "bad image size %dx%d", p->image_width, p->image_height);
+  if (p->input_components != 1 && p->input_components != 3) return fail(MJH_EUNSUPPORTED, "input_components %d (RGB or gray only)", p->input_components);
+  if (p->num_components != 1 && p->num_components != 3) return fail(MJH_EUNSUPPORTED, "num_components %d", p->num_components);
+  if (p->num_components == 3 && p->input_components != 3) return fail(MJH_EUNSUPPORTED, "gray input cannot produce 3 components");
+  if (p->num_components == 1 && (p->h_samp_factor[0] != 1 || p->v_samp_factor[0] != 1))
+    return fail(MJH_EUNSUPPORTED, "grayscale must be sampled 1x1");
+  if (p->num_components == 3) {
+    const int h = p->h_samp_factor[0], v = p->v_samp_factor[0];
+    if (!((h == 1 || h == 2) && (v == 1 || v == 2))) return fail(MJH_EUNSUPPORTED, "luma sampling %dx%d", h, v);
+    for (int i = 1; i < 3; i++)
+      if (p->h_samp_factor[i] != 1 || p->v_samp_factor[i] != 1) return fail(MJH_EUNSUPPORTED, "chroma sampling must be 1x1");
+  }
+  for (int i = 0; i < p->num_components; i++) {
+    if (p->quant_tbl_no[i] < 0 || p->quant_tbl_no[i] > 3 || p->dc_tbl_no[i] < 0 || p->dc_tbl_no[i] > 3 || p->ac_tbl_no[i] < 0 || p->ac_tbl_no[i] > 3)
+      return fail(MJH_EINVAL, "table number out of range");
+    for (int k = 0; k < 64; k++)
+      if (p->quantval[p->quant_tbl_no[i]][k] == 0) return fail(MJH_EINVAL, "quantization table %d has a zero entry", p->quant_tbl_no[i]);
+  }
+  if (p->num_scans != 0) return fail(MJH_EUNSUPPORTED, "progressive scan scripts are not on the GPU path yet");
+  if (p->restart_interval != 0 || p->restart_in_rows != 0) return fail(MJH_EUNSUPPORTED, "restart intervals are not on the GPU path yet");
+  if (p->trellis_quant && !p->optimize_coding) return fail(MJH_EUNSUPPORTED, "trellis_quant requires optimize_coding (jcmaster.c:686-702 never selects a component otherwise)");
+  if (!p->optimize_coding) {
+    for (int i = 0; i < p->num_components; i++)
+      if (p->dc_tbl_no[i] > 1 || p->ac_tbl_no[i] > 1) return fail(MJH_EUNSUPPORTED, "standard Huffman tables exist only for table numbers 0 and 1");
+  }
+  return MJH_OK;
+}
+
+static void build_const(const mjh_params *p, MjhConst *C)
+{
+  memset(C, 0, sizeof(*C));
+  C->W = p->image_width; C->H = p->image_height;
+  C->in_comps = p->input_components; C->ncomp = p->num_components;
+  C->maxh = C->maxv = 1;
+  for (int i = 0; i < C->ncomp; i++) {
+    if (p->h_samp_factor[i] > C->maxh) C->maxh = p->h_samp_factor[i];
+    if (p->v_samp_factor[i] > C->maxv) C->maxv = p->v_samp_factor[i];
+  }
+  C->mcus_per_row = (int)div_round_up(C->W, C->maxh * 8);   // per_scan_setup jcmaster.c:561-566
+  C->mcu_rows = (int)div_round_up(C->H, C->maxv * 8);
+  C->groups_x = C->mcus_per_row * 8;
+  C->groups_y = C->mcu_rows * 8;
+  C->real_groups_y = (int)div_round_up(C->H, C->maxv);
+  long long plane_off = 0, coef_off = 0, blk_off = 0;
+  int mcu_blk0 = 0;
+  for (int i = 0; i < C->ncomp; i++) {
+    MjhComp &c = C->c[i];
+    c.h = p->h_samp_factor[i]; c.v = p->v_samp_factor[i];
+    c.hexp = C->maxh / c.h; c.vexp = C->maxv / c.v;
+    c.wib = (int)div_round_up((long)C->W * c.h, (long)C->maxh * 8);   // initial_setup jcmaster.c:237-247
+    c.hib = (int)div_round_up((long)C->H * c.v, (long)C->maxv * 8);
+    c.wpad = (int)(div_round_up(c.wib, c.h) * c.h);                   // jccoefct.c:587-601
+    c.hpad = (int)(div_round_up(c.hib, c.v) * c.v);
+    c.pw = c.wib * 8; c.ph = c.hib * 8;
+    c.nblk = c.wib * c.hib;
+    c.kstride = (c.nblk + 63) & ~63;
+    c.qtbl = p->quant_tbl_no[i]; c.dctbl = p->dc_tbl_no[i]; c.actbl = p->ac_tbl_no[i];
+    c.mcu_blk0 = mcu_blk0; mcu_blk0 += c.h * c.v;
+    c.plane_off = plane_off; plane_off += (long long)c.pw * c.ph;
+    c.coef_off = coef_off; coef_off += (long long)c.kstride * 64;
+    c.blk_off = blk_off; blk_off += c.nblk;
+  }
+  C->blocks_per_mcu = mcu_blk0;
+  C->total_mcu_blocks = C->mcus_per_row * C->mcu_rows * C->blocks_per_mcu;
+  C->total_real_blocks = (int)blk_off;
+  C->planes_per_image = plane_off;
+  C->coefs_per_image = coef_off;
+  C->deringing = p->overshoot_deringing;
+  C->trellis_dc = p->trellis_quant_dc;
+  C->restart_interval = 0;
+  C->lambda_log_scale1 = p->lambda_log_scale1;
+  C->lambda_log_scale2 = p->lambda_log_scale2;
+  // pow() evaluated by the host libm, like the reference (jcdctmgr.c:1033-1037)
+  if (p->lambda_log_scale2 > 0.0f) {
+    C->pow_scale1 = pow(2.0, (double)p->lambda_log_scale1);
+    C->pow_scale2 = pow(2.0, (double)p->lambda_log_scale2);
+  } else {
+    C->pow_scale1 = pow(2.0, (double)p->lambda_log_scale1 - 12.0);
+    C->pow_scale2 = 0.0;
+  }
+}
+
+// ---- marker bytes that do not depend on the image (jcmarker.c) -------------------------------------
+static void put2(std::vector<uint8_t> &o, int v) { o.push_back((uint8_t)(v >> 8)); o.push_back((uint8_t)v); }
+
+static void build_prefix(const mjh_params *p, std::vector<uint8_t> &o, bool *baseline_sof)
+{
+  const bool multi = p->compress_profile != MJH_PROFILE_FASTEST;
+  o.push_back(0xFF); o.push_back(0xD8);                     // SOI, write_file_header :649
+  if (p->write_JFIF_header) {                               // emit_jfif_app0 :534-565 (version 1.01, density 1:1)
+    o.push_back(0xFF); o.push_back(0xE0); put2(o, 16);
+    const uint8_t jf[] = { 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0 };
+    o.insert(o.end(), jf, jf + sizeof(jf));
+  }
+  int prec[MJH_MAX_COMPS], prec_any = 0;
+  for (int ci = 0; ci < p->num_components; ci++) {
+    prec[ci] = 0;
+    for (int i = 0; i < 64; i++) if (p->quantval[p->quant_tbl_no[ci]][i] > 255) prec[ci] = 1;
+    prec_any += prec[ci];
+  }
+  bool sent[4] = { false, false, false, false };
+  if (multi) {                                              // emit_multi_dqt :189-254
+    bool seen[4] = { false, false, false, false };
+    int size = 2;
+    for (int ci = 0; ci < p->num_components; ci++) {
+      const int t = p->quant_tbl_no[ci];
+      if (!seen[t]) { size += 64 * (prec[ci] + 1) + 1; seen[t] = true; }
+    }
+    o.push_back(0xFF); o.push_back(0xDB); put2(o, size);
+  }
+  for (int ci = 0; ci < p->num_components; ci++) {
+    const int t = p->quant_tbl_no[ci];
+    if (sent[t]) continue;
+    if (!multi) {                                           // emit_dqt :140-186
+      o.push_back(0xFF); o.push_back(0xDB);
+      put2(o, prec[ci] ? 64 * 2 + 1 + 2 : 64 + 1 + 2);
+    }
+    o.push_back((uint8_t)(t + (prec[ci] << 4)));
+    for (int i = 0; i < 64; i++) {
+      const unsigned qv = p->quantval[t][kZZ[i]];
+      if (prec[ci]) o.push_back((uint8_t)(qv >> 8));
+      o.push_back((uint8_t)(qv & 0xFF));
+    }
+    sent[t] = true;
+  }
+  bool is_baseline = true;                                  // write_frame_header :699-734
+  for (int ci = 0; ci < p->num_components; ci++)
+    if (p->dc_tbl_no[ci] > 1 || p->ac_tbl_no[ci] > 1) is_baseline = false;
+  if (prec_any) is_baseline = false;
+  *baseline_sof = is_baseline;
+  o.push_back(0xFF); o.push_back(is_baseline ? 0xC0 : 0xC1);  // emit_sof :464-490
+  put2(o, 3 * p->num_components + 2 + 5 + 1);
+  o.push_back(8);
+  put2(o, p->image_height); put2(o, p->image_width);
+  o.push_back((uint8_t)p->num_components);
+  for (int ci = 0; ci < p->num_components; ci++) {
+    o.push_back((uint8_t)p->component_id[ci]);
+    o.push_back((uint8_t)((p->h_samp_factor[ci] << 4) + p->v_samp_factor[ci]));
+    o.push_back((uint8_t)p->quant_tbl_no[ci]);
+  }
+}
+
+static void build_sos(const mjh_params *p, std::vector<uint8_t> &o)
+{                                                           // emit_sos :494-531, sequential scan of all components
+  o.push_back(0xFF); o.push_back(0xDA);
+  put2(o, 2 * p->num_components + 2 + 1 + 3);
+  o.push_back((uint8_t)p->num_components);
+  for (int ci = 0; ci < p->num_components; ci++) {
+    o.push_back((uint8_t)p->component_id[ci]);
+    o.push_back((uint8_t)((p->dc_tbl_no[ci] << 4) + p->ac_tbl_no[ci]));
+  }
+  o.push_back(0); o.push_back(63); o.push_back(0);
+}
+
+// Annex K.3 standard tables (jstdhuff.c:54-131), used when optimize_coding is off
+static const uint8_t kStdDcLBits[17] = { 0, 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0 };
+static const uint8_t kStdDcCBits[17] = { 0, 0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0 };
+static const uint8_t kStdDcVal[12] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11 };
+static const uint8_t kStdAcLBits[17] = { 0, 0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d };
+static const uint8_t kStdAcLVal[162] = {
+  0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07,
+  0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0,
+  0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28,
+  0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49,
+  0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69,
+  0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89,
+  0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7,
+  0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5,
+  0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
+  0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8,
+  0xf9, 0xfa };
+static const uint8_t kStdAcCBits[17] = { 0, 0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77 };
+static const uint8_t kStdAcCVal[162] = {
+  0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71,
+  0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0,
+  0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26,
+  0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48,
+  0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68,
+  0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87,
+  0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5,
+  0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+  0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda,
+  0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8,
+  0xf9, 0xfa };
+
+static void fill_std_table(MjhHuffTable *T, const uint8_t *bits, const uint8_t *vals, int nvals)
+{   // jpeg_make_c_derived_tbl jchuff.c:231-318 on the host (tables are constants here)
+  memset(T, 0, sizeof(*T));
+  memcpy(T->bits, bits, 17);
+  memcpy(T->huffval, vals, nvals);
+  T->nsyms = nvals;
+  int p = 0;
+  unsigned code = 0;
+  for (int l = 1; l <= 16; l++) {
+    for (int i = 0; i < bits[l]; i++) {
+      T->ehufsi[vals[p]] = (uint8_t)l;
+      T->ehufco[vals[p]] = (uint16_t)code;
+      code++; p++;
+    }
+    code <<= 1;
+  }
+}
+
+static void free_all(mjh_encoder *e)
+{
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  void *ptrs[] = { e->d_pix, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back,
+                   e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
+                   e->d_meta, e->d_prefix, e->d_sos };
+  for (void *q : ptrs) if (q) (void)hipFree(q);
+  if (e->h_pix) (void)hipHostFree(e->h_pix);
+  for (hipEvent_t ev : e->prof_events) (void)hipEventDestroy(ev);
+  if (e->copy_done) (void)hipEventDestroy(e->copy_done);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+  delete e;
+}
+
+extern "C" void mjh_encoder_destroy(mjh_encoder *e) { free_all(e); }
+
+#define HIPCHK_E(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { int rc_ = fail(MJH_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); free_all(e); return rc_; } } while (0)
+
+extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device, mjh_encoder **out)
+{
+  if (!p || !out || max_batch < 1) return fail(MJH_EINVAL, "bad arguments");
+  *out = nullptr;
+  int rc = check_supported(p);
+  if (rc) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(MJH_EHIP, "no HIP device available: libmozjpeg_hip has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(MJH_EINVAL, "device %d out of range (%d devices)", device, ndev);
+  mjh_encoder *e = new mjh_encoder();
+  e->p = *p;
+  e->device = device;
+  e->max_batch = max_batch;
+  build_const(p, &e->C);
+  const MjhConst &C = e->C;
+  HIPCHK_E(hipSetDevice(device));
+  HIPCHK_E(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  HIPCHK_E(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  HIPCHK_E(hipEventCreateWithFlags(&e->copy_done, hipEventDisableTiming));
+  const size_t B = (size_t)max_batch;
+  e->pix_image_bytes = (size_t)C.W * C.H * C.in_comps;
+  HIPCHK_E(hipMalloc((void **)&e->d_planes, B * C.planes_per_image));
+  HIPCHK_E(hipMalloc((void **)&e->d_uq, B * C.coefs_per_image * 2));
+  HIPCHK_E(hipMalloc((void **)&e->d_q, B * C.coefs_per_image * 2));
+  HIPCHK_E(hipMalloc((void **)&e->d_quant, sizeof(MjhQuant)));
+  HIPCHK_E(hipMalloc((void **)&e->d_tabs, B * SLOTS_PER_IMAGE * sizeof(MjhHuffTable)));
+  HIPCHK_E(hipMalloc((void **)&e->d_tabs_init, B * SLOTS_PER_IMAGE * sizeof(MjhHuffTable)));
+  HIPCHK_E(hipMalloc((void **)&e->d_lambda, B * C.total_real_blocks * sizeof(float)));
+  HIPCHK_E(hipMalloc((void **)&e->d_back, B * (size_t)C.total_real_blocks * 16));
+  HIPCHK_E(hipMalloc((void **)&e->d_len16, B * (size_t)C.total_mcu_blocks * 2));
+  HIPCHK_E(hipMalloc((void **)&e->d_off32, B * (size_t)C.total_mcu_blocks * 4));
+  e->chunks = (C.total_mcu_blocks + 2047) / 2048;
+  // worst case 1665 bits per block (DC 16+11, 63 x (16+10)) -> 53 words
+  size_t words = (size_t)C.total_mcu_blocks * 53 + 64;
+  if (words > (size_t)1 << 27) words = (size_t)1 << 27;   // bit offsets are 32-bit
+  e->stream_words = (words + 63) & ~(size_t)63;
+  e->ff_chunks = (int)((e->stream_words + 2047) / 2048);
+  HIPCHK_E(hipMalloc((void **)&e->d_sums, B * e->chunks * sizeof(unsigned)));
+  HIPCHK_E(hipMalloc((void **)&e->d_ffsums, B * e->ff_chunks * sizeof(unsigned)));
+  HIPCHK_E(hipMalloc((void **)&e->d_totals, B * sizeof(unsigned)));
+  HIPCHK_E(hipMalloc((void **)&e->d_fftotals, B * sizeof(unsigned)));
+  HIPCHK_E(hipMalloc((void **)&e->d_stream, B * e->stream_words * 4));
+  e->out_stride = ((size_t)2048 + e->stream_words * 8 + 255) & ~(size_t)255;
+  HIPCHK_E(hipMalloc((void **)&e->d_out, B * e->out_stride));
+  HIPCHK_E(hipMalloc((void **)&e->d_sizes, B * sizeof(unsigned)));
+  HIPCHK_E(hipMalloc(&e->d_meta, B * sizeof(MjhImageMeta)));
+  e->h_sizes.resize(B);
+
+  // quantizer constants
+  MjhQuant hq;
+  memset(&hq, 0, sizeof(hq));
+  for (int t = 0; t < 4; t++)
+    for (int k = 0; k < 64; k++) {
+      const int q = p->quantval[t][kZZ[k]] ? p->quantval[t][kZZ[k]] : 1;
+      hq.q[t][k] = (uint16_t)q;
+      hq.rcp8q[t][k] = 1.0f / (float)(8 * q);
+      hq.lambda_tbl[t][k] = (float)(1.0 / (double)(q * q));   // jcdctmgr.c:1017-1021
+    }
+  HIPCHK_E(hipMemcpy(e->d_quant, &hq, sizeof(hq), hipMemcpyHostToDevice));
+
+  // table template (zero counts; standard tables in the final slots when optimize_coding is off)
+  {
+    std::vector<MjhHuffTable> ht(B * SLOTS_PER_IMAGE);
+    memset(ht.data(), 0, ht.size() * sizeof(MjhHuffTable));
+    if (!p->optimize_coding) {
+      for (size_t b = 0; b < B; b++) {
+        MjhHuffTable *T = &ht[b * SLOTS_PER_IMAGE + SLOT_FINAL];
+        fill_std_table(&T[0], kStdDcLBits, kStdDcVal, 12);
+        fill_std_table(&T[1], kStdAcLBits, kStdAcLVal, 162);
+        fill_std_table(&T[2], kStdDcCBits, kStdDcVal, 12);
+        fill_std_table(&T[3], kStdAcCBits, kStdAcCVal, 162);
+      }
+    }
+    HIPCHK_E(hipMemcpy(e->d_tabs_init, ht.data(), ht.size() * sizeof(MjhHuffTable), hipMemcpyHostToDevice));
+  }
+  // static marker bytes + DHT plan (emit_multi_dht jcmarker.c:365-398: component order, tables not yet sent)
+  {
+    std::vector<uint8_t> pre, sos;
+    bool base;
+    build_prefix(p, pre, &base);
+    build_sos(p, sos);
+    e->prefix_len = (int)pre.size();
+    e->sos_len = (int)sos.size();
+    HIPCHK_E(hipMalloc((void **)&e->d_prefix, pre.size()));
+    HIPCHK_E(hipMalloc((void **)&e->d_sos, sos.size()));
+    HIPCHK_E(hipMemcpy(e->d_prefix, pre.data(), pre.size(), hipMemcpyHostToDevice));
+    HIPCHK_E(hipMemcpy(e->d_sos, sos.data(), sos.size(), hipMemcpyHostToDevice));
+    bool dc_sent[4] = { false, false, false, false }, ac_sent[4] = { false, false, false, false };
+    e->ndht = 0;
+    for (int ci = 0; ci < p->num_components; ci++) {
+      const int d = p->dc_tbl_no[ci], a = p->ac_tbl_no[ci];
+      // max-compression: the reference's loop `continue`s past the AC table when the DC table was
+      // already sent (jcmarker.c:371-376); tables are shared pairwise here so the result is the same.
+      if (!dc_sent[d] && e->ndht < 4) { e->dht_slots[e->ndht] = SLOT_FINAL + 2 * d; e->dht_ids[e->ndht] = d; e->ndht++; dc_sent[d] = true; }
+      if (!ac_sent[a] && e->ndht < 4) { e->dht_slots[e->ndht] = SLOT_FINAL + 2 * a + 1; e->dht_ids[e->ndht] = a + 0x10; e->ndht++; ac_sent[a] = true; }
+    }
+  }
+  HIPCHK_E(hipDeviceSynchronize());
+  *out = e;
+  return MJH_OK;
+}
+
+// ---- the kernel schedule ---------------------------------------------------------------------------
+struct Prof {
+  mjh_encoder *e;
+  hipStream_t s;
+  size_t next = 0;
+  void mark(const char *name)
+  {
+    if (!e->profiling) return;
+    if (next >= e->prof_events.size()) { hipEvent_t ev; (void)hipEventCreate(&ev); e->prof_events.push_back(ev); }
+    (void)hipEventRecord(e->prof_events[next++], s);
+    if (name) e->prof_names.push_back(name);
+  }
+};
+
+static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, size_t image_stride, int n, hipStream_t s)
+{
+  const MjhConst &C = e->C;
+  const mjh_params &p = e->p;
+  const int spi = SLOTS_PER_IMAGE;
+  e->sizes_valid = false;
+  e->last_n = n;
+  e->prof_names.clear();
+  Prof pr{ e, s };
+  HIPCHK(hipMemcpyAsync(e->d_tabs, e->d_tabs_init, (size_t)n * spi * sizeof(MjhHuffTable), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemsetAsync(e->d_stream, 0, (size_t)n * e->stream_words * 4, s));
+  pr.mark("color");
+  mjh_launch_color(C, d_pixels, row_pitch, image_stride, e->d_planes, n, s);
+  pr.mark("dct_quant");
+  mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, n, s);
+
+  int tr_dc[4], tr_ac[4], fin_dc[4], fin_ac[4], zero4[4] = { 0, 0, 0, 0 };
+  for (int i = 0; i < 4; i++) {
+    tr_dc[i] = 2 * i; tr_ac[i] = 2 * i + 1;
+    fin_dc[i] = SLOT_FINAL + 2 * (i < C.ncomp ? p.dc_tbl_no[i] : 0);
+    fin_ac[i] = SLOT_FINAL + 2 * (i < C.ncomp ? p.ac_tbl_no[i] : 0) + 1;
+  }
+  if (p.trellis_quant) {
+    // passes 0,2,4 of SURVEY 3.3 (statistics of the conventionally quantized component) ...
+    pr.mark("stats_ac(pre-trellis)");
+    mjh_launch_stats_ac(C, e->d_q, e->d_tabs, spi, tr_ac, 0, n, s);
+    pr.mark("stats_dc(pre-trellis)");
+    mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, tr_dc, 0, zero4, n, s);
+    int slots[8], ns = 0;
+    for (int i = 0; i < C.ncomp; i++) { slots[ns++] = tr_dc[i]; slots[ns++] = tr_ac[i]; }
+    pr.mark("gen_tables(trellis)");
+    mjh_launch_gen_tables(e->d_tabs, spi, slots, ns, n, s);
+    if (e->debug_taps) {
+      if (!e->d_q0) HIPCHK(hipMalloc((void **)&e->d_q0, (size_t)e->max_batch * C.coefs_per_image * 2));
+      HIPCHK(hipMemcpyAsync(e->d_q0, e->d_q, (size_t)n * C.coefs_per_image * 2, hipMemcpyDeviceToDevice, s));
+    }
+    // ... passes 1,3,5: trellis quantization with those tables
+    pr.mark("trellis_ac");
+    mjh_launch_trellis_ac(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_ac, e->d_lambda, n, s);
+    if (p.trellis_quant_dc) {
+      pr.mark("trellis_dc");
+      mjh_launch_trellis_dc(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_dc, e->d_lambda, e->d_back, n, s);
+    }
+  }
+  if (p.optimize_coding) {
+    // pass 6: statistics of the interleaved scan (dummy blocks included) -> final tables
+    pr.mark("stats_ac(final)");
+    mjh_launch_stats_ac(C, e->d_q, e->d_tabs, spi, fin_ac, 1, n, s);
+    pr.mark("stats_dc(final)");
+    mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, fin_dc, 1, zero4, n, s);
+    pr.mark("gen_tables(final)");
+    mjh_launch_gen_tables(e->d_tabs, spi, e->dht_slots, e->ndht, n, s);
+  }
+  // pass 7: headers + entropy-coded data
+  pr.mark("header");
+  mjh_launch_header(e->d_prefix, e->prefix_len, e->d_sos, e->sos_len, e->d_tabs, spi, e->dht_slots, e->dht_ids, e->ndht,
+                    p.compress_profile != MJH_PROFILE_FASTEST, e->d_out, e->out_stride, e->d_meta, n, s);
+  pr.mark("huff_encode");
+  mjh_launch_encode(C, e->d_q, e->d_tabs, spi, fin_dc, fin_ac, e->d_len16, e->d_off32, e->d_sums, e->chunks, e->d_totals,
+                    e->d_stream, e->stream_words, e->d_meta, n, s);
+  pr.mark("byte_stuff");
+  mjh_launch_stuff(e->d_stream, e->stream_words, e->d_totals, e->d_ffsums, e->ff_chunks, e->d_fftotals, e->d_out, e->out_stride,
+                   e->d_meta, e->d_sizes, n, s);
+  pr.mark(nullptr);
+  HIPCHK(hipGetLastError());
+  return MJH_OK;
+}
+
+extern "C" int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t row_pitch, size_t image_stride, int n, void *stream)
+{
+  if (!e || !d_pixels || n < 1 || n > e->max_batch) return fail(MJH_EINVAL, "bad arguments (n=%d, max_batch=%d)", n, e ? e->max_batch : 0);
+  HIPCHK(hipSetDevice(e->device));
+  return run_pipeline(e, d_pixels, row_pitch, image_stride, n, stream ? (hipStream_t)stream : e->stream);
+}
+
+extern "C" int mjh_encode_host(mjh_encoder *e, const void *pixels, size_t row_pitch, size_t image_stride, int n)
+{
+  if (!e || !pixels || n < 1 || n > e->max_batch) return fail(MJH_EINVAL, "bad arguments");
+  HIPCHK(hipSetDevice(e->device));
+  const size_t row_bytes = (size_t)e->C.W * e->C.in_comps;
+  if (!e->d_pix) {
+    HIPCHK(hipMalloc((void **)&e->d_pix, (size_t)e->max_batch * e->pix_image_bytes));
+    HIPCHK(hipHostMalloc((void **)&e->h_pix, (size_t)e->max_batch * e->pix_image_bytes, hipHostMallocDefault));
+  }
+  // host staging through pinned memory, H2D on the side stream
+  for (int i = 0; i < n; i++) {
+    const uint8_t *src = (const uint8_t *)pixels + (size_t)i * image_stride;
+    uint8_t *dst = e->h_pix + (size_t)i * e->pix_image_bytes;
+    if (row_pitch == row_bytes) memcpy(dst, src, e->pix_image_bytes);
+    else for (int y = 0; y < e->C.H; y++) memcpy(dst + (size_t)y * row_bytes, src + (size_t)y * row_pitch, row_bytes);
+    HIPCHK(hipMemcpyAsync(e->d_pix + (size_t)i * e->pix_image_bytes, dst, e->pix_image_bytes, hipMemcpyHostToDevice, e->copy_stream));
+  }
+  HIPCHK(hipEventRecord(e->copy_done, e->copy_stream));
+  HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done, 0));
+  return run_pipeline(e, e->d_pix, row_bytes, e->pix_image_bytes, n, e->stream);
+}
+
+extern "C" int mjh_encoder_sync(mjh_encoder *e)
+{
+  if (!e) return fail(MJH_EINVAL, "null encoder");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return MJH_OK;
+}
+
+static int fetch_sizes(mjh_encoder *e)
+{
+  if (e->sizes_valid) return MJH_OK;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(e->h_sizes.data(), e->d_sizes, (size_t)e->last_n * sizeof(unsigned), hipMemcpyDeviceToHost));
+  e->sizes_valid = true;
+  return MJH_OK;
+}
+
+extern "C" int mjh_get_jpeg_size(mjh_encoder *e, int i, size_t *size)
+{
+  if (!e || !size || i < 0 || i >= e->last_n) return fail(MJH_EINVAL, "bad image index");
+  int rc = fetch_sizes(e);
+  if (rc) return rc;
+  *size = e->h_sizes[i];
+  return MJH_OK;
+}
+
+extern "C" int mjh_get_jpeg(mjh_encoder *e, int i, void *dst, size_t cap, size_t *size)
+{
+  if (!e || !dst || i < 0 || i >= e->last_n) return fail(MJH_EINVAL, "bad image index");
+  int rc = fetch_sizes(e);
+  if (rc) return rc;
+  const size_t n = e->h_sizes[i];
+  if (size) *size = n;
+  if (n > cap) return fail(MJH_ETOOSMALL, "output buffer too small: need %zu bytes", n);
+  HIPCHK(hipMemcpy(dst, e->d_out + (size_t)i * e->out_stride, n, hipMemcpyDeviceToHost));
+  return MJH_OK;
+}
+
+extern "C" int mjh_get_output_device(mjh_encoder *e, void **d_base, size_t *stride, void **d_sizes)
+{
+  if (!e) return fail(MJH_EINVAL, "null encoder");
+  if (d_base) *d_base = e->d_out;
+  if (stride) *stride = e->out_stride;
+  if (d_sizes) *d_sizes = e->d_sizes;
+  return MJH_OK;
+}
+
+extern "C" int mjh_set_debug_taps(mjh_encoder *e, int on) { if (!e) return fail(MJH_EINVAL, "null encoder"); e->debug_taps = on != 0; return MJH_OK; }
+extern "C" int mjh_set_profiling(mjh_encoder *e, int on) { if (!e) return fail(MJH_EINVAL, "null encoder"); e->profiling = on != 0; return MJH_OK; }
+
+extern "C" int mjh_get_kernel_times(mjh_encoder *e, const char *const **names, const float **ms, int *count)
+{
+  if (!e || !count) return fail(MJH_EINVAL, "bad arguments");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipDeviceSynchronize());
+  const size_t n = e->prof_names.size();
+  e->prof_ms.assign(n, 0.f);
+  e->prof_cnames.resize(n);
+  for (size_t i = 0; i < n; i++) {
+    e->prof_cnames[i] = e->prof_names[i].c_str();
+    if (i + 1 < e->prof_events.size()) HIPCHK(hipEventElapsedTime(&e->prof_ms[i], e->prof_events[i], e->prof_events[i + 1]));
+  }
+  if (names) *names = e->prof_cnames.data();
+  if (ms) *ms = e->prof_ms.data();
+  *count = (int)n;
+  return MJH_OK;
+}
+
+extern "C" int mjh_component_geometry(const mjh_encoder *e, int c, int *wib, int *hib, int *pw, int *ph)
+{
+  if (!e || c < 0 || c >= e->C.ncomp) return fail(MJH_EINVAL, "bad component");
+  if (wib) *wib = e->C.c[c].wib;
+  if (hib) *hib = e->C.c[c].hib;
+  if (pw) *pw = e->C.c[c].pw;
+  if (ph) *ph = e->C.c[c].ph;
+  return MJH_OK;
+}
+
+extern "C" int mjh_read_tap(mjh_encoder *e, int what, int image, int comp, void *dst, size_t cap, size_t *size)
+{
+  if (!e || !dst || image < 0 || image >= e->last_n) return fail(MJH_EINVAL, "bad arguments");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipDeviceSynchronize());
+  const MjhConst &C = e->C;
+  if (what == MJH_TAP_HUFF_BITS || what == MJH_TAP_HUFF_VALS) {
+    std::vector<MjhHuffTable> t(4);
+    const size_t need = what == MJH_TAP_HUFF_BITS ? 4 * 17 : 4 * 256;
+    if (cap < need) return fail(MJH_ETOOSMALL, "need %zu bytes", need);
+    HIPCHK(hipMemcpy(t.data(), e->d_tabs + (size_t)image * SLOTS_PER_IMAGE + SLOT_FINAL, 4 * sizeof(MjhHuffTable), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; i++) {
+      if (what == MJH_TAP_HUFF_BITS) memcpy((uint8_t *)dst + i * 17, t[i].bits, 17);
+      else memcpy((uint8_t *)dst + i * 256, t[i].huffval, 256);
+    }
+    if (size) *size = need;
+    return MJH_OK;
+  }
+  if (comp < 0 || comp >= C.ncomp) return fail(MJH_EINVAL, "bad component");
+  const MjhComp &cc = C.c[comp];
+  if (what == MJH_TAP_PLANE) {
+    const size_t need = (size_t)cc.pw * cc.ph;
+    if (cap < need) return fail(MJH_ETOOSMALL, "need %zu bytes", need);
+    HIPCHK(hipMemcpy(dst, e->d_planes + (size_t)image * C.planes_per_image + cc.plane_off, need, hipMemcpyDeviceToHost));
+    if (size) *size = need;
+    return MJH_OK;
+  }
+  const int16_t *src = what == MJH_TAP_COEF_UQ ? e->d_uq : what == MJH_TAP_COEF_Q ? e->d_q : what == MJH_TAP_COEF_Q0 ? e->d_q0 : nullptr;
+  if (!src) return fail(MJH_EINVAL, "tap %d not available (enable debug taps before encoding)", what);
+  const size_t need = (size_t)64 * cc.nblk * 2;
+  if (cap < need) return fail(MJH_ETOOSMALL, "need %zu bytes", need);
+  // strip the kstride padding: [64][nblk]
+  HIPCHK(hipMemcpy2D(dst, (size_t)cc.nblk * 2, src + (size_t)image * C.coefs_per_image + cc.coef_off, (size_t)cc.kstride * 2,
+                     (size_t)cc.nblk * 2, 64, hipMemcpyDeviceToHost));
+  if (size) *size = need;
+  return MJH_OK;
+}

@@ -1,0 +1,76 @@
+// mjh_internal.h -- structures shared by the host pipeline (mjh_encoder.cpp) and the gfx950
+// kernels (mjh_kernels.hip).  Not part of the public ABI.
+#ifndef MJH_INTERNAL_H
+#define MJH_INTERNAL_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#define MJH_MAXC 4
+
+// Huffman table slot as it lives in HBM (one per image and per role).
+// counts[] is the gather histogram (a10), bits/huffval the JHUFF_TBL content (a11),
+// ehufsi/ehufco the derived code lengths / codes (jchuff.c:231-318).
+struct MjhHuffTable {
+  uint32_t counts[260];   // 257 used
+  uint8_t bits[20];       // bits[1..16]
+  uint8_t huffval[256];
+  uint8_t ehufsi[256];
+  uint16_t ehufco[256];
+  uint32_t nsyms;         // sum(bits[1..16])
+  uint32_t pad[3];
+};
+
+// geometry of one component (initial_setup jcmaster.c:237-259)
+struct MjhComp {
+  int h, v;               // sampling factors
+  int hexp, vexp;         // max_h/h, max_v/v
+  int wib, hib;           // real blocks across / down
+  int wpad, hpad;         // rounded up to the sampling factors (dummy blocks, jccoefct.c:587-601)
+  int pw, ph;             // sample plane = wib*8 x hib*8
+  int nblk;               // wib*hib
+  int kstride;            // elements between consecutive zig-zag planes (nblk rounded up to 64)
+  int qtbl, dctbl, actbl; // table numbers
+  int mcu_blk0;           // index of this component's first block inside an interleaved MCU
+  long long plane_off;    // sample offset of this component's plane inside one image's plane set
+  long long coef_off;     // element offset of this component's coefficient planes inside one image's set
+  long long blk_off;      // offset of this component in per-block arrays (sum of nblk of previous comps)
+};
+
+struct MjhConst {
+  int W, H;
+  int in_comps;           // 3 or 1
+  int ncomp;
+  int maxh, maxv;
+  int mcus_per_row, mcu_rows;
+  int groups_x, groups_y; // colour-conversion groups (maxh x maxv pixels each) across / down
+  int real_groups_y;      // ceil(H / maxv): groups below replicate the last downsampled row
+  int blocks_per_mcu;
+  int total_mcu_blocks;   // mcus * blocks_per_mcu (dummy blocks included)
+  int total_real_blocks;  // sum of nblk
+  int deringing;
+  int trellis_dc;
+  int restart_interval;   // of the final interleaved scan, in MCUs (0 = none)
+  float lambda_log_scale1, lambda_log_scale2;
+  double pow_scale1, pow_scale2;  // pow(2, s1) [or pow(2, s1-12) when s2 <= 0], pow(2, s2): host libm
+  long long planes_per_image;     // samples
+  long long coefs_per_image;      // int16 elements
+  MjhComp c[MJH_MAXC];
+};
+
+// per-table-slot constant data uploaded once per encoder
+struct MjhQuant {
+  uint16_t q[4][64];        // zig-zag order quantizer step
+  float rcp8q[4][64];       // 1.0f / (8*q) for the exact-division helper
+  float lambda_tbl[4][64];  // (float)(1.0 / (q*q)), zig-zag order (jcdctmgr.c:1017-1021)
+};
+
+// per-image bookkeeping written by the encode kernels
+struct MjhImageMeta {
+  unsigned total_bits;     // entropy-coded bits of the scan
+  unsigned hdr_len;        // bytes before the entropy-coded data
+  unsigned stuffed_len;    // entropy-coded bytes after stuffing
+  unsigned file_len;       // whole file
+};
+
+#endif

@@ -1,0 +1,1249 @@
+// mjh_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the JPEG encode hot path.
+//
+// Data layout in HBM (one "image set" per image of the batch):
+//   planes : uint8  per component [ph][pw]                     (downsampled samples)
+//   coef   : int16  per component [64 zig-zag k][kstride]       (coefficient-major "SoA":
+//            lane = block, so every per-block kernel reads/writes 128 contiguous bytes per
+//            wave and per coefficient index -- fully coalesced, no LDS transpose needed)
+//   tables : MjhHuffTable per image and role
+// Every kernel is "one 8x8 block per lane" unless stated otherwise; no MFMA (nothing here is a
+// dense contraction).  Float arithmetic of the trellis / deringing reproduces the reference's
+// IEEE single/double operation order; this file MUST be built with -ffp-contract=off.
+//
+// Reference behaviour each kernel reproduces is cited as file:line under /root/reference.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mjh_internal.h"
+
+#define WAVE 64
+
+// zig-zag -> natural (jutils.c:59) and its inverse
+__device__ __constant__ const uint8_t d_zz[64] = {
+  0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
+  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
+  35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+  58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63
+};
+struct ZZTab { int v[64]; };
+static constexpr ZZTab make_zz() {
+  ZZTab t{};
+  const int z[64] = {
+    0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
+    12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+    58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
+  for (int i = 0; i < 64; i++) t.v[i] = z[i];
+  return t;
+}
+static constexpr ZZTab make_izz() {
+  ZZTab z = make_zz(), t{};
+  for (int i = 0; i < 64; i++) t.v[z.v[i]] = i;
+  return t;
+}
+static constexpr ZZTab kZZ = make_zz();    // kZZ.v[k]  = natural index of zig-zag position k
+static constexpr ZZTab kIZZ = make_izz();  // kIZZ.v[n] = zig-zag position of natural index n
+
+__device__ __forceinline__ int bitlen(unsigned v) { return 32 - __clz((int)v); }  // JPEG_NBITS; clz(0)=32
+
+// exact floor(n/d) for 0 <= n < 2^24, 1 <= d < 2^24, rcp = RN(1/d)
+__device__ __forceinline__ int udiv_exact(int n, int d, float rcp)
+{
+  int q = (int)((float)n * rcp);
+  int r = n - q * d;
+  if (r < 0) q--; else if (r >= d) q++;
+  return q;
+}
+
+// =============================================================================================
+// K1  colour conversion + chroma downsampling + edge replication  
+//   rgb_ycc_convert jccolext.c:30-75 (tables jccolor.c:213-246), h2v2/h2v1/int_downsample
+//   jcsample.c:151-295, expand_right_edge jcsample.c:98, expand_bottom_edge jcprepct.c:113
+//   with its two call sites :161-168 / :180-190.  Every replicated sample is an index clamp.
+// One lane = one group of H0 x V0 pixels (one chroma sample).  Component 0 has the maximum
+// sampling factors H0 x V0, components 1,2 are 1x1.
+// =============================================================================================
+#define FIXC(x) ((int)((x) * 65536.0 + 0.5))
+
+template <int H0, int V0>
+__global__ void __launch_bounds__(256)
+k_color(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, size_t img_stride,
+        uint8_t *__restrict__ planes)
+{
+  const int gx = blockIdx.x * 256 + threadIdx.x;
+  const int gy = blockIdx.y;
+  const int img = blockIdx.z;
+  if (gx >= C.groups_x) return;
+  const uint8_t *p = pix + (size_t)img * img_stride;
+  uint8_t *pl = planes + (size_t)img * C.planes_per_image;
+  const int ic = C.in_comps;
+  const bool below = gy >= C.real_groups_y;          // replicate the last DOWNSAMPLED row
+  const int gys = below ? C.real_groups_y - 1 : gy;
+  int yv[V0][H0];
+  int cbs = 0, crs = 0;
+#pragma unroll
+  for (int vy = 0; vy < V0; vy++) {
+    int iy = gys * V0 + vy;
+    if (iy > C.H - 1) iy = C.H - 1;                   // last INPUT row replicated (jcprepct.c:161)
+    const uint8_t *row = p + (size_t)iy * row_pitch;
+#pragma unroll
+    for (int vx = 0; vx < H0; vx++) {
+      int ix = gx * H0 + vx;
+      if (ix > C.W - 1) ix = C.W - 1;                 // jcsample.c:98
+      if (ic == 3) {
+        const int r = row[ix * 3], g = row[ix * 3 + 1], b = row[ix * 3 + 2];
+        yv[vy][vx] = (FIXC(0.29900) * r + FIXC(0.58700) * g + FIXC(0.11400) * b + 32768) >> 16;
+        cbs += (-FIXC(0.16874) * r - FIXC(0.33126) * g + FIXC(0.50000) * b + (128 << 16) + 32767) >> 16;
+        crs += (FIXC(0.50000) * r - FIXC(0.41869) * g - FIXC(0.08131) * b + (128 << 16) + 32767) >> 16;
+      } else {
+        yv[vy][vx] = row[ix];
+      }
+    }
+  }
+  {
+    const MjhComp &c0 = C.c[0];
+    uint8_t *y = pl + c0.plane_off;
+#pragma unroll
+    for (int vy = 0; vy < V0; vy++) {
+      const int r = gy * V0 + vy;
+      const int svy = below ? V0 - 1 : vy;
+#pragma unroll
+      for (int vx = 0; vx < H0; vx++) {
+        const int c = gx * H0 + vx;
+        if (r < c0.ph && c < c0.pw) y[(size_t)r * c0.pw + c] = (uint8_t)yv[svy][vx];
+      }
+    }
+  }
+  if (C.ncomp == 3) {
+    int cb, cr;
+    if (H0 == 2 && V0 == 2) { const int bias = 1 + (gx & 1); cb = (cbs + bias) >> 2; cr = (crs + bias) >> 2; }       // h2v2 :263
+    else if (H0 == 2 && V0 == 1) { const int bias = gx & 1; cb = (cbs + bias) >> 1; cr = (crs + bias) >> 1; }       // h2v1 :226
+    else if (H0 == 1 && V0 == 1) { cb = cbs; cr = crs; }                                                             // fullsize :199
+    else { const int n = H0 * V0; cb = (cbs + n / 2) / n; cr = (crs + n / 2) / n; }                                  // int_downsample :151
+    const MjhComp &c1 = C.c[1];
+    const MjhComp &c2 = C.c[2];
+    if (gy < c1.ph && gx < c1.pw) {
+      pl[c1.plane_off + (size_t)gy * c1.pw + gx] = (uint8_t)cb;
+      pl[c2.plane_off + (size_t)gy * c2.pw + gx] = (uint8_t)cr;
+    }
+  }
+}
+
+// =============================================================================================
+// K2  convsamp + overshoot deringing + islow FDCT + quantize   (rows a4-a8)
+//   convsamp jcdctmgr.c:576, preprocess_deringing :416-498 (catmull_rom :387), jpeg_fdct_islow
+//   jfdctint.c:142-286, quantize jcdctmgr.c:611 (== sign(x)*((|x|+d/2)/d), d = 8q), post-clamp
+//   :761-770, unquantized copy :729-756.
+// One lane = one block, whole 8x8 in registers.  Only blocks that touch the maximum sample
+// value take the (rare, divergent) deringing path, which walks the block in zig-zag order
+// through a per-lane LDS column ([64][64] ints, conflict-free: bank = lane).
+// =============================================================================================
+#define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
+
+template <int PASS>
+__device__ __forceinline__ void fdct8(int &d0, int &d1, int &d2, int &d3, int &d4, int &d5, int &d6, int &d7)
+{
+  const int t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
+  const int t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+  const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+  constexpr int SH = PASS == 0 ? 13 - 2 : 13 + 2;
+  if (PASS == 0) { d0 = (t10 + t11) * 4; d4 = (t10 - t11) * 4; }
+  else { d0 = DESCALE(t10 + t11, 2); d4 = DESCALE(t10 - t11, 2); }
+  int z1 = (t12 + t13) * 4433;
+  d2 = DESCALE(z1 + t13 * 6270, SH);
+  d6 = DESCALE(z1 + t12 * (-15137), SH);
+  z1 = t4 + t7;
+  int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+  const int z5 = (z3 + z4) * 9633;
+  const int a4 = t4 * 2446, a5 = t5 * 16819, a6 = t6 * 25172, a7 = t7 * 12299;
+  z1 *= -7373; z2 *= -20995; z3 *= -16069; z4 *= -3196;
+  z3 += z5; z4 += z5;
+  d7 = DESCALE(a4 + z1 + z3, SH);
+  d5 = DESCALE(a5 + z2 + z4, SH);
+  d3 = DESCALE(a6 + z2 + z3, SH);
+  d1 = DESCALE(a7 + z1 + z4, SH);
+}
+
+__device__ __forceinline__ float catmull_rom(int v1, int v2, int v3, int v4, float t, int size)
+{
+  const int tan1 = (v3 - v1) * size;
+  const int tan2 = (v4 - v2) * size;
+  const float t2 = t * t;
+  const float t3 = t2 * t;
+  const float f1 = ((2.f * t3) - (3.f * t2)) + 1.f;
+  const float f2 = (-2.f * t3) + (3.f * t2);
+  const float f3 = (t3 - (2.f * t2)) + t;
+  const float f4 = t3 - t2;
+  float r = (float)v2 * f1;
+  r = r + (float)tan1 * f3;
+  r = r + (float)v3 * f2;
+  r = r + (float)tan2 * f4;
+  return r;
+}
+
+__global__ void __launch_bounds__(64)
+k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const uint8_t *__restrict__ planes,
+            int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q)
+{
+  __shared__ int lds[64][64];
+  const int comp = blockIdx.y, img = blockIdx.z;
+  const MjhComp cc = C.c[comp];
+  const int lane = threadIdx.x;
+  const int blk = blockIdx.x * 64 + lane;
+  if (blk >= cc.nblk) return;
+  const int br = blk / cc.wib, bc = blk - br * cc.wib;
+  const uint8_t *src = planes + (size_t)img * C.planes_per_image + cc.plane_off + (size_t)(br * 8) * cc.pw + bc * 8;
+  int d[64];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(src + (size_t)r * cc.pw);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      d[r * 8 + i] = (int)((v.x >> (8 * i)) & 0xFF) - 128;
+      d[r * 8 + 4 + i] = (int)((v.y >> (8 * i)) & 0xFF) - 128;
+    }
+  }
+  const uint16_t *qz = Q->q[cc.qtbl];
+  if (C.deringing) {
+    const int maxsample = 127;
+    int sum = 0, cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 64; i++) { sum += d[i]; cnt += (d[i] >= maxsample); }
+    if (cnt != 0 && cnt != 64) {
+#pragma unroll
+      for (int i = 0; i < 64; i++) lds[i][lane] = d[i];
+      const int q0 = qz[0];
+      const int a = min(31, 2 * q0);
+      const int b = (maxsample * 64 - sum) / cnt;
+      const int maxovershoot = maxsample + min(a, b);
+      int n = 0;
+      do {
+        if (lds[d_zz[n]][lane] < maxsample) { n++; continue; }
+        const int start = n;
+        while (++n < 64 && lds[d_zz[n]][lane] >= maxsample) {}
+        const int end = n;
+        const int f1 = lds[d_zz[start >= 1 ? start - 1 : 0]][lane];
+        const int f2 = lds[d_zz[start >= 2 ? start - 2 : 0]][lane];
+        const int l1 = lds[d_zz[end < 63 ? end : 63]][lane];
+        const int l2 = lds[d_zz[end < 62 ? end + 1 : 63]][lane];
+        int fslope = max(f1 - f2, maxsample - f1);
+        int lslope = max(l1 - l2, maxsample - l1);
+        if (start == 0) fslope = lslope;
+        if (end == 64) lslope = fslope;
+        const int length = end - start;
+        const float step = 1.f / (float)(length + 1);
+        float position = step;
+        for (int i = start; i < end; i++, position += step) {
+          const int tmp = (int)ceilf(catmull_rom(maxsample - fslope, maxsample, maxsample, maxsample - lslope, position, length));
+          lds[d_zz[i]][lane] = min(tmp, maxovershoot);
+        }
+        n++;
+      } while (n < 64);
+#pragma unroll
+      for (int i = 0; i < 64; i++) d[i] = lds[i][lane];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    fdct8<0>(d[r * 8], d[r * 8 + 1], d[r * 8 + 2], d[r * 8 + 3], d[r * 8 + 4], d[r * 8 + 5], d[r * 8 + 6], d[r * 8 + 7]);
+#pragma unroll
+  for (int c = 0; c < 8; c++)
+    fdct8<1>(d[c], d[8 + c], d[16 + c], d[24 + c], d[32 + c], d[40 + c], d[48 + c], d[56 + c]);
+
+  const float *rcp = Q->rcp8q[cc.qtbl];
+  int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+  int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+  const bool clampq = C.deringing != 0;
+#pragma unroll
+  for (int k = 0; k < 64; k++) {
+    const int x = d[kZZ.v[k]];
+    const int dq = 8 * (int)qz[k];
+    const int ax = x < 0 ? -x : x;
+    int v = udiv_exact(ax + (dq >> 1), dq, rcp[k]);
+    if (x < 0) v = -v;
+    if (clampq) v = max(-1023, min(1023, v));
+    uq[(size_t)k * cc.kstride] = (int16_t)x;
+    qo[(size_t)k * cc.kstride] = (int16_t)v;
+  }
+}
+
+// =============================================================================================
+// Dummy-block resolution (compress_first_pass jccoefct.c:312-345, compress_trellis_pass
+// :443-476): dummy blocks are never stored.  A padded position (r,c) of a component maps to
+// the real block whose DC it copies; its AC coefficients are zero.
+// =============================================================================================
+__device__ __forceinline__ int dc_source_block(const MjhComp &cc, int r, int c)
+{
+  if (r >= cc.hib) { c = (c / cc.h) * cc.h + cc.h - 1; r = cc.hib - 1; }
+  if (c > cc.wib - 1) c = cc.wib - 1;
+  return r * cc.wib + c;
+}
+
+// previous block of the same component in interleaved MCU order; returns false if there is
+// none (first MCU of the scan or of a restart interval).  (pr,pc) in padded coordinates.
+__device__ __forceinline__ bool mcu_prev_block(const MjhConst &C, const MjhComp &cc, int r, int c, int &pr, int &pc)
+{
+  const int xi = c % cc.h, yi = r % cc.v;
+  if (xi > 0) { pr = r; pc = c - 1; return true; }
+  if (yi > 0) { pr = r - 1; pc = c + cc.h - 1; return true; }
+  const int m = (r / cc.v) * C.mcus_per_row + c / cc.h;
+  if (m == 0) return false;
+  if (C.restart_interval && (m % C.restart_interval) == 0) return false;
+  const int pm = m - 1;
+  const int pmy = pm / C.mcus_per_row, pmx = pm - pmy * C.mcus_per_row;
+  pr = pmy * cc.v + cc.v - 1;
+  pc = pmx * cc.h + cc.h - 1;
+  return true;
+}
+
+// =============================================================================================
+// K3  symbol statistics (row a10): htest_one_block / encode_mcu_gather jchuff.c:812-915.
+// AC symbols of a block do not depend on scan order, DC symbols do, so they are gathered by
+// two kernels:
+//   k_stats_ac : one lane per real block, LDS histogram (4 interleaved copies), one global
+//                atomic per used symbol and workgroup.
+//   k_stats_dc : one lane per block in scan order (component raster order for the
+//                per-component passes, interleaved MCU order incl. dummy blocks for the final
+//                scan); per-wave ballot counting, no LDS atomics.
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+k_stats_ac(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restrict__ tabs,
+           int slots_per_image, int4 slot_of_comp, int count_dummies)
+{
+  __shared__ unsigned h[4][256];
+  const int comp = blockIdx.y, img = blockIdx.z;
+  const MjhComp cc = C.c[comp];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 1024; i += 256) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const int blk = blockIdx.x * 256 + tid;
+  if (blk < cc.nblk) {
+    unsigned *hh = h[tid & 3];
+    const int16_t *q = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+    int r = 0;
+    for (int k = 1; k < 64; k++) {
+      const int v = q[(size_t)k * cc.kstride];
+      if (v == 0) { r++; continue; }
+      while (r > 15) { atomicAdd(&hh[0xF0], 1u); r -= 16; }
+      const int nb = bitlen((unsigned)(v < 0 ? -v : v));
+      atomicAdd(&hh[(r << 4) + nb], 1u);
+      r = 0;
+    }
+    if (r > 0) atomicAdd(&hh[0], 1u);
+  }
+  __syncthreads();
+  const int slot = comp == 0 ? slot_of_comp.x : comp == 1 ? slot_of_comp.y : comp == 2 ? slot_of_comp.z : slot_of_comp.w;
+  MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+  unsigned s = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+  if (count_dummies && tid == 0 && blockIdx.x == 0)
+    s += (unsigned)(cc.wpad * cc.hpad - cc.nblk);  // every dummy block codes one EOB (all-zero AC)
+  if (s) atomicAdd(&T->counts[tid], s);
+}
+
+template <int MCU_ORDER>
+__global__ void __launch_bounds__(256)
+k_stats_dc(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restrict__ tabs,
+           int slots_per_image, int4 slot_of_comp, int4 comp_restart)
+{
+  const int comp = blockIdx.y, img = blockIdx.z;
+  const MjhComp cc = C.c[comp];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int16_t *q0 = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;  // plane k = 0
+  int nb = -1;
+  if (MCU_ORDER) {
+    if (t < cc.wpad * cc.hpad) {
+      const int r = t / cc.wpad, c = t - r * cc.wpad;
+      const int dc = q0[dc_source_block(cc, r, c)];
+      int pr, pc, pred = 0;
+      if (mcu_prev_block(C, cc, r, c, pr, pc)) pred = q0[dc_source_block(cc, pr, pc)];
+      const int df = dc - pred;
+      nb = bitlen((unsigned)(df < 0 ? -df : df));
+    }
+  } else {
+    if (t < cc.nblk) {
+      const int ri = comp == 0 ? comp_restart.x : comp == 1 ? comp_restart.y : comp == 2 ? comp_restart.z : comp_restart.w;
+      const int dc = q0[t];
+      const int pred = (t == 0 || (ri && (t % ri) == 0)) ? 0 : q0[t - 1];
+      const int df = dc - pred;
+      nb = bitlen((unsigned)(df < 0 ? -df : df));
+    }
+  }
+  const int slot = comp == 0 ? slot_of_comp.x : comp == 1 ? slot_of_comp.y : comp == 2 ? slot_of_comp.z : slot_of_comp.w;
+  MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int s = 0; s < 12; s++) {
+    const unsigned long long m = __ballot(nb == s);
+    if (lane == 0 && m) atomicAdd(&T->counts[s], (unsigned)__popcll(m));
+  }
+}
+
+// =============================================================================================
+// K4  optimal Huffman table construction (row a11): jpeg_gen_optimal_table jchuff.c:947-1106,
+// jpeg_make_c_derived_tbl :231-318.  ONE WAVE per table: the 257 symbols live 5 per lane.
+//  * "two smallest, ties -> larger symbol index" (jchuff.c:990-1012) is a wave arg-min on the
+//    key (freq, 511-symbol); the reference's chain walk over others[] is replaced by a group id
+//    per symbol (every member of the two merged trees gets codesize+1), identical result.
+//  * code-length limiting (K.2, :1073-1084) and pseudo-symbol removal are serial on lane 0.
+//  * huffval order = (codesize, symbol) via per-length ballots (bit_pos, :1060-1064,:1099-1102).
+// =============================================================================================
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)v, o, 64);
+    const unsigned hi = __shfl_xor((unsigned)(v >> 32), o, 64);
+    const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+    v = w < v ? w : v;
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(64)
+k_gen_tables(MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 slots_a, int4 slots_b)
+{
+  __shared__ int s_bits[33];
+  __shared__ int s_bitpos[33];
+  __shared__ int s_cum[18];
+  __shared__ int s_first[18];
+  __shared__ unsigned char s_val[256];
+  const int img = blockIdx.y;
+  const int li = blockIdx.x;
+  const int slot = li == 0 ? slots_a.x : li == 1 ? slots_a.y : li == 2 ? slots_a.z : li == 3 ? slots_a.w
+                 : li == 4 ? slots_b.x : li == 5 ? slots_b.y : li == 6 ? slots_b.z : slots_b.w;
+  MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+  const int lane = threadIdx.x;
+  const unsigned INF = 1000000001u;
+  unsigned f[5];
+  int cs[5], g[5];
+  bool nz[5];
+#pragma unroll
+  for (int t = 0; t < 5; t++) {
+    const int s = lane + 64 * t;
+    const unsigned c = s < 256 ? T->counts[s] : (s == 256 ? 1u : 0u);
+    nz[t] = c != 0;
+    f[t] = c ? c : INF;
+    cs[t] = 0;
+    g[t] = s;
+  }
+  for (;;) {
+    unsigned long long k1 = ~0ull;
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+      const unsigned long long key = ((unsigned long long)f[t] << 9) | (unsigned)(511 - (lane + 64 * t));
+      k1 = key < k1 ? key : k1;
+    }
+    k1 = wave_min_u64(k1);
+    const int c1 = 511 - (int)(k1 & 511);
+    const unsigned f1 = (unsigned)(k1 >> 9);
+    unsigned long long k2 = ~0ull;
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+      const int s = lane + 64 * t;
+      const unsigned long long key = ((unsigned long long)f[t] << 9) | (unsigned)(511 - s);
+      if (s != c1) k2 = key < k2 ? key : k2;
+    }
+    k2 = wave_min_u64(k2);
+    const int c2 = 511 - (int)(k2 & 511);
+    const unsigned f2 = (unsigned)(k2 >> 9);
+    if (f1 > 1000000000u || f2 > 1000000000u) break;
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+      const int s = lane + 64 * t;
+      if (s == c1) f[t] = f1 + f2;
+      if (s == c2) f[t] = INF;
+      if (g[t] == c1 || g[t] == c2) { cs[t]++; g[t] = c1; }
+    }
+  }
+  // bits[L] = number of symbols (incl. pseudo-symbol 256) with code length L
+  for (int L = lane; L < 33; L += 64) s_bits[L] = 0;
+  __syncthreads();
+  for (int L = 1; L <= 32; L++) {
+    int cnt = 0;
+#pragma unroll
+    for (int t = 0; t < 5; t++) cnt += __popcll(__ballot(nz[t] && cs[t] == L));
+    if (lane == 0) s_bits[L] = cnt;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int p = 0;
+    for (int L = 1; L <= 32; L++) { s_bitpos[L] = p; p += s_bits[L]; }
+  }
+  __syncthreads();
+  // symbols sorted by (code length, symbol value); the pseudo-symbol is never listed
+  for (int L = 1; L <= 32; L++) {
+    int p = s_bitpos[L];
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+      const int s = lane + 64 * t;
+      const bool mine = nz[t] && cs[t] == L && s != 256;
+      const unsigned long long m = __ballot(mine);
+      if (mine) {
+        const int pos = p + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < 256) s_val[pos] = (unsigned char)s;
+      }
+      p += __popcll(m);
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int i, j;
+    for (i = 32; i > 16; i--) {
+      while (s_bits[i] > 0) {
+        j = i - 2;
+        while (s_bits[j] == 0) j--;
+        s_bits[i] -= 2; s_bits[i - 1]++; s_bits[j + 1] += 2; s_bits[j]--;
+      }
+    }
+    i = 16;
+    while (i > 0 && s_bits[i] == 0) i--;
+    if (i > 0) s_bits[i]--;
+    int code = 0, cum = 0;
+    s_cum[0] = 0;
+    for (int L = 1; L <= 16; L++) {
+      s_first[L] = code;
+      code = (code + s_bits[L]) << 1;
+      cum += s_bits[L];
+      s_cum[L] = cum;
+      T->bits[L] = (uint8_t)s_bits[L];
+    }
+    T->bits[0] = 0;
+    T->nsyms = (uint32_t)cum;
+  }
+  __syncthreads();
+  const int nsyms = s_cum[16];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int p = lane + 64 * t;
+    T->ehufsi[p] = 0;
+    T->ehufco[p] = 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int p = lane + 64 * t;
+    if (p < nsyms) {
+      int L = 1;
+      while (s_cum[L] <= p) L++;
+      const int sym = s_val[p];
+      T->huffval[p] = (uint8_t)sym;
+      T->ehufsi[sym] = (uint8_t)L;
+      T->ehufco[sym] = (uint16_t)(s_first[L] + (p - s_cum[L - 1]));
+    }
+  }
+}
+
+// =============================================================================================
+// K5  AC trellis quantization (row a9): quantize_trellis jcdctmgr.c:1120-1222 (+ norm/lambda
+// :1011-1037).  One lane = one block.  The rate-distortion DP only ever looks back at
+// positions whose chosen coefficient is non-zero, so each lane keeps a compact list of "live"
+// predecessors {position, accumulated zero distortion, accumulated cost, back pointer, value}
+// in LDS columns ([64 entries][64 lanes], bank = lane => conflict-free).  The zig-zag loop
+// index is wave-uniform, so quantizer steps / lambda weights come from scalar loads.
+// Float recipe T5 of SURVEY 9 is followed operation by operation; first-minimum ties resolve
+// in (predecessor, candidate) lexicographic order exactly as the reference's strict '<' scan.
+// T6: a position whose candidates all lack a Huffman code keeps a stale value in the
+// reference; such a position can never win (its cost is >= 1e38) and is zeroed by the
+// back-track, so it is simply not appended here.
+// =============================================================================================
+__global__ void __launch_bounds__(64)
+k_trellis_ac(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
+             int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
+             int4 ac_slot_of_comp, float *__restrict__ lambda_out)
+{
+  __shared__ float e_azd[64][64];
+  __shared__ float e_acc[64][64];
+  __shared__ unsigned e_pk[64][64];   // pos | from<<6 | (value & 0xFFFF) << 12
+  __shared__ unsigned char si[256];
+  const int comp = blockIdx.y, img = blockIdx.z;
+  const MjhComp cc = C.c[comp];
+  const int lane = threadIdx.x;
+  const int slot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
+  const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+#pragma unroll
+  for (int t = 0; t < 4; t++) si[lane + 64 * t] = T->ehufsi[lane + 64 * t];
+  __syncthreads();
+  const int blk = blockIdx.x * 64 + lane;
+  if (blk >= cc.nblk) return;
+  const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+  int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+  const uint16_t *qz = Q->q[cc.qtbl];
+  const float *rcp = Q->rcp8q[cc.qtbl];
+  const float *lt = Q->lambda_tbl[cc.qtbl];
+
+  // norm over the 63 AC coefficients in NATURAL index order (jcdctmgr.c:1027-1031)
+  float norm = 0.0f;
+#pragma unroll
+  for (int n = 1; n < 64; n++) {
+    const int x = uq[(size_t)kIZZ.v[n] * cc.kstride];
+    norm = norm + (float)(x * x);
+  }
+  norm = (float)((double)norm / 63.0);
+  float lambda;
+  if (C.lambda_log_scale2 > 0.0f) lambda = (float)(C.pow_scale1 * 1.0 / (C.pow_scale2 + (double)norm));
+  else lambda = (float)(C.pow_scale1 * 1.0);
+  lambda_out[(size_t)img * C.total_real_blocks + cc.blk_off + blk] = lambda;
+
+  const int si_f0 = si[0xF0], si_eob = si[0];
+  int nlive = 1;
+  e_azd[0][lane] = 0.0f;
+  e_acc[0][lane] = 0.0f;
+  e_pk[0][lane] = 0u;
+  float azd_prev = 0.0f;
+  for (int i = 1; i < 64; i++) {
+    const int xs = uq[(size_t)i * cc.kstride];
+    const int x = xs < 0 ? -xs : xs;
+    const int dq = 8 * (int)qz[i];
+    float t = (float)(x * x) * lambda;
+    t = t * lt[i];
+    const float azd_cur = t + azd_prev;
+    int qval = udiv_exact(x + (dq >> 1), dq, rcp[i]);
+    if (qval != 0) {
+      if (qval >= 1024) qval = 1023;
+      const int ncd = bitlen((unsigned)qval);
+      float best = 1e38f;
+      int beste = -1, bestv = 0;
+      for (int k = 0; k < ncd; k++) {
+        const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
+        const int delta = cand * dq - x;
+        float dist = (float)(delta * delta) * lambda;
+        dist = dist * lt[i];
+        for (int e = 0; e < nlive; e++) {
+          const int pos = (int)(e_pk[e][lane] & 63u);
+          const int zero_run = i - 1 - pos;
+          const int hi = zero_run >> 4;
+          if (hi && si_f0 == 0) continue;
+          const int cb = si[16 * (zero_run & 15) + k + 1];
+          if (cb == 0) continue;
+          const int rate = cb + (k + 1) + hi * si_f0;
+          float cost = (float)rate + dist;
+          float rhs = azd_prev - e_azd[e][lane];
+          rhs = rhs + e_acc[e][lane];
+          cost = cost + rhs;
+          if (cost < best || (cost == best && e < beste)) { best = cost; beste = e; bestv = cand; }
+        }
+      }
+      if (beste >= 0) {
+        const int v = xs < 0 ? -bestv : bestv;
+        e_azd[nlive][lane] = azd_cur;
+        e_acc[nlive][lane] = best;
+        e_pk[nlive][lane] = (unsigned)i | ((unsigned)beste << 6) | (((unsigned)v & 0xFFFFu) << 12);
+        nlive++;
+      }
+    }
+    azd_prev = azd_cur;
+  }
+  // end-of-block choice (jcdctmgr.c:1187-1207); azd_prev == accumulated_zero_dist[63]
+  float best_cost = azd_prev + (float)si_eob;
+  int last = 0;
+  for (int e = 1; e < nlive; e++) {
+    float cost = e_acc[e][lane] + azd_prev;
+    cost = cost - e_azd[e][lane];
+    if ((int)(e_pk[e][lane] & 63u) < 63) cost = cost + (float)si_eob;
+    if (cost < best_cost) { best_cost = cost; last = e; }
+  }
+  // back-track (jcdctmgr.c:1211-1222) fused with the store of the 63 AC planes
+  int cur = last;
+  unsigned pk = e_pk[cur][lane];
+  for (int k = 63; k >= 1; k--) {
+    int v = 0;
+    if (cur != 0 && (int)(pk & 63u) == k) {
+      v = (int)(int16_t)(pk >> 12);
+      cur = (int)((pk >> 6) & 63u);
+      pk = e_pk[cur][lane];
+    }
+    qo[(size_t)k * cc.kstride] = (int16_t)v;
+  }
+}
+
+// =============================================================================================
+// K6  DC trellis (row a9, DC part): quantize_trellis jcdctmgr.c:1044-1118 + :1308-1327, driven
+// per iMCU row by compress_trellis_pass jccoefct.c:418-441 (lastDC = 0 at the start of each
+// iMCU row, chained over its v_samp_factor block rows).
+// The Viterbi recursion along a block row is strictly sequential in float (no associativity),
+// so the parallelism is: one 16-lane group per (image, component, iMCU row) chain, lane = the
+// candidate k (<= 9 live), the 9 predecessor costs come over cross-lane shuffles.  Back
+// pointers go to a byte scratch array (16 B per block, one coalesced store per group) and the
+// back-track walks 16 blocks per step with shuffles instead of dependent global loads.
+// =============================================================================================
+__device__ __forceinline__ int grp_shfl(int v, int srclane_in_group, int lane)
+{
+  return __shfl(v, (lane & ~15) | srclane_in_group, 64);
+}
+__device__ __forceinline__ float grp_shfl_f(float v, int srclane_in_group, int lane)
+{
+  return __shfl(v, (lane & ~15) | srclane_in_group, 64);
+}
+
+__global__ void __launch_bounds__(64)
+k_trellis_dc(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
+             int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
+             int4 dc_slot_of_comp, const float *__restrict__ lambda_in, uint8_t *__restrict__ back)
+{
+  const int img = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int k = lane & 15;
+  const int chain = blockIdx.x * 4 + (lane >> 4);
+  const int nchains = C.ncomp * C.mcu_rows;
+  if (chain >= nchains) return;   // whole 16-lane groups leave together
+  const int comp = chain / C.mcu_rows, imcu = chain - comp * C.mcu_rows;
+  const MjhComp cc = C.c[comp];
+  const int slot = comp == 0 ? dc_slot_of_comp.x : comp == 1 ? dc_slot_of_comp.y : comp == 2 ? dc_slot_of_comp.z : dc_slot_of_comp.w;
+  const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+  unsigned long long dsi = 0;   // 12 DC code lengths, 5 bits each
+  for (int s = 0; s < 12; s++) dsi |= (unsigned long long)(T->ehufsi[s] & 31) << (5 * s);
+  const int q0 = Q->q[cc.qtbl][0];
+  const int dq = 8 * q0;
+  const float rcp = Q->rcp8q[cc.qtbl][0];
+  const float lt0 = Q->lambda_tbl[cc.qtbl][0];
+  int ncand = (2 + 60 / q0) | 1;                 // get_num_dc_trellis_candidates :930-933
+  if (ncand > 9) ncand = 9;
+  const int16_t *uq0 = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off;  // plane k = 0
+  int16_t *qo0 = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;
+  const float *lam = lambda_in + (size_t)img * C.total_real_blocks + cc.blk_off;
+  uint8_t *bk = back + ((size_t)img * C.total_real_blocks + cc.blk_off) * 16;
+  const bool live = k < ncand;
+  int last_dc = 0;
+  for (int sub = 0; sub < cc.v; sub++) {
+    const int br = imcu * cc.v + sub;
+    if (br >= cc.hib) break;
+    const int row0 = br * cc.wib;
+    int prev_c = 0;
+    float prev_cost = 0.0f;
+    for (int bi = 0; bi < cc.wib; bi++) {
+      const int xs = uq0[row0 + bi];
+      const float lambda_dc = lam[row0 + bi] * lt0;
+      const int x = xs < 0 ? -xs : xs;
+      const int qval = udiv_exact(x + (dq >> 1), dq, rcp);
+      int cnd = qval - ncand / 2 + k;
+      cnd = min(1023, max(-1023, cnd));
+      const int delta = cnd * dq - x;
+      const float dist = (float)(delta * delta) * lambda_dc;
+      if (xs < 0) cnd = -cnd;
+      float best;
+      int bb = 0;
+      if (bi == 0) {
+        const int df = cnd - last_dc;
+        const int bits = bitlen((unsigned)(df < 0 ? -df : df));
+        best = (float)(bits + (int)((dsi >> (5 * bits)) & 31)) + dist;
+      } else {
+        best = 0.0f;
+        for (int l = 0; l < ncand; l++) {
+          const int pc = grp_shfl(prev_c, l, lane);
+          const float pcost = grp_shfl_f(prev_cost, l, lane);
+          const int df = cnd - pc;
+          const int bits = bitlen((unsigned)(df < 0 ? -df : df));
+          float cost = (float)(bits + (int)((dsi >> (5 * bits)) & 31)) + dist;
+          cost = cost + pcost;
+          if (l == 0 || cost < best) { best = cost; bb = l; }
+        }
+      }
+      prev_c = cnd;
+      prev_cost = best;
+      bk[(size_t)(row0 + bi) * 16 + k] = (uint8_t)bb;
+    }
+    // first minimum over the live candidates (:1309-1313)
+    int j = 0;
+    {
+      float bc = grp_shfl_f(prev_cost, 0, lane);
+      for (int l = 1; l < ncand; l++) {
+        const float c = grp_shfl_f(prev_cost, l, lane);
+        if (c < bc) { bc = c; j = l; }
+      }
+    }
+    __threadfence_block();
+    // back-track, 16 blocks per step: lane k owns block top-k
+    for (int top = cc.wib - 1; top >= 0; top -= 16) {
+      const int b = top - k;
+      int qv = 0, neg = 0;
+      uint4 w = make_uint4(0, 0, 0, 0);
+      if (b >= 0) {
+        const int xs = uq0[row0 + b];
+        const int x = xs < 0 ? -xs : xs;
+        neg = xs < 0;
+        qv = udiv_exact(x + (dq >> 1), dq, rcp);
+        w = *reinterpret_cast<const uint4 *>(bk + (size_t)(row0 + b) * 16);
+      }
+      int myj = 0;
+      const int steps = min(16, top + 1);
+      for (int s = 0; s < steps; s++) {
+        if (k == s) myj = j;
+        const unsigned word = j < 4 ? w.x : (j < 8 ? w.y : w.z);
+        const int nj = (int)((word >> (8 * (j & 3))) & 0xFF);
+        j = grp_shfl(nj, s, lane);
+      }
+      if (b >= 0) {
+        int cnd = qv - ncand / 2 + myj;
+        cnd = min(1023, max(-1023, cnd));
+        if (neg) cnd = -cnd;
+        qo0[row0 + b] = (int16_t)cnd;
+        if (b == cc.wib - 1) last_dc = cnd;
+      }
+    }
+    last_dc = grp_shfl(last_dc, 0, lane);  // owner of block wib-1 is lane 0 of the first step
+    __threadfence_block();
+    (void)live;
+  }
+}
+
+// =============================================================================================
+// K7  Huffman bit packing of the interleaved baseline scan (row a12): encode_one_block
+// jchuff.c:563-652, encode_mcu_huff :693-763, flush_bits :479-514 (pad with 1-bits),
+// byte stuffing :354-387.  Three steps, all one lane per block:
+//   k_enc_len   : bits of every block (dummy blocks included) -> len16[mcu-order position]
+//   (scan)      : k_chunk_sums / k_scan_sums / k_offsets: exclusive prefix sum -> bit offset
+//   k_enc_write : re-walk the block and OR its bits into the (zeroed) unstuffed bit stream
+// then the 0xFF -> 0xFF00 stuffing is a second count/scan/scatter over the byte stream.
+// =============================================================================================
+struct EncTables {
+  const MjhHuffTable *dc;
+  const MjhHuffTable *ac;
+};
+
+__device__ __forceinline__ int mcu_position(const MjhConst &C, const MjhComp &cc, int r, int c)
+{
+  const int m = (r / cc.v) * C.mcus_per_row + c / cc.h;
+  return m * C.blocks_per_mcu + cc.mcu_blk0 + (r % cc.v) * cc.h + (c % cc.h);
+}
+
+__global__ void __launch_bounds__(256)
+k_enc_len(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs,
+          int slots_per_image, int4 dc_slot_of_comp, int4 ac_slot_of_comp, uint16_t *__restrict__ len16)
+{
+  __shared__ unsigned char s_ac[256];
+  __shared__ unsigned char s_dc[16];
+  const int comp = blockIdx.y, img = blockIdx.z;
+  const MjhComp cc = C.c[comp];
+  const int tid = threadIdx.x;
+  const int dslot = comp == 0 ? dc_slot_of_comp.x : comp == 1 ? dc_slot_of_comp.y : comp == 2 ? dc_slot_of_comp.z : dc_slot_of_comp.w;
+  const int aslot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
+  const MjhHuffTable *TD = tabs + (size_t)img * slots_per_image + dslot;
+  const MjhHuffTable *TA = tabs + (size_t)img * slots_per_image + aslot;
+  s_ac[tid] = TA->ehufsi[tid];
+  if (tid < 16) s_dc[tid] = TD->ehufsi[tid];
+  __syncthreads();
+  const int t = blockIdx.x * 256 + tid;
+  if (t >= cc.wpad * cc.hpad) return;
+  const int r = t / cc.wpad, c = t - r * cc.wpad;
+  const int16_t *q = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;
+  const int dc = q[dc_source_block(cc, r, c)];
+  int pr, pc, pred = 0;
+  if (mcu_prev_block(C, cc, r, c, pr, pc)) pred = q[dc_source_block(cc, pr, pc)];
+  const int df = dc - pred;
+  int nb = bitlen((unsigned)(df < 0 ? -df : df));
+  int bits = s_dc[nb] + nb;
+  if (r < cc.hib && c < cc.wib) {
+    const int16_t *qb = q + r * cc.wib + c;
+    int run = 0;
+    for (int k = 1; k < 64; k++) {
+      const int v = qb[(size_t)k * cc.kstride];
+      if (v == 0) { run++; continue; }
+      bits += (run >> 4) * s_ac[0xF0];
+      nb = bitlen((unsigned)(v < 0 ? -v : v));
+      bits += s_ac[((run & 15) << 4) + nb] + nb;
+      run = 0;
+    }
+    if (run > 0) bits += s_ac[0];
+  } else {
+    bits += s_ac[0];
+  }
+  len16[(size_t)img * C.total_mcu_blocks + mcu_position(C, cc, r, c)] = (uint16_t)bits;
+}
+
+// ---- generic 32-bit exclusive scan over n items per image, items produced by a functor ----
+// chunk = 2048 items (256 threads x 8)
+#define SCAN_CHUNK 2048
+
+__device__ __forceinline__ unsigned block_reduce_256(unsigned v, unsigned *sh)
+{
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  const unsigned tot = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return tot;
+}
+
+// exclusive scan of one value per thread within a 256-thread block; returns exclusive prefix
+__device__ __forceinline__ unsigned block_excl_scan_256(unsigned v, unsigned *sh, unsigned *total)
+{
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned n = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += n;
+  }
+  if (lane == 63) sh[w] = inc;
+  __syncthreads();
+  unsigned base = 0;
+  for (int i = 0; i < w; i++) base += sh[i];
+  const unsigned tot = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  if (total) *total = tot;
+  return base + inc - v;
+}
+
+__global__ void __launch_bounds__(256)
+k_chunk_sums_u16(const uint16_t *__restrict__ len16, int n_per_image, unsigned *__restrict__ sums, int chunks_per_image)
+{
+  __shared__ unsigned sh[4];
+  const int img = blockIdx.y, chunk = blockIdx.x;
+  const uint16_t *p = len16 + (size_t)img * n_per_image;
+  unsigned s = 0;
+  const int base = chunk * SCAN_CHUNK + threadIdx.x * 8;
+#pragma unroll
+  for (int i = 0; i < 8; i++) if (base + i < n_per_image) s += p[base + i];
+  const unsigned tot = block_reduce_256(s, sh);
+  if (threadIdx.x == 0) sums[(size_t)img * chunks_per_image + chunk] = tot;
+}
+
+// one workgroup per image: exclusive scan of the chunk sums in place; total -> totals[img]
+__global__ void __launch_bounds__(256)
+k_scan_sums(unsigned *__restrict__ sums, int chunks_per_image, unsigned *__restrict__ totals)
+{
+  __shared__ unsigned sh[4];
+  const int img = blockIdx.x;
+  unsigned *p = sums + (size_t)img * chunks_per_image;
+  unsigned carry = 0;
+  for (int base = 0; base < chunks_per_image; base += 256) {
+    const int i = base + threadIdx.x;
+    const unsigned v = i < chunks_per_image ? p[i] : 0u;
+    unsigned tot;
+    const unsigned ex = block_excl_scan_256(v, sh, &tot);
+    if (i < chunks_per_image) p[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) totals[img] = carry;
+}
+
+__global__ void __launch_bounds__(256)
+k_offsets_u16(const uint16_t *__restrict__ len16, int n_per_image, const unsigned *__restrict__ sums,
+              int chunks_per_image, unsigned *__restrict__ off32)
+{
+  __shared__ unsigned sh[4];
+  const int img = blockIdx.y, chunk = blockIdx.x;
+  const uint16_t *p = len16 + (size_t)img * n_per_image;
+  unsigned *o = off32 + (size_t)img * n_per_image;
+  const int base = chunk * SCAN_CHUNK + threadIdx.x * 8;
+  unsigned v[8], s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { v[i] = base + i < n_per_image ? p[base + i] : 0u; s += v[i]; }
+  unsigned ex = block_excl_scan_256(s, sh, nullptr) + sums[(size_t)img * chunks_per_image + chunk];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { if (base + i < n_per_image) o[base + i] = ex; ex += v[i]; }
+}
+
+// bit writer: ORs big-endian bit strings into a zero-initialised word array
+struct BitWriter {
+  unsigned *words;       // stream base (32-bit words, bytes are big-endian inside the stream)
+  unsigned long long acc;
+  int nacc;              // valid bits in acc (low end)
+  unsigned widx;
+  __device__ __forceinline__ void init(unsigned *w, unsigned bitoff) { words = w; widx = bitoff >> 5; nacc = (int)(bitoff & 31); acc = 0; }
+  __device__ __forceinline__ void put(unsigned code, int n)
+  {
+    acc = (acc << n) | (unsigned long long)(code & ((1u << n) - 1u));
+    nacc += n;
+    if (nacc >= 32) {
+      const unsigned w = (unsigned)(acc >> (nacc - 32));
+      atomicOr(&words[widx], __builtin_bswap32(w));
+      widx++;
+      nacc -= 32;
+    }
+  }
+  __device__ __forceinline__ void flush()
+  {
+    if (nacc > 0) {
+      const unsigned w = (unsigned)(acc << (32 - nacc));
+      atomicOr(&words[widx], __builtin_bswap32(w));
+    }
+  }
+};
+
+__global__ void __launch_bounds__(256)
+k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs,
+            int slots_per_image, int4 dc_slot_of_comp, int4 ac_slot_of_comp,
+            const unsigned *__restrict__ off32, unsigned *__restrict__ stream, size_t stream_words_per_image)
+{
+  __shared__ unsigned s_ac[256];   // size << 16 | code
+  __shared__ unsigned s_dc[16];
+  const int comp = blockIdx.y, img = blockIdx.z;
+  const MjhComp cc = C.c[comp];
+  const int tid = threadIdx.x;
+  const int dslot = comp == 0 ? dc_slot_of_comp.x : comp == 1 ? dc_slot_of_comp.y : comp == 2 ? dc_slot_of_comp.z : dc_slot_of_comp.w;
+  const int aslot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
+  const MjhHuffTable *TD = tabs + (size_t)img * slots_per_image + dslot;
+  const MjhHuffTable *TA = tabs + (size_t)img * slots_per_image + aslot;
+  s_ac[tid] = ((unsigned)TA->ehufsi[tid] << 16) | TA->ehufco[tid];
+  if (tid < 16) s_dc[tid] = ((unsigned)TD->ehufsi[tid] << 16) | TD->ehufco[tid];
+  __syncthreads();
+  const int t = blockIdx.x * 256 + tid;
+  if (t >= cc.wpad * cc.hpad) return;
+  const int r = t / cc.wpad, c = t - r * cc.wpad;
+  const int16_t *q = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;
+  const int dc = q[dc_source_block(cc, r, c)];
+  int pr, pc, pred = 0;
+  if (mcu_prev_block(C, cc, r, c, pr, pc)) pred = q[dc_source_block(cc, pr, pc)];
+  BitWriter bw;
+  bw.init(stream + (size_t)img * stream_words_per_image,
+          off32[(size_t)img * C.total_mcu_blocks + mcu_position(C, cc, r, c)]);
+  {
+    const int df = dc - pred;
+    const int a = df < 0 ? -df : df;
+    const int nb = bitlen((unsigned)a);
+    const unsigned e = s_dc[nb];
+    bw.put(e & 0xFFFF, (int)(e >> 16));
+    if (nb) bw.put((unsigned)(df < 0 ? df - 1 : df), nb);
+  }
+  if (r < cc.hib && c < cc.wib) {
+    const int16_t *qb = q + r * cc.wib + c;
+    int run = 0;
+    for (int k = 1; k < 64; k++) {
+      const int v = qb[(size_t)k * cc.kstride];
+      if (v == 0) { run++; continue; }
+      while (run > 15) { const unsigned e = s_ac[0xF0]; bw.put(e & 0xFFFF, (int)(e >> 16)); run -= 16; }
+      const int a = v < 0 ? -v : v;
+      const int nb = bitlen((unsigned)a);
+      const unsigned e = s_ac[(run << 4) + nb];
+      bw.put(e & 0xFFFF, (int)(e >> 16));
+      bw.put((unsigned)(v < 0 ? v - 1 : v), nb);
+      run = 0;
+    }
+    if (run > 0) { const unsigned e = s_ac[0]; bw.put(e & 0xFFFF, (int)(e >> 16)); }
+  } else {
+    const unsigned e = s_ac[0];
+    bw.put(e & 0xFFFF, (int)(e >> 16));
+  }
+  bw.flush();
+}
+
+// ---- header + stuffing + trailer -------------------------------------------------------------
+
+// One workgroup per image: [prefix: SOI APP0 DQT SOF] [DHT...] [SOS] -> out, hdr_len.
+// emit_multi_dht jcmarker.c:293-401 (max-compression profile: ONE DHT marker holding every table
+// the scan needs, in component order) / emit_dht :257-290 (fastest profile: one marker per table).
+__global__ void __launch_bounds__(64)
+k_header(const uint8_t *__restrict__ prefix, int prefix_len, const uint8_t *__restrict__ sos, int sos_len,
+         const MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 dht_slots, int4 dht_ids, int ndht,
+         int multi_dht, uint8_t *__restrict__ out, size_t out_stride, MjhImageMeta *__restrict__ meta)
+{
+  const int img = blockIdx.x;
+  const int lane = threadIdx.x;
+  uint8_t *o = out + (size_t)img * out_stride;
+  for (int i = lane; i < prefix_len; i += 64) o[i] = prefix[i];
+  int pos = prefix_len;
+  const int slots[4] = { dht_slots.x, dht_slots.y, dht_slots.z, dht_slots.w };
+  const int ids[4] = { dht_ids.x, dht_ids.y, dht_ids.z, dht_ids.w };
+  if (multi_dht) {
+    int length = 2;
+    for (int i = 0; i < ndht; i++) length += (int)tabs[(size_t)img * slots_per_image + slots[i]].nsyms + 17;
+    if (lane == 0) { o[pos] = 0xFF; o[pos + 1] = 0xC4; o[pos + 2] = (uint8_t)(length >> 8); o[pos + 3] = (uint8_t)length; }
+    pos += 4;
+  }
+  for (int i = 0; i < ndht; i++) {
+    const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slots[i];
+    const int n = (int)T->nsyms;
+    if (!multi_dht) {
+      const int length = n + 2 + 1 + 16;
+      if (lane == 0) { o[pos] = 0xFF; o[pos + 1] = 0xC4; o[pos + 2] = (uint8_t)(length >> 8); o[pos + 3] = (uint8_t)length; }
+      pos += 4;
+    }
+    if (lane == 0) o[pos] = (uint8_t)ids[i];
+    if (lane < 16) o[pos + 1 + lane] = T->bits[lane + 1];
+    for (int j = lane; j < n; j += 64) o[pos + 17 + j] = T->huffval[j];
+    pos += 17 + n;
+  }
+  for (int i = lane; i < sos_len; i += 64) o[pos + i] = sos[i];
+  pos += sos_len;
+  if (lane == 0) meta[img].hdr_len = (unsigned)pos;
+}
+
+// after the bit offsets are known: pad the last partial byte with 1-bits (jchuff.c:505-514)
+__global__ void __launch_bounds__(64)
+k_finish_bits(const unsigned *__restrict__ totals, unsigned *__restrict__ stream, size_t stream_words_per_image,
+              MjhImageMeta *__restrict__ meta, int nimg)
+{
+  const int img = blockIdx.x * 64 + threadIdx.x;
+  if (img >= nimg) return;
+  const unsigned tb = totals[img];
+  meta[img].total_bits = tb;
+  if (tb & 7) {
+    const unsigned padbits = 8 - (tb & 7);
+    const unsigned bitpos = tb & 31;
+    // the pad occupies bits [bitpos, bitpos+padbits) of big-endian word tb>>5
+    const unsigned w = (((1u << padbits) - 1u) << (32 - bitpos - padbits));
+    atomicOr(&stream[(size_t)img * stream_words_per_image + (tb >> 5)], __builtin_bswap32(w));
+  }
+}
+
+// number of 0xFF bytes per 4-byte word -> chunk sums (chunk = 2048 words)
+__device__ __forceinline__ unsigned ff_count(unsigned w)
+{
+  // bytes equal to 0xFF: (w & (w>>1) & ... ) trick via per-byte compare
+  unsigned c = 0;
+  c += ((w & 0xFFu) == 0xFFu);
+  c += ((w & 0xFF00u) == 0xFF00u);
+  c += ((w & 0xFF0000u) == 0xFF0000u);
+  c += ((w & 0xFF000000u) == 0xFF000000u);
+  return c;
+}
+
+__global__ void __launch_bounds__(256)
+k_ff_chunk_sums(const unsigned *__restrict__ stream, size_t stream_words_per_image, const unsigned *__restrict__ totals,
+                unsigned *__restrict__ sums, int chunks_per_image)
+{
+  __shared__ unsigned sh[4];
+  const int img = blockIdx.y, chunk = blockIdx.x;
+  const unsigned nbytes = (totals[img] + 7) >> 3;
+  const unsigned nwords = (nbytes + 3) >> 2;
+  const unsigned *p = stream + (size_t)img * stream_words_per_image;
+  unsigned s = 0;
+  const unsigned base = chunk * SCAN_CHUNK + threadIdx.x * 8;
+#pragma unroll
+  for (int i = 0; i < 8; i++) if (base + i < nwords) s += ff_count(p[base + i]);  // bytes past nbytes are zero
+  const unsigned tot = block_reduce_256(s, sh);
+  if (threadIdx.x == 0) sums[(size_t)img * chunks_per_image + chunk] = tot;
+}
+
+__global__ void __launch_bounds__(256)
+k_stuff_write(const unsigned *__restrict__ stream, size_t stream_words_per_image, const unsigned *__restrict__ totals,
+              const unsigned *__restrict__ sums, int chunks_per_image, const unsigned *__restrict__ ff_totals,
+              uint8_t *__restrict__ out, size_t out_stride, MjhImageMeta *__restrict__ meta, unsigned *__restrict__ sizes)
+{
+  __shared__ unsigned sh[4];
+  const int img = blockIdx.y, chunk = blockIdx.x;
+  const unsigned nbytes = (totals[img] + 7) >> 3;
+  const unsigned nwords = (nbytes + 3) >> 2;
+  const unsigned *p = stream + (size_t)img * stream_words_per_image;
+  const unsigned hdr = meta[img].hdr_len;
+  uint8_t *o = out + (size_t)img * out_stride + hdr;
+  const unsigned base = chunk * SCAN_CHUNK + threadIdx.x * 8;
+  unsigned w[8], s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { w[i] = base + i < nwords ? p[base + i] : 0u; s += ff_count(w[i]); }
+  unsigned ex = block_excl_scan_256(s, sh, nullptr) + sums[(size_t)img * chunks_per_image + chunk];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const unsigned wi = base + i;
+    if (wi < nwords) {
+      unsigned dst = wi * 4 + ex;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const unsigned byte = (w[i] >> (8 * b)) & 0xFF;   // little-endian word = stream byte order
+        if (wi * 4 + b < nbytes) {
+          o[dst++] = (uint8_t)byte;
+          if (byte == 0xFF) { o[dst++] = 0; ex++; }
+        }
+      }
+    }
+  }
+  if (chunk == 0 && threadIdx.x == 0) {
+    const unsigned stuffed = nbytes + ff_totals[img];
+    o[stuffed] = 0xFF;       // EOI, write_file_trailer jcmarker.c:791
+    o[stuffed + 1] = 0xD9;
+    meta[img].stuffed_len = stuffed;
+    meta[img].file_len = hdr + stuffed + 2;
+    sizes[img] = hdr + stuffed + 2;
+  }
+}
+
+// =============================================================================================
+// host-callable launch wrappers (C++ linkage, used by mjh_encoder.cpp)
+// =============================================================================================
+#include "mjh_launch.h"
+
+static inline dim3 g3(unsigned x, unsigned y, unsigned z) { return dim3(x, y, z); }
+
+void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size_t img_stride, void *planes, int n, hipStream_t s)
+{
+  dim3 grid((C.groups_x + 255) / 256, C.groups_y, n);
+  const int H0 = C.maxh, V0 = C.maxv;
+#define LC(h, v) hipLaunchKernelGGL((k_color<h, v>), grid, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint8_t *)planes)
+  if (H0 == 2 && V0 == 2) LC(2, 2);
+  else if (H0 == 2 && V0 == 1) LC(2, 1);
+  else if (H0 == 1 && V0 == 2) LC(1, 2);
+  else LC(1, 1);
+#undef LC
+}
+
+static int max_nblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp; i++) m = C.c[i].nblk > m ? C.c[i].nblk : m; return m; }
+static int max_padblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp; i++) { int v = C.c[i].wpad * C.c[i].hpad; m = v > m ? v : m; } return m; }
+
+void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, int n, hipStream_t s)
+{
+  dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
+  hipLaunchKernelGGL(k_dct_quant, grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q);
+}
+
+void mjh_launch_stats_ac(const MjhConst &C, const void *q, MjhHuffTable *tabs, int spi, const int slot[4], int count_dummies, int n, hipStream_t s)
+{
+  dim3 grid((max_nblk(C) + 255) / 256, C.ncomp, n);
+  hipLaunchKernelGGL(k_stats_ac, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, make_int4(slot[0], slot[1], slot[2], slot[3]), count_dummies);
+}
+
+void mjh_launch_stats_dc(const MjhConst &C, const void *q, MjhHuffTable *tabs, int spi, const int slot[4], int mcu_order, const int comp_restart[4], int n, hipStream_t s)
+{
+  const int4 sl = make_int4(slot[0], slot[1], slot[2], slot[3]);
+  const int4 cr = make_int4(comp_restart[0], comp_restart[1], comp_restart[2], comp_restart[3]);
+  if (mcu_order) {
+    dim3 grid((max_padblk(C) + 255) / 256, C.ncomp, n);
+    hipLaunchKernelGGL((k_stats_dc<1>), grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, sl, cr);
+  } else {
+    dim3 grid((max_nblk(C) + 255) / 256, C.ncomp, n);
+    hipLaunchKernelGGL((k_stats_dc<0>), grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, sl, cr);
+  }
+}
+
+void mjh_launch_gen_tables(MjhHuffTable *tabs, int spi, const int *slots, int nslots, int n, hipStream_t s)
+{
+  int sl[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  for (int i = 0; i < nslots && i < 8; i++) sl[i] = slots[i];
+  hipLaunchKernelGGL(k_gen_tables, dim3(nslots, n), dim3(64), 0, s, tabs, spi, make_int4(sl[0], sl[1], sl[2], sl[3]), make_int4(sl[4], sl[5], sl[6], sl[7]));
+}
+
+void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], float *lambda, int n, hipStream_t s)
+{
+  dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
+  hipLaunchKernelGGL(k_trellis_ac, grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]), lambda);
+}
+
+void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s)
+{
+  const int nchains = C.ncomp * C.mcu_rows;
+  dim3 grid((nchains + 3) / 4, n);
+  hipLaunchKernelGGL(k_trellis_dc, grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]), lambda, (uint8_t *)back);
+}
+
+void mjh_launch_encode(const MjhConst &C, const void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const int ac_slot[4],
+                       void *len16, void *off32, unsigned *sums, int chunks_per_image, unsigned *totals,
+                       unsigned *stream, size_t stream_words_per_image, void *meta, int n, hipStream_t s)
+{
+  const int4 ds = make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]);
+  const int4 as = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
+  dim3 grid((max_padblk(C) + 255) / 256, C.ncomp, n);
+  hipLaunchKernelGGL(k_enc_len, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, ds, as, (uint16_t *)len16);
+  hipLaunchKernelGGL(k_chunk_sums_u16, dim3(chunks_per_image, n), dim3(256), 0, s, (const uint16_t *)len16, C.total_mcu_blocks, sums, chunks_per_image);
+  hipLaunchKernelGGL(k_scan_sums, dim3(n), dim3(256), 0, s, sums, chunks_per_image, totals);
+  hipLaunchKernelGGL(k_offsets_u16, dim3(chunks_per_image, n), dim3(256), 0, s, (const uint16_t *)len16, C.total_mcu_blocks, sums, chunks_per_image, (unsigned *)off32);
+  hipLaunchKernelGGL(k_enc_write, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image);
+  hipLaunchKernelGGL(k_finish_bits, dim3((n + 63) / 64), dim3(64), 0, s, totals, stream, stream_words_per_image, (MjhImageMeta *)meta, n);
+}
+
+void mjh_launch_header(const void *prefix, int prefix_len, const void *sos, int sos_len, const MjhHuffTable *tabs, int spi,
+                       const int dht_slots[4], const int dht_ids[4], int ndht, int multi_dht, void *out, size_t out_stride, void *meta, int n, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_header, dim3(n), dim3(64), 0, s, (const uint8_t *)prefix, prefix_len, (const uint8_t *)sos, sos_len, tabs, spi,
+                     make_int4(dht_slots[0], dht_slots[1], dht_slots[2], dht_slots[3]), make_int4(dht_ids[0], dht_ids[1], dht_ids[2], dht_ids[3]),
+                     ndht, multi_dht, (uint8_t *)out, out_stride, (MjhImageMeta *)meta);
+}
+
+void mjh_launch_stuff(const unsigned *stream, size_t stream_words_per_image, const unsigned *totals, unsigned *ffsums, int ff_chunks_per_image,
+                      unsigned *ff_totals, void *out, size_t out_stride, void *meta, unsigned *sizes, int n, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_ff_chunk_sums, dim3(ff_chunks_per_image, n), dim3(256), 0, s, stream, stream_words_per_image, totals, ffsums, ff_chunks_per_image);
+  hipLaunchKernelGGL(k_scan_sums, dim3(n), dim3(256), 0, s, ffsums, ff_chunks_per_image, ff_totals);
+  hipLaunchKernelGGL(k_stuff_write, dim3(ff_chunks_per_image, n), dim3(256), 0, s, stream, stream_words_per_image, totals, ffsums, ff_chunks_per_image,
+                     ff_totals, (uint8_t *)out, out_stride, (MjhImageMeta *)meta, sizes);
+}

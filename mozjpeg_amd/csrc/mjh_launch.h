@@ -1,0 +1,21 @@
+// mjh_launch.h -- host-callable launch wrappers implemented in mjh_kernels.hip
+#ifndef MJH_LAUNCH_H
+#define MJH_LAUNCH_H
+#include <hip/hip_runtime.h>
+#include "mjh_internal.h"
+
+void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size_t img_stride, void *planes, int n, hipStream_t s);
+void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, int n, hipStream_t s);
+void mjh_launch_stats_ac(const MjhConst &C, const void *q, MjhHuffTable *tabs, int spi, const int slot[4], int count_dummies, int n, hipStream_t s);
+void mjh_launch_stats_dc(const MjhConst &C, const void *q, MjhHuffTable *tabs, int spi, const int slot[4], int mcu_order, const int comp_restart[4], int n, hipStream_t s);
+void mjh_launch_gen_tables(MjhHuffTable *tabs, int spi, const int *slots, int nslots, int n, hipStream_t s);
+void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], float *lambda, int n, hipStream_t s);
+void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s);
+void mjh_launch_encode(const MjhConst &C, const void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const int ac_slot[4],
+                       void *len16, void *off32, unsigned *sums, int chunks_per_image, unsigned *totals,
+                       unsigned *stream, size_t stream_words_per_image, void *meta, int n, hipStream_t s);
+void mjh_launch_header(const void *prefix, int prefix_len, const void *sos, int sos_len, const MjhHuffTable *tabs, int spi,
+                       const int dht_slots[4], const int dht_ids[4], int ndht, int multi_dht, void *out, size_t out_stride, void *meta, int n, hipStream_t s);
+void mjh_launch_stuff(const unsigned *stream, size_t stream_words_per_image, const unsigned *totals, unsigned *ffsums, int ff_chunks_per_image,
+                      unsigned *ff_totals, void *out, size_t out_stride, void *meta, unsigned *sizes, int n, hipStream_t s);
+#endif
