@@ -45,5 +45,26 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_shim(force=False, verbose=False):
+    """libjpeg drop-in entry points (jpeg_start_compress / jpeg_write_scanlines /
+    jpeg_finish_compress) on top of the batch encoder.  It is compiled against the libjpeg headers
+    of the tree it drops into (struct jpeg_compress_struct is ABI), so it is only built where
+    /root/reference (and the generated config headers under oracle/_ref/include) exist."""
+    src = os.path.join(CSRC, "jpeg_shim.c")
+    ref = os.environ.get("MOZJPEG_REFERENCE", "/root/reference")
+    cfg = os.path.join(HERE, "..", "oracle", "_ref", "include")
+    if not (os.path.exists(src) and os.path.exists(os.path.join(ref, "jpeglib.h")) and os.path.exists(cfg)):
+        if verbose:
+            print("shim: reference headers not present, keeping prebuilt", SHIM if os.path.exists(SHIM) else "(none)")
+        return SHIM if os.path.exists(SHIM) else None
+    if force or _newer(SHIM, [src, LIB]):
+        cmd = ["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-I" + cfg, "-I" + ref, "-I" + os.path.join(HERE, "..", "include"),
+               "-o", SHIM, src, "-L" + HERE, "-l:libmozjpeg_hip.so", "-Wl,-rpath,$ORIGIN", "-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return SHIM
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

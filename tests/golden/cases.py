@@ -1,0 +1,58 @@
+"""Fixture images and switch sets shared by the golden generator and the tests."""
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def images():
+    import oracle_lib as O
+    big = O.synthetic_frame(640, 480, 1234)
+    rng = np.random.default_rng(7)
+    edge = np.zeros((64, 80, 3), np.uint8)
+    edge[:, :40] = 255
+    edge[20:40, 50:70] = (255, 0, 0)
+    return {
+        "testorig": O.read_ppm(os.path.join(HERE, "testorig.ppm")),   # the reference's own test image
+        "syn250x187": big[100:287, 50:300].copy(),
+        "syn96x64": big[0:64, 0:96].copy(),
+        "syn17x33": big[:33, :17].copy(),
+        "syn1x1": big[:1, :1].copy(),
+        "noise121x75": rng.integers(0, 256, (75, 121, 3), dtype=np.uint8),
+        "edge80x64": edge,
+        "syn640x480": big,
+    }
+
+
+# switch sets (cjpeg vocabulary, see oracle_lib.make_params).  "gpu": covered by the HIP path today.
+CASES = [
+    ("revert", dict(revert=True), True),
+    ("revert_opt", dict(revert=True, optimize=True), True),
+    ("base_notrellis_noover", dict(baseline=True, notrellis=True, noovershoot=True), True),
+    ("base_notrellis", dict(baseline=True, notrellis=True), True),
+    ("base_noover", dict(baseline=True, noovershoot=True), True),
+    ("base_notrellis_dc", dict(baseline=True, notrellis_dc=True), True),
+    ("base", dict(baseline=True), True),
+    ("base_q90_444", dict(baseline=True, quality=90, sample=(1, 1)), True),
+    ("base_q30", dict(baseline=True, quality=30), True),
+    ("base_422", dict(baseline=True, sample=(2, 1)), True),
+    ("revert_440", dict(revert=True, sample=(1, 2)), True),
+    ("revert_gray", dict(revert=True, gray=True), True),
+    ("base_gray", dict(baseline=True, gray=True), True),
+    ("base_qtbl0", dict(baseline=True, quant_table=0), True),
+    ("base_restart1", dict(baseline=True, restart=1), False),
+    ("base_restart5b", dict(baseline=True, restart="5b"), False),
+    ("fastcrush", dict(fastcrush=True), False),
+    ("default_progressive", dict(), False),
+    ("q85_420_progressive", dict(quality=85), False),
+    ("revert_progressive", dict(revert=True, progressive=True), False),
+    ("q5_16bit_tables", dict(quality=5, fastcrush=True), False),
+]
+
+# constants the REFERENCE itself pins for this path (CMakeLists.txt:1347-1420), cjpeg -revert ... testorig.ppm
+REFERENCE_PINNED = {
+    ("testorig", "revert"): "9a68f56bc76e466aa7e52f415d0f4a5f",        # MD5_JPEG_420_ISLOW   :1391
+    ("testorig", "revert_440"): "538bc02bd4b4658fd85de6ece6cbeda6",    # MD5_JPEG_440_ISLOW   :1354
+    ("testorig", "revert_gray"): "72b51f894b8f4a10b3ee3066770aa38d",   # MD5_JPEG_GRAY_ISLOW  :1362
+}

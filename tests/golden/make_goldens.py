@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/goldens.json from the REAL reference (oracle/_ref/refenc = mozjpeg compiled
+from /root/reference by oracle/Makefile).  Run in the build container:
+    make -C oracle ref && python tests/golden/make_goldens.py
+The JSON (MD5 + size of every fixture x switch set) is committed; /root/reference is not needed to
+run the tests."""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import oracle_lib as O  # noqa: E402
+from cases import CASES, images  # noqa: E402
+
+
+def main():
+    assert O.have_ref(), "build the reference first: make -C oracle ref"
+    out = {}
+    for iname, img in images().items():
+        for cname, kw, _ in CASES:
+            data, _info = O.ref_encode(img, **kw)
+            out["%s/%s" % (iname, cname)] = {"md5": O.md5(data), "bytes": len(data)}
+    with open(os.path.join(HERE, "goldens.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote %d goldens" % len(out))
+
+
+if __name__ == "__main__":
+    main()

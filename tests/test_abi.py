@@ -1,0 +1,86 @@
+"""CPU: the product library loads, exports every symbol include/mozjpeg_hip.h declares, the host
+helpers mirror the reference's parameter logic, and the encoder refuses to run without a GPU
+(no CPU fallback).  No compute is launched here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import mozjpeg_amd as M
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "mozjpeg_hip.h")).read()
+    return sorted(set(re.findall(r"\b(mjh_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = M.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(L, s), "missing export " + s
+
+
+def test_params_struct_layout_matches_header():
+    # sizeof(mjh_params) computed from the header's field list: ints/floats are 4 bytes
+    assert C.sizeof(M.Params) == 4 * (4 + 6 * 4) + 2 * 64 * 4 + 4 * 5 + 4 * 2 + 4 * 3 + C.sizeof(M.Scan) * 64 + 8
+    assert C.sizeof(M.Scan) == 4 * 9
+
+
+@pytest.mark.parametrize("kw", [dict(baseline=True), dict(revert=True), dict(baseline=True, quality=30),
+                                dict(baseline=True, quality=92, sample=(1, 1)), dict(revert=True, quality=10),
+                                dict(baseline=True, quant_table=0), dict(baseline=True, gray=True)])
+def test_host_parameter_helpers_match_oracle(kw):
+    """mjh_params_defaults / mjh_params_set_quality reproduce jpeg_set_defaults / jpeg_set_quality"""
+    pg = M.make_params(333, 222, **kw)
+    po = O.make_params(333, 222, **kw)
+    assert pg.num_components == po.num_components
+    for i in range(po.num_components):
+        assert (pg.h_samp_factor[i], pg.v_samp_factor[i]) == (po.h_samp[i], po.v_samp[i])
+        assert pg.quant_tbl_no[i] == po.quant_tbl_no[i]
+        assert list(pg.quantval[pg.quant_tbl_no[i]]) == list(po.qtbl[po.quant_tbl_no[i]])
+    assert bool(pg.optimize_coding) == bool(po.optimize_coding)
+    assert bool(pg.trellis_quant) == bool(po.trellis_quant)
+    assert bool(pg.overshoot_deringing) == bool(po.overshoot_deringing)
+    assert (pg.compress_profile == M.PROFILE_FASTEST) == bool(po.fastest_profile)
+
+
+def _gpu_present():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_unsupported_configurations_are_errors_not_fallbacks():
+    p = M.make_params(64, 64)           # cjpeg default = progressive + scan search: not on the GPU path yet
+    with pytest.raises(M.MjhError) as ei:
+        M.Encoder(p)
+    assert ei.value.code == M.EUNSUPPORTED
+    p = M.make_params(64, 64, baseline=True, restart=1)
+    with pytest.raises(M.MjhError) as ei:
+        M.Encoder(p)
+    assert ei.value.code == M.EUNSUPPORTED
+    p = M.make_params(64, 64, baseline=True)
+    p.optimize_coding = 0               # trellis without optimize_coding: jcmaster.c never selects a component
+    with pytest.raises(M.MjhError) as ei:
+        M.Encoder(p)
+    assert ei.value.code == M.EUNSUPPORTED
+    p = M.make_params(0, 64, baseline=True)
+    with pytest.raises(M.MjhError) as ei:
+        M.Encoder(p)
+    assert ei.value.code == M.EINVAL
+
+
+@pytest.mark.skipif(_gpu_present(), reason="only meaningful on a machine without a GPU")
+def test_no_gpu_means_loud_failure():
+    with pytest.raises(M.MjhError) as ei:
+        M.Encoder(M.make_params(64, 64, baseline=True))
+    assert ei.value.code == M.EHIP
+    assert "no CPU fallback" in str(ei.value)

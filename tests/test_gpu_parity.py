@@ -1,0 +1,106 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (ctypes -> libmozjpeg_hip.so), against the
+CPU oracle on the same inputs -- stage by stage and byte for byte -- against the committed goldens
+produced by the real reference, and at BASELINE.json's full sizes."""
+import numpy as np
+import pytest
+
+import mozjpeg_amd as M
+import oracle_lib as O
+from cases import CASES
+from gpu_stage_check import check_case
+
+pytestmark = pytest.mark.gpu
+
+GPU_CASES = [(c, kw) for c, kw, on_gpu in CASES if on_gpu]
+
+
+@pytest.mark.parametrize("cname,kw", GPU_CASES)
+def test_every_stage_matches_oracle(cname, kw, fixture_images):
+    """planes, raw DCT, pre-trellis and post-trellis coefficients, Huffman tables, final bytes"""
+    for iname, img in fixture_images.items():
+        assert check_case(img, kw, verbose=False), (iname, cname)
+
+
+@pytest.mark.parametrize("cname,kw", GPU_CASES)
+def test_bytes_match_reference_goldens(cname, kw, goldens, fixture_images):
+    for iname, img in fixture_images.items():
+        h, w = img.shape[:2]
+        enc = M.Encoder(M.make_params(w, h, **kw))
+        data = enc.encode_host(img)[0]
+        enc.close()
+        g = goldens["%s/%s" % (iname, cname)]
+        assert (len(data), O.md5(data)) == (g["bytes"], g["md5"]), (iname, cname)
+
+
+@pytest.mark.parametrize("w,h,kw", [(1920, 1080, dict(baseline=True)),              # BASELINE config 2
+                                    (3840, 2160, dict(baseline=True)),              # the metric's workload
+                                    (1920, 1080, dict(revert=True)),
+                                    (2048, 2048, dict(baseline=True, quality=90, sample=(1, 1)))])
+def test_full_size_frames_bit_exact(w, h, kw):
+    img = O.synthetic_frame(w, h, 1234)
+    enc = M.Encoder(M.make_params(w, h, **kw))
+    data = enc.encode_host(img)[0]
+    enc.close()
+    ref = O.encode(O.make_params(w, h, **kw), img)
+    assert data == ref
+
+
+def test_batch_positions_are_independent_and_deterministic():
+    w, h = 640, 360
+    frames = np.stack([O.synthetic_frame(w, h, 50 + i) for i in range(5)])
+    enc = M.Encoder(M.make_params(w, h, baseline=True), max_batch=5)
+    a = enc.encode_host(frames)
+    b = enc.encode_host(frames[::-1].copy())
+    assert a == b[::-1]
+    single = M.Encoder(M.make_params(w, h, baseline=True), max_batch=1)
+    for i in range(5):
+        assert single.encode_host(frames[i])[0] == a[i]
+    po = O.make_params(w, h, baseline=True)
+    for i in range(5):
+        assert a[i] == O.encode(po, frames[i])
+
+
+def test_device_resident_input_via_torch_tensor():
+    import torch
+    w, h = 800, 600
+    frames = np.stack([O.synthetic_frame(w, h, 9 + i) for i in range(3)])
+    t = torch.from_numpy(frames).cuda()
+    enc = M.Encoder(M.make_params(w, h, baseline=True), max_batch=3)
+    enc.encode_tensor(t)
+    enc.sync()
+    po = O.make_params(w, h, baseline=True)
+    for i in range(3):
+        assert enc.get_jpeg(i) == O.encode(po, frames[i])
+
+
+def test_jpeg_structure_properties():
+    """size-independent properties: SOI/EOI, marker walk, no unstuffed 0xFF in the scan"""
+    w, h = 1024, 768
+    img = O.synthetic_frame(w, h, 3)
+    enc = M.Encoder(M.make_params(w, h, baseline=True))
+    d = enc.encode_host(img)[0]
+    assert d[:2] == b"\xff\xd8" and d[-2:] == b"\xff\xd9"
+    pos, seen = 2, []
+    while True:
+        assert d[pos] == 0xFF
+        m = d[pos + 1]
+        seen.append(m)
+        ln = (d[pos + 2] << 8) | d[pos + 3]
+        pos += 2 + ln
+        if m == 0xDA:
+            break
+    assert seen == [0xE0, 0xDB, 0xC0, 0xC4, 0xDA]     # APP0, one DQT, SOF0, one DHT, SOS (jcmarker.c:189,293)
+    scan = d[pos:-2]
+    i = scan.find(b"\xff")
+    while i >= 0:
+        assert scan[i + 1] == 0, "unstuffed 0xFF inside entropy-coded data"
+        i = scan.find(b"\xff", i + 2)
+
+
+def test_extreme_inputs():
+    for img in (np.zeros((40, 40, 3), np.uint8), np.full((40, 40, 3), 255, np.uint8),
+                np.random.default_rng(0).integers(0, 256, (64, 64, 3), dtype=np.uint8)):
+        for kw in (dict(baseline=True), dict(baseline=True, quality=100), dict(baseline=True, quality=1)):
+            h, w = img.shape[:2]
+            enc = M.Encoder(M.make_params(w, h, **kw))
+            assert enc.encode_host(img)[0] == O.encode(O.make_params(w, h, **kw), img), kw
