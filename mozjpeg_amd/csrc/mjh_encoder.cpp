@@ -141,6 +141,8 @@ struct mjh_encoder {
   MjhHuffTable *d_tabs = nullptr, *d_tabs_init = nullptr;
   float *d_lambda = nullptr;
   uint8_t *d_back = nullptr;
+  unsigned *d_worklist = nullptr;   // deferred trellis blocks: [0] = count, [4+2i], [5+2i] = (image, comp<<28|block)
+  int trellis_variant = 0;
   uint16_t *d_len16 = nullptr;
   unsigned *d_off32 = nullptr, *d_sums = nullptr, *d_totals = nullptr, *d_ffsums = nullptr, *d_fftotals = nullptr;
   unsigned *d_stream = nullptr;
@@ -375,7 +377,7 @@ static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *ptrs[] = { e->d_pix, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back,
+  void *ptrs[] = { e->d_pix, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -421,6 +423,8 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   HIPCHK_E(hipMalloc((void **)&e->d_tabs_init, B * SLOTS_PER_IMAGE * sizeof(MjhHuffTable)));
   HIPCHK_E(hipMalloc((void **)&e->d_lambda, B * C.total_real_blocks * sizeof(float)));
   HIPCHK_E(hipMalloc((void **)&e->d_back, B * (size_t)C.total_real_blocks * 16));
+  HIPCHK_E(hipMalloc((void **)&e->d_worklist, 16 + B * (size_t)C.total_real_blocks * 8));
+  if (const char *v = getenv("MJH_TRELLIS_VARIANT")) e->trellis_variant = atoi(v);
   HIPCHK_E(hipMalloc((void **)&e->d_len16, B * (size_t)C.total_mcu_blocks * 2));
   HIPCHK_E(hipMalloc((void **)&e->d_off32, B * (size_t)C.total_mcu_blocks * 4));
   e->chunks = (C.total_mcu_blocks + 2047) / 2048;
@@ -546,7 +550,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     }
     // ... passes 1,3,5: trellis quantization with those tables
     pr.mark("trellis_ac");
-    mjh_launch_trellis_ac(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_ac, e->d_lambda, n, s);
+    mjh_launch_trellis_ac(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_ac, e->d_lambda, e->d_worklist, e->trellis_variant, n, s);
     if (p.trellis_quant_dc) {
       pr.mark("trellis_dc");
       mjh_launch_trellis_dc(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_dc, e->d_lambda, e->d_back, n, s);

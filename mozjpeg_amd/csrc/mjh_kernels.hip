@@ -339,6 +339,7 @@ k_stats_ac(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restr
   if (s) atomicAdd(&T->counts[tid], s);
 }
 
+#define STATS_DC_ITER 16
 template <int MCU_ORDER>
 __global__ void __launch_bounds__(256)
 k_stats_dc(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restrict__ tabs,
@@ -346,35 +347,38 @@ k_stats_dc(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restr
 {
   const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
-  const int t = blockIdx.x * 256 + threadIdx.x;
   const int16_t *q0 = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;  // plane k = 0
-  int nb = -1;
-  if (MCU_ORDER) {
-    if (t < cc.wpad * cc.hpad) {
-      const int r = t / cc.wpad, c = t - r * cc.wpad;
-      const int dc = q0[dc_source_block(cc, r, c)];
-      int pr, pc, pred = 0;
-      if (mcu_prev_block(C, cc, r, c, pr, pc)) pred = q0[dc_source_block(cc, pr, pc)];
+  const int lane = threadIdx.x & 63;
+  const int nitems = MCU_ORDER ? cc.wpad * cc.hpad : cc.nblk;
+  const int ri = comp == 0 ? comp_restart.x : comp == 1 ? comp_restart.y : comp == 2 ? comp_restart.z : comp_restart.w;
+  unsigned cnt = 0;   // lane s (< 12) counts symbol s for this wave
+  for (int it = 0; it < STATS_DC_ITER; it++) {
+    const int t = (blockIdx.x * STATS_DC_ITER + it) * 256 + threadIdx.x;
+    if ((blockIdx.x * STATS_DC_ITER + it) * 256 >= nitems) break;   // uniform
+    int nb = -1;
+    if (t < nitems) {
+      int dc, pred = 0;
+      if (MCU_ORDER) {
+        const int r = t / cc.wpad, c = t - r * cc.wpad;
+        dc = q0[dc_source_block(cc, r, c)];
+        int pr, pc;
+        if (mcu_prev_block(C, cc, r, c, pr, pc)) pred = q0[dc_source_block(cc, pr, pc)];
+      } else {
+        dc = q0[t];
+        pred = (t == 0 || (ri && (t % ri) == 0)) ? 0 : q0[t - 1];
+      }
       const int df = dc - pred;
       nb = bitlen((unsigned)(df < 0 ? -df : df));
     }
-  } else {
-    if (t < cc.nblk) {
-      const int ri = comp == 0 ? comp_restart.x : comp == 1 ? comp_restart.y : comp == 2 ? comp_restart.z : comp_restart.w;
-      const int dc = q0[t];
-      const int pred = (t == 0 || (ri && (t % ri) == 0)) ? 0 : q0[t - 1];
-      const int df = dc - pred;
-      nb = bitlen((unsigned)(df < 0 ? -df : df));
+#pragma unroll
+    for (int s = 0; s < 12; s++) {
+      const unsigned long long m = __ballot(nb == s);
+      if (lane == s) cnt += (unsigned)__popcll(m);
     }
   }
   const int slot = comp == 0 ? slot_of_comp.x : comp == 1 ? slot_of_comp.y : comp == 2 ? slot_of_comp.z : slot_of_comp.w;
   MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int s = 0; s < 12; s++) {
-    const unsigned long long m = __ballot(nb == s);
-    if (lane == 0 && m) atomicAdd(&T->counts[s], (unsigned)__popcll(m));
-  }
+  if (lane < 12 && cnt) atomicAdd(&T->counts[lane], cnt);
 }
 
 // =============================================================================================
@@ -545,84 +549,68 @@ k_gen_tables(MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 slots_a,
 // reference; such a position can never win (its cost is >= 1e38) and is zeroed by the
 // back-track, so it is simply not appended here.
 // =============================================================================================
-__global__ void __launch_bounds__(64)
-k_trellis_ac(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
-             int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
-             int4 ac_slot_of_comp, float *__restrict__ lambda_out)
+// The DP of one block.  `SI` returns AC code lengths, XS the block's raw coefficient at a zig-zag
+// position; NE is the capacity of the live-predecessor list.  Returns false (nothing written)
+// when the list would overflow -- the caller then defers the block to the full-capacity kernel.
+template <int NE, class SI, class XS>
+__device__ __forceinline__ bool trellis_ac_block(const SI &si, const XS &xsrc, int16_t *__restrict__ qo, int kstride,
+                                                 const uint16_t *__restrict__ qz, const float *__restrict__ rcp,
+                                                 const float *__restrict__ lt, float lambda,
+                                                 float (*e_azd)[64], float (*e_acc)[64], unsigned (*e_pk)[64], int lane)
 {
-  __shared__ float e_azd[64][64];
-  __shared__ float e_acc[64][64];
-  __shared__ unsigned e_pk[64][64];   // pos | from<<6 | (value & 0xFFFF) << 12
-  __shared__ unsigned char si[256];
-  const int comp = blockIdx.y, img = blockIdx.z;
-  const MjhComp cc = C.c[comp];
-  const int lane = threadIdx.x;
-  const int slot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
-  const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
-#pragma unroll
-  for (int t = 0; t < 4; t++) si[lane + 64 * t] = T->ehufsi[lane + 64 * t];
-  __syncthreads();
-  const int blk = blockIdx.x * 64 + lane;
-  if (blk >= cc.nblk) return;
-  const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
-  int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
-  const uint16_t *qz = Q->q[cc.qtbl];
-  const float *rcp = Q->rcp8q[cc.qtbl];
-  const float *lt = Q->lambda_tbl[cc.qtbl];
-
-  // norm over the 63 AC coefficients in NATURAL index order (jcdctmgr.c:1027-1031)
-  float norm = 0.0f;
-#pragma unroll
-  for (int n = 1; n < 64; n++) {
-    const int x = uq[(size_t)kIZZ.v[n] * cc.kstride];
-    norm = norm + (float)(x * x);
-  }
-  norm = (float)((double)norm / 63.0);
-  float lambda;
-  if (C.lambda_log_scale2 > 0.0f) lambda = (float)(C.pow_scale1 * 1.0 / (C.pow_scale2 + (double)norm));
-  else lambda = (float)(C.pow_scale1 * 1.0);
-  lambda_out[(size_t)img * C.total_real_blocks + cc.blk_off + blk] = lambda;
-
-  const int si_f0 = si[0xF0], si_eob = si[0];
+  const int si_f0 = si(0xF0), si_eob = si(0);
   int nlive = 1;
   e_azd[0][lane] = 0.0f;
   e_acc[0][lane] = 0.0f;
   e_pk[0][lane] = 0u;
   float azd_prev = 0.0f;
   for (int i = 1; i < 64; i++) {
-    const int xs = uq[(size_t)i * cc.kstride];
+    const int xs = xsrc(i);
     const int x = xs < 0 ? -xs : xs;
     const int dq = 8 * (int)qz[i];
     float t = (float)(x * x) * lambda;
     t = t * lt[i];
     const float azd_cur = t + azd_prev;
-    int qval = udiv_exact(x + (dq >> 1), dq, rcp[i]);
-    if (qval != 0) {
+    if (x + (dq >> 1) >= dq) {                      // qval != 0
+      int qval = udiv_exact(x + (dq >> 1), dq, rcp[i]);
       if (qval >= 1024) qval = 1023;
       const int ncd = bitlen((unsigned)qval);
+      float dist[10];
+#pragma unroll
+      for (int k = 0; k < 10; k++) {
+        if (k < ncd) {
+          const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
+          const int delta = cand * dq - x;
+          float d = (float)(delta * delta) * lambda;
+          dist[k] = d * lt[i];
+        } else dist[k] = 0.0f;
+      }
       float best = 1e38f;
-      int beste = -1, bestv = 0;
-      for (int k = 0; k < ncd; k++) {
-        const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
-        const int delta = cand * dq - x;
-        float dist = (float)(delta * delta) * lambda;
-        dist = dist * lt[i];
-        for (int e = 0; e < nlive; e++) {
-          const int pos = (int)(e_pk[e][lane] & 63u);
-          const int zero_run = i - 1 - pos;
-          const int hi = zero_run >> 4;
-          if (hi && si_f0 == 0) continue;
-          const int cb = si[16 * (zero_run & 15) + k + 1];
-          if (cb == 0) continue;
-          const int rate = cb + (k + 1) + hi * si_f0;
-          float cost = (float)rate + dist;
-          float rhs = azd_prev - e_azd[e][lane];
-          rhs = rhs + e_acc[e][lane];
-          cost = cost + rhs;
-          if (cost < best || (cost == best && e < beste)) { best = cost; beste = e; bestv = cand; }
+      int beste = -1, bestk = 0;
+      for (int e = 0; e < nlive; e++) {
+        const int pos = (int)(e_pk[e][lane] & 63u);
+        const int zero_run = i - 1 - pos;
+        const int hi = zero_run >> 4;
+        if (hi && si_f0 == 0) continue;
+        float rhs = azd_prev - e_azd[e][lane];
+        rhs = rhs + e_acc[e][lane];
+        const int rbase = hi * si_f0;
+        const int sbase = 16 * (zero_run & 15) + 1;
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+          if (k < ncd) {
+            const int cb = si(sbase + k);
+            if (cb != 0) {
+              float cost = (float)(cb + (k + 1) + rbase) + dist[k];
+              cost = cost + rhs;
+              if (cost < best) { best = cost; beste = e; bestk = k; }
+            }
+          }
         }
       }
       if (beste >= 0) {
+        if (nlive >= NE) return false;
+        const int bestv = (bestk < ncd - 1) ? (2 << bestk) - 1 : qval;
         const int v = xs < 0 ? -bestv : bestv;
         e_azd[nlive][lane] = azd_cur;
         e_acc[nlive][lane] = best;
@@ -651,7 +639,96 @@ k_trellis_ac(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restri
       cur = (int)((pk >> 6) & 63u);
       pk = e_pk[cur][lane];
     }
-    qo[(size_t)k * cc.kstride] = (int16_t)v;
+    qo[(size_t)k * kstride] = (int16_t)v;
+  }
+  return true;
+}
+
+// norm / lambda of one block (jcdctmgr.c:1027-1037): 63 coalesced loads in one burst, summed in
+// NATURAL index order; optionally parks the values in an LDS column for the DP loop.
+template <bool STAGE>
+__device__ __forceinline__ float trellis_lambda(const MjhConst &C, const int16_t *__restrict__ uq, int kstride, short (*s_x)[64], int lane)
+{
+  float norm = 0.0f;
+#pragma unroll
+  for (int n = 1; n < 64; n++) {
+    const int x = uq[(size_t)kIZZ.v[n] * kstride];
+    if (STAGE) s_x[kIZZ.v[n]][lane] = (short)x;
+    norm = norm + (float)(x * x);
+  }
+  norm = (float)((double)norm / 63.0);
+  if (C.lambda_log_scale2 > 0.0f) return (float)(C.pow_scale1 * 1.0 / (C.pow_scale2 + (double)norm));
+  return (float)(C.pow_scale1 * 1.0);
+}
+
+struct SiLds { const unsigned char *p; __device__ __forceinline__ int operator()(int i) const { return p[i]; } };
+struct SiGlobal { const uint8_t *p; __device__ __forceinline__ int operator()(int i) const { return p[i]; } };
+struct XsLds { short (*p)[64]; int lane; __device__ __forceinline__ int operator()(int i) const { return p[i][lane]; } };
+struct XsGlobal { const int16_t *p; int kstride; __device__ __forceinline__ int operator()(int i) const { return p[(size_t)i * kstride]; } };
+
+// fast path: NE live entries per lane in LDS; blocks that need more go to the work list
+template <int NE, bool STAGE>
+__global__ void __launch_bounds__(64)
+k_trellis_ac(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
+             int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
+             int4 ac_slot_of_comp, float *__restrict__ lambda_out, unsigned *__restrict__ worklist)
+{
+  __shared__ float e_azd[NE][64];
+  __shared__ float e_acc[NE][64];
+  __shared__ unsigned e_pk[NE][64];   // pos | from<<6 | (value & 0xFFFF) << 12
+  __shared__ short s_x[STAGE ? 64 : 1][64];
+  __shared__ unsigned char si[256];
+  const int comp = blockIdx.y, img = blockIdx.z;
+  const MjhComp cc = C.c[comp];
+  const int lane = threadIdx.x;
+  const int slot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
+  const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+#pragma unroll
+  for (int t = 0; t < 4; t++) si[lane + 64 * t] = T->ehufsi[lane + 64 * t];
+  __syncthreads();
+  const int blk = blockIdx.x * 64 + lane;
+  if (blk >= cc.nblk) return;
+  const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+  int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+  const float lambda = trellis_lambda<STAGE>(C, uq, cc.kstride, s_x, lane);
+  lambda_out[(size_t)img * C.total_real_blocks + cc.blk_off + blk] = lambda;
+  bool ok;
+  if (STAGE)
+    ok = trellis_ac_block<NE>(SiLds{ si }, XsLds{ s_x, lane }, qo, cc.kstride, Q->q[cc.qtbl], Q->rcp8q[cc.qtbl], Q->lambda_tbl[cc.qtbl],
+                              lambda, e_azd, e_acc, e_pk, lane);
+  else
+    ok = trellis_ac_block<NE>(SiLds{ si }, XsGlobal{ uq, cc.kstride }, qo, cc.kstride, Q->q[cc.qtbl], Q->rcp8q[cc.qtbl], Q->lambda_tbl[cc.qtbl],
+                              lambda, e_azd, e_acc, e_pk, lane);
+  if (!ok) {
+    const unsigned idx = atomicAdd(&worklist[0], 1u);
+    worklist[4 + 2 * (size_t)idx] = (unsigned)img;
+    worklist[5 + 2 * (size_t)idx] = ((unsigned)comp << 28) | (unsigned)blk;
+  }
+}
+
+// full-capacity path for the deferred blocks (any image / component per lane)
+__global__ void __launch_bounds__(64)
+k_trellis_ac_deferred(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
+                      int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
+                      int4 ac_slot_of_comp, const float *__restrict__ lambda_in, const unsigned *__restrict__ worklist)
+{
+  __shared__ float e_azd[64][64];
+  __shared__ float e_acc[64][64];
+  __shared__ unsigned e_pk[64][64];
+  const int lane = threadIdx.x;
+  const unsigned count = worklist[0];
+  for (unsigned it = blockIdx.x * 64 + lane; it < count; it += gridDim.x * 64) {
+    const int img = (int)worklist[4 + 2 * (size_t)it];
+    const unsigned w = worklist[5 + 2 * (size_t)it];
+    const int comp = (int)(w >> 28), blk = (int)(w & 0x0FFFFFFFu);
+    const MjhComp cc = C.c[comp];
+    const int slot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
+    const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+    const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+    int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+    const float lambda = lambda_in[(size_t)img * C.total_real_blocks + cc.blk_off + blk];
+    trellis_ac_block<64>(SiGlobal{ T->ehufsi }, XsGlobal{ uq, cc.kstride }, qo, cc.kstride, Q->q[cc.qtbl], Q->rcp8q[cc.qtbl],
+                         Q->lambda_tbl[cc.qtbl], lambda, e_azd, e_acc, e_pk, lane);
   }
 }
 
@@ -709,9 +786,18 @@ k_trellis_dc(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restri
     const int row0 = br * cc.wib;
     int prev_c = 0;
     float prev_cost = 0.0f;
+    int xs_l = 0;
+    float lam_l = 0.0f;
     for (int bi = 0; bi < cc.wib; bi++) {
-      const int xs = uq0[row0 + bi];
-      const float lambda_dc = lam[row0 + bi] * lt0;
+      // every 16 blocks the group fetches the next 16 (DC, lambda) pairs with one coalesced load
+      // per lane; the sequential recursion then only sees cross-lane shuffles, never HBM latency
+      if ((bi & 15) == 0) {
+        const int b = bi + k;
+        xs_l = b < cc.wib ? (int)uq0[row0 + b] : 0;
+        lam_l = b < cc.wib ? lam[row0 + b] : 0.0f;
+      }
+      const int xs = grp_shfl(xs_l, bi & 15, lane);
+      const float lambda_dc = grp_shfl_f(lam_l, bi & 15, lane) * lt0;
       const int x = xs < 0 ? -xs : xs;
       const int qval = udiv_exact(x + (dq >> 1), dq, rcp);
       int cnd = qval - ncand / 2 + k;
@@ -726,16 +812,27 @@ k_trellis_dc(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restri
         const int bits = bitlen((unsigned)(df < 0 ? -df : df));
         best = (float)(bits + (int)((dsi >> (5 * bits)) & 31)) + dist;
       } else {
-        best = 0.0f;
-        for (int l = 0; l < ncand; l++) {
-          const int pc = grp_shfl(prev_c, l, lane);
-          const float pcost = grp_shfl_f(prev_cost, l, lane);
-          const int df = cnd - pc;
+        // all 18 cross-lane reads are issued back to back (fully unrolled), then 9 independent
+        // cost evaluations; the first-minimum scan over l keeps the reference's strict '<' order
+        int pcs[9];
+        float pcosts[9];
+#pragma unroll
+        for (int l = 0; l < 9; l++) {
+          pcs[l] = grp_shfl(prev_c, l, lane);
+          pcosts[l] = grp_shfl_f(prev_cost, l, lane);
+        }
+        float costs[9];
+#pragma unroll
+        for (int l = 0; l < 9; l++) {
+          const int df = cnd - pcs[l];
           const int bits = bitlen((unsigned)(df < 0 ? -df : df));
           float cost = (float)(bits + (int)((dsi >> (5 * bits)) & 31)) + dist;
-          cost = cost + pcost;
-          if (l == 0 || cost < best) { best = cost; bb = l; }
+          costs[l] = cost + pcosts[l];
         }
+        best = costs[0];
+#pragma unroll
+        for (int l = 1; l < 9; l++)
+          if (l < ncand && costs[l] < best) { best = costs[l]; bb = l; }
       }
       prev_c = cnd;
       prev_cost = best;
@@ -1187,11 +1284,12 @@ void mjh_launch_stats_dc(const MjhConst &C, const void *q, MjhHuffTable *tabs, i
 {
   const int4 sl = make_int4(slot[0], slot[1], slot[2], slot[3]);
   const int4 cr = make_int4(comp_restart[0], comp_restart[1], comp_restart[2], comp_restart[3]);
+  const int per_wg = 256 * STATS_DC_ITER;
   if (mcu_order) {
-    dim3 grid((max_padblk(C) + 255) / 256, C.ncomp, n);
+    dim3 grid((max_padblk(C) + per_wg - 1) / per_wg, C.ncomp, n);
     hipLaunchKernelGGL((k_stats_dc<1>), grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, sl, cr);
   } else {
-    dim3 grid((max_nblk(C) + 255) / 256, C.ncomp, n);
+    dim3 grid((max_nblk(C) + per_wg - 1) / per_wg, C.ncomp, n);
     hipLaunchKernelGGL((k_stats_dc<0>), grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, sl, cr);
   }
 }
@@ -1203,10 +1301,22 @@ void mjh_launch_gen_tables(MjhHuffTable *tabs, int spi, const int *slots, int ns
   hipLaunchKernelGGL(k_gen_tables, dim3(nslots, n), dim3(64), 0, s, tabs, spi, make_int4(sl[0], sl[1], sl[2], sl[3]), make_int4(sl[4], sl[5], sl[6], sl[7]));
 }
 
-void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], float *lambda, int n, hipStream_t s)
+void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], float *lambda, unsigned *worklist, int variant, int n, hipStream_t s)
 {
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
-  hipLaunchKernelGGL(k_trellis_ac, grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]), lambda);
+  const int4 sl = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
+  (void)hipMemsetAsync(worklist, 0, 16, s);
+#define LT(NE, ST) hipLaunchKernelGGL((k_trellis_ac<NE, ST>), grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, worklist)
+  switch (variant) {
+    case 1: LT(16, false); break;
+    case 2: LT(24, true); break;
+    case 3: LT(16, true); break;
+    case 4: LT(32, false); break;
+    case 5: LT(12, false); break;
+    default: LT(24, false); break;
+  }
+#undef LT
+  hipLaunchKernelGGL(k_trellis_ac_deferred, dim3(512), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, (const float *)lambda, (const unsigned *)worklist);
 }
 
 void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s)
