@@ -1,0 +1,37 @@
+/*
+ * mozjpeg_hip_jpeglib.h -- the libjpeg drop-in boundary of the MI355X hot path.
+ *
+ * libmozjpeg_hip_jpeg62.so (mozjpeg_amd/csrc/jpeg_shim.c) exports, with the reference's exact
+ * signatures, the three libjpeg entry points that bracket the encode hot path:
+ *
+ *   void       jpeg_start_compress (j_compress_ptr cinfo, boolean write_all_tables);
+ *                  replaces jcapistd.c:44   (declared jpeglib.h:1065)
+ *   JDIMENSION jpeg_write_scanlines(j_compress_ptr cinfo, JSAMPARRAY scanlines, JDIMENSION num_lines);
+ *                  replaces jcapistd.c:90   (declared jpeglib.h:1067)
+ *   void       jpeg_finish_compress(j_compress_ptr cinfo);
+ *                  replaces jcapimin.c:176  (declared jpeglib.h:1076)
+ *
+ * Everything else of the libjpeg API (jpeg_CreateCompress, jpeg_set_defaults, jpeg_set_quality,
+ * jpeg_c_set_*_param, jpeg_mem_dest, jpeg_stdio_dest, jpeg_std_error, jpeg_abort, ...) keeps being
+ * served by the host's libjpeg.so.62; the shim is placed in front of it (link order or
+ * LD_PRELOAD), so an UNCHANGED client such as `cjpeg` runs the GPU path.  See INTEGRATION.md.
+ *
+ * Contract kept from the reference:
+ *  - call order / global_state: CSTATE_START -> SCANNING -> START, wrong order = ERREXIT1(JERR_BAD_STATE)
+ *  - scanline memory is only read during the call (rows are copied into the staging buffer)
+ *  - output only through cinfo->dest (init_destination / empty_output_buffer / term_destination)
+ *  - SOI + JFIF APP0 are emitted by jpeg_start_compress so that jpeg_write_marker / ICC / COM
+ *    markers written by the application land where the reference would put them
+ *  - errors never return: ERREXIT -> cinfo->err->error_exit.  A configuration the GPU path does
+ *    not cover is an ERROR (message on stderr + JERR_NOT_COMPILED), not a silent CPU fallback;
+ *    setting MOZJPEG_HIP_PASSTHROUGH=1 in the environment turns it into an explicit, logged
+ *    hand-over to the next jpeg_start_compress in link order instead.
+ *
+ * This header intentionally declares nothing new: the prototypes are the ones in the tree's own
+ * <jpeglib.h>, against which the shim is compiled (struct jpeg_compress_struct is ABI:
+ * jcapimin.c:41-45 checks its size and JPEG_LIB_VERSION).
+ */
+#ifndef MOZJPEG_HIP_JPEGLIB_H
+#define MOZJPEG_HIP_JPEGLIB_H
+#define MOZJPEG_HIP_SHIM_SYMBOLS "jpeg_start_compress jpeg_write_scanlines jpeg_finish_compress"
+#endif

@@ -1,0 +1,245 @@
+/*
+ * jpeg_shim.c -- libjpeg drop-in entry points on top of the MI355X batch encoder.
+ * See include/mozjpeg_hip_jpeglib.h for the contract.  Compiled against the libjpeg headers of the
+ * tree it drops into; links only to libmozjpeg_hip.so (and libdl).
+ */
+#define _GNU_SOURCE
+#define JPEG_INTERNALS
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "jinclude.h"
+#include "jpeglib.h"   /* JPEG_INTERNALS: pulls in jpegint.h and jerror.h */
+
+#include "mozjpeg_hip.h"
+
+typedef struct shim_state {
+  j_compress_ptr cinfo;
+  mjh_params p;
+  unsigned char *pixels;     /* staged scanlines, image_width*input_components per row */
+  size_t row_bytes;
+  int header_bytes;          /* SOI (+APP0) already written by jpeg_start_compress */
+  struct shim_state *next;
+} shim_state;
+
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static shim_state *g_states = NULL;
+
+/* one cached encoder per thread: creating device buffers per image would dominate small images */
+static __thread mjh_encoder *t_enc = NULL;
+static __thread mjh_params t_enc_params;
+
+static shim_state *find_state(j_compress_ptr cinfo, int remove)
+{
+  shim_state **pp, *s = NULL;
+  pthread_mutex_lock(&g_lock);
+  for (pp = &g_states; *pp; pp = &(*pp)->next)
+    if ((*pp)->cinfo == cinfo) { s = *pp; if (remove) *pp = s->next; break; }
+  pthread_mutex_unlock(&g_lock);
+  return s;
+}
+
+static void emit_byte(j_compress_ptr cinfo, int v)
+{ /* same protocol as jcmarker.c:113-123 */
+  struct jpeg_destination_mgr *dest = cinfo->dest;
+  *(dest->next_output_byte)++ = (JOCTET)v;
+  if (--dest->free_in_buffer == 0)
+    if (!(*dest->empty_output_buffer) (cinfo)) ERREXIT(cinfo, JERR_CANT_SUSPEND);
+}
+static void emit_bytes(j_compress_ptr cinfo, const unsigned char *p, size_t n)
+{
+  struct jpeg_destination_mgr *dest = cinfo->dest;
+  while (n > 0) {
+    size_t k = n < dest->free_in_buffer ? n : dest->free_in_buffer;
+    memcpy(dest->next_output_byte, p, k);
+    dest->next_output_byte += k; dest->free_in_buffer -= k; p += k; n -= k;
+    if (dest->free_in_buffer == 0)
+      if (!(*dest->empty_output_buffer) (cinfo)) ERREXIT(cinfo, JERR_CANT_SUSPEND);
+  }
+}
+
+/* minimal marker writer so that jpeg_write_marker / jpeg_write_m_header keep working
+ * (jcmarker.c:590-615) between jpeg_start_compress and the first scanline */
+static void mw_header(j_compress_ptr cinfo, int marker, unsigned int datalen)
+{
+  if (datalen > 65533u) ERREXIT(cinfo, JERR_BAD_LENGTH);
+  emit_byte(cinfo, 0xFF); emit_byte(cinfo, marker);
+  emit_byte(cinfo, (int)((datalen + 2) >> 8) & 0xFF); emit_byte(cinfo, (int)(datalen + 2) & 0xFF);
+}
+static void mw_byte(j_compress_ptr cinfo, int val) { emit_byte(cinfo, val); }
+static void mw_nop(j_compress_ptr cinfo) { (void)cinfo; }
+
+typedef void (*start_fn)(j_compress_ptr, boolean);
+typedef JDIMENSION (*write_fn)(j_compress_ptr, JSAMPARRAY, JDIMENSION);
+typedef void (*finish_fn)(j_compress_ptr);
+
+static const char *capture_params(j_compress_ptr cinfo, mjh_params *p)
+{
+  int ci, i;
+  memset(p, 0, sizeof(*p));
+  if (cinfo->data_precision != 8) return "data_precision != 8";
+  if (cinfo->arith_code) return "arithmetic coding";
+  if (cinfo->raw_data_in) return "raw_data_in";
+  if (cinfo->smoothing_factor) return "input smoothing";
+  if (cinfo->dct_method != JDCT_ISLOW) return "dct_method other than JDCT_ISLOW";
+  if (cinfo->write_Adobe_marker) return "Adobe marker";
+  if (cinfo->in_color_space == JCS_RGB && cinfo->input_components == 3) p->input_components = 3;
+  else if (cinfo->in_color_space == JCS_GRAYSCALE && cinfo->input_components == 1) p->input_components = 1;
+  else return "input colour space (only JCS_RGB / JCS_GRAYSCALE)";
+  if (cinfo->jpeg_color_space == JCS_YCbCr && cinfo->num_components == 3) p->num_components = 3;
+  else if (cinfo->jpeg_color_space == JCS_GRAYSCALE && cinfo->num_components == 1) p->num_components = 1;
+  else return "JPEG colour space (only YCbCr / grayscale)";
+  if (cinfo->write_JFIF_header &&
+      (cinfo->JFIF_major_version != 1 || cinfo->JFIF_minor_version != 1 || cinfo->density_unit != 0 ||
+       cinfo->X_density != 1 || cinfo->Y_density != 1))
+    return "non-default JFIF version/density";
+  p->image_width = (int)cinfo->image_width;
+  p->image_height = (int)cinfo->image_height;
+  for (ci = 0; ci < cinfo->num_components; ci++) {
+    jpeg_component_info *c = &cinfo->comp_info[ci];
+    p->h_samp_factor[ci] = c->h_samp_factor; p->v_samp_factor[ci] = c->v_samp_factor;
+    p->quant_tbl_no[ci] = c->quant_tbl_no; p->dc_tbl_no[ci] = c->dc_tbl_no; p->ac_tbl_no[ci] = c->ac_tbl_no;
+    p->component_id[ci] = c->component_id;
+    if (c->quant_tbl_no < 0 || c->quant_tbl_no >= NUM_QUANT_TBLS || cinfo->quant_tbl_ptrs[c->quant_tbl_no] == NULL)
+      ERREXIT1(cinfo, JERR_NO_QUANT_TABLE, c->quant_tbl_no);
+    for (i = 0; i < 64; i++) p->quantval[c->quant_tbl_no][i] = cinfo->quant_tbl_ptrs[c->quant_tbl_no]->quantval[i];
+  }
+  p->compress_profile = jpeg_c_get_int_param(cinfo, JINT_COMPRESS_PROFILE) == JCP_FASTEST ? MJH_PROFILE_FASTEST
+                                                                                            : MJH_PROFILE_MAX_COMPRESSION;
+  p->optimize_coding = cinfo->optimize_coding;
+  p->trellis_quant = jpeg_c_get_bool_param(cinfo, JBOOLEAN_TRELLIS_QUANT);
+  p->trellis_quant_dc = jpeg_c_get_bool_param(cinfo, JBOOLEAN_TRELLIS_QUANT_DC);
+  p->overshoot_deringing = jpeg_c_get_bool_param(cinfo, JBOOLEAN_OVERSHOOT_DERINGING);
+  p->lambda_log_scale1 = jpeg_c_get_float_param(cinfo, JFLOAT_LAMBDA_LOG_SCALE1);
+  p->lambda_log_scale2 = jpeg_c_get_float_param(cinfo, JFLOAT_LAMBDA_LOG_SCALE2);
+  if (jpeg_c_get_bool_param(cinfo, JBOOLEAN_TRELLIS_EOB_OPT)) return "trellis_eob_opt";
+  if (jpeg_c_get_bool_param(cinfo, JBOOLEAN_USE_SCANS_IN_TRELLIS)) return "use_scans_in_trellis";
+  if (jpeg_c_get_bool_param(cinfo, JBOOLEAN_TRELLIS_Q_OPT)) return "trellis_q_opt";
+  if (jpeg_c_get_int_param(cinfo, JINT_TRELLIS_NUM_LOOPS) != 1) return "trellis_num_loops != 1";
+  if (jpeg_c_get_float_param(cinfo, JFLOAT_TRELLIS_DELTA_DC_WEIGHT) != 0.0f) return "trellis_delta_dc_weight";
+  if (p->trellis_quant && !p->optimize_coding) return "trellis without optimize_coding";
+  p->restart_interval = cinfo->restart_interval;
+  p->restart_in_rows = cinfo->restart_in_rows;
+  if (cinfo->scan_info != NULL && cinfo->num_scans > 0) return "multi-scan (progressive) script";
+  if (!cinfo->optimize_coding) {
+    /* standard tables are baked into the GPU path; anything else needs optimize_coding */
+    if (cinfo->dc_huff_tbl_ptrs[0] == NULL || cinfo->ac_huff_tbl_ptrs[0] == NULL) return "missing Huffman tables";
+  }
+  p->write_JFIF_header = cinfo->write_JFIF_header;
+  return NULL;
+}
+
+void jpeg_start_compress(j_compress_ptr cinfo, boolean write_all_tables)
+{
+  const char *why;
+  shim_state *s;
+  struct jpeg_marker_writer *mw;
+
+  if (cinfo->global_state != CSTATE_START) ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
+  s = (shim_state *)calloc(1, sizeof(*s));
+  if (!s) ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0);
+  why = capture_params(cinfo, &s->p);
+  if (!why) {
+    /* let the encoder validate too (geometry limits, sampling factors ...) */
+    if (t_enc == NULL || memcmp(&t_enc_params, &s->p, sizeof(mjh_params)) != 0) {
+      if (t_enc) { mjh_encoder_destroy(t_enc); t_enc = NULL; }
+      if (mjh_encoder_create(&s->p, 1, 0, &t_enc) != MJH_OK) why = mjh_last_error();
+      else t_enc_params = s->p;
+    }
+  }
+  if (why) {
+    free(s);
+    if (getenv("MOZJPEG_HIP_PASSTHROUGH")) {
+      start_fn next = (start_fn)dlsym(RTLD_NEXT, "jpeg_start_compress");
+      fprintf(stderr, "mozjpeg_hip: %s is outside the GPU path; MOZJPEG_HIP_PASSTHROUGH set, handing over to the host libjpeg\n", why);
+      if (next) { next(cinfo, write_all_tables); return; }
+    }
+    fprintf(stderr, "mozjpeg_hip: unsupported configuration (%s); no CPU fallback\n", why);
+    ERREXIT(cinfo, JERR_NOT_COMPILED);
+  }
+  if (write_all_tables) jpeg_suppress_tables(cinfo, FALSE);
+  (*cinfo->err->reset_error_mgr) ((j_common_ptr)cinfo);
+  (*cinfo->dest->init_destination) (cinfo);
+  /* marker writer object for jpeg_write_marker (lives in the image pool like the reference's) */
+  mw = (struct jpeg_marker_writer *)(*cinfo->mem->alloc_small) ((j_common_ptr)cinfo, JPOOL_IMAGE, sizeof(*mw));
+  mw->write_file_header = mw_nop; mw->write_frame_header = mw_nop; mw->write_scan_header = mw_nop;
+  mw->write_file_trailer = mw_nop; mw->write_tables_only = mw_nop;
+  mw->write_marker_header = mw_header; mw->write_marker_byte = mw_byte;
+  cinfo->marker = mw;
+  /* write_file_header jcmarker.c:649: SOI + JFIF APP0 */
+  emit_byte(cinfo, 0xFF); emit_byte(cinfo, 0xD8);
+  s->header_bytes = 2;
+  if (cinfo->write_JFIF_header) {
+    static const unsigned char app0[18] = { 0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0 };
+    emit_bytes(cinfo, app0, sizeof(app0));
+    s->header_bytes += 18;
+  }
+  s->cinfo = cinfo;
+  s->row_bytes = (size_t)cinfo->image_width * cinfo->input_components;
+  s->pixels = (unsigned char *)malloc(s->row_bytes * cinfo->image_height);
+  if (!s->pixels) { free(s); ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0); }
+  pthread_mutex_lock(&g_lock);
+  s->next = g_states; g_states = s;
+  pthread_mutex_unlock(&g_lock);
+  cinfo->next_scanline = 0;
+  cinfo->global_state = CSTATE_SCANNING;
+}
+
+JDIMENSION jpeg_write_scanlines(j_compress_ptr cinfo, JSAMPARRAY scanlines, JDIMENSION num_lines)
+{
+  shim_state *s = find_state(cinfo, 0);
+  JDIMENSION rows_left, i;
+  if (!s) {
+    write_fn next = (write_fn)dlsym(RTLD_NEXT, "jpeg_write_scanlines");
+    if (next) return next(cinfo, scanlines, num_lines);
+    ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
+  }
+  if (cinfo->global_state != CSTATE_SCANNING) ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
+  if (cinfo->next_scanline >= cinfo->image_height) WARNMS(cinfo, JWRN_TOO_MUCH_DATA);
+  if (cinfo->progress != NULL) {
+    cinfo->progress->pass_counter = (long)cinfo->next_scanline;
+    cinfo->progress->pass_limit = (long)cinfo->image_height;
+    (*cinfo->progress->progress_monitor) ((j_common_ptr)cinfo);
+  }
+  rows_left = cinfo->image_height - cinfo->next_scanline;
+  if (num_lines > rows_left) num_lines = rows_left;
+  for (i = 0; i < num_lines; i++)
+    memcpy(s->pixels + (size_t)(cinfo->next_scanline + i) * s->row_bytes, scanlines[i], s->row_bytes);
+  cinfo->next_scanline += num_lines;
+  return num_lines;
+}
+
+void jpeg_finish_compress(j_compress_ptr cinfo)
+{
+  shim_state *s = find_state(cinfo, 0);
+  size_t n = 0;
+  unsigned char *buf;
+  if (!s) {
+    finish_fn next = (finish_fn)dlsym(RTLD_NEXT, "jpeg_finish_compress");
+    if (next) { next(cinfo); return; }
+    ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
+  }
+  if (cinfo->global_state != CSTATE_SCANNING) ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
+  if (cinfo->next_scanline < cinfo->image_height) ERREXIT(cinfo, JERR_TOO_LITTLE_DATA);
+  if (mjh_encode_host(t_enc, s->pixels, s->row_bytes, s->row_bytes * cinfo->image_height, 1) != MJH_OK ||
+      mjh_get_jpeg_size(t_enc, 0, &n) != MJH_OK) {
+    fprintf(stderr, "mozjpeg_hip: %s\n", mjh_last_error());
+    find_state(cinfo, 1); free(s->pixels); free(s);
+    ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0);
+  }
+  buf = (unsigned char *)malloc(n);
+  if (!buf || mjh_get_jpeg(t_enc, 0, buf, n, &n) != MJH_OK) {
+    fprintf(stderr, "mozjpeg_hip: %s\n", mjh_last_error());
+    find_state(cinfo, 1); free(buf); free(s->pixels); free(s);
+    ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0);
+  }
+  find_state(cinfo, 1);
+  /* the device wrote a complete file; SOI(+APP0) went out in jpeg_start_compress already */
+  emit_bytes(cinfo, buf + s->header_bytes, n - (size_t)s->header_bytes);
+  free(buf); free(s->pixels); free(s);
+  (*cinfo->dest->term_destination) (cinfo);
+  jpeg_abort((j_common_ptr)cinfo);   /* releases JPOOL_IMAGE, global_state = CSTATE_START (jcapimin.c:228) */
+}
