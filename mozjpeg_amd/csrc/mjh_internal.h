@@ -11,14 +11,14 @@
 // Huffman table slot as it lives in HBM (one per image and per role).
 // counts[] is the gather histogram (a10), bits/huffval the JHUFF_TBL content (a11),
 // ehufsi/ehufco the derived code lengths / codes (jchuff.c:231-318).
-struct MjhHuffTable {
+struct alignas(16) MjhHuffTable {
   uint32_t counts[260];   // 257 used
-  uint8_t bits[20];       // bits[1..16]
-  uint8_t huffval[256];
-  uint8_t ehufsi[256];
+  uint8_t ehufsi[256];    // 16-byte aligned: the trellis reads whole 16-symbol rows (run r: symbols 16r..16r+15)
   uint16_t ehufco[256];
+  uint8_t huffval[256];
+  uint8_t bits[20];       // bits[1..16]
   uint32_t nsyms;         // sum(bits[1..16])
-  uint32_t pad[3];
+  uint32_t pad[2];
 };
 
 // geometry of one component (initial_setup jcmaster.c:237-259)
@@ -49,6 +49,7 @@ struct MjhConst {
   int total_mcu_blocks;   // mcus * blocks_per_mcu (dummy blocks included)
   int total_real_blocks;  // sum of nblk
   int deringing;
+  int trellis;            // trellis_quant: the FDCT kernel also emits the per-block lambda
   int trellis_dc;
   int restart_interval;   // of the final interleaved scan, in MCUs (0 = none)
   float lambda_log_scale1, lambda_log_scale2;

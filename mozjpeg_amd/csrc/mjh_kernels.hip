@@ -182,7 +182,7 @@ __device__ __forceinline__ float catmull_rom(int v1, int v2, int v3, int v4, flo
 
 __global__ void __launch_bounds__(64)
 k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const uint8_t *__restrict__ planes,
-            int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q)
+            int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out)
 {
   __shared__ int lds[64][64];
   const int comp = blockIdx.y, img = blockIdx.z;
@@ -249,6 +249,19 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const uint8_t *__restric
   for (int c = 0; c < 8; c++)
     fdct8<1>(d[c], d[8 + c], d[16 + c], d[24 + c], d[32 + c], d[40 + c], d[48 + c], d[56 + c]);
 
+  if (C.trellis) {
+    // per-block trellis lambda (jcdctmgr.c:1027-1037): norm of the 63 AC coefficients summed in
+    // NATURAL index order in float, /63 in double, then lambda in double -> float.  pow(2, .) comes
+    // from the host libm.  Both trellis kernels consume it.
+    float norm = 0.0f;
+#pragma unroll
+    for (int n = 1; n < 64; n++) norm = norm + (float)(d[n] * d[n]);
+    norm = (float)((double)norm / 63.0);
+    float lambda;
+    if (C.lambda_log_scale2 > 0.0f) lambda = (float)(C.pow_scale1 * 1.0 / (C.pow_scale2 + (double)norm));
+    else lambda = (float)(C.pow_scale1 * 1.0);
+    lambda_out[(size_t)img * C.total_real_blocks + cc.blk_off + blk] = lambda;
+  }
   const float *rcp = Q->rcp8q[cc.qtbl];
   int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
   int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
@@ -549,156 +562,176 @@ k_gen_tables(MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 slots_a,
 // reference; such a position can never win (its cost is >= 1e38) and is zeroed by the
 // back-track, so it is simply not appended here.
 // =============================================================================================
-// The DP of one block.  `SI` returns AC code lengths, XS the block's raw coefficient at a zig-zag
-// position; NE is the capacity of the live-predecessor list.  Returns false (nothing written)
-// when the list would overflow -- the caller then defers the block to the full-capacity kernel.
-template <int NE, class SI, class XS>
-__device__ __forceinline__ bool trellis_ac_block(const SI &si, const XS &xsrc, int16_t *__restrict__ qo, int kstride,
+// The DP of one block.
+//  * live predecessors = positions whose chosen coefficient is non-zero: a 64-bit mask per lane
+//    (bit 0 = the virtual start), walked with ctz; entry e of the LDS columns belongs to the e-th
+//    set bit.  An entry is {azd, acc} (float2, one ds_read_b64) plus a 16-bit {back position,
+//    magnitude}; NE entries per lane.  Returns false, with nothing written, if the list would
+//    overflow -- the caller then defers the block to the full-capacity kernel.
+//  * AC code lengths are read one 16-symbol row (= one zero-run length) at a time as a uint4.
+//  * the 63 raw coefficients arrive in 8 chunks of 8 coalesced loads, chunk c+1 in flight while
+//    chunk c is processed, so the sequential DP never waits on HBM.
+//  * candidates 0..3 (|q| < 16) are unrolled; larger magnitudes take a rare dynamic loop.
+__device__ __forceinline__ int row_byte(const uint4 &r, int b)
+{
+  const unsigned w = b < 4 ? r.x : (b < 8 ? r.y : (b < 12 ? r.z : r.w));
+  return (int)((w >> (8 * (b & 3))) & 0xFFu);
+}
+
+template <int NE>
+__device__ __forceinline__ bool trellis_ac_block(const uint4 *si_rows, const int16_t *__restrict__ uq,
+                                                 int16_t *__restrict__ qo, int kstride,
                                                  const uint16_t *__restrict__ qz, const float *__restrict__ rcp,
                                                  const float *__restrict__ lt, float lambda,
-                                                 float (*e_azd)[64], float (*e_acc)[64], unsigned (*e_pk)[64], int lane)
+                                                 float2 (*e_aa)[64], unsigned short (*e_pk)[64], int lane)
 {
-  const int si_f0 = si(0xF0), si_eob = si(0);
+  const int si_f0 = (int)(si_rows[15].x & 0xFFu), si_eob = (int)(si_rows[0].x & 0xFFu);
+  unsigned long long live = 1ull, neg = 0ull;
   int nlive = 1;
-  e_azd[0][lane] = 0.0f;
-  e_acc[0][lane] = 0.0f;
-  e_pk[0][lane] = 0u;
+  e_aa[0][lane] = make_float2(0.0f, 0.0f);
   float azd_prev = 0.0f;
-  for (int i = 1; i < 64; i++) {
-    const int xs = xsrc(i);
-    const int x = xs < 0 ? -xs : xs;
-    const int dq = 8 * (int)qz[i];
-    float t = (float)(x * x) * lambda;
-    t = t * lt[i];
-    const float azd_cur = t + azd_prev;
-    if (x + (dq >> 1) >= dq) {                      // qval != 0
-      int qval = udiv_exact(x + (dq >> 1), dq, rcp[i]);
-      if (qval >= 1024) qval = 1023;
-      const int ncd = bitlen((unsigned)qval);
-      float dist[10];
+  short xn[8];
 #pragma unroll
-      for (int k = 0; k < 10; k++) {
-        if (k < ncd) {
+  for (int j = 0; j < 8; j++) xn[j] = uq[(size_t)j * kstride];
+  for (int c = 0; c < 8; c++) {
+    short xc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) xc[j] = xn[j];
+    if (c < 7) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) xn[j] = uq[(size_t)(8 * (c + 1) + j) * kstride];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int i = 8 * c + j;
+      if (j == 0 && c == 0) continue;
+      const int xs = xc[j];
+      const int x = xs < 0 ? -xs : xs;
+      const int dq = 8 * (int)qz[i];
+      const float lti = lt[i];
+      float t = (float)(x * x) * lambda;
+      t = t * lti;
+      const float azd_cur = t + azd_prev;
+      if (x + (dq >> 1) >= dq) {                      // qval != 0
+        int qval = udiv_exact(x + (dq >> 1), dq, rcp[i]);
+        if (qval >= 1024) qval = 1023;
+        const int ncd = bitlen((unsigned)qval);
+        float dist[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
           const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
           const int delta = cand * dq - x;
           float d = (float)(delta * delta) * lambda;
-          dist[k] = d * lt[i];
-        } else dist[k] = 0.0f;
-      }
-      float best = 1e38f;
-      int beste = -1, bestk = 0;
-      for (int e = 0; e < nlive; e++) {
-        const int pos = (int)(e_pk[e][lane] & 63u);
-        const int zero_run = i - 1 - pos;
-        const int hi = zero_run >> 4;
-        if (hi && si_f0 == 0) continue;
-        float rhs = azd_prev - e_azd[e][lane];
-        rhs = rhs + e_acc[e][lane];
-        const int rbase = hi * si_f0;
-        const int sbase = 16 * (zero_run & 15) + 1;
+          dist[k] = d * lti;
+        }
+        float best = 1e38f;
+        int bestp = -1, bestk = 0;
+        unsigned long long m = live;
+        int e = 0;
+        while (m) {
+          const int p = __builtin_ctzll(m);
+          m &= m - 1;
+          const float2 aa = e_aa[e][lane];
+          e++;
+          const int zero_run = i - 1 - p;
+          const int hi = zero_run >> 4;
+          if (hi && si_f0 == 0) continue;
+          const uint4 row = si_rows[zero_run & 15];
+          float rhs = azd_prev - aa.x;
+          rhs = rhs + aa.y;
+          const int rbase = hi * si_f0;
 #pragma unroll
-        for (int k = 0; k < 10; k++) {
-          if (k < ncd) {
-            const int cb = si(sbase + k);
-            if (cb != 0) {
+          for (int k = 0; k < 4; k++) {
+            const int cb = row_byte(row, k + 1);
+            if (k < ncd && cb != 0) {
               float cost = (float)(cb + (k + 1) + rbase) + dist[k];
               cost = cost + rhs;
-              if (cost < best) { best = cost; beste = e; bestk = k; }
+              if (cost < best) { best = cost; bestp = p; bestk = k; }
+            }
+          }
+          for (int k = 4; k < ncd; k++) {             // |q| >= 16: rare
+            const int cb = row_byte(row, k + 1);
+            if (cb != 0) {
+              const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
+              const int delta = cand * dq - x;
+              float d = (float)(delta * delta) * lambda;
+              d = d * lti;
+              float cost = (float)(cb + (k + 1) + rbase) + d;
+              cost = cost + rhs;
+              if (cost < best) { best = cost; bestp = p; bestk = k; }
             }
           }
         }
+        if (bestp >= 0) {
+          if (nlive >= NE) return false;
+          const int mag = (bestk < ncd - 1) ? (2 << bestk) - 1 : qval;
+          e_aa[nlive][lane] = make_float2(azd_cur, best);
+          e_pk[nlive][lane] = (unsigned short)(bestp | (mag << 6));
+          live |= 1ull << i;
+          if (xs < 0) neg |= 1ull << i;
+          nlive++;
+        }
       }
-      if (beste >= 0) {
-        if (nlive >= NE) return false;
-        const int bestv = (bestk < ncd - 1) ? (2 << bestk) - 1 : qval;
-        const int v = xs < 0 ? -bestv : bestv;
-        e_azd[nlive][lane] = azd_cur;
-        e_acc[nlive][lane] = best;
-        e_pk[nlive][lane] = (unsigned)i | ((unsigned)beste << 6) | (((unsigned)v & 0xFFFFu) << 12);
-        nlive++;
-      }
+      azd_prev = azd_cur;
     }
-    azd_prev = azd_cur;
   }
   // end-of-block choice (jcdctmgr.c:1187-1207); azd_prev == accumulated_zero_dist[63]
   float best_cost = azd_prev + (float)si_eob;
   int last = 0;
-  for (int e = 1; e < nlive; e++) {
-    float cost = e_acc[e][lane] + azd_prev;
-    cost = cost - e_azd[e][lane];
-    if ((int)(e_pk[e][lane] & 63u) < 63) cost = cost + (float)si_eob;
-    if (cost < best_cost) { best_cost = cost; last = e; }
+  {
+    unsigned long long m = live & ~1ull;
+    int e = 1;
+    while (m) {
+      const int p = __builtin_ctzll(m);
+      m &= m - 1;
+      const float2 aa = e_aa[e][lane];
+      e++;
+      float cost = aa.y + azd_prev;
+      cost = cost - aa.x;
+      if (p < 63) cost = cost + (float)si_eob;
+      if (cost < best_cost) { best_cost = cost; last = p; }
+    }
   }
   // back-track (jcdctmgr.c:1211-1222) fused with the store of the 63 AC planes
-  int cur = last;
-  unsigned pk = e_pk[cur][lane];
+  int p = last;
   for (int k = 63; k >= 1; k--) {
     int v = 0;
-    if (cur != 0 && (int)(pk & 63u) == k) {
-      v = (int)(int16_t)(pk >> 12);
-      cur = (int)((pk >> 6) & 63u);
-      pk = e_pk[cur][lane];
+    if (k == p) {
+      const int e = __popcll(live & ((1ull << k) - 1ull));
+      const unsigned pk = e_pk[e][lane];
+      const int mag = (int)(pk >> 6);
+      v = ((neg >> k) & 1ull) ? -mag : mag;
+      p = (int)(pk & 63u);
     }
     qo[(size_t)k * kstride] = (int16_t)v;
   }
   return true;
 }
 
-// norm / lambda of one block (jcdctmgr.c:1027-1037): 63 coalesced loads in one burst, summed in
-// NATURAL index order; optionally parks the values in an LDS column for the DP loop.
-template <bool STAGE>
-__device__ __forceinline__ float trellis_lambda(const MjhConst &C, const int16_t *__restrict__ uq, int kstride, short (*s_x)[64], int lane)
-{
-  float norm = 0.0f;
-#pragma unroll
-  for (int n = 1; n < 64; n++) {
-    const int x = uq[(size_t)kIZZ.v[n] * kstride];
-    if (STAGE) s_x[kIZZ.v[n]][lane] = (short)x;
-    norm = norm + (float)(x * x);
-  }
-  norm = (float)((double)norm / 63.0);
-  if (C.lambda_log_scale2 > 0.0f) return (float)(C.pow_scale1 * 1.0 / (C.pow_scale2 + (double)norm));
-  return (float)(C.pow_scale1 * 1.0);
-}
-
-struct SiLds { const unsigned char *p; __device__ __forceinline__ int operator()(int i) const { return p[i]; } };
-struct SiGlobal { const uint8_t *p; __device__ __forceinline__ int operator()(int i) const { return p[i]; } };
-struct XsLds { short (*p)[64]; int lane; __device__ __forceinline__ int operator()(int i) const { return p[i][lane]; } };
-struct XsGlobal { const int16_t *p; int kstride; __device__ __forceinline__ int operator()(int i) const { return p[(size_t)i * kstride]; } };
-
 // fast path: NE live entries per lane in LDS; blocks that need more go to the work list
-template <int NE, bool STAGE>
+template <int NE>
 __global__ void __launch_bounds__(64)
 k_trellis_ac(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
              int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
-             int4 ac_slot_of_comp, float *__restrict__ lambda_out, unsigned *__restrict__ worklist)
+             int4 ac_slot_of_comp, const float *__restrict__ lambda_in, unsigned *__restrict__ worklist)
 {
-  __shared__ float e_azd[NE][64];
-  __shared__ float e_acc[NE][64];
-  __shared__ unsigned e_pk[NE][64];   // pos | from<<6 | (value & 0xFFFF) << 12
-  __shared__ short s_x[STAGE ? 64 : 1][64];
-  __shared__ unsigned char si[256];
+  __shared__ float2 e_aa[NE][64];
+  __shared__ unsigned short e_pk[NE][64];   // back position | magnitude << 6
+  __shared__ uint4 si_rows[16];
   const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
   const int lane = threadIdx.x;
   const int slot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
   const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
-#pragma unroll
-  for (int t = 0; t < 4; t++) si[lane + 64 * t] = T->ehufsi[lane + 64 * t];
+  if (lane < 16) si_rows[lane] = reinterpret_cast<const uint4 *>(T->ehufsi)[lane];
   __syncthreads();
   const int blk = blockIdx.x * 64 + lane;
   if (blk >= cc.nblk) return;
   const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
   int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
-  const float lambda = trellis_lambda<STAGE>(C, uq, cc.kstride, s_x, lane);
-  lambda_out[(size_t)img * C.total_real_blocks + cc.blk_off + blk] = lambda;
-  bool ok;
-  if (STAGE)
-    ok = trellis_ac_block<NE>(SiLds{ si }, XsLds{ s_x, lane }, qo, cc.kstride, Q->q[cc.qtbl], Q->rcp8q[cc.qtbl], Q->lambda_tbl[cc.qtbl],
-                              lambda, e_azd, e_acc, e_pk, lane);
-  else
-    ok = trellis_ac_block<NE>(SiLds{ si }, XsGlobal{ uq, cc.kstride }, qo, cc.kstride, Q->q[cc.qtbl], Q->rcp8q[cc.qtbl], Q->lambda_tbl[cc.qtbl],
-                              lambda, e_azd, e_acc, e_pk, lane);
+  const float lambda = lambda_in[(size_t)img * C.total_real_blocks + cc.blk_off + blk];
+  const bool ok = trellis_ac_block<NE>(si_rows, uq, qo, cc.kstride, Q->q[cc.qtbl], Q->rcp8q[cc.qtbl], Q->lambda_tbl[cc.qtbl],
+                                       lambda, e_aa, e_pk, lane);
   if (!ok) {
     const unsigned idx = atomicAdd(&worklist[0], 1u);
     worklist[4 + 2 * (size_t)idx] = (unsigned)img;
@@ -712,9 +745,8 @@ k_trellis_ac_deferred(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t 
                       int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
                       int4 ac_slot_of_comp, const float *__restrict__ lambda_in, const unsigned *__restrict__ worklist)
 {
-  __shared__ float e_azd[64][64];
-  __shared__ float e_acc[64][64];
-  __shared__ unsigned e_pk[64][64];
+  __shared__ float2 e_aa[64][64];
+  __shared__ unsigned short e_pk[64][64];
   const int lane = threadIdx.x;
   const unsigned count = worklist[0];
   for (unsigned it = blockIdx.x * 64 + lane; it < count; it += gridDim.x * 64) {
@@ -727,8 +759,8 @@ k_trellis_ac_deferred(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t 
     const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
     int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
     const float lambda = lambda_in[(size_t)img * C.total_real_blocks + cc.blk_off + blk];
-    trellis_ac_block<64>(SiGlobal{ T->ehufsi }, XsGlobal{ uq, cc.kstride }, qo, cc.kstride, Q->q[cc.qtbl], Q->rcp8q[cc.qtbl],
-                         Q->lambda_tbl[cc.qtbl], lambda, e_azd, e_acc, e_pk, lane);
+    trellis_ac_block<64>(reinterpret_cast<const uint4 *>(T->ehufsi), uq, qo, cc.kstride, Q->q[cc.qtbl], Q->rcp8q[cc.qtbl],
+                         Q->lambda_tbl[cc.qtbl], lambda, e_aa, e_pk, lane);
   }
 }
 
@@ -1268,10 +1300,10 @@ void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size
 static int max_nblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp; i++) m = C.c[i].nblk > m ? C.c[i].nblk : m; return m; }
 static int max_padblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp; i++) { int v = C.c[i].wpad * C.c[i].hpad; m = v > m ? v : m; } return m; }
 
-void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, int n, hipStream_t s)
+void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda, int n, hipStream_t s)
 {
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
-  hipLaunchKernelGGL(k_dct_quant, grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q);
+  hipLaunchKernelGGL(k_dct_quant, grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda);
 }
 
 void mjh_launch_stats_ac(const MjhConst &C, const void *q, MjhHuffTable *tabs, int spi, const int slot[4], int count_dummies, int n, hipStream_t s)
@@ -1301,22 +1333,22 @@ void mjh_launch_gen_tables(MjhHuffTable *tabs, int spi, const int *slots, int ns
   hipLaunchKernelGGL(k_gen_tables, dim3(nslots, n), dim3(64), 0, s, tabs, spi, make_int4(sl[0], sl[1], sl[2], sl[3]), make_int4(sl[4], sl[5], sl[6], sl[7]));
 }
 
-void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], float *lambda, unsigned *worklist, int variant, int n, hipStream_t s)
+void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda, unsigned *worklist, int variant, int n, hipStream_t s)
 {
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
   const int4 sl = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
   (void)hipMemsetAsync(worklist, 0, 16, s);
-#define LT(NE, ST) hipLaunchKernelGGL((k_trellis_ac<NE, ST>), grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, worklist)
+#define LT(NE) hipLaunchKernelGGL((k_trellis_ac<NE>), grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, worklist)
   switch (variant) {
-    case 1: LT(16, false); break;
-    case 2: LT(24, true); break;
-    case 3: LT(16, true); break;
-    case 4: LT(32, false); break;
-    case 5: LT(12, false); break;
-    default: LT(24, false); break;
+    case 1: LT(12); break;
+    case 2: LT(20); break;
+    case 3: LT(24); break;
+    case 4: LT(32); break;
+    case 5: LT(4); break;
+    default: LT(16); break;
   }
 #undef LT
-  hipLaunchKernelGGL(k_trellis_ac_deferred, dim3(512), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, (const float *)lambda, (const unsigned *)worklist);
+  hipLaunchKernelGGL(k_trellis_ac_deferred, dim3(1024), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, (const unsigned *)worklist);
 }
 
 void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s)
