@@ -142,6 +142,9 @@ struct mjh_encoder {
   MjhHuffTable *d_tabs = nullptr, *d_tabs_init = nullptr;
   float *d_lambda = nullptr;
   uint8_t *d_back = nullptr;
+  unsigned *d_seg_x = nullptr, *d_seg_E = nullptr, *d_seg_sums = nullptr, *d_seg_totals = nullptr, *d_mpos = nullptr;
+  int nseg = 1;
+  int comp_restart[4] = { 0, 0, 0, 0 };
   unsigned *d_worklist = nullptr;   // deferred trellis blocks: [0] = count, [4+2i], [5+2i] = (image, comp<<28|block)
   int trellis_variant = 0;
   uint16_t *d_len16 = nullptr;
@@ -190,7 +193,7 @@ static int check_supported(const mjh_params *p)
       if (p->quantval[p->quant_tbl_no[i]][k] == 0) return fail(MJH_EINVAL, "quantization table %d has a zero entry", p->quant_tbl_no[i]);
   }
   if (p->num_scans != 0) return fail(MJH_EUNSUPPORTED, "progressive scan scripts are not on the GPU path yet");
-  if (p->restart_interval != 0 || p->restart_in_rows != 0) return fail(MJH_EUNSUPPORTED, "restart intervals are not on the GPU path yet");
+  if (p->restart_interval > 65535u || p->restart_in_rows < 0) return fail(MJH_EINVAL, "bad restart interval");
   if (p->trellis_quant && !p->optimize_coding) return fail(MJH_EUNSUPPORTED, "trellis_quant requires optimize_coding (jcmaster.c:686-702 never selects a component otherwise)");
   if (!p->optimize_coding) {
     for (int i = 0; i < p->num_components; i++)
@@ -241,7 +244,13 @@ static void build_const(const mjh_params *p, MjhConst *C)
   C->deringing = p->overshoot_deringing;
   C->trellis = p->trellis_quant;
   C->trellis_dc = p->trellis_quant_dc;
-  C->restart_interval = 0;
+  // per_scan_setup jcmaster.c:595-600: restart_in_rows is converted per scan; here for the final
+  // interleaved scan (the per-component statistics passes use their own MCUs_per_row, T10)
+  C->restart_interval = (int)p->restart_interval;
+  if (p->restart_in_rows > 0) {
+    const long nominal = (long)p->restart_in_rows * C->mcus_per_row;
+    C->restart_interval = (int)(nominal < 65535L ? nominal : 65535L);
+  }
   C->lambda_log_scale1 = p->lambda_log_scale1;
   C->lambda_log_scale2 = p->lambda_log_scale2;
   // pow() evaluated by the host libm, like the reference (jcdctmgr.c:1033-1037)
@@ -314,8 +323,10 @@ static void build_prefix(const mjh_params *p, std::vector<uint8_t> &o, bool *bas
   }
 }
 
-static void build_sos(const mjh_params *p, std::vector<uint8_t> &o)
-{                                                           // emit_sos :494-531, sequential scan of all components
+static void build_sos(const mjh_params *p, int restart_interval, std::vector<uint8_t> &o)
+{                                                           // emit_dri :452 (only when != 0, write_scan_header :778-781)
+  if (restart_interval) { o.push_back(0xFF); o.push_back(0xDD); put2(o, 4); put2(o, restart_interval); }
+                                                            // emit_sos :494-531, sequential scan of all components
   o.push_back(0xFF); o.push_back(0xDA);
   put2(o, 2 * p->num_components + 2 + 1 + 3);
   o.push_back((uint8_t)p->num_components);
@@ -379,7 +390,7 @@ static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *ptrs[] = { e->d_pix, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist,
+  void *ptrs[] = { e->d_pix, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -439,6 +450,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   e->chunks = (C.total_mcu_blocks + 2047) / 2048;
   // worst case 1665 bits per block (DC 16+11, 63 x (16+10)) -> 53 words
   size_t words = (size_t)C.total_mcu_blocks * 53 + 64;
+  if (C.restart_interval) words += (size_t)(C.mcus_per_row * C.mcu_rows) / C.restart_interval + 1;   // pad + RSTn per interval
   if (words > (size_t)1 << 27) words = (size_t)1 << 27;   // bit offsets are 32-bit
   e->stream_words = (words + 63) & ~(size_t)63;
   e->ff_chunks = (int)((e->stream_words + 2047) / 2048);
@@ -450,6 +462,21 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   e->out_stride = ((size_t)2048 + e->stream_words * 8 + 255) & ~(size_t)255;
   HIPCHK_E(hipMalloc((void **)&e->d_out, B * e->out_stride));
   HIPCHK_E(hipMalloc((void **)&e->d_sizes, B * sizeof(unsigned)));
+  {
+    const int nmcu = C.mcus_per_row * C.mcu_rows;
+    e->nseg = C.restart_interval ? (nmcu + C.restart_interval - 1) / C.restart_interval : 1;
+    for (int i = 0; i < C.ncomp; i++) {     // restart interval of the per-component statistics passes, in blocks
+      long ri = p->restart_interval;
+      if (p->restart_in_rows > 0) { ri = (long)p->restart_in_rows * C.c[i].wib; if (ri > 65535L) ri = 65535L; }
+      e->comp_restart[i] = (int)ri;
+    }
+    const size_t ns = (size_t)e->nseg;
+    HIPCHK_E(hipMalloc((void **)&e->d_seg_x, B * ns * 4));
+    HIPCHK_E(hipMalloc((void **)&e->d_seg_E, B * ns * 4));
+    HIPCHK_E(hipMalloc((void **)&e->d_mpos, B * ns * 4));
+    HIPCHK_E(hipMalloc((void **)&e->d_seg_sums, B * ((ns + 2047) / 2048) * 4));
+    HIPCHK_E(hipMalloc((void **)&e->d_seg_totals, B * 4));
+  }
   HIPCHK_E(hipMalloc(&e->d_meta, B * sizeof(MjhImageMeta)));
   e->h_sizes.resize(B);
 
@@ -485,7 +512,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     std::vector<uint8_t> pre, sos;
     bool base;
     build_prefix(p, pre, &base);
-    build_sos(p, sos);
+    build_sos(p, C.restart_interval, sos);
     e->prefix_len = (int)pre.size();
     e->sos_len = (int)sos.size();
     HIPCHK_E(hipMalloc((void **)&e->d_prefix, pre.size()));
@@ -548,7 +575,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     pr.mark("stats_ac(pre-trellis)");
     mjh_launch_stats_ac(C, e->d_q, e->d_tabs, spi, tr_ac, 0, n, s);
     pr.mark("stats_dc(pre-trellis)");
-    mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, tr_dc, 0, zero4, n, s);
+    mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, tr_dc, 0, e->comp_restart, n, s);
     int slots[8], ns = 0;
     for (int i = 0; i < C.ncomp; i++) { slots[ns++] = tr_dc[i]; slots[ns++] = tr_ac[i]; }
     pr.mark("gen_tables(trellis)");
@@ -591,10 +618,10 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
                     p.compress_profile != MJH_PROFILE_FASTEST, e->d_out, e->out_stride, e->d_meta, n, s);
   pr.mark("huff_encode");
   mjh_launch_encode(C, e->d_q, e->d_tabs, spi, fin_dc, fin_ac, e->d_len16, e->d_off32, e->d_sums, e->chunks, e->d_totals,
-                    e->d_stream, e->stream_words, e->d_meta, n, s);
+                    e->d_stream, e->stream_words, e->d_meta, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos, e->nseg, n, s);
   pr.mark("byte_stuff");
   mjh_launch_stuff(e->d_stream, e->stream_words, e->d_totals, e->d_ffsums, e->ff_chunks, e->d_fftotals, e->d_out, e->out_stride,
-                   e->d_meta, e->d_sizes, n, s);
+                   e->d_meta, e->d_sizes, e->d_mpos, e->nseg, n, s);
   pr.mark(nullptr);
   HIPCHK(hipGetLastError());
   return MJH_OK;

@@ -1014,12 +1014,13 @@ __device__ __forceinline__ unsigned block_excl_scan_256(unsigned v, unsigned *sh
   return base + inc - v;
 }
 
+template <class T>
 __global__ void __launch_bounds__(256)
-k_chunk_sums_u16(const uint16_t *__restrict__ len16, int n_per_image, unsigned *__restrict__ sums, int chunks_per_image)
+k_chunk_sums(const T *__restrict__ len16, int n_per_image, unsigned *__restrict__ sums, int chunks_per_image)
 {
   __shared__ unsigned sh[4];
   const int img = blockIdx.y, chunk = blockIdx.x;
-  const uint16_t *p = len16 + (size_t)img * n_per_image;
+  const T *p = len16 + (size_t)img * n_per_image;
   unsigned s = 0;
   const int base = chunk * SCAN_CHUNK + threadIdx.x * 8;
 #pragma unroll
@@ -1047,13 +1048,14 @@ k_scan_sums(unsigned *__restrict__ sums, int chunks_per_image, unsigned *__restr
   if (threadIdx.x == 0) totals[img] = carry;
 }
 
+template <class T>
 __global__ void __launch_bounds__(256)
-k_offsets_u16(const uint16_t *__restrict__ len16, int n_per_image, const unsigned *__restrict__ sums,
-              int chunks_per_image, unsigned *__restrict__ off32)
+k_offsets(const T *__restrict__ len16, int n_per_image, const unsigned *__restrict__ sums,
+          int chunks_per_image, unsigned *__restrict__ off32)
 {
   __shared__ unsigned sh[4];
   const int img = blockIdx.y, chunk = blockIdx.x;
-  const uint16_t *p = len16 + (size_t)img * n_per_image;
+  const T *p = len16 + (size_t)img * n_per_image;
   unsigned *o = off32 + (size_t)img * n_per_image;
   const int base = chunk * SCAN_CHUNK + threadIdx.x * 8;
   unsigned v[8], s = 0;
@@ -1062,6 +1064,38 @@ k_offsets_u16(const uint16_t *__restrict__ len16, int n_per_image, const unsigne
   unsigned ex = block_excl_scan_256(s, sh, nullptr) + sums[(size_t)img * chunks_per_image + chunk];
 #pragma unroll
   for (int i = 0; i < 8; i++) { if (base + i < n_per_image) o[base + i] = ex; ex += v[i]; }
+}
+
+// ---- restart intervals (emit_restart jchuff.c:668-686): the scan is cut into segments of
+// restart_interval MCUs; every segment but the last is padded with 1-bits to a byte boundary and
+// followed by an RSTn marker.  seg_x[s] = bits added after segment s; its exclusive prefix seg_E
+// shifts the bit offsets of all later blocks.
+__global__ void __launch_bounds__(256)
+k_seg_extra(MjhConst C, const unsigned *__restrict__ off32, const unsigned *__restrict__ totals,
+            unsigned *__restrict__ seg_x, int nseg)
+{
+  const int img = blockIdx.y;
+  const int sidx = blockIdx.x * 256 + threadIdx.x;
+  if (sidx >= nseg) return;
+  const unsigned *o = off32 + (size_t)img * C.total_mcu_blocks;
+  const long long per = (long long)C.restart_interval * C.blocks_per_mcu;
+  const long long bs = sidx * per, be = bs + per;
+  const unsigned start = o[bs];
+  const unsigned end = be < C.total_mcu_blocks ? o[be] : totals[img];
+  const unsigned L = end - start;
+  seg_x[(size_t)img * nseg + sidx] = sidx < nseg - 1 ? ((8u - (L & 7u)) & 7u) + 16u : 0u;
+}
+
+__device__ __forceinline__ bool is_marker_pos(const unsigned *__restrict__ mpos, int nmark, unsigned bytepos)
+{
+  int lo = 0, hi = nmark - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const unsigned v = mpos[mid];
+    if (v == bytepos) return true;
+    if (v < bytepos) lo = mid + 1; else hi = mid - 1;
+  }
+  return false;
 }
 
 // bit writer: ORs big-endian bit strings into a zero-initialised word array
@@ -1094,7 +1128,8 @@ struct BitWriter {
 __global__ void __launch_bounds__(256)
 k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs,
             int slots_per_image, int4 dc_slot_of_comp, int4 ac_slot_of_comp,
-            const unsigned *__restrict__ off32, unsigned *__restrict__ stream, size_t stream_words_per_image)
+            const unsigned *__restrict__ off32, unsigned *__restrict__ stream, size_t stream_words_per_image,
+            const unsigned *__restrict__ seg_E, unsigned *__restrict__ mpos, int nseg)
 {
   __shared__ unsigned s_ac[256];   // size << 16 | code
   __shared__ unsigned s_dc[16];
@@ -1116,8 +1151,11 @@ k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *
   int pr, pc, pred = 0;
   if (mcu_prev_block(C, cc, r, c, pr, pc)) pred = q[dc_source_block(cc, pr, pc)];
   BitWriter bw;
+  const int mcu = (r / cc.v) * C.mcus_per_row + c / cc.h;
+  const int segi = C.restart_interval ? mcu / C.restart_interval : 0;
   bw.init(stream + (size_t)img * stream_words_per_image,
-          off32[(size_t)img * C.total_mcu_blocks + mcu_position(C, cc, r, c)]);
+          off32[(size_t)img * C.total_mcu_blocks + mcu_position(C, cc, r, c)] +
+          (nseg > 1 ? seg_E[(size_t)img * nseg + segi] : 0u));
   {
     const int df = dc - pred;
     const int a = df < 0 ? -df : df;
@@ -1144,6 +1182,15 @@ k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *
   } else {
     const unsigned e = s_ac[0];
     bw.put(e & 0xFFFF, (int)(e >> 16));
+  }
+  if (C.restart_interval && segi < nseg - 1 && (mcu + 1) % C.restart_interval == 0 &&
+      cc.mcu_blk0 + (r % cc.v) * cc.h + (c % cc.h) == C.blocks_per_mcu - 1) {
+    // last block of a restart interval: pad with 1-bits, then RSTn (n = interval index mod 8)
+    const unsigned bitpos = bw.widx * 32u + (unsigned)bw.nacc;
+    const int pad = (int)((8u - (bitpos & 7u)) & 7u);
+    if (pad) bw.put((1u << pad) - 1u, pad);
+    mpos[(size_t)img * nseg + segi] = (bitpos + (unsigned)pad) >> 3;
+    bw.put(0xFFD0u + (unsigned)(segi & 7), 16);
   }
   bw.flush();
 }
@@ -1191,12 +1238,13 @@ k_header(const uint8_t *__restrict__ prefix, int prefix_len, const uint8_t *__re
 
 // after the bit offsets are known: pad the last partial byte with 1-bits (jchuff.c:505-514)
 __global__ void __launch_bounds__(64)
-k_finish_bits(const unsigned *__restrict__ totals, unsigned *__restrict__ stream, size_t stream_words_per_image,
-              MjhImageMeta *__restrict__ meta, int nimg)
+k_finish_bits(unsigned *__restrict__ totals, const unsigned *__restrict__ seg_totals, unsigned *__restrict__ stream,
+              size_t stream_words_per_image, MjhImageMeta *__restrict__ meta, int nimg)
 {
   const int img = blockIdx.x * 64 + threadIdx.x;
   if (img >= nimg) return;
-  const unsigned tb = totals[img];
+  const unsigned tb = totals[img] + (seg_totals ? seg_totals[img] : 0u);
+  totals[img] = tb;   // from here on: total bits of the scan including restart padding and markers
   meta[img].total_bits = tb;
   if (tb & 7) {
     const unsigned padbits = 8 - (tb & 7);
@@ -1221,7 +1269,7 @@ __device__ __forceinline__ unsigned ff_count(unsigned w)
 
 __global__ void __launch_bounds__(256)
 k_ff_chunk_sums(const unsigned *__restrict__ stream, size_t stream_words_per_image, const unsigned *__restrict__ totals,
-                unsigned *__restrict__ sums, int chunks_per_image)
+                unsigned *__restrict__ sums, int chunks_per_image, const unsigned *__restrict__ mpos_all, int nseg)
 {
   __shared__ unsigned sh[4];
   const int img = blockIdx.y, chunk = blockIdx.x;
@@ -1230,8 +1278,17 @@ k_ff_chunk_sums(const unsigned *__restrict__ stream, size_t stream_words_per_ima
   const unsigned *p = stream + (size_t)img * stream_words_per_image;
   unsigned s = 0;
   const unsigned base = chunk * SCAN_CHUNK + threadIdx.x * 8;
+  const unsigned *mpos = nseg > 1 ? mpos_all + (size_t)img * nseg : nullptr;
 #pragma unroll
-  for (int i = 0; i < 8; i++) if (base + i < nwords) s += ff_count(p[base + i]);  // bytes past nbytes are zero
+  for (int i = 0; i < 8; i++) if (base + i < nwords) {  // bytes past nbytes are zero
+    const unsigned w = p[base + i];
+    unsigned cnt = ff_count(w);
+    if (cnt && mpos) {   // the 0xFF of an RSTn marker is not data: never stuffed
+      for (int b = 0; b < 4; b++)
+        if (((w >> (8 * b)) & 0xFFu) == 0xFFu && is_marker_pos(mpos, nseg - 1, (base + i) * 4 + b)) cnt--;
+    }
+    s += cnt;
+  }
   const unsigned tot = block_reduce_256(s, sh);
   if (threadIdx.x == 0) sums[(size_t)img * chunks_per_image + chunk] = tot;
 }
@@ -1239,7 +1296,8 @@ k_ff_chunk_sums(const unsigned *__restrict__ stream, size_t stream_words_per_ima
 __global__ void __launch_bounds__(256)
 k_stuff_write(const unsigned *__restrict__ stream, size_t stream_words_per_image, const unsigned *__restrict__ totals,
               const unsigned *__restrict__ sums, int chunks_per_image, const unsigned *__restrict__ ff_totals,
-              uint8_t *__restrict__ out, size_t out_stride, MjhImageMeta *__restrict__ meta, unsigned *__restrict__ sizes)
+              uint8_t *__restrict__ out, size_t out_stride, MjhImageMeta *__restrict__ meta, unsigned *__restrict__ sizes,
+              const unsigned *__restrict__ mpos_all, int nseg)
 {
   __shared__ unsigned sh[4];
   const int img = blockIdx.y, chunk = blockIdx.x;
@@ -1249,9 +1307,19 @@ k_stuff_write(const unsigned *__restrict__ stream, size_t stream_words_per_image
   const unsigned hdr = meta[img].hdr_len;
   uint8_t *o = out + (size_t)img * out_stride + hdr;
   const unsigned base = chunk * SCAN_CHUNK + threadIdx.x * 8;
+  const unsigned *mpos = nseg > 1 ? mpos_all + (size_t)img * nseg : nullptr;
   unsigned w[8], s = 0;
+  unsigned mk = 0;   // bit (4*i+b) set: byte b of word i is the 0xFF of a restart marker
 #pragma unroll
-  for (int i = 0; i < 8; i++) { w[i] = base + i < nwords ? p[base + i] : 0u; s += ff_count(w[i]); }
+  for (int i = 0; i < 8; i++) {
+    w[i] = base + i < nwords ? p[base + i] : 0u;
+    unsigned cnt = ff_count(w[i]);
+    if (cnt && mpos) {
+      for (int b = 0; b < 4; b++)
+        if (((w[i] >> (8 * b)) & 0xFFu) == 0xFFu && is_marker_pos(mpos, nseg - 1, (base + i) * 4 + b)) { cnt--; mk |= 1u << (4 * i + b); }
+    }
+    s += cnt;
+  }
   unsigned ex = block_excl_scan_256(s, sh, nullptr) + sums[(size_t)img * chunks_per_image + chunk];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -1263,7 +1331,7 @@ k_stuff_write(const unsigned *__restrict__ stream, size_t stream_words_per_image
         const unsigned byte = (w[i] >> (8 * b)) & 0xFF;   // little-endian word = stream byte order
         if (wi * 4 + b < nbytes) {
           o[dst++] = (uint8_t)byte;
-          if (byte == 0xFF) { o[dst++] = 0; ex++; }
+          if (byte == 0xFF && !((mk >> (4 * i + b)) & 1u)) { o[dst++] = 0; ex++; }
         }
       }
     }
@@ -1360,17 +1428,29 @@ void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq,
 
 void mjh_launch_encode(const MjhConst &C, const void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const int ac_slot[4],
                        void *len16, void *off32, unsigned *sums, int chunks_per_image, unsigned *totals,
-                       unsigned *stream, size_t stream_words_per_image, void *meta, int n, hipStream_t s)
+                       unsigned *stream, size_t stream_words_per_image, void *meta,
+                       unsigned *seg_x, unsigned *seg_E, unsigned *seg_sums, unsigned *seg_totals, unsigned *mpos, int nseg,
+                       int n, hipStream_t s)
 {
   const int4 ds = make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]);
   const int4 as = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
   dim3 grid((max_padblk(C) + 255) / 256, C.ncomp, n);
   hipLaunchKernelGGL(k_enc_len, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, ds, as, (uint16_t *)len16);
-  hipLaunchKernelGGL(k_chunk_sums_u16, dim3(chunks_per_image, n), dim3(256), 0, s, (const uint16_t *)len16, C.total_mcu_blocks, sums, chunks_per_image);
+  hipLaunchKernelGGL((k_chunk_sums<uint16_t>), dim3(chunks_per_image, n), dim3(256), 0, s, (const uint16_t *)len16, C.total_mcu_blocks, sums, chunks_per_image);
   hipLaunchKernelGGL(k_scan_sums, dim3(n), dim3(256), 0, s, sums, chunks_per_image, totals);
-  hipLaunchKernelGGL(k_offsets_u16, dim3(chunks_per_image, n), dim3(256), 0, s, (const uint16_t *)len16, C.total_mcu_blocks, sums, chunks_per_image, (unsigned *)off32);
-  hipLaunchKernelGGL(k_enc_write, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image);
-  hipLaunchKernelGGL(k_finish_bits, dim3((n + 63) / 64), dim3(64), 0, s, totals, stream, stream_words_per_image, (MjhImageMeta *)meta, n);
+  hipLaunchKernelGGL((k_offsets<uint16_t>), dim3(chunks_per_image, n), dim3(256), 0, s, (const uint16_t *)len16, C.total_mcu_blocks, sums, chunks_per_image, (unsigned *)off32);
+  const bool rst = C.restart_interval != 0 && nseg > 1;
+  if (rst) {
+    const int seg_chunks = (nseg + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    hipLaunchKernelGGL(k_seg_extra, dim3((nseg + 255) / 256, n), dim3(256), 0, s, C, (const unsigned *)off32, totals, seg_x, nseg);
+    hipLaunchKernelGGL((k_chunk_sums<unsigned>), dim3(seg_chunks, n), dim3(256), 0, s, (const unsigned *)seg_x, nseg, seg_sums, seg_chunks);
+    hipLaunchKernelGGL(k_scan_sums, dim3(n), dim3(256), 0, s, seg_sums, seg_chunks, seg_totals);
+    hipLaunchKernelGGL((k_offsets<unsigned>), dim3(seg_chunks, n), dim3(256), 0, s, (const unsigned *)seg_x, nseg, seg_sums, seg_chunks, seg_E);
+  }
+  hipLaunchKernelGGL(k_enc_write, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image,
+                     (const unsigned *)seg_E, mpos, rst ? nseg : 1);
+  hipLaunchKernelGGL(k_finish_bits, dim3((n + 63) / 64), dim3(64), 0, s, totals, rst ? (const unsigned *)seg_totals : (const unsigned *)nullptr, stream,
+                     stream_words_per_image, (MjhImageMeta *)meta, n);
 }
 
 void mjh_launch_header(const void *prefix, int prefix_len, const void *sos, int sos_len, const MjhHuffTable *tabs, int spi,
@@ -1382,10 +1462,10 @@ void mjh_launch_header(const void *prefix, int prefix_len, const void *sos, int 
 }
 
 void mjh_launch_stuff(const unsigned *stream, size_t stream_words_per_image, const unsigned *totals, unsigned *ffsums, int ff_chunks_per_image,
-                      unsigned *ff_totals, void *out, size_t out_stride, void *meta, unsigned *sizes, int n, hipStream_t s)
+                      unsigned *ff_totals, void *out, size_t out_stride, void *meta, unsigned *sizes, const unsigned *mpos, int nseg, int n, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_ff_chunk_sums, dim3(ff_chunks_per_image, n), dim3(256), 0, s, stream, stream_words_per_image, totals, ffsums, ff_chunks_per_image);
+  hipLaunchKernelGGL(k_ff_chunk_sums, dim3(ff_chunks_per_image, n), dim3(256), 0, s, stream, stream_words_per_image, totals, ffsums, ff_chunks_per_image, mpos, nseg);
   hipLaunchKernelGGL(k_scan_sums, dim3(n), dim3(256), 0, s, ffsums, ff_chunks_per_image, ff_totals);
   hipLaunchKernelGGL(k_stuff_write, dim3(ff_chunks_per_image, n), dim3(256), 0, s, stream, stream_words_per_image, totals, ffsums, ff_chunks_per_image,
-                     ff_totals, (uint8_t *)out, out_stride, (MjhImageMeta *)meta, sizes);
+                     ff_totals, (uint8_t *)out, out_stride, (MjhImageMeta *)meta, sizes, mpos, nseg);
 }

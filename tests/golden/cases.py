@@ -41,8 +41,8 @@ CASES = [
     ("revert_gray", dict(revert=True, gray=True), True),
     ("base_gray", dict(baseline=True, gray=True), True),
     ("base_qtbl0", dict(baseline=True, quant_table=0), True),
-    ("base_restart1", dict(baseline=True, restart=1), False),
-    ("base_restart5b", dict(baseline=True, restart="5b"), False),
+    ("base_restart1", dict(baseline=True, restart=1), True),
+    ("base_restart5b", dict(baseline=True, restart="5b"), True),
     ("fastcrush", dict(fastcrush=True), False),
     ("default_progressive", dict(), False),
     ("q85_420_progressive", dict(quality=85), False),

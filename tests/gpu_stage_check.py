@@ -87,7 +87,9 @@ def main():
              dict(baseline=True, notrellis=True, noovershoot=True), dict(baseline=True, notrellis=True),
              dict(baseline=True, notrellis_dc=True), dict(baseline=True),
              dict(baseline=True, quality=90, sample=(1, 1)), dict(baseline=True, sample=(2, 1)),
-             dict(revert=True, sample=(1, 2)), dict(baseline=True, gray=True), dict(baseline=True, quality=30)]
+             dict(revert=True, sample=(1, 2)), dict(baseline=True, gray=True), dict(baseline=True, quality=30),
+             dict(baseline=True, restart=1), dict(baseline=True, restart="5b"), dict(revert=True, restart=2),
+             dict(baseline=True, restart="1b", sample=(1, 1))]
     bad = 0
     for img in imgs:
         for kw in cases:

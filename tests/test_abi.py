@@ -63,10 +63,6 @@ def test_unsupported_configurations_are_errors_not_fallbacks():
     with pytest.raises(M.MjhError) as ei:
         M.Encoder(p)
     assert ei.value.code == M.EUNSUPPORTED
-    p = M.make_params(64, 64, baseline=True, restart=1)
-    with pytest.raises(M.MjhError) as ei:
-        M.Encoder(p)
-    assert ei.value.code == M.EUNSUPPORTED
     p = M.make_params(64, 64, baseline=True)
     p.optimize_coding = 0               # trellis without optimize_coding: jcmaster.c never selects a component
     with pytest.raises(M.MjhError) as ei:
