@@ -89,6 +89,13 @@ int mjh_params_defaults(mjh_params *p, int width, int height, int input_componen
  * (-1 = the profile's default: 3 for max compression, 0 for fastest; jcparam.c:509-510). */
 int mjh_params_set_quality(mjh_params *p, int quality, int force_baseline, int base_quant_tbl_idx);
 
+/* jpeg_simple_progression (jcparam.c:859-1004): the profile's fixed script (9 scans for YCbCr in
+ * the max-compression profile, 10 in the fastest profile); clears optimize_scans. */
+int mjh_params_simple_progression(mjh_params *p);
+/* jpeg_search_progression (jcparam.c:733-852): the 64 (YCbCr) / 23 (gray) candidate scans of the
+ * scan search; sets optimize_scans (what jpeg_set_defaults selects in the max-compression profile). */
+int mjh_params_search_progression(mjh_params *p);
+
 /* ---- encoder lifetime ----------------------------------------------------------------- */
 /* Creates the device-resident state for up to max_batch images of p's geometry on HIP device
  * `device`.  Returns MJH_EUNSUPPORTED for configurations the GPU path does not cover. */

@@ -59,6 +59,8 @@ def lib():
         L.mjh_version.restype = C.c_char_p
         L.mjh_params_defaults.argtypes = [C.POINTER(Params)] + [C.c_int] * 7
         L.mjh_params_set_quality.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int]
+        L.mjh_params_simple_progression.argtypes = [C.POINTER(Params)]
+        L.mjh_params_search_progression.argtypes = [C.POINTER(Params)]
         L.mjh_encoder_create.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.mjh_encoder_destroy.argtypes = [C.c_void_p]
         L.mjh_encoder_destroy.restype = None
@@ -90,7 +92,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 grayin=False, quant_table=-1, lambda1=None, lambda2=None, restart=None,
                 progressive=False, fastcrush=False):
     """Parameters with cjpeg's switch vocabulary (cjpeg.c:371-714).  Without `baseline` or
-    `revert` cjpeg would select progressive + scan search, which the GPU path rejects for now."""
+    `revert` this is cjpeg's default: progressive with scan search (`fastcrush`: fixed 9-scan script)."""
     p = Params()
     L = lib()
     _chk(L.mjh_params_defaults(C.byref(p), width, height, 1 if grayin else 3, 1 if gray else 0,
@@ -113,8 +115,15 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
             p.restart_interval = int(restart[:-1])
         else:
             p.restart_in_rows = int(restart)
-    if progressive or fastcrush or not (baseline or revert):
-        p.num_scans = -1  # marks "a progressive script is required": rejected by mjh_encoder_create
+    if revert:
+        if progressive:
+            _chk(L.mjh_params_simple_progression(C.byref(p)))
+    elif not baseline:
+        # cjpeg's default in the max-compression profile: progressive, scan search unless -fastcrush
+        if fastcrush or progressive:
+            _chk(L.mjh_params_simple_progression(C.byref(p)))
+        else:
+            _chk(L.mjh_params_search_progression(C.byref(p)))
     return p
 
 

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmozjpeg_hip.so")
 SHIM = os.path.join(HERE, "libmozjpeg_hip_jpeg62.so")
-SOURCES = ["mjh_kernels.hip", "mjh_encoder.cpp"]
+SOURCES = ["mjh_kernels.hip", "mjh_prog.hip", "mjh_encoder.cpp"]
 # -ffp-contract=off: the trellis / deringing float recipes must not be fused into FMAs
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]

@@ -1,0 +1,106 @@
+// mjh_device.h -- device helpers shared by the gfx950 kernel files (mjh_kernels.hip, mjh_prog.hip)
+#ifndef MJH_DEVICE_H
+#define MJH_DEVICE_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mjh_internal.h"
+
+__device__ __forceinline__ int bitlen(unsigned v) { return 32 - __clz((int)v); }  // JPEG_NBITS; clz(0)=32
+
+// exact floor(n/d) for 0 <= n < 2^24, 1 <= d < 2^24, rcp = RN(1/d)
+__device__ __forceinline__ int udiv_exact(int n, int d, float rcp)
+{
+  int q = (int)((float)n * rcp);
+  int r = n - q * d;
+  if (r < 0) q--; else if (r >= d) q++;
+  return q;
+}
+
+
+__device__ __forceinline__ int dc_source_block(const MjhComp &cc, int r, int c)
+{
+  if (r >= cc.hib) { c = (c / cc.h) * cc.h + cc.h - 1; r = cc.hib - 1; }
+  if (c > cc.wib - 1) c = cc.wib - 1;
+  return r * cc.wib + c;
+}
+
+// previous block of the same component in interleaved MCU order; returns false if there is
+// none (first MCU of the scan or of a restart interval).  (pr,pc) in padded coordinates.
+__device__ __forceinline__ bool mcu_prev_block(const MjhConst &C, const MjhComp &cc, int r, int c, int &pr, int &pc)
+{
+  const int xi = c % cc.h, yi = r % cc.v;
+  if (xi > 0) { pr = r; pc = c - 1; return true; }
+  if (yi > 0) { pr = r - 1; pc = c + cc.h - 1; return true; }
+  const int m = (r / cc.v) * C.mcus_per_row + c / cc.h;
+  if (m == 0) return false;
+  if (C.restart_interval && (m % C.restart_interval) == 0) return false;
+  const int pm = m - 1;
+  const int pmy = pm / C.mcus_per_row, pmx = pm - pmy * C.mcus_per_row;
+  pr = pmy * cc.v + cc.v - 1;
+  pc = pmx * cc.h + cc.h - 1;
+  return true;
+}
+
+
+__device__ __forceinline__ unsigned block_reduce_256(unsigned v, unsigned *sh)
+{
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  const unsigned tot = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return tot;
+}
+
+// exclusive scan of one value per thread within a 256-thread block; returns exclusive prefix
+__device__ __forceinline__ unsigned block_excl_scan_256(unsigned v, unsigned *sh, unsigned *total)
+{
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned n = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += n;
+  }
+  if (lane == 63) sh[w] = inc;
+  __syncthreads();
+  unsigned base = 0;
+  for (int i = 0; i < w; i++) base += sh[i];
+  const unsigned tot = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  if (total) *total = tot;
+  return base + inc - v;
+}
+
+
+// bit writer: ORs big-endian bit strings into a zero-initialised word array
+struct BitWriter {
+  unsigned *words;       // stream base (32-bit words, bytes are big-endian inside the stream)
+  unsigned long long acc;
+  int nacc;              // valid bits in acc (low end)
+  unsigned widx;
+  __device__ __forceinline__ void init(unsigned *w, unsigned bitoff) { words = w; widx = bitoff >> 5; nacc = (int)(bitoff & 31); acc = 0; }
+  __device__ __forceinline__ void put(unsigned code, int n)
+  {
+    acc = (acc << n) | (unsigned long long)(code & ((1u << n) - 1u));
+    nacc += n;
+    if (nacc >= 32) {
+      const unsigned w = (unsigned)(acc >> (nacc - 32));
+      atomicOr(&words[widx], __builtin_bswap32(w));
+      widx++;
+      nacc -= 32;
+    }
+  }
+  __device__ __forceinline__ void flush()
+  {
+    if (nacc > 0) {
+      const unsigned w = (unsigned)(acc << (32 - nacc));
+      atomicOr(&words[widx], __builtin_bswap32(w));
+    }
+  }
+};
+
+
+#endif

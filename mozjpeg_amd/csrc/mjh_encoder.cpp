@@ -119,8 +119,104 @@ extern "C" int mjh_params_defaults(mjh_params *p, int width, int height, int inp
   return mjh_params_set_quality(p, 75, 1, -1);
 }
 
+
+// ---- scan scripts (jcparam.c:652-1004) -------------------------------------------------------------
+static mjh_scan *fill_a_scan(mjh_scan *s, int ci, int Ss, int Se, int Ah, int Al)
+{
+  memset(s, 0, sizeof(*s));
+  s->comps_in_scan = 1; s->component_index[0] = ci; s->Ss = Ss; s->Se = Se; s->Ah = Ah; s->Al = Al;
+  return s + 1;
+}
+static mjh_scan *fill_dc_scans(mjh_scan *s, int first, int ncomps, int Ah, int Al)
+{
+  memset(s, 0, sizeof(*s));
+  s->comps_in_scan = ncomps;
+  for (int ci = 0; ci < ncomps; ci++) s->component_index[ci] = first + ci;
+  s->Ss = s->Se = 0; s->Ah = Ah; s->Al = Al;
+  return s + 1;
+}
+
+extern "C" int mjh_params_simple_progression(mjh_params *p)
+{
+  if (!p) return fail(MJH_EINVAL, "null params");
+  mjh_scan *s = p->scan_info;
+  const int nc = p->num_components;
+  const bool maxc = p->compress_profile != MJH_PROFILE_FASTEST;
+  p->optimize_scans = 0;
+  if (nc == 3) {
+    if (maxc) {   // jcparam.c:940-963 (dc_scan_opt_mode 0)
+      s = fill_dc_scans(s, 0, nc, 0, 0);
+      s = fill_a_scan(s, 0, 1, 8, 0, 2); s = fill_a_scan(s, 1, 1, 8, 0, 0); s = fill_a_scan(s, 2, 1, 8, 0, 0);
+      s = fill_a_scan(s, 0, 9, 63, 0, 2);
+      s = fill_a_scan(s, 0, 1, 63, 2, 1); s = fill_a_scan(s, 0, 1, 63, 1, 0);
+      s = fill_a_scan(s, 1, 9, 63, 0, 0); s = fill_a_scan(s, 2, 9, 63, 0, 0);
+    } else {      // :964-982
+      s = fill_dc_scans(s, 0, nc, 0, 1);
+      s = fill_a_scan(s, 0, 1, 5, 0, 2); s = fill_a_scan(s, 2, 1, 63, 0, 1); s = fill_a_scan(s, 1, 1, 63, 0, 1);
+      s = fill_a_scan(s, 0, 6, 63, 0, 2); s = fill_a_scan(s, 0, 1, 63, 2, 1);
+      s = fill_dc_scans(s, 0, nc, 1, 0);
+      s = fill_a_scan(s, 2, 1, 63, 1, 0); s = fill_a_scan(s, 1, 1, 63, 1, 0); s = fill_a_scan(s, 0, 1, 63, 1, 0);
+    }
+  } else if (nc == 1) {
+    if (maxc) {   // :985-995
+      s = fill_dc_scans(s, 0, 1, 0, 0);
+      s = fill_a_scan(s, 0, 1, 8, 0, 2); s = fill_a_scan(s, 0, 9, 63, 0, 2);
+      s = fill_a_scan(s, 0, 1, 63, 2, 1); s = fill_a_scan(s, 0, 1, 63, 1, 0);
+    } else {      // :996-1003
+      s = fill_dc_scans(s, 0, 1, 0, 1);
+      s = fill_a_scan(s, 0, 1, 5, 0, 2); s = fill_a_scan(s, 0, 6, 63, 0, 2);
+      s = fill_a_scan(s, 0, 1, 63, 2, 1);
+      s = fill_dc_scans(s, 0, 1, 1, 0);
+      s = fill_a_scan(s, 0, 1, 63, 1, 0);
+    }
+  } else return fail(MJH_EUNSUPPORTED, "scan scripts for %d components", nc);
+  p->num_scans = (int)(s - p->scan_info);
+  p->optimize_coding = 1;   // jcmaster.c:1091-1094
+  return MJH_OK;
+}
+
+static int build_search_script(mjh_scan *out, int nc)
+{
+  static const int fs[5] = { 2, 8, 5, 12, 18 };
+  mjh_scan *s = out;
+  s = fill_dc_scans(s, 0, nc, 0, 0);
+  s = fill_a_scan(s, 0, 1, 8, 0, 0); s = fill_a_scan(s, 0, 9, 63, 0, 0);
+  for (int Al = 0; Al < 3; Al++) {
+    s = fill_a_scan(s, 0, 1, 63, Al + 1, Al); s = fill_a_scan(s, 0, 1, 8, 0, Al + 1); s = fill_a_scan(s, 0, 9, 63, 0, Al + 1);
+  }
+  s = fill_a_scan(s, 0, 1, 63, 0, 0);
+  for (int i = 0; i < 5; i++) { s = fill_a_scan(s, 0, 1, fs[i], 0, 0); s = fill_a_scan(s, 0, fs[i] + 1, 63, 0, 0); }
+  if (nc == 3) {
+    s = fill_dc_scans(s, 1, 2, 0, 0);
+    s = fill_a_scan(s, 1, 0, 0, 0, 0); s = fill_a_scan(s, 2, 0, 0, 0, 0);
+    s = fill_a_scan(s, 1, 1, 8, 0, 0); s = fill_a_scan(s, 1, 9, 63, 0, 0);
+    s = fill_a_scan(s, 2, 1, 8, 0, 0); s = fill_a_scan(s, 2, 9, 63, 0, 0);
+    for (int Al = 0; Al < 2; Al++) {
+      s = fill_a_scan(s, 1, 1, 63, Al + 1, Al); s = fill_a_scan(s, 2, 1, 63, Al + 1, Al);
+      s = fill_a_scan(s, 1, 1, 8, 0, Al + 1); s = fill_a_scan(s, 1, 9, 63, 0, Al + 1);
+      s = fill_a_scan(s, 2, 1, 8, 0, Al + 1); s = fill_a_scan(s, 2, 9, 63, 0, Al + 1);
+    }
+    s = fill_a_scan(s, 1, 1, 63, 0, 0); s = fill_a_scan(s, 2, 1, 63, 0, 0);
+    for (int i = 0; i < 5; i++) {
+      s = fill_a_scan(s, 1, 1, fs[i], 0, 0); s = fill_a_scan(s, 1, fs[i] + 1, 63, 0, 0);
+      s = fill_a_scan(s, 2, 1, fs[i], 0, 0); s = fill_a_scan(s, 2, fs[i] + 1, 63, 0, 0);
+    }
+  }
+  return (int)(s - out);
+}
+
+extern "C" int mjh_params_search_progression(mjh_params *p)
+{
+  if (!p) return fail(MJH_EINVAL, "null params");
+  if (p->num_components != 3 && p->num_components != 1) return fail(MJH_EUNSUPPORTED, "scan search for %d components", p->num_components);
+  p->num_scans = build_search_script(p->scan_info, p->num_components);
+  p->optimize_scans = 1;
+  p->optimize_coding = 1;
+  return MJH_OK;
+}
+
 // ---- encoder object -------------------------------------------------------------------------------
-enum { SLOTS_PER_IMAGE = 16, SLOT_FINAL = 8 };   // 0..7: per-component trellis-pass tables (DC,AC); 8..15: final DC t / AC t
+enum { SLOTS_BASE = 16, SLOT_FINAL = 8, SLOT_PROG = 16 };   // 0..7: per-component trellis-pass tables (DC,AC); 8..15: final DC t / AC t
 
 
 struct mjh_encoder {
@@ -147,6 +243,19 @@ struct mjh_encoder {
   int comp_restart[4] = { 0, 0, 0, 0 };
   unsigned *d_worklist = nullptr;   // deferred trellis blocks: [0] = count, [4+2i], [5+2i] = (image, comp<<28|block)
   int trellis_variant = 0;
+  int spi = SLOTS_BASE;             // table slots per image (16 + 2 per progressive scan)
+  // progressive mode
+  bool progressive = false;
+  int nscans = 0;                   // script scans; the per-component trellis statistics scans follow
+  void *d_prog_scans = nullptr, *d_prog_ctl = nullptr;
+  int *d_lists = nullptr;           // device copies of the scan / slot lists below
+  std::vector<int> h_lists;
+  struct PList { int scan_off, nscan, slot_off, nslot; };
+  PList pl_trellis{}, pl_phase[2]{};
+  int nphases = 0;
+  unsigned *d_pool = nullptr; size_t pool_words = 0;
+  uint8_t *d_outpool = nullptr; size_t outpool_bytes = 0;
+  uint8_t *d_frame_hdr = nullptr; int frame_hdr_len = 0, file_hdr_len = 0;
   uint16_t *d_len16 = nullptr;
   unsigned *d_off32 = nullptr, *d_sums = nullptr, *d_totals = nullptr, *d_ffsums = nullptr, *d_fftotals = nullptr;
   unsigned *d_stream = nullptr;
@@ -192,7 +301,37 @@ static int check_supported(const mjh_params *p)
     for (int k = 0; k < 64; k++)
       if (p->quantval[p->quant_tbl_no[i]][k] == 0) return fail(MJH_EINVAL, "quantization table %d has a zero entry", p->quant_tbl_no[i]);
   }
-  if (p->num_scans != 0) return fail(MJH_EUNSUPPORTED, "progressive scan scripts are not on the GPU path yet");
+  if (p->num_scans < 0 || p->num_scans > MJH_MAX_SCANS) return fail(p->num_scans < 0 ? MJH_EUNSUPPORTED : MJH_EINVAL, "num_scans %d", p->num_scans);
+  if (p->num_scans > 0) {
+    // progressive mode: the checks of validate_script (jcmaster.c:269-432) that matter here
+    if (!p->optimize_coding) return fail(MJH_EUNSUPPORTED, "progressive mode forces optimize_coding (jcmaster.c:1091-1094)");
+    if (p->restart_interval || p->restart_in_rows) return fail(MJH_EUNSUPPORTED, "restart intervals in progressive mode are not on the GPU path yet");
+    for (int i = 0; i < p->num_components; i++)
+      if (p->dc_tbl_no[i] > 1 || p->ac_tbl_no[i] > 1) return fail(MJH_EUNSUPPORTED, "progressive mode: table numbers 0/1 only");
+    if (p->optimize_scans) {
+      mjh_scan ref[MJH_MAX_SCANS];
+      const int n = build_search_script(ref, p->num_components);
+      if (n != p->num_scans || memcmp(ref, p->scan_info, sizeof(mjh_scan) * n) != 0)
+        return fail(MJH_EUNSUPPORTED, "optimize_scans needs the jpeg_search_progression script");
+    }
+    bool dc_seen[MJH_MAX_COMPS] = { false, false, false, false };
+    for (int si = 0; si < p->num_scans; si++) {
+      const mjh_scan &sc = p->scan_info[si];
+      if (sc.comps_in_scan < 1 || sc.comps_in_scan > p->num_components) return fail(MJH_EINVAL, "scan %d: component count", si);
+      for (int ci = 0; ci < sc.comps_in_scan; ci++) {
+        const int c = sc.component_index[ci];
+        if (c < 0 || c >= p->num_components || (ci > 0 && c <= sc.component_index[ci - 1])) return fail(MJH_EINVAL, "scan %d: component order", si);
+      }
+      if (sc.Ss < 0 || sc.Ss > 63 || sc.Se < sc.Ss || sc.Se > 63 || sc.Ah < 0 || sc.Ah > 10 || sc.Al < 0 || sc.Al > 10)
+        return fail(MJH_EINVAL, "scan %d: bad progression parameters", si);
+      if (sc.Ss == 0 && sc.Se != 0) return fail(MJH_EUNSUPPORTED, "scan %d: sequential multi-scan scripts are not supported", si);
+      if (sc.Ss != 0 && sc.comps_in_scan != 1) return fail(MJH_EINVAL, "scan %d: AC scans are single-component", si);
+      for (int ci = 0; ci < sc.comps_in_scan; ci++) {
+        if (sc.Ss == 0) dc_seen[sc.component_index[ci]] = true;
+        else if (!dc_seen[sc.component_index[ci]] && !p->optimize_scans) return fail(MJH_EINVAL, "scan %d: AC before DC", si);
+      }
+    }
+  }
   if (p->restart_interval > 65535u || p->restart_in_rows < 0) return fail(MJH_EINVAL, "bad restart interval");
   if (p->trellis_quant && !p->optimize_coding) return fail(MJH_EUNSUPPORTED, "trellis_quant requires optimize_coding (jcmaster.c:686-702 never selects a component otherwise)");
   if (!p->optimize_coding) {
@@ -266,7 +405,7 @@ static void build_const(const mjh_params *p, MjhConst *C)
 // ---- marker bytes that do not depend on the image (jcmarker.c) -------------------------------------
 static void put2(std::vector<uint8_t> &o, int v) { o.push_back((uint8_t)(v >> 8)); o.push_back((uint8_t)v); }
 
-static void build_prefix(const mjh_params *p, std::vector<uint8_t> &o, bool *baseline_sof)
+static void build_prefix(const mjh_params *p, std::vector<uint8_t> &o, bool *baseline_sof, int *file_hdr_len)
 {
   const bool multi = p->compress_profile != MJH_PROFILE_FASTEST;
   o.push_back(0xFF); o.push_back(0xD8);                     // SOI, write_file_header :649
@@ -275,6 +414,7 @@ static void build_prefix(const mjh_params *p, std::vector<uint8_t> &o, bool *bas
     const uint8_t jf[] = { 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0 };
     o.insert(o.end(), jf, jf + sizeof(jf));
   }
+  *file_hdr_len = (int)o.size();   // SOI + APP0: what jpeg_start_compress writes
   int prec[MJH_MAX_COMPS], prec_any = 0;
   for (int ci = 0; ci < p->num_components; ci++) {
     prec[ci] = 0;
@@ -311,7 +451,7 @@ static void build_prefix(const mjh_params *p, std::vector<uint8_t> &o, bool *bas
     if (p->dc_tbl_no[ci] > 1 || p->ac_tbl_no[ci] > 1) is_baseline = false;
   if (prec_any) is_baseline = false;
   *baseline_sof = is_baseline;
-  o.push_back(0xFF); o.push_back(is_baseline ? 0xC0 : 0xC1);  // emit_sof :464-490
+  o.push_back(0xFF); o.push_back(p->num_scans > 0 ? 0xC2 : (is_baseline ? 0xC0 : 0xC1));  // emit_sof :464-490 (SOF2 = progressive)
   put2(o, 3 * p->num_components + 2 + 5 + 1);
   o.push_back(8);
   put2(o, p->image_height); put2(o, p->image_width);
@@ -390,7 +530,7 @@ static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *ptrs[] = { e->d_pix, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pix, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -424,6 +564,9 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   e->max_batch = max_batch;
   build_const(p, &e->C);
   const MjhConst &C = e->C;
+  e->progressive = p->num_scans > 0;
+  e->nscans = p->num_scans;
+  if (e->progressive) e->spi = SLOT_PROG + 2 * (p->num_scans + C.ncomp);
   HIPCHK_E(hipSetDevice(device));
   HIPCHK_E(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   HIPCHK_E(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
@@ -439,8 +582,8 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   HIPCHK_E(hipMalloc((void **)&e->d_uq, B * C.coefs_per_image * 2));
   HIPCHK_E(hipMalloc((void **)&e->d_q, B * C.coefs_per_image * 2));
   HIPCHK_E(hipMalloc((void **)&e->d_quant, sizeof(MjhQuant)));
-  HIPCHK_E(hipMalloc((void **)&e->d_tabs, B * SLOTS_PER_IMAGE * sizeof(MjhHuffTable)));
-  HIPCHK_E(hipMalloc((void **)&e->d_tabs_init, B * SLOTS_PER_IMAGE * sizeof(MjhHuffTable)));
+  HIPCHK_E(hipMalloc((void **)&e->d_tabs, B * e->spi * sizeof(MjhHuffTable)));
+  HIPCHK_E(hipMalloc((void **)&e->d_tabs_init, B * e->spi * sizeof(MjhHuffTable)));
   HIPCHK_E(hipMalloc((void **)&e->d_lambda, B * C.total_real_blocks * sizeof(float)));
   HIPCHK_E(hipMalloc((void **)&e->d_back, B * (size_t)C.total_real_blocks * 16));
   HIPCHK_E(hipMalloc((void **)&e->d_worklist, 16 + B * (size_t)C.total_real_blocks * 8));
@@ -494,11 +637,11 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
 
   // table template (zero counts; standard tables in the final slots when optimize_coding is off)
   {
-    std::vector<MjhHuffTable> ht(B * SLOTS_PER_IMAGE);
+    std::vector<MjhHuffTable> ht(B * e->spi);
     memset(ht.data(), 0, ht.size() * sizeof(MjhHuffTable));
-    if (!p->optimize_coding) {
+    if (!p->optimize_coding || p->num_scans > 0) {   // progressive + trellis rates DC with the standard tables (T7)
       for (size_t b = 0; b < B; b++) {
-        MjhHuffTable *T = &ht[b * SLOTS_PER_IMAGE + SLOT_FINAL];
+        MjhHuffTable *T = &ht[b * e->spi + SLOT_FINAL];
         fill_std_table(&T[0], kStdDcLBits, kStdDcVal, 12);
         fill_std_table(&T[1], kStdAcLBits, kStdAcLVal, 162);
         fill_std_table(&T[2], kStdDcCBits, kStdDcVal, 12);
@@ -511,7 +654,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   {
     std::vector<uint8_t> pre, sos;
     bool base;
-    build_prefix(p, pre, &base);
+    build_prefix(p, pre, &base, &e->file_hdr_len);
     build_sos(p, C.restart_interval, sos);
     e->prefix_len = (int)pre.size();
     e->sos_len = (int)sos.size();
@@ -528,6 +671,87 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       if (!dc_sent[d] && e->ndht < 4) { e->dht_slots[e->ndht] = SLOT_FINAL + 2 * d; e->dht_ids[e->ndht] = d; e->ndht++; dc_sent[d] = true; }
       if (!ac_sent[a] && e->ndht < 4) { e->dht_slots[e->ndht] = SLOT_FINAL + 2 * a + 1; e->dht_ids[e->ndht] = a + 0x10; e->ndht++; ac_sent[a] = true; }
     }
+  }
+  if (e->progressive) {
+    // frame header (DQT + SOF2) = prefix minus SOI/APP0; it opens scan 0's buffer (jcmaster.c:680-681)
+    e->frame_hdr_len = e->prefix_len - e->file_hdr_len;
+    e->d_frame_hdr = nullptr;
+    HIPCHK_E(hipMalloc((void **)&e->d_frame_hdr, (size_t)e->frame_hdr_len + 16));
+    HIPCHK_E(hipMemcpy(e->d_frame_hdr, e->d_prefix + e->file_hdr_len, e->frame_hdr_len, hipMemcpyDeviceToDevice));
+    // scan descriptors: the script, then one AC-first statistics scan per component for the trellis passes
+    std::vector<MjhProgScan> ps(p->num_scans + C.ncomp);
+    memset(ps.data(), 0, ps.size() * sizeof(MjhProgScan));
+    const int nsl = 23, cfs = 42, lfs = 12;
+    for (int si = 0; si < p->num_scans; si++) {
+      const mjh_scan &ms = p->scan_info[si];
+      MjhProgScan &d = ps[si];
+      d.ncomp = ms.comps_in_scan;
+      d.Ss = ms.Ss; d.Se = ms.Se; d.Ah = ms.Ah; d.Al = ms.Al;
+      d.slot[0] = d.slot[1] = -1;
+      d.frame_header = si == 0;
+      if (p->optimize_scans) {   // jcmaster.c:487-497
+        if (si >= lfs && si < nsl) d.al_sel = 1;
+        if (si >= cfs) d.al_sel = 2;
+      }
+      for (int ci = 0; ci < ms.comps_in_scan; ci++) {
+        const int c = ms.component_index[ci];
+        d.comp[ci] = c;
+        d.comp_id[ci] = p->component_id[c];
+        d.td[ci] = (ms.Ss == 0 && ms.Ah == 0) ? p->dc_tbl_no[c] : 0;   // emit_sos jcmarker.c:519-523
+        d.ta[ci] = ms.Se ? p->ac_tbl_no[c] : 0;
+        if (ms.Ss == 0) {
+          if (ms.Ah == 0) {
+            const int t = p->dc_tbl_no[c];
+            if (d.slot[t] < 0) {
+              d.slot[t] = SLOT_PROG + 2 * si + t;
+              d.dht_slot[d.ndht] = d.slot[t]; d.dht_id[d.ndht] = t; d.ndht++;
+            }
+          }
+        } else {
+          d.slot[0] = SLOT_PROG + 2 * si;
+          d.dht_slot[0] = d.slot[0]; d.dht_id[0] = 0x10 + p->ac_tbl_no[c]; d.ndht = 1;
+        }
+      }
+    }
+    for (int c = 0; c < C.ncomp; c++) {
+      MjhProgScan &d = ps[p->num_scans + c];
+      d.ncomp = 1; d.comp[0] = c; d.Ss = 1; d.Se = 63; d.Ah = 0; d.Al = 0;   // jcmaster.c:462-466, T15
+      d.slot[0] = 2 * c + 1; d.slot[1] = -1; d.seed = 1;
+    }
+    HIPCHK_E(hipMalloc(&e->d_prog_scans, ps.size() * sizeof(MjhProgScan)));
+    HIPCHK_E(hipMemcpy(e->d_prog_scans, ps.data(), ps.size() * sizeof(MjhProgScan), hipMemcpyHostToDevice));
+    HIPCHK_E(hipMalloc(&e->d_prog_ctl, B * sizeof(MjhProgCtl)));
+    // scan lists per phase (+ the table slots each phase has to build)
+    auto add_list = [&](const std::vector<int> &scn) {
+      mjh_encoder::PList pl;
+      pl.scan_off = (int)e->h_lists.size(); pl.nscan = (int)scn.size();
+      e->h_lists.insert(e->h_lists.end(), scn.begin(), scn.end());
+      pl.slot_off = (int)e->h_lists.size(); pl.nslot = 0;
+      for (int si : scn)
+        for (int t = 0; t < 2; t++)
+          if (ps[si].slot[t] >= 0 && (ps[si].Ss != 0 || ps[si].Ah == 0)) { e->h_lists.push_back(ps[si].slot[t]); pl.nslot++; }
+      return pl;
+    };
+    std::vector<int> tr, a, b;
+    for (int c = 0; c < C.ncomp; c++) tr.push_back(p->num_scans + c);
+    if (p->optimize_scans) {   // phase A: everything the Al decisions need; phase B: the frequency-split candidates
+      for (int si = 0; si < p->num_scans; si++) ((si >= lfs && si < nsl) || si >= cfs ? b : a).push_back(si);
+      e->nphases = 2;
+    } else {
+      for (int si = 0; si < p->num_scans; si++) a.push_back(si);
+      e->nphases = 1;
+    }
+    e->pl_trellis = add_list(tr);
+    e->pl_phase[0] = add_list(a);
+    e->pl_phase[1] = add_list(b);
+    HIPCHK_E(hipMalloc((void **)&e->d_lists, e->h_lists.size() * sizeof(int) + 16));
+    HIPCHK_E(hipMemcpy(e->d_lists, e->h_lists.data(), e->h_lists.size() * sizeof(int), hipMemcpyHostToDevice));
+    // every candidate scan of the search keeps its own bit stream: the bands are coded ~11 times over
+    e->pool_words = e->stream_words * (p->optimize_scans ? 8 : 2);
+    if (e->pool_words > ((size_t)1 << 27)) e->pool_words = (size_t)1 << 27;   // 32-bit bit offsets
+    e->outpool_bytes = (size_t)1280 * (p->num_scans + 1) + 8 * e->pool_words;
+    HIPCHK_E(hipMalloc((void **)&e->d_pool, B * e->pool_words * 4));
+    HIPCHK_E(hipMalloc((void **)&e->d_outpool, B * e->outpool_bytes));
   }
   HIPCHK_E(hipDeviceSynchronize());
   *out = e;
@@ -552,7 +776,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
 {
   const MjhConst &C = e->C;
   const mjh_params &p = e->p;
-  const int spi = SLOTS_PER_IMAGE;
+  const int spi = e->spi;
   e->sizes_valid = false;
   e->last_n = n;
   e->prof_names.clear();
@@ -570,16 +794,30 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     fin_dc[i] = SLOT_FINAL + 2 * (i < C.ncomp ? p.dc_tbl_no[i] : 0);
     fin_ac[i] = SLOT_FINAL + 2 * (i < C.ncomp ? p.ac_tbl_no[i] : 0) + 1;
   }
+  if (e->progressive) {
+    mjh_launch_prog_reset(e->d_prog_ctl, e->nscans, n, s);
+    HIPCHK(hipMemsetAsync(e->d_pool, 0, (size_t)n * e->pool_words * 4, s));
+  }
   if (p.trellis_quant) {
-    // passes 0,2,4 of SURVEY 3.3 (statistics of the conventionally quantized component) ...
-    pr.mark("stats_ac(pre-trellis)");
-    mjh_launch_stats_ac(C, e->d_q, e->d_tabs, spi, tr_ac, 0, n, s);
-    pr.mark("stats_dc(pre-trellis)");
-    mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, tr_dc, 0, e->comp_restart, n, s);
-    int slots[8], ns = 0;
-    for (int i = 0; i < C.ncomp; i++) { slots[ns++] = tr_dc[i]; slots[ns++] = tr_ac[i]; }
-    pr.mark("gen_tables(trellis)");
-    mjh_launch_gen_tables(e->d_tabs, spi, slots, ns, n, s);
+    if (!e->progressive) {
+      // passes 0,2,4 of SURVEY 3.3 (statistics of the conventionally quantized component) ...
+      pr.mark("stats_ac(pre-trellis)");
+      mjh_launch_stats_ac(C, e->d_q, e->d_tabs, spi, tr_ac, 0, n, s);
+      pr.mark("stats_dc(pre-trellis)");
+      mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, tr_dc, 0, e->comp_restart, n, s);
+      int slots[8], ns = 0;
+      for (int i = 0; i < C.ncomp; i++) { slots[ns++] = tr_dc[i]; slots[ns++] = tr_ac[i]; }
+      pr.mark("gen_tables(trellis)");
+      mjh_launch_gen_tables(e->d_tabs, spi, slots, ns, n, s);
+    } else {
+      // progressive: the trellis passes gather AC-first statistics (Ss=1, Se=63, Al=0, seeded counts,
+      // jcphuff.c:257-264); the DC rate table stays the STANDARD table
+      pr.mark("prog_stats(pre-trellis)");
+      mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + e->pl_trellis.scan_off, e->pl_trellis.nscan, e->d_prog_ctl, e->d_q, e->d_tabs, spi, n, s);
+      pr.mark("gen_tables(trellis)");
+      mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + e->pl_trellis.slot_off, e->pl_trellis.nslot, n, s);
+      for (int i = 0; i < 4; i++) tr_dc[i] = fin_dc[i];
+    }
     if (e->debug_taps) {
       if (!e->d_q0) HIPCHK(hipMalloc((void **)&e->d_q0, (size_t)e->max_batch * C.coefs_per_image * 2));
       HIPCHK(hipMemcpyAsync(e->d_q0, e->d_q, (size_t)n * C.coefs_per_image * 2, hipMemcpyDeviceToDevice, s));
@@ -602,6 +840,25 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       pr.mark("join(trellis_dc)");
       HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
     }
+  }
+  if (e->progressive) {
+    // every candidate scan of a phase: statistics -> optimal tables -> exact size -> headers, bits, stuffing
+    for (int ph = 0; ph < e->nphases; ph++) {
+      const mjh_encoder::PList &pl = e->pl_phase[ph];
+      pr.mark(ph == 0 ? "prog_stats(A)" : "prog_stats(B)");
+      mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + pl.scan_off, pl.nscan, e->d_prog_ctl, e->d_q, e->d_tabs, spi, n, s);
+      pr.mark(ph == 0 ? "gen_tables(A)" : "gen_tables(B)");
+      mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + pl.slot_off, pl.nslot, n, s);
+      pr.mark(ph == 0 ? "prog_encode(A)" : "prog_encode(B)");
+      mjh_launch_prog_encode(C, e->d_prog_scans, e->d_lists + pl.scan_off, pl.nscan, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_pool, e->pool_words,
+                             e->d_frame_hdr, e->frame_hdr_len, p.compress_profile != MJH_PROFILE_FASTEST, e->d_outpool, e->outpool_bytes, n, s);
+      if (p.optimize_scans) { pr.mark("prog_select"); mjh_launch_prog_select(e->d_prog_ctl, C.ncomp, ph, n, s); }
+    }
+    pr.mark("prog_concat");
+    mjh_launch_prog_concat(e->d_prog_ctl, e->d_prefix, e->file_hdr_len, e->d_outpool, e->outpool_bytes, e->d_out, e->out_stride, e->d_sizes, n, s);
+    pr.mark(nullptr);
+    HIPCHK(hipGetLastError());
+    return MJH_OK;
   }
   if (p.optimize_coding) {
     // pass 6: statistics of the interleaved scan (dummy blocks included) -> final tables
@@ -670,6 +927,13 @@ static int fetch_sizes(mjh_encoder *e)
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(e->h_sizes.data(), e->d_sizes, (size_t)e->last_n * sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (e->progressive) {
+    std::vector<MjhProgCtl> ctl(e->last_n);
+    HIPCHK(hipMemcpy(ctl.data(), e->d_prog_ctl, (size_t)e->last_n * sizeof(MjhProgCtl), hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->last_n; i++)
+      if (ctl[i].error) return fail(ctl[i].error == 1 ? MJH_ETOOSMALL : MJH_EHIP, "progressive encode of image %d failed (%s)", i,
+                                    ctl[i].error == 1 ? "scan buffers exceed the bit-stream pool" : "internal: scan size prediction mismatch");
+  }
   e->sizes_valid = true;
   return MJH_OK;
 }
@@ -752,7 +1016,7 @@ extern "C" int mjh_read_tap(mjh_encoder *e, int what, int image, int comp, void 
     std::vector<MjhHuffTable> t(4);
     const size_t need = what == MJH_TAP_HUFF_BITS ? 4 * 17 : 4 * 256;
     if (cap < need) return fail(MJH_ETOOSMALL, "need %zu bytes", need);
-    HIPCHK(hipMemcpy(t.data(), e->d_tabs + (size_t)image * SLOTS_PER_IMAGE + SLOT_FINAL, 4 * sizeof(MjhHuffTable), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(t.data(), e->d_tabs + (size_t)image * e->spi + SLOT_FINAL, 4 * sizeof(MjhHuffTable), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; i++) {
       if (what == MJH_TAP_HUFF_BITS) memcpy((uint8_t *)dst + i * 17, t[i].bits, 17);
       else memcpy((uint8_t *)dst + i * 256, t[i].huffval, 256);

@@ -74,4 +74,38 @@ struct MjhImageMeta {
   unsigned file_len;       // whole file
 };
 
+
+// ---- progressive mode (jcphuff.c, scan scripts jcparam.c:733-1004, scan search jcmaster.c:773-962) ----
+#define MJH_MAX_PROG_SCANS 72   // 64 script scans + the 3 per-component trellis statistics passes
+
+struct MjhProgScan {
+  int ncomp;
+  int comp[MJH_MAXC];
+  int comp_id[MJH_MAXC];   // SOS component ids
+  int td[MJH_MAXC], ta[MJH_MAXC];
+  int Ss, Se, Ah, Al;
+  int al_sel;              // 0: Al as given; 1: MjhProgCtl.best_Al_luma; 2: best_Al_chroma (jcmaster.c:487-497)
+  int slot[2];             // DC scans: slot of DC table number 0 / 1; AC scans: slot[0] = AC table
+  int seed;                // statistics of a trellis pass: every (run,size<12) count starts at 1 (jcphuff.c:257-264)
+  int frame_header;        // 1: this scan's buffer starts with DQT + SOF (scan 0)
+  int ndht;                // tables to emit in the scan's DHT, in order
+  int dht_slot[2], dht_id[2];
+};
+
+struct MjhProgCtl {        // per image, lives in HBM
+  int best_Al_luma, best_Al_chroma, best_fs_luma, best_fs_chroma;
+  unsigned pool_words_used;   // running allocation in the bit-stream pool
+  unsigned out_bytes_used;    // running allocation in the scan-buffer pool
+  unsigned error;             // 1: pool overflow
+  unsigned pad;
+  unsigned scan_bits[MJH_MAX_PROG_SCANS];      // entropy-coded bits (incl. final pad)
+  unsigned scan_words_off[MJH_MAX_PROG_SCANS]; // word offset of the scan's bit stream in the pool
+  unsigned scan_out_off[MJH_MAX_PROG_SCANS];   // byte offset of the scan's buffer (headers + stuffed data)
+  unsigned scan_hdr_len[MJH_MAX_PROG_SCANS];
+  unsigned scan_size[MJH_MAX_PROG_SCANS];      // master->scan_size[]: bytes of the whole scan buffer
+  int order[MJH_MAX_PROG_SCANS];               // final scan order
+  int norder;
+  int pad2[3];
+};
+
 #endif

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mjh_internal.h"
+#include "mjh_device.h"
 
 #define WAVE 64
 
@@ -42,17 +43,6 @@ static constexpr ZZTab make_izz() {
 }
 static constexpr ZZTab kZZ = make_zz();    // kZZ.v[k]  = natural index of zig-zag position k
 static constexpr ZZTab kIZZ = make_izz();  // kIZZ.v[n] = zig-zag position of natural index n
-
-__device__ __forceinline__ int bitlen(unsigned v) { return 32 - __clz((int)v); }  // JPEG_NBITS; clz(0)=32
-
-// exact floor(n/d) for 0 <= n < 2^24, 1 <= d < 2^24, rcp = RN(1/d)
-__device__ __forceinline__ int udiv_exact(int n, int d, float rcp)
-{
-  int q = (int)((float)n * rcp);
-  int r = n - q * d;
-  if (r < 0) q--; else if (r >= d) q++;
-  return q;
-}
 
 // =============================================================================================
 // K1  colour conversion + chroma downsampling + edge replication  
@@ -284,30 +274,6 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const uint8_t *__restric
 // :443-476): dummy blocks are never stored.  A padded position (r,c) of a component maps to
 // the real block whose DC it copies; its AC coefficients are zero.
 // =============================================================================================
-__device__ __forceinline__ int dc_source_block(const MjhComp &cc, int r, int c)
-{
-  if (r >= cc.hib) { c = (c / cc.h) * cc.h + cc.h - 1; r = cc.hib - 1; }
-  if (c > cc.wib - 1) c = cc.wib - 1;
-  return r * cc.wib + c;
-}
-
-// previous block of the same component in interleaved MCU order; returns false if there is
-// none (first MCU of the scan or of a restart interval).  (pr,pc) in padded coordinates.
-__device__ __forceinline__ bool mcu_prev_block(const MjhConst &C, const MjhComp &cc, int r, int c, int &pr, int &pc)
-{
-  const int xi = c % cc.h, yi = r % cc.v;
-  if (xi > 0) { pr = r; pc = c - 1; return true; }
-  if (yi > 0) { pr = r - 1; pc = c + cc.h - 1; return true; }
-  const int m = (r / cc.v) * C.mcus_per_row + c / cc.h;
-  if (m == 0) return false;
-  if (C.restart_interval && (m % C.restart_interval) == 0) return false;
-  const int pm = m - 1;
-  const int pmy = pm / C.mcus_per_row, pmx = pm - pmy * C.mcus_per_row;
-  pr = pmy * cc.v + cc.v - 1;
-  pc = pmx * cc.h + cc.h - 1;
-  return true;
-}
-
 // =============================================================================================
 // K3  symbol statistics (row a10): htest_one_block / encode_mcu_gather jchuff.c:812-915.
 // AC symbols of a block do not depend on scan order, DC symbols do, so they are gathered by
@@ -415,20 +381,13 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
   return v;
 }
 
-__global__ void __launch_bounds__(64)
-k_gen_tables(MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 slots_a, int4 slots_b)
+__device__ __forceinline__ void gen_table_body(MjhHuffTable *__restrict__ T, int lane)
 {
   __shared__ int s_bits[33];
   __shared__ int s_bitpos[33];
   __shared__ int s_cum[18];
   __shared__ int s_first[18];
   __shared__ unsigned char s_val[256];
-  const int img = blockIdx.y;
-  const int li = blockIdx.x;
-  const int slot = li == 0 ? slots_a.x : li == 1 ? slots_a.y : li == 2 ? slots_a.z : li == 3 ? slots_a.w
-                 : li == 4 ? slots_b.x : li == 5 ? slots_b.y : li == 6 ? slots_b.z : slots_b.w;
-  MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
-  const int lane = threadIdx.x;
   const unsigned INF = 1000000001u;
   unsigned f[5];
   int cs[5], g[5];
@@ -547,6 +506,24 @@ k_gen_tables(MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 slots_a,
       T->ehufco[sym] = (uint16_t)(s_first[L] + (p - s_cum[L - 1]));
     }
   }
+}
+
+
+__global__ void __launch_bounds__(64)
+k_gen_tables(MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 slots_a, int4 slots_b)
+{
+  const int img = blockIdx.y;
+  const int li = blockIdx.x;
+  const int slot = li == 0 ? slots_a.x : li == 1 ? slots_a.y : li == 2 ? slots_a.z : li == 3 ? slots_a.w
+                 : li == 4 ? slots_b.x : li == 5 ? slots_b.y : li == 6 ? slots_b.z : slots_b.w;
+  gen_table_body(tabs + (size_t)img * slots_per_image + slot, threadIdx.x);
+}
+
+// same, slots from a device array (progressive mode: one table set per candidate scan)
+__global__ void __launch_bounds__(64)
+k_gen_tables_list(MjhHuffTable *__restrict__ tabs, int slots_per_image, const int *__restrict__ slot_list)
+{
+  gen_table_body(tabs + (size_t)blockIdx.y * slots_per_image + slot_list[blockIdx.x], threadIdx.x);
 }
 
 // =============================================================================================
@@ -982,38 +959,6 @@ k_enc_len(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *__
 // chunk = 2048 items (256 threads x 8)
 #define SCAN_CHUNK 2048
 
-__device__ __forceinline__ unsigned block_reduce_256(unsigned v, unsigned *sh)
-{
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) sh[w] = v;
-  __syncthreads();
-  const unsigned tot = sh[0] + sh[1] + sh[2] + sh[3];
-  __syncthreads();
-  return tot;
-}
-
-// exclusive scan of one value per thread within a 256-thread block; returns exclusive prefix
-__device__ __forceinline__ unsigned block_excl_scan_256(unsigned v, unsigned *sh, unsigned *total)
-{
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  unsigned inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const unsigned n = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += n;
-  }
-  if (lane == 63) sh[w] = inc;
-  __syncthreads();
-  unsigned base = 0;
-  for (int i = 0; i < w; i++) base += sh[i];
-  const unsigned tot = sh[0] + sh[1] + sh[2] + sh[3];
-  __syncthreads();
-  if (total) *total = tot;
-  return base + inc - v;
-}
-
 template <class T>
 __global__ void __launch_bounds__(256)
 k_chunk_sums(const T *__restrict__ len16, int n_per_image, unsigned *__restrict__ sums, int chunks_per_image)
@@ -1097,33 +1042,6 @@ __device__ __forceinline__ bool is_marker_pos(const unsigned *__restrict__ mpos,
   }
   return false;
 }
-
-// bit writer: ORs big-endian bit strings into a zero-initialised word array
-struct BitWriter {
-  unsigned *words;       // stream base (32-bit words, bytes are big-endian inside the stream)
-  unsigned long long acc;
-  int nacc;              // valid bits in acc (low end)
-  unsigned widx;
-  __device__ __forceinline__ void init(unsigned *w, unsigned bitoff) { words = w; widx = bitoff >> 5; nacc = (int)(bitoff & 31); acc = 0; }
-  __device__ __forceinline__ void put(unsigned code, int n)
-  {
-    acc = (acc << n) | (unsigned long long)(code & ((1u << n) - 1u));
-    nacc += n;
-    if (nacc >= 32) {
-      const unsigned w = (unsigned)(acc >> (nacc - 32));
-      atomicOr(&words[widx], __builtin_bswap32(w));
-      widx++;
-      nacc -= 32;
-    }
-  }
-  __device__ __forceinline__ void flush()
-  {
-    if (nacc > 0) {
-      const unsigned w = (unsigned)(acc << (32 - nacc));
-      atomicOr(&words[widx], __builtin_bswap32(w));
-    }
-  }
-};
 
 __global__ void __launch_bounds__(256)
 k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs,
@@ -1399,6 +1317,11 @@ void mjh_launch_gen_tables(MjhHuffTable *tabs, int spi, const int *slots, int ns
   int sl[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
   for (int i = 0; i < nslots && i < 8; i++) sl[i] = slots[i];
   hipLaunchKernelGGL(k_gen_tables, dim3(nslots, n), dim3(64), 0, s, tabs, spi, make_int4(sl[0], sl[1], sl[2], sl[3]), make_int4(sl[4], sl[5], sl[6], sl[7]));
+}
+
+void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots, int nslots, int n, hipStream_t s)
+{
+  if (nslots > 0) hipLaunchKernelGGL(k_gen_tables_list, dim3(nslots, n), dim3(64), 0, s, tabs, spi, d_slots);
 }
 
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda, unsigned *worklist, int variant, int n, hipStream_t s)

@@ -20,4 +20,15 @@ void mjh_launch_header(const void *prefix, int prefix_len, const void *sos, int 
                        const int dht_slots[4], const int dht_ids[4], int ndht, int multi_dht, void *out, size_t out_stride, void *meta, int n, hipStream_t s);
 void mjh_launch_stuff(const unsigned *stream, size_t stream_words_per_image, const unsigned *totals, unsigned *ffsums, int ff_chunks_per_image,
                       unsigned *ff_totals, void *out, size_t out_stride, void *meta, unsigned *sizes, const unsigned *mpos, int nseg, int n, hipStream_t s);
+void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots, int nslots, int n, hipStream_t s);
+// progressive mode (mjh_prog.hip)
+void mjh_launch_prog_reset(void *ctl, int nscans, int n, hipStream_t s);
+void mjh_launch_prog_stats(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
+                           MjhHuffTable *tabs, int spi, int n, hipStream_t s);
+void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
+                            MjhHuffTable *tabs, int spi, unsigned *pool, size_t pool_words, const void *frame_hdr, int frame_hdr_len,
+                            int multi_dht, void *outpool, size_t out_bytes, int n, hipStream_t s);
+void mjh_launch_prog_select(void *ctl, int ncomp, int phase, int n, hipStream_t s);
+void mjh_launch_prog_concat(const void *ctl, const void *file_hdr, int file_hdr_len, const void *outpool, size_t out_bytes,
+                            void *out, size_t out_stride, unsigned *sizes, int n, hipStream_t s);
 #endif

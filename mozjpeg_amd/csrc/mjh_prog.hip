@@ -1,0 +1,682 @@
+// mjh_prog.hip -- progressive-JPEG entropy coding on gfx950.
+//
+// Reference behaviour: jcphuff.c (encode_mcu_DC_first :468, encode_mcu_AC_first :648,
+// encode_mcu_DC_refine :746, encode_mcu_AC_refine :918, emit_eobrun :409, flush_bits :362),
+// per-scan optimal tables (finish_pass_gather_phuff :1055), scan buffers with their own headers
+// (jcmaster.c:671-684) and the scan search (select_scans jcmaster.c:773-962).
+//
+// Parallelisation.  Progressive AC coding carries state across blocks (EOBRUN, and for refinement
+// scans up to ~1000 buffered correction bits with a data-dependent forced-flush rule), so a scan
+// is inherently a sequence.  What IS independent: scans (up to 64 candidates in the scan search),
+// images, and -- inside a scan -- the per-block symbol work.  Hence:
+//   one WAVE per (scan, image); the wave walks the scan 64 blocks (lanes) at a time:
+//     phase A  every lane analyses its block in parallel (coalesced plane reads): own symbol
+//              bits, "non-empty" and "contributes to EOBRUN" flags, trailing correction bits;
+//     phase B  a wave-uniform pass over the 64 lane summaries runs the EOBRUN / correction-bit
+//              state machine of the reference verbatim (incl. the 0x7FFF and BE>937 forced
+//              flushes), assigning every lane its bit offset; pending correction bits live in an
+//              LDS bit buffer that is copied out cooperatively at each flush;
+//     phase C  lanes write their own symbols at their offsets (atomicOr into the zeroed pool).
+// The same kernel in statistics mode feeds the on-device Huffman table builder.  All candidate
+// scans of a search phase run concurrently; the host never sees a symbol.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mjh_internal.h"
+#include "mjh_device.h"
+#include "mjh_launch.h"
+
+__device__ __forceinline__ unsigned wave_excl_scan(unsigned v, int lane, unsigned *total)
+{
+  unsigned inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned n = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += n;
+  }
+  *total = __shfl(inc, 63, 64);
+  return inc - v;
+}
+
+__device__ __forceinline__ void put_long(BitWriter &bw, unsigned v, int n)   // n <= 32
+{
+  if (n > 16) { bw.put(v >> 16, n - 16); bw.put(v & 0xFFFFu, 16); }
+  else if (n > 0) bw.put(v, n);
+}
+
+// EOBRUN symbol: (nbits-1) << 4, followed by nbits-1 extra bits (emit_eobrun jcphuff.c:409-431)
+__device__ __forceinline__ int eobrun_symbol(unsigned eobrun, int *nextra)
+{
+  const int nb = bitlen(eobrun) - 1;
+  *nextra = nb;
+  return nb << 4;
+}
+
+template <int ENCODE>
+__global__ void __launch_bounds__(64)
+k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
+            MjhProgCtl *__restrict__ ctl, const int16_t *__restrict__ coef_q, MjhHuffTable *__restrict__ tabs,
+            int slots_per_image, unsigned *__restrict__ pool, size_t pool_words_per_image)
+{
+  __shared__ unsigned hist[2][256];
+  __shared__ unsigned s_tab[2][256];   // size << 16 | code
+  __shared__ unsigned pend[36];        // pending correction bits, MSB first
+  const int img = blockIdx.y;
+  const int sidx = scan_list[blockIdx.x];
+  const MjhProgScan sc = scans[sidx];
+  MjhProgCtl *ct = ctl + img;
+  const int lane = threadIdx.x;
+  const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
+  const int16_t *qimg = coef_q + (size_t)img * C.coefs_per_image;
+  const bool has0 = sc.slot[0] >= 0, has1 = sc.slot[1] >= 0;   // DC scans: table number 0 / 1; AC scans: slot[0]
+  MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + (has0 ? sc.slot[0] : 0);
+  MjhHuffTable *T1 = tabs + (size_t)img * slots_per_image + (has1 ? sc.slot[1] : 0);
+  unsigned *stream = pool + (size_t)img * pool_words_per_image;
+  if (ENCODE && ct->error) return;
+
+  for (int i = lane; i < 256; i += 64) {
+    hist[0][i] = 0; hist[1][i] = 0;
+    if (ENCODE) {
+      s_tab[0][i] = has0 ? ((unsigned)T0->ehufsi[i] << 16) | T0->ehufco[i] : 0u;
+      s_tab[1][i] = has1 ? ((unsigned)T1->ehufsi[i] << 16) | T1->ehufco[i] : 0u;
+    }
+  }
+  if (lane < 36) pend[lane] = 0;
+  __syncthreads();
+
+  unsigned cur = ENCODE ? ct->scan_words_off[sidx] * 32u : 0u;   // running bit offset in the pool
+  const unsigned start_bits = cur;
+  unsigned corr_total = 0;   // statistics mode: total correction bits of a refinement scan
+
+  if (sc.Ss == 0) {
+    // ------------------------------------------------------------------ DC scans (first / refine)
+    const bool inter = sc.ncomp > 1;
+    const MjhComp c0 = C.c[sc.comp[0]];
+    const int nunits = inter ? C.mcus_per_row * C.mcu_rows : c0.nblk;
+    for (int base = 0; base < nunits; base += 64) {
+      const int u = base + lane;
+      const bool valid = u < nunits;
+      unsigned mybits = 0;
+      // pass 0: bits (or statistics); pass 1 (encode only): write
+      for (int pass = 0; pass < (ENCODE ? 2 : 1); pass++) {
+        BitWriter bw;
+        unsigned off = 0, tot = 0;
+        if (pass == 1) {
+          off = wave_excl_scan(mybits, lane, &tot);
+          bw.init(stream, cur + off);
+        }
+        if (valid) {
+          for (int ci = 0; ci < sc.ncomp; ci++) {
+            const MjhComp cc = C.c[sc.comp[ci]];
+            const int16_t *q0 = qimg + cc.coef_off;
+            const int tb = cc.dctbl & 1;
+            const int mh = inter ? cc.v : 1, mw = inter ? cc.h : 1;
+            for (int yi = 0; yi < mh; yi++)
+              for (int xi = 0; xi < mw; xi++) {
+                int dc, pred = 0;
+                if (inter) {
+                  const int my = u / C.mcus_per_row, mx = u - my * C.mcus_per_row;
+                  const int r = my * cc.v + yi, c = mx * cc.h + xi;
+                  dc = q0[dc_source_block(cc, r, c)];
+                  int pr, pc;
+                  if (sc.Ah == 0 && mcu_prev_block(C, cc, r, c, pr, pc)) pred = q0[dc_source_block(cc, pr, pc)] >> Al;
+                } else {
+                  dc = q0[u];
+                  if (sc.Ah == 0 && u > 0) pred = q0[u - 1] >> Al;
+                }
+                if (sc.Ah == 0) {                       // encode_mcu_DC_first
+                  const int v = dc >> Al;               // arithmetic shift = point transform
+                  const int df = v - pred;
+                  const int a = df < 0 ? -df : df;
+                  const int nb = bitlen((unsigned)a);
+                  if (!ENCODE) atomicAdd(&hist[tb][nb], 1u);
+                  else if (pass == 0) mybits += (s_tab[tb][nb] >> 16) + nb;
+                  else {
+                    const unsigned e = s_tab[tb][nb];
+                    bw.put(e & 0xFFFF, (int)(e >> 16));
+                    if (nb) bw.put((unsigned)(df < 0 ? df - 1 : df), nb);
+                  }
+                } else {                                // encode_mcu_DC_refine: the Al'th bit
+                  if (ENCODE) { if (pass == 0) mybits += 1; else bw.put((unsigned)(dc >> Al) & 1u, 1); }
+                }
+              }
+          }
+        }
+        if (pass == 1) { bw.flush(); cur += tot; }
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------ AC scans (first / refine)
+    const MjhComp cc = C.c[sc.comp[0]];
+    const int16_t *qc = qimg + cc.coef_off;
+    const int Ss = sc.Ss, Se = sc.Se;
+    const bool refine = sc.Ah != 0;
+    unsigned EOBRUN = 0, BE = 0;
+
+    // flush the pending EOB run (+ buffered correction bits) at bit offset `cur`
+    auto flush_run = [&]() {
+      int nextra;
+      const int sym = eobrun_symbol(EOBRUN, &nextra);
+      if (!ENCODE) { if (lane == 0) atomicAdd(&hist[0][sym], 1u); }
+      else {
+        const unsigned e = s_tab[0][sym];
+        const int len = (int)(e >> 16);
+        if (lane == 0) {
+          BitWriter bw;
+          bw.init(stream, cur);
+          bw.put(e & 0xFFFF, len);
+          if (nextra) bw.put(EOBRUN & ((1u << nextra) - 1u), nextra);
+          bw.flush();
+        }
+        cur += (unsigned)(len + nextra);
+        if (BE) {
+          __syncthreads();
+          const int nw = (int)((BE + 31) >> 5);
+          if (lane < nw) {
+            const int nb = (int)min(32u, BE - 32u * lane);
+            BitWriter bw;
+            bw.init(stream, cur + 32u * lane);
+            put_long(bw, pend[lane] >> (32 - nb), nb);
+            bw.flush();
+            pend[lane] = 0;
+          }
+          __syncthreads();
+          cur += BE;
+        }
+      }
+      EOBRUN = 0;
+      BE = 0;
+    };
+
+    for (int base = 0; base < cc.nblk; base += 64) {
+      const int b = base + lane;
+      const bool valid = b < cc.nblk;
+      const int nvalid = min(64, cc.nblk - base);
+      const int16_t *qb = qc + b;
+      // ---- phase A: per-lane block analysis
+      bool ne = false, E = false;
+      unsigned own_bits = 0;
+      unsigned long long newm = 0, nzm = 0, corrm = 0, posm = 0, tailm = 0;
+      int tail_cnt = 0;
+      if (valid) {
+        if (!refine) {
+          int r = 0;
+          for (int k = Ss; k <= Se; k++) {
+            const int v = qb[(size_t)k * cc.kstride];
+            const int a = (v < 0 ? -v : v) >> Al;
+            if (a == 0) { r++; continue; }
+            ne = true;
+            const int nz16 = r >> 4;
+            r &= 15;
+            const int nb = bitlen((unsigned)a);
+            const int sym = (r << 4) + nb;
+            if (!ENCODE) { if (nz16) atomicAdd(&hist[0][0xF0], (unsigned)nz16); atomicAdd(&hist[0][sym], 1u); }
+            else own_bits += (unsigned)nz16 * (s_tab[0][0xF0] >> 16) + (s_tab[0][sym] >> 16) + nb;
+            r = 0;
+          }
+          E = r > 0;
+        } else {
+          for (int k = Ss; k <= Se; k++) {
+            const int v = qb[(size_t)k * cc.kstride];
+            const int a = (v < 0 ? -v : v) >> Al;
+            if (a == 1) { newm |= 1ull << k; if (v >= 0) posm |= 1ull << k; }
+            else if (a > 1) { nzm |= 1ull << k; if (a & 1) corrm |= 1ull << k; }
+          }
+          ne = newm != 0;
+          const int EOBk = ne ? 63 - __builtin_clzll(newm) : -1;
+          int r = 0, prev = Ss - 1, BR = 0, flushed_below = Ss;
+          unsigned long long mm = newm | nzm;
+          while (mm) {
+            const int k = __builtin_ctzll(mm);
+            mm &= mm - 1;
+            r += k - prev - 1;
+            prev = k;
+            while (r > 15 && k <= EOBk) {
+              if (!ENCODE) atomicAdd(&hist[0][0xF0], 1u);
+              else own_bits += (s_tab[0][0xF0] >> 16) + BR;
+              BR = 0; flushed_below = k; r -= 16;
+            }
+            if ((nzm >> k) & 1ull) { BR++; continue; }
+            const int sym = (r << 4) + 1;
+            if (!ENCODE) atomicAdd(&hist[0][sym], 1u);
+            else own_bits += (s_tab[0][sym] >> 16) + 1 + BR;
+            BR = 0; flushed_below = k + 1; r = 0;
+          }
+          r += Se - prev;
+          tail_cnt = BR;
+          E = (r > 0) || (BR > 0);
+          tailm = flushed_below < 64 ? (nzm & ~((1ull << flushed_below) - 1ull)) : 0ull;
+          if (!ENCODE) corr_total += (unsigned)__popcll(nzm);
+        }
+      }
+      // trailing correction bits as an MSB-first string
+      unsigned long long tail_bits = 0;
+      {
+        unsigned long long tm = tailm;
+        while (tm) { const int k = __builtin_ctzll(tm); tm &= tm - 1; tail_bits = (tail_bits << 1) | ((corrm >> k) & 1ull); }
+      }
+      // ---- phase B: the EOBRUN / correction-bit state machine over the 64 lane summaries
+      const unsigned long long ne_mask = __ballot(ne), E_mask = __ballot(E);
+      unsigned out_off = 0;
+      for (int j = 0; j < nvalid; j++) {
+        const bool ne_j = (ne_mask >> j) & 1ull, E_j = (E_mask >> j) & 1ull;
+        if (!ne_j && !E_j) continue;
+        const unsigned own_j = (unsigned)__builtin_amdgcn_readlane((int)own_bits, j);
+        if (ne_j) {
+          if (EOBRUN > 0) flush_run();
+          if (lane == j) out_off = cur;
+          cur += own_j;
+        }
+        if (E_j) {
+          if (refine) {
+            const int tc = __builtin_amdgcn_readlane(tail_cnt, j);
+            if (ENCODE && tc > 0) {
+              const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)tail_bits, j);
+              const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(tail_bits >> 32), j);
+              const unsigned long long tb = ((unsigned long long)hi << 32) | lo;
+              if (lane == 0) {
+                unsigned pos = BE;
+                int rem = tc;
+                while (rem > 0) {
+                  const int w = (int)(pos >> 5), o = (int)(pos & 31);
+                  const int take = min(32 - o, rem);
+                  const unsigned chunk = (unsigned)((tb >> (rem - take)) & ((1ull << take) - 1ull));
+                  pend[w] |= chunk << (32 - o - take);
+                  pos += take; rem -= take;
+                }
+              }
+            }
+            BE += (unsigned)tc;
+          }
+          EOBRUN++;
+          if (EOBRUN == 0x7FFF || BE > 1000u - 64u + 1u) flush_run();   // jcphuff.c:719,:998-1000
+        }
+      }
+      // ---- phase C: lanes write their own symbols
+      if (ENCODE && ne) {
+        BitWriter bw;
+        bw.init(stream, out_off);
+        if (!refine) {
+          int r = 0;
+          for (int k = Ss; k <= Se; k++) {
+            const int v = qb[(size_t)k * cc.kstride];
+            const int a = (v < 0 ? -v : v) >> Al;
+            if (a == 0) { r++; continue; }
+            while (r > 15) { const unsigned e = s_tab[0][0xF0]; bw.put(e & 0xFFFF, (int)(e >> 16)); r -= 16; }
+            const int nb = bitlen((unsigned)a);
+            const unsigned e = s_tab[0][(r << 4) + nb];
+            bw.put(e & 0xFFFF, (int)(e >> 16));
+            bw.put((unsigned)(v < 0 ? ~a : a), nb);
+            r = 0;
+          }
+        } else {
+          const int EOBk = 63 - __builtin_clzll(newm);
+          int r = 0, prev = Ss - 1, fb = Ss;
+          unsigned long long mm = newm | nzm;
+          auto put_corr = [&](int lo, int hi) {   // correction bits of already-nonzero positions in [lo, hi)
+            unsigned long long m = nzm & ~((1ull << lo) - 1ull);
+            if (hi < 64) m &= (1ull << hi) - 1ull;
+            while (m) { const int k = __builtin_ctzll(m); m &= m - 1; bw.put((unsigned)((corrm >> k) & 1ull), 1); }
+          };
+          while (mm) {
+            const int k = __builtin_ctzll(mm);
+            mm &= mm - 1;
+            r += k - prev - 1;
+            prev = k;
+            while (r > 15 && k <= EOBk) {
+              const unsigned e = s_tab[0][0xF0];
+              bw.put(e & 0xFFFF, (int)(e >> 16));
+              put_corr(fb, k);
+              fb = k; r -= 16;
+            }
+            if ((nzm >> k) & 1ull) continue;
+            const unsigned e = s_tab[0][(r << 4) + 1];
+            bw.put(e & 0xFFFF, (int)(e >> 16));
+            bw.put((unsigned)((posm >> k) & 1ull), 1);
+            put_corr(fb, k);
+            fb = k + 1; r = 0;
+          }
+        }
+        bw.flush();
+      }
+    }
+    if (EOBRUN > 0) flush_run();   // finish_pass_phuff / finish_pass_gather_phuff
+  }
+
+  __syncthreads();
+  if (!ENCODE) {
+    // statistics -> table slots (+ the trellis-pass seeding of jcphuff.c:257-264)
+    for (int i = lane; i < 256; i += 64) {
+      unsigned s0 = hist[0][i];
+      if (sc.seed && (i & 15) < 12) s0 += 1;
+      if (has0) T0->counts[i] = s0;
+      if (has1) T1->counts[i] = hist[1][i];
+    }
+    // total correction bits of this scan (needed to size its bit stream): wave sum -> counts[258]
+    unsigned t = corr_total;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (lane == 0 && has0) { T0->counts[256] = 0; T0->counts[257] = 0; T0->counts[258] = t; }
+  } else {
+    // flush_bits jcphuff.c:362-367: pad the last byte with 1-bits
+    const unsigned tb = cur - start_bits;
+    if (lane == 0) {
+      if (tb & 7u) {
+        const unsigned padbits = 8u - (tb & 7u), bitpos = cur & 31u;
+        atomicOr(&stream[cur >> 5], __builtin_bswap32(((1u << padbits) - 1u) << (32u - bitpos - padbits)));
+      }
+      if (ct->scan_bits[sidx] != tb) ct->error = 2;   // the size predicted from the statistics must be exact
+      ct->scan_bits[sidx] = tb;
+    }
+  }
+}
+
+// exact size of every scan's bit stream from its statistics and code lengths, and its place in the
+// pools.  One thread per image (a few dozen scans x 256 symbols).
+__global__ void __launch_bounds__(64)
+k_prog_alloc(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, int nlist,
+             MjhProgCtl *__restrict__ ctl, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
+             size_t pool_words_per_image, size_t out_bytes_per_image, int nimg)
+{
+  const int img = blockIdx.x * 64 + threadIdx.x;
+  if (img >= nimg) return;
+  MjhProgCtl *ct = ctl + img;
+  for (int li = 0; li < nlist; li++) {
+    const int sidx = scan_list[li];
+    const MjhProgScan sc = scans[sidx];
+    unsigned long long bits = 0;
+    if (sc.Ss == 0) {
+      if (sc.Ah == 0) {
+        for (int t = 0; t < 2; t++) {
+          if (sc.slot[t] < 0) continue;
+          const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + sc.slot[t];
+          for (int s = 0; s < 17; s++) bits += (unsigned long long)T->counts[s] * (T->ehufsi[s] + s);
+        }
+      } else {
+        for (int ci = 0; ci < sc.ncomp; ci++) {
+          const MjhComp &cc = C.c[sc.comp[ci]];
+          bits += sc.ncomp > 1 ? (unsigned long long)cc.wpad * cc.hpad : (unsigned long long)cc.nblk;
+        }
+      }
+    } else {
+      const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + sc.slot[0];
+      for (int s = 0; s < 256; s++) {
+        const unsigned c = T->counts[s];
+        if (!c) continue;
+        const int extra = (s & 15) ? (s & 15) : (s == 0xF0 ? 0 : (s >> 4));
+        bits += (unsigned long long)c * (T->ehufsi[s] + extra);
+      }
+      bits += T->counts[258];   // correction bits (refinement scans)
+    }
+    const unsigned words = (unsigned)((bits + 7) / 32) + 2;
+    ct->scan_bits[sidx] = (unsigned)bits;
+    ct->scan_words_off[sidx] = ct->pool_words_used;
+    ct->scan_out_off[sidx] = ct->out_bytes_used;
+    const unsigned long long pw = (unsigned long long)ct->pool_words_used + words;
+    const unsigned long long ob = (unsigned long long)ct->out_bytes_used + 1280ull + 8ull * words;
+    if (pw > pool_words_per_image || ob > out_bytes_per_image) { ct->error = 1; continue; }
+    ct->pool_words_used = (unsigned)pw;
+    ct->out_bytes_used = (unsigned)ob;
+  }
+}
+
+// scan header into the scan's buffer: [DQT + SOF for scan 0] DHT SOS (jcmaster.c:671-684,
+// write_scan_header jcmarker.c:744-784)
+__global__ void __launch_bounds__(64)
+k_prog_header(const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, MjhProgCtl *__restrict__ ctl,
+              const MjhHuffTable *__restrict__ tabs, int slots_per_image, const uint8_t *__restrict__ frame_hdr, int frame_hdr_len,
+              int multi_dht, uint8_t *__restrict__ outpool, size_t out_bytes_per_image)
+{
+  const int img = blockIdx.y;
+  const int sidx = scan_list[blockIdx.x];
+  const MjhProgScan sc = scans[sidx];
+  MjhProgCtl *ct = ctl + img;
+  const int lane = threadIdx.x;
+  if (ct->error) return;
+  uint8_t *o = outpool + (size_t)img * out_bytes_per_image + ct->scan_out_off[sidx];
+  int pos = 0;
+  if (sc.frame_header) {
+    for (int i = lane; i < frame_hdr_len; i += 64) o[i] = frame_hdr[i];
+    pos = frame_hdr_len;
+  }
+  if (multi_dht) {     // emit_multi_dht jcmarker.c:293-401: one marker, possibly empty (DC refinement scans)
+    int length = 2;
+    for (int i = 0; i < sc.ndht; i++) length += (int)tabs[(size_t)img * slots_per_image + sc.dht_slot[i]].nsyms + 17;
+    if (lane == 0) { o[pos] = 0xFF; o[pos + 1] = 0xC4; o[pos + 2] = (uint8_t)(length >> 8); o[pos + 3] = (uint8_t)length; }
+    pos += 4;
+  }
+  for (int i = 0; i < sc.ndht; i++) {
+    const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + sc.dht_slot[i];
+    const int n = (int)T->nsyms;
+    if (!multi_dht) {
+      const int length = n + 2 + 1 + 16;
+      if (lane == 0) { o[pos] = 0xFF; o[pos + 1] = 0xC4; o[pos + 2] = (uint8_t)(length >> 8); o[pos + 3] = (uint8_t)length; }
+      pos += 4;
+    }
+    if (lane == 0) o[pos] = (uint8_t)sc.dht_id[i];
+    if (lane < 16) o[pos + 1 + lane] = T->bits[lane + 1];
+    for (int j = lane; j < n; j += 64) o[pos + 17 + j] = T->huffval[j];
+    pos += 17 + n;
+  }
+  if (lane == 0) {     // emit_sos jcmarker.c:494-531
+    const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
+    uint8_t *s = o + pos;
+    int k = 0;
+    s[k++] = 0xFF; s[k++] = 0xDA;
+    const int len = 2 * sc.ncomp + 2 + 1 + 3;
+    s[k++] = (uint8_t)(len >> 8); s[k++] = (uint8_t)len;
+    s[k++] = (uint8_t)sc.ncomp;
+    for (int i = 0; i < sc.ncomp; i++) { s[k++] = (uint8_t)sc.comp_id[i]; s[k++] = (uint8_t)((sc.td[i] << 4) + sc.ta[i]); }
+    s[k++] = (uint8_t)sc.Ss; s[k++] = (uint8_t)sc.Se; s[k++] = (uint8_t)((sc.Ah << 4) + Al);
+    ct->scan_hdr_len[sidx] = (unsigned)(pos + k);
+  }
+}
+
+// byte stuffing of one scan's bit stream into its buffer; one workgroup per (scan, image)
+__global__ void __launch_bounds__(256)
+k_prog_stuff(const int *__restrict__ scan_list, MjhProgCtl *__restrict__ ctl, const unsigned *__restrict__ pool,
+             size_t pool_words_per_image, uint8_t *__restrict__ outpool, size_t out_bytes_per_image)
+{
+  __shared__ unsigned sh[4];
+  const int img = blockIdx.y;
+  const int sidx = scan_list[blockIdx.x];
+  MjhProgCtl *ct = ctl + img;
+  if (ct->error) return;
+  const unsigned nbytes = (ct->scan_bits[sidx] + 7) >> 3;
+  const unsigned nwords = (nbytes + 3) >> 2;
+  const unsigned *p = pool + (size_t)img * pool_words_per_image + ct->scan_words_off[sidx];
+  const unsigned hdr = ct->scan_hdr_len[sidx];
+  uint8_t *o = outpool + (size_t)img * out_bytes_per_image + ct->scan_out_off[sidx] + hdr;
+  unsigned carry = 0;
+  for (unsigned cb = 0; cb < nwords; cb += 2048) {
+    const unsigned base = cb + threadIdx.x * 8;
+    unsigned w[8], s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      w[i] = base + i < nwords ? p[base + i] : 0u;
+      s += ((w[i] & 0xFFu) == 0xFFu) + ((w[i] & 0xFF00u) == 0xFF00u) + ((w[i] & 0xFF0000u) == 0xFF0000u) + ((w[i] & 0xFF000000u) == 0xFF000000u);
+    }
+    unsigned tot;
+    unsigned ex = block_excl_scan_256(s, sh, &tot) + carry;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const unsigned wi = base + i;
+      if (wi < nwords) {
+        unsigned dst = wi * 4 + ex;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const unsigned byte = (w[i] >> (8 * b)) & 0xFF;
+          if (wi * 4 + b < nbytes) {
+            o[dst++] = (uint8_t)byte;
+            if (byte == 0xFF) { o[dst++] = 0; ex++; }
+          }
+        }
+      }
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) ct->scan_size[sidx] = hdr + nbytes + carry;
+}
+
+// ---- scan search decisions: select_scans jcmaster.c:773-962 with the constants of
+// jpeg_search_progression (jcparam.c:733-852).  Every candidate of a phase has been coded, but the
+// decision consults sizes exactly as the reference would: it walks the candidates in order and
+// stops where the reference would have stopped coding them.
+__global__ void __launch_bounds__(64)
+k_prog_select_al(MjhProgCtl *__restrict__ ctl, int ncomp, int nimg)
+{
+  const int img = blockIdx.x * 64 + threadIdx.x;
+  if (img >= nimg) return;
+  MjhProgCtl *ct = ctl + img;
+  const unsigned *sz = ct->scan_size;
+  // luma successive approximation: scans 1,2 (Al 0) then {3+3a, 4+3a, 5+3a} for a = 0..2
+  unsigned long long best = 0;
+  int bestAl = 0;
+  for (int Al = 0; Al <= 3; Al++) {
+    // next_scan_number = 3 + 3*Al: cost = the two band scans just coded + all refinements below
+    unsigned long long cost = (unsigned long long)sz[3 * Al + 1] + sz[3 * Al + 2];
+    for (int i = 0; i < Al; i++) cost += sz[3 + 3 * i];
+    if (Al == 0 || cost < best) { best = cost; bestAl = Al; } else break;
+  }
+  ct->best_Al_luma = bestAl;
+  ct->best_Al_chroma = 0;
+  if (ncomp == 3) {
+    const int base = 23 + 3;   // num_scans_luma + num_scans_chroma_dc
+    best = 0; bestAl = 0;
+    for (int Al = 0; Al <= 2; Al++) {
+      // next_scan_number - base == 6*Al + 4: the four band scans just coded + refinements below
+      unsigned long long cost = 0;
+      for (int i = 0; i < 4; i++) cost += sz[base + 6 * Al + i];
+      for (int i = 0; i < Al; i++) cost += (unsigned long long)sz[base + 4 + 6 * i] + sz[base + 5 + 6 * i];
+      if (Al == 0 || cost < best) { best = cost; bestAl = Al; } else break;
+    }
+    ct->best_Al_chroma = bestAl;
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_prog_select_order(MjhProgCtl *__restrict__ ctl, int ncomp, int nimg)
+{
+  const int img = blockIdx.x * 64 + threadIdx.x;
+  if (img >= nimg) return;
+  MjhProgCtl *ct = ctl + img;
+  const unsigned *sz = ct->scan_size;
+  const int lfs = 12;                    // luma_freq_split_scan_start
+  const int nsl = 23;                    // num_scans_luma
+  const int base = nsl + 3;              // + num_scans_chroma_dc
+  const int cfs = nsl + 3 + (6 * 2 + 4); // chroma_freq_split_scan_start = 42
+  // luma frequency split: scan 12 = full band, then pairs (13+2i, 14+2i), i = 0..4
+  unsigned long long best = sz[lfs];
+  int fsl = 0;
+  for (int idx = 1; idx <= 5; idx++) {
+    const unsigned long long cost = (unsigned long long)sz[lfs + 2 * idx - 1] + sz[lfs + 2 * idx];
+    if (cost < best) { best = cost; fsl = idx; }
+    if ((idx == 2 && fsl == 0) || (idx == 3 && fsl != 2) || (idx == 4 && fsl != 4)) break;
+  }
+  ct->best_fs_luma = fsl;
+  int fsc = 0;
+  if (ncomp == 3) {
+    best = (unsigned long long)sz[cfs] + sz[cfs + 1];
+    for (int idx = 1; idx <= 5; idx++) {
+      unsigned long long cost = 0;
+      for (int i = 0; i < 4; i++) cost += sz[cfs + 4 * idx - 2 + i];
+      if (cost < best) { best = cost; fsc = idx; }
+      if ((idx == 2 && fsc == 0) || (idx == 3 && fsc != 2) || (idx == 4 && fsc != 4)) break;
+    }
+  }
+  ct->best_fs_chroma = fsc;
+  // final order, jcmaster.c:898-956
+  int n = 0;
+  int *ord = ct->order;
+  const int bl = ct->best_Al_luma, bc = ct->best_Al_chroma;
+  const int min_Al = bl < bc ? bl : bc;
+  ord[n++] = 0;
+  if (fsl == 0) ord[n++] = lfs;
+  else { ord[n++] = lfs + 2 * (fsl - 1) + 1; ord[n++] = lfs + 2 * (fsl - 1) + 2; }
+  for (int Al = bl - 1; Al >= min_Al; Al--) ord[n++] = 3 + 3 * Al;
+  if (ncomp == 3) {
+    if (fsc == 0) { ord[n++] = cfs; ord[n++] = cfs + 1; }
+    else for (int i = 2; i <= 5; i++) ord[n++] = cfs + 4 * (fsc - 1) + i;
+    for (int Al = bc - 1; Al >= min_Al; Al--) { ord[n++] = base + 6 * Al + 4; ord[n++] = base + 6 * Al + 5; }
+  }
+  for (int Al = min_Al - 1; Al >= 0; Al--) {
+    ord[n++] = 3 + 3 * Al;
+    if (ncomp == 3) { ord[n++] = base + 6 * Al + 4; ord[n++] = base + 6 * Al + 5; }
+  }
+  ct->norder = n;
+}
+
+// final file: SOI (+APP0), the chosen scan buffers in order, EOI
+__global__ void __launch_bounds__(256)
+k_prog_concat(const MjhProgCtl *__restrict__ ctl, const uint8_t *__restrict__ file_hdr, int file_hdr_len,
+              const uint8_t *__restrict__ outpool, size_t out_bytes_per_image, uint8_t *__restrict__ out, size_t out_stride,
+              unsigned *__restrict__ sizes)
+{
+  const int img = blockIdx.x;
+  const MjhProgCtl *ct = ctl + img;
+  uint8_t *o = out + (size_t)img * out_stride;
+  if (ct->error) { if (threadIdx.x == 0) sizes[img] = 0; return; }
+  for (int i = threadIdx.x; i < file_hdr_len; i += 256) o[i] = file_hdr[i];
+  size_t pos = file_hdr_len;
+  for (int s = 0; s < ct->norder; s++) {
+    const int sidx = ct->order[s];
+    const uint8_t *src = outpool + (size_t)img * out_bytes_per_image + ct->scan_out_off[sidx];
+    const unsigned n = ct->scan_size[sidx];
+    for (unsigned i = threadIdx.x; i < n; i += 256) o[pos + i] = src[i];
+    pos += n;
+  }
+  if (threadIdx.x == 0) { o[pos] = 0xFF; o[pos + 1] = 0xD9; sizes[img] = (unsigned)(pos + 2); }
+}
+
+__global__ void __launch_bounds__(64)
+k_prog_reset(MjhProgCtl *__restrict__ ctl, int nscans, int nimg)
+{
+  const int img = blockIdx.x * 64 + threadIdx.x;
+  if (img >= nimg) return;
+  MjhProgCtl *ct = ctl + img;
+  ct->best_Al_luma = ct->best_Al_chroma = ct->best_fs_luma = ct->best_fs_chroma = 0;
+  ct->pool_words_used = 0; ct->out_bytes_used = 0; ct->error = 0;
+  ct->norder = nscans;
+  for (int i = 0; i < nscans; i++) ct->order[i] = i;
+}
+
+// =============================================================================================
+// launch wrappers
+// =============================================================================================
+void mjh_launch_prog_reset(void *ctl, int nscans, int n, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_prog_reset, dim3((n + 63) / 64), dim3(64), 0, s, (MjhProgCtl *)ctl, nscans, n);
+}
+
+void mjh_launch_prog_stats(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
+                           MjhHuffTable *tabs, int spi, int n, hipStream_t s)
+{
+  hipLaunchKernelGGL((k_prog_scan<0>), dim3(nlist, n), dim3(64), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
+                     (const int16_t *)q, tabs, spi, (unsigned *)nullptr, (size_t)0);
+}
+
+void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
+                            MjhHuffTable *tabs, int spi, unsigned *pool, size_t pool_words, const void *frame_hdr, int frame_hdr_len,
+                            int multi_dht, void *outpool, size_t out_bytes, int n, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_prog_alloc, dim3((n + 63) / 64), dim3(64), 0, s, C, (const MjhProgScan *)scans, list, nlist, (MjhProgCtl *)ctl,
+                     (const MjhHuffTable *)tabs, spi, pool_words, out_bytes, n);
+  hipLaunchKernelGGL(k_prog_header, dim3(nlist, n), dim3(64), 0, s, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
+                     (const MjhHuffTable *)tabs, spi, (const uint8_t *)frame_hdr, frame_hdr_len, multi_dht, (uint8_t *)outpool, out_bytes);
+  hipLaunchKernelGGL((k_prog_scan<1>), dim3(nlist, n), dim3(64), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
+                     (const int16_t *)q, tabs, spi, pool, pool_words);
+  hipLaunchKernelGGL(k_prog_stuff, dim3(nlist, n), dim3(256), 0, s, list, (MjhProgCtl *)ctl, (const unsigned *)pool, pool_words,
+                     (uint8_t *)outpool, out_bytes);
+}
+
+void mjh_launch_prog_select(void *ctl, int ncomp, int phase, int n, hipStream_t s)
+{
+  if (phase == 0) hipLaunchKernelGGL(k_prog_select_al, dim3((n + 63) / 64), dim3(64), 0, s, (MjhProgCtl *)ctl, ncomp, n);
+  else hipLaunchKernelGGL(k_prog_select_order, dim3((n + 63) / 64), dim3(64), 0, s, (MjhProgCtl *)ctl, ncomp, n);
+}
+
+void mjh_launch_prog_concat(const void *ctl, const void *file_hdr, int file_hdr_len, const void *outpool, size_t out_bytes,
+                            void *out, size_t out_stride, unsigned *sizes, int n, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_prog_concat, dim3(n), dim3(256), 0, s, (const MjhProgCtl *)ctl, (const uint8_t *)file_hdr, file_hdr_len,
+                     (const uint8_t *)outpool, out_bytes, (uint8_t *)out, out_stride, sizes);
+}

@@ -43,11 +43,11 @@ CASES = [
     ("base_qtbl0", dict(baseline=True, quant_table=0), True),
     ("base_restart1", dict(baseline=True, restart=1), True),
     ("base_restart5b", dict(baseline=True, restart="5b"), True),
-    ("fastcrush", dict(fastcrush=True), False),
-    ("default_progressive", dict(), False),
-    ("q85_420_progressive", dict(quality=85), False),
-    ("revert_progressive", dict(revert=True, progressive=True), False),
-    ("q5_16bit_tables", dict(quality=5, fastcrush=True), False),
+    ("fastcrush", dict(fastcrush=True), True),
+    ("default_progressive", dict(), True),
+    ("q85_420_progressive", dict(quality=85), True),
+    ("revert_progressive", dict(revert=True, progressive=True), True),
+    ("q5_16bit_tables", dict(quality=5, fastcrush=True), True),
 ]
 
 # constants the REFERENCE itself pins for this path (CMakeLists.txt:1347-1420), cjpeg -revert ... testorig.ppm

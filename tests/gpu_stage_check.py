@@ -55,7 +55,7 @@ def check_case(img, kw, verbose=True):
             ok = False
     bits = enc.read_tap(M.TAP_HUFF_BITS, 0)
     vals = enc.read_tap(M.TAP_HUFF_VALS, 0)
-    if pg.optimize_coding:
+    if pg.optimize_coding and pg.num_scans == 0:
         for t in range(2 if pg.num_components == 3 else 1):
             for nm, gb, gv, ob, ov in (("dc", bits[2 * t], vals[2 * t], taps["dc_bits"][t], taps["dc_vals"][t]),
                                        ("ac", bits[2 * t + 1], vals[2 * t + 1], taps["ac_bits"][t], taps["ac_vals"][t])):
@@ -89,7 +89,10 @@ def main():
              dict(baseline=True, quality=90, sample=(1, 1)), dict(baseline=True, sample=(2, 1)),
              dict(revert=True, sample=(1, 2)), dict(baseline=True, gray=True), dict(baseline=True, quality=30),
              dict(baseline=True, restart=1), dict(baseline=True, restart="5b"), dict(revert=True, restart=2),
-             dict(baseline=True, restart="1b", sample=(1, 1))]
+             dict(baseline=True, restart="1b", sample=(1, 1)),
+             dict(revert=True, progressive=True), dict(fastcrush=True), dict(), dict(quality=85),
+             dict(gray=True), dict(fastcrush=True, notrellis=True), dict(quality=5, fastcrush=True),
+             dict(quality=92, sample=(1, 1))]
     bad = 0
     for img in imgs:
         for kw in cases:

@@ -59,7 +59,12 @@ def _gpu_present():
 
 
 def test_unsupported_configurations_are_errors_not_fallbacks():
-    p = M.make_params(64, 64)           # cjpeg default = progressive + scan search: not on the GPU path yet
+    p = M.make_params(64, 64, fastcrush=True, restart=1)   # restart intervals in progressive mode: not on the GPU path yet
+    with pytest.raises(M.MjhError) as ei:
+        M.Encoder(p)
+    assert ei.value.code == M.EUNSUPPORTED
+    p = M.make_params(64, 64)
+    p.scan_info[5].Ss = 2                                  # optimize_scans with a script that is not jpeg_search_progression's
     with pytest.raises(M.MjhError) as ei:
         M.Encoder(p)
     assert ei.value.code == M.EUNSUPPORTED
