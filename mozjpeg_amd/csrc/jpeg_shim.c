@@ -123,7 +123,24 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p)
   if (p->trellis_quant && !p->optimize_coding) return "trellis without optimize_coding";
   p->restart_interval = cinfo->restart_interval;
   p->restart_in_rows = cinfo->restart_in_rows;
-  if (cinfo->scan_info != NULL && cinfo->num_scans > 0) return "multi-scan (progressive) script";
+  if (cinfo->scan_info != NULL && cinfo->num_scans > 0) {
+    /* progressive script: jpeg_scan_info (jpeglib.h:196-201) -> mjh_scan; jpeg_start_compress drops
+     * optimize_scans when no search script was set up (jcapistd.c:53-56) */
+    int si;
+    if (cinfo->num_scans > MJH_MAX_SCANS) return "more than 64 scans";
+    p->num_scans = cinfo->num_scans;
+    for (si = 0; si < cinfo->num_scans; si++) {
+      const jpeg_scan_info *js = &cinfo->scan_info[si];
+      mjh_scan *ms = &p->scan_info[si];
+      int k;
+      ms->comps_in_scan = js->comps_in_scan;
+      for (k = 0; k < js->comps_in_scan && k < MJH_MAX_COMPS; k++) ms->component_index[k] = js->component_index[k];
+      ms->Ss = js->Ss; ms->Se = js->Se; ms->Ah = js->Ah; ms->Al = js->Al;
+    }
+    p->optimize_scans = jpeg_c_get_bool_param(cinfo, JBOOLEAN_OPTIMIZE_SCANS) && cinfo->master->num_scans_luma != 0;
+    p->optimize_coding = 1;   /* jcmaster.c:1091-1094 */
+    if (jpeg_c_get_int_param(cinfo, JINT_DC_SCAN_OPT_MODE) != 0) return "dc_scan_opt_mode != 0";
+  }
   if (!cinfo->optimize_coding) {
     /* standard tables are baked into the GPU path; anything else needs optimize_coding */
     if (cinfo->dc_huff_tbl_ptrs[0] == NULL || cinfo->ac_huff_tbl_ptrs[0] == NULL) return "missing Huffman tables";
