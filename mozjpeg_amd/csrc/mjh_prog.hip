@@ -9,14 +9,18 @@
 // scans up to ~1000 buffered correction bits with a data-dependent forced-flush rule), so a scan
 // is inherently a sequence.  What IS independent: scans (up to 64 candidates in the scan search),
 // images, and -- inside a scan -- the per-block symbol work.  Hence:
-//   one WAVE per (scan, image); the wave walks the scan 64 blocks (lanes) at a time:
-//     phase A  every lane analyses its block in parallel (coalesced plane reads): own symbol
-//              bits, "non-empty" and "contributes to EOBRUN" flags, trailing correction bits;
-//     phase B  a wave-uniform pass over the 64 lane summaries runs the EOBRUN / correction-bit
-//              state machine of the reference verbatim (incl. the 0x7FFF and BE>937 forced
-//              flushes), assigning every lane its bit offset; pending correction bits live in an
-//              LDS bit buffer that is copied out cooperatively at each flush;
-//     phase C  lanes write their own symbols at their offsets (atomicOr into the zeroed pool).
+//   one WORKGROUP (8 waves) per (scan, image); wave w takes the 64-block steps w, w+8, ...:
+//     phase A  every lane analyses its block in parallel (63 coalesced plane loads in one burst):
+//              own symbol bits, "non-empty" / "contributes to EOBRUN" flags; refinement scans reduce a
+//              block to four 64-bit masks (new / already-nonzero / correction bit / sign);
+//     phase B  runs in step order under a token (LDS word + state {EOBRUN, BE, bit offset}).  Inside a
+//              run EOBRUN and BE only grow, so if the step cannot reach a forced flush (EOBRUN < 0x7FFF
+//              and BE <= 937 at its end) every flush is the natural one in front of a non-empty lane and
+//              all offsets follow in closed form from ballots and one wave prefix sum: O(1) per step.
+//              Otherwise the reference's state machine is run lane by lane (ordered path), with the
+//              pending correction bits in an LDS bit buffer that is copied out at each flush;
+//     phase C  lanes write their own symbols (and their trailing correction bits) at their offsets
+//              (atomicOr into the zeroed pool), overlapping the next steps' phase A/B of other waves.
 // The same kernel in statistics mode feeds the on-device Huffman table builder.  All candidate
 // scans of a search phase run concurrently; the host never sees a symbol.
 #include <hip/hip_runtime.h>
@@ -24,6 +28,7 @@
 #include "mjh_internal.h"
 #include "mjh_device.h"
 #include "mjh_launch.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ unsigned wave_excl_scan(unsigned v, int lane, unsigned *total)
 {
@@ -51,8 +56,9 @@ __device__ __forceinline__ int eobrun_symbol(unsigned eobrun, int *nextra)
   return nb << 4;
 }
 
+#define PROG_WAVES 8
 template <int ENCODE>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64 * PROG_WAVES)
 k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
             MjhProgCtl *__restrict__ ctl, const int16_t *__restrict__ coef_q, MjhHuffTable *__restrict__ tabs,
             int slots_per_image, unsigned *__restrict__ pool, size_t pool_words_per_image)
@@ -60,11 +66,12 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
   __shared__ unsigned hist[2][256];
   __shared__ unsigned s_tab[2][256];   // size << 16 | code
   __shared__ unsigned pend[36];        // pending correction bits, MSB first
+  __shared__ unsigned st_turn, st_eobrun, st_be, st_cur;   // the token: which 64-block step may run phase B, and its state
   const int img = blockIdx.y;
   const int sidx = scan_list[blockIdx.x];
   const MjhProgScan sc = scans[sidx];
   MjhProgCtl *ct = ctl + img;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
   const int16_t *qimg = coef_q + (size_t)img * C.coefs_per_image;
   const bool has0 = sc.slot[0] >= 0, has1 = sc.slot[1] >= 0;   // DC scans: table number 0 / 1; AC scans: slot[0]
@@ -73,14 +80,15 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
   unsigned *stream = pool + (size_t)img * pool_words_per_image;
   if (ENCODE && ct->error) return;
 
-  for (int i = lane; i < 256; i += 64) {
+  for (int i = threadIdx.x; i < 256; i += 64 * PROG_WAVES) {
     hist[0][i] = 0; hist[1][i] = 0;
     if (ENCODE) {
       s_tab[0][i] = has0 ? ((unsigned)T0->ehufsi[i] << 16) | T0->ehufco[i] : 0u;
       s_tab[1][i] = has1 ? ((unsigned)T1->ehufsi[i] << 16) | T1->ehufco[i] : 0u;
     }
   }
-  if (lane < 36) pend[lane] = 0;
+  if (threadIdx.x < 36) pend[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { st_turn = 0; st_eobrun = 0; st_be = 0; st_cur = ENCODE ? ct->scan_words_off[sidx] * 32u : 0u; }
   __syncthreads();
 
   unsigned cur = ENCODE ? ct->scan_words_off[sidx] * 32u : 0u;   // running bit offset in the pool
@@ -89,6 +97,7 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
 
   if (sc.Ss == 0) {
     // ------------------------------------------------------------------ DC scans (first / refine)
+    if (wave == 0) {
     const bool inter = sc.ncomp > 1;
     const MjhComp c0 = C.c[sc.comp[0]];
     const int nunits = inter ? C.mcus_per_row * C.mcu_rows : c0.nblk;
@@ -106,7 +115,7 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
         }
         if (valid) {
           for (int ci = 0; ci < sc.ncomp; ci++) {
-            const MjhComp cc = C.c[sc.comp[ci]];
+            const MjhComp cc = C.c[scans[sidx].comp[ci]];
             const int16_t *q0 = qimg + cc.coef_off;
             const int tb = cc.dctbl & 1;
             const int mh = inter ? cc.v : 1, mw = inter ? cc.h : 1;
@@ -144,6 +153,7 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
         if (pass == 1) { bw.flush(); cur += tot; }
       }
     }
+    }
   } else {
     // ------------------------------------------------------------------ AC scans (first / refine)
     const MjhComp cc = C.c[sc.comp[0]];
@@ -169,7 +179,7 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
         }
         cur += (unsigned)(len + nextra);
         if (BE) {
-          __syncthreads();
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // lane 0's LDS appends -> visible to the wave
           const int nw = (int)((BE + 31) >> 5);
           if (lane < nw) {
             const int nb = (int)min(32u, BE - 32u * lane);
@@ -179,7 +189,7 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
             bw.flush();
             pend[lane] = 0;
           }
-          __syncthreads();
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
           cur += BE;
         }
       }
@@ -187,39 +197,58 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
       BE = 0;
     };
 
-    for (int base = 0; base < cc.nblk; base += 64) {
+    const int nsteps = (cc.nblk + 63) >> 6;
+    for (int step = wave; step < nsteps; step += PROG_WAVES) {
+      const int base = step * 64;
       const int b = base + lane;
       const bool valid = b < cc.nblk;
       const int nvalid = min(64, cc.nblk - base);
-      const int16_t *qb = qc + b;
-      // ---- phase A: per-lane block analysis
+      // ---- phase A: per-lane block analysis.  The band is fetched with a fully unrolled, statically
+      // indexed loop: all (Se-Ss+1) coalesced plane loads are in flight together and the values stay
+      // in registers for phase C (a dependent load per coefficient would cost one HBM latency each).
       bool ne = false, E = false;
       unsigned own_bits = 0;
       unsigned long long newm = 0, nzm = 0, corrm = 0, posm = 0, tailm = 0;
       int tail_cnt = 0;
+      int x[64];
+      {
+        // unconditional, in-bounds loads (invalid lanes re-read the last block): straight-line code, so the
+        // compiler issues all 63 before the first use instead of one waitcnt per predicated load
+        const int16_t *qs = qc + (valid ? b : cc.nblk - 1);
+#pragma unroll
+        for (int k = 1; k < 64; k++) x[k] = (int)qs[(size_t)k * cc.kstride];
+      }
       if (valid) {
         if (!refine) {
           int r = 0;
-          for (int k = Ss; k <= Se; k++) {
-            const int v = qb[(size_t)k * cc.kstride];
-            const int a = (v < 0 ? -v : v) >> Al;
-            if (a == 0) { r++; continue; }
-            ne = true;
-            const int nz16 = r >> 4;
-            r &= 15;
-            const int nb = bitlen((unsigned)a);
-            const int sym = (r << 4) + nb;
-            if (!ENCODE) { if (nz16) atomicAdd(&hist[0][0xF0], (unsigned)nz16); atomicAdd(&hist[0][sym], 1u); }
-            else own_bits += (unsigned)nz16 * (s_tab[0][0xF0] >> 16) + (s_tab[0][sym] >> 16) + nb;
-            r = 0;
+#pragma unroll
+          for (int k = 1; k < 64; k++) {
+            if (k >= Ss && k <= Se) {
+              const int v = x[k];
+              const int a = (v < 0 ? -v : v) >> Al;
+              if (a == 0) r++;
+              else {
+                ne = true;
+                const int nz16 = r >> 4;
+                r &= 15;
+                const int nb = bitlen((unsigned)a);
+                const int sym = (r << 4) + nb;
+                if (!ENCODE) { if (nz16) atomicAdd(&hist[0][0xF0], (unsigned)nz16); atomicAdd(&hist[0][sym], 1u); }
+                else own_bits += (unsigned)nz16 * (s_tab[0][0xF0] >> 16) + (s_tab[0][sym] >> 16) + nb;
+                r = 0;
+              }
+            }
           }
           E = r > 0;
         } else {
-          for (int k = Ss; k <= Se; k++) {
-            const int v = qb[(size_t)k * cc.kstride];
-            const int a = (v < 0 ? -v : v) >> Al;
-            if (a == 1) { newm |= 1ull << k; if (v >= 0) posm |= 1ull << k; }
-            else if (a > 1) { nzm |= 1ull << k; if (a & 1) corrm |= 1ull << k; }
+#pragma unroll
+          for (int k = 1; k < 64; k++) {
+            if (k >= Ss && k <= Se) {
+              const int v = x[k];
+              const int a = (v < 0 ? -v : v) >> Al;
+              if (a == 1) { newm |= 1ull << k; if (v >= 0) posm |= 1ull << k; }
+              else if (a > 1) { nzm |= 1ull << k; if (a & 1) corrm |= 1ull << k; }
+            }
           }
           ne = newm != 0;
           const int EOBk = ne ? 63 - __builtin_clzll(newm) : -1;
@@ -254,9 +283,115 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
         unsigned long long tm = tailm;
         while (tm) { const int k = __builtin_ctzll(tm); tm &= tm - 1; tail_bits = (tail_bits << 1) | ((corrm >> k) & 1ull); }
       }
-      // ---- phase B: the EOBRUN / correction-bit state machine over the 64 lane summaries
+      // ---- phase B (in step order: wait for the token, run, pass it on)
       const unsigned long long ne_mask = __ballot(ne), E_mask = __ballot(E);
+      while (__hip_atomic_load(&st_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)step) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      EOBRUN = st_eobrun; BE = st_be; cur = st_cur;
       unsigned out_off = 0;
+      bool fast = EOBRUN + 64u < 0x7FFFu;
+      unsigned tsum = 0, texcl = 0;
+      if (refine) {
+        texcl = wave_excl_scan((unsigned)tail_cnt, lane, &tsum);
+        fast = fast && (BE + tsum <= 937u);
+      }
+      if (fast) {
+        // No forced flush can trigger inside this step (EOBRUN and BE only grow inside a run), so every
+        // flush is the natural one in front of a non-empty block and its pending state follows from the
+        // position of the previous non-empty lane: closed form, all lanes in parallel.
+        unsigned flushbits = 0, cnt = 0, be = 0;
+        int fsym = 0, fextra = 0;
+        const unsigned long long below = ne_mask & ((1ull << lane) - 1ull);
+        const int pl = below ? 63 - __builtin_clzll(below) : -1;          // previous non-empty lane
+        const unsigned texcl_pl = refine ? (unsigned)__shfl((int)texcl, pl < 0 ? 0 : pl, 64) : 0u;
+        if (ne) {
+          if (pl >= 0) {                                    // the run = pl's EOB + the empties between
+            cnt = (unsigned)((E_mask >> pl) & 1ull) + (unsigned)(lane - pl - 1);
+            be = texcl - texcl_pl;
+          } else {                                          // run carried in from earlier steps + leading empties
+            cnt = EOBRUN + (unsigned)lane;
+            be = BE + texcl;
+          }
+          if (cnt > 0) {
+            fsym = eobrun_symbol(cnt, &fextra);
+            if (!ENCODE) atomicAdd(&hist[0][fsym], 1u);
+            else flushbits = (s_tab[0][fsym] >> 16) + (unsigned)fextra + be;
+          }
+        }
+        unsigned tot;
+        const unsigned ex = wave_excl_scan(ne ? flushbits + own_bits : 0u, lane, &tot);
+        if (ENCODE) {
+          // correction area of a flushing lane = right behind its EOBRUN symbol
+          const unsigned ca = cur + ex + (flushbits - be);
+          if (ne) {
+            if (cnt > 0) {      // the EOBRUN symbol of the pending run goes in front of the lane's own symbols
+              const unsigned e = s_tab[0][fsym];
+              BitWriter bw;
+              bw.init(stream, cur + ex);
+              bw.put(e & 0xFFFF, (int)(e >> 16));
+              if (fextra) bw.put(cnt & ((1u << fextra) - 1u), fextra);
+              bw.flush();
+            }
+            out_off = cur + ex + flushbits;
+          }
+          if (refine) {
+            // (1) correction bits carried in from earlier steps: flushed by the first non-empty lane
+            if (ne_mask && BE) {
+              const int f0 = __builtin_ctzll(ne_mask);
+              const unsigned ca0 = (unsigned)__shfl((int)ca, f0, 64);
+              const int nw = (int)((BE + 31) >> 5);
+              if (lane < nw) {
+                const int nb = (int)min(32u, BE - 32u * lane);
+                BitWriter bw;
+                bw.init(stream, ca0 + 32u * lane);
+                put_long(bw, pend[lane] >> (32 - nb), nb);
+                bw.flush();
+                pend[lane] = 0;
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            }
+            // (2) every lane's trailing correction bits go to the correction area of the next non-empty
+            //     lane, or into the LDS buffer if the run is still pending at the end of this step
+            const unsigned long long above = lane < 63 ? (ne_mask & ~((2ull << lane) - 1ull)) : 0ull;
+            const int fl = above ? __builtin_ctzll(above) : 0;
+            const unsigned ca_f = (unsigned)__shfl((int)ca, fl, 64);
+            const int rs = ne ? lane : pl;                  // first lane of my run (-1: carried in)
+            const unsigned rs_excl = ne ? texcl : texcl_pl;
+            const unsigned offs = rs >= 0 ? texcl - rs_excl : BE + texcl;
+            if (tail_cnt > 0) {
+              if (above) {
+                BitWriter bw;
+                bw.init(stream, ca_f + offs);
+                put_long(bw, (unsigned)(tail_bits >> 32), tail_cnt > 32 ? tail_cnt - 32 : 0);
+                put_long(bw, (unsigned)tail_bits, tail_cnt > 32 ? 32 : tail_cnt);
+                bw.flush();
+              } else {
+                unsigned pos = offs;   // relative to the pending run (the carried bits were flushed above if a non-empty lane exists)
+                int rem = tail_cnt;
+                while (rem > 0) {
+                  const int w = (int)(pos >> 5), o = (int)(pos & 31);
+                  const int take = min(32 - o, rem);
+                  const unsigned chunk = (unsigned)((tail_bits >> (rem - take)) & ((1ull << take) - 1ull));
+                  atomicOr(&pend[w], chunk << (32 - o - take));
+                  pos += take; rem -= take;
+                }
+              }
+            }
+          }
+        }
+        cur += tot;
+        if (ne_mask) {
+          const int last = 63 - __builtin_clzll(ne_mask);
+          EOBRUN = (unsigned)((E_mask >> last) & 1ull) + (unsigned)(nvalid - 1 - last);
+          if (refine) BE = tsum - (unsigned)__shfl((int)texcl, last, 64);
+        } else {
+          EOBRUN += (unsigned)nvalid;
+          BE += tsum;
+        }
+      } else {
+      // ordered path: the reference's state machine over the 64 lane summaries (forced flushes at
+      // EOBRUN == 0x7FFF and BE > 937, pending correction bits buffered in LDS)
+#pragma nounroll
       for (int j = 0; j < nvalid; j++) {
         const bool ne_j = (ne_mask >> j) & 1ull, E_j = (E_mask >> j) & 1ull;
         if (!ne_j && !E_j) continue;
@@ -291,22 +426,31 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
           if (EOBRUN == 0x7FFF || BE > 1000u - 64u + 1u) flush_run();   // jcphuff.c:719,:998-1000
         }
       }
+      }
+      if (lane == 0) { st_eobrun = EOBRUN; st_be = BE; st_cur = cur; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(&st_turn, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       // ---- phase C: lanes write their own symbols
       if (ENCODE && ne) {
         BitWriter bw;
         bw.init(stream, out_off);
         if (!refine) {
           int r = 0;
-          for (int k = Ss; k <= Se; k++) {
-            const int v = qb[(size_t)k * cc.kstride];
-            const int a = (v < 0 ? -v : v) >> Al;
-            if (a == 0) { r++; continue; }
-            while (r > 15) { const unsigned e = s_tab[0][0xF0]; bw.put(e & 0xFFFF, (int)(e >> 16)); r -= 16; }
-            const int nb = bitlen((unsigned)a);
-            const unsigned e = s_tab[0][(r << 4) + nb];
-            bw.put(e & 0xFFFF, (int)(e >> 16));
-            bw.put((unsigned)(v < 0 ? ~a : a), nb);
-            r = 0;
+#pragma unroll
+          for (int k = 1; k < 64; k++) {
+            if (k >= Ss && k <= Se) {
+              const int v = x[k];
+              const int a = (v < 0 ? -v : v) >> Al;
+              if (a == 0) r++;
+              else {
+                while (r > 15) { const unsigned e = s_tab[0][0xF0]; bw.put(e & 0xFFFF, (int)(e >> 16)); r -= 16; }
+                const int nb = bitlen((unsigned)a);
+                const unsigned e = s_tab[0][(r << 4) + nb];
+                bw.put(e & 0xFFFF, (int)(e >> 16));
+                bw.put((unsigned)(v < 0 ? ~a : a), nb);
+                r = 0;
+              }
+            }
           }
         } else {
           const int EOBk = 63 - __builtin_clzll(newm);
@@ -339,13 +483,17 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
         bw.flush();
       }
     }
-    if (EOBRUN > 0) flush_run();   // finish_pass_phuff / finish_pass_gather_phuff
+    __syncthreads();
+    if (wave == 0) {
+      EOBRUN = st_eobrun; BE = st_be; cur = st_cur;
+      if (EOBRUN > 0) flush_run();   // finish_pass_phuff / finish_pass_gather_phuff
+    }
   }
 
   __syncthreads();
   if (!ENCODE) {
     // statistics -> table slots (+ the trellis-pass seeding of jcphuff.c:257-264)
-    for (int i = lane; i < 256; i += 64) {
+    for (int i = threadIdx.x; i < 256; i += 64 * PROG_WAVES) {
       unsigned s0 = hist[0][i];
       if (sc.seed && (i & 15) < 12) s0 += 1;
       if (has0) T0->counts[i] = s0;
@@ -355,11 +503,15 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
     unsigned t = corr_total;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
-    if (lane == 0 && has0) { T0->counts[256] = 0; T0->counts[257] = 0; T0->counts[258] = t; }
+    if (threadIdx.x == 0) st_be = 0;               // st_be is free again: sum of the waves' correction-bit counts
+    __syncthreads();
+    if (lane == 0 && t) atomicAdd(&st_be, t);
+    __syncthreads();
+    if (threadIdx.x == 0 && has0) { T0->counts[256] = 0; T0->counts[257] = 0; T0->counts[258] = st_be; }
   } else {
     // flush_bits jcphuff.c:362-367: pad the last byte with 1-bits
     const unsigned tb = cur - start_bits;
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
       if (tb & 7u) {
         const unsigned padbits = 8u - (tb & 7u), bitpos = cur & 31u;
         atomicOr(&stream[cur >> 5], __builtin_bswap32(((1u << padbits) - 1u) << (32u - bitpos - padbits)));
@@ -650,7 +802,7 @@ void mjh_launch_prog_reset(void *ctl, int nscans, int n, hipStream_t s)
 void mjh_launch_prog_stats(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
                            MjhHuffTable *tabs, int spi, int n, hipStream_t s)
 {
-  hipLaunchKernelGGL((k_prog_scan<0>), dim3(nlist, n), dim3(64), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
+  hipLaunchKernelGGL((k_prog_scan<0>), dim3(nlist, n), dim3(64 * PROG_WAVES), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
                      (const int16_t *)q, tabs, spi, (unsigned *)nullptr, (size_t)0);
 }
 
@@ -662,7 +814,7 @@ void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *lis
                      (const MjhHuffTable *)tabs, spi, pool_words, out_bytes, n);
   hipLaunchKernelGGL(k_prog_header, dim3(nlist, n), dim3(64), 0, s, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
                      (const MjhHuffTable *)tabs, spi, (const uint8_t *)frame_hdr, frame_hdr_len, multi_dht, (uint8_t *)outpool, out_bytes);
-  hipLaunchKernelGGL((k_prog_scan<1>), dim3(nlist, n), dim3(64), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
+  hipLaunchKernelGGL((k_prog_scan<1>), dim3(nlist, n), dim3(64 * PROG_WAVES), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
                      (const int16_t *)q, tabs, spi, pool, pool_words);
   hipLaunchKernelGGL(k_prog_stuff, dim3(nlist, n), dim3(256), 0, s, list, (MjhProgCtl *)ctl, (const unsigned *)pool, pool_words,
                      (uint8_t *)outpool, out_bytes);
