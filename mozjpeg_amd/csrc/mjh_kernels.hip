@@ -295,19 +295,29 @@ k_stats_ac(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restr
   for (int i = tid; i < 1024; i += 256) (&h[0][0])[i] = 0;
   __syncthreads();
   const int blk = blockIdx.x * 256 + tid;
-  if (blk < cc.nblk) {
-    unsigned *hh = h[tid & 3];
-    const int16_t *q = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
-    int r = 0;
-    for (int k = 1; k < 64; k++) {
-      const int v = q[(size_t)k * cc.kstride];
-      if (v == 0) { r++; continue; }
-      while (r > 15) { atomicAdd(&hh[0xF0], 1u); r -= 16; }
-      const int nb = bitlen((unsigned)(v < 0 ? -v : v));
-      atomicAdd(&hh[(r << 4) + nb], 1u);
-      r = 0;
+  {
+    // all 63 plane loads in one burst (unconditional, index clamped for the tail lanes): a load
+    // inside the data-dependent run-length loop would cost one memory latency per coefficient
+    const int16_t *q = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + (blk < cc.nblk ? blk : cc.nblk - 1);
+    int x[64];
+#pragma unroll
+    for (int k = 1; k < 64; k++) x[k] = q[(size_t)k * cc.kstride];
+    if (blk < cc.nblk) {
+      unsigned *hh = h[tid & 3];
+      int r = 0;
+#pragma unroll
+      for (int k = 1; k < 64; k++) {
+        const int v = x[k];
+        if (v == 0) r++;
+        else {
+          if (r > 15) { atomicAdd(&hh[0xF0], (unsigned)(r >> 4)); r &= 15; }
+          const int nb = bitlen((unsigned)(v < 0 ? -v : v));
+          atomicAdd(&hh[(r << 4) + nb], 1u);
+          r = 0;
+        }
+      }
+      if (r > 0) atomicAdd(&hh[0], 1u);
     }
-    if (r > 0) atomicAdd(&hh[0], 1u);
   }
   __syncthreads();
   const int slot = comp == 0 ? slot_of_comp.x : comp == 1 ? slot_of_comp.y : comp == 2 ? slot_of_comp.z : slot_of_comp.w;
@@ -937,16 +947,25 @@ k_enc_len(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *__
   const int df = dc - pred;
   int nb = bitlen((unsigned)(df < 0 ? -df : df));
   int bits = s_dc[nb] + nb;
-  if (r < cc.hib && c < cc.wib) {
-    const int16_t *qb = q + r * cc.wib + c;
+  const bool real = r < cc.hib && c < cc.wib;
+  int x[64];
+  {
+    const int16_t *qb = q + (real ? r * cc.wib + c : 0);   // dummy blocks: load anything in bounds, ignore it
+#pragma unroll
+    for (int k = 1; k < 64; k++) x[k] = qb[(size_t)k * cc.kstride];
+  }
+  if (real) {
     int run = 0;
+#pragma unroll
     for (int k = 1; k < 64; k++) {
-      const int v = qb[(size_t)k * cc.kstride];
-      if (v == 0) { run++; continue; }
-      bits += (run >> 4) * s_ac[0xF0];
-      nb = bitlen((unsigned)(v < 0 ? -v : v));
-      bits += s_ac[((run & 15) << 4) + nb] + nb;
-      run = 0;
+      const int v = x[k];
+      if (v == 0) run++;
+      else {
+        bits += (run >> 4) * s_ac[0xF0];
+        nb = bitlen((unsigned)(v < 0 ? -v : v));
+        bits += s_ac[((run & 15) << 4) + nb] + nb;
+        run = 0;
+      }
     }
     if (run > 0) bits += s_ac[0];
   } else {
@@ -1082,19 +1101,28 @@ k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *
     bw.put(e & 0xFFFF, (int)(e >> 16));
     if (nb) bw.put((unsigned)(df < 0 ? df - 1 : df), nb);
   }
-  if (r < cc.hib && c < cc.wib) {
-    const int16_t *qb = q + r * cc.wib + c;
+  const bool real = r < cc.hib && c < cc.wib;
+  int x[64];
+  {
+    const int16_t *qb = q + (real ? r * cc.wib + c : 0);
+#pragma unroll
+    for (int k = 1; k < 64; k++) x[k] = qb[(size_t)k * cc.kstride];
+  }
+  if (real) {
     int run = 0;
+#pragma unroll
     for (int k = 1; k < 64; k++) {
-      const int v = qb[(size_t)k * cc.kstride];
-      if (v == 0) { run++; continue; }
-      while (run > 15) { const unsigned e = s_ac[0xF0]; bw.put(e & 0xFFFF, (int)(e >> 16)); run -= 16; }
-      const int a = v < 0 ? -v : v;
-      const int nb = bitlen((unsigned)a);
-      const unsigned e = s_ac[(run << 4) + nb];
-      bw.put(e & 0xFFFF, (int)(e >> 16));
-      bw.put((unsigned)(v < 0 ? v - 1 : v), nb);
-      run = 0;
+      const int v = x[k];
+      if (v == 0) run++;
+      else {
+        while (run > 15) { const unsigned e = s_ac[0xF0]; bw.put(e & 0xFFFF, (int)(e >> 16)); run -= 16; }
+        const int a = v < 0 ? -v : v;
+        const int nb = bitlen((unsigned)a);
+        const unsigned e = s_ac[(run << 4) + nb];
+        bw.put(e & 0xFFFF, (int)(e >> 16));
+        bw.put((unsigned)(v < 0 ? v - 1 : v), nb);
+        run = 0;
+      }
     }
     if (run > 0) { const unsigned e = s_ac[0]; bw.put(e & 0xFFFF, (int)(e >> 16)); }
   } else {
