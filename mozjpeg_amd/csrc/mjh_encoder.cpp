@@ -241,7 +241,7 @@ struct mjh_encoder {
   unsigned *d_seg_x = nullptr, *d_seg_E = nullptr, *d_seg_sums = nullptr, *d_seg_totals = nullptr, *d_mpos = nullptr;
   int nseg = 1;
   int comp_restart[4] = { 0, 0, 0, 0 };
-  unsigned *d_worklist = nullptr;   // deferred trellis blocks: [0] = count, [4+2i], [5+2i] = (image, comp<<28|block)
+  unsigned *d_worklist = nullptr, *d_worklist2 = nullptr;   // deferred trellis blocks: [0] = count, [4+2i], [5+2i] = (image, comp<<28|block)
   int trellis_variant = 0;
   int spi = SLOTS_BASE;             // table slots per image (16 + 2 per progressive scan)
   // progressive mode
@@ -530,7 +530,7 @@ static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *ptrs[] = { e->d_pix, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pix, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -587,6 +587,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   HIPCHK_E(hipMalloc((void **)&e->d_lambda, B * C.total_real_blocks * sizeof(float)));
   HIPCHK_E(hipMalloc((void **)&e->d_back, B * (size_t)C.total_real_blocks * 16));
   HIPCHK_E(hipMalloc((void **)&e->d_worklist, 16 + B * (size_t)C.total_real_blocks * 8));
+  HIPCHK_E(hipMalloc((void **)&e->d_worklist2, 16 + B * (size_t)C.total_real_blocks * 8));
   if (const char *v = getenv("MJH_TRELLIS_VARIANT")) e->trellis_variant = atoi(v);
   HIPCHK_E(hipMalloc((void **)&e->d_len16, B * (size_t)C.total_mcu_blocks * 2));
   HIPCHK_E(hipMalloc((void **)&e->d_off32, B * (size_t)C.total_mcu_blocks * 4));
@@ -835,7 +836,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
     }
     pr.mark("trellis_ac");
-    mjh_launch_trellis_ac(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_ac, e->d_lambda, e->d_worklist, e->trellis_variant, n, s);
+    mjh_launch_trellis_ac(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->trellis_variant, n, s);
     if (p.trellis_quant_dc) {
       pr.mark("join(trellis_dc)");
       HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));

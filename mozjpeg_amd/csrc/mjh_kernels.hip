@@ -726,14 +726,17 @@ k_trellis_ac(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restri
   }
 }
 
-// full-capacity path for the deferred blocks (any image / component per lane)
+// deferred blocks (any image / component per lane): capacity NE2; blocks that still overflow go to
+// the next work list (NE2 = 64 never overflows: at most 63 AC positions + the start entry)
+template <int NE2>
 __global__ void __launch_bounds__(64)
 k_trellis_ac_deferred(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
                       int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
-                      int4 ac_slot_of_comp, const float *__restrict__ lambda_in, const unsigned *__restrict__ worklist)
+                      int4 ac_slot_of_comp, const float *__restrict__ lambda_in, const unsigned *__restrict__ worklist,
+                      unsigned *__restrict__ worklist_next)
 {
-  __shared__ float2 e_aa[64][64];
-  __shared__ unsigned short e_pk[64][64];
+  __shared__ float2 e_aa[NE2][64];
+  __shared__ unsigned short e_pk[NE2][64];
   const int lane = threadIdx.x;
   const unsigned count = worklist[0];
   for (unsigned it = blockIdx.x * 64 + lane; it < count; it += gridDim.x * 64) {
@@ -746,8 +749,13 @@ k_trellis_ac_deferred(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t 
     const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
     int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
     const float lambda = lambda_in[(size_t)img * C.total_real_blocks + cc.blk_off + blk];
-    trellis_ac_block<64>(reinterpret_cast<const uint4 *>(T->ehufsi), uq, qo, cc.kstride, Q->q[cc.qtbl], Q->rcp8q[cc.qtbl],
-                         Q->lambda_tbl[cc.qtbl], lambda, e_aa, e_pk, lane);
+    const bool ok = trellis_ac_block<NE2>(reinterpret_cast<const uint4 *>(T->ehufsi), uq, qo, cc.kstride, Q->q[cc.qtbl], Q->rcp8q[cc.qtbl],
+                                          Q->lambda_tbl[cc.qtbl], lambda, e_aa, e_pk, lane);
+    if (!ok && NE2 < 64) {
+      const unsigned idx = atomicAdd(&worklist_next[0], 1u);
+      worklist_next[4 + 2 * (size_t)idx] = (unsigned)img;
+      worklist_next[5 + 2 * (size_t)idx] = w;
+    }
   }
 }
 
@@ -1352,11 +1360,12 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
   if (nslots > 0) hipLaunchKernelGGL(k_gen_tables_list, dim3(nslots, n), dim3(64), 0, s, tabs, spi, d_slots);
 }
 
-void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda, unsigned *worklist, int variant, int n, hipStream_t s)
+void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda, unsigned *worklist, unsigned *worklist2, int variant, int n, hipStream_t s)
 {
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
   const int4 sl = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
   (void)hipMemsetAsync(worklist, 0, 16, s);
+  (void)hipMemsetAsync(worklist2, 0, 16, s);
 #define LT(NE) hipLaunchKernelGGL((k_trellis_ac<NE>), grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, worklist)
   switch (variant) {
     case 1: LT(12); break;
@@ -1367,7 +1376,9 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     default: LT(16); break;
   }
 #undef LT
-  hipLaunchKernelGGL(k_trellis_ac_deferred, dim3(1024), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, (const unsigned *)worklist);
+  // second and third tier: 32 entries (20 KB LDS per wave), then the full 64
+  hipLaunchKernelGGL((k_trellis_ac_deferred<32>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, (const unsigned *)worklist, worklist2);
+  hipLaunchKernelGGL((k_trellis_ac_deferred<64>), dim3(512), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, (const unsigned *)worklist2, worklist2);
 }
 
 void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s)
