@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
@@ -155,6 +155,16 @@ def main():
         dom_ms = ktimes[dom] / args.steps
         algo_bytes = float(w) * h * 3 * B + jpeg_bytes
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # separate runs, fetch corrected by the factor calibrated on k_color; tools/rocprof_summary.py) -- per launch
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_hbm_traffic_batch16.json")))
+            if (w, h) == (W, H) and dom.startswith("trellis_ac"):
+                per_frame = sum(v["hbm_bytes_per_frame"] for k, v in pmc["kernels"].items() if k.startswith("k_trellis_ac"))
+                traffic = int(per_frame * B)
+        except Exception:
+            traffic = None
         out = {
             "metric": "Mpixels/s encode (4K RGB q75 trellis baseline), bit-exact vs cjpeg",
             "value": round(total_px / elapsed / 1e6, 2), "unit": "Mpixels/s", "n_gpus": world,
@@ -168,7 +178,9 @@ def main():
             "bit_exact_vs_oracle": bitexact,
             "jpeg_bytes_per_frame": int(jpeg_bytes / B),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": "profiles/r01b_pmc_hbm_traffic_batch16.json (bytes per launch, scaled to this batch)" if traffic else None,
+                         "algorithmic_bytes_per_launch": int(algo_bytes),
                          "kernel_ms_per_step": {k: round(v / args.steps, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])}},
         }
         if not args.no_cpu_baseline:

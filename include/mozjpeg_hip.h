@@ -76,6 +76,11 @@ typedef struct {
   mjh_scan scan_info[MJH_MAX_SCANS];
   int optimize_scans;
   int write_JFIF_header;
+  /* layout of one input pixel, the extended RGB colour spaces of jpeglib.h:262-290 / jccolext.c
+   * (TurboJPEG's TJPF_*): bytes per pixel (0 = input_components) and the byte offsets of R, G, B
+   * (all 0 = R,G,B at 0,1,2).  input_components stays 3 for every RGB-family layout. */
+  int input_pixel_size;
+  int rgb_offset[3];
 } mjh_params;
 
 typedef struct mjh_encoder mjh_encoder;

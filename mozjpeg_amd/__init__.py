@@ -42,7 +42,8 @@ class Params(C.Structure):
                 ("trellis_quant_dc", C.c_int), ("overshoot_deringing", C.c_int),
                 ("lambda_log_scale1", C.c_float), ("lambda_log_scale2", C.c_float),
                 ("restart_interval", C.c_uint), ("restart_in_rows", C.c_int), ("num_scans", C.c_int),
-                ("scan_info", Scan * MAX_SCANS), ("optimize_scans", C.c_int), ("write_JFIF_header", C.c_int)]
+                ("scan_info", Scan * MAX_SCANS), ("optimize_scans", C.c_int), ("write_JFIF_header", C.c_int),
+                ("input_pixel_size", C.c_int), ("rgb_offset", C.c_int * 3)]
 
 
 _lib = None

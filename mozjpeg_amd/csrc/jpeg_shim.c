@@ -86,9 +86,23 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p)
   if (cinfo->smoothing_factor) return "input smoothing";
   if (cinfo->dct_method != JDCT_ISLOW) return "dct_method other than JDCT_ISLOW";
   if (cinfo->write_Adobe_marker) return "Adobe marker";
-  if (cinfo->in_color_space == JCS_RGB && cinfo->input_components == 3) p->input_components = 3;
-  else if (cinfo->in_color_space == JCS_GRAYSCALE && cinfo->input_components == 1) p->input_components = 1;
-  else return "input colour space (only JCS_RGB / JCS_GRAYSCALE)";
+  {
+    /* rgb_red/green/blue/pixelsize of jccolor.c / jmorecfg.h for the extended colour spaces */
+    int ps = 0, ro = 0, go = 1, bo = 2;
+    switch (cinfo->in_color_space) {
+    case JCS_RGB: case JCS_EXT_RGB: ps = 3; break;
+    case JCS_EXT_BGR: ps = 3; ro = 2; bo = 0; break;
+    case JCS_EXT_RGBX: case JCS_EXT_RGBA: ps = 4; break;
+    case JCS_EXT_BGRX: case JCS_EXT_BGRA: ps = 4; ro = 2; bo = 0; break;
+    case JCS_EXT_XBGR: case JCS_EXT_ABGR: ps = 4; ro = 3; go = 2; bo = 1; break;
+    case JCS_EXT_XRGB: case JCS_EXT_ARGB: ps = 4; ro = 1; go = 2; bo = 3; break;
+    case JCS_GRAYSCALE: ps = 1; break;
+    default: return "input colour space (RGB family / grayscale only)";
+    }
+    if (cinfo->input_components != ps) ERREXIT(cinfo, JERR_BAD_IN_COLORSPACE);
+    if (ps == 1) p->input_components = 1;
+    else { p->input_components = 3; p->input_pixel_size = ps; p->rgb_offset[0] = ro; p->rgb_offset[1] = go; p->rgb_offset[2] = bo; }
+  }
   if (cinfo->jpeg_color_space == JCS_YCbCr && cinfo->num_components == 3) p->num_components = 3;
   else if (cinfo->jpeg_color_space == JCS_GRAYSCALE && cinfo->num_components == 1) p->num_components = 1;
   else return "JPEG colour space (only YCbCr / grayscale)";

@@ -295,6 +295,11 @@ static int check_supported(const mjh_params *p)
     for (int i = 1; i < 3; i++)
       if (p->h_samp_factor[i] != 1 || p->v_samp_factor[i] != 1) return fail(MJH_EUNSUPPORTED, "chroma sampling must be 1x1");
   }
+  if (p->input_components == 3) {
+    const int ps = p->input_pixel_size ? p->input_pixel_size : 3;
+    if (ps != 3 && ps != 4) return fail(MJH_EINVAL, "input_pixel_size %d", ps);
+    for (int i = 0; i < 3; i++) if (p->rgb_offset[i] < 0 || p->rgb_offset[i] >= ps) return fail(MJH_EINVAL, "rgb_offset out of range");
+  } else if (p->input_pixel_size > 1) return fail(MJH_EINVAL, "grayscale input has 1 byte per pixel");
   for (int i = 0; i < p->num_components; i++) {
     if (p->quant_tbl_no[i] < 0 || p->quant_tbl_no[i] > 3 || p->dc_tbl_no[i] < 0 || p->dc_tbl_no[i] > 3 || p->ac_tbl_no[i] < 0 || p->ac_tbl_no[i] > 3)
       return fail(MJH_EINVAL, "table number out of range");
@@ -346,6 +351,9 @@ static void build_const(const mjh_params *p, MjhConst *C)
   memset(C, 0, sizeof(*C));
   C->W = p->image_width; C->H = p->image_height;
   C->in_comps = p->input_components; C->ncomp = p->num_components;
+  C->px_size = p->input_pixel_size ? p->input_pixel_size : p->input_components;
+  C->off_r = p->rgb_offset[0]; C->off_g = p->rgb_offset[1]; C->off_b = p->rgb_offset[2];
+  if (C->off_r == 0 && C->off_g == 0 && C->off_b == 0) { C->off_g = 1; C->off_b = 2; }
   C->maxh = C->maxv = 1;
   for (int i = 0; i < C->ncomp; i++) {
     if (p->h_samp_factor[i] > C->maxh) C->maxh = p->h_samp_factor[i];
@@ -577,7 +585,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   HIPCHK_E(hipEventCreate(&e->ev_side0));
   HIPCHK_E(hipEventCreate(&e->ev_side1));
   const size_t B = (size_t)max_batch;
-  e->pix_image_bytes = (size_t)C.W * C.H * C.in_comps;
+  e->pix_image_bytes = (size_t)C.W * C.H * C.px_size;
   HIPCHK_E(hipMalloc((void **)&e->d_planes, B * C.planes_per_image));
   HIPCHK_E(hipMalloc((void **)&e->d_uq, B * C.coefs_per_image * 2));
   HIPCHK_E(hipMalloc((void **)&e->d_q, B * C.coefs_per_image * 2));
@@ -896,7 +904,7 @@ extern "C" int mjh_encode_host(mjh_encoder *e, const void *pixels, size_t row_pi
 {
   if (!e || !pixels || n < 1 || n > e->max_batch) return fail(MJH_EINVAL, "bad arguments");
   HIPCHK(hipSetDevice(e->device));
-  const size_t row_bytes = (size_t)e->C.W * e->C.in_comps;
+  const size_t row_bytes = (size_t)e->C.W * e->C.px_size;
   if (!e->d_pix) {
     HIPCHK(hipMalloc((void **)&e->d_pix, (size_t)e->max_batch * e->pix_image_bytes));
     HIPCHK(hipHostMalloc((void **)&e->h_pix, (size_t)e->max_batch * e->pix_image_bytes, hipHostMallocDefault));

@@ -40,6 +40,7 @@ struct MjhComp {
 struct MjhConst {
   int W, H;
   int in_comps;           // 3 or 1
+  int px_size, off_r, off_g, off_b;   // input pixel layout (extended RGB formats)
   int ncomp;
   int maxh, maxv;
   int mcus_per_row, mcu_rows;

@@ -80,7 +80,8 @@ k_color(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, size_t im
       int ix = gx * H0 + vx;
       if (ix > C.W - 1) ix = C.W - 1;                 // jcsample.c:98
       if (ic == 3) {
-        const int r = row[ix * 3], g = row[ix * 3 + 1], b = row[ix * 3 + 2];
+        const uint8_t *px = row + (size_t)ix * C.px_size;
+        const int r = px[C.off_r], g = px[C.off_g], b = px[C.off_b];
         yv[vy][vx] = (FIXC(0.29900) * r + FIXC(0.58700) * g + FIXC(0.11400) * b + 32768) >> 16;
         cbs += (-FIXC(0.16874) * r - FIXC(0.33126) * g + FIXC(0.50000) * b + (128 << 16) + 32767) >> 16;
         crs += (FIXC(0.50000) * r - FIXC(0.41869) * g - FIXC(0.08131) * b + (128 << 16) + 32767) >> 16;

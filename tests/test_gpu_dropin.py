@@ -74,3 +74,56 @@ def test_explicit_passthrough_is_logged(goldens, tmp_path):
     assert r.returncode == 0, r.stderr.decode()
     assert b"handing over to the host libjpeg" in r.stderr
     assert open(out, "rb").read()[:2] == b"\xff\xd8"
+
+
+# ---- TurboJPEG boundary: the reference's own tjCompress2 (turbojpeg.c:1169, unchanged, built into
+# oracle/_ref/libturbojpeg.so.0) with the libjpeg drop-in in front of it --------------------------
+TJH = os.path.join(O.REF_DIR, "tjharness")
+needs_tj = pytest.mark.skipif(not (os.path.exists(SHIM) and os.path.exists(TJH)), reason="shim or tjharness not built")
+TJPF = {"RGB": (0, [0, 1, 2], 3), "BGR": (1, [2, 1, 0], 3), "RGBX": (2, [0, 1, 2], 4), "BGRX": (3, [2, 1, 0], 4),
+        "XBGR": (4, [3, 2, 1], 4), "XRGB": (5, [1, 2, 3], 4)}
+TJSAMP = {"444": 0, "422": 1, "420": 2, "GRAY": 3, "440": 4}
+ACCURATE, BOTTOMUP, PROGRESSIVE = 4096, 2, 16384
+
+
+def tj_run(raw, w, h, pf, ss, q, flags, out, preload):
+    env = dict(os.environ)
+    if preload:
+        env["LD_PRELOAD"] = SHIM
+    return subprocess.run([TJH, str(w), str(h), str(pf), str(ss), str(q), str(flags), raw, out], env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+
+@needs_tj
+@pytest.mark.parametrize("pfname", list(TJPF))
+@pytest.mark.parametrize("ssname,q,flags", [("420", 75, ACCURATE), ("444", 96, 0), ("422", 80, ACCURATE | BOTTOMUP),
+                                            ("GRAY", 75, ACCURATE), ("440", 60, ACCURATE), ("420", 85, ACCURATE | PROGRESSIVE)])
+def test_unchanged_tjcompress2_through_the_shim(pfname, ssname, q, flags, tmp_path):
+    import numpy as np
+    rgb = O.read_ppm(PPM)
+    h, w = rgb.shape[:2]
+    pf, offs, ps = TJPF[pfname]
+    px = np.full((h, w, ps), 0x5A, np.uint8)
+    for ch in range(3):
+        px[..., offs[ch]] = rgb[..., ch]
+    raw = str(tmp_path / "in.raw")
+    px.tofile(raw)
+    ref, gpu = str(tmp_path / "ref.jpg"), str(tmp_path / "gpu.jpg")
+    r0 = tj_run(raw, w, h, pf, TJSAMP[ssname], q, flags, ref, preload=False)
+    r1 = tj_run(raw, w, h, pf, TJSAMP[ssname], q, flags, gpu, preload=True)
+    assert r0.returncode == 0, r0.stderr.decode()
+    assert r1.returncode == 0, r1.stderr.decode()
+    assert open(gpu, "rb").read() == open(ref, "rb").read()
+
+
+@needs_tj
+def test_tjcompress2_fast_dct_is_refused_not_emulated(tmp_path):
+    """without TJFLAG_ACCURATEDCT and quality < 96 TurboJPEG selects JDCT_FASTEST (turbojpeg.c:523-526):
+    outside the integer-DCT hot path, so the drop-in must fail loudly"""
+    rgb = O.read_ppm(PPM)
+    h, w = rgb.shape[:2]
+    raw = str(tmp_path / "in.raw")
+    rgb.tofile(raw)
+    r = tj_run(raw, w, h, 0, 2, 75, 0, str(tmp_path / "o.jpg"), preload=True)
+    assert r.returncode != 0
+    assert b"no CPU fallback" in r.stderr
