@@ -263,29 +263,38 @@ void mjo_geometry(const mjo_params *p, mjo_geom g[MJO_MAX_COMPS], int *mcus_per_
  * ------------------------------------------------------------------------------------------ */
 #define FIXC(x) ((int)((x) * 65536.0 + 0.5))
 
+static int prec_of(const mjo_params *p) { return p->data_precision == 12 ? 12 : 8; }
+
 static void convert_pixel(const mjo_params *p, const uint8_t *px, int out[3])
 {
+  const int P = prec_of(p);
+  const int center = 1 << (P - 1);
+  int v[3], i;
+  /* 12-bit samples are uint16 and are masked to 12 bits (RANGE_LIMIT, jccolor.c:96-101) */
+  for (i = 0; i < p->input_components; i++)
+    v[i] = P == 12 ? (((const uint16_t *)px)[i] & 0xFFF) : px[i];
   if (p->input_components == 1) {
-    out[0] = px[0];
+    out[0] = P == 12 ? ((const uint16_t *)px)[0] : v[0];   /* grayscale_convert / null path: no masking */
     return;
   }
   {
-    int r = px[0], g = px[1], b = px[2];
-    out[0] = (FIXC(0.29900) * r + FIXC(0.58700) * g + FIXC(0.11400) * b + 32768) >> 16;
+    long r = v[0], g = v[1], b = v[2];
+    out[0] = (int)((FIXC(0.29900) * r + FIXC(0.58700) * g + FIXC(0.11400) * b + 32768) >> 16);
     if (p->num_components == 3) {
-      out[1] = (-FIXC(0.16874) * r - FIXC(0.33126) * g + FIXC(0.50000) * b + (128 << 16) + 32767) >> 16;
-      out[2] = (FIXC(0.50000) * r - FIXC(0.41869) * g - FIXC(0.08131) * b + (128 << 16) + 32767) >> 16;
+      out[1] = (int)((-FIXC(0.16874) * r - FIXC(0.33126) * g + FIXC(0.50000) * b + ((long)center << 16) + 32767) >> 16);
+      out[2] = (int)((FIXC(0.50000) * r - FIXC(0.41869) * g - FIXC(0.08131) * b + ((long)center << 16) + 32767) >> 16);
     }
   }
 }
 
-void mjo_color_downsample(const mjo_params *p, const uint8_t *pixels, size_t row_stride, uint8_t *planes[MJO_MAX_COMPS])
+static void color_downsample16(const mjo_params *p, const uint8_t *pixels, size_t row_stride, uint16_t *planes[MJO_MAX_COMPS])
 {
   mjo_geom g[MJO_MAX_COMPS];
   int ci, maxh = 1, maxv = 1, W = p->width, H = p->height;
   int groups; /* number of input row groups, jcprepct.c:135-192 */
-  uint8_t *full[3] = { 0, 0, 0 };
+  uint16_t *full[3] = { 0, 0, 0 };
   int x, y;
+  const int bps = prec_of(p) == 12 ? 2 : 1;
   mjo_geometry(p, g, NULL, NULL);
   for (ci = 0; ci < p->num_components; ci++) {
     if (p->h_samp[ci] > maxh) maxh = p->h_samp[ci];
@@ -293,13 +302,13 @@ void mjo_color_downsample(const mjo_params *p, const uint8_t *pixels, size_t row
   }
   groups = (int)div_round_up(H, maxv);
   /* full-resolution converted planes (the colour buffer of jcprepct.c, whole image) */
-  for (ci = 0; ci < p->num_components; ci++) full[ci] = (uint8_t *)malloc((size_t)W * H);
+  for (ci = 0; ci < p->num_components; ci++) full[ci] = (uint16_t *)malloc((size_t)W * H * 2);
   for (y = 0; y < H; y++) {
     const uint8_t *row = pixels + (size_t)y * row_stride;
     for (x = 0; x < W; x++) {
       int v[3];
-      convert_pixel(p, row + (size_t)x * p->input_components, v);
-      for (ci = 0; ci < p->num_components; ci++) full[ci][(size_t)y * W + x] = (uint8_t)v[ci];
+      convert_pixel(p, row + (size_t)x * p->input_components * bps, v);
+      for (ci = 0; ci < p->num_components; ci++) full[ci][(size_t)y * W + x] = (uint16_t)v[ci];
     }
   }
   for (ci = 0; ci < p->num_components; ci++) {
@@ -327,11 +336,26 @@ void mjo_color_downsample(const mjo_params *p, const uint8_t *pixels, size_t row
         else if (hexp == 2 && vexp == 1) val = (sum + (c & 1)) >> 1; /* h2v1 :226, bias 0,1,0,1 */
         else if (hexp == 2 && vexp == 2) val = (sum + 1 + (c & 1)) >> 2; /* h2v2 :263, bias 1,2,1,2 */
         else val = (sum + numpix / 2) / numpix;                      /* int_downsample :151 */
-        planes[ci][(size_t)r * g[ci].pw + c] = (uint8_t)val;
+        planes[ci][(size_t)r * g[ci].pw + c] = (uint16_t)val;
       }
     }
   }
   for (ci = 0; ci < p->num_components; ci++) free(full[ci]);
+}
+
+void mjo_color_downsample(const mjo_params *p, const uint8_t *pixels, size_t row_stride, uint8_t *planes[MJO_MAX_COMPS])
+{ /* 8-bit public tap */
+  mjo_geom g[MJO_MAX_COMPS];
+  uint16_t *p16[MJO_MAX_COMPS] = { 0, 0, 0, 0 };
+  int ci;
+  size_t i;
+  mjo_geometry(p, g, NULL, NULL);
+  for (ci = 0; ci < p->num_components; ci++) p16[ci] = (uint16_t *)malloc((size_t)g[ci].pw * g[ci].ph * 2);
+  color_downsample16(p, pixels, row_stride, p16);
+  for (ci = 0; ci < p->num_components; ci++) {
+    for (i = 0; i < (size_t)g[ci].pw * g[ci].ph; i++) planes[ci][i] = (uint8_t)p16[ci][i];
+    free(p16[ci]);
+  }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -398,21 +422,21 @@ void mjo_deringing(int data[64], int q0)
  * a6  jpeg_fdct_islow jfdctint.c:142-286 (8-bit: CONST_BITS 13, PASS1_BITS 2)
  * ------------------------------------------------------------------------------------------ */
 #define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
-static void fdct_1d(int *d, int stride, int pass)
-{
+static void fdct_1d(int *d, int stride, int pass, int p1)
+{ /* p1 = PASS1_BITS: 2 for 8-bit, 1 for 12-bit samples (jfdctint.c:80-86) */
   int t0 = d[0] + d[7 * stride], t7 = d[0] - d[7 * stride];
   int t1 = d[stride] + d[6 * stride], t6 = d[stride] - d[6 * stride];
   int t2 = d[2 * stride] + d[5 * stride], t5 = d[2 * stride] - d[5 * stride];
   int t3 = d[3 * stride] + d[4 * stride], t4 = d[3 * stride] - d[4 * stride];
   int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
   int z1, z2, z3, z4, z5;
-  int sh = pass == 0 ? 13 - 2 : 13 + 2;
+  int sh = pass == 0 ? 13 - p1 : 13 + p1;
   if (pass == 0) {
-    d[0] = (t10 + t11) * 4;
-    d[4 * stride] = (t10 - t11) * 4;
+    d[0] = (t10 + t11) * (1 << p1);
+    d[4 * stride] = (t10 - t11) * (1 << p1);
   } else {
-    d[0] = DESCALE(t10 + t11, 2);
-    d[4 * stride] = DESCALE(t10 - t11, 2);
+    d[0] = DESCALE(t10 + t11, p1);
+    d[4 * stride] = DESCALE(t10 - t11, p1);
   }
   z1 = (t12 + t13) * 4433;
   d[2 * stride] = DESCALE(z1 + t13 * 6270, sh);
@@ -428,12 +452,14 @@ static void fdct_1d(int *d, int stride, int pass)
   d[stride] = DESCALE(t7 + z1 + z4, sh);
 }
 
-void mjo_fdct_islow(int data[64])
+static void fdct_islow_p(int data[64], int p1)
 {
   int i;
-  for (i = 0; i < 8; i++) fdct_1d(data + 8 * i, 1, 0);
-  for (i = 0; i < 8; i++) fdct_1d(data + i, 8, 1);
+  for (i = 0; i < 8; i++) fdct_1d(data + 8 * i, 1, 0, p1);
+  for (i = 0; i < 8; i++) fdct_1d(data + i, 8, 1, p1);
 }
+
+void mjo_fdct_islow(int data[64]) { fdct_islow_p(data, 2); }
 
 /* ------------------------------------------------------------------------------------------
  * a4,a7,a8  convsamp jcdctmgr.c:576, quantize :611 (the reciprocal form there is, for d = 8*q,
@@ -461,9 +487,10 @@ static void build_dummies(const mjo_params *p, const mjo_geom *g, int ci, int16_
   }
 }
 
-void mjo_forward(const mjo_params *p, uint8_t *const planes[MJO_MAX_COMPS],
-                 int16_t *coef_uq[MJO_MAX_COMPS], int16_t *coef_q[MJO_MAX_COMPS])
+static void forward16(const mjo_params *p, uint16_t *const planes[MJO_MAX_COMPS],
+                      int16_t *coef_uq[MJO_MAX_COMPS], int16_t *coef_q[MJO_MAX_COMPS])
 {
+  const int P = prec_of(p), center = 1 << (P - 1), maxval = (1 << (P + 2)) - 1;
   mjo_geom g[MJO_MAX_COMPS];
   int ci;
   mjo_geometry(p, g, NULL, NULL);
@@ -477,17 +504,17 @@ void mjo_forward(const mjo_params *p, uint8_t *const planes[MJO_MAX_COMPS],
         int16_t *uq = coef_uq[ci] + ((size_t)br * g[ci].wpad + bc) * 64;
         int16_t *q = coef_q[ci] + ((size_t)br * g[ci].wpad + bc) * 64;
         for (i = 0; i < 64; i++)
-          ws[i] = planes[ci][(size_t)(br * 8 + i / 8) * g[ci].pw + bc * 8 + (i & 7)] - 128;
+          ws[i] = (int)planes[ci][(size_t)(br * 8 + i / 8) * g[ci].pw + bc * 8 + (i & 7)] - center;
         if (p->overshoot_deringing) mjo_deringing(ws, qt[0]);
-        mjo_fdct_islow(ws);
+        fdct_islow_p(ws, P == 12 ? 1 : 2);
         for (i = 0; i < 64; i++) {
           int d = 8 * qt[i], x = ws[i], v;
-          uq[i] = (int16_t)x;
+          uq[i] = (int16_t)x;   /* (12-bit: may wrap; only the 8-bit trellis reads it) */
           v = ((x < 0 ? -x : x) + d / 2) / d;
           if (x < 0) v = -v;
           if (p->overshoot_deringing) { /* jcdctmgr.c:761-770 */
-            if (v < -1023) v = -1023;
-            if (v > 1023) v = 1023;
+            if (v < -maxval) v = -maxval;
+            if (v > maxval) v = maxval;
           }
           q[i] = (int16_t)v;
         }
@@ -495,6 +522,22 @@ void mjo_forward(const mjo_params *p, uint8_t *const planes[MJO_MAX_COMPS],
     }
     build_dummies(p, &g[ci], ci, coef_q[ci]);
   }
+}
+
+void mjo_forward(const mjo_params *p, uint8_t *const planes[MJO_MAX_COMPS],
+                 int16_t *coef_uq[MJO_MAX_COMPS], int16_t *coef_q[MJO_MAX_COMPS])
+{ /* 8-bit public tap */
+  mjo_geom g[MJO_MAX_COMPS];
+  uint16_t *p16[MJO_MAX_COMPS] = { 0, 0, 0, 0 };
+  int ci;
+  size_t i;
+  mjo_geometry(p, g, NULL, NULL);
+  for (ci = 0; ci < p->num_components; ci++) {
+    p16[ci] = (uint16_t *)malloc((size_t)g[ci].pw * g[ci].ph * 2);
+    for (i = 0; i < (size_t)g[ci].pw * g[ci].ph; i++) p16[ci][i] = planes[ci][i];
+  }
+  forward16(p, p16, coef_uq, coef_q);
+  for (ci = 0; ci < p->num_components; ci++) free(p16[ci]);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1125,7 +1168,7 @@ static void emit_frame_header(enc_t *e, bytebuf *o)
       e->qsent[t] = 1;
     }
   }
-  is_baseline = !e->progressive;
+  is_baseline = !e->progressive && prec_of(p) == 8;
   if (is_baseline) {
     for (ci = 0; ci < p->num_components; ci++)
       if (p->dc_tbl_no[ci] > 1 || p->ac_tbl_no[ci] > 1) is_baseline = 0;
@@ -1134,7 +1177,7 @@ static void emit_frame_header(enc_t *e, bytebuf *o)
   bb_put(o, 0xFF);
   bb_put(o, e->progressive ? 0xC2 : (is_baseline ? 0xC0 : 0xC1));
   bb_put2(o, 3 * p->num_components + 2 + 5 + 1);
-  bb_put(o, 8);
+  bb_put(o, prec_of(p));
   bb_put2(o, p->height);
   bb_put2(o, p->width);
   bb_put(o, p->num_components);
@@ -1300,21 +1343,24 @@ static void bb_append(bytebuf *dst, const bytebuf *src)
   for (i = 0; i < src->len; i++) bb_put(dst, src->buf[i]);
 }
 
-size_t mjo_encode(const mjo_params *p, const uint8_t *pixels, size_t row_stride,
+size_t mjo_encode(const mjo_params *p_in, const uint8_t *pixels, size_t row_stride,
                   uint8_t *out, size_t cap, mjo_taps *taps)
 {
   enc_t e;
   bytebuf o = { 0, 0, 0 };
-  uint8_t *planes[MJO_MAX_COMPS] = { 0, 0, 0, 0 };
+  uint16_t *planes[MJO_MAX_COMPS] = { 0, 0, 0, 0 };
   int ci, t;
   size_t n;
+  mjo_params pp = *p_in;
+  const mjo_params *p = &pp;
+  if (prec_of(p) == 12) { pp.optimize_coding = 1; if (pp.trellis_quant) return 0; }   /* jcparam.c:452, SURVEY F1 */
 
   memset(&e, 0, sizeof(e));
   e.p = p;
   e.progressive = p->num_scans > 0;
   mjo_geometry(p, e.g, &e.mcus_per_row, &e.mcu_rows);
   for (ci = 0; ci < p->num_components; ci++) {
-    planes[ci] = (uint8_t *)malloc((size_t)e.g[ci].pw * e.g[ci].ph);
+    planes[ci] = (uint16_t *)malloc((size_t)e.g[ci].pw * e.g[ci].ph * 2);
     e.uq[ci] = (int16_t *)calloc((size_t)e.g[ci].hpad * e.g[ci].wpad * 64, 2);
     e.q[ci] = (int16_t *)calloc((size_t)e.g[ci].hpad * e.g[ci].wpad * 64, 2);
   }
@@ -1324,12 +1370,12 @@ size_t mjo_encode(const mjo_params *p, const uint8_t *pixels, size_t row_stride,
   memcpy(e.ac[0].bits, STD_AC_L_BITS, 17); memcpy(e.ac[0].huffval, STD_AC_L_VAL, 162);
   memcpy(e.ac[1].bits, STD_AC_C_BITS, 17); memcpy(e.ac[1].huffval, STD_AC_C_VAL, 162);
 
-  mjo_color_downsample(p, pixels, row_stride, planes);
-  mjo_forward(p, planes, e.uq, e.q);
+  color_downsample16(p, pixels, row_stride, planes);
+  forward16(p, planes, e.uq, e.q);
   if (taps) {
     for (ci = 0; ci < p->num_components; ci++) {
       size_t nb = (size_t)e.g[ci].hpad * e.g[ci].wpad * 128;
-      if (taps->planes[ci]) memcpy(taps->planes[ci], planes[ci], (size_t)e.g[ci].pw * e.g[ci].ph);
+      if (taps->planes[ci]) { size_t i; for (i = 0; i < (size_t)e.g[ci].pw * e.g[ci].ph; i++) taps->planes[ci][i] = (uint8_t)planes[ci][i]; }
       if (taps->coef_uq[ci]) memcpy(taps->coef_uq[ci], e.uq[ci], nb);
       if (taps->coef_q0[ci]) memcpy(taps->coef_q0[ci], e.q[ci], nb);
     }

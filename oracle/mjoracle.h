@@ -54,6 +54,7 @@ typedef struct {
   mjo_scan scans[MJO_MAX_SCANS];
   int optimize_scans;
   int write_jfif;
+  int data_precision;             /* 0 or 8: 8-bit samples (uint8); 12: 12-bit samples (uint16), no trellis */
 } mjo_params;
 
 /* jpeg_set_defaults + jpeg_set_quality + colorspace defaults, as cjpeg would leave them:

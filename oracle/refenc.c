@@ -63,6 +63,7 @@ int main(int argc, char **argv)
   int notrellis = 0, notrellis_dc = 0, noovershoot = 0, gray = 0, grayin = 0, qtbl = -1;
   int hs = 2, vs = 2, restart = 0, restart_blocks = 0, reps = 1, rawW = 0, rawH = 0;
   double l1 = -1e9, l2 = -1e9;
+  int precision = 8;
   const char *dump = NULL, *in = NULL, *out = NULL;
   int i, w, h, nc;
   unsigned char *img;
@@ -93,6 +94,7 @@ int main(int argc, char **argv)
       restart = (int)v; restart_blocks = (ch == 'b' || ch == 'B');
     }
     else if (!strcmp(a, "-reps")) reps = atoi(argv[++i]);
+    else if (!strcmp(a, "-precision")) precision = atoi(argv[++i]);   /* 12: raw input is uint16 samples */
     else if (!strcmp(a, "-raw")) { rawW = atoi(argv[++i]); rawH = atoi(argv[++i]); }
     else if (!strcmp(a, "-dumpcoef")) dump = argv[++i];
     else if (!in) in = a;
@@ -105,7 +107,7 @@ int main(int argc, char **argv)
     size_t n;
     if (!f) { perror(in); return 2; }
     w = rawW; h = rawH; nc = grayin ? 1 : 3;
-    n = (size_t)w * h * nc;
+    n = (size_t)w * h * nc * (precision == 12 ? 2 : 1);
     img = malloc(n);
     if (fread(img, 1, n, f) != n) { fprintf(stderr, "short raw\n"); return 2; }
     fclose(f);
@@ -131,6 +133,7 @@ int main(int argc, char **argv)
     cinfo.image_width = w;
     cinfo.image_height = h;
     cinfo.dct_method = JDCT_ISLOW;
+    cinfo.data_precision = precision;   /* cjpeg.c:533 sets it after jpeg_set_defaults as well */
     if (qtbl >= 0) jpeg_c_set_int_param(&cinfo, JINT_BASE_QUANT_TBL_IDX, qtbl);
     if (l1 > -1e8) jpeg_c_set_float_param(&cinfo, JFLOAT_LAMBDA_LOG_SCALE1, (float)l1);
     if (l2 > -1e8) jpeg_c_set_float_param(&cinfo, JFLOAT_LAMBDA_LOG_SCALE2, (float)l2);
@@ -158,9 +161,13 @@ int main(int argc, char **argv)
     jpeg_mem_dest(&cinfo, &jbuf, &jsize);
     jpeg_start_compress(&cinfo, TRUE);
     rows = malloc(sizeof(JSAMPROW) * h);
-    for (y = 0; y < h; y++) rows[y] = img + (size_t)y * w * nc;
-    while (cinfo.next_scanline < cinfo.image_height)
-      jpeg_write_scanlines(&cinfo, rows + cinfo.next_scanline, cinfo.image_height - cinfo.next_scanline);
+    for (y = 0; y < h; y++) rows[y] = img + (size_t)y * w * nc * (precision == 12 ? 2 : 1);
+    while (cinfo.next_scanline < cinfo.image_height) {
+      if (precision == 12)
+        jpeg12_write_scanlines(&cinfo, (J12SAMPARRAY)(rows + cinfo.next_scanline), cinfo.image_height - cinfo.next_scanline);
+      else
+        jpeg_write_scanlines(&cinfo, rows + cinfo.next_scanline, cinfo.image_height - cinfo.next_scanline);
+    }
     jpeg_finish_compress(&cinfo);
     jpeg_destroy_compress(&cinfo);
     free(rows);

@@ -31,7 +31,7 @@ class Params(C.Structure):
                 ("lambda_log_scale1", C.c_float), ("lambda_log_scale2", C.c_float),
                 ("restart_interval", C.c_int), ("restart_in_rows", C.c_int),
                 ("num_scans", C.c_int), ("scans", Scan * MAXS), ("optimize_scans", C.c_int),
-                ("write_jfif", C.c_int)]
+                ("write_jfif", C.c_int), ("data_precision", C.c_int)]
 
 
 class Geom(C.Structure):
@@ -69,7 +69,7 @@ def lib():
 def make_params(width, height, *, quality=75, baseline=False, revert=False, optimize=False,
                 progressive=False, fastcrush=False, notrellis=False, notrellis_dc=False,
                 noovershoot=False, sample=(2, 2), restart=None, gray=False, grayin=False,
-                quant_table=-1, lambda1=None, lambda2=None):
+                quant_table=-1, lambda1=None, lambda2=None, precision=8):
     """Same switch vocabulary as cjpeg / oracle/refenc.c.  Default (no switch) is cjpeg's default:
     max-compression profile, progressive with scan search."""
     p = Params()
@@ -88,6 +88,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
         p.lambda_log_scale1 = lambda1
     if lambda2 is not None:
         p.lambda_log_scale2 = lambda2
+    p.data_precision = precision
     if restart is not None:
         if isinstance(restart, str) and restart.lower().endswith("b"):
             p.restart_interval = int(restart[:-1])
@@ -115,10 +116,10 @@ def geometry(p):
 
 def encode(p, pixels, want_taps=False):
     """pixels: uint8 array [H, W, C] (C contiguous).  Returns bytes (and taps dict)."""
-    pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
+    pixels = np.ascontiguousarray(pixels, dtype=np.uint16 if p.data_precision == 12 else np.uint8)
     h, w = pixels.shape[:2]
     assert (w, h) == (p.width, p.height)
-    cap = w * h * 4 + 65536
+    cap = w * h * 8 + 65536
     out = np.empty(cap, np.uint8)
     taps = None
     keep = {}
@@ -177,12 +178,14 @@ def ref_switches(**kw):
         sw += ["-lambda1", str(kw["lambda1"])]
     if kw.get("lambda2") is not None:
         sw += ["-lambda2", str(kw["lambda2"])]
+    if kw.get("precision", 8) == 12:
+        sw += ["-precision", "12"]
     return sw
 
 
 def ref_encode(pixels, reps=1, dumpcoef=False, **kw):
     """Encode with the REAL reference library through oracle/_ref/refenc."""
-    pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
+    pixels = np.ascontiguousarray(pixels, dtype=np.uint16 if kw.get("precision", 8) == 12 else np.uint8)
     h, w = pixels.shape[:2]
     with tempfile.TemporaryDirectory() as td:
         raw = os.path.join(td, "in.rgb")
@@ -223,6 +226,22 @@ def read_ppm(path):
     w, h = int(parts[1]), int(parts[2])
     data = blob[len(blob) - w * h * 3:]
     return np.frombuffer(data, np.uint8).reshape(h, w, 3).copy()
+
+
+def synthetic_frame12(width, height, seed=1234):
+    """12-bit variant of the SURVEY 8d frame: same formula x16, clipped to 0..4095, uint16."""
+    y, x = np.mgrid[0:height, 0:width].astype(np.float64)
+    s = float(seed)
+    f = [np.sin(x / 97 + s) * np.cos(y / 71), np.sin((x + y) / 53), np.cos(x / 31 - y / 43)]
+    amp = (100, 90, 80)
+    rng = np.random.default_rng(seed)
+    img = np.empty((height, width, 3), np.float64)
+    for c in range(3):
+        img[..., c] = (128 + amp[c] * f[c] + rng.normal(0, 12, (height, width))) * 16
+    img = np.clip(img, 0, 4095).astype(np.uint16)
+    tiles = ((x.astype(np.int64) // 64 + y.astype(np.int64) // 64) % 7) == 0
+    img[tiles] = 4095
+    return img
 
 
 def synthetic_frame(width, height, seed=1234):

@@ -46,3 +46,6 @@ if __name__ == "__main__":
     run("C3 4K q85 4:2:0 progressive + scan search", 3840, 2160, dict(quality=85), a.batch)
     run("4K q75 fastcrush (progressive, no search)", 3840, 2160, dict(fastcrush=True), a.batch)
     run("4K q75 -revert (libjpeg-turbo defaults)", 3840, 2160, dict(revert=True), a.batch)
+    run("C4-like batch: 32 x 1080p q75 baseline trellis", 1920, 1080, dict(baseline=True), 32)
+    run("C5 8-bit twin: 8192x8192 q90 4:4:4 baseline trellis, restart every MCU row", 8192, 8192,
+        dict(baseline=True, quality=90, sample=(1, 1), restart=1), 1, steps=3)
