@@ -81,6 +81,10 @@ typedef struct {
    * (all 0 = R,G,B at 0,1,2).  input_components stays 3 for every RGB-family layout. */
   int input_pixel_size;
   int rgb_offset[3];
+  /* 0 or 8: 8-bit samples (one byte each); 12: 12-bit samples stored as uint16 (jpeg12_write_scanlines,
+   * J12SAMPLE).  row_pitch / image_stride stay in BYTES.  Trellis quantization has no 12-bit reference
+   * behaviour (jccoefct.c:132-138) and is rejected. */
+  int data_precision;
 } mjh_params;
 
 typedef struct mjh_encoder mjh_encoder;

@@ -284,6 +284,9 @@ static int check_supported(const mjh_params *p)
 {
   if (p->image_width <= 0 || p->image_height <= 0 || p->image_width > 65500 || p->image_height > 65500)
     return fail(MJH_EINVAL, "bad image size %dx%d", p->image_width, p->image_height);
+  if (p->data_precision != 0 && p->data_precision != 8 && p->data_precision != 12) return fail(MJH_EUNSUPPORTED, "data_precision %d", p->data_precision);
+  if (p->data_precision == 12 && p->trellis_quant)
+    return fail(MJH_EUNSUPPORTED, "trellis quantization is 8-bit only in the reference (jccoefct.c:132-138: 12-bit + trellis aborts)");
   if (p->input_components != 1 && p->input_components != 3) return fail(MJH_EUNSUPPORTED, "input_components %d (RGB or gray only)", p->input_components);
   if (p->num_components != 1 && p->num_components != 3) return fail(MJH_EUNSUPPORTED, "num_components %d", p->num_components);
   if (p->num_components == 3 && p->input_components != 3) return fail(MJH_EUNSUPPORTED, "gray input cannot produce 3 components");
@@ -327,7 +330,7 @@ static int check_supported(const mjh_params *p)
         const int c = sc.component_index[ci];
         if (c < 0 || c >= p->num_components || (ci > 0 && c <= sc.component_index[ci - 1])) return fail(MJH_EINVAL, "scan %d: component order", si);
       }
-      if (sc.Ss < 0 || sc.Ss > 63 || sc.Se < sc.Ss || sc.Se > 63 || sc.Ah < 0 || sc.Ah > 10 || sc.Al < 0 || sc.Al > 10)
+      if (sc.Ss < 0 || sc.Ss > 63 || sc.Se < sc.Ss || sc.Se > 63 || sc.Ah < 0 || sc.Ah > (p->data_precision == 12 ? 13 : 10) || sc.Al < 0 || sc.Al > (p->data_precision == 12 ? 13 : 10))
         return fail(MJH_EINVAL, "scan %d: bad progression parameters", si);
       if (sc.Ss == 0 && sc.Se != 0) return fail(MJH_EUNSUPPORTED, "scan %d: sequential multi-scan scripts are not supported", si);
       if (sc.Ss != 0 && sc.comps_in_scan != 1) return fail(MJH_EINVAL, "scan %d: AC scans are single-component", si);
@@ -354,6 +357,7 @@ static void build_const(const mjh_params *p, MjhConst *C)
   C->px_size = p->input_pixel_size ? p->input_pixel_size : p->input_components;
   C->off_r = p->rgb_offset[0]; C->off_g = p->rgb_offset[1]; C->off_b = p->rgb_offset[2];
   if (C->off_r == 0 && C->off_g == 0 && C->off_b == 0) { C->off_g = 1; C->off_b = 2; }
+  C->precision = p->data_precision == 12 ? 12 : 8;
   C->maxh = C->maxv = 1;
   for (int i = 0; i < C->ncomp; i++) {
     if (p->h_samp_factor[i] > C->maxh) C->maxh = p->h_samp_factor[i];
@@ -457,11 +461,11 @@ static void build_prefix(const mjh_params *p, std::vector<uint8_t> &o, bool *bas
   bool is_baseline = true;                                  // write_frame_header :699-734
   for (int ci = 0; ci < p->num_components; ci++)
     if (p->dc_tbl_no[ci] > 1 || p->ac_tbl_no[ci] > 1) is_baseline = false;
-  if (prec_any) is_baseline = false;
+  if (prec_any || p->data_precision == 12) is_baseline = false;   // write_frame_header :699-703
   *baseline_sof = is_baseline;
   o.push_back(0xFF); o.push_back(p->num_scans > 0 ? 0xC2 : (is_baseline ? 0xC0 : 0xC1));  // emit_sof :464-490 (SOF2 = progressive)
   put2(o, 3 * p->num_components + 2 + 5 + 1);
-  o.push_back(8);
+  o.push_back(p->data_precision == 12 ? 12 : 8);
   put2(o, p->image_height); put2(o, p->image_width);
   o.push_back((uint8_t)p->num_components);
   for (int ci = 0; ci < p->num_components; ci++) {
@@ -568,6 +572,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   if (device < 0 || device >= ndev) return fail(MJH_EINVAL, "device %d out of range (%d devices)", device, ndev);
   mjh_encoder *e = new mjh_encoder();
   e->p = *p;
+  if (p->data_precision == 12) e->p.optimize_coding = 1;   // standard tables are 8-bit only (jcparam.c:452-453, jcmaster.c:1102-1105)
   e->device = device;
   e->max_batch = max_batch;
   build_const(p, &e->C);
@@ -585,8 +590,9 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   HIPCHK_E(hipEventCreate(&e->ev_side0));
   HIPCHK_E(hipEventCreate(&e->ev_side1));
   const size_t B = (size_t)max_batch;
-  e->pix_image_bytes = (size_t)C.W * C.H * C.px_size;
-  HIPCHK_E(hipMalloc((void **)&e->d_planes, B * C.planes_per_image));
+  const size_t bps = C.precision == 12 ? 2 : 1;   // bytes per sample
+  e->pix_image_bytes = (size_t)C.W * C.H * C.px_size * bps;
+  HIPCHK_E(hipMalloc((void **)&e->d_planes, B * C.planes_per_image * bps));
   HIPCHK_E(hipMalloc((void **)&e->d_uq, B * C.coefs_per_image * 2));
   HIPCHK_E(hipMalloc((void **)&e->d_q, B * C.coefs_per_image * 2));
   HIPCHK_E(hipMalloc((void **)&e->d_quant, sizeof(MjhQuant)));
@@ -600,8 +606,8 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   HIPCHK_E(hipMalloc((void **)&e->d_len16, B * (size_t)C.total_mcu_blocks * 2));
   HIPCHK_E(hipMalloc((void **)&e->d_off32, B * (size_t)C.total_mcu_blocks * 4));
   e->chunks = (C.total_mcu_blocks + 2047) / 2048;
-  // worst case 1665 bits per block (DC 16+11, 63 x (16+10)) -> 53 words
-  size_t words = (size_t)C.total_mcu_blocks * 53 + 64;
+  // worst case per block: DC 16+11, 63 x (16+10) = 1665 bits -> 53 words (12-bit: 16+15, 63 x (16+14) -> 61 words)
+  size_t words = (size_t)C.total_mcu_blocks * (C.precision == 12 ? 61 : 53) + 64;
   if (C.restart_interval) words += (size_t)(C.mcus_per_row * C.mcu_rows) / C.restart_interval + 1;   // pad + RSTn per interval
   if (words > (size_t)1 << 27) words = (size_t)1 << 27;   // bit offsets are 32-bit
   e->stream_words = (words + 63) & ~(size_t)63;
@@ -904,7 +910,7 @@ extern "C" int mjh_encode_host(mjh_encoder *e, const void *pixels, size_t row_pi
 {
   if (!e || !pixels || n < 1 || n > e->max_batch) return fail(MJH_EINVAL, "bad arguments");
   HIPCHK(hipSetDevice(e->device));
-  const size_t row_bytes = (size_t)e->C.W * e->C.px_size;
+  const size_t row_bytes = (size_t)e->C.W * e->C.px_size * (e->C.precision == 12 ? 2 : 1);
   if (!e->d_pix) {
     HIPCHK(hipMalloc((void **)&e->d_pix, (size_t)e->max_batch * e->pix_image_bytes));
     HIPCHK(hipHostMalloc((void **)&e->h_pix, (size_t)e->max_batch * e->pix_image_bytes, hipHostMallocDefault));
@@ -1036,9 +1042,10 @@ extern "C" int mjh_read_tap(mjh_encoder *e, int what, int image, int comp, void 
   if (comp < 0 || comp >= C.ncomp) return fail(MJH_EINVAL, "bad component");
   const MjhComp &cc = C.c[comp];
   if (what == MJH_TAP_PLANE) {
-    const size_t need = (size_t)cc.pw * cc.ph;
+    const size_t bps = C.precision == 12 ? 2 : 1;
+    const size_t need = (size_t)cc.pw * cc.ph * bps;
     if (cap < need) return fail(MJH_ETOOSMALL, "need %zu bytes", need);
-    HIPCHK(hipMemcpy(dst, e->d_planes + (size_t)image * C.planes_per_image + cc.plane_off, need, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dst, e->d_planes + ((size_t)image * C.planes_per_image + cc.plane_off) * bps, need, hipMemcpyDeviceToHost));
     if (size) *size = need;
     return MJH_OK;
   }

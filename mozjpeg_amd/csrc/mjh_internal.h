@@ -40,7 +40,8 @@ struct MjhComp {
 struct MjhConst {
   int W, H;
   int in_comps;           // 3 or 1
-  int px_size, off_r, off_g, off_b;   // input pixel layout (extended RGB formats)
+  int px_size, off_r, off_g, off_b;   // input pixel layout (extended RGB formats), in SAMPLES
+  int precision;          // 8 or 12 (12: samples and planes are uint16)
   int ncomp;
   int maxh, maxv;
   int mcus_per_row, mcu_rows;

@@ -54,18 +54,19 @@ static constexpr ZZTab kIZZ = make_izz();  // kIZZ.v[n] = zig-zag position of na
 // =============================================================================================
 #define FIXC(x) ((int)((x) * 65536.0 + 0.5))
 
-template <int H0, int V0>
+template <int H0, int V0, class T>   // T = uint8_t (8-bit) or uint16_t (12-bit samples, jccolor.c:96-101)
 __global__ void __launch_bounds__(256)
 k_color(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, size_t img_stride,
-        uint8_t *__restrict__ planes)
+        T *__restrict__ planes)
 {
   const int gx = blockIdx.x * 256 + threadIdx.x;
   const int gy = blockIdx.y;
   const int img = blockIdx.z;
   if (gx >= C.groups_x) return;
   const uint8_t *p = pix + (size_t)img * img_stride;
-  uint8_t *pl = planes + (size_t)img * C.planes_per_image;
+  T *pl = planes + (size_t)img * C.planes_per_image;
   const int ic = C.in_comps;
+  const int center = sizeof(T) == 2 ? 2048 : 128;
   const bool below = gy >= C.real_groups_y;          // replicate the last DOWNSAMPLED row
   const int gys = below ? C.real_groups_y - 1 : gy;
   int yv[V0][H0];
@@ -74,17 +75,18 @@ k_color(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, size_t im
   for (int vy = 0; vy < V0; vy++) {
     int iy = gys * V0 + vy;
     if (iy > C.H - 1) iy = C.H - 1;                   // last INPUT row replicated (jcprepct.c:161)
-    const uint8_t *row = p + (size_t)iy * row_pitch;
+    const T *row = reinterpret_cast<const T *>(p + (size_t)iy * row_pitch);
 #pragma unroll
     for (int vx = 0; vx < H0; vx++) {
       int ix = gx * H0 + vx;
       if (ix > C.W - 1) ix = C.W - 1;                 // jcsample.c:98
       if (ic == 3) {
-        const uint8_t *px = row + (size_t)ix * C.px_size;
-        const int r = px[C.off_r], g = px[C.off_g], b = px[C.off_b];
+        const T *px = row + (size_t)ix * C.px_size;
+        int r = px[C.off_r], g = px[C.off_g], b = px[C.off_b];
+        if (sizeof(T) == 2) { r &= 0xFFF; g &= 0xFFF; b &= 0xFFF; }   // RANGE_LIMIT of the 12-bit build
         yv[vy][vx] = (FIXC(0.29900) * r + FIXC(0.58700) * g + FIXC(0.11400) * b + 32768) >> 16;
-        cbs += (-FIXC(0.16874) * r - FIXC(0.33126) * g + FIXC(0.50000) * b + (128 << 16) + 32767) >> 16;
-        crs += (FIXC(0.50000) * r - FIXC(0.41869) * g - FIXC(0.08131) * b + (128 << 16) + 32767) >> 16;
+        cbs += (-FIXC(0.16874) * r - FIXC(0.33126) * g + FIXC(0.50000) * b + (center << 16) + 32767) >> 16;
+        crs += (FIXC(0.50000) * r - FIXC(0.41869) * g - FIXC(0.08131) * b + (center << 16) + 32767) >> 16;
       } else {
         yv[vy][vx] = row[ix];
       }
@@ -92,7 +94,7 @@ k_color(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, size_t im
   }
   {
     const MjhComp &c0 = C.c[0];
-    uint8_t *y = pl + c0.plane_off;
+    T *y = pl + c0.plane_off;
 #pragma unroll
     for (int vy = 0; vy < V0; vy++) {
       const int r = gy * V0 + vy;
@@ -100,7 +102,7 @@ k_color(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, size_t im
 #pragma unroll
       for (int vx = 0; vx < H0; vx++) {
         const int c = gx * H0 + vx;
-        if (r < c0.ph && c < c0.pw) y[(size_t)r * c0.pw + c] = (uint8_t)yv[svy][vx];
+        if (r < c0.ph && c < c0.pw) y[(size_t)r * c0.pw + c] = (T)yv[svy][vx];
       }
     }
   }
@@ -113,8 +115,8 @@ k_color(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, size_t im
     const MjhComp &c1 = C.c[1];
     const MjhComp &c2 = C.c[2];
     if (gy < c1.ph && gx < c1.pw) {
-      pl[c1.plane_off + (size_t)gy * c1.pw + gx] = (uint8_t)cb;
-      pl[c2.plane_off + (size_t)gy * c2.pw + gx] = (uint8_t)cr;
+      pl[c1.plane_off + (size_t)gy * c1.pw + gx] = (T)cb;
+      pl[c2.plane_off + (size_t)gy * c2.pw + gx] = (T)cr;
     }
   }
 }
@@ -130,15 +132,15 @@ k_color(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, size_t im
 // =============================================================================================
 #define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
 
-template <int PASS>
+template <int PASS, int P1>   // P1 = PASS1_BITS: 2 for 8-bit, 1 for 12-bit samples (jfdctint.c:80-86)
 __device__ __forceinline__ void fdct8(int &d0, int &d1, int &d2, int &d3, int &d4, int &d5, int &d6, int &d7)
 {
   const int t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
   const int t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
   const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
-  constexpr int SH = PASS == 0 ? 13 - 2 : 13 + 2;
-  if (PASS == 0) { d0 = (t10 + t11) * 4; d4 = (t10 - t11) * 4; }
-  else { d0 = DESCALE(t10 + t11, 2); d4 = DESCALE(t10 - t11, 2); }
+  constexpr int SH = PASS == 0 ? 13 - P1 : 13 + P1;
+  if (PASS == 0) { d0 = (t10 + t11) * (1 << P1); d4 = (t10 - t11) * (1 << P1); }
+  else { d0 = DESCALE(t10 + t11, P1); d4 = DESCALE(t10 - t11, P1); }
   int z1 = (t12 + t13) * 4433;
   d2 = DESCALE(z1 + t13 * 6270, SH);
   d6 = DESCALE(z1 + t12 * (-15137), SH);
@@ -171,10 +173,12 @@ __device__ __forceinline__ float catmull_rom(int v1, int v2, int v3, int v4, flo
   return r;
 }
 
+template <class T>   // uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
 __global__ void __launch_bounds__(64)
-k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const uint8_t *__restrict__ planes,
+k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ planes,
             int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out)
 {
+  constexpr bool W12 = sizeof(T) == 2;
   __shared__ int lds[64][64];
   const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
@@ -182,15 +186,25 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const uint8_t *__restric
   const int blk = blockIdx.x * 64 + lane;
   if (blk >= cc.nblk) return;
   const int br = blk / cc.wib, bc = blk - br * cc.wib;
-  const uint8_t *src = planes + (size_t)img * C.planes_per_image + cc.plane_off + (size_t)(br * 8) * cc.pw + bc * 8;
+  const T *src = planes + (size_t)img * C.planes_per_image + cc.plane_off + (size_t)(br * 8) * cc.pw + bc * 8;
   int d[64];
 #pragma unroll
   for (int r = 0; r < 8; r++) {
-    const uint2 v = *reinterpret_cast<const uint2 *>(src + (size_t)r * cc.pw);
+    if (!W12) {
+      const uint2 v = *reinterpret_cast<const uint2 *>(src + (size_t)r * cc.pw);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      d[r * 8 + i] = (int)((v.x >> (8 * i)) & 0xFF) - 128;
-      d[r * 8 + 4 + i] = (int)((v.y >> (8 * i)) & 0xFF) - 128;
+      for (int i = 0; i < 4; i++) {
+        d[r * 8 + i] = (int)((v.x >> (8 * i)) & 0xFF) - 128;
+        d[r * 8 + 4 + i] = (int)((v.y >> (8 * i)) & 0xFF) - 128;
+      }
+    } else {
+      const uint4 v = *reinterpret_cast<const uint4 *>(src + (size_t)r * cc.pw);
+      const unsigned w4[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        d[r * 8 + 2 * i] = (int)(w4[i] & 0xFFFF) - 2048;
+        d[r * 8 + 2 * i + 1] = (int)(w4[i] >> 16) - 2048;
+      }
     }
   }
   const uint16_t *qz = Q->q[cc.qtbl];
@@ -204,7 +218,7 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const uint8_t *__restric
       for (int i = 0; i < 64; i++) lds[i][lane] = d[i];
       const int q0 = qz[0];
       const int a = min(31, 2 * q0);
-      const int b = (maxsample * 64 - sum) / cnt;
+      const int b = (maxsample * 64 - sum) / cnt;   // C division truncates toward zero: negative for 12-bit data (T9)
       const int maxovershoot = maxsample + min(a, b);
       int n = 0;
       do {
@@ -235,12 +249,12 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const uint8_t *__restric
   }
 #pragma unroll
   for (int r = 0; r < 8; r++)
-    fdct8<0>(d[r * 8], d[r * 8 + 1], d[r * 8 + 2], d[r * 8 + 3], d[r * 8 + 4], d[r * 8 + 5], d[r * 8 + 6], d[r * 8 + 7]);
+    fdct8<0, W12 ? 1 : 2>(d[r * 8], d[r * 8 + 1], d[r * 8 + 2], d[r * 8 + 3], d[r * 8 + 4], d[r * 8 + 5], d[r * 8 + 6], d[r * 8 + 7]);
 #pragma unroll
   for (int c = 0; c < 8; c++)
-    fdct8<1>(d[c], d[8 + c], d[16 + c], d[24 + c], d[32 + c], d[40 + c], d[48 + c], d[56 + c]);
+    fdct8<1, W12 ? 1 : 2>(d[c], d[8 + c], d[16 + c], d[24 + c], d[32 + c], d[40 + c], d[48 + c], d[56 + c]);
 
-  if (C.trellis) {
+  if (!W12 && C.trellis) {
     // per-block trellis lambda (jcdctmgr.c:1027-1037): norm of the 63 AC coefficients summed in
     // NATURAL index order in float, /63 in double, then lambda in double -> float.  pow(2, .) comes
     // from the host libm.  Both trellis kernels consume it.
@@ -264,8 +278,8 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const uint8_t *__restric
     const int ax = x < 0 ? -x : x;
     int v = udiv_exact(ax + (dq >> 1), dq, rcp[k]);
     if (x < 0) v = -v;
-    if (clampq) v = max(-1023, min(1023, v));
-    uq[(size_t)k * cc.kstride] = (int16_t)x;
+    if (clampq) v = W12 ? max(-16383, min(16383, v)) : max(-1023, min(1023, v));
+    if (!W12) uq[(size_t)k * cc.kstride] = (int16_t)x;   // raw x8 coefficients only feed the (8-bit only) trellis
     qo[(size_t)k * cc.kstride] = (int16_t)v;
   }
 }
@@ -341,7 +355,7 @@ k_stats_dc(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restr
   const int lane = threadIdx.x & 63;
   const int nitems = MCU_ORDER ? cc.wpad * cc.hpad : cc.nblk;
   const int ri = comp == 0 ? comp_restart.x : comp == 1 ? comp_restart.y : comp == 2 ? comp_restart.z : comp_restart.w;
-  unsigned cnt = 0;   // lane s (< 12) counts symbol s for this wave
+  unsigned cnt = 0;   // lane s (< 16) counts symbol s for this wave
   for (int it = 0; it < STATS_DC_ITER; it++) {
     const int t = (blockIdx.x * STATS_DC_ITER + it) * 256 + threadIdx.x;
     if ((blockIdx.x * STATS_DC_ITER + it) * 256 >= nitems) break;   // uniform
@@ -361,14 +375,14 @@ k_stats_dc(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restr
       nb = bitlen((unsigned)(df < 0 ? -df : df));
     }
 #pragma unroll
-    for (int s = 0; s < 12; s++) {
+    for (int s = 0; s < 16; s++) {   // DC categories 0..11 for 8-bit, up to 15 for 12-bit samples
       const unsigned long long m = __ballot(nb == s);
       if (lane == s) cnt += (unsigned)__popcll(m);
     }
   }
   const int slot = comp == 0 ? slot_of_comp.x : comp == 1 ? slot_of_comp.y : comp == 2 ? slot_of_comp.z : slot_of_comp.w;
   MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
-  if (lane < 12 && cnt) atomicAdd(&T->counts[lane], cnt);
+  if (lane < 16 && cnt) atomicAdd(&T->counts[lane], cnt);
 }
 
 // =============================================================================================
@@ -1312,7 +1326,8 @@ void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size
 {
   dim3 grid((C.groups_x + 255) / 256, C.groups_y, n);
   const int H0 = C.maxh, V0 = C.maxv;
-#define LC(h, v) hipLaunchKernelGGL((k_color<h, v>), grid, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint8_t *)planes)
+#define LC(h, v) do { if (C.precision == 12) hipLaunchKernelGGL((k_color<h, v, uint16_t>), grid, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint16_t *)planes); \
+                      else hipLaunchKernelGGL((k_color<h, v, uint8_t>), grid, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint8_t *)planes); } while (0)
   if (H0 == 2 && V0 == 2) LC(2, 2);
   else if (H0 == 2 && V0 == 1) LC(2, 1);
   else if (H0 == 1 && V0 == 2) LC(1, 2);
@@ -1326,7 +1341,8 @@ static int max_padblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncom
 void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda, int n, hipStream_t s)
 {
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
-  hipLaunchKernelGGL(k_dct_quant, grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda);
+  if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda);
+  else hipLaunchKernelGGL((k_dct_quant<uint8_t>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda);
 }
 
 void mjh_launch_stats_ac(const MjhConst &C, const void *q, MjhHuffTable *tabs, int spi, const int slot[4], int count_dummies, int n, hipStream_t s)
