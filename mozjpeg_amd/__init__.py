@@ -165,7 +165,8 @@ class Encoder:
     def encode_tensor(self, t, stream=None):
         """t: torch uint8 CUDA tensor [n, H, W, C], contiguous.  Asynchronous."""
         assert t.is_cuda and t.is_contiguous() and t.dim() == 4
-        self.encode_device_ptr(t.data_ptr(), t.stride(1), t.stride(0), t.shape[0], stream)
+        es = t.element_size()   # 1 for uint8, 2 for the 12-bit path (int16/uint16 storage)
+        self.encode_device_ptr(t.data_ptr(), t.stride(1) * es, t.stride(0) * es, t.shape[0], stream)
 
     def sync(self):
         _chk(lib().mjh_encoder_sync(self._h))

@@ -50,6 +50,32 @@ CASES = [
     ("q5_16bit_tables", dict(quality=5, fastcrush=True), True),
 ]
 
+
+
+def images12():
+    """12-bit fixtures (uint16 samples 0..4095)"""
+    import oracle_lib as O
+    big = O.synthetic_frame12(640, 480, 1234)
+    rng = np.random.default_rng(9)
+    return {
+        "syn12_250x187": big[100:287, 50:300].copy(),
+        "syn12_17x33": big[:33, :17].copy(),
+        "syn12_1x1": big[:1, :1].copy(),
+        "noise12_121x75": rng.integers(0, 4096, (75, 121, 3)).astype(np.uint16),
+    }
+
+
+# 12-bit: trellis has no reference behaviour (jccoefct.c:132-138 aborts, SURVEY F1) => -notrellis everywhere
+CASES12 = [
+    ("p12_base_q90_444", dict(precision=12, baseline=True, notrellis=True, quality=90, sample=(1, 1)), True),
+    ("p12_base_420", dict(precision=12, baseline=True, notrellis=True), True),
+    ("p12_base_q90_444_noover_restart1", dict(precision=12, baseline=True, notrellis=True, noovershoot=True, quality=90, sample=(1, 1), restart=1), True),
+    ("p12_default_progressive", dict(precision=12, notrellis=True), True),
+    ("p12_fastcrush", dict(precision=12, notrellis=True, fastcrush=True), True),
+    ("p12_revert_q90", dict(precision=12, revert=True, quality=90), True),
+    ("p12_base_gray", dict(precision=12, baseline=True, notrellis=True, gray=True), True),
+]
+
 # constants the REFERENCE itself pins for this path (CMakeLists.txt:1347-1420), cjpeg -revert ... testorig.ppm
 REFERENCE_PINNED = {
     ("testorig", "revert"): "9a68f56bc76e466aa7e52f415d0f4a5f",        # MD5_JPEG_420_ISLOW   :1391

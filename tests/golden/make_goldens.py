@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 import oracle_lib as O  # noqa: E402
-from cases import CASES, images  # noqa: E402
+from cases import CASES, CASES12, images, images12  # noqa: E402
 
 
 def main():
@@ -20,6 +20,10 @@ def main():
     out = {}
     for iname, img in images().items():
         for cname, kw, _ in CASES:
+            data, _info = O.ref_encode(img, **kw)
+            out["%s/%s" % (iname, cname)] = {"md5": O.md5(data), "bytes": len(data)}
+    for iname, img in images12().items():
+        for cname, kw, _ in CASES12:
             data, _info = O.ref_encode(img, **kw)
             out["%s/%s" % (iname, cname)] = {"md5": O.md5(data), "bytes": len(data)}
     with open(os.path.join(HERE, "goldens.json"), "w") as f:

@@ -6,7 +6,7 @@ import pytest
 
 import mozjpeg_amd as M
 import oracle_lib as O
-from cases import CASES
+from cases import CASES, CASES12, images12
 from gpu_stage_check import check_case
 
 pytestmark = pytest.mark.gpu
@@ -32,12 +32,34 @@ def test_bytes_match_reference_goldens(cname, kw, goldens, fixture_images):
         assert (len(data), O.md5(data)) == (g["bytes"], g["md5"]), (iname, cname)
 
 
+@pytest.mark.parametrize("cname,kw", [(c, kw) for c, kw, _ in CASES12])
+def test_12bit_stages_and_goldens(cname, kw, goldens):
+    for iname, img in images12().items():
+        assert check_case(img, kw, verbose=False), (iname, cname)
+        h, w = img.shape[:2]
+        enc = M.Encoder(M.make_params(w, h, **kw))
+        data = enc.encode_host(img)[0]
+        enc.close()
+        g = goldens["%s/%s" % (iname, cname)]
+        assert (len(data), O.md5(data)) == (g["bytes"], g["md5"]), (iname, cname)
+
+
+def test_12bit_trellis_is_refused():
+    """the reference aborts for 12-bit + trellis ("Bogus buffer control mode"): no behaviour to match"""
+    with pytest.raises(M.MjhError) as ei:
+        M.Encoder(M.make_params(64, 64, baseline=True, precision=12))
+    assert ei.value.code == M.EUNSUPPORTED
+
+
 @pytest.mark.parametrize("w,h,kw", [(1920, 1080, dict(baseline=True)),              # BASELINE config 2
                                     (3840, 2160, dict(baseline=True)),              # the metric's workload
                                     (1920, 1080, dict(revert=True)),
-                                    (2048, 2048, dict(baseline=True, quality=90, sample=(1, 1)))])
+                                    (2048, 2048, dict(baseline=True, quality=90, sample=(1, 1))),
+                                    (3840, 2160, dict(quality=85)),                 # BASELINE config 3: progressive + scan search
+                                    (2048, 2048, dict(precision=12, baseline=True, notrellis=True, quality=90,
+                                                      sample=(1, 1), restart=1))])   # BASELINE config 5 at reduced size
 def test_full_size_frames_bit_exact(w, h, kw):
-    img = O.synthetic_frame(w, h, 1234)
+    img = O.synthetic_frame12(w, h, 1234) if kw.get("precision") == 12 else O.synthetic_frame(w, h, 1234)
     enc = M.Encoder(M.make_params(w, h, **kw))
     data = enc.encode_host(img)[0]
     enc.close()

@@ -4,7 +4,7 @@ reference's own CTest suite pins."""
 import pytest
 
 import oracle_lib as O
-from cases import CASES, REFERENCE_PINNED
+from cases import CASES, CASES12, REFERENCE_PINNED, images12
 
 
 def test_reference_pinned_constants_are_in_goldens(goldens):
@@ -23,6 +23,15 @@ def test_oracle_matches_goldens(cname, kw, goldens, fixture_images):
         g = goldens["%s/%s" % (iname, cname)]
         assert len(data) == g["bytes"], (iname, cname)
         assert O.md5(data) == g["md5"], (iname, cname)
+
+
+@pytest.mark.parametrize("cname,kw", [(c, kw) for c, kw, _ in CASES12])
+def test_oracle_matches_12bit_goldens(cname, kw, goldens):
+    for iname, img in images12().items():
+        h, w = img.shape[:2]
+        data = O.encode(O.make_params(w, h, **kw), img)
+        g = goldens["%s/%s" % (iname, cname)]
+        assert (len(data), O.md5(data)) == (g["bytes"], g["md5"]), (iname, cname)
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="compiled reference (oracle/_ref) not present")

@@ -18,8 +18,9 @@ import oracle_lib as O  # noqa: E402
 
 def run(name, w, h, kw, batch, steps=5):
     import torch
-    frames = np.stack([O.synthetic_frame(w, h, 1234 + i) for i in range(batch)])
-    t = torch.from_numpy(frames).cuda()
+    gen = O.synthetic_frame12 if kw.get("precision") == 12 else O.synthetic_frame
+    frames = np.stack([gen(w, h, 1234 + i) for i in range(batch)])
+    t = torch.from_numpy(frames.view(np.int16) if frames.dtype == np.uint16 else frames).cuda()
     enc = M.Encoder(M.make_params(w, h, **kw), max_batch=batch)
     enc.encode_tensor(t); enc.sync()
     ok = enc.get_jpeg(0) == O.encode(O.make_params(w, h, **kw), frames[0])
@@ -49,3 +50,5 @@ if __name__ == "__main__":
     run("C4-like batch: 32 x 1080p q75 baseline trellis", 1920, 1080, dict(baseline=True), 32)
     run("C5 8-bit twin: 8192x8192 q90 4:4:4 baseline trellis, restart every MCU row", 8192, 8192,
         dict(baseline=True, quality=90, sample=(1, 1), restart=1), 1, steps=3)
+    run("C5: 8192x8192 12-bit q90 4:4:4 baseline, restart every MCU row, -notrellis (12-bit trellis does not exist, F1)", 8192, 8192,
+        dict(precision=12, baseline=True, notrellis=True, quality=90, sample=(1, 1), restart=1), 1, steps=3)
