@@ -8,6 +8,8 @@
  *                  replaces jcapistd.c:44   (declared jpeglib.h:1065)
  *   JDIMENSION jpeg_write_scanlines(j_compress_ptr cinfo, JSAMPARRAY scanlines, JDIMENSION num_lines);
  *                  replaces jcapistd.c:90   (declared jpeglib.h:1067)
+ *   JDIMENSION jpeg12_write_scanlines(j_compress_ptr cinfo, J12SAMPARRAY scanlines, JDIMENSION num_lines);
+ *                  the 12-bit twin (declared jpeglib.h:1070): rows of 16-bit samples, data_precision 12
  *   void       jpeg_finish_compress(j_compress_ptr cinfo);
  *                  replaces jcapimin.c:176  (declared jpeglib.h:1076)
  *
@@ -33,5 +35,5 @@
  */
 #ifndef MOZJPEG_HIP_JPEGLIB_H
 #define MOZJPEG_HIP_JPEGLIB_H
-#define MOZJPEG_HIP_SHIM_SYMBOLS "jpeg_start_compress jpeg_write_scanlines jpeg_finish_compress"
+#define MOZJPEG_HIP_SHIM_SYMBOLS "jpeg_start_compress jpeg_write_scanlines jpeg12_write_scanlines jpeg_finish_compress"
 #endif

@@ -80,7 +80,8 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p)
 {
   int ci, i;
   memset(p, 0, sizeof(*p));
-  if (cinfo->data_precision != 8) return "data_precision != 8";
+  if (cinfo->data_precision != 8 && cinfo->data_precision != 12) return "data_precision other than 8 or 12";
+  p->data_precision = cinfo->data_precision;
   if (cinfo->arith_code) return "arithmetic coding";
   if (cinfo->raw_data_in) return "raw_data_in";
   if (cinfo->smoothing_factor) return "input smoothing";
@@ -129,6 +130,7 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p)
   p->overshoot_deringing = jpeg_c_get_bool_param(cinfo, JBOOLEAN_OVERSHOOT_DERINGING);
   p->lambda_log_scale1 = jpeg_c_get_float_param(cinfo, JFLOAT_LAMBDA_LOG_SCALE1);
   p->lambda_log_scale2 = jpeg_c_get_float_param(cinfo, JFLOAT_LAMBDA_LOG_SCALE2);
+  if (cinfo->data_precision == 12 && p->trellis_quant) return "12-bit trellis (the reference itself aborts: jccoefct.c:132-138)";
   if (jpeg_c_get_bool_param(cinfo, JBOOLEAN_TRELLIS_EOB_OPT)) return "trellis_eob_opt";
   if (jpeg_c_get_bool_param(cinfo, JBOOLEAN_USE_SCANS_IN_TRELLIS)) return "use_scans_in_trellis";
   if (jpeg_c_get_bool_param(cinfo, JBOOLEAN_TRELLIS_Q_OPT)) return "trellis_q_opt";
@@ -209,7 +211,7 @@ void jpeg_start_compress(j_compress_ptr cinfo, boolean write_all_tables)
     s->header_bytes += 18;
   }
   s->cinfo = cinfo;
-  s->row_bytes = (size_t)cinfo->image_width * cinfo->input_components;
+  s->row_bytes = (size_t)cinfo->image_width * cinfo->input_components * (cinfo->data_precision == 12 ? 2 : 1);
   s->pixels = (unsigned char *)malloc(s->row_bytes * cinfo->image_height);
   if (!s->pixels) { free(s); ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0); }
   pthread_mutex_lock(&g_lock);
@@ -219,15 +221,16 @@ void jpeg_start_compress(j_compress_ptr cinfo, boolean write_all_tables)
   cinfo->global_state = CSTATE_SCANNING;
 }
 
-JDIMENSION jpeg_write_scanlines(j_compress_ptr cinfo, JSAMPARRAY scanlines, JDIMENSION num_lines)
+static JDIMENSION write_rows(j_compress_ptr cinfo, void **scanlines, JDIMENSION num_lines, int precision, const char *name)
 {
   shim_state *s = find_state(cinfo, 0);
   JDIMENSION rows_left, i;
   if (!s) {
-    write_fn next = (write_fn)dlsym(RTLD_NEXT, "jpeg_write_scanlines");
-    if (next) return next(cinfo, scanlines, num_lines);
+    write_fn next = (write_fn)dlsym(RTLD_NEXT, name);
+    if (next) return next(cinfo, (JSAMPARRAY)scanlines, num_lines);
     ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
   }
+  if (cinfo->data_precision != precision) ERREXIT1(cinfo, JERR_BAD_PRECISION, cinfo->data_precision);   /* jcapistd.c:96-97 */
   if (cinfo->global_state != CSTATE_SCANNING) ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
   if (cinfo->next_scanline >= cinfo->image_height) WARNMS(cinfo, JWRN_TOO_MUCH_DATA);
   if (cinfo->progress != NULL) {
@@ -241,6 +244,17 @@ JDIMENSION jpeg_write_scanlines(j_compress_ptr cinfo, JSAMPARRAY scanlines, JDIM
     memcpy(s->pixels + (size_t)(cinfo->next_scanline + i) * s->row_bytes, scanlines[i], s->row_bytes);
   cinfo->next_scanline += num_lines;
   return num_lines;
+}
+
+JDIMENSION jpeg_write_scanlines(j_compress_ptr cinfo, JSAMPARRAY scanlines, JDIMENSION num_lines)
+{
+  return write_rows(cinfo, (void **)scanlines, num_lines, 8, "jpeg_write_scanlines");
+}
+
+/* 12-bit twin (jpeglib.h:1070, J12SAMPLE = short): rows of 16-bit samples */
+JDIMENSION jpeg12_write_scanlines(j_compress_ptr cinfo, J12SAMPARRAY scanlines, JDIMENSION num_lines)
+{
+  return write_rows(cinfo, (void **)scanlines, num_lines, 12, "jpeg12_write_scanlines");
 }
 
 void jpeg_finish_compress(j_compress_ptr cinfo)

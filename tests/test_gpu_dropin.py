@@ -60,6 +60,22 @@ def test_unchanged_cjpeg_through_the_shim_matches_reference(cname, args, goldens
 
 
 @needs
+@pytest.mark.parametrize("args", [["-precision", "12", "-quality", "90", "-baseline", "-notrellis", "-sample", "1x1"],
+                                  ["-precision", "12", "-quality", "75", "-notrellis"],
+                                  ["-precision", "12", "-revert", "-quality", "90"]])
+def test_unchanged_cjpeg_12bit_through_the_shim(args, tmp_path):
+    """cjpeg -precision 12 rescales the 8-bit PPM to 12 bits (rdppm.c:844-848) and calls jpeg12_write_scanlines;
+    reference = the same binary without the shim"""
+    ref, gpu = str(tmp_path / "ref.jpg"), str(tmp_path / "gpu.jpg")
+    r1 = run_cjpeg(args, gpu)
+    env = dict(os.environ)
+    r0 = subprocess.run([CJPEG, "-dct", "int"] + args + ["-outfile", ref, PPM], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r0.returncode == 0, r0.stderr.decode()
+    assert r1.returncode == 0, r1.stderr.decode()
+    assert open(gpu, "rb").read() == open(ref, "rb").read()
+
+
+@needs
 def test_unsupported_configuration_is_an_error_without_fallback(tmp_path):
     out = str(tmp_path / "o.jpg")
     r = run_cjpeg(["-quality", "75", "-arithmetic"], out)          # arithmetic coding is outside the GPU path
