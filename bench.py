@@ -183,7 +183,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "kernel_ms_per_step": {k: round(v / args.steps, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])}},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(frames[0])
         print(json.dumps(out), flush=True)
     if dist is not None:

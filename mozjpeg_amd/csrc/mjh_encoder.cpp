@@ -797,7 +797,6 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   e->prof_names.clear();
   Prof pr{ e, s };
   HIPCHK(hipMemcpyAsync(e->d_tabs, e->d_tabs_init, (size_t)n * spi * sizeof(MjhHuffTable), hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemsetAsync(e->d_stream, 0, (size_t)n * e->stream_words * 4, s));
   pr.mark("color");
   mjh_launch_color(C, d_pixels, row_pitch, image_stride, e->d_planes, n, s);
   pr.mark("dct_quant");

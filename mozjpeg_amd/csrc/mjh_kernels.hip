@@ -121,6 +121,91 @@ k_color(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, size_t im
   }
 }
 
+// Vectorised variant for the common case (8-bit, 3 bytes per pixel, 2:1 horizontal chroma
+// subsampling, 8-byte aligned rows): one lane converts 8 pixels x V0 rows = 4 chroma samples.  The
+// 24 bytes per row arrive as three 8-byte loads, Y leaves as one 8-byte store per row, Cb/Cr as one
+// 4-byte store each; lanes whose 8 pixels touch the right image edge take the clamped byte path.
+template <int V0>
+__global__ void __launch_bounds__(256)
+k_color_vec(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, size_t img_stride,
+            uint8_t *__restrict__ planes)
+{
+  const int g4 = blockIdx.x * 256 + threadIdx.x;   // index of a run of 4 groups (8 pixels)
+  const int gy = blockIdx.y;
+  const int img = blockIdx.z;
+  if (g4 * 4 >= C.groups_x) return;
+  const uint8_t *p = pix + (size_t)img * img_stride;
+  uint8_t *pl = planes + (size_t)img * C.planes_per_image;
+  const bool below = gy >= C.real_groups_y;
+  const int gys = below ? C.real_groups_y - 1 : gy;
+  const int x0 = g4 * 8;
+  const bool interior = x0 + 7 <= C.W - 1;
+  const bool bgr = C.off_r == 2;
+  int yv[V0][8];
+  int cbs[4] = { 0, 0, 0, 0 }, crs[4] = { 0, 0, 0, 0 };
+#pragma unroll
+  for (int vy = 0; vy < V0; vy++) {
+    int iy = gys * V0 + vy;
+    if (iy > C.H - 1) iy = C.H - 1;
+    const uint8_t *row = p + (size_t)iy * row_pitch;
+    unsigned char px[24];
+    if (interior) {
+      const uint2 *rv = reinterpret_cast<const uint2 *>(row + (size_t)x0 * 3);
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const uint2 v = rv[i];
+#pragma unroll
+        for (int b = 0; b < 4; b++) { px[8 * i + b] = (unsigned char)(v.x >> (8 * b)); px[8 * i + 4 + b] = (unsigned char)(v.y >> (8 * b)); }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        int ix = x0 + j;
+        if (ix > C.W - 1) ix = C.W - 1;
+        px[3 * j] = row[ix * 3]; px[3 * j + 1] = row[ix * 3 + 1]; px[3 * j + 2] = row[ix * 3 + 2];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      // static indices only (a runtime channel offset would push px[] to scratch): RGB or BGR by a uniform select
+      const int c0v = px[3 * j], g = px[3 * j + 1], c2v = px[3 * j + 2];
+      const int r = bgr ? c2v : c0v, b = bgr ? c0v : c2v;
+      yv[vy][j] = (FIXC(0.29900) * r + FIXC(0.58700) * g + FIXC(0.11400) * b + 32768) >> 16;
+      cbs[j >> 1] += (-FIXC(0.16874) * r - FIXC(0.33126) * g + FIXC(0.50000) * b + (128 << 16) + 32767) >> 16;
+      crs[j >> 1] += (FIXC(0.50000) * r - FIXC(0.41869) * g - FIXC(0.08131) * b + (128 << 16) + 32767) >> 16;
+    }
+  }
+  const MjhComp &c0 = C.c[0];
+  if (x0 < c0.pw) {
+#pragma unroll
+    for (int vy = 0; vy < V0; vy++) {
+      const int r = gy * V0 + vy;
+      const int svy = below ? V0 - 1 : vy;
+      if (r < c0.ph) {
+        uint2 o;
+        o.x = (unsigned)yv[svy][0] | ((unsigned)yv[svy][1] << 8) | ((unsigned)yv[svy][2] << 16) | ((unsigned)yv[svy][3] << 24);
+        o.y = (unsigned)yv[svy][4] | ((unsigned)yv[svy][5] << 8) | ((unsigned)yv[svy][6] << 16) | ((unsigned)yv[svy][7] << 24);
+        *reinterpret_cast<uint2 *>(pl + c0.plane_off + (size_t)r * c0.pw + x0) = o;
+      }
+    }
+  }
+  const MjhComp &c1 = C.c[1];
+  const MjhComp &c2 = C.c[2];
+  if (gy < c1.ph && g4 * 4 < c1.pw) {
+    unsigned ocb = 0, ocr = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int cb, cr;
+      if (V0 == 2) { const int bias = 1 + (j & 1); cb = (cbs[j] + bias) >> 2; cr = (crs[j] + bias) >> 2; }   // h2v2, bias 1,2,1,2 (4*g4 is even)
+      else { const int bias = j & 1; cb = (cbs[j] + bias) >> 1; cr = (crs[j] + bias) >> 1; }                 // h2v1, bias 0,1,0,1
+      ocb |= (unsigned)cb << (8 * j);
+      ocr |= (unsigned)cr << (8 * j);
+    }
+    *reinterpret_cast<unsigned *>(pl + c1.plane_off + (size_t)gy * c1.pw + g4 * 4) = ocb;
+    *reinterpret_cast<unsigned *>(pl + c2.plane_off + (size_t)gy * c2.pw + g4 * 4) = ocr;
+  }
+}
+
 // =============================================================================================
 // K2  convsamp + overshoot deringing + islow FDCT + quantize   (rows a4-a8)
 //   convsamp jcdctmgr.c:576, preprocess_deringing :416-498 (catmull_rom :387), jpeg_fdct_islow
@@ -1018,18 +1103,23 @@ k_chunk_sums(const T *__restrict__ len16, int n_per_image, unsigned *__restrict_
 
 // one workgroup per image: exclusive scan of the chunk sums in place; total -> totals[img]
 __global__ void __launch_bounds__(256)
-k_scan_sums(unsigned *__restrict__ sums, int chunks_per_image, unsigned *__restrict__ totals)
+k_scan_sums(unsigned *__restrict__ sums, int chunks_per_image, unsigned *__restrict__ totals, const unsigned *__restrict__ stream_bits)
 {
   __shared__ unsigned sh[4];
   const int img = blockIdx.x;
   unsigned *p = sums + (size_t)img * chunks_per_image;
   unsigned carry = 0;
-  for (int base = 0; base < chunks_per_image; base += 256) {
+  int nchunks = chunks_per_image;
+  if (stream_bits) {   // byte-stuffing pass: only the chunks that hold entropy-coded words were produced
+    const unsigned nwords = ((((stream_bits[img] + 7) >> 3) + 3) >> 2);
+    nchunks = min(chunks_per_image, (int)((nwords + SCAN_CHUNK - 1) / SCAN_CHUNK));
+  }
+  for (int base = 0; base < nchunks; base += 256) {
     const int i = base + threadIdx.x;
-    const unsigned v = i < chunks_per_image ? p[i] : 0u;
+    const unsigned v = i < nchunks ? p[i] : 0u;
     unsigned tot;
     const unsigned ex = block_excl_scan_256(v, sh, &tot);
-    if (i < chunks_per_image) p[i] = carry + ex;
+    if (i < nchunks) p[i] = carry + ex;
     carry += tot;
   }
   if (threadIdx.x == 0) totals[img] = carry;
@@ -1164,6 +1254,19 @@ k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *
   bw.flush();
 }
 
+// zero exactly the words the entropy coder is going to OR its bits into (the buffer itself is sized for the
+// worst case of 1665 bits per block; clearing all of it would cost more HBM traffic than the whole encode)
+__global__ void __launch_bounds__(256)
+k_zero_stream(unsigned *__restrict__ stream, size_t stream_words_per_image, const unsigned *__restrict__ totals,
+              const unsigned *__restrict__ seg_totals)
+{
+  const int img = blockIdx.y;
+  const unsigned bits = totals[img] + (seg_totals ? seg_totals[img] : 0u);
+  const unsigned nvec = ((bits >> 5) + 8) >> 2;   // uint4 units, a few words of slack for the trailing partial word
+  uint4 *p = reinterpret_cast<uint4 *>(stream + (size_t)img * stream_words_per_image);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i <= nvec; i += gridDim.x * 256) p[i] = make_uint4(0, 0, 0, 0);
+}
+
 // ---- header + stuffing + trailer -------------------------------------------------------------
 
 // One workgroup per image: [prefix: SOI APP0 DQT SOF] [DHT...] [SOS] -> out, hdr_len.
@@ -1241,13 +1344,15 @@ k_ff_chunk_sums(const unsigned *__restrict__ stream, size_t stream_words_per_ima
                 unsigned *__restrict__ sums, int chunks_per_image, const unsigned *__restrict__ mpos_all, int nseg)
 {
   __shared__ unsigned sh[4];
-  const int img = blockIdx.y, chunk = blockIdx.x;
+  const int img = blockIdx.y;
   const unsigned nbytes = (totals[img] + 7) >> 3;
   const unsigned nwords = (nbytes + 3) >> 2;
   const unsigned *p = stream + (size_t)img * stream_words_per_image;
+  const unsigned *mpos = nseg > 1 ? mpos_all + (size_t)img * nseg : nullptr;
+  // the stream buffer is sized for the worst case; only the chunks that hold data are visited
+  for (unsigned chunk = blockIdx.x; chunk * SCAN_CHUNK < nwords; chunk += gridDim.x) {
   unsigned s = 0;
   const unsigned base = chunk * SCAN_CHUNK + threadIdx.x * 8;
-  const unsigned *mpos = nseg > 1 ? mpos_all + (size_t)img * nseg : nullptr;
 #pragma unroll
   for (int i = 0; i < 8; i++) if (base + i < nwords) {  // bytes past nbytes are zero
     const unsigned w = p[base + i];
@@ -1260,6 +1365,7 @@ k_ff_chunk_sums(const unsigned *__restrict__ stream, size_t stream_words_per_ima
   }
   const unsigned tot = block_reduce_256(s, sh);
   if (threadIdx.x == 0) sums[(size_t)img * chunks_per_image + chunk] = tot;
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -1269,14 +1375,15 @@ k_stuff_write(const unsigned *__restrict__ stream, size_t stream_words_per_image
               const unsigned *__restrict__ mpos_all, int nseg)
 {
   __shared__ unsigned sh[4];
-  const int img = blockIdx.y, chunk = blockIdx.x;
+  const int img = blockIdx.y;
   const unsigned nbytes = (totals[img] + 7) >> 3;
   const unsigned nwords = (nbytes + 3) >> 2;
   const unsigned *p = stream + (size_t)img * stream_words_per_image;
   const unsigned hdr = meta[img].hdr_len;
   uint8_t *o = out + (size_t)img * out_stride + hdr;
-  const unsigned base = chunk * SCAN_CHUNK + threadIdx.x * 8;
   const unsigned *mpos = nseg > 1 ? mpos_all + (size_t)img * nseg : nullptr;
+  for (unsigned chunk = blockIdx.x; chunk * SCAN_CHUNK < nwords; chunk += gridDim.x) {
+  const unsigned base = chunk * SCAN_CHUNK + threadIdx.x * 8;
   unsigned w[8], s = 0;
   unsigned mk = 0;   // bit (4*i+b) set: byte b of word i is the 0xFF of a restart marker
 #pragma unroll
@@ -1305,7 +1412,8 @@ k_stuff_write(const unsigned *__restrict__ stream, size_t stream_words_per_image
       }
     }
   }
-  if (chunk == 0 && threadIdx.x == 0) {
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     const unsigned stuffed = nbytes + ff_totals[img];
     o[stuffed] = 0xFF;       // EOI, write_file_trailer jcmarker.c:791
     o[stuffed + 1] = 0xD9;
@@ -1324,8 +1432,15 @@ static inline dim3 g3(unsigned x, unsigned y, unsigned z) { return dim3(x, y, z)
 
 void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size_t img_stride, void *planes, int n, hipStream_t s)
 {
-  dim3 grid((C.groups_x + 255) / 256, C.groups_y, n);
   const int H0 = C.maxh, V0 = C.maxv;
+  if (C.precision == 8 && C.in_comps == 3 && C.ncomp == 3 && C.px_size == 3 && H0 == 2 && (row_pitch & 7) == 0 &&
+      (img_stride & 7) == 0 && ((uintptr_t)pix & 7) == 0 && C.off_g == 1 && (C.off_r == 0 || C.off_r == 2)) {
+    dim3 gridv(((C.groups_x + 3) / 4 + 255) / 256, C.groups_y, n);
+    if (V0 == 2) hipLaunchKernelGGL((k_color_vec<2>), gridv, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint8_t *)planes);
+    else hipLaunchKernelGGL((k_color_vec<1>), gridv, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint8_t *)planes);
+    return;
+  }
+  dim3 grid((C.groups_x + 255) / 256, C.groups_y, n);
 #define LC(h, v) do { if (C.precision == 12) hipLaunchKernelGGL((k_color<h, v, uint16_t>), grid, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint16_t *)planes); \
                       else hipLaunchKernelGGL((k_color<h, v, uint8_t>), grid, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint8_t *)planes); } while (0)
   if (H0 == 2 && V0 == 2) LC(2, 2);
@@ -1416,16 +1531,18 @@ void mjh_launch_encode(const MjhConst &C, const void *q, const MjhHuffTable *tab
   dim3 grid((max_padblk(C) + 255) / 256, C.ncomp, n);
   hipLaunchKernelGGL(k_enc_len, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, ds, as, (uint16_t *)len16);
   hipLaunchKernelGGL((k_chunk_sums<uint16_t>), dim3(chunks_per_image, n), dim3(256), 0, s, (const uint16_t *)len16, C.total_mcu_blocks, sums, chunks_per_image);
-  hipLaunchKernelGGL(k_scan_sums, dim3(n), dim3(256), 0, s, sums, chunks_per_image, totals);
+  hipLaunchKernelGGL(k_scan_sums, dim3(n), dim3(256), 0, s, sums, chunks_per_image, totals, (const unsigned *)nullptr);
   hipLaunchKernelGGL((k_offsets<uint16_t>), dim3(chunks_per_image, n), dim3(256), 0, s, (const uint16_t *)len16, C.total_mcu_blocks, sums, chunks_per_image, (unsigned *)off32);
   const bool rst = C.restart_interval != 0 && nseg > 1;
   if (rst) {
     const int seg_chunks = (nseg + SCAN_CHUNK - 1) / SCAN_CHUNK;
     hipLaunchKernelGGL(k_seg_extra, dim3((nseg + 255) / 256, n), dim3(256), 0, s, C, (const unsigned *)off32, totals, seg_x, nseg);
     hipLaunchKernelGGL((k_chunk_sums<unsigned>), dim3(seg_chunks, n), dim3(256), 0, s, (const unsigned *)seg_x, nseg, seg_sums, seg_chunks);
-    hipLaunchKernelGGL(k_scan_sums, dim3(n), dim3(256), 0, s, seg_sums, seg_chunks, seg_totals);
+    hipLaunchKernelGGL(k_scan_sums, dim3(n), dim3(256), 0, s, seg_sums, seg_chunks, seg_totals, (const unsigned *)nullptr);
     hipLaunchKernelGGL((k_offsets<unsigned>), dim3(seg_chunks, n), dim3(256), 0, s, (const unsigned *)seg_x, nseg, seg_sums, seg_chunks, seg_E);
   }
+  hipLaunchKernelGGL(k_zero_stream, dim3(64, n), dim3(256), 0, s, stream, stream_words_per_image, (const unsigned *)totals,
+                     rst ? (const unsigned *)seg_totals : (const unsigned *)nullptr);
   hipLaunchKernelGGL(k_enc_write, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image,
                      (const unsigned *)seg_E, mpos, rst ? nseg : 1);
   hipLaunchKernelGGL(k_finish_bits, dim3((n + 63) / 64), dim3(64), 0, s, totals, rst ? (const unsigned *)seg_totals : (const unsigned *)nullptr, stream,
@@ -1443,8 +1560,8 @@ void mjh_launch_header(const void *prefix, int prefix_len, const void *sos, int 
 void mjh_launch_stuff(const unsigned *stream, size_t stream_words_per_image, const unsigned *totals, unsigned *ffsums, int ff_chunks_per_image,
                       unsigned *ff_totals, void *out, size_t out_stride, void *meta, unsigned *sizes, const unsigned *mpos, int nseg, int n, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_ff_chunk_sums, dim3(ff_chunks_per_image, n), dim3(256), 0, s, stream, stream_words_per_image, totals, ffsums, ff_chunks_per_image, mpos, nseg);
-  hipLaunchKernelGGL(k_scan_sums, dim3(n), dim3(256), 0, s, ffsums, ff_chunks_per_image, ff_totals);
-  hipLaunchKernelGGL(k_stuff_write, dim3(ff_chunks_per_image, n), dim3(256), 0, s, stream, stream_words_per_image, totals, ffsums, ff_chunks_per_image,
+  hipLaunchKernelGGL(k_ff_chunk_sums, dim3(ff_chunks_per_image < 128 ? ff_chunks_per_image : 128, n), dim3(256), 0, s, stream, stream_words_per_image, totals, ffsums, ff_chunks_per_image, mpos, nseg);
+  hipLaunchKernelGGL(k_scan_sums, dim3(n), dim3(256), 0, s, ffsums, ff_chunks_per_image, ff_totals, totals);
+  hipLaunchKernelGGL(k_stuff_write, dim3(ff_chunks_per_image < 128 ? ff_chunks_per_image : 128, n), dim3(256), 0, s, stream, stream_words_per_image, totals, ffsums, ff_chunks_per_image,
                      ff_totals, (uint8_t *)out, out_stride, (MjhImageMeta *)meta, sizes, mpos, nseg);
 }
