@@ -713,27 +713,35 @@ __device__ __forceinline__ bool trellis_ac_block(const uint4 *si_rows, const int
         }
         float best = 1e38f;
         int bestp = -1, bestk = 0;
+        // Walk the live predecessors NEWEST FIRST.  The reference scans them oldest first and keeps the
+        // first minimum (strict '<'), i.e. on equal cost the OLDER predecessor (and for one predecessor
+        // the smaller candidate) wins -- reproduced here by the explicit tie rule.  The reversed order
+        // lets old predecessors be rejected with one compare: cost = (rate + dist) + rhs >= rhs in
+        // float arithmetic (adding a positive term never rounds below the other operand), so
+        // rhs > best already proves "not better, not a tie".
         unsigned long long m = live;
-        int e = 0;
+        int e = nlive;
         while (m) {
-          const int p = __builtin_ctzll(m);
-          m &= m - 1;
+          const int p = 63 - __builtin_clzll(m);
+          m &= ~(1ull << p);
+          e--;
           const float2 aa = e_aa[e][lane];
-          e++;
+          float rhs = azd_prev - aa.x;
+          rhs = rhs + aa.y;
+          if (rhs > best) continue;
           const int zero_run = i - 1 - p;
           const int hi = zero_run >> 4;
           if (hi && si_f0 == 0) continue;
           const uint4 row = si_rows[zero_run & 15];
-          float rhs = azd_prev - aa.x;
-          rhs = rhs + aa.y;
           const int rbase = hi * si_f0;
+          bool first = true;   // within one predecessor the smaller candidate index wins ties
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const int cb = row_byte(row, k + 1);
             if (k < ncd && cb != 0) {
               float cost = (float)(cb + (k + 1) + rbase) + dist[k];
               cost = cost + rhs;
-              if (cost < best) { best = cost; bestp = p; bestk = k; }
+              if (cost < best || (cost == best && first && bestp >= 0)) { best = cost; bestp = p; bestk = k; first = false; }
             }
           }
           for (int k = 4; k < ncd; k++) {             // |q| >= 16: rare
@@ -745,7 +753,7 @@ __device__ __forceinline__ bool trellis_ac_block(const uint4 *si_rows, const int
               d = d * lti;
               float cost = (float)(cb + (k + 1) + rbase) + d;
               cost = cost + rhs;
-              if (cost < best) { best = cost; bestp = p; bestk = k; }
+              if (cost < best || (cost == best && first && bestp >= 0)) { best = cost; bestp = p; bestk = k; first = false; }
             }
           }
         }
