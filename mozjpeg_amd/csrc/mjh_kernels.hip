@@ -727,6 +727,9 @@ __device__ __forceinline__ bool trellis_ac_block(const uint4 *si_rows, const int
           e--;
           const float2 aa = e_aa[e][lane];
           float rhs = azd_prev - aa.x;
+          // accumulated zero distortion only grows with distance and acc >= 0, so once the gap alone
+          // exceeds the best cost every OLDER predecessor is out as well: leave the loop
+          if (rhs > best) break;
           rhs = rhs + aa.y;
           if (rhs > best) continue;
           const int zero_run = i - 1 - p;
