@@ -645,6 +645,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     for (int k = 0; k < 64; k++) {
       const int q = p->quantval[t][kZZ[k]] ? p->quantval[t][kZZ[k]] : 1;
       hq.q[t][k] = (uint16_t)q;
+      hq.dq8[t][k] = 8 * q;
       hq.rcp8q[t][k] = 1.0f / (float)(8 * q);
       hq.lambda_tbl[t][k] = (float)(1.0 / (double)(q * q));   // jcdctmgr.c:1017-1021
     }

@@ -64,6 +64,7 @@ struct MjhConst {
 // per-table-slot constant data uploaded once per encoder
 struct MjhQuant {
   uint16_t q[4][64];        // zig-zag order quantizer step
+  int dq8[4][64];           // 8*q as a 32-bit word: wave-uniform reads become scalar loads (no 16-bit s_load)
   float rcp8q[4][64];       // 1.0f / (8*q) for the exact-division helper
   float lambda_tbl[4][64];  // (float)(1.0 / (q*q)), zig-zag order (jcdctmgr.c:1017-1021)
 };

@@ -359,7 +359,7 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
 #pragma unroll
   for (int k = 0; k < 64; k++) {
     const int x = d[kZZ.v[k]];
-    const int dq = 8 * (int)qz[k];
+    const int dq = Q->dq8[cc.qtbl][k];
     const int ax = x < 0 ? -x : x;
     int v = udiv_exact(ax + (dq >> 1), dq, rcp[k]);
     if (x < 0) v = -v;
@@ -665,14 +665,24 @@ __device__ __forceinline__ int row_byte(const uint4 &r, int b)
   return (int)((w >> (8 * (b & 3))) & 0xFFu);
 }
 
-template <int NE>
-__device__ __forceinline__ bool trellis_ac_block(const uint4 *si_rows, const int16_t *__restrict__ uq,
+// code lengths of one zero-run row as floats with the magnitude bits folded in: element k =
+// (float)(size(run, k+1) + k + 1), or 3e38 where the table has no code (such a candidate can never win)
+__device__ __forceinline__ float4 rate_row(const uint4 &r)
+{
+  const int b1 = (int)((r.x >> 8) & 0xFFu), b2 = (int)((r.x >> 16) & 0xFFu), b3 = (int)(r.x >> 24), b4 = (int)(r.y & 0xFFu);
+  return make_float4(b1 ? (float)(b1 + 1) : 3e38f, b2 ? (float)(b2 + 2) : 3e38f, b3 ? (float)(b3 + 3) : 3e38f,
+                     b4 ? (float)(b4 + 4) : 3e38f);
+}
+
+template <int NE, bool LDS_ROWS>
+__device__ __forceinline__ bool trellis_ac_block(const uint4 *si_rows, const float4 *rate_rows, const int16_t *__restrict__ uq,
                                                  int16_t *__restrict__ qo, int kstride,
-                                                 const uint16_t *__restrict__ qz, const float *__restrict__ rcp,
+                                                 const int *__restrict__ dq8, const float *__restrict__ rcp,
                                                  const float *__restrict__ lt, float lambda,
                                                  float2 (*e_aa)[64], unsigned short (*e_pk)[64], int lane)
 {
   const int si_f0 = (int)(si_rows[15].x & 0xFFu), si_eob = (int)(si_rows[0].x & 0xFFu);
+  const float f0f = si_f0 ? (float)si_f0 : 3e38f;   // cost of one ZRL; no code => unreachable
   unsigned long long live = 1ull, neg = 0ull;
   int nlive = 1;
   e_aa[0][lane] = make_float2(0.0f, 0.0f);
@@ -694,7 +704,7 @@ __device__ __forceinline__ bool trellis_ac_block(const uint4 *si_rows, const int
       if (j == 0 && c == 0) continue;
       const int xs = xc[j];
       const int x = xs < 0 ? -xs : xs;
-      const int dq = 8 * (int)qz[i];
+      const int dq = dq8[i];
       const float lti = lt[i];
       float t = (float)(x * x) * lambda;
       t = t * lti;
@@ -709,7 +719,7 @@ __device__ __forceinline__ bool trellis_ac_block(const uint4 *si_rows, const int
           const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
           const int delta = cand * dq - x;
           float d = (float)(delta * delta) * lambda;
-          dist[k] = d * lti;
+          dist[k] = k < ncd ? d * lti : 3e38f;
         }
         float best = 1e38f;
         int bestp = -1, bestk = 0;
@@ -734,31 +744,40 @@ __device__ __forceinline__ bool trellis_ac_block(const uint4 *si_rows, const int
           if (rhs > best) continue;
           const int zero_run = i - 1 - p;
           const int hi = zero_run >> 4;
-          if (hi && si_f0 == 0) continue;
-          const uint4 row = si_rows[zero_run & 15];
-          const int rbase = hi * si_f0;
-          bool first = true;   // within one predecessor the smaller candidate index wins ties
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const int cb = row_byte(row, k + 1);
-            if (k < ncd && cb != 0) {
-              float cost = (float)(cb + (k + 1) + rbase) + dist[k];
-              cost = cost + rhs;
-              if (cost < best || (cost == best && first && bestp >= 0)) { best = cost; bestp = p; bestk = k; first = false; }
+          // rate = size + magnitude bits (+ ZRLs): all small integers, so the float sums below are
+          // exact and equal (float)(size + k + 1 + hi * size_f0) of the reference
+          const float4 rr = LDS_ROWS ? rate_rows[zero_run & 15] : rate_row(si_rows[zero_run & 15]);
+          const float rb = (float)hi * f0f;
+          float c0 = (rr.x + rb) + dist[0];
+          float c1 = (rr.y + rb) + dist[1];
+          float c2 = (rr.z + rb) + dist[2];
+          float c3 = (rr.w + rb) + dist[3];
+          c0 = c0 + rhs; c1 = c1 + rhs; c2 = c2 + rhs; c3 = c3 + rhs;
+          // within one predecessor the smaller candidate index wins ties (strict '<')
+          float lb = c0;
+          int lk = 0;
+          if (c1 < lb) { lb = c1; lk = 1; }
+          if (c2 < lb) { lb = c2; lk = 2; }
+          if (c3 < lb) { lb = c3; lk = 3; }
+          if (ncd > 4 && !(hi && si_f0 == 0)) {        // |q| >= 16: rare
+            const uint4 row = si_rows[zero_run & 15];
+            const int rbase = hi * si_f0;
+#pragma nounroll   // unrolled, the candidate distortions get hoisted and computed for EVERY coefficient
+            for (int k = 4; k < ncd; k++) {
+              const int cb = row_byte(row, k + 1);
+              if (cb != 0) {
+                const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
+                const int delta = cand * dq - x;
+                float d = (float)(delta * delta) * lambda;
+                d = d * lti;
+                float cost = (float)(cb + (k + 1) + rbase) + d;
+                cost = cost + rhs;
+                if (cost < lb) { lb = cost; lk = k; }
+              }
             }
           }
-          for (int k = 4; k < ncd; k++) {             // |q| >= 16: rare
-            const int cb = row_byte(row, k + 1);
-            if (cb != 0) {
-              const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
-              const int delta = cand * dq - x;
-              float d = (float)(delta * delta) * lambda;
-              d = d * lti;
-              float cost = (float)(cb + (k + 1) + rbase) + d;
-              cost = cost + rhs;
-              if (cost < best || (cost == best && first && bestp >= 0)) { best = cost; bestp = p; bestk = k; first = false; }
-            }
-          }
+          // across predecessors the OLDER one wins ties, and this walk goes newest -> oldest
+          if (lb < best || (lb == best && bestp >= 0)) { best = lb; bestp = p; bestk = lk; }
         }
         if (bestp >= 0) {
           if (nlive >= NE) return false;
@@ -816,19 +835,24 @@ k_trellis_ac(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restri
   __shared__ float2 e_aa[NE][64];
   __shared__ unsigned short e_pk[NE][64];   // back position | magnitude << 6
   __shared__ uint4 si_rows[16];
+  __shared__ float4 rate_rows[16];
   const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
   const int lane = threadIdx.x;
   const int slot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
   const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
-  if (lane < 16) si_rows[lane] = reinterpret_cast<const uint4 *>(T->ehufsi)[lane];
+  if (lane < 16) {
+    const uint4 r = reinterpret_cast<const uint4 *>(T->ehufsi)[lane];
+    si_rows[lane] = r;
+    rate_rows[lane] = rate_row(r);
+  }
   __syncthreads();
   const int blk = blockIdx.x * 64 + lane;
   if (blk >= cc.nblk) return;
   const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
   int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
   const float lambda = lambda_in[(size_t)img * C.total_real_blocks + cc.blk_off + blk];
-  const bool ok = trellis_ac_block<NE>(si_rows, uq, qo, cc.kstride, Q->q[cc.qtbl], Q->rcp8q[cc.qtbl], Q->lambda_tbl[cc.qtbl],
+  const bool ok = trellis_ac_block<NE, true>(si_rows, rate_rows, uq, qo, cc.kstride, Q->dq8[cc.qtbl], Q->rcp8q[cc.qtbl], Q->lambda_tbl[cc.qtbl],
                                        lambda, e_aa, e_pk, lane);
   if (!ok) {
     const unsigned idx = atomicAdd(&worklist[0], 1u);
@@ -860,7 +884,7 @@ k_trellis_ac_deferred(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t 
     const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
     int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
     const float lambda = lambda_in[(size_t)img * C.total_real_blocks + cc.blk_off + blk];
-    const bool ok = trellis_ac_block<NE2>(reinterpret_cast<const uint4 *>(T->ehufsi), uq, qo, cc.kstride, Q->q[cc.qtbl], Q->rcp8q[cc.qtbl],
+    const bool ok = trellis_ac_block<NE2, false>(reinterpret_cast<const uint4 *>(T->ehufsi), nullptr, uq, qo, cc.kstride, Q->dq8[cc.qtbl], Q->rcp8q[cc.qtbl],
                                           Q->lambda_tbl[cc.qtbl], lambda, e_aa, e_pk, lane);
     if (!ok && NE2 < 64) {
       const unsigned idx = atomicAdd(&worklist_next[0], 1u);
