@@ -698,19 +698,24 @@ __device__ __forceinline__ bool trellis_ac_block(const uint4 *si_rows, const flo
 #pragma unroll
       for (int j = 0; j < 8; j++) xn[j] = uq[(size_t)(8 * (c + 1) + j) * kstride];
     }
+    // the chunk's wave-uniform constants in three wide scalar loads instead of one load + wait per coefficient
+    int dqc[8];
+    float ltc[8], rcpc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { dqc[j] = dq8[8 * c + j]; ltc[j] = lt[8 * c + j]; rcpc[j] = rcp[8 * c + j]; }
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int i = 8 * c + j;
       if (j == 0 && c == 0) continue;
       const int xs = xc[j];
       const int x = xs < 0 ? -xs : xs;
-      const int dq = dq8[i];
-      const float lti = lt[i];
+      const int dq = dqc[j];
+      const float lti = ltc[j];
       float t = (float)(x * x) * lambda;
       t = t * lti;
       const float azd_cur = t + azd_prev;
       if (x + (dq >> 1) >= dq) {                      // qval != 0
-        int qval = udiv_exact(x + (dq >> 1), dq, rcp[i]);
+        int qval = udiv_exact(x + (dq >> 1), dq, rcpc[j]);
         if (qval >= 1024) qval = 1023;
         const int ncd = bitlen((unsigned)qval);
         float dist[4];
