@@ -674,6 +674,87 @@ __device__ __forceinline__ float4 rate_row(const uint4 &r)
                      b4 ? (float)(b4 + 4) : 3e38f);
 }
 
+// The predecessor walk of one coefficient position (jcdctmgr.c:1143-1180), NC = number of unrolled
+// candidates (1 when the whole wave has |q| == 1, else 4; |q| >= 16 takes the rolled tail loop).
+// Walks the live predecessors NEWEST FIRST.  The reference scans them oldest first and keeps the first
+// minimum (strict '<'), i.e. on equal cost the OLDER predecessor (and for one predecessor the smaller
+// candidate) wins -- reproduced here by the explicit tie rule.  The reversed order lets old
+// predecessors be rejected with one compare: cost = (rate + dist) + rhs >= rhs in float arithmetic
+// (adding a positive term never rounds below the other operand), so rhs > best already proves
+// "not better, not a tie".
+template <int NC, bool LDS_ROWS>
+__device__ __forceinline__ void trellis_walk(const uint4 *si_rows, const float4 *rate_rows, float2 (*e_aa)[64], int lane,
+                                             unsigned long long live, int nlive, float azd_prev, int i, int x, int dq,
+                                             int qval, int ncd, float lambda, float lti, int si_f0, float f0f,
+                                             float &best, int &bestp, int &bestk)
+{
+  float dist[NC];
+#pragma unroll
+  for (int k = 0; k < NC; k++) {
+    const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
+    const int delta = cand * dq - x;
+    float d = (float)(delta * delta) * lambda;
+    dist[k] = k < ncd ? d * lti : 3e38f;
+  }
+  unsigned long long m = live;
+  int e = nlive;
+  while (m) {
+    const int p = 63 - __builtin_clzll(m);
+    m &= ~(1ull << p);
+    e--;
+    const float2 aa = e_aa[e][lane];
+    float rhs = azd_prev - aa.x;
+    // accumulated zero distortion only grows with distance and acc >= 0, so once the gap alone
+    // exceeds the best cost every OLDER predecessor is out as well: leave the loop
+    if (rhs > best) break;
+    rhs = rhs + aa.y;
+    if (rhs > best) continue;
+    const int zero_run = i - 1 - p;
+    const int hi = zero_run >> 4;
+    // rate = size + magnitude bits (+ ZRLs): all small integers, so the float sums below are
+    // exact and equal (float)(size + k + 1 + hi * size_f0) of the reference
+    const float rb = (float)hi * f0f;
+    float lb;
+    int lk = 0;
+    if (NC == 1) {
+      const float r0 = LDS_ROWS ? rate_rows[zero_run & 15].x : rate_row(si_rows[zero_run & 15]).x;
+      lb = (r0 + rb) + dist[0];
+      lb = lb + rhs;
+    } else {
+      const float4 rr = LDS_ROWS ? rate_rows[zero_run & 15] : rate_row(si_rows[zero_run & 15]);
+      float c0 = (rr.x + rb) + dist[0];
+      float c1 = (rr.y + rb) + dist[NC > 1 ? 1 : 0];
+      float c2 = (rr.z + rb) + dist[NC > 2 ? 2 : 0];
+      float c3 = (rr.w + rb) + dist[NC > 3 ? 3 : 0];
+      c0 = c0 + rhs; c1 = c1 + rhs; c2 = c2 + rhs; c3 = c3 + rhs;
+      // within one predecessor the smaller candidate index wins ties (strict '<')
+      lb = c0;
+      if (c1 < lb) { lb = c1; lk = 1; }
+      if (c2 < lb) { lb = c2; lk = 2; }
+      if (c3 < lb) { lb = c3; lk = 3; }
+      if (ncd > 4 && !(hi && si_f0 == 0)) {        // |q| >= 16: rare
+        const uint4 row = si_rows[zero_run & 15];
+        const int rbase = hi * si_f0;
+#pragma nounroll   // unrolled, the candidate distortions get hoisted and computed for EVERY coefficient
+        for (int k = 4; k < ncd; k++) {
+          const int cb = row_byte(row, k + 1);
+          if (cb != 0) {
+            const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
+            const int delta = cand * dq - x;
+            float d = (float)(delta * delta) * lambda;
+            d = d * lti;
+            float cost = (float)(cb + (k + 1) + rbase) + d;
+            cost = cost + rhs;
+            if (cost < lb) { lb = cost; lk = k; }
+          }
+        }
+      }
+    }
+    // across predecessors the OLDER one wins ties, and this walk goes newest -> oldest
+    if (lb < best || (lb == best && bestp >= 0)) { best = lb; bestp = p; bestk = lk; }
+  }
+}
+
 template <int NE, bool LDS_ROWS>
 __device__ __forceinline__ bool trellis_ac_block(const uint4 *si_rows, const float4 *rate_rows, const int16_t *__restrict__ uq,
                                                  int16_t *__restrict__ qo, int kstride,
@@ -718,72 +799,16 @@ __device__ __forceinline__ bool trellis_ac_block(const uint4 *si_rows, const flo
         int qval = udiv_exact(x + (dq >> 1), dq, rcpc[j]);
         if (qval >= 1024) qval = 1023;
         const int ncd = bitlen((unsigned)qval);
-        float dist[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
-          const int delta = cand * dq - x;
-          float d = (float)(delta * delta) * lambda;
-          dist[k] = k < ncd ? d * lti : 3e38f;
-        }
         float best = 1e38f;
         int bestp = -1, bestk = 0;
-        // Walk the live predecessors NEWEST FIRST.  The reference scans them oldest first and keeps the
-        // first minimum (strict '<'), i.e. on equal cost the OLDER predecessor (and for one predecessor
-        // the smaller candidate) wins -- reproduced here by the explicit tie rule.  The reversed order
-        // lets old predecessors be rejected with one compare: cost = (rate + dist) + rhs >= rhs in
-        // float arithmetic (adding a positive term never rounds below the other operand), so
-        // rhs > best already proves "not better, not a tie".
-        unsigned long long m = live;
-        int e = nlive;
-        while (m) {
-          const int p = 63 - __builtin_clzll(m);
-          m &= ~(1ull << p);
-          e--;
-          const float2 aa = e_aa[e][lane];
-          float rhs = azd_prev - aa.x;
-          // accumulated zero distortion only grows with distance and acc >= 0, so once the gap alone
-          // exceeds the best cost every OLDER predecessor is out as well: leave the loop
-          if (rhs > best) break;
-          rhs = rhs + aa.y;
-          if (rhs > best) continue;
-          const int zero_run = i - 1 - p;
-          const int hi = zero_run >> 4;
-          // rate = size + magnitude bits (+ ZRLs): all small integers, so the float sums below are
-          // exact and equal (float)(size + k + 1 + hi * size_f0) of the reference
-          const float4 rr = LDS_ROWS ? rate_rows[zero_run & 15] : rate_row(si_rows[zero_run & 15]);
-          const float rb = (float)hi * f0f;
-          float c0 = (rr.x + rb) + dist[0];
-          float c1 = (rr.y + rb) + dist[1];
-          float c2 = (rr.z + rb) + dist[2];
-          float c3 = (rr.w + rb) + dist[3];
-          c0 = c0 + rhs; c1 = c1 + rhs; c2 = c2 + rhs; c3 = c3 + rhs;
-          // within one predecessor the smaller candidate index wins ties (strict '<')
-          float lb = c0;
-          int lk = 0;
-          if (c1 < lb) { lb = c1; lk = 1; }
-          if (c2 < lb) { lb = c2; lk = 2; }
-          if (c3 < lb) { lb = c3; lk = 3; }
-          if (ncd > 4 && !(hi && si_f0 == 0)) {        // |q| >= 16: rare
-            const uint4 row = si_rows[zero_run & 15];
-            const int rbase = hi * si_f0;
-#pragma nounroll   // unrolled, the candidate distortions get hoisted and computed for EVERY coefficient
-            for (int k = 4; k < ncd; k++) {
-              const int cb = row_byte(row, k + 1);
-              if (cb != 0) {
-                const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
-                const int delta = cand * dq - x;
-                float d = (float)(delta * delta) * lambda;
-                d = d * lti;
-                float cost = (float)(cb + (k + 1) + rbase) + d;
-                cost = cost + rhs;
-                if (cost < lb) { lb = cost; lk = k; }
-              }
-            }
-          }
-          // across predecessors the OLDER one wins ties, and this walk goes newest -> oldest
-          if (lb < best || (lb == best && bestp >= 0)) { best = lb; bestp = p; bestk = lk; }
-        }
+        // wave-uniform specialisation: when every lane quantizes this coefficient to +-1 there is a single
+        // candidate (the common case at mid/high frequencies), which halves the work per predecessor
+        if (__builtin_amdgcn_ballot_w64(ncd > 1) == 0ull)
+          trellis_walk<1, LDS_ROWS>(si_rows, rate_rows, e_aa, lane, live, nlive, azd_prev, i, x, dq, qval, ncd, lambda, lti,
+                                    si_f0, f0f, best, bestp, bestk);
+        else
+          trellis_walk<4, LDS_ROWS>(si_rows, rate_rows, e_aa, lane, live, nlive, azd_prev, i, x, dq, qval, ncd, lambda, lti,
+                                    si_f0, f0f, best, bestp, bestk);
         if (bestp >= 0) {
           if (nlive >= NE) return false;
           const int mag = (bestk < ncd - 1) ? (2 << bestk) - 1 : qval;
