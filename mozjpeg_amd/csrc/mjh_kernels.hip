@@ -720,6 +720,14 @@ __device__ __forceinline__ void trellis_walk(const uint4 *si_rows, const float4 
       const float r0 = LDS_ROWS ? rate_rows[zero_run & 15].x : rate_row(si_rows[zero_run & 15]).x;
       lb = (r0 + rb) + dist[0];
       lb = lb + rhs;
+    } else if (NC == 2) {
+      const float2 rr = LDS_ROWS ? *reinterpret_cast<const float2 *>(&rate_rows[zero_run & 15])
+                                 : make_float2(rate_row(si_rows[zero_run & 15]).x, rate_row(si_rows[zero_run & 15]).y);
+      float c0 = (rr.x + rb) + dist[0];
+      float c1 = (rr.y + rb) + dist[NC > 1 ? 1 : 0];
+      c0 = c0 + rhs; c1 = c1 + rhs;
+      lb = c0;
+      if (c1 < lb) { lb = c1; lk = 1; }
     } else {
       const float4 rr = LDS_ROWS ? rate_rows[zero_run & 15] : rate_row(si_rows[zero_run & 15]);
       float c0 = (rr.x + rb) + dist[0];
@@ -805,6 +813,9 @@ __device__ __forceinline__ bool trellis_ac_block(const uint4 *si_rows, const flo
         // candidate (the common case at mid/high frequencies), which halves the work per predecessor
         if (__builtin_amdgcn_ballot_w64(ncd > 1) == 0ull)
           trellis_walk<1, LDS_ROWS>(si_rows, rate_rows, e_aa, lane, live, nlive, azd_prev, i, x, dq, qval, ncd, lambda, lti,
+                                    si_f0, f0f, best, bestp, bestk);
+        else if (__builtin_amdgcn_ballot_w64(ncd > 2) == 0ull)
+          trellis_walk<2, LDS_ROWS>(si_rows, rate_rows, e_aa, lane, live, nlive, azd_prev, i, x, dq, qval, ncd, lambda, lti,
                                     si_f0, f0f, best, bestp, bestk);
         else
           trellis_walk<4, LDS_ROWS>(si_rows, rate_rows, e_aa, lane, live, nlive, azd_prev, i, x, dq, qval, ncd, lambda, lti,
