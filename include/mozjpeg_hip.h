@@ -145,9 +145,13 @@ int mjh_read_tap(mjh_encoder *e, int what, int image, int component, void *dst, 
 int mjh_component_geometry(const mjh_encoder *e, int c, int *width_in_blocks, int *height_in_blocks,
                            int *plane_width, int *plane_height);
 
-/* Per-kernel HIP-event timing of the last mjh_encode_* call when profiling is on
- * (names/ms arrays are owned by the encoder; *count entries). */
-int mjh_set_profiling(mjh_encoder *e, int on);
+/* Per-kernel HIP-event timing.  level 0 = off; 1 = every kernel of the schedule (the events serialise
+ * back-to-back launches, so whole-step throughput drops by some percent); 2 = only the dominant kernel
+ * (the AC trellis when trellis quantization is on, else the DCT/quantize kernel): two events per encode
+ * call.  Times accumulate over the mjh_encode_* calls (at most 256) since the level was set or since the
+ * last read; mjh_get_kernel_times synchronises, returns the AVERAGE milliseconds per call and starts a new
+ * accumulation (names/ms arrays are owned by the encoder; *count entries). */
+int mjh_set_profiling(mjh_encoder *e, int level);
 int mjh_get_kernel_times(mjh_encoder *e, const char *const **names, const float **ms, int *count);
 
 const char *mjh_last_error(void);

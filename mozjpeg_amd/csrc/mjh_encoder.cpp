@@ -268,8 +268,14 @@ struct mjh_encoder {
   uint8_t *d_prefix = nullptr, *d_sos = nullptr;
   int prefix_len = 0, sos_len = 0;
   int dht_slots[4] = { 0, 0, 0, 0 }, dht_ids[4] = { 0, 0, 0, 0 }, ndht = 0;
-  bool debug_taps = false, profiling = false;
-  // profiling
+  bool debug_taps = false;
+  // profiling: 0 off, 1 every kernel, 2 only the dominant kernel (prof_focus).  Events accumulate over the
+  // encode calls since the last read (prof_calls), every call records the same sequence of marks.
+  int profiling = 0;
+  const char *prof_focus = "trellis_ac";
+  int prof_calls = 0;
+  size_t prof_per_call = 0;
+  std::vector<hipEvent_t> side_events;   // 2 per call: the DC trellis on the side stream
   std::vector<std::string> prof_names;
   std::vector<const char *> prof_cnames;
   std::vector<float> prof_ms;
@@ -548,6 +554,7 @@ static void free_all(mjh_encoder *e)
   for (void *q : ptrs) if (q) (void)hipFree(q);
   if (e->h_pix) (void)hipHostFree(e->h_pix);
   for (hipEvent_t ev : e->prof_events) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : e->side_events) (void)hipEventDestroy(ev);
   if (e->copy_done) (void)hipEventDestroy(e->copy_done);
   for (hipEvent_t ev : { e->ev_fork, e->ev_join, e->ev_side0, e->ev_side1 }) if (ev) (void)hipEventDestroy(ev);
   if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
@@ -779,12 +786,23 @@ struct Prof {
   mjh_encoder *e;
   hipStream_t s;
   size_t next = 0;
+  bool first_call = true, enabled = false, prev_focus = false;
   void mark(const char *name)
   {
-    if (!e->profiling) return;
+    if (!enabled) return;
+    const bool focus = name && strcmp(name, e->prof_focus) == 0;
+    const bool closing = prev_focus && !focus;          // the mark that ends the focus kernel's interval
+    prev_focus = focus;
+    if (e->profiling == 2 && !focus && !closing) return;
     if (next >= e->prof_events.size()) { hipEvent_t ev; (void)hipEventCreate(&ev); e->prof_events.push_back(ev); }
     (void)hipEventRecord(e->prof_events[next++], s);
-    if (name) e->prof_names.push_back(name);
+    if (first_call && name && !(e->profiling == 2 && !focus)) e->prof_names.push_back(name);
+  }
+  void finish()
+  {
+    if (!enabled) return;
+    if (first_call) e->prof_per_call = next;
+    e->prof_calls++;
   }
 };
 
@@ -795,8 +813,13 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   const int spi = e->spi;
   e->sizes_valid = false;
   e->last_n = n;
-  e->prof_names.clear();
   Prof pr{ e, s };
+  if (e->profiling && e->prof_calls < 256) {
+    pr.enabled = true;
+    pr.first_call = e->prof_calls == 0;
+    if (pr.first_call) e->prof_names.clear();
+    pr.next = (size_t)e->prof_calls * e->prof_per_call;
+  }
   HIPCHK(hipMemcpyAsync(e->d_tabs, e->d_tabs_init, (size_t)n * spi * sizeof(MjhHuffTable), hipMemcpyDeviceToDevice, s));
   pr.mark("color");
   mjh_launch_color(C, d_pixels, row_pitch, image_stride, e->d_planes, n, s);
@@ -844,9 +867,12 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     if (p.trellis_quant_dc) {
       HIPCHK(hipEventRecord(e->ev_fork, s));
       HIPCHK(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
-      if (e->profiling) HIPCHK(hipEventRecord(e->ev_side0, e->side_stream));
+      if (pr.enabled && e->profiling == 1) {
+        while (e->side_events.size() < 2 * (size_t)(e->prof_calls + 1)) { hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); e->side_events.push_back(ev); }
+        HIPCHK(hipEventRecord(e->side_events[2 * e->prof_calls], e->side_stream));
+      }
       mjh_launch_trellis_dc(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_dc, e->d_lambda, e->d_back, n, e->side_stream);
-      if (e->profiling) { HIPCHK(hipEventRecord(e->ev_side1, e->side_stream)); e->side_timed = true; }
+      if (pr.enabled && e->profiling == 1) { HIPCHK(hipEventRecord(e->side_events[2 * e->prof_calls + 1], e->side_stream)); e->side_timed = true; }
       HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
     }
     pr.mark("trellis_ac");
@@ -872,6 +898,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     pr.mark("prog_concat");
     mjh_launch_prog_concat(e->d_prog_ctl, e->d_prefix, e->file_hdr_len, e->d_outpool, e->outpool_bytes, e->d_out, e->out_stride, e->d_sizes, n, s);
     pr.mark(nullptr);
+    pr.finish();
     HIPCHK(hipGetLastError());
     return MJH_OK;
   }
@@ -895,6 +922,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   mjh_launch_stuff(e->d_stream, e->stream_words, e->d_totals, e->d_ffsums, e->ff_chunks, e->d_fftotals, e->d_out, e->out_stride,
                    e->d_meta, e->d_sizes, e->d_mpos, e->nseg, n, s);
   pr.mark(nullptr);
+  pr.finish();
   HIPCHK(hipGetLastError());
   return MJH_OK;
 }
@@ -984,7 +1012,15 @@ extern "C" int mjh_get_output_device(mjh_encoder *e, void **d_base, size_t *stri
 }
 
 extern "C" int mjh_set_debug_taps(mjh_encoder *e, int on) { if (!e) return fail(MJH_EINVAL, "null encoder"); e->debug_taps = on != 0; return MJH_OK; }
-extern "C" int mjh_set_profiling(mjh_encoder *e, int on) { if (!e) return fail(MJH_EINVAL, "null encoder"); e->profiling = on != 0; return MJH_OK; }
+extern "C" int mjh_set_profiling(mjh_encoder *e, int on)
+{
+  if (!e) return fail(MJH_EINVAL, "null encoder");
+  if (on < 0 || on > 2) return fail(MJH_EINVAL, "profiling level must be 0, 1 or 2");
+  e->profiling = on;
+  e->prof_calls = 0;
+  e->prof_focus = e->p.trellis_quant && !e->progressive ? "trellis_ac" : "dct_quant";
+  return MJH_OK;
+}
 
 extern "C" int mjh_get_kernel_times(mjh_encoder *e, const char *const **names, const float **ms, int *count)
 {
@@ -992,19 +1028,30 @@ extern "C" int mjh_get_kernel_times(mjh_encoder *e, const char *const **names, c
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipDeviceSynchronize());
   const size_t n = e->prof_names.size();
+  const int calls = e->prof_calls;
   e->prof_ms.assign(n, 0.f);
   e->prof_cnames.resize(n);
-  for (size_t i = 0; i < n; i++) {
-    e->prof_cnames[i] = e->prof_names[i].c_str();
-    if (i + 1 < e->prof_events.size()) HIPCHK(hipEventElapsedTime(&e->prof_ms[i], e->prof_events[i], e->prof_events[i + 1]));
-  }
-  if (e->side_timed) {   // the DC trellis runs concurrently on the side stream: its own event pair
-    float t = 0.f;
-    HIPCHK(hipEventElapsedTime(&t, e->ev_side0, e->ev_side1));
+  for (size_t i = 0; i < n; i++) e->prof_cnames[i] = e->prof_names[i].c_str();
+  for (int c = 0; c < calls; c++)
+    for (size_t i = 0; i < n; i++) {
+      const size_t k = (size_t)c * e->prof_per_call + i;
+      if (k + 1 >= e->prof_events.size()) continue;
+      float t = 0.f;
+      HIPCHK(hipEventElapsedTime(&t, e->prof_events[k], e->prof_events[k + 1]));
+      e->prof_ms[i] += t / (float)calls;
+    }
+  if (e->side_timed && e->profiling == 1 && calls > 0) {   // the DC trellis runs concurrently on the side stream: its own event pairs
+    float sum = 0.f;
+    for (int c = 0; c < calls && 2 * (size_t)c + 1 < e->side_events.size(); c++) {
+      float t = 0.f;
+      HIPCHK(hipEventElapsedTime(&t, e->side_events[2 * c], e->side_events[2 * c + 1]));
+      sum += t;
+    }
     static const char *kDc = "trellis_dc(side stream, overlaps trellis_ac)";
     e->prof_cnames.push_back(kDc);
-    e->prof_ms.push_back(t);
+    e->prof_ms.push_back(sum / (float)calls);
   }
+  e->prof_calls = 0;   // the next encode call starts a new accumulation
   if (names) *names = e->prof_cnames.data();
   if (ms) *ms = e->prof_ms.data();
   *count = (int)e->prof_cnames.size();
