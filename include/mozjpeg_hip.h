@@ -120,6 +120,22 @@ int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t row_pitch, si
                       int n, void *stream);
 /* Same with host pixels: staged through pinned memory and a side stream (H2D), then encoded. */
 int mjh_encode_host(mjh_encoder *e, const void *pixels, size_t row_pitch, size_t image_stride, int n);
+/* Component planes instead of pixels: jpeg_write_raw_data (jcapistd.c:145) for whole images, the entry
+ * tj3CompressFromYUVPlanes8 (turbojpeg.c:1222) uses.  Colour conversion and downsampling are skipped; the
+ * encoder must have been created with the sampling factors the planes were made for (input_components and
+ * the pixel layout fields are ignored by these calls).  Plane c of image i starts at planes[c] + i *
+ * image_stride[c] (image_stride may be NULL for n == 1), its rows are row_pitch[c] BYTES apart and
+ * plane_width[c] x plane_height[c] samples of it are valid.  The encoder reads width_in_blocks*8 x
+ * height_in_blocks*8 samples per component (mjh_component_geometry); where the plane is smaller its last
+ * sample / row is replicated, which is exactly what tj3CompressFromYUVPlanes8 does before it calls
+ * jpeg_write_raw_data (turbojpeg.c:1295-1316), so TurboJPEG-layout planes (tj3YUVPlaneWidth/Height) can be
+ * passed as they are. */
+int mjh_encode_planes_device(mjh_encoder *e, const void *const d_planes[MJH_MAX_COMPS], const size_t row_pitch[MJH_MAX_COMPS],
+                             const size_t image_stride[MJH_MAX_COMPS], const int plane_width[MJH_MAX_COMPS],
+                             const int plane_height[MJH_MAX_COMPS], int n, void *stream);
+int mjh_encode_planes_host(mjh_encoder *e, const void *const planes[MJH_MAX_COMPS], const size_t row_pitch[MJH_MAX_COMPS],
+                           const size_t image_stride[MJH_MAX_COMPS], const int plane_width[MJH_MAX_COMPS],
+                           const int plane_height[MJH_MAX_COMPS], int n);
 int mjh_encoder_sync(mjh_encoder *e);
 
 /* Size in bytes of JPEG i of the last batch (synchronises). */

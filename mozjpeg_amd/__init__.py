@@ -67,6 +67,8 @@ def lib():
         L.mjh_encoder_destroy.restype = None
         L.mjh_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
         L.mjh_encode_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+        L.mjh_encode_planes_device.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
+        L.mjh_encode_planes_host.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int]
         L.mjh_encoder_sync.argtypes = [C.c_void_p]
         L.mjh_get_jpeg_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
         L.mjh_get_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -167,6 +169,34 @@ class Encoder:
         assert t.is_cuda and t.is_contiguous() and t.dim() == 4
         es = t.element_size()   # 1 for uint8, 2 for the 12-bit path (int16/uint16 storage)
         self.encode_device_ptr(t.data_ptr(), t.stride(1) * es, t.stride(0) * es, t.shape[0], stream)
+
+    # component planes in (jpeg_write_raw_data / tj3CompressFromYUVPlanes8): no colour conversion
+    @staticmethod
+    def _plane_args(ptrs, pitches, strides, widths, heights):
+        k = len(ptrs)
+        pad = lambda v, z: list(v) + [z] * (4 - k)
+        return ((C.c_void_p * 4)(*pad(ptrs, None)), (C.c_size_t * 4)(*pad(pitches, 0)), (C.c_size_t * 4)(*pad(strides, 0)),
+                (C.c_int * 4)(*pad(widths, 0)), (C.c_int * 4)(*pad(heights, 0)))
+
+    def encode_planes_host(self, planes):
+        """planes: one array per component, [n, h_c, w_c] or [h_c, w_c] (uint8; uint16 for 12-bit).  Returns list of bytes."""
+        dt = np.uint16 if self.params.data_precision == 12 else np.uint8
+        arrs = [np.ascontiguousarray(a if a.ndim == 3 else a[None], dtype=dt) for a in planes]
+        n = arrs[0].shape[0]
+        args = self._plane_args([a.ctypes.data for a in arrs], [a.strides[1] for a in arrs], [a.strides[0] for a in arrs],
+                                [a.shape[2] for a in arrs], [a.shape[1] for a in arrs])
+        _chk(lib().mjh_encode_planes_host(self._h, *args, n))
+        return [self.get_jpeg(i) for i in range(n)]
+
+    def encode_planes_tensors(self, planes, stream=None):
+        """planes: one CUDA tensor [n, h_c, w_c] per component (contiguous rows).  Asynchronous."""
+        for t in planes:
+            assert t.is_cuda and t.dim() == 3 and t.stride(2) == 1
+        es = planes[0].element_size()
+        n = planes[0].shape[0]
+        args = self._plane_args([t.data_ptr() for t in planes], [t.stride(1) * es for t in planes],
+                                [t.stride(0) * es for t in planes], [t.shape[2] for t in planes], [t.shape[1] for t in planes])
+        _chk(lib().mjh_encode_planes_device(self._h, *args, n, stream))
 
     def sync(self):
         _chk(lib().mjh_encoder_sync(self._h))

@@ -21,6 +21,9 @@ typedef struct shim_state {
   mjh_params p;
   unsigned char *pixels;     /* staged scanlines, image_width*input_components per row */
   size_t row_bytes;
+  int raw;                   /* raw_data_in: component planes arrive through jpeg_write_raw_data */
+  unsigned char *planes[MAX_COMPONENTS];   /* staged planes, width_in_blocks*8 x height_in_blocks*8 samples */
+  size_t plane_pitch[MAX_COMPONENTS];
   int header_bytes;          /* SOI (+APP0) already written by jpeg_start_compress */
   struct shim_state *next;
 } shim_state;
@@ -83,7 +86,6 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p)
   if (cinfo->data_precision != 8 && cinfo->data_precision != 12) return "data_precision other than 8 or 12";
   p->data_precision = cinfo->data_precision;
   if (cinfo->arith_code) return "arithmetic coding";
-  if (cinfo->raw_data_in) return "raw_data_in";
   if (cinfo->smoothing_factor) return "input smoothing";
   if (cinfo->dct_method != JDCT_ISLOW) return "dct_method other than JDCT_ISLOW";
   if (cinfo->write_Adobe_marker) return "Adobe marker";
@@ -98,9 +100,12 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p)
     case JCS_EXT_XBGR: case JCS_EXT_ABGR: ps = 4; ro = 3; go = 2; bo = 1; break;
     case JCS_EXT_XRGB: case JCS_EXT_ARGB: ps = 4; ro = 1; go = 2; bo = 3; break;
     case JCS_GRAYSCALE: ps = 1; break;
-    default: return "input colour space (RGB family / grayscale only)";
+    default:
+      if (!cinfo->raw_data_in) return "input colour space (RGB family / grayscale only)";
+      ps = cinfo->input_components == 1 ? 1 : 3;   /* raw data: the input colour space is never looked at */
+      break;
     }
-    if (cinfo->input_components != ps) ERREXIT(cinfo, JERR_BAD_IN_COLORSPACE);
+    if (!cinfo->raw_data_in && cinfo->input_components != ps) ERREXIT(cinfo, JERR_BAD_IN_COLORSPACE);
     if (ps == 1) p->input_components = 1;
     else { p->input_components = 3; p->input_pixel_size = ps; p->rgb_offset[0] = ro; p->rgb_offset[1] = go; p->rgb_offset[2] = bo; }
   }
@@ -211,14 +216,49 @@ void jpeg_start_compress(j_compress_ptr cinfo, boolean write_all_tables)
     s->header_bytes += 18;
   }
   s->cinfo = cinfo;
+  s->raw = cinfo->raw_data_in ? 1 : 0;
+  {
+    /* the geometry fields callers read back after jpeg_start_compress (initial_setup jcmaster.c:237-259);
+     * tj3CompressFromYUVPlanes8 sizes its row buffers from width_in_blocks / max_*_samp_factor */
+    int ci;
+    jpeg_component_info *c;
+    cinfo->max_h_samp_factor = cinfo->max_v_samp_factor = 1;
+    for (ci = 0, c = cinfo->comp_info; ci < cinfo->num_components; ci++, c++) {
+      if (c->h_samp_factor > cinfo->max_h_samp_factor) cinfo->max_h_samp_factor = c->h_samp_factor;
+      if (c->v_samp_factor > cinfo->max_v_samp_factor) cinfo->max_v_samp_factor = c->v_samp_factor;
+    }
+    for (ci = 0, c = cinfo->comp_info; ci < cinfo->num_components; ci++, c++) {
+      const long hd = (long)cinfo->max_h_samp_factor * DCTSIZE, vd = (long)cinfo->max_v_samp_factor * DCTSIZE;
+      c->component_index = ci;
+      c->DCT_scaled_size = DCTSIZE;
+      c->width_in_blocks = (JDIMENSION)(((long)cinfo->image_width * c->h_samp_factor + hd - 1) / hd);
+      c->height_in_blocks = (JDIMENSION)(((long)cinfo->image_height * c->v_samp_factor + vd - 1) / vd);
+      c->downsampled_width = (JDIMENSION)(((long)cinfo->image_width * c->h_samp_factor + cinfo->max_h_samp_factor - 1) / cinfo->max_h_samp_factor);
+      c->downsampled_height = (JDIMENSION)(((long)cinfo->image_height * c->v_samp_factor + cinfo->max_v_samp_factor - 1) / cinfo->max_v_samp_factor);
+      c->component_needed = TRUE;
+    }
+    cinfo->total_iMCU_rows = (JDIMENSION)(((long)cinfo->image_height + cinfo->max_v_samp_factor * DCTSIZE - 1) /
+                                          ((long)cinfo->max_v_samp_factor * DCTSIZE));
+  }
   s->row_bytes = (size_t)cinfo->image_width * cinfo->input_components * (cinfo->data_precision == 12 ? 2 : 1);
-  s->pixels = (unsigned char *)malloc(s->row_bytes * cinfo->image_height);
-  if (!s->pixels) { free(s); ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0); }
+  if (s->raw) {
+    int ci, bad = 0;
+    for (ci = 0; ci < cinfo->num_components; ci++) {
+      jpeg_component_info *c = &cinfo->comp_info[ci];
+      s->plane_pitch[ci] = (size_t)c->width_in_blocks * DCTSIZE * (cinfo->data_precision == 12 ? 2 : 1);
+      s->planes[ci] = (unsigned char *)malloc(s->plane_pitch[ci] * c->height_in_blocks * DCTSIZE);
+      if (!s->planes[ci]) bad = 1;
+    }
+    if (bad) { for (ci = 0; ci < cinfo->num_components; ci++) free(s->planes[ci]); free(s); ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0); }
+  } else {
+    s->pixels = (unsigned char *)malloc(s->row_bytes * cinfo->image_height);
+    if (!s->pixels) { free(s); ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0); }
+  }
   pthread_mutex_lock(&g_lock);
   s->next = g_states; g_states = s;
   pthread_mutex_unlock(&g_lock);
   cinfo->next_scanline = 0;
-  cinfo->global_state = CSTATE_SCANNING;
+  cinfo->global_state = s->raw ? CSTATE_RAW_OK : CSTATE_SCANNING;   /* jcapistd.c:62 */
 }
 
 static JDIMENSION write_rows(j_compress_ptr cinfo, void **scanlines, JDIMENSION num_lines, int precision, const char *name)
@@ -257,6 +297,80 @@ JDIMENSION jpeg12_write_scanlines(j_compress_ptr cinfo, J12SAMPARRAY scanlines, 
   return write_rows(cinfo, (void **)scanlines, num_lines, 12, "jpeg12_write_scanlines");
 }
 
+/* jpeg_write_raw_data jcapistd.c:145-199: exactly one iMCU row of caller-made component planes per call
+ * (data[ci] = v_samp_factor*8 row pointers of width_in_blocks*8 samples); the rows are staged and the whole
+ * image goes to the GPU at jpeg_finish_compress through mjh_encode_planes_host. */
+typedef JDIMENSION (*raw_fn)(j_compress_ptr, JSAMPIMAGE, JDIMENSION);
+
+static JDIMENSION write_raw(j_compress_ptr cinfo, void ***data, JDIMENSION num_lines, int precision, const char *name)
+{
+  shim_state *s = find_state(cinfo, 0);
+  JDIMENSION lines_per_iMCU_row, imcu;
+  int ci;
+  if (!s) {
+    raw_fn next = (raw_fn)dlsym(RTLD_NEXT, name);
+    if (next) return next(cinfo, (JSAMPIMAGE)data, num_lines);
+    ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
+  }
+  if (cinfo->data_precision != precision) ERREXIT1(cinfo, JERR_BAD_PRECISION, cinfo->data_precision);
+  if (cinfo->global_state != CSTATE_RAW_OK) ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
+  if (cinfo->next_scanline >= cinfo->image_height) { WARNMS(cinfo, JWRN_TOO_MUCH_DATA); return 0; }
+  if (cinfo->progress != NULL) {
+    cinfo->progress->pass_counter = (long)cinfo->next_scanline;
+    cinfo->progress->pass_limit = (long)cinfo->image_height;
+    (*cinfo->progress->progress_monitor) ((j_common_ptr)cinfo);
+  }
+  lines_per_iMCU_row = (JDIMENSION)cinfo->max_v_samp_factor * DCTSIZE;
+  if (num_lines < lines_per_iMCU_row) ERREXIT(cinfo, JERR_BUFFER_SIZE);
+  imcu = cinfo->next_scanline / lines_per_iMCU_row;
+  for (ci = 0; ci < cinfo->num_components; ci++) {
+    jpeg_component_info *c = &cinfo->comp_info[ci];
+    const JDIMENSION rows = (JDIMENSION)c->v_samp_factor * DCTSIZE, plane_rows = c->height_in_blocks * DCTSIZE;
+    JDIMENSION r;
+    for (r = 0; r < rows; r++) {
+      const JDIMENSION dr = imcu * rows + r;
+      if (dr >= plane_rows) break;      /* rows of dummy blocks below the image are never read (jccoefct.c:327-345) */
+      memcpy(s->planes[ci] + (size_t)dr * s->plane_pitch[ci], data[ci][r], s->plane_pitch[ci]);
+    }
+  }
+  cinfo->next_scanline += lines_per_iMCU_row;
+  return lines_per_iMCU_row;
+}
+
+JDIMENSION jpeg_write_raw_data(j_compress_ptr cinfo, JSAMPIMAGE data, JDIMENSION num_lines)
+{
+  return write_raw(cinfo, (void ***)data, num_lines, 8, "jpeg_write_raw_data");
+}
+
+JDIMENSION jpeg12_write_raw_data(j_compress_ptr cinfo, J12SAMPIMAGE data, JDIMENSION num_lines)
+{
+  return write_raw(cinfo, (void ***)data, num_lines, 12, "jpeg12_write_raw_data");
+}
+
+static void free_state(shim_state *s)
+{
+  int ci;
+  for (ci = 0; ci < MAX_COMPONENTS; ci++) free(s->planes[ci]);
+  free(s->pixels);
+  free(s);
+}
+
+static int encode_staged(j_compress_ptr cinfo, shim_state *s)
+{
+  if (s->raw) {
+    const void *pl[MJH_MAX_COMPS] = { 0, 0, 0, 0 };
+    size_t pitch[MJH_MAX_COMPS] = { 0, 0, 0, 0 };
+    int pw[MJH_MAX_COMPS] = { 0, 0, 0, 0 }, ph[MJH_MAX_COMPS] = { 0, 0, 0, 0 }, ci;
+    for (ci = 0; ci < cinfo->num_components && ci < MJH_MAX_COMPS; ci++) {
+      pl[ci] = s->planes[ci]; pitch[ci] = s->plane_pitch[ci];
+      pw[ci] = (int)cinfo->comp_info[ci].width_in_blocks * DCTSIZE;
+      ph[ci] = (int)cinfo->comp_info[ci].height_in_blocks * DCTSIZE;
+    }
+    return mjh_encode_planes_host(t_enc, pl, pitch, NULL, pw, ph, 1);
+  }
+  return mjh_encode_host(t_enc, s->pixels, s->row_bytes, s->row_bytes * cinfo->image_height, 1);
+}
+
 void jpeg_finish_compress(j_compress_ptr cinfo)
 {
   shim_state *s = find_state(cinfo, 0);
@@ -267,24 +381,23 @@ void jpeg_finish_compress(j_compress_ptr cinfo)
     if (next) { next(cinfo); return; }
     ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
   }
-  if (cinfo->global_state != CSTATE_SCANNING) ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
+  if (cinfo->global_state != CSTATE_SCANNING && cinfo->global_state != CSTATE_RAW_OK) ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
   if (cinfo->next_scanline < cinfo->image_height) ERREXIT(cinfo, JERR_TOO_LITTLE_DATA);
-  if (mjh_encode_host(t_enc, s->pixels, s->row_bytes, s->row_bytes * cinfo->image_height, 1) != MJH_OK ||
-      mjh_get_jpeg_size(t_enc, 0, &n) != MJH_OK) {
+  if (encode_staged(cinfo, s) != MJH_OK || mjh_get_jpeg_size(t_enc, 0, &n) != MJH_OK) {
     fprintf(stderr, "mozjpeg_hip: %s\n", mjh_last_error());
-    find_state(cinfo, 1); free(s->pixels); free(s);
+    find_state(cinfo, 1); free_state(s);
     ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0);
   }
   buf = (unsigned char *)malloc(n);
   if (!buf || mjh_get_jpeg(t_enc, 0, buf, n, &n) != MJH_OK) {
     fprintf(stderr, "mozjpeg_hip: %s\n", mjh_last_error());
-    find_state(cinfo, 1); free(buf); free(s->pixels); free(s);
+    find_state(cinfo, 1); free(buf); free_state(s);
     ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0);
   }
   find_state(cinfo, 1);
   /* the device wrote a complete file; SOI(+APP0) went out in jpeg_start_compress already */
   emit_bytes(cinfo, buf + s->header_bytes, n - (size_t)s->header_bytes);
-  free(buf); free(s->pixels); free(s);
+  free(buf); free_state(s);
   (*cinfo->dest->term_destination) (cinfo);
   jpeg_abort((j_common_ptr)cinfo);   /* releases JPOOL_IMAGE, global_state = CSTATE_START (jcapimin.c:228) */
 }

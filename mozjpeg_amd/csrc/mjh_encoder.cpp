@@ -231,6 +231,7 @@ struct mjh_encoder {
   // device buffers
   uint8_t *d_pix = nullptr;        // staging for mjh_encode_host
   uint8_t *h_pix = nullptr;        // pinned host staging
+  uint8_t *d_plin = nullptr, *h_plin = nullptr;   // the same for mjh_encode_planes_host
   size_t pix_image_bytes = 0;
   uint8_t *d_planes = nullptr;
   int16_t *d_uq = nullptr, *d_q = nullptr, *d_q0 = nullptr;
@@ -548,11 +549,12 @@ static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *ptrs[] = { e->d_pix, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pix, e->d_plin, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
   if (e->h_pix) (void)hipHostFree(e->h_pix);
+  if (e->h_plin) (void)hipHostFree(e->h_plin);
   for (hipEvent_t ev : e->prof_events) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : e->side_events) (void)hipEventDestroy(ev);
   if (e->copy_done) (void)hipEventDestroy(e->copy_done);
@@ -806,7 +808,8 @@ struct Prof {
   }
 };
 
-static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, size_t image_stride, int n, hipStream_t s)
+static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, size_t image_stride, int n, hipStream_t s,
+                        const MjhPlaneSrc *plane_src = nullptr)
 {
   const MjhConst &C = e->C;
   const mjh_params &p = e->p;
@@ -821,8 +824,13 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     pr.next = (size_t)e->prof_calls * e->prof_per_call;
   }
   HIPCHK(hipMemcpyAsync(e->d_tabs, e->d_tabs_init, (size_t)n * spi * sizeof(MjhHuffTable), hipMemcpyDeviceToDevice, s));
-  pr.mark("color");
-  mjh_launch_color(C, d_pixels, row_pitch, image_stride, e->d_planes, n, s);
+  if (plane_src) {   // jpeg_write_raw_data: the caller's component planes replace colour conversion + downsampling
+    pr.mark("import_planes");
+    mjh_launch_import_planes(C, *plane_src, e->d_planes, n, s);
+  } else {
+    pr.mark("color");
+    mjh_launch_color(C, d_pixels, row_pitch, image_stride, e->d_planes, n, s);
+  }
   pr.mark("dct_quant");
   mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, n, s);
 
@@ -939,6 +947,7 @@ extern "C" int mjh_encode_host(mjh_encoder *e, const void *pixels, size_t row_pi
   if (!e || !pixels || n < 1 || n > e->max_batch) return fail(MJH_EINVAL, "bad arguments");
   HIPCHK(hipSetDevice(e->device));
   const size_t row_bytes = (size_t)e->C.W * e->C.px_size * (e->C.precision == 12 ? 2 : 1);
+  HIPCHK(hipStreamSynchronize(e->stream));   // the staging buffers may still feed the previous batch
   if (!e->d_pix) {
     HIPCHK(hipMalloc((void **)&e->d_pix, (size_t)e->max_batch * e->pix_image_bytes));
     HIPCHK(hipHostMalloc((void **)&e->h_pix, (size_t)e->max_batch * e->pix_image_bytes, hipHostMallocDefault));
@@ -954,6 +963,74 @@ extern "C" int mjh_encode_host(mjh_encoder *e, const void *pixels, size_t row_pi
   HIPCHK(hipEventRecord(e->copy_done, e->copy_stream));
   HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done, 0));
   return run_pipeline(e, e->d_pix, row_bytes, e->pix_image_bytes, n, e->stream);
+}
+
+static int check_plane_args(mjh_encoder *e, const void *const planes[], const size_t row_pitch[], const int plane_width[],
+                            const int plane_height[], int n)
+{
+  if (!e || !planes || !row_pitch || !plane_width || !plane_height || n < 1 || n > e->max_batch)
+    return fail(MJH_EINVAL, "bad arguments (n=%d, max_batch=%d)", n, e ? e->max_batch : 0);
+  const size_t ss = e->C.precision == 12 ? 2 : 1;
+  for (int c = 0; c < e->C.ncomp; c++)
+    if (!planes[c] || plane_width[c] < 1 || plane_height[c] < 1 || row_pitch[c] < (size_t)plane_width[c] * ss)
+      return fail(MJH_EINVAL, "bad plane %d (pointer, size %dx%d or pitch %zu)", c, plane_width[c], plane_height[c], row_pitch[c]);
+  return MJH_OK;
+}
+
+extern "C" int mjh_encode_planes_device(mjh_encoder *e, const void *const d_planes[], const size_t row_pitch[],
+                                        const size_t image_stride[], const int plane_width[], const int plane_height[],
+                                        int n, void *stream)
+{
+  int rc = check_plane_args(e, d_planes, row_pitch, plane_width, plane_height, n);
+  if (rc) return rc;
+  if (n > 1 && !image_stride) return fail(MJH_EINVAL, "image_stride is required for n > 1");
+  HIPCHK(hipSetDevice(e->device));
+  MjhPlaneSrc ps;
+  memset(&ps, 0, sizeof(ps));
+  for (int c = 0; c < e->C.ncomp; c++) {
+    ps.base[c] = d_planes[c]; ps.pitch[c] = (long long)row_pitch[c]; ps.stride[c] = image_stride ? (long long)image_stride[c] : 0;
+    ps.w[c] = plane_width[c]; ps.h[c] = plane_height[c];
+  }
+  return run_pipeline(e, nullptr, 0, 0, n, stream ? (hipStream_t)stream : e->stream, &ps);
+}
+
+extern "C" int mjh_encode_planes_host(mjh_encoder *e, const void *const planes[], const size_t row_pitch[],
+                                      const size_t image_stride[], const int plane_width[], const int plane_height[], int n)
+{
+  int rc = check_plane_args(e, planes, row_pitch, plane_width, plane_height, n);
+  if (rc) return rc;
+  if (n > 1 && !image_stride) return fail(MJH_EINVAL, "image_stride is required for n > 1");
+  HIPCHK(hipSetDevice(e->device));
+  const size_t ss = e->C.precision == 12 ? 2 : 1;
+  // only the part of each plane the encoder reads (<= width_in_blocks*8 x height_in_blocks*8) is staged, tightly packed
+  MjhPlaneSrc ps;
+  memset(&ps, 0, sizeof(ps));
+  size_t off[MJH_MAXC], per_image = 0;
+  for (int c = 0; c < e->C.ncomp; c++) {
+    ps.w[c] = plane_width[c] < e->C.c[c].pw ? plane_width[c] : e->C.c[c].pw;
+    ps.h[c] = plane_height[c] < e->C.c[c].ph ? plane_height[c] : e->C.c[c].ph;
+    ps.pitch[c] = (long long)((size_t)ps.w[c] * ss);
+    off[c] = per_image;
+    per_image += ((size_t)ps.w[c] * ps.h[c] * ss + 15) & ~(size_t)15;
+  }
+  const size_t cap = (size_t)e->C.planes_per_image * ss + 16 * MJH_MAXC;   // >= per_image by construction
+  HIPCHK(hipStreamSynchronize(e->stream));   // the staging buffers may still feed the previous batch
+  if (!e->d_plin) {
+    HIPCHK(hipMalloc((void **)&e->d_plin, (size_t)e->max_batch * cap));
+    HIPCHK(hipHostMalloc((void **)&e->h_plin, (size_t)e->max_batch * cap, hipHostMallocDefault));
+  }
+  for (int i = 0; i < n; i++) {
+    for (int c = 0; c < e->C.ncomp; c++) {
+      const uint8_t *src = (const uint8_t *)planes[c] + (image_stride ? (size_t)i * image_stride[c] : 0);
+      uint8_t *dst = e->h_plin + (size_t)i * per_image + off[c];
+      for (int y = 0; y < ps.h[c]; y++) memcpy(dst + (size_t)y * ps.pitch[c], src + (size_t)y * row_pitch[c], (size_t)ps.pitch[c]);
+    }
+    HIPCHK(hipMemcpyAsync(e->d_plin + (size_t)i * per_image, e->h_plin + (size_t)i * per_image, per_image, hipMemcpyHostToDevice, e->copy_stream));
+  }
+  HIPCHK(hipEventRecord(e->copy_done, e->copy_stream));
+  HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done, 0));
+  for (int c = 0; c < e->C.ncomp; c++) { ps.base[c] = e->d_plin + off[c]; ps.stride[c] = (long long)per_image; }
+  return run_pipeline(e, nullptr, 0, 0, n, e->stream, &ps);
 }
 
 extern "C" int mjh_encoder_sync(mjh_encoder *e)

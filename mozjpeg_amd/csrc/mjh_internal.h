@@ -61,6 +61,14 @@ struct MjhConst {
   MjhComp c[MJH_MAXC];
 };
 
+// caller-supplied component planes (jpeg_write_raw_data path): one entry per component
+struct MjhPlaneSrc {
+  const void *base[MJH_MAXC];        // plane of image 0
+  long long pitch[MJH_MAXC];         // bytes between rows
+  long long stride[MJH_MAXC];        // bytes between images
+  int w[MJH_MAXC], h[MJH_MAXC];      // valid samples; beyond them the last sample / row is replicated
+};
+
 // per-table-slot constant data uploaded once per encoder
 struct MjhQuant {
   uint16_t q[4][64];        // zig-zag order quantizer step

@@ -207,6 +207,31 @@ k_color_vec(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, size_
 }
 
 // =============================================================================================
+// K1b  plane import: jpeg_write_raw_data jcapistd.c:145-199 hands caller-made component
+// planes straight to the coefficient controller, which reads width_in_blocks*8 samples of
+// height_in_blocks*8 rows (compress_first_pass jccoefct.c:262-353).  Callers with smaller planes
+// replicate the last sample / row first (tj3CompressFromYUVPlanes8 turbojpeg.c:1295-1316): the two
+// clamps.  One lane = 4 consecutive samples of one plane row.
+// =============================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_import_planes(MjhConst C, MjhPlaneSrc S, T *__restrict__ planes)
+{
+  const int comp = blockIdx.z % C.ncomp, img = blockIdx.z / C.ncomp;
+  const MjhComp cc = C.c[comp];
+  const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4, r = blockIdx.y;
+  if (r >= cc.ph || c0 >= cc.pw) return;        // pw is a multiple of 8, so the 4 samples are all inside
+  const int sr = min(r, S.h[comp] - 1);
+  const T *src = reinterpret_cast<const T *>(reinterpret_cast<const uint8_t *>(S.base[comp]) + (size_t)img * S.stride[comp] +
+                                            (size_t)sr * S.pitch[comp]);
+  T v[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) v[j] = src[min(c0 + j, S.w[comp] - 1)];
+  T *dst = planes + (size_t)img * C.planes_per_image + cc.plane_off + (size_t)r * cc.pw + c0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) dst[j] = v[j];
+}
+// =============================================================================================
 // K2  convsamp + overshoot deringing + islow FDCT + quantize   (rows a4-a8)
 //   convsamp jcdctmgr.c:576, preprocess_deringing :416-498 (catmull_rom :387), jpeg_fdct_islow
 //   jfdctint.c:142-286, quantize jcdctmgr.c:611 (== sign(x)*((|x|+d/2)/d), d = 8q), post-clamp
@@ -1505,6 +1530,15 @@ k_stuff_write(const unsigned *__restrict__ stream, size_t stream_words_per_image
 #include "mjh_launch.h"
 
 static inline dim3 g3(unsigned x, unsigned y, unsigned z) { return dim3(x, y, z); }
+
+void mjh_launch_import_planes(const MjhConst &C, const MjhPlaneSrc &S, void *planes, int n, hipStream_t s)
+{
+  int pw = 0, ph = 0;
+  for (int i = 0; i < C.ncomp; i++) { pw = C.c[i].pw > pw ? C.c[i].pw : pw; ph = C.c[i].ph > ph ? C.c[i].ph : ph; }
+  dim3 grid((pw / 4 + 255) / 256, ph, n * C.ncomp);
+  if (C.precision == 12) hipLaunchKernelGGL((k_import_planes<uint16_t>), grid, dim3(256), 0, s, C, S, (uint16_t *)planes);
+  else hipLaunchKernelGGL((k_import_planes<uint8_t>), grid, dim3(256), 0, s, C, S, (uint8_t *)planes);
+}
 
 void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size_t img_stride, void *planes, int n, hipStream_t s)
 {

@@ -1343,8 +1343,37 @@ static void bb_append(bytebuf *dst, const bytebuf *src)
   for (i = 0; i < src->len; i++) bb_put(dst, src->buf[i]);
 }
 
-size_t mjo_encode(const mjo_params *p_in, const uint8_t *pixels, size_t row_stride,
-                  uint8_t *out, size_t cap, mjo_taps *taps)
+/* The whole encode from the point where the sample planes exist.  `fill` produces them: colour
+ * conversion + downsampling of pixels (jpeg_write_scanlines) or a copy of caller-supplied component
+ * planes (jpeg_write_raw_data). */
+typedef struct {
+  const uint8_t *pixels; size_t row_stride;                 /* pixel input */
+  const uint8_t *const *src; const size_t *src_stride;      /* plane input (NULL = pixels) */
+  const int *src_w, *src_h;
+} plane_source;
+
+static void import_planes16(const mjo_params *p, const plane_source *ps, uint16_t *planes[MJO_MAX_COMPS])
+{
+  /* jpeg_write_raw_data jcapistd.c:145-199 hands the rows straight to the coefficient controller, which
+   * reads width_in_blocks*8 samples of height_in_blocks*8 rows per component (compress_first_pass
+   * jccoefct.c:262-353).  A caller whose planes are smaller replicates the last sample / row up to that
+   * size first, as tj3CompressFromYUVPlanes8 does (turbojpeg.c:1295-1316): modelled by the clamps. */
+  mjo_geom g[MJO_MAX_COMPS];
+  int ci, r, c;
+  const int bps = prec_of(p) == 12 ? 2 : 1;
+  mjo_geometry(p, g, NULL, NULL);
+  for (ci = 0; ci < p->num_components; ci++)
+    for (r = 0; r < g[ci].ph; r++) {
+      const int sr = r < ps->src_h[ci] ? r : ps->src_h[ci] - 1;
+      const uint8_t *row = ps->src[ci] + (size_t)sr * ps->src_stride[ci];
+      for (c = 0; c < g[ci].pw; c++) {
+        const int sc = c < ps->src_w[ci] ? c : ps->src_w[ci] - 1;
+        planes[ci][(size_t)r * g[ci].pw + c] = bps == 2 ? ((const uint16_t *)row)[sc] : row[sc];
+      }
+    }
+}
+
+static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_t *out, size_t cap, mjo_taps *taps)
 {
   enc_t e;
   bytebuf o = { 0, 0, 0 };
@@ -1370,7 +1399,8 @@ size_t mjo_encode(const mjo_params *p_in, const uint8_t *pixels, size_t row_stri
   memcpy(e.ac[0].bits, STD_AC_L_BITS, 17); memcpy(e.ac[0].huffval, STD_AC_L_VAL, 162);
   memcpy(e.ac[1].bits, STD_AC_C_BITS, 17); memcpy(e.ac[1].huffval, STD_AC_C_VAL, 162);
 
-  color_downsample16(p, pixels, row_stride, planes);
+  if (ps->src) import_planes16(p, ps, planes);
+  else color_downsample16(p, ps->pixels, ps->row_stride, planes);
   forward16(p, planes, e.uq, e.q);
   if (taps) {
     for (ci = 0; ci < p->num_components; ci++) {
@@ -1538,4 +1568,24 @@ size_t mjo_encode(const mjo_params *p_in, const uint8_t *pixels, size_t row_stri
   free(o.buf);
   for (ci = 0; ci < p->num_components; ci++) { free(planes[ci]); free(e.uq[ci]); free(e.q[ci]); }
   return n;
+}
+
+
+size_t mjo_encode(const mjo_params *p, const uint8_t *pixels, size_t row_stride,
+                  uint8_t *out, size_t cap, mjo_taps *taps)
+{
+  plane_source ps;
+  memset(&ps, 0, sizeof(ps));
+  ps.pixels = pixels; ps.row_stride = row_stride;
+  return encode_core(p, &ps, out, cap, taps);
+}
+
+size_t mjo_encode_planes(const mjo_params *p, const uint8_t *const src[MJO_MAX_COMPS],
+                         const size_t src_stride[MJO_MAX_COMPS], const int src_w[MJO_MAX_COMPS],
+                         const int src_h[MJO_MAX_COMPS], uint8_t *out, size_t cap, mjo_taps *taps)
+{
+  plane_source ps;
+  memset(&ps, 0, sizeof(ps));
+  ps.src = src; ps.src_stride = src_stride; ps.src_w = src_w; ps.src_h = src_h;
+  return encode_core(p, &ps, out, cap, taps);
 }

@@ -101,6 +101,14 @@ typedef struct {
 size_t mjo_encode(const mjo_params *p, const uint8_t *pixels, size_t row_stride,
                   uint8_t *out, size_t cap, mjo_taps *taps);
 
+/* Same encode from caller-supplied component planes instead of pixels: jpeg_write_raw_data
+ * (jcapistd.c:145) as tj3CompressFromYUVPlanes8 drives it (turbojpeg.c:1222-1335).  Plane ci is
+ * src_w[ci] x src_h[ci] samples (uint8, or uint16 for 12-bit), rows src_stride[ci] BYTES apart; if it
+ * is smaller than width_in_blocks*8 x height_in_blocks*8 its last sample / row is replicated. */
+size_t mjo_encode_planes(const mjo_params *p, const uint8_t *const src[MJO_MAX_COMPS],
+                         const size_t src_stride[MJO_MAX_COMPS], const int src_w[MJO_MAX_COMPS],
+                         const int src_h[MJO_MAX_COMPS], uint8_t *out, size_t cap, mjo_taps *taps);
+
 #ifdef __cplusplus
 }
 #endif

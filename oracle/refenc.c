@@ -63,7 +63,7 @@ int main(int argc, char **argv)
   int notrellis = 0, notrellis_dc = 0, noovershoot = 0, gray = 0, grayin = 0, qtbl = -1;
   int hs = 2, vs = 2, restart = 0, restart_blocks = 0, reps = 1, rawW = 0, rawH = 0;
   double l1 = -1e9, l2 = -1e9;
-  int precision = 8;
+  int precision = 8, yuvin = 0;
   const char *dump = NULL, *in = NULL, *out = NULL;
   int i, w, h, nc;
   unsigned char *img;
@@ -97,6 +97,7 @@ int main(int argc, char **argv)
     else if (!strcmp(a, "-precision")) precision = atoi(argv[++i]);   /* 12: raw input is uint16 samples */
     else if (!strcmp(a, "-raw")) { rawW = atoi(argv[++i]); rawH = atoi(argv[++i]); }
     else if (!strcmp(a, "-dumpcoef")) dump = argv[++i];
+    else if (!strcmp(a, "-yuvin")) yuvin = 1;   /* -raw W H input holds component planes: jpeg_write_raw_data */
     else if (!in) in = a;
     else out = a;
   }
@@ -108,6 +109,10 @@ int main(int argc, char **argv)
     if (!f) { perror(in); return 2; }
     w = rawW; h = rawH; nc = grayin ? 1 : 3;
     n = (size_t)w * h * nc * (precision == 12 ? 2 : 1);
+    if (yuvin) {   /* planes are at most (w+3)*(h+3) samples each */
+      fseek(f, 0, SEEK_END); n = (size_t)ftell(f); fseek(f, 0, SEEK_SET);
+      nc = 3;
+    }
     img = malloc(n);
     if (fread(img, 1, n, f) != n) { fprintf(stderr, "short raw\n"); return 2; }
     fclose(f);
@@ -159,6 +164,52 @@ int main(int argc, char **argv)
       else cinfo.restart_in_rows = restart;
     }
     jpeg_mem_dest(&cinfo, &jbuf, &jsize);
+    if (yuvin) {
+      /* Planar input the way TurboJPEG's YUV entry points feed it (turbojpeg.c:1222-1335): plane ci is
+       * PAD(w,maxh)*h_i/maxh x PAD(h,maxv)*v_i/maxv samples, tightly packed, planes back to back; the
+       * last sample / row is replicated out to whole iMCU rows; one jpeg_write_raw_data call per iMCU row. */
+      int ci, maxh = 1, maxv = 1, r, c, imcu;
+      unsigned char *pl[4], *tmp[4];
+      JSAMPROW *rowp[4];
+      JSAMPARRAY data[4];
+      int pw[4], ph[4], iw[4], th[4];
+      size_t off = 0;
+      cinfo.raw_data_in = TRUE;
+      jpeg_start_compress(&cinfo, TRUE);
+      for (ci = 0; ci < cinfo.num_components; ci++) {
+        if (cinfo.comp_info[ci].h_samp_factor > maxh) maxh = cinfo.comp_info[ci].h_samp_factor;
+        if (cinfo.comp_info[ci].v_samp_factor > maxv) maxv = cinfo.comp_info[ci].v_samp_factor;
+      }
+      for (ci = 0; ci < cinfo.num_components; ci++) {
+        jpeg_component_info *cp = &cinfo.comp_info[ci];
+        pw[ci] = (w + maxh - 1) / maxh * maxh * cp->h_samp_factor / maxh;
+        ph[ci] = (h + maxv - 1) / maxv * maxv * cp->v_samp_factor / maxv;
+        iw[ci] = cp->width_in_blocks * 8;
+        th[ci] = cp->v_samp_factor * 8;
+        pl[ci] = img + off;
+        off += (size_t)pw[ci] * ph[ci];
+        tmp[ci] = malloc((size_t)iw[ci] * th[ci]);
+        rowp[ci] = malloc(sizeof(JSAMPROW) * th[ci]);
+        for (r = 0; r < th[ci]; r++) rowp[ci][r] = tmp[ci] + (size_t)r * iw[ci];
+        data[ci] = rowp[ci];
+      }
+      for (imcu = 0; imcu * maxv * 8 < h; imcu++) {
+        for (ci = 0; ci < cinfo.num_components; ci++)
+          for (r = 0; r < th[ci]; r++) {
+            int sr = imcu * th[ci] + r;
+            if (sr > ph[ci] - 1) sr = ph[ci] - 1;
+            for (c = 0; c < iw[ci]; c++) tmp[ci][(size_t)r * iw[ci] + c] = pl[ci][(size_t)sr * pw[ci] + (c < pw[ci] ? c : pw[ci] - 1)];
+          }
+        jpeg_write_raw_data(&cinfo, data, maxv * 8);
+      }
+      jpeg_finish_compress(&cinfo);
+      jpeg_destroy_compress(&cinfo);
+      for (ci = 0; ci < 4 && ci < 3; ci++) if (ci < (gray ? 1 : 3)) { free(tmp[ci]); free(rowp[ci]); }
+      t1 = now();
+      if (t1 - t0 < best) best = t1 - t0;
+      total += t1 - t0;
+      continue;
+    }
     jpeg_start_compress(&cinfo, TRUE);
     rows = malloc(sizeof(JSAMPROW) * h);
     for (y = 0; y < h; y++) rows[y] = img + (size_t)y * w * nc * (precision == 12 ? 2 : 1);

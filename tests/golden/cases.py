@@ -82,3 +82,18 @@ REFERENCE_PINNED = {
     ("testorig", "revert_440"): "538bc02bd4b4658fd85de6ece6cbeda6",    # MD5_JPEG_440_ISLOW   :1354
     ("testorig", "revert_gray"): "72b51f894b8f4a10b3ee3066770aa38d",   # MD5_JPEG_GRAY_ISLOW  :1362
 }
+
+
+# Planar (raw data) input: jpeg_write_raw_data as tj3CompressFromYUVPlanes8 drives it.
+# (width, height, switches); the planes come from oracle_lib.synthetic_planes(params, seed=7).
+PLANE_CASES = [
+    ("yuv_227x149_base", 227, 149, dict(baseline=True)),
+    ("yuv_64x48_revert", 64, 48, dict(revert=True)),                       # TurboJPEG's configuration
+    ("yuv_130x75_base_422", 130, 75, dict(baseline=True, sample=(2, 1))),
+    ("yuv_97x61_q85_progressive", 97, 61, dict(quality=85)),
+    ("yuv_50x33_base_gray", 50, 33, dict(baseline=True, sample=(1, 1), gray=True)),
+    ("yuv_101x77_fastcrush_440", 101, 77, dict(fastcrush=True, sample=(1, 2))),
+    ("yuv_1x1_base", 1, 1, dict(baseline=True)),
+    ("yuv_321x243_base_444_restart1", 321, 243, dict(baseline=True, sample=(1, 1), restart=1)),
+    ("yuv_640x480_revert_opt", 640, 480, dict(revert=True, optimize=True)),
+]

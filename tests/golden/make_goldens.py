@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 import oracle_lib as O  # noqa: E402
-from cases import CASES, CASES12, images, images12  # noqa: E402
+from cases import CASES, CASES12, PLANE_CASES, images, images12  # noqa: E402
 
 
 def main():
@@ -29,6 +29,15 @@ def main():
     with open(os.path.join(HERE, "goldens.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote %d goldens" % len(out))
+    # planar input through jpeg_write_raw_data (refenc -yuvin): separate file
+    outp = {}
+    for cname, w, h, kw in PLANE_CASES:
+        p = O.make_params(w, h, **kw)
+        data = O.ref_encode_planes(O.synthetic_planes(p, 7), w, h, **kw)
+        outp[cname] = {"md5": O.md5(data), "bytes": len(data)}
+    with open(os.path.join(HERE, "goldens_planes.json"), "w") as f:
+        json.dump(outp, f, indent=1, sort_keys=True)
+    print("wrote %d plane goldens" % len(outp))
 
 
 if __name__ == "__main__":

@@ -154,6 +154,60 @@ def encode(p, pixels, want_taps=False):
     return data, res
 
 
+def tj_plane_dims(p):
+    """Plane sizes of TurboJPEG's planar YUV image for these parameters (tj3YUVPlaneWidth/Height,
+    turbojpeg.c:1283-1286): component ci is PAD(W, maxh) * h_i / maxh by PAD(H, maxv) * v_i / maxv."""
+    nc = p.num_components
+    maxh = max(p.h_samp[i] for i in range(nc))
+    maxv = max(p.v_samp[i] for i in range(nc))
+    pad = lambda v, m: (v + m - 1) // m * m
+    return [(pad(p.width, maxh) * p.h_samp[i] // maxh, pad(p.height, maxv) * p.v_samp[i] // maxv) for i in range(nc)]
+
+
+def synthetic_planes(p, seed=7):
+    """Deterministic YCbCr component planes in TurboJPEG's layout (smooth field + noise + saturated patches)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i, (pw, ph) in enumerate(tj_plane_dims(p)):
+        y, x = np.mgrid[0:ph, 0:pw].astype(np.float64)
+        f = 128 + (90 - 20 * i) * np.sin(x / (23.0 + 7 * i) + seed) * np.cos(y / (17.0 + 5 * i)) + rng.normal(0, 10, (ph, pw))
+        a = np.clip(f, 0, 255).astype(np.uint8)
+        a[((x.astype(np.int64) // 24 + y.astype(np.int64) // 24) % 5) == 0] = 255
+        out.append(a)
+    return out
+
+
+def encode_planes(p, planes):
+    """Oracle encode from component planes (jpeg_write_raw_data path).  planes: list of 2-D uint8 arrays."""
+    planes = [np.ascontiguousarray(a, dtype=np.uint16 if p.data_precision == 12 else np.uint8) for a in planes]
+    n = len(planes)
+    src = (C.c_void_p * 4)(*[a.ctypes.data for a in planes] + [None] * (4 - n))
+    stride = (C.c_size_t * 4)(*[a.strides[0] for a in planes] + [0] * (4 - n))
+    sw = (C.c_int * 4)(*[a.shape[1] for a in planes] + [0] * (4 - n))
+    sh = (C.c_int * 4)(*[a.shape[0] for a in planes] + [0] * (4 - n))
+    cap = p.width * p.height * 8 + 65536
+    out = np.empty(cap, np.uint8)
+    L = lib()
+    L.mjo_encode_planes.restype = C.c_size_t
+    L.mjo_encode_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    nb = L.mjo_encode_planes(C.byref(p), src, stride, sw, sh, out.ctypes.data, cap, None)
+    assert nb > 0, "oracle plane encode failed"
+    return out[:nb].tobytes()
+
+
+def ref_encode_planes(planes, width, height, **kw):
+    """The REAL reference fed through jpeg_write_raw_data (oracle/_ref/refenc -yuvin); planes in TurboJPEG's layout."""
+    with tempfile.TemporaryDirectory() as td:
+        raw = os.path.join(td, "in.yuv")
+        outp = os.path.join(td, "out.jpg")
+        with open(raw, "wb") as f:
+            for a in planes:
+                f.write(np.ascontiguousarray(a, dtype=np.uint8).tobytes())
+        cmd = [os.path.join(REF_DIR, "refenc")] + ref_switches(**kw) + ["-raw", str(width), str(height), "-yuvin", raw, outp]
+        subprocess.check_output(cmd)
+        return open(outp, "rb").read()
+
+
 # ---- the compiled reference (oracle/_ref), where present -------------------------------------
 def have_ref():
     return os.path.exists(os.path.join(REF_DIR, "refenc"))

@@ -1,6 +1,8 @@
 """GPU (-m gpu): the HIP path, called through the C ABI (ctypes -> libmozjpeg_hip.so), against the
 CPU oracle on the same inputs -- stage by stage and byte for byte -- against the committed goldens
 produced by the real reference, and at BASELINE.json's full sizes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -126,3 +128,60 @@ def test_extreme_inputs():
             h, w = img.shape[:2]
             enc = M.Encoder(M.make_params(w, h, **kw))
             assert enc.encode_host(img)[0] == O.encode(O.make_params(w, h, **kw), img), kw
+
+
+# ---- component planes in: jpeg_write_raw_data / tj3CompressFromYUVPlanes8 -------------------
+def _plane_goldens():
+    import json
+    from cases import HERE
+    return json.load(open(os.path.join(HERE, "goldens_planes.json")))
+
+
+@pytest.mark.gpu
+def test_plane_input_matches_reference_goldens_and_oracle():
+    from cases import PLANE_CASES
+    g = _plane_goldens()
+    for cname, w, h, kw in PLANE_CASES:
+        po = O.make_params(w, h, **kw)
+        planes = O.synthetic_planes(po, 7)
+        enc = M.Encoder(M.make_params(w, h, **kw), max_batch=1)
+        data = enc.encode_planes_host(planes)[0]
+        enc.close()
+        assert (len(data), O.md5(data)) == (g[cname]["bytes"], g[cname]["md5"]), cname
+        assert data == O.encode_planes(po, planes), cname
+
+
+@pytest.mark.gpu
+def test_plane_input_device_batch_and_full_size_planes():
+    """device-resident planes, a batch of 3, 1080p 4:2:0 trellis; also planes already padded to whole blocks"""
+    import torch
+    w, h, kw = 1920, 1080, dict(baseline=True)
+    po = O.make_params(w, h, **kw)
+    sets = [O.synthetic_planes(po, 20 + i) for i in range(3)]
+    enc = M.Encoder(M.make_params(w, h, **kw), max_batch=3)
+    ts = [torch.from_numpy(np.stack([s[c] for s in sets])).cuda() for c in range(3)]
+    enc.encode_planes_tensors(ts)
+    enc.sync()
+    for i in range(3):
+        assert enc.get_jpeg(i) == O.encode_planes(po, sets[i]), i
+    # same image with the planes padded by replication to width_in_blocks*8 x height_in_blocks*8 (what a direct
+    # jpeg_write_raw_data caller supplies): identical file
+    padded = []
+    for c in range(3):
+        wib, hib, pw, ph = enc.geometry(c)
+        a = sets[0][c]
+        padded.append(np.pad(a, ((0, max(0, ph - a.shape[0])), (0, max(0, pw - a.shape[1]))), mode="edge"))
+    assert enc.encode_planes_host(padded)[0] == O.encode_planes(po, sets[0])
+    enc.close()
+
+
+@pytest.mark.gpu
+def test_plane_input_of_pixel_path_planes_gives_pixel_path_file():
+    img = O.synthetic_frame(250, 187, 3)
+    kw = dict(quality=85)
+    enc = M.Encoder(M.make_params(250, 187, **kw), max_batch=1)
+    enc.set_debug_taps(True)
+    ref = enc.encode_host(img)[0]
+    planes = [enc.read_tap(M.TAP_PLANE, 0, c) for c in range(3)]
+    assert enc.encode_planes_host(planes)[0] == ref
+    enc.close()

@@ -73,3 +73,30 @@ def test_gen_optimal_table_known_answer():
     O.lib().mjo_gen_optimal_table(freq, bits, vals)
     assert list(bits)[1:6] == [1, 1, 1, 1, 0]
     assert list(vals)[:4] == [0, 1, 2, 3]
+
+
+def _plane_goldens():
+    import json
+    import os
+    from cases import HERE
+    return json.load(open(os.path.join(HERE, "goldens_planes.json")))
+
+
+def test_oracle_plane_input_matches_goldens():
+    """jpeg_write_raw_data path (component planes in, TurboJPEG YUV layout): oracle vs the real reference's bytes"""
+    from cases import PLANE_CASES
+    g = _plane_goldens()
+    for cname, w, h, kw in PLANE_CASES:
+        p = O.make_params(w, h, **kw)
+        data = O.encode_planes(p, O.synthetic_planes(p, 7))
+        assert (len(data), O.md5(data)) == (g[cname]["bytes"], g[cname]["md5"]), cname
+
+
+def test_oracle_plane_input_equals_pixel_path_on_its_own_planes():
+    """feeding the planes the pixel path produced (colour conversion + downsampling taps) must give the same file"""
+    img = O.synthetic_frame(120, 88, 5)
+    for kw in (dict(baseline=True), dict(revert=True, sample=(2, 1))):
+        p = O.make_params(120, 88, **kw)
+        data, taps = O.encode(p, img, want_taps=True)
+        planes = [taps[("planes", ci)] for ci in range(3)]
+        assert O.encode_planes(p, planes) == data
