@@ -136,6 +136,18 @@ int mjh_encode_planes_device(mjh_encoder *e, const void *const d_planes[MJH_MAX_
 int mjh_encode_planes_host(mjh_encoder *e, const void *const planes[MJH_MAX_COMPS], const size_t row_pitch[MJH_MAX_COMPS],
                            const size_t image_stride[MJH_MAX_COMPS], const int plane_width[MJH_MAX_COMPS],
                            const int plane_height[MJH_MAX_COMPS], int n);
+/* Quantized DCT coefficients instead of pixels: jpeg_write_coefficients (jctrans.c:44) for whole images -- the
+ * lossless re-encode jpegtran performs ("jpegrescan": optimal tables, progressive scan search).  Only the
+ * entropy-coding passes run; quantval[] of the parameters is written to the DQT marker unchanged.  The encoder
+ * must have been created with trellis_quant = 0 (there is no unquantized data; jpeg_copy_critical_parameters
+ * switches it off as well, jctrans.c:102) -- otherwise MJH_EINVAL.  coefs[c] of image i starts at coefs[c] +
+ * i * image_stride[c] bytes (image_stride may be NULL for n == 1) and holds height_in_blocks rows of
+ * blocks_per_row[c] (>= width_in_blocks) blocks of 64 int16 in natural order (JBLOCKARRAY layout, 4-byte
+ * aligned); dummy blocks are generated, not read (compress_output jctrans.c:322-373). */
+int mjh_encode_coefficients_device(mjh_encoder *e, const void *const d_coefs[MJH_MAX_COMPS], const size_t blocks_per_row[MJH_MAX_COMPS],
+                                   const size_t image_stride[MJH_MAX_COMPS], int n, void *stream);
+int mjh_encode_coefficients_host(mjh_encoder *e, const void *const coefs[MJH_MAX_COMPS], const size_t blocks_per_row[MJH_MAX_COMPS],
+                                 const size_t image_stride[MJH_MAX_COMPS], int n);
 int mjh_encoder_sync(mjh_encoder *e);
 
 /* Size in bytes of JPEG i of the last batch (synchronises). */

@@ -2,7 +2,7 @@
  * mozjpeg_hip_jpeglib.h -- the libjpeg drop-in boundary of the MI355X hot path.
  *
  * libmozjpeg_hip_jpeg62.so (mozjpeg_amd/csrc/jpeg_shim.c) exports, with the reference's exact
- * signatures, the three libjpeg entry points that bracket the encode hot path:
+ * signatures, the libjpeg entry points that bracket the encode hot path:
  *
  *   void       jpeg_start_compress (j_compress_ptr cinfo, boolean write_all_tables);
  *                  replaces jcapistd.c:44   (declared jpeglib.h:1065)
@@ -12,6 +12,16 @@
  *                  the 12-bit twin (declared jpeglib.h:1070): rows of 16-bit samples, data_precision 12
  *   void       jpeg_finish_compress(j_compress_ptr cinfo);
  *                  replaces jcapimin.c:176  (declared jpeglib.h:1076)
+ *   JDIMENSION jpeg_write_raw_data(j_compress_ptr cinfo, JSAMPIMAGE data, JDIMENSION num_lines);
+ *   JDIMENSION jpeg12_write_raw_data(j_compress_ptr cinfo, J12SAMPIMAGE data, JDIMENSION num_lines);
+ *                  replace jcapistd.c:145   (declared jpeglib.h:1084,:1086): component planes, one iMCU row
+ *                  per call, when cinfo->raw_data_in is set -- what tj3CompressFromYUVPlanes8 uses
+ *                  (turbojpeg.c:1222).  jpeg_start_compress also fills the geometry fields callers read back
+ *                  (comp_info[].width_in_blocks/height_in_blocks, max_h/v_samp_factor, total_iMCU_rows).
+ *   void       jpeg_write_coefficients(j_compress_ptr cinfo, jvirt_barray_ptr *coef_arrays);
+ *                  replaces jctrans.c:44    (declared jpeglib.h:1178): lossless re-encode of existing
+ *                  quantized coefficients (jpegtran); the virtual arrays are read at jpeg_finish_compress,
+ *                  so transforms executed in between are honoured.
  *
  * Everything else of the libjpeg API (jpeg_CreateCompress, jpeg_set_defaults, jpeg_set_quality,
  * jpeg_c_set_*_param, jpeg_mem_dest, jpeg_stdio_dest, jpeg_std_error, jpeg_abort, ...) keeps being
@@ -19,7 +29,7 @@
  * LD_PRELOAD), so an UNCHANGED client such as `cjpeg` runs the GPU path.  See INTEGRATION.md.
  *
  * Contract kept from the reference:
- *  - call order / global_state: CSTATE_START -> SCANNING -> START, wrong order = ERREXIT1(JERR_BAD_STATE)
+ *  - call order / global_state: CSTATE_START -> SCANNING | RAW_OK | WRCOEFS -> START, wrong order = ERREXIT1(JERR_BAD_STATE)
  *  - scanline memory is only read during the call (rows are copied into the staging buffer)
  *  - output only through cinfo->dest (init_destination / empty_output_buffer / term_destination)
  *  - SOI + JFIF APP0 are emitted by jpeg_start_compress so that jpeg_write_marker / ICC / COM
@@ -35,5 +45,5 @@
  */
 #ifndef MOZJPEG_HIP_JPEGLIB_H
 #define MOZJPEG_HIP_JPEGLIB_H
-#define MOZJPEG_HIP_SHIM_SYMBOLS "jpeg_start_compress jpeg_write_scanlines jpeg12_write_scanlines jpeg_finish_compress"
+#define MOZJPEG_HIP_SHIM_SYMBOLS "jpeg_start_compress jpeg_write_scanlines jpeg12_write_scanlines jpeg_finish_compress jpeg_write_raw_data jpeg12_write_raw_data jpeg_write_coefficients"
 #endif

@@ -69,6 +69,8 @@ def lib():
         L.mjh_encode_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
         L.mjh_encode_planes_device.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
         L.mjh_encode_planes_host.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int]
+        L.mjh_encode_coefficients_device.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
+        L.mjh_encode_coefficients_host.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int]
         L.mjh_encoder_sync.argtypes = [C.c_void_p]
         L.mjh_get_jpeg_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
         L.mjh_get_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -197,6 +199,27 @@ class Encoder:
         args = self._plane_args([t.data_ptr() for t in planes], [t.stride(1) * es for t in planes],
                                 [t.stride(0) * es for t in planes], [t.shape[2] for t in planes], [t.shape[1] for t in planes])
         _chk(lib().mjh_encode_planes_device(self._h, *args, n, stream))
+
+    # quantized coefficients in (jpeg_write_coefficients / jpegtran): entropy-coding passes only
+    def encode_coefficients_host(self, coefs):
+        """coefs: one int16 array per component, [n, hib, wib(+pad), 64] or [hib, wib(+pad), 64], natural order."""
+        arrs = [np.ascontiguousarray(a if a.ndim == 4 else a[None], dtype=np.int16) for a in coefs]
+        n, k = arrs[0].shape[0], len(arrs)
+        pad = lambda v, z: list(v) + [z] * (4 - k)
+        _chk(lib().mjh_encode_coefficients_host(self._h, (C.c_void_p * 4)(*pad([a.ctypes.data for a in arrs], None)),
+                                                (C.c_size_t * 4)(*pad([a.shape[2] for a in arrs], 0)),
+                                                (C.c_size_t * 4)(*pad([a.strides[0] for a in arrs], 0)), n))
+        return [self.get_jpeg(i) for i in range(n)]
+
+    def encode_coefficients_tensors(self, coefs, stream=None):
+        """coefs: one int16 CUDA tensor [n, hib, wib(+pad), 64] per component, contiguous.  Asynchronous."""
+        for t in coefs:
+            assert t.is_cuda and t.is_contiguous() and t.dim() == 4 and t.element_size() == 2
+        n, k = coefs[0].shape[0], len(coefs)
+        pad = lambda v, z: list(v) + [z] * (4 - k)
+        _chk(lib().mjh_encode_coefficients_device(self._h, (C.c_void_p * 4)(*pad([t.data_ptr() for t in coefs], None)),
+                                                  (C.c_size_t * 4)(*pad([t.shape[2] for t in coefs], 0)),
+                                                  (C.c_size_t * 4)(*pad([t.stride(0) * 2 for t in coefs], 0)), n, stream))
 
     def sync(self):
         _chk(lib().mjh_encoder_sync(self._h))

@@ -22,6 +22,7 @@ typedef struct shim_state {
   unsigned char *pixels;     /* staged scanlines, image_width*input_components per row */
   size_t row_bytes;
   int raw;                   /* raw_data_in: component planes arrive through jpeg_write_raw_data */
+  jvirt_barray_ptr *coef_arrays;   /* jpeg_write_coefficients: the caller's virtual arrays, read at jpeg_finish_compress */
   unsigned char *planes[MAX_COMPONENTS];   /* staged planes, width_in_blocks*8 x height_in_blocks*8 samples */
   size_t plane_pitch[MAX_COMPONENTS];
   int header_bytes;          /* SOI (+APP0) already written by jpeg_start_compress */
@@ -79,7 +80,7 @@ typedef void (*start_fn)(j_compress_ptr, boolean);
 typedef JDIMENSION (*write_fn)(j_compress_ptr, JSAMPARRAY, JDIMENSION);
 typedef void (*finish_fn)(j_compress_ptr);
 
-static const char *capture_params(j_compress_ptr cinfo, mjh_params *p)
+static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pixels)
 {
   int ci, i;
   memset(p, 0, sizeof(*p));
@@ -101,21 +102,20 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p)
     case JCS_EXT_XRGB: case JCS_EXT_ARGB: ps = 4; ro = 1; go = 2; bo = 3; break;
     case JCS_GRAYSCALE: ps = 1; break;
     default:
-      if (!cinfo->raw_data_in) return "input colour space (RGB family / grayscale only)";
-      ps = cinfo->input_components == 1 ? 1 : 3;   /* raw data: the input colour space is never looked at */
+      if (!no_pixels) return "input colour space (RGB family / grayscale only)";
+      ps = 3;
       break;
     }
-    if (!cinfo->raw_data_in && cinfo->input_components != ps) ERREXIT(cinfo, JERR_BAD_IN_COLORSPACE);
+    if (no_pixels) { ps = cinfo->num_components == 1 ? 1 : 3; ro = 0; go = 1; bo = 2; }   /* planes / coefficients in: the input pixel format is never looked at */
+    if (!no_pixels && cinfo->input_components != ps) ERREXIT(cinfo, JERR_BAD_IN_COLORSPACE);
     if (ps == 1) p->input_components = 1;
     else { p->input_components = 3; p->input_pixel_size = ps; p->rgb_offset[0] = ro; p->rgb_offset[1] = go; p->rgb_offset[2] = bo; }
   }
   if (cinfo->jpeg_color_space == JCS_YCbCr && cinfo->num_components == 3) p->num_components = 3;
   else if (cinfo->jpeg_color_space == JCS_GRAYSCALE && cinfo->num_components == 1) p->num_components = 1;
   else return "JPEG colour space (only YCbCr / grayscale)";
-  if (cinfo->write_JFIF_header &&
-      (cinfo->JFIF_major_version != 1 || cinfo->JFIF_minor_version != 1 || cinfo->density_unit != 0 ||
-       cinfo->X_density != 1 || cinfo->Y_density != 1))
-    return "non-default JFIF version/density";
+  /* JFIF version / density: the APP0 segment is written by this shim from the cinfo fields (emit_jfif_app0
+   * jcmarker.c:422-449), the device's fixed APP0 is dropped, so any values are fine */
   p->image_width = (int)cinfo->image_width;
   p->image_height = (int)cinfo->image_height;
   for (ci = 0; ci < cinfo->num_components; ci++) {
@@ -135,6 +135,7 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p)
   p->overshoot_deringing = jpeg_c_get_bool_param(cinfo, JBOOLEAN_OVERSHOOT_DERINGING);
   p->lambda_log_scale1 = jpeg_c_get_float_param(cinfo, JFLOAT_LAMBDA_LOG_SCALE1);
   p->lambda_log_scale2 = jpeg_c_get_float_param(cinfo, JFLOAT_LAMBDA_LOG_SCALE2);
+  if (no_pixels == 2) p->trellis_quant = p->trellis_quant_dc = p->overshoot_deringing = 0;   /* no trellis passes when transcoding (jcmaster.c transcode_only) */
   if (cinfo->data_precision == 12 && p->trellis_quant) return "12-bit trellis (the reference itself aborts: jccoefct.c:132-138)";
   if (jpeg_c_get_bool_param(cinfo, JBOOLEAN_TRELLIS_EOB_OPT)) return "trellis_eob_opt";
   if (jpeg_c_get_bool_param(cinfo, JBOOLEAN_USE_SCANS_IN_TRELLIS)) return "use_scans_in_trellis";
@@ -170,7 +171,10 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p)
   return NULL;
 }
 
-void jpeg_start_compress(j_compress_ptr cinfo, boolean write_all_tables)
+typedef void (*wrcoef_fn)(j_compress_ptr, jvirt_barray_ptr *);
+
+/* common start of jpeg_start_compress (mode 0 pixels / 1 raw data) and jpeg_write_coefficients (mode 2) */
+static void shim_begin(j_compress_ptr cinfo, boolean write_all_tables, int mode, jvirt_barray_ptr *coef_arrays)
 {
   const char *why;
   shim_state *s;
@@ -179,7 +183,8 @@ void jpeg_start_compress(j_compress_ptr cinfo, boolean write_all_tables)
   if (cinfo->global_state != CSTATE_START) ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
   s = (shim_state *)calloc(1, sizeof(*s));
   if (!s) ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0);
-  why = capture_params(cinfo, &s->p);
+  if (mode == 2) cinfo->input_components = 1;   /* transencode_master_selection jctrans.c:186 */
+  why = capture_params(cinfo, &s->p, mode);
   if (!why) {
     /* let the encoder validate too (geometry limits, sampling factors ...) */
     if (t_enc == NULL || memcmp(&t_enc_params, &s->p, sizeof(mjh_params)) != 0) {
@@ -191,9 +196,14 @@ void jpeg_start_compress(j_compress_ptr cinfo, boolean write_all_tables)
   if (why) {
     free(s);
     if (getenv("MOZJPEG_HIP_PASSTHROUGH")) {
-      start_fn next = (start_fn)dlsym(RTLD_NEXT, "jpeg_start_compress");
       fprintf(stderr, "mozjpeg_hip: %s is outside the GPU path; MOZJPEG_HIP_PASSTHROUGH set, handing over to the host libjpeg\n", why);
-      if (next) { next(cinfo, write_all_tables); return; }
+      if (mode == 2) {
+        wrcoef_fn next = (wrcoef_fn)dlsym(RTLD_NEXT, "jpeg_write_coefficients");
+        if (next) { next(cinfo, coef_arrays); return; }
+      } else {
+        start_fn next = (start_fn)dlsym(RTLD_NEXT, "jpeg_start_compress");
+        if (next) { next(cinfo, write_all_tables); return; }
+      }
     }
     fprintf(stderr, "mozjpeg_hip: unsupported configuration (%s); no CPU fallback\n", why);
     ERREXIT(cinfo, JERR_NOT_COMPILED);
@@ -210,13 +220,17 @@ void jpeg_start_compress(j_compress_ptr cinfo, boolean write_all_tables)
   /* write_file_header jcmarker.c:649: SOI + JFIF APP0 */
   emit_byte(cinfo, 0xFF); emit_byte(cinfo, 0xD8);
   s->header_bytes = 2;
-  if (cinfo->write_JFIF_header) {
-    static const unsigned char app0[18] = { 0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0 };
+  if (cinfo->write_JFIF_header) {   /* emit_jfif_app0 jcmarker.c:422-449 */
+    unsigned char app0[18] = { 0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0 };
+    app0[9] = cinfo->JFIF_major_version; app0[10] = cinfo->JFIF_minor_version; app0[11] = cinfo->density_unit;
+    app0[12] = (unsigned char)(cinfo->X_density >> 8); app0[13] = (unsigned char)cinfo->X_density;
+    app0[14] = (unsigned char)(cinfo->Y_density >> 8); app0[15] = (unsigned char)cinfo->Y_density;
     emit_bytes(cinfo, app0, sizeof(app0));
-    s->header_bytes += 18;
+    s->header_bytes += 18;   /* the device file carries the default APP0 at the same place: skipped on output */
   }
   s->cinfo = cinfo;
-  s->raw = cinfo->raw_data_in ? 1 : 0;
+  s->raw = mode == 1;
+  s->coef_arrays = mode == 2 ? coef_arrays : NULL;
   {
     /* the geometry fields callers read back after jpeg_start_compress (initial_setup jcmaster.c:237-259);
      * tj3CompressFromYUVPlanes8 sizes its row buffers from width_in_blocks / max_*_samp_factor */
@@ -241,7 +255,10 @@ void jpeg_start_compress(j_compress_ptr cinfo, boolean write_all_tables)
                                           ((long)cinfo->max_v_samp_factor * DCTSIZE));
   }
   s->row_bytes = (size_t)cinfo->image_width * cinfo->input_components * (cinfo->data_precision == 12 ? 2 : 1);
-  if (s->raw) {
+  if (mode == 2) {
+    /* arrays requested from this object's memory manager get realised here, as in the reference (jctrans.c:214) */
+    (*cinfo->mem->realize_virt_arrays) ((j_common_ptr)cinfo);
+  } else if (s->raw) {
     int ci, bad = 0;
     for (ci = 0; ci < cinfo->num_components; ci++) {
       jpeg_component_info *c = &cinfo->comp_info[ci];
@@ -258,7 +275,20 @@ void jpeg_start_compress(j_compress_ptr cinfo, boolean write_all_tables)
   s->next = g_states; g_states = s;
   pthread_mutex_unlock(&g_lock);
   cinfo->next_scanline = 0;
-  cinfo->global_state = s->raw ? CSTATE_RAW_OK : CSTATE_SCANNING;   /* jcapistd.c:62 */
+  cinfo->global_state = mode == 2 ? CSTATE_WRCOEFS : (s->raw ? CSTATE_RAW_OK : CSTATE_SCANNING);   /* jcapistd.c:62, jctrans.c:67 */
+}
+
+void jpeg_start_compress(j_compress_ptr cinfo, boolean write_all_tables)
+{
+  shim_begin(cinfo, write_all_tables, cinfo->raw_data_in ? 1 : 0, NULL);
+}
+
+/* jpeg_write_coefficients jctrans.c:44-68: start of a lossless re-encode (jpegtran).  All tables are written; the
+ * virtual arrays may still be filled by the caller (jtransform_execute_transformation) until jpeg_finish_compress. */
+void jpeg_write_coefficients(j_compress_ptr cinfo, jvirt_barray_ptr *coef_arrays)
+{
+  if (cinfo->master->num_scans_luma == 0) cinfo->master->optimize_scans = FALSE;
+  shim_begin(cinfo, TRUE, 2, coef_arrays);
 }
 
 static JDIMENSION write_rows(j_compress_ptr cinfo, void **scanlines, JDIMENSION num_lines, int precision, const char *name)
@@ -357,6 +387,24 @@ static void free_state(shim_state *s)
 
 static int encode_staged(j_compress_ptr cinfo, shim_state *s)
 {
+  if (s->coef_arrays) {
+    const void *cf[MJH_MAX_COMPS] = { 0, 0, 0, 0 };
+    size_t bpr[MJH_MAX_COMPS] = { 0, 0, 0, 0 };
+    int ci, rc;
+    for (ci = 0; ci < cinfo->num_components && ci < MJH_MAX_COMPS; ci++) {
+      jpeg_component_info *c = &cinfo->comp_info[ci];
+      JDIMENSION r;
+      s->planes[ci] = (unsigned char *)malloc((size_t)c->width_in_blocks * c->height_in_blocks * sizeof(JBLOCK));
+      if (!s->planes[ci]) return MJH_ENOMEM;
+      for (r = 0; r < c->height_in_blocks; r++) {   /* one block row at a time: always within the array's maxaccess */
+        JBLOCKARRAY ba = (*cinfo->mem->access_virt_barray) ((j_common_ptr)cinfo, s->coef_arrays[ci], r, 1, FALSE);
+        memcpy(s->planes[ci] + (size_t)r * c->width_in_blocks * sizeof(JBLOCK), ba[0], (size_t)c->width_in_blocks * sizeof(JBLOCK));
+      }
+      cf[ci] = s->planes[ci]; bpr[ci] = c->width_in_blocks;
+    }
+    rc = mjh_encode_coefficients_host(t_enc, cf, bpr, NULL, 1);
+    return rc;
+  }
   if (s->raw) {
     const void *pl[MJH_MAX_COMPS] = { 0, 0, 0, 0 };
     size_t pitch[MJH_MAX_COMPS] = { 0, 0, 0, 0 };
@@ -381,8 +429,10 @@ void jpeg_finish_compress(j_compress_ptr cinfo)
     if (next) { next(cinfo); return; }
     ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
   }
-  if (cinfo->global_state != CSTATE_SCANNING && cinfo->global_state != CSTATE_RAW_OK) ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
-  if (cinfo->next_scanline < cinfo->image_height) ERREXIT(cinfo, JERR_TOO_LITTLE_DATA);
+  if (cinfo->global_state == CSTATE_SCANNING || cinfo->global_state == CSTATE_RAW_OK) {
+    if (cinfo->next_scanline < cinfo->image_height) ERREXIT(cinfo, JERR_TOO_LITTLE_DATA);
+  } else if (cinfo->global_state != CSTATE_WRCOEFS)
+    ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);   /* jcapimin.c:180-189 */
   if (encode_staged(cinfo, s) != MJH_OK || mjh_get_jpeg_size(t_enc, 0, &n) != MJH_OK) {
     fprintf(stderr, "mozjpeg_hip: %s\n", mjh_last_error());
     find_state(cinfo, 1); free_state(s);

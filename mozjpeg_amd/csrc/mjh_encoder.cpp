@@ -232,6 +232,7 @@ struct mjh_encoder {
   uint8_t *d_pix = nullptr;        // staging for mjh_encode_host
   uint8_t *h_pix = nullptr;        // pinned host staging
   uint8_t *d_plin = nullptr, *h_plin = nullptr;   // the same for mjh_encode_planes_host
+  uint8_t *d_cfin = nullptr, *h_cfin = nullptr;   // and for mjh_encode_coefficients_host
   size_t pix_image_bytes = 0;
   uint8_t *d_planes = nullptr;
   int16_t *d_uq = nullptr, *d_q = nullptr, *d_q0 = nullptr;
@@ -549,12 +550,13 @@ static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *ptrs[] = { e->d_pix, e->d_plin, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pix, e->d_plin, e->d_cfin, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
   if (e->h_pix) (void)hipHostFree(e->h_pix);
   if (e->h_plin) (void)hipHostFree(e->h_plin);
+  if (e->h_cfin) (void)hipHostFree(e->h_cfin);
   for (hipEvent_t ev : e->prof_events) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : e->side_events) (void)hipEventDestroy(ev);
   if (e->copy_done) (void)hipEventDestroy(e->copy_done);
@@ -809,7 +811,7 @@ struct Prof {
 };
 
 static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, size_t image_stride, int n, hipStream_t s,
-                        const MjhPlaneSrc *plane_src = nullptr)
+                        const MjhPlaneSrc *plane_src = nullptr, const MjhCoefSrc *coef_src = nullptr)
 {
   const MjhConst &C = e->C;
   const mjh_params &p = e->p;
@@ -824,15 +826,20 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     pr.next = (size_t)e->prof_calls * e->prof_per_call;
   }
   HIPCHK(hipMemcpyAsync(e->d_tabs, e->d_tabs_init, (size_t)n * spi * sizeof(MjhHuffTable), hipMemcpyDeviceToDevice, s));
-  if (plane_src) {   // jpeg_write_raw_data: the caller's component planes replace colour conversion + downsampling
-    pr.mark("import_planes");
-    mjh_launch_import_planes(C, *plane_src, e->d_planes, n, s);
+  if (coef_src) {    // jpeg_write_coefficients: the caller's quantized blocks go straight to the entropy-coding passes
+    pr.mark("import_coefs");
+    mjh_launch_import_coefs(C, *coef_src, e->d_q, n, s);
   } else {
-    pr.mark("color");
-    mjh_launch_color(C, d_pixels, row_pitch, image_stride, e->d_planes, n, s);
+    if (plane_src) {   // jpeg_write_raw_data: the caller's component planes replace colour conversion + downsampling
+      pr.mark("import_planes");
+      mjh_launch_import_planes(C, *plane_src, e->d_planes, n, s);
+    } else {
+      pr.mark("color");
+      mjh_launch_color(C, d_pixels, row_pitch, image_stride, e->d_planes, n, s);
+    }
+    pr.mark("dct_quant");
+    mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, n, s);
   }
-  pr.mark("dct_quant");
-  mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, n, s);
 
   int tr_dc[4], tr_ac[4], fin_dc[4], fin_ac[4], zero4[4] = { 0, 0, 0, 0 };
   for (int i = 0; i < 4; i++) {
@@ -963,6 +970,67 @@ extern "C" int mjh_encode_host(mjh_encoder *e, const void *pixels, size_t row_pi
   HIPCHK(hipEventRecord(e->copy_done, e->copy_stream));
   HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done, 0));
   return run_pipeline(e, e->d_pix, row_bytes, e->pix_image_bytes, n, e->stream);
+}
+
+static int check_coef_args(mjh_encoder *e, const void *const coefs[], const size_t blocks_per_row[], int n)
+{
+  if (!e || !coefs || !blocks_per_row || n < 1 || n > e->max_batch)
+    return fail(MJH_EINVAL, "bad arguments (n=%d, max_batch=%d)", n, e ? e->max_batch : 0);
+  if (e->p.trellis_quant)
+    return fail(MJH_EINVAL, "trellis quantization needs the unquantized DCT output: create the encoder with trellis_quant = 0 "
+                            "for coefficient input (jpeg_copy_critical_parameters does the same, jctrans.c:102)");
+  for (int c = 0; c < e->C.ncomp; c++)
+    if (!coefs[c] || ((uintptr_t)coefs[c] & 3) || blocks_per_row[c] < (size_t)e->C.c[c].wib)
+      return fail(MJH_EINVAL, "bad coefficient array %d (NULL, not 4-byte aligned, or fewer than %d blocks per row)", c, e->C.c[c].wib);
+  return MJH_OK;
+}
+
+extern "C" int mjh_encode_coefficients_device(mjh_encoder *e, const void *const d_coefs[], const size_t blocks_per_row[],
+                                              const size_t image_stride[], int n, void *stream)
+{
+  int rc = check_coef_args(e, d_coefs, blocks_per_row, n);
+  if (rc) return rc;
+  if (n > 1 && !image_stride) return fail(MJH_EINVAL, "image_stride is required for n > 1");
+  HIPCHK(hipSetDevice(e->device));
+  MjhCoefSrc cs;
+  memset(&cs, 0, sizeof(cs));
+  for (int c = 0; c < e->C.ncomp; c++) {
+    cs.base[c] = d_coefs[c]; cs.blocks_per_row[c] = (long long)blocks_per_row[c];
+    cs.stride[c] = image_stride ? (long long)image_stride[c] : 0;
+  }
+  return run_pipeline(e, nullptr, 0, 0, n, stream ? (hipStream_t)stream : e->stream, nullptr, &cs);
+}
+
+extern "C" int mjh_encode_coefficients_host(mjh_encoder *e, const void *const coefs[], const size_t blocks_per_row[],
+                                            const size_t image_stride[], int n)
+{
+  int rc = check_coef_args(e, coefs, blocks_per_row, n);
+  if (rc) return rc;
+  if (n > 1 && !image_stride) return fail(MJH_EINVAL, "image_stride is required for n > 1");
+  HIPCHK(hipSetDevice(e->device));
+  // real blocks only, rows packed to width_in_blocks
+  size_t off[MJH_MAXC], per_image = 0;
+  for (int c = 0; c < e->C.ncomp; c++) { off[c] = per_image; per_image += (size_t)e->C.c[c].nblk * 128; }
+  HIPCHK(hipStreamSynchronize(e->stream));   // the staging buffers may still feed the previous batch
+  if (!e->d_cfin) {
+    HIPCHK(hipMalloc((void **)&e->d_cfin, (size_t)e->max_batch * per_image));
+    HIPCHK(hipHostMalloc((void **)&e->h_cfin, (size_t)e->max_batch * per_image, hipHostMallocDefault));
+  }
+  for (int i = 0; i < n; i++) {
+    for (int c = 0; c < e->C.ncomp; c++) {
+      const uint8_t *src = (const uint8_t *)coefs[c] + (image_stride ? (size_t)i * image_stride[c] : 0);
+      uint8_t *dst = e->h_cfin + (size_t)i * per_image + off[c];
+      const size_t row = (size_t)e->C.c[c].wib * 128;
+      for (int r = 0; r < e->C.c[c].hib; r++) memcpy(dst + (size_t)r * row, src + (size_t)r * blocks_per_row[c] * 128, row);
+    }
+    HIPCHK(hipMemcpyAsync(e->d_cfin + (size_t)i * per_image, e->h_cfin + (size_t)i * per_image, per_image, hipMemcpyHostToDevice, e->copy_stream));
+  }
+  HIPCHK(hipEventRecord(e->copy_done, e->copy_stream));
+  HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done, 0));
+  MjhCoefSrc cs;
+  memset(&cs, 0, sizeof(cs));
+  for (int c = 0; c < e->C.ncomp; c++) { cs.base[c] = e->d_cfin + off[c]; cs.blocks_per_row[c] = e->C.c[c].wib; cs.stride[c] = (long long)per_image; }
+  return run_pipeline(e, nullptr, 0, 0, n, e->stream, nullptr, &cs);
 }
 
 static int check_plane_args(mjh_encoder *e, const void *const planes[], const size_t row_pitch[], const int plane_width[],

@@ -69,6 +69,13 @@ struct MjhPlaneSrc {
   int w[MJH_MAXC], h[MJH_MAXC];      // valid samples; beyond them the last sample / row is replicated
 };
 
+// caller-supplied quantized coefficients (jpeg_write_coefficients path): one entry per component
+struct MjhCoefSrc {
+  const void *base[MJH_MAXC];        // first block of image 0: [height_in_blocks][blocks_per_row][64] int16, natural order
+  long long blocks_per_row[MJH_MAXC];
+  long long stride[MJH_MAXC];        // bytes between images
+};
+
 // per-table-slot constant data uploaded once per encoder
 struct MjhQuant {
   uint16_t q[4][64];        // zig-zag order quantizer step

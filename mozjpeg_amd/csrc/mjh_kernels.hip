@@ -395,6 +395,34 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
 }
 
 // =============================================================================================
+// K2b  coefficient import: jpeg_write_coefficients jctrans.c:44 entropy-codes blocks the
+// caller already has (jpegtran, "jpegrescan").  The caller's arrays are block-major, natural order
+// (JBLOCKARRAY); the pipeline's layout is coefficient-major in zig-zag order.  One lane = one block: 32
+// dword loads of its 128 contiguous bytes, 64 coalesced plane stores.  Dummy blocks stay virtual
+// (compress_output jctrans.c:322-373 builds them with the same rule as the pixel path).
+// =============================================================================================
+__global__ void __launch_bounds__(64)
+k_import_coefs(MjhConst C, MjhCoefSrc S, int16_t *__restrict__ coef_q)
+{
+  const int comp = blockIdx.y, img = blockIdx.z;
+  const MjhComp cc = C.c[comp];
+  const int blk = blockIdx.x * 64 + threadIdx.x;
+  if (blk >= cc.nblk) return;
+  const int br = blk / cc.wib, bc = blk - br * cc.wib;
+  const unsigned *src = reinterpret_cast<const unsigned *>(reinterpret_cast<const uint8_t *>(S.base[comp]) + (size_t)img * S.stride[comp] +
+                                                          ((size_t)br * S.blocks_per_row[comp] + bc) * 128);
+  int v[64];
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    const unsigned w = src[i];
+    v[2 * i] = (int)(short)(w & 0xFFFFu);
+    v[2 * i + 1] = (int)(short)(w >> 16);
+  }
+  int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+#pragma unroll
+  for (int k = 0; k < 64; k++) qo[(size_t)k * cc.kstride] = (int16_t)v[kZZ.v[k]];
+}
+// =============================================================================================
 // Dummy-block resolution (compress_first_pass jccoefct.c:312-345, compress_trellis_pass
 // :443-476): dummy blocks are never stored.  A padded position (r,c) of a component maps to
 // the real block whose DC it copies; its AC coefficients are zero.
@@ -1530,6 +1558,14 @@ k_stuff_write(const unsigned *__restrict__ stream, size_t stream_words_per_image
 #include "mjh_launch.h"
 
 static inline dim3 g3(unsigned x, unsigned y, unsigned z) { return dim3(x, y, z); }
+
+void mjh_launch_import_coefs(const MjhConst &C, const MjhCoefSrc &S, void *coef_q, int n, hipStream_t s)
+{
+  int m = 0;
+  for (int i = 0; i < C.ncomp; i++) m = C.c[i].nblk > m ? C.c[i].nblk : m;
+  dim3 grid((m + 63) / 64, C.ncomp, n);
+  hipLaunchKernelGGL(k_import_coefs, grid, dim3(64), 0, s, C, S, (int16_t *)coef_q);
+}
 
 void mjh_launch_import_planes(const MjhConst &C, const MjhPlaneSrc &S, void *planes, int n, hipStream_t s)
 {

@@ -1350,6 +1350,7 @@ typedef struct {
   const uint8_t *pixels; size_t row_stride;                 /* pixel input */
   const uint8_t *const *src; const size_t *src_stride;      /* plane input (NULL = pixels) */
   const int *src_w, *src_h;
+  const int16_t *const *coef; const size_t *coef_pitch;     /* quantized coefficient input (jpeg_write_coefficients) */
 } plane_source;
 
 static void import_planes16(const mjo_params *p, const plane_source *ps, uint16_t *planes[MJO_MAX_COMPS])
@@ -1399,9 +1400,23 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
   memcpy(e.ac[0].bits, STD_AC_L_BITS, 17); memcpy(e.ac[0].huffval, STD_AC_L_VAL, 162);
   memcpy(e.ac[1].bits, STD_AC_C_BITS, 17); memcpy(e.ac[1].huffval, STD_AC_C_VAL, 162);
 
-  if (ps->src) import_planes16(p, ps, planes);
-  else color_downsample16(p, ps->pixels, ps->row_stride, planes);
-  forward16(p, planes, e.uq, e.q);
+  if (ps->coef) {
+    /* jpeg_write_coefficients jctrans.c:44: the caller's quantized blocks (width_in_blocks x height_in_blocks per
+     * component, natural order) are entropy-coded as they are; dummy blocks are made on the fly with the same
+     * rule as the pixel path (compress_output jctrans.c:322-373).  No unquantized data exists, so no trellis
+     * (jpeg_copy_critical_parameters switches it off, jctrans.c:102). */
+    int r;
+    if (p->trellis_quant) return 0;
+    for (ci = 0; ci < p->num_components; ci++) {
+      for (r = 0; r < e.g[ci].hib; r++)
+        memcpy(e.q[ci] + (size_t)r * e.g[ci].wpad * 64, ps->coef[ci] + (size_t)r * ps->coef_pitch[ci] * 64, (size_t)e.g[ci].wib * 128);
+      build_dummies(p, &e.g[ci], ci, e.q[ci]);
+    }
+  } else {
+    if (ps->src) import_planes16(p, ps, planes);
+    else color_downsample16(p, ps->pixels, ps->row_stride, planes);
+    forward16(p, planes, e.uq, e.q);
+  }
   if (taps) {
     for (ci = 0; ci < p->num_components; ci++) {
       size_t nb = (size_t)e.g[ci].hpad * e.g[ci].wpad * 128;
@@ -1588,4 +1603,13 @@ size_t mjo_encode_planes(const mjo_params *p, const uint8_t *const src[MJO_MAX_C
   memset(&ps, 0, sizeof(ps));
   ps.src = src; ps.src_stride = src_stride; ps.src_w = src_w; ps.src_h = src_h;
   return encode_core(p, &ps, out, cap, taps);
+}
+
+size_t mjo_encode_coefficients(const mjo_params *p, const int16_t *const coef[MJO_MAX_COMPS],
+                               const size_t blocks_per_row[MJO_MAX_COMPS], uint8_t *out, size_t cap)
+{
+  plane_source ps;
+  memset(&ps, 0, sizeof(ps));
+  ps.coef = coef; ps.coef_pitch = blocks_per_row;
+  return encode_core(p, &ps, out, cap, NULL);
 }

@@ -109,6 +109,12 @@ size_t mjo_encode_planes(const mjo_params *p, const uint8_t *const src[MJO_MAX_C
                          const size_t src_stride[MJO_MAX_COMPS], const int src_w[MJO_MAX_COMPS],
                          const int src_h[MJO_MAX_COMPS], uint8_t *out, size_t cap, mjo_taps *taps);
 
+/* Entropy-code existing quantized coefficients: jpeg_write_coefficients (jctrans.c:44), what jpegtran does.
+ * coef[ci] = height_in_blocks rows of blocks_per_row[ci] (>= width_in_blocks) blocks of 64 int16 in natural
+ * order.  p->qtbl only goes into the DQT marker; p->trellis_quant must be 0 (jctrans.c:102). */
+size_t mjo_encode_coefficients(const mjo_params *p, const int16_t *const coef[MJO_MAX_COMPS],
+                               const size_t blocks_per_row[MJO_MAX_COMPS], uint8_t *out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,3 +97,22 @@ PLANE_CASES = [
     ("yuv_321x243_base_444_restart1", 321, 243, dict(baseline=True, sample=(1, 1), restart=1)),
     ("yuv_640x480_revert_opt", 640, 480, dict(revert=True, optimize=True)),
 ]
+
+
+# Transcoding (jpeg_write_coefficients): (name, fixture image, switches of the encode that made the
+# source file, jpegtran switches, the same switches in make_params vocabulary).  The source file is produced by the
+# oracle (itself pinned above); the golden is the REAL jpegtran's output for that file.
+TRANSCODE_CASES = [
+    ("tr_base_to_rescan", "syn250x187", dict(baseline=True), ["-progressive"], dict()),
+    ("tr_base_to_revert", "syn250x187", dict(baseline=True), ["-revert"], dict(revert=True)),
+    ("tr_base_to_revert_opt", "syn250x187", dict(baseline=True), ["-revert", "-optimize"], dict(revert=True, optimize=True)),
+    ("tr_revert422_to_rescan", "syn250x187", dict(revert=True, sample=(2, 1)), ["-progressive"], dict()),
+    ("tr_revert422_to_revert_prog", "syn250x187", dict(revert=True, sample=(2, 1)), ["-revert", "-progressive"], dict(revert=True, progressive=True)),
+    ("tr_gray_to_rescan", "syn96x64", dict(baseline=True, gray=True), ["-progressive"], dict()),
+    ("tr_444_to_fastcrush", "noise121x75", dict(quality=90, sample=(1, 1), fastcrush=True), ["-fastcrush", "-progressive"], dict(fastcrush=True)),
+    ("tr_base_to_revert_restart2", "testorig", dict(baseline=True), ["-revert", "-restart", "2"], dict(revert=True, restart=2)),
+    ("tr_base_to_revert_opt_restart3b", "testorig", dict(baseline=True), ["-revert", "-optimize", "-restart", "3B"], dict(revert=True, optimize=True, restart="3b")),
+    ("tr_testorig_default_to_rescan", "testorig", dict(), ["-progressive"], dict()),
+    ("tr_1x1_to_rescan", "syn1x1", dict(baseline=True), ["-progressive"], dict()),
+    ("tr_640x480_to_rescan", "syn640x480", dict(baseline=True), ["-progressive"], dict()),
+]

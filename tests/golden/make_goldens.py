@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 import oracle_lib as O  # noqa: E402
-from cases import CASES, CASES12, PLANE_CASES, images, images12  # noqa: E402
+from cases import CASES, CASES12, PLANE_CASES, TRANSCODE_CASES, images, images12  # noqa: E402
 
 
 def main():
@@ -38,6 +38,18 @@ def main():
     with open(os.path.join(HERE, "goldens_planes.json"), "w") as f:
         json.dump(outp, f, indent=1, sort_keys=True)
     print("wrote %d plane goldens" % len(outp))
+    # transcoding: the real jpegtran on source files made by the oracle
+    outt = {}
+    imgs = images()
+    for cname, iname, src_kw, switches, _kw in TRANSCODE_CASES:
+        img = imgs[iname]
+        h, w = img.shape[:2]
+        src = O.encode(O.make_params(w, h, **src_kw), img)
+        data = O.ref_jpegtran(src, switches)
+        outt[cname] = {"md5": O.md5(data), "bytes": len(data), "source_md5": O.md5(src)}
+    with open(os.path.join(HERE, "goldens_transcode.json"), "w") as f:
+        json.dump(outt, f, indent=1, sort_keys=True)
+    print("wrote %d transcode goldens" % len(outt))
 
 
 if __name__ == "__main__":

@@ -208,6 +208,57 @@ def ref_encode_planes(planes, width, height, **kw):
         return open(outp, "rb").read()
 
 
+def transcode_params(src, **kw):
+    """Parameters of a jpegtran run on a file that was encoded with `src`: jpeg_copy_critical_parameters
+    (jctrans.c:70-171) = library defaults for the profile + the source's size, sampling factors and
+    quantization tables, trellis off; kw = jpegtran's own switches (revert, optimize, progressive, fastcrush,
+    restart) in make_params vocabulary."""
+    nc = src.num_components
+    p = make_params(src.width, src.height, notrellis=True, gray=(nc == 1), grayin=(nc == 1),
+                    sample=(src.h_samp[0], src.v_samp[0]), precision=src.data_precision or 8, **kw)
+    for t in range(4):
+        for i in range(64):
+            p.qtbl[t][i] = src.qtbl[t][i]
+    return p
+
+
+def encode_coefficients(p, coefs):
+    """Oracle entropy-coding of existing quantized coefficients (jpeg_write_coefficients path).
+    coefs: one int16 array [hib, wib(+pad), 64] (natural order) per component."""
+    coefs = [np.ascontiguousarray(a, dtype=np.int16) for a in coefs]
+    n = len(coefs)
+    ptrs = (C.c_void_p * 4)(*[a.ctypes.data for a in coefs] + [None] * (4 - n))
+    bpr = (C.c_size_t * 4)(*[a.shape[1] for a in coefs] + [0] * (4 - n))
+    cap = p.width * p.height * 8 + 65536
+    out = np.empty(cap, np.uint8)
+    L = lib()
+    L.mjo_encode_coefficients.restype = C.c_size_t
+    L.mjo_encode_coefficients.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    nb = L.mjo_encode_coefficients(C.byref(p), ptrs, bpr, out.ctypes.data, cap)
+    assert nb > 0, "oracle coefficient encode failed"
+    return out[:nb].tobytes()
+
+
+def real_coefficients(p, taps):
+    """the real (non-dummy) blocks of an encode's final coefficients, as a transcoder would read them back"""
+    gs, _, _ = geometry(p)
+    return [taps[("coef_q", ci)][:g.hib, :g.wib].copy() for ci, g in enumerate(gs)]
+
+
+def ref_jpegtran(jpeg, switches=(), preload=None):
+    """The REAL reference jpegtran (oracle/_ref/jpegtran) on a JPEG byte string."""
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "in.jpg"), os.path.join(td, "out.jpg")
+        open(inp, "wb").write(jpeg)
+        env = dict(os.environ)
+        if preload:
+            env["LD_PRELOAD"] = preload
+        r = subprocess.run([os.path.join(REF_DIR, "jpegtran")] + list(switches) + ["-outfile", outp, inp], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
+        return open(outp, "rb").read()
+
+
 # ---- the compiled reference (oracle/_ref), where present -------------------------------------
 def have_ref():
     return os.path.exists(os.path.join(REF_DIR, "refenc"))

@@ -169,3 +169,25 @@ def test_unchanged_tjcompressfromyuv_through_the_shim(w, h, ssname, q, flags, tm
     data = open(gpu, "rb").read()
     assert data == open(ref, "rb").read()
     assert data == O.encode_planes(po, planes)
+
+
+# ---- jpegtran boundary: the reference's own jpegtran binary, unchanged, with the drop-in in
+# front: jpeg_write_coefficients (jctrans.c:44) -> GPU entropy-coding passes ---------------------------------------
+JPEGTRAN = os.path.join(O.REF_DIR, "jpegtran")
+needs_jt = pytest.mark.skipif(not (os.path.exists(SHIM) and os.path.exists(JPEGTRAN)), reason="shim or jpegtran not built")
+
+
+@needs_jt
+@pytest.mark.parametrize("src_kw", [dict(baseline=True), dict(revert=True, sample=(2, 1)), dict(baseline=True, gray=True)])
+@pytest.mark.parametrize("switches", [["-progressive"], ["-revert"], ["-revert", "-optimize"], ["-fastcrush", "-progressive"],
+                                      ["-revert", "-restart", "2"], ["-progressive", "-rotate", "90"],
+                                      ["-revert", "-optimize", "-flip", "horizontal", "-trim"]])
+def test_unchanged_jpegtran_through_the_shim(src_kw, switches):
+    """same bytes as the reference jpegtran, including after lossless transforms (which rewrite the coefficient arrays
+    between jpeg_write_coefficients and jpeg_finish_compress)"""
+    img = O.read_ppm(PPM)
+    h, w = img.shape[:2]
+    src = O.encode(O.make_params(w, h, **src_kw), img)
+    ref = O.ref_jpegtran(src, switches)
+    gpu = O.ref_jpegtran(src, switches, preload=SHIM)
+    assert gpu == ref

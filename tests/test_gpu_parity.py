@@ -185,3 +185,56 @@ def test_plane_input_of_pixel_path_planes_gives_pixel_path_file():
     planes = [enc.read_tap(M.TAP_PLANE, 0, c) for c in range(3)]
     assert enc.encode_planes_host(planes)[0] == ref
     enc.close()
+
+
+# ---- quantized coefficients in: jpeg_write_coefficients / jpegtran -------------------------
+@pytest.mark.gpu
+def test_coefficient_input_matches_jpegtran_goldens_and_oracle(fixture_images):
+    import json
+    from cases import HERE, TRANSCODE_CASES
+    g = json.load(open(os.path.join(HERE, "goldens_transcode.json")))
+    for cname, iname, src_kw, _switches, kw in TRANSCODE_CASES:
+        img = fixture_images[iname]
+        h, w = img.shape[:2]
+        ps = O.make_params(w, h, **src_kw)
+        _src, taps = O.encode(ps, img, want_taps=True)
+        coefs = O.real_coefficients(ps, taps)
+        pt = O.transcode_params(ps, **kw)
+        mp = M.make_params(w, h, notrellis=True, gray=(ps.num_components == 1), grayin=(ps.num_components == 1),
+                           sample=(ps.h_samp[0], ps.v_samp[0]), **kw)
+        for t in range(4):
+            for i in range(64):
+                mp.quantval[t][i] = ps.qtbl[t][i]
+        enc = M.Encoder(mp, max_batch=1)
+        data = enc.encode_coefficients_host(coefs)[0]
+        enc.close()
+        assert (len(data), O.md5(data)) == (g[cname]["bytes"], g[cname]["md5"]), cname
+        assert data == O.encode_coefficients(pt, coefs), cname
+
+
+@pytest.mark.gpu
+def test_coefficient_input_device_batch_1080p_and_trellis_is_refused():
+    import torch
+    w, h = 1920, 1080
+    ps = O.make_params(w, h, baseline=True, notrellis=True)
+    sets = []
+    for i in range(2):
+        _d, taps = O.encode(ps, O.synthetic_frame(w, h, 40 + i), want_taps=True)
+        sets.append(O.real_coefficients(ps, taps))
+    for kw in (dict(), dict(revert=True)):
+        pt = O.transcode_params(ps, **kw)
+        mp = M.make_params(w, h, notrellis=True, **kw)
+        for t in range(4):
+            for i in range(64):
+                mp.quantval[t][i] = ps.qtbl[t][i]
+        enc = M.Encoder(mp, max_batch=2)
+        ts = [torch.from_numpy(np.stack([s[c] for s in sets])).cuda() for c in range(3)]
+        enc.encode_coefficients_tensors(ts)
+        enc.sync()
+        for i in range(2):
+            assert enc.get_jpeg(i) == O.encode_coefficients(pt, sets[i]), (kw, i)
+        enc.close()
+    enc = M.Encoder(M.make_params(w, h, baseline=True), max_batch=1)   # trellis on
+    with pytest.raises(M.MjhError):
+        enc.encode_coefficients_host(sets[0])
+    enc.close()

@@ -100,3 +100,20 @@ def test_oracle_plane_input_equals_pixel_path_on_its_own_planes():
         data, taps = O.encode(p, img, want_taps=True)
         planes = [taps[("planes", ci)] for ci in range(3)]
         assert O.encode_planes(p, planes) == data
+
+
+def test_oracle_coefficient_input_matches_jpegtran_goldens(fixture_images):
+    """jpeg_write_coefficients path: the oracle re-encodes the coefficients of a file it made; the golden is what the
+    real jpegtran wrote for that same file (tests/golden/make_goldens.py)."""
+    import json
+    import os
+    from cases import HERE, TRANSCODE_CASES
+    g = json.load(open(os.path.join(HERE, "goldens_transcode.json")))
+    for cname, iname, src_kw, _switches, kw in TRANSCODE_CASES:
+        img = fixture_images[iname]
+        h, w = img.shape[:2]
+        ps = O.make_params(w, h, **src_kw)
+        src, taps = O.encode(ps, img, want_taps=True)
+        assert O.md5(src) == g[cname]["source_md5"], cname
+        data = O.encode_coefficients(O.transcode_params(ps, **kw), O.real_coefficients(ps, taps))
+        assert (len(data), O.md5(data)) == (g[cname]["bytes"], g[cname]["md5"]), cname
