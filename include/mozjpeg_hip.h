@@ -165,7 +165,9 @@ enum {
   MJH_TAP_COEF_Q = 3,    /* int16  [64 zig-zag][nblk] quantized (after trellis if enabled)  */
   MJH_TAP_COEF_Q0 = 4,   /* int16  quantized before trellis (kept only when debug taps on)  */
   MJH_TAP_HUFF_BITS = 5, /* uint8  [4 slots: DC0,AC0,DC1,AC1][17] final tables               */
-  MJH_TAP_HUFF_VALS = 6  /* uint8  [4][256]                                                  */
+  MJH_TAP_HUFF_VALS = 6, /* uint8  [4][256]                                                  */
+  MJH_TAP_PROG_SCAN_US = 7 /* uint32 [2][64] progressive: microseconds the statistics [0] / encode [1]
+                              workgroup of each scan-script entry ran (0 = not run)              */
 };
 int mjh_set_debug_taps(mjh_encoder *e, int on);
 int mjh_read_tap(mjh_encoder *e, int what, int image, int component, void *dst, size_t cap, size_t *size);

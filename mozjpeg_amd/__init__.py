@@ -17,7 +17,7 @@ MAX_COMPS, MAX_SCANS = 4, 64
 PROFILE_MAX_COMPRESSION = 0x5D083AAD
 PROFILE_FASTEST = 0x2AEA5CB4
 OK, EINVAL, EUNSUPPORTED, EHIP, ENOMEM, ETOOSMALL = 0, -1, -2, -3, -4, -5
-TAP_PLANE, TAP_COEF_UQ, TAP_COEF_Q, TAP_COEF_Q0, TAP_HUFF_BITS, TAP_HUFF_VALS = 1, 2, 3, 4, 5, 6
+TAP_PLANE, TAP_COEF_UQ, TAP_COEF_Q, TAP_COEF_Q0, TAP_HUFF_BITS, TAP_HUFF_VALS, TAP_PROG_SCAN_US = 1, 2, 3, 4, 5, 6, 7
 
 
 class MjhError(RuntimeError):
@@ -249,8 +249,10 @@ class Encoder:
         return tuple(x.value for x in v)  # wib, hib, pw, ph
 
     def read_tap(self, what, image=0, comp=0):
-        wib, hib, pw, ph = self.geometry(comp if what not in (TAP_HUFF_BITS, TAP_HUFF_VALS) else 0)
-        if what == TAP_PLANE:
+        wib, hib, pw, ph = self.geometry(comp if what not in (TAP_HUFF_BITS, TAP_HUFF_VALS, TAP_PROG_SCAN_US) else 0)
+        if what == TAP_PROG_SCAN_US:
+            out = np.zeros((2, 72), np.uint32)
+        elif what == TAP_PLANE:
             out = np.empty((ph, pw), np.uint8)
         elif what == TAP_HUFF_BITS:
             out = np.empty((4, 17), np.uint8)

@@ -1231,6 +1231,14 @@ extern "C" int mjh_read_tap(mjh_encoder *e, int what, int image, int comp, void 
     if (size) *size = need;
     return MJH_OK;
   }
+  if (what == MJH_TAP_PROG_SCAN_US) {
+    if (!e->progressive) return fail(MJH_EINVAL, "not a progressive encoder");
+    const size_t need = sizeof(((MjhProgCtl *)0)->scan_us);
+    if (cap < need) return fail(MJH_ETOOSMALL, "need %zu bytes", need);
+    HIPCHK(hipMemcpy(dst, (const uint8_t *)e->d_prog_ctl + (size_t)image * sizeof(MjhProgCtl) + offsetof(MjhProgCtl, scan_us), need, hipMemcpyDeviceToHost));
+    if (size) *size = need;
+    return MJH_OK;
+  }
   if (comp < 0 || comp >= C.ncomp) return fail(MJH_EINVAL, "bad component");
   const MjhComp &cc = C.c[comp];
   if (what == MJH_TAP_PLANE) {

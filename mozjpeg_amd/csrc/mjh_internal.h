@@ -124,6 +124,7 @@ struct MjhProgCtl {        // per image, lives in HBM
   int order[MJH_MAX_PROG_SCANS];               // final scan order
   int norder;
   int pad2[3];
+  unsigned scan_us[2][MJH_MAX_PROG_SCANS];     // introspection: duration of the statistics [0] / encode [1] workgroup of each scan, microseconds
 };
 
 #endif

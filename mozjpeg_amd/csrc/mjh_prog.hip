@@ -13,12 +13,16 @@
 //     phase A  every lane analyses its block in parallel (63 coalesced plane loads in one burst):
 //              own symbol bits, "non-empty" / "contributes to EOBRUN" flags; refinement scans reduce a
 //              block to four 64-bit masks (new / already-nonzero / correction bit / sign);
-//     phase B  runs in step order under a token (LDS word + state {EOBRUN, BE, bit offset}).  Inside a
+//     phase B  the state {EOBRUN, BE, bit offset} passes from step to step under a token (LDS word).  Inside a
 //              run EOBRUN and BE only grow, so if the step cannot reach a forced flush (EOBRUN < 0x7FFF
 //              and BE <= 937 at its end) every flush is the natural one in front of a non-empty lane and
-//              all offsets follow in closed form from ballots and one wave prefix sum: O(1) per step.
+//              all offsets follow in closed form from ballots and wave prefix sums.  B1 (before the token,
+//              concurrent) does all of that except the first non-empty lane's flush, the only quantity that
+//              depends on the carried-in state; B2 (under the token) is a handful of scalar operations plus,
+//              in refinement scans, the accesses to the shared LDS buffer of pending correction bits; B3
+//              (token already passed on) places the flush symbols and correction bits.
 //              Otherwise the reference's state machine is run lane by lane (ordered path), with the
-//              pending correction bits in an LDS bit buffer that is copied out at each flush;
+//              pending correction bits in the LDS bit buffer that is copied out at each flush;
 //     phase C  lanes write their own symbols (and their trailing correction bits) at their offsets
 //              (atomicOr into the zeroed pool), overlapping the next steps' phase A/B of other waves.
 // The same kernel in statistics mode feeds the on-device Huffman table builder.  All candidate
@@ -56,9 +60,12 @@ __device__ __forceinline__ int eobrun_symbol(unsigned eobrun, int *nextra)
   return nb << 4;
 }
 
-#define PROG_WAVES 8
+// waves per (scan, image) workgroup: the walk is latency-bound (one workgroup per CU, dependent LDS look-ups
+// and 63 plane loads per step), so as many waves as the register budget allows: statistics 92 VGPRs -> 16 waves
+// (4 per SIMD), encode 154 VGPRs -> 12 waves (3 per SIMD)
+#define PROG_WAVES(ENCODE) ((ENCODE) ? 12 : 16)
 template <int ENCODE>
-__global__ void __launch_bounds__(64 * PROG_WAVES)
+__global__ void __launch_bounds__(64 * PROG_WAVES(ENCODE))
 k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
             MjhProgCtl *__restrict__ ctl, const int16_t *__restrict__ coef_q, MjhHuffTable *__restrict__ tabs,
             int slots_per_image, unsigned *__restrict__ pool, size_t pool_words_per_image)
@@ -79,8 +86,9 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
   MjhHuffTable *T1 = tabs + (size_t)img * slots_per_image + (has1 ? sc.slot[1] : 0);
   unsigned *stream = pool + (size_t)img * pool_words_per_image;
   if (ENCODE && ct->error) return;
+  const unsigned long long t_start = wall_clock64();   // 100 MHz constant clock
 
-  for (int i = threadIdx.x; i < 256; i += 64 * PROG_WAVES) {
+  for (int i = threadIdx.x; i < 256; i += 64 * PROG_WAVES(ENCODE)) {
     hist[0][i] = 0; hist[1][i] = 0;
     if (ENCODE) {
       s_tab[0][i] = has0 ? ((unsigned)T0->ehufsi[i] << 16) | T0->ehufco[i] : 0u;
@@ -97,20 +105,28 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
 
   if (sc.Ss == 0) {
     // ------------------------------------------------------------------ DC scans (first / refine)
-    if (wave == 0) {
+    // No state crosses blocks except the bit offset (the predictor is simply the previous block's value), so
+    // the 64-unit steps are spread over all waves; in encode mode the offset passes along under the token.
     const bool inter = sc.ncomp > 1;
     const MjhComp c0 = C.c[sc.comp[0]];
     const int nunits = inter ? C.mcus_per_row * C.mcu_rows : c0.nblk;
-    for (int base = 0; base < nunits; base += 64) {
-      const int u = base + lane;
+    const int nsteps = (nunits + 63) >> 6;
+    for (int step = wave; step < nsteps; step += PROG_WAVES(ENCODE)) {
+      const int u = step * 64 + lane;
       const bool valid = u < nunits;
       unsigned mybits = 0;
       // pass 0: bits (or statistics); pass 1 (encode only): write
       for (int pass = 0; pass < (ENCODE ? 2 : 1); pass++) {
         BitWriter bw;
-        unsigned off = 0, tot = 0;
         if (pass == 1) {
-          off = wave_excl_scan(mybits, lane, &tot);
+          unsigned tot;
+          const unsigned off = wave_excl_scan(mybits, lane, &tot);
+          while (__hip_atomic_load(&st_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)step) __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          cur = st_cur;
+          if (lane == 0) st_cur = cur + tot;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) __hip_atomic_store(&st_turn, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           bw.init(stream, cur + off);
         }
         if (valid) {
@@ -150,10 +166,11 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
               }
           }
         }
-        if (pass == 1) { bw.flush(); cur += tot; }
+        if (pass == 1) bw.flush();
       }
     }
-    }
+    __syncthreads();
+    cur = st_cur;
   } else {
     // ------------------------------------------------------------------ AC scans (first / refine)
     const MjhComp cc = C.c[sc.comp[0]];
@@ -198,7 +215,7 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
     };
 
     const int nsteps = (cc.nblk + 63) >> 6;
-    for (int step = wave; step < nsteps; step += PROG_WAVES) {
+    for (int step = wave; step < nsteps; step += PROG_WAVES(ENCODE)) {
       const int base = step * 64;
       const int b = base + lane;
       const bool valid = b < cc.nblk;
@@ -283,111 +300,90 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
         unsigned long long tm = tailm;
         while (tm) { const int k = __builtin_ctzll(tm); tm &= tm - 1; tail_bits = (tail_bits << 1) | ((corrm >> k) & 1ull); }
       }
-      // ---- phase B (in step order: wait for the token, run, pass it on)
+      // ---- phase B1: everything that does not depend on the state carried in from earlier steps -- runs
+      // concurrently in all waves.  Inside a run EOBRUN and BE only grow, so if the step cannot reach a forced
+      // flush (checked under the token) every flush is the natural one in front of a non-empty lane and its
+      // pending state follows from the position of the previous non-empty lane: closed form, all lanes in
+      // parallel.  Only the FIRST non-empty lane's flush depends on the carried-in (EOBRUN, BE).
       const unsigned long long ne_mask = __ballot(ne), E_mask = __ballot(E);
+      unsigned tsum = 0, texcl = 0;
+      if (refine) texcl = wave_excl_scan((unsigned)tail_cnt, lane, &tsum);
+      const unsigned long long below = ne_mask & ((1ull << lane) - 1ull);
+      const int pl = below ? 63 - __builtin_clzll(below) : -1;          // previous non-empty lane
+      const unsigned texcl_pl = refine ? (unsigned)__shfl((int)texcl, pl < 0 ? 0 : pl, 64) : 0u;
+      const int f0 = ne_mask ? __builtin_ctzll(ne_mask) : 0;            // first non-empty lane
+      const unsigned texcl_f0 = refine ? (unsigned)__shfl((int)texcl, f0, 64) : 0u;
+      unsigned l_flush = 0, l_cnt = 0, l_be = 0;
+      int l_sym = 0, l_extra = 0;
+      if (ne && pl >= 0) {                                  // the run = pl's EOB + the empties between
+        l_cnt = (unsigned)((E_mask >> pl) & 1ull) + (unsigned)(lane - pl - 1);
+        l_be = texcl - texcl_pl;
+        if (l_cnt > 0) {
+          l_sym = eobrun_symbol(l_cnt, &l_extra);
+          if (ENCODE) l_flush = (s_tab[0][l_sym] >> 16) + (unsigned)l_extra + l_be;
+        }
+      }
+      unsigned l_tot;
+      const unsigned l_ex = wave_excl_scan(ne ? l_flush + own_bits : 0u, lane, &l_tot);
+      unsigned run_out = 0, be_out = 0;                     // run state behind this step's last non-empty lane
+      if (ne_mask) {
+        const int last = 63 - __builtin_clzll(ne_mask);
+        run_out = (unsigned)((E_mask >> last) & 1ull) + (unsigned)(nvalid - 1 - last);
+        if (refine) be_out = tsum - (unsigned)__shfl((int)texcl, last, 64);
+      }
+      const unsigned long long above = lane < 63 ? (ne_mask & ~((2ull << lane) - 1ull)) : 0ull;
+      const int rs = ne ? lane : pl;                        // first lane of my run (-1: carried in)
+      const unsigned rs_excl = ne ? texcl : texcl_pl;
+      // ---- phase B2 (in step order under the token): a few scalar operations in the common case
       while (__hip_atomic_load(&st_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)step) __builtin_amdgcn_s_sleep(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       EOBRUN = st_eobrun; BE = st_be; cur = st_cur;
       unsigned out_off = 0;
-      bool fast = EOBRUN + 64u < 0x7FFFu;
-      unsigned tsum = 0, texcl = 0;
-      if (refine) {
-        texcl = wave_excl_scan((unsigned)tail_cnt, lane, &tsum);
-        fast = fast && (BE + tsum <= 937u);
-      }
+      const bool fast = EOBRUN + 64u < 0x7FFFu && (!refine || BE + tsum <= 937u);
+      const unsigned cur_in = cur, BE_in = BE;
+      unsigned fb0 = 0, be0 = 0, cnt0 = 0;
+      int sym0 = 0, extra0 = 0;
       if (fast) {
-        // No forced flush can trigger inside this step (EOBRUN and BE only grow inside a run), so every
-        // flush is the natural one in front of a non-empty block and its pending state follows from the
-        // position of the previous non-empty lane: closed form, all lanes in parallel.
-        unsigned flushbits = 0, cnt = 0, be = 0;
-        int fsym = 0, fextra = 0;
-        const unsigned long long below = ne_mask & ((1ull << lane) - 1ull);
-        const int pl = below ? 63 - __builtin_clzll(below) : -1;          // previous non-empty lane
-        const unsigned texcl_pl = refine ? (unsigned)__shfl((int)texcl, pl < 0 ? 0 : pl, 64) : 0u;
-        if (ne) {
-          if (pl >= 0) {                                    // the run = pl's EOB + the empties between
-            cnt = (unsigned)((E_mask >> pl) & 1ull) + (unsigned)(lane - pl - 1);
-            be = texcl - texcl_pl;
-          } else {                                          // run carried in from earlier steps + leading empties
-            cnt = EOBRUN + (unsigned)lane;
-            be = BE + texcl;
-          }
-          if (cnt > 0) {
-            fsym = eobrun_symbol(cnt, &fextra);
-            if (!ENCODE) atomicAdd(&hist[0][fsym], 1u);
-            else flushbits = (s_tab[0][fsym] >> 16) + (unsigned)fextra + be;
+        if (ne_mask) {                                      // run carried in from earlier steps + leading empties
+          cnt0 = EOBRUN + (unsigned)f0;
+          be0 = BE + texcl_f0;
+          if (cnt0 > 0) {
+            sym0 = eobrun_symbol(cnt0, &extra0);
+            if (ENCODE) fb0 = (s_tab[0][sym0] >> 16) + (unsigned)extra0 + be0;
           }
         }
-        unsigned tot;
-        const unsigned ex = wave_excl_scan(ne ? flushbits + own_bits : 0u, lane, &tot);
-        if (ENCODE) {
-          // correction area of a flushing lane = right behind its EOBRUN symbol
-          const unsigned ca = cur + ex + (flushbits - be);
-          if (ne) {
-            if (cnt > 0) {      // the EOBRUN symbol of the pending run goes in front of the lane's own symbols
-              const unsigned e = s_tab[0][fsym];
+        if (ENCODE && refine) {
+          // the LDS buffer of pending correction bits is shared by the steps: touched only under the token
+          // (1) correction bits carried in from earlier steps: flushed behind the first non-empty lane's EOBRUN symbol
+          if (ne_mask && BE_in) {
+            const unsigned ca0 = cur_in + fb0 - be0;
+            const int nw = (int)((BE_in + 31) >> 5);
+            if (lane < nw) {
+              const int nb = (int)min(32u, BE_in - 32u * lane);
               BitWriter bw;
-              bw.init(stream, cur + ex);
-              bw.put(e & 0xFFFF, (int)(e >> 16));
-              if (fextra) bw.put(cnt & ((1u << fextra) - 1u), fextra);
+              bw.init(stream, ca0 + 32u * lane);
+              put_long(bw, pend[lane] >> (32 - nb), nb);
               bw.flush();
+              pend[lane] = 0;
             }
-            out_off = cur + ex + flushbits;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
           }
-          if (refine) {
-            // (1) correction bits carried in from earlier steps: flushed by the first non-empty lane
-            if (ne_mask && BE) {
-              const int f0 = __builtin_ctzll(ne_mask);
-              const unsigned ca0 = (unsigned)__shfl((int)ca, f0, 64);
-              const int nw = (int)((BE + 31) >> 5);
-              if (lane < nw) {
-                const int nb = (int)min(32u, BE - 32u * lane);
-                BitWriter bw;
-                bw.init(stream, ca0 + 32u * lane);
-                put_long(bw, pend[lane] >> (32 - nb), nb);
-                bw.flush();
-                pend[lane] = 0;
-              }
-              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            }
-            // (2) every lane's trailing correction bits go to the correction area of the next non-empty
-            //     lane, or into the LDS buffer if the run is still pending at the end of this step
-            const unsigned long long above = lane < 63 ? (ne_mask & ~((2ull << lane) - 1ull)) : 0ull;
-            const int fl = above ? __builtin_ctzll(above) : 0;
-            const unsigned ca_f = (unsigned)__shfl((int)ca, fl, 64);
-            const int rs = ne ? lane : pl;                  // first lane of my run (-1: carried in)
-            const unsigned rs_excl = ne ? texcl : texcl_pl;
-            const unsigned offs = rs >= 0 ? texcl - rs_excl : BE + texcl;
-            if (tail_cnt > 0) {
-              if (above) {
-                BitWriter bw;
-                bw.init(stream, ca_f + offs);
-                put_long(bw, (unsigned)(tail_bits >> 32), tail_cnt > 32 ? tail_cnt - 32 : 0);
-                put_long(bw, (unsigned)tail_bits, tail_cnt > 32 ? 32 : tail_cnt);
-                bw.flush();
-              } else {
-                unsigned pos = offs;   // relative to the pending run (the carried bits were flushed above if a non-empty lane exists)
-                int rem = tail_cnt;
-                while (rem > 0) {
-                  const int w = (int)(pos >> 5), o = (int)(pos & 31);
-                  const int take = min(32 - o, rem);
-                  const unsigned chunk = (unsigned)((tail_bits >> (rem - take)) & ((1ull << take) - 1ull));
-                  atomicOr(&pend[w], chunk << (32 - o - take));
-                  pos += take; rem -= take;
-                }
-              }
+          // (2) trailing correction bits of a run that is still pending at the end of this step
+          if (tail_cnt > 0 && !above) {
+            unsigned pos = rs >= 0 ? texcl - rs_excl : BE_in + texcl;
+            int rem = tail_cnt;
+            while (rem > 0) {
+              const int w = (int)(pos >> 5), o = (int)(pos & 31);
+              const int take = min(32 - o, rem);
+              const unsigned chunk = (unsigned)((tail_bits >> (rem - take)) & ((1ull << take) - 1ull));
+              atomicOr(&pend[w], chunk << (32 - o - take));
+              pos += take; rem -= take;
             }
           }
         }
-        cur += tot;
-        if (ne_mask) {
-          const int last = 63 - __builtin_clzll(ne_mask);
-          EOBRUN = (unsigned)((E_mask >> last) & 1ull) + (unsigned)(nvalid - 1 - last);
-          if (refine) BE = tsum - (unsigned)__shfl((int)texcl, last, 64);
-        } else {
-          EOBRUN += (unsigned)nvalid;
-          BE += tsum;
-        }
+        cur = cur_in + l_tot + fb0;
+        if (ne_mask) { EOBRUN = run_out; BE = be_out; }
+        else { EOBRUN += (unsigned)nvalid; BE += tsum; }
       } else {
       // ordered path: the reference's state machine over the 64 lane summaries (forced flushes at
       // EOBRUN == 0x7FFF and BE > 937, pending correction bits buffered in LDS)
@@ -430,6 +426,41 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
       if (lane == 0) { st_eobrun = EOBRUN; st_be = BE; st_cur = cur; }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) __hip_atomic_store(&st_turn, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // ---- phase B3 (token passed on): offsets and the writes that belong to the flushes
+      if (fast) {
+        const bool first = ne_mask && lane == f0;
+        if (!ENCODE) { if (ne && (first ? cnt0 : l_cnt) > 0) atomicAdd(&hist[0][first ? sym0 : l_sym], 1u); }
+        else {
+          const unsigned my_flush = first ? fb0 : l_flush, my_be = first ? be0 : l_be, my_cnt = first ? cnt0 : l_cnt;
+          const int my_sym = first ? sym0 : l_sym, my_extra = first ? extra0 : l_extra;
+          const unsigned pos = cur_in + ((ne_mask && lane > f0) ? fb0 : 0u) + l_ex;   // start of this lane's flush + symbols
+          const unsigned ca = pos + (my_flush - my_be);     // correction area of a flushing lane = right behind its EOBRUN symbol
+          if (ne) {
+            if (my_cnt > 0) {      // the EOBRUN symbol of the pending run goes in front of the lane's own symbols
+              const unsigned e = s_tab[0][my_sym];
+              BitWriter bw;
+              bw.init(stream, pos);
+              bw.put(e & 0xFFFF, (int)(e >> 16));
+              if (my_extra) bw.put(my_cnt & ((1u << my_extra) - 1u), my_extra);
+              bw.flush();
+            }
+            out_off = pos + my_flush;
+          }
+          if (refine) {
+            // every lane's trailing correction bits go to the correction area of the next non-empty lane
+            const int fl = above ? __builtin_ctzll(above) : 0;
+            const unsigned ca_f = (unsigned)__shfl((int)ca, fl, 64);
+            const unsigned offs = rs >= 0 ? texcl - rs_excl : BE_in + texcl;
+            if (tail_cnt > 0 && above) {
+              BitWriter bw;
+              bw.init(stream, ca_f + offs);
+              put_long(bw, (unsigned)(tail_bits >> 32), tail_cnt > 32 ? tail_cnt - 32 : 0);
+              put_long(bw, (unsigned)tail_bits, tail_cnt > 32 ? 32 : tail_cnt);
+              bw.flush();
+            }
+          }
+        }
+      }
       // ---- phase C: lanes write their own symbols
       if (ENCODE && ne) {
         BitWriter bw;
@@ -493,7 +524,7 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
   __syncthreads();
   if (!ENCODE) {
     // statistics -> table slots (+ the trellis-pass seeding of jcphuff.c:257-264)
-    for (int i = threadIdx.x; i < 256; i += 64 * PROG_WAVES) {
+    for (int i = threadIdx.x; i < 256; i += 64 * PROG_WAVES(ENCODE)) {
       unsigned s0 = hist[0][i];
       if (sc.seed && (i & 15) < 12) s0 += 1;
       if (has0) T0->counts[i] = s0;
@@ -520,6 +551,7 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
       ct->scan_bits[sidx] = tb;
     }
   }
+  if (threadIdx.x == 0) ct->scan_us[ENCODE][sidx] = (unsigned)((wall_clock64() - t_start) / 100ull);
 }
 
 // exact size of every scan's bit stream from its statistics and code lengths, and its place in the
@@ -789,6 +821,7 @@ k_prog_reset(MjhProgCtl *__restrict__ ctl, int nscans, int nimg)
   ct->pool_words_used = 0; ct->out_bytes_used = 0; ct->error = 0;
   ct->norder = nscans;
   for (int i = 0; i < nscans; i++) ct->order[i] = i;
+  for (int i = 0; i < MJH_MAX_PROG_SCANS; i++) { ct->scan_us[0][i] = 0; ct->scan_us[1][i] = 0; }
 }
 
 // =============================================================================================
@@ -802,7 +835,7 @@ void mjh_launch_prog_reset(void *ctl, int nscans, int n, hipStream_t s)
 void mjh_launch_prog_stats(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
                            MjhHuffTable *tabs, int spi, int n, hipStream_t s)
 {
-  hipLaunchKernelGGL((k_prog_scan<0>), dim3(nlist, n), dim3(64 * PROG_WAVES), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
+  hipLaunchKernelGGL((k_prog_scan<0>), dim3(nlist, n), dim3(64 * PROG_WAVES(0)), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
                      (const int16_t *)q, tabs, spi, (unsigned *)nullptr, (size_t)0);
 }
 
@@ -814,7 +847,7 @@ void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *lis
                      (const MjhHuffTable *)tabs, spi, pool_words, out_bytes, n);
   hipLaunchKernelGGL(k_prog_header, dim3(nlist, n), dim3(64), 0, s, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
                      (const MjhHuffTable *)tabs, spi, (const uint8_t *)frame_hdr, frame_hdr_len, multi_dht, (uint8_t *)outpool, out_bytes);
-  hipLaunchKernelGGL((k_prog_scan<1>), dim3(nlist, n), dim3(64 * PROG_WAVES), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
+  hipLaunchKernelGGL((k_prog_scan<1>), dim3(nlist, n), dim3(64 * PROG_WAVES(1)), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
                      (const int16_t *)q, tabs, spi, pool, pool_words);
   hipLaunchKernelGGL(k_prog_stuff, dim3(nlist, n), dim3(256), 0, s, list, (MjhProgCtl *)ctl, (const unsigned *)pool, pool_words,
                      (uint8_t *)outpool, out_bytes);
