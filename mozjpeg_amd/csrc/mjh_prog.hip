@@ -74,8 +74,10 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
   __shared__ unsigned s_tab[2][256];   // size << 16 | code
   __shared__ unsigned pend[36];        // pending correction bits, MSB first
   __shared__ unsigned st_turn, st_eobrun, st_be, st_cur;   // the token: which 64-block step may run phase B, and its state
-  const int img = blockIdx.y;
-  const int sidx = scan_list[blockIdx.x];
+  // image index fastest: the workgroups of the long scans (the luma scans lead every script) of ALL images are
+  // dispatched first and the short chroma scans fill in behind them
+  const int img = blockIdx.x;
+  const int sidx = scan_list[blockIdx.y];
   const MjhProgScan sc = scans[sidx];
   MjhProgCtl *ct = ctl + img;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -835,7 +837,7 @@ void mjh_launch_prog_reset(void *ctl, int nscans, int n, hipStream_t s)
 void mjh_launch_prog_stats(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
                            MjhHuffTable *tabs, int spi, int n, hipStream_t s)
 {
-  hipLaunchKernelGGL((k_prog_scan<0>), dim3(nlist, n), dim3(64 * PROG_WAVES(0)), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
+  hipLaunchKernelGGL((k_prog_scan<0>), dim3(n, nlist), dim3(64 * PROG_WAVES(0)), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
                      (const int16_t *)q, tabs, spi, (unsigned *)nullptr, (size_t)0);
 }
 
@@ -847,7 +849,7 @@ void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *lis
                      (const MjhHuffTable *)tabs, spi, pool_words, out_bytes, n);
   hipLaunchKernelGGL(k_prog_header, dim3(nlist, n), dim3(64), 0, s, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
                      (const MjhHuffTable *)tabs, spi, (const uint8_t *)frame_hdr, frame_hdr_len, multi_dht, (uint8_t *)outpool, out_bytes);
-  hipLaunchKernelGGL((k_prog_scan<1>), dim3(nlist, n), dim3(64 * PROG_WAVES(1)), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
+  hipLaunchKernelGGL((k_prog_scan<1>), dim3(n, nlist), dim3(64 * PROG_WAVES(1)), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
                      (const int16_t *)q, tabs, spi, pool, pool_words);
   hipLaunchKernelGGL(k_prog_stuff, dim3(nlist, n), dim3(256), 0, s, list, (MjhProgCtl *)ctl, (const unsigned *)pool, pool_words,
                      (uint8_t *)outpool, out_bytes);
