@@ -557,27 +557,29 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
 }
 
 // exact size of every scan's bit stream from its statistics and code lengths, and its place in the
-// pools.  One thread per image (a few dozen scans x 256 symbols).
-__global__ void __launch_bounds__(64)
+// pools.  One workgroup per image: wave w sizes the scans w, w+4, ... (lanes over the 256 symbols), then one
+// thread hands out the pool space in list order.
+__global__ void __launch_bounds__(256)
 k_prog_alloc(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, int nlist,
              MjhProgCtl *__restrict__ ctl, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
              size_t pool_words_per_image, size_t out_bytes_per_image, int nimg)
 {
-  const int img = blockIdx.x * 64 + threadIdx.x;
+  __shared__ unsigned long long s_bits[MJH_MAX_PROG_SCANS];
+  const int img = blockIdx.x;
   if (img >= nimg) return;
   MjhProgCtl *ct = ctl + img;
-  for (int li = 0; li < nlist; li++) {
-    const int sidx = scan_list[li];
-    const MjhProgScan sc = scans[sidx];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int li = wave; li < nlist; li += 4) {
+    const MjhProgScan sc = scans[scan_list[li]];
     unsigned long long bits = 0;
     if (sc.Ss == 0) {
       if (sc.Ah == 0) {
         for (int t = 0; t < 2; t++) {
           if (sc.slot[t] < 0) continue;
           const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + sc.slot[t];
-          for (int s = 0; s < 17; s++) bits += (unsigned long long)T->counts[s] * (T->ehufsi[s] + s);
+          if (lane < 17) bits += (unsigned long long)T->counts[lane] * (T->ehufsi[lane] + lane);
         }
-      } else {
+      } else if (lane == 0) {
         for (int ci = 0; ci < sc.ncomp; ci++) {
           const MjhComp &cc = C.c[sc.comp[ci]];
           bits += sc.ncomp > 1 ? (unsigned long long)cc.wpad * cc.hpad : (unsigned long long)cc.nblk;
@@ -585,14 +587,24 @@ k_prog_alloc(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
       }
     } else {
       const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + sc.slot[0];
-      for (int s = 0; s < 256; s++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int s = lane + 64 * j;
         const unsigned c = T->counts[s];
-        if (!c) continue;
         const int extra = (s & 15) ? (s & 15) : (s == 0xF0 ? 0 : (s >> 4));
         bits += (unsigned long long)c * (T->ehufsi[s] + extra);
       }
-      bits += T->counts[258];   // correction bits (refinement scans)
+      if (lane == 0) bits += T->counts[258];   // correction bits (refinement scans)
     }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bits += __shfl_xor(bits, o, 64);
+    if (lane == 0) s_bits[li] = bits;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int li = 0; li < nlist; li++) {
+    const int sidx = scan_list[li];
+    const unsigned long long bits = s_bits[li];
     const unsigned words = (unsigned)((bits + 7) / 32) + 2;
     ct->scan_bits[sidx] = (unsigned)bits;
     ct->scan_words_off[sidx] = ct->pool_words_used;
@@ -845,7 +857,7 @@ void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *lis
                             MjhHuffTable *tabs, int spi, unsigned *pool, size_t pool_words, const void *frame_hdr, int frame_hdr_len,
                             int multi_dht, void *outpool, size_t out_bytes, int n, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_prog_alloc, dim3((n + 63) / 64), dim3(64), 0, s, C, (const MjhProgScan *)scans, list, nlist, (MjhProgCtl *)ctl,
+  hipLaunchKernelGGL(k_prog_alloc, dim3(n), dim3(256), 0, s, C, (const MjhProgScan *)scans, list, nlist, (MjhProgCtl *)ctl,
                      (const MjhHuffTable *)tabs, spi, pool_words, out_bytes, n);
   hipLaunchKernelGGL(k_prog_header, dim3(nlist, n), dim3(64), 0, s, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
                      (const MjhHuffTable *)tabs, spi, (const uint8_t *)frame_hdr, frame_hdr_len, multi_dht, (uint8_t *)outpool, out_bytes);
