@@ -627,7 +627,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   HIPCHK_E(hipMalloc((void **)&e->d_ffsums, B * e->ff_chunks * sizeof(unsigned)));
   HIPCHK_E(hipMalloc((void **)&e->d_totals, B * sizeof(unsigned)));
   HIPCHK_E(hipMalloc((void **)&e->d_fftotals, B * sizeof(unsigned)));
-  HIPCHK_E(hipMalloc((void **)&e->d_stream, B * e->stream_words * 4));
+  HIPCHK_E(hipMalloc((void **)&e->d_stream, B * e->stream_words * 4 + 4096));   // slack: a bit writer may touch two words past its last offset
   e->out_stride = ((size_t)2048 + e->stream_words * 8 + 255) & ~(size_t)255;
   HIPCHK_E(hipMalloc((void **)&e->d_out, B * e->out_stride));
   HIPCHK_E(hipMalloc((void **)&e->d_sizes, B * sizeof(unsigned)));
@@ -1121,6 +1121,12 @@ static int fetch_sizes(mjh_encoder *e)
     for (int i = 0; i < e->last_n; i++)
       if (ctl[i].error) return fail(ctl[i].error == 1 ? MJH_ETOOSMALL : MJH_EHIP, "progressive encode of image %d failed (%s)", i,
                                     ctl[i].error == 1 ? "scan buffers exceed the bit-stream pool" : "internal: scan size prediction mismatch");
+  }
+  else {
+    std::vector<MjhImageMeta> mt(e->last_n);
+    HIPCHK(hipMemcpy(mt.data(), e->d_meta, (size_t)e->last_n * sizeof(MjhImageMeta), hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->last_n; i++)
+      if (mt[i].total_bits == 0xFFFFFFFFu) return fail(MJH_ETOOSMALL, "entropy-coded data of image %d exceeds the 2^32-bit (512 MB) offset range of one scan", i);
   }
   e->sizes_valid = true;
   return MJH_OK;

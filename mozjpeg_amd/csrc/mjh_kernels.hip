@@ -1238,6 +1238,7 @@ k_scan_sums(unsigned *__restrict__ sums, int chunks_per_image, unsigned *__restr
   const int img = blockIdx.x;
   unsigned *p = sums + (size_t)img * chunks_per_image;
   unsigned carry = 0;
+  unsigned long long wide = 0;   // bit offsets are 32-bit: a scan beyond 2^32 bits (512 MB) is reported, not wrapped silently
   int nchunks = chunks_per_image;
   if (stream_bits) {   // byte-stuffing pass: only the chunks that hold entropy-coded words were produced
     const unsigned nwords = ((((stream_bits[img] + 7) >> 3) + 3) >> 2);
@@ -1250,8 +1251,9 @@ k_scan_sums(unsigned *__restrict__ sums, int chunks_per_image, unsigned *__restr
     const unsigned ex = block_excl_scan_256(v, sh, &tot);
     if (i < nchunks) p[i] = carry + ex;
     carry += tot;
+    wide += tot;
   }
-  if (threadIdx.x == 0) totals[img] = carry;
+  if (threadIdx.x == 0) totals[img] = wide >= 0xFFF00000ull ? 0xFFFFFFFFu : carry;   // sentinel read by the host (MJH_ETOOSMALL)
 }
 
 template <class T>
@@ -1390,6 +1392,7 @@ k_zero_stream(unsigned *__restrict__ stream, size_t stream_words_per_image, cons
               const unsigned *__restrict__ seg_totals)
 {
   const int img = blockIdx.y;
+  if (totals[img] == 0xFFFFFFFFu) return;   // scan beyond the 32-bit offset range: reported by k_finish_bits, nothing to prepare
   const unsigned bits = totals[img] + (seg_totals ? seg_totals[img] : 0u);
   const unsigned nvec = ((bits >> 5) + 8) >> 2;   // uint4 units, a few words of slack for the trailing partial word
   uint4 *p = reinterpret_cast<uint4 *>(stream + (size_t)img * stream_words_per_image);
@@ -1444,6 +1447,11 @@ k_finish_bits(unsigned *__restrict__ totals, const unsigned *__restrict__ seg_to
 {
   const int img = blockIdx.x * 64 + threadIdx.x;
   if (img >= nimg) return;
+  if (totals[img] == 0xFFFFFFFFu) {   // offsets wrapped: no file (the host turns the marker into MJH_ETOOSMALL)
+    totals[img] = 0;
+    meta[img].total_bits = 0xFFFFFFFFu;
+    return;
+  }
   const unsigned tb = totals[img] + (seg_totals ? seg_totals[img] : 0u);
   totals[img] = tb;   // from here on: total bits of the scan including restart padding and markers
   meta[img].total_bits = tb;

@@ -611,7 +611,7 @@ k_prog_alloc(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
     ct->scan_out_off[sidx] = ct->out_bytes_used;
     const unsigned long long pw = (unsigned long long)ct->pool_words_used + words;
     const unsigned long long ob = (unsigned long long)ct->out_bytes_used + 1280ull + 8ull * words;
-    if (pw > pool_words_per_image || ob > out_bytes_per_image) { ct->error = 1; continue; }
+    if (pw > pool_words_per_image || pw >= (1ull << 27) || ob > out_bytes_per_image || ob >= (1ull << 32)) { ct->error = 1; continue; }   // 32-bit bit / byte offsets
     ct->pool_words_used = (unsigned)pw;
     ct->out_bytes_used = (unsigned)ob;
   }

@@ -238,3 +238,17 @@ def test_coefficient_input_device_batch_1080p_and_trellis_is_refused():
     with pytest.raises(M.MjhError):
         enc.encode_coefficients_host(sets[0])
     enc.close()
+
+
+@pytest.mark.gpu
+def test_scan_beyond_the_32bit_offset_range_is_an_error_not_a_wrapped_file():
+    """bit offsets inside one scan are 32-bit; a scan of more than 2^32 bits (a > 512 MB JPEG) must be reported"""
+    w = h = 16384
+    rng = np.random.default_rng(3)
+    tile = rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)
+    img = np.tile(tile, (h // 512, w // 512, 1))          # incompressible at q100 4:4:4: several bits per coefficient
+    enc = M.Encoder(M.make_params(w, h, quality=100, baseline=True, notrellis=True, sample=(1, 1)), max_batch=1)
+    with pytest.raises(M.MjhError) as ei:
+        enc.encode_host(img)
+    assert "2^32" in str(ei.value)
+    enc.close()
