@@ -80,12 +80,18 @@ def cpu_baseline(frame, budget_s=20.0):
             "sample": "1 encode of one %dx%d frame with oracle/libmjoracle.so (scalar C port)" % (w, h)}
 
 
+def _make_frame(w, h, seed):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    return O.synthetic_frame(w, h, seed)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
@@ -107,8 +113,20 @@ def main():
     dev = torch.device("cuda", local_rank)
     w, h, B = args.width, args.height, args.batch
 
-    # synthetic frames, different seed per frame and rank
-    frames = np.stack([O.synthetic_frame(w, h, 1234 + rank * B + i) for i in range(B)])
+    # synthetic frames, different seed per frame and rank; generated by a few worker processes
+    # (numpy takes seconds per 4K frame) -- input preparation, outside every timed region
+    seeds = [1234 + rank * B + i for i in range(B)]
+    workers = max(1, min(B, usable_cores() // max(1, world)))
+    frames = None
+    if workers > 1:
+        try:
+            import multiprocessing as mp
+            with mp.get_context("spawn").Pool(workers) as pool:
+                frames = np.stack(pool.starmap(_make_frame, [(w, h, sd) for sd in seeds]))
+        except Exception as exc:   # no worker processes available: same frames, just slower
+            print("bench: frame workers unavailable (%s), generating serially" % exc, file=sys.stderr)
+    if frames is None:
+        frames = np.stack([O.synthetic_frame(w, h, sd) for sd in seeds])
     d_frames = torch.from_numpy(frames).to(dev)
     params = M.make_params(w, h, quality=QUALITY, baseline=True)
     enc = M.Encoder(params, max_batch=B, device=local_rank)
