@@ -985,8 +985,8 @@ static int check_coef_args(mjh_encoder *e, const void *const coefs[], const size
   return MJH_OK;
 }
 
-extern "C" int mjh_encode_coefficients_device(mjh_encoder *e, const void *const d_coefs[], const size_t blocks_per_row[],
-                                              const size_t image_stride[], int n, void *stream)
+extern "C" int mjh_encode_coefficients_device(mjh_encoder *e, const void *const d_coefs[MJH_MAX_COMPS], const size_t blocks_per_row[MJH_MAX_COMPS],
+                                              const size_t image_stride[MJH_MAX_COMPS], int n, void *stream)
 {
   int rc = check_coef_args(e, d_coefs, blocks_per_row, n);
   if (rc) return rc;
@@ -1001,8 +1001,8 @@ extern "C" int mjh_encode_coefficients_device(mjh_encoder *e, const void *const 
   return run_pipeline(e, nullptr, 0, 0, n, stream ? (hipStream_t)stream : e->stream, nullptr, &cs);
 }
 
-extern "C" int mjh_encode_coefficients_host(mjh_encoder *e, const void *const coefs[], const size_t blocks_per_row[],
-                                            const size_t image_stride[], int n)
+extern "C" int mjh_encode_coefficients_host(mjh_encoder *e, const void *const coefs[MJH_MAX_COMPS], const size_t blocks_per_row[MJH_MAX_COMPS],
+                                            const size_t image_stride[MJH_MAX_COMPS], int n)
 {
   int rc = check_coef_args(e, coefs, blocks_per_row, n);
   if (rc) return rc;
@@ -1045,9 +1045,9 @@ static int check_plane_args(mjh_encoder *e, const void *const planes[], const si
   return MJH_OK;
 }
 
-extern "C" int mjh_encode_planes_device(mjh_encoder *e, const void *const d_planes[], const size_t row_pitch[],
-                                        const size_t image_stride[], const int plane_width[], const int plane_height[],
-                                        int n, void *stream)
+extern "C" int mjh_encode_planes_device(mjh_encoder *e, const void *const d_planes[MJH_MAX_COMPS], const size_t row_pitch[MJH_MAX_COMPS],
+                                        const size_t image_stride[MJH_MAX_COMPS], const int plane_width[MJH_MAX_COMPS],
+                                        const int plane_height[MJH_MAX_COMPS], int n, void *stream)
 {
   int rc = check_plane_args(e, d_planes, row_pitch, plane_width, plane_height, n);
   if (rc) return rc;
@@ -1062,8 +1062,9 @@ extern "C" int mjh_encode_planes_device(mjh_encoder *e, const void *const d_plan
   return run_pipeline(e, nullptr, 0, 0, n, stream ? (hipStream_t)stream : e->stream, &ps);
 }
 
-extern "C" int mjh_encode_planes_host(mjh_encoder *e, const void *const planes[], const size_t row_pitch[],
-                                      const size_t image_stride[], const int plane_width[], const int plane_height[], int n)
+extern "C" int mjh_encode_planes_host(mjh_encoder *e, const void *const planes[MJH_MAX_COMPS], const size_t row_pitch[MJH_MAX_COMPS],
+                                      const size_t image_stride[MJH_MAX_COMPS], const int plane_width[MJH_MAX_COMPS],
+                                      const int plane_height[MJH_MAX_COMPS], int n)
 {
   int rc = check_plane_args(e, planes, row_pitch, plane_width, plane_height, n);
   if (rc) return rc;

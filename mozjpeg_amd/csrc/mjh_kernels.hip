@@ -36,13 +36,7 @@ static constexpr ZZTab make_zz() {
   for (int i = 0; i < 64; i++) t.v[i] = z[i];
   return t;
 }
-static constexpr ZZTab make_izz() {
-  ZZTab z = make_zz(), t{};
-  for (int i = 0; i < 64; i++) t.v[z.v[i]] = i;
-  return t;
-}
 static constexpr ZZTab kZZ = make_zz();    // kZZ.v[k]  = natural index of zig-zag position k
-static constexpr ZZTab kIZZ = make_izz();  // kIZZ.v[n] = zig-zag position of natural index n
 
 // =============================================================================================
 // K1  colour conversion + chroma downsampling + edge replication  
@@ -496,7 +490,7 @@ k_stats_dc(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restr
   unsigned cnt = 0;   // lane s (< 16) counts symbol s for this wave
   for (int it = 0; it < STATS_DC_ITER; it++) {
     const int t = (blockIdx.x * STATS_DC_ITER + it) * 256 + threadIdx.x;
-    if ((blockIdx.x * STATS_DC_ITER + it) * 256 >= nitems) break;   // uniform
+    if ((int)(blockIdx.x * STATS_DC_ITER + it) * 256 >= nitems) break;   // uniform
     int nb = -1;
     if (t < nitems) {
       int dc, pred = 0;
