@@ -233,6 +233,8 @@ struct mjh_encoder {
   uint8_t *h_pix = nullptr;        // pinned host staging
   uint8_t *d_plin = nullptr, *h_plin = nullptr;   // the same for mjh_encode_planes_host
   uint8_t *d_cfin = nullptr, *h_cfin = nullptr;   // and for mjh_encode_coefficients_host
+  unsigned *d_prog_mpos = nullptr;                // progressive + restart intervals: byte positions of the RSTn markers of every scan
+  int mpos_per_image = 0;
   size_t pix_image_bytes = 0;
   uint8_t *d_planes = nullptr;
   int16_t *d_uq = nullptr, *d_q = nullptr, *d_q0 = nullptr;
@@ -321,7 +323,7 @@ static int check_supported(const mjh_params *p)
   if (p->num_scans > 0) {
     // progressive mode: the checks of validate_script (jcmaster.c:269-432) that matter here
     if (!p->optimize_coding) return fail(MJH_EUNSUPPORTED, "progressive mode forces optimize_coding (jcmaster.c:1091-1094)");
-    if (p->restart_interval || p->restart_in_rows) return fail(MJH_EUNSUPPORTED, "restart intervals in progressive mode are not on the GPU path yet");
+
     for (int i = 0; i < p->num_components; i++)
       if (p->dc_tbl_no[i] > 1 || p->ac_tbl_no[i] > 1) return fail(MJH_EUNSUPPORTED, "progressive mode: table numbers 0/1 only");
     if (p->optimize_scans) {
@@ -550,7 +552,7 @@ static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *ptrs[] = { e->d_pix, e->d_plin, e->d_cfin, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pix, e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -745,6 +747,26 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       d.ncomp = 1; d.comp[0] = c; d.Ss = 1; d.Se = 63; d.Ah = 0; d.Al = 0;   // jcmaster.c:462-466, T15
       d.slot[0] = 2 * c + 1; d.slot[1] = -1; d.seed = 1;
     }
+    // restart intervals are a per-scan quantity (per_scan_setup jcmaster.c:595-600, T10): `restart_in_rows` rows of the
+    // SCAN's MCUs (a single-component scan's MCU is one block, its row is width_in_blocks blocks), capped at 65535
+    {
+      int last_ri = 0, total = 0;   // write_file_header resets last_restart_interval to 0 (jcmarker.c:660)
+      for (size_t si = 0; si < ps.size(); si++) {
+        MjhProgScan &d = ps[si];
+        const MjhComp &c0 = C.c[d.comp[0]];
+        const long units = d.ncomp > 1 ? (long)C.mcus_per_row * C.mcu_rows : (long)c0.nblk;
+        const long per_row = d.ncomp > 1 ? C.mcus_per_row : c0.wib;
+        long ri = p->restart_interval;
+        if (p->restart_in_rows > 0) { ri = (long)p->restart_in_rows * per_row; if (ri > 65535L) ri = 65535L; }
+        d.ri = (int)ri;
+        d.nrst = ri > 0 && units > 0 ? (int)((units - 1) / ri) : 0;
+        d.mpos_off = total;
+        total += d.nrst;
+        if ((int)si < p->num_scans) { d.emit_dri = d.ri != last_ri; last_ri = d.ri; }   // the trellis statistics scans write no header
+      }
+      e->mpos_per_image = total;
+      HIPCHK_E(hipMalloc((void **)&e->d_prog_mpos, (B * (size_t)total + 16) * sizeof(unsigned)));
+    }
     HIPCHK_E(hipMalloc(&e->d_prog_scans, ps.size() * sizeof(MjhProgScan)));
     HIPCHK_E(hipMemcpy(e->d_prog_scans, ps.data(), ps.size() * sizeof(MjhProgScan), hipMemcpyHostToDevice));
     HIPCHK_E(hipMalloc(&e->d_prog_ctl, B * sizeof(MjhProgCtl)));
@@ -777,7 +799,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     e->pool_words = e->stream_words * (p->optimize_scans ? 8 : 2);
     if (e->pool_words > ((size_t)1 << 27)) e->pool_words = (size_t)1 << 27;   // 32-bit bit offsets
     e->outpool_bytes = (size_t)1280 * (p->num_scans + 1) + 8 * e->pool_words;
-    HIPCHK_E(hipMalloc((void **)&e->d_pool, B * e->pool_words * 4));
+    HIPCHK_E(hipMalloc((void **)&e->d_pool, B * e->pool_words * 4 + 4096));   // slack: a bit writer may touch two words past its last offset
     HIPCHK_E(hipMalloc((void **)&e->d_outpool, B * e->outpool_bytes));
   }
   HIPCHK_E(hipDeviceSynchronize());
@@ -866,7 +888,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       // progressive: the trellis passes gather AC-first statistics (Ss=1, Se=63, Al=0, seeded counts,
       // jcphuff.c:257-264); the DC rate table stays the STANDARD table
       pr.mark("prog_stats(pre-trellis)");
-      mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + e->pl_trellis.scan_off, e->pl_trellis.nscan, e->d_prog_ctl, e->d_q, e->d_tabs, spi, n, s);
+      mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + e->pl_trellis.scan_off, e->pl_trellis.nscan, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
       pr.mark("gen_tables(trellis)");
       mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + e->pl_trellis.slot_off, e->pl_trellis.nslot, n, s);
       for (int i = 0; i < 4; i++) tr_dc[i] = fin_dc[i];
@@ -902,12 +924,13 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     for (int ph = 0; ph < e->nphases; ph++) {
       const mjh_encoder::PList &pl = e->pl_phase[ph];
       pr.mark(ph == 0 ? "prog_stats(A)" : "prog_stats(B)");
-      mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + pl.scan_off, pl.nscan, e->d_prog_ctl, e->d_q, e->d_tabs, spi, n, s);
+      mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + pl.scan_off, pl.nscan, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
       pr.mark(ph == 0 ? "gen_tables(A)" : "gen_tables(B)");
       mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + pl.slot_off, pl.nslot, n, s);
       pr.mark(ph == 0 ? "prog_encode(A)" : "prog_encode(B)");
       mjh_launch_prog_encode(C, e->d_prog_scans, e->d_lists + pl.scan_off, pl.nscan, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_pool, e->pool_words,
-                             e->d_frame_hdr, e->frame_hdr_len, p.compress_profile != MJH_PROFILE_FASTEST, e->d_outpool, e->outpool_bytes, n, s);
+                             e->d_frame_hdr, e->frame_hdr_len, p.compress_profile != MJH_PROFILE_FASTEST, e->d_outpool, e->outpool_bytes,
+                             e->d_prog_mpos, e->mpos_per_image, n, s);
       if (p.optimize_scans) { pr.mark("prog_select"); mjh_launch_prog_select(e->d_prog_ctl, C.ncomp, ph, n, s); }
     }
     pr.mark("prog_concat");

@@ -108,6 +108,10 @@ struct MjhProgScan {
   int frame_header;        // 1: this scan's buffer starts with DQT + SOF (scan 0)
   int ndht;                // tables to emit in the scan's DHT, in order
   int dht_slot[2], dht_id[2];
+  // restart intervals of THIS scan (per_scan_setup jcmaster.c:595-600, T10): ri in the scan's MCUs (= blocks for a
+  // single-component scan), nrst markers, their byte positions at mpos_off in the image's marker-position list
+  int ri, nrst, mpos_off;
+  int emit_dri;            // write_scan_header jcmarker.c:778-781: DRI when the interval differs from the previous scan's
 };
 
 struct MjhProgCtl {        // per image, lives in HBM

@@ -26,10 +26,10 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
 // progressive mode (mjh_prog.hip)
 void mjh_launch_prog_reset(void *ctl, int nscans, int n, hipStream_t s);
 void mjh_launch_prog_stats(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
-                           MjhHuffTable *tabs, int spi, int n, hipStream_t s);
+                           MjhHuffTable *tabs, int spi, unsigned *mpos, int mpos_per_image, int n, hipStream_t s);
 void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
                             MjhHuffTable *tabs, int spi, unsigned *pool, size_t pool_words, const void *frame_hdr, int frame_hdr_len,
-                            int multi_dht, void *outpool, size_t out_bytes, int n, hipStream_t s);
+                            int multi_dht, void *outpool, size_t out_bytes, unsigned *mpos, int mpos_per_image, int n, hipStream_t s);
 void mjh_launch_prog_select(void *ctl, int ncomp, int phase, int n, hipStream_t s);
 void mjh_launch_prog_concat(const void *ctl, const void *file_hdr, int file_hdr_len, const void *outpool, size_t out_bytes,
                             void *out, size_t out_stride, unsigned *sizes, int n, hipStream_t s);

@@ -68,7 +68,8 @@ template <int ENCODE>
 __global__ void __launch_bounds__(64 * PROG_WAVES(ENCODE))
 k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
             MjhProgCtl *__restrict__ ctl, const int16_t *__restrict__ coef_q, MjhHuffTable *__restrict__ tabs,
-            int slots_per_image, unsigned *__restrict__ pool, size_t pool_words_per_image)
+            int slots_per_image, unsigned *__restrict__ pool, size_t pool_words_per_image,
+            unsigned *__restrict__ mpos_pool, int mpos_per_image)
 {
   __shared__ unsigned hist[2][256];
   __shared__ unsigned s_tab[2][256];   // size << 16 | code
@@ -87,6 +88,8 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
   MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + (has0 ? sc.slot[0] : 0);
   MjhHuffTable *T1 = tabs + (size_t)img * slots_per_image + (has1 ? sc.slot[1] : 0);
   unsigned *stream = pool + (size_t)img * pool_words_per_image;
+  unsigned *mp = mpos_pool + (size_t)img * mpos_per_image + sc.mpos_off;   // byte positions of this scan's RSTn markers
+  const int ri = sc.ri;
   if (ENCODE && ct->error) return;
   const unsigned long long t_start = wall_clock64();   // 100 MHz constant clock
 
@@ -117,16 +120,45 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
       const int u = step * 64 + lane;
       const bool valid = u < nunits;
       unsigned mybits = 0;
+      // emit_restart jcphuff.c:438-465 in front of unit u: the DC predictions restart at 0, the bit stream is padded
+      // to a byte and RSTn follows
+      const bool rst_here = ri && u > 0 && (u % ri) == 0;
+      const int last_u = min(step * 64 + 63, nunits - 1), mrst = ri ? (last_u / ri) * ri : 0;
+      const bool step_has_rst = ri && mrst > 0 && mrst >= step * 64;
       // pass 0: bits (or statistics); pass 1 (encode only): write
       for (int pass = 0; pass < (ENCODE ? 2 : 1); pass++) {
         BitWriter bw;
         if (pass == 1) {
           unsigned tot;
-          const unsigned off = wave_excl_scan(mybits, lane, &tot);
+          unsigned off = wave_excl_scan(mybits, lane, &tot);
           while (__hip_atomic_load(&st_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)step) __builtin_amdgcn_s_sleep(1);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
           cur = st_cur;
-          if (lane == 0) st_cur = cur + tot;
+          unsigned cur_out = cur + tot;
+          if (step_has_rst) {       // offsets depend on the byte alignment at every marker: walk the units in order
+            unsigned c2 = cur;
+            off = 0;
+            for (int j = 0; j <= last_u - step * 64; j++) {
+              const int uj = step * 64 + j;
+              if (uj > 0 && (uj % ri) == 0) {
+                const unsigned pad = (8u - (c2 & 7u)) & 7u;
+                const int idx = uj / ri - 1;
+                if (lane == 0) {
+                  BitWriter mw;
+                  mw.init(stream, c2);
+                  if (pad) mw.put((1u << pad) - 1u, (int)pad);
+                  mw.put(0xFFD0u + (unsigned)(idx & 7), 16);
+                  mw.flush();
+                  mp[idx] = (c2 + pad - start_bits) >> 3;
+                }
+                c2 += pad + 16u;
+              }
+              if (lane == j) off = c2 - cur;
+              c2 += (unsigned)__builtin_amdgcn_readlane((int)mybits, j);
+            }
+            cur_out = c2;
+          }
+          if (lane == 0) st_cur = cur_out;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           if (lane == 0) __hip_atomic_store(&st_turn, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           bw.init(stream, cur + off);
@@ -145,10 +177,11 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
                   const int r = my * cc.v + yi, c = mx * cc.h + xi;
                   dc = q0[dc_source_block(cc, r, c)];
                   int pr, pc;
-                  if (sc.Ah == 0 && mcu_prev_block(C, cc, r, c, pr, pc)) pred = q0[dc_source_block(cc, pr, pc)] >> Al;
+                if (sc.Ah == 0 && mcu_prev_block(C, cc, r, c, pr, pc) && !(rst_here && yi == 0 && xi == 0))
+                    pred = q0[dc_source_block(cc, pr, pc)] >> Al;
                 } else {
                   dc = q0[u];
-                  if (sc.Ah == 0 && u > 0) pred = q0[u - 1] >> Al;
+                  if (sc.Ah == 0 && u > 0 && !rst_here) pred = q0[u - 1] >> Al;
                 }
                 if (sc.Ah == 0) {                       // encode_mcu_DC_first
                   const int v = dc >> Al;               // arithmetic shift = point transform
@@ -214,6 +247,23 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
       }
       EOBRUN = 0;
       BE = 0;
+    };
+
+    // emit_restart jcphuff.c:438-465 in front of block bj: pending EOB run out, pad to a byte, RSTn, run state cleared
+    auto do_restart = [&](int idx) {
+      if (EOBRUN > 0) flush_run();
+      if (ENCODE) {
+        const unsigned pad = (8u - (cur & 7u)) & 7u;
+        if (lane == 0) {
+          BitWriter mw;
+          mw.init(stream, cur);
+          if (pad) mw.put((1u << pad) - 1u, (int)pad);
+          mw.put(0xFFD0u + (unsigned)(idx & 7), 16);
+          mw.flush();
+          mp[idx] = (cur + pad - start_bits) >> 3;
+        }
+        cur += pad + 16u;
+      }
     };
 
     const int nsteps = (cc.nblk + 63) >> 6;
@@ -341,7 +391,9 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       EOBRUN = st_eobrun; BE = st_be; cur = st_cur;
       unsigned out_off = 0;
-      const bool fast = EOBRUN + 64u < 0x7FFFu && (!refine || BE + tsum <= 937u);
+      const int mrst = ri ? ((base + nvalid - 1) / ri) * ri : 0;          // a restart boundary inside this step?
+      const bool step_has_rst = ri && mrst > 0 && mrst >= base;
+      const bool fast = EOBRUN + 64u < 0x7FFFu && (!refine || BE + tsum <= 937u) && !step_has_rst;
       const unsigned cur_in = cur, BE_in = BE;
       unsigned fb0 = 0, be0 = 0, cnt0 = 0;
       int sym0 = 0, extra0 = 0;
@@ -392,6 +444,7 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
 #pragma nounroll
       for (int j = 0; j < nvalid; j++) {
         const bool ne_j = (ne_mask >> j) & 1ull, E_j = (E_mask >> j) & 1ull;
+        if (step_has_rst && base + j > 0 && ((base + j) % ri) == 0) do_restart((base + j) / ri - 1);
         if (!ne_j && !E_j) continue;
         const unsigned own_j = (unsigned)__builtin_amdgcn_readlane((int)own_bits, j);
         if (ne_j) {
@@ -549,7 +602,9 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
         const unsigned padbits = 8u - (tb & 7u), bitpos = cur & 31u;
         atomicOr(&stream[cur >> 5], __builtin_bswap32(((1u << padbits) - 1u) << (32u - bitpos - padbits)));
       }
-      if (ct->scan_bits[sidx] != tb) ct->error = 2;   // the size predicted from the statistics must be exact
+      // the size predicted from the statistics must be exact; with restart markers the pads (0..7 bits each) are
+      // only bounded, so the prediction is an upper bound there
+      if (sc.nrst ? tb > ct->scan_bits[sidx] : ct->scan_bits[sidx] != tb) ct->error = 2;
       ct->scan_bits[sidx] = tb;
     }
   }
@@ -598,7 +653,7 @@ k_prog_alloc(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) bits += __shfl_xor(bits, o, 64);
-    if (lane == 0) s_bits[li] = bits;
+    if (lane == 0) s_bits[li] = bits + 23ull * (unsigned long long)sc.nrst;   // per RSTn: up to 7 pad bits + 16
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
@@ -655,10 +710,11 @@ k_prog_header(const MjhProgScan *__restrict__ scans, const int *__restrict__ sca
     for (int j = lane; j < n; j += 64) o[pos + 17 + j] = T->huffval[j];
     pos += 17 + n;
   }
-  if (lane == 0) {     // emit_sos jcmarker.c:494-531
+  if (lane == 0) {     // emit_dri jcmarker.c:404-414 (only when the interval changes, :778-781), emit_sos :494-531
     const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
     uint8_t *s = o + pos;
     int k = 0;
+    if (sc.emit_dri) { s[k++] = 0xFF; s[k++] = 0xDD; s[k++] = 0; s[k++] = 4; s[k++] = (uint8_t)(sc.ri >> 8); s[k++] = (uint8_t)sc.ri; }
     s[k++] = 0xFF; s[k++] = 0xDA;
     const int len = 2 * sc.ncomp + 2 + 1 + 3;
     s[k++] = (uint8_t)(len >> 8); s[k++] = (uint8_t)len;
@@ -671,13 +727,27 @@ k_prog_header(const MjhProgScan *__restrict__ scans, const int *__restrict__ sca
 
 // byte stuffing of one scan's bit stream into its buffer; one workgroup per (scan, image)
 __global__ void __launch_bounds__(256)
-k_prog_stuff(const int *__restrict__ scan_list, MjhProgCtl *__restrict__ ctl, const unsigned *__restrict__ pool,
-             size_t pool_words_per_image, uint8_t *__restrict__ outpool, size_t out_bytes_per_image)
+k_prog_stuff(const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, MjhProgCtl *__restrict__ ctl,
+             const unsigned *__restrict__ pool, size_t pool_words_per_image, uint8_t *__restrict__ outpool,
+             size_t out_bytes_per_image, const unsigned *__restrict__ mpos_pool, int mpos_per_image)
 {
   __shared__ unsigned sh[4];
   const int img = blockIdx.y;
   const int sidx = scan_list[blockIdx.x];
   MjhProgCtl *ct = ctl + img;
+  const int nrst = scans[sidx].nrst;
+  const unsigned *mp = mpos_pool + (size_t)img * mpos_per_image + scans[sidx].mpos_off;
+  // the 0xFF of an RSTn marker is not entropy-coded data: no zero byte behind it (binary search in the sorted positions)
+  auto is_marker = [&](unsigned pos) {
+    int lo = 0, hi = nrst - 1;
+    while (lo <= hi) {
+      const int mid = (lo + hi) >> 1;
+      const unsigned v = mp[mid];
+      if (v == pos) return true;
+      if (v < pos) lo = mid + 1; else hi = mid - 1;
+    }
+    return false;
+  };
   if (ct->error) return;
   const unsigned nbytes = (ct->scan_bits[sidx] + 7) >> 3;
   const unsigned nwords = (nbytes + 3) >> 2;
@@ -692,6 +762,11 @@ k_prog_stuff(const int *__restrict__ scan_list, MjhProgCtl *__restrict__ ctl, co
     for (int i = 0; i < 8; i++) {
       w[i] = base + i < nwords ? p[base + i] : 0u;
       s += ((w[i] & 0xFFu) == 0xFFu) + ((w[i] & 0xFF00u) == 0xFF00u) + ((w[i] & 0xFF0000u) == 0xFF0000u) + ((w[i] & 0xFF000000u) == 0xFF000000u);
+      if (nrst) {
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+          if (((w[i] >> (8 * b)) & 0xFFu) == 0xFFu && is_marker((base + i) * 4 + b)) s--;
+      }
     }
     unsigned tot;
     unsigned ex = block_excl_scan_256(s, sh, &tot) + carry;
@@ -705,7 +780,7 @@ k_prog_stuff(const int *__restrict__ scan_list, MjhProgCtl *__restrict__ ctl, co
           const unsigned byte = (w[i] >> (8 * b)) & 0xFF;
           if (wi * 4 + b < nbytes) {
             o[dst++] = (uint8_t)byte;
-            if (byte == 0xFF) { o[dst++] = 0; ex++; }
+            if (byte == 0xFF && !(nrst && is_marker(wi * 4 + b))) { o[dst++] = 0; ex++; }
           }
         }
       }
@@ -847,24 +922,24 @@ void mjh_launch_prog_reset(void *ctl, int nscans, int n, hipStream_t s)
 }
 
 void mjh_launch_prog_stats(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
-                           MjhHuffTable *tabs, int spi, int n, hipStream_t s)
+                           MjhHuffTable *tabs, int spi, unsigned *mpos, int mpos_per_image, int n, hipStream_t s)
 {
   hipLaunchKernelGGL((k_prog_scan<0>), dim3(n, nlist), dim3(64 * PROG_WAVES(0)), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
-                     (const int16_t *)q, tabs, spi, (unsigned *)nullptr, (size_t)0);
+                     (const int16_t *)q, tabs, spi, (unsigned *)nullptr, (size_t)0, mpos, mpos_per_image);
 }
 
 void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
                             MjhHuffTable *tabs, int spi, unsigned *pool, size_t pool_words, const void *frame_hdr, int frame_hdr_len,
-                            int multi_dht, void *outpool, size_t out_bytes, int n, hipStream_t s)
+                            int multi_dht, void *outpool, size_t out_bytes, unsigned *mpos, int mpos_per_image, int n, hipStream_t s)
 {
   hipLaunchKernelGGL(k_prog_alloc, dim3(n), dim3(256), 0, s, C, (const MjhProgScan *)scans, list, nlist, (MjhProgCtl *)ctl,
                      (const MjhHuffTable *)tabs, spi, pool_words, out_bytes, n);
   hipLaunchKernelGGL(k_prog_header, dim3(nlist, n), dim3(64), 0, s, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
                      (const MjhHuffTable *)tabs, spi, (const uint8_t *)frame_hdr, frame_hdr_len, multi_dht, (uint8_t *)outpool, out_bytes);
   hipLaunchKernelGGL((k_prog_scan<1>), dim3(n, nlist), dim3(64 * PROG_WAVES(1)), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
-                     (const int16_t *)q, tabs, spi, pool, pool_words);
-  hipLaunchKernelGGL(k_prog_stuff, dim3(nlist, n), dim3(256), 0, s, list, (MjhProgCtl *)ctl, (const unsigned *)pool, pool_words,
-                     (uint8_t *)outpool, out_bytes);
+                     (const int16_t *)q, tabs, spi, pool, pool_words, mpos, mpos_per_image);
+  hipLaunchKernelGGL(k_prog_stuff, dim3(nlist, n), dim3(256), 0, s, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl, (const unsigned *)pool,
+                     pool_words, (uint8_t *)outpool, out_bytes, (const unsigned *)mpos, mpos_per_image);
 }
 
 void mjh_launch_prog_select(void *ctl, int ncomp, int phase, int n, hipStream_t s)

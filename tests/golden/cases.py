@@ -48,6 +48,13 @@ CASES = [
     ("q85_420_progressive", dict(quality=85), True),
     ("revert_progressive", dict(revert=True, progressive=True), True),
     ("q5_16bit_tables", dict(quality=5, fastcrush=True), True),
+    # restart intervals inside progressive scans (emit_restart jcphuff.c:438; per-scan interval T10, DRI per scan)
+    ("prog_search_restart1", dict(restart=1), True),
+    ("fastcrush_restart2", dict(fastcrush=True, restart=2), True),
+    ("revert_prog_restart3b", dict(revert=True, progressive=True, restart="3b"), True),
+    ("fastcrush_444_restart1", dict(fastcrush=True, restart=1, sample=(1, 1)), True),
+    ("gray_prog_restart1", dict(gray=True, restart=1), True),
+    ("prog_notrellis_restart7b", dict(notrellis=True, restart="7b"), True),
 ]
 
 

@@ -36,6 +36,9 @@ CJPEG_CASES = [
     ("fastcrush", ["-quality", "75", "-fastcrush", "-sample", "2x2"]),
     ("q85_420_progressive", ["-quality", "85", "-sample", "2x2"]),
     ("revert_progressive", ["-revert", "-progressive", "-quality", "75", "-sample", "2x2"]),
+    ("prog_search_restart1", ["-quality", "75", "-restart", "1", "-sample", "2x2"]),      # restart markers inside progressive scans
+    ("fastcrush_restart2", ["-quality", "75", "-fastcrush", "-restart", "2", "-sample", "2x2"]),
+    ("revert_prog_restart3b", ["-revert", "-progressive", "-quality", "75", "-restart", "3B", "-sample", "2x2"]),
 ]
 
 
@@ -180,7 +183,7 @@ needs_jt = pytest.mark.skipif(not (os.path.exists(SHIM) and os.path.exists(JPEGT
 @needs_jt
 @pytest.mark.parametrize("src_kw", [dict(baseline=True), dict(revert=True, sample=(2, 1)), dict(baseline=True, gray=True)])
 @pytest.mark.parametrize("switches", [["-progressive"], ["-revert"], ["-revert", "-optimize"], ["-fastcrush", "-progressive"],
-                                      ["-revert", "-restart", "2"], ["-progressive", "-rotate", "90"],
+                                      ["-revert", "-restart", "2"], ["-progressive", "-restart", "1"], ["-progressive", "-rotate", "90"],
                                       ["-revert", "-optimize", "-flip", "horizontal", "-trim"]])
 def test_unchanged_jpegtran_through_the_shim(src_kw, switches):
     """same bytes as the reference jpegtran, including after lossless transforms (which rewrite the coefficient arrays
