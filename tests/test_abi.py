@@ -59,7 +59,12 @@ def _gpu_present():
 
 
 def test_unsupported_configurations_are_errors_not_fallbacks():
-    p = M.make_params(64, 64, fastcrush=True, restart=1)   # restart intervals in progressive mode: not on the GPU path yet
+    p = M.make_params(64, 64, baseline=True, precision=12)  # 12-bit + trellis: the reference itself aborts
+    with pytest.raises(M.MjhError) as ei:
+        M.Encoder(p)
+    assert ei.value.code == M.EUNSUPPORTED
+    p = M.make_params(64, 64, baseline=True, sample=(2, 2))
+    p.h_samp_factor[1] = 2                                  # chroma sampling other than 1x1
     with pytest.raises(M.MjhError) as ei:
         M.Encoder(p)
     assert ei.value.code == M.EUNSUPPORTED
