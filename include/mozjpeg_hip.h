@@ -85,6 +85,10 @@ typedef struct {
    * J12SAMPLE).  row_pitch / image_stride stay in BYTES.  Trellis quantization has no 12-bit reference
    * behaviour (jccoefct.c:132-138) and is rejected. */
   int data_precision;
+  /* JINT_TRELLIS_NUM_LOOPS (jpeglib.h:345, default 1, 0 is read as 1): (statistics, trellis) pass pairs per component,
+   * each trellis pass restarting from the unquantized coefficients with the tables of the previous result
+   * (jcmaster.c:451-466, :1128-1138) */
+  int trellis_num_loops;
 } mjh_params;
 
 typedef struct mjh_encoder mjh_encoder;

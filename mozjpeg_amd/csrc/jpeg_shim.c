@@ -140,7 +140,8 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
   if (jpeg_c_get_bool_param(cinfo, JBOOLEAN_TRELLIS_EOB_OPT)) return "trellis_eob_opt";
   if (jpeg_c_get_bool_param(cinfo, JBOOLEAN_USE_SCANS_IN_TRELLIS)) return "use_scans_in_trellis";
   if (jpeg_c_get_bool_param(cinfo, JBOOLEAN_TRELLIS_Q_OPT)) return "trellis_q_opt";
-  if (jpeg_c_get_int_param(cinfo, JINT_TRELLIS_NUM_LOOPS) != 1) return "trellis_num_loops != 1";
+  p->trellis_num_loops = jpeg_c_get_int_param(cinfo, JINT_TRELLIS_NUM_LOOPS);
+  if (p->trellis_num_loops < 1 || p->trellis_num_loops > 16) return "trellis_num_loops outside 1..16";
   if (jpeg_c_get_float_param(cinfo, JFLOAT_TRELLIS_DELTA_DC_WEIGHT) != 0.0f) return "trellis_delta_dc_weight";
   if (p->trellis_quant && !p->optimize_coding) return "trellis without optimize_coding";
   p->restart_interval = cinfo->restart_interval;

@@ -115,6 +115,7 @@ extern "C" int mjh_params_defaults(mjh_params *p, int width, int height, int inp
   p->overshoot_deringing = maxc;    // :463
   p->lambda_log_scale1 = 14.75f;    // :507-508
   p->lambda_log_scale2 = 16.5f;
+  p->trellis_num_loops = 1;         // :515
   p->write_JFIF_header = 1;
   return mjh_params_set_quality(p, 75, 1, -1);
 }
@@ -295,6 +296,7 @@ static int check_supported(const mjh_params *p)
   if (p->image_width <= 0 || p->image_height <= 0 || p->image_width > 65500 || p->image_height > 65500)
     return fail(MJH_EINVAL, "bad image size %dx%d", p->image_width, p->image_height);
   if (p->data_precision != 0 && p->data_precision != 8 && p->data_precision != 12) return fail(MJH_EUNSUPPORTED, "data_precision %d", p->data_precision);
+  if (p->trellis_num_loops < 0 || p->trellis_num_loops > 16) return fail(MJH_EINVAL, "trellis_num_loops %d (0..16)", p->trellis_num_loops);
   if (p->data_precision == 12 && p->trellis_quant)
     return fail(MJH_EUNSUPPORTED, "trellis quantization is 8-bit only in the reference (jccoefct.c:132-138: 12-bit + trellis aborts)");
   if (p->input_components != 1 && p->input_components != 3) return fail(MJH_EUNSUPPORTED, "input_components %d (RGB or gray only)", p->input_components);
@@ -873,7 +875,13 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     mjh_launch_prog_reset(e->d_prog_ctl, e->nscans, n, s);
     HIPCHK(hipMemsetAsync(e->d_pool, 0, (size_t)n * e->pool_words * 4, s));
   }
-  if (p.trellis_quant) {
+  // trellis_num_loops (statistics, trellis) rounds (jcmaster.c:451-466): every round gathers the statistics of the
+  // current quantized coefficients and re-runs the trellis from the unquantized ones (components are independent,
+  // so doing all of them per round equals the reference's component-major order)
+  const int nloops = p.trellis_quant ? (p.trellis_num_loops > 1 ? p.trellis_num_loops : 1) : 0;
+  for (int loop = 0; loop < nloops; loop++) {
+    if (loop > 0)   // fresh (zero) statistics for this round
+      HIPCHK(hipMemcpyAsync(e->d_tabs, e->d_tabs_init, (size_t)n * spi * sizeof(MjhHuffTable), hipMemcpyDeviceToDevice, s));
     if (!e->progressive) {
       // passes 0,2,4 of SURVEY 3.3 (statistics of the conventionally quantized component) ...
       pr.mark("stats_ac(pre-trellis)");
@@ -893,7 +901,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + e->pl_trellis.slot_off, e->pl_trellis.nslot, n, s);
       for (int i = 0; i < 4; i++) tr_dc[i] = fin_dc[i];
     }
-    if (e->debug_taps) {
+    if (e->debug_taps && loop == 0) {
       if (!e->d_q0) HIPCHK(hipMalloc((void **)&e->d_q0, (size_t)e->max_batch * C.coefs_per_image * 2));
       HIPCHK(hipMemcpyAsync(e->d_q0, e->d_q, (size_t)n * C.coefs_per_image * 2, hipMemcpyDeviceToDevice, s));
     }

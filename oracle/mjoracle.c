@@ -1437,12 +1437,18 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
       memset(&ms, 0, sizeof(ms));
       ms.comps_in_scan = 1; ms.component_index[0] = ci;
       ms.Ss = 1; ms.Se = 63; ms.Ah = 0; ms.Al = 0;
+      int loop;
       setup_scan(&e, &sc, &ms);
-      gather_and_build(&e, &sc, 1);
-      make_derived(&e.dc[p->dc_tbl_no[ci]], &dcd);
-      make_derived(&e.ac[p->ac_tbl_no[ci]], &acd);
-      trellis_component(&e, ci, &dcd, &acd);
-      gather_and_build(&e, &sc, 1);
+      /* trellis_num_loops (gather, trellis) pass pairs per component: pass_number / (2 * trellis_num_loops) selects
+       * the component (jcmaster.c:462-466); every trellis pass restarts from the unquantized coefficients with the
+       * tables gathered from the previous loop's result */
+      for (loop = 0; loop < (p->trellis_num_loops > 1 ? p->trellis_num_loops : 1); loop++) {
+        gather_and_build(&e, &sc, 1);
+        make_derived(&e.dc[p->dc_tbl_no[ci]], &dcd);
+        make_derived(&e.ac[p->ac_tbl_no[ci]], &acd);
+        trellis_component(&e, ci, &dcd, &acd);
+        gather_and_build(&e, &sc, 1);
+      }
     }
   }
   if (taps)

@@ -55,6 +55,10 @@ CASES = [
     ("fastcrush_444_restart1", dict(fastcrush=True, restart=1, sample=(1, 1)), True),
     ("gray_prog_restart1", dict(gray=True, restart=1), True),
     ("prog_notrellis_restart7b", dict(notrellis=True, restart="7b"), True),
+    # more than one (statistics, trellis) round per component (JINT_TRELLIS_NUM_LOOPS)
+    ("base_trellis_loops2", dict(baseline=True, trellis_loops=2), True),
+    ("default_progressive_trellis_loops2", dict(trellis_loops=2), True),
+    ("base_444_trellis_loops3", dict(baseline=True, trellis_loops=3, sample=(1, 1), quality=90), True),
 ]
 
 
