@@ -89,6 +89,9 @@ typedef struct {
    * each trellis pass restarting from the unquantized coefficients with the tables of the previous result
    * (jcmaster.c:451-466, :1128-1138) */
   int trellis_num_loops;
+  /* cinfo->smoothing_factor (jpeglib.h:459, cjpeg -smooth N), 0..100: input smoothing inside the full-size and the
+   * 2x2 downsamplers (jcsample.c:306-455); the other sampling ratios have no smoothing variant in the reference */
+  int smoothing_factor;
 } mjh_params;
 
 typedef struct mjh_encoder mjh_encoder;

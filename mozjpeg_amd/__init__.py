@@ -44,7 +44,7 @@ class Params(C.Structure):
                 ("restart_interval", C.c_uint), ("restart_in_rows", C.c_int), ("num_scans", C.c_int),
                 ("scan_info", Scan * MAX_SCANS), ("optimize_scans", C.c_int), ("write_JFIF_header", C.c_int),
                 ("input_pixel_size", C.c_int), ("rgb_offset", C.c_int * 3), ("data_precision", C.c_int),
-                ("trellis_num_loops", C.c_int)]
+                ("trellis_num_loops", C.c_int), ("smoothing_factor", C.c_int)]
 
 
 _lib = None
@@ -96,7 +96,7 @@ def _chk(rc):
 def make_params(width, height, *, quality=75, baseline=False, revert=False, optimize=False,
                 notrellis=False, notrellis_dc=False, noovershoot=False, sample=(2, 2), gray=False,
                 grayin=False, quant_table=-1, lambda1=None, lambda2=None, restart=None,
-                progressive=False, fastcrush=False, precision=8, trellis_loops=1):
+                progressive=False, fastcrush=False, precision=8, trellis_loops=1, smooth=0):
     """Parameters with cjpeg's switch vocabulary (cjpeg.c:371-714).  Without `baseline` or
     `revert` this is cjpeg's default: progressive with scan search (`fastcrush`: fixed 9-scan script)."""
     p = Params()
@@ -118,6 +118,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
         p.lambda_log_scale2 = lambda2
     p.data_precision = precision
     p.trellis_num_loops = trellis_loops
+    p.smoothing_factor = smooth
     if restart is not None:
         if isinstance(restart, str) and restart.lower().endswith("b"):
             p.restart_interval = int(restart[:-1])

@@ -87,7 +87,7 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
   if (cinfo->data_precision != 8 && cinfo->data_precision != 12) return "data_precision other than 8 or 12";
   p->data_precision = cinfo->data_precision;
   if (cinfo->arith_code) return "arithmetic coding";
-  if (cinfo->smoothing_factor) return "input smoothing";
+  p->smoothing_factor = cinfo->smoothing_factor;   /* cjpeg -smooth N; ignored for raw data / coefficients like in the reference */
   if (cinfo->dct_method != JDCT_ISLOW) return "dct_method other than JDCT_ISLOW";
   if (cinfo->write_Adobe_marker) return "Adobe marker";
   {

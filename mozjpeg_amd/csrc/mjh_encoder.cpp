@@ -296,6 +296,7 @@ static int check_supported(const mjh_params *p)
   if (p->image_width <= 0 || p->image_height <= 0 || p->image_width > 65500 || p->image_height > 65500)
     return fail(MJH_EINVAL, "bad image size %dx%d", p->image_width, p->image_height);
   if (p->data_precision != 0 && p->data_precision != 8 && p->data_precision != 12) return fail(MJH_EUNSUPPORTED, "data_precision %d", p->data_precision);
+  if (p->smoothing_factor < 0 || p->smoothing_factor > 100) return fail(MJH_EINVAL, "smoothing_factor %d (0..100)", p->smoothing_factor);
   if (p->trellis_num_loops < 0 || p->trellis_num_loops > 16) return fail(MJH_EINVAL, "trellis_num_loops %d (0..16)", p->trellis_num_loops);
   if (p->data_precision == 12 && p->trellis_quant)
     return fail(MJH_EUNSUPPORTED, "trellis quantization is 8-bit only in the reference (jccoefct.c:132-138: 12-bit + trellis aborts)");
@@ -405,6 +406,7 @@ static void build_const(const mjh_params *p, MjhConst *C)
   C->planes_per_image = plane_off;
   C->coefs_per_image = coef_off;
   C->deringing = p->overshoot_deringing;
+  C->smoothing = p->smoothing_factor;
   C->trellis = p->trellis_quant;
   C->trellis_dc = p->trellis_quant_dc;
   // per_scan_setup jcmaster.c:595-600: restart_in_rows is converted per scan; here for the final

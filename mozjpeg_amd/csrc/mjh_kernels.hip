@@ -115,6 +115,70 @@ k_color(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, size_t im
   }
 }
 
+// Input smoothing (cjpeg -smooth N): h2v2_smooth_downsample jcsample.c:304-391, fullsize_smooth_downsample :400-455.
+// A smoothing downsampler asks for context rows, which switches the whole preprocessor to pre_process_context
+// (jcprepct.c:200-262): rows above the image are copies of row 0, EVERY row below it is a copy of the last input
+// row (the padding row groups are downsampled like real ones; this mode has no "replicate the last downsampled
+// row" step), columns beyond the image repeat the last one and column -1 counts as column 0 -- all of it is index
+// clamping here.  Ratios without a smoothing variant (2x1, 1x2 ...) use the plain filters on the same clamped rows.
+// One lane = one output sample of one component; the colour conversion of its 3x3 / 4x4 neighbourhood is redone
+// per lane (non-default mode: clarity over speed).
+template <class T>
+__device__ __forceinline__ int smooth_px(const MjhConst &C, const uint8_t *p, size_t row_pitch, int comp, int iy, int ix)
+{
+  iy = iy < 0 ? 0 : (iy > C.H - 1 ? C.H - 1 : iy);
+  ix = ix < 0 ? 0 : (ix > C.W - 1 ? C.W - 1 : ix);
+  const T *row = reinterpret_cast<const T *>(p + (size_t)iy * row_pitch);
+  if (C.in_comps != 3) return row[ix];
+  const int center = sizeof(T) == 2 ? 2048 : 128;
+  const T *px = row + (size_t)ix * C.px_size;
+  int r = px[C.off_r], g = px[C.off_g], b = px[C.off_b];
+  if (sizeof(T) == 2) { r &= 0xFFF; g &= 0xFFF; b &= 0xFFF; }
+  if (comp == 0) return (FIXC(0.29900) * r + FIXC(0.58700) * g + FIXC(0.11400) * b + 32768) >> 16;
+  if (comp == 1) return (-FIXC(0.16874) * r - FIXC(0.33126) * g + FIXC(0.50000) * b + (center << 16) + 32767) >> 16;
+  return (FIXC(0.50000) * r - FIXC(0.41869) * g - FIXC(0.08131) * b + (center << 16) + 32767) >> 16;
+}
+
+template <class T>
+__global__ void __launch_bounds__(256)
+k_color_smooth(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, size_t img_stride, T *__restrict__ planes)
+{
+  const int comp = blockIdx.z % C.ncomp, img = blockIdx.z / C.ncomp;
+  const MjhComp cc = C.c[comp];
+  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (r >= cc.ph || c >= cc.pw) return;
+  const uint8_t *p = pix + (size_t)img * img_stride;
+  const long long sf = C.smoothing;
+  long long val;
+#define SPX(yy, xx) ((long long)smooth_px<T>(C, p, row_pitch, comp, (yy), (xx)))
+  if (cc.hexp == 1 && cc.vexp == 1) {
+    const long long member = SPX(r, c);
+    long long neigh = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+      for (int dx = -1; dx <= 1; dx++)
+        if (dy || dx) neigh += SPX(r + dy, c + dx);
+    val = (member * (65536ll - sf * 512ll) + neigh * (sf * 64ll) + 32768ll) >> 16;
+  } else if (cc.hexp == 2 && cc.vexp == 2) {
+    const int y0 = 2 * r, x0 = 2 * c;
+    const long long member = SPX(y0, x0) + SPX(y0, x0 + 1) + SPX(y0 + 1, x0) + SPX(y0 + 1, x0 + 1);
+    const long long edge = SPX(y0 - 1, x0) + SPX(y0 - 1, x0 + 1) + SPX(y0 + 2, x0) + SPX(y0 + 2, x0 + 1) +
+                           SPX(y0, x0 - 1) + SPX(y0, x0 + 2) + SPX(y0 + 1, x0 - 1) + SPX(y0 + 1, x0 + 2);
+    const long long corner = SPX(y0 - 1, x0 - 1) + SPX(y0 - 1, x0 + 2) + SPX(y0 + 2, x0 - 1) + SPX(y0 + 2, x0 + 2);
+    val = (member * (16384ll - sf * 80ll) + (2 * edge + corner) * (sf * 16ll) + 32768ll) >> 16;
+  } else {
+    long long sum = 0;
+    for (int vv = 0; vv < cc.vexp; vv++)
+      for (int hh = 0; hh < cc.hexp; hh++) sum += SPX(r * cc.vexp + vv, c * cc.hexp + hh);
+    const int n = cc.hexp * cc.vexp;
+    if (cc.hexp == 2 && cc.vexp == 1) val = (sum + (c & 1)) >> 1;
+    else val = (sum + n / 2) / n;
+  }
+#undef SPX
+  planes[(size_t)img * C.planes_per_image + cc.plane_off + (size_t)r * cc.pw + c] = (T)val;
+}
+
 // Vectorised variant for the common case (8-bit, 3 bytes per pixel, 2:1 horizontal chroma
 // subsampling, 8-byte aligned rows): one lane converts 8 pixels x V0 rows = 4 chroma samples.  The
 // 24 bytes per row arrive as three 8-byte loads, Y leaves as one 8-byte store per row, Cb/Cr as one
@@ -1581,6 +1645,14 @@ void mjh_launch_import_planes(const MjhConst &C, const MjhPlaneSrc &S, void *pla
 void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size_t img_stride, void *planes, int n, hipStream_t s)
 {
   const int H0 = C.maxh, V0 = C.maxv;
+  if (C.smoothing) {
+    int pw = 0, ph = 0;
+    for (int i = 0; i < C.ncomp; i++) { pw = C.c[i].pw > pw ? C.c[i].pw : pw; ph = C.c[i].ph > ph ? C.c[i].ph : ph; }
+    dim3 grid((pw + 255) / 256, ph, n * C.ncomp);
+    if (C.precision == 12) hipLaunchKernelGGL((k_color_smooth<uint16_t>), grid, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint16_t *)planes);
+    else hipLaunchKernelGGL((k_color_smooth<uint8_t>), grid, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint8_t *)planes);
+    return;
+  }
   if (C.precision == 8 && C.in_comps == 3 && C.ncomp == 3 && C.px_size == 3 && H0 == 2 && (row_pitch & 7) == 0 &&
       (img_stride & 7) == 0 && ((uintptr_t)pix & 7) == 0 && C.off_g == 1 && (C.off_r == 0 || C.off_r == 2)) {
     dim3 gridv(((C.groups_x + 3) / 4 + 255) / 256, C.groups_y, n);

@@ -317,6 +317,45 @@ static void color_downsample16(const mjo_params *p, const uint8_t *pixels, size_
     int real_rows = groups * v; /* downsampled rows that exist before the iMCU padding */
     int numpix = hexp * vexp;
     int r, c;
+    if (p->smoothing_factor) {
+      /* Input smoothing (cjpeg -smooth N).  need_context_rows switches the WHOLE preprocessor to
+       * pre_process_context (jcprepct.c:200-262): rows above the image are copies of row 0 (:224-232), every row
+       * below it is a copy of the last input row (:243-249, the padding groups are downsampled like real ones --
+       * there is no "replicate the last downsampled row" step in this mode), columns are replicated to the right by
+       * expand_right_edge and column -1 counts as column 0: all of it is index clamping.  Only the full-size and the
+       * 2x2 downsamplers have smoothing variants (jinit_downsampler jcsample.c:486-535). */
+      const long sf = p->smoothing_factor;
+      for (r = 0; r < g[ci].ph; r++)
+        for (c = 0; c < g[ci].pw; c++) {
+#define PX(yy, xx) ((long)full[ci][(size_t)((yy) < 0 ? 0 : (yy) > H - 1 ? H - 1 : (yy)) * W + ((xx) < 0 ? 0 : (xx) > W - 1 ? W - 1 : (xx))])
+          long val;
+          if (hexp == 1 && vexp == 1) {             /* fullsize_smooth_downsample jcsample.c:400-455 */
+            long member = PX(r, c), neigh = 0;
+            int dy, dx;
+            for (dy = -1; dy <= 1; dy++)
+              for (dx = -1; dx <= 1; dx++)
+                if (dy || dx) neigh += PX(r + dy, c + dx);
+            val = (member * (65536L - sf * 512L) + neigh * (sf * 64) + 32768) >> 16;
+          } else if (hexp == 2 && vexp == 2) {      /* h2v2_smooth_downsample jcsample.c:304-391 */
+            int y0 = 2 * r, x0 = 2 * c;
+            long member = PX(y0, x0) + PX(y0, x0 + 1) + PX(y0 + 1, x0) + PX(y0 + 1, x0 + 1);
+            long edge = PX(y0 - 1, x0) + PX(y0 - 1, x0 + 1) + PX(y0 + 2, x0) + PX(y0 + 2, x0 + 1) +
+                        PX(y0, x0 - 1) + PX(y0, x0 + 2) + PX(y0 + 1, x0 - 1) + PX(y0 + 1, x0 + 2);
+            long corner = PX(y0 - 1, x0 - 1) + PX(y0 - 1, x0 + 2) + PX(y0 + 2, x0 - 1) + PX(y0 + 2, x0 + 2);
+            val = (member * (16384 - sf * 80) + (2 * edge + corner) * (sf * 16) + 32768) >> 16;
+          } else {                                   /* no smoothing variant: the plain downsamplers, context-mode rows */
+            long sum = 0;
+            int hh, vv;
+            for (vv = 0; vv < vexp; vv++)
+              for (hh = 0; hh < hexp; hh++) sum += PX(r * vexp + vv, c * hexp + hh);
+            if (hexp == 2 && vexp == 1) val = (sum + (c & 1)) >> 1;
+            else val = (sum + numpix / 2) / numpix;
+          }
+#undef PX
+          planes[ci][(size_t)r * g[ci].pw + c] = (uint16_t)val;
+        }
+      continue;
+    }
     for (r = 0; r < g[ci].ph; r++) {
       int rr = r < real_rows ? r : real_rows - 1; /* jcprepct.c:180-190 */
       int grp = rr / v, sub = rr % v;

@@ -56,6 +56,7 @@ typedef struct {
   int write_jfif;
   int data_precision;             /* 0 or 8: 8-bit samples (uint8); 12: 12-bit samples (uint16), no trellis */
   int trellis_num_loops;          /* JINT_TRELLIS_NUM_LOOPS (jcparam.c:515 default 1; 0 is read as 1): trellis passes per component */
+  int smoothing_factor;           /* cinfo->smoothing_factor 0..100 (cjpeg -smooth N): input smoothing in the downsampler, jcsample.c:306-455 */
 } mjo_params;
 
 /* jpeg_set_defaults + jpeg_set_quality + colorspace defaults, as cjpeg would leave them:

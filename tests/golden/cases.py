@@ -59,6 +59,13 @@ CASES = [
     ("base_trellis_loops2", dict(baseline=True, trellis_loops=2), True),
     ("default_progressive_trellis_loops2", dict(trellis_loops=2), True),
     ("base_444_trellis_loops3", dict(baseline=True, trellis_loops=3, sample=(1, 1), quality=90), True),
+    # input smoothing (cjpeg -smooth N, jcsample.c:306-455; context-row preprocessing jcprepct.c:200-262)
+    ("revert_opt_smooth1", dict(revert=True, optimize=True, smooth=1), True),     # testorig: MD5_JPEG_420S_IFAST_OPT, CMakeLists.txt:1367
+    ("base_smooth30", dict(baseline=True, smooth=30), True),
+    ("base_444_smooth100", dict(baseline=True, smooth=100, sample=(1, 1)), True),
+    ("revert_422_smooth50", dict(revert=True, smooth=50, sample=(2, 1)), True),
+    ("revert_440_smooth10", dict(revert=True, smooth=10, sample=(1, 2)), True),
+    ("gray_progressive_smooth20", dict(smooth=20, gray=True), True),
 ]
 
 
@@ -92,6 +99,7 @@ REFERENCE_PINNED = {
     ("testorig", "revert"): "9a68f56bc76e466aa7e52f415d0f4a5f",        # MD5_JPEG_420_ISLOW   :1391
     ("testorig", "revert_440"): "538bc02bd4b4658fd85de6ece6cbeda6",    # MD5_JPEG_440_ISLOW   :1354
     ("testorig", "revert_gray"): "72b51f894b8f4a10b3ee3066770aa38d",   # MD5_JPEG_GRAY_ISLOW  :1362
+    ("testorig", "revert_opt_smooth1"): "388708217ac46273ca33086b22827ed8",   # MD5_JPEG_420S_IFAST_OPT :1367 (-sample 2x2 -smooth 1 -dct int -opt)
 }
 
 

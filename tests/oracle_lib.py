@@ -31,7 +31,8 @@ class Params(C.Structure):
                 ("lambda_log_scale1", C.c_float), ("lambda_log_scale2", C.c_float),
                 ("restart_interval", C.c_int), ("restart_in_rows", C.c_int),
                 ("num_scans", C.c_int), ("scans", Scan * MAXS), ("optimize_scans", C.c_int),
-                ("write_jfif", C.c_int), ("data_precision", C.c_int), ("trellis_num_loops", C.c_int)]
+                ("write_jfif", C.c_int), ("data_precision", C.c_int), ("trellis_num_loops", C.c_int),
+                ("smoothing_factor", C.c_int)]
 
 
 class Geom(C.Structure):
@@ -69,7 +70,7 @@ def lib():
 def make_params(width, height, *, quality=75, baseline=False, revert=False, optimize=False,
                 progressive=False, fastcrush=False, notrellis=False, notrellis_dc=False,
                 noovershoot=False, sample=(2, 2), restart=None, gray=False, grayin=False,
-                quant_table=-1, lambda1=None, lambda2=None, precision=8, trellis_loops=1):
+                quant_table=-1, lambda1=None, lambda2=None, precision=8, trellis_loops=1, smooth=0):
     """Same switch vocabulary as cjpeg / oracle/refenc.c.  Default (no switch) is cjpeg's default:
     max-compression profile, progressive with scan search."""
     p = Params()
@@ -90,6 +91,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
         p.lambda_log_scale2 = lambda2
     p.data_precision = precision
     p.trellis_num_loops = trellis_loops
+    p.smoothing_factor = smooth
     if restart is not None:
         if isinstance(restart, str) and restart.lower().endswith("b"):
             p.restart_interval = int(restart[:-1])
@@ -286,6 +288,8 @@ def ref_switches(**kw):
         sw += ["-lambda2", str(kw["lambda2"])]
     if kw.get("precision", 8) == 12:
         sw += ["-precision", "12"]
+    if kw.get("smooth", 0):
+        sw += ["-smooth", str(kw["smooth"])]
     if kw.get("trellis_loops", 1) != 1:
         sw += ["-trellis-loops", str(kw["trellis_loops"])]
     return sw

@@ -39,6 +39,8 @@ CJPEG_CASES = [
     ("prog_search_restart1", ["-quality", "75", "-restart", "1", "-sample", "2x2"]),      # restart markers inside progressive scans
     ("fastcrush_restart2", ["-quality", "75", "-fastcrush", "-restart", "2", "-sample", "2x2"]),
     ("revert_prog_restart3b", ["-revert", "-progressive", "-quality", "75", "-restart", "3B", "-sample", "2x2"]),
+    ("revert_opt_smooth1", ["-revert", "-optimize", "-quality", "75", "-smooth", "1", "-sample", "2x2"]),   # MD5_JPEG_420S_IFAST_OPT
+    ("base_smooth30", ["-quality", "75", "-baseline", "-smooth", "30", "-sample", "2x2"]),
 ]
 
 
@@ -89,7 +91,7 @@ def test_unsupported_configuration_is_an_error_without_fallback(tmp_path):
 @needs
 def test_explicit_passthrough_is_logged(goldens, tmp_path):
     out = str(tmp_path / "o.jpg")
-    r = run_cjpeg(["-quality", "75", "-smooth", "10"], out, {"MOZJPEG_HIP_PASSTHROUGH": "1"})
+    r = run_cjpeg(["-quality", "75", "-arithmetic"], out, {"MOZJPEG_HIP_PASSTHROUGH": "1"})   # arithmetic coding: outside the GPU path
     assert r.returncode == 0, r.stderr.decode()
     assert b"handing over to the host libjpeg" in r.stderr
     assert open(out, "rb").read()[:2] == b"\xff\xd8"
