@@ -307,7 +307,9 @@ static int check_supported(const mjh_params *p)
     return fail(MJH_EUNSUPPORTED, "grayscale must be sampled 1x1");
   if (p->num_components == 3) {
     const int h = p->h_samp_factor[0], v = p->v_samp_factor[0];
-    if (!((h == 1 || h == 2) && (v == 1 || v == 2))) return fail(MJH_EUNSUPPORTED, "luma sampling %dx%d", h, v);
+    // 1x1 chroma with luma 1/2/4 in either direction, at most 10 blocks per MCU (C_MAX_BLOCKS_IN_MCU, jcmaster.c:540-544):
+    // 4:4:4, 4:2:2, 4:4:0, 4:2:0, 4:1:1, 4:4:1 and the 4x2 / 2x4 ratios
+    if (!((h == 1 || h == 2 || h == 4) && (v == 1 || v == 2 || v == 4) && h * v + 2 <= 10)) return fail(MJH_EUNSUPPORTED, "luma sampling %dx%d", h, v);
     for (int i = 1; i < 3; i++)
       if (p->h_samp_factor[i] != 1 || p->v_samp_factor[i] != 1) return fail(MJH_EUNSUPPORTED, "chroma sampling must be 1x1");
   }

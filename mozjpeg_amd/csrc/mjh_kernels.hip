@@ -1653,7 +1653,7 @@ void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size
     else hipLaunchKernelGGL((k_color_smooth<uint8_t>), grid, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint8_t *)planes);
     return;
   }
-  if (C.precision == 8 && C.in_comps == 3 && C.ncomp == 3 && C.px_size == 3 && H0 == 2 && (row_pitch & 7) == 0 &&
+  if (C.precision == 8 && C.in_comps == 3 && C.ncomp == 3 && C.px_size == 3 && H0 == 2 && V0 <= 2 && (row_pitch & 7) == 0 &&
       (img_stride & 7) == 0 && ((uintptr_t)pix & 7) == 0 && C.off_g == 1 && (C.off_r == 0 || C.off_r == 2)) {
     dim3 gridv(((C.groups_x + 3) / 4 + 255) / 256, C.groups_y, n);
     if (V0 == 2) hipLaunchKernelGGL((k_color_vec<2>), gridv, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint8_t *)planes);
@@ -1666,6 +1666,10 @@ void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size
   if (H0 == 2 && V0 == 2) LC(2, 2);
   else if (H0 == 2 && V0 == 1) LC(2, 1);
   else if (H0 == 1 && V0 == 2) LC(1, 2);
+  else if (H0 == 4 && V0 == 1) LC(4, 1);      // 4:1:1 (TJSAMP_411)
+  else if (H0 == 1 && V0 == 4) LC(1, 4);      // 4:4:1 (TJSAMP_441)
+  else if (H0 == 4 && V0 == 2) LC(4, 2);
+  else if (H0 == 2 && V0 == 4) LC(2, 4);
   else LC(1, 1);
 #undef LC
 }

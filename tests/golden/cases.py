@@ -66,6 +66,12 @@ CASES = [
     ("revert_422_smooth50", dict(revert=True, smooth=50, sample=(2, 1)), True),
     ("revert_440_smooth10", dict(revert=True, smooth=10, sample=(1, 2)), True),
     ("gray_progressive_smooth20", dict(smooth=20, gray=True), True),
+    # 4:1 luma sampling ratios (int_downsample jcsample.c:151; TurboJPEG's TJSAMP_411 / TJSAMP_441), up to 10 blocks per MCU
+    ("revert_411", dict(revert=True, sample=(4, 1)), True),
+    ("base_441", dict(baseline=True, sample=(1, 4)), True),
+    ("base_4x2_restart1", dict(baseline=True, sample=(4, 2), restart=1), True),
+    ("default_progressive_2x4", dict(sample=(2, 4)), True),
+    ("base_411_smooth20", dict(baseline=True, sample=(4, 1), smooth=20), True),
 ]
 
 

@@ -103,7 +103,7 @@ TJH = os.path.join(O.REF_DIR, "tjharness")
 needs_tj = pytest.mark.skipif(not (os.path.exists(SHIM) and os.path.exists(TJH)), reason="shim or tjharness not built")
 TJPF = {"RGB": (0, [0, 1, 2], 3), "BGR": (1, [2, 1, 0], 3), "RGBX": (2, [0, 1, 2], 4), "BGRX": (3, [2, 1, 0], 4),
         "XBGR": (4, [3, 2, 1], 4), "XRGB": (5, [1, 2, 3], 4)}
-TJSAMP = {"444": 0, "422": 1, "420": 2, "GRAY": 3, "440": 4}
+TJSAMP = {"444": 0, "422": 1, "420": 2, "GRAY": 3, "440": 4, "411": 5, "441": 6}
 ACCURATE, BOTTOMUP, PROGRESSIVE = 4096, 2, 16384
 
 
@@ -118,7 +118,8 @@ def tj_run(raw, w, h, pf, ss, q, flags, out, preload):
 @needs_tj
 @pytest.mark.parametrize("pfname", list(TJPF))
 @pytest.mark.parametrize("ssname,q,flags", [("420", 75, ACCURATE), ("444", 96, 0), ("422", 80, ACCURATE | BOTTOMUP),
-                                            ("GRAY", 75, ACCURATE), ("440", 60, ACCURATE), ("420", 85, ACCURATE | PROGRESSIVE)])
+                                            ("GRAY", 75, ACCURATE), ("440", 60, ACCURATE), ("420", 85, ACCURATE | PROGRESSIVE),
+                                            ("411", 75, ACCURATE), ("441", 90, ACCURATE | PROGRESSIVE)])
 def test_unchanged_tjcompress2_through_the_shim(pfname, ssname, q, flags, tmp_path):
     import numpy as np
     rgb = O.read_ppm(PPM)
