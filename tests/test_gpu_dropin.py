@@ -154,12 +154,13 @@ def test_tjcompress2_fast_dct_is_refused_not_emulated(tmp_path):
 @needs_tj
 @pytest.mark.parametrize("w,h,ssname,q,flags", [(227, 149, "420", 75, ACCURATE), (64, 48, "444", 96, 0), (131, 77, "422", 80, ACCURATE),
                                                 (50, 33, "GRAY", 75, ACCURATE), (101, 77, "440", 60, ACCURATE),
-                                                (227, 149, "420", 85, ACCURATE | PROGRESSIVE), (1920, 1080, "420", 75, ACCURATE)])
+                                                (227, 149, "420", 85, ACCURATE | PROGRESSIVE), (1920, 1080, "420", 75, ACCURATE),
+                                                (229, 151, "411", 75, ACCURATE), (99, 203, "441", 80, ACCURATE)])
 def test_unchanged_tjcompressfromyuv_through_the_shim(w, h, ssname, q, flags, tmp_path):
     """the reference's tjCompressFromYUV -> tj3CompressFromYUVPlanes8 (turbojpeg.c:1222) ->
     jpeg_write_raw_data (jcapistd.c:145) chain, unchanged, lands in the GPU plane-input path; the file equals
     the one the reference library writes for the same planar YUV image (and the oracle's)."""
-    samp = {"444": (1, 1), "422": (2, 1), "420": (2, 2), "GRAY": (1, 1), "440": (1, 2)}[ssname]
+    samp = {"444": (1, 1), "422": (2, 1), "420": (2, 2), "GRAY": (1, 1), "440": (1, 2), "411": (4, 1), "441": (1, 4)}[ssname]
     kw = dict(revert=True, quality=q, sample=samp, gray=(ssname == "GRAY"), progressive=bool(flags & PROGRESSIVE))
     po = O.make_params(w, h, **kw)
     planes = O.synthetic_planes(po, 11)

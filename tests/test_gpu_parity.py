@@ -252,3 +252,31 @@ def test_scan_beyond_the_32bit_offset_range_is_an_error_not_a_wrapped_file():
         enc.encode_host(img)
     assert "2^32" in str(ei.value)
     enc.close()
+
+
+@pytest.mark.gpu
+def test_two_host_threads_with_their_own_encoders():
+    """SURVEY 8b threading contract: distinct compress objects may run concurrently (one encoder per thread here;
+    ctypes drops the GIL during the calls, mjh_last_error is thread-local)"""
+    import threading
+    jobs = [(O.synthetic_frame(640, 480, 11), dict(baseline=True)), (O.synthetic_frame(517, 389, 12), dict(quality=85)),
+            (O.synthetic_frame(640, 480, 13), dict(revert=True, sample=(2, 1))), (O.synthetic_frame(333, 222, 14), dict(fastcrush=True))]
+    results = [None] * len(jobs)
+
+    def work(i):
+        img, kw = jobs[i]
+        h, w = img.shape[:2]
+        enc = M.Encoder(M.make_params(w, h, **kw), max_batch=1)
+        outs = [enc.encode_host(img)[0] for _ in range(5)]
+        enc.close()
+        results[i] = outs
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for (img, kw), outs in zip(jobs, results):
+        h, w = img.shape[:2]
+        ref = O.encode(O.make_params(w, h, **kw), img)
+        assert outs is not None and all(o == ref for o in outs), kw
