@@ -183,7 +183,7 @@ def main():
         # separate runs, fetch corrected by the factor calibrated on k_color; tools/rocprof_summary.py) -- per launch
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01f_pmc_hbm_traffic_batch64.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_hbm_traffic_batch64.json")))
             if (w, h) == (W, H) and dom.startswith("trellis_ac"):
                 per_frame = sum(v["hbm_bytes_per_frame"] for k, v in pmc["kernels"].items() if k.startswith("k_trellis_ac"))
                 traffic = int(per_frame * B)
@@ -203,7 +203,7 @@ def main():
             "jpeg_bytes_per_frame": int(jpeg_bytes / B),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_source": "profiles/r01f_pmc_hbm_traffic_batch64.json (bytes per launch, scaled to this batch)" if traffic else None,
+                         "traffic_source": "profiles/r01g_pmc_hbm_traffic_batch64.json (bytes per launch, scaled to this batch)" if traffic else None,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "kernel_ms": round(dom_ms, 4),
                          "kernel_ms_source": "HIP events around the kernel in every step of the timed region",
