@@ -90,3 +90,17 @@ def test_no_gpu_means_loud_failure():
         M.Encoder(M.make_params(64, 64, baseline=True))
     assert ei.value.code == M.EHIP
     assert "no CPU fallback" in str(ei.value)
+
+
+def test_shim_exports_every_symbol_its_contract_names():
+    """include/mozjpeg_hip_jpeglib.h lists the libjpeg entry points the drop-in library must export"""
+    import subprocess
+    shim = os.path.join(ROOT, "mozjpeg_amd", "libmozjpeg_hip_jpeg62.so")
+    if not os.path.exists(shim):
+        pytest.skip("shim not built (needs the reference's libjpeg headers)")
+    hdr = open(os.path.join(ROOT, "include", "mozjpeg_hip_jpeglib.h")).read()
+    names = re.search(r'MOZJPEG_HIP_SHIM_SYMBOLS\s+"([^"]+)"', hdr).group(1).split()
+    assert len(names) == 7
+    exported = subprocess.check_output(["nm", "-D", "--defined-only", shim]).decode()
+    for n in names:
+        assert re.search(r"\sT\s+%s\b" % re.escape(n), exported), "shim does not export " + n
