@@ -255,7 +255,11 @@ struct mjh_encoder {
   void *d_prog_scans = nullptr, *d_prog_ctl = nullptr;
   int *d_lists = nullptr;           // device copies of the scan / slot lists below
   std::vector<int> h_lists;
-  struct PList { int scan_off, nscan, slot_off, nslot; };
+  // scans of one phase + the table slots they build; for the statistics the scans are split into AC-first scans
+  // without restart intervals (parallel kernel) and the rest (sequential per-scan walk)
+  struct PList { int scan_off, nscan, slot_off, nslot, par_off, npar, seq_off, nseq; };
+  void *d_prog_chunks = nullptr;     // chunk summaries of the parallel statistics kernel
+  int chunks_per_scan = 0;
   PList pl_trellis{}, pl_phase[2]{};
   int nphases = 0;
   unsigned *d_pool = nullptr; size_t pool_words = 0;
@@ -558,7 +562,7 @@ static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *ptrs[] = { e->d_pix, e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pix, e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_chunks, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -785,6 +789,10 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       for (int si : scn)
         for (int t = 0; t < 2; t++)
           if (ps[si].slot[t] >= 0 && (ps[si].Ss != 0 || ps[si].Ah == 0)) { e->h_lists.push_back(ps[si].slot[t]); pl.nslot++; }
+      pl.par_off = (int)e->h_lists.size(); pl.npar = 0;
+      for (int si : scn) if (ps[si].Ss != 0 && ps[si].Ah == 0 && ps[si].ri == 0) { e->h_lists.push_back(si); pl.npar++; }
+      pl.seq_off = (int)e->h_lists.size(); pl.nseq = 0;
+      for (int si : scn) if (!(ps[si].Ss != 0 && ps[si].Ah == 0 && ps[si].ri == 0)) { e->h_lists.push_back(si); pl.nseq++; }
       return pl;
     };
     std::vector<int> tr, a, b;
@@ -799,6 +807,13 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     e->pl_trellis = add_list(tr);
     e->pl_phase[0] = add_list(a);
     e->pl_phase[1] = add_list(b);
+    {
+      int mx = 0, maxlist = 1;
+      for (int c = 0; c < C.ncomp; c++) mx = C.c[c].nblk > mx ? C.c[c].nblk : mx;
+      e->chunks_per_scan = (mx + MJH_PSTAT_BLOCKS - 1) / MJH_PSTAT_BLOCKS;
+      for (const mjh_encoder::PList *pl : { &e->pl_trellis, &e->pl_phase[0], &e->pl_phase[1] }) maxlist = pl->npar > maxlist ? pl->npar : maxlist;
+      HIPCHK_E(hipMalloc(&e->d_prog_chunks, B * (size_t)maxlist * e->chunks_per_scan * sizeof(MjhProgChunk)));
+    }
     HIPCHK_E(hipMalloc((void **)&e->d_lists, e->h_lists.size() * sizeof(int) + 16));
     HIPCHK_E(hipMemcpy(e->d_lists, e->h_lists.data(), e->h_lists.size() * sizeof(int), hipMemcpyHostToDevice));
     // every candidate scan of the search keeps its own bit stream: the bands are coded ~11 times over
@@ -900,7 +915,10 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       // progressive: the trellis passes gather AC-first statistics (Ss=1, Se=63, Al=0, seeded counts,
       // jcphuff.c:257-264); the DC rate table stays the STANDARD table
       pr.mark("prog_stats(pre-trellis)");
-      mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + e->pl_trellis.scan_off, e->pl_trellis.nscan, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
+      if (e->pl_trellis.nseq)
+        mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + e->pl_trellis.seq_off, e->pl_trellis.nseq, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
+      mjh_launch_prog_stats_acfirst(C, e->d_prog_scans, e->d_lists + e->pl_trellis.par_off, e->pl_trellis.npar, e->d_prog_ctl, e->d_q, e->d_tabs, spi,
+                                    e->d_prog_chunks, e->chunks_per_scan, n, s);
       pr.mark("gen_tables(trellis)");
       mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + e->pl_trellis.slot_off, e->pl_trellis.nslot, n, s);
       for (int i = 0; i < 4; i++) tr_dc[i] = fin_dc[i];
@@ -936,7 +954,10 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     for (int ph = 0; ph < e->nphases; ph++) {
       const mjh_encoder::PList &pl = e->pl_phase[ph];
       pr.mark(ph == 0 ? "prog_stats(A)" : "prog_stats(B)");
-      mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + pl.scan_off, pl.nscan, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
+      if (pl.nseq)
+        mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + pl.seq_off, pl.nseq, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
+      mjh_launch_prog_stats_acfirst(C, e->d_prog_scans, e->d_lists + pl.par_off, pl.npar, e->d_prog_ctl, e->d_q, e->d_tabs, spi,
+                                    e->d_prog_chunks, e->chunks_per_scan, n, s);
       pr.mark(ph == 0 ? "gen_tables(A)" : "gen_tables(B)");
       mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + pl.slot_off, pl.nslot, n, s);
       pr.mark(ph == 0 ? "prog_encode(A)" : "prog_encode(B)");

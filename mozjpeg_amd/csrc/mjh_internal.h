@@ -115,6 +115,11 @@ struct MjhProgScan {
   int emit_dri;            // write_scan_header jcmarker.c:778-781: DRI when the interval differs from the previous scan's
 };
 
+// summary of one 2048-block chunk of an AC-first scan (parallel statistics): where its non-empty blocks begin and
+// end, so that the EOB runs that cross chunk borders can be resolved afterwards
+#define MJH_PSTAT_BLOCKS 2048
+struct MjhProgChunk { int first_ne, last_ne, e_last, nblk; };
+
 struct MjhProgCtl {        // per image, lives in HBM
   int best_Al_luma, best_Al_chroma, best_fs_luma, best_fs_chroma;
   unsigned pool_words_used;   // running allocation in the bit-stream pool

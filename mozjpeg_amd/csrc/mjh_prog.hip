@@ -611,6 +611,131 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
   if (threadIdx.x == 0) ct->scan_us[ENCODE][sidx] = (unsigned)((wall_clock64() - t_start) / 100ull);
 }
 
+// =============================================================================================
+// Statistics of AC-FIRST scans without restart intervals, in parallel over the whole component.  Such a scan carries
+// only the EOB run from block to block, and for the statistics only the run LENGTHS matter: a non-empty block flushes
+// the run that precedes it = [trailing-zero flag of the previous non-empty block] + the all-zero blocks in between
+// (encode_mcu_AC_first jcphuff.c:648-745, emit_eobrun :409).  Workgroups take 2048-block chunks: block symbols and
+// the runs between non-empty blocks of the same chunk go to an LDS histogram; a chunk summary lets
+// k_prog_stats_resolve add the runs that cross chunk borders, the forced emissions at EOBRUN == 0x7FFF (:719) and
+// the run pending at the end of the scan (finish_pass_gather_phuff).  Same counts as the sequential walk.
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+k_prog_stats_acfirst(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
+                     const MjhProgCtl *__restrict__ ctl, const int16_t *__restrict__ coef_q, MjhHuffTable *__restrict__ tabs,
+                     int slots_per_image, MjhProgChunk *__restrict__ chunks, int chunks_per_scan)
+{
+  __shared__ unsigned hist[256];
+  __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64], e_bits[MJH_PSTAT_BLOCKS / 64];
+  const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x;
+  const int sidx = scan_list[li];
+  const MjhProgScan sc = scans[sidx];
+  const MjhComp cc = C.c[sc.comp[0]];
+  const int cb = chunk * MJH_PSTAT_BLOCKS;
+  if (cb >= cc.nblk) return;
+  const int nb = min(MJH_PSTAT_BLOCKS, cc.nblk - cb);
+  const MjhProgCtl *ct = ctl + img;
+  const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
+  const int Ss = sc.Ss, Se = sc.Se;
+  const int16_t *qc = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;
+  const int tid = threadIdx.x;
+  hist[tid] = 0;
+  if (tid < MJH_PSTAT_BLOCKS / 64) { ne_bits[tid] = 0; e_bits[tid] = 0; }
+  __syncthreads();
+  unsigned my_ne = 0;   // bit i: my i-th block is non-empty
+#pragma unroll 1
+  for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
+    const int j = i * 256 + tid;
+    if (i * 256 >= nb) break;   // uniform
+    int x[64];
+    const int16_t *qs = qc + cb + (j < nb ? j : nb - 1);
+#pragma unroll
+    for (int k = 1; k < 64; k++) x[k] = (int)qs[(size_t)k * cc.kstride];
+    if (j < nb) {
+      int r = 0;
+      bool ne = false;
+#pragma unroll
+      for (int k = 1; k < 64; k++) {
+        if (k >= Ss && k <= Se) {
+          const int v = x[k];
+          const int a = (v < 0 ? -v : v) >> Al;
+          if (a == 0) r++;
+          else {
+            ne = true;
+            const int nz16 = r >> 4;
+            r &= 15;
+            if (nz16) atomicAdd(&hist[0xF0], (unsigned)nz16);
+            atomicAdd(&hist[(r << 4) + bitlen((unsigned)a)], 1u);
+            r = 0;
+          }
+        }
+      }
+      if (ne) { my_ne |= 1u << i; atomicOr(&ne_bits[j >> 6], 1ull << (j & 63)); }
+      if (r > 0) atomicOr(&e_bits[j >> 6], 1ull << (j & 63));
+    }
+  }
+  __syncthreads();
+  // runs between two non-empty blocks of this chunk
+  for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
+    if (!((my_ne >> i) & 1u)) continue;
+    const int j = i * 256 + tid;
+    int w = j >> 6;
+    unsigned long long m = ne_bits[w] & ((1ull << (j & 63)) - 1ull);
+    while (!m && w > 0) { w--; m = ne_bits[w]; }
+    if (m) {
+      const int p = w * 64 + 63 - __builtin_clzll(m);
+      const unsigned cnt = (unsigned)((e_bits[p >> 6] >> (p & 63)) & 1ull) + (unsigned)(j - p - 1);
+      if (cnt) { int nextra; atomicAdd(&hist[eobrun_symbol(cnt, &nextra)], 1u); }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    MjhProgChunk ch;
+    ch.first_ne = -1; ch.last_ne = -1; ch.e_last = 0; ch.nblk = nb;
+    for (int w = 0; w < MJH_PSTAT_BLOCKS / 64; w++)
+      if (ne_bits[w]) { ch.first_ne = w * 64 + __builtin_ctzll(ne_bits[w]); break; }
+    for (int w = MJH_PSTAT_BLOCKS / 64 - 1; w >= 0; w--)
+      if (ne_bits[w]) { ch.last_ne = w * 64 + 63 - __builtin_clzll(ne_bits[w]); break; }
+    if (ch.last_ne >= 0) ch.e_last = (int)((e_bits[ch.last_ne >> 6] >> (ch.last_ne & 63)) & 1ull);
+    chunks[((size_t)img * gridDim.y + li) * chunks_per_scan + chunk] = ch;
+  }
+  MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
+  if (hist[tid]) atomicAdd(&T0->counts[tid], hist[tid]);
+}
+
+__global__ void __launch_bounds__(64)
+k_prog_stats_resolve(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
+                     MjhHuffTable *__restrict__ tabs, int slots_per_image, const MjhProgChunk *__restrict__ chunks,
+                     int chunks_per_scan)
+{
+  const int img = blockIdx.y, li = blockIdx.x, lane = threadIdx.x;
+  const MjhProgScan sc = scans[scan_list[li]];
+  const MjhComp cc = C.c[sc.comp[0]];
+  MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
+  if (lane == 0) {
+    const int nchunks = (cc.nblk + MJH_PSTAT_BLOCKS - 1) / MJH_PSTAT_BLOCKS;
+    const MjhProgChunk *chs = chunks + ((size_t)img * gridDim.x + li) * chunks_per_scan;
+    unsigned pending = 0;
+    int nextra;
+    for (int c = 0; c < nchunks; c++) {
+      const MjhProgChunk ch = chs[c];
+      if (ch.first_ne >= 0) {
+        unsigned run = pending + (unsigned)ch.first_ne;
+        while (run >= 0x7FFFu) { T0->counts[eobrun_symbol(0x7FFFu, &nextra)] += 1; run -= 0x7FFFu; }   // forced emission at 0x7FFF
+        if (run) T0->counts[eobrun_symbol(run, &nextra)] += 1;
+        pending = (unsigned)ch.e_last + (unsigned)(ch.nblk - 1 - ch.last_ne);
+      } else
+        pending += (unsigned)ch.nblk;
+      while (pending >= 0x7FFFu) { T0->counts[eobrun_symbol(0x7FFFu, &nextra)] += 1; pending -= 0x7FFFu; }
+    }
+    if (pending) T0->counts[eobrun_symbol(pending, &nextra)] += 1;
+  }
+  __syncthreads();
+  if (sc.seed)   // trellis passes: every (run, size < 12) count starts at 1 (jcphuff.c:257-264)
+    for (int i = lane; i < 256; i += 64)
+      if ((i & 15) < 12) T0->counts[i] += 1;
+}
+
 // exact size of every scan's bit stream from its statistics and code lengths, and its place in the
 // pools.  One workgroup per image: wave w sizes the scans w, w+4, ... (lanes over the 256 symbols), then one
 // thread hands out the pool space in list order.
@@ -926,6 +1051,16 @@ void mjh_launch_prog_stats(const MjhConst &C, const void *scans, const int *list
 {
   hipLaunchKernelGGL((k_prog_scan<0>), dim3(n, nlist), dim3(64 * PROG_WAVES(0)), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
                      (const int16_t *)q, tabs, spi, (unsigned *)nullptr, (size_t)0, mpos, mpos_per_image);
+}
+
+void mjh_launch_prog_stats_acfirst(const MjhConst &C, const void *scans, const int *list, int nlist, const void *ctl, const void *q,
+                                   MjhHuffTable *tabs, int spi, void *chunks, int chunks_per_scan, int n, hipStream_t s)
+{
+  if (nlist <= 0) return;
+  hipLaunchKernelGGL(k_prog_stats_acfirst, dim3(chunks_per_scan, nlist, n), dim3(256), 0, s, C, (const MjhProgScan *)scans, list,
+                     (const MjhProgCtl *)ctl, (const int16_t *)q, tabs, spi, (MjhProgChunk *)chunks, chunks_per_scan);
+  hipLaunchKernelGGL(k_prog_stats_resolve, dim3(nlist, n), dim3(64), 0, s, C, (const MjhProgScan *)scans, list, tabs, spi,
+                     (const MjhProgChunk *)chunks, chunks_per_scan);
 }
 
 void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
