@@ -954,10 +954,21 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     for (int ph = 0; ph < e->nphases; ph++) {
       const mjh_encoder::PList &pl = e->pl_phase[ph];
       pr.mark(ph == 0 ? "prog_stats(A)" : "prog_stats(B)");
+      // the sequential walks (refinement / DC / restart scans: a few long workgroups) and the parallel AC-first
+      // statistics touch different table slots: the latter run on the side stream underneath the former
+      const bool both = pl.nseq > 0 && pl.npar > 0;
+      hipStream_t ps = s;
+      if (both) {
+        HIPCHK(hipEventRecord(e->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
+        ps = e->side_stream;
+      }
+      mjh_launch_prog_stats_acfirst(C, e->d_prog_scans, e->d_lists + pl.par_off, pl.npar, e->d_prog_ctl, e->d_q, e->d_tabs, spi,
+                                    e->d_prog_chunks, e->chunks_per_scan, n, ps);
+      if (both) HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
       if (pl.nseq)
         mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + pl.seq_off, pl.nseq, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
-      mjh_launch_prog_stats_acfirst(C, e->d_prog_scans, e->d_lists + pl.par_off, pl.npar, e->d_prog_ctl, e->d_q, e->d_tabs, spi,
-                                    e->d_prog_chunks, e->chunks_per_scan, n, s);
+      if (both) HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
       pr.mark(ph == 0 ? "gen_tables(A)" : "gen_tables(B)");
       mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + pl.slot_off, pl.nslot, n, s);
       pr.mark(ph == 0 ? "prog_encode(A)" : "prog_encode(B)");
