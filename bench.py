@@ -108,7 +108,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RCCL ("nccl") on a multi-GPU node.  MJH_BENCH_DIST_BACKEND=gloo exists only to exercise this code path on a
+        # box with fewer GPUs than ranks (ranks then share devices; numbers from such a run mean nothing)
+        dist.init_process_group(os.environ.get("MJH_BENCH_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     w, h, B = args.width, args.height, args.batch

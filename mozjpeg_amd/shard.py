@@ -12,6 +12,8 @@ def max_over_ranks(value, dist=None, device=None):
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
     import torch
+    if dist.get_backend() == "gloo":
+        device = None   # gloo reduces host tensors
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
