@@ -258,8 +258,9 @@ struct mjh_encoder {
   // scans of one phase + the table slots they build; for the statistics the scans are split into AC-first scans
   // without restart intervals (parallel kernel) and the rest (sequential per-scan walk)
   struct PList { int scan_off, nscan, slot_off, nslot, par_off, npar, seq_off, nseq; };
-  void *d_prog_chunks = nullptr;     // chunk summaries of the parallel statistics kernel
+  void *d_prog_chunks = nullptr;     // chunk summaries of the parallel statistics / encode kernels
   int chunks_per_scan = 0;
+  MjhProgPE pe{};                    // buffers of the parallel AC-first encode
   PList pl_trellis{}, pl_phase[2]{};
   int nphases = 0;
   unsigned *d_pool = nullptr; size_t pool_words = 0;
@@ -562,7 +563,7 @@ static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *ptrs[] = { e->d_pix, e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_chunks, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pix, e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.info, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -813,6 +814,20 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       e->chunks_per_scan = (mx + MJH_PSTAT_BLOCKS - 1) / MJH_PSTAT_BLOCKS;
       for (const mjh_encoder::PList *pl : { &e->pl_trellis, &e->pl_phase[0], &e->pl_phase[1] }) maxlist = pl->npar > maxlist ? pl->npar : maxlist;
       HIPCHK_E(hipMalloc(&e->d_prog_chunks, B * (size_t)maxlist * e->chunks_per_scan * sizeof(MjhProgChunk)));
+      // parallel encode of the AC-first scans: block lengths / runs / offsets per (scan, image) pair
+      const int maxpar = e->pl_phase[0].npar > e->pl_phase[1].npar ? e->pl_phase[0].npar : e->pl_phase[1].npar;
+      e->pe.chunks_per_scan = e->chunks_per_scan;
+      e->pe.nblk_pad = e->chunks_per_scan * MJH_PSTAT_BLOCKS;
+      e->pe.chunks = (MjhProgChunk *)e->d_prog_chunks;
+      if (maxpar > 0) {
+        const size_t pairs = B * (size_t)maxpar, ent = pairs * (size_t)e->pe.nblk_pad;
+        HIPCHK_E(hipMalloc((void **)&e->pe.len16, ent * 2));
+        HIPCHK_E(hipMalloc((void **)&e->pe.run16, ent * 2));
+        HIPCHK_E(hipMalloc((void **)&e->pe.off32, ent * 4));
+        HIPCHK_E(hipMalloc((void **)&e->pe.sums, pairs * (size_t)e->chunks_per_scan * 4));
+        HIPCHK_E(hipMalloc((void **)&e->pe.totals, pairs * 4));
+        HIPCHK_E(hipMalloc((void **)&e->pe.info, pairs * sizeof(MjhProgPair)));
+      }
     }
     HIPCHK_E(hipMalloc((void **)&e->d_lists, e->h_lists.size() * sizeof(int) + 16));
     HIPCHK_E(hipMemcpy(e->d_lists, e->h_lists.data(), e->h_lists.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -972,9 +987,10 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       pr.mark(ph == 0 ? "gen_tables(A)" : "gen_tables(B)");
       mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + pl.slot_off, pl.nslot, n, s);
       pr.mark(ph == 0 ? "prog_encode(A)" : "prog_encode(B)");
-      mjh_launch_prog_encode(C, e->d_prog_scans, e->d_lists + pl.scan_off, pl.nscan, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_pool, e->pool_words,
+      mjh_launch_prog_encode(C, e->d_prog_scans, e->d_lists + pl.scan_off, pl.nscan, e->d_lists + pl.seq_off, pl.nseq, e->d_lists + pl.par_off, pl.npar,
+                             e->pe, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_pool, e->pool_words,
                              e->d_frame_hdr, e->frame_hdr_len, p.compress_profile != MJH_PROFILE_FASTEST, e->d_outpool, e->outpool_bytes,
-                             e->d_prog_mpos, e->mpos_per_image, n, s);
+                             e->d_prog_mpos, e->mpos_per_image, n, s, e->side_stream, e->ev_fork, e->ev_join);
       if (p.optimize_scans) { pr.mark("prog_select"); mjh_launch_prog_select(e->d_prog_ctl, C.ncomp, ph, n, s); }
     }
     pr.mark("prog_concat");

@@ -120,6 +120,17 @@ struct MjhProgScan {
 #define MJH_PSTAT_BLOCKS 2048
 struct MjhProgChunk { int first_ne, last_ne, e_last, nblk; };
 
+// parallel encode of AC-first scans: per (scan of the list, image) pair the run pending at the end of the scan and
+// whether the pair has to fall back to the sequential walk (a forced emission at EOBRUN == 0x7FFF inside it)
+struct MjhProgPair { unsigned final_run; int fallback; };
+struct MjhProgPE {         // device buffers of that path, [image][scan of the list][...]
+  uint16_t *len16, *run16; // bits of every block (own symbols + the EOBRUN flush in front of it); the run it flushes
+  unsigned *off32, *sums, *totals;
+  MjhProgPair *info;
+  MjhProgChunk *chunks;
+  int chunks_per_scan, nblk_pad;   // nblk_pad = chunks_per_scan * MJH_PSTAT_BLOCKS entries per pair
+};
+
 struct MjhProgCtl {        // per image, lives in HBM
   int best_Al_luma, best_Al_chroma, best_fs_luma, best_fs_chroma;
   unsigned pool_words_used;   // running allocation in the bit-stream pool

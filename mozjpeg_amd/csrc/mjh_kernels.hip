@@ -1737,6 +1737,15 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   hipLaunchKernelGGL((k_trellis_ac_deferred<64>), dim3(512), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, (const unsigned *)worklist2, worklist2);
 }
 
+// exclusive prefix sum of 16-bit lengths, `npairs` independent arrays of n_per entries (the progressive path's
+// parallel encode reuses the sequential coder's scan kernels)
+void mjh_launch_scan16(const void *len16, int n_per, unsigned *sums, int chunks, unsigned *totals, unsigned *off32, int npairs, hipStream_t s)
+{
+  hipLaunchKernelGGL((k_chunk_sums<uint16_t>), dim3(chunks, npairs), dim3(256), 0, s, (const uint16_t *)len16, n_per, sums, chunks);
+  hipLaunchKernelGGL(k_scan_sums, dim3(npairs), dim3(256), 0, s, sums, chunks, totals, (const unsigned *)nullptr);
+  hipLaunchKernelGGL((k_offsets<uint16_t>), dim3(chunks, npairs), dim3(256), 0, s, (const uint16_t *)len16, n_per, sums, chunks, off32);
+}
+
 void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s)
 {
   const int nchains = C.ncomp * C.mcu_rows;

@@ -69,8 +69,10 @@ __global__ void __launch_bounds__(64 * PROG_WAVES(ENCODE))
 k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
             MjhProgCtl *__restrict__ ctl, const int16_t *__restrict__ coef_q, MjhHuffTable *__restrict__ tabs,
             int slots_per_image, unsigned *__restrict__ pool, size_t pool_words_per_image,
-            unsigned *__restrict__ mpos_pool, int mpos_per_image)
+            unsigned *__restrict__ mpos_pool, int mpos_per_image, const MjhProgPair *__restrict__ run_if)
 {
+  // fallback of the parallel encode: only the pairs it flagged are walked sequentially
+  if (run_if && !run_if[(size_t)blockIdx.x * gridDim.y + blockIdx.y].fallback) return;
   __shared__ unsigned hist[2][256];
   __shared__ unsigned s_tab[2][256];   // size << 16 | code
   __shared__ unsigned pend[36];        // pending correction bits, MSB first
@@ -649,8 +651,18 @@ k_prog_stats_acfirst(MjhConst C, const MjhProgScan *__restrict__ scans, const in
     if (i * 256 >= nb) break;   // uniform
     int x[64];
     const int16_t *qs = qc + cb + (j < nb ? j : nb - 1);
+    // only the 8-coefficient groups that overlap the band are fetched (wave-uniform branches; the loads of a group
+    // still go out together): the candidate scans of the search split the band, so this halves their traffic
 #pragma unroll
-    for (int k = 1; k < 64; k++) x[k] = (int)qs[(size_t)k * cc.kstride];
+    for (int g = 0; g < 8; g++) {
+      if (8 * g + 7 >= Ss && 8 * g <= Se) {
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) { const int k = 8 * g + kk; if (k >= 1) x[k] = (int)qs[(size_t)k * cc.kstride]; }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) x[8 * g + kk] = 0;
+      }
+    }
     if (j < nb) {
       int r = 0;
       bool ne = false;
@@ -734,6 +746,262 @@ k_prog_stats_resolve(MjhConst C, const MjhProgScan *__restrict__ scans, const in
   if (sc.seed)   // trellis passes: every (run, size < 12) count starts at 1 (jcphuff.c:257-264)
     for (int i = lane; i < 256; i += 64)
       if ((i & 15) < 12) T0->counts[i] += 1;
+}
+
+// =============================================================================================
+// Parallel ENCODE of AC-first scans without restart intervals (same chunk scheme as the statistics above).  The bits
+// a block contributes = the EOBRUN symbol of the run in front of it (non-empty blocks only) + its own symbols, so:
+//   k_pe_len     per block: own bits, the run in front of it if the previous non-empty block is in the same chunk
+//   k_pe_resolve per (scan, image): the run carried into each chunk -> bits / run of the chunk's first non-empty block;
+//                a run that would reach 0x7FFF (forced emission, jcphuff.c:719) flags the pair for the sequential walk
+//   (prefix sum over the block lengths: the sequential coder's scan kernels)
+//   k_pe_write   per block: EOBRUN symbol + own symbols at its offset
+//   k_pe_finish  per (scan, image): the run pending at the end, the final pad, the size check
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+k_pe_len(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl,
+         const int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe)
+{
+  __shared__ unsigned char s_size[256];
+  __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64], e_bits[MJH_PSTAT_BLOCKS / 64];
+  const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const size_t pair = (size_t)img * gridDim.y + li;
+  const int sidx = scan_list[li];
+  const MjhProgScan sc = scans[sidx];
+  const MjhComp cc = C.c[sc.comp[0]];
+  const int cb = chunk * MJH_PSTAT_BLOCKS;
+  uint16_t *len = pe.len16 + pair * pe.nblk_pad + cb;
+  uint16_t *run = pe.run16 + pair * pe.nblk_pad + cb;
+  if (cb >= cc.nblk) {        // padding of the length array behind the component: contributes nothing to the prefix sum
+    for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) len[i * 256 + tid] = 0;
+    return;
+  }
+  const int nb = min(MJH_PSTAT_BLOCKS, cc.nblk - cb);
+  const MjhProgCtl *ct = ctl + img;
+  const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
+  const int Ss = sc.Ss, Se = sc.Se;
+  const MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
+  const int16_t *qc = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;
+  s_size[tid] = T0->ehufsi[tid];
+  if (tid < MJH_PSTAT_BLOCKS / 64) { ne_bits[tid] = 0; e_bits[tid] = 0; }
+  __syncthreads();
+  unsigned my_ne = 0;
+#pragma unroll 1
+  for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
+    const int j = i * 256 + tid;
+    if (i * 256 >= nb) { len[j] = 0; continue; }   // uniform
+    int x[64];
+    const int16_t *qs = qc + cb + (j < nb ? j : nb - 1);
+    // only the 8-coefficient groups that overlap the band are fetched (wave-uniform branches; the loads of a group
+    // still go out together): the candidate scans of the search split the band, so this halves their traffic
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+      if (8 * g + 7 >= Ss && 8 * g <= Se) {
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) { const int k = 8 * g + kk; if (k >= 1) x[k] = (int)qs[(size_t)k * cc.kstride]; }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) x[8 * g + kk] = 0;
+      }
+    }
+    unsigned own = 0;
+    if (j < nb) {
+      int r = 0;
+      bool ne = false;
+#pragma unroll
+      for (int k = 1; k < 64; k++) {
+        if (k >= Ss && k <= Se) {
+          const int v = x[k];
+          const int a = (v < 0 ? -v : v) >> Al;
+          if (a == 0) r++;
+          else {
+            ne = true;
+            const int nz16 = r >> 4;
+            r &= 15;
+            const int nbits = bitlen((unsigned)a);
+            own += (unsigned)nz16 * s_size[0xF0] + s_size[(r << 4) + nbits] + (unsigned)nbits;
+            r = 0;
+          }
+        }
+      }
+      if (ne) { my_ne |= 1u << i; atomicOr(&ne_bits[j >> 6], 1ull << (j & 63)); }
+      else own = 0;
+      if (r > 0) atomicOr(&e_bits[j >> 6], 1ull << (j & 63));
+      run[j] = 0;
+    }
+    len[j] = (uint16_t)own;
+  }
+  __syncthreads();
+  for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
+    if (!((my_ne >> i) & 1u)) continue;
+    const int j = i * 256 + tid;
+    int w = j >> 6;
+    unsigned long long m = ne_bits[w] & ((1ull << (j & 63)) - 1ull);
+    while (!m && w > 0) { w--; m = ne_bits[w]; }
+    if (m) {
+      const int p = w * 64 + 63 - __builtin_clzll(m);
+      const unsigned cnt = (unsigned)((e_bits[p >> 6] >> (p & 63)) & 1ull) + (unsigned)(j - p - 1);
+      run[j] = (uint16_t)cnt;
+      if (cnt) { int nextra; const int sym = eobrun_symbol(cnt, &nextra); len[j] = (uint16_t)(len[j] + s_size[sym] + nextra); }
+    } else
+      run[j] = 0xFFFFu;    // first non-empty block of the chunk: the run comes from k_pe_resolve
+  }
+  __syncthreads();
+  if (tid == 0) {
+    MjhProgChunk ch;
+    ch.first_ne = -1; ch.last_ne = -1; ch.e_last = 0; ch.nblk = nb;
+    for (int w = 0; w < MJH_PSTAT_BLOCKS / 64; w++)
+      if (ne_bits[w]) { ch.first_ne = w * 64 + __builtin_ctzll(ne_bits[w]); break; }
+    for (int w = MJH_PSTAT_BLOCKS / 64 - 1; w >= 0; w--)
+      if (ne_bits[w]) { ch.last_ne = w * 64 + 63 - __builtin_clzll(ne_bits[w]); break; }
+    if (ch.last_ne >= 0) ch.e_last = (int)((e_bits[ch.last_ne >> 6] >> (ch.last_ne & 63)) & 1ull);
+    pe.chunks[pair * pe.chunks_per_scan + chunk] = ch;
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_pe_resolve(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
+             const MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe)
+{
+  if (threadIdx.x != 0) return;
+  const int img = blockIdx.y, li = blockIdx.x;
+  const size_t pair = (size_t)img * gridDim.x + li;
+  const MjhProgScan sc = scans[scan_list[li]];
+  const MjhComp cc = C.c[sc.comp[0]];
+  const MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
+  const int nchunks = (cc.nblk + MJH_PSTAT_BLOCKS - 1) / MJH_PSTAT_BLOCKS;
+  const MjhProgChunk *chs = pe.chunks + pair * pe.chunks_per_scan;
+  uint16_t *len = pe.len16 + pair * pe.nblk_pad;
+  uint16_t *run = pe.run16 + pair * pe.nblk_pad;
+  unsigned pending = 0;
+  int fallback = 0;
+  for (int c = 0; c < nchunks && !fallback; c++) {
+    const MjhProgChunk ch = chs[c];
+    if (ch.first_ne >= 0) {
+      const unsigned r = pending + (unsigned)ch.first_ne;
+      if (r >= 0x7FFFu) { fallback = 1; break; }
+      const size_t b = (size_t)c * MJH_PSTAT_BLOCKS + ch.first_ne;
+      run[b] = (uint16_t)r;
+      if (r) { int nextra; const int sym = eobrun_symbol(r, &nextra); len[b] = (uint16_t)(len[b] + T0->ehufsi[sym] + nextra); }
+      pending = (unsigned)ch.e_last + (unsigned)(ch.nblk - 1 - ch.last_ne);
+    } else
+      pending += (unsigned)ch.nblk;
+    if (pending >= 0x7FFFu) fallback = 1;
+  }
+  pe.info[pair].final_run = pending;
+  pe.info[pair].fallback = fallback;
+}
+
+__global__ void __launch_bounds__(256)
+k_pe_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl,
+           const int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
+           unsigned *__restrict__ pool, size_t pool_words_per_image, MjhProgPE pe)
+{
+  __shared__ unsigned s_tab[256];   // size << 16 | code
+  const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const size_t pair = (size_t)img * gridDim.y + li;
+  const int sidx = scan_list[li];
+  const MjhProgScan sc = scans[sidx];
+  const MjhComp cc = C.c[sc.comp[0]];
+  const int cb = chunk * MJH_PSTAT_BLOCKS;
+  const MjhProgCtl *ct = ctl + img;
+  if (cb >= cc.nblk || pe.info[pair].fallback || ct->error) return;
+  const int nb = min(MJH_PSTAT_BLOCKS, cc.nblk - cb);
+  const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
+  const int Ss = sc.Ss, Se = sc.Se;
+  const MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
+  const int16_t *qc = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;
+  unsigned *stream = pool + (size_t)img * pool_words_per_image;
+  const unsigned base = ct->scan_words_off[sidx] * 32u;
+  const uint16_t *len = pe.len16 + pair * pe.nblk_pad + cb;
+  const uint16_t *run = pe.run16 + pair * pe.nblk_pad + cb;
+  const unsigned *off = pe.off32 + pair * pe.nblk_pad + cb;
+  s_tab[tid] = ((unsigned)T0->ehufsi[tid] << 16) | T0->ehufco[tid];
+  __syncthreads();
+#pragma unroll 1
+  for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
+    const int j = i * 256 + tid;
+    if (i * 256 >= nb) break;   // uniform
+    int x[64];
+    const int16_t *qs = qc + cb + (j < nb ? j : nb - 1);
+    // only the 8-coefficient groups that overlap the band are fetched (wave-uniform branches; the loads of a group
+    // still go out together): the candidate scans of the search split the band, so this halves their traffic
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+      if (8 * g + 7 >= Ss && 8 * g <= Se) {
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) { const int k = 8 * g + kk; if (k >= 1) x[k] = (int)qs[(size_t)k * cc.kstride]; }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) x[8 * g + kk] = 0;
+      }
+    }
+    if (j < nb && len[j] != 0) {          // non-empty block (its own symbols alone are at least one bit)
+      BitWriter bw;
+      bw.init(stream, base + off[j]);
+      const unsigned cnt = run[j];
+      if (cnt) {                          // the pending EOB run goes out in front of the block (emit_eobrun jcphuff.c:409)
+        int nextra;
+        const unsigned e = s_tab[eobrun_symbol(cnt, &nextra)];
+        bw.put(e & 0xFFFF, (int)(e >> 16));
+        if (nextra) bw.put(cnt & ((1u << nextra) - 1u), nextra);
+      }
+      int r = 0;
+#pragma unroll
+      for (int k = 1; k < 64; k++) {
+        if (k >= Ss && k <= Se) {
+          const int v = x[k];
+          const int a = (v < 0 ? -v : v) >> Al;
+          if (a == 0) r++;
+          else {
+            while (r > 15) { const unsigned e = s_tab[0xF0]; bw.put(e & 0xFFFF, (int)(e >> 16)); r -= 16; }
+            const int nbits = bitlen((unsigned)a);
+            const unsigned e = s_tab[(r << 4) + nbits];
+            bw.put(e & 0xFFFF, (int)(e >> 16));
+            bw.put((unsigned)(v < 0 ? ~a : a), nbits);
+            r = 0;
+          }
+        }
+      }
+      bw.flush();
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_pe_finish(const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, MjhProgCtl *__restrict__ ctl,
+            const MjhHuffTable *__restrict__ tabs, int slots_per_image, unsigned *__restrict__ pool, size_t pool_words_per_image,
+            MjhProgPE pe)
+{
+  if (threadIdx.x != 0) return;
+  const int img = blockIdx.y, li = blockIdx.x;
+  const size_t pair = (size_t)img * gridDim.x + li;
+  const int sidx = scan_list[li];
+  const MjhProgScan sc = scans[sidx];
+  MjhProgCtl *ct = ctl + img;
+  if (pe.info[pair].fallback || ct->error) return;
+  const MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
+  unsigned *stream = pool + (size_t)img * pool_words_per_image;
+  const unsigned base = ct->scan_words_off[sidx] * 32u;
+  unsigned cur = base + pe.totals[pair];
+  const unsigned fr = pe.info[pair].final_run;
+  if (fr) {     // finish_pass_phuff: the run still pending at the end of the scan
+    int nextra;
+    const int sym = eobrun_symbol(fr, &nextra);
+    BitWriter bw;
+    bw.init(stream, cur);
+    bw.put(T0->ehufco[sym], (int)T0->ehufsi[sym]);
+    if (nextra) bw.put(fr & ((1u << nextra) - 1u), nextra);
+    bw.flush();
+    cur += (unsigned)T0->ehufsi[sym] + (unsigned)nextra;
+  }
+  const unsigned tb = cur - base;
+  if (tb & 7u) {   // flush_bits jcphuff.c:362-367: pad the last byte with 1-bits
+    const unsigned padbits = 8u - (tb & 7u), bitpos = cur & 31u;
+    atomicOr(&stream[cur >> 5], __builtin_bswap32(((1u << padbits) - 1u) << (32u - bitpos - padbits)));
+  }
+  if (ct->scan_bits[sidx] != tb) ct->error = 2;   // the size predicted from the statistics must be exact
+  ct->scan_bits[sidx] = tb;
 }
 
 // exact size of every scan's bit stream from its statistics and code lengths, and its place in the
@@ -1050,7 +1318,7 @@ void mjh_launch_prog_stats(const MjhConst &C, const void *scans, const int *list
                            MjhHuffTable *tabs, int spi, unsigned *mpos, int mpos_per_image, int n, hipStream_t s)
 {
   hipLaunchKernelGGL((k_prog_scan<0>), dim3(n, nlist), dim3(64 * PROG_WAVES(0)), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
-                     (const int16_t *)q, tabs, spi, (unsigned *)nullptr, (size_t)0, mpos, mpos_per_image);
+                     (const int16_t *)q, tabs, spi, (unsigned *)nullptr, (size_t)0, mpos, mpos_per_image, (const MjhProgPair *)nullptr);
 }
 
 void mjh_launch_prog_stats_acfirst(const MjhConst &C, const void *scans, const int *list, int nlist, const void *ctl, const void *q,
@@ -1063,16 +1331,44 @@ void mjh_launch_prog_stats_acfirst(const MjhConst &C, const void *scans, const i
                      (const MjhProgChunk *)chunks, chunks_per_scan);
 }
 
-void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
+void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *list, int nlist, const int *seq_list, int nseq,
+                            const int *par_list, int npar, const MjhProgPE &pe, void *ctl, const void *q,
                             MjhHuffTable *tabs, int spi, unsigned *pool, size_t pool_words, const void *frame_hdr, int frame_hdr_len,
-                            int multi_dht, void *outpool, size_t out_bytes, unsigned *mpos, int mpos_per_image, int n, hipStream_t s)
+                            int multi_dht, void *outpool, size_t out_bytes, unsigned *mpos, int mpos_per_image, int n, hipStream_t s,
+                            hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join)
 {
   hipLaunchKernelGGL(k_prog_alloc, dim3(n), dim3(256), 0, s, C, (const MjhProgScan *)scans, list, nlist, (MjhProgCtl *)ctl,
                      (const MjhHuffTable *)tabs, spi, pool_words, out_bytes, n);
   hipLaunchKernelGGL(k_prog_header, dim3(nlist, n), dim3(64), 0, s, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
                      (const MjhHuffTable *)tabs, spi, (const uint8_t *)frame_hdr, frame_hdr_len, multi_dht, (uint8_t *)outpool, out_bytes);
-  hipLaunchKernelGGL((k_prog_scan<1>), dim3(n, nlist), dim3(64 * PROG_WAVES(1)), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
-                     (const int16_t *)q, tabs, spi, pool, pool_words, mpos, mpos_per_image);
+  // the sequential walks (a few long workgroups) and the parallel chain write disjoint scan streams: the chain runs on
+  // the side stream underneath them
+  const bool both = nseq > 0 && npar > 0;
+  hipStream_t ps = s;
+  if (both) {
+    (void)hipEventRecord(ev_fork, s);
+    (void)hipStreamWaitEvent(side, ev_fork, 0);
+    ps = side;
+  }
+  if (npar > 0) {   // AC-first scans: parallel over the whole component
+    const dim3 gchunks(pe.chunks_per_scan, npar, n), gpairs(npar, n);
+    hipLaunchKernelGGL(k_pe_len, gchunks, dim3(256), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhProgCtl *)ctl, (const int16_t *)q,
+                       (const MjhHuffTable *)tabs, spi, pe);
+    hipLaunchKernelGGL(k_pe_resolve, gpairs, dim3(64), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhHuffTable *)tabs, spi, pe);
+    mjh_launch_scan16(pe.len16, pe.nblk_pad, pe.sums, pe.chunks_per_scan, pe.totals, pe.off32, npar * n, ps);
+    hipLaunchKernelGGL(k_pe_write, gchunks, dim3(256), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhProgCtl *)ctl, (const int16_t *)q,
+                       (const MjhHuffTable *)tabs, spi, pool, pool_words, pe);
+    hipLaunchKernelGGL(k_pe_finish, gpairs, dim3(64), 0, ps, (const MjhProgScan *)scans, par_list, (MjhProgCtl *)ctl, (const MjhHuffTable *)tabs, spi,
+                       pool, pool_words, pe);
+    // pairs with a forced emission inside (an EOB run of 32767 blocks): the sequential walk, others return at once
+    hipLaunchKernelGGL((k_prog_scan<1>), dim3(n, npar), dim3(64 * PROG_WAVES(1)), 0, ps, C, (const MjhProgScan *)scans, par_list, (MjhProgCtl *)ctl,
+                       (const int16_t *)q, tabs, spi, pool, pool_words, mpos, mpos_per_image, (const MjhProgPair *)pe.info);
+  }
+  if (both) (void)hipEventRecord(ev_join, side);
+  if (nseq > 0)     // DC, refinement and restart-interval scans: the sequential walk
+    hipLaunchKernelGGL((k_prog_scan<1>), dim3(n, nseq), dim3(64 * PROG_WAVES(1)), 0, s, C, (const MjhProgScan *)scans, seq_list, (MjhProgCtl *)ctl,
+                       (const int16_t *)q, tabs, spi, pool, pool_words, mpos, mpos_per_image, (const MjhProgPair *)nullptr);
+  if (both) (void)hipStreamWaitEvent(s, ev_join, 0);
   hipLaunchKernelGGL(k_prog_stuff, dim3(nlist, n), dim3(256), 0, s, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl, (const unsigned *)pool,
                      pool_words, (uint8_t *)outpool, out_bytes, (const unsigned *)mpos, mpos_per_image);
 }
