@@ -280,3 +280,17 @@ def test_two_host_threads_with_their_own_encoders():
         h, w = img.shape[:2]
         ref = O.encode(O.make_params(w, h, **kw), img)
         assert outs is not None and all(o == ref for o in outs), kw
+
+
+@pytest.mark.gpu
+def test_progressive_eob_run_longer_than_32767_blocks():
+    """a flat image with one busy corner: EOB runs of more than 0x7FFF blocks force an emission inside the run
+    (jcphuff.c:719) -- the parallel AC-first encode hands such scans to the sequential walk"""
+    w = h = 2048                                   # 65 536 luma blocks
+    img = np.full((h, w, 3), 97, np.uint8)
+    img[-64:, -64:] = np.random.default_rng(5).integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    for kw in (dict(fastcrush=True, notrellis=True), dict(fastcrush=True, notrellis=True, sample=(1, 1))):
+        enc = M.Encoder(M.make_params(w, h, **kw))
+        out = enc.encode_host(img)[0]
+        enc.close()
+        assert out == O.encode(O.make_params(w, h, **kw), img), kw
