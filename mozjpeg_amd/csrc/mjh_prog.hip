@@ -7,9 +7,10 @@
 //
 // Parallelisation.  Progressive AC coding carries state across blocks (EOBRUN, and for refinement
 // scans up to ~1000 buffered correction bits with a data-dependent forced-flush rule), so a scan
-// is inherently a sequence.  What IS independent: scans (up to 64 candidates in the scan search),
-// images, and -- inside a scan -- the per-block symbol work.  Hence:
-//   one WORKGROUP (8 waves) per (scan, image); wave w takes the 64-block steps w, w+8, ...:
+// is a sequence in general.  What IS independent: scans (up to 64 candidates in the scan search),
+// images, and -- inside a scan -- the per-block symbol work.  Hence, for DC scans, refinement scans and
+// scans with restart intervals (k_prog_scan):
+//   one WORKGROUP (16 waves) per (scan, image); wave w takes the 64-block steps w, w+16, ...:
 //     phase A  every lane analyses its block in parallel (63 coalesced plane loads in one burst):
 //              own symbol bits, "non-empty" / "contributes to EOBRUN" flags; refinement scans reduce a
 //              block to four 64-bit masks (new / already-nonzero / correction bit / sign);
@@ -27,6 +28,9 @@
 //              (atomicOr into the zeroed pool), overlapping the next steps' phase A/B of other waves.
 // The same kernel in statistics mode feeds the on-device Huffman table builder.  All candidate
 // scans of a search phase run concurrently; the host never sees a symbol.
+// AC-FIRST scans without restart intervals need none of this: a block's bits depend on the blocks before it
+// only through the LENGTH of the EOB run in front of it, so their statistics and their encoding run in
+// parallel over the whole component (k_prog_stats_acfirst/_resolve, k_pe_len/_resolve/_write/_finish below).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mjh_internal.h"
