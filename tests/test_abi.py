@@ -82,6 +82,16 @@ def test_unsupported_configurations_are_errors_not_fallbacks():
     with pytest.raises(M.MjhError) as ei:
         M.Encoder(p)
     assert ei.value.code == M.EINVAL
+    for field, bad in (("smoothing_factor", 101), ("smoothing_factor", -1), ("trellis_num_loops", 17), ("trellis_num_loops", -2)):
+        p = M.make_params(64, 64, baseline=True)
+        setattr(p, field, bad)
+        with pytest.raises(M.MjhError) as ei:
+            M.Encoder(p)
+        assert ei.value.code == M.EINVAL, field
+    p = M.make_params(64, 64, baseline=True, sample=(4, 4))     # 16 + 2 blocks per MCU > 10 (jcmaster.c:540-544)
+    with pytest.raises(M.MjhError) as ei:
+        M.Encoder(p)
+    assert ei.value.code == M.EUNSUPPORTED
 
 
 @pytest.mark.skipif(_gpu_present(), reason="only meaningful on a machine without a GPU")
