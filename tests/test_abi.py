@@ -114,3 +114,21 @@ def test_shim_exports_every_symbol_its_contract_names():
     exported = subprocess.check_output(["nm", "-D", "--defined-only", shim]).decode()
     for n in names:
         assert re.search(r"\sT\s+%s\b" % re.escape(n), exported), "shim does not export " + n
+
+
+@pytest.mark.skipif(_gpu_present(), reason="only meaningful on a machine without a GPU")
+def test_drop_in_without_gpu_fails_loudly_and_writes_nothing(tmp_path):
+    """the unchanged cjpeg with the drop-in in front, on a machine without a GPU: an error exit, never a silent CPU encode"""
+    import subprocess
+    shim = os.path.join(ROOT, "mozjpeg_amd", "libmozjpeg_hip_jpeg62.so")
+    cjpeg = os.path.join(O.REF_DIR, "cjpeg")
+    if not (os.path.exists(shim) and os.path.exists(cjpeg)):
+        pytest.skip("shim or reference cjpeg not built")
+    out = str(tmp_path / "o.jpg")
+    env = dict(os.environ, LD_PRELOAD=shim)
+    env.pop("MOZJPEG_HIP_PASSTHROUGH", None)
+    r = subprocess.run([cjpeg, "-quality", "75", "-baseline", "-outfile", out, os.path.join(ROOT, "tests", "golden", "testorig.ppm")],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0
+    assert b"no CPU fallback" in r.stderr
+    assert not os.path.exists(out) or os.path.getsize(out) == 0
