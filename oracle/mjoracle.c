@@ -720,6 +720,10 @@ typedef struct {
   int qsent[4];
   int last_restart_interval; /* jcmarker.c:660 */
   int progressive;
+  /* trellis_q_opt: sums over the blocks of sum(raw * quantized) and sum(8 * quantized^2) per table and coefficient
+   * (jcdctmgr.c:1299-1306).  Every term is an integer and the totals stay far below 2^53, so the double sums are
+   * exact in ANY order -- a parallel reduction reproduces them bit for bit */
+  double norm_src[4][64], norm_coef[4][64];
 } enc_t;
 
 /* an entropy sink: counts (gather) or bits (emit) */
@@ -974,6 +978,23 @@ static void code_scan(enc_t *e, const scan_t *sc, sink_t *s)
  * a9  quantize_trellis jcdctmgr.c:936-1329 driven by compress_trellis_pass jccoefct.c:356-486.
  * One component; dctbl/actbl are the code LENGTHS of the component's current tables (T7).
  * ------------------------------------------------------------------------------------------ */
+static void q_opt_accumulate(enc_t *e, int ci)
+{ /* jcdctmgr.c:1299-1306 (run per block row there; the order does not matter, see enc_t) */
+  const mjo_params *p = e->p;
+  const mjo_geom *g = &e->g[ci];
+  const int t = p->quant_tbl_no[ci];
+  int br, bi, i;
+  for (br = 0; br < g->hib; br++)
+    for (bi = 0; bi < g->wib; bi++) {
+      const int16_t *src = e->uq[ci] + ((size_t)br * g->wpad + bi) * 64;
+      const int16_t *coef = e->q[ci] + ((size_t)br * g->wpad + bi) * 64;
+      for (i = 1; i < 64; i++) {
+        e->norm_src[t][i] += (int)src[i] * (int)coef[i];
+        e->norm_coef[t][i] += 8 * (int)coef[i] * (int)coef[i];
+      }
+    }
+}
+
 static void trellis_component(enc_t *e, int ci, const dtbl *dctbl, const dtbl *actbl)
 {
   const mjo_params *p = e->p;
@@ -1481,11 +1502,31 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
       /* trellis_num_loops (gather, trellis) pass pairs per component: pass_number / (2 * trellis_num_loops) selects
        * the component (jcmaster.c:462-466); every trellis pass restarts from the unquantized coefficients with the
        * tables gathered from the previous loop's result */
-      for (loop = 0; loop < (p->trellis_num_loops > 1 ? p->trellis_num_loops : 1); loop++) {
+      const int nloops = p->trellis_num_loops > 1 ? p->trellis_num_loops : 1;
+      for (loop = 0; loop < nloops; loop++) {
+        const int pass_number = (ci * nloops + loop) * 2 + 1;   /* of this trellis pass (its gather pass is one before) */
         gather_and_build(&e, &sc, 1);
         make_derived(&e.dc[p->dc_tbl_no[ci]], &dcd);
         make_derived(&e.ac[p->ac_tbl_no[ci]], &acd);
+        if (p->trellis_q_opt && pass_number % (p->num_components * 2) == 1) { /* prepare_for_pass jcmaster.c:687-698 */
+          memset(e.norm_src, 0, sizeof(e.norm_src));
+          memset(e.norm_coef, 0, sizeof(e.norm_coef));
+        }
         trellis_component(&e, ci, &dcd, &acd);
+        if (p->trellis_q_opt) {
+          q_opt_accumulate(&e, ci);
+          if ((pass_number + 1) % (p->num_components * 2) == 0) { /* finish_pass_master jcmaster.c:1014-1030 */
+            int ti, j;
+            for (ti = 0; ti < 4; ti++)
+              for (j = 1; j < 64; j++)
+                if (e.norm_coef[ti][j] != 0.0) {
+                  int q = (int)(e.norm_src[ti][j] / e.norm_coef[ti][j] + 0.5);
+                  if (q > 254) q = 254;
+                  if (q < 1) q = 1;
+                  pp.qtbl[ti][j] = (uint16_t)q;
+                }
+          }
+        }
         gather_and_build(&e, &sc, 1);
       }
     }

@@ -57,6 +57,8 @@ typedef struct {
   int data_precision;             /* 0 or 8: 8-bit samples (uint8); 12: 12-bit samples (uint16), no trellis */
   int trellis_num_loops;          /* JINT_TRELLIS_NUM_LOOPS (jcparam.c:515 default 1; 0 is read as 1): trellis passes per component */
   int smoothing_factor;           /* cinfo->smoothing_factor 0..100 (cjpeg -smooth N): input smoothing in the downsampler, jcsample.c:306-455 */
+  int trellis_q_opt;              /* JBOOLEAN_TRELLIS_Q_OPT: quantization tables re-estimated from the trellis result (jcmaster.c:1014-1030).
+                                   * ORACLE ONLY so far -- the HIP path refuses it */
 } mjo_params;
 
 /* jpeg_set_defaults + jpeg_set_quality + colorspace defaults, as cjpeg would leave them:

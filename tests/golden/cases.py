@@ -72,6 +72,11 @@ CASES = [
     ("base_4x2_restart1", dict(baseline=True, sample=(4, 2), restart=1), True),
     ("default_progressive_2x4", dict(sample=(2, 4)), True),
     ("base_411_smooth20", dict(baseline=True, sample=(4, 1), smooth=20), True),
+    # trellis_q_opt (JBOOLEAN_TRELLIS_Q_OPT, jcmaster.c:1014-1030): ORACLE ONLY so far -- pinned here so that the HIP path
+    # can be checked the day it is built (its sums are exact integers, so a parallel reduction can be bit-exact)
+    ("base_trellis_q_opt", dict(baseline=True, trellis_q_opt=True), False),
+    ("default_progressive_trellis_q_opt", dict(trellis_q_opt=True), False),
+    ("base_422_trellis_q_opt_loops3", dict(baseline=True, trellis_q_opt=True, trellis_loops=3, sample=(2, 1)), False),
 ]
 
 
