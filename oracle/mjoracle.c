@@ -995,13 +995,15 @@ static void q_opt_accumulate(enc_t *e, int ci)
     }
 }
 
-static void trellis_component(enc_t *e, int ci, const dtbl *dctbl, const dtbl *actbl)
-{
+static void trellis_component(enc_t *e, int ci, const dtbl *dctbl, const dtbl *actbl, int Ss, int Se)
+{ /* Ss..Se: 1..63, or one of the two bands of use_scans_in_trellis (select_scan_parameters jcmaster.c:451-467) */
   const mjo_params *p = e->p;
   const mjo_geom *g = &e->g[ci];
   const uint16_t *qt = p->qtbl[p->quant_tbl_no[ci]];
-  const int Ss = 1, Se = 63; /* select_scan_parameters jcmaster.c:462-466 */
   const int v = p->v_samp[ci];
+  /* trellis_eob_opt state of one block row (jcdctmgr.c:977-993) */
+  float *azbc = NULL, *abc = NULL;
+  int *block_run_start = NULL, *requires_eob = NULL;
   int ncand = 2 + 60 / qt[0]; /* get_num_dc_trellis_candidates :930-933 */
   float lambda_tbl[64];
   float *acc_dc[9];
@@ -1019,15 +1021,22 @@ static void trellis_component(enc_t *e, int ci, const dtbl *dctbl, const dtbl *a
     cand_dc[i] = (int16_t *)malloc(sizeof(int16_t) * g->wib);
   }
   memset(run_start, 0, sizeof(run_start));
+  if (p->trellis_eob_opt) {
+    azbc = (float *)malloc(sizeof(float) * (g->wib + 1));
+    abc = (float *)malloc(sizeof(float) * (g->wib + 1));
+    block_run_start = (int *)calloc(g->wib, sizeof(int));
+    requires_eob = (int *)malloc(sizeof(int) * (g->wib + 1));
+  }
 
   for (br = 0; br < g->hib; br++) {
     if (br % v == 0) last_dc = 0; /* jccoefct.c:418: per iMCU row */
+    if (p->trellis_eob_opt) { azbc[0] = 0.0f; abc[0] = 0.0f; requires_eob[0] = 0; }
     for (bi = 0; bi < g->wib; bi++) {
       const int16_t *src = e->uq[ci] + ((size_t)br * g->wpad + bi) * 64;
       int16_t *coef = e->q[ci] + ((size_t)br * g->wpad + bi) * 64;
       float azd[64], acost[64];
-      float norm = 0.0f, lambda, lambda_dc, best_cost;
-      int last_coeff_idx;
+      float norm = 0.0f, lambda, lambda_dc, best_cost, cost_all_zeros, best_cost_skip;
+      int last_coeff_idx, has_eob;
       for (i = 1; i < 64; i++) norm = norm + (float)((int)src[i] * (int)src[i]); /* :1027-1031 */
       norm = (float)((double)norm / 63.0);
       if (p->lambda_log_scale2 > 0.0f)
@@ -1131,21 +1140,74 @@ static void trellis_component(enc_t *e, int ci, const dtbl *dctbl, const dtbl *a
       /* EOB choice :1187-1207 */
       last_coeff_idx = Ss - 1;
       best_cost = azd[Se] + (float)actbl->size[0];
+      cost_all_zeros = azd[Se];
+      best_cost_skip = cost_all_zeros;
       for (i = Ss; i <= Se; i++) {
         int z = ZZ[i];
         if (coef[z] != 0) {
-          float cost = acost[i] + azd[Se];
+          float cost = acost[i] + azd[Se], cost_wo_eob;
           cost = cost - azd[i];
+          cost_wo_eob = cost;
           if (i < Se) cost = cost + (float)actbl->size[0];
-          if (cost < best_cost) { best_cost = cost; last_coeff_idx = i; }
+          if (cost < best_cost) { best_cost = cost; last_coeff_idx = i; best_cost_skip = cost_wo_eob; }
         }
       }
+      has_eob = (last_coeff_idx < Se) + (last_coeff_idx == Ss - 1);
       /* back-track :1211-1222 */
       i = Se;
       while (i >= Ss) {
         while (i > last_coeff_idx) { coef[ZZ[i]] = 0; i--; }
         last_coeff_idx = run_start[i];
         i--;
+      }
+      if (p->trellis_eob_opt) { /* :1224-1256: cheapest way to reach block bi through runs of all-zero blocks */
+        azbc[bi + 1] = azbc[bi];
+        azbc[bi + 1] += cost_all_zeros;
+        requires_eob[bi + 1] = has_eob;
+        best_cost = 1e38f;
+        if (has_eob != 2) {
+          for (i = 0; i <= bi; i++) {
+            int zero_block_run, nb;
+            float cost;
+            if (requires_eob[i] == 2) continue;
+            cost = best_cost_skip;
+            cost += azbc[bi];
+            cost -= azbc[i];
+            cost += abc[i];
+            zero_block_run = bi - i + requires_eob[i];
+            nb = nbits_of((unsigned)zero_block_run);
+            cost += (float)(actbl->size[16 * nb] + nb);
+            if (cost < best_cost) { block_run_start[bi] = i; best_cost = cost; abc[bi + 1] = cost; }
+          }
+        }
+      }
+    }
+    if (p->trellis_eob_opt) { /* :1259-1293: choose the end of the last run, then zero the blocks inside the chosen runs */
+      const int num_blocks = g->wib;
+      int last_block = num_blocks;
+      float best = 1e38f;
+      for (i = 0; i <= num_blocks; i++) {
+        int zero_block_run, nb;
+        float cost = 0.0f;
+        if (requires_eob[i] == 2) continue;
+        cost += azbc[num_blocks];
+        cost -= azbc[i];
+        zero_block_run = num_blocks - i + requires_eob[i];
+        nb = nbits_of((unsigned)zero_block_run);
+        cost += (float)(actbl->size[16 * nb] + nb);
+        if (cost < best) { best = cost; last_block = i; }
+      }
+      last_block--;
+      bi = num_blocks - 1;
+      while (bi >= 0) {
+        while (bi > last_block) {
+          int16_t *coef = e->q[ci] + ((size_t)br * g->wpad + bi) * 64;
+          for (j = Ss; j <= Se; j++) coef[ZZ[j]] = 0;
+          bi--;
+        }
+        if (bi < 0) break;
+        last_block = block_run_start[bi] - 1;
+        bi--;
       }
     }
     if (p->trellis_quant_dc) { /* :1308-1327 */
@@ -1161,6 +1223,7 @@ static void trellis_component(enc_t *e, int ci, const dtbl *dctbl, const dtbl *a
   }
   build_dummies(p, g, ci, e->q[ci]); /* jccoefct.c:443-476 */
   for (i = 0; i < 9; i++) { free(acc_dc[i]); free(back_dc[i]); free(cand_dc[i]); }
+  free(azbc); free(abc); free(block_run_start); free(requires_eob);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1503,31 +1566,41 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
        * the component (jcmaster.c:462-466); every trellis pass restarts from the unquantized coefficients with the
        * tables gathered from the previous loop's result */
       const int nloops = p->trellis_num_loops > 1 ? p->trellis_num_loops : 1;
+      const int nbands = p->use_scans_in_trellis ? 2 : 1;          /* jcmaster.c:451-467 */
+      const int split = p->trellis_freq_split > 0 ? p->trellis_freq_split : 8;
+      const int ppc = 2 * nbands;                                   /* passes per component and loop */
       for (loop = 0; loop < nloops; loop++) {
-        const int pass_number = (ci * nloops + loop) * 2 + 1;   /* of this trellis pass (its gather pass is one before) */
-        gather_and_build(&e, &sc, 1);
-        make_derived(&e.dc[p->dc_tbl_no[ci]], &dcd);
-        make_derived(&e.ac[p->ac_tbl_no[ci]], &acd);
-        if (p->trellis_q_opt && pass_number % (p->num_components * 2) == 1) { /* prepare_for_pass jcmaster.c:687-698 */
-          memset(e.norm_src, 0, sizeof(e.norm_src));
-          memset(e.norm_coef, 0, sizeof(e.norm_coef));
-        }
-        trellis_component(&e, ci, &dcd, &acd);
-        if (p->trellis_q_opt) {
-          q_opt_accumulate(&e, ci);
-          if ((pass_number + 1) % (p->num_components * 2) == 0) { /* finish_pass_master jcmaster.c:1014-1030 */
-            int ti, j;
-            for (ti = 0; ti < 4; ti++)
-              for (j = 1; j < 64; j++)
-                if (e.norm_coef[ti][j] != 0.0) {
-                  int q = (int)(e.norm_src[ti][j] / e.norm_coef[ti][j] + 0.5);
-                  if (q > 254) q = 254;
-                  if (q < 1) q = 1;
-                  pp.qtbl[ti][j] = (uint16_t)q;
-                }
+        int band;
+        for (band = 0; band < nbands; band++) {
+          const int pass_number = (ci * nloops + loop) * ppc + 2 * band + 1;   /* of this trellis pass (its gather pass is one before) */
+          const int bSs = nbands == 1 ? 1 : (band == 0 ? 1 : split + 1);
+          const int bSe = nbands == 1 ? 63 : (band == 0 ? split : 63);
+          ms.Ss = bSs; ms.Se = bSe;
+          setup_scan(&e, &sc, &ms);
+          gather_and_build(&e, &sc, 1);
+          make_derived(&e.dc[p->dc_tbl_no[ci]], &dcd);
+          make_derived(&e.ac[p->ac_tbl_no[ci]], &acd);
+          if (p->trellis_q_opt && pass_number % (p->num_components * ppc) == 1) { /* prepare_for_pass jcmaster.c:687-698 */
+            memset(e.norm_src, 0, sizeof(e.norm_src));
+            memset(e.norm_coef, 0, sizeof(e.norm_coef));
           }
+          if (bSe >= bSs) trellis_component(&e, ci, &dcd, &acd, bSs, bSe);   /* quantize_trellis returns at once for an empty band (:983-984) */
+          if (p->trellis_q_opt) {
+            q_opt_accumulate(&e, ci);
+            if ((pass_number + 1) % (p->num_components * ppc) == 0) { /* finish_pass_master jcmaster.c:1014-1030 */
+              int ti, j;
+              for (ti = 0; ti < 4; ti++)
+                for (j = 1; j < 64; j++)
+                  if (e.norm_coef[ti][j] != 0.0) {
+                    int q = (int)(e.norm_src[ti][j] / e.norm_coef[ti][j] + 0.5);
+                    if (q > 254) q = 254;
+                    if (q < 1) q = 1;
+                    pp.qtbl[ti][j] = (uint16_t)q;
+                  }
+            }
+          }
+          gather_and_build(&e, &sc, 1);
         }
-        gather_and_build(&e, &sc, 1);
       }
     }
   }

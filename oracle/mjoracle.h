@@ -59,6 +59,10 @@ typedef struct {
   int smoothing_factor;           /* cinfo->smoothing_factor 0..100 (cjpeg -smooth N): input smoothing in the downsampler, jcsample.c:306-455 */
   int trellis_q_opt;              /* JBOOLEAN_TRELLIS_Q_OPT: quantization tables re-estimated from the trellis result (jcmaster.c:1014-1030).
                                    * ORACLE ONLY so far -- the HIP path refuses it */
+  /* the remaining trellis options of SURVEY 8f row 4 -- ORACLE ONLY so far, the HIP path refuses them */
+  int trellis_eob_opt;            /* JBOOLEAN_TRELLIS_EOB_OPT: EOB runs over all-zero blocks optimised along a block row, jcdctmgr.c:1224-1297 */
+  int use_scans_in_trellis;       /* JBOOLEAN_USE_SCANS_IN_TRELLIS: two trellis passes per component, bands 1..split / split+1..63, jcmaster.c:453-460 */
+  int trellis_freq_split;         /* JINT_TRELLIS_FREQ_SPLIT (0 is read as the default 8, jcparam.c:512) */
 } mjo_params;
 
 /* jpeg_set_defaults + jpeg_set_quality + colorspace defaults, as cjpeg would leave them:

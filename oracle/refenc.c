@@ -63,7 +63,7 @@ int main(int argc, char **argv)
   int notrellis = 0, notrellis_dc = 0, noovershoot = 0, gray = 0, grayin = 0, qtbl = -1;
   int hs = 2, vs = 2, restart = 0, restart_blocks = 0, reps = 1, rawW = 0, rawH = 0;
   double l1 = -1e9, l2 = -1e9;
-  int precision = 8, yuvin = 0, trellis_loops = 0, smooth = 0, trellis_q_opt = 0;
+  int precision = 8, yuvin = 0, trellis_loops = 0, smooth = 0, trellis_q_opt = 0, eob_opt = 0, scans_in_trellis = 0, freq_split = 0;
   const char *dump = NULL, *in = NULL, *out = NULL;
   int i, w, h, nc;
   unsigned char *img;
@@ -98,6 +98,9 @@ int main(int argc, char **argv)
     else if (!strcmp(a, "-raw")) { rawW = atoi(argv[++i]); rawH = atoi(argv[++i]); }
     else if (!strcmp(a, "-dumpcoef")) dump = argv[++i];
     else if (!strcmp(a, "-trellis-loops")) trellis_loops = atoi(argv[++i]);   /* JINT_TRELLIS_NUM_LOOPS: API-only parameter */
+    else if (!strcmp(a, "-trellis-eob-opt")) eob_opt = 1;                 /* JBOOLEAN_TRELLIS_EOB_OPT */
+    else if (!strcmp(a, "-use-scans-in-trellis")) scans_in_trellis = 1;   /* JBOOLEAN_USE_SCANS_IN_TRELLIS */
+    else if (!strcmp(a, "-trellis-freq-split")) freq_split = atoi(argv[++i]);   /* JINT_TRELLIS_FREQ_SPLIT */
     else if (!strcmp(a, "-trellis-q-opt")) trellis_q_opt = 1;   /* JBOOLEAN_TRELLIS_Q_OPT: API-only parameter */
     else if (!strcmp(a, "-smooth")) smooth = atoi(argv[++i]);   /* cjpeg -smooth N (cjpeg.c: cinfo->smoothing_factor) */
     else if (!strcmp(a, "-yuvin")) yuvin = 1;   /* -raw W H input holds component planes: jpeg_write_raw_data */
@@ -155,6 +158,9 @@ int main(int argc, char **argv)
     if (progressive || fastcrush || (!revert && !baseline)) jpeg_simple_progression(&cinfo);
     cinfo.smoothing_factor = smooth;
     if (trellis_q_opt) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_TRELLIS_Q_OPT, TRUE);
+    if (eob_opt) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_TRELLIS_EOB_OPT, TRUE);
+    if (scans_in_trellis) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_USE_SCANS_IN_TRELLIS, TRUE);
+    if (freq_split) jpeg_c_set_int_param(&cinfo, JINT_TRELLIS_FREQ_SPLIT, freq_split);
     if (trellis_loops) jpeg_c_set_int_param(&cinfo, JINT_TRELLIS_NUM_LOOPS, trellis_loops);
     if (notrellis) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_TRELLIS_QUANT, FALSE);
     if (notrellis_dc) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_TRELLIS_QUANT_DC, FALSE);

@@ -77,6 +77,12 @@ CASES = [
     ("base_trellis_q_opt", dict(baseline=True, trellis_q_opt=True), False),
     ("default_progressive_trellis_q_opt", dict(trellis_q_opt=True), False),
     ("base_422_trellis_q_opt_loops3", dict(baseline=True, trellis_q_opt=True, trellis_loops=3, sample=(2, 1)), False),
+    # trellis_eob_opt (jcdctmgr.c:1224-1297) and use_scans_in_trellis (jcmaster.c:451-460): ORACLE ONLY so far
+    ("default_progressive_eob_opt", dict(trellis_eob_opt=True), False),
+    ("fastcrush_scans_in_trellis_eob_opt", dict(fastcrush=True, use_scans_in_trellis=True, trellis_eob_opt=True), False),
+    ("base_scans_in_trellis", dict(baseline=True, use_scans_in_trellis=True), False),
+    ("progressive_all_trellis_options", dict(use_scans_in_trellis=True, trellis_freq_split=5, trellis_eob_opt=True, trellis_q_opt=True,
+                                             trellis_loops=2), False),
 ]
 
 

@@ -32,7 +32,8 @@ class Params(C.Structure):
                 ("restart_interval", C.c_int), ("restart_in_rows", C.c_int),
                 ("num_scans", C.c_int), ("scans", Scan * MAXS), ("optimize_scans", C.c_int),
                 ("write_jfif", C.c_int), ("data_precision", C.c_int), ("trellis_num_loops", C.c_int),
-                ("smoothing_factor", C.c_int), ("trellis_q_opt", C.c_int)]
+                ("smoothing_factor", C.c_int), ("trellis_q_opt", C.c_int),
+                ("trellis_eob_opt", C.c_int), ("use_scans_in_trellis", C.c_int), ("trellis_freq_split", C.c_int)]
 
 
 class Geom(C.Structure):
@@ -70,7 +71,8 @@ def lib():
 def make_params(width, height, *, quality=75, baseline=False, revert=False, optimize=False,
                 progressive=False, fastcrush=False, notrellis=False, notrellis_dc=False,
                 noovershoot=False, sample=(2, 2), restart=None, gray=False, grayin=False,
-                quant_table=-1, lambda1=None, lambda2=None, precision=8, trellis_loops=1, smooth=0, trellis_q_opt=False):
+                quant_table=-1, lambda1=None, lambda2=None, precision=8, trellis_loops=1, smooth=0, trellis_q_opt=False,
+                trellis_eob_opt=False, use_scans_in_trellis=False, trellis_freq_split=0):
     """Same switch vocabulary as cjpeg / oracle/refenc.c.  Default (no switch) is cjpeg's default:
     max-compression profile, progressive with scan search."""
     p = Params()
@@ -93,6 +95,9 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     p.trellis_num_loops = trellis_loops
     p.smoothing_factor = smooth
     p.trellis_q_opt = 1 if trellis_q_opt else 0
+    p.trellis_eob_opt = 1 if trellis_eob_opt else 0
+    p.use_scans_in_trellis = 1 if use_scans_in_trellis else 0
+    p.trellis_freq_split = trellis_freq_split
     if restart is not None:
         if isinstance(restart, str) and restart.lower().endswith("b"):
             p.restart_interval = int(restart[:-1])
@@ -291,6 +296,12 @@ def ref_switches(**kw):
         sw += ["-precision", "12"]
     if kw.get("trellis_q_opt"):
         sw.append("-trellis-q-opt")
+    if kw.get("trellis_eob_opt"):
+        sw.append("-trellis-eob-opt")
+    if kw.get("use_scans_in_trellis"):
+        sw.append("-use-scans-in-trellis")
+    if kw.get("trellis_freq_split", 0):
+        sw += ["-trellis-freq-split", str(kw["trellis_freq_split"])]
     if kw.get("smooth", 0):
         sw += ["-smooth", str(kw["smooth"])]
     if kw.get("trellis_loops", 1) != 1:
