@@ -44,7 +44,8 @@ def test_oracle_matches_live_reference_random_sizes():
         img = base[:h, :w].copy()
         for kw in (dict(baseline=True), dict(), dict(baseline=True, restart=1), dict(fastcrush=True, restart=2),
                    dict(baseline=True, sample=(4, 1), smooth=25), dict(revert=True, sample=(1, 4), optimize=True),
-                   dict(baseline=True, trellis_loops=2, sample=(2, 1))):
+                   dict(baseline=True, trellis_loops=2, sample=(2, 1)),
+                   dict(fastcrush=True, trellis_eob_opt=True, use_scans_in_trellis=True, trellis_q_opt=True)):
             a = O.encode(O.make_params(w, h, **kw), img)
             b, _ = O.ref_encode(img, **kw)
             assert a == b, (w, h, kw)
