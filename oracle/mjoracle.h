@@ -10,7 +10,7 @@
  * MD5_JPEG_420_ISLOW = 9a68f56bc76e466aa7e52f415d0f4a5f (CMakeLists.txt:1391) and the other
  * cjpeg -revert bittest constants usable on this path, and (ii) the REAL reference compiled
  * from /root/reference into oracle/_ref (oracle/Makefile), byte for byte, on the fixture set
- * under tests/golden/ (tests/test_oracle_vs_reference.py, tests/golden/make_goldens.py).
+ * under tests/golden/ (tests/test_oracle_goldens.py, tests/golden/make_goldens.py).
  * The reference has no test that pins trellis / deringing / scan search; for
  * those modes the compiled reference is the only authority.
  *
