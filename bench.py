@@ -3,20 +3,28 @@
 
 One "step" = one pass of the whole hot path (colour/downsample -> FDCT/quantize -> statistics ->
 Huffman tables -> AC+DC trellis -> final tables -> bit packing/stuffing/headers) over one batch
-of synthetic frames that are already resident in HBM.  Workload at every N: 3840x2160 RGB,
-quality 75, 4:2:0, baseline (sequential) mode with trellis quantization, overshoot deringing
-and optimal Huffman tables = `cjpeg -quality 75 -baseline` = the configuration the metric is
-quoted on.  N>1: one process per GPU, every rank encodes its own batch (images are independent:
-weak scaling, no collective on the data path).
+of synthetic frames.  Default workload (--config metric): 3840x2160 RGB, quality 75, 4:2:0,
+baseline (sequential) mode with trellis quantization, overshoot deringing and optimal Huffman
+tables = `cjpeg -quality 75 -baseline` = the configuration the metric is quoted on.  --config
+c2|c3|c4|c5|c5t selects the other BASELINE.json configurations (same JSON line, their own workload).
+N>1: one process per GPU, every rank encodes its own share of the batch (images are independent:
+weak scaling, no collective on the data path; c4 shards its 1024 frames: strong scaling).
 
-Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- dominant kernel by HIP-event time inside the timed region (events are recorded
-                  on the encoder's own stream), algorithmic bytes = input samples + JPEG bytes of
-                  one batch, peak = 8 TB/s HBM.
-  cpu_baseline -- the reference mozjpeg (oracle/_ref, C build) or, if that binary is absent, the
-                  C port in oracle/, timed on this box's host cores on a bounded sample.
+Prints ONE JSON line (rank 0).  `value` is the DEVICE-RESIDENT rate (frames already in HBM when the
+timed region starts, complete JPEG files left in HBM), as the contract defines it.  Extra objects:
+  host_inclusive -- the wall the reference's own definition asks for: pixels in pinned host
+                  memory -> JPEG files in host memory, H2D and D2H included, >= 3 s of back-to-back batches through the
+                  asynchronous double-buffered mjh_encode_host / mjh_collect path.  Never `value`.
+  bit_exact     -- EVERY frame of the batch compared byte for byte with the real reference (oracle/_ref/refenc, the
+                  reference's libjpeg driven like cjpeg) where that binary exists, else with the C port (oracle/).
+  roofline      -- dominant kernel by HIP-event time inside the timed region (events are recorded on the encoder's own
+                  stream), algorithmic bytes = input samples + JPEG bytes of one batch, peak = 8 TB/s HBM.
+  cpu_baseline  -- the reference mozjpeg (oracle/_ref, C build) or, if that binary is absent, the C port in oracle/,
+                  timed on this box's host cores on a bounded sample.
 """
 import argparse
+import concurrent.futures as cf
+import glob
 import json
 import os
 import subprocess
@@ -30,8 +38,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-W, H, QUALITY = 3840, 2160, 75
 HBM_PEAK_GBS = 8000.0
+
+# BASELINE.json configs (SURVEY 8d "Config -> concrete runs").  batch = frames per step per GPU.
+CONFIGS = {
+    "metric": dict(w=3840, h=2160, kw=dict(quality=75, baseline=True), batch=64,
+                   name="3840x2160 synthetic RGB, q75 4:2:0 baseline, trellis+deringing+optimal Huffman (cjpeg -quality 75 -baseline)"),
+    "c2": dict(w=1920, h=1080, kw=dict(quality=75, baseline=True), batch=64,
+               name="C2: 1920x1080 synthetic RGB, q75 4:2:0 baseline, trellis on (cjpeg -quality 75 -baseline)"),
+    "c3": dict(w=3840, h=2160, kw=dict(quality=85, sample=(2, 2)), batch=8,
+               name="C3: 3840x2160 synthetic RGB, q85 4:2:0 progressive + scan search (cjpeg -quality 85 -sample 2x2)"),
+    "c4": dict(w=1920, h=1080, kw=dict(quality=75, baseline=True), batch=128, total=1024,
+               name="C4: batch of 1024 x 1920x1080 frames, q75 trellis baseline, sharded over the GPUs (128 per encode call)"),
+    "c5": dict(w=8192, h=8192, kw=dict(precision=12, baseline=True, notrellis=True, quality=90, sample=(1, 1), restart=1), batch=1,
+               name="C5: 8192x8192 12-bit, q90 4:4:4, restart interval = MCU row, -notrellis (the reference aborts on 12-bit + trellis, SURVEY F1)"),
+    "c5t": dict(w=8192, h=8192, kw=dict(baseline=True, quality=90, sample=(1, 1), restart=1), batch=1,
+                name="C5 8-bit twin: 8192x8192, q90 4:4:4 trellis, restart interval = MCU row"),
+}
 
 
 def usable_cores():
@@ -46,18 +69,53 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(frame, budget_s=20.0):
+def _refenc_cmd(w, h, kw):
+    import oracle_lib as O
+    return [os.path.join(O.REF_DIR, "refenc")] + O.ref_switches(**kw) + ["-raw", str(w), str(h)]
+
+
+def _ref_one(args):
+    cmd, raw, out = args
+    subprocess.check_output(cmd + [raw, out])
+    with open(out, "rb") as f:
+        return f.read()
+
+
+def verify_frames(frames, jpegs, w, h, kw, limit=None):
+    """EVERY frame (or the first `limit`) against the real reference where it exists (oracle/_ref/refenc), else the
+    C port.  Checker only: nothing here is timed or shipped."""
+    import oracle_lib as O
+    n = len(jpegs) if limit is None else min(limit, len(jpegs))
+    if O.have_ref():
+        cmd = _refenc_cmd(w, h, kw)
+        with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+            jobs = []
+            for i in range(n):
+                raw = os.path.join(td, "f%d.raw" % i)
+                frames[i].tofile(raw)
+                jobs.append((cmd, raw, os.path.join(td, "o%d.jpg" % i)))
+            with cf.ThreadPoolExecutor(max_workers=usable_cores()) as ex:
+                refs = list(ex.map(_ref_one, jobs))
+        kind = "reference (oracle/_ref/refenc)"
+    else:
+        po = O.make_params(w, h, **kw)
+        refs = [O.encode(po, frames[i]) for i in range(n)]
+        kind = "port (oracle/libmjoracle.so)"
+    same = sum(1 for i in range(n) if refs[i] == jpegs[i])
+    return {"checked": n, "identical": same, "against": kind, "ok": same == n}
+
+
+def cpu_baseline(frame, kw, budget_s=20.0):
     """Reference encoder on the host cores, bounded sample.  Checker/baseline only."""
     import oracle_lib as O
     cores = usable_cores()
     h, w = frame.shape[:2]
     if O.have_ref():
-        # one process per core, each encodes the same 4K frame `reps` times in memory
+        # one process per core, each encodes the same frame `reps` times in memory
         with tempfile.TemporaryDirectory() as td:
             raw = os.path.join(td, "f.rgb")
             frame.tofile(raw)
-            exe = os.path.join(O.REF_DIR, "refenc")
-            base = [exe, "-quality", str(QUALITY), "-baseline", "-sample", "2x2", "-raw", str(w), str(h)]
+            base = _refenc_cmd(w, h, kw)
             t0 = time.time()
             subprocess.check_output(base + ["-reps", "1", raw, os.path.join(td, "o.jpg")])
             one = time.time() - t0
@@ -72,7 +130,7 @@ def cpu_baseline(frame, budget_s=20.0):
                 "kind": "reference",
                 "sample": "%d procs x %d reps of one %dx%d frame, refenc (mozjpeg C build, no SIMD: no NASM), "
                           "in-memory libjpeg API; best single-core %.1f Mpixels/s" % (cores, reps, w, h, best1)}
-    p = O.make_params(w, h, quality=QUALITY, baseline=True)
+    p = O.make_params(w, h, **kw)
     t0 = time.time()
     O.encode(p, frame)
     dt = time.time() - t0
@@ -88,10 +146,77 @@ def baseline_metric():
         return "Mpixels/s encode (4K RGB q75 trellis) at 1/2/4/8 GPUs; bit-exact vs cjpeg"
 
 
-def _make_frame(w, h, seed):
+def _make_frame(w, h, seed, twelve):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    return O.synthetic_frame(w, h, seed)
+    return (O.synthetic_frame12 if twelve else O.synthetic_frame)(w, h, seed)
+
+
+def make_frames(w, h, seeds, twelve, world):
+    """synthetic frames, one seed per frame, generated by a few worker processes (numpy takes seconds per
+    4K frame) -- input preparation, outside every timed region"""
+    workers = max(1, min(len(seeds), usable_cores() // max(1, world)))
+    if workers > 1:
+        try:
+            import multiprocessing as mp
+            with mp.get_context("spawn").Pool(workers) as pool:
+                return np.stack(pool.starmap(_make_frame, [(w, h, sd, twelve) for sd in seeds]))
+        except Exception as exc:   # no worker processes available: same frames, just slower
+            print("bench: frame workers unavailable (%s), generating serially" % exc, file=sys.stderr)
+    return np.stack([_make_frame(w, h, sd, twelve) for sd in seeds])
+
+
+def host_inclusive(M, params, frames, hb, device, min_s, ref_jpegs):
+    """pixels in PINNED host memory -> JPEG files in host memory, >= min_s seconds of back-to-back batches of hb frames:
+    batch k+1 is queued (H2D on the copy stream) before batch k is picked up, so copies, kernels and the hand-over of
+    the files overlap.  Every file of the first pass is compared with the device-resident run's (already verified)."""
+    n = frames.shape[0]
+    pinned = M.pinned_empty(frames.shape, frames.dtype)
+    pinned[...] = frames
+    enc = M.Encoder(params, max_batch=hb, device=device)
+    starts = list(range(0, n - hb + 1, hb)) or [0]
+    hb = min(hb, n)
+
+    def take(age):
+        return enc.collect(age=age, copy=False)
+
+    # warm-up + check of every file of one pass over the frames
+    same = checked = 0
+    enc.submit_host(pinned[starts[0]:starts[0] + hb])
+    for k in range(1, len(starts)):
+        enc.submit_host(pinned[starts[k]:starts[k] + hb])
+        for j, mv in enumerate(take(1)):
+            checked += 1
+            same += bytes(mv) == ref_jpegs[starts[k - 1] + j]
+    for j, mv in enumerate(take(0)):
+        checked += 1
+        same += bytes(mv) == ref_jpegs[starts[-1] + j]
+    # timed: the host touches every output byte once (sums the sizes; the files ARE in host memory)
+    done = 0
+    out_bytes = 0
+    t0 = time.perf_counter()
+    enc.submit_host(pinned[starts[0]:starts[0] + hb])
+    k = 1
+    while True:
+        enc.submit_host(pinned[starts[k % len(starts)]:starts[k % len(starts)] + hb])
+        res = take(1)
+        done += len(res)
+        out_bytes += sum(len(r) for r in res)
+        k += 1
+        if time.perf_counter() - t0 >= min_s and k >= 3:
+            break
+    res = take(0)
+    done += len(res)
+    out_bytes += sum(len(r) for r in res)
+    dt = time.perf_counter() - t0
+    h, w = frames.shape[1:3]
+    enc.close()
+    in_bytes = done * frames[0].nbytes
+    return {"value": round(done * w * h / dt / 1e6, 2), "unit": "Mpixels/s", "seconds": round(dt, 3), "frames": done,
+            "frames_per_call": hb, "input_GBps": round(in_bytes / dt / 1e9, 2), "output_GBps": round(out_bytes / dt / 1e9, 3),
+            "files_identical_to_device_run": "%d/%d" % (same, checked),
+            "path": "pinned host pixels -> hipMemcpyAsync on the copy stream -> kernels -> files packed into pinned host memory by "
+                    "the device (mjh_encode_host / mjh_collect, double-buffered); one host thread"}
 
 
 def main():
@@ -99,16 +224,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--config", default="metric", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="frames per encode call per GPU (0 = the config's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--width", type=int, default=W)
-    ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--no-host-leg", action="store_true")
+    ap.add_argument("--host-seconds", type=float, default=3.0)
+    ap.add_argument("--host-batch", type=int, default=16)
+    ap.add_argument("--verify", default="all", help="frames per batch to compare with the reference: all | N")
     args = ap.parse_args()
 
     import torch
     import mozjpeg_amd as M
-    import oracle_lib as O
 
+    cfg = CONFIGS[args.config]
+    w, h, kw = cfg["w"], cfg["h"], cfg["kw"]
+    twelve = kw.get("precision", 8) == 12
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,28 +252,29 @@ def main():
     local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    w, h, B = args.width, args.height, args.batch
-
-    # synthetic frames, different seed per frame and rank; generated by a few worker processes
-    # (numpy takes seconds per 4K frame) -- input preparation, outside every timed region
-    seeds = [1234 + rank * B + i for i in range(B)]
-    workers = max(1, min(B, usable_cores() // max(1, world)))
-    frames = None
-    if workers > 1:
-        try:
-            import multiprocessing as mp
-            with mp.get_context("spawn").Pool(workers) as pool:
-                frames = np.stack(pool.starmap(_make_frame, [(w, h, sd) for sd in seeds]))
-        except Exception as exc:   # no worker processes available: same frames, just slower
-            print("bench: frame workers unavailable (%s), generating serially" % exc, file=sys.stderr)
-    if frames is None:
-        frames = np.stack([O.synthetic_frame(w, h, sd) for sd in seeds])
-    d_frames = torch.from_numpy(frames).to(dev)
-    params = M.make_params(w, h, quality=QUALITY, baseline=True)
+    B = args.batch or cfg["batch"]
+    # frames this rank encodes per step: its own batch (weak scaling), or its shard of a fixed total (c4: strong)
+    total = cfg.get("total")
+    from mozjpeg_amd import shard
+    if total:
+        mine = shard.shard_indices(total, rank, world)
+        nframes = len(mine)
+        B = min(B, nframes)
+        seeds = [1234 + i for i in mine]
+    else:
+        nframes = B
+        seeds = [1234 + rank * B + i for i in range(B)]
+    frames = make_frames(w, h, seeds, twelve, world)
+    d_frames = torch.from_numpy(frames.view(np.int16) if twelve else frames).to(dev)
+    params = M.make_params(w, h, **kw)
     enc = M.Encoder(params, max_batch=B, device=local_rank)
+    calls = [(s, min(B, nframes - s)) for s in range(0, nframes, B)]   # encode calls per step
 
-    def step():
-        enc.encode_tensor(d_frames)
+    def step(keep=None):
+        for s0, cnt in calls:
+            enc.encode_tensor(d_frames[s0:s0 + cnt])
+            if keep is not None:
+                keep.extend(enc.get_jpeg(i) for i in range(cnt))
 
     def barrier():
         if dist is not None:
@@ -151,16 +282,17 @@ def main():
         torch.cuda.synchronize()
         enc.sync()
 
-    for _ in range(args.warmup):
+    for _ in range(max(0, args.warmup - 1)):
         step()
+    jpegs = []
+    step(keep=jpegs)                       # the last warm-up step also fetches every file for the check below
     barrier()
-    # bit-exactness spot check of frame 0 against the CPU oracle (outside the timed region)
-    jpeg0 = enc.get_jpeg(0)
-    jpeg_bytes = sum(enc.jpeg_size(i) for i in range(B))
+    jpeg_bytes = sum(len(j) for j in jpegs)
+    # bit-exactness of EVERY frame against the real reference (outside the timed region)
     bitexact = None
     if rank == 0:
-        po = O.make_params(w, h, quality=QUALITY, baseline=True)
-        bitexact = O.encode(po, frames[0]) == jpeg0
+        lim = None if args.verify == "all" else int(args.verify)
+        bitexact = verify_frames(frames, jpegs, w, h, kw, lim)
 
     # Timed region: K steps back to back.  HIP events bracket only the dominant kernel here (profiling
     # level 2: two events per step on the encoder's stream, read once after the loop), so the event
@@ -173,8 +305,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    dom_times = dict(enc.kernel_times())          # average ms per step over the timed region
-    from mozjpeg_amd import shard
+    dom_times = dict(enc.kernel_times())          # average ms per encode call over the timed region
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
 
     # Untimed extra pass with every kernel bracketed (level 1) for the per-kernel breakdown
@@ -183,46 +314,64 @@ def main():
         step()
     ktimes = dict(enc.kernel_times())
     enc.set_profiling(0)
+    enc.close()
+    del d_frames
 
     if rank == 0:
-        total_px = float(w) * h * B * args.steps * world
+        frames_per_step_all = total if total else B * world
+        total_px = float(w) * h * frames_per_step_all * args.steps
         dom = max(dom_times, key=dom_times.get) if dom_times else max(ktimes, key=ktimes.get)
         dom_ms = dom_times.get(dom, ktimes.get(dom))
-        algo_bytes = float(w) * h * 3 * B + jpeg_bytes
+        per_call = float(calls[0][1])
+        algo_bytes = frames[0].nbytes * per_call + jpeg_bytes * per_call / nframes
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
         # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-        # separate runs, fetch corrected by the factor calibrated on k_color; tools/rocprof_summary.py) -- per launch
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_hbm_traffic_batch64.json")))
-            if (w, h) == (W, H) and dom.startswith("trellis_ac"):
-                per_frame = sum(v["hbm_bytes_per_frame"] for k, v in pmc["kernels"].items() if k.startswith("k_trellis_ac"))
-                traffic = int(per_frame * B)
-        except Exception:
-            traffic = None
+        # separate runs, fetch corrected by the factor calibrated on k_color; tools/pmc_traffic.py) -- per launch
+        traffic, traffic_src = None, None
+        if args.config == "metric" and dom.startswith("trellis_ac"):
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_batch64.json")), reverse=True):
+                try:
+                    pmc = json.load(open(path))
+                    per_frame = sum(v["hbm_bytes_per_frame"] for k, v in pmc["kernels"].items() if k.startswith("k_trellis_ac"))
+                    traffic = int(per_frame * per_call)
+                    traffic_src = os.path.relpath(path, ROOT) + " (bytes per launch, scaled to this batch)"
+                    break
+                except Exception:
+                    continue
         out = {
             "metric": baseline_metric(),
             "value": round(total_px / elapsed / 1e6, 2), "unit": "Mpixels/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int16 (+f32 trellis costs)",
+            "higher_is_better": True, "scaling": "strong" if total else "weak", "vs_baseline": None,
+            "dtype": "u16/int16" if twelve else "u8/int16 (+f32 trellis costs)",
             "data": "synthetic",
-            "config": {"workload": "%dx%d synthetic RGB, q%d 4:2:0 baseline, trellis+deringing+optimal Huffman "
-                                   "(cjpeg -quality %d -baseline)" % (w, h, QUALITY, QUALITY),
-                       "frames_per_step_per_gpu": B, "input": "resident in HBM", "output": "complete JPEG files in HBM",
+            "value_is": "device-resident rate: frames in HBM when the timed region starts, complete JPEG files left in HBM "
+                        "(the PCIe-inclusive wall is host_inclusive.value)",
+            "config": {"workload": cfg["name"], "config_key": args.config,
+                       "frames_per_step_per_gpu": nframes, "frames_per_encode_call": int(per_call),
+                       "input": "resident in HBM", "output": "complete JPEG files in HBM",
                        "parallelism": "images sharded, 1 process per GPU, no collective"},
-            "bit_exact_vs_oracle": bitexact,
-            "jpeg_bytes_per_frame": int(jpeg_bytes / B),
+            "bit_exact": bitexact,
+            "bit_exact_vs_reference": bool(bitexact and bitexact["ok"]),
+            "jpeg_bytes_per_frame": int(jpeg_bytes / nframes),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_source": "profiles/r01g_pmc_hbm_traffic_batch64.json (bytes per launch, scaled to this batch)" if traffic else None,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "kernel_ms": round(dom_ms, 4),
-                         "kernel_ms_source": "HIP events around the kernel in every step of the timed region",
-                         "kernel_ms_per_step(untimed pass, every kernel bracketed)":
+                         "kernel_ms_source": "HIP events around the kernel in every encode call of the timed region",
+                         "whole_step_GBps": round(algo_bytes * len(calls) / (elapsed / args.steps) / 1e9, 1),
+                         "kernel_ms_per_call(untimed pass, every kernel bracketed)":
                              {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])}},
         }
+        if not args.no_host_leg and world == 1:
+            try:
+                hb = min(args.host_batch, nframes)
+                out["host_inclusive"] = host_inclusive(M, params, frames, hb, local_rank, args.host_seconds, jpegs)
+            except Exception as exc:   # the leg is extra information: the contract line must still come out
+                out["host_inclusive"] = {"error": str(exc)}
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(frames[0])
+            out["cpu_baseline"] = cpu_baseline(frames[0], kw)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -125,8 +125,33 @@ void mjh_encoder_destroy(mjh_encoder *e);
  * mjh_encoder_sync() or any later synchronising call. */
 int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t row_pitch, size_t image_stride,
                       int n, void *stream);
-/* Same with host pixels: staged through pinned memory and a side stream (H2D), then encoded. */
+/* Same with host pixels -- the whole-image form of jpeg_write_scanlines (jcapistd.c:90) + jpeg_finish_compress
+ * (jcapimin.c:176) for a batch.  ASYNCHRONOUS and double-buffered: the call queues the host->device copy, the kernel
+ * schedule and the hand-over of the finished files to pinned host memory, and returns; the copy of batch k+1 overlaps
+ * the kernels of batch k and the hand-over of batch k-1.  Pixels in pinned memory (mjh_host_alloc,
+ * mjh_host_register, or the encoder's own buffer from mjh_host_staging) are read by the DMA engine where they lie and
+ * must stay untouched until mjh_wait_input or mjh_collect returns; pixels in ordinary (pageable) memory are first
+ * copied to a pinned staging buffer by a few worker threads (MJH_HOST_THREADS, default min(8, cores/2)) and may be
+ * reused as soon as the call returns.  Results: mjh_collect (zero-copy) or mjh_get_jpeg[_size]. */
 int mjh_encode_host(mjh_encoder *e, const void *pixels, size_t row_pitch, size_t image_stride, int n);
+/* One finished file of a batch inside the pinned result arena. */
+typedef struct { uint64_t offset, size; } mjh_result;
+/* Waits for a batch queued by mjh_encode_host -- age 0: the most recent call, age 1: the call before it (so that a
+ * loop can queue batch k+1 before it picks up batch k) -- and returns its files where the device put them: file i is
+ * results[i].size bytes at (const uint8_t *)base + results[i].offset, in pinned host memory owned by the encoder.
+ * The memory of a batch is reused by the SECOND mjh_encode_host call after the one that queued it. */
+int mjh_collect(mjh_encoder *e, int age, const void **base, const mjh_result **results, int *count);
+/* Blocks until the pixels handed to the most recent mjh_encode_host call have been read (pinned sources only matter). */
+int mjh_wait_input(mjh_encoder *e);
+/* The encoder's own pinned staging buffer for the NEXT mjh_encode_host call (max_batch images, tightly packed rows):
+ * a caller that produces pixels row by row (the libjpeg drop-in's jpeg_write_scanlines) writes them here and passes
+ * the pointer to mjh_encode_host, which then copies nothing on the host. */
+int mjh_host_staging(mjh_encoder *e, void **buffer, size_t *bytes);
+/* Pinned host memory for zero-copy hand-over (hipHostMalloc / hipHostRegister underneath; no HIP types in the ABI). */
+void *mjh_host_alloc(size_t bytes);
+void mjh_host_free(void *p);
+int mjh_host_register(void *p, size_t bytes);
+int mjh_host_unregister(void *p);
 /* Component planes instead of pixels: jpeg_write_raw_data (jcapistd.c:145) for whole images, the entry
  * tj3CompressFromYUVPlanes8 (turbojpeg.c:1222) uses.  Colour conversion and downsampling are skipped; the
  * encoder must have been created with the sampling factors the planes were made for (input_components and

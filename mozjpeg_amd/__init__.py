@@ -47,6 +47,11 @@ class Params(C.Structure):
                 ("trellis_num_loops", C.c_int), ("smoothing_factor", C.c_int)]
 
 
+class Result(C.Structure):
+    """mjh_result: one finished file inside the pinned result arena"""
+    _fields_ = [("offset", C.c_uint64), ("size", C.c_uint64)]
+
+
 _lib = None
 
 
@@ -73,6 +78,15 @@ def lib():
         L.mjh_encode_coefficients_device.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
         L.mjh_encode_coefficients_host.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int]
         L.mjh_encoder_sync.argtypes = [C.c_void_p]
+        L.mjh_collect.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(Result)), C.POINTER(C.c_int)]
+        L.mjh_wait_input.argtypes = [C.c_void_p]
+        L.mjh_host_staging.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.mjh_host_alloc.argtypes = [C.c_size_t]
+        L.mjh_host_alloc.restype = C.c_void_p
+        L.mjh_host_free.argtypes = [C.c_void_p]
+        L.mjh_host_free.restype = None
+        L.mjh_host_register.argtypes = [C.c_void_p, C.c_size_t]
+        L.mjh_host_unregister.argtypes = [C.c_void_p]
         L.mjh_get_jpeg_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
         L.mjh_get_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mjh_get_output_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
@@ -136,6 +150,20 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     return p
 
 
+def pinned_empty(shape, dtype=np.uint8):
+    """numpy array in pinned host memory (mjh_host_alloc): mjh_encode_host reads it by DMA, without a staging copy.
+    The memory is released when the array (and every view of it) is gone."""
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = lib().mjh_host_alloc(nbytes)
+    if not ptr:
+        raise MjhError(ENOMEM, lib().mjh_last_error().decode())
+    buf = (C.c_uint8 * nbytes).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+    import weakref
+    weakref.finalize(buf, lib().mjh_host_free, ptr)
+    return arr
+
+
 class Encoder:
     """One parameter set + one GPU + device buffers for up to max_batch images."""
 
@@ -165,6 +193,28 @@ class Encoder:
         n = a.shape[0]
         _chk(lib().mjh_encode_host(self._h, a.ctypes.data, a.strides[1], a.strides[0], n))
         return [self.get_jpeg(i) for i in range(n)]
+
+    def submit_host(self, images):
+        """Asynchronous mjh_encode_host: queues copy + kernels + hand-over and returns.  Pinned arrays (pinned_empty)
+        are read in place and must stay untouched until wait_input()/collect(); others are staged by the library."""
+        a = images if images.ndim == 4 else images[None]
+        assert a.flags.c_contiguous or (a.strides[3] == a.itemsize and a.strides[2] == a.shape[3] * a.itemsize)
+        _chk(lib().mjh_encode_host(self._h, a.ctypes.data, a.strides[1], a.strides[0], a.shape[0]))
+        return a.shape[0]
+
+    def wait_input(self):
+        _chk(lib().mjh_wait_input(self._h))
+
+    def collect(self, age=0, copy=True):
+        """Files of the most recent submit_host batch (age 0) or of the one before it (age 1).  copy=False: memoryviews
+        into the encoder's pinned result arena (reused by the second submit_host call after the batch's own)."""
+        base, res, cnt = C.c_void_p(), C.POINTER(Result)(), C.c_int()
+        _chk(lib().mjh_collect(self._h, age, C.byref(base), C.byref(res), C.byref(cnt)))
+        out = []
+        for i in range(cnt.value):
+            mv = (C.c_uint8 * res[i].size).from_address(base.value + res[i].offset)
+            out.append(bytes(mv) if copy else memoryview(mv))
+        return out
 
     def encode_device_ptr(self, ptr, row_pitch, image_stride, n, stream=None):
         _chk(lib().mjh_encode_device(self._h, ptr, row_pitch, image_stride, n, stream))

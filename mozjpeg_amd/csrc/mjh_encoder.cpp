@@ -11,7 +11,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mozjpeg_hip.h"
@@ -230,8 +235,19 @@ struct mjh_encoder {
   hipEvent_t copy_done = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_side0 = nullptr, ev_side1 = nullptr;
   bool side_timed = false;
   // device buffers
-  uint8_t *d_pix = nullptr;        // staging for mjh_encode_host
-  uint8_t *h_pix = nullptr;        // pinned host staging
+  // mjh_encode_host: everything double-buffered (index = host_calls & 1) so that the H2D copy of batch n+1, the
+  // kernels of batch n and the hand-over of the files of batch n-1 overlap
+  uint8_t *d_pixb[2] = { nullptr, nullptr };     // device-side input pixels
+  uint8_t *h_stage[2] = { nullptr, nullptr };    // pinned staging for callers whose pixels are in pageable memory
+  uint8_t *h_res[2] = { nullptr, nullptr };      // pinned, device-mapped result arenas: the files of a batch packed back to back
+  unsigned long long *h_tab[2] = { nullptr, nullptr };   // [0] bytes used, [1] error flags, then {offset, size} per image
+  size_t res_cap = 0;
+  hipEvent_t ev_h2d[2] = { nullptr, nullptr }, ev_pix_free[2] = { nullptr, nullptr }, ev_packed[2] = { nullptr, nullptr };
+  hipStream_t d2h_stream = nullptr;
+  unsigned host_calls = 0;
+  int res_buf = -1;                // arena that holds the results of the last batch (-1: encoded through a *_device entry)
+  int res_n[2] = { 0, 0 };         // images in each arena (0: nothing there)
+  bool res_waited[2] = { false, false };
   uint8_t *d_plin = nullptr, *h_plin = nullptr;   // the same for mjh_encode_planes_host
   uint8_t *d_cfin = nullptr, *h_cfin = nullptr;   // and for mjh_encode_coefficients_host
   unsigned *d_prog_mpos = nullptr;                // progressive + restart intervals: byte positions of the RSTn markers of every scan
@@ -563,11 +579,17 @@ static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *ptrs[] = { e->d_pix, e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.info, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.info, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
-  if (e->h_pix) (void)hipHostFree(e->h_pix);
+  for (int b = 0; b < 2; b++) {
+    if (e->h_stage[b]) (void)hipHostFree(e->h_stage[b]);
+    if (e->h_res[b]) (void)hipHostFree(e->h_res[b]);
+    if (e->h_tab[b]) (void)hipHostFree(e->h_tab[b]);
+    for (hipEvent_t ev : { e->ev_h2d[b], e->ev_pix_free[b], e->ev_packed[b] }) if (ev) (void)hipEventDestroy(ev);
+  }
+  if (e->d2h_stream) (void)hipStreamDestroy(e->d2h_stream);
   if (e->h_plin) (void)hipHostFree(e->h_plin);
   if (e->h_cfin) (void)hipHostFree(e->h_cfin);
   for (hipEvent_t ev : e->prof_events) (void)hipEventDestroy(ev);
@@ -868,14 +890,18 @@ struct Prof {
   }
 };
 
+// input_read (optional) is recorded once the kernels that read the caller's input have been queued; before_output
+// (optional) is waited for before the first kernel that overwrites the output files of the previous batch
 static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, size_t image_stride, int n, hipStream_t s,
-                        const MjhPlaneSrc *plane_src = nullptr, const MjhCoefSrc *coef_src = nullptr)
+                        const MjhPlaneSrc *plane_src = nullptr, const MjhCoefSrc *coef_src = nullptr,
+                        hipEvent_t input_read = nullptr, hipEvent_t before_output = nullptr)
 {
   const MjhConst &C = e->C;
   const mjh_params &p = e->p;
   const int spi = e->spi;
   e->sizes_valid = false;
   e->last_n = n;
+  e->res_buf = -1;
   Prof pr{ e, s };
   if (e->profiling && e->prof_calls < 256) {
     pr.enabled = true;
@@ -895,6 +921,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       pr.mark("color");
       mjh_launch_color(C, d_pixels, row_pitch, image_stride, e->d_planes, n, s);
     }
+    if (input_read) HIPCHK(hipEventRecord(input_read, s));
     pr.mark("dct_quant");
     mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, n, s);
   }
@@ -906,6 +933,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     fin_ac[i] = SLOT_FINAL + 2 * (i < C.ncomp ? p.ac_tbl_no[i] : 0) + 1;
   }
   if (e->progressive) {
+    if (before_output) { HIPCHK(hipStreamWaitEvent(s, before_output, 0)); before_output = nullptr; }   // the hand-over also reads the scan control block
     mjh_launch_prog_reset(e->d_prog_ctl, e->nscans, n, s);
     HIPCHK(hipMemsetAsync(e->d_pool, 0, (size_t)n * e->pool_words * 4, s));
   }
@@ -993,6 +1021,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
                              e->d_prog_mpos, e->mpos_per_image, n, s, e->side_stream, e->ev_fork, e->ev_join);
       if (p.optimize_scans) { pr.mark("prog_select"); mjh_launch_prog_select(e->d_prog_ctl, C.ncomp, ph, n, s); }
     }
+    if (before_output) HIPCHK(hipStreamWaitEvent(s, before_output, 0));
     pr.mark("prog_concat");
     mjh_launch_prog_concat(e->d_prog_ctl, e->d_prefix, e->file_hdr_len, e->d_outpool, e->outpool_bytes, e->d_out, e->out_stride, e->d_sizes, n, s);
     pr.mark(nullptr);
@@ -1010,6 +1039,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     mjh_launch_gen_tables(e->d_tabs, spi, e->dht_slots, e->ndht, n, s);
   }
   // pass 7: headers + entropy-coded data
+  if (before_output) HIPCHK(hipStreamWaitEvent(s, before_output, 0));
   pr.mark("header");
   mjh_launch_header(e->d_prefix, e->prefix_len, e->d_sos, e->sos_len, e->d_tabs, spi, e->dht_slots, e->dht_ids, e->ndht,
                     p.compress_profile != MJH_PROFILE_FASTEST, e->d_out, e->out_stride, e->d_meta, n, s);
@@ -1032,27 +1062,239 @@ extern "C" int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t ro
   return run_pipeline(e, d_pixels, row_pitch, image_stride, n, stream ? (hipStream_t)stream : e->stream);
 }
 
+// ---- host entry: pixels in host memory -> JPEG files in host memory ----------------------------------
+// Staging copies of callers whose pixels live in pageable memory are spread over a few worker threads (one core
+// moves ~5-10 GB/s, the host link wants ~50); callers that hand over pinned memory (mjh_host_alloc /
+// mjh_host_register) skip the staging copy altogether.
+namespace {
+class CopyPool {
+ public:
+  // never destroyed: the detached workers wait on its condition variable for the life of the process (a static
+  // object's destructor would block in pthread_cond_destroy at exit)
+  static CopyPool &get() { static CopyPool *p = new CopyPool; return *p; }
+  int threads() const { return nthreads_; }
+  // run fn(i) for i in [0, njobs) on the pool (the caller works too); returns when all are done
+  void run(int njobs, const std::function<void(int)> &fn)
+  {
+    if (njobs <= 0) return;
+    if (nthreads_ <= 1 || njobs == 1) { for (int i = 0; i < njobs; i++) fn(i); return; }
+    std::unique_lock<std::mutex> big(submit_);   // one batch of jobs at a time
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn; njobs_ = njobs; next_.store(0); done_ = 0; gen_++;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(m_);
+    cv_done_.wait(lk, [&] { return done_ == njobs_; });
+    fn_ = nullptr;
+  }
+ private:
+  CopyPool()
+  {
+    int n = 0;
+    if (const char *v = getenv("MJH_HOST_THREADS")) n = atoi(v);
+    if (n <= 0) { n = (int)std::thread::hardware_concurrency() / 2; if (n > 8) n = 8; }
+    if (n < 1) n = 1;
+    nthreads_ = n;
+    for (int i = 1; i < n; i++) std::thread([this] { loop(); }).detach();
+  }
+  void work()
+  {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= njobs_) break;
+      (*fn_)(i);
+      std::lock_guard<std::mutex> lk(m_);
+      if (++done_ == njobs_) cv_done_.notify_all();
+    }
+  }
+  void loop()
+  {
+    unsigned long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+      }
+      work();
+    }
+  }
+  std::mutex m_, submit_;
+  std::condition_variable cv_, cv_done_;
+  const std::function<void(int)> *fn_ = nullptr;
+  int njobs_ = 0, done_ = 0, nthreads_ = 1;
+  std::atomic<int> next_{ 0 };
+  unsigned long gen_ = 0;
+};
+}  // namespace
+
+extern "C" void *mjh_host_alloc(size_t bytes)
+{
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); fail(MJH_ENOMEM, "hipHostMalloc(%zu) failed", bytes); return nullptr; }
+  return p;
+}
+extern "C" void mjh_host_free(void *p) { if (p) (void)hipHostFree(p); }
+extern "C" int mjh_host_register(void *p, size_t bytes)
+{
+  if (!p || !bytes) return fail(MJH_EINVAL, "bad arguments");
+  HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+  return MJH_OK;
+}
+extern "C" int mjh_host_unregister(void *p)
+{
+  if (!p) return fail(MJH_EINVAL, "bad arguments");
+  HIPCHK(hipHostUnregister(p));
+  return MJH_OK;
+}
+
+static bool is_pinned(const void *p)
+{
+  hipPointerAttribute_t a;
+  memset(&a, 0, sizeof(a));
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+
+static int host_buffers(mjh_encoder *e)
+{
+  if (e->d_pixb[0]) return MJH_OK;
+  const size_t in_bytes = (size_t)e->max_batch * e->pix_image_bytes;
+  // results: a JPEG file is normally a small fraction of its input; files that do not fit the arena are fetched from
+  // the device buffer one by one (slow path, flagged in the table)
+  e->res_cap = (size_t)e->max_batch * (e->pix_image_bytes / 2 + 65536);
+  HIPCHK(hipStreamCreateWithFlags(&e->d2h_stream, hipStreamNonBlocking));
+  for (int b = 0; b < 2; b++) {
+    HIPCHK(hipMalloc((void **)&e->d_pixb[b], in_bytes));
+    HIPCHK(hipHostMalloc((void **)&e->h_res[b], e->res_cap, hipHostMallocMapped));
+    HIPCHK(hipHostMalloc((void **)&e->h_tab[b], (2 + 2 * (size_t)e->max_batch) * sizeof(unsigned long long), hipHostMallocMapped));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_h2d[b], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_pix_free[b], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_packed[b], hipEventDisableTiming));
+  }
+  return MJH_OK;
+}
+
+// after a batch has been queued on e->stream: pack its files into the pinned arena `b` on the D2H stream
+static int queue_pack(mjh_encoder *e, int b, int n)
+{
+  HIPCHK(hipEventRecord(e->ev_join, e->stream));
+  HIPCHK(hipStreamWaitEvent(e->d2h_stream, e->ev_join, 0));
+  void *d_res = nullptr, *d_tab = nullptr;
+  HIPCHK(hipHostGetDevicePointer(&d_res, e->h_res[b], 0));
+  HIPCHK(hipHostGetDevicePointer(&d_tab, e->h_tab[b], 0));
+  mjh_launch_pack_results(e->d_out, e->out_stride, e->d_sizes, e->progressive ? nullptr : e->d_meta, e->progressive ? e->d_prog_ctl : nullptr,
+                          n, d_res, e->res_cap, d_tab, e->d2h_stream);
+  HIPCHK(hipEventRecord(e->ev_packed[b], e->d2h_stream));
+  e->res_buf = b;
+  e->res_n[b] = n;
+  e->res_waited[b] = false;
+  return MJH_OK;
+}
+
 extern "C" int mjh_encode_host(mjh_encoder *e, const void *pixels, size_t row_pitch, size_t image_stride, int n)
 {
   if (!e || !pixels || n < 1 || n > e->max_batch) return fail(MJH_EINVAL, "bad arguments");
   HIPCHK(hipSetDevice(e->device));
   const size_t row_bytes = (size_t)e->C.W * e->C.px_size * (e->C.precision == 12 ? 2 : 1);
-  HIPCHK(hipStreamSynchronize(e->stream));   // the staging buffers may still feed the previous batch
-  if (!e->d_pix) {
-    HIPCHK(hipMalloc((void **)&e->d_pix, (size_t)e->max_batch * e->pix_image_bytes));
-    HIPCHK(hipHostMalloc((void **)&e->h_pix, (size_t)e->max_batch * e->pix_image_bytes, hipHostMallocDefault));
+  if (row_pitch < row_bytes) return fail(MJH_EINVAL, "row_pitch %zu is smaller than a row (%zu bytes)", row_pitch, row_bytes);
+  int rc = host_buffers(e);
+  if (rc) return rc;
+  const int b = (int)(e->host_calls++ & 1u);
+  const int H = e->C.H;
+  const bool own_staging = pixels == e->h_stage[0] || pixels == e->h_stage[1];
+  const bool direct = own_staging || is_pinned(pixels);
+  // d_pixb[b] was last read by the colour kernel of the call before the previous one
+  HIPCHK(hipStreamWaitEvent(e->copy_stream, e->ev_pix_free[b], 0));
+  if (direct) {
+    // pinned source: the DMA engine reads the caller's memory; it must stay untouched until mjh_wait_input / mjh_collect
+    for (int i = 0; i < n; i++) {
+      const uint8_t *src = (const uint8_t *)pixels + (size_t)i * image_stride;
+      uint8_t *dst = e->d_pixb[b] + (size_t)i * e->pix_image_bytes;
+      if (row_pitch == row_bytes) HIPCHK(hipMemcpyAsync(dst, src, e->pix_image_bytes, hipMemcpyHostToDevice, e->copy_stream));
+      else HIPCHK(hipMemcpy2DAsync(dst, row_bytes, src, row_pitch, row_bytes, (size_t)H, hipMemcpyHostToDevice, e->copy_stream));
+    }
+  } else {
+    if (!e->h_stage[b]) HIPCHK(hipHostMalloc((void **)&e->h_stage[b], (size_t)e->max_batch * e->pix_image_bytes, hipHostMallocDefault));
+    HIPCHK(hipEventSynchronize(e->ev_h2d[b]));   // the staging buffer's previous H2D copy (two calls ago)
+    CopyPool &pool = CopyPool::get();
+    const int parts = pool.threads() > 1 ? pool.threads() * 2 : 1;   // row bands per image
+    for (int i = 0; i < n; i++) {
+      const uint8_t *src = (const uint8_t *)pixels + (size_t)i * image_stride;
+      uint8_t *dst = e->h_stage[b] + (size_t)i * e->pix_image_bytes;
+      pool.run(parts, [&](int part) {
+        const int y0 = (int)((long long)H * part / parts), y1 = (int)((long long)H * (part + 1) / parts);
+        if (row_pitch == row_bytes) memcpy(dst + (size_t)y0 * row_bytes, src + (size_t)y0 * row_bytes, (size_t)(y1 - y0) * row_bytes);
+        else for (int y = y0; y < y1; y++) memcpy(dst + (size_t)y * row_bytes, src + (size_t)y * row_pitch, row_bytes);
+      });
+      // image i travels while image i+1 is being staged
+      HIPCHK(hipMemcpyAsync(e->d_pixb[b] + (size_t)i * e->pix_image_bytes, dst, e->pix_image_bytes, hipMemcpyHostToDevice, e->copy_stream));
+    }
   }
-  // host staging through pinned memory, H2D on the side stream
-  for (int i = 0; i < n; i++) {
-    const uint8_t *src = (const uint8_t *)pixels + (size_t)i * image_stride;
-    uint8_t *dst = e->h_pix + (size_t)i * e->pix_image_bytes;
-    if (row_pitch == row_bytes) memcpy(dst, src, e->pix_image_bytes);
-    else for (int y = 0; y < e->C.H; y++) memcpy(dst + (size_t)y * row_bytes, src + (size_t)y * row_pitch, row_bytes);
-    HIPCHK(hipMemcpyAsync(e->d_pix + (size_t)i * e->pix_image_bytes, dst, e->pix_image_bytes, hipMemcpyHostToDevice, e->copy_stream));
+  HIPCHK(hipEventRecord(e->ev_h2d[b], e->copy_stream));
+  HIPCHK(hipStreamWaitEvent(e->stream, e->ev_h2d[b], 0));
+  // the output buffers are single: the files of the previous batch must have left for the host before this batch's
+  // header / stuffing kernels overwrite them (they are the last kernels of the schedule)
+  rc = run_pipeline(e, e->d_pixb[b], row_bytes, e->pix_image_bytes, n, e->stream, nullptr, nullptr, e->ev_pix_free[b],
+                    e->host_calls > 1 ? e->ev_packed[b ^ 1] : nullptr);
+  if (rc) return rc;
+  return queue_pack(e, b, n);
+}
+
+extern "C" int mjh_host_staging(mjh_encoder *e, void **buffer, size_t *bytes)
+{
+  if (!e || !buffer) return fail(MJH_EINVAL, "bad arguments");
+  HIPCHK(hipSetDevice(e->device));
+  int rc = host_buffers(e);
+  if (rc) return rc;
+  const int b = (int)(e->host_calls & 1u);   // the buffer the NEXT mjh_encode_host call uses
+  if (!e->h_stage[b]) HIPCHK(hipHostMalloc((void **)&e->h_stage[b], (size_t)e->max_batch * e->pix_image_bytes, hipHostMallocDefault));
+  HIPCHK(hipEventSynchronize(e->ev_h2d[b]));
+  *buffer = e->h_stage[b];
+  if (bytes) *bytes = (size_t)e->max_batch * e->pix_image_bytes;
+  return MJH_OK;
+}
+
+extern "C" int mjh_wait_input(mjh_encoder *e)
+{
+  if (!e) return fail(MJH_EINVAL, "null encoder");
+  if (e->host_calls == 0) return MJH_OK;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipEventSynchronize(e->ev_h2d[(e->host_calls - 1) & 1u]));
+  return MJH_OK;
+}
+
+static int wait_results(mjh_encoder *e, int b)
+{
+  if (b < 0 || e->res_n[b] == 0) return fail(MJH_EINVAL, "no batch of this age was encoded through mjh_encode_host");
+  if (!e->res_waited[b]) {
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipEventSynchronize(e->ev_packed[b]));
+    e->res_waited[b] = true;
   }
-  HIPCHK(hipEventRecord(e->copy_done, e->copy_stream));
-  HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done, 0));
-  return run_pipeline(e, e->d_pix, row_bytes, e->pix_image_bytes, n, e->stream);
+  const unsigned long long err = e->h_tab[b][1];
+  if (err & 1) return fail(MJH_ETOOSMALL, "entropy-coded data of an image exceeds the 32-bit bit-offset range of one scan / the bit-stream pool");
+  if (err & 2) return fail(MJH_EHIP, "internal: scan size prediction mismatch");
+  return MJH_OK;
+}
+
+extern "C" int mjh_collect(mjh_encoder *e, int age, const void **base, const mjh_result **results, int *count)
+{
+  if (!e || age < 0 || age > 1) return fail(MJH_EINVAL, "bad arguments (age is 0 or 1)");
+  if (e->res_buf < 0 && age == 0) return fail(MJH_EINVAL, "the last batch was not encoded through mjh_encode_host");
+  const int b = age == 0 ? e->res_buf : (int)((e->host_calls - 2) & 1u);
+  if (age == 1 && e->host_calls < 2) return fail(MJH_EINVAL, "there is no batch before the last one");
+  int rc = wait_results(e, b);
+  if (rc) return rc;
+  const unsigned long long *t = e->h_tab[b];
+  for (int i = 0; i < e->res_n[b]; i++)
+    if (t[2 + 2 * i] == ~0ull) return fail(MJH_ETOOSMALL, "file %d does not fit the pinned result arena: fetch it with mjh_get_jpeg", i);
+  if (base) *base = e->h_res[b];
+  if (results) *results = reinterpret_cast<const mjh_result *>(t + 2);
+  if (count) *count = e->res_n[b];
+  return MJH_OK;
 }
 
 static int check_coef_args(mjh_encoder *e, const void *const coefs[], const size_t blocks_per_row[], int n)
@@ -1196,6 +1438,13 @@ extern "C" int mjh_encoder_sync(mjh_encoder *e)
 static int fetch_sizes(mjh_encoder *e)
 {
   if (e->sizes_valid) return MJH_OK;
+  if (e->res_buf >= 0) {   // encoded through mjh_encode_host: sizes and error flags came over with the files
+    int rc = wait_results(e, e->res_buf);
+    if (rc) return rc;
+    for (int i = 0; i < e->last_n; i++) e->h_sizes[i] = (unsigned)e->h_tab[e->res_buf][3 + 2 * i];
+    e->sizes_valid = true;
+    return MJH_OK;
+  }
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(e->h_sizes.data(), e->d_sizes, (size_t)e->last_n * sizeof(unsigned), hipMemcpyDeviceToHost));
@@ -1233,6 +1482,11 @@ extern "C" int mjh_get_jpeg(mjh_encoder *e, int i, void *dst, size_t cap, size_t
   const size_t n = e->h_sizes[i];
   if (size) *size = n;
   if (n > cap) return fail(MJH_ETOOSMALL, "output buffer too small: need %zu bytes", n);
+  if (e->res_buf >= 0 && e->h_tab[e->res_buf][2 + 2 * i] != ~0ull) {
+    memcpy(dst, e->h_res[e->res_buf] + e->h_tab[e->res_buf][2 + 2 * i], n);
+    return MJH_OK;
+  }
+  HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipMemcpy(dst, e->d_out + (size_t)i * e->out_stride, n, hipMemcpyDeviceToHost));
   return MJH_OK;
 }

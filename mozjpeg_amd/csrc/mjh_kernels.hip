@@ -977,6 +977,11 @@ __device__ __forceinline__ bool trellis_ac_block(const uint4 *si_rows, const flo
   return true;
 }
 
+__global__ void k_zero_counters(unsigned *__restrict__ a, unsigned *__restrict__ b)
+{
+  if (threadIdx.x < 4) { a[threadIdx.x] = 0; b[threadIdx.x] = 0; }
+}
+
 // fast path: NE live entries per lane in LDS; blocks that need more go to the work list
 template <int NE>
 __global__ void __launch_bounds__(64)
@@ -1618,12 +1623,57 @@ k_stuff_write(const unsigned *__restrict__ stream, size_t stream_words_per_image
   }
 }
 
+// ---- hand-over to the host (mjh_encode_host / mjh_collect): the files of a batch are packed back to back (16-byte
+// aligned starts) straight into a pinned, device-mapped arena -- the kernel's stores travel over the host link, so no
+// sizes have to reach the host before a copy can be queued.  table: [0] bytes used, [1] error flags (1: offset range /
+// pool overflow, 2: internal), then {offset, size} per image (offset ~0: the file did not fit the arena).
+__global__ void __launch_bounds__(256)
+k_pack_results(const uint8_t *__restrict__ out, size_t out_stride, const unsigned *__restrict__ sizes,
+               const MjhImageMeta *__restrict__ meta, const MjhProgCtl *__restrict__ ctl, int n,
+               uint8_t *__restrict__ dst, size_t cap, unsigned long long *__restrict__ table)
+{
+  const int img = blockIdx.y;
+  unsigned long long off = 0;
+  for (int j = 0; j < img; j++) {
+    const unsigned long long r = ((unsigned long long)sizes[j] + 15ull) & ~15ull;
+    if (off + r <= cap) off += r;   // a file that does not fit takes no room
+  }
+  const unsigned sz = sizes[img];
+  const unsigned long long r = ((unsigned long long)sz + 15ull) & ~15ull;
+  const bool fits = off + r <= cap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    table[2 + 2 * img] = fits ? off : ~0ull;
+    table[3 + 2 * img] = sz;
+    if (img == n - 1) table[0] = off + (fits ? r : 0ull);
+    if (img == 0) {
+      unsigned long long err = 0;
+      for (int j = 0; j < n; j++) {
+        if (meta && meta[j].total_bits == 0xFFFFFFFFu) err |= 1ull;
+        if (ctl && ctl[j].error) err |= ctl[j].error == 1 ? 1ull : 2ull;
+      }
+      table[1] = err;
+    }
+  }
+  if (!fits) return;
+  const uint4 *src = reinterpret_cast<const uint4 *>(out + (size_t)img * out_stride);
+  uint4 *d = reinterpret_cast<uint4 *>(dst + off);
+  const unsigned nvec = (sz + 15u) >> 4;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) d[i] = src[i];
+}
+
 // =============================================================================================
 // host-callable launch wrappers (C++ linkage, used by mjh_encoder.cpp)
 // =============================================================================================
 #include "mjh_launch.h"
 
 static inline dim3 g3(unsigned x, unsigned y, unsigned z) { return dim3(x, y, z); }
+
+void mjh_launch_pack_results(const void *out, size_t out_stride, const unsigned *sizes, const void *meta, const void *prog_ctl, int n,
+                             void *dst, size_t cap, void *table, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_pack_results, dim3(16, n), dim3(256), 0, s, (const uint8_t *)out, out_stride, sizes, (const MjhImageMeta *)meta,
+                     (const MjhProgCtl *)prog_ctl, n, (uint8_t *)dst, cap, (unsigned long long *)table);
+}
 
 void mjh_launch_import_coefs(const MjhConst &C, const MjhCoefSrc &S, void *coef_q, int n, hipStream_t s)
 {
@@ -1720,8 +1770,7 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
 {
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
   const int4 sl = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
-  (void)hipMemsetAsync(worklist, 0, 16, s);
-  (void)hipMemsetAsync(worklist2, 0, 16, s);
+  hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, worklist, worklist2);   // (a 16-byte hipMemsetAsync costs ~80 us of stream time)
 #define LT(NE) hipLaunchKernelGGL((k_trellis_ac<NE>), grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, worklist)
   switch (variant) {
     case 1: LT(12); break;

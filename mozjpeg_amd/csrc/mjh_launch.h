@@ -22,6 +22,8 @@ void mjh_launch_header(const void *prefix, int prefix_len, const void *sos, int 
                        const int dht_slots[4], const int dht_ids[4], int ndht, int multi_dht, void *out, size_t out_stride, void *meta, int n, hipStream_t s);
 void mjh_launch_stuff(const unsigned *stream, size_t stream_words_per_image, const unsigned *totals, unsigned *ffsums, int ff_chunks_per_image,
                       unsigned *ff_totals, void *out, size_t out_stride, void *meta, unsigned *sizes, const unsigned *mpos, int nseg, int n, hipStream_t s);
+void mjh_launch_pack_results(const void *out, size_t out_stride, const unsigned *sizes, const void *meta, const void *prog_ctl, int n,
+                             void *dst, size_t cap, void *table, hipStream_t s);
 void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots, int nslots, int n, hipStream_t s);
 // progressive mode (mjh_prog.hip)
 void mjh_launch_prog_reset(void *ctl, int nscans, int n, hipStream_t s);
