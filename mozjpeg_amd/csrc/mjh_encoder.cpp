@@ -262,7 +262,8 @@ struct mjh_encoder {
   unsigned *d_seg_x = nullptr, *d_seg_E = nullptr, *d_seg_sums = nullptr, *d_seg_totals = nullptr, *d_mpos = nullptr;
   int nseg = 1;
   int comp_restart[4] = { 0, 0, 0, 0 };
-  unsigned *d_worklist = nullptr, *d_worklist2 = nullptr;   // deferred trellis blocks: [0] = count, [4+2i], [5+2i] = (image, comp<<28|block)
+  int16_t *d_dense = nullptr; unsigned dense_cap = 0;       // raw coefficients of deferred blocks, 64 int16 per work-list slot
+  unsigned *d_worklist = nullptr, *d_worklist2 = nullptr;   // deferred trellis blocks: [0] = count, [4+3i..6+3i] = (image, comp<<28|block, dense slot)
   int trellis_variant = 0;
   int spi = SLOTS_BASE;             // table slots per image (16 + 2 per progressive scan)
   // progressive mode
@@ -579,7 +580,7 @@ static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.info, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.info, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -646,8 +647,12 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   HIPCHK_E(hipMalloc((void **)&e->d_tabs_init, B * e->spi * sizeof(MjhHuffTable)));
   HIPCHK_E(hipMalloc((void **)&e->d_lambda, B * C.total_real_blocks * sizeof(float)));
   HIPCHK_E(hipMalloc((void **)&e->d_back, B * (size_t)C.total_real_blocks * 16));
-  HIPCHK_E(hipMalloc((void **)&e->d_worklist, 16 + B * (size_t)C.total_real_blocks * 8));
-  HIPCHK_E(hipMalloc((void **)&e->d_worklist2, 16 + B * (size_t)C.total_real_blocks * 8));
+  HIPCHK_E(hipMalloc((void **)&e->d_worklist, 16 + B * (size_t)C.total_real_blocks * 12));
+  HIPCHK_E(hipMalloc((void **)&e->d_worklist2, 16 + B * (size_t)C.total_real_blocks * 12));
+  if (p->trellis_quant) {   // room for a quarter of all blocks (typically 1-2 % overflow); the rest would be read from the planes
+    e->dense_cap = (unsigned)(B * (size_t)C.total_real_blocks / 4 + 1024);
+    HIPCHK_E(hipMalloc((void **)&e->d_dense, (size_t)e->dense_cap * 128));
+  }
   if (const char *v = getenv("MJH_TRELLIS_VARIANT")) e->trellis_variant = atoi(v);
   HIPCHK_E(hipMalloc((void **)&e->d_len16, B * (size_t)C.total_mcu_blocks * 2));
   HIPCHK_E(hipMalloc((void **)&e->d_off32, B * (size_t)C.total_mcu_blocks * 4));
@@ -986,7 +991,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
     }
     pr.mark("trellis_ac");
-    mjh_launch_trellis_ac(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->trellis_variant, n, s);
+    mjh_launch_trellis_ac(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap, e->trellis_variant, n, s);
     if (p.trellis_quant_dc) {
       pr.mark("join(trellis_dc)");
       HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));

@@ -751,25 +751,25 @@ k_gen_tables_list(MjhHuffTable *__restrict__ tabs, int slots_per_image, const in
 // K5  AC trellis quantization (row a9): quantize_trellis jcdctmgr.c:1120-1222 (+ norm/lambda
 // :1011-1037).  One lane = one block.  The rate-distortion DP only ever looks back at
 // positions whose chosen coefficient is non-zero, so each lane keeps a compact list of "live"
-// predecessors {position, accumulated zero distortion, accumulated cost, back pointer, value}
-// in LDS columns ([64 entries][64 lanes], bank = lane => conflict-free).  The zig-zag loop
-// index is wave-uniform, so quantizer steps / lambda weights come from scalar loads.
+// predecessors {accumulated zero distortion, accumulated cost} + {back pointer, value} in LDS columns
+// ([entries][64 lanes], bank = lane => conflict-free) and a 64-bit mask of their positions (bit 0 = the virtual
+// start) in registers.
 // Float recipe T5 of SURVEY 9 is followed operation by operation; first-minimum ties resolve
 // in (predecessor, candidate) lexicographic order exactly as the reference's strict '<' scan.
 // T6: a position whose candidates all lack a Huffman code keeps a stale value in the
 // reference; such a position can never win (its cost is >= 1e38) and is zeroed by the
 // back-track, so it is simply not appended here.
+//  * predecessors are walked NEWEST FIRST, two per step.  The reference scans them oldest first and keeps the first
+//    minimum (strict '<'), i.e. on equal cost the OLDER predecessor (and for one predecessor the smaller candidate)
+//    wins -- reproduced by the explicit tie rule.  cost = (rate + dist) + rhs >= rhs >= gap in float arithmetic (adding
+//    a non-negative term never rounds below the other operand), so once the gap (azd difference) of the oldest entry
+//    looked at exceeds the best cost every older predecessor is out; evaluating a predecessor that could have been
+//    pruned changes nothing, which is why pairs can be evaluated without branches.
+//  * AC code lengths: one 16-symbol row (= one zero-run length) pre-converted to floats with the magnitude bits
+//    folded in (rate_rows in LDS); all sums stay exact small integers = the reference's (float)(size + nbits + zrl).
+//  * candidates 0..3 (|q| < 16) are unrolled, instantiated with 1 / 2 / 4 candidates by a wave-uniform test;
+//    larger magnitudes take a rare rolled loop.
 // =============================================================================================
-// The DP of one block.
-//  * live predecessors = positions whose chosen coefficient is non-zero: a 64-bit mask per lane
-//    (bit 0 = the virtual start), walked with ctz; entry e of the LDS columns belongs to the e-th
-//    set bit.  An entry is {azd, acc} (float2, one ds_read_b64) plus a 16-bit {back position,
-//    magnitude}; NE entries per lane.  Returns false, with nothing written, if the list would
-//    overflow -- the caller then defers the block to the full-capacity kernel.
-//  * AC code lengths are read one 16-symbol row (= one zero-run length) at a time as a uint4.
-//  * the 63 raw coefficients arrive in 8 chunks of 8 coalesced loads, chunk c+1 in flight while
-//    chunk c is processed, so the sequential DP never waits on HBM.
-//  * candidates 0..3 (|q| < 16) are unrolled; larger magnitudes take a rare dynamic loop.
 __device__ __forceinline__ int row_byte(const uint4 &r, int b)
 {
   const unsigned w = b < 4 ? r.x : (b < 8 ? r.y : (b < 12 ? r.z : r.w));
@@ -785,20 +785,109 @@ __device__ __forceinline__ float4 rate_row(const uint4 &r)
                      b4 ? (float)(b4 + 4) : 3e38f);
 }
 
-// The predecessor walk of one coefficient position (jcdctmgr.c:1143-1180), NC = number of unrolled
-// candidates (1 when the whole wave has |q| == 1, else 4; |q| >= 16 takes the rolled tail loop).
-// Walks the live predecessors NEWEST FIRST.  The reference scans them oldest first and keeps the first
-// minimum (strict '<'), i.e. on equal cost the OLDER predecessor (and for one predecessor the smaller
-// candidate) wins -- reproduced here by the explicit tie rule.  The reversed order lets old
-// predecessors be rejected with one compare: cost = (rate + dist) + rhs >= rhs in float arithmetic
-// (adding a positive term never rounds below the other operand), so rhs > best already proves
-// "not better, not a tie".
+// cost of ONE predecessor for every candidate of the current position: local minimum lb, its candidate index lk
 template <int NC, bool LDS_ROWS>
-__device__ __forceinline__ void trellis_walk(const uint4 *si_rows, const float4 *rate_rows, float2 (*e_aa)[64], int lane,
-                                             unsigned long long live, int nlive, float azd_prev, int i, int x, int dq,
-                                             int qval, int ncd, float lambda, float lti, int si_f0, float f0f,
-                                             float &best, int &bestp, int &bestk)
+__device__ __forceinline__ void pred_cost(const uint4 *si_rows, const float4 &rr, int zero_run, float rhs, const float *dist,
+                                          int ncd, int x, int dq, int qval, float lambda, float lti, int si_f0, float f0f,
+                                          float &lb, int &lk)
 {
+  const int hi = zero_run >> 4;
+  const float rb = (float)hi * f0f;
+  lk = 0;
+  if (NC == 1) {
+    lb = (rr.x + rb) + dist[0];
+    lb = lb + rhs;
+  } else if (NC == 2) {
+    float c0 = (rr.x + rb) + dist[0];
+    float c1 = (rr.y + rb) + dist[NC > 1 ? 1 : 0];
+    c0 = c0 + rhs; c1 = c1 + rhs;
+    lb = c0;
+    if (c1 < lb) { lb = c1; lk = 1; }
+  } else {
+    float c0 = (rr.x + rb) + dist[0];
+    float c1 = (rr.y + rb) + dist[NC > 1 ? 1 : 0];
+    float c2 = (rr.z + rb) + dist[NC > 2 ? 2 : 0];
+    float c3 = (rr.w + rb) + dist[NC > 3 ? 3 : 0];
+    c0 = c0 + rhs; c1 = c1 + rhs; c2 = c2 + rhs; c3 = c3 + rhs;
+    lb = c0;
+    if (c1 < lb) { lb = c1; lk = 1; }
+    if (c2 < lb) { lb = c2; lk = 2; }
+    if (c3 < lb) { lb = c3; lk = 3; }
+    if (ncd > 4 && !(hi && si_f0 == 0)) {        // |q| >= 16: rare
+      const uint4 row = si_rows[zero_run & 15];
+      const int rbase = hi * si_f0;
+#pragma nounroll
+      for (int k = 4; k < ncd; k++) {
+        const int cb = row_byte(row, k + 1);
+        if (cb != 0) {
+          const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
+          const int delta = cand * dq - x;
+          float d = (float)(delta * delta) * lambda;
+          d = d * lti;
+          float cost = (float)(cb + (k + 1) + rbase) + d;
+          cost = cost + rhs;
+          if (cost < lb) { lb = cost; lk = k; }
+        }
+      }
+    }
+  }
+}
+
+template <int NC, bool LDS_ROWS>
+__device__ __forceinline__ float4 load_rate(const uint4 *si_rows, const float4 *rate_rows, int zero_run)
+{
+  if (LDS_ROWS) {
+    if (NC == 1) return make_float4(rate_rows[zero_run & 15].x, 0.f, 0.f, 0.f);
+    if (NC == 2) { const float2 t = *reinterpret_cast<const float2 *>(&rate_rows[zero_run & 15]); return make_float4(t.x, t.y, 0.f, 0.f); }
+    return rate_rows[zero_run & 15];
+  }
+  return rate_row(si_rows[zero_run & 15]);
+}
+
+// =============================================================================================
+// LANE-AUTONOMOUS walk.  A wave that moves over the 63 positions in lockstep (round 1's kernel) visits a position if
+// ANY of its 64 blocks quantizes it to non-zero and walks predecessors as long as ANY lane still has one to look at:
+// measured, 17 of 64 lanes were active per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU) with the VALU
+// pipe ~75 % busy.  Here the work is split in two:
+//   phase 1 (uniform, no divergence, all 63 plane loads in flight at once): the accumulated zero distortion of
+//     every position in float, in position order, and one queue record {position, sign, quantized value, |x|,
+//     azd before the position} per position with a non-zero quantized value, pushed to the lane's own LDS column;
+//   phase 2: every lane pops ITS OWN records and walks ITS OWN live predecessors, two per step (the two newest come
+//     from registers); a wave iterates until its busiest lane is done, i.e. max over lanes of the lane's own work
+//     instead of the sum over positions of the busiest lane per position.
+// Live entry e (created while record r >= e-1 is being consumed) overwrites queue slot e-1, so queue and live list
+// share one LDS column of QN 8-byte slots; entry 0 (the virtual start, {0, 0}) is not stored.  Blocks with more
+// than QN non-zero positions go to the work list (their raw coefficients are still in registers for the dense copy).
+// =============================================================================================
+template <int QN>
+__device__ __forceinline__ float2 q_entry(const uint2 (*col)[64], int lane, int e)
+{   // {azd, acc} of live entry e; entry 0 is the virtual start
+  const uint2 v = col[e > 0 ? e - 1 : 0][lane];
+  return e > 0 ? make_float2(__uint_as_float(v.x), __uint_as_float(v.y)) : make_float2(0.0f, 0.0f);
+}
+
+template <int NC, bool LDS_ROWS>
+__device__ __forceinline__ void q_pair_step(const uint4 *si_rows, const float4 *rate_rows, const uint2 (*col)[64], int lane,
+                                            unsigned long long &m, int &e, bool &first, float2 n0, float2 n1, float azd_prev, int i,
+                                            int x, int dq, int qval, int ncd, float lambda, float lti, int si_f0, float f0f,
+                                            float &best, int &bestp, int &bestk, bool &fin)
+{
+  const int p0 = 63 - __builtin_clzll(m);
+  m &= ~(1ull << p0);
+  const bool has1 = m != 0ull;
+  const int p1 = has1 ? 63 - __builtin_clzll(m) : p0;
+  if (has1) m &= ~(1ull << p1);
+  const int zr0 = i - 1 - p0, zr1 = i - 1 - p1;
+  // every load of the step is issued before the first use
+  const float4 r0 = load_rate<NC, LDS_ROWS>(si_rows, rate_rows, zr0);
+  const float4 r1 = load_rate<NC, LDS_ROWS>(si_rows, rate_rows, zr1);
+  float2 a0 = n0, a1 = n1;
+  if (!first) {
+    a0 = q_entry<0>(col, lane, e - 1);
+    a1 = q_entry<0>(col, lane, has1 ? e - 2 : e - 1);
+  }
+  first = false;
+  e -= 2;
   float dist[NC];
 #pragma unroll
   for (int k = 0; k < NC; k++) {
@@ -807,172 +896,191 @@ __device__ __forceinline__ void trellis_walk(const uint4 *si_rows, const float4 
     float d = (float)(delta * delta) * lambda;
     dist[k] = k < ncd ? d * lti : 3e38f;
   }
-  unsigned long long m = live;
-  int e = nlive;
-  while (m) {
-    const int p = 63 - __builtin_clzll(m);
-    m &= ~(1ull << p);
-    e--;
-    const float2 aa = e_aa[e][lane];
-    float rhs = azd_prev - aa.x;
-    // accumulated zero distortion only grows with distance and acc >= 0, so once the gap alone
-    // exceeds the best cost every OLDER predecessor is out as well: leave the loop
-    if (rhs > best) break;
-    rhs = rhs + aa.y;
-    if (rhs > best) continue;
-    const int zero_run = i - 1 - p;
-    const int hi = zero_run >> 4;
-    // rate = size + magnitude bits (+ ZRLs): all small integers, so the float sums below are
-    // exact and equal (float)(size + k + 1 + hi * size_f0) of the reference
-    const float rb = (float)hi * f0f;
-    float lb;
-    int lk = 0;
-    if (NC == 1) {
-      const float r0 = LDS_ROWS ? rate_rows[zero_run & 15].x : rate_row(si_rows[zero_run & 15]).x;
-      lb = (r0 + rb) + dist[0];
-      lb = lb + rhs;
-    } else if (NC == 2) {
-      const float2 rr = LDS_ROWS ? *reinterpret_cast<const float2 *>(&rate_rows[zero_run & 15])
-                                 : make_float2(rate_row(si_rows[zero_run & 15]).x, rate_row(si_rows[zero_run & 15]).y);
-      float c0 = (rr.x + rb) + dist[0];
-      float c1 = (rr.y + rb) + dist[NC > 1 ? 1 : 0];
-      c0 = c0 + rhs; c1 = c1 + rhs;
-      lb = c0;
-      if (c1 < lb) { lb = c1; lk = 1; }
+  const float gap0 = azd_prev - a0.x, gap1 = azd_prev - a1.x;
+  const float rhs0 = gap0 + a0.y, rhs1 = gap1 + a1.y;
+  float lb0, lb1;
+  int lk0, lk1;
+  pred_cost<NC, LDS_ROWS>(si_rows, r0, zr0, rhs0, dist, ncd, x, dq, qval, lambda, lti, si_f0, f0f, lb0, lk0);
+  pred_cost<NC, LDS_ROWS>(si_rows, r1, zr1, rhs1, dist, ncd, x, dq, qval, lambda, lti, si_f0, f0f, lb1, lk1);
+  if (lb0 < best || (lb0 == best && bestp >= 0)) { best = lb0; bestp = p0; bestk = lk0; }
+  if (has1 && (lb1 < best || (lb1 == best && bestp >= 0))) { best = lb1; bestp = p1; bestk = lk1; }
+  fin = m == 0ull || gap1 > best;
+}
+
+// The DP of one block per lane, lane-autonomous.  xs[1..63] = the lane's raw coefficients (zig-zag order), dq8/rcp/lt =
+// the component's quantizer constants in GLOBAL memory (wave-uniform: scalar loads) when UNIFORM_Q, else per lane;
+// dqT/ltT = the same constants in LDS for the per-lane lookups of phase 2 (row qrow).  Returns false, with nothing
+// written, when the block has more than QN non-zero positions; `active` false = the lane has no block (it still has to
+// take part in the wave-level loop).
+template <int QN, bool LDS_ROWS>
+__device__ __forceinline__ bool trellis_q_lane(const uint4 *si_rows, const float4 *rate_rows, const int (*dqT)[64], const float (*ltT)[64],
+                                               int qrow, const short (&xs)[64], const int *__restrict__ dq8, const float *__restrict__ rcp,
+                                               const float *__restrict__ lt, float lambda, bool active, int16_t *__restrict__ qo,
+                                               int kstride, uint2 (*col)[64], unsigned short (*e_pk)[64], int lane)
+{
+  const int si_f0 = (int)(si_rows[15].x & 0xFFu), si_eob = (int)(si_rows[0].x & 0xFFu);
+  const float f0f = si_f0 ? (float)si_f0 : 3e38f;
+  // ---- phase 1: zero-distortion prefix + queue of the positions with a non-zero quantized value ----
+  int nq = 0;
+  float azd63;
+  {
+    float azd = 0.0f;
+#pragma unroll
+    for (int k = 1; k < 64; k++) {
+      const int xsg = xs[k];
+      const int x = xsg < 0 ? -xsg : xsg;
+      const int dq = dq8[k];
+      float t = (float)(x * x) * lambda;
+      t = t * lt[k];
+      const float azd_cur = t + azd;
+      if (x + (dq >> 1) >= dq) {
+        int qval = udiv_exact(x + (dq >> 1), dq, rcp[k]);
+        if (qval >= 1024) qval = 1023;
+        if (nq < QN) col[nq][lane] = make_uint2((unsigned)k | (xsg < 0 ? 64u : 0u) | ((unsigned)qval << 7) | ((unsigned)x << 17), __float_as_uint(azd));
+        nq++;
+      }
+      azd = azd_cur;
+    }
+    azd63 = azd;
+  }
+  const bool over_q = active && nq > QN;
+  if (!active || over_q) nq = 0;     // nothing to walk (the lane stays for the wave-level loop)
+
+  // ---- phase 2: every lane consumes its own queue; the NEXT record is always one load ahead ----
+  unsigned long long live = 1ull, neg = 0ull;
+  int nlive = 1;
+  float2 n0 = make_float2(0.0f, 0.0f), n1 = n0;
+  int qi = 0;
+  bool need = true, done = nq == 0;
+  int i = 0, x = 0, dq = 1, qval = 0, ncd = 0, sgn = 0, e = 0, bestp = -1, bestk = 0;
+  float lti = 0.0f, azd_prev = 0.0f, azd_cur = 0.0f, best = 1e38f;
+  unsigned long long m = 0ull;
+  bool first = true;
+  uint2 rec_n = col[0][lane];
+  while (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
+    if (need && !done) {
+      const uint2 rec = rec_n;
+      qi++;
+      rec_n = col[qi < QN ? qi : QN - 1][lane];          // unconsumed slots are never overwritten (entry e lives in slot e-1 <= qi-1)
+      i = (int)(rec.x & 63u); sgn = (int)((rec.x >> 6) & 1u); qval = (int)((rec.x >> 7) & 1023u); x = (int)(rec.x >> 17);
+      azd_prev = __uint_as_float(rec.y);
+      dq = dqT[qrow][i]; lti = ltT[qrow][i];
+      float t = (float)(x * x) * lambda;
+      t = t * lti;
+      azd_cur = t + azd_prev;
+      ncd = bitlen((unsigned)qval);
+      best = 1e38f; bestp = -1; bestk = 0;
+      m = live; e = nlive; first = true; need = false;
+    }
+    if (!done) {
+      bool fin = false;
+      if (__builtin_amdgcn_ballot_w64(ncd > 1) == 0ull)
+        q_pair_step<1, LDS_ROWS>(si_rows, rate_rows, col, lane, m, e, first, n0, n1, azd_prev, i, x, dq, qval, ncd, lambda, lti, si_f0, f0f, best, bestp, bestk, fin);
+      else if (__builtin_amdgcn_ballot_w64(ncd > 2) == 0ull)
+        q_pair_step<2, LDS_ROWS>(si_rows, rate_rows, col, lane, m, e, first, n0, n1, azd_prev, i, x, dq, qval, ncd, lambda, lti, si_f0, f0f, best, bestp, bestk, fin);
+      else
+        q_pair_step<4, LDS_ROWS>(si_rows, rate_rows, col, lane, m, e, first, n0, n1, azd_prev, i, x, dq, qval, ncd, lambda, lti, si_f0, f0f, best, bestp, bestk, fin);
+      if (fin) {
+        if (bestp >= 0) {
+          const int mag = (bestk < ncd - 1) ? (2 << bestk) - 1 : qval;
+          n1 = n0;
+          n0 = make_float2(azd_cur, best);
+          col[nlive - 1][lane] = make_uint2(__float_as_uint(azd_cur), __float_as_uint(best));   // live entry nlive
+          e_pk[nlive][lane] = (unsigned short)(bestp | (mag << 6));
+          live |= 1ull << i;
+          if (sgn) neg |= 1ull << i;
+          nlive++;
+        }
+        need = true;
+        done = qi >= nq;
+      }
+    }
+  }
+  if (!active || over_q) return !over_q;
+
+  // ---- end-of-block choice (jcdctmgr.c:1187-1207): independent loads of every live entry, then the scan in position order
+  float best_cost = azd63 + (float)si_eob;
+  int last = 0;
+  {
+    unsigned long long mm = live & ~1ull;
+    if (QN <= 24) {
+      uint2 ent[QN];
+#pragma unroll
+      for (int s2 = 0; s2 < QN; s2++) ent[s2] = col[s2][lane];
+#pragma unroll
+      for (int s2 = 0; s2 < QN; s2++) {
+        if (s2 + 1 < nlive) {
+          const int p = __builtin_ctzll(mm);
+          mm &= mm - 1;
+          float cost = __uint_as_float(ent[s2].y) + azd63;
+          cost = cost - __uint_as_float(ent[s2].x);
+          if (p < 63) cost = cost + (float)si_eob;
+          if (cost < best_cost) { best_cost = cost; last = p; }
+        }
+      }
     } else {
-      const float4 rr = LDS_ROWS ? rate_rows[zero_run & 15] : rate_row(si_rows[zero_run & 15]);
-      float c0 = (rr.x + rb) + dist[0];
-      float c1 = (rr.y + rb) + dist[NC > 1 ? 1 : 0];
-      float c2 = (rr.z + rb) + dist[NC > 2 ? 2 : 0];
-      float c3 = (rr.w + rb) + dist[NC > 3 ? 3 : 0];
-      c0 = c0 + rhs; c1 = c1 + rhs; c2 = c2 + rhs; c3 = c3 + rhs;
-      // within one predecessor the smaller candidate index wins ties (strict '<')
-      lb = c0;
-      if (c1 < lb) { lb = c1; lk = 1; }
-      if (c2 < lb) { lb = c2; lk = 2; }
-      if (c3 < lb) { lb = c3; lk = 3; }
-      if (ncd > 4 && !(hi && si_f0 == 0)) {        // |q| >= 16: rare
-        const uint4 row = si_rows[zero_run & 15];
-        const int rbase = hi * si_f0;
-#pragma nounroll   // unrolled, the candidate distortions get hoisted and computed for EVERY coefficient
-        for (int k = 4; k < ncd; k++) {
-          const int cb = row_byte(row, k + 1);
-          if (cb != 0) {
-            const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
-            const int delta = cand * dq - x;
-            float d = (float)(delta * delta) * lambda;
-            d = d * lti;
-            float cost = (float)(cb + (k + 1) + rbase) + d;
-            cost = cost + rhs;
-            if (cost < lb) { lb = cost; lk = k; }
+      for (int s2 = 0; s2 + 1 < nlive; s2++) {
+        const uint2 en = col[s2][lane];
+        const int p = __builtin_ctzll(mm);
+        mm &= mm - 1;
+        float cost = __uint_as_float(en.y) + azd63;
+        cost = cost - __uint_as_float(en.x);
+        if (p < 63) cost = cost + (float)si_eob;
+        if (cost < best_cost) { best_cost = cost; last = p; }
+      }
+    }
+  }
+  // ---- back-track (jcdctmgr.c:1211-1222): the path is followed newest entry first, the values travel through the
+  // lane's LDS column (64 int16 = 16 slots; the queue is dead by now) so that the 63 plane stores use static registers
+  {
+    typedef unsigned short __attribute__((may_alias)) us_alias;
+    typedef uint2 __attribute__((may_alias)) u2_alias;
+    u2_alias *colw = reinterpret_cast<u2_alias *>(&col[0][0]);
+    us_alias *colh = reinterpret_cast<us_alias *>(&col[0][0]);   // value of position k: row k>>2, half-word k&3
+    unsigned long long mm = live & ~1ull;
+    int p = last;
+    if (QN <= 24) {
+      unsigned pk[QN + 1];
+#pragma unroll
+      for (int e2 = 1; e2 <= QN; e2++) pk[e2] = e_pk[e2][lane];
+#pragma unroll
+      for (int r = 0; r < 16; r++) colw[r * 64 + lane] = make_uint2(0u, 0u);
+#pragma unroll
+      for (int e2 = QN; e2 >= 1; e2--) {
+        if (e2 < nlive) {
+          const int pos = 63 - __builtin_clzll(mm);
+          mm &= ~(1ull << pos);
+          if (pos == p) {
+            const int mag = (int)(pk[e2] >> 6);
+            const int v = ((neg >> pos) & 1ull) ? -mag : mag;
+            colh[((pos >> 2) * 64 + lane) * 4 + (pos & 3)] = (unsigned short)v;
+            p = (int)(pk[e2] & 63u);
           }
         }
       }
-    }
-    // across predecessors the OLDER one wins ties, and this walk goes newest -> oldest
-    if (lb < best || (lb == best && bestp >= 0)) { best = lb; bestp = p; bestk = lk; }
-  }
-}
-
-template <int NE, bool LDS_ROWS>
-__device__ __forceinline__ bool trellis_ac_block(const uint4 *si_rows, const float4 *rate_rows, const int16_t *__restrict__ uq,
-                                                 int16_t *__restrict__ qo, int kstride,
-                                                 const int *__restrict__ dq8, const float *__restrict__ rcp,
-                                                 const float *__restrict__ lt, float lambda,
-                                                 float2 (*e_aa)[64], unsigned short (*e_pk)[64], int lane)
-{
-  const int si_f0 = (int)(si_rows[15].x & 0xFFu), si_eob = (int)(si_rows[0].x & 0xFFu);
-  const float f0f = si_f0 ? (float)si_f0 : 3e38f;   // cost of one ZRL; no code => unreachable
-  unsigned long long live = 1ull, neg = 0ull;
-  int nlive = 1;
-  e_aa[0][lane] = make_float2(0.0f, 0.0f);
-  float azd_prev = 0.0f;
-  short xn[8];
+    } else {
 #pragma unroll
-  for (int j = 0; j < 8; j++) xn[j] = uq[(size_t)j * kstride];
-  for (int c = 0; c < 8; c++) {
-    short xc[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) xc[j] = xn[j];
-    if (c < 7) {
-#pragma unroll
-      for (int j = 0; j < 8; j++) xn[j] = uq[(size_t)(8 * (c + 1) + j) * kstride];
-    }
-    // the chunk's wave-uniform constants in three wide scalar loads instead of one load + wait per coefficient
-    int dqc[8];
-    float ltc[8], rcpc[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) { dqc[j] = dq8[8 * c + j]; ltc[j] = lt[8 * c + j]; rcpc[j] = rcp[8 * c + j]; }
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int i = 8 * c + j;
-      if (j == 0 && c == 0) continue;
-      const int xs = xc[j];
-      const int x = xs < 0 ? -xs : xs;
-      const int dq = dqc[j];
-      const float lti = ltc[j];
-      float t = (float)(x * x) * lambda;
-      t = t * lti;
-      const float azd_cur = t + azd_prev;
-      if (x + (dq >> 1) >= dq) {                      // qval != 0
-        int qval = udiv_exact(x + (dq >> 1), dq, rcpc[j]);
-        if (qval >= 1024) qval = 1023;
-        const int ncd = bitlen((unsigned)qval);
-        float best = 1e38f;
-        int bestp = -1, bestk = 0;
-        // wave-uniform specialisation: when every lane quantizes this coefficient to +-1 there is a single
-        // candidate (the common case at mid/high frequencies), which halves the work per predecessor
-        if (__builtin_amdgcn_ballot_w64(ncd > 1) == 0ull)
-          trellis_walk<1, LDS_ROWS>(si_rows, rate_rows, e_aa, lane, live, nlive, azd_prev, i, x, dq, qval, ncd, lambda, lti,
-                                    si_f0, f0f, best, bestp, bestk);
-        else if (__builtin_amdgcn_ballot_w64(ncd > 2) == 0ull)
-          trellis_walk<2, LDS_ROWS>(si_rows, rate_rows, e_aa, lane, live, nlive, azd_prev, i, x, dq, qval, ncd, lambda, lti,
-                                    si_f0, f0f, best, bestp, bestk);
-        else
-          trellis_walk<4, LDS_ROWS>(si_rows, rate_rows, e_aa, lane, live, nlive, azd_prev, i, x, dq, qval, ncd, lambda, lti,
-                                    si_f0, f0f, best, bestp, bestk);
-        if (bestp >= 0) {
-          if (nlive >= NE) return false;
-          const int mag = (bestk < ncd - 1) ? (2 << bestk) - 1 : qval;
-          e_aa[nlive][lane] = make_float2(azd_cur, best);
-          e_pk[nlive][lane] = (unsigned short)(bestp | (mag << 6));
-          live |= 1ull << i;
-          if (xs < 0) neg |= 1ull << i;
-          nlive++;
+      for (int r = 0; r < 16; r++) colw[r * 64 + lane] = make_uint2(0u, 0u);
+      for (int e2 = nlive - 1; e2 >= 1; e2--) {
+        const int pos = 63 - __builtin_clzll(mm);
+        mm &= ~(1ull << pos);
+        if (pos == p) {
+          const unsigned pkv = e_pk[e2][lane];
+          const int mag = (int)(pkv >> 6);
+          const int v = ((neg >> pos) & 1ull) ? -mag : mag;
+          colh[((pos >> 2) * 64 + lane) * 4 + (pos & 3)] = (unsigned short)v;
+          p = (int)(pkv & 63u);
         }
       }
-      azd_prev = azd_cur;
     }
-  }
-  // end-of-block choice (jcdctmgr.c:1187-1207); azd_prev == accumulated_zero_dist[63]
-  float best_cost = azd_prev + (float)si_eob;
-  int last = 0;
-  {
-    unsigned long long m = live & ~1ull;
-    int e = 1;
-    while (m) {
-      const int p = __builtin_ctzll(m);
-      m &= m - 1;
-      const float2 aa = e_aa[e][lane];
-      e++;
-      float cost = aa.y + azd_prev;
-      cost = cost - aa.x;
-      if (p < 63) cost = cost + (float)si_eob;
-      if (cost < best_cost) { best_cost = cost; last = p; }
+    uint2 vals[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) vals[r] = colw[r * 64 + lane];
+#pragma unroll
+    for (int k = 1; k < 64; k++) {
+      const unsigned w = (k & 2) ? vals[k >> 2].y : vals[k >> 2].x;
+      qo[(size_t)k * kstride] = (int16_t)((k & 1) ? (w >> 16) : (w & 0xFFFFu));
     }
-  }
-  // back-track (jcdctmgr.c:1211-1222) fused with the store of the 63 AC planes
-  int p = last;
-  for (int k = 63; k >= 1; k--) {
-    int v = 0;
-    if (k == p) {
-      const int e = __popcll(live & ((1ull << k) - 1ull));
-      const unsigned pk = e_pk[e][lane];
-      const int mag = (int)(pk >> 6);
-      v = ((neg >> k) & 1ull) ? -mag : mag;
-      p = (int)(pk & 63u);
-    }
-    qo[(size_t)k * kstride] = (int16_t)v;
   }
   return true;
 }
@@ -982,72 +1090,133 @@ __global__ void k_zero_counters(unsigned *__restrict__ a, unsigned *__restrict__
   if (threadIdx.x < 4) { a[threadIdx.x] = 0; b[threadIdx.x] = 0; }
 }
 
-// fast path: NE live entries per lane in LDS; blocks that need more go to the work list
-template <int NE>
-__global__ void __launch_bounds__(64)
-k_trellis_ac(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
-             int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
-             int4 ac_slot_of_comp, const float *__restrict__ lambda_in, unsigned *__restrict__ worklist)
+// work-list entries: 3 words per deferred block at [4 + 3i]: image, component << 28 | block, slot of its dense copy
+__device__ __forceinline__ void defer_blocks(bool mine, unsigned *__restrict__ list, unsigned img, unsigned compblk, unsigned dense_slot_in,
+                                             const short (&xs)[64], int16_t *__restrict__ dense, unsigned dense_cap, bool make_copy, int lane)
 {
-  __shared__ float2 e_aa[NE][64];
-  __shared__ unsigned short e_pk[NE][64];   // back position | magnitude << 6
+  const unsigned long long over = __ballot(mine);
+  if (over == 0ull) return;
+  unsigned base = 0;
+  if (lane == 0) base = atomicAdd(&list[0], (unsigned)__popcll(over));   // one atomic per wave, consecutive slots
+  base = __shfl(base, 0, 64);
+  if (!mine) return;
+  const unsigned idx = base + (unsigned)__popcll(over & ((1ull << lane) - 1ull));
+  list[4 + 3 * (size_t)idx] = img;
+  list[5 + 3 * (size_t)idx] = compblk;
+  list[6 + 3 * (size_t)idx] = make_copy ? idx : dense_slot_in;
+  if (make_copy && idx < dense_cap) {
+    // the raw coefficients are still in registers: one 128-byte line per block for the next kernel, instead of 63
+    // different DRAM sectors in the coefficient-major planes
+    uint4 *d = reinterpret_cast<uint4 *>(dense + (size_t)idx * 64);
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+      unsigned w[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int k = 8 * v + 2 * j;
+        w[j] = (k == 0 ? 0u : (unsigned)(unsigned short)xs[k]) | ((unsigned)(unsigned short)xs[k + 1] << 16);
+      }
+      d[v] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
+template <int QN>
+__global__ void __launch_bounds__(64)
+k_trellis_ac_q(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
+               int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
+               int4 ac_slot_of_comp, int4 wave0_of_comp, const float *__restrict__ lambda_in, unsigned *__restrict__ worklist,
+               int16_t *__restrict__ dense, unsigned dense_cap)
+{
+  static_assert(QN >= 16 && QN <= 63, "queue capacity");
+  __shared__ uint2 col[QN][64];                  // queue records, then live entries {azd, acc}, then the value column
+  __shared__ unsigned short e_pk[QN + 1][64];    // back position | magnitude << 6 of live entry e
   __shared__ uint4 si_rows[16];
   __shared__ float4 rate_rows[16];
-  const int comp = blockIdx.y, img = blockIdx.z;
+  __shared__ int dqT[1][64];
+  __shared__ float ltT[1][64];
+  // flattened grid: blockIdx.x counts the waves of all components of one image (wave0_of_comp = first wave of each)
+  const int img = blockIdx.y;
+  const int wv = blockIdx.x;
+  const int comp = wv >= wave0_of_comp.w ? 3 : wv >= wave0_of_comp.z ? 2 : wv >= wave0_of_comp.y ? 1 : 0;
+  const int w0 = comp == 0 ? 0 : comp == 1 ? wave0_of_comp.y : comp == 2 ? wave0_of_comp.z : wave0_of_comp.w;
   const MjhComp cc = C.c[comp];
   const int lane = threadIdx.x;
   const int slot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
   const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+  const int blk = (wv - w0) * 64 + lane;
+  const bool inside = blk < cc.nblk;
+  const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + (inside ? blk : cc.nblk - 1);
+  // all 63 raw coefficients at once (coalesced lines, one burst), then the small stuff
+  short xs[64];
+#pragma unroll
+  for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
+  const float lambda = lambda_in[(size_t)img * C.total_real_blocks + cc.blk_off + (inside ? blk : cc.nblk - 1)];
   if (lane < 16) {
     const uint4 r = reinterpret_cast<const uint4 *>(T->ehufsi)[lane];
     si_rows[lane] = r;
     rate_rows[lane] = rate_row(r);
   }
+  dqT[0][lane] = Q->dq8[cc.qtbl][lane];
+  ltT[0][lane] = Q->lambda_tbl[cc.qtbl][lane];
   __syncthreads();
-  const int blk = blockIdx.x * 64 + lane;
-  if (blk >= cc.nblk) return;
-  const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
   int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
-  const float lambda = lambda_in[(size_t)img * C.total_real_blocks + cc.blk_off + blk];
-  const bool ok = trellis_ac_block<NE, true>(si_rows, rate_rows, uq, qo, cc.kstride, Q->dq8[cc.qtbl], Q->rcp8q[cc.qtbl], Q->lambda_tbl[cc.qtbl],
-                                       lambda, e_aa, e_pk, lane);
-  if (!ok) {
-    const unsigned idx = atomicAdd(&worklist[0], 1u);
-    worklist[4 + 2 * (size_t)idx] = (unsigned)img;
-    worklist[5 + 2 * (size_t)idx] = ((unsigned)comp << 28) | (unsigned)blk;
-  }
+  const bool ok = trellis_q_lane<QN, true>(si_rows, rate_rows, dqT, ltT, 0, xs, Q->dq8[cc.qtbl], Q->rcp8q[cc.qtbl], Q->lambda_tbl[cc.qtbl],
+                                           lambda, inside, qo, cc.kstride, col, e_pk, lane);
+  defer_blocks(!ok, worklist, (unsigned)img, ((unsigned)comp << 28) | (unsigned)blk, 0u, xs, dense, dense_cap, true, lane);
 }
 
-// deferred blocks (any image / component per lane): capacity NE2; blocks that still overflow go to
-// the next work list (NE2 = 64 never overflows: at most 63 AC positions + the start entry)
-template <int NE2>
+// Deferred blocks (any image / component per lane), same walk with a longer queue: raw coefficients come from the dense
+// copies (one line per block), code lengths from the image's table in global memory (L2-resident), quantizer constants
+// of all four tables from LDS.  Blocks beyond QN2 non-zero positions go to the next list (QN2 = 63 takes everything).
+template <int QN2>
 __global__ void __launch_bounds__(64)
-k_trellis_ac_deferred(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
-                      int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
-                      int4 ac_slot_of_comp, const float *__restrict__ lambda_in, const unsigned *__restrict__ worklist,
-                      unsigned *__restrict__ worklist_next)
+k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
+                int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
+                int4 ac_slot_of_comp, const float *__restrict__ lambda_in, const unsigned *__restrict__ worklist,
+                unsigned *__restrict__ worklist_next, const int16_t *__restrict__ dense, unsigned dense_cap)
 {
-  __shared__ float2 e_aa[NE2][64];
-  __shared__ unsigned short e_pk[NE2][64];
+  __shared__ uint2 col[QN2][64];
+  __shared__ unsigned short e_pk[QN2 + 1][64];
+  __shared__ int dqT[4][64];
+  __shared__ float ltT[4][64];
   const int lane = threadIdx.x;
+#pragma unroll
+  for (int t = 0; t < 4; t++) { dqT[t][lane] = Q->dq8[t][lane]; ltT[t][lane] = Q->lambda_tbl[t][lane]; }
+  __syncthreads();
   const unsigned count = worklist[0];
-  for (unsigned it = blockIdx.x * 64 + lane; it < count; it += gridDim.x * 64) {
-    const int img = (int)worklist[4 + 2 * (size_t)it];
-    const unsigned w = worklist[5 + 2 * (size_t)it];
+  for (unsigned base = blockIdx.x * 64; base < count; base += gridDim.x * 64) {   // wave-uniform trip count
+    const unsigned it = base + lane;
+    const bool active = it < count;
+    const unsigned ii = active ? it : count - 1;
+    const int img = (int)worklist[4 + 3 * (size_t)ii];
+    const unsigned w = worklist[5 + 3 * (size_t)ii];
+    const unsigned ds = worklist[6 + 3 * (size_t)ii];
     const int comp = (int)(w >> 28), blk = (int)(w & 0x0FFFFFFFu);
     const MjhComp cc = C.c[comp];
     const int slot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
     const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
-    const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
-    int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
-    const float lambda = lambda_in[(size_t)img * C.total_real_blocks + cc.blk_off + blk];
-    const bool ok = trellis_ac_block<NE2, false>(reinterpret_cast<const uint4 *>(T->ehufsi), nullptr, uq, qo, cc.kstride, Q->dq8[cc.qtbl], Q->rcp8q[cc.qtbl],
-                                          Q->lambda_tbl[cc.qtbl], lambda, e_aa, e_pk, lane);
-    if (!ok && NE2 < 64) {
-      const unsigned idx = atomicAdd(&worklist_next[0], 1u);
-      worklist_next[4 + 2 * (size_t)idx] = (unsigned)img;
-      worklist_next[5 + 2 * (size_t)idx] = w;
+    short xs[64];
+    if (ds < dense_cap) {
+      const uint4 *d = reinterpret_cast<const uint4 *>(dense + (size_t)ds * 64);
+#pragma unroll
+      for (int v = 0; v < 8; v++) {
+        const uint4 q4 = d[v];
+        const unsigned ww[4] = { q4.x, q4.y, q4.z, q4.w };
+#pragma unroll
+        for (int j = 0; j < 4; j++) { xs[8 * v + 2 * j] = (short)(ww[j] & 0xFFFFu); xs[8 * v + 2 * j + 1] = (short)(ww[j] >> 16); }
+      }
+    } else {
+      const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+#pragma unroll
+      for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
     }
+    const float lambda = lambda_in[(size_t)img * C.total_real_blocks + cc.blk_off + blk];
+    int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+    const bool ok = trellis_q_lane<QN2, false>(reinterpret_cast<const uint4 *>(T->ehufsi), nullptr, dqT, ltT, cc.qtbl, xs, dqT[cc.qtbl], Q->rcp8q[cc.qtbl],
+                                               ltT[cc.qtbl], lambda, active, qo, cc.kstride, col, e_pk, lane);
+    if (QN2 < 63) defer_blocks(!ok, worklist_next, (unsigned)img, w, ds, xs, nullptr, 0u, false, lane);
+    __syncthreads();   // the LDS columns are reused by the next round
   }
 }
 
@@ -1766,24 +1935,26 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
   if (nslots > 0) hipLaunchKernelGGL(k_gen_tables_list, dim3(nslots, n), dim3(64), 0, s, tabs, spi, d_slots);
 }
 
-void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda, unsigned *worklist, unsigned *worklist2, int variant, int n, hipStream_t s)
+void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda, unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, int variant, int n, hipStream_t s)
 {
-  dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
   const int4 sl = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
   hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, worklist, worklist2);   // (a 16-byte hipMemsetAsync costs ~80 us of stream time)
-#define LT(NE) hipLaunchKernelGGL((k_trellis_ac<NE>), grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, worklist)
-  switch (variant) {
-    case 1: LT(12); break;
-    case 2: LT(20); break;
-    case 3: LT(24); break;
-    case 4: LT(32); break;
-    case 5: LT(4); break;
-    default: LT(16); break;
+  int w0[5] = { 0, 0, 0, 0, 0 };
+  for (int i = 0; i < 4; i++) w0[i + 1] = w0[i] + (i < C.ncomp ? (C.c[i].nblk + 63) / 64 : 0);
+  dim3 gridq(w0[C.ncomp], n);
+  for (int i = C.ncomp; i < 4; i++) w0[i] = 0x7FFFFFFF;   // components that do not exist never match
+  const int4 wv = make_int4(w0[0], w0[1], w0[2], w0[3]);
+#define LQ(QN) hipLaunchKernelGGL((k_trellis_ac_q<QN>), gridq, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, wv, lambda, worklist, (int16_t *)dense, dense_cap)
+  switch (variant) {   // MJH_TRELLIS_VARIANT: queue capacity of the first tier (all bit-identical; LDS per wave = 10 * QN * 64 bytes)
+    case 1: LQ(20); break;
+    case 2: LQ(24); break;
+    case 3: LQ(32); break;
+    default: LQ(16); break;
   }
-#undef LT
-  // second and third tier: 32 entries (20 KB LDS per wave), then the full 64
-  hipLaunchKernelGGL((k_trellis_ac_deferred<32>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, (const unsigned *)worklist, worklist2);
-  hipLaunchKernelGGL((k_trellis_ac_deferred<64>), dim3(512), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, (const unsigned *)worklist2, worklist2);
+#undef LQ
+  // second and third tier: blocks with more than QN (then 32) non-zero positions, from their dense copies
+  hipLaunchKernelGGL((k_trellis_ac_qd<32>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, (const unsigned *)worklist, worklist2, (const int16_t *)dense, dense_cap);
+  hipLaunchKernelGGL((k_trellis_ac_qd<63>), dim3(1024), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, (const unsigned *)worklist2, (unsigned *)nullptr, (const int16_t *)dense, dense_cap);
 }
 
 // exclusive prefix sum of 16-bit lengths, `npairs` independent arrays of n_per entries (the progressive path's

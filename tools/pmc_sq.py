@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Per-kernel averages of every counter found in rocprofv3 --pmc result databases (separate passes).
+usage: tools/pmc_sq.py pass1_results.db [pass2_results.db ...] [--kernels substr,substr] > json"""
+import json
+import sqlite3
+import sys
+
+
+def main():
+    dbs = [a for a in sys.argv[1:] if not a.startswith("--")]
+    filt = None
+    for a in sys.argv[1:]:
+        if a.startswith("--kernels="):
+            filt = a.split("=", 1)[1].split(",")
+    out = {}
+    for db in dbs:
+        cur = sqlite3.connect(db).cursor()
+        q = "select kernel_name, counter_name, avg(value), count(*) from counters_collection group by kernel_name, counter_name"
+        for name, cname, avg, n in cur.execute(q):
+            short = name.split("(")[0].replace("void ", "")
+            if filt and not any(f in short for f in filt):
+                continue
+            out.setdefault(short, {})[cname] = round(avg, 1)
+            out[short]["launches"] = n
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
