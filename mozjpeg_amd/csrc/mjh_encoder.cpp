@@ -265,6 +265,7 @@ struct mjh_encoder {
   int16_t *d_dense = nullptr; unsigned dense_cap = 0;       // raw coefficients of deferred blocks, 64 int16 per work-list slot
   unsigned *d_worklist = nullptr, *d_worklist2 = nullptr;   // deferred trellis blocks: [0] = count, [4+3i..6+3i] = (image, comp<<28|block, dense slot)
   int trellis_variant = 0;
+  int fuse_mask = 1;                // MJH_FUSE: 1 = pre-trellis AC statistics inside the FDCT kernel (+ unread planes not stored), 2 = final AC statistics inside the trellis
   int spi = SLOTS_BASE;             // table slots per image (16 + 2 per progressive scan)
   // progressive mode
   bool progressive = false;
@@ -654,6 +655,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     HIPCHK_E(hipMalloc((void **)&e->d_dense, (size_t)e->dense_cap * 128));
   }
   if (const char *v = getenv("MJH_TRELLIS_VARIANT")) e->trellis_variant = atoi(v);
+  if (const char *v = getenv("MJH_FUSE")) e->fuse_mask = atoi(v);
   HIPCHK_E(hipMalloc((void **)&e->d_len16, B * (size_t)C.total_mcu_blocks * 2));
   HIPCHK_E(hipMalloc((void **)&e->d_off32, B * (size_t)C.total_mcu_blocks * 4));
   e->chunks = (C.total_mcu_blocks + 2047) / 2048;
@@ -927,16 +929,28 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       mjh_launch_color(C, d_pixels, row_pitch, image_stride, e->d_planes, n, s);
     }
     if (input_read) HIPCHK(hipEventRecord(input_read, s));
-    pr.mark("dct_quant");
-    mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, n, s);
   }
-
   int tr_dc[4], tr_ac[4], fin_dc[4], fin_ac[4], zero4[4] = { 0, 0, 0, 0 };
   for (int i = 0; i < 4; i++) {
     tr_dc[i] = 2 * i; tr_ac[i] = 2 * i + 1;
     fin_dc[i] = SLOT_FINAL + 2 * (i < C.ncomp ? p.dc_tbl_no[i] : 0);
     fin_ac[i] = SLOT_FINAL + 2 * (i < C.ncomp ? p.ac_tbl_no[i] : 0) + 1;
   }
+  // Sequential mode with trellis quantization: the AC statistics of the conventionally quantized blocks are gathered by
+  // the FDCT kernel itself (no separate pass over the 63 planes), and the quantized AC planes it would write are never
+  // read (the trellis recomputes them), so they are not stored; optionally the statistics of the final coefficients
+  // are gathered by the trellis back-track.
+  const bool fuse_seq = !e->progressive && p.trellis_quant && !coef_src;
+  // (debug taps expose the pre-trellis quantized planes, so they keep the unfused schedule.)  Measured: the fused FDCT
+  // kernel costs what the separate statistics pass cost (7.19 vs 7.23 ms per 64 4K frames) but moves 3.2 GB less; the
+  // final statistics inside the trellis cost MORE than their own pass (3.83 vs 3.36 + 0.38 ms: the low-occupancy kernel
+  // pays for every extra instruction), so that fusion exists (MJH_FUSE=3) but is off by default.
+  const bool fuse_pre = fuse_seq && (e->fuse_mask & 1) && !e->debug_taps, fuse_fin = fuse_seq && (e->fuse_mask & 2);
+  if (!coef_src) {
+    pr.mark("dct_quant");
+    mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, n, s);
+  }
+
   if (e->progressive) {
     if (before_output) { HIPCHK(hipStreamWaitEvent(s, before_output, 0)); before_output = nullptr; }   // the hand-over also reads the scan control block
     mjh_launch_prog_reset(e->d_prog_ctl, e->nscans, n, s);
@@ -950,9 +964,12 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     if (loop > 0)   // fresh (zero) statistics for this round
       HIPCHK(hipMemcpyAsync(e->d_tabs, e->d_tabs_init, (size_t)n * spi * sizeof(MjhHuffTable), hipMemcpyDeviceToDevice, s));
     if (!e->progressive) {
-      // passes 0,2,4 of SURVEY 3.3 (statistics of the conventionally quantized component) ...
-      pr.mark("stats_ac(pre-trellis)");
-      mjh_launch_stats_ac(C, e->d_q, e->d_tabs, spi, tr_ac, 0, n, s);
+      // passes 0,2,4 of SURVEY 3.3 (statistics of the conventionally quantized component): AC part fused into the FDCT
+      // kernel in the first round, a pass over the previous round's result afterwards ...
+      if (loop > 0 || !fuse_pre) {
+        pr.mark("stats_ac(pre-trellis)");
+        mjh_launch_stats_ac(C, e->d_q, e->d_tabs, spi, tr_ac, 0, n, s);
+      }
       pr.mark("stats_dc(pre-trellis)");
       mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, tr_dc, 0, e->comp_restart, n, s);
       int slots[8], ns = 0;
@@ -991,7 +1008,8 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
     }
     pr.mark("trellis_ac");
-    mjh_launch_trellis_ac(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap, e->trellis_variant, n, s);
+    mjh_launch_trellis_ac(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap,
+                          fuse_fin && p.optimize_coding && loop == nloops - 1 ? fin_ac : nullptr, e->trellis_variant, n, s);
     if (p.trellis_quant_dc) {
       pr.mark("join(trellis_dc)");
       HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
@@ -1036,8 +1054,10 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   }
   if (p.optimize_coding) {
     // pass 6: statistics of the interleaved scan (dummy blocks included) -> final tables
-    pr.mark("stats_ac(final)");
-    mjh_launch_stats_ac(C, e->d_q, e->d_tabs, spi, fin_ac, 1, n, s);
+    if (!fuse_fin) {   // (else the last trellis round has counted the AC symbols already)
+      pr.mark("stats_ac(final)");
+      mjh_launch_stats_ac(C, e->d_q, e->d_tabs, spi, fin_ac, 1, n, s);
+    }
     pr.mark("stats_dc(final)");
     mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, fin_dc, 1, zero4, n, s);
     pr.mark("gen_tables(final)");

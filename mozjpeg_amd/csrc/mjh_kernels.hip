@@ -341,18 +341,27 @@ __device__ __forceinline__ float catmull_rom(int v1, int v2, int v3, int v4, flo
   return r;
 }
 
-template <class T>   // uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
+// Fused extras (sequential mode with trellis quantization, the metric's configuration):
+//  * STATS: the AC symbol statistics of the conventionally quantized block (passes 0,2,4 of SURVEY 3.3,
+//    htest_one_block jchuff.c:812-915) are gathered here, while the values are in registers in zig-zag order, instead
+//    of by a k_stats_ac pass that re-reads all 63 planes;
+//    and, because the AC trellis recomputes every AC coefficient from coef_uq, the 63 quantized AC planes this kernel
+//    would write are then never read: only plane 0 (DC statistics / DC trellis) is stored.
+template <class T, bool STATS>   // uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
 __global__ void __launch_bounds__(64)
 k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ planes,
-            int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out)
+            int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
+            MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp)
 {
   constexpr bool W12 = sizeof(T) == 2;
   __shared__ int lds[64][64];
   const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
   const int lane = threadIdx.x;
-  const int blk = blockIdx.x * 64 + lane;
-  if (blk >= cc.nblk) return;
+  const int blk_raw = blockIdx.x * 64 + lane;
+  if (blockIdx.x * 64 >= cc.nblk) return;              // whole wave outside (grid is sized for the largest component)
+  const bool valid = blk_raw < cc.nblk;                  // tail lanes redo the last block (identical stores), they only stay out of the statistics
+  const int blk = valid ? blk_raw : cc.nblk - 1;
   const int br = blk / cc.wib, bc = blk - br * cc.wib;
   const T *src = planes + (size_t)img * C.planes_per_image + cc.plane_off + (size_t)(br * 8) * cc.pw + bc * 8;
   int d[64];
@@ -439,6 +448,15 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
   int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
   int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
   const bool clampq = C.deringing != 0;
+  constexpr bool stats = STATS;
+  unsigned *hist = reinterpret_cast<unsigned *>(&lds[0][0]);   // 16 interleaved copies of 256 bins (the deringing columns are dead)
+  if (stats) {
+#pragma unroll
+    for (int j = 0; j < 64; j++) hist[j * 64 + lane] = 0u;
+    __syncthreads();
+  }
+  unsigned *hh = hist + (lane & 15) * 256;
+  int run = 0;
 #pragma unroll
   for (int k = 0; k < 64; k++) {
     const int x = d[kZZ.v[k]];
@@ -448,7 +466,30 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
     if (x < 0) v = -v;
     if (clampq) v = W12 ? max(-16383, min(16383, v)) : max(-1023, min(1023, v));
     if (!W12) uq[(size_t)k * cc.kstride] = (int16_t)x;   // raw x8 coefficients only feed the (8-bit only) trellis
-    qo[(size_t)k * cc.kstride] = (int16_t)v;
+    if (k == 0 || !STATS) qo[(size_t)k * cc.kstride] = (int16_t)v;   // STATS: the AC planes would never be read
+    if (stats && k > 0 && valid) {
+      if (v == 0) run++;
+      else {
+        if (run > 15) { atomicAdd(&hh[0xF0], (unsigned)(run >> 4)); run &= 15; }
+        const int nb = bitlen((unsigned)(v < 0 ? -v : v));
+        atomicAdd(&hh[(run << 4) + nb], 1u);
+        run = 0;
+      }
+    }
+  }
+  if (stats) {
+    if (valid && run > 0) atomicAdd(&hh[0], 1u);
+    __syncthreads();
+    const int slot = comp == 0 ? stat_slot_of_comp.x : comp == 1 ? stat_slot_of_comp.y : comp == 2 ? stat_slot_of_comp.z : stat_slot_of_comp.w;
+    MjhHuffTable *T2 = stat_tabs + (size_t)img * slots_per_image + slot;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int bin = lane + 64 * j;
+      unsigned sum = 0;
+#pragma unroll
+      for (int c2 = 0; c2 < 16; c2++) sum += hist[c2 * 256 + bin];
+      if (sum) atomicAdd(&T2->counts[bin], sum);
+    }
   }
 }
 
@@ -912,17 +953,13 @@ __device__ __forceinline__ void q_pair_step(const uint4 *si_rows, const float4 *
 // dqT/ltT = the same constants in LDS for the per-lane lookups of phase 2 (row qrow).  Returns false, with nothing
 // written, when the block has more than QN non-zero positions; `active` false = the lane has no block (it still has to
 // take part in the wave-level loop).
-template <int QN, bool LDS_ROWS>
-__device__ __forceinline__ bool trellis_q_lane(const uint4 *si_rows, const float4 *rate_rows, const int (*dqT)[64], const float (*ltT)[64],
-                                               int qrow, const short (&xs)[64], const int *__restrict__ dq8, const float *__restrict__ rcp,
-                                               const float *__restrict__ lt, float lambda, bool active, int16_t *__restrict__ qo,
-                                               int kstride, uint2 (*col)[64], unsigned short (*e_pk)[64], int lane)
+// phase 1 of the lane-autonomous DP: zero-distortion prefix + queue of the positions with a non-zero quantized value.
+// Returns the number of such positions (> QN: the block has to be deferred; the queue then holds the first QN).
+template <int QN>
+__device__ __forceinline__ int trellis_q_phase1(const short (&xs)[64], const int *__restrict__ dq8, const float *__restrict__ rcp,
+                                                const float *__restrict__ lt, float lambda, uint2 (*col)[64], int lane, float &azd63)
 {
-  const int si_f0 = (int)(si_rows[15].x & 0xFFu), si_eob = (int)(si_rows[0].x & 0xFFu);
-  const float f0f = si_f0 ? (float)si_f0 : 3e38f;
-  // ---- phase 1: zero-distortion prefix + queue of the positions with a non-zero quantized value ----
   int nq = 0;
-  float azd63;
   {
     float azd = 0.0f;
 #pragma unroll
@@ -943,8 +980,25 @@ __device__ __forceinline__ bool trellis_q_lane(const uint4 *si_rows, const float
     }
     azd63 = azd;
   }
-  const bool over_q = active && nq > QN;
-  if (!active || over_q) nq = 0;     // nothing to walk (the lane stays for the wave-level loop)
+  return nq;
+}
+
+// STATS: the AC symbol statistics of the FINAL coefficients (the reference's last gather pass, jchuff.c:812-915) fall out
+// of the back-track -- a path entry at position pos with predecessor p is the symbol (run = pos-p-1, size of its
+// magnitude) -- so they are counted here instead of by one more pass over the 63 planes: 1 = into an LDS histogram
+// (2 interleaved copies in the dead e_pk rows; the caller zeroes and flushes it), 2 = straight into the global table
+// `counts` of this lane's image/component (deferred tiers: few blocks, any table per lane), 0 = not at all.
+// phases 2.. : nq_in = what phase 1 returned.  `active` false or nq_in > QN: the lane has nothing to do but still takes
+// part in the wave-level loop.
+template <int QN, bool LDS_ROWS, int STATS>
+__device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float4 *rate_rows, const int (*dqT)[64], const float (*ltT)[64],
+                                               int qrow, int nq_in, float azd63, float lambda, bool active, int16_t *__restrict__ qo,
+                                               int kstride, uint2 (*col)[64], unsigned short (*e_pk)[64], int lane, unsigned *counts)
+{
+  const int si_f0 = (int)(si_rows[15].x & 0xFFu), si_eob = (int)(si_rows[0].x & 0xFFu);
+  const float f0f = si_f0 ? (float)si_f0 : 3e38f;
+  const bool over_q = active && nq_in > QN;
+  int nq = (!active || over_q) ? 0 : nq_in;     // nothing to walk (the lane stays for the wave-level loop)
 
   // ---- phase 2: every lane consumes its own queue; the NEXT record is always one load ahead ----
   unsigned long long live = 1ull, neg = 0ull;
@@ -996,7 +1050,21 @@ __device__ __forceinline__ bool trellis_q_lane(const uint4 *si_rows, const float
       }
     }
   }
-  if (!active || over_q) return !over_q;
+  const bool work = active && !over_q;
+  unsigned pk[QN <= 24 ? QN + 1 : 1];
+  if (QN <= 24) {
+#pragma unroll
+    for (int e2 = 1; e2 <= QN; e2++) pk[e2] = e_pk[e2][lane];
+  }
+  if (STATS == 1) {   // every lane of the wave: the e_pk rows are dead now (their words are in registers), they become the histogram
+    typedef unsigned __attribute__((may_alias)) u_alias;
+    u_alias *hz = reinterpret_cast<u_alias *>(&e_pk[0][0]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) hz[j * 64 + lane] = 0u;
+    __syncthreads();
+  }
+  if (!work) return;
+  unsigned *hh = STATS == 1 ? counts + (lane & 1) * 256 : counts;
 
   // ---- end-of-block choice (jcdctmgr.c:1187-1207): independent loads of every live entry, then the scan in position order
   float best_cost = azd63 + (float)si_eob;
@@ -1039,10 +1107,8 @@ __device__ __forceinline__ bool trellis_q_lane(const uint4 *si_rows, const float
     us_alias *colh = reinterpret_cast<us_alias *>(&col[0][0]);   // value of position k: row k>>2, half-word k&3
     unsigned long long mm = live & ~1ull;
     int p = last;
+    if (STATS) { if (last < 63) atomicAdd(&hh[0], 1u); }      // trailing zeros (or an all-zero block): EOB
     if (QN <= 24) {
-      unsigned pk[QN + 1];
-#pragma unroll
-      for (int e2 = 1; e2 <= QN; e2++) pk[e2] = e_pk[e2][lane];
 #pragma unroll
       for (int r = 0; r < 16; r++) colw[r * 64 + lane] = make_uint2(0u, 0u);
 #pragma unroll
@@ -1055,6 +1121,11 @@ __device__ __forceinline__ bool trellis_q_lane(const uint4 *si_rows, const float
             const int v = ((neg >> pos) & 1ull) ? -mag : mag;
             colh[((pos >> 2) * 64 + lane) * 4 + (pos & 3)] = (unsigned short)v;
             p = (int)(pk[e2] & 63u);
+            if (STATS) {
+              const int run = pos - p - 1;
+              if (run > 15) atomicAdd(&hh[0xF0], (unsigned)(run >> 4));
+              atomicAdd(&hh[((run & 15) << 4) + bitlen((unsigned)mag)], 1u);
+            }
           }
         }
       }
@@ -1070,6 +1141,11 @@ __device__ __forceinline__ bool trellis_q_lane(const uint4 *si_rows, const float
           const int v = ((neg >> pos) & 1ull) ? -mag : mag;
           colh[((pos >> 2) * 64 + lane) * 4 + (pos & 3)] = (unsigned short)v;
           p = (int)(pkv & 63u);
+          if (STATS) {
+            const int run = pos - p - 1;
+            if (run > 15) atomicAdd(&hh[0xF0], (unsigned)(run >> 4));
+            atomicAdd(&hh[((run & 15) << 4) + bitlen((unsigned)mag)], 1u);
+          }
         }
       }
     }
@@ -1082,7 +1158,6 @@ __device__ __forceinline__ bool trellis_q_lane(const uint4 *si_rows, const float
       qo[(size_t)k * kstride] = (int16_t)((k & 1) ? (w >> 16) : (w & 0xFFFFu));
     }
   }
-  return true;
 }
 
 __global__ void k_zero_counters(unsigned *__restrict__ a, unsigned *__restrict__ b)
@@ -1121,16 +1196,16 @@ __device__ __forceinline__ void defer_blocks(bool mine, unsigned *__restrict__ l
   }
 }
 
-template <int QN>
+template <int QN, bool FSTATS>   // FSTATS: count the AC symbols of the final coefficients (sequential mode, last trellis round)
 __global__ void __launch_bounds__(64)
 k_trellis_ac_q(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
                int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
                int4 ac_slot_of_comp, int4 wave0_of_comp, const float *__restrict__ lambda_in, unsigned *__restrict__ worklist,
-               int16_t *__restrict__ dense, unsigned dense_cap)
+               int16_t *__restrict__ dense, unsigned dense_cap, MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp)
 {
   static_assert(QN >= 16 && QN <= 63, "queue capacity");
   __shared__ uint2 col[QN][64];                  // queue records, then live entries {azd, acc}, then the value column
-  __shared__ unsigned short e_pk[QN + 1][64];    // back position | magnitude << 6 of live entry e
+  __shared__ unsigned short e_pk[QN + 1][64];    // back position | magnitude << 6 of live entry e; then the symbol histogram
   __shared__ uint4 si_rows[16];
   __shared__ float4 rate_rows[16];
   __shared__ int dqT[1][64];
@@ -1146,11 +1221,6 @@ k_trellis_ac_q(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__rest
   const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
   const int blk = (wv - w0) * 64 + lane;
   const bool inside = blk < cc.nblk;
-  const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + (inside ? blk : cc.nblk - 1);
-  // all 63 raw coefficients at once (coalesced lines, one burst), then the small stuff
-  short xs[64];
-#pragma unroll
-  for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
   const float lambda = lambda_in[(size_t)img * C.total_real_blocks + cc.blk_off + (inside ? blk : cc.nblk - 1)];
   if (lane < 16) {
     const uint4 r = reinterpret_cast<const uint4 *>(T->ehufsi)[lane];
@@ -1159,22 +1229,47 @@ k_trellis_ac_q(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__rest
   }
   dqT[0][lane] = Q->dq8[cc.qtbl][lane];
   ltT[0][lane] = Q->lambda_tbl[cc.qtbl][lane];
+  int nq;
+  float azd63;
+  {
+    // all 63 raw coefficients at once (coalesced lines, one burst); they are dead after phase 1 / the dense copy
+    const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + (inside ? blk : cc.nblk - 1);
+    short xs[64];
+#pragma unroll
+    for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
+    nq = trellis_q_phase1<QN>(xs, Q->dq8[cc.qtbl], Q->rcp8q[cc.qtbl], Q->lambda_tbl[cc.qtbl], lambda, col, lane, azd63);
+    defer_blocks(inside && nq > QN, worklist, (unsigned)img, ((unsigned)comp << 28) | (unsigned)blk, 0u, xs, dense, dense_cap, true, lane);
+  }
   __syncthreads();
   int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
-  const bool ok = trellis_q_lane<QN, true>(si_rows, rate_rows, dqT, ltT, 0, xs, Q->dq8[cc.qtbl], Q->rcp8q[cc.qtbl], Q->lambda_tbl[cc.qtbl],
-                                           lambda, inside, qo, cc.kstride, col, e_pk, lane);
-  defer_blocks(!ok, worklist, (unsigned)img, ((unsigned)comp << 28) | (unsigned)blk, 0u, xs, dense, dense_cap, true, lane);
+  typedef unsigned __attribute__((may_alias)) u_alias;
+  u_alias *hist = reinterpret_cast<u_alias *>(&e_pk[0][0]);   // 2 x 256 bins, zeroed inside once the e_pk words are in registers
+  trellis_q_walk<QN, true, FSTATS ? 1 : 0>(si_rows, rate_rows, dqT, ltT, 0, nq, azd63, lambda, inside, qo, cc.kstride, col, e_pk, lane, (unsigned *)hist);
+  if (FSTATS) {
+    __syncthreads();
+    const int sslot = comp == 0 ? stat_slot_of_comp.x : comp == 1 ? stat_slot_of_comp.y : comp == 2 ? stat_slot_of_comp.z : stat_slot_of_comp.w;
+    MjhHuffTable *TS = stat_tabs + (size_t)img * slots_per_image + sslot;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int bin = lane + 64 * j;
+      unsigned sum = hist[bin] + hist[256 + bin];
+      // every dummy block of the interleaved scan codes one EOB (all-zero AC, jccoefct.c:312-345): counted once per component
+      if (bin == 0 && wv == w0) sum += (unsigned)(cc.wpad * cc.hpad - cc.nblk);
+      if (sum) atomicAdd(&TS->counts[bin], sum);
+    }
+  }
 }
 
 // Deferred blocks (any image / component per lane), same walk with a longer queue: raw coefficients come from the dense
 // copies (one line per block), code lengths from the image's table in global memory (L2-resident), quantizer constants
 // of all four tables from LDS.  Blocks beyond QN2 non-zero positions go to the next list (QN2 = 63 takes everything).
-template <int QN2>
+template <int QN2, bool FSTATS>
 __global__ void __launch_bounds__(64)
 k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
                 int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
                 int4 ac_slot_of_comp, const float *__restrict__ lambda_in, const unsigned *__restrict__ worklist,
-                unsigned *__restrict__ worklist_next, const int16_t *__restrict__ dense, unsigned dense_cap)
+                unsigned *__restrict__ worklist_next, const int16_t *__restrict__ dense, unsigned dense_cap,
+                MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp)
 {
   __shared__ uint2 col[QN2][64];
   __shared__ unsigned short e_pk[QN2 + 1][64];
@@ -1196,26 +1291,33 @@ k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     const MjhComp cc = C.c[comp];
     const int slot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
     const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
-    short xs[64];
-    if (ds < dense_cap) {
-      const uint4 *d = reinterpret_cast<const uint4 *>(dense + (size_t)ds * 64);
-#pragma unroll
-      for (int v = 0; v < 8; v++) {
-        const uint4 q4 = d[v];
-        const unsigned ww[4] = { q4.x, q4.y, q4.z, q4.w };
-#pragma unroll
-        for (int j = 0; j < 4; j++) { xs[8 * v + 2 * j] = (short)(ww[j] & 0xFFFFu); xs[8 * v + 2 * j + 1] = (short)(ww[j] >> 16); }
-      }
-    } else {
-      const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
-#pragma unroll
-      for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
-    }
     const float lambda = lambda_in[(size_t)img * C.total_real_blocks + cc.blk_off + blk];
+    int nq;
+    float azd63;
+    {
+      short xs[64];
+      if (ds < dense_cap) {
+        const uint4 *d = reinterpret_cast<const uint4 *>(dense + (size_t)ds * 64);
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+          const uint4 q4 = d[v];
+          const unsigned ww[4] = { q4.x, q4.y, q4.z, q4.w };
+#pragma unroll
+          for (int j = 0; j < 4; j++) { xs[8 * v + 2 * j] = (short)(ww[j] & 0xFFFFu); xs[8 * v + 2 * j + 1] = (short)(ww[j] >> 16); }
+        }
+      } else {
+        const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+#pragma unroll
+        for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
+      }
+      nq = trellis_q_phase1<QN2>(xs, dqT[cc.qtbl], Q->rcp8q[cc.qtbl], ltT[cc.qtbl], lambda, col, lane, azd63);
+      if (QN2 < 63) defer_blocks(active && nq > QN2, worklist_next, (unsigned)img, w, ds, xs, nullptr, 0u, false, lane);
+    }
     int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
-    const bool ok = trellis_q_lane<QN2, false>(reinterpret_cast<const uint4 *>(T->ehufsi), nullptr, dqT, ltT, cc.qtbl, xs, dqT[cc.qtbl], Q->rcp8q[cc.qtbl],
-                                               ltT[cc.qtbl], lambda, active, qo, cc.kstride, col, e_pk, lane);
-    if (QN2 < 63) defer_blocks(!ok, worklist_next, (unsigned)img, w, ds, xs, nullptr, 0u, false, lane);
+    const int sslot = comp == 0 ? stat_slot_of_comp.x : comp == 1 ? stat_slot_of_comp.y : comp == 2 ? stat_slot_of_comp.z : stat_slot_of_comp.w;
+    unsigned *cnt = FSTATS ? stat_tabs[(size_t)img * slots_per_image + sslot].counts : nullptr;
+    trellis_q_walk<QN2, false, FSTATS ? 2 : 0>(reinterpret_cast<const uint4 *>(T->ehufsi), nullptr, dqT, ltT, cc.qtbl, nq, azd63, lambda, active, qo, cc.kstride,
+                                                col, e_pk, lane, cnt);
     __syncthreads();   // the LDS columns are reused by the next round
   }
 }
@@ -1896,11 +1998,14 @@ void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size
 static int max_nblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp; i++) m = C.c[i].nblk > m ? C.c[i].nblk : m; return m; }
 static int max_padblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp; i++) { int v = C.c[i].wpad * C.c[i].hpad; m = v > m ? v : m; } return m; }
 
-void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda, int n, hipStream_t s)
+void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
+                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], int n, hipStream_t s)
 {
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
-  if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda);
-  else hipLaunchKernelGGL((k_dct_quant<uint8_t>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda);
+  const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
+  if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t, false>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl);
+  else if (stat_tabs) hipLaunchKernelGGL((k_dct_quant<uint8_t, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl);
+  else hipLaunchKernelGGL((k_dct_quant<uint8_t, false>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl);
 }
 
 void mjh_launch_stats_ac(const MjhConst &C, const void *q, MjhHuffTable *tabs, int spi, const int slot[4], int count_dummies, int n, hipStream_t s)
@@ -1935,26 +2040,34 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
   if (nslots > 0) hipLaunchKernelGGL(k_gen_tables_list, dim3(nslots, n), dim3(64), 0, s, tabs, spi, d_slots);
 }
 
-void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda, unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, int variant, int n, hipStream_t s)
+void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
+                           unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant, int n, hipStream_t s)
 {
   const int4 sl = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
+  // stat_slot != nullptr: the statistics of the final coefficients go to these table slots (one per component)
+  MjhHuffTable *st = stat_slot ? tabs : nullptr;
+  const int4 ss = stat_slot ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
   hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, worklist, worklist2);   // (a 16-byte hipMemsetAsync costs ~80 us of stream time)
   int w0[5] = { 0, 0, 0, 0, 0 };
   for (int i = 0; i < 4; i++) w0[i + 1] = w0[i] + (i < C.ncomp ? (C.c[i].nblk + 63) / 64 : 0);
   dim3 gridq(w0[C.ncomp], n);
   for (int i = C.ncomp; i < 4; i++) w0[i] = 0x7FFFFFFF;   // components that do not exist never match
   const int4 wv = make_int4(w0[0], w0[1], w0[2], w0[3]);
-#define LQ(QN) hipLaunchKernelGGL((k_trellis_ac_q<QN>), gridq, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, wv, lambda, worklist, (int16_t *)dense, dense_cap)
-  switch (variant) {   // MJH_TRELLIS_VARIANT: queue capacity of the first tier (all bit-identical; LDS per wave = 10 * QN * 64 bytes)
-    case 1: LQ(20); break;
-    case 2: LQ(24); break;
-    case 3: LQ(32); break;
-    default: LQ(16); break;
+#define LQ(QN, FS) hipLaunchKernelGGL((k_trellis_ac_q<QN, FS>), gridq, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, wv, lambda, worklist, (int16_t *)dense, dense_cap, st, ss)
+#define LD(QN, FS, GRID, WL, WLN) hipLaunchKernelGGL((k_trellis_ac_qd<QN, FS>), dim3(GRID), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda, (const unsigned *)WL, WLN, (const int16_t *)dense, dense_cap, st, ss)
+  // MJH_TRELLIS_VARIANT: queue capacity of the first tier (all bit-identical; LDS per wave = 10 * QN * 64 bytes);
+  // second and third tier: blocks with more than QN (then 32) non-zero positions, from their dense copies
+  if (st) {
+    switch (variant) { case 1: LQ(20, true); break; case 2: LQ(24, true); break; default: LQ(16, true); break; }
+    LD(32, true, 2048, worklist, worklist2);
+    LD(63, true, 1024, worklist2, (unsigned *)nullptr);
+  } else {
+    switch (variant) { case 1: LQ(20, false); break; case 2: LQ(24, false); break; default: LQ(16, false); break; }
+    LD(32, false, 2048, worklist, worklist2);
+    LD(63, false, 1024, worklist2, (unsigned *)nullptr);
   }
 #undef LQ
-  // second and third tier: blocks with more than QN (then 32) non-zero positions, from their dense copies
-  hipLaunchKernelGGL((k_trellis_ac_qd<32>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, (const unsigned *)worklist, worklist2, (const int16_t *)dense, dense_cap);
-  hipLaunchKernelGGL((k_trellis_ac_qd<63>), dim3(1024), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, sl, lambda, (const unsigned *)worklist2, (unsigned *)nullptr, (const int16_t *)dense, dense_cap);
+#undef LD
 }
 
 // exclusive prefix sum of 16-bit lengths, `npairs` independent arrays of n_per entries (the progressive path's
