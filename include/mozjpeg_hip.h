@@ -92,7 +92,15 @@ typedef struct {
   /* cinfo->smoothing_factor (jpeglib.h:459, cjpeg -smooth N), 0..100: input smoothing inside the full-size and the
    * 2x2 downsamplers (jcsample.c:306-455); the other sampling ratios have no smoothing variant in the reference */
   int smoothing_factor;
+  /* colour transform between input pixels and JPEG components: MJH_COLOR_YCC (0) = RGB -> YCbCr / gray (rgb_ycc_convert,
+   * rgb_gray_convert, grayscale_convert of jccolor.c), MJH_COLOR_NONE = the three input samples become the three
+   * components unconverted (null_convert jccolor.c:479, JCS_RGB output = `cjpeg -rgb`; an Adobe APP14 marker with
+   * transform 0 replaces the JFIF APP0, component ids are whatever component_id[] says, 'R' 'G' 'B' for cjpeg) */
+  int color_transform;
 } mjh_params;
+
+#define MJH_COLOR_YCC  0
+#define MJH_COLOR_NONE 1
 
 typedef struct mjh_encoder mjh_encoder;
 
@@ -102,8 +110,12 @@ typedef struct mjh_encoder mjh_encoder;
 int mjh_params_defaults(mjh_params *p, int width, int height, int input_components,
                         int gray_output, int compress_profile, int hsamp, int vsamp);
 /* jpeg_set_quality (jcparam.c:360-380) with the base table selected by base_quant_tbl_idx
- * (-1 = the profile's default: 3 for max compression, 0 for fastest; jcparam.c:509-510). */
+ * (-1 = the profile's default: 3 for max compression, 0 for fastest; jcparam.c:509-510; 0..8 = cjpeg -quant-table N). */
 int mjh_params_set_quality(mjh_params *p, int quality, int force_baseline, int base_quant_tbl_idx);
+
+/* The Annex K.3 Huffman tables jpeg_set_defaults installs (std_huff_tables jstdhuff.c:31-131): bits[0..16] and the
+ * symbol list of DC / AC table 0 (luminance) or 1 (chrominance).  Constants owned by the library. */
+int mjh_std_huffman_table(int is_ac, int tblno, const uint8_t **bits, const uint8_t **vals, int *nvals);
 
 /* jpeg_simple_progression (jcparam.c:859-1004): the profile's fixed script (9 scans for YCbCr in
  * the max-compression profile, 10 in the fastest profile); clears optimize_scans. */
@@ -116,6 +128,8 @@ int mjh_params_search_progression(mjh_params *p);
 /* Creates the device-resident state for up to max_batch images of p's geometry on HIP device
  * `device`.  Returns MJH_EUNSUPPORTED for configurations the GPU path does not cover. */
 int mjh_encoder_create(const mjh_params *p, int max_batch, int device, mjh_encoder **out);
+/* number of visible HIP devices (0 if there is none: every mjh_encoder_create then fails with MJH_EHIP) */
+int mjh_device_count(void);
 void mjh_encoder_destroy(mjh_encoder *e);
 
 /* ---- encode ---------------------------------------------------------------------------- */

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libmozjpeg_hip.so")
 MAX_COMPS, MAX_SCANS = 4, 64
 PROFILE_MAX_COMPRESSION = 0x5D083AAD
 PROFILE_FASTEST = 0x2AEA5CB4
+COLOR_YCC, COLOR_NONE = 0, 1
 OK, EINVAL, EUNSUPPORTED, EHIP, ENOMEM, ETOOSMALL = 0, -1, -2, -3, -4, -5
 TAP_PLANE, TAP_COEF_UQ, TAP_COEF_Q, TAP_COEF_Q0, TAP_HUFF_BITS, TAP_HUFF_VALS, TAP_PROG_SCAN_US = 1, 2, 3, 4, 5, 6, 7
 
@@ -44,7 +45,7 @@ class Params(C.Structure):
                 ("restart_interval", C.c_uint), ("restart_in_rows", C.c_int), ("num_scans", C.c_int),
                 ("scan_info", Scan * MAX_SCANS), ("optimize_scans", C.c_int), ("write_JFIF_header", C.c_int),
                 ("input_pixel_size", C.c_int), ("rgb_offset", C.c_int * 3), ("data_precision", C.c_int),
-                ("trellis_num_loops", C.c_int), ("smoothing_factor", C.c_int)]
+                ("trellis_num_loops", C.c_int), ("smoothing_factor", C.c_int), ("color_transform", C.c_int)]
 
 
 class Result(C.Structure):
@@ -110,7 +111,7 @@ def _chk(rc):
 def make_params(width, height, *, quality=75, baseline=False, revert=False, optimize=False,
                 notrellis=False, notrellis_dc=False, noovershoot=False, sample=(2, 2), gray=False,
                 grayin=False, quant_table=-1, lambda1=None, lambda2=None, restart=None,
-                progressive=False, fastcrush=False, precision=8, trellis_loops=1, smooth=0):
+                progressive=False, fastcrush=False, precision=8, trellis_loops=1, smooth=0, rgb=False):
     """Parameters with cjpeg's switch vocabulary (cjpeg.c:371-714).  Without `baseline` or
     `revert` this is cjpeg's default: progressive with scan search (`fastcrush`: fixed 9-scan script)."""
     p = Params()
@@ -133,6 +134,13 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     p.data_precision = precision
     p.trellis_num_loops = trellis_loops
     p.smoothing_factor = smooth
+    if rgb:   # cjpeg -rgb: jpeg_set_colorspace(JCS_RGB) (jcparam.c:611-619): all components 1x1 / table 0, ids 'R' 'G' 'B', no JFIF
+        p.color_transform = COLOR_NONE
+        p.write_JFIF_header = 0
+        for i, cid in enumerate(b"RGB"):
+            p.component_id[i] = cid
+            p.h_samp_factor[i] = p.v_samp_factor[i] = 1
+            p.quant_tbl_no[i] = p.dc_tbl_no[i] = p.ac_tbl_no[i] = 0
     if restart is not None:
         if isinstance(restart, str) and restart.lower().endswith("b"):
             p.restart_interval = int(restart[:-1])

@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmozjpeg_hip.so")
 SHIM = os.path.join(HERE, "libmozjpeg_hip_jpeg62.so")
+STANDALONE = os.path.join(HERE, "standalone", "libjpeg.so.62")
 SOURCES = ["mjh_kernels.hip", "mjh_prog.hip", "mjh_encoder.cpp"]
 # -ffp-contract=off: the trellis / deringing float recipes must not be fused into FMAs
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-fast-math",
@@ -57,9 +58,22 @@ def build_shim(force=False, verbose=False):
         if verbose:
             print("shim: reference headers not present, keeping prebuilt", SHIM if os.path.exists(SHIM) else "(none)")
         return SHIM if os.path.exists(SHIM) else None
-    if force or _newer(SHIM, [src, LIB]):
-        cmd = ["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-I" + cfg, "-I" + ref, "-I" + os.path.join(HERE, "..", "include"),
-               "-o", SHIM, src, "-L" + HERE, "-l:libmozjpeg_hip.so", "-Wl,-rpath,$ORIGIN", "-ldl"]
+    hdr = os.path.join(CSRC, "jpeg_shim.h")
+    inc = ["-I" + cfg, "-I" + ref, "-I" + os.path.join(HERE, "..", "include"), "-I" + CSRC]
+    if force or _newer(SHIM, [src, hdr, LIB]):
+        # preload / link-order flavour: the hot-path entry points + abort/destroy hooks in front of a libjpeg
+        cmd = ["gcc", "-O2", "-fPIC", "-shared", "-Wall"] + inc + ["-o", SHIM, src, "-L" + HERE, "-l:libmozjpeg_hip.so",
+                                                                     "-Wl,-rpath,$ORIGIN", "-ldl", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    api = os.path.join(CSRC, "jpeg_api.c")
+    if force or _newer(STANDALONE, [src, api, hdr, LIB, os.path.join(CSRC, "mjh_quant_presets.h")]):
+        # stand-alone flavour: a complete libjpeg.so.62 for the COMPRESS API, nothing of the reference at run time
+        os.makedirs(os.path.dirname(STANDALONE), exist_ok=True)
+        cmd = ["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-DMJH_STANDALONE"] + inc + ["-o", STANDALONE, src, api, "-L" + HERE,
+                                                                                         "-l:libmozjpeg_hip.so", "-Wl,-soname,libjpeg.so.62",
+                                                                                         "-Wl,-rpath,$ORIGIN/..", "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -2,6 +2,19 @@
  * jpeg_shim.c -- libjpeg drop-in entry points on top of the MI355X batch encoder.
  * See include/mozjpeg_hip_jpeglib.h for the contract.  Compiled against the libjpeg headers of the
  * tree it drops into; links only to libmozjpeg_hip.so (and libdl).
+ *
+ * Two builds of this file:
+ *   (default)        libmozjpeg_hip_jpeg62.so -- placed IN FRONT of a libjpeg (link order / LD_PRELOAD): exports only
+ *                    the entry points that bracket the hot path plus the abort / destroy hooks, everything else of
+ *                    the API keeps coming from the library behind it (dlsym(RTLD_NEXT)).
+ *   -DMJH_STANDALONE standalone/libjpeg.so.62 -- together with jpeg_api.c a complete replacement of the libjpeg
+ *                    COMPRESS API: nothing of the reference is needed at run time.
+ *
+ * State: one shim_state per active compress object (start .. finish / abort / destroy), found through a small
+ * table keyed by the cinfo address.  A state OWNS its encoder from start to finish: encoders come from a process-wide
+ * cache keyed by (parameters, device), so two interleaved compress objects of one thread can never meet in one
+ * encoder, and repeated compressions with the same parameters reuse device buffers.  Devices: MOZJPEG_HIP_DEVICE=n
+ * pins the process to one GPU; otherwise host threads are dealt round-robin over the visible GPUs.
  */
 #define _GNU_SOURCE
 #define JPEG_INTERNALS
@@ -15,27 +28,94 @@
 #include "jpeglib.h"   /* JPEG_INTERNALS: pulls in jpegint.h and jerror.h */
 
 #include "mozjpeg_hip.h"
+#include "jpeg_shim.h"
 
 typedef struct shim_state {
   j_compress_ptr cinfo;
   mjh_params p;
-  unsigned char *pixels;     /* staged scanlines, image_width*input_components per row */
+  mjh_encoder *enc;          /* owned from start to finish / abort */
+  unsigned char *pixels;     /* scanlines go straight into the encoder's pinned staging buffer (not owned) */
   size_t row_bytes;
   int raw;                   /* raw_data_in: component planes arrive through jpeg_write_raw_data */
   jvirt_barray_ptr *coef_arrays;   /* jpeg_write_coefficients: the caller's virtual arrays, read at jpeg_finish_compress */
-  unsigned char *planes[MAX_COMPONENTS];   /* staged planes, width_in_blocks*8 x height_in_blocks*8 samples */
+  unsigned char *planes[MAX_COMPONENTS];   /* staged planes / coefficient blocks (owned) */
   size_t plane_pitch[MAX_COMPONENTS];
-  int header_bytes;          /* SOI (+APP0) already written by jpeg_start_compress */
+  int header_bytes;          /* SOI (+APP0, +APP14) already written by jpeg_start_compress */
+  int total_passes;          /* what the reference's master would report to a progress monitor */
   struct shim_state *next;
 } shim_state;
 
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static shim_state *g_states = NULL;
 
-/* one cached encoder per thread: creating device buffers per image would dominate small images */
-static __thread mjh_encoder *t_enc = NULL;
-static __thread mjh_params t_enc_params;
+/* ---- encoder cache ------------------------------------------------------------------------------------------------ */
+#define CACHE_MAX_IDLE 6
+typedef struct cache_ent {
+  mjh_params p;
+  int device;
+  mjh_encoder *enc;
+  int busy;
+  unsigned long stamp;
+  struct cache_ent *next;
+} cache_ent;
+static cache_ent *g_cache = NULL;
+static unsigned long g_stamp = 0;
+static int g_next_device = 0;
+static __thread int t_device = -1;
 
+static int pick_device(void)
+{
+  if (t_device < 0) {
+    const char *v = getenv("MOZJPEG_HIP_DEVICE");
+    int n = mjh_device_count();
+    if (n < 1) n = 1;
+    if (v && *v >= '0' && *v <= '9') t_device = atoi(v) % n;
+    else {   /* host threads are dealt round-robin over the GPUs: N client threads reach N devices */
+      pthread_mutex_lock(&g_lock);
+      t_device = g_next_device++ % n;
+      pthread_mutex_unlock(&g_lock);
+    }
+  }
+  return t_device;
+}
+
+static mjh_encoder *cache_acquire(const mjh_params *p, int device)
+{
+  cache_ent *c, **pp, *lru = NULL, **lru_pp = NULL;
+  mjh_encoder *enc = NULL;
+  int idle = 0;
+  pthread_mutex_lock(&g_lock);
+  for (c = g_cache; c; c = c->next)
+    if (!c->busy && c->device == device && memcmp(&c->p, p, sizeof(*p)) == 0) { c->busy = 1; c->stamp = ++g_stamp; enc = c->enc; break; }
+  if (!enc) {   /* make room: the least recently used idle encoder goes (each holds device buffers for one image) */
+    for (pp = &g_cache; *pp; pp = &(*pp)->next)
+      if (!(*pp)->busy) { idle++; if (!lru || (*pp)->stamp < lru->stamp) { lru = *pp; lru_pp = pp; } }
+    if (idle >= CACHE_MAX_IDLE && lru) { *lru_pp = lru->next; } else lru = NULL;
+  }
+  pthread_mutex_unlock(&g_lock);
+  if (enc) return enc;
+  if (lru) { mjh_encoder_destroy(lru->enc); free(lru); }
+  if (mjh_encoder_create(p, 1, device, &enc) != MJH_OK) return NULL;
+  c = (cache_ent *)calloc(1, sizeof(*c));
+  if (!c) { mjh_encoder_destroy(enc); return NULL; }
+  c->p = *p; c->device = device; c->enc = enc; c->busy = 1;
+  pthread_mutex_lock(&g_lock);
+  c->stamp = ++g_stamp;
+  c->next = g_cache; g_cache = c;
+  pthread_mutex_unlock(&g_lock);
+  return enc;
+}
+
+static void cache_release(mjh_encoder *enc)
+{
+  cache_ent *c;
+  if (!enc) return;
+  pthread_mutex_lock(&g_lock);
+  for (c = g_cache; c; c = c->next) if (c->enc == enc) { c->busy = 0; break; }
+  pthread_mutex_unlock(&g_lock);
+}
+
+/* ---- state table ---------------------------------------------------------------------------------------------------- */
 static shim_state *find_state(j_compress_ptr cinfo, int remove)
 {
   shim_state **pp, *s = NULL;
@@ -46,12 +126,34 @@ static shim_state *find_state(j_compress_ptr cinfo, int remove)
   return s;
 }
 
+static void free_state(shim_state *s)
+{
+  int ci;
+  if (!s) return;
+  for (ci = 0; ci < MAX_COMPONENTS; ci++) free(s->planes[ci]);
+  cache_release(s->enc);
+  free(s);
+}
+
+/* jpeg_abort / jpeg_destroy on an object that is in the middle of a compression (the application's error_exit
+ * longjmp'ed out, or it simply gave up): forget the staged image, hand the encoder back.  Returns 1 if there was one. */
+int mjh_shim_drop(void *cinfo)
+{
+  shim_state *s = find_state((j_compress_ptr)cinfo, 1);
+  if (!s) return 0;
+  free_state(s);
+  return 1;
+}
+
+/* every ERREXIT of this file goes through here once a state exists: the state must not outlive the error */
+#define FAIL_WITH_STATE(cinfo, stmt) do { mjh_shim_drop(cinfo); stmt; } while (0)
+
 static void emit_byte(j_compress_ptr cinfo, int v)
 { /* same protocol as jcmarker.c:113-123 */
   struct jpeg_destination_mgr *dest = cinfo->dest;
   *(dest->next_output_byte)++ = (JOCTET)v;
   if (--dest->free_in_buffer == 0)
-    if (!(*dest->empty_output_buffer) (cinfo)) ERREXIT(cinfo, JERR_CANT_SUSPEND);
+    if (!(*dest->empty_output_buffer) (cinfo)) FAIL_WITH_STATE(cinfo, ERREXIT(cinfo, JERR_CANT_SUSPEND));
 }
 static void emit_bytes(j_compress_ptr cinfo, const unsigned char *p, size_t n)
 {
@@ -61,7 +163,7 @@ static void emit_bytes(j_compress_ptr cinfo, const unsigned char *p, size_t n)
     memcpy(dest->next_output_byte, p, k);
     dest->next_output_byte += k; dest->free_in_buffer -= k; p += k; n -= k;
     if (dest->free_in_buffer == 0)
-      if (!(*dest->empty_output_buffer) (cinfo)) ERREXIT(cinfo, JERR_CANT_SUSPEND);
+      if (!(*dest->empty_output_buffer) (cinfo)) FAIL_WITH_STATE(cinfo, ERREXIT(cinfo, JERR_CANT_SUSPEND));
   }
 }
 
@@ -69,7 +171,7 @@ static void emit_bytes(j_compress_ptr cinfo, const unsigned char *p, size_t n)
  * (jcmarker.c:590-615) between jpeg_start_compress and the first scanline */
 static void mw_header(j_compress_ptr cinfo, int marker, unsigned int datalen)
 {
-  if (datalen > 65533u) ERREXIT(cinfo, JERR_BAD_LENGTH);
+  if (datalen > 65533u) FAIL_WITH_STATE(cinfo, ERREXIT(cinfo, JERR_BAD_LENGTH));
   emit_byte(cinfo, 0xFF); emit_byte(cinfo, marker);
   emit_byte(cinfo, (int)((datalen + 2) >> 8) & 0xFF); emit_byte(cinfo, (int)(datalen + 2) & 0xFF);
 }
@@ -79,6 +181,14 @@ static void mw_nop(j_compress_ptr cinfo) { (void)cinfo; }
 typedef void (*start_fn)(j_compress_ptr, boolean);
 typedef JDIMENSION (*write_fn)(j_compress_ptr, JSAMPARRAY, JDIMENSION);
 typedef void (*finish_fn)(j_compress_ptr);
+typedef void (*wrcoef_fn)(j_compress_ptr, jvirt_barray_ptr *);
+typedef JDIMENSION (*raw_fn)(j_compress_ptr, JSAMPIMAGE, JDIMENSION);
+
+#ifdef MJH_STANDALONE
+#define NEXT_SYMBOL(name) NULL
+#else
+#define NEXT_SYMBOL(name) dlsym(RTLD_NEXT, name)
+#endif
 
 static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pixels)
 {
@@ -87,9 +197,9 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
   if (cinfo->data_precision != 8 && cinfo->data_precision != 12) return "data_precision other than 8 or 12";
   p->data_precision = cinfo->data_precision;
   if (cinfo->arith_code) return "arithmetic coding";
+  if (cinfo->master->lossless) return "lossless mode";
   p->smoothing_factor = cinfo->smoothing_factor;   /* cjpeg -smooth N; ignored for raw data / coefficients like in the reference */
   if (cinfo->dct_method != JDCT_ISLOW) return "dct_method other than JDCT_ISLOW";
-  if (cinfo->write_Adobe_marker) return "Adobe marker";
   {
     /* rgb_red/green/blue/pixelsize of jccolor.c / jmorecfg.h for the extended colour spaces */
     int ps = 0, ro = 0, go = 1, bo = 2;
@@ -107,13 +217,17 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
       break;
     }
     if (no_pixels) { ps = cinfo->num_components == 1 ? 1 : 3; ro = 0; go = 1; bo = 2; }   /* planes / coefficients in: the input pixel format is never looked at */
-    if (!no_pixels && cinfo->input_components != ps) ERREXIT(cinfo, JERR_BAD_IN_COLORSPACE);
+    if (!no_pixels && cinfo->input_components != ps) return "input_components does not match in_color_space";
     if (ps == 1) p->input_components = 1;
     else { p->input_components = 3; p->input_pixel_size = ps; p->rgb_offset[0] = ro; p->rgb_offset[1] = go; p->rgb_offset[2] = bo; }
   }
   if (cinfo->jpeg_color_space == JCS_YCbCr && cinfo->num_components == 3) p->num_components = 3;
   else if (cinfo->jpeg_color_space == JCS_GRAYSCALE && cinfo->num_components == 1) p->num_components = 1;
-  else return "JPEG colour space (only YCbCr / grayscale)";
+  else if (cinfo->jpeg_color_space == JCS_RGB && cinfo->num_components == 3 && (no_pixels || p->input_components == 3)) {
+    p->num_components = 3;           /* cjpeg -rgb: null_convert (jccolor.c:479), the samples go through unconverted */
+    p->color_transform = MJH_COLOR_NONE;
+  } else return "JPEG colour space (only YCbCr / grayscale / RGB)";
+  if (cinfo->write_Adobe_marker && cinfo->jpeg_color_space != JCS_RGB) return "Adobe marker for this colour space";
   /* JFIF version / density: the APP0 segment is written by this shim from the cinfo fields (emit_jfif_app0
    * jcmarker.c:422-449), the device's fixed APP0 is dropped, so any values are fine */
   p->image_width = (int)cinfo->image_width;
@@ -124,7 +238,7 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
     p->quant_tbl_no[ci] = c->quant_tbl_no; p->dc_tbl_no[ci] = c->dc_tbl_no; p->ac_tbl_no[ci] = c->ac_tbl_no;
     p->component_id[ci] = c->component_id;
     if (c->quant_tbl_no < 0 || c->quant_tbl_no >= NUM_QUANT_TBLS || cinfo->quant_tbl_ptrs[c->quant_tbl_no] == NULL)
-      ERREXIT1(cinfo, JERR_NO_QUANT_TABLE, c->quant_tbl_no);
+      return "component without a quantization table";
     for (i = 0; i < 64; i++) p->quantval[c->quant_tbl_no][i] = cinfo->quant_tbl_ptrs[c->quant_tbl_no]->quantval[i];
   }
   p->compress_profile = jpeg_c_get_int_param(cinfo, JINT_COMPRESS_PROFILE) == JCP_FASTEST ? MJH_PROFILE_FASTEST
@@ -162,7 +276,7 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
     }
     p->optimize_scans = jpeg_c_get_bool_param(cinfo, JBOOLEAN_OPTIMIZE_SCANS) && cinfo->master->num_scans_luma != 0;
     p->optimize_coding = 1;   /* jcmaster.c:1091-1094 */
-    if (jpeg_c_get_int_param(cinfo, JINT_DC_SCAN_OPT_MODE) != 0) return "dc_scan_opt_mode != 0";
+    if (p->optimize_scans && jpeg_c_get_int_param(cinfo, JINT_DC_SCAN_OPT_MODE) != 0) return "dc_scan_opt_mode != 0 with the scan search";
   }
   if (!cinfo->optimize_coding) {
     /* standard tables are baked into the GPU path; anything else needs optimize_coding */
@@ -172,7 +286,17 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
   return NULL;
 }
 
-typedef void (*wrcoef_fn)(j_compress_ptr, jvirt_barray_ptr *);
+/* what the reference's master would report as total_passes (jcmaster.c:1121-1139) */
+static int reference_total_passes(j_compress_ptr cinfo, const mjh_params *p)
+{
+  const int nscans = p->num_scans > 0 ? p->num_scans : 1;
+  int total = p->optimize_coding ? nscans * 2 : nscans;
+  if (p->trellis_quant) {
+    const int loops = p->trellis_num_loops > 0 ? p->trellis_num_loops : 1;
+    total += p->optimize_coding ? 2 * cinfo->num_components * loops : cinfo->num_components * loops + 1;
+  }
+  return total;
+}
 
 /* common start of jpeg_start_compress (mode 0 pixels / 1 raw data) and jpeg_write_coefficients (mode 2) */
 static void shim_begin(j_compress_ptr cinfo, boolean write_all_tables, int mode, jvirt_barray_ptr *coef_arrays)
@@ -180,35 +304,41 @@ static void shim_begin(j_compress_ptr cinfo, boolean write_all_tables, int mode,
   const char *why;
   shim_state *s;
   struct jpeg_marker_writer *mw;
+  static __thread char whybuf[320];
 
   if (cinfo->global_state != CSTATE_START) ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
+  mjh_shim_drop(cinfo);   /* a stale entry for this address (object destroyed behind our back) must never be found again */
   s = (shim_state *)calloc(1, sizeof(*s));
   if (!s) ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0);
   if (mode == 2) cinfo->input_components = 1;   /* transencode_master_selection jctrans.c:186 */
   why = capture_params(cinfo, &s->p, mode);
   if (!why) {
-    /* let the encoder validate too (geometry limits, sampling factors ...) */
-    if (t_enc == NULL || memcmp(&t_enc_params, &s->p, sizeof(mjh_params)) != 0) {
-      if (t_enc) { mjh_encoder_destroy(t_enc); t_enc = NULL; }
-      if (mjh_encoder_create(&s->p, 1, 0, &t_enc) != MJH_OK) why = mjh_last_error();
-      else t_enc_params = s->p;
-    }
+    /* the encoder validates too (geometry limits, sampling factors ...) and is this object's until finish / abort */
+    s->enc = cache_acquire(&s->p, pick_device());
+    if (!s->enc) { snprintf(whybuf, sizeof(whybuf), "%s", mjh_last_error()); why = whybuf; }
   }
   if (why) {
-    free(s);
+    free_state(s);
     if (getenv("MOZJPEG_HIP_PASSTHROUGH")) {
-      fprintf(stderr, "mozjpeg_hip: %s is outside the GPU path; MOZJPEG_HIP_PASSTHROUGH set, handing over to the host libjpeg\n", why);
       if (mode == 2) {
-        wrcoef_fn next = (wrcoef_fn)dlsym(RTLD_NEXT, "jpeg_write_coefficients");
-        if (next) { next(cinfo, coef_arrays); return; }
+        wrcoef_fn next = (wrcoef_fn)NEXT_SYMBOL("jpeg_write_coefficients");
+        if (next) { fprintf(stderr, "mozjpeg_hip: %s is outside the GPU path; MOZJPEG_HIP_PASSTHROUGH set, handing over to the host libjpeg\n", why); next(cinfo, coef_arrays); return; }
       } else {
-        start_fn next = (start_fn)dlsym(RTLD_NEXT, "jpeg_start_compress");
-        if (next) { next(cinfo, write_all_tables); return; }
+        start_fn next = (start_fn)NEXT_SYMBOL("jpeg_start_compress");
+        if (next) { fprintf(stderr, "mozjpeg_hip: %s is outside the GPU path; MOZJPEG_HIP_PASSTHROUGH set, handing over to the host libjpeg\n", why); next(cinfo, write_all_tables); return; }
       }
     }
     fprintf(stderr, "mozjpeg_hip: unsupported configuration (%s); no CPU fallback\n", why);
     ERREXIT(cinfo, JERR_NOT_COMPILED);
   }
+  s->cinfo = cinfo;
+  s->raw = mode == 1;
+  s->coef_arrays = mode == 2 ? coef_arrays : NULL;
+  s->total_passes = reference_total_passes(cinfo, &s->p);
+  pthread_mutex_lock(&g_lock);
+  s->next = g_states; g_states = s;
+  pthread_mutex_unlock(&g_lock);
+  /* from here on an error exit has to drop the state first (FAIL_WITH_STATE) */
   if (write_all_tables) jpeg_suppress_tables(cinfo, FALSE);
   (*cinfo->err->reset_error_mgr) ((j_common_ptr)cinfo);
   (*cinfo->dest->init_destination) (cinfo);
@@ -218,7 +348,7 @@ static void shim_begin(j_compress_ptr cinfo, boolean write_all_tables, int mode,
   mw->write_file_trailer = mw_nop; mw->write_tables_only = mw_nop;
   mw->write_marker_header = mw_header; mw->write_marker_byte = mw_byte;
   cinfo->marker = mw;
-  /* write_file_header jcmarker.c:649: SOI + JFIF APP0 */
+  /* write_file_header jcmarker.c:649: SOI + JFIF APP0 (+ Adobe APP14) */
   emit_byte(cinfo, 0xFF); emit_byte(cinfo, 0xD8);
   s->header_bytes = 2;
   if (cinfo->write_JFIF_header) {   /* emit_jfif_app0 jcmarker.c:422-449 */
@@ -229,9 +359,10 @@ static void shim_begin(j_compress_ptr cinfo, boolean write_all_tables, int mode,
     emit_bytes(cinfo, app0, sizeof(app0));
     s->header_bytes += 18;   /* the device file carries the default APP0 at the same place: skipped on output */
   }
-  s->cinfo = cinfo;
-  s->raw = mode == 1;
-  s->coef_arrays = mode == 2 ? coef_arrays : NULL;
+  if (cinfo->write_Adobe_marker) {  /* emit_adobe_app14 jcmarker.c:452-486: version 100, flags 0, transform 0 = RGB */
+    static const unsigned char app14[16] = { 0xFF, 0xEE, 0, 14, 'A', 'd', 'o', 'b', 'e', 0, 100, 0, 0, 0, 0, 0 };
+    emit_bytes(cinfo, app14, sizeof(app14));   /* the device file carries the same 16 bytes: skipped on output */
+  }
   {
     /* the geometry fields callers read back after jpeg_start_compress (initial_setup jcmaster.c:237-259);
      * tj3CompressFromYUVPlanes8 sizes its row buffers from width_in_blocks / max_*_samp_factor */
@@ -267,14 +398,18 @@ static void shim_begin(j_compress_ptr cinfo, boolean write_all_tables, int mode,
       s->planes[ci] = (unsigned char *)malloc(s->plane_pitch[ci] * c->height_in_blocks * DCTSIZE);
       if (!s->planes[ci]) bad = 1;
     }
-    if (bad) { for (ci = 0; ci < cinfo->num_components; ci++) free(s->planes[ci]); free(s); ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0); }
+    if (bad) FAIL_WITH_STATE(cinfo, ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0));
   } else {
-    s->pixels = (unsigned char *)malloc(s->row_bytes * cinfo->image_height);
-    if (!s->pixels) { free(s); ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0); }
+    /* scanlines are written straight into the encoder's pinned staging buffer: no second host copy at finish */
+    void *buf = NULL;
+    size_t cap = 0;
+    if (mjh_host_staging(s->enc, &buf, &cap) != MJH_OK || cap < s->row_bytes * cinfo->image_height) {
+      fprintf(stderr, "mozjpeg_hip: %s\n", mjh_last_error());
+      FAIL_WITH_STATE(cinfo, ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0));
+    }
+    s->pixels = (unsigned char *)buf;
   }
-  pthread_mutex_lock(&g_lock);
-  s->next = g_states; g_states = s;
-  pthread_mutex_unlock(&g_lock);
+  if (cinfo->progress != NULL) { cinfo->progress->completed_passes = 0; cinfo->progress->total_passes = s->total_passes; }
   cinfo->next_scanline = 0;
   cinfo->global_state = mode == 2 ? CSTATE_WRCOEFS : (s->raw ? CSTATE_RAW_OK : CSTATE_SCANNING);   /* jcapistd.c:62, jctrans.c:67 */
 }
@@ -297,12 +432,12 @@ static JDIMENSION write_rows(j_compress_ptr cinfo, void **scanlines, JDIMENSION 
   shim_state *s = find_state(cinfo, 0);
   JDIMENSION rows_left, i;
   if (!s) {
-    write_fn next = (write_fn)dlsym(RTLD_NEXT, name);
+    write_fn next = (write_fn)NEXT_SYMBOL(name);
     if (next) return next(cinfo, (JSAMPARRAY)scanlines, num_lines);
     ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
   }
-  if (cinfo->data_precision != precision) ERREXIT1(cinfo, JERR_BAD_PRECISION, cinfo->data_precision);   /* jcapistd.c:96-97 */
-  if (cinfo->global_state != CSTATE_SCANNING) ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
+  if (cinfo->data_precision != precision) FAIL_WITH_STATE(cinfo, ERREXIT1(cinfo, JERR_BAD_PRECISION, cinfo->data_precision));   /* jcapistd.c:96-97 */
+  if (cinfo->global_state != CSTATE_SCANNING) FAIL_WITH_STATE(cinfo, ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state));
   if (cinfo->next_scanline >= cinfo->image_height) WARNMS(cinfo, JWRN_TOO_MUCH_DATA);
   if (cinfo->progress != NULL) {
     cinfo->progress->pass_counter = (long)cinfo->next_scanline;
@@ -331,20 +466,18 @@ JDIMENSION jpeg12_write_scanlines(j_compress_ptr cinfo, J12SAMPARRAY scanlines, 
 /* jpeg_write_raw_data jcapistd.c:145-199: exactly one iMCU row of caller-made component planes per call
  * (data[ci] = v_samp_factor*8 row pointers of width_in_blocks*8 samples); the rows are staged and the whole
  * image goes to the GPU at jpeg_finish_compress through mjh_encode_planes_host. */
-typedef JDIMENSION (*raw_fn)(j_compress_ptr, JSAMPIMAGE, JDIMENSION);
-
 static JDIMENSION write_raw(j_compress_ptr cinfo, void ***data, JDIMENSION num_lines, int precision, const char *name)
 {
   shim_state *s = find_state(cinfo, 0);
   JDIMENSION lines_per_iMCU_row, imcu;
   int ci;
   if (!s) {
-    raw_fn next = (raw_fn)dlsym(RTLD_NEXT, name);
+    raw_fn next = (raw_fn)NEXT_SYMBOL(name);
     if (next) return next(cinfo, (JSAMPIMAGE)data, num_lines);
     ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
   }
-  if (cinfo->data_precision != precision) ERREXIT1(cinfo, JERR_BAD_PRECISION, cinfo->data_precision);
-  if (cinfo->global_state != CSTATE_RAW_OK) ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
+  if (cinfo->data_precision != precision) FAIL_WITH_STATE(cinfo, ERREXIT1(cinfo, JERR_BAD_PRECISION, cinfo->data_precision));
+  if (cinfo->global_state != CSTATE_RAW_OK) FAIL_WITH_STATE(cinfo, ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state));
   if (cinfo->next_scanline >= cinfo->image_height) { WARNMS(cinfo, JWRN_TOO_MUCH_DATA); return 0; }
   if (cinfo->progress != NULL) {
     cinfo->progress->pass_counter = (long)cinfo->next_scanline;
@@ -352,7 +485,7 @@ static JDIMENSION write_raw(j_compress_ptr cinfo, void ***data, JDIMENSION num_l
     (*cinfo->progress->progress_monitor) ((j_common_ptr)cinfo);
   }
   lines_per_iMCU_row = (JDIMENSION)cinfo->max_v_samp_factor * DCTSIZE;
-  if (num_lines < lines_per_iMCU_row) ERREXIT(cinfo, JERR_BUFFER_SIZE);
+  if (num_lines < lines_per_iMCU_row) FAIL_WITH_STATE(cinfo, ERREXIT(cinfo, JERR_BUFFER_SIZE));
   imcu = cinfo->next_scanline / lines_per_iMCU_row;
   for (ci = 0; ci < cinfo->num_components; ci++) {
     jpeg_component_info *c = &cinfo->comp_info[ci];
@@ -378,20 +511,12 @@ JDIMENSION jpeg12_write_raw_data(j_compress_ptr cinfo, J12SAMPIMAGE data, JDIMEN
   return write_raw(cinfo, (void ***)data, num_lines, 12, "jpeg12_write_raw_data");
 }
 
-static void free_state(shim_state *s)
-{
-  int ci;
-  for (ci = 0; ci < MAX_COMPONENTS; ci++) free(s->planes[ci]);
-  free(s->pixels);
-  free(s);
-}
-
 static int encode_staged(j_compress_ptr cinfo, shim_state *s)
 {
   if (s->coef_arrays) {
     const void *cf[MJH_MAX_COMPS] = { 0, 0, 0, 0 };
     size_t bpr[MJH_MAX_COMPS] = { 0, 0, 0, 0 };
-    int ci, rc;
+    int ci;
     for (ci = 0; ci < cinfo->num_components && ci < MJH_MAX_COMPS; ci++) {
       jpeg_component_info *c = &cinfo->comp_info[ci];
       JDIMENSION r;
@@ -403,8 +528,7 @@ static int encode_staged(j_compress_ptr cinfo, shim_state *s)
       }
       cf[ci] = s->planes[ci]; bpr[ci] = c->width_in_blocks;
     }
-    rc = mjh_encode_coefficients_host(t_enc, cf, bpr, NULL, 1);
-    return rc;
+    return mjh_encode_coefficients_host(s->enc, cf, bpr, NULL, 1);
   }
   if (s->raw) {
     const void *pl[MJH_MAX_COMPS] = { 0, 0, 0, 0 };
@@ -415,40 +539,96 @@ static int encode_staged(j_compress_ptr cinfo, shim_state *s)
       pw[ci] = (int)cinfo->comp_info[ci].width_in_blocks * DCTSIZE;
       ph[ci] = (int)cinfo->comp_info[ci].height_in_blocks * DCTSIZE;
     }
-    return mjh_encode_planes_host(t_enc, pl, pitch, NULL, pw, ph, 1);
+    return mjh_encode_planes_host(s->enc, pl, pitch, NULL, pw, ph, 1);
   }
-  return mjh_encode_host(t_enc, s->pixels, s->row_bytes, s->row_bytes * cinfo->image_height, 1);
+  return mjh_encode_host(s->enc, s->pixels, s->row_bytes, s->row_bytes * cinfo->image_height, 1);
 }
 
 void jpeg_finish_compress(j_compress_ptr cinfo)
 {
   shim_state *s = find_state(cinfo, 0);
   size_t n = 0;
-  unsigned char *buf;
+  const void *base = NULL;
+  const mjh_result *res = NULL;
+  unsigned char *copy = NULL;
+  const unsigned char *file;
+  int cnt = 0, pass;
   if (!s) {
-    finish_fn next = (finish_fn)dlsym(RTLD_NEXT, "jpeg_finish_compress");
+    finish_fn next = (finish_fn)NEXT_SYMBOL("jpeg_finish_compress");
     if (next) { next(cinfo); return; }
     ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);
   }
   if (cinfo->global_state == CSTATE_SCANNING || cinfo->global_state == CSTATE_RAW_OK) {
-    if (cinfo->next_scanline < cinfo->image_height) ERREXIT(cinfo, JERR_TOO_LITTLE_DATA);
+    if (cinfo->next_scanline < cinfo->image_height) FAIL_WITH_STATE(cinfo, ERREXIT(cinfo, JERR_TOO_LITTLE_DATA));
   } else if (cinfo->global_state != CSTATE_WRCOEFS)
-    ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state);   /* jcapimin.c:180-189 */
-  if (encode_staged(cinfo, s) != MJH_OK || mjh_get_jpeg_size(t_enc, 0, &n) != MJH_OK) {
+    FAIL_WITH_STATE(cinfo, ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state));   /* jcapimin.c:180-189 */
+  if (encode_staged(cinfo, s) != MJH_OK) {
     fprintf(stderr, "mozjpeg_hip: %s\n", mjh_last_error());
-    find_state(cinfo, 1); free_state(s);
-    ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0);
+    FAIL_WITH_STATE(cinfo, ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0));
   }
-  buf = (unsigned char *)malloc(n);
-  if (!buf || mjh_get_jpeg(t_enc, 0, buf, n, &n) != MJH_OK) {
+  /* the remaining passes run on the device; a progress monitor sees them go by (jcmaster.c:708-713) */
+  if (cinfo->progress != NULL) {
+    for (pass = 1; pass < s->total_passes; pass++) {
+      cinfo->progress->completed_passes = pass;
+      cinfo->progress->total_passes = s->total_passes;
+      cinfo->progress->pass_counter = 0;
+      cinfo->progress->pass_limit = (long)cinfo->total_iMCU_rows;
+      (*cinfo->progress->progress_monitor) ((j_common_ptr)cinfo);
+    }
+  }
+  if (mjh_collect(s->enc, 0, &base, &res, &cnt) == MJH_OK && cnt == 1) {   /* zero-copy: the file lies in pinned host memory */
+    file = (const unsigned char *)base + res[0].offset;
+    n = (size_t)res[0].size;
+  } else if (mjh_get_jpeg_size(s->enc, 0, &n) == MJH_OK && (copy = (unsigned char *)malloc(n)) != NULL &&
+             mjh_get_jpeg(s->enc, 0, copy, n, &n) == MJH_OK) {
+    file = copy;
+  } else {
     fprintf(stderr, "mozjpeg_hip: %s\n", mjh_last_error());
-    find_state(cinfo, 1); free(buf); free_state(s);
-    ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0);
+    free(copy);
+    FAIL_WITH_STATE(cinfo, ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0));
+    return;
   }
-  find_state(cinfo, 1);
   /* the device wrote a complete file; SOI(+APP0) went out in jpeg_start_compress already */
-  emit_bytes(cinfo, buf + s->header_bytes, n - (size_t)s->header_bytes);
-  free(buf); free_state(s);
+  {
+    const size_t skip = (size_t)(2 + (cinfo->write_JFIF_header ? 18 : 0) + (cinfo->write_Adobe_marker ? 16 : 0));
+    emit_bytes(cinfo, file + skip, n - skip);
+  }
+  free(copy);
+  mjh_shim_drop(cinfo);
   (*cinfo->dest->term_destination) (cinfo);
   jpeg_abort((j_common_ptr)cinfo);   /* releases JPOOL_IMAGE, global_state = CSTATE_START (jcapimin.c:228) */
 }
+
+#ifndef MJH_STANDALONE
+/* ---- abort / destroy hooks (preload build): drop our state, then let the library behind us do its part -------------- */
+typedef void (*common_fn)(j_common_ptr);
+typedef void (*compress_fn)(j_compress_ptr);
+
+void jpeg_abort(j_common_ptr cinfo)
+{
+  common_fn next = (common_fn)dlsym(RTLD_NEXT, "jpeg_abort");
+  mjh_shim_drop(cinfo);
+  if (next) next(cinfo);
+}
+
+void jpeg_destroy(j_common_ptr cinfo)
+{
+  common_fn next = (common_fn)dlsym(RTLD_NEXT, "jpeg_destroy");
+  mjh_shim_drop(cinfo);
+  if (next) next(cinfo);
+}
+
+void jpeg_abort_compress(j_compress_ptr cinfo)
+{
+  compress_fn next = (compress_fn)dlsym(RTLD_NEXT, "jpeg_abort_compress");
+  mjh_shim_drop(cinfo);
+  if (next) next(cinfo);
+}
+
+void jpeg_destroy_compress(j_compress_ptr cinfo)
+{
+  compress_fn next = (compress_fn)dlsym(RTLD_NEXT, "jpeg_destroy_compress");
+  mjh_shim_drop(cinfo);
+  if (next) next(cinfo);
+}
+#endif

@@ -36,7 +36,13 @@ static int fail(int code, const char *fmt, ...)
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MJH_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
 extern "C" const char *mjh_last_error(void) { return g_err; }
-extern "C" const char *mjh_version(void) { return "mozjpeg_hip 0.1 (gfx950)"; }
+extern "C" const char *mjh_version(void) { return "mozjpeg_hip 0.2 (gfx950)"; }
+extern "C" int mjh_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
 
 // zig-zag (jutils.c:59)
 static const int kZZ[64] = {
@@ -46,23 +52,9 @@ static const int kZZ[64] = {
   58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
 
 // ---- parameter helpers --------------------------------------------------------------------------
-// Base quantization tables the two profiles use: index 0 = Annex K.1 (jcparam.c:76-99,:180-190),
-// index 3 = the max-compression default (jcparam.c:111-122 == :218-229, same table for chroma).
-static const unsigned kBaseLuma0[64] = {
-  16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55,
-  14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
-  18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
-  49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99 };
-static const unsigned kBaseChroma0[64] = {
-  17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99,
-  24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
-  99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
-  99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99 };
-static const unsigned kBase3[64] = {
-  16, 16, 16, 18, 25, 37, 56, 85, 16, 17, 20, 27, 34, 40, 53, 75,
-  16, 20, 24, 31, 43, 62, 91, 135, 18, 27, 31, 40, 53, 74, 106, 156,
-  25, 34, 43, 53, 69, 94, 131, 189, 37, 40, 62, 74, 94, 124, 169, 238,
-  56, 53, 91, 106, 131, 169, 226, 311, 85, 75, 135, 156, 189, 238, 311, 418 };
+// Base quantization tables: index 0 = Annex K.1 (jcparam.c:76-99,:180-190), 3 = the max-compression default
+// (jcparam.c:111-122 == :218-229), 0..8 = what `cjpeg -quant-table N` selects (generated header, data only)
+#include "mjh_quant_presets.h"
 
 extern "C" int mjh_params_set_quality(mjh_params *p, int quality, int force_baseline, int base_idx)
 {
@@ -74,9 +66,9 @@ extern "C" int mjh_params_set_quality(mjh_params *p, int quality, int force_base
   q = q < 50.f ? 5000.f / q : 200.f - q * 2.f;
   const int scale = (int)q;
   if (base_idx < 0) base_idx = p->compress_profile == MJH_PROFILE_FASTEST ? 0 : 3;
-  if (base_idx != 0 && base_idx != 3) return fail(MJH_EUNSUPPORTED, "base quant table index %d: pass the table in quantval[] instead", base_idx);
-  const unsigned *bl = base_idx == 3 ? kBase3 : kBaseLuma0;
-  const unsigned *bc = base_idx == 3 ? kBase3 : kBaseChroma0;
+  if (base_idx > 8) return fail(MJH_EINVAL, "base quant table index %d (0..8)", base_idx);
+  const unsigned *bl = mjh_base_luma[base_idx];
+  const unsigned *bc = mjh_base_chroma[base_idx];
   for (int t = 0; t < 2; t++) {
     const unsigned *b = t ? bc : bl;
     for (int i = 0; i < 64; i++) {  // jpeg_add_quant_table jcparam.c:55-64
@@ -149,7 +141,14 @@ extern "C" int mjh_params_simple_progression(mjh_params *p)
   const int nc = p->num_components;
   const bool maxc = p->compress_profile != MJH_PROFILE_FASTEST;
   p->optimize_scans = 0;
-  if (nc == 3) {
+  if (nc == 3 && p->color_transform == MJH_COLOR_NONE) {   // all-purpose script for other colour spaces (jcparam.c:985-1003)
+    s = fill_dc_scans(s, 0, nc, 0, maxc ? 0 : 1);
+    for (int c = 0; c < nc; c++) s = fill_a_scan(s, c, 1, maxc ? 8 : 5, 0, 2);
+    for (int c = 0; c < nc; c++) s = fill_a_scan(s, c, maxc ? 9 : 6, 63, 0, 2);
+    for (int c = 0; c < nc; c++) s = fill_a_scan(s, c, 1, 63, 2, 1);
+    if (!maxc) s = fill_dc_scans(s, 0, nc, 1, 0);
+    for (int c = 0; c < nc; c++) s = fill_a_scan(s, c, 1, 63, 1, 0);
+  } else if (nc == 3) {
     if (maxc) {   // jcparam.c:940-963 (dc_scan_opt_mode 0)
       s = fill_dc_scans(s, 0, nc, 0, 0);
       s = fill_a_scan(s, 0, 1, 8, 0, 2); s = fill_a_scan(s, 1, 1, 8, 0, 0); s = fill_a_scan(s, 2, 1, 8, 0, 0);
@@ -215,6 +214,8 @@ extern "C" int mjh_params_search_progression(mjh_params *p)
 {
   if (!p) return fail(MJH_EINVAL, "null params");
   if (p->num_components != 3 && p->num_components != 1) return fail(MJH_EUNSUPPORTED, "scan search for %d components", p->num_components);
+  if (p->num_components == 3 && p->color_transform == MJH_COLOR_NONE)   // jpeg_search_progression knows YCbCr and gray only (jcparam.c:749-757)
+    return mjh_params_simple_progression(p);
   p->num_scans = build_search_script(p->scan_info, p->num_components);
   p->optimize_scans = 1;
   p->optimize_coding = 1;
@@ -326,6 +327,8 @@ static int check_supported(const mjh_params *p)
   if (p->input_components != 1 && p->input_components != 3) return fail(MJH_EUNSUPPORTED, "input_components %d (RGB or gray only)", p->input_components);
   if (p->num_components != 1 && p->num_components != 3) return fail(MJH_EUNSUPPORTED, "num_components %d", p->num_components);
   if (p->num_components == 3 && p->input_components != 3) return fail(MJH_EUNSUPPORTED, "gray input cannot produce 3 components");
+  if (p->color_transform != MJH_COLOR_YCC && p->color_transform != MJH_COLOR_NONE) return fail(MJH_EINVAL, "color_transform %d", p->color_transform);
+  if (p->color_transform == MJH_COLOR_NONE && p->num_components != 3) return fail(MJH_EUNSUPPORTED, "MJH_COLOR_NONE needs three components");
   if (p->num_components == 1 && (p->h_samp_factor[0] != 1 || p->v_samp_factor[0] != 1))
     return fail(MJH_EUNSUPPORTED, "grayscale must be sampled 1x1");
   if (p->num_components == 3) {
@@ -396,6 +399,7 @@ static void build_const(const mjh_params *p, MjhConst *C)
   C->off_r = p->rgb_offset[0]; C->off_g = p->rgb_offset[1]; C->off_b = p->rgb_offset[2];
   if (C->off_r == 0 && C->off_g == 0 && C->off_b == 0) { C->off_g = 1; C->off_b = 2; }
   C->precision = p->data_precision == 12 ? 12 : 8;
+  C->no_ycc = p->color_transform == MJH_COLOR_NONE;
   C->maxh = C->maxv = 1;
   for (int i = 0; i < C->ncomp; i++) {
     if (p->h_samp_factor[i] > C->maxh) C->maxh = p->h_samp_factor[i];
@@ -465,7 +469,11 @@ static void build_prefix(const mjh_params *p, std::vector<uint8_t> &o, bool *bas
     const uint8_t jf[] = { 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0 };
     o.insert(o.end(), jf, jf + sizeof(jf));
   }
-  *file_hdr_len = (int)o.size();   // SOI + APP0: what jpeg_start_compress writes
+  if (p->color_transform == MJH_COLOR_NONE && p->num_components == 3) {   // emit_adobe_app14 :452-486: version 100, flags 0, transform 0 (RGB)
+    const uint8_t ad[] = { 0xFF, 0xEE, 0, 14, 'A', 'd', 'o', 'b', 'e', 0, 100, 0, 0, 0, 0, 0 };
+    o.insert(o.end(), ad, ad + sizeof(ad));
+  }
+  *file_hdr_len = (int)o.size();   // SOI + APP0 / APP14: what jpeg_start_compress writes
   int prec[MJH_MAX_COMPS], prec_any = 0;
   for (int ci = 0; ci < p->num_components; ci++) {
     prec[ci] = 0;
@@ -558,6 +566,16 @@ static const uint8_t kStdAcCVal[162] = {
   0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda,
   0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8,
   0xf9, 0xfa };
+
+// the Annex K.3 tables for the libjpeg drop-in's jpeg_set_defaults (std_huff_tables jstdhuff.c:31-131)
+extern "C" int mjh_std_huffman_table(int is_ac, int tblno, const uint8_t **bits, const uint8_t **vals, int *nvals)
+{
+  if (!bits || !vals || !nvals || tblno < 0 || tblno > 1) return fail(MJH_EINVAL, "bad arguments");
+  *bits = is_ac ? (tblno ? kStdAcCBits : kStdAcLBits) : (tblno ? kStdDcCBits : kStdDcLBits);
+  *vals = is_ac ? (tblno ? kStdAcCVal : kStdAcLVal) : kStdDcVal;
+  *nvals = is_ac ? 162 : 12;
+  return MJH_OK;
+}
 
 static void fill_std_table(MjhHuffTable *T, const uint8_t *bits, const uint8_t *vals, int nvals)
 {   // jpeg_make_c_derived_tbl jchuff.c:231-318 on the host (tables are constants here)

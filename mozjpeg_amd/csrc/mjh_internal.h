@@ -50,6 +50,7 @@ struct MjhConst {
   int blocks_per_mcu;
   int total_mcu_blocks;   // mcus * blocks_per_mcu (dummy blocks included)
   int total_real_blocks;  // sum of nblk
+  int no_ycc;             // MJH_COLOR_NONE: input samples become the components unconverted (null_convert jccolor.c:479)
   int smoothing;          // smoothing_factor (0 = off): k_color_smooth replaces k_color
   int deringing;
   int trellis;            // trellis_quant: the FDCT kernel also emits the per-block lambda

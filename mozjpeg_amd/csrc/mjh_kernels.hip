@@ -77,10 +77,13 @@ k_color(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, size_t im
       if (ic == 3) {
         const T *px = row + (size_t)ix * C.px_size;
         int r = px[C.off_r], g = px[C.off_g], b = px[C.off_b];
-        if (sizeof(T) == 2) { r &= 0xFFF; g &= 0xFFF; b &= 0xFFF; }   // RANGE_LIMIT of the 12-bit build
-        yv[vy][vx] = (FIXC(0.29900) * r + FIXC(0.58700) * g + FIXC(0.11400) * b + 32768) >> 16;
-        cbs += (-FIXC(0.16874) * r - FIXC(0.33126) * g + FIXC(0.50000) * b + (center << 16) + 32767) >> 16;
-        crs += (FIXC(0.50000) * r - FIXC(0.41869) * g - FIXC(0.08131) * b + (center << 16) + 32767) >> 16;
+        if (C.no_ycc) { yv[vy][vx] = r; cbs += g; crs += b; }        // null_convert jccolor.c:479 (cjpeg -rgb)
+        else {
+          if (sizeof(T) == 2) { r &= 0xFFF; g &= 0xFFF; b &= 0xFFF; }   // RANGE_LIMIT of the 12-bit build
+          yv[vy][vx] = (FIXC(0.29900) * r + FIXC(0.58700) * g + FIXC(0.11400) * b + 32768) >> 16;
+          cbs += (-FIXC(0.16874) * r - FIXC(0.33126) * g + FIXC(0.50000) * b + (center << 16) + 32767) >> 16;
+          crs += (FIXC(0.50000) * r - FIXC(0.41869) * g - FIXC(0.08131) * b + (center << 16) + 32767) >> 16;
+        }
       } else {
         yv[vy][vx] = row[ix];
       }
@@ -133,6 +136,7 @@ __device__ __forceinline__ int smooth_px(const MjhConst &C, const uint8_t *p, si
   const int center = sizeof(T) == 2 ? 2048 : 128;
   const T *px = row + (size_t)ix * C.px_size;
   int r = px[C.off_r], g = px[C.off_g], b = px[C.off_b];
+  if (C.no_ycc) return comp == 0 ? r : comp == 1 ? g : b;
   if (sizeof(T) == 2) { r &= 0xFFF; g &= 0xFFF; b &= 0xFFF; }
   if (comp == 0) return (FIXC(0.29900) * r + FIXC(0.58700) * g + FIXC(0.11400) * b + 32768) >> 16;
   if (comp == 1) return (-FIXC(0.16874) * r - FIXC(0.33126) * g + FIXC(0.50000) * b + (center << 16) + 32767) >> 16;
@@ -1974,7 +1978,7 @@ void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size
     else hipLaunchKernelGGL((k_color_smooth<uint8_t>), grid, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint8_t *)planes);
     return;
   }
-  if (C.precision == 8 && C.in_comps == 3 && C.ncomp == 3 && C.px_size == 3 && H0 == 2 && V0 <= 2 && (row_pitch & 7) == 0 &&
+  if (!C.no_ycc && C.precision == 8 && C.in_comps == 3 && C.ncomp == 3 && C.px_size == 3 && H0 == 2 && V0 <= 2 && (row_pitch & 7) == 0 &&
       (img_stride & 7) == 0 && ((uintptr_t)pix & 7) == 0 && C.off_g == 1 && (C.off_r == 0 || C.off_r == 2)) {
     dim3 gridv(((C.groups_x + 3) / 4 + 255) / 256, C.groups_y, n);
     if (V0 == 2) hipLaunchKernelGGL((k_color_vec<2>), gridv, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint8_t *)planes);

@@ -118,6 +118,19 @@ void mjo_default_params(mjo_params *p, int width, int height, int input_componen
   p->optimize_scans = 0;
 }
 
+void mjo_set_rgb_output(mjo_params *p)
+{ /* jpeg_set_colorspace jcparam.c:611-619 */
+  int i;
+  p->rgb_output = 1;
+  p->write_jfif = 0;
+  p->num_components = 3;
+  for (i = 0; i < 3; i++) {
+    p->component_id[i] = "RGB"[i];
+    p->h_samp[i] = p->v_samp[i] = 1;
+    p->quant_tbl_no[i] = p->dc_tbl_no[i] = p->ac_tbl_no[i] = 0;
+  }
+}
+
 static mjo_scan *fill_a_scan(mjo_scan *s, int ci, int Ss, int Se, int Ah, int Al)
 {
   s->comps_in_scan = 1; s->component_index[0] = ci;
@@ -139,7 +152,15 @@ void mjo_simple_progression(mjo_params *p)
   mjo_scan *s = p->scans;
   int ci, nc = p->num_components;
   p->optimize_scans = 0;
-  if (nc == 3) {
+  if (nc == 3 && p->rgb_output) {   /* all-purpose script for other colour spaces, jcparam.c:985-1003 */
+    const int mx = !p->fastest_profile;
+    s = fill_dc_scans(s, nc, 0, mx ? 0 : 1);
+    for (ci = 0; ci < nc; ci++) s = fill_a_scan(s, ci, 1, mx ? 8 : 5, 0, 2);
+    for (ci = 0; ci < nc; ci++) s = fill_a_scan(s, ci, mx ? 9 : 6, 63, 0, 2);
+    for (ci = 0; ci < nc; ci++) s = fill_a_scan(s, ci, 1, 63, 2, 1);
+    if (!mx) s = fill_dc_scans(s, nc, 1, 0);
+    for (ci = 0; ci < nc; ci++) s = fill_a_scan(s, ci, 1, 63, 1, 0);
+  } else if (nc == 3) {
     if (!p->fastest_profile) {
       s = fill_dc_scans(s, nc, 0, 0);
       s = fill_a_scan(s, 0, 1, 8, 0, 2);
@@ -187,6 +208,7 @@ void mjo_search_progression(mjo_params *p)
   static const int fs[5] = { 2, 8, 5, 12, 18 };
   mjo_scan *s = p->scans;
   int Al, i, nc = p->num_components;
+  if (nc == 3 && p->rgb_output) { mjo_simple_progression(p); return; }   /* the search knows YCbCr and gray only (jcparam.c:749-757) */
   p->optimize_scans = 1;
   s = fill_dc_scans(s, nc, 0, 0);
   s = fill_a_scan(s, 0, 1, 8, 0, 0);
@@ -275,6 +297,10 @@ static void convert_pixel(const mjo_params *p, const uint8_t *px, int out[3])
     v[i] = P == 12 ? (((const uint16_t *)px)[i] & 0xFFF) : px[i];
   if (p->input_components == 1) {
     out[0] = P == 12 ? ((const uint16_t *)px)[0] : v[0];   /* grayscale_convert / null path: no masking */
+    return;
+  }
+  if (p->rgb_output) {   /* null_convert jccolor.c:479: samples copied as they are */
+    for (i = 0; i < 3; i++) out[i] = P == 12 ? ((const uint16_t *)px)[i] : px[i];
     return;
   }
   {
@@ -1240,6 +1266,11 @@ static void emit_file_header(const enc_t *e, bytebuf *o)
     bb_put(o, 0);
     bb_put2(o, 1); bb_put2(o, 1);
     bb_put(o, 0); bb_put(o, 0);
+  }
+  if (e->p->rgb_output) {   /* emit_adobe_app14 :452-486: "Adobe", version 100, flags0 0, flags1 0, transform 0 */
+    static const unsigned char ad[16] = { 0xFF, 0xEE, 0, 14, 'A', 'd', 'o', 'b', 'e', 0, 100, 0, 0, 0, 0, 0 };
+    int i;
+    for (i = 0; i < 16; i++) bb_put(o, ad[i]);
   }
 }
 

@@ -63,7 +63,11 @@ typedef struct {
   int trellis_eob_opt;            /* JBOOLEAN_TRELLIS_EOB_OPT: EOB runs over all-zero blocks optimised along a block row, jcdctmgr.c:1224-1297 */
   int use_scans_in_trellis;       /* JBOOLEAN_USE_SCANS_IN_TRELLIS: two trellis passes per component, bands 1..split / split+1..63, jcmaster.c:453-460 */
   int trellis_freq_split;         /* JINT_TRELLIS_FREQ_SPLIT (0 is read as the default 8, jcparam.c:512) */
+  int rgb_output;                 /* jpeg_color_space JCS_RGB (cjpeg -rgb): null_convert jccolor.c:479, Adobe APP14 instead of JFIF APP0,
+                                   * all-purpose progressive script; set it through mjo_set_rgb_output */
 } mjo_params;
+/* jpeg_set_colorspace(cinfo, JCS_RGB) (jcparam.c:611-619): three 1x1 components 'R' 'G' 'B', tables 0, no JFIF marker */
+void mjo_set_rgb_output(mjo_params *p);
 
 /* jpeg_set_defaults + jpeg_set_quality + colorspace defaults, as cjpeg would leave them:
  * profile_fastest=0 is the max-compression profile (jcparam.c:386-519).

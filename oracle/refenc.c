@@ -60,7 +60,7 @@ static unsigned char *read_ppm(const char *fn, int *w, int *h, int *nc)
 int main(int argc, char **argv)
 {
   int quality = 75, baseline = 0, revert = 0, optimize = 0, progressive = 0, fastcrush = 0;
-  int notrellis = 0, notrellis_dc = 0, noovershoot = 0, gray = 0, grayin = 0, qtbl = -1;
+  int notrellis = 0, notrellis_dc = 0, noovershoot = 0, gray = 0, rgbout = 0, grayin = 0, qtbl = -1;
   int hs = 2, vs = 2, restart = 0, restart_blocks = 0, reps = 1, rawW = 0, rawH = 0;
   double l1 = -1e9, l2 = -1e9;
   int precision = 8, yuvin = 0, trellis_loops = 0, smooth = 0, trellis_q_opt = 0, eob_opt = 0, scans_in_trellis = 0, freq_split = 0;
@@ -83,6 +83,7 @@ int main(int argc, char **argv)
     else if (!strcmp(a, "-notrellis-dc")) notrellis_dc = 1;
     else if (!strcmp(a, "-noovershoot")) noovershoot = 1;
     else if (!strcmp(a, "-gray")) gray = 1;
+    else if (!strcmp(a, "-rgb")) rgbout = 1;   /* cjpeg -rgb: jpeg_set_colorspace(JCS_RGB), samples unconverted */
     else if (!strcmp(a, "-grayin")) grayin = 1;
     else if (!strcmp(a, "-quant-table")) qtbl = atoi(argv[++i]);
     else if (!strcmp(a, "-lambda1")) l1 = atof(argv[++i]);
@@ -149,6 +150,7 @@ int main(int argc, char **argv)
     if (l1 > -1e8) jpeg_c_set_float_param(&cinfo, JFLOAT_LAMBDA_LOG_SCALE1, (float)l1);
     if (l2 > -1e8) jpeg_c_set_float_param(&cinfo, JFLOAT_LAMBDA_LOG_SCALE2, (float)l2);
     if (gray) jpeg_set_colorspace(&cinfo, JCS_GRAYSCALE);
+    if (rgbout) jpeg_set_colorspace(&cinfo, JCS_RGB);
     jpeg_set_quality(&cinfo, quality, baseline ? TRUE : FALSE);
     if (baseline) { cinfo.num_scans = 0; cinfo.scan_info = NULL; }
     if (optimize) cinfo.optimize_coding = TRUE;
@@ -165,7 +167,7 @@ int main(int argc, char **argv)
     if (notrellis) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_TRELLIS_QUANT, FALSE);
     if (notrellis_dc) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_TRELLIS_QUANT_DC, FALSE);
     if (noovershoot) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_OVERSHOOT_DERINGING, FALSE);
-    if (cinfo.num_components == 3) {
+    if (cinfo.num_components == 3 && !rgbout) {
       cinfo.comp_info[0].h_samp_factor = hs;
       cinfo.comp_info[0].v_samp_factor = vs;
       cinfo.comp_info[1].h_samp_factor = cinfo.comp_info[1].v_samp_factor = 1;

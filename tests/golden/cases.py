@@ -72,6 +72,10 @@ CASES = [
     ("base_4x2_restart1", dict(baseline=True, sample=(4, 2), restart=1), True),
     ("default_progressive_2x4", dict(sample=(2, 4)), True),
     ("base_411_smooth20", dict(baseline=True, sample=(4, 1), smooth=20), True),
+    # JCS_RGB output (cjpeg -rgb): null_convert jccolor.c:479, Adobe APP14, component ids 'R' 'G' 'B', all-purpose progressive script
+    ("rgb_revert", dict(revert=True, rgb=True), True),                      # + -icc test1.icc = the reference's MD5_JPEG_RGB_ISLOW (drop-in test)
+    ("rgb_base", dict(baseline=True, rgb=True), True),
+    ("rgb_default_progressive", dict(rgb=True), True),
     # trellis_q_opt (JBOOLEAN_TRELLIS_Q_OPT, jcmaster.c:1014-1030): ORACLE ONLY so far -- pinned here so that the HIP path
     # can be checked the day it is built (its sums are exact integers, so a parallel reduction can be bit-exact)
     ("base_trellis_q_opt", dict(baseline=True, trellis_q_opt=True), False),

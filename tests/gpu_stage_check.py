@@ -58,7 +58,8 @@ def check_case(img, kw, verbose=True):
     bits = enc.read_tap(M.TAP_HUFF_BITS, 0)
     vals = enc.read_tap(M.TAP_HUFF_VALS, 0)
     if pg.optimize_coding and pg.num_scans == 0:
-        for t in range(2 if pg.num_components == 3 else 1):
+        used = sorted({pg.dc_tbl_no[i] for i in range(pg.num_components)})   # tables a component refers to (RGB output: only 0)
+        for t in used:
             for nm, gb, gv, ob, ov in (("dc", bits[2 * t], vals[2 * t], taps["dc_bits"][t], taps["dc_vals"][t]),
                                        ("ac", bits[2 * t + 1], vals[2 * t + 1], taps["ac_bits"][t], taps["ac_vals"][t])):
                 n = int(ob[1:].sum())

@@ -1,0 +1,148 @@
+/* shim_harness.c -- libjpeg client scenarios the drop-in has to survive, written against the public API
+ * only.  The same binary runs against the reference's libjpeg.so.62 (expected output), with the preload shim in front of
+ * it, and against the stand-alone library; tests/test_gpu_dropin.py compares the printed hashes.
+ *   scenario names on the command line; image = deterministic synthetic RGB.                                        */
+#include <setjmp.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "jpeglib.h"
+#include "jerror.h"
+
+static jmp_buf env;
+static void my_exit(j_common_ptr cinfo) { (void)cinfo; longjmp(env, 1); }
+
+static unsigned char *make_image(int w, int h, int seed)
+{
+  unsigned char *p = (unsigned char *)malloc((size_t)w * h * 3);
+  unsigned s = 12345u + (unsigned)seed * 7919u;
+  int x, y, c;
+  for (y = 0; y < h; y++)
+    for (x = 0; x < w; x++)
+      for (c = 0; c < 3; c++) {
+        s = s * 1664525u + 1013904223u;
+        p[((size_t)y * w + x) * 3 + c] = (unsigned char)(((x * (3 + c) + y * (5 - c)) & 0xFF) / 2 + ((s >> 24) & 0x3F) + (((x / 16 + y / 16) % 5) == 0 ? 64 : 0));
+      }
+  return p;
+}
+
+static unsigned long hash(const unsigned char *b, unsigned long n) { unsigned long h = 1469598103934665603ul, i; for (i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ul; return h; }
+
+static void setup(struct jpeg_compress_struct *c, int w, int h, int quality, int baseline)
+{
+  c->image_width = w; c->image_height = h; c->input_components = 3; c->in_color_space = JCS_RGB;
+  jpeg_set_defaults(c);
+  c->dct_method = JDCT_ISLOW;
+  jpeg_set_quality(c, quality, TRUE);
+  if (baseline) { c->num_scans = 0; c->scan_info = NULL; }
+}
+
+static void rows(struct jpeg_compress_struct *c, unsigned char *img, int upto)
+{
+  while ((int)c->next_scanline < upto) {
+    JSAMPROW r = img + (size_t)c->next_scanline * c->image_width * 3;
+    jpeg_write_scanlines(c, &r, 1);
+  }
+}
+
+static long rss_kb(void)
+{
+  long pages = 0, dummy = 0;
+  FILE *f = fopen("/proc/self/statm", "r");
+  if (f) { if (fscanf(f, "%ld %ld", &dummy, &pages) != 2) pages = 0; fclose(f); }
+  return pages * 4;
+}
+
+int main(int argc, char **argv)
+{
+  struct jpeg_error_mgr err;
+  int a;
+  for (a = 1; a < argc; a++) {
+    const char *sc = argv[a];
+    if (!strcmp(sc, "interleaved")) {
+      /* two compress objects of different geometry, started and fed alternately on one thread (thumbnail + main image) */
+      struct jpeg_compress_struct c1, c2;
+      unsigned char *o1 = NULL, *o2 = NULL, *i1 = make_image(160, 120, 1), *i2 = make_image(333, 211, 2);
+      unsigned long n1 = 0, n2 = 0;
+      c1.err = c2.err = jpeg_std_error(&err);
+      jpeg_create_compress(&c1); jpeg_create_compress(&c2);
+      jpeg_mem_dest(&c1, &o1, &n1); jpeg_mem_dest(&c2, &o2, &n2);
+      setup(&c1, 160, 120, 80, 1); setup(&c2, 333, 211, 60, 1);
+      jpeg_start_compress(&c1, TRUE); jpeg_start_compress(&c2, TRUE);
+      rows(&c1, i1, 60); rows(&c2, i2, 100); rows(&c1, i1, 120); rows(&c2, i2, 211);
+      jpeg_finish_compress(&c1); jpeg_finish_compress(&c2);
+      printf("interleaved %lu %016lx %lu %016lx\n", n1, hash(o1, n1), n2, hash(o2, n2));
+      jpeg_destroy_compress(&c1); jpeg_destroy_compress(&c2);
+      free(o1); free(o2); free(i1); free(i2);
+    } else if (!strcmp(sc, "abort_reuse")) {
+      /* the application's error_exit longjmps out of jpeg_finish_compress (too little data), the object is aborted and
+       * then used again; afterwards many start/abort and create/destroy cycles must not accumulate anything */
+      struct jpeg_compress_struct c;
+      unsigned char *o = NULL, *img = make_image(200, 150, 3);
+      unsigned long n = 0;
+      long r0, r1;
+      int k;
+      c.err = jpeg_std_error(&err);
+      err.error_exit = my_exit;
+      jpeg_create_compress(&c);
+      jpeg_mem_dest(&c, &o, &n);
+      setup(&c, 200, 150, 75, 1);
+      if (!setjmp(env)) { jpeg_start_compress(&c, TRUE); rows(&c, img, 70); jpeg_finish_compress(&c); printf("abort_reuse: finish did not fail\n"); }
+      else { printf("abort_reuse: error %d caught\n", err.msg_code == JERR_TOO_LITTLE_DATA); jpeg_abort_compress(&c); }
+      jpeg_mem_dest(&c, &o, &n);
+      jpeg_start_compress(&c, TRUE); rows(&c, img, 150); jpeg_finish_compress(&c);
+      printf("abort_reuse %lu %016lx\n", n, hash(o, n));
+      for (k = 0; k < 30; k++) { jpeg_start_compress(&c, TRUE); rows(&c, img, 10); jpeg_abort_compress(&c); }
+      r0 = rss_kb();
+      for (k = 0; k < 300; k++) { jpeg_start_compress(&c, TRUE); rows(&c, img, 10); jpeg_abort_compress(&c); }
+      for (k = 0; k < 100; k++) {
+        struct jpeg_compress_struct d;
+        unsigned char *od = NULL; unsigned long nd = 0;
+        d.err = c.err; jpeg_create_compress(&d); jpeg_mem_dest(&d, &od, &nd); setup(&d, 200, 150, 75, 1);
+        jpeg_start_compress(&d, TRUE); rows(&d, img, 5); jpeg_destroy_compress(&d); free(od);
+      }
+      r1 = rss_kb();
+      printf("abort_reuse growth_ok %d\n", r1 - r0 < 20000);
+      jpeg_start_compress(&c, TRUE); rows(&c, img, 150); jpeg_finish_compress(&c);
+      printf("abort_reuse again %lu %016lx\n", n, hash(o, n));
+      jpeg_destroy_compress(&c); free(o); free(img);
+    } else if (!strcmp(sc, "markers")) {
+      /* COM + APPn + ICC markers written by the application between start and the first scanline */
+      struct jpeg_compress_struct c;
+      unsigned char *o = NULL, *img = make_image(97, 61, 4), icc[70000];
+      unsigned long n = 0;
+      unsigned k;
+      for (k = 0; k < sizeof(icc); k++) icc[k] = (unsigned char)(k * 31 + (k >> 8));
+      c.err = jpeg_std_error(&err);
+      jpeg_create_compress(&c);
+      jpeg_mem_dest(&c, &o, &n);
+      setup(&c, 97, 61, 85, 0);           /* default mode: progressive with scan search */
+      c.density_unit = 1; c.X_density = 300; c.Y_density = 150; c.JFIF_minor_version = 2;
+      jpeg_start_compress(&c, TRUE);
+      jpeg_write_marker(&c, JPEG_COM, (const JOCTET *)"made by the harness", 19);
+      jpeg_write_m_header(&c, JPEG_APP0 + 5, 3); jpeg_write_m_byte(&c, 1); jpeg_write_m_byte(&c, 2); jpeg_write_m_byte(&c, 3);
+      jpeg_write_icc_profile(&c, icc, sizeof(icc));
+      rows(&c, img, 61);
+      jpeg_finish_compress(&c);
+      printf("markers %lu %016lx\n", n, hash(o, n));
+      jpeg_destroy_compress(&c); free(o); free(img);
+    } else if (!strcmp(sc, "stdio")) {
+      struct jpeg_compress_struct c;
+      unsigned char *img = make_image(640, 400, 5), *buf;
+      FILE *f = tmpfile();
+      long n;
+      c.err = jpeg_std_error(&err);
+      jpeg_create_compress(&c);
+      jpeg_stdio_dest(&c, f);
+      setup(&c, 640, 400, 90, 1);
+      jpeg_start_compress(&c, TRUE); rows(&c, img, 400); jpeg_finish_compress(&c);
+      jpeg_destroy_compress(&c);
+      n = ftell(f); rewind(f);
+      buf = (unsigned char *)malloc((size_t)n);
+      if (fread(buf, 1, (size_t)n, f) != (size_t)n) n = 0;
+      printf("stdio %ld %016lx\n", n, hash(buf, (unsigned long)n));
+      free(buf); fclose(f); free(img);
+    }
+  }
+  return 0;
+}

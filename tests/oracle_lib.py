@@ -33,7 +33,8 @@ class Params(C.Structure):
                 ("num_scans", C.c_int), ("scans", Scan * MAXS), ("optimize_scans", C.c_int),
                 ("write_jfif", C.c_int), ("data_precision", C.c_int), ("trellis_num_loops", C.c_int),
                 ("smoothing_factor", C.c_int), ("trellis_q_opt", C.c_int),
-                ("trellis_eob_opt", C.c_int), ("use_scans_in_trellis", C.c_int), ("trellis_freq_split", C.c_int)]
+                ("trellis_eob_opt", C.c_int), ("use_scans_in_trellis", C.c_int), ("trellis_freq_split", C.c_int),
+                ("rgb_output", C.c_int)]
 
 
 class Geom(C.Structure):
@@ -72,7 +73,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 progressive=False, fastcrush=False, notrellis=False, notrellis_dc=False,
                 noovershoot=False, sample=(2, 2), restart=None, gray=False, grayin=False,
                 quant_table=-1, lambda1=None, lambda2=None, precision=8, trellis_loops=1, smooth=0, trellis_q_opt=False,
-                trellis_eob_opt=False, use_scans_in_trellis=False, trellis_freq_split=0):
+                trellis_eob_opt=False, use_scans_in_trellis=False, trellis_freq_split=0, rgb=False):
     """Same switch vocabulary as cjpeg / oracle/refenc.c.  Default (no switch) is cjpeg's default:
     max-compression profile, progressive with scan search."""
     p = Params()
@@ -98,6 +99,8 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     p.trellis_eob_opt = 1 if trellis_eob_opt else 0
     p.use_scans_in_trellis = 1 if use_scans_in_trellis else 0
     p.trellis_freq_split = trellis_freq_split
+    if rgb:
+        L.mjo_set_rgb_output(C.byref(p))
     if restart is not None:
         if isinstance(restart, str) and restart.lower().endswith("b"):
             p.restart_interval = int(restart[:-1])
@@ -277,7 +280,7 @@ def ref_switches(**kw):
     """Translate make_params keywords into refenc/cjpeg switches."""
     sw = ["-quality", str(kw.get("quality", 75))]
     for k in ("baseline", "revert", "optimize", "progressive", "fastcrush", "notrellis",
-              "noovershoot", "gray", "grayin"):
+              "noovershoot", "gray", "grayin", "rgb"):
         if kw.get(k):
             sw.append("-" + k)
     if kw.get("notrellis_dc"):

@@ -97,6 +97,89 @@ def test_explicit_passthrough_is_logged(goldens, tmp_path):
     assert open(out, "rb").read()[:2] == b"\xff\xd8"
 
 
+# ---- the stand-alone library: mozjpeg_amd/standalone/libjpeg.so.62 replaces the reference's libjpeg
+# for the compress API; the unchanged cjpeg binary finds it through LD_LIBRARY_PATH and nothing of the reference's
+# library is in the process -------------------------------------------------------------------------------------------
+STANDALONE_DIR = os.path.join(ROOT, "mozjpeg_amd", "standalone")
+needs_sa = pytest.mark.skipif(not (os.path.exists(os.path.join(STANDALONE_DIR, "libjpeg.so.62")) and os.path.exists(CJPEG)),
+                              reason="stand-alone library or reference cjpeg not built")
+
+
+def run_cjpeg_standalone(args, out, inp=PPM):
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    env["LD_LIBRARY_PATH"] = STANDALONE_DIR
+    # prove which library the binary gets: the loader's own trace names every object it maps
+    env["LD_DEBUG"] = "libs"
+    r = subprocess.run([CJPEG, "-dct", "int"] + args + ["-outfile", out, inp], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    loaded = [ln for ln in r.stderr.decode(errors="replace").splitlines() if "calling init:" in ln]
+    assert any(STANDALONE_DIR in ln for ln in loaded), loaded
+    assert not any(O.REF_DIR in ln and "libjpeg" in ln for ln in loaded), "the reference's libjpeg was loaded"
+    return r
+
+
+@needs_sa
+@pytest.mark.parametrize("cname,args", CJPEG_CASES)
+def test_unchanged_cjpeg_against_the_standalone_library(cname, args, goldens, tmp_path):
+    out = str(tmp_path / "o.jpg")
+    r = run_cjpeg_standalone(args, out)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    data = open(out, "rb").read()
+    g = goldens["testorig/%s" % cname]
+    assert (len(data), hashlib.md5(data).hexdigest()) == (g["bytes"], g["md5"])
+
+
+ICC = os.path.join(ROOT, "tests", "golden", "test1.icc")
+
+
+@needs
+@pytest.mark.parametrize("standalone", [False, True])
+def test_rgb_output_with_icc_profile_reproduces_the_references_pinned_md5(standalone, tmp_path):
+    """cjpeg -revert -rgb -dct int -icc test1.icc testorig.ppm = the reference's own bit test `rgb-islow`
+    (CMakeLists.txt:1347,1427: MD5_JPEG_RGB_ISLOW): JCS_RGB output (null_convert), Adobe APP14, ICC APP2 segments written by
+    the application between jpeg_start_compress and the first scanline"""
+    out = str(tmp_path / "o.jpg")
+    args = ["-revert", "-rgb", "-icc", ICC]
+    r = run_cjpeg_standalone(args, out) if standalone else run_cjpeg(args, out)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == "1d44a406f61da743b5fd31c0a9abdca3"
+
+
+HARNESS = os.path.join(ROOT, "tests", "native", "shim_harness")
+needs_h = pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(SHIM)), reason="tests/native/shim_harness not built")
+
+
+@needs_h
+@pytest.mark.parametrize("mode", ["preload", "standalone"])
+@pytest.mark.parametrize("scenario", ["interleaved", "abort_reuse", "markers", "stdio"])
+def test_libjpeg_client_scenarios(scenario, mode):
+    """two interleaved compress objects on one thread; error_exit longjmp -> jpeg_abort_compress -> reuse, and hundreds
+    of start/abort and create/destroy cycles without growth; COM / APPn / ICC markers and JFIF density fields; the stdio
+    destination.  Expected output = the same binary on the reference's libjpeg."""
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    env["LD_LIBRARY_PATH"] = O.REF_DIR
+    want = subprocess.run([HARNESS, scenario], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert want.returncode == 0, want.stderr.decode()
+    if mode == "preload":
+        env["LD_PRELOAD"] = SHIM
+    else:
+        env["LD_LIBRARY_PATH"] = STANDALONE_DIR
+    got = subprocess.run([HARNESS, scenario], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert got.returncode == 0, got.stderr.decode()[-2000:]
+    assert got.stdout == want.stdout, (got.stdout, want.stdout, got.stderr[-500:])
+
+
+@needs
+def test_device_selection_by_environment(goldens, tmp_path):
+    """MOZJPEG_HIP_DEVICE pins the drop-in to a GPU (taken modulo the device count, so any value works on a 1-GPU box)"""
+    out = str(tmp_path / "o.jpg")
+    r = run_cjpeg(["-quality", "75", "-baseline", "-sample", "2x2"], out, {"MOZJPEG_HIP_DEVICE": "5"})
+    assert r.returncode == 0, r.stderr.decode()
+    g = goldens["testorig/base"]
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == g["md5"]
+
+
 # ---- TurboJPEG boundary: the reference's own tjCompress2 (turbojpeg.c:1169, unchanged, built into
 # oracle/_ref/libturbojpeg.so.0) with the libjpeg drop-in in front of it --------------------------
 TJH = os.path.join(O.REF_DIR, "tjharness")
