@@ -272,7 +272,7 @@ def main():
 
     def step(keep=None):
         for s0, cnt in calls:
-            enc.encode_tensor(d_frames[s0:s0 + cnt])
+            enc.encode_tensor(d_frames[s0:s0 + cnt], stream="own")
             if keep is not None:
                 keep.extend(enc.get_jpeg(i) for i in range(cnt))
 

@@ -228,9 +228,21 @@ class Encoder:
         _chk(lib().mjh_encode_device(self._h, ptr, row_pitch, image_stride, n, stream))
 
     def encode_tensor(self, t, stream=None):
-        """t: torch uint8 CUDA tensor [n, H, W, C], contiguous.  Asynchronous."""
-        assert t.is_cuda and t.is_contiguous() and t.dim() == 4
-        es = t.element_size()   # 1 for uint8, 2 for the 12-bit path (int16/uint16 storage)
+        """t: torch CUDA tensor [n, H, W, C] (uint8; int16/uint16 storage for 12-bit), rows contiguous.  Asynchronous.
+        stream: None = the torch stream current on t's device (ordered after whatever produced t); "own" = the encoder's
+        private stream (the caller guarantees t is complete, e.g. after a synchronize); or a raw hipStream_t value."""
+        import torch
+        p = self.params
+        px = p.input_pixel_size or p.input_components
+        es = 2 if p.data_precision == 12 else 1
+        assert t.is_cuda and t.dim() == 4 and t.element_size() == es and t.stride(3) == 1 and t.stride(2) == t.shape[3], "layout"
+        assert tuple(t.shape[1:]) == (p.image_height, p.image_width, px), "tensor %s does not match the encoder (%d x %d x %d)" % (
+            tuple(t.shape), p.image_height, p.image_width, px)
+        assert 1 <= t.shape[0] <= self.max_batch
+        if stream is None:
+            stream = torch.cuda.current_stream(t.device).cuda_stream or None
+        elif stream == "own":
+            stream = None
         self.encode_device_ptr(t.data_ptr(), t.stride(1) * es, t.stride(0) * es, t.shape[0], stream)
 
     # component planes in (jpeg_write_raw_data / tj3CompressFromYUVPlanes8): no colour conversion

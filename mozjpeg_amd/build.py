@@ -12,6 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmozjpeg_hip.so")
 SHIM = os.path.join(HERE, "libmozjpeg_hip_jpeg62.so")
 STANDALONE = os.path.join(HERE, "standalone", "libjpeg.so.62")
+TJSHIM = os.path.join(HERE, "libmozjpeg_hip_turbojpeg.so")
 SOURCES = ["mjh_kernels.hip", "mjh_prog.hip", "mjh_encoder.cpp"]
 # -ffp-contract=off: the trellis / deringing float recipes must not be fused into FMAs
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-fast-math",
@@ -74,6 +75,14 @@ def build_shim(force=False, verbose=False):
         cmd = ["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-DMJH_STANDALONE"] + inc + ["-o", STANDALONE, src, api, "-L" + HERE,
                                                                                          "-l:libmozjpeg_hip.so", "-Wl,-soname,libjpeg.so.62",
                                                                                          "-Wl,-rpath,$ORIGIN/..", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    tj = os.path.join(CSRC, "tj_shim.c")
+    if force or _newer(TJSHIM, [tj, LIB]):
+        # TurboJPEG-signature entry points (tjCompress2 / tj3Compress8 / ...FromYUV...) straight on the batch encoder
+        cmd = ["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-I" + ref, "-I" + os.path.join(HERE, "..", "include"), "-o", TJSHIM, tj,
+               "-L" + HERE, "-l:libmozjpeg_hip.so", "-Wl,-rpath,$ORIGIN", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -544,6 +544,17 @@ static int encode_staged(j_compress_ptr cinfo, shim_state *s)
   return mjh_encode_host(s->enc, s->pixels, s->row_bytes, s->row_bytes * cinfo->image_height, 1);
 }
 
+/* an encoder error ends the compression: message on stderr, state dropped, the libjpeg error code that fits */
+static void encoder_failed(j_compress_ptr cinfo)
+{
+  const char *msg = mjh_last_error();
+  const int bad_coef = strstr(msg, "JERR_BAD_DCT_COEF") != NULL;
+  fprintf(stderr, "mozjpeg_hip: %s\n", msg);
+  mjh_shim_drop(cinfo);
+  if (bad_coef) ERREXIT(cinfo, JERR_BAD_DCT_COEF);
+  ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0);
+}
+
 void jpeg_finish_compress(j_compress_ptr cinfo)
 {
   shim_state *s = find_state(cinfo, 0);
@@ -562,10 +573,7 @@ void jpeg_finish_compress(j_compress_ptr cinfo)
     if (cinfo->next_scanline < cinfo->image_height) FAIL_WITH_STATE(cinfo, ERREXIT(cinfo, JERR_TOO_LITTLE_DATA));
   } else if (cinfo->global_state != CSTATE_WRCOEFS)
     FAIL_WITH_STATE(cinfo, ERREXIT1(cinfo, JERR_BAD_STATE, cinfo->global_state));   /* jcapimin.c:180-189 */
-  if (encode_staged(cinfo, s) != MJH_OK) {
-    fprintf(stderr, "mozjpeg_hip: %s\n", mjh_last_error());
-    FAIL_WITH_STATE(cinfo, ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0));
-  }
+  if (encode_staged(cinfo, s) != MJH_OK) encoder_failed(cinfo);
   /* the remaining passes run on the device; a progress monitor sees them go by (jcmaster.c:708-713) */
   if (cinfo->progress != NULL) {
     for (pass = 1; pass < s->total_passes; pass++) {
@@ -583,9 +591,8 @@ void jpeg_finish_compress(j_compress_ptr cinfo)
              mjh_get_jpeg(s->enc, 0, copy, n, &n) == MJH_OK) {
     file = copy;
   } else {
-    fprintf(stderr, "mozjpeg_hip: %s\n", mjh_last_error());
     free(copy);
-    FAIL_WITH_STATE(cinfo, ERREXIT1(cinfo, JERR_OUT_OF_MEMORY, 0));
+    encoder_failed(cinfo);
     return;
   }
   /* the device wrote a complete file; SOI(+APP0) went out in jpeg_start_compress already */

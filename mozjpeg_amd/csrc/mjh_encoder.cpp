@@ -311,6 +311,8 @@ struct mjh_encoder {
   std::vector<hipEvent_t> prof_events;
   std::vector<unsigned> h_sizes;
   bool sizes_valid = false;
+  bool coef_input = false;         // last batch came in through mjh_encode_coefficients_*: d_meta[].bad_coef is meaningful
+  hipStream_t last_stream = nullptr;   // the stream the last batch was queued on (mjh_encoder_sync waits for it)
 };
 
 static long div_round_up(long a, long b) { return (a + b - 1) / b; }
@@ -927,6 +929,8 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   e->sizes_valid = false;
   e->last_n = n;
   e->res_buf = -1;
+  e->coef_input = coef_src != nullptr;
+  e->last_stream = s;
   Prof pr{ e, s };
   if (e->profiling && e->prof_calls < 256) {
     pr.enabled = true;
@@ -937,7 +941,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   HIPCHK(hipMemcpyAsync(e->d_tabs, e->d_tabs_init, (size_t)n * spi * sizeof(MjhHuffTable), hipMemcpyDeviceToDevice, s));
   if (coef_src) {    // jpeg_write_coefficients: the caller's quantized blocks go straight to the entropy-coding passes
     pr.mark("import_coefs");
-    mjh_launch_import_coefs(C, *coef_src, e->d_q, n, s);
+    mjh_launch_import_coefs(C, *coef_src, e->d_q, e->d_meta, n, s);
   } else {
     if (plane_src) {   // jpeg_write_raw_data: the caller's component planes replace colour conversion + downsampling
       pr.mark("import_planes");
@@ -1101,6 +1105,11 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
 extern "C" int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t row_pitch, size_t image_stride, int n, void *stream)
 {
   if (!e || !d_pixels || n < 1 || n > e->max_batch) return fail(MJH_EINVAL, "bad arguments (n=%d, max_batch=%d)", n, e ? e->max_batch : 0);
+  {
+    const size_t row_bytes = (size_t)e->C.W * e->C.px_size * (e->C.precision == 12 ? 2 : 1);
+    if (row_pitch < row_bytes || (n > 1 && image_stride < row_pitch * (size_t)(e->C.H - 1) + row_bytes))
+      return fail(MJH_EINVAL, "row_pitch %zu / image_stride %zu too small for %dx%d images of %zu-byte rows", row_pitch, image_stride, e->C.W, e->C.H, row_bytes);
+  }
   HIPCHK(hipSetDevice(e->device));
   return run_pipeline(e, d_pixels, row_pitch, image_stride, n, stream ? (hipStream_t)stream : e->stream);
 }
@@ -1474,7 +1483,7 @@ extern "C" int mjh_encoder_sync(mjh_encoder *e)
 {
   if (!e) return fail(MJH_EINVAL, "null encoder");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipStreamSynchronize(e->last_stream ? e->last_stream : e->stream));
   return MJH_OK;
 }
 
@@ -1502,7 +1511,14 @@ static int fetch_sizes(mjh_encoder *e)
     std::vector<MjhImageMeta> mt(e->last_n);
     HIPCHK(hipMemcpy(mt.data(), e->d_meta, (size_t)e->last_n * sizeof(MjhImageMeta), hipMemcpyDeviceToHost));
     for (int i = 0; i < e->last_n; i++)
-      if (mt[i].total_bits == 0xFFFFFFFFu) return fail(MJH_ETOOSMALL, "entropy-coded data of image %d exceeds the 2^32-bit (512 MB) offset range of one scan", i);
+      if (mt[i].total_bits == 0xFFFFFFFFu) return fail(MJH_ETOOSMALL, "entropy-coded data of image %d exceeds the 32-bit (2^32 bits = 512 MB) offset range of one scan", i);
+
+  }
+  if (e->coef_input) {   // untrusted coefficients: the import / length kernels flag values no Huffman symbol exists for
+    std::vector<MjhImageMeta> mt(e->last_n);
+    HIPCHK(hipMemcpy(mt.data(), e->d_meta, (size_t)e->last_n * sizeof(MjhImageMeta), hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->last_n; i++)
+      if (mt[i].bad_coef) return fail(MJH_EINVAL, "image %d holds a DCT coefficient out of range (JERR_BAD_DCT_COEF, jchuff.c:489,596,624)", i);
   }
   e->sizes_valid = true;
   return MJH_OK;

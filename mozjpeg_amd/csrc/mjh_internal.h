@@ -92,6 +92,7 @@ struct MjhImageMeta {
   unsigned hdr_len;        // bytes before the entropy-coded data
   unsigned stuffed_len;    // entropy-coded bytes after stuffing
   unsigned file_len;       // whole file
+  unsigned bad_coef;       // coefficient input only: a value no Huffman symbol exists for (JERR_BAD_DCT_COEF, jchuff.c:489,596,624)
 };
 
 

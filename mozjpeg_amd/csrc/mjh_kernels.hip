@@ -505,7 +505,7 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
 // (compress_output jctrans.c:322-373 builds them with the same rule as the pixel path).
 // =============================================================================================
 __global__ void __launch_bounds__(64)
-k_import_coefs(MjhConst C, MjhCoefSrc S, int16_t *__restrict__ coef_q)
+k_import_coefs(MjhConst C, MjhCoefSrc S, int16_t *__restrict__ coef_q, MjhImageMeta *__restrict__ meta)
 {
   const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
@@ -522,6 +522,13 @@ k_import_coefs(MjhConst C, MjhCoefSrc S, int16_t *__restrict__ coef_q)
     v[2 * i + 1] = (int)(short)(w >> 16);
   }
   int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+  // untrusted input (jpegtran on arbitrary files): a coefficient beyond MAX_COEF_BITS has no Huffman symbol; the reference
+  // raises JERR_BAD_DCT_COEF when it meets one (jchuff.c:596,624) -- flagged here, the DC difference in k_enc_len
+  const int lim = C.precision == 12 ? 16383 : 1023;
+  int worst = 0;
+#pragma unroll
+  for (int k = 1; k < 64; k++) { const int a = v[k] < 0 ? -v[k] : v[k]; worst = a > worst ? a : worst; }
+  if (worst > lim) meta[img].bad_coef = 1u;
 #pragma unroll
   for (int k = 0; k < 64; k++) qo[(size_t)k * cc.kstride] = (int16_t)v[kZZ.v[k]];
 }
@@ -1498,10 +1505,10 @@ __device__ __forceinline__ int mcu_position(const MjhConst &C, const MjhComp &cc
 
 __global__ void __launch_bounds__(256)
 k_enc_len(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs,
-          int slots_per_image, int4 dc_slot_of_comp, int4 ac_slot_of_comp, uint16_t *__restrict__ len16)
+          int slots_per_image, int4 dc_slot_of_comp, int4 ac_slot_of_comp, uint16_t *__restrict__ len16, MjhImageMeta *__restrict__ meta)
 {
   __shared__ unsigned char s_ac[256];
-  __shared__ unsigned char s_dc[16];
+  __shared__ unsigned char s_dc[32];   // a DC difference of untrusted coefficient input can have up to 17 bits
   const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
   const int tid = threadIdx.x;
@@ -1510,7 +1517,7 @@ k_enc_len(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *__
   const MjhHuffTable *TD = tabs + (size_t)img * slots_per_image + dslot;
   const MjhHuffTable *TA = tabs + (size_t)img * slots_per_image + aslot;
   s_ac[tid] = TA->ehufsi[tid];
-  if (tid < 16) s_dc[tid] = TD->ehufsi[tid];
+  if (tid < 32) s_dc[tid] = tid < 16 ? TD->ehufsi[tid] : 0;
   __syncthreads();
   const int t = blockIdx.x * 256 + tid;
   if (t >= cc.wpad * cc.hpad) return;
@@ -1521,6 +1528,7 @@ k_enc_len(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *__
   if (mcu_prev_block(C, cc, r, c, pr, pc)) pred = q[dc_source_block(cc, pr, pc)];
   const int df = dc - pred;
   int nb = bitlen((unsigned)(df < 0 ? -df : df));
+  if (nb > (C.precision == 12 ? 15 : 11)) meta[img].bad_coef = 1u;   // MAX_COEF_BITS + 1 (jchuff.c:489)
   int bits = s_dc[nb] + nb;
   const bool real = r < cc.hib && c < cc.wib;
   int x[64];
@@ -1651,7 +1659,7 @@ k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *
             const unsigned *__restrict__ seg_E, unsigned *__restrict__ mpos, int nseg)
 {
   __shared__ unsigned s_ac[256];   // size << 16 | code
-  __shared__ unsigned s_dc[16];
+  __shared__ unsigned s_dc[32];
   const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
   const int tid = threadIdx.x;
@@ -1660,7 +1668,7 @@ k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *
   const MjhHuffTable *TD = tabs + (size_t)img * slots_per_image + dslot;
   const MjhHuffTable *TA = tabs + (size_t)img * slots_per_image + aslot;
   s_ac[tid] = ((unsigned)TA->ehufsi[tid] << 16) | TA->ehufco[tid];
-  if (tid < 16) s_dc[tid] = ((unsigned)TD->ehufsi[tid] << 16) | TD->ehufco[tid];
+  if (tid < 32) s_dc[tid] = tid < 16 ? ((unsigned)TD->ehufsi[tid] << 16) | TD->ehufco[tid] : 0u;
   __syncthreads();
   const int t = blockIdx.x * 256 + tid;
   if (t >= cc.wpad * cc.hpad) return;
@@ -1924,6 +1932,7 @@ k_pack_results(const uint8_t *__restrict__ out, size_t out_stride, const unsigne
       unsigned long long err = 0;
       for (int j = 0; j < n; j++) {
         if (meta && meta[j].total_bits == 0xFFFFFFFFu) err |= 1ull;
+        if (meta && meta[j].bad_coef) err |= 4ull;
         if (ctl && ctl[j].error) err |= ctl[j].error == 1 ? 1ull : 2ull;
       }
       table[1] = err;
@@ -1950,12 +1959,13 @@ void mjh_launch_pack_results(const void *out, size_t out_stride, const unsigned 
                      (const MjhProgCtl *)prog_ctl, n, (uint8_t *)dst, cap, (unsigned long long *)table);
 }
 
-void mjh_launch_import_coefs(const MjhConst &C, const MjhCoefSrc &S, void *coef_q, int n, hipStream_t s)
+void mjh_launch_import_coefs(const MjhConst &C, const MjhCoefSrc &S, void *coef_q, void *meta, int n, hipStream_t s)
 {
+  (void)hipMemsetAsync(meta, 0, (size_t)n * sizeof(MjhImageMeta), s);
   int m = 0;
   for (int i = 0; i < C.ncomp; i++) m = C.c[i].nblk > m ? C.c[i].nblk : m;
   dim3 grid((m + 63) / 64, C.ncomp, n);
-  hipLaunchKernelGGL(k_import_coefs, grid, dim3(64), 0, s, C, S, (int16_t *)coef_q);
+  hipLaunchKernelGGL(k_import_coefs, grid, dim3(64), 0, s, C, S, (int16_t *)coef_q, (MjhImageMeta *)meta);
 }
 
 void mjh_launch_import_planes(const MjhConst &C, const MjhPlaneSrc &S, void *planes, int n, hipStream_t s)
@@ -2099,7 +2109,7 @@ void mjh_launch_encode(const MjhConst &C, const void *q, const MjhHuffTable *tab
   const int4 ds = make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]);
   const int4 as = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
   dim3 grid((max_padblk(C) + 255) / 256, C.ncomp, n);
-  hipLaunchKernelGGL(k_enc_len, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, ds, as, (uint16_t *)len16);
+  hipLaunchKernelGGL(k_enc_len, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, ds, as, (uint16_t *)len16, (MjhImageMeta *)meta);
   hipLaunchKernelGGL((k_chunk_sums<uint16_t>), dim3(chunks_per_image, n), dim3(256), 0, s, (const uint16_t *)len16, C.total_mcu_blocks, sums, chunks_per_image);
   hipLaunchKernelGGL(k_scan_sums, dim3(n), dim3(256), 0, s, sums, chunks_per_image, totals, (const unsigned *)nullptr);
   hipLaunchKernelGGL((k_offsets<uint16_t>), dim3(chunks_per_image, n), dim3(256), 0, s, (const uint16_t *)len16, C.total_mcu_blocks, sums, chunks_per_image, (unsigned *)off32);

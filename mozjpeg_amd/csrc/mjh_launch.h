@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 #include "mjh_internal.h"
 
-void mjh_launch_import_coefs(const MjhConst &C, const MjhCoefSrc &S, void *coef_q, int n, hipStream_t s);
+void mjh_launch_import_coefs(const MjhConst &C, const MjhCoefSrc &S, void *coef_q, void *meta, int n, hipStream_t s);
 void mjh_launch_import_planes(const MjhConst &C, const MjhPlaneSrc &S, void *planes, int n, hipStream_t s);
 void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size_t img_stride, void *planes, int n, hipStream_t s);
 void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,

@@ -190,9 +190,17 @@ TJSAMP = {"444": 0, "422": 1, "420": 2, "GRAY": 3, "440": 4, "411": 5, "441": 6}
 ACCURATE, BOTTOMUP, PROGRESSIVE = 4096, 2, 16384
 
 
+TJSHIM = os.path.join(ROOT, "mozjpeg_amd", "libmozjpeg_hip_turbojpeg.so")
+
+
 def tj_run(raw, w, h, pf, ss, q, flags, out, preload):
+    """preload: False = the reference alone; True = the libjpeg drop-in in front of the reference's libjpeg (underneath its
+    unchanged libturbojpeg); "tj" = the TurboJPEG-signature library in front of libturbojpeg itself (what a STOCK
+    libturbojpeg with its private libjpeg needs)"""
     env = dict(os.environ)
-    if preload:
+    if preload == "tj":
+        env["LD_PRELOAD"] = TJSHIM
+    elif preload:
         env["LD_PRELOAD"] = SHIM
     return subprocess.run([TJH, str(w), str(h), str(pf), str(ss), str(q), str(flags), raw, out], env=env,
                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
@@ -222,14 +230,61 @@ def test_unchanged_tjcompress2_through_the_shim(pfname, ssname, q, flags, tmp_pa
 
 
 @needs_tj
-def test_tjcompress2_fast_dct_is_refused_not_emulated(tmp_path):
+@pytest.mark.parametrize("pfname", ["RGB", "BGRX", "XRGB"])
+@pytest.mark.parametrize("ssname,q,flags", [("420", 75, ACCURATE), ("444", 96, 0), ("422", 80, ACCURATE | BOTTOMUP),
+                                            ("GRAY", 75, ACCURATE), ("440", 60, ACCURATE), ("420", 85, ACCURATE | PROGRESSIVE),
+                                            ("411", 75, ACCURATE), ("441", 90, ACCURATE | PROGRESSIVE)])
+def test_turbojpeg_signature_exports_match_the_reference_turbojpeg(pfname, ssname, q, flags, tmp_path):
+    """libmozjpeg_hip_turbojpeg.so: tjInitCompress / tjCompress2 / tjDestroy served directly by the batch encoder"""
+    if not os.path.exists(TJSHIM):
+        pytest.skip("TurboJPEG-signature library not built")
+    import numpy as np
+    rgb = O.read_ppm(PPM)
+    h, w = rgb.shape[:2]
+    pf, offs, ps = TJPF[pfname]
+    px = np.full((h, w, ps), 0x5A, np.uint8)
+    for ch in range(3):
+        px[..., offs[ch]] = rgb[..., ch]
+    raw = str(tmp_path / "in.raw")
+    px.tofile(raw)
+    ref, gpu = str(tmp_path / "ref.jpg"), str(tmp_path / "gpu.jpg")
+    r0 = tj_run(raw, w, h, pf, TJSAMP[ssname], q, flags, ref, preload=False)
+    r1 = tj_run(raw, w, h, pf, TJSAMP[ssname], q, flags, gpu, preload="tj")
+    assert r0.returncode == 0, r0.stderr.decode()
+    assert r1.returncode == 0, r1.stderr.decode()
+    assert open(gpu, "rb").read() == open(ref, "rb").read()
+
+
+@needs_tj
+@pytest.mark.parametrize("w,h,ssname,q,flags", [(227, 149, "420", 75, ACCURATE), (64, 48, "444", 96, 0), (50, 33, "GRAY", 75, ACCURATE),
+                                                (229, 151, "411", 75, ACCURATE), (227, 149, "420", 85, ACCURATE | PROGRESSIVE)])
+def test_turbojpeg_signature_yuv_exports_match_the_reference_turbojpeg(w, h, ssname, q, flags, tmp_path):
+    if not os.path.exists(TJSHIM):
+        pytest.skip("TurboJPEG-signature library not built")
+    samp = {"444": (1, 1), "422": (2, 1), "420": (2, 2), "GRAY": (1, 1), "440": (1, 2), "411": (4, 1), "441": (1, 4)}[ssname]
+    po = O.make_params(w, h, revert=True, quality=q, sample=samp, gray=(ssname == "GRAY"), progressive=bool(flags & PROGRESSIVE))
+    raw = str(tmp_path / "in.yuv")
+    with open(raw, "wb") as f:
+        for a in O.synthetic_planes(po, 11):
+            f.write(a.tobytes())
+    ref, gpu = str(tmp_path / "ref.jpg"), str(tmp_path / "gpu.jpg")
+    r0 = tj_run(raw, w, h, -1, TJSAMP[ssname], q, flags, ref, preload=False)
+    r1 = tj_run(raw, w, h, -1, TJSAMP[ssname], q, flags, gpu, preload="tj")
+    assert r0.returncode == 0, r0.stderr.decode()
+    assert r1.returncode == 0, r1.stderr.decode()
+    assert open(gpu, "rb").read() == open(ref, "rb").read()
+
+
+@needs_tj
+@pytest.mark.parametrize("preload", [True, "tj"])
+def test_tjcompress2_fast_dct_is_refused_not_emulated(preload, tmp_path):
     """without TJFLAG_ACCURATEDCT and quality < 96 TurboJPEG selects JDCT_FASTEST (turbojpeg.c:523-526):
     outside the integer-DCT hot path, so the drop-in must fail loudly"""
     rgb = O.read_ppm(PPM)
     h, w = rgb.shape[:2]
     raw = str(tmp_path / "in.raw")
     rgb.tofile(raw)
-    r = tj_run(raw, w, h, 0, 2, 75, 0, str(tmp_path / "o.jpg"), preload=True)
+    r = tj_run(raw, w, h, 0, 2, 75, 0, str(tmp_path / "o.jpg"), preload=preload)
     assert r.returncode != 0
     assert b"no CPU fallback" in r.stderr
 

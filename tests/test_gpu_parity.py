@@ -241,6 +241,33 @@ def test_coefficient_input_device_batch_1080p_and_trellis_is_refused():
 
 
 @pytest.mark.gpu
+def test_coefficient_input_out_of_range_is_an_error():
+    """jpegtran on untrusted files: an AC coefficient beyond MAX_COEF_BITS or a DC difference beyond MAX_COEF_BITS + 1 has
+    no Huffman symbol; the reference raises JERR_BAD_DCT_COEF (jchuff.c:489,596,624), the GPU path reports it as well"""
+    w, h = 64, 48
+    mp = M.make_params(w, h, baseline=True, notrellis=True)
+    good = [np.zeros((6, 8, 64), np.int16), np.zeros((3, 4, 64), np.int16), np.zeros((3, 4, 64), np.int16)]
+    good[0][2, 3, 5] = 1023
+    good[0][0, 0, 0] = 1023
+    good[0][0, 1, 0] = -1024            # DC difference 2047: 11 bits, the largest that exists
+    enc = M.Encoder(mp)
+    assert len(enc.encode_coefficients_host(good)[0]) > 100
+    for k, v in ((5, 1024), (63, -2000)):
+        bad = [a.copy() for a in good]
+        bad[1][1, 2, k] = v
+        with pytest.raises(M.MjhError) as ei:
+            enc.encode_coefficients_host(bad)
+        assert "JERR_BAD_DCT_COEF" in str(ei.value)
+    bad = [a.copy() for a in good]
+    bad[0][0, 1, 0] = -1100              # DC difference 2123: 12 bits
+    with pytest.raises(M.MjhError) as ei:
+        enc.encode_coefficients_host(bad)
+    assert "JERR_BAD_DCT_COEF" in str(ei.value)
+    assert len(enc.encode_coefficients_host(good)[0]) > 100   # the encoder is usable afterwards
+    enc.close()
+
+
+@pytest.mark.gpu
 def test_scan_beyond_the_32bit_offset_range_is_an_error_not_a_wrapped_file():
     """bit offsets inside one scan are 32-bit; a scan of more than 2^32 bits (a > 512 MB JPEG) must be reported"""
     w = h = 16384

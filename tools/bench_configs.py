@@ -22,13 +22,13 @@ def run(name, w, h, kw, batch, steps=5):
     frames = np.stack([gen(w, h, 1234 + i) for i in range(batch)])
     t = torch.from_numpy(frames.view(np.int16) if frames.dtype == np.uint16 else frames).cuda()
     enc = M.Encoder(M.make_params(w, h, **kw), max_batch=batch)
-    enc.encode_tensor(t); enc.sync()
+    enc.encode_tensor(t, stream="own"); enc.sync()
     ok = enc.get_jpeg(0) == O.encode(O.make_params(w, h, **kw), frames[0])
     enc.set_profiling(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        enc.encode_tensor(t)
+        enc.encode_tensor(t, stream="own")
     enc.sync()
     dt = (time.perf_counter() - t0) / steps
     kt = enc.kernel_times()

@@ -31,7 +31,7 @@ if __name__ == "__main__":
     for v in a.variants.split(","):
         os.environ[a.env] = v
         enc = M.Encoder(M.make_params(w, h, **kw), max_batch=a.batch)
-        enc.encode_tensor(d); enc.sync()
+        enc.encode_tensor(d, stream="own"); enc.sync()
         files = [enc.get_jpeg(i) for i in range(a.batch)]
         if base is None:
             base = files
@@ -39,12 +39,12 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            enc.encode_tensor(d)
+            enc.encode_tensor(d, stream="own")
         enc.sync()
         dt = (time.perf_counter() - t0) / a.steps
         enc.set_profiling(1)
         for _ in range(3):
-            enc.encode_tensor(d)
+            enc.encode_tensor(d, stream="own")
         kt = dict(enc.kernel_times())
         print(json.dumps({"variant": "%s=%s" % (a.env, v), "ms_per_batch": round(dt * 1e3, 3), "mpix_per_s": round(w * h * a.batch / dt / 1e6, 1),
                           "identical_to_first": files == base,
