@@ -251,6 +251,7 @@ struct mjh_encoder {
   bool res_waited[2] = { false, false };
   uint8_t *d_plin = nullptr, *h_plin = nullptr;   // the same for mjh_encode_planes_host
   uint8_t *d_cfin = nullptr, *h_cfin = nullptr;   // and for mjh_encode_coefficients_host
+  unsigned *d_prog_ffsums = nullptr;              // stuffed-byte counts of the shares of every scan (k_prog_stuff)
   unsigned *d_prog_mpos = nullptr;                // progressive + restart intervals: byte positions of the RSTn markers of every scan
   int mpos_per_image = 0;
   size_t pix_image_bytes = 0;
@@ -265,7 +266,9 @@ struct mjh_encoder {
   int comp_restart[4] = { 0, 0, 0, 0 };
   int16_t *d_dense = nullptr; unsigned dense_cap = 0;       // raw coefficients of deferred blocks, 64 int16 per work-list slot
   unsigned *d_worklist = nullptr, *d_worklist2 = nullptr;   // deferred trellis blocks: [0] = count, [4+3i..6+3i] = (image, comp<<28|block, dense slot)
-  int trellis_variant = 0;
+  int trellis_variant = 0;           // first-tier queue capacity of the AC trellis: 0 = 16, 1 = 20, 2 = 24, 3 = 32 (all bit-identical)
+  bool trellis_adapt = true;         // no MJH_TRELLIS_VARIANT given: follow the share of deferred blocks of the previous batches
+  unsigned *h_defer = nullptr;       // pinned: work-list count of the last finished trellis pass
   int fuse_mask = 1;                // MJH_FUSE: 1 = pre-trellis AC statistics inside the FDCT kernel (+ unread planes not stored), 2 = final AC statistics inside the trellis
   int spi = SLOTS_BASE;             // table slots per image (16 + 2 per progressive scan)
   // progressive mode
@@ -276,7 +279,7 @@ struct mjh_encoder {
   std::vector<int> h_lists;
   // scans of one phase + the table slots they build; for the statistics the scans are split into AC-first scans
   // without restart intervals (parallel kernel) and the rest (sequential per-scan walk)
-  struct PList { int scan_off, nscan, slot_off, nslot, par_off, npar, seq_off, nseq; };
+  struct PList { int scan_off, nscan, slot_off, nslot, par_off, npar, seq_off, nseq; bool any_refine; };
   void *d_prog_chunks = nullptr;     // chunk summaries of the parallel statistics / encode kernels
   int chunks_per_scan = 0;
   MjhProgPE pe{};                    // buffers of the parallel AC-first encode
@@ -601,10 +604,11 @@ static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.info, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
+  if (e->h_defer) (void)hipHostFree(e->h_defer);
   for (int b = 0; b < 2; b++) {
     if (e->h_stage[b]) (void)hipHostFree(e->h_stage[b]);
     if (e->h_res[b]) (void)hipHostFree(e->h_res[b]);
@@ -674,7 +678,9 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     e->dense_cap = (unsigned)(B * (size_t)C.total_real_blocks / 4 + 1024);
     HIPCHK_E(hipMalloc((void **)&e->d_dense, (size_t)e->dense_cap * 128));
   }
-  if (const char *v = getenv("MJH_TRELLIS_VARIANT")) e->trellis_variant = atoi(v);
+  if (const char *v = getenv("MJH_TRELLIS_VARIANT")) { e->trellis_variant = atoi(v); e->trellis_adapt = false; }
+  HIPCHK_E(hipHostMalloc((void **)&e->h_defer, 64, hipHostMallocDefault));
+  e->h_defer[0] = 0xFFFFFFFFu;
   if (const char *v = getenv("MJH_FUSE")) e->fuse_mask = atoi(v);
   HIPCHK_E(hipMalloc((void **)&e->d_len16, B * (size_t)C.total_mcu_blocks * 2));
   HIPCHK_E(hipMalloc((void **)&e->d_off32, B * (size_t)C.total_mcu_blocks * 4));
@@ -827,6 +833,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       e->mpos_per_image = total;
       HIPCHK_E(hipMalloc((void **)&e->d_prog_mpos, (B * (size_t)total + 16) * sizeof(unsigned)));
     }
+    HIPCHK_E(hipMalloc((void **)&e->d_prog_ffsums, B * ps.size() * 8 * sizeof(unsigned)));   // PROG_STUFF_SPLIT shares per (scan, image)
     HIPCHK_E(hipMalloc(&e->d_prog_scans, ps.size() * sizeof(MjhProgScan)));
     HIPCHK_E(hipMemcpy(e->d_prog_scans, ps.data(), ps.size() * sizeof(MjhProgScan), hipMemcpyHostToDevice));
     HIPCHK_E(hipMalloc(&e->d_prog_ctl, B * sizeof(MjhProgCtl)));
@@ -839,10 +846,11 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       for (int si : scn)
         for (int t = 0; t < 2; t++)
           if (ps[si].slot[t] >= 0 && (ps[si].Ss != 0 || ps[si].Ah == 0)) { e->h_lists.push_back(ps[si].slot[t]); pl.nslot++; }
-      pl.par_off = (int)e->h_lists.size(); pl.npar = 0;
-      for (int si : scn) if (ps[si].Ss != 0 && ps[si].Ah == 0 && ps[si].ri == 0) { e->h_lists.push_back(si); pl.npar++; }
+      // scans without a restart interval go through the parallel chain (mjh_prog.hip), the others are walked in order
+      pl.par_off = (int)e->h_lists.size(); pl.npar = 0; pl.any_refine = false;
+      for (int si : scn) if (ps[si].ri == 0) { e->h_lists.push_back(si); pl.npar++; if (ps[si].Ss != 0 && ps[si].Ah != 0) pl.any_refine = true; }
       pl.seq_off = (int)e->h_lists.size(); pl.nseq = 0;
-      for (int si : scn) if (!(ps[si].Ss != 0 && ps[si].Ah == 0 && ps[si].ri == 0)) { e->h_lists.push_back(si); pl.nseq++; }
+      for (int si : scn) if (ps[si].ri != 0) { e->h_lists.push_back(si); pl.nseq++; }
       return pl;
     };
     std::vector<int> tr, a, b;
@@ -864,17 +872,25 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       for (const mjh_encoder::PList *pl : { &e->pl_trellis, &e->pl_phase[0], &e->pl_phase[1] }) maxlist = pl->npar > maxlist ? pl->npar : maxlist;
       HIPCHK_E(hipMalloc(&e->d_prog_chunks, B * (size_t)maxlist * e->chunks_per_scan * sizeof(MjhProgChunk)));
       // parallel encode of the AC-first scans: block lengths / runs / offsets per (scan, image) pair
-      const int maxpar = e->pl_phase[0].npar > e->pl_phase[1].npar ? e->pl_phase[0].npar : e->pl_phase[1].npar;
+      const int maxpar = maxlist;
       e->pe.chunks_per_scan = e->chunks_per_scan;
       e->pe.nblk_pad = e->chunks_per_scan * MJH_PSTAT_BLOCKS;
       e->pe.chunks = (MjhProgChunk *)e->d_prog_chunks;
       if (maxpar > 0) {
-        const size_t pairs = B * (size_t)maxpar, ent = pairs * (size_t)e->pe.nblk_pad;
+        const size_t pairs = B * (size_t)maxpar, ent = pairs * (size_t)e->pe.nblk_pad, nch = pairs * (size_t)e->chunks_per_scan;
         HIPCHK_E(hipMalloc((void **)&e->pe.len16, ent * 2));
         HIPCHK_E(hipMalloc((void **)&e->pe.run16, ent * 2));
+        HIPCHK_E(hipMalloc((void **)&e->pe.tail16, ent * 2));
+        HIPCHK_E(hipMalloc((void **)&e->pe.be16, ent * 2));
         HIPCHK_E(hipMalloc((void **)&e->pe.off32, ent * 4));
-        HIPCHK_E(hipMalloc((void **)&e->pe.sums, pairs * (size_t)e->chunks_per_scan * 4));
+        HIPCHK_E(hipMalloc((void **)&e->pe.T32, ent * 4));
+        HIPCHK_E(hipMalloc((void **)&e->pe.sums, nch * 4));
+        HIPCHK_E(hipMalloc((void **)&e->pe.tsums, nch * 4));
         HIPCHK_E(hipMalloc((void **)&e->pe.totals, pairs * 4));
+        HIPCHK_E(hipMalloc((void **)&e->pe.ttotals, pairs * 4));
+        HIPCHK_E(hipMalloc((void **)&e->pe.ne_bits, nch * (MJH_PSTAT_BLOCKS / 64) * 8));
+        HIPCHK_E(hipMalloc((void **)&e->pe.e_bits, nch * (MJH_PSTAT_BLOCKS / 64) * 8));
+        HIPCHK_E(hipMalloc((void **)&e->pe.ne2_bits, nch * (MJH_PSTAT_BLOCKS / 64) * 8));
         HIPCHK_E(hipMalloc((void **)&e->pe.info, pairs * sizeof(MjhProgPair)));
       }
     }
@@ -1004,8 +1020,8 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       pr.mark("prog_stats(pre-trellis)");
       if (e->pl_trellis.nseq)
         mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + e->pl_trellis.seq_off, e->pl_trellis.nseq, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
-      mjh_launch_prog_stats_acfirst(C, e->d_prog_scans, e->d_lists + e->pl_trellis.par_off, e->pl_trellis.npar, e->d_prog_ctl, e->d_q, e->d_tabs, spi,
-                                    e->d_prog_chunks, e->chunks_per_scan, n, s);
+      mjh_launch_prog_stats_par(C, e->d_prog_scans, e->d_lists + e->pl_trellis.par_off, e->pl_trellis.npar, e->d_prog_ctl, e->d_q, e->d_tabs, spi,
+                                e->pe, e->pl_trellis.any_refine, n, s);
       pr.mark("gen_tables(trellis)");
       mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + e->pl_trellis.slot_off, e->pl_trellis.nslot, n, s);
       for (int i = 0; i < 4; i++) tr_dc[i] = fin_dc[i];
@@ -1029,9 +1045,22 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       if (pr.enabled && e->profiling == 1) { HIPCHK(hipEventRecord(e->side_events[2 * e->prof_calls + 1], e->side_stream)); e->side_timed = true; }
       HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
     }
+    if (e->trellis_adapt && e->h_defer[0] != 0xFFFFFFFFu) {
+      // The first tier's queue capacity trades LDS occupancy (16 entries: 14 waves per CU) against the share of blocks that
+      // have to be redone by the slower big-capacity tier: few at q75 (the metric: ~5 %), a third of all blocks at q85.
+      // The share seen in the last finished batch (read back asynchronously, never waited for) moves it one notch.
+      const double share = (double)e->h_defer[0] / ((double)e->h_defer[1] * (double)C.total_real_blocks + 1.0);
+      if (share > 0.12 && e->trellis_variant < 3) e->trellis_variant++;
+      else if (share < 0.03 && e->trellis_variant > 0) e->trellis_variant--;
+      e->h_defer[0] = 0xFFFFFFFFu;
+    }
     pr.mark("trellis_ac");
     mjh_launch_trellis_ac(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap,
                           fuse_fin && p.optimize_coding && loop == nloops - 1 ? fin_ac : nullptr, e->trellis_variant, n, s);
+    if (e->trellis_adapt && loop == 0) {
+      e->h_defer[1] = (unsigned)n;
+      HIPCHK(hipMemcpyAsync(&e->h_defer[0], e->d_worklist, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    }
     if (p.trellis_quant_dc) {
       pr.mark("join(trellis_dc)");
       HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
@@ -1051,8 +1080,8 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
         HIPCHK(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
         ps = e->side_stream;
       }
-      mjh_launch_prog_stats_acfirst(C, e->d_prog_scans, e->d_lists + pl.par_off, pl.npar, e->d_prog_ctl, e->d_q, e->d_tabs, spi,
-                                    e->d_prog_chunks, e->chunks_per_scan, n, ps);
+      mjh_launch_prog_stats_par(C, e->d_prog_scans, e->d_lists + pl.par_off, pl.npar, e->d_prog_ctl, e->d_q, e->d_tabs, spi,
+                                e->pe, pl.any_refine, n, ps);
       if (both) HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
       if (pl.nseq)
         mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + pl.seq_off, pl.nseq, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
@@ -1063,7 +1092,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       mjh_launch_prog_encode(C, e->d_prog_scans, e->d_lists + pl.scan_off, pl.nscan, e->d_lists + pl.seq_off, pl.nseq, e->d_lists + pl.par_off, pl.npar,
                              e->pe, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_pool, e->pool_words,
                              e->d_frame_hdr, e->frame_hdr_len, p.compress_profile != MJH_PROFILE_FASTEST, e->d_outpool, e->outpool_bytes,
-                             e->d_prog_mpos, e->mpos_per_image, n, s, e->side_stream, e->ev_fork, e->ev_join);
+                             e->d_prog_mpos, e->mpos_per_image, e->d_prog_ffsums, n, s, e->side_stream, e->ev_fork, e->ev_join);
       if (p.optimize_scans) { pr.mark("prog_select"); mjh_launch_prog_select(e->d_prog_ctl, C.ncomp, ph, n, s); }
     }
     if (before_output) HIPCHK(hipStreamWaitEvent(s, before_output, 0));

@@ -117,17 +117,26 @@ struct MjhProgScan {
   int emit_dri;            // write_scan_header jcmarker.c:778-781: DRI when the interval differs from the previous scan's
 };
 
-// summary of one 2048-block chunk of an AC-first scan (parallel statistics): where its non-empty blocks begin and
-// end, so that the EOB runs that cross chunk borders can be resolved afterwards
+// parallel chain (scans without restart intervals, mjh_prog.hip): summary of one 2048-block chunk -- where its non-empty
+// blocks begin and end, and what k_pp_resolve found on either side of it
 #define MJH_PSTAT_BLOCKS 2048
-struct MjhProgChunk { int first_ne, last_ne, e_last, nblk; };
+struct MjhProgChunk {
+  int first_ne, last_ne, e_last, nblk;
+  int carry_p, carry_e;      // last non-empty block before the chunk (index in the scan, -1: none) and its "ends in zeros" flag
+  int next_after;            // first non-empty block behind the chunk (-1: none)
+  int pad;
+};
 
-// parallel encode of AC-first scans: per (scan of the list, image) pair the run pending at the end of the scan and
-// whether the pair has to fall back to the sequential walk (a forced emission at EOBRUN == 0x7FFF inside it)
-struct MjhProgPair { unsigned final_run; int fallback; };
+// per (scan of the list, image) pair: the run / correction bits pending at the end of the scan and the total number of
+// correction bits of a refinement scan (sizes its bit stream)
+struct MjhProgPair { unsigned final_run, final_be; int fallback; unsigned corr_total; };
 struct MjhProgPE {         // device buffers of that path, [image][scan of the list][...]
-  uint16_t *len16, *run16; // bits of every block (own symbols + the EOBRUN flush in front of it); the run it flushes
-  unsigned *off32, *sums, *totals;
+  uint16_t *len16, *run16; // bits of every block / unit (own symbols + the flush in front of it); the run it flushes
+  uint16_t *tail16, *be16; // refinement scans: trailing correction bits of every block; correction bits in front of a non-empty block
+  unsigned *off32, *sums, *totals;     // prefix sum of len16
+  unsigned *T32, *tsums, *ttotals;     // prefix sum of tail16
+  unsigned long long *ne_bits, *e_bits;   // [pair][chunk][32]: non-empty / ends-in-zeros bitmaps
+  unsigned long long *ne2_bits;           // non-empty blocks + forced-flush marks = the flush points
   MjhProgPair *info;
   MjhProgChunk *chunks;
   int chunks_per_scan, nblk_pad;   // nblk_pad = chunks_per_scan * MJH_PSTAT_BLOCKS entries per pair

@@ -2072,13 +2072,13 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   // MJH_TRELLIS_VARIANT: queue capacity of the first tier (all bit-identical; LDS per wave = 10 * QN * 64 bytes);
   // second and third tier: blocks with more than QN (then 32) non-zero positions, from their dense copies
   if (st) {
-    switch (variant) { case 1: LQ(20, true); break; case 2: LQ(24, true); break; default: LQ(16, true); break; }
-    LD(32, true, 2048, worklist, worklist2);
-    LD(63, true, 1024, worklist2, (unsigned *)nullptr);
+    switch (variant) { case 1: LQ(20, true); break; case 2: LQ(24, true); break; case 3: LQ(32, true); break; default: LQ(16, true); break; }
+    if (variant == 3) LD(63, true, 2048, worklist, (unsigned *)nullptr);
+    else { LD(32, true, 2048, worklist, worklist2); LD(63, true, 1024, worklist2, (unsigned *)nullptr); }
   } else {
-    switch (variant) { case 1: LQ(20, false); break; case 2: LQ(24, false); break; default: LQ(16, false); break; }
-    LD(32, false, 2048, worklist, worklist2);
-    LD(63, false, 1024, worklist2, (unsigned *)nullptr);
+    switch (variant) { case 1: LQ(20, false); break; case 2: LQ(24, false); break; case 3: LQ(32, false); break; default: LQ(16, false); break; }
+    if (variant == 3) LD(63, false, 2048, worklist, (unsigned *)nullptr);
+    else { LD(32, false, 2048, worklist, worklist2); LD(63, false, 1024, worklist2, (unsigned *)nullptr); }
   }
 #undef LQ
 #undef LD

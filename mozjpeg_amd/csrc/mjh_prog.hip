@@ -618,133 +618,389 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
 }
 
 // =============================================================================================
-// Statistics of AC-FIRST scans without restart intervals, in parallel over the whole component.  Such a scan carries
-// only the EOB run from block to block, and for the statistics only the run LENGTHS matter: a non-empty block flushes
-// the run that precedes it = [trailing-zero flag of the previous non-empty block] + the all-zero blocks in between
-// (encode_mcu_AC_first jcphuff.c:648-745, emit_eobrun :409).  Workgroups take 2048-block chunks: block symbols and
-// the runs between non-empty blocks of the same chunk go to an LDS histogram; a chunk summary lets
-// k_prog_stats_resolve add the runs that cross chunk borders, the forced emissions at EOBRUN == 0x7FFF (:719) and
-// the run pending at the end of the scan (finish_pass_gather_phuff).  Same counts as the sequential walk.
+// Scans WITHOUT restart intervals, in parallel over the whole component ("parallel chain").
+//
+// A progressive scan looks like a sequence (EOB runs across blocks, buffered correction bits), but what one block
+// contributes depends on the blocks before it only through two numbers:
+//   AC first   : the LENGTH of the EOB run in front of a non-empty block (encode_mcu_AC_first jcphuff.c:648-745,
+//                emit_eobrun :409): run(j) = E(p) + (j - p - 1), p = previous non-empty block, E = "ends in zeros";
+//   AC refine  : that run length AND the number of correction bits buffered along the run (encode_mcu_AC_refine
+//                :918-1000): with T = exclusive prefix sum of the per-block trailing-correction-bit counts,
+//                be(j) = T[j] - T[p].  Block j writes [EOBRUN symbol][be(j) correction bits][own symbols]; a block i of the
+//                run writes its trailing bits at off(j) + size(symbol) + T[i] - T[p]   (tools/prototype_refine_parallel.py
+//                checks this against the sequential state machine, forced flushes included);
+//   DC first / refine : nothing at all (the predictor is the previous block's value, no coder state).
+// The forced flushes of the reference -- after a block that brings the pending run to 0x7FFF blocks (jcphuff.c:719) or
+// the buffered correction bits beyond 937 (:998) -- fit in as well: a forced flush after block i writes exactly what a
+// flush in front of a non-empty block i+1 would write, and leaves the coder in the state an empty block i+1 expects.  So
+// block i+1 is simply MARKED as a flush point (a non-empty block without symbols of its own): k_pp_cuts finds the marks of
+// every gap between two non-empty blocks by the greedy rule of the reference (binary search in T, one thread per gap).
+//
+// Work units are 2048-block chunks (DC scans: 2048 units = MCUs of an interleaved scan, blocks otherwise).
+//   statistics:  k_pp_stats   per block: symbols -> LDS histogram, non-empty / ends-in-zeros bitmaps, trailing-bit counts
+//                (prefix sum of the trailing-bit counts: the sequential coder's scan kernels)
+//                k_pp_carry   per pair: last non-empty block in front of every chunk; forced flushes of the final gap
+//                k_pp_cuts    per gap: forced-flush marks
+//                k_pp_runs    per flush point: run(j), be(j), EOBRUN symbol statistics
+//                k_pp_resolve per pair: runs that cross chunk borders, the run pending at the end
+//   encode:      k_pp_len     per block: bits = [EOBRUN symbol + be] + own symbols
+//                (prefix sum of the lengths)
+//                k_pp_write   per block: the bits at their offsets
+//                k_pp_finish  per pair: pending run, pad, size check
+// The statistics kernels leave bitmaps, runs, trailing counts and T behind: the encode kernels of the same phase reuse them.
 // =============================================================================================
-__global__ void __launch_bounds__(256)
-k_prog_stats_acfirst(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
-                     const MjhProgCtl *__restrict__ ctl, const int16_t *__restrict__ coef_q, MjhHuffTable *__restrict__ tabs,
-                     int slots_per_image, MjhProgChunk *__restrict__ chunks, int chunks_per_scan)
+enum { PP_DC_FIRST = 0, PP_DC_REFINE = 1, PP_AC_FIRST = 2, PP_AC_REFINE = 3 };
+__device__ __forceinline__ int pp_kind(const MjhProgScan &sc) { return sc.Ss == 0 ? (sc.Ah == 0 ? PP_DC_FIRST : PP_DC_REFINE) : (sc.Ah == 0 ? PP_AC_FIRST : PP_AC_REFINE); }
+
+// units of a scan: MCUs of an interleaved DC scan, blocks of the component otherwise
+__device__ __forceinline__ int pp_units(const MjhConst &C, const MjhProgScan &sc)
 {
-  __shared__ unsigned hist[256];
+  return sc.Ss == 0 && sc.ncomp > 1 ? C.mcus_per_row * C.mcu_rows : C.c[sc.comp[0]].nblk;
+}
+
+// the band of one block, all loads in flight together (only the 8-coefficient groups that overlap the band)
+#define PP_LOAD_BAND(x, qs, kstride, Ss, Se)                                                                         \
+  _Pragma("unroll") for (int g_ = 0; g_ < 8; g_++) {                                                                 \
+    if (8 * g_ + 7 >= (Ss) && 8 * g_ <= (Se)) {                                                                       \
+      _Pragma("unroll") for (int kk_ = 0; kk_ < 8; kk_++) { const int k_ = 8 * g_ + kk_; if (k_ >= 1) x[k_] = (int)(qs)[(size_t)k_ * (kstride)]; } \
+    } else {                                                                                                           \
+      _Pragma("unroll") for (int kk_ = 0; kk_ < 8; kk_++) x[8 * g_ + kk_] = 0;                                        \
+    }                                                                                                                  \
+  }
+
+// refinement-scan analysis of one block (encode_mcu_AC_refine :918-1000): masks of newly non-zero / already non-zero
+// positions, their sign / correction bits; own = bits of the block's own symbols incl. the correction bits flushed inside;
+// tail = correction bits still buffered behind its last symbol (positions tailm); SIZES: 0 = count symbols into hist
+struct PPRefine { unsigned long long newm, nzm, corrm, posm, tailm; int tail_cnt; bool ne, E; unsigned own; };
+template <bool COUNT>
+__device__ __forceinline__ PPRefine pp_refine_block(const int (&x)[64], int Ss, int Se, int Al, const unsigned char *s_size, unsigned *hist)
+{
+  PPRefine R;
+  R.newm = R.nzm = R.corrm = R.posm = R.tailm = 0; R.own = 0;
+#pragma unroll
+  for (int g = 0; g < 8; g++) if (8 * g + 7 >= Ss && 8 * g <= Se) {   // wave-uniform: only the groups of 8 that overlap the band
+#pragma unroll
+  for (int kk = 0; kk < 8; kk++) {
+    const int k = 8 * g + kk;
+    if (k >= 1 && k >= Ss && k <= Se) {
+      const int v = x[k];
+      const int a = (v < 0 ? -v : v) >> Al;
+      if (a == 1) { R.newm |= 1ull << k; if (v >= 0) R.posm |= 1ull << k; }
+      else if (a > 1) { R.nzm |= 1ull << k; if (a & 1) R.corrm |= 1ull << k; }
+    }
+  } }
+  R.ne = R.newm != 0;
+  const int EOBk = R.ne ? 63 - __builtin_clzll(R.newm) : -1;
+  int r = 0, prev = Ss - 1, BR = 0, flushed_below = Ss;
+  unsigned long long mm = R.newm | R.nzm;
+  while (mm) {
+    const int k = __builtin_ctzll(mm);
+    mm &= mm - 1;
+    r += k - prev - 1;
+    prev = k;
+    while (r > 15 && k <= EOBk) {
+      if (COUNT) atomicAdd(&hist[0xF0], 1u); else R.own += s_size[0xF0] + (unsigned)BR;
+      BR = 0; flushed_below = k; r -= 16;
+    }
+    if ((R.nzm >> k) & 1ull) { BR++; continue; }
+    const int sym = (r << 4) + 1;
+    if (COUNT) atomicAdd(&hist[sym], 1u); else R.own += s_size[sym] + 1u + (unsigned)BR;
+    BR = 0; flushed_below = k + 1; r = 0;
+  }
+  r += Se - prev;
+  R.tail_cnt = BR;
+  R.E = (r > 0) || (BR > 0);
+  R.tailm = flushed_below < 64 ? (R.nzm & ~((1ull << flushed_below) - 1ull)) : 0ull;
+  return R;
+}
+
+// previous non-empty block of block j inside a chunk bitmap (-1: none)
+__device__ __forceinline__ int pp_prev_ne(const unsigned long long *ne_bits, int j)
+{
+  int w = j >> 6;
+  unsigned long long m = ne_bits[w] & ((1ull << (j & 63)) - 1ull);
+  while (!m && w > 0) { w--; m = ne_bits[w]; }
+  return m ? w * 64 + 63 - __builtin_clzll(m) : -1;
+}
+__device__ __forceinline__ int pp_next_ne(const unsigned long long *ne_bits, int j)
+{
+  int w = j >> 6;
+  unsigned long long m = (j & 63) == 63 ? 0ull : (ne_bits[w] & ~((2ull << (j & 63)) - 1ull));
+  while (!m && w < MJH_PSTAT_BLOCKS / 64 - 1) { w++; m = ne_bits[w]; }
+  return m ? w * 64 + __builtin_ctzll(m) : -1;
+}
+
+__global__ void __launch_bounds__(64)
+k_pp_init(MjhProgPE pe, int npairs)
+{
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < npairs) { pe.info[i].final_run = 0; pe.info[i].final_be = 0; pe.info[i].fallback = 0; pe.info[i].corr_total = 0; }
+}
+
+__global__ void __launch_bounds__(256)
+k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
+           const MjhProgCtl *__restrict__ ctl, const int16_t *__restrict__ coef_q, MjhHuffTable *__restrict__ tabs,
+           int slots_per_image, MjhProgPE pe)
+{
+  __shared__ unsigned hist[4][256];   // DC scans: [table 0 / 1]; AC scans: four interleaved copies (the hot symbols serialise the LDS atomics)
   __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64], e_bits[MJH_PSTAT_BLOCKS / 64];
-  const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x;
+  __shared__ unsigned s_corr;
+  const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const size_t pair = (size_t)img * gridDim.y + li;
   const int sidx = scan_list[li];
   const MjhProgScan sc = scans[sidx];
-  const MjhComp cc = C.c[sc.comp[0]];
+  const int kind = pp_kind(sc);
+  const int nunits = pp_units(C, sc);
   const int cb = chunk * MJH_PSTAT_BLOCKS;
-  if (cb >= cc.nblk) return;
-  const int nb = min(MJH_PSTAT_BLOCKS, cc.nblk - cb);
+  if (cb >= nunits || kind == PP_DC_REFINE) return;
+  const int nb = min(MJH_PSTAT_BLOCKS, nunits - cb);
   const MjhProgCtl *ct = ctl + img;
   const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
-  const int Ss = sc.Ss, Se = sc.Se;
-  const int16_t *qc = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;
-  const int tid = threadIdx.x;
-  hist[tid] = 0;
+  const int16_t *qimg = coef_q + (size_t)img * C.coefs_per_image;
+  hist[0][tid] = 0; hist[1][tid] = 0; hist[2][tid] = 0; hist[3][tid] = 0;
   if (tid < MJH_PSTAT_BLOCKS / 64) { ne_bits[tid] = 0; e_bits[tid] = 0; }
+  if (tid == 0) s_corr = 0;
   __syncthreads();
-  unsigned my_ne = 0;   // bit i: my i-th block is non-empty
+
+  if (kind == PP_DC_FIRST) {
+    // encode_mcu_DC_first jcphuff.c:468-555: category of the difference to the previous block of the component in scan order
+    const bool inter = sc.ncomp > 1;
+    for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
+      const int u = cb + i * 256 + tid;
+      if (u >= nunits) break;
+      for (int ci = 0; ci < sc.ncomp; ci++) {
+        const MjhComp cc = C.c[sc.comp[ci]];
+        const int16_t *q0 = qimg + cc.coef_off;
+        const int tb = cc.dctbl & 1;
+        const int mh = inter ? cc.v : 1, mw = inter ? cc.h : 1;
+        for (int yi = 0; yi < mh; yi++)
+          for (int xi = 0; xi < mw; xi++) {
+            int dc, pred = 0;
+            if (inter) {
+              const int my = u / C.mcus_per_row, mx = u - my * C.mcus_per_row;
+              const int r = my * cc.v + yi, c = mx * cc.h + xi;
+              dc = q0[dc_source_block(cc, r, c)];
+              int pr = 0, pc = 0;
+              bool has = true;    // no restart intervals here: the predictor only starts at 0 in the first MCU
+              if (xi > 0) { pr = r; pc = c - 1; }
+              else if (yi > 0) { pr = r - 1; pc = c + cc.h - 1; }
+              else if (u == 0) has = false;
+              else { const int pm = u - 1, pmy = pm / C.mcus_per_row, pmx = pm - pmy * C.mcus_per_row; pr = pmy * cc.v + cc.v - 1; pc = pmx * cc.h + cc.h - 1; }
+              if (has) pred = q0[dc_source_block(cc, pr, pc)] >> Al;
+            } else {
+              dc = q0[u];
+              if (u > 0) pred = q0[u - 1] >> Al;
+            }
+            const int df = (dc >> Al) - pred;
+            atomicAdd(&hist[tb][bitlen((unsigned)(df < 0 ? -df : df))], 1u);
+          }
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int t = tid >> 4, sym = tid & 15;
+      if (sc.slot[t] >= 0 && hist[t][sym]) atomicAdd(&tabs[(size_t)img * slots_per_image + sc.slot[t]].counts[sym], hist[t][sym]);
+    }
+    return;
+  }
+
+  const MjhComp cc = C.c[sc.comp[0]];
+  const int Ss = sc.Ss, Se = sc.Se;
+  const bool refine = kind == PP_AC_REFINE;
+  const int16_t *qc = qimg + cc.coef_off;
+  uint16_t *tail = pe.tail16 + pair * pe.nblk_pad + cb;
+  unsigned corr = 0;
 #pragma unroll 1
   for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
     const int j = i * 256 + tid;
-    if (i * 256 >= nb) break;   // uniform
+    if (i * 256 >= nb) { if (refine) tail[j] = 0; continue; }   // uniform
     int x[64];
     const int16_t *qs = qc + cb + (j < nb ? j : nb - 1);
-    // only the 8-coefficient groups that overlap the band are fetched (wave-uniform branches; the loads of a group
-    // still go out together): the candidate scans of the search split the band, so this halves their traffic
-#pragma unroll
-    for (int g = 0; g < 8; g++) {
-      if (8 * g + 7 >= Ss && 8 * g <= Se) {
-#pragma unroll
-        for (int kk = 0; kk < 8; kk++) { const int k = 8 * g + kk; if (k >= 1) x[k] = (int)qs[(size_t)k * cc.kstride]; }
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < 8; kk++) x[8 * g + kk] = 0;
-      }
-    }
+    PP_LOAD_BAND(x, qs, cc.kstride, Ss, Se)
+    bool ne = false, E = false;
+    int tc = 0;
     if (j < nb) {
-      int r = 0;
-      bool ne = false;
+      if (!refine) {
+        int r = 0;
 #pragma unroll
-      for (int k = 1; k < 64; k++) {
-        if (k >= Ss && k <= Se) {
-          const int v = x[k];
-          const int a = (v < 0 ? -v : v) >> Al;
-          if (a == 0) r++;
-          else {
-            ne = true;
-            const int nz16 = r >> 4;
-            r &= 15;
-            if (nz16) atomicAdd(&hist[0xF0], (unsigned)nz16);
-            atomicAdd(&hist[(r << 4) + bitlen((unsigned)a)], 1u);
-            r = 0;
+        for (int g = 0; g < 8; g++) if (8 * g + 7 >= Ss && 8 * g <= Se) {   // wave-uniform: only the groups of 8 that overlap the band
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+          const int k = 8 * g + kk;
+          if (k >= 1 && k >= Ss && k <= Se) {
+            const int v = x[k];
+            const int a = (v < 0 ? -v : v) >> Al;
+            if (a == 0) r++;
+            else {
+              ne = true;
+              const int nz16 = r >> 4;
+              r &= 15;
+              if (nz16) atomicAdd(&hist[tid & 3][0xF0], (unsigned)nz16);
+              atomicAdd(&hist[tid & 3][(r << 4) + bitlen((unsigned)a)], 1u);
+              r = 0;
+            }
           }
-        }
+        } }
+        E = r > 0;
+      } else {
+        const PPRefine R = pp_refine_block<true>(x, Ss, Se, Al, nullptr, hist[tid & 3]);
+        ne = R.ne; E = R.E; tc = R.tail_cnt;
+        corr += (unsigned)__popcll(R.nzm);
       }
-      if (ne) { my_ne |= 1u << i; atomicOr(&ne_bits[j >> 6], 1ull << (j & 63)); }
-      if (r > 0) atomicOr(&e_bits[j >> 6], 1ull << (j & 63));
+      if (ne) atomicOr(&ne_bits[j >> 6], 1ull << (j & 63));
+      if (E) atomicOr(&e_bits[j >> 6], 1ull << (j & 63));
     }
+    if (refine) tail[j] = (uint16_t)tc;
   }
+  if (refine && corr) atomicAdd(&s_corr, corr);
   __syncthreads();
-  // runs between two non-empty blocks of this chunk
-  for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
-    if (!((my_ne >> i) & 1u)) continue;
-    const int j = i * 256 + tid;
-    int w = j >> 6;
-    unsigned long long m = ne_bits[w] & ((1ull << (j & 63)) - 1ull);
-    while (!m && w > 0) { w--; m = ne_bits[w]; }
-    if (m) {
-      const int p = w * 64 + 63 - __builtin_clzll(m);
-      const unsigned cnt = (unsigned)((e_bits[p >> 6] >> (p & 63)) & 1ull) + (unsigned)(j - p - 1);
-      if (cnt) { int nextra; atomicAdd(&hist[eobrun_symbol(cnt, &nextra)], 1u); }
-    }
+  if (tid < MJH_PSTAT_BLOCKS / 64) {
+    pe.ne_bits[(pair * pe.chunks_per_scan + chunk) * (MJH_PSTAT_BLOCKS / 64) + tid] = ne_bits[tid];
+    pe.ne2_bits[(pair * pe.chunks_per_scan + chunk) * (MJH_PSTAT_BLOCKS / 64) + tid] = ne_bits[tid];   // + forced-flush marks (k_pp_cuts)
+    pe.e_bits[(pair * pe.chunks_per_scan + chunk) * (MJH_PSTAT_BLOCKS / 64) + tid] = e_bits[tid];
   }
-  __syncthreads();
   if (tid == 0) {
     MjhProgChunk ch;
-    ch.first_ne = -1; ch.last_ne = -1; ch.e_last = 0; ch.nblk = nb;
+    ch.first_ne = -1; ch.last_ne = -1; ch.e_last = 0; ch.nblk = nb; ch.carry_p = -1; ch.carry_e = 0; ch.next_after = -1; ch.pad = 0;
     for (int w = 0; w < MJH_PSTAT_BLOCKS / 64; w++)
       if (ne_bits[w]) { ch.first_ne = w * 64 + __builtin_ctzll(ne_bits[w]); break; }
     for (int w = MJH_PSTAT_BLOCKS / 64 - 1; w >= 0; w--)
       if (ne_bits[w]) { ch.last_ne = w * 64 + 63 - __builtin_clzll(ne_bits[w]); break; }
     if (ch.last_ne >= 0) ch.e_last = (int)((e_bits[ch.last_ne >> 6] >> (ch.last_ne & 63)) & 1ull);
-    chunks[((size_t)img * gridDim.y + li) * chunks_per_scan + chunk] = ch;
+    pe.chunks[pair * pe.chunks_per_scan + chunk] = ch;
+    if (refine && s_corr) atomicAdd(&pe.info[pair].corr_total, s_corr);
   }
   MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
-  if (hist[tid]) atomicAdd(&T0->counts[tid], hist[tid]);
+  const unsigned hsum = hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid];
+  if (hsum) atomicAdd(&T0->counts[tid], hsum);
 }
 
+// T at index i of a pair (exclusive prefix sum of the trailing-bit counts); the entry behind the last unit is the total
+__device__ __forceinline__ unsigned pp_T(const MjhProgPE &pe, size_t pair, int i, bool refine)
+{
+  if (!refine) return 0u;
+  return i < pe.nblk_pad ? pe.T32[pair * pe.nblk_pad + i] : pe.ttotals[pair];
+}
+
+// forced flushes of the gap that starts accumulating at block a and ends in front of flush point j (j = number of blocks:
+// the end of the scan): the reference flushes after block i as soon as the run has 0x7FFF blocks or more than 937 buffered
+// bits (jcphuff.c:719,:998-1000); block i+1 becomes a flush point.  Greedy, as in the reference.
+__device__ __forceinline__ void pp_mark_cuts(const MjhProgPE &pe, size_t pair, int a, int j, bool refine)
+{
+  unsigned long long *ne2 = pe.ne2_bits + pair * pe.chunks_per_scan * (MJH_PSTAT_BLOCKS / 64);
+  while (a < j) {
+    int cut = a + 0x7FFF - 1;                       // the block that makes the run 0x7FFF long
+    if (refine) {
+      const unsigned Ta = pp_T(pe, pair, a, true);
+      if (pp_T(pe, pair, j, true) - Ta > 937u) {    // smallest i in [a, j-1] with T[i+1] - T[a] > 937
+        int lo = a, hi = j - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (pp_T(pe, pair, mid + 1, true) - Ta > 937u) hi = mid; else lo = mid + 1; }
+        cut = lo < cut ? lo : cut;
+      }
+    }
+    if (cut + 1 >= j) break;                        // a flush right in front of j happens anyway
+    a = cut + 1;
+    atomicOr(&ne2[a >> 6], 1ull << (a & 63));       // (word index over the whole pair: chunks are 32 consecutive words)
+  }
+}
+
+// per (scan, image) pair, before the marks: the last real non-empty block in front of every chunk; marks of the final gap
 __global__ void __launch_bounds__(64)
-k_prog_stats_resolve(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
-                     MjhHuffTable *__restrict__ tabs, int slots_per_image, const MjhProgChunk *__restrict__ chunks,
-                     int chunks_per_scan)
+k_pp_carry(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, MjhProgPE pe)
+{
+  const int img = blockIdx.y, li = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const size_t pair = (size_t)img * gridDim.x + li;
+  const MjhProgScan sc = scans[scan_list[li]];
+  const int kind = pp_kind(sc);
+  if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) return;
+  const MjhComp cc = C.c[sc.comp[0]];
+  const int nchunks = (cc.nblk + MJH_PSTAT_BLOCKS - 1) / MJH_PSTAT_BLOCKS;
+  MjhProgChunk *chs = pe.chunks + pair * pe.chunks_per_scan;
+  int last = -1, last_e = 0;
+  for (int c = 0; c < nchunks; c++) {
+    chs[c].carry_p = last; chs[c].carry_e = last_e;
+    if (chs[c].first_ne >= 0) { last = c * MJH_PSTAT_BLOCKS + chs[c].last_ne; last_e = chs[c].e_last; }
+  }
+  pp_mark_cuts(pe, pair, last < 0 ? 0 : (last_e ? last : last + 1), cc.nblk, kind == PP_AC_REFINE);
+}
+
+// one thread per real non-empty block: the gap in front of it
+__global__ void __launch_bounds__(256)
+k_pp_cuts(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, MjhProgPE pe)
+{
+  __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64], e_bits[MJH_PSTAT_BLOCKS / 64];
+  const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const size_t pair = (size_t)img * gridDim.y + li;
+  const MjhProgScan sc = scans[scan_list[li]];
+  const int kind = pp_kind(sc);
+  if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) return;
+  const MjhComp cc = C.c[sc.comp[0]];
+  const int cb = chunk * MJH_PSTAT_BLOCKS;
+  if (cb >= cc.nblk) return;
+  const MjhProgChunk ch = pe.chunks[pair * pe.chunks_per_scan + chunk];
+  if (ch.first_ne < 0) return;      // uniform: no real non-empty block here
+  if (tid < MJH_PSTAT_BLOCKS / 64) {
+    ne_bits[tid] = pe.ne_bits[(pair * pe.chunks_per_scan + chunk) * (MJH_PSTAT_BLOCKS / 64) + tid];
+    e_bits[tid] = pe.e_bits[(pair * pe.chunks_per_scan + chunk) * (MJH_PSTAT_BLOCKS / 64) + tid];
+  }
+  __syncthreads();
+  for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
+    const int j = i * 256 + tid;
+    if (!((ne_bits[j >> 6] >> (j & 63)) & 1ull)) continue;
+    const int p = pp_prev_ne(ne_bits, j);
+    int a;
+    if (p >= 0) a = cb + (((e_bits[p >> 6] >> (p & 63)) & 1ull) ? p : p + 1);
+    else a = ch.carry_p < 0 ? 0 : (ch.carry_e ? ch.carry_p : ch.carry_p + 1);
+    pp_mark_cuts(pe, pair, a, cb + j, kind == PP_AC_REFINE);
+  }
+}
+
+// per (scan, image) pair, after the marks: what crosses chunk borders.  One lane walks the chunks (at most a few dozen).
+__global__ void __launch_bounds__(64)
+k_pp_resolve(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
+             MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe)
 {
   const int img = blockIdx.y, li = blockIdx.x, lane = threadIdx.x;
+  const size_t pair = (size_t)img * gridDim.x + li;
   const MjhProgScan sc = scans[scan_list[li]];
+  const int kind = pp_kind(sc);
+  if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) return;
+  const bool refine = kind == PP_AC_REFINE;
   const MjhComp cc = C.c[sc.comp[0]];
   MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
   if (lane == 0) {
     const int nchunks = (cc.nblk + MJH_PSTAT_BLOCKS - 1) / MJH_PSTAT_BLOCKS;
-    const MjhProgChunk *chs = chunks + ((size_t)img * gridDim.x + li) * chunks_per_scan;
+    MjhProgChunk *chs = pe.chunks + pair * pe.chunks_per_scan;
+    uint16_t *run = pe.run16 + pair * pe.nblk_pad;
+    uint16_t *be16 = pe.be16 + pair * pe.nblk_pad;
     unsigned pending = 0;
-    int nextra;
+    int last = -1, last_e = 0, nextra;
     for (int c = 0; c < nchunks; c++) {
-      const MjhProgChunk ch = chs[c];
+      MjhProgChunk ch = chs[c];          // first_ne / last_ne / e_last: flush points of the chunk (k_pp_runs)
+      ch.carry_p = last; ch.carry_e = last_e;
       if (ch.first_ne >= 0) {
-        unsigned run = pending + (unsigned)ch.first_ne;
-        while (run >= 0x7FFFu) { T0->counts[eobrun_symbol(0x7FFFu, &nextra)] += 1; run -= 0x7FFFu; }   // forced emission at 0x7FFF
-        if (run) T0->counts[eobrun_symbol(run, &nextra)] += 1;
+        const int b = c * MJH_PSTAT_BLOCKS + ch.first_ne;
+        const unsigned r = pending + (unsigned)ch.first_ne;
+        run[b] = (uint16_t)r;
+        if (r) T0->counts[eobrun_symbol(r, &nextra)] += 1;
+        if (refine) be16[b] = (uint16_t)(pp_T(pe, pair, b, true) - (last >= 0 ? pp_T(pe, pair, last, true) : 0u));
+        last = c * MJH_PSTAT_BLOCKS + ch.last_ne; last_e = ch.e_last;
         pending = (unsigned)ch.e_last + (unsigned)(ch.nblk - 1 - ch.last_ne);
       } else
         pending += (unsigned)ch.nblk;
-      while (pending >= 0x7FFFu) { T0->counts[eobrun_symbol(0x7FFFu, &nextra)] += 1; pending -= 0x7FFFu; }
+      chs[c] = ch;
     }
     if (pending) T0->counts[eobrun_symbol(pending, &nextra)] += 1;
+    int nxt = -1;
+    for (int c = nchunks - 1; c >= 0; c--) {
+      chs[c].next_after = nxt;
+      if (chs[c].first_ne >= 0) nxt = c * MJH_PSTAT_BLOCKS + chs[c].first_ne;
+    }
+    pe.info[pair].final_run = pending;
+    pe.info[pair].final_be = refine ? pp_T(pe, pair, cc.nblk, true) - (last >= 0 ? pp_T(pe, pair, last, true) : 0u) : 0u;
+    T0->counts[256] = 0; T0->counts[257] = 0;
+    T0->counts[258] = refine ? pe.info[pair].corr_total : 0u;   // correction bits of the scan: needed to size its bit stream
   }
   __syncthreads();
   if (sc.seed)   // trellis passes: every (run, size < 12) count starts at 1 (jcphuff.c:257-264)
@@ -752,195 +1008,272 @@ k_prog_stats_resolve(MjhConst C, const MjhProgScan *__restrict__ scans, const in
       if ((i & 15) < 12) T0->counts[i] += 1;
 }
 
-// =============================================================================================
-// Parallel ENCODE of AC-first scans without restart intervals (same chunk scheme as the statistics above).  The bits
-// a block contributes = the EOBRUN symbol of the run in front of it (non-empty blocks only) + its own symbols, so:
-//   k_pe_len     per block: own bits, the run in front of it if the previous non-empty block is in the same chunk
-//   k_pe_resolve per (scan, image): the run carried into each chunk -> bits / run of the chunk's first non-empty block;
-//                a run that would reach 0x7FFF (forced emission, jcphuff.c:719) flags the pair for the sequential walk
-//   (prefix sum over the block lengths: the sequential coder's scan kernels)
-//   k_pe_write   per block: EOBRUN symbol + own symbols at its offset
-//   k_pe_finish  per (scan, image): the run pending at the end, the final pad, the size check
-// =============================================================================================
+// every flush point that is not the first of its chunk: the run and the correction bits in front of it, EOBRUN statistics
 __global__ void __launch_bounds__(256)
-k_pe_len(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl,
+k_pp_runs(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, MjhHuffTable *__restrict__ tabs,
+          int slots_per_image, MjhProgPE pe)
+{
+  __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64], e_bits[MJH_PSTAT_BLOCKS / 64];
+  __shared__ unsigned hist[16];       // EOBRUN symbols: (nbits - 1) << 4, nbits - 1 = 0..14
+  const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const size_t pair = (size_t)img * gridDim.y + li;
+  const MjhProgScan sc = scans[scan_list[li]];
+  const int kind = pp_kind(sc);
+  if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) return;
+  const bool refine = kind == PP_AC_REFINE;
+  const MjhComp cc = C.c[sc.comp[0]];
+  const int cb = chunk * MJH_PSTAT_BLOCKS;
+  if (cb >= cc.nblk) return;
+  if (tid < MJH_PSTAT_BLOCKS / 64) {
+    ne_bits[tid] = pe.ne2_bits[(pair * pe.chunks_per_scan + chunk) * (MJH_PSTAT_BLOCKS / 64) + tid];
+    e_bits[tid] = pe.e_bits[(pair * pe.chunks_per_scan + chunk) * (MJH_PSTAT_BLOCKS / 64) + tid];
+  }
+  if (tid < 16) hist[tid] = 0;
+  __syncthreads();
+  const unsigned *T = pe.T32 + pair * pe.nblk_pad + cb;
+  uint16_t *run = pe.run16 + pair * pe.nblk_pad + cb;
+  uint16_t *be16 = pe.be16 + pair * pe.nblk_pad + cb;
+  for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
+    const int j = i * 256 + tid;
+    if (!((ne_bits[j >> 6] >> (j & 63)) & 1ull)) continue;
+    const int p = pp_prev_ne(ne_bits, j);
+    if (p < 0) continue;                 // first of the chunk: k_pp_resolve
+    const unsigned cnt = (unsigned)((e_bits[p >> 6] >> (p & 63)) & 1ull) + (unsigned)(j - p - 1);
+    run[j] = (uint16_t)cnt;
+    if (refine) be16[j] = (uint16_t)(T[j] - T[p]);
+    if (cnt) { int nextra; atomicAdd(&hist[eobrun_symbol(cnt, &nextra) >> 4], 1u); }
+  }
+  __syncthreads();
+  if (tid < 16 && hist[tid]) atomicAdd(&tabs[(size_t)img * slots_per_image + sc.slot[0]].counts[tid << 4], hist[tid]);
+  if (tid == 0) {   // first / last flush point of the chunk (real non-empty blocks and forced-flush marks) for k_pp_resolve
+    MjhProgChunk *ch = pe.chunks + pair * pe.chunks_per_scan + chunk;
+    int first = -1, last = -1;
+    for (int w = 0; w < MJH_PSTAT_BLOCKS / 64; w++) if (ne_bits[w]) { first = w * 64 + __builtin_ctzll(ne_bits[w]); break; }
+    for (int w = MJH_PSTAT_BLOCKS / 64 - 1; w >= 0; w--) if (ne_bits[w]) { last = w * 64 + 63 - __builtin_clzll(ne_bits[w]); break; }
+    ch->first_ne = first; ch->last_ne = last;
+    ch->e_last = last >= 0 ? (int)((e_bits[last >> 6] >> (last & 63)) & 1ull) : 0;
+  }
+}
+
+// ---- encode -------------------------------------------------------------------------------------------------------
+// DC units: bits of one unit (all its blocks) / writing them
+template <bool WRITE>
+__device__ __forceinline__ unsigned pp_dc_unit(const MjhConst &C, const MjhProgScan &sc, const int16_t *qimg, int u, int Al,
+                                               const unsigned (*s_tab)[16], BitWriter *bw)
+{
+  const bool inter = sc.ncomp > 1;
+  unsigned bits = 0;
+  for (int ci = 0; ci < sc.ncomp; ci++) {
+    const MjhComp cc = C.c[sc.comp[ci]];
+    const int16_t *q0 = qimg + cc.coef_off;
+    const int tb = cc.dctbl & 1;
+    const int mh = inter ? cc.v : 1, mw = inter ? cc.h : 1;
+    for (int yi = 0; yi < mh; yi++)
+      for (int xi = 0; xi < mw; xi++) {
+        int dc, pred = 0;
+        if (inter) {
+          const int my = u / C.mcus_per_row, mx = u - my * C.mcus_per_row;
+          const int r = my * cc.v + yi, c = mx * cc.h + xi;
+          dc = q0[dc_source_block(cc, r, c)];
+          if (sc.Ah == 0) {
+            int pr = 0, pc = 0;
+            bool has = true;
+            if (xi > 0) { pr = r; pc = c - 1; }
+            else if (yi > 0) { pr = r - 1; pc = c + cc.h - 1; }
+            else if (u == 0) has = false;
+            else { const int pm = u - 1, pmy = pm / C.mcus_per_row, pmx = pm - pmy * C.mcus_per_row; pr = pmy * cc.v + cc.v - 1; pc = pmx * cc.h + cc.h - 1; }
+            if (has) pred = q0[dc_source_block(cc, pr, pc)] >> Al;
+          }
+        } else {
+          dc = q0[u];
+          if (sc.Ah == 0 && u > 0) pred = q0[u - 1] >> Al;
+        }
+        if (sc.Ah == 0) {
+          const int df = (dc >> Al) - pred;
+          const int nb = bitlen((unsigned)(df < 0 ? -df : df));
+          const unsigned e = s_tab[tb][nb];
+          if (!WRITE) bits += (e >> 16) + (unsigned)nb;
+          else { bw->put(e & 0xFFFF, (int)(e >> 16)); if (nb) bw->put((unsigned)(df < 0 ? df - 1 : df), nb); }
+        } else {
+          if (!WRITE) bits += 1; else bw->put((unsigned)(dc >> Al) & 1u, 1);
+        }
+      }
+  }
+  return bits;
+}
+
+__global__ void __launch_bounds__(256)
+k_pp_len(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl,
          const int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe)
 {
   __shared__ unsigned char s_size[256];
-  __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64], e_bits[MJH_PSTAT_BLOCKS / 64];
+  __shared__ unsigned s_dc[2][16];
   const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const size_t pair = (size_t)img * gridDim.y + li;
   const int sidx = scan_list[li];
   const MjhProgScan sc = scans[sidx];
-  const MjhComp cc = C.c[sc.comp[0]];
+  const int kind = pp_kind(sc);
+  const int nunits = pp_units(C, sc);
   const int cb = chunk * MJH_PSTAT_BLOCKS;
   uint16_t *len = pe.len16 + pair * pe.nblk_pad + cb;
-  uint16_t *run = pe.run16 + pair * pe.nblk_pad + cb;
-  if (cb >= cc.nblk) {        // padding of the length array behind the component: contributes nothing to the prefix sum
+  if (cb >= nunits) {         // padding of the length array behind the scan's units: contributes nothing to the prefix sum
     for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) len[i * 256 + tid] = 0;
     return;
   }
-  const int nb = min(MJH_PSTAT_BLOCKS, cc.nblk - cb);
+  const int nb = min(MJH_PSTAT_BLOCKS, nunits - cb);
   const MjhProgCtl *ct = ctl + img;
   const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
+  const int16_t *qimg = coef_q + (size_t)img * C.coefs_per_image;
+  if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) {
+    if (tid < 32) {
+      const int t = tid >> 4, sym = tid & 15;
+      const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + (sc.slot[t] >= 0 ? sc.slot[t] : 0);
+      s_dc[t][sym] = sc.slot[t] >= 0 && kind == PP_DC_FIRST ? ((unsigned)T->ehufsi[sym] << 16) | T->ehufco[sym] : 0u;
+    }
+    __syncthreads();
+    for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
+      const int j = i * 256 + tid;
+      len[j] = j < nb ? (uint16_t)pp_dc_unit<false>(C, sc, qimg, cb + j, Al, s_dc, nullptr) : (uint16_t)0;
+    }
+    return;
+  }
+  const MjhComp cc = C.c[sc.comp[0]];
   const int Ss = sc.Ss, Se = sc.Se;
+  const bool refine = kind == PP_AC_REFINE;
   const MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
-  const int16_t *qc = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;
+  const int16_t *qc = qimg + cc.coef_off;
+  const uint16_t *run = pe.run16 + pair * pe.nblk_pad + cb;
+  const uint16_t *be16 = pe.be16 + pair * pe.nblk_pad + cb;
+  __shared__ unsigned long long fp_bits[MJH_PSTAT_BLOCKS / 64];   // flush points: real non-empty blocks + forced-flush marks
+  __shared__ unsigned long long rn_bits[MJH_PSTAT_BLOCKS / 64];   // real non-empty blocks (from the statistics pass of this phase)
   s_size[tid] = T0->ehufsi[tid];
-  if (tid < MJH_PSTAT_BLOCKS / 64) { ne_bits[tid] = 0; e_bits[tid] = 0; }
+  if (tid < MJH_PSTAT_BLOCKS / 64) {
+    fp_bits[tid] = pe.ne2_bits[(pair * pe.chunks_per_scan + chunk) * (MJH_PSTAT_BLOCKS / 64) + tid];
+    rn_bits[tid] = pe.ne_bits[(pair * pe.chunks_per_scan + chunk) * (MJH_PSTAT_BLOCKS / 64) + tid];
+  }
   __syncthreads();
-  unsigned my_ne = 0;
 #pragma unroll 1
   for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
     const int j = i * 256 + tid;
     if (i * 256 >= nb) { len[j] = 0; continue; }   // uniform
+    // a wave whose 64 blocks are all empty (sparse bands, refinement scans) has no symbols to size: skip its plane loads
+    const bool has_own = j < nb && ((rn_bits[j >> 6] >> (j & 63)) & 1ull);
     int x[64];
-    const int16_t *qs = qc + cb + (j < nb ? j : nb - 1);
-    // only the 8-coefficient groups that overlap the band are fetched (wave-uniform branches; the loads of a group
-    // still go out together): the candidate scans of the search split the band, so this halves their traffic
+    if (__builtin_amdgcn_ballot_w64(has_own) != 0ull) {
+      const int16_t *qs = qc + cb + (j < nb ? j : nb - 1);
+      PP_LOAD_BAND(x, qs, cc.kstride, Ss, Se)
+    } else {
 #pragma unroll
-    for (int g = 0; g < 8; g++) {
-      if (8 * g + 7 >= Ss && 8 * g <= Se) {
-#pragma unroll
-        for (int kk = 0; kk < 8; kk++) { const int k = 8 * g + kk; if (k >= 1) x[k] = (int)qs[(size_t)k * cc.kstride]; }
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < 8; kk++) x[8 * g + kk] = 0;
-      }
+      for (int k = 0; k < 64; k++) x[k] = 0;
     }
     unsigned own = 0;
-    if (j < nb) {
-      int r = 0;
-      bool ne = false;
+    bool ne = false;
+    if (has_own) {
+      if (!refine) {
+        int r = 0;
 #pragma unroll
-      for (int k = 1; k < 64; k++) {
-        if (k >= Ss && k <= Se) {
-          const int v = x[k];
-          const int a = (v < 0 ? -v : v) >> Al;
-          if (a == 0) r++;
-          else {
-            ne = true;
-            const int nz16 = r >> 4;
-            r &= 15;
-            const int nbits = bitlen((unsigned)a);
-            own += (unsigned)nz16 * s_size[0xF0] + s_size[(r << 4) + nbits] + (unsigned)nbits;
-            r = 0;
+        for (int g = 0; g < 8; g++) if (8 * g + 7 >= Ss && 8 * g <= Se) {   // wave-uniform: only the groups of 8 that overlap the band
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+          const int k = 8 * g + kk;
+          if (k >= 1 && k >= Ss && k <= Se) {
+            const int v = x[k];
+            const int a = (v < 0 ? -v : v) >> Al;
+            if (a == 0) r++;
+            else {
+              ne = true;
+              const int nz16 = r >> 4;
+              r &= 15;
+              const int nbits = bitlen((unsigned)a);
+              own += (unsigned)nz16 * s_size[0xF0] + s_size[(r << 4) + nbits] + (unsigned)nbits;
+              r = 0;
+            }
           }
-        }
+        } }
+      } else {
+        const PPRefine R = pp_refine_block<false>(x, Ss, Se, Al, s_size, nullptr);
+        ne = R.ne; own = R.own;
       }
-      if (ne) { my_ne |= 1u << i; atomicOr(&ne_bits[j >> 6], 1ull << (j & 63)); }
-      else own = 0;
-      if (r > 0) atomicOr(&e_bits[j >> 6], 1ull << (j & 63));
-      run[j] = 0;
+      if (!ne) own = 0;
+    }
+    if (j < nb && ((fp_bits[j >> 6] >> (j & 63)) & 1ull)) {     // the pending run (+ its buffered correction bits) goes out in front of this block
+      const unsigned cnt = run[j];
+      if (cnt) { int nextra; const int sym = eobrun_symbol(cnt, &nextra); own += s_size[sym] + (unsigned)nextra + (refine ? be16[j] : 0u); }
     }
     len[j] = (uint16_t)own;
   }
-  __syncthreads();
-  for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
-    if (!((my_ne >> i) & 1u)) continue;
-    const int j = i * 256 + tid;
-    int w = j >> 6;
-    unsigned long long m = ne_bits[w] & ((1ull << (j & 63)) - 1ull);
-    while (!m && w > 0) { w--; m = ne_bits[w]; }
-    if (m) {
-      const int p = w * 64 + 63 - __builtin_clzll(m);
-      const unsigned cnt = (unsigned)((e_bits[p >> 6] >> (p & 63)) & 1ull) + (unsigned)(j - p - 1);
-      run[j] = (uint16_t)cnt;
-      if (cnt) { int nextra; const int sym = eobrun_symbol(cnt, &nextra); len[j] = (uint16_t)(len[j] + s_size[sym] + nextra); }
-    } else
-      run[j] = 0xFFFFu;    // first non-empty block of the chunk: the run comes from k_pe_resolve
-  }
-  __syncthreads();
-  if (tid == 0) {
-    MjhProgChunk ch;
-    ch.first_ne = -1; ch.last_ne = -1; ch.e_last = 0; ch.nblk = nb;
-    for (int w = 0; w < MJH_PSTAT_BLOCKS / 64; w++)
-      if (ne_bits[w]) { ch.first_ne = w * 64 + __builtin_ctzll(ne_bits[w]); break; }
-    for (int w = MJH_PSTAT_BLOCKS / 64 - 1; w >= 0; w--)
-      if (ne_bits[w]) { ch.last_ne = w * 64 + 63 - __builtin_clzll(ne_bits[w]); break; }
-    if (ch.last_ne >= 0) ch.e_last = (int)((e_bits[ch.last_ne >> 6] >> (ch.last_ne & 63)) & 1ull);
-    pe.chunks[pair * pe.chunks_per_scan + chunk] = ch;
-  }
-}
-
-__global__ void __launch_bounds__(64)
-k_pe_resolve(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
-             const MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe)
-{
-  if (threadIdx.x != 0) return;
-  const int img = blockIdx.y, li = blockIdx.x;
-  const size_t pair = (size_t)img * gridDim.x + li;
-  const MjhProgScan sc = scans[scan_list[li]];
-  const MjhComp cc = C.c[sc.comp[0]];
-  const MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
-  const int nchunks = (cc.nblk + MJH_PSTAT_BLOCKS - 1) / MJH_PSTAT_BLOCKS;
-  const MjhProgChunk *chs = pe.chunks + pair * pe.chunks_per_scan;
-  uint16_t *len = pe.len16 + pair * pe.nblk_pad;
-  uint16_t *run = pe.run16 + pair * pe.nblk_pad;
-  unsigned pending = 0;
-  int fallback = 0;
-  for (int c = 0; c < nchunks && !fallback; c++) {
-    const MjhProgChunk ch = chs[c];
-    if (ch.first_ne >= 0) {
-      const unsigned r = pending + (unsigned)ch.first_ne;
-      if (r >= 0x7FFFu) { fallback = 1; break; }
-      const size_t b = (size_t)c * MJH_PSTAT_BLOCKS + ch.first_ne;
-      run[b] = (uint16_t)r;
-      if (r) { int nextra; const int sym = eobrun_symbol(r, &nextra); len[b] = (uint16_t)(len[b] + T0->ehufsi[sym] + nextra); }
-      pending = (unsigned)ch.e_last + (unsigned)(ch.nblk - 1 - ch.last_ne);
-    } else
-      pending += (unsigned)ch.nblk;
-    if (pending >= 0x7FFFu) fallback = 1;
-  }
-  pe.info[pair].final_run = pending;
-  pe.info[pair].fallback = fallback;
 }
 
 __global__ void __launch_bounds__(256)
-k_pe_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl,
+k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl,
            const int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
            unsigned *__restrict__ pool, size_t pool_words_per_image, MjhProgPE pe)
 {
   __shared__ unsigned s_tab[256];   // size << 16 | code
+  __shared__ unsigned s_dc[2][16];
+  __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64];
   const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const size_t pair = (size_t)img * gridDim.y + li;
   const int sidx = scan_list[li];
   const MjhProgScan sc = scans[sidx];
-  const MjhComp cc = C.c[sc.comp[0]];
+  const int kind = pp_kind(sc);
+  const int nunits = pp_units(C, sc);
   const int cb = chunk * MJH_PSTAT_BLOCKS;
   const MjhProgCtl *ct = ctl + img;
-  if (cb >= cc.nblk || pe.info[pair].fallback || ct->error) return;
-  const int nb = min(MJH_PSTAT_BLOCKS, cc.nblk - cb);
+  if (cb >= nunits || ct->error) return;
+  const int nb = min(MJH_PSTAT_BLOCKS, nunits - cb);
   const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
-  const int Ss = sc.Ss, Se = sc.Se;
-  const MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
-  const int16_t *qc = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;
+  const int16_t *qimg = coef_q + (size_t)img * C.coefs_per_image;
   unsigned *stream = pool + (size_t)img * pool_words_per_image;
   const unsigned base = ct->scan_words_off[sidx] * 32u;
   const uint16_t *len = pe.len16 + pair * pe.nblk_pad + cb;
-  const uint16_t *run = pe.run16 + pair * pe.nblk_pad + cb;
   const unsigned *off = pe.off32 + pair * pe.nblk_pad + cb;
+  if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) {
+    if (tid < 32) {
+      const int t = tid >> 4, sym = tid & 15;
+      const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + (sc.slot[t] >= 0 ? sc.slot[t] : 0);
+      s_dc[t][sym] = sc.slot[t] >= 0 && kind == PP_DC_FIRST ? ((unsigned)T->ehufsi[sym] << 16) | T->ehufco[sym] : 0u;
+    }
+    __syncthreads();
+    for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
+      const int j = i * 256 + tid;
+      if (j >= nb) break;
+      BitWriter bw;
+      bw.init(stream, base + off[j]);
+      pp_dc_unit<true>(C, sc, qimg, cb + j, Al, s_dc, &bw);
+      bw.flush();
+    }
+    return;
+  }
+  const MjhComp cc = C.c[sc.comp[0]];
+  const int Ss = sc.Ss, Se = sc.Se;
+  const bool refine = kind == PP_AC_REFINE;
+  const MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
+  const int16_t *qc = qimg + cc.coef_off;
+  const uint16_t *run = pe.run16 + pair * pe.nblk_pad + cb;
+  const uint16_t *be16 = pe.be16 + pair * pe.nblk_pad + cb;
+  const unsigned *T = pe.T32 + pair * pe.nblk_pad;          // pair-global index
+  const unsigned *offg = pe.off32 + pair * pe.nblk_pad;
+  const uint16_t *rung = pe.run16 + pair * pe.nblk_pad;
+  const MjhProgChunk ch = pe.chunks[pair * pe.chunks_per_scan + chunk];
   s_tab[tid] = ((unsigned)T0->ehufsi[tid] << 16) | T0->ehufco[tid];
+  if (tid < MJH_PSTAT_BLOCKS / 64) ne_bits[tid] = pe.ne2_bits[(pair * pe.chunks_per_scan + chunk) * (MJH_PSTAT_BLOCKS / 64) + tid];   // flush points
   __syncthreads();
 #pragma unroll 1
   for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
     const int j = i * 256 + tid;
     if (i * 256 >= nb) break;   // uniform
+    // blocks without symbols or trailing correction bits of their own need no coefficients: a wave of such blocks skips the loads
+    const bool has_data = j < nb && (len[j] != 0 || (refine && pe.tail16[pair * pe.nblk_pad + cb + j] != 0));
     int x[64];
-    const int16_t *qs = qc + cb + (j < nb ? j : nb - 1);
-    // only the 8-coefficient groups that overlap the band are fetched (wave-uniform branches; the loads of a group
-    // still go out together): the candidate scans of the search split the band, so this halves their traffic
-#pragma unroll
-    for (int g = 0; g < 8; g++) {
-      if (8 * g + 7 >= Ss && 8 * g <= Se) {
-#pragma unroll
-        for (int kk = 0; kk < 8; kk++) { const int k = 8 * g + kk; if (k >= 1) x[k] = (int)qs[(size_t)k * cc.kstride]; }
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < 8; kk++) x[8 * g + kk] = 0;
-      }
-    }
-    if (j < nb && len[j] != 0) {          // non-empty block (its own symbols alone are at least one bit)
+    if (__builtin_amdgcn_ballot_w64(has_data) != 0ull) {
+      const int16_t *qs = qc + cb + (j < nb ? j : nb - 1);
+      PP_LOAD_BAND(x, qs, cc.kstride, Ss, Se)
+    } else continue;
+    if (!has_data) continue;
+    const bool flush_point = (ne_bits[j >> 6] >> (j & 63)) & 1ull;
+    if (!refine) {
+      if (len[j] == 0) continue;          // nothing to write (a non-empty block has at least one bit of its own)
       BitWriter bw;
       bw.init(stream, base + off[j]);
       const unsigned cnt = run[j];
@@ -952,8 +1285,11 @@ k_pe_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
       }
       int r = 0;
 #pragma unroll
-      for (int k = 1; k < 64; k++) {
-        if (k >= Ss && k <= Se) {
+      for (int g = 0; g < 8; g++) if (8 * g + 7 >= Ss && 8 * g <= Se) {   // wave-uniform: only the groups of 8 that overlap the band
+#pragma unroll
+      for (int kk = 0; kk < 8; kk++) {
+        const int k = 8 * g + kk;
+        if (k >= 1 && k >= Ss && k <= Se) {
           const int v = x[k];
           const int a = (v < 0 ? -v : v) >> Al;
           if (a == 0) r++;
@@ -966,14 +1302,90 @@ k_pe_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
             r = 0;
           }
         }
+      } }
+      bw.flush();
+      continue;
+    }
+    // ---- refinement scan
+    const PPRefine R = pp_refine_block<false>(x, Ss, Se, Al, reinterpret_cast<const unsigned char *>(s_tab), nullptr);   // (own bits unused here)
+    if (flush_point) {
+      BitWriter bw;
+      bw.init(stream, base + off[j]);
+      const unsigned cnt = run[j];
+      unsigned flush = 0;
+      if (cnt) {
+        int nextra;
+        const unsigned e = s_tab[eobrun_symbol(cnt, &nextra)];
+        bw.put(e & 0xFFFF, (int)(e >> 16));
+        if (nextra) bw.put(cnt & ((1u << nextra) - 1u), nextra);
+        bw.flush();
+        flush = (e >> 16) + (unsigned)nextra + be16[j];
       }
+      if (!R.ne) goto tails;                    // a forced-flush mark: no symbols of its own
+      bw.init(stream, base + off[j] + flush);   // the buffered correction bits of the run lie in between (written by their blocks)
+      const int EOBk = 63 - __builtin_clzll(R.newm);
+      int r = 0, prev = Ss - 1, fb = Ss;
+      unsigned long long mm = R.newm | R.nzm;
+      auto put_corr = [&](int lo, int hi) {   // correction bits of already-nonzero positions in [lo, hi)
+        unsigned long long m = R.nzm & ~((1ull << lo) - 1ull);
+        if (hi < 64) m &= (1ull << hi) - 1ull;
+        while (m) { const int k = __builtin_ctzll(m); m &= m - 1; bw.put((unsigned)((R.corrm >> k) & 1ull), 1); }
+      };
+      while (mm) {
+        const int k = __builtin_ctzll(mm);
+        mm &= mm - 1;
+        r += k - prev - 1;
+        prev = k;
+        while (r > 15 && k <= EOBk) {
+          const unsigned e = s_tab[0xF0];
+          bw.put(e & 0xFFFF, (int)(e >> 16));
+          put_corr(fb, k);
+          fb = k; r -= 16;
+        }
+        if ((R.nzm >> k) & 1ull) continue;
+        const unsigned e = s_tab[(r << 4) + 1];
+        bw.put(e & 0xFFFF, (int)(e >> 16));
+        bw.put((unsigned)((R.posm >> k) & 1ull), 1);
+        put_corr(fb, k);
+        fb = k + 1; r = 0;
+      }
+      bw.flush();
+    }
+  tails:
+    if (R.tail_cnt > 0) {
+      // my trailing correction bits belong to the run that the NEXT non-empty block (or the end of the scan) flushes:
+      // they go behind that flush's EOBRUN symbol, at the distance T[me] - T[first block of the run]
+      const int gj = cb + j;
+      int start = flush_point ? gj : -2;
+      if (start == -2) { const int p = pp_prev_ne(ne_bits, j); start = p >= 0 ? cb + p : ch.carry_p; }
+      int nxt = pp_next_ne(ne_bits, j);
+      nxt = nxt >= 0 ? cb + nxt : ch.next_after;
+      const unsigned rel = T[gj] - (start >= 0 ? T[start] : 0u);
+      unsigned where;
+      int nextra;
+      if (nxt >= 0) {
+        const unsigned e = s_tab[eobrun_symbol(rung[nxt], &nextra)];
+        where = base + offg[nxt] + (e >> 16) + (unsigned)nextra + rel;
+      } else {
+        const unsigned e = s_tab[eobrun_symbol(pe.info[pair].final_run, &nextra)];
+        where = base + pe.totals[pair] + (e >> 16) + (unsigned)nextra + rel;
+      }
+      unsigned long long tail_bits = 0;
+      {
+        unsigned long long tm = R.tailm;
+        while (tm) { const int k = __builtin_ctzll(tm); tm &= tm - 1; tail_bits = (tail_bits << 1) | ((R.corrm >> k) & 1ull); }
+      }
+      BitWriter bw;
+      bw.init(stream, where);
+      put_long(bw, (unsigned)(tail_bits >> 32), R.tail_cnt > 32 ? R.tail_cnt - 32 : 0);
+      put_long(bw, (unsigned)tail_bits, R.tail_cnt > 32 ? 32 : R.tail_cnt);
       bw.flush();
     }
   }
 }
 
 __global__ void __launch_bounds__(64)
-k_pe_finish(const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, MjhProgCtl *__restrict__ ctl,
+k_pp_finish(const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, MjhProgCtl *__restrict__ ctl,
             const MjhHuffTable *__restrict__ tabs, int slots_per_image, unsigned *__restrict__ pool, size_t pool_words_per_image,
             MjhProgPE pe)
 {
@@ -983,21 +1395,23 @@ k_pe_finish(const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_
   const int sidx = scan_list[li];
   const MjhProgScan sc = scans[sidx];
   MjhProgCtl *ct = ctl + img;
-  if (pe.info[pair].fallback || ct->error) return;
-  const MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
+  if (ct->error) return;
   unsigned *stream = pool + (size_t)img * pool_words_per_image;
   const unsigned base = ct->scan_words_off[sidx] * 32u;
   unsigned cur = base + pe.totals[pair];
-  const unsigned fr = pe.info[pair].final_run;
-  if (fr) {     // finish_pass_phuff: the run still pending at the end of the scan
-    int nextra;
-    const int sym = eobrun_symbol(fr, &nextra);
-    BitWriter bw;
-    bw.init(stream, cur);
-    bw.put(T0->ehufco[sym], (int)T0->ehufsi[sym]);
-    if (nextra) bw.put(fr & ((1u << nextra) - 1u), nextra);
-    bw.flush();
-    cur += (unsigned)T0->ehufsi[sym] + (unsigned)nextra;
+  if (sc.Ss != 0) {
+    const MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
+    const unsigned fr = pe.info[pair].final_run;
+    if (fr) {     // finish_pass_phuff: the run still pending at the end of the scan (+ its buffered correction bits, already in place)
+      int nextra;
+      const int sym = eobrun_symbol(fr, &nextra);
+      BitWriter bw;
+      bw.init(stream, cur);
+      bw.put(T0->ehufco[sym], (int)T0->ehufsi[sym]);
+      if (nextra) bw.put(fr & ((1u << nextra) - 1u), nextra);
+      bw.flush();
+      cur += (unsigned)T0->ehufsi[sym] + (unsigned)nextra + pe.info[pair].final_be;
+    }
   }
   const unsigned tb = cur - base;
   if (tb & 7u) {   // flush_bits jcphuff.c:362-367: pad the last byte with 1-bits
@@ -1122,69 +1536,89 @@ k_prog_header(const MjhProgScan *__restrict__ scans, const int *__restrict__ sca
   }
 }
 
-// byte stuffing of one scan's bit stream into its buffer; one workgroup per (scan, image)
+// byte stuffing of one scan's bit stream into its buffer: PROG_STUFF_SPLIT workgroups per (scan, image), each takes an
+// equal share of the scan's words; k_prog_stuff_count leaves the number of stuffed zero bytes of every share behind so
+// that k_prog_stuff knows where its share starts in the output
+#define PROG_STUFF_SPLIT 8
+__device__ __forceinline__ bool prog_is_marker(const unsigned *mp, int nrst, unsigned pos)
+{ // the 0xFF of an RSTn marker is not entropy-coded data: no zero byte behind it (binary search in the sorted positions)
+  int lo = 0, hi = nrst - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const unsigned v = mp[mid];
+    if (v == pos) return true;
+    if (v < pos) lo = mid + 1; else hi = mid - 1;
+  }
+  return false;
+}
+__device__ __forceinline__ void prog_stuff_share(unsigned nwords, int part, unsigned &w0, unsigned &w1)
+{
+  const unsigned per = (((nwords + PROG_STUFF_SPLIT - 1) / PROG_STUFF_SPLIT) + 2047u) & ~2047u;   // whole 2048-word rounds
+  w0 = min(nwords, per * (unsigned)part);
+  w1 = min(nwords, per * (unsigned)(part + 1));
+}
+
+template <bool WRITE>
 __global__ void __launch_bounds__(256)
 k_prog_stuff(const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, MjhProgCtl *__restrict__ ctl,
              const unsigned *__restrict__ pool, size_t pool_words_per_image, uint8_t *__restrict__ outpool,
-             size_t out_bytes_per_image, const unsigned *__restrict__ mpos_pool, int mpos_per_image)
+             size_t out_bytes_per_image, const unsigned *__restrict__ mpos_pool, int mpos_per_image, unsigned *__restrict__ ffsums)
 {
   __shared__ unsigned sh[4];
-  const int img = blockIdx.y;
-  const int sidx = scan_list[blockIdx.x];
+  const int img = blockIdx.z, li = blockIdx.y, part = blockIdx.x;
+  const int sidx = scan_list[li];
   MjhProgCtl *ct = ctl + img;
   const int nrst = scans[sidx].nrst;
   const unsigned *mp = mpos_pool + (size_t)img * mpos_per_image + scans[sidx].mpos_off;
-  // the 0xFF of an RSTn marker is not entropy-coded data: no zero byte behind it (binary search in the sorted positions)
-  auto is_marker = [&](unsigned pos) {
-    int lo = 0, hi = nrst - 1;
-    while (lo <= hi) {
-      const int mid = (lo + hi) >> 1;
-      const unsigned v = mp[mid];
-      if (v == pos) return true;
-      if (v < pos) lo = mid + 1; else hi = mid - 1;
-    }
-    return false;
-  };
+  unsigned *fs = ffsums + ((size_t)img * gridDim.y + li) * PROG_STUFF_SPLIT;
   if (ct->error) return;
   const unsigned nbytes = (ct->scan_bits[sidx] + 7) >> 3;
   const unsigned nwords = (nbytes + 3) >> 2;
+  unsigned w0, w1;
+  prog_stuff_share(nwords, part, w0, w1);
   const unsigned *p = pool + (size_t)img * pool_words_per_image + ct->scan_words_off[sidx];
   const unsigned hdr = ct->scan_hdr_len[sidx];
   uint8_t *o = outpool + (size_t)img * out_bytes_per_image + ct->scan_out_off[sidx] + hdr;
   unsigned carry = 0;
-  for (unsigned cb = 0; cb < nwords; cb += 2048) {
+  if (WRITE) for (int q = 0; q < part; q++) carry += fs[q];
+  for (unsigned cb = w0; cb < w1; cb += 2048) {
     const unsigned base = cb + threadIdx.x * 8;
     unsigned w[8], s = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      w[i] = base + i < nwords ? p[base + i] : 0u;
+      w[i] = base + i < w1 ? p[base + i] : 0u;
       s += ((w[i] & 0xFFu) == 0xFFu) + ((w[i] & 0xFF00u) == 0xFF00u) + ((w[i] & 0xFF0000u) == 0xFF0000u) + ((w[i] & 0xFF000000u) == 0xFF000000u);
       if (nrst) {
 #pragma unroll
         for (int b = 0; b < 4; b++)
-          if (((w[i] >> (8 * b)) & 0xFFu) == 0xFFu && is_marker((base + i) * 4 + b)) s--;
+          if (((w[i] >> (8 * b)) & 0xFFu) == 0xFFu && prog_is_marker(mp, nrst, (base + i) * 4 + b)) s--;
       }
     }
     unsigned tot;
     unsigned ex = block_excl_scan_256(s, sh, &tot) + carry;
+    if (WRITE) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const unsigned wi = base + i;
-      if (wi < nwords) {
-        unsigned dst = wi * 4 + ex;
+      for (int i = 0; i < 8; i++) {
+        const unsigned wi = base + i;
+        if (wi < w1) {
+          unsigned dst = wi * 4 + ex;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-          const unsigned byte = (w[i] >> (8 * b)) & 0xFF;
-          if (wi * 4 + b < nbytes) {
-            o[dst++] = (uint8_t)byte;
-            if (byte == 0xFF && !(nrst && is_marker(wi * 4 + b))) { o[dst++] = 0; ex++; }
+          for (int b = 0; b < 4; b++) {
+            const unsigned byte = (w[i] >> (8 * b)) & 0xFF;
+            if (wi * 4 + b < nbytes) {
+              o[dst++] = (uint8_t)byte;
+              if (byte == 0xFF && !(nrst && prog_is_marker(mp, nrst, wi * 4 + b))) { o[dst++] = 0; ex++; }
+            }
           }
         }
       }
     }
     carry += tot;
   }
-  if (threadIdx.x == 0) ct->scan_size[sidx] = hdr + nbytes + carry;
+  if (threadIdx.x == 0) {
+    if (!WRITE) fs[part] = carry;
+    else if (part == PROG_STUFF_SPLIT - 1) ct->scan_size[sidx] = hdr + nbytes + carry;
+  }
 }
 
 // ---- scan search decisions: select_scans jcmaster.c:773-962 with the constants of
@@ -1325,28 +1759,34 @@ void mjh_launch_prog_stats(const MjhConst &C, const void *scans, const int *list
                      (const int16_t *)q, tabs, spi, (unsigned *)nullptr, (size_t)0, mpos, mpos_per_image, (const MjhProgPair *)nullptr);
 }
 
-void mjh_launch_prog_stats_acfirst(const MjhConst &C, const void *scans, const int *list, int nlist, const void *ctl, const void *q,
-                                   MjhHuffTable *tabs, int spi, void *chunks, int chunks_per_scan, int n, hipStream_t s)
+// statistics of the parallel chain (every scan of the list has no restart interval)
+void mjh_launch_prog_stats_par(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
+                               MjhHuffTable *tabs, int spi, const MjhProgPE &pe, bool any_refine, int n, hipStream_t s)
 {
   if (nlist <= 0) return;
-  hipLaunchKernelGGL(k_prog_stats_acfirst, dim3(chunks_per_scan, nlist, n), dim3(256), 0, s, C, (const MjhProgScan *)scans, list,
-                     (const MjhProgCtl *)ctl, (const int16_t *)q, tabs, spi, (MjhProgChunk *)chunks, chunks_per_scan);
-  hipLaunchKernelGGL(k_prog_stats_resolve, dim3(nlist, n), dim3(64), 0, s, C, (const MjhProgScan *)scans, list, tabs, spi,
-                     (const MjhProgChunk *)chunks, chunks_per_scan);
+  const dim3 gchunks(pe.chunks_per_scan, nlist, n), gpairs(nlist, n);
+  hipLaunchKernelGGL(k_pp_init, dim3((nlist * n + 63) / 64), dim3(64), 0, s, pe, nlist * n);
+  hipLaunchKernelGGL(k_pp_stats, gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, (const MjhProgCtl *)ctl, (const int16_t *)q,
+                     tabs, spi, pe);
+  if (any_refine) mjh_launch_scan16(pe.tail16, pe.nblk_pad, pe.tsums, pe.chunks_per_scan, pe.ttotals, pe.T32, nlist * n, s);
+  hipLaunchKernelGGL(k_pp_carry, gpairs, dim3(64), 0, s, C, (const MjhProgScan *)scans, list, pe);
+  hipLaunchKernelGGL(k_pp_cuts, gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, pe);
+  hipLaunchKernelGGL(k_pp_runs, gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, tabs, spi, pe);
+  hipLaunchKernelGGL(k_pp_resolve, gpairs, dim3(64), 0, s, C, (const MjhProgScan *)scans, list, tabs, spi, pe);
 }
 
 void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *list, int nlist, const int *seq_list, int nseq,
                             const int *par_list, int npar, const MjhProgPE &pe, void *ctl, const void *q,
                             MjhHuffTable *tabs, int spi, unsigned *pool, size_t pool_words, const void *frame_hdr, int frame_hdr_len,
-                            int multi_dht, void *outpool, size_t out_bytes, unsigned *mpos, int mpos_per_image, int n, hipStream_t s,
+                            int multi_dht, void *outpool, size_t out_bytes, unsigned *mpos, int mpos_per_image, unsigned *ffsums, int n, hipStream_t s,
                             hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join)
 {
   hipLaunchKernelGGL(k_prog_alloc, dim3(n), dim3(256), 0, s, C, (const MjhProgScan *)scans, list, nlist, (MjhProgCtl *)ctl,
                      (const MjhHuffTable *)tabs, spi, pool_words, out_bytes, n);
   hipLaunchKernelGGL(k_prog_header, dim3(nlist, n), dim3(64), 0, s, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
                      (const MjhHuffTable *)tabs, spi, (const uint8_t *)frame_hdr, frame_hdr_len, multi_dht, (uint8_t *)outpool, out_bytes);
-  // the sequential walks (a few long workgroups) and the parallel chain write disjoint scan streams: the chain runs on
-  // the side stream underneath them
+  // the sequential walks (scans with restart intervals: a few long workgroups) and the parallel chain write disjoint scan
+  // streams: the chain runs on the side stream underneath them
   const bool both = nseq > 0 && npar > 0;
   hipStream_t ps = s;
   if (both) {
@@ -1354,27 +1794,25 @@ void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *lis
     (void)hipStreamWaitEvent(side, ev_fork, 0);
     ps = side;
   }
-  if (npar > 0) {   // AC-first scans: parallel over the whole component
+  if (npar > 0) {
     const dim3 gchunks(pe.chunks_per_scan, npar, n), gpairs(npar, n);
-    hipLaunchKernelGGL(k_pe_len, gchunks, dim3(256), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhProgCtl *)ctl, (const int16_t *)q,
+    hipLaunchKernelGGL(k_pp_len, gchunks, dim3(256), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhProgCtl *)ctl, (const int16_t *)q,
                        (const MjhHuffTable *)tabs, spi, pe);
-    hipLaunchKernelGGL(k_pe_resolve, gpairs, dim3(64), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhHuffTable *)tabs, spi, pe);
     mjh_launch_scan16(pe.len16, pe.nblk_pad, pe.sums, pe.chunks_per_scan, pe.totals, pe.off32, npar * n, ps);
-    hipLaunchKernelGGL(k_pe_write, gchunks, dim3(256), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhProgCtl *)ctl, (const int16_t *)q,
+    hipLaunchKernelGGL(k_pp_write, gchunks, dim3(256), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhProgCtl *)ctl, (const int16_t *)q,
                        (const MjhHuffTable *)tabs, spi, pool, pool_words, pe);
-    hipLaunchKernelGGL(k_pe_finish, gpairs, dim3(64), 0, ps, (const MjhProgScan *)scans, par_list, (MjhProgCtl *)ctl, (const MjhHuffTable *)tabs, spi,
+    hipLaunchKernelGGL(k_pp_finish, gpairs, dim3(64), 0, ps, (const MjhProgScan *)scans, par_list, (MjhProgCtl *)ctl, (const MjhHuffTable *)tabs, spi,
                        pool, pool_words, pe);
-    // pairs with a forced emission inside (an EOB run of 32767 blocks): the sequential walk, others return at once
-    hipLaunchKernelGGL((k_prog_scan<1>), dim3(n, npar), dim3(64 * PROG_WAVES(1)), 0, ps, C, (const MjhProgScan *)scans, par_list, (MjhProgCtl *)ctl,
-                       (const int16_t *)q, tabs, spi, pool, pool_words, mpos, mpos_per_image, (const MjhProgPair *)pe.info);
   }
   if (both) (void)hipEventRecord(ev_join, side);
-  if (nseq > 0)     // DC, refinement and restart-interval scans: the sequential walk
+  if (nseq > 0)     // scans with restart intervals: the sequential walk
     hipLaunchKernelGGL((k_prog_scan<1>), dim3(n, nseq), dim3(64 * PROG_WAVES(1)), 0, s, C, (const MjhProgScan *)scans, seq_list, (MjhProgCtl *)ctl,
                        (const int16_t *)q, tabs, spi, pool, pool_words, mpos, mpos_per_image, (const MjhProgPair *)nullptr);
   if (both) (void)hipStreamWaitEvent(s, ev_join, 0);
-  hipLaunchKernelGGL(k_prog_stuff, dim3(nlist, n), dim3(256), 0, s, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl, (const unsigned *)pool,
-                     pool_words, (uint8_t *)outpool, out_bytes, (const unsigned *)mpos, mpos_per_image);
+  hipLaunchKernelGGL((k_prog_stuff<false>), dim3(PROG_STUFF_SPLIT, nlist, n), dim3(256), 0, s, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl, (const unsigned *)pool,
+                     pool_words, (uint8_t *)outpool, out_bytes, (const unsigned *)mpos, mpos_per_image, ffsums);
+  hipLaunchKernelGGL((k_prog_stuff<true>), dim3(PROG_STUFF_SPLIT, nlist, n), dim3(256), 0, s, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl, (const unsigned *)pool,
+                     pool_words, (uint8_t *)outpool, out_bytes, (const unsigned *)mpos, mpos_per_image, ffsums);
 }
 
 void mjh_launch_prog_select(void *ctl, int ncomp, int phase, int n, hipStream_t s)
