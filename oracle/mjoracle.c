@@ -146,7 +146,7 @@ static mjo_scan *fill_dc_scans(mjo_scan *s, int ncomps, int Ah, int Al)
   return s + 1;
 }
 
-/* jpeg_simple_progression, jcparam.c:859-1004, max-compression profile, dc_scan_opt_mode 0 */
+/* jpeg_simple_progression, jcparam.c:859-1004 (dc_scan_opt_mode :887-892, :934-947) */
 void mjo_simple_progression(mjo_params *p)
 {
   mjo_scan *s = p->scans;
@@ -162,7 +162,16 @@ void mjo_simple_progression(mjo_params *p)
     for (ci = 0; ci < nc; ci++) s = fill_a_scan(s, ci, 1, 63, 1, 0);
   } else if (nc == 3) {
     if (!p->fastest_profile) {
-      s = fill_dc_scans(s, nc, 0, 0);
+      if (p->dc_scan_opt_mode == 0) s = fill_dc_scans(s, nc, 0, 0);          /* one DC scan for all components */
+      else if (p->dc_scan_opt_mode == 1) {                                   /* one per component */
+        s = fill_a_scan(s, 0, 0, 0, 0, 0);
+        s = fill_a_scan(s, 1, 0, 0, 0, 0);
+        s = fill_a_scan(s, 2, 0, 0, 0, 0);
+      } else {                                                               /* luma, then Cb+Cr interleaved (fill_a_scan_pair) */
+        s = fill_dc_scans(s, 1, 0, 0);
+        s->comps_in_scan = 2; s->component_index[0] = 1; s->component_index[1] = 2;
+        s->Ss = s->Se = s->Ah = s->Al = 0; s++;
+      }
       s = fill_a_scan(s, 0, 1, 8, 0, 2);
       s = fill_a_scan(s, 1, 1, 8, 0, 0);
       s = fill_a_scan(s, 2, 1, 8, 0, 0);
@@ -202,7 +211,7 @@ void mjo_simple_progression(mjo_params *p)
   p->num_scans = (int)(s - p->scans);
 }
 
-/* jpeg_search_progression, jcparam.c:733-852 (dc_scan_opt_mode 0) */
+/* jpeg_search_progression, jcparam.c:733-852 (dc_scan_opt_mode :791-794: scan 0 is the luma DC alone unless mode 0) */
 void mjo_search_progression(mjo_params *p)
 {
   static const int fs[5] = { 2, 8, 5, 12, 18 };
@@ -210,7 +219,7 @@ void mjo_search_progression(mjo_params *p)
   int Al, i, nc = p->num_components;
   if (nc == 3 && p->rgb_output) { mjo_simple_progression(p); return; }   /* the search knows YCbCr and gray only (jcparam.c:749-757) */
   p->optimize_scans = 1;
-  s = fill_dc_scans(s, nc, 0, 0);
+  s = fill_dc_scans(s, p->dc_scan_opt_mode == 0 ? nc : 1, 0, 0);
   s = fill_a_scan(s, 0, 1, 8, 0, 0);
   s = fill_a_scan(s, 0, 9, 63, 0, 0);
   for (Al = 0; Al < 3; Al++) {
@@ -250,6 +259,16 @@ void mjo_search_progression(mjo_params *p)
     }
   }
   p->num_scans = (int)(s - p->scans);
+}
+
+void mjo_set_dc_scan_opt_mode(mjo_params *p, int mode)
+{ /* jcext.c:192, then what cjpeg does next: jpeg_simple_progression (cjpeg.c:747-749), which builds the search script
+   * when optimize_scans is on (jcparam.c:866-869) */
+  p->dc_scan_opt_mode = mode;
+  if (p->num_scans > 0) {
+    if (p->optimize_scans) mjo_search_progression(p);
+    else mjo_simple_progression(p);
+  }
 }
 
 /* initial_setup, jcmaster.c:163-259; per_scan_setup :561-566; jccoefct.c:587-601 (padding) */
@@ -1089,6 +1108,20 @@ static void trellis_component(enc_t *e, int ci, const dtbl *dctbl, const dtbl *a
           dist = (float)(delta * delta) * lambda_dc;
           cnd *= 1 + 2 * sign;
           cand_dc[k][bi] = (int16_t)cnd;
+          if (br % v != 0 && p->trellis_delta_dc_weight > 0.0f) {
+            /* :1069-1084: the block above exists only inside an iMCU row (compress_trellis_pass jccoefct.c:426-427 hands
+             * over buffer[block_row-1], NULL for the first row); its quantized DC is final (that row's DC trellis ran) */
+            const int dc_above_orig = e->uq[ci][((size_t)(br - 1) * g->wpad + bi) * 64];
+            const int dc_above_recon = e->q[ci][((size_t)(br - 1) * g->wpad + bi) * 64] * q;
+            const int dc_orig = src[0];
+            const int dc_recon = cnd * q;
+            float vertical_dist, t;
+            delta = (dc_above_orig - dc_orig) - (dc_above_recon - dc_recon);
+            vertical_dist = (float)(delta * delta) * lambda_dc;
+            t = vertical_dist - dist;
+            t = p->trellis_delta_dc_weight * t;
+            dist = dist + t;
+          }
           if (bi == 0) {
             dc_delta = cnd - last_dc;
             bits = nbits_of((unsigned)(dc_delta < 0 ? -dc_delta : dc_delta));
@@ -1669,7 +1702,7 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
     const int chroma_fs_start = nsl + nsc_dc + (6 * Al_max_chroma + 4); /* 42 */
     unsigned long best_cost = 0;
     int best_Al_luma = 0, best_Al_chroma = 0, best_fs_luma = 0, best_fs_chroma = 0;
-    int sn = 0, i, Al, min_Al, base;
+    int sn = 0, i, Al, min_Al, base, interleave_chroma_dc = 0;
     memset(sb, 0, sizeof(sb));
     memset(size, 0, sizeof(size));
     while (sn < p->num_scans) {
@@ -1703,7 +1736,7 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
         }
       } else if (p->num_scans > nsl) {
         if (next == nsl + nsc_dc) {
-          /* interleave_chroma_dc decision only matters for dc_scan_opt_mode != 0 */
+          interleave_chroma_dc = size[nsl] <= size[nsl + 1] + size[nsl + 2];   /* jcmaster.c:836-838 */
         } else if (next > nsl + nsc_dc && next <= chroma_fs_start) {
           base = nsl + nsc_dc;
           if ((next - base) % 6 == 4) {
@@ -1732,6 +1765,10 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
     /* final assembly, jcmaster.c:898-956 */
     min_Al = best_Al_luma < best_Al_chroma ? best_Al_luma : best_Al_chroma;
     bb_append(&o, &sb[0]);
+    if (p->num_scans > nsl && p->dc_scan_opt_mode != 0) {   /* :904-913 */
+      if (interleave_chroma_dc && p->dc_scan_opt_mode != 1) bb_append(&o, &sb[nsl]);
+      else { bb_append(&o, &sb[nsl + 1]); bb_append(&o, &sb[nsl + 2]); }
+    }
     if (best_fs_luma == 0) bb_append(&o, &sb[luma_fs_start]);
     else {
       bb_append(&o, &sb[luma_fs_start + 2 * (best_fs_luma - 1) + 1]);

@@ -65,9 +65,17 @@ typedef struct {
   int trellis_freq_split;         /* JINT_TRELLIS_FREQ_SPLIT (0 is read as the default 8, jcparam.c:512) */
   int rgb_output;                 /* jpeg_color_space JCS_RGB (cjpeg -rgb): null_convert jccolor.c:479, Adobe APP14 instead of JFIF APP0,
                                    * all-purpose progressive script; set it through mjo_set_rgb_output */
+  float trellis_delta_dc_weight;  /* JFLOAT_TRELLIS_DELTA_DC_WEIGHT (cjpeg -trellis-dc-ver-weight): the DC trellis mixes the vertical-gradient
+                                   * error against the block above of the same iMCU row into the candidate distortion, jcdctmgr.c:1069-1084 */
+  int dc_scan_opt_mode;           /* JINT_DC_SCAN_OPT_MODE (cjpeg -dc-scan-opt N): 0 one DC scan for all components, 1 one per component,
+                                   * 2 luma alone + chroma by the scan search's choice (jcparam.c:791,887-940, jcmaster.c:836-838,905-913);
+                                   * set it through mjo_set_dc_scan_opt_mode (it rebuilds the script) */
 } mjo_params;
 /* jpeg_set_colorspace(cinfo, JCS_RGB) (jcparam.c:611-619): three 1x1 components 'R' 'G' 'B', tables 0, no JFIF marker */
 void mjo_set_rgb_output(mjo_params *p);
+/* jpeg_c_set_int_param(JINT_DC_SCAN_OPT_MODE) followed by the script builder the parameters already selected
+ * (jpeg_simple_progression or jpeg_search_progression; nothing to rebuild for a sequential file) */
+void mjo_set_dc_scan_opt_mode(mjo_params *p, int mode);
 
 /* jpeg_set_defaults + jpeg_set_quality + colorspace defaults, as cjpeg would leave them:
  * profile_fastest=0 is the max-compression profile (jcparam.c:386-519).

@@ -63,6 +63,8 @@ int main(int argc, char **argv)
   int notrellis = 0, notrellis_dc = 0, noovershoot = 0, gray = 0, rgbout = 0, grayin = 0, qtbl = -1;
   int hs = 2, vs = 2, restart = 0, restart_blocks = 0, reps = 1, rawW = 0, rawH = 0;
   double l1 = -1e9, l2 = -1e9;
+  int dc_scan_opt = -1;
+  double dc_ver_weight = -1e9;
   int precision = 8, yuvin = 0, trellis_loops = 0, smooth = 0, trellis_q_opt = 0, eob_opt = 0, scans_in_trellis = 0, freq_split = 0;
   const char *dump = NULL, *in = NULL, *out = NULL;
   int i, w, h, nc;
@@ -103,6 +105,8 @@ int main(int argc, char **argv)
     else if (!strcmp(a, "-use-scans-in-trellis")) scans_in_trellis = 1;   /* JBOOLEAN_USE_SCANS_IN_TRELLIS */
     else if (!strcmp(a, "-trellis-freq-split")) freq_split = atoi(argv[++i]);   /* JINT_TRELLIS_FREQ_SPLIT */
     else if (!strcmp(a, "-trellis-q-opt")) trellis_q_opt = 1;   /* JBOOLEAN_TRELLIS_Q_OPT: API-only parameter */
+    else if (!strcmp(a, "-dc-scan-opt")) dc_scan_opt = atoi(argv[++i]);   /* cjpeg -dc-scan-opt N (cjpeg.c:494-499) */
+    else if (!strcmp(a, "-trellis-dc-ver-weight")) dc_ver_weight = atof(argv[++i]);   /* cjpeg.c:667-672 */
     else if (!strcmp(a, "-smooth")) smooth = atoi(argv[++i]);   /* cjpeg -smooth N (cjpeg.c: cinfo->smoothing_factor) */
     else if (!strcmp(a, "-yuvin")) yuvin = 1;   /* -raw W H input holds component planes: jpeg_write_raw_data */
     else if (!in) in = a;
@@ -155,6 +159,8 @@ int main(int argc, char **argv)
     if (baseline) { cinfo.num_scans = 0; cinfo.scan_info = NULL; }
     if (optimize) cinfo.optimize_coding = TRUE;
     if (fastcrush) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_OPTIMIZE_SCANS, FALSE);
+    if (dc_scan_opt >= 0) jpeg_c_set_int_param(&cinfo, JINT_DC_SCAN_OPT_MODE, dc_scan_opt);   /* a switch: before the script is rebuilt */
+    if (dc_ver_weight > -1e8) jpeg_c_set_float_param(&cinfo, JFLOAT_TRELLIS_DELTA_DC_WEIGHT, (float)dc_ver_weight);
     /* cjpeg.c re-runs jpeg_simple_progression after all colourspace switches (simple_progressive
      * is TRUE by default in the max-compression profile, cjpeg.c:345-347,:767-768) */
     if (progressive || fastcrush || (!revert && !baseline)) jpeg_simple_progression(&cinfo);

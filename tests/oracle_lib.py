@@ -34,7 +34,7 @@ class Params(C.Structure):
                 ("write_jfif", C.c_int), ("data_precision", C.c_int), ("trellis_num_loops", C.c_int),
                 ("smoothing_factor", C.c_int), ("trellis_q_opt", C.c_int),
                 ("trellis_eob_opt", C.c_int), ("use_scans_in_trellis", C.c_int), ("trellis_freq_split", C.c_int),
-                ("rgb_output", C.c_int)]
+                ("rgb_output", C.c_int), ("trellis_delta_dc_weight", C.c_float), ("dc_scan_opt_mode", C.c_int)]
 
 
 class Geom(C.Structure):
@@ -73,7 +73,8 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 progressive=False, fastcrush=False, notrellis=False, notrellis_dc=False,
                 noovershoot=False, sample=(2, 2), restart=None, gray=False, grayin=False,
                 quant_table=-1, lambda1=None, lambda2=None, precision=8, trellis_loops=1, smooth=0, trellis_q_opt=False,
-                trellis_eob_opt=False, use_scans_in_trellis=False, trellis_freq_split=0, rgb=False):
+                trellis_eob_opt=False, use_scans_in_trellis=False, trellis_freq_split=0, rgb=False,
+                dc_scan_opt=None, dc_ver_weight=None):
     """Same switch vocabulary as cjpeg / oracle/refenc.c.  Default (no switch) is cjpeg's default:
     max-compression profile, progressive with scan search."""
     p = Params()
@@ -101,6 +102,10 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     p.trellis_freq_split = trellis_freq_split
     if rgb:
         L.mjo_set_rgb_output(C.byref(p))
+    if dc_ver_weight is not None:
+        p.trellis_delta_dc_weight = dc_ver_weight
+    if dc_scan_opt is not None:
+        p.dc_scan_opt_mode = dc_scan_opt      # read by the script builders below
     if restart is not None:
         if isinstance(restart, str) and restart.lower().endswith("b"):
             p.restart_interval = int(restart[:-1])
@@ -307,6 +312,10 @@ def ref_switches(**kw):
         sw += ["-trellis-freq-split", str(kw["trellis_freq_split"])]
     if kw.get("smooth", 0):
         sw += ["-smooth", str(kw["smooth"])]
+    if kw.get("dc_scan_opt") is not None:
+        sw += ["-dc-scan-opt", str(kw["dc_scan_opt"])]
+    if kw.get("dc_ver_weight") is not None:
+        sw += ["-trellis-dc-ver-weight", repr(float(kw["dc_ver_weight"]))]
     if kw.get("trellis_loops", 1) != 1:
         sw += ["-trellis-loops", str(kw["trellis_loops"])]
     return sw
