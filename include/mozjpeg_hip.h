@@ -97,6 +97,24 @@ typedef struct {
    * components unconverted (null_convert jccolor.c:479, JCS_RGB output = `cjpeg -rgb`; an Adobe APP14 marker with
    * transform 0 replaces the JFIF APP0, component ids are whatever component_id[] says, 'R' 'G' 'B' for cjpeg) */
   int color_transform;
+  /* JINT_DC_SCAN_OPT_MODE (jpeglib.h:349, cjpeg -dc-scan-opt N; library default 0, jcparam.c:495): 0 = one DC scan for
+   * all components, 1 = one DC scan per component, 2 = luma alone, then chroma interleaved or separate -- with the scan
+   * search whichever is smaller (jcmaster.c:836-838, :904-913).  mjh_params_simple_progression /
+   * mjh_params_search_progression read it when they build the script (jcparam.c:791-794, :934-947); the encoder
+   * reads it for the scan search's final choice of the chroma DC scans. */
+  int dc_scan_opt_mode;
+  /* JFLOAT_TRELLIS_DELTA_DC_WEIGHT (jpeglib.h:337, cjpeg -trellis-dc-ver-weight W; default 0): weight of the
+   * vertical-gradient error against the block above (same iMCU row) in the DC trellis (jcdctmgr.c:1069-1084) */
+  float trellis_delta_dc_weight;
+  /* JBOOLEAN_USE_SCANS_IN_TRELLIS + JINT_TRELLIS_FREQ_SPLIT (jpeglib.h:326,344; split 0 is read as the default 8):
+   * two (statistics, trellis) pass pairs per component, AC bands 1..split and split+1..63 (jcmaster.c:451-460) */
+  int use_scans_in_trellis, trellis_freq_split;
+  /* JBOOLEAN_TRELLIS_EOB_OPT (jpeglib.h:325): end-of-band runs over all-zero blocks chosen by a second dynamic
+   * programme along each block row (jcdctmgr.c:1224-1297) */
+  int trellis_eob_opt;
+  /* JBOOLEAN_TRELLIS_Q_OPT (jpeglib.h:327): quantization tables re-estimated from the trellis result
+   * (sums jcdctmgr.c:1299-1306, update jcmaster.c:1014-1030) */
+  int trellis_q_opt;
 } mjh_params;
 
 #define MJH_COLOR_YCC  0

@@ -45,7 +45,10 @@ class Params(C.Structure):
                 ("restart_interval", C.c_uint), ("restart_in_rows", C.c_int), ("num_scans", C.c_int),
                 ("scan_info", Scan * MAX_SCANS), ("optimize_scans", C.c_int), ("write_JFIF_header", C.c_int),
                 ("input_pixel_size", C.c_int), ("rgb_offset", C.c_int * 3), ("data_precision", C.c_int),
-                ("trellis_num_loops", C.c_int), ("smoothing_factor", C.c_int), ("color_transform", C.c_int)]
+                ("trellis_num_loops", C.c_int), ("smoothing_factor", C.c_int), ("color_transform", C.c_int),
+                ("dc_scan_opt_mode", C.c_int), ("trellis_delta_dc_weight", C.c_float),
+                ("use_scans_in_trellis", C.c_int), ("trellis_freq_split", C.c_int),
+                ("trellis_eob_opt", C.c_int), ("trellis_q_opt", C.c_int)]
 
 
 class Result(C.Structure):
@@ -111,7 +114,9 @@ def _chk(rc):
 def make_params(width, height, *, quality=75, baseline=False, revert=False, optimize=False,
                 notrellis=False, notrellis_dc=False, noovershoot=False, sample=(2, 2), gray=False,
                 grayin=False, quant_table=-1, lambda1=None, lambda2=None, restart=None,
-                progressive=False, fastcrush=False, precision=8, trellis_loops=1, smooth=0, rgb=False):
+                progressive=False, fastcrush=False, precision=8, trellis_loops=1, smooth=0, rgb=False,
+                dc_scan_opt=None, dc_ver_weight=None, use_scans_in_trellis=False, trellis_freq_split=0,
+                trellis_eob_opt=False, trellis_q_opt=False):
     """Parameters with cjpeg's switch vocabulary (cjpeg.c:371-714).  Without `baseline` or
     `revert` this is cjpeg's default: progressive with scan search (`fastcrush`: fixed 9-scan script)."""
     p = Params()
@@ -134,6 +139,14 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     p.data_precision = precision
     p.trellis_num_loops = trellis_loops
     p.smoothing_factor = smooth
+    if dc_scan_opt is not None:
+        p.dc_scan_opt_mode = dc_scan_opt        # read by the script builders below
+    if dc_ver_weight is not None:
+        p.trellis_delta_dc_weight = dc_ver_weight
+    p.use_scans_in_trellis = 1 if use_scans_in_trellis else 0
+    p.trellis_freq_split = trellis_freq_split
+    p.trellis_eob_opt = 1 if trellis_eob_opt else 0
+    p.trellis_q_opt = 1 if trellis_q_opt else 0
     if rgb:   # cjpeg -rgb: jpeg_set_colorspace(JCS_RGB) (jcparam.c:611-619): all components 1x1 / table 0, ids 'R' 'G' 'B', no JFIF
         p.color_transform = COLOR_NONE
         p.write_JFIF_header = 0

@@ -251,12 +251,15 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
   p->lambda_log_scale2 = jpeg_c_get_float_param(cinfo, JFLOAT_LAMBDA_LOG_SCALE2);
   if (no_pixels == 2) p->trellis_quant = p->trellis_quant_dc = p->overshoot_deringing = 0;   /* no trellis passes when transcoding (jcmaster.c transcode_only) */
   if (cinfo->data_precision == 12 && p->trellis_quant) return "12-bit trellis (the reference itself aborts: jccoefct.c:132-138)";
-  if (jpeg_c_get_bool_param(cinfo, JBOOLEAN_TRELLIS_EOB_OPT)) return "trellis_eob_opt";
-  if (jpeg_c_get_bool_param(cinfo, JBOOLEAN_USE_SCANS_IN_TRELLIS)) return "use_scans_in_trellis";
-  if (jpeg_c_get_bool_param(cinfo, JBOOLEAN_TRELLIS_Q_OPT)) return "trellis_q_opt";
+  /* the remaining extension parameters travel as they are; mjh_encoder_create refuses what the device path lacks */
+  p->trellis_eob_opt = jpeg_c_get_bool_param(cinfo, JBOOLEAN_TRELLIS_EOB_OPT);
+  p->use_scans_in_trellis = jpeg_c_get_bool_param(cinfo, JBOOLEAN_USE_SCANS_IN_TRELLIS);
+  p->trellis_freq_split = jpeg_c_get_int_param(cinfo, JINT_TRELLIS_FREQ_SPLIT);
+  p->trellis_q_opt = jpeg_c_get_bool_param(cinfo, JBOOLEAN_TRELLIS_Q_OPT);
+  p->trellis_delta_dc_weight = jpeg_c_get_float_param(cinfo, JFLOAT_TRELLIS_DELTA_DC_WEIGHT);
+  p->dc_scan_opt_mode = jpeg_c_get_int_param(cinfo, JINT_DC_SCAN_OPT_MODE);
   p->trellis_num_loops = jpeg_c_get_int_param(cinfo, JINT_TRELLIS_NUM_LOOPS);
   if (p->trellis_num_loops < 1 || p->trellis_num_loops > 16) return "trellis_num_loops outside 1..16";
-  if (jpeg_c_get_float_param(cinfo, JFLOAT_TRELLIS_DELTA_DC_WEIGHT) != 0.0f) return "trellis_delta_dc_weight";
   if (p->trellis_quant && !p->optimize_coding) return "trellis without optimize_coding";
   p->restart_interval = cinfo->restart_interval;
   p->restart_in_rows = cinfo->restart_in_rows;
@@ -276,7 +279,6 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
     }
     p->optimize_scans = jpeg_c_get_bool_param(cinfo, JBOOLEAN_OPTIMIZE_SCANS) && cinfo->master->num_scans_luma != 0;
     p->optimize_coding = 1;   /* jcmaster.c:1091-1094 */
-    if (p->optimize_scans && jpeg_c_get_int_param(cinfo, JINT_DC_SCAN_OPT_MODE) != 0) return "dc_scan_opt_mode != 0 with the scan search";
   }
   if (!cinfo->optimize_coding) {
     /* standard tables are baked into the GPU path; anything else needs optimize_coding */
@@ -293,7 +295,8 @@ static int reference_total_passes(j_compress_ptr cinfo, const mjh_params *p)
   int total = p->optimize_coding ? nscans * 2 : nscans;
   if (p->trellis_quant) {
     const int loops = p->trellis_num_loops > 0 ? p->trellis_num_loops : 1;
-    total += p->optimize_coding ? 2 * cinfo->num_components * loops : cinfo->num_components * loops + 1;
+    const int bands = p->use_scans_in_trellis ? 2 : 1;   /* jcmaster.c:1129-1138 */
+    total += p->optimize_coding ? 2 * bands * cinfo->num_components * loops : bands * cinfo->num_components * loops + 1;
   }
   return total;
 }

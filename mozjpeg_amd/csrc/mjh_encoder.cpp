@@ -149,8 +149,10 @@ extern "C" int mjh_params_simple_progression(mjh_params *p)
     if (!maxc) s = fill_dc_scans(s, 0, nc, 1, 0);
     for (int c = 0; c < nc; c++) s = fill_a_scan(s, c, 1, 63, 1, 0);
   } else if (nc == 3) {
-    if (maxc) {   // jcparam.c:940-963 (dc_scan_opt_mode 0)
-      s = fill_dc_scans(s, 0, nc, 0, 0);
+    if (maxc) {   // jcparam.c:931-963
+      if (p->dc_scan_opt_mode == 0) s = fill_dc_scans(s, 0, nc, 0, 0);                 // one DC scan for all components
+      else if (p->dc_scan_opt_mode == 1) { s = fill_a_scan(s, 0, 0, 0, 0, 0); s = fill_a_scan(s, 1, 0, 0, 0, 0); s = fill_a_scan(s, 2, 0, 0, 0, 0); }
+      else { s = fill_dc_scans(s, 0, 1, 0, 0); s = fill_dc_scans(s, 1, 2, 0, 0); }  // luma, then Cb+Cr interleaved
       s = fill_a_scan(s, 0, 1, 8, 0, 2); s = fill_a_scan(s, 1, 1, 8, 0, 0); s = fill_a_scan(s, 2, 1, 8, 0, 0);
       s = fill_a_scan(s, 0, 9, 63, 0, 2);
       s = fill_a_scan(s, 0, 1, 63, 2, 1); s = fill_a_scan(s, 0, 1, 63, 1, 0);
@@ -180,11 +182,11 @@ extern "C" int mjh_params_simple_progression(mjh_params *p)
   return MJH_OK;
 }
 
-static int build_search_script(mjh_scan *out, int nc)
+static int build_search_script(mjh_scan *out, int nc, int dc_scan_opt_mode)
 {
   static const int fs[5] = { 2, 8, 5, 12, 18 };
   mjh_scan *s = out;
-  s = fill_dc_scans(s, 0, nc, 0, 0);
+  s = fill_dc_scans(s, 0, dc_scan_opt_mode == 0 ? nc : 1, 0, 0);   // jcparam.c:791-794
   s = fill_a_scan(s, 0, 1, 8, 0, 0); s = fill_a_scan(s, 0, 9, 63, 0, 0);
   for (int Al = 0; Al < 3; Al++) {
     s = fill_a_scan(s, 0, 1, 63, Al + 1, Al); s = fill_a_scan(s, 0, 1, 8, 0, Al + 1); s = fill_a_scan(s, 0, 9, 63, 0, Al + 1);
@@ -216,7 +218,7 @@ extern "C" int mjh_params_search_progression(mjh_params *p)
   if (p->num_components != 3 && p->num_components != 1) return fail(MJH_EUNSUPPORTED, "scan search for %d components", p->num_components);
   if (p->num_components == 3 && p->color_transform == MJH_COLOR_NONE)   // jpeg_search_progression knows YCbCr and gray only (jcparam.c:749-757)
     return mjh_params_simple_progression(p);
-  p->num_scans = build_search_script(p->scan_info, p->num_components);
+  p->num_scans = build_search_script(p->scan_info, p->num_components, p->dc_scan_opt_mode);
   p->optimize_scans = 1;
   p->optimize_coding = 1;
   return MJH_OK;
@@ -261,6 +263,10 @@ struct mjh_encoder {
   MjhHuffTable *d_tabs = nullptr, *d_tabs_init = nullptr;
   float *d_lambda = nullptr;
   uint8_t *d_back = nullptr;
+  // SURVEY 8f row 4 options: per-block outputs of the AC trellis for trellis_eob_opt, 64-bit sums of trellis_q_opt
+  void *d_eob_cost = nullptr; int *d_eob_has = nullptr; long long *d_qsums = nullptr;
+  int dqt_off[4] = { -1, -1, -1, -1 };      // file offset of the first entry of every 8-bit DQT table
+  int nbands = 1, freq_split = 8;
   unsigned *d_seg_x = nullptr, *d_seg_E = nullptr, *d_seg_sums = nullptr, *d_seg_totals = nullptr, *d_mpos = nullptr;
   int nseg = 1;
   int comp_restart[4] = { 0, 0, 0, 0 };
@@ -283,7 +289,7 @@ struct mjh_encoder {
   void *d_prog_chunks = nullptr;     // chunk summaries of the parallel statistics / encode kernels
   int chunks_per_scan = 0;
   MjhProgPE pe{};                    // buffers of the parallel AC-first encode
-  PList pl_trellis{}, pl_phase[2]{};
+  PList pl_trellis[2]{}, pl_phase[2]{};   // pl_trellis: the statistics scans of the trellis passes, one list per band
   int nphases = 0;
   unsigned *d_pool = nullptr; size_t pool_words = 0;
   uint8_t *d_outpool = nullptr; size_t outpool_bytes = 0;
@@ -327,6 +333,18 @@ static int check_supported(const mjh_params *p)
   if (p->data_precision != 0 && p->data_precision != 8 && p->data_precision != 12) return fail(MJH_EUNSUPPORTED, "data_precision %d", p->data_precision);
   if (p->smoothing_factor < 0 || p->smoothing_factor > 100) return fail(MJH_EINVAL, "smoothing_factor %d (0..100)", p->smoothing_factor);
   if (p->trellis_num_loops < 0 || p->trellis_num_loops > 16) return fail(MJH_EINVAL, "trellis_num_loops %d (0..16)", p->trellis_num_loops);
+  if (p->trellis_freq_split < 0 || p->trellis_freq_split > 63) return fail(MJH_EINVAL, "trellis_freq_split %d (0..63)", p->trellis_freq_split);
+  if (p->trellis_quant && p->trellis_q_opt) {
+    // the table update sits between groups of num_components passes of the reference's component-major pass order
+    // (jcmaster.c:687-698, :1014-1030): with one round per component that is once, after the last pass; with more
+    // rounds later components would be quantized with tables re-estimated from earlier ones
+    if (p->trellis_num_loops > 1) return fail(MJH_EUNSUPPORTED, "trellis_q_opt with trellis_num_loops > 1");
+    for (int i = 0; i < p->num_components; i++)
+      for (int k = 0; k < 64; k++)
+        if (p->quantval[p->quant_tbl_no[i]][k] > 255) return fail(MJH_EUNSUPPORTED, "trellis_q_opt with 16-bit quantization tables (the DQT entries are rewritten in place)");
+  }
+  if (p->dc_scan_opt_mode < 0 || p->dc_scan_opt_mode > 2) return fail(MJH_EINVAL, "dc_scan_opt_mode %d (0..2)", p->dc_scan_opt_mode);
+  if (!(p->trellis_delta_dc_weight == p->trellis_delta_dc_weight)) return fail(MJH_EINVAL, "trellis_delta_dc_weight is not a number");
   if (p->data_precision == 12 && p->trellis_quant)
     return fail(MJH_EUNSUPPORTED, "trellis quantization is 8-bit only in the reference (jccoefct.c:132-138: 12-bit + trellis aborts)");
   if (p->input_components != 1 && p->input_components != 3) return fail(MJH_EUNSUPPORTED, "input_components %d (RGB or gray only)", p->input_components);
@@ -364,8 +382,13 @@ static int check_supported(const mjh_params *p)
       if (p->dc_tbl_no[i] > 1 || p->ac_tbl_no[i] > 1) return fail(MJH_EUNSUPPORTED, "progressive mode: table numbers 0/1 only");
     if (p->optimize_scans) {
       mjh_scan ref[MJH_MAX_SCANS];
-      const int n = build_search_script(ref, p->num_components);
-      if (n != p->num_scans || memcmp(ref, p->scan_info, sizeof(mjh_scan) * n) != 0)
+      // scan 0 is whatever dc_scan_opt_mode was when the script was built (all components, or the luma alone,
+      // jcparam.c:791-794) -- an application may change the mode afterwards, the final choice reads the current one
+      const int n = build_search_script(ref, p->num_components, 0);
+      const mjh_scan &s0 = p->scan_info[0];
+      const bool s0_ok = s0.Ss == 0 && s0.Se == 0 && s0.Ah == 0 && s0.Al == 0 && s0.component_index[0] == 0 &&
+                         (s0.comps_in_scan == 1 || (s0.comps_in_scan == p->num_components && memcmp(&ref[0], &s0, sizeof(mjh_scan)) == 0));
+      if (n != p->num_scans || !s0_ok || memcmp(ref + 1, p->scan_info + 1, sizeof(mjh_scan) * (n - 1)) != 0)
         return fail(MJH_EUNSUPPORTED, "optimize_scans needs the jpeg_search_progression script");
     }
     bool dc_seen[MJH_MAX_COMPS] = { false, false, false, false };
@@ -443,6 +466,7 @@ static void build_const(const mjh_params *p, MjhConst *C)
   C->smoothing = p->smoothing_factor;
   C->trellis = p->trellis_quant;
   C->trellis_dc = p->trellis_quant_dc;
+  C->delta_dc_weight = p->trellis_delta_dc_weight;
   // per_scan_setup jcmaster.c:595-600: restart_in_rows is converted per scan; here for the final
   // interleaved scan (the per-component statistics passes use their own MCUs_per_row, T10)
   C->restart_interval = (int)p->restart_interval;
@@ -465,8 +489,9 @@ static void build_const(const mjh_params *p, MjhConst *C)
 // ---- marker bytes that do not depend on the image (jcmarker.c) -------------------------------------
 static void put2(std::vector<uint8_t> &o, int v) { o.push_back((uint8_t)(v >> 8)); o.push_back((uint8_t)v); }
 
-static void build_prefix(const mjh_params *p, std::vector<uint8_t> &o, bool *baseline_sof, int *file_hdr_len)
+static void build_prefix(const mjh_params *p, std::vector<uint8_t> &o, bool *baseline_sof, int *file_hdr_len, int dqt_off[4] = nullptr)
 {
+  if (dqt_off) for (int t = 0; t < 4; t++) dqt_off[t] = -1;
   const bool multi = p->compress_profile != MJH_PROFILE_FASTEST;
   o.push_back(0xFF); o.push_back(0xD8);                     // SOI, write_file_header :649
   if (p->write_JFIF_header) {                               // emit_jfif_app0 :534-565 (version 1.01, density 1:1)
@@ -503,6 +528,7 @@ static void build_prefix(const mjh_params *p, std::vector<uint8_t> &o, bool *bas
       put2(o, prec[ci] ? 64 * 2 + 1 + 2 : 64 + 1 + 2);
     }
     o.push_back((uint8_t)(t + (prec[ci] << 4)));
+    if (dqt_off && !prec[ci]) dqt_off[t] = (int)o.size();   // trellis_q_opt rewrites the 8-bit entries in place
     for (int i = 0; i < 64; i++) {
       const unsigned qv = p->quantval[t][kZZ[i]];
       if (prec[ci]) o.push_back((uint8_t)(qv >> 8));
@@ -604,7 +630,7 @@ static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -652,6 +678,8 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   e->progressive = p->num_scans > 0;
   e->nscans = p->num_scans;
   if (e->progressive) e->spi = SLOT_PROG + 2 * (p->num_scans + C.ncomp);
+  e->nbands = p->trellis_quant && p->use_scans_in_trellis ? 2 : 1;          // jcmaster.c:451-460
+  e->freq_split = p->trellis_freq_split > 0 ? p->trellis_freq_split : 8;   // jcparam.c:512
   HIPCHK_E(hipSetDevice(device));
   HIPCHK_E(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   HIPCHK_E(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
@@ -674,6 +702,11 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   HIPCHK_E(hipMalloc((void **)&e->d_back, B * (size_t)C.total_real_blocks * 16));
   HIPCHK_E(hipMalloc((void **)&e->d_worklist, 16 + B * (size_t)C.total_real_blocks * 12));
   HIPCHK_E(hipMalloc((void **)&e->d_worklist2, 16 + B * (size_t)C.total_real_blocks * 12));
+  if (p->trellis_quant && p->trellis_eob_opt) {
+    HIPCHK_E(hipMalloc(&e->d_eob_cost, B * (size_t)C.total_real_blocks * 8));
+    HIPCHK_E(hipMalloc((void **)&e->d_eob_has, B * (size_t)C.total_real_blocks * 4));
+  }
+  if (p->trellis_quant && p->trellis_q_opt) HIPCHK_E(hipMalloc((void **)&e->d_qsums, B * 4 * 64 * 2 * sizeof(long long)));
   if (p->trellis_quant) {   // room for a quarter of all blocks (typically 1-2 % overflow); the rest would be read from the planes
     e->dense_cap = (unsigned)(B * (size_t)C.total_real_blocks / 4 + 1024);
     HIPCHK_E(hipMalloc((void **)&e->d_dense, (size_t)e->dense_cap * 128));
@@ -749,7 +782,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   {
     std::vector<uint8_t> pre, sos;
     bool base;
-    build_prefix(p, pre, &base, &e->file_hdr_len);
+    build_prefix(p, pre, &base, &e->file_hdr_len, e->dqt_off);
     build_sos(p, C.restart_interval, sos);
     e->prefix_len = (int)pre.size();
     e->sos_len = (int)sos.size();
@@ -774,7 +807,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     HIPCHK_E(hipMalloc((void **)&e->d_frame_hdr, (size_t)e->frame_hdr_len + 16));
     HIPCHK_E(hipMemcpy(e->d_frame_hdr, e->d_prefix + e->file_hdr_len, e->frame_hdr_len, hipMemcpyDeviceToDevice));
     // scan descriptors: the script, then one AC-first statistics scan per component for the trellis passes
-    std::vector<MjhProgScan> ps(p->num_scans + C.ncomp);
+    std::vector<MjhProgScan> ps(p->num_scans + C.ncomp * e->nbands);
     memset(ps.data(), 0, ps.size() * sizeof(MjhProgScan));
     const int nsl = 23, cfs = 42, lfs = 12;
     for (int si = 0; si < p->num_scans; si++) {
@@ -808,11 +841,15 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
         }
       }
     }
-    for (int c = 0; c < C.ncomp; c++) {
-      MjhProgScan &d = ps[p->num_scans + c];
-      d.ncomp = 1; d.comp[0] = c; d.Ss = 1; d.Se = 63; d.Ah = 0; d.Al = 0;   // jcmaster.c:462-466, T15
-      d.slot[0] = 2 * c + 1; d.slot[1] = -1; d.seed = 1;
-    }
+    for (int band = 0; band < e->nbands; band++)
+      for (int c = 0; c < C.ncomp; c++) {
+        MjhProgScan &d = ps[p->num_scans + band * C.ncomp + c];
+        d.ncomp = 1; d.comp[0] = c; d.Ah = 0; d.Al = 0;   // jcmaster.c:451-466, T15
+        d.Ss = e->nbands == 1 ? 1 : band == 0 ? 1 : e->freq_split + 1;
+        d.Se = e->nbands == 1 ? 63 : band == 0 ? e->freq_split : 63;
+        if (d.Se < d.Ss) { d.Ss = 1; d.Se = 63; }         // empty band: its passes are skipped, the descriptor only has to be valid
+        d.slot[0] = 2 * c + 1; d.slot[1] = -1; d.seed = 1;
+      }
     // restart intervals are a per-scan quantity (per_scan_setup jcmaster.c:595-600, T10): `restart_in_rows` rows of the
     // SCAN's MCUs (a single-component scan's MCU is one block, its row is width_in_blocks blocks), capped at 65535
     {
@@ -853,8 +890,9 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       for (int si : scn) if (ps[si].ri != 0) { e->h_lists.push_back(si); pl.nseq++; }
       return pl;
     };
-    std::vector<int> tr, a, b;
-    for (int c = 0; c < C.ncomp; c++) tr.push_back(p->num_scans + c);
+    std::vector<int> tr[2], a, b;
+    for (int band = 0; band < e->nbands; band++)
+      for (int c = 0; c < C.ncomp; c++) tr[band].push_back(p->num_scans + band * C.ncomp + c);
     if (p->optimize_scans) {   // phase A: everything the Al decisions need; phase B: the frequency-split candidates
       for (int si = 0; si < p->num_scans; si++) ((si >= lfs && si < nsl) || si >= cfs ? b : a).push_back(si);
       e->nphases = 2;
@@ -862,14 +900,15 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       for (int si = 0; si < p->num_scans; si++) a.push_back(si);
       e->nphases = 1;
     }
-    e->pl_trellis = add_list(tr);
+    e->pl_trellis[0] = add_list(tr[0]);
+    e->pl_trellis[1] = add_list(tr[1]);
     e->pl_phase[0] = add_list(a);
     e->pl_phase[1] = add_list(b);
     {
       int mx = 0, maxlist = 1;
       for (int c = 0; c < C.ncomp; c++) mx = C.c[c].nblk > mx ? C.c[c].nblk : mx;
       e->chunks_per_scan = (mx + MJH_PSTAT_BLOCKS - 1) / MJH_PSTAT_BLOCKS;
-      for (const mjh_encoder::PList *pl : { &e->pl_trellis, &e->pl_phase[0], &e->pl_phase[1] }) maxlist = pl->npar > maxlist ? pl->npar : maxlist;
+      for (const mjh_encoder::PList *pl : { &e->pl_trellis[0], &e->pl_trellis[1], &e->pl_phase[0], &e->pl_phase[1] }) maxlist = pl->npar > maxlist ? pl->npar : maxlist;
       HIPCHK_E(hipMalloc(&e->d_prog_chunks, B * (size_t)maxlist * e->chunks_per_scan * sizeof(MjhProgChunk)));
       // parallel encode of the AC-first scans: block lengths / runs / offsets per (scan, image) pair
       const int maxpar = maxlist;
@@ -983,7 +1022,12 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   // kernel costs what the separate statistics pass cost (7.19 vs 7.23 ms per 64 4K frames) but moves 3.2 GB less; the
   // final statistics inside the trellis cost MORE than their own pass (3.83 vs 3.36 + 0.38 ms: the low-occupancy kernel
   // pays for every extra instruction), so that fusion exists (MJH_FUSE=3) but is off by default.
-  const bool fuse_pre = fuse_seq && (e->fuse_mask & 1) && !e->debug_taps, fuse_fin = fuse_seq && (e->fuse_mask & 2);
+  // band-limited passes (use_scans_in_trellis) keep the other band's quantized planes, and the block-row
+  // pass of trellis_eob_opt changes coefficients behind the per-block DP: neither fusion applies then
+  const bool ext_eob = p.trellis_quant && p.trellis_eob_opt, ext_qopt = p.trellis_quant && p.trellis_q_opt;
+  const int nbands = p.trellis_quant ? e->nbands : 1;
+  const bool fuse_pre = fuse_seq && (e->fuse_mask & 1) && !e->debug_taps && nbands == 1;
+  const bool fuse_fin = fuse_seq && (e->fuse_mask & 2) && nbands == 1 && !ext_eob;
   if (!coef_src) {
     pr.mark("dct_quant");
     mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, n, s);
@@ -994,17 +1038,25 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     mjh_launch_prog_reset(e->d_prog_ctl, e->nscans, n, s);
     HIPCHK(hipMemsetAsync(e->d_pool, 0, (size_t)n * e->pool_words * 4, s));
   }
+  if (ext_qopt) HIPCHK(hipMemsetAsync(e->d_qsums, 0, (size_t)n * 4 * 64 * 2 * sizeof(long long), s));   // prepare_for_pass jcmaster.c:687-698
   // trellis_num_loops (statistics, trellis) rounds (jcmaster.c:451-466): every round gathers the statistics of the
   // current quantized coefficients and re-runs the trellis from the unquantized ones (components are independent,
-  // so doing all of them per round equals the reference's component-major order)
+  // so doing all of them per round equals the reference's component-major order); with use_scans_in_trellis a round
+  // is two such pass pairs, AC bands 1..split and split+1..63
   const int nloops = p.trellis_quant ? (p.trellis_num_loops > 1 ? p.trellis_num_loops : 1) : 0;
-  for (int loop = 0; loop < nloops; loop++) {
-    if (loop > 0)   // fresh (zero) statistics for this round
+  bool first_pass = true;
+  for (int loop = 0; loop < nloops; loop++)
+  for (int band = 0; band < nbands; band++) {
+    const int Ss = nbands == 1 ? 1 : band == 0 ? 1 : e->freq_split + 1;
+    const int Se = nbands == 1 ? 63 : band == 0 ? e->freq_split : 63;
+    if (Se < Ss) continue;   // quantize_trellis returns at once (jcdctmgr.c:979-980); the statistics of that pass feed nothing
+    if (!first_pass)   // fresh (zero) statistics for this pass
       HIPCHK(hipMemcpyAsync(e->d_tabs, e->d_tabs_init, (size_t)n * spi * sizeof(MjhHuffTable), hipMemcpyDeviceToDevice, s));
     if (!e->progressive) {
-      // passes 0,2,4 of SURVEY 3.3 (statistics of the conventionally quantized component): AC part fused into the FDCT
-      // kernel in the first round, a pass over the previous round's result afterwards ...
-      if (loop > 0 || !fuse_pre) {
+      // passes 0,2,4 of SURVEY 3.3 (statistics of the conventionally quantized component; the sequential coder's gather
+      // counts whole blocks whatever the band, jchuff.c:812-915): AC part fused into the FDCT kernel in the first pass,
+      // a pass over the previous result afterwards ...
+      if (!first_pass || !fuse_pre) {
         pr.mark("stats_ac(pre-trellis)");
         mjh_launch_stats_ac(C, e->d_q, e->d_tabs, spi, tr_ac, 0, n, s);
       }
@@ -1015,18 +1067,19 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       pr.mark("gen_tables(trellis)");
       mjh_launch_gen_tables(e->d_tabs, spi, slots, ns, n, s);
     } else {
-      // progressive: the trellis passes gather AC-first statistics (Ss=1, Se=63, Al=0, seeded counts,
+      // progressive: the trellis passes gather AC-first statistics (Ss..Se of the band, Al=0, seeded counts,
       // jcphuff.c:257-264); the DC rate table stays the STANDARD table
+      const mjh_encoder::PList &plt = e->pl_trellis[band];
       pr.mark("prog_stats(pre-trellis)");
-      if (e->pl_trellis.nseq)
-        mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + e->pl_trellis.seq_off, e->pl_trellis.nseq, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
-      mjh_launch_prog_stats_par(C, e->d_prog_scans, e->d_lists + e->pl_trellis.par_off, e->pl_trellis.npar, e->d_prog_ctl, e->d_q, e->d_tabs, spi,
-                                e->pe, e->pl_trellis.any_refine, n, s);
+      if (plt.nseq)
+        mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + plt.seq_off, plt.nseq, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
+      mjh_launch_prog_stats_par(C, e->d_prog_scans, e->d_lists + plt.par_off, plt.npar, e->d_prog_ctl, e->d_q, e->d_tabs, spi,
+                                e->pe, plt.any_refine, n, s);
       pr.mark("gen_tables(trellis)");
-      mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + e->pl_trellis.slot_off, e->pl_trellis.nslot, n, s);
+      mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + plt.slot_off, plt.nslot, n, s);
       for (int i = 0; i < 4; i++) tr_dc[i] = fin_dc[i];
     }
-    if (e->debug_taps && loop == 0) {
+    if (e->debug_taps && first_pass) {
       if (!e->d_q0) HIPCHK(hipMalloc((void **)&e->d_q0, (size_t)e->max_batch * C.coefs_per_image * 2));
       HIPCHK(hipMemcpyAsync(e->d_q0, e->d_q, (size_t)n * C.coefs_per_image * 2, hipMemcpyDeviceToDevice, s));
     }
@@ -1045,7 +1098,8 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       if (pr.enabled && e->profiling == 1) { HIPCHK(hipEventRecord(e->side_events[2 * e->prof_calls + 1], e->side_stream)); e->side_timed = true; }
       HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
     }
-    if (e->trellis_adapt && e->h_defer[0] != 0xFFFFFFFFu) {
+    const bool extended = nbands > 1 || ext_eob;
+    if (e->trellis_adapt && !extended && e->h_defer[0] != 0xFFFFFFFFu) {
       // The first tier's queue capacity trades LDS occupancy (16 entries: 14 waves per CU) against the share of blocks that
       // have to be redone by the slower big-capacity tier: few at q75 (the metric: ~5 %), a third of all blocks at q85.
       // The share seen in the last finished batch (read back asynchronously, never waited for) moves it one notch.
@@ -1056,15 +1110,25 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     }
     pr.mark("trellis_ac");
     mjh_launch_trellis_ac(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap,
-                          fuse_fin && p.optimize_coding && loop == nloops - 1 ? fin_ac : nullptr, e->trellis_variant, n, s);
-    if (e->trellis_adapt && loop == 0) {
+                          fuse_fin && p.optimize_coding && loop == nloops - 1 ? fin_ac : nullptr, e->trellis_variant,
+                          Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, n, s);
+    if (e->trellis_adapt && !extended && loop == 0) {
       e->h_defer[1] = (unsigned)n;
       HIPCHK(hipMemcpyAsync(&e->h_defer[0], e->d_worklist, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    }
+    if (ext_eob) {   // jcdctmgr.c:1224-1297: end-of-band runs along every block row, with the band's AC rate table
+      pr.mark("trellis_eob_runs");
+      mjh_launch_trellis_eob_chain(C, e->d_q, e->d_tabs, spi, tr_ac, e->d_eob_cost, e->d_eob_has, Ss, Se, n, s);
+    }
+    if (ext_qopt) {  // :1299-1306
+      pr.mark("trellis_q_opt(sums)");
+      mjh_launch_qopt_accumulate(C, e->d_uq, e->d_q, e->d_qsums, n, s);
     }
     if (p.trellis_quant_dc) {
       pr.mark("join(trellis_dc)");
       HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
     }
+    first_pass = false;
   }
   if (e->progressive) {
     // every candidate scan of a phase: statistics -> optimal tables -> exact size -> headers, bits, stuffing
@@ -1093,11 +1157,12 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
                              e->pe, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_pool, e->pool_words,
                              e->d_frame_hdr, e->frame_hdr_len, p.compress_profile != MJH_PROFILE_FASTEST, e->d_outpool, e->outpool_bytes,
                              e->d_prog_mpos, e->mpos_per_image, e->d_prog_ffsums, n, s, e->side_stream, e->ev_fork, e->ev_join);
-      if (p.optimize_scans) { pr.mark("prog_select"); mjh_launch_prog_select(e->d_prog_ctl, C.ncomp, ph, n, s); }
+      if (p.optimize_scans) { pr.mark("prog_select"); mjh_launch_prog_select(e->d_prog_ctl, C.ncomp, ph, p.dc_scan_opt_mode, n, s); }
     }
     if (before_output) HIPCHK(hipStreamWaitEvent(s, before_output, 0));
     pr.mark("prog_concat");
     mjh_launch_prog_concat(e->d_prog_ctl, e->d_prefix, e->file_hdr_len, e->d_outpool, e->outpool_bytes, e->d_out, e->out_stride, e->d_sizes, n, s);
+    if (ext_qopt) { pr.mark("trellis_q_opt(tables)"); mjh_launch_qopt_patch(e->d_qsums, e->d_out, e->out_stride, e->dqt_off, e->d_sizes, n, s); }   // jcmaster.c:1014-1030
     pr.mark(nullptr);
     pr.finish();
     HIPCHK(hipGetLastError());
@@ -1125,6 +1190,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   pr.mark("byte_stuff");
   mjh_launch_stuff(e->d_stream, e->stream_words, e->d_totals, e->d_ffsums, e->ff_chunks, e->d_fftotals, e->d_out, e->out_stride,
                    e->d_meta, e->d_sizes, e->d_mpos, e->nseg, n, s);
+  if (ext_qopt) { pr.mark("trellis_q_opt(tables)"); mjh_launch_qopt_patch(e->d_qsums, e->d_out, e->out_stride, e->dqt_off, e->d_sizes, n, s); }   // jcmaster.c:1014-1030
   pr.mark(nullptr);
   pr.finish();
   HIPCHK(hipGetLastError());

@@ -55,6 +55,7 @@ struct MjhConst {
   int deringing;
   int trellis;            // trellis_quant: the FDCT kernel also emits the per-block lambda
   int trellis_dc;
+  float delta_dc_weight;  // trellis_delta_dc_weight (> 0: the DC trellis adds the vertical-gradient term, jcdctmgr.c:1069-1084)
   int restart_interval;   // of the final interleaved scan, in MCUs (0 = none)
   float lambda_log_scale1, lambda_log_scale2;
   double pow_scale1, pow_scale2;  // pow(2, s1) [or pow(2, s1-12) when s2 <= 0], pow(2, s2): host libm

@@ -966,15 +966,19 @@ __device__ __forceinline__ void q_pair_step(const uint4 *si_rows, const float4 *
 // take part in the wave-level loop).
 // phase 1 of the lane-autonomous DP: zero-distortion prefix + queue of the positions with a non-zero quantized value.
 // Returns the number of such positions (> QN: the block has to be deferred; the queue then holds the first QN).
-template <int QN>
+// EXT (use_scans_in_trellis / trellis_eob_opt): only the positions Ss..Se take part (the zero-distortion
+// prefix starts at Ss, azd63 is its value at Se); Ss/Se are ignored otherwise.
+template <int QN, bool EXT = false>
 __device__ __forceinline__ int trellis_q_phase1(const short (&xs)[64], const int *__restrict__ dq8, const float *__restrict__ rcp,
-                                                const float *__restrict__ lt, float lambda, uint2 (*col)[64], int lane, float &azd63)
+                                                const float *__restrict__ lt, float lambda, uint2 (*col)[64], int lane, float &azd63,
+                                                int Ss = 1, int Se = 63)
 {
   int nq = 0;
   {
     float azd = 0.0f;
 #pragma unroll
     for (int k = 1; k < 64; k++) {
+      if (EXT && (k < Ss || k > Se)) continue;   // wave-uniform
       const int xsg = xs[k];
       const int x = xsg < 0 ? -xsg : xsg;
       const int dq = dq8[k];
@@ -1001,18 +1005,24 @@ __device__ __forceinline__ int trellis_q_phase1(const short (&xs)[64], const int
 // `counts` of this lane's image/component (deferred tiers: few blocks, any table per lane), 0 = not at all.
 // phases 2.. : nq_in = what phase 1 returned.  `active` false or nq_in > QN: the lane has nothing to do but still takes
 // part in the wave-level loop.
-template <int QN, bool LDS_ROWS, int STATS>
+// EXT: band Ss..Se (the virtual start sits at position Ss-1, positions outside the band are neither read nor written)
+// and, when eob_out is not null, the three per-block results the end-of-band-run optimisation needs (jcdctmgr.c:1187-1209):
+// eob_out[0] = cost of the all-zero band, eob_out[1] = cost of the chosen path without its EOB, eob_has = 0/1/2.
+template <int QN, bool LDS_ROWS, int STATS, bool EXT = false>
 __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float4 *rate_rows, const int (*dqT)[64], const float (*ltT)[64],
                                                int qrow, int nq_in, float azd63, float lambda, bool active, int16_t *__restrict__ qo,
-                                               int kstride, uint2 (*col)[64], unsigned short (*e_pk)[64], int lane, unsigned *counts)
+                                               int kstride, uint2 (*col)[64], unsigned short (*e_pk)[64], int lane, unsigned *counts,
+                                               int Ss = 1, int Se = 63, float2 *__restrict__ eob_out = nullptr, int *__restrict__ eob_has = nullptr)
 {
+  static_assert(!(EXT && STATS), "the fused statistics exist for the plain 1..63 pass only");
+  const int vstart = EXT ? Ss - 1 : 0;          // position of the virtual start entry
   const int si_f0 = (int)(si_rows[15].x & 0xFFu), si_eob = (int)(si_rows[0].x & 0xFFu);
   const float f0f = si_f0 ? (float)si_f0 : 3e38f;
   const bool over_q = active && nq_in > QN;
   int nq = (!active || over_q) ? 0 : nq_in;     // nothing to walk (the lane stays for the wave-level loop)
 
   // ---- phase 2: every lane consumes its own queue; the NEXT record is always one load ahead ----
-  unsigned long long live = 1ull, neg = 0ull;
+  unsigned long long live = 1ull << vstart, neg = 0ull;
   int nlive = 1;
   float2 n0 = make_float2(0.0f, 0.0f), n1 = n0;
   int qi = 0;
@@ -1079,9 +1089,11 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
 
   // ---- end-of-block choice (jcdctmgr.c:1187-1207): independent loads of every live entry, then the scan in position order
   float best_cost = azd63 + (float)si_eob;
-  int last = 0;
+  float best_skip = azd63;                       // EXT: best_cost_skip (:1190, :1203)
+  const int last_pos = EXT ? Se : 63;
+  int last = vstart;
   {
-    unsigned long long mm = live & ~1ull;
+    unsigned long long mm = live & ~(1ull << vstart);
     if (QN <= 24) {
       uint2 ent[QN];
 #pragma unroll
@@ -1093,8 +1105,9 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
           mm &= mm - 1;
           float cost = __uint_as_float(ent[s2].y) + azd63;
           cost = cost - __uint_as_float(ent[s2].x);
-          if (p < 63) cost = cost + (float)si_eob;
-          if (cost < best_cost) { best_cost = cost; last = p; }
+          const float wo = cost;
+          if (p < last_pos) cost = cost + (float)si_eob;
+          if (cost < best_cost) { best_cost = cost; last = p; if (EXT) best_skip = wo; }
         }
       }
     } else {
@@ -1104,10 +1117,15 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
         mm &= mm - 1;
         float cost = __uint_as_float(en.y) + azd63;
         cost = cost - __uint_as_float(en.x);
-        if (p < 63) cost = cost + (float)si_eob;
-        if (cost < best_cost) { best_cost = cost; last = p; }
+        const float wo = cost;
+        if (p < last_pos) cost = cost + (float)si_eob;
+        if (cost < best_cost) { best_cost = cost; last = p; if (EXT) best_skip = wo; }
       }
     }
+  }
+  if (EXT && eob_out) {
+    *eob_out = make_float2(azd63, best_skip);
+    *eob_has = (last < Se ? 1 : 0) + (last == vstart ? 1 : 0);   // :1209
   }
   // ---- back-track (jcdctmgr.c:1211-1222): the path is followed newest entry first, the values travel through the
   // lane's LDS column (64 int16 = 16 slots; the queue is dead by now) so that the 63 plane stores use static registers
@@ -1116,7 +1134,7 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
     typedef uint2 __attribute__((may_alias)) u2_alias;
     u2_alias *colw = reinterpret_cast<u2_alias *>(&col[0][0]);
     us_alias *colh = reinterpret_cast<us_alias *>(&col[0][0]);   // value of position k: row k>>2, half-word k&3
-    unsigned long long mm = live & ~1ull;
+    unsigned long long mm = live & ~(1ull << vstart);
     int p = last;
     if (STATS) { if (last < 63) atomicAdd(&hh[0], 1u); }      // trailing zeros (or an all-zero block): EOB
     if (QN <= 24) {
@@ -1165,10 +1183,168 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
     for (int r = 0; r < 16; r++) vals[r] = colw[r * 64 + lane];
 #pragma unroll
     for (int k = 1; k < 64; k++) {
+      if (EXT && (k < Ss || k > Se)) continue;   // positions outside the band keep what they hold
       const unsigned w = (k & 2) ? vals[k >> 2].y : vals[k >> 2].x;
       qo[(size_t)k * kstride] = (int16_t)((k & 1) ? (w >> 16) : (w & 0xFFFFu));
     }
   }
+}
+
+// =============================================================================================
+// trellis_eob_opt: jcdctmgr.c:1224-1297.  After the per-block DP of a band the reference walks
+// every block row once more: the cheapest way to reach block bi through runs of blocks whose band is all zero (coded as
+// EOBRUN symbols in progressive mode), then the blocks inside the chosen runs lose their band.  The recursion is
+// sequential in float along the row (abc[bi+1] needs abc[0..bi]) and quadratic (every earlier block is a candidate
+// start), so: one wave per (image, component, block row); for each bi the candidates i = lane, lane + 64, ... are
+// evaluated in parallel and reduced to the FIRST minimum (the reference's strict '<' in increasing i).
+// LDS: azbc / abc (float), requires_eob (byte), block_run_start (16 bit), zero flags: 13 bytes per block.
+// =============================================================================================
+__device__ __forceinline__ void wave_first_min(float &c, int &idx)
+{
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float oc = __shfl_xor(c, off, 64);
+    const int oi = __shfl_xor(idx, off, 64);
+    if (oc < c || (oc == c && oi < idx)) { c = oc; idx = oi; }
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_trellis_eob_chain(MjhConst C, int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
+                    int4 ac_slot_of_comp, int4 row0_of_comp, const float2 *__restrict__ eob_cost, const int *__restrict__ eob_has, int Ss, int Se)
+{
+  extern __shared__ unsigned char dyn_lds[];
+  const int img = blockIdx.y, row = blockIdx.x, lane = threadIdx.x;
+  const int comp = row >= row0_of_comp.w ? 3 : row >= row0_of_comp.z ? 2 : row >= row0_of_comp.y ? 1 : 0;
+  const int r0 = comp == 0 ? 0 : comp == 1 ? row0_of_comp.y : comp == 2 ? row0_of_comp.z : row0_of_comp.w;
+  const MjhComp cc = C.c[comp];
+  const int br = row - r0, n = cc.wib;
+  const int slot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
+  const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+  float *azbc = reinterpret_cast<float *>(dyn_lds);                  // [n + 1]
+  float *abc = azbc + (n + 1);                                        // [n + 1]
+  float *skip = abc + (n + 1);                                        // [n]     best_cost_skip of every block
+  unsigned short *run_start = reinterpret_cast<unsigned short *>(skip + n);   // [n]
+  unsigned char *req = reinterpret_cast<unsigned char *>(run_start + n);      // [n + 1]
+  unsigned char *zero = req + (n + 1);                                // [n]
+  __shared__ float eobrun_cost[16];                                   // (float)(size[16 * nb] + nb)
+  if (lane < 16) eobrun_cost[lane] = (float)((int)T->ehufsi[16 * lane] + lane);
+  const size_t g0 = (size_t)img * C.total_real_blocks + cc.blk_off + (size_t)br * n;
+  for (int b = lane; b < n; b += 64) {
+    const float2 c2 = eob_cost[g0 + b];
+    abc[b + 1] = c2.x;            // parked here until the prefix below has consumed it
+    skip[b] = c2.y;
+    req[b + 1] = (unsigned char)eob_has[g0 + b];
+    zero[b] = 0;
+  }
+  __syncthreads();
+  if (lane == 0) {   // azbc[bi+1] = azbc[bi] + cost_all_zeros(bi): a float sum in block order (:1226-1227)
+    float a = 0.0f;
+    azbc[0] = 0.0f; abc[0] = 0.0f; req[0] = 0;
+    for (int b = 0; b < n; b++) { a = a + abc[b + 1]; azbc[b + 1] = a; }
+  }
+  __syncthreads();
+  for (int bi = 0; bi < n; bi++) {
+    if (req[bi + 1] != 2) {        // wave-uniform
+      const float sk = skip[bi], ab = azbc[bi];
+      float best = 1e38f;
+      int bidx = 0x7FFFFFFF;
+      for (int i = lane; i <= bi; i += 64) {
+        const int rq = req[i];
+        if (rq == 2) continue;
+        float cost = sk;
+        cost = cost + ab;
+        cost = cost - azbc[i];
+        cost = cost + abc[i];
+        cost = cost + eobrun_cost[bitlen((unsigned)(bi - i + rq))];
+        if (cost < best) { best = cost; bidx = i; }
+      }
+      wave_first_min(best, bidx);
+      if (lane == 0) { abc[bi + 1] = best; run_start[bi] = (unsigned short)bidx; }
+    }
+    __syncthreads();
+  }
+  // end of the last run (:1259-1276; NB the reference leaves abc out of this one), then the back-track (:1278-1293)
+  {
+    float best = 1e38f;
+    int bidx = 0x7FFFFFFF;
+    const float an = azbc[n];
+    for (int i = lane; i <= n; i += 64) {
+      const int rq = req[i];
+      if (rq == 2) continue;
+      float cost = 0.0f;
+      cost = cost + an;
+      cost = cost - azbc[i];
+      cost = cost + eobrun_cost[bitlen((unsigned)(n - i + rq))];
+      if (cost < best) { best = cost; bidx = i; }
+    }
+    wave_first_min(best, bidx);
+    if (lane == 0) {
+      int last_block = bidx - 1, bi = n - 1;
+      while (bi >= 0) {
+        while (bi > last_block) { zero[bi] = 1; bi--; }
+        if (bi < 0) break;
+        last_block = (int)run_start[bi] - 1;
+        bi--;
+      }
+    }
+  }
+  __syncthreads();
+  int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + (size_t)br * n;
+  for (int b = lane; b < n; b += 64)
+    if (zero[b])
+      for (int k = Ss; k <= Se; k++) qo[(size_t)k * cc.kstride + b] = 0;
+}
+
+// =============================================================================================
+// trellis_q_opt: jcdctmgr.c:1299-1306 sums, per quantization table and coefficient, raw * quantized and
+// 8 * quantized^2 over every block of every trellis pass; jcmaster.c:1014-1030 turns them into new table entries
+// q = clamp((int)(sum_src / sum_coef + 0.5), 1, 254) for the coefficients with a non-zero denominator.  Every term is an
+// integer and the totals stay far below 2^53, so the reference's double sums are exact and equal these 64-bit integer
+// sums whatever the order; the division is one IEEE double division, the same on both sides.
+// sums[image][table][64][2] (signed 64 bit).
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+k_qopt_accumulate(MjhConst C, const int16_t *__restrict__ coef_uq, const int16_t *__restrict__ coef_q, long long *__restrict__ sums)
+{
+  const int k = blockIdx.x + 1, comp = blockIdx.y, img = blockIdx.z;
+  const MjhComp cc = C.c[comp];
+  const int16_t *u = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + (size_t)k * cc.kstride;
+  const int16_t *q = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + (size_t)k * cc.kstride;
+  long long a = 0, b = 0;
+  for (int i = threadIdx.x; i < cc.nblk; i += 256) {
+    const int x = u[i], v = q[i];
+    a += (long long)(x * v);
+    b += (long long)(8 * v * v);
+  }
+  __shared__ long long sa[256], sb[256];
+  sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) { sa[threadIdx.x] += sa[threadIdx.x + off]; sb[threadIdx.x] += sb[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    long long *d = sums + (((size_t)img * 4 + cc.qtbl) * 64 + k) * 2;
+    atomicAdd(reinterpret_cast<unsigned long long *>(d), (unsigned long long)sa[0]);
+    atomicAdd(reinterpret_cast<unsigned long long *>(d + 1), (unsigned long long)sb[0]);
+  }
+}
+
+// new table entries -> the DQT bytes of every image's file (8-bit tables: one byte per entry at dqt_off[table] + k,
+// zig-zag order like the marker); out = first byte of image 0's frame header copy
+__global__ void __launch_bounds__(64)
+k_qopt_patch(const long long *__restrict__ sums, uint8_t *__restrict__ out, size_t out_stride, int4 dqt_off, const unsigned *__restrict__ sizes)
+{
+  const int img = blockIdx.x, t = blockIdx.y, k = threadIdx.x;
+  const int off = t == 0 ? dqt_off.x : t == 1 ? dqt_off.y : t == 2 ? dqt_off.z : dqt_off.w;
+  if (off < 0 || k == 0 || sizes[img] == 0) return;
+  const long long *d = sums + (((size_t)img * 4 + t) * 64 + k) * 2;
+  if (d[1] == 0) return;
+  int q = (int)((double)d[0] / (double)d[1] + 0.5);
+  if (q > 254) q = 254;
+  if (q < 1) q = 1;
+  out[(size_t)img * out_stride + off + k] = (uint8_t)q;
 }
 
 __global__ void k_zero_counters(unsigned *__restrict__ a, unsigned *__restrict__ b)
@@ -1207,12 +1383,20 @@ __device__ __forceinline__ void defer_blocks(bool mine, unsigned *__restrict__ l
   }
 }
 
-template <int QN, bool FSTATS>   // FSTATS: count the AC symbols of the final coefficients (sequential mode, last trellis round)
+// band limits + the per-block outputs of trellis_eob_opt ([image][real blocks of all components]); EXT kernels only
+struct MjhTrellisExt {
+  int Ss, Se;
+  float2 *eob_cost;   // {cost of the all-zero band, cost of the chosen path without its EOB}; null: trellis_eob_opt off
+  int *eob_has;       // has_eob 0 / 1 / 2 (jcdctmgr.c:1209)
+};
+
+template <int QN, bool FSTATS, bool EXT = false>   // FSTATS: count the AC symbols of the final coefficients (sequential mode, last trellis round)
 __global__ void __launch_bounds__(64)
 k_trellis_ac_q(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
                int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
                int4 ac_slot_of_comp, int4 wave0_of_comp, const float *__restrict__ lambda_in, unsigned *__restrict__ worklist,
-               int16_t *__restrict__ dense, unsigned dense_cap, MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp)
+               int16_t *__restrict__ dense, unsigned dense_cap, MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp,
+               MjhTrellisExt ext)
 {
   static_assert(QN >= 16 && QN <= 63, "queue capacity");
   __shared__ uint2 col[QN][64];                  // queue records, then live entries {azd, acc}, then the value column
@@ -1248,14 +1432,16 @@ k_trellis_ac_q(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__rest
     short xs[64];
 #pragma unroll
     for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
-    nq = trellis_q_phase1<QN>(xs, Q->dq8[cc.qtbl], Q->rcp8q[cc.qtbl], Q->lambda_tbl[cc.qtbl], lambda, col, lane, azd63);
+    nq = trellis_q_phase1<QN, EXT>(xs, Q->dq8[cc.qtbl], Q->rcp8q[cc.qtbl], Q->lambda_tbl[cc.qtbl], lambda, col, lane, azd63, ext.Ss, ext.Se);
     defer_blocks(inside && nq > QN, worklist, (unsigned)img, ((unsigned)comp << 28) | (unsigned)blk, 0u, xs, dense, dense_cap, true, lane);
   }
   __syncthreads();
   int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
   typedef unsigned __attribute__((may_alias)) u_alias;
   u_alias *hist = reinterpret_cast<u_alias *>(&e_pk[0][0]);   // 2 x 256 bins, zeroed inside once the e_pk words are in registers
-  trellis_q_walk<QN, true, FSTATS ? 1 : 0>(si_rows, rate_rows, dqT, ltT, 0, nq, azd63, lambda, inside, qo, cc.kstride, col, e_pk, lane, (unsigned *)hist);
+  const size_t gblk = (size_t)img * C.total_real_blocks + cc.blk_off + (inside ? blk : 0);
+  trellis_q_walk<QN, true, FSTATS ? 1 : 0, EXT>(si_rows, rate_rows, dqT, ltT, 0, nq, azd63, lambda, inside, qo, cc.kstride, col, e_pk, lane, (unsigned *)hist,
+                                                ext.Ss, ext.Se, EXT && ext.eob_cost ? ext.eob_cost + gblk : nullptr, EXT && ext.eob_cost ? ext.eob_has + gblk : nullptr);
   if (FSTATS) {
     __syncthreads();
     const int sslot = comp == 0 ? stat_slot_of_comp.x : comp == 1 ? stat_slot_of_comp.y : comp == 2 ? stat_slot_of_comp.z : stat_slot_of_comp.w;
@@ -1274,13 +1460,13 @@ k_trellis_ac_q(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__rest
 // Deferred blocks (any image / component per lane), same walk with a longer queue: raw coefficients come from the dense
 // copies (one line per block), code lengths from the image's table in global memory (L2-resident), quantizer constants
 // of all four tables from LDS.  Blocks beyond QN2 non-zero positions go to the next list (QN2 = 63 takes everything).
-template <int QN2, bool FSTATS>
+template <int QN2, bool FSTATS, bool EXT = false>
 __global__ void __launch_bounds__(64)
 k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
                 int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
                 int4 ac_slot_of_comp, const float *__restrict__ lambda_in, const unsigned *__restrict__ worklist,
                 unsigned *__restrict__ worklist_next, const int16_t *__restrict__ dense, unsigned dense_cap,
-                MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp)
+                MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp, MjhTrellisExt ext)
 {
   __shared__ uint2 col[QN2][64];
   __shared__ unsigned short e_pk[QN2 + 1][64];
@@ -1321,14 +1507,16 @@ k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
 #pragma unroll
         for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
       }
-      nq = trellis_q_phase1<QN2>(xs, dqT[cc.qtbl], Q->rcp8q[cc.qtbl], ltT[cc.qtbl], lambda, col, lane, azd63);
+      nq = trellis_q_phase1<QN2, EXT>(xs, dqT[cc.qtbl], Q->rcp8q[cc.qtbl], ltT[cc.qtbl], lambda, col, lane, azd63, ext.Ss, ext.Se);
       if (QN2 < 63) defer_blocks(active && nq > QN2, worklist_next, (unsigned)img, w, ds, xs, nullptr, 0u, false, lane);
     }
     int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
     const int sslot = comp == 0 ? stat_slot_of_comp.x : comp == 1 ? stat_slot_of_comp.y : comp == 2 ? stat_slot_of_comp.z : stat_slot_of_comp.w;
     unsigned *cnt = FSTATS ? stat_tabs[(size_t)img * slots_per_image + sslot].counts : nullptr;
-    trellis_q_walk<QN2, false, FSTATS ? 2 : 0>(reinterpret_cast<const uint4 *>(T->ehufsi), nullptr, dqT, ltT, cc.qtbl, nq, azd63, lambda, active, qo, cc.kstride,
-                                                col, e_pk, lane, cnt);
+    const size_t gblk = (size_t)img * C.total_real_blocks + cc.blk_off + blk;
+    trellis_q_walk<QN2, false, FSTATS ? 2 : 0, EXT>(reinterpret_cast<const uint4 *>(T->ehufsi), nullptr, dqT, ltT, cc.qtbl, nq, azd63, lambda, active, qo, cc.kstride,
+                                                     col, e_pk, lane, cnt, ext.Ss, ext.Se, EXT && ext.eob_cost ? ext.eob_cost + gblk : nullptr,
+                                                     EXT && ext.eob_cost ? ext.eob_has + gblk : nullptr);
     __syncthreads();   // the LDS columns are reused by the next round
   }
 }
@@ -1387,8 +1575,12 @@ k_trellis_dc(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restri
     const int row0 = br * cc.wib;
     int prev_c = 0;
     float prev_cost = 0.0f;
-    int xs_l = 0;
+    int xs_l = 0, above_l = 0;
     float lam_l = 0.0f;
+    // trellis_delta_dc_weight: the block above counts only inside an iMCU row (compress_trellis_pass jccoefct.c:426-427
+    // passes buffer[block_row-1], NULL for the first row); its quantized DC was written by this group's own back-track
+    // of the previous sub-row (made visible by the fence below)
+    const bool vert = sub > 0 && C.delta_dc_weight > 0.0f;
     for (int bi = 0; bi < cc.wib; bi++) {
       // every 16 blocks the group fetches the next 16 (DC, lambda) pairs with one coalesced load
       // per lane; the sequential recursion then only sees cross-lane shuffles, never HBM latency
@@ -1396,6 +1588,9 @@ k_trellis_dc(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restri
         const int b = bi + k;
         xs_l = b < cc.wib ? (int)uq0[row0 + b] : 0;
         lam_l = b < cc.wib ? lam[row0 + b] : 0.0f;
+        if (vert && b < cc.wib)   // raw DC above (low half) and the gradient's reconstructed part: final quantized DC above * 8q (high half)
+          above_l = ((int)uq0[row0 - cc.wib + b] & 0xFFFF) |
+                    ((int)__hip_atomic_load(reinterpret_cast<const unsigned short *>(qo0 + row0 - cc.wib + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 16);
       }
       const int xs = grp_shfl(xs_l, bi & 15, lane);
       const float lambda_dc = grp_shfl_f(lam_l, bi & 15, lane) * lt0;
@@ -1404,8 +1599,17 @@ k_trellis_dc(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restri
       int cnd = qval - ncand / 2 + k;
       cnd = min(1023, max(-1023, cnd));
       const int delta = cnd * dq - x;
-      const float dist = (float)(delta * delta) * lambda_dc;
+      float dist = (float)(delta * delta) * lambda_dc;
       if (xs < 0) cnd = -cnd;
+      if (vert) {   // jcdctmgr.c:1069-1084
+        const int ab = grp_shfl(above_l, bi & 15, lane);
+        const int dc_above_orig = (int)(short)(ab & 0xFFFF), dc_above_recon = (ab >> 16) * dq;
+        const int d2 = (dc_above_orig - xs) - (dc_above_recon - cnd * dq);
+        const float vertical_dist = (float)(d2 * d2) * lambda_dc;
+        float t = vertical_dist - dist;
+        t = C.delta_dc_weight * t;
+        dist = dist + t;
+      }
       float best;
       int bb = 0;
       if (bi == 0) {
@@ -1478,7 +1682,8 @@ k_trellis_dc(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restri
       }
     }
     last_dc = grp_shfl(last_dc, 0, lane);  // owner of block wib-1 is lane 0 of the first step
-    __threadfence_block();
+    if (C.delta_dc_weight > 0.0f) __threadfence();   // the next sub-row reads this row's final DC values back (other lanes of the group)
+    else __threadfence_block();
     (void)live;
   }
 }
@@ -2055,8 +2260,13 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
 }
 
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
-                           unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant, int n, hipStream_t s)
+                           unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
+                           int Ss, int Se, void *eob_cost, int *eob_has, int n, hipStream_t s)
 {
+  // band-limited pass (use_scans_in_trellis) and / or the per-block outputs of trellis_eob_opt: the EXT instantiations
+  const bool extended = Ss != 1 || Se != 63 || eob_cost != nullptr;
+  MjhTrellisExt ext;
+  ext.Ss = Ss; ext.Se = Se; ext.eob_cost = (float2 *)eob_cost; ext.eob_has = eob_has;
   const int4 sl = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
   // stat_slot != nullptr: the statistics of the final coefficients go to these table slots (one per component)
   MjhHuffTable *st = stat_slot ? tabs : nullptr;
@@ -2067,8 +2277,17 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   dim3 gridq(w0[C.ncomp], n);
   for (int i = C.ncomp; i < 4; i++) w0[i] = 0x7FFFFFFF;   // components that do not exist never match
   const int4 wv = make_int4(w0[0], w0[1], w0[2], w0[3]);
-#define LQ(QN, FS) hipLaunchKernelGGL((k_trellis_ac_q<QN, FS>), gridq, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, wv, lambda, worklist, (int16_t *)dense, dense_cap, st, ss)
-#define LD(QN, FS, GRID, WL, WLN) hipLaunchKernelGGL((k_trellis_ac_qd<QN, FS>), dim3(GRID), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda, (const unsigned *)WL, WLN, (const int16_t *)dense, dense_cap, st, ss)
+#define LQ(QN, FS) hipLaunchKernelGGL((k_trellis_ac_q<QN, FS>), gridq, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, wv, lambda, worklist, (int16_t *)dense, dense_cap, st, ss, ext)
+#define LD(QN, FS, GRID, WL, WLN) hipLaunchKernelGGL((k_trellis_ac_qd<QN, FS>), dim3(GRID), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda, (const unsigned *)WL, WLN, (const int16_t *)dense, dense_cap, st, ss, ext)
+  if (extended) {   // the rarely used options take one fixed tiering (16 -> 32 -> 63); the fused statistics do not exist here
+    hipLaunchKernelGGL((k_trellis_ac_q<16, false, true>), gridq, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, wv, lambda,
+                       worklist, (int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
+    hipLaunchKernelGGL((k_trellis_ac_qd<32, false, true>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
+                       (const unsigned *)worklist, worklist2, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
+    hipLaunchKernelGGL((k_trellis_ac_qd<63, false, true>), dim3(1024), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
+                       (const unsigned *)worklist2, (unsigned *)nullptr, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
+    return;
+  }
   // MJH_TRELLIS_VARIANT: queue capacity of the first tier (all bit-identical; LDS per wave = 10 * QN * 64 bytes);
   // second and third tier: blocks with more than QN (then 32) non-zero positions, from their dense copies
   if (st) {
@@ -2144,4 +2363,32 @@ void mjh_launch_stuff(const unsigned *stream, size_t stream_words_per_image, con
   hipLaunchKernelGGL(k_scan_sums, dim3(n), dim3(256), 0, s, ffsums, ff_chunks_per_image, ff_totals, totals);
   hipLaunchKernelGGL(k_stuff_write, dim3(ff_chunks_per_image < 128 ? ff_chunks_per_image : 128, n), dim3(256), 0, s, stream, stream_words_per_image, totals, ffsums, ff_chunks_per_image,
                      ff_totals, (uint8_t *)out, out_stride, (MjhImageMeta *)meta, sizes, mpos, nseg);
+}
+
+void mjh_launch_trellis_eob_chain(const MjhConst &C, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const void *eob_cost, const int *eob_has,
+                                  int Ss, int Se, int n, hipStream_t s)
+{
+  int r0[5] = { 0, 0, 0, 0, 0 }, maxw = 0;
+  for (int i = 0; i < 4; i++) { r0[i + 1] = r0[i] + (i < C.ncomp ? C.c[i].hib : 0); if (i < C.ncomp && C.c[i].wib > maxw) maxw = C.c[i].wib; }
+  const int rows = r0[C.ncomp];
+  for (int i = C.ncomp; i < 4; i++) r0[i] = 0x7FFFFFFF;
+  const size_t lds = (size_t)(maxw + 1) * 8 + (size_t)maxw * 4 + (size_t)maxw * 2 + (size_t)(maxw + 1) + (size_t)maxw + 16;
+  static bool raised = false;
+  if (lds > 48 * 1024 && !raised) {   // very wide images only: allow the dynamic allocation beyond the default limit
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_trellis_eob_chain), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    raised = true;
+  }
+  hipLaunchKernelGGL(k_trellis_eob_chain, dim3(rows, n), dim3(64), lds, s, C, (int16_t *)q, tabs, spi, make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]),
+                     make_int4(r0[0], r0[1], r0[2], r0[3]), (const float2 *)eob_cost, eob_has, Ss, Se);
+}
+
+void mjh_launch_qopt_accumulate(const MjhConst &C, const void *uq, const void *q, void *sums, int n, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_qopt_accumulate, dim3(63, C.ncomp, n), dim3(256), 0, s, C, (const int16_t *)uq, (const int16_t *)q, (long long *)sums);
+}
+
+void mjh_launch_qopt_patch(const void *sums, void *out, size_t out_stride, const int dqt_off[4], const unsigned *sizes, int n, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_qopt_patch, dim3(n, 4), dim3(64), 0, s, (const long long *)sums, (uint8_t *)out, out_stride,
+                     make_int4(dqt_off[0], dqt_off[1], dqt_off[2], dqt_off[3]), sizes);
 }

@@ -13,7 +13,14 @@ void mjh_launch_stats_ac(const MjhConst &C, const void *q, MjhHuffTable *tabs, i
 void mjh_launch_stats_dc(const MjhConst &C, const void *q, MjhHuffTable *tabs, int spi, const int slot[4], int mcu_order, const int comp_restart[4], int n, hipStream_t s);
 void mjh_launch_gen_tables(MjhHuffTable *tabs, int spi, const int *slots, int nslots, int n, hipStream_t s);
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
-                           unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant, int n, hipStream_t s);
+                           unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
+                           int Ss, int Se, void *eob_cost, int *eob_has, int n, hipStream_t s);
+// trellis_eob_opt: the block-row pass behind a (band-limited) AC trellis; eob_cost / eob_has as written by mjh_launch_trellis_ac
+void mjh_launch_trellis_eob_chain(const MjhConst &C, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const void *eob_cost, const int *eob_has,
+                                  int Ss, int Se, int n, hipStream_t s);
+// trellis_q_opt: sums[image][4 tables][64][2] += over all blocks; new entries patched into the DQT bytes of the finished files
+void mjh_launch_qopt_accumulate(const MjhConst &C, const void *uq, const void *q, void *sums, int n, hipStream_t s);
+void mjh_launch_qopt_patch(const void *sums, void *out, size_t out_stride, const int dqt_off[4], const unsigned *sizes, int n, hipStream_t s);
 void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s);
 void mjh_launch_encode(const MjhConst &C, const void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const int ac_slot[4],
                        void *len16, void *off32, unsigned *sums, int chunks_per_image, unsigned *totals,
@@ -39,7 +46,7 @@ void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *lis
                             int multi_dht, void *outpool, size_t out_bytes, unsigned *mpos, int mpos_per_image, unsigned *ffsums, int n, hipStream_t s,
                             hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join);
 void mjh_launch_scan16(const void *len16, int n_per, unsigned *sums, int chunks, unsigned *totals, unsigned *off32, int npairs, hipStream_t s);
-void mjh_launch_prog_select(void *ctl, int ncomp, int phase, int n, hipStream_t s);
+void mjh_launch_prog_select(void *ctl, int ncomp, int phase, int dc_scan_opt_mode, int n, hipStream_t s);
 void mjh_launch_prog_concat(const void *ctl, const void *file_hdr, int file_hdr_len, const void *outpool, size_t out_bytes,
                             void *out, size_t out_stride, unsigned *sizes, int n, hipStream_t s);
 #endif

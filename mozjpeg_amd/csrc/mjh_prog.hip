@@ -1658,7 +1658,7 @@ k_prog_select_al(MjhProgCtl *__restrict__ ctl, int ncomp, int nimg)
 }
 
 __global__ void __launch_bounds__(64)
-k_prog_select_order(MjhProgCtl *__restrict__ ctl, int ncomp, int nimg)
+k_prog_select_order(MjhProgCtl *__restrict__ ctl, int ncomp, int dc_scan_opt_mode, int nimg)
 {
   const int img = blockIdx.x * 64 + threadIdx.x;
   if (img >= nimg) return;
@@ -1694,6 +1694,11 @@ k_prog_select_order(MjhProgCtl *__restrict__ ctl, int ncomp, int nimg)
   const int bl = ct->best_Al_luma, bc = ct->best_Al_chroma;
   const int min_Al = bl < bc ? bl : bc;
   ord[n++] = 0;
+  if (ncomp == 3 && dc_scan_opt_mode != 0) {   // :836-838, :904-913: chroma DC interleaved (scan 23) or separate (24, 25)
+    const bool interleave = (unsigned long long)sz[nsl] <= (unsigned long long)sz[nsl + 1] + sz[nsl + 2];
+    if (interleave && dc_scan_opt_mode != 1) ord[n++] = nsl;
+    else { ord[n++] = nsl + 1; ord[n++] = nsl + 2; }
+  }
   if (fsl == 0) ord[n++] = lfs;
   else { ord[n++] = lfs + 2 * (fsl - 1) + 1; ord[n++] = lfs + 2 * (fsl - 1) + 2; }
   for (int Al = bl - 1; Al >= min_Al; Al--) ord[n++] = 3 + 3 * Al;
@@ -1815,10 +1820,10 @@ void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *lis
                      pool_words, (uint8_t *)outpool, out_bytes, (const unsigned *)mpos, mpos_per_image, ffsums);
 }
 
-void mjh_launch_prog_select(void *ctl, int ncomp, int phase, int n, hipStream_t s)
+void mjh_launch_prog_select(void *ctl, int ncomp, int phase, int dc_scan_opt_mode, int n, hipStream_t s)
 {
   if (phase == 0) hipLaunchKernelGGL(k_prog_select_al, dim3((n + 63) / 64), dim3(64), 0, s, (MjhProgCtl *)ctl, ncomp, n);
-  else hipLaunchKernelGGL(k_prog_select_order, dim3((n + 63) / 64), dim3(64), 0, s, (MjhProgCtl *)ctl, ncomp, n);
+  else hipLaunchKernelGGL(k_prog_select_order, dim3((n + 63) / 64), dim3(64), 0, s, (MjhProgCtl *)ctl, ncomp, dc_scan_opt_mode, n);
 }
 
 void mjh_launch_prog_concat(const void *ctl, const void *file_hdr, int file_hdr_len, const void *outpool, size_t out_bytes,

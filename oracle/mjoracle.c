@@ -1648,9 +1648,9 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
             memset(e.norm_src, 0, sizeof(e.norm_src));
             memset(e.norm_coef, 0, sizeof(e.norm_coef));
           }
-          if (bSe >= bSs) trellis_component(&e, ci, &dcd, &acd, bSs, bSe);   /* quantize_trellis returns at once for an empty band (:983-984) */
+          if (bSe >= bSs) trellis_component(&e, ci, &dcd, &acd, bSs, bSe);   /* quantize_trellis returns at once for an empty band (:979-980) ... */
           if (p->trellis_q_opt) {
-            q_opt_accumulate(&e, ci);
+            if (bSe >= bSs) q_opt_accumulate(&e, ci);                        /* ... before it reaches the sums (:1299-1306) */
             if ((pass_number + 1) % (p->num_components * ppc) == 0) { /* finish_pass_master jcmaster.c:1014-1030 */
               int ti, j;
               for (ti = 0; ti < 4; ti++)

@@ -76,17 +76,36 @@ CASES = [
     ("rgb_revert", dict(revert=True, rgb=True), True),                      # + -icc test1.icc = the reference's MD5_JPEG_RGB_ISLOW (drop-in test)
     ("rgb_base", dict(baseline=True, rgb=True), True),
     ("rgb_default_progressive", dict(rgb=True), True),
-    # trellis_q_opt (JBOOLEAN_TRELLIS_Q_OPT, jcmaster.c:1014-1030): ORACLE ONLY so far -- pinned here so that the HIP path
-    # can be checked the day it is built (its sums are exact integers, so a parallel reduction can be bit-exact)
-    ("base_trellis_q_opt", dict(baseline=True, trellis_q_opt=True), False),
-    ("default_progressive_trellis_q_opt", dict(trellis_q_opt=True), False),
+    # cjpeg -trellis-dc-ver-weight W (JFLOAT_TRELLIS_DELTA_DC_WEIGHT, jcdctmgr.c:1069-1084): needs a block above inside the iMCU row
+    ("base_dc_ver_weight1", dict(baseline=True, dc_ver_weight=1.0), True),
+    ("base_440_dc_ver_weight0p7", dict(baseline=True, dc_ver_weight=0.7, sample=(1, 2)), True),
+    ("q60_progressive_dc_ver_weight2", dict(dc_ver_weight=2.0, quality=60), True),
+    ("base_2x4_dc_ver_weight0p3", dict(baseline=True, dc_ver_weight=0.3, sample=(2, 4)), True),
+    # cjpeg -dc-scan-opt N (JINT_DC_SCAN_OPT_MODE, jcparam.c:791-794,:934-947, jcmaster.c:836-838,:904-913)
+    ("dc_scan_opt1", dict(dc_scan_opt=1), True),
+    ("dc_scan_opt2", dict(dc_scan_opt=2), True),
+    ("fastcrush_dc_scan_opt1", dict(fastcrush=True, dc_scan_opt=1), True),
+    ("fastcrush_dc_scan_opt2", dict(fastcrush=True, dc_scan_opt=2), True),
+    ("q30_444_dc_scan_opt2_restart1", dict(dc_scan_opt=2, quality=30, sample=(1, 1), restart=1), True),
+    ("gray_dc_scan_opt1", dict(dc_scan_opt=1, gray=True), True),
+    # trellis_q_opt (JBOOLEAN_TRELLIS_Q_OPT, sums jcdctmgr.c:1299-1306, table update jcmaster.c:1014-1030): on the device with one
+    # trellis round per component (the update then sits behind the last pass); with more rounds the reference re-estimates
+    # the tables between components -- oracle only (the HIP path refuses that combination)
+    ("base_trellis_q_opt", dict(baseline=True, trellis_q_opt=True), True),
+    ("default_progressive_trellis_q_opt", dict(trellis_q_opt=True), True),
     ("base_422_trellis_q_opt_loops3", dict(baseline=True, trellis_q_opt=True, trellis_loops=3, sample=(2, 1)), False),
-    # trellis_eob_opt (jcdctmgr.c:1224-1297) and use_scans_in_trellis (jcmaster.c:451-460): ORACLE ONLY so far
-    ("default_progressive_eob_opt", dict(trellis_eob_opt=True), False),
-    ("fastcrush_scans_in_trellis_eob_opt", dict(fastcrush=True, use_scans_in_trellis=True, trellis_eob_opt=True), False),
-    ("base_scans_in_trellis", dict(baseline=True, use_scans_in_trellis=True), False),
+    # trellis_eob_opt (jcdctmgr.c:1224-1297) and use_scans_in_trellis (jcmaster.c:451-460)
+    ("default_progressive_eob_opt", dict(trellis_eob_opt=True), True),
+    ("fastcrush_scans_in_trellis_eob_opt", dict(fastcrush=True, use_scans_in_trellis=True, trellis_eob_opt=True), True),
+    ("base_scans_in_trellis", dict(baseline=True, use_scans_in_trellis=True), True),
     ("progressive_all_trellis_options", dict(use_scans_in_trellis=True, trellis_freq_split=5, trellis_eob_opt=True, trellis_q_opt=True,
                                              trellis_loops=2), False),
+    ("progressive_all_trellis_options_1loop", dict(use_scans_in_trellis=True, trellis_freq_split=5, trellis_eob_opt=True, trellis_q_opt=True,
+                                                   dc_ver_weight=0.5), True),
+    ("base_444_eob_opt_q90", dict(baseline=True, trellis_eob_opt=True, quality=90, sample=(1, 1)), True),
+    ("base_scans_in_trellis_loops2_split20", dict(baseline=True, use_scans_in_trellis=True, trellis_loops=2, trellis_freq_split=20), True),
+    ("base_q_opt_scans_split63", dict(baseline=True, trellis_q_opt=True, use_scans_in_trellis=True, trellis_freq_split=63), True),   # empty second band
+    ("q40_progressive_eob_opt_restart1", dict(trellis_eob_opt=True, quality=40, restart=1), True),
 ]
 
 

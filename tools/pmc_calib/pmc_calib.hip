@@ -29,14 +29,43 @@ __global__ void __launch_bounds__(64) rd2B(const int16_t *__restrict__ a, unsign
   const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
   int acc = 0;
 #pragma unroll
-  for (int k = 1; k < 64; k++) acc += a[(size_t)k * stride + b];
-  if (acc == 0x1234567) sink[0] = 1;
+  for (int k = 1; k < 64; k++) acc ^= a[(size_t)k * stride + b];
+  if (acc == (int)stride) sink[0] = 1;
 }
 __global__ void __launch_bounds__(64) wr2B(int16_t *__restrict__ a, size_t stride)
 {
   const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
 #pragma unroll
   for (int k = 1; k < 64; k++) a[(size_t)k * stride + b] = (int16_t)(k + (int)b);
+}
+
+// the encoder's actual layout: [image][64 planes][kstride = 32448 int16] (4K luma: 32400 blocks rounded up to 64), one
+// wave per 64 blocks, 63 plane accesses per lane 64 896 bytes apart
+#define KSTRIDE 32448
+__global__ void __launch_bounds__(64) rd2B_planes(const int16_t *__restrict__ a, unsigned *__restrict__ sink, int magic)
+{
+  const int16_t *p = a + ((size_t)blockIdx.y * 64) * KSTRIDE + (size_t)blockIdx.x * 64 + threadIdx.x;
+  int acc = 0;
+#pragma unroll
+  for (int k = 1; k < 64; k++) acc ^= p[(size_t)k * KSTRIDE];
+  if (acc == magic) sink[0] = 1;
+}
+__global__ void __launch_bounds__(64) wr2B_planes(int16_t *__restrict__ a)
+{
+  int16_t *p = a + ((size_t)blockIdx.y * 64) * KSTRIDE + (size_t)blockIdx.x * 64 + threadIdx.x;
+#pragma unroll
+  for (int k = 1; k < 64; k++) p[(size_t)k * KSTRIDE] = (int16_t)(k + threadIdx.x);
+}
+// the same stores with arithmetic between them (the FDCT kernel computes one coefficient, stores it, computes the next)
+__global__ void __launch_bounds__(64) wr2B_planes_spaced(int16_t *__restrict__ a, int m)
+{
+  int16_t *p = a + ((size_t)blockIdx.y * 64) * KSTRIDE + (size_t)blockIdx.x * 64 + threadIdx.x;
+  int v = threadIdx.x;
+#pragma unroll
+  for (int k = 1; k < 64; k++) {
+    for (int j = 0; j < 40; j++) v = v * m + k;
+    p[(size_t)k * KSTRIDE] = (int16_t)v;
+  }
 }
 
 int main()
@@ -53,8 +82,12 @@ int main()
     hipLaunchKernelGGL(wr16B, dim3((unsigned)(n16 / 256)), dim3(256), 0, 0, (uint4 *)buf, n16);
     hipLaunchKernelGGL(rd2B, dim3((unsigned)(stride / 64)), dim3(64), 0, 0, (const int16_t *)buf, sink, stride);
     hipLaunchKernelGGL(wr2B, dim3((unsigned)(stride / 64)), dim3(64), 0, 0, (int16_t *)buf, stride);
+    hipLaunchKernelGGL(rd2B_planes, dim3(KSTRIDE / 64, 256), dim3(64), 0, 0, (const int16_t *)buf, sink, 12345 + rep);
+    hipLaunchKernelGGL(wr2B_planes, dim3(KSTRIDE / 64, 256), dim3(64), 0, 0, (int16_t *)buf);
+    hipLaunchKernelGGL(wr2B_planes_spaced, dim3(KSTRIDE / 64, 256), dim3(64), 0, 0, (int16_t *)buf, 3 + rep);
   }
   hipDeviceSynchronize();
-  printf("{\"rd16B_bytes\": %zu, \"wr16B_bytes\": %zu, \"rd2B_bytes\": %zu, \"wr2B_bytes\": %zu}\n", BYTES, BYTES, stride * 63 * 2, stride * 63 * 2);
+  printf("{\"rd16B_bytes\": %zu, \"wr16B_bytes\": %zu, \"rd2B_bytes\": %zu, \"wr2B_bytes\": %zu, \"planes_bytes\": %zu}\n", BYTES, BYTES, stride * 63 * 2, stride * 63 * 2,
+         (size_t)256 * 63 * KSTRIDE * 2);
   return 0;
 }
