@@ -149,6 +149,22 @@ int mjh_encoder_create(const mjh_params *p, int max_batch, int device, mjh_encod
 /* number of visible HIP devices (0 if there is none: every mjh_encoder_create then fails with MJH_EHIP) */
 int mjh_device_count(void);
 void mjh_encoder_destroy(mjh_encoder *e);
+/* the parameters the encoder was created with (owned by the encoder) */
+const mjh_params *mjh_encoder_params(const mjh_encoder *e);
+
+/* ---- one process, several GPUs --------------------------------------------- */
+/* A pool owns one encoder per device (devices == NULL: every visible device) and drives each from its own host thread.
+ * mjh_pool_encode_host deals the n images of a batch round-robin (image i -> device i mod N, nothing is exchanged
+ * between devices), pipelines every device's share through mjh_encode_host / mjh_collect in steps of
+ * max_batch_per_device, and returns the finished files in the caller's image order: (*jpegs)[i] is (*sizes)[i] bytes,
+ * in host memory owned by the pool, valid until the next call.  Pixels may be pageable or pinned. */
+typedef struct mjh_pool mjh_pool;
+int mjh_pool_create(const mjh_params *p, int max_batch_per_device, const int *devices, int ndevices, mjh_pool **out);
+void mjh_pool_destroy(mjh_pool *pool);
+int mjh_pool_device_count(const mjh_pool *pool);
+int mjh_pool_encode_host(mjh_pool *pool, const void *pixels, size_t row_pitch, size_t image_stride, int n,
+                         const uint8_t *const **jpegs, const size_t **sizes);
+const char *mjh_pool_last_error(const mjh_pool *pool);
 
 /* ---- encode ---------------------------------------------------------------------------- */
 /* Encode n images that are ALREADY in device memory (interleaved samples, row_pitch bytes per

@@ -82,6 +82,16 @@ def lib():
         L.mjh_encode_coefficients_device.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
         L.mjh_encode_coefficients_host.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int]
         L.mjh_encoder_sync.argtypes = [C.c_void_p]
+        L.mjh_encoder_params.argtypes = [C.c_void_p]
+        L.mjh_encoder_params.restype = C.POINTER(Params)
+        L.mjh_pool_create.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+        L.mjh_pool_destroy.argtypes = [C.c_void_p]
+        L.mjh_pool_destroy.restype = None
+        L.mjh_pool_device_count.argtypes = [C.c_void_p]
+        L.mjh_pool_encode_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
+                                           C.POINTER(C.POINTER(C.c_void_p)), C.POINTER(C.POINTER(C.c_size_t))]
+        L.mjh_pool_last_error.argtypes = [C.c_void_p]
+        L.mjh_pool_last_error.restype = C.c_char_p
         L.mjh_collect.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(Result)), C.POINTER(C.c_int)]
         L.mjh_wait_input.argtypes = [C.c_void_p]
         L.mjh_host_staging.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
@@ -183,6 +193,42 @@ def pinned_empty(shape, dtype=np.uint8):
     import weakref
     weakref.finalize(buf, lib().mjh_host_free, ptr)
     return arr
+
+
+class Pool:
+    """One process driving several GPUs (mjh_pool_*): one encoder + one host thread per device, images dealt
+    round-robin (image i -> device i mod N), files returned in image order.  devices=None: every visible device."""
+
+    def __init__(self, params, max_batch_per_device=8, devices=None):
+        self._h = C.c_void_p()
+        self.params = params
+        arr = (C.c_int * len(devices))(*devices) if devices else None
+        _chk(lib().mjh_pool_create(C.byref(params), max_batch_per_device, arr, len(devices) if devices else 0, C.byref(self._h)))
+
+    @property
+    def device_count(self):
+        return lib().mjh_pool_device_count(self._h)
+
+    def encode_host(self, frames):
+        """frames: uint8 [n, H, W, C] (or uint16 for 12-bit) C-contiguous.  Returns a list of bytes."""
+        frames = np.ascontiguousarray(frames)
+        n = frames.shape[0]
+        jp, sz = C.POINTER(C.c_void_p)(), C.POINTER(C.c_size_t)()
+        rc = lib().mjh_pool_encode_host(self._h, frames.ctypes.data, frames.strides[1], frames.strides[0], n, C.byref(jp), C.byref(sz))
+        if rc != OK:
+            raise MjhError(rc, lib().mjh_pool_last_error(self._h).decode() or lib().mjh_last_error().decode())
+        return [C.string_at(jp[i], sz[i]) for i in range(n)]
+
+    def close(self):
+        if self._h:
+            lib().mjh_pool_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Encoder:

@@ -1197,6 +1197,8 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   return MJH_OK;
 }
 
+extern "C" const mjh_params *mjh_encoder_params(const mjh_encoder *e) { return e ? &e->p : nullptr; }
+
 extern "C" int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t row_pitch, size_t image_stride, int n, void *stream)
 {
   if (!e || !d_pixels || n < 1 || n > e->max_batch) return fail(MJH_EINVAL, "bad arguments (n=%d, max_batch=%d)", n, e ? e->max_batch : 0);

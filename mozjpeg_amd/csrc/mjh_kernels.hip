@@ -1845,17 +1845,23 @@ k_seg_extra(MjhConst C, const unsigned *__restrict__ off32, const unsigned *__re
   seg_x[(size_t)img * nseg + sidx] = sidx < nseg - 1 ? ((8u - (L & 7u)) & 7u) + 16u : 0u;
 }
 
-__device__ __forceinline__ bool is_marker_pos(const unsigned *__restrict__ mpos, int nmark, unsigned bytepos)
-{
-  int lo = 0, hi = nmark - 1;
-  while (lo <= hi) {
-    const int mid = (lo + hi) >> 1;
-    const unsigned v = mpos[mid];
-    if (v == bytepos) return true;
-    if (v < bytepos) lo = mid + 1; else hi = mid - 1;
+// Restart markers inside the byte stream (their 0xFF is not data: never stuffed).  mpos[] is sorted; a lane looks at 32
+// consecutive bytes, so ONE lower-bound search for the first byte of its span (made only when the span holds a 0xFF at
+// all) and a cursor that moves forward replace a binary search per 0xFF byte.
+struct MarkerCursor {
+  const unsigned *mpos; int n, idx;
+  __device__ __forceinline__ MarkerCursor(const unsigned *m, int nmark) : mpos(m), n(nmark), idx(-1) {}
+  __device__ __forceinline__ bool at(unsigned bytepos)   // bytepos must not decrease between calls
+  {
+    if (idx < 0) {
+      int lo = 0, hi = n;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (mpos[mid] < bytepos) lo = mid + 1; else hi = mid; }
+      idx = lo;
+    }
+    while (idx < n && mpos[idx] < bytepos) idx++;
+    return idx < n && mpos[idx] == bytepos;
   }
-  return false;
-}
+};
 
 __global__ void __launch_bounds__(256)
 k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs,
@@ -2041,13 +2047,14 @@ k_ff_chunk_sums(const unsigned *__restrict__ stream, size_t stream_words_per_ima
   for (unsigned chunk = blockIdx.x; chunk * SCAN_CHUNK < nwords; chunk += gridDim.x) {
   unsigned s = 0;
   const unsigned base = chunk * SCAN_CHUNK + threadIdx.x * 8;
+  MarkerCursor mc(mpos, nseg - 1);
 #pragma unroll
   for (int i = 0; i < 8; i++) if (base + i < nwords) {  // bytes past nbytes are zero
     const unsigned w = p[base + i];
     unsigned cnt = ff_count(w);
     if (cnt && mpos) {   // the 0xFF of an RSTn marker is not data: never stuffed
       for (int b = 0; b < 4; b++)
-        if (((w >> (8 * b)) & 0xFFu) == 0xFFu && is_marker_pos(mpos, nseg - 1, (base + i) * 4 + b)) cnt--;
+        if (((w >> (8 * b)) & 0xFFu) == 0xFFu && mc.at((base + i) * 4 + b)) cnt--;
     }
     s += cnt;
   }
@@ -2074,13 +2081,14 @@ k_stuff_write(const unsigned *__restrict__ stream, size_t stream_words_per_image
   const unsigned base = chunk * SCAN_CHUNK + threadIdx.x * 8;
   unsigned w[8], s = 0;
   unsigned mk = 0;   // bit (4*i+b) set: byte b of word i is the 0xFF of a restart marker
+  MarkerCursor mc(mpos, nseg - 1);
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     w[i] = base + i < nwords ? p[base + i] : 0u;
     unsigned cnt = ff_count(w[i]);
     if (cnt && mpos) {
       for (int b = 0; b < 4; b++)
-        if (((w[i] >> (8 * b)) & 0xFFu) == 0xFFu && is_marker_pos(mpos, nseg - 1, (base + i) * 4 + b)) { cnt--; mk |= 1u << (4 * i + b); }
+        if (((w[i] >> (8 * b)) & 0xFFu) == 0xFFu && mc.at((base + i) * 4 + b)) { cnt--; mk |= 1u << (4 * i + b); }
     }
     s += cnt;
   }
@@ -2375,8 +2383,7 @@ void mjh_launch_trellis_eob_chain(const MjhConst &C, void *q, const MjhHuffTable
   const size_t lds = (size_t)(maxw + 1) * 8 + (size_t)maxw * 4 + (size_t)maxw * 2 + (size_t)(maxw + 1) + (size_t)maxw + 16;
   static bool raised = false;
   if (lds > 48 * 1024 && !raised) {   // very wide images only: allow the dynamic allocation beyond the default limit
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k_trellis_eob_chain), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    raised = true;
+    raised = hipFuncSetAttribute(reinterpret_cast<const void *>(k_trellis_eob_chain), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
   }
   hipLaunchKernelGGL(k_trellis_eob_chain, dim3(rows, n), dim3(64), lds, s, C, (int16_t *)q, tabs, spi, make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]),
                      make_int4(r0[0], r0[1], r0[2], r0[3]), (const float2 *)eob_cost, eob_has, Ss, Se);

@@ -142,6 +142,30 @@ int main(int argc, char **argv)
       if (fread(buf, 1, (size_t)n, f) != (size_t)n) n = 0;
       printf("stdio %ld %016lx\n", n, hash(buf, (unsigned long)n));
       free(buf); fclose(f); free(img);
+    } else if (!strcmp(sc, "ext_params")) {
+      /* the extension parameters no cjpeg switch reaches (jpeglib.h:321-356, jcext.c): trellis_eob_opt, use_scans_in_trellis
+       * + trellis_freq_split, trellis_q_opt, trellis_delta_dc_weight, dc_scan_opt_mode changed AFTER the script was built
+       * (scan 0 keeps all components and the search appends the separate chroma DC scans, jcmaster.c:904-913) */
+      int v;
+      for (v = 0; v < 4; v++) {
+        struct jpeg_compress_struct c;
+        unsigned char *o = NULL, *img = make_image(208, 136, 6 + v);
+        unsigned long n = 0;
+        c.err = jpeg_std_error(&err);
+        jpeg_create_compress(&c);
+        jpeg_mem_dest(&c, &o, &n);
+        setup(&c, 208, 136, 70 + 5 * v, v == 1);
+        if (v == 0) { jpeg_c_set_bool_param(&c, JBOOLEAN_TRELLIS_EOB_OPT, TRUE); jpeg_c_set_bool_param(&c, JBOOLEAN_TRELLIS_Q_OPT, TRUE); }
+        if (v == 1) { jpeg_c_set_bool_param(&c, JBOOLEAN_USE_SCANS_IN_TRELLIS, TRUE); jpeg_c_set_int_param(&c, JINT_TRELLIS_FREQ_SPLIT, 12);
+                      jpeg_c_set_float_param(&c, JFLOAT_TRELLIS_DELTA_DC_WEIGHT, 0.75f); }
+        if (v == 2) { jpeg_c_set_int_param(&c, JINT_DC_SCAN_OPT_MODE, 1); }
+        if (v == 3) { jpeg_c_set_int_param(&c, JINT_DC_SCAN_OPT_MODE, 2); jpeg_simple_progression(&c); jpeg_c_set_bool_param(&c, JBOOLEAN_TRELLIS_EOB_OPT, TRUE);
+                      jpeg_c_set_bool_param(&c, JBOOLEAN_USE_SCANS_IN_TRELLIS, TRUE); }
+        jpeg_start_compress(&c, TRUE); rows(&c, img, 136); jpeg_finish_compress(&c);
+        printf("ext_params %d %lu %016lx\n", v, n, hash(o, n));
+        jpeg_destroy_compress(&c);
+        free(o); free(img);
+      }
     }
   }
   return 0;

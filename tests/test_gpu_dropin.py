@@ -41,6 +41,11 @@ CJPEG_CASES = [
     ("revert_prog_restart3b", ["-revert", "-progressive", "-quality", "75", "-restart", "3B", "-sample", "2x2"]),
     ("revert_opt_smooth1", ["-revert", "-optimize", "-quality", "75", "-smooth", "1", "-sample", "2x2"]),   # MD5_JPEG_420S_IFAST_OPT
     ("base_smooth30", ["-quality", "75", "-baseline", "-smooth", "30", "-sample", "2x2"]),
+    ("dc_scan_opt1", ["-quality", "75", "-dc-scan-opt", "1", "-sample", "2x2"]),
+    ("dc_scan_opt2", ["-quality", "75", "-dc-scan-opt", "2", "-sample", "2x2"]),
+    ("fastcrush_dc_scan_opt2", ["-quality", "75", "-fastcrush", "-dc-scan-opt", "2", "-sample", "2x2"]),
+    ("base_dc_ver_weight1", ["-quality", "75", "-baseline", "-trellis-dc-ver-weight", "1.0", "-sample", "2x2"]),
+    ("q60_progressive_dc_ver_weight2", ["-quality", "60", "-trellis-dc-ver-weight", "2.0", "-sample", "2x2"]),
 ]
 
 
@@ -151,7 +156,7 @@ needs_h = pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(SHI
 
 @needs_h
 @pytest.mark.parametrize("mode", ["preload", "standalone"])
-@pytest.mark.parametrize("scenario", ["interleaved", "abort_reuse", "markers", "stdio"])
+@pytest.mark.parametrize("scenario", ["interleaved", "abort_reuse", "markers", "stdio", "ext_params"])
 def test_libjpeg_client_scenarios(scenario, mode):
     """two interleaved compress objects on one thread; error_exit longjmp -> jpeg_abort_compress -> reuse, and hundreds
     of start/abort and create/destroy cycles without growth; COM / APPn / ICC markers and JFIF density fields; the stdio
