@@ -23,10 +23,21 @@
  *                  quantized coefficients (jpegtran); the virtual arrays are read at jpeg_finish_compress,
  *                  so transforms executed in between are honoured.
  *
- * Everything else of the libjpeg API (jpeg_CreateCompress, jpeg_set_defaults, jpeg_set_quality,
- * jpeg_c_set_*_param, jpeg_mem_dest, jpeg_stdio_dest, jpeg_std_error, jpeg_abort, ...) keeps being
- * served by the host's libjpeg.so.62; the shim is placed in front of it (link order or
- * LD_PRELOAD), so an UNCHANGED client such as `cjpeg` runs the GPU path.  See INTEGRATION.md.
+ *   void       jpeg_abort_compress(j_compress_ptr), jpeg_abort(j_common_ptr),
+ *              jpeg_destroy_compress(j_compress_ptr), jpeg_destroy(j_common_ptr);
+ *                  replace jcapimin.c:118-135 / jcomapi.c:30-106: release what the entry points above attached
+ *                  to the object (staging image, cached encoder), then chain to the next definition in link order.
+ *
+ * Two libraries carry these symbols:
+ *  - libmozjpeg_hip_jpeg62.so (INTERPOSING): only the symbols above; everything else of the libjpeg API
+ *    (jpeg_CreateCompress, jpeg_set_defaults, jpeg_set_quality, jpeg_c_set_*_param, jpeg_mem_dest, jpeg_stdio_dest,
+ *    jpeg_std_error, ...) keeps being served by the host's libjpeg.so.62; the shim is placed in front of it (link
+ *    order or LD_PRELOAD), so an UNCHANGED client such as `cjpeg` runs the GPU path.
+ *  - mozjpeg_amd/standalone/libjpeg.so.62 (STAND-ALONE, jpeg_shim.c + jpeg_api.c built with -DMJH_STANDALONE): the
+ *    whole compress side of the API from our own sources (object life cycle jcapimin.c:34-135, error manager jerror.c,
+ *    pool memory manager jmemmgr.c, jpeg_set_defaults / jpeg_set_quality / jpeg_simple_progression / colour spaces
+ *    jcparam.c, extension accessors jcext.c, destinations jdatadst.c, markers / ICC / tables, jpeg_copy_critical_parameters
+ *    jctrans.c:97); an unchanged `cjpeg` runs against it alone.  See INTEGRATION.md 1 / 1b.
  *
  * Contract kept from the reference:
  *  - call order / global_state: CSTATE_START -> SCANNING | RAW_OK | WRCOEFS -> START, wrong order = ERREXIT1(JERR_BAD_STATE)
@@ -45,5 +56,5 @@
  */
 #ifndef MOZJPEG_HIP_JPEGLIB_H
 #define MOZJPEG_HIP_JPEGLIB_H
-#define MOZJPEG_HIP_SHIM_SYMBOLS "jpeg_start_compress jpeg_write_scanlines jpeg12_write_scanlines jpeg_finish_compress jpeg_write_raw_data jpeg12_write_raw_data jpeg_write_coefficients"
+#define MOZJPEG_HIP_SHIM_SYMBOLS "jpeg_start_compress jpeg_write_scanlines jpeg12_write_scanlines jpeg_finish_compress jpeg_write_raw_data jpeg12_write_raw_data jpeg_write_coefficients jpeg_abort_compress jpeg_abort jpeg_destroy_compress jpeg_destroy"
 #endif
