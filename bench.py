@@ -46,7 +46,7 @@ CONFIGS = {
                    name="3840x2160 synthetic RGB, q75 4:2:0 baseline, trellis+deringing+optimal Huffman (cjpeg -quality 75 -baseline)"),
     "c2": dict(w=1920, h=1080, kw=dict(quality=75, baseline=True), batch=64,
                name="C2: 1920x1080 synthetic RGB, q75 4:2:0 baseline, trellis on (cjpeg -quality 75 -baseline)"),
-    "c3": dict(w=3840, h=2160, kw=dict(quality=85, sample=(2, 2)), batch=8,
+    "c3": dict(w=3840, h=2160, kw=dict(quality=85, sample=(2, 2)), batch=32,
                name="C3: 3840x2160 synthetic RGB, q85 4:2:0 progressive + scan search (cjpeg -quality 85 -sample 2x2)"),
     "c4": dict(w=1920, h=1080, kw=dict(quality=75, baseline=True), batch=128, total=1024,
                name="C4: batch of 1024 x 1920x1080 frames, q75 trellis baseline, sharded over the GPUs (128 per encode call)"),

@@ -1035,8 +1035,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
 
   if (e->progressive) {
     if (before_output) { HIPCHK(hipStreamWaitEvent(s, before_output, 0)); before_output = nullptr; }   // the hand-over also reads the scan control block
-    mjh_launch_prog_reset(e->d_prog_ctl, e->nscans, n, s);
-    HIPCHK(hipMemsetAsync(e->d_pool, 0, (size_t)n * e->pool_words * 4, s));
+    mjh_launch_prog_reset(e->d_prog_ctl, e->nscans, n, s);   // (the scan pool is zeroed phase by phase, only what k_prog_alloc hands out)
   }
   if (ext_qopt) HIPCHK(hipMemsetAsync(e->d_qsums, 0, (size_t)n * 4 * 64 * 2 * sizeof(long long), s));   // prepare_for_pass jcmaster.c:687-698
   // trellis_num_loops (statistics, trellis) rounds (jcmaster.c:451-466): every round gathers the statistics of the

@@ -146,6 +146,7 @@ struct MjhProgPE {         // device buffers of that path, [image][scan of the l
 struct MjhProgCtl {        // per image, lives in HBM
   int best_Al_luma, best_Al_chroma, best_fs_luma, best_fs_chroma;
   unsigned pool_words_used;   // running allocation in the bit-stream pool
+  unsigned pool_zero_from;    // first word handed out by the current phase: [pool_zero_from, pool_words_used) is zeroed before the bit writers run
   unsigned out_bytes_used;    // running allocation in the scan-buffer pool
   unsigned error;             // 1: pool overflow
   unsigned pad;

@@ -1468,6 +1468,7 @@ k_prog_alloc(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
+  ct->pool_zero_from = ct->pool_words_used;
   for (int li = 0; li < nlist; li++) {
     const int sidx = scan_list[li];
     const unsigned long long bits = s_bits[li];
@@ -1481,6 +1482,25 @@ k_prog_alloc(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
     ct->pool_words_used = (unsigned)pw;
     ct->out_bytes_used = (unsigned)ob;
   }
+}
+
+// the bit writers OR into their words: the part of the pool this phase handed out is zeroed (the pool is sized for the
+// worst case, 8x the sequential stream with the scan search; what a phase uses is a few per cent of it)
+__global__ void __launch_bounds__(256)
+k_prog_zero_pool(const MjhProgCtl *__restrict__ ctl, unsigned *__restrict__ pool, size_t pool_words_per_image)
+{
+  const int img = blockIdx.y;
+  const MjhProgCtl *ct = ctl + img;
+  unsigned *p = pool + (size_t)img * pool_words_per_image;
+  const unsigned lo = ct->pool_zero_from, hi = ct->pool_words_used;
+  const unsigned lo4 = (lo + 3u) & ~3u, hi4 = hi & ~3u;
+  if (blockIdx.x == 0 && threadIdx.x < 8) {   // unaligned ends
+    const unsigned t = threadIdx.x;
+    if (t < 4) { if (lo + t < (lo4 < hi ? lo4 : hi)) p[lo + t] = 0u; }
+    else if (hi4 >= lo4 && hi4 + (t - 4) < hi) p[hi4 + (t - 4)] = 0u;
+  }
+  uint4 *p4 = reinterpret_cast<uint4 *>(p);
+  for (unsigned i = lo4 / 4 + blockIdx.x * 256 + threadIdx.x; i < hi4 / 4; i += gridDim.x * 256) p4[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // scan header into the scan's buffer: [DQT + SOF for scan 0] DHT SOS (jcmaster.c:671-684,
@@ -1743,7 +1763,7 @@ k_prog_reset(MjhProgCtl *__restrict__ ctl, int nscans, int nimg)
   if (img >= nimg) return;
   MjhProgCtl *ct = ctl + img;
   ct->best_Al_luma = ct->best_Al_chroma = ct->best_fs_luma = ct->best_fs_chroma = 0;
-  ct->pool_words_used = 0; ct->out_bytes_used = 0; ct->error = 0;
+  ct->pool_words_used = 0; ct->pool_zero_from = 0; ct->out_bytes_used = 0; ct->error = 0;
   ct->norder = nscans;
   for (int i = 0; i < nscans; i++) ct->order[i] = i;
   for (int i = 0; i < MJH_MAX_PROG_SCANS; i++) { ct->scan_us[0][i] = 0; ct->scan_us[1][i] = 0; }
@@ -1788,6 +1808,7 @@ void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *lis
 {
   hipLaunchKernelGGL(k_prog_alloc, dim3(n), dim3(256), 0, s, C, (const MjhProgScan *)scans, list, nlist, (MjhProgCtl *)ctl,
                      (const MjhHuffTable *)tabs, spi, pool_words, out_bytes, n);
+  hipLaunchKernelGGL(k_prog_zero_pool, dim3(128, n), dim3(256), 0, s, (const MjhProgCtl *)ctl, pool, pool_words);
   hipLaunchKernelGGL(k_prog_header, dim3(nlist, n), dim3(64), 0, s, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl,
                      (const MjhHuffTable *)tabs, spi, (const uint8_t *)frame_hdr, frame_hdr_len, multi_dht, (uint8_t *)outpool, out_bytes);
   // the sequential walks (scans with restart intervals: a few long workgroups) and the parallel chain write disjoint scan
