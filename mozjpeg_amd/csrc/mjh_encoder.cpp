@@ -265,6 +265,9 @@ struct mjh_encoder {
   uint8_t *d_back = nullptr;
   // SURVEY 8f row 4 options: per-block outputs of the AC trellis for trellis_eob_opt, 64-bit sums of trellis_q_opt
   void *d_eob_cost = nullptr; int *d_eob_has = nullptr; long long *d_qsums = nullptr;
+  // compact coefficient records between the AC trellis and the sequential coder: non-zero position masks;
+  // the values live in the AC planes of d_q, plane i+1 = i-th non-zero.  compact_last: the last batch's d_q is in that form
+  unsigned long long *d_nzmask = nullptr; bool use_compact = false, compact_last = false;
   int dqt_off[4] = { -1, -1, -1, -1 };      // file offset of the first entry of every 8-bit DQT table
   int nbands = 1, freq_split = 8;
   unsigned *d_seg_x = nullptr, *d_seg_E = nullptr, *d_seg_sums = nullptr, *d_seg_totals = nullptr, *d_mpos = nullptr;
@@ -630,7 +633,7 @@ static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -707,6 +710,15 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     HIPCHK_E(hipMalloc((void **)&e->d_eob_has, B * (size_t)C.total_real_blocks * 4));
   }
   if (p->trellis_quant && p->trellis_q_opt) HIPCHK_E(hipMalloc((void **)&e->d_qsums, B * 4 * 64 * 2 * sizeof(long long)));
+  {
+    // sequential mode, one plain trellis round: the trellis hands compact records to the final statistics, the bit-length
+    // and the bit-writing pass (MJH_COMPACT=0 keeps the one-plane-per-position form; both are bit-identical)
+    const char *v = getenv("MJH_COMPACT");
+    const int nl = p->trellis_num_loops > 1 ? p->trellis_num_loops : 1;
+    e->use_compact = !(v && atoi(v) == 0) && !e->progressive && p->trellis_quant && nl == 1 && e->nbands == 1 && !p->trellis_eob_opt && !p->trellis_q_opt &&
+                     !(e->fuse_mask & 2);
+    if (e->use_compact) HIPCHK_E(hipMalloc((void **)&e->d_nzmask, B * (size_t)C.total_real_blocks * sizeof(unsigned long long)));
+  }
   if (p->trellis_quant) {   // room for a quarter of all blocks (typically 1-2 % overflow); the rest would be read from the planes
     e->dense_cap = (unsigned)(B * (size_t)C.total_real_blocks / 4 + 1024);
     HIPCHK_E(hipMalloc((void **)&e->d_dense, (size_t)e->dense_cap * 128));
@@ -1025,6 +1037,9 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   // band-limited passes (use_scans_in_trellis) keep the other band's quantized planes, and the block-row
   // pass of trellis_eob_opt changes coefficients behind the per-block DP: neither fusion applies then
   const bool ext_eob = p.trellis_quant && p.trellis_eob_opt, ext_qopt = p.trellis_quant && p.trellis_q_opt;
+  const bool compact = e->use_compact && !coef_src;   // (coefficient input runs no trellis: planes stay one per position)
+  unsigned long long *const nzm = compact ? e->d_nzmask : nullptr;
+  e->compact_last = compact;
   const int nbands = p.trellis_quant ? e->nbands : 1;
   const bool fuse_pre = fuse_seq && (e->fuse_mask & 1) && !e->debug_taps && nbands == 1;
   const bool fuse_fin = fuse_seq && (e->fuse_mask & 2) && nbands == 1 && !ext_eob;
@@ -1057,7 +1072,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       // a pass over the previous result afterwards ...
       if (!first_pass || !fuse_pre) {
         pr.mark("stats_ac(pre-trellis)");
-        mjh_launch_stats_ac(C, e->d_q, e->d_tabs, spi, tr_ac, 0, n, s);
+        mjh_launch_stats_ac(C, e->d_q, nullptr, e->d_tabs, spi, tr_ac, 0, n, s);
       }
       pr.mark("stats_dc(pre-trellis)");
       mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, tr_dc, 0, e->comp_restart, n, s);
@@ -1110,7 +1125,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     pr.mark("trellis_ac");
     mjh_launch_trellis_ac(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap,
                           fuse_fin && p.optimize_coding && loop == nloops - 1 ? fin_ac : nullptr, e->trellis_variant,
-                          Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, n, s);
+                          Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, nzm, n, s);
     if (e->trellis_adapt && !extended && loop == 0) {
       e->h_defer[1] = (unsigned)n;
       HIPCHK(hipMemcpyAsync(&e->h_defer[0], e->d_worklist, sizeof(unsigned), hipMemcpyDeviceToHost, s));
@@ -1171,7 +1186,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     // pass 6: statistics of the interleaved scan (dummy blocks included) -> final tables
     if (!fuse_fin) {   // (else the last trellis round has counted the AC symbols already)
       pr.mark("stats_ac(final)");
-      mjh_launch_stats_ac(C, e->d_q, e->d_tabs, spi, fin_ac, 1, n, s);
+      mjh_launch_stats_ac(C, e->d_q, nzm, e->d_tabs, spi, fin_ac, 1, n, s);
     }
     pr.mark("stats_dc(final)");
     mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, fin_dc, 1, zero4, n, s);
@@ -1184,7 +1199,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   mjh_launch_header(e->d_prefix, e->prefix_len, e->d_sos, e->sos_len, e->d_tabs, spi, e->dht_slots, e->dht_ids, e->ndht,
                     p.compress_profile != MJH_PROFILE_FASTEST, e->d_out, e->out_stride, e->d_meta, n, s);
   pr.mark("huff_encode");
-  mjh_launch_encode(C, e->d_q, e->d_tabs, spi, fin_dc, fin_ac, e->d_len16, e->d_off32, e->d_sums, e->chunks, e->d_totals,
+  mjh_launch_encode(C, e->d_q, nzm, e->d_tabs, spi, fin_dc, fin_ac, e->d_len16, e->d_off32, e->d_sums, e->chunks, e->d_totals,
                     e->d_stream, e->stream_words, e->d_meta, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos, e->nseg, n, s);
   pr.mark("byte_stuff");
   mjh_launch_stuff(e->d_stream, e->stream_words, e->d_totals, e->d_ffsums, e->ff_chunks, e->d_fftotals, e->d_out, e->out_stride,
@@ -1752,6 +1767,23 @@ extern "C" int mjh_read_tap(mjh_encoder *e, int what, int image, int comp, void 
   if (!src) return fail(MJH_EINVAL, "tap %d not available (enable debug taps before encoding)", what);
   const size_t need = (size_t)64 * cc.nblk * 2;
   if (cap < need) return fail(MJH_ETOOSMALL, "need %zu bytes", need);
+  if (what == MJH_TAP_COEF_Q && e->compact_last) {
+    // the batch left compact records (plane i+1 = i-th non-zero of the block, d_nzmask = its positions): expand to [64][nblk]
+    std::vector<int16_t> planes((size_t)64 * cc.nblk);
+    std::vector<unsigned long long> mask(cc.nblk);
+    HIPCHK(hipMemcpy2D(planes.data(), (size_t)cc.nblk * 2, src + (size_t)image * C.coefs_per_image + cc.coef_off, (size_t)cc.kstride * 2,
+                       (size_t)cc.nblk * 2, 64, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(mask.data(), e->d_nzmask + (size_t)image * C.total_real_blocks + cc.blk_off, (size_t)cc.nblk * 8, hipMemcpyDeviceToHost));
+    int16_t *out = (int16_t *)dst;
+    for (int b = 0; b < cc.nblk; b++) {
+      out[b] = planes[b];   // DC plane
+      unsigned long long m = mask[b];
+      int i = 0;
+      for (int k = 1; k < 64; k++) out[(size_t)k * cc.nblk + b] = ((m >> k) & 1ull) ? planes[(size_t)(++i) * cc.nblk + b] : (int16_t)0;
+    }
+    if (size) *size = need;
+    return MJH_OK;
+  }
   // strip the kstride padding: [64][nblk]
   HIPCHK(hipMemcpy2D(dst, (size_t)cc.nblk * 2, src + (size_t)image * C.coefs_per_image + cc.coef_off, (size_t)cc.kstride * 2,
                      (size_t)cc.nblk * 2, 64, hipMemcpyDeviceToHost));

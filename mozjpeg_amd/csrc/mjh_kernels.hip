@@ -547,6 +547,70 @@ k_import_coefs(MjhConst C, MjhCoefSrc S, int16_t *__restrict__ coef_q, MjhImageM
 //                per-component passes, interleaved MCU order incl. dummy blocks for the final
 //                scan); per-wave ballot counting, no LDS atomics.
 // =============================================================================================
+// Compact coefficient records (written by the COMPACT trellis kernels): `mask` = the block's non-zero positions, plane i+1 =
+// its i-th non-zero value in position order.  f(position, value) is called for every non-zero coefficient in
+// position order; values arrive in bursts of 8 plane loads, and a burst is skipped once no block of the wave has a
+// value left for it.
+template <class F>
+__device__ __forceinline__ void for_each_nonzero(const int16_t *__restrict__ qb, size_t kstride, unsigned long long mask, bool active, F &&f)
+{
+  // (measured: this rolled form beats issuing every load of the wave up front -- the consumers are bound by their
+  // per-coefficient work (LDS histogram atomics, table lookups, bit writer), not by the load latency)
+  const int n = active ? __popcll(mask) : 0;
+#pragma unroll 1
+  for (int base = 0; base < 63; base += 8) {
+    if (__builtin_amdgcn_ballot_w64(base < n) == 0ull) break;
+    int v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = (base + j < n) ? (int)qb[(size_t)(base + j + 1) * kstride] : 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (base + j < n) {
+        const int pos = __builtin_ctzll(mask);
+        mask &= mask - 1ull;
+        f(pos, v[j]);
+      }
+  }
+}
+
+// k_stats_ac on compact records (the final statistics of the sequential scan)
+__global__ void __launch_bounds__(256)
+k_stats_ac_compact(MjhConst C, const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask, MjhHuffTable *__restrict__ tabs,
+                   int slots_per_image, int4 slot_of_comp, int count_dummies)
+{
+  __shared__ unsigned h[16][256];   // 16 interleaved copies: the common symbols would otherwise serialise the LDS atomics
+  const int comp = blockIdx.y, img = blockIdx.z;
+  const MjhComp cc = C.c[comp];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 4096; i += 256) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const int blk = blockIdx.x * 256 + tid;
+  {
+    const bool in = blk < cc.nblk;
+    const int b = in ? blk : cc.nblk - 1;
+    const int16_t *q = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + b;
+    const unsigned long long m = nzmask[(size_t)img * C.total_real_blocks + cc.blk_off + b];
+    unsigned *hh = h[tid & 15];
+    int prev = 0;
+    for_each_nonzero(q, (size_t)cc.kstride, m, in, [&](int pos, int v) {
+      int r = pos - prev - 1;
+      prev = pos;
+      if (r > 15) { atomicAdd(&hh[0xF0], (unsigned)(r >> 4)); r &= 15; }
+      atomicAdd(&hh[(r << 4) + bitlen((unsigned)(v < 0 ? -v : v))], 1u);
+    });
+    if (in && prev < 63) atomicAdd(&hh[0], 1u);
+  }
+  __syncthreads();
+  const int slot = comp == 0 ? slot_of_comp.x : comp == 1 ? slot_of_comp.y : comp == 2 ? slot_of_comp.z : slot_of_comp.w;
+  MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+  unsigned s = 0;
+#pragma unroll
+  for (int c2 = 0; c2 < 16; c2++) s += h[c2][tid];
+  if (count_dummies && tid == 0 && blockIdx.x == 0)
+    s += (unsigned)(cc.wpad * cc.hpad - cc.nblk);  // every dummy block codes one EOB (all-zero AC)
+  if (s) atomicAdd(&T->counts[tid], s);
+}
+
 __global__ void __launch_bounds__(256)
 k_stats_ac(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restrict__ tabs,
            int slots_per_image, int4 slot_of_comp, int count_dummies)
@@ -1008,13 +1072,19 @@ __device__ __forceinline__ int trellis_q_phase1(const short (&xs)[64], const int
 // EXT: band Ss..Se (the virtual start sits at position Ss-1, positions outside the band are neither read nor written)
 // and, when eob_out is not null, the three per-block results the end-of-band-run optimisation needs (jcdctmgr.c:1187-1209):
 // eob_out[0] = cost of the all-zero band, eob_out[1] = cost of the chosen path without its EOB, eob_has = 0/1/2.
-template <int QN, bool LDS_ROWS, int STATS, bool EXT = false>
+// COMPACT (sequential mode, plain 1..63 pass): instead of 63 position planes the block's result is written as a RECORD --
+// *nz_out = 64-bit mask of its non-zero positions, plane i+1 of the block = its i-th non-zero value in position order --
+// which is all the statistics / bit-length / bit-writing passes behind the trellis need: they then touch as many
+// planes as the busiest block of a wave has non-zero coefficients (~20 at q75) instead of 63.
+template <int QN, bool LDS_ROWS, int STATS, bool EXT = false, bool COMPACT = false>
 __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float4 *rate_rows, const int (*dqT)[64], const float (*ltT)[64],
                                                int qrow, int nq_in, float azd63, float lambda, bool active, int16_t *__restrict__ qo,
                                                int kstride, uint2 (*col)[64], unsigned short (*e_pk)[64], int lane, unsigned *counts,
-                                               int Ss = 1, int Se = 63, float2 *__restrict__ eob_out = nullptr, int *__restrict__ eob_has = nullptr)
+                                               int Ss = 1, int Se = 63, float2 *__restrict__ eob_out = nullptr, int *__restrict__ eob_has = nullptr,
+                                               unsigned long long *__restrict__ nz_out = nullptr)
 {
   static_assert(!(EXT && STATS), "the fused statistics exist for the plain 1..63 pass only");
+  static_assert(!(COMPACT && (EXT || STATS)), "compact records exist for the plain pass without fused statistics");
   const int vstart = EXT ? Ss - 1 : 0;          // position of the virtual start entry
   const int si_f0 = (int)(si_rows[15].x & 0xFFu), si_eob = (int)(si_rows[0].x & 0xFFu);
   const float f0f = si_f0 ? (float)si_f0 : 3e38f;
@@ -1136,10 +1206,14 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
     us_alias *colh = reinterpret_cast<us_alias *>(&col[0][0]);   // value of position k: row k>>2, half-word k&3
     unsigned long long mm = live & ~(1ull << vstart);
     int p = last;
+    unsigned long long pmask = 0ull;   // COMPACT: positions on the path; their values go to slots 0,1,.. in visiting (descending) order
+    int cnt = 0;
     if (STATS) { if (last < 63) atomicAdd(&hh[0], 1u); }      // trailing zeros (or an all-zero block): EOB
     if (QN <= 24) {
+      if (!COMPACT) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) colw[r * 64 + lane] = make_uint2(0u, 0u);
+        for (int r = 0; r < 16; r++) colw[r * 64 + lane] = make_uint2(0u, 0u);
+      }
 #pragma unroll
       for (int e2 = QN; e2 >= 1; e2--) {
         if (e2 < nlive) {
@@ -1148,7 +1222,9 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
           if (pos == p) {
             const int mag = (int)(pk[e2] >> 6);
             const int v = ((neg >> pos) & 1ull) ? -mag : mag;
-            colh[((pos >> 2) * 64 + lane) * 4 + (pos & 3)] = (unsigned short)v;
+            const int slot = COMPACT ? cnt : pos;
+            colh[((slot >> 2) * 64 + lane) * 4 + (slot & 3)] = (unsigned short)v;
+            if (COMPACT) { pmask |= 1ull << pos; cnt++; }
             p = (int)(pk[e2] & 63u);
             if (STATS) {
               const int run = pos - p - 1;
@@ -1159,8 +1235,10 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
         }
       }
     } else {
+      if (!COMPACT) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) colw[r * 64 + lane] = make_uint2(0u, 0u);
+        for (int r = 0; r < 16; r++) colw[r * 64 + lane] = make_uint2(0u, 0u);
+      }
       for (int e2 = nlive - 1; e2 >= 1; e2--) {
         const int pos = 63 - __builtin_clzll(mm);
         mm &= ~(1ull << pos);
@@ -1168,7 +1246,9 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
           const unsigned pkv = e_pk[e2][lane];
           const int mag = (int)(pkv >> 6);
           const int v = ((neg >> pos) & 1ull) ? -mag : mag;
-          colh[((pos >> 2) * 64 + lane) * 4 + (pos & 3)] = (unsigned short)v;
+          const int slot = COMPACT ? cnt : pos;
+          colh[((slot >> 2) * 64 + lane) * 4 + (slot & 3)] = (unsigned short)v;
+          if (COMPACT) { pmask |= 1ull << pos; cnt++; }
           p = (int)(pkv & 63u);
           if (STATS) {
             const int run = pos - p - 1;
@@ -1177,6 +1257,20 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
           }
         }
       }
+    }
+    if (COMPACT) {
+      *nz_out = pmask;
+      // plane i+1 <- the i-th non-zero in position order = slot cnt-1-i (per-lane LDS address); a plane is stored only
+      // while some block of the wave still has a value for it
+#pragma unroll
+      for (int i = 0; i < (QN < 63 ? QN : 63); i++) {
+        if (__builtin_amdgcn_ballot_w64(i < cnt) == 0ull) break;
+        if (i < cnt) {
+          const int slot = cnt - 1 - i;
+          qo[(size_t)(i + 1) * kstride] = (int16_t)colh[((slot >> 2) * 64 + lane) * 4 + (slot & 3)];
+        }
+      }
+      return;
     }
     uint2 vals[16];
 #pragma unroll
@@ -1388,9 +1482,10 @@ struct MjhTrellisExt {
   int Ss, Se;
   float2 *eob_cost;   // {cost of the all-zero band, cost of the chosen path without its EOB}; null: trellis_eob_opt off
   int *eob_has;       // has_eob 0 / 1 / 2 (jcdctmgr.c:1209)
+  unsigned long long *nzmask;   // COMPACT instantiations: non-zero position mask per block, [image][real blocks of all components]
 };
 
-template <int QN, bool FSTATS, bool EXT = false>   // FSTATS: count the AC symbols of the final coefficients (sequential mode, last trellis round)
+template <int QN, bool FSTATS, bool EXT = false, bool COMPACT = false>   // FSTATS: count the AC symbols of the final coefficients (sequential mode, last trellis round)
 __global__ void __launch_bounds__(64)
 k_trellis_ac_q(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
                int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
@@ -1440,8 +1535,9 @@ k_trellis_ac_q(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__rest
   typedef unsigned __attribute__((may_alias)) u_alias;
   u_alias *hist = reinterpret_cast<u_alias *>(&e_pk[0][0]);   // 2 x 256 bins, zeroed inside once the e_pk words are in registers
   const size_t gblk = (size_t)img * C.total_real_blocks + cc.blk_off + (inside ? blk : 0);
-  trellis_q_walk<QN, true, FSTATS ? 1 : 0, EXT>(si_rows, rate_rows, dqT, ltT, 0, nq, azd63, lambda, inside, qo, cc.kstride, col, e_pk, lane, (unsigned *)hist,
-                                                ext.Ss, ext.Se, EXT && ext.eob_cost ? ext.eob_cost + gblk : nullptr, EXT && ext.eob_cost ? ext.eob_has + gblk : nullptr);
+  trellis_q_walk<QN, true, FSTATS ? 1 : 0, EXT, COMPACT>(si_rows, rate_rows, dqT, ltT, 0, nq, azd63, lambda, inside, qo, cc.kstride, col, e_pk, lane, (unsigned *)hist,
+                                                         ext.Ss, ext.Se, EXT && ext.eob_cost ? ext.eob_cost + gblk : nullptr, EXT && ext.eob_cost ? ext.eob_has + gblk : nullptr,
+                                                         COMPACT ? ext.nzmask + gblk : nullptr);
   if (FSTATS) {
     __syncthreads();
     const int sslot = comp == 0 ? stat_slot_of_comp.x : comp == 1 ? stat_slot_of_comp.y : comp == 2 ? stat_slot_of_comp.z : stat_slot_of_comp.w;
@@ -1460,7 +1556,7 @@ k_trellis_ac_q(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__rest
 // Deferred blocks (any image / component per lane), same walk with a longer queue: raw coefficients come from the dense
 // copies (one line per block), code lengths from the image's table in global memory (L2-resident), quantizer constants
 // of all four tables from LDS.  Blocks beyond QN2 non-zero positions go to the next list (QN2 = 63 takes everything).
-template <int QN2, bool FSTATS, bool EXT = false>
+template <int QN2, bool FSTATS, bool EXT = false, bool COMPACT = false>
 __global__ void __launch_bounds__(64)
 k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
                 int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
@@ -1514,9 +1610,9 @@ k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     const int sslot = comp == 0 ? stat_slot_of_comp.x : comp == 1 ? stat_slot_of_comp.y : comp == 2 ? stat_slot_of_comp.z : stat_slot_of_comp.w;
     unsigned *cnt = FSTATS ? stat_tabs[(size_t)img * slots_per_image + sslot].counts : nullptr;
     const size_t gblk = (size_t)img * C.total_real_blocks + cc.blk_off + blk;
-    trellis_q_walk<QN2, false, FSTATS ? 2 : 0, EXT>(reinterpret_cast<const uint4 *>(T->ehufsi), nullptr, dqT, ltT, cc.qtbl, nq, azd63, lambda, active, qo, cc.kstride,
-                                                     col, e_pk, lane, cnt, ext.Ss, ext.Se, EXT && ext.eob_cost ? ext.eob_cost + gblk : nullptr,
-                                                     EXT && ext.eob_cost ? ext.eob_has + gblk : nullptr);
+    trellis_q_walk<QN2, false, FSTATS ? 2 : 0, EXT, COMPACT>(reinterpret_cast<const uint4 *>(T->ehufsi), nullptr, dqT, ltT, cc.qtbl, nq, azd63, lambda, active, qo, cc.kstride,
+                                                              col, e_pk, lane, cnt, ext.Ss, ext.Se, EXT && ext.eob_cost ? ext.eob_cost + gblk : nullptr,
+                                                              EXT && ext.eob_cost ? ext.eob_has + gblk : nullptr, COMPACT ? ext.nzmask + gblk : nullptr);
     __syncthreads();   // the LDS columns are reused by the next round
   }
 }
@@ -1708,8 +1804,9 @@ __device__ __forceinline__ int mcu_position(const MjhConst &C, const MjhComp &cc
   return m * C.blocks_per_mcu + cc.mcu_blk0 + (r % cc.v) * cc.h + (c % cc.h);
 }
 
+template <bool COMPACT>
 __global__ void __launch_bounds__(256)
-k_enc_len(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs,
+k_enc_len(MjhConst C, const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask, const MjhHuffTable *__restrict__ tabs,
           int slots_per_image, int4 dc_slot_of_comp, int4 ac_slot_of_comp, uint16_t *__restrict__ len16, MjhImageMeta *__restrict__ meta)
 {
   __shared__ unsigned char s_ac[256];
@@ -1736,6 +1833,21 @@ k_enc_len(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *__
   if (nb > (C.precision == 12 ? 15 : 11)) meta[img].bad_coef = 1u;   // MAX_COEF_BITS + 1 (jchuff.c:489)
   int bits = s_dc[nb] + nb;
   const bool real = r < cc.hib && c < cc.wib;
+  if (COMPACT) {
+    const int b = real ? r * cc.wib + c : 0;
+    const unsigned long long m = nzmask[(size_t)img * C.total_real_blocks + cc.blk_off + b];
+    const int zrl = s_ac[0xF0];
+    int prev = 0;
+    for_each_nonzero(q + b, (size_t)cc.kstride, m, real, [&](int pos, int v) {
+      const int run = pos - prev - 1;
+      prev = pos;
+      const int nbv = bitlen((unsigned)(v < 0 ? -v : v));
+      bits += (run >> 4) * zrl + s_ac[((run & 15) << 4) + nbv] + nbv;
+    });
+    if (!real || prev < 63) bits += s_ac[0];
+    len16[(size_t)img * C.total_mcu_blocks + mcu_position(C, cc, r, c)] = (uint16_t)bits;
+    return;
+  }
   int x[64];
   {
     const int16_t *qb = q + (real ? r * cc.wib + c : 0);   // dummy blocks: load anything in bounds, ignore it
@@ -1863,8 +1975,9 @@ struct MarkerCursor {
   }
 };
 
+template <bool COMPACT>
 __global__ void __launch_bounds__(256)
-k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs,
+k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask, const MjhHuffTable *__restrict__ tabs,
             int slots_per_image, int4 dc_slot_of_comp, int4 ac_slot_of_comp,
             const unsigned *__restrict__ off32, unsigned *__restrict__ stream, size_t stream_words_per_image,
             const unsigned *__restrict__ seg_E, unsigned *__restrict__ mpos, int nseg)
@@ -1903,6 +2016,22 @@ k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *
     if (nb) bw.put((unsigned)(df < 0 ? df - 1 : df), nb);
   }
   const bool real = r < cc.hib && c < cc.wib;
+  if (COMPACT) {
+    const int b = real ? r * cc.wib + c : 0;
+    const unsigned long long m = nzmask[(size_t)img * C.total_real_blocks + cc.blk_off + b];
+    int prev = 0;
+    for_each_nonzero(q + b, (size_t)cc.kstride, m, real, [&](int pos, int v) {
+      int run = pos - prev - 1;
+      prev = pos;
+      while (run > 15) { const unsigned e = s_ac[0xF0]; bw.put(e & 0xFFFF, (int)(e >> 16)); run -= 16; }
+      const int a = v < 0 ? -v : v;
+      const int nbv = bitlen((unsigned)a);
+      const unsigned e = s_ac[(run << 4) + nbv];
+      bw.put(e & 0xFFFF, (int)(e >> 16));
+      bw.put((unsigned)(v < 0 ? v - 1 : v), nbv);
+    });
+    if (!real || prev < 63) { const unsigned e = s_ac[0]; bw.put(e & 0xFFFF, (int)(e >> 16)); }
+  } else {
   int x[64];
   {
     const int16_t *qb = q + (real ? r * cc.wib + c : 0);
@@ -1929,6 +2058,7 @@ k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const MjhHuffTable *
   } else {
     const unsigned e = s_ac[0];
     bw.put(e & 0xFFFF, (int)(e >> 16));
+  }
   }
   if (C.restart_interval && segi < nseg - 1 && (mcu + 1) % C.restart_interval == 0 &&
       cc.mcu_blk0 + (r % cc.v) * cc.h + (c % cc.h) == C.blocks_per_mcu - 1) {
@@ -2235,10 +2365,11 @@ void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, vo
   else hipLaunchKernelGGL((k_dct_quant<uint8_t, false>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl);
 }
 
-void mjh_launch_stats_ac(const MjhConst &C, const void *q, MjhHuffTable *tabs, int spi, const int slot[4], int count_dummies, int n, hipStream_t s)
+void mjh_launch_stats_ac(const MjhConst &C, const void *q, const unsigned long long *nzmask, MjhHuffTable *tabs, int spi, const int slot[4], int count_dummies, int n, hipStream_t s)
 {
   dim3 grid((max_nblk(C) + 255) / 256, C.ncomp, n);
-  hipLaunchKernelGGL(k_stats_ac, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, make_int4(slot[0], slot[1], slot[2], slot[3]), count_dummies);
+  if (nzmask) hipLaunchKernelGGL(k_stats_ac_compact, grid, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, make_int4(slot[0], slot[1], slot[2], slot[3]), count_dummies);
+  else hipLaunchKernelGGL(k_stats_ac, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, make_int4(slot[0], slot[1], slot[2], slot[3]), count_dummies);
 }
 
 void mjh_launch_stats_dc(const MjhConst &C, const void *q, MjhHuffTable *tabs, int spi, const int slot[4], int mcu_order, const int comp_restart[4], int n, hipStream_t s)
@@ -2269,12 +2400,12 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
 
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
-                           int Ss, int Se, void *eob_cost, int *eob_has, int n, hipStream_t s)
+                           int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int n, hipStream_t s)
 {
   // band-limited pass (use_scans_in_trellis) and / or the per-block outputs of trellis_eob_opt: the EXT instantiations
   const bool extended = Ss != 1 || Se != 63 || eob_cost != nullptr;
   MjhTrellisExt ext;
-  ext.Ss = Ss; ext.Se = Se; ext.eob_cost = (float2 *)eob_cost; ext.eob_has = eob_has;
+  ext.Ss = Ss; ext.Se = Se; ext.eob_cost = (float2 *)eob_cost; ext.eob_has = eob_has; ext.nzmask = nzmask;
   const int4 sl = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
   // stat_slot != nullptr: the statistics of the final coefficients go to these table slots (one per component)
   MjhHuffTable *st = stat_slot ? tabs : nullptr;
@@ -2298,7 +2429,15 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   }
   // MJH_TRELLIS_VARIANT: queue capacity of the first tier (all bit-identical; LDS per wave = 10 * QN * 64 bytes);
   // second and third tier: blocks with more than QN (then 32) non-zero positions, from their dense copies
-  if (st) {
+  if (nzmask) {   // compact records out (the caller guarantees: plain pass, no fused statistics)
+#define LQC(QN) hipLaunchKernelGGL((k_trellis_ac_q<QN, false, false, true>), gridq, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, wv, lambda, worklist, (int16_t *)dense, dense_cap, st, ss, ext)
+#define LDC(QN, GRID, WL, WLN) hipLaunchKernelGGL((k_trellis_ac_qd<QN, false, false, true>), dim3(GRID), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda, (const unsigned *)WL, WLN, (const int16_t *)dense, dense_cap, st, ss, ext)
+    switch (variant) { case 1: LQC(20); break; case 2: LQC(24); break; case 3: LQC(32); break; default: LQC(16); break; }
+    if (variant == 3) LDC(63, 2048, worklist, (unsigned *)nullptr);
+    else { LDC(32, 2048, worklist, worklist2); LDC(63, 1024, worklist2, (unsigned *)nullptr); }
+#undef LQC
+#undef LDC
+  } else if (st) {
     switch (variant) { case 1: LQ(20, true); break; case 2: LQ(24, true); break; case 3: LQ(32, true); break; default: LQ(16, true); break; }
     if (variant == 3) LD(63, true, 2048, worklist, (unsigned *)nullptr);
     else { LD(32, true, 2048, worklist, worklist2); LD(63, true, 1024, worklist2, (unsigned *)nullptr); }
@@ -2327,7 +2466,7 @@ void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq,
   hipLaunchKernelGGL(k_trellis_dc, grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]), lambda, (uint8_t *)back);
 }
 
-void mjh_launch_encode(const MjhConst &C, const void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const int ac_slot[4],
+void mjh_launch_encode(const MjhConst &C, const void *q, const unsigned long long *nzmask, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const int ac_slot[4],
                        void *len16, void *off32, unsigned *sums, int chunks_per_image, unsigned *totals,
                        unsigned *stream, size_t stream_words_per_image, void *meta,
                        unsigned *seg_x, unsigned *seg_E, unsigned *seg_sums, unsigned *seg_totals, unsigned *mpos, int nseg,
@@ -2336,7 +2475,8 @@ void mjh_launch_encode(const MjhConst &C, const void *q, const MjhHuffTable *tab
   const int4 ds = make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]);
   const int4 as = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
   dim3 grid((max_padblk(C) + 255) / 256, C.ncomp, n);
-  hipLaunchKernelGGL(k_enc_len, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, ds, as, (uint16_t *)len16, (MjhImageMeta *)meta);
+  if (nzmask) hipLaunchKernelGGL((k_enc_len<true>), grid, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, ds, as, (uint16_t *)len16, (MjhImageMeta *)meta);
+  else hipLaunchKernelGGL((k_enc_len<false>), grid, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, ds, as, (uint16_t *)len16, (MjhImageMeta *)meta);
   hipLaunchKernelGGL((k_chunk_sums<uint16_t>), dim3(chunks_per_image, n), dim3(256), 0, s, (const uint16_t *)len16, C.total_mcu_blocks, sums, chunks_per_image);
   hipLaunchKernelGGL(k_scan_sums, dim3(n), dim3(256), 0, s, sums, chunks_per_image, totals, (const unsigned *)nullptr);
   hipLaunchKernelGGL((k_offsets<uint16_t>), dim3(chunks_per_image, n), dim3(256), 0, s, (const uint16_t *)len16, C.total_mcu_blocks, sums, chunks_per_image, (unsigned *)off32);
@@ -2350,8 +2490,10 @@ void mjh_launch_encode(const MjhConst &C, const void *q, const MjhHuffTable *tab
   }
   hipLaunchKernelGGL(k_zero_stream, dim3(64, n), dim3(256), 0, s, stream, stream_words_per_image, (const unsigned *)totals,
                      rst ? (const unsigned *)seg_totals : (const unsigned *)nullptr);
-  hipLaunchKernelGGL(k_enc_write, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image,
-                     (const unsigned *)seg_E, mpos, rst ? nseg : 1);
+  if (nzmask) hipLaunchKernelGGL((k_enc_write<true>), grid, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image,
+                                 (const unsigned *)seg_E, mpos, rst ? nseg : 1);
+  else hipLaunchKernelGGL((k_enc_write<false>), grid, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image,
+                          (const unsigned *)seg_E, mpos, rst ? nseg : 1);
   hipLaunchKernelGGL(k_finish_bits, dim3((n + 63) / 64), dim3(64), 0, s, totals, rst ? (const unsigned *)seg_totals : (const unsigned *)nullptr, stream,
                      stream_words_per_image, (MjhImageMeta *)meta, n);
 }

@@ -9,12 +9,14 @@ void mjh_launch_import_planes(const MjhConst &C, const MjhPlaneSrc &S, void *pla
 void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size_t img_stride, void *planes, int n, hipStream_t s);
 void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
                     MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], int n, hipStream_t s);
-void mjh_launch_stats_ac(const MjhConst &C, const void *q, MjhHuffTable *tabs, int spi, const int slot[4], int count_dummies, int n, hipStream_t s);
+// nzmask != nullptr (here and in mjh_launch_encode / mjh_launch_trellis_ac): the AC planes hold COMPACT records (plane i+1 = the block's i-th
+// non-zero value in position order, nzmask = its non-zero positions) instead of one plane per position
+void mjh_launch_stats_ac(const MjhConst &C, const void *q, const unsigned long long *nzmask, MjhHuffTable *tabs, int spi, const int slot[4], int count_dummies, int n, hipStream_t s);
 void mjh_launch_stats_dc(const MjhConst &C, const void *q, MjhHuffTable *tabs, int spi, const int slot[4], int mcu_order, const int comp_restart[4], int n, hipStream_t s);
 void mjh_launch_gen_tables(MjhHuffTable *tabs, int spi, const int *slots, int nslots, int n, hipStream_t s);
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
-                           int Ss, int Se, void *eob_cost, int *eob_has, int n, hipStream_t s);
+                           int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int n, hipStream_t s);
 // trellis_eob_opt: the block-row pass behind a (band-limited) AC trellis; eob_cost / eob_has as written by mjh_launch_trellis_ac
 void mjh_launch_trellis_eob_chain(const MjhConst &C, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const void *eob_cost, const int *eob_has,
                                   int Ss, int Se, int n, hipStream_t s);
@@ -22,7 +24,7 @@ void mjh_launch_trellis_eob_chain(const MjhConst &C, void *q, const MjhHuffTable
 void mjh_launch_qopt_accumulate(const MjhConst &C, const void *uq, const void *q, void *sums, int n, hipStream_t s);
 void mjh_launch_qopt_patch(const void *sums, void *out, size_t out_stride, const int dqt_off[4], const unsigned *sizes, int n, hipStream_t s);
 void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s);
-void mjh_launch_encode(const MjhConst &C, const void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const int ac_slot[4],
+void mjh_launch_encode(const MjhConst &C, const void *q, const unsigned long long *nzmask, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const int ac_slot[4],
                        void *len16, void *off32, unsigned *sums, int chunks_per_image, unsigned *totals,
                        unsigned *stream, size_t stream_words_per_image, void *meta,
                        unsigned *seg_x, unsigned *seg_E, unsigned *seg_sums, unsigned *seg_totals, unsigned *mpos, int nseg,
