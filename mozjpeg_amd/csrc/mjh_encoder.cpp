@@ -715,8 +715,10 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     // and the bit-writing pass (MJH_COMPACT=0 keeps the one-plane-per-position form; both are bit-identical)
     const char *v = getenv("MJH_COMPACT");
     const int nl = p->trellis_num_loops > 1 ? p->trellis_num_loops : 1;
-    e->use_compact = !(v && atoi(v) == 0) && !e->progressive && p->trellis_quant && nl == 1 && e->nbands == 1 && !p->trellis_eob_opt && !p->trellis_q_opt &&
-                     !(e->fuse_mask & 2);
+    bool restart_scans = false;   // progressive: scans with restart intervals go through the sequential walk, which reads one plane per position
+    if (e->progressive && (p->restart_interval || p->restart_in_rows)) restart_scans = true;
+    e->use_compact = !(v && atoi(v) == 0) && p->trellis_quant && nl == 1 && e->nbands == 1 && !p->trellis_eob_opt && !p->trellis_q_opt &&
+                     (e->progressive ? !restart_scans : !(e->fuse_mask & 2));
     if (e->use_compact) HIPCHK_E(hipMalloc((void **)&e->d_nzmask, B * (size_t)C.total_real_blocks * sizeof(unsigned long long)));
   }
   if (p->trellis_quant) {   // room for a quarter of all blocks (typically 1-2 % overflow); the rest would be read from the planes
@@ -1088,7 +1090,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       if (plt.nseq)
         mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + plt.seq_off, plt.nseq, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
       mjh_launch_prog_stats_par(C, e->d_prog_scans, e->d_lists + plt.par_off, plt.npar, e->d_prog_ctl, e->d_q, e->d_tabs, spi,
-                                e->pe, plt.any_refine, n, s);
+                                e->pe, plt.any_refine, nullptr, n, s);   // (the conventionally quantized planes: one per position)
       pr.mark("gen_tables(trellis)");
       mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + plt.slot_off, plt.nslot, n, s);
       for (int i = 0; i < 4; i++) tr_dc[i] = fin_dc[i];
@@ -1159,7 +1161,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
         ps = e->side_stream;
       }
       mjh_launch_prog_stats_par(C, e->d_prog_scans, e->d_lists + pl.par_off, pl.npar, e->d_prog_ctl, e->d_q, e->d_tabs, spi,
-                                e->pe, pl.any_refine, n, ps);
+                                e->pe, pl.any_refine, nzm, n, ps);
       if (both) HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
       if (pl.nseq)
         mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + pl.seq_off, pl.nseq, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
@@ -1170,7 +1172,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       mjh_launch_prog_encode(C, e->d_prog_scans, e->d_lists + pl.scan_off, pl.nscan, e->d_lists + pl.seq_off, pl.nseq, e->d_lists + pl.par_off, pl.npar,
                              e->pe, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_pool, e->pool_words,
                              e->d_frame_hdr, e->frame_hdr_len, p.compress_profile != MJH_PROFILE_FASTEST, e->d_outpool, e->outpool_bytes,
-                             e->d_prog_mpos, e->mpos_per_image, e->d_prog_ffsums, n, s, e->side_stream, e->ev_fork, e->ev_join);
+                             e->d_prog_mpos, e->mpos_per_image, e->d_prog_ffsums, nzm, n, s, e->side_stream, e->ev_fork, e->ev_join);
       if (p.optimize_scans) { pr.mark("prog_select"); mjh_launch_prog_select(e->d_prog_ctl, C.ncomp, ph, p.dc_scan_opt_mode, n, s); }
     }
     if (before_output) HIPCHK(hipStreamWaitEvent(s, before_output, 0));

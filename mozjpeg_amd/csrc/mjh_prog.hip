@@ -672,6 +672,50 @@ __device__ __forceinline__ int pp_units(const MjhConst &C, const MjhProgScan &sc
 // positions, their sign / correction bits; own = bits of the block's own symbols incl. the correction bits flushed inside;
 // tail = correction bits still buffered behind its last symbol (positions tailm); SIZES: 0 = count symbols into hist
 struct PPRefine { unsigned long long newm, nzm, corrm, posm, tailm; int tail_cnt; bool ne, E; unsigned own; };
+
+// COMPACT coefficient records (written by the compact AC trellis, mjh_kernels.hip: nzmask = non-zero positions of the block,
+// plane i+1 = its i-th non-zero value in position order): f(position, value) for the non-zero coefficients at positions
+// Ss..Se in position order.  Every lane of a wave reads the same plane at a time (coalesced), bursts of 8, up to the
+// rank of the last position <= Se the busiest block of the wave has; positions below Ss are read and dropped.
+template <class F>
+__device__ __forceinline__ void pp_band_nonzeros(const int16_t *__restrict__ qb, size_t kstride, unsigned long long mask, int Ss, int Se, bool active, F &&f)
+{
+  if (Se < 63) mask &= (2ull << Se) - 1ull;
+  const int n = active ? __popcll(mask) : 0;
+#pragma unroll 1
+  for (int base = 0; base < 63; base += 8) {
+    if (__builtin_amdgcn_ballot_w64(base < n) == 0ull) break;
+    int v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = (base + j < n) ? (int)qb[(size_t)(base + j + 1) * kstride] : 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (base + j < n) {
+        const int pos = __builtin_ctzll(mask);
+        mask &= mask - 1ull;
+        if (pos >= Ss) f(pos, v[j]);
+      }
+  }
+}
+
+template <bool COUNT>
+__device__ __forceinline__ PPRefine pp_refine_finish(PPRefine R, int Ss, int Se, const unsigned char *s_size, unsigned *hist);
+
+// the four masks of a refinement block from a compact record, then the common part
+template <bool COUNT>
+__device__ __forceinline__ PPRefine pp_refine_block_compact(const int16_t *__restrict__ qb, size_t kstride, unsigned long long mask, bool active,
+                                                            int Ss, int Se, int Al, const unsigned char *s_size, unsigned *hist)
+{
+  PPRefine R;
+  R.newm = R.nzm = R.corrm = R.posm = R.tailm = 0; R.own = 0;
+  pp_band_nonzeros(qb, kstride, mask, Ss, Se, active, [&](int k, int v) {
+    const int a = (v < 0 ? -v : v) >> Al;
+    if (a == 1) { R.newm |= 1ull << k; if (v >= 0) R.posm |= 1ull << k; }
+    else if (a > 1) { R.nzm |= 1ull << k; if (a & 1) R.corrm |= 1ull << k; }
+  });
+  return pp_refine_finish<COUNT>(R, Ss, Se, s_size, hist);
+}
+
 template <bool COUNT>
 __device__ __forceinline__ PPRefine pp_refine_block(const int (&x)[64], int Ss, int Se, int Al, const unsigned char *s_size, unsigned *hist)
 {
@@ -689,6 +733,12 @@ __device__ __forceinline__ PPRefine pp_refine_block(const int (&x)[64], int Ss, 
       else if (a > 1) { R.nzm |= 1ull << k; if (a & 1) R.corrm |= 1ull << k; }
     }
   } }
+  return pp_refine_finish<COUNT>(R, Ss, Se, s_size, hist);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ PPRefine pp_refine_finish(PPRefine R, int Ss, int Se, const unsigned char *s_size, unsigned *hist)
+{
   R.ne = R.newm != 0;
   const int EOBk = R.ne ? 63 - __builtin_clzll(R.newm) : -1;
   int r = 0, prev = Ss - 1, BR = 0, flushed_below = Ss;
@@ -737,10 +787,11 @@ k_pp_init(MjhProgPE pe, int npairs)
   if (i < npairs) { pe.info[i].final_run = 0; pe.info[i].final_be = 0; pe.info[i].fallback = 0; pe.info[i].corr_total = 0; }
 }
 
+template <bool COMPACT>
 __global__ void __launch_bounds__(256)
 k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
-           const MjhProgCtl *__restrict__ ctl, const int16_t *__restrict__ coef_q, MjhHuffTable *__restrict__ tabs,
-           int slots_per_image, MjhProgPE pe)
+           const MjhProgCtl *__restrict__ ctl, const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask,
+           MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe)
 {
   __shared__ unsigned hist[4][256];   // DC scans: [table 0 / 1]; AC scans: four interleaved copies (the hot symbols serialise the LDS atomics)
   __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64], e_bits[MJH_PSTAT_BLOCKS / 64];
@@ -814,11 +865,38 @@ k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
   for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
     const int j = i * 256 + tid;
     if (i * 256 >= nb) { if (refine) tail[j] = 0; continue; }   // uniform
-    int x[64];
     const int16_t *qs = qc + cb + (j < nb ? j : nb - 1);
-    PP_LOAD_BAND(x, qs, cc.kstride, Ss, Se)
     bool ne = false, E = false;
     int tc = 0;
+    if (COMPACT) {
+      const unsigned long long m = nzmask[(size_t)img * C.total_real_blocks + cc.blk_off + cb + (j < nb ? j : nb - 1)];
+      if (!refine) {
+        int prev = Ss - 1;
+        unsigned *hh = hist[tid & 3];
+        pp_band_nonzeros(qs, (size_t)cc.kstride, m, Ss, Se, j < nb, [&](int k, int v) {
+          const int a = (v < 0 ? -v : v) >> Al;
+          if (a == 0) return;
+          int r = k - prev - 1;
+          prev = k;
+          if (r > 15) { atomicAdd(&hh[0xF0], (unsigned)(r >> 4)); r &= 15; }
+          atomicAdd(&hh[(r << 4) + bitlen((unsigned)a)], 1u);
+        });
+        ne = prev != Ss - 1;
+        E = prev < Se;
+      } else {
+        const PPRefine R = pp_refine_block_compact<true>(qs, (size_t)cc.kstride, m, j < nb, Ss, Se, Al, nullptr, hist[tid & 3]);
+        ne = R.ne; E = R.E; tc = R.tail_cnt;
+        corr += (unsigned)__popcll(R.nzm);
+      }
+      if (j < nb) {
+        if (ne) atomicOr(&ne_bits[j >> 6], 1ull << (j & 63));
+        if (E) atomicOr(&e_bits[j >> 6], 1ull << (j & 63));
+      }
+      if (refine) tail[j] = (uint16_t)(j < nb ? tc : 0);
+      continue;
+    }
+    int x[64];
+    PP_LOAD_BAND(x, qs, cc.kstride, Ss, Se)
     if (j < nb) {
       if (!refine) {
         int r = 0;
@@ -1102,9 +1180,10 @@ __device__ __forceinline__ unsigned pp_dc_unit(const MjhConst &C, const MjhProgS
   return bits;
 }
 
+template <bool COMPACT>
 __global__ void __launch_bounds__(256)
 k_pp_len(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl,
-         const int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe)
+         const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask, const MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe)
 {
   __shared__ unsigned char s_size[256];
   __shared__ unsigned s_dc[2][16];
@@ -1158,6 +1237,37 @@ k_pp_len(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restric
     if (i * 256 >= nb) { len[j] = 0; continue; }   // uniform
     // a wave whose 64 blocks are all empty (sparse bands, refinement scans) has no symbols to size: skip its plane loads
     const bool has_own = j < nb && ((rn_bits[j >> 6] >> (j & 63)) & 1ull);
+    unsigned own = 0;
+    bool ne = false;
+    if (COMPACT) {
+      if (__builtin_amdgcn_ballot_w64(has_own) != 0ull) {
+        const int jb = cb + (j < nb ? j : nb - 1);
+        const unsigned long long m = nzmask[(size_t)img * C.total_real_blocks + cc.blk_off + jb];
+        if (!refine) {
+          int prev = Ss - 1;
+          const unsigned zrl = s_size[0xF0];
+          pp_band_nonzeros(qc + jb, (size_t)cc.kstride, m, Ss, Se, has_own, [&](int k, int v) {
+            const int a = (v < 0 ? -v : v) >> Al;
+            if (a == 0) return;
+            const int r = k - prev - 1;
+            prev = k;
+            const int nbits = bitlen((unsigned)a);
+            own += (unsigned)(r >> 4) * zrl + s_size[((r & 15) << 4) + nbits] + (unsigned)nbits;
+          });
+          ne = prev != Ss - 1;
+        } else {
+          const PPRefine R = pp_refine_block_compact<false>(qc + jb, (size_t)cc.kstride, m, has_own, Ss, Se, Al, s_size, nullptr);
+          ne = R.ne; own = R.own;
+        }
+        if (!ne || !has_own) own = 0;
+      }
+      if (j < nb && ((fp_bits[j >> 6] >> (j & 63)) & 1ull)) {
+        const unsigned cnt = run[j];
+        if (cnt) { int nextra; const int sym = eobrun_symbol(cnt, &nextra); own += s_size[sym] + (unsigned)nextra + (refine ? be16[j] : 0u); }
+      }
+      len[j] = (uint16_t)own;
+      continue;
+    }
     int x[64];
     if (__builtin_amdgcn_ballot_w64(has_own) != 0ull) {
       const int16_t *qs = qc + cb + (j < nb ? j : nb - 1);
@@ -1166,8 +1276,6 @@ k_pp_len(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restric
 #pragma unroll
       for (int k = 0; k < 64; k++) x[k] = 0;
     }
-    unsigned own = 0;
-    bool ne = false;
     if (has_own) {
       if (!refine) {
         int r = 0;
@@ -1204,9 +1312,10 @@ k_pp_len(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restric
   }
 }
 
+template <bool COMPACT>
 __global__ void __launch_bounds__(256)
 k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl,
-           const int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
+           const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
            unsigned *__restrict__ pool, size_t pool_words_per_image, MjhProgPE pe)
 {
   __shared__ unsigned s_tab[256];   // size << 16 | code
@@ -1265,11 +1374,46 @@ k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
     if (i * 256 >= nb) break;   // uniform
     // blocks without symbols or trailing correction bits of their own need no coefficients: a wave of such blocks skips the loads
     const bool has_data = j < nb && (len[j] != 0 || (refine && pe.tail16[pair * pe.nblk_pad + cb + j] != 0));
+    if (__builtin_amdgcn_ballot_w64(has_data) == 0ull) continue;
+    const int jb = cb + (j < nb ? j : nb - 1);
+    unsigned long long cmask = 0ull;
+    if (COMPACT) cmask = nzmask[(size_t)img * C.total_real_blocks + cc.blk_off + jb];
     int x[64];
-    if (__builtin_amdgcn_ballot_w64(has_data) != 0ull) {
-      const int16_t *qs = qc + cb + (j < nb ? j : nb - 1);
+    if (!COMPACT) {
+      const int16_t *qs = qc + jb;
       PP_LOAD_BAND(x, qs, cc.kstride, Ss, Se)
-    } else continue;
+    }
+    if (COMPACT && !refine) {
+      // AC-first scan from compact records: every lane of the wave takes part in the (wave-uniform) plane loads
+      const bool wr = has_data && len[j] != 0;
+      BitWriter bw;
+      bw.init(stream, base + (wr ? off[j] : 0u));
+      if (wr) {
+        const unsigned cnt = run[j];
+        if (cnt) {
+          int nextra;
+          const unsigned e = s_tab[eobrun_symbol(cnt, &nextra)];
+          bw.put(e & 0xFFFF, (int)(e >> 16));
+          if (nextra) bw.put(cnt & ((1u << nextra) - 1u), nextra);
+        }
+      }
+      int prev = Ss - 1;
+      pp_band_nonzeros(qc + jb, (size_t)cc.kstride, cmask, Ss, Se, wr, [&](int k, int v) {
+        const int a = (v < 0 ? -v : v) >> Al;
+        if (a == 0) return;
+        int r = k - prev - 1;
+        prev = k;
+        while (r > 15) { const unsigned e = s_tab[0xF0]; bw.put(e & 0xFFFF, (int)(e >> 16)); r -= 16; }
+        const int nbits = bitlen((unsigned)a);
+        const unsigned e = s_tab[(r << 4) + nbits];
+        bw.put(e & 0xFFFF, (int)(e >> 16));
+        bw.put((unsigned)(v < 0 ? ~a : a), nbits);
+      });
+      if (wr) bw.flush();
+      continue;
+    }
+    PPRefine Rc;
+    if (COMPACT) Rc = pp_refine_block_compact<false>(qc + jb, (size_t)cc.kstride, cmask, has_data, Ss, Se, Al, reinterpret_cast<const unsigned char *>(s_tab), nullptr);
     if (!has_data) continue;
     const bool flush_point = (ne_bits[j >> 6] >> (j & 63)) & 1ull;
     if (!refine) {
@@ -1307,7 +1451,7 @@ k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
       continue;
     }
     // ---- refinement scan
-    const PPRefine R = pp_refine_block<false>(x, Ss, Se, Al, reinterpret_cast<const unsigned char *>(s_tab), nullptr);   // (own bits unused here)
+    const PPRefine R = COMPACT ? Rc : pp_refine_block<false>(x, Ss, Se, Al, reinterpret_cast<const unsigned char *>(s_tab), nullptr);   // (own bits unused here)
     if (flush_point) {
       BitWriter bw;
       bw.init(stream, base + off[j]);
@@ -1786,13 +1930,15 @@ void mjh_launch_prog_stats(const MjhConst &C, const void *scans, const int *list
 
 // statistics of the parallel chain (every scan of the list has no restart interval)
 void mjh_launch_prog_stats_par(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
-                               MjhHuffTable *tabs, int spi, const MjhProgPE &pe, bool any_refine, int n, hipStream_t s)
+                               MjhHuffTable *tabs, int spi, const MjhProgPE &pe, bool any_refine, const unsigned long long *nzmask, int n, hipStream_t s)
 {
   if (nlist <= 0) return;
   const dim3 gchunks(pe.chunks_per_scan, nlist, n), gpairs(nlist, n);
   hipLaunchKernelGGL(k_pp_init, dim3((nlist * n + 63) / 64), dim3(64), 0, s, pe, nlist * n);
-  hipLaunchKernelGGL(k_pp_stats, gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, (const MjhProgCtl *)ctl, (const int16_t *)q,
-                     tabs, spi, pe);
+  if (nzmask) hipLaunchKernelGGL((k_pp_stats<true>), gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, (const MjhProgCtl *)ctl, (const int16_t *)q,
+                                 nzmask, tabs, spi, pe);
+  else hipLaunchKernelGGL((k_pp_stats<false>), gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, (const MjhProgCtl *)ctl, (const int16_t *)q,
+                          nzmask, tabs, spi, pe);
   if (any_refine) mjh_launch_scan16(pe.tail16, pe.nblk_pad, pe.tsums, pe.chunks_per_scan, pe.ttotals, pe.T32, nlist * n, s);
   hipLaunchKernelGGL(k_pp_carry, gpairs, dim3(64), 0, s, C, (const MjhProgScan *)scans, list, pe);
   hipLaunchKernelGGL(k_pp_cuts, gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, pe);
@@ -1803,7 +1949,8 @@ void mjh_launch_prog_stats_par(const MjhConst &C, const void *scans, const int *
 void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *list, int nlist, const int *seq_list, int nseq,
                             const int *par_list, int npar, const MjhProgPE &pe, void *ctl, const void *q,
                             MjhHuffTable *tabs, int spi, unsigned *pool, size_t pool_words, const void *frame_hdr, int frame_hdr_len,
-                            int multi_dht, void *outpool, size_t out_bytes, unsigned *mpos, int mpos_per_image, unsigned *ffsums, int n, hipStream_t s,
+                            int multi_dht, void *outpool, size_t out_bytes, unsigned *mpos, int mpos_per_image, unsigned *ffsums,
+                            const unsigned long long *nzmask, int n, hipStream_t s,
                             hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join)
 {
   hipLaunchKernelGGL(k_prog_alloc, dim3(n), dim3(256), 0, s, C, (const MjhProgScan *)scans, list, nlist, (MjhProgCtl *)ctl,
@@ -1822,11 +1969,15 @@ void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *lis
   }
   if (npar > 0) {
     const dim3 gchunks(pe.chunks_per_scan, npar, n), gpairs(npar, n);
-    hipLaunchKernelGGL(k_pp_len, gchunks, dim3(256), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhProgCtl *)ctl, (const int16_t *)q,
-                       (const MjhHuffTable *)tabs, spi, pe);
+    if (nzmask) hipLaunchKernelGGL((k_pp_len<true>), gchunks, dim3(256), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhProgCtl *)ctl, (const int16_t *)q,
+                                   nzmask, (const MjhHuffTable *)tabs, spi, pe);
+    else hipLaunchKernelGGL((k_pp_len<false>), gchunks, dim3(256), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhProgCtl *)ctl, (const int16_t *)q,
+                            nzmask, (const MjhHuffTable *)tabs, spi, pe);
     mjh_launch_scan16(pe.len16, pe.nblk_pad, pe.sums, pe.chunks_per_scan, pe.totals, pe.off32, npar * n, ps);
-    hipLaunchKernelGGL(k_pp_write, gchunks, dim3(256), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhProgCtl *)ctl, (const int16_t *)q,
-                       (const MjhHuffTable *)tabs, spi, pool, pool_words, pe);
+    if (nzmask) hipLaunchKernelGGL((k_pp_write<true>), gchunks, dim3(256), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhProgCtl *)ctl, (const int16_t *)q,
+                                   nzmask, (const MjhHuffTable *)tabs, spi, pool, pool_words, pe);
+    else hipLaunchKernelGGL((k_pp_write<false>), gchunks, dim3(256), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhProgCtl *)ctl, (const int16_t *)q,
+                            nzmask, (const MjhHuffTable *)tabs, spi, pool, pool_words, pe);
     hipLaunchKernelGGL(k_pp_finish, gpairs, dim3(64), 0, ps, (const MjhProgScan *)scans, par_list, (MjhProgCtl *)ctl, (const MjhHuffTable *)tabs, spi,
                        pool, pool_words, pe);
   }
