@@ -195,6 +195,19 @@ def pinned_empty(shape, dtype=np.uint8):
     return arr
 
 
+def _as_batch(params, a):
+    """[n, H, W, C] view of one image or a batch; gray images may come without the channel axis ([H, W] / [n, H, W]), which
+    only the encoder's geometry can tell apart from a single [H, W, C] image"""
+    h, w, c = params.image_height, params.image_width, (1 if params.input_components == 1 else a.shape[-1])
+    if params.input_components == 1:
+        if a.shape[-1] != 1 or a.shape[-2:] == (h, w):
+            a = a[..., None]                   # no channel axis yet
+    if a.ndim == 3:
+        a = a[None]
+    assert a.ndim == 4 and a.shape[1] == h and a.shape[2] == w, "expected [n, %d, %d, C], got %s" % (h, w, a.shape)
+    return a
+
+
 class Pool:
     """One process driving several GPUs (mjh_pool_*): one encoder + one host thread per device, images dealt
     round-robin (image i -> device i mod N), files returned in image order.  devices=None: every visible device."""
@@ -211,7 +224,7 @@ class Pool:
 
     def encode_host(self, frames):
         """frames: uint8 [n, H, W, C] (or uint16 for 12-bit) C-contiguous.  Returns a list of bytes."""
-        frames = np.ascontiguousarray(frames)
+        frames = _as_batch(self.params, np.ascontiguousarray(frames))
         n = frames.shape[0]
         jp, sz = C.POINTER(C.c_void_p)(), C.POINTER(C.c_size_t)()
         rc = lib().mjh_pool_encode_host(self._h, frames.ctypes.data, frames.strides[1], frames.strides[0], n, C.byref(jp), C.byref(sz))
@@ -254,9 +267,7 @@ class Encoder:
     # -- encode -------------------------------------------------------------------------------
     def encode_host(self, images):
         """images: uint8 ndarray [n, H, W, C] (or [H, W, C]); returns list of bytes."""
-        a = np.ascontiguousarray(images, dtype=np.uint16 if self.params.data_precision == 12 else np.uint8)
-        if a.ndim == 3:
-            a = a[None]
+        a = _as_batch(self.params, np.ascontiguousarray(images, dtype=np.uint16 if self.params.data_precision == 12 else np.uint8))
         n = a.shape[0]
         _chk(lib().mjh_encode_host(self._h, a.ctypes.data, a.strides[1], a.strides[0], n))
         return [self.get_jpeg(i) for i in range(n)]

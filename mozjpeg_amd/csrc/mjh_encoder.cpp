@@ -259,7 +259,7 @@ struct mjh_encoder {
   size_t pix_image_bytes = 0;
   uint8_t *d_planes = nullptr;
   int16_t *d_uq = nullptr, *d_q = nullptr, *d_q0 = nullptr;
-  MjhQuant *d_quant = nullptr;
+  MjhQuant *d_quant = nullptr, *d_quant_init = nullptr;   // trellis_q_opt: d_quant holds one table set per image, d_quant_init the parameters' tables
   MjhHuffTable *d_tabs = nullptr, *d_tabs_init = nullptr;
   float *d_lambda = nullptr;
   uint8_t *d_back = nullptr;
@@ -292,7 +292,7 @@ struct mjh_encoder {
   void *d_prog_chunks = nullptr;     // chunk summaries of the parallel statistics / encode kernels
   int chunks_per_scan = 0;
   MjhProgPE pe{};                    // buffers of the parallel AC-first encode
-  PList pl_trellis[2]{}, pl_phase[2]{};   // pl_trellis: the statistics scans of the trellis passes, one list per band
+  PList pl_trellis[2]{}, pl_phase[2]{}, pl_trellis_c[2][4]{};   // pl_trellis_c: per component (trellis_q_opt walks component-major)   // pl_trellis: the statistics scans of the trellis passes, one list per band
   int nphases = 0;
   unsigned *d_pool = nullptr; size_t pool_words = 0;
   uint8_t *d_outpool = nullptr; size_t outpool_bytes = 0;
@@ -338,10 +338,7 @@ static int check_supported(const mjh_params *p)
   if (p->trellis_num_loops < 0 || p->trellis_num_loops > 16) return fail(MJH_EINVAL, "trellis_num_loops %d (0..16)", p->trellis_num_loops);
   if (p->trellis_freq_split < 0 || p->trellis_freq_split > 63) return fail(MJH_EINVAL, "trellis_freq_split %d (0..63)", p->trellis_freq_split);
   if (p->trellis_quant && p->trellis_q_opt) {
-    // the table update sits between groups of num_components passes of the reference's component-major pass order
-    // (jcmaster.c:687-698, :1014-1030): with one round per component that is once, after the last pass; with more
-    // rounds later components would be quantized with tables re-estimated from earlier ones
-    if (p->trellis_num_loops > 1) return fail(MJH_EUNSUPPORTED, "trellis_q_opt with trellis_num_loops > 1");
+    // (the new entries are at most 254, so 8-bit tables stay 8-bit and their DQT bytes can be rewritten in place)
     for (int i = 0; i < p->num_components; i++)
       for (int k = 0; k < 64; k++)
         if (p->quantval[p->quant_tbl_no[i]][k] > 255) return fail(MJH_EUNSUPPORTED, "trellis_q_opt with 16-bit quantization tables (the DQT entries are rewritten in place)");
@@ -633,7 +630,7 @@ static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -698,7 +695,8 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   HIPCHK_E(hipMalloc((void **)&e->d_planes, B * C.planes_per_image * bps));
   HIPCHK_E(hipMalloc((void **)&e->d_uq, B * C.coefs_per_image * 2));
   HIPCHK_E(hipMalloc((void **)&e->d_q, B * C.coefs_per_image * 2));
-  HIPCHK_E(hipMalloc((void **)&e->d_quant, sizeof(MjhQuant)));
+  HIPCHK_E(hipMalloc((void **)&e->d_quant, sizeof(MjhQuant) * (p->trellis_quant && p->trellis_q_opt ? B : 1)));
+  HIPCHK_E(hipMalloc((void **)&e->d_quant_init, sizeof(MjhQuant)));
   HIPCHK_E(hipMalloc((void **)&e->d_tabs, B * e->spi * sizeof(MjhHuffTable)));
   HIPCHK_E(hipMalloc((void **)&e->d_tabs_init, B * e->spi * sizeof(MjhHuffTable)));
   HIPCHK_E(hipMalloc((void **)&e->d_lambda, B * C.total_real_blocks * sizeof(float)));
@@ -776,6 +774,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       hq.lambda_tbl[t][k] = (float)(1.0 / (double)(q * q));   // jcdctmgr.c:1017-1021
     }
   HIPCHK_E(hipMemcpy(e->d_quant, &hq, sizeof(hq), hipMemcpyHostToDevice));
+  HIPCHK_E(hipMemcpy(e->d_quant_init, &hq, sizeof(hq), hipMemcpyHostToDevice));
 
   // table template (zero counts; standard tables in the final slots when optimize_coding is off)
   {
@@ -916,6 +915,8 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     }
     e->pl_trellis[0] = add_list(tr[0]);
     e->pl_trellis[1] = add_list(tr[1]);
+    for (int band = 0; band < e->nbands; band++)
+      for (int c = 0; c < C.ncomp; c++) e->pl_trellis_c[band][c] = add_list(std::vector<int>{ p->num_scans + band * C.ncomp + c });
     e->pl_phase[0] = add_list(a);
     e->pl_phase[1] = add_list(b);
     {
@@ -1043,7 +1044,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   unsigned long long *const nzm = compact ? e->d_nzmask : nullptr;
   e->compact_last = compact;
   const int nbands = p.trellis_quant ? e->nbands : 1;
-  const bool fuse_pre = fuse_seq && (e->fuse_mask & 1) && !e->debug_taps && nbands == 1;
+  const bool fuse_pre = fuse_seq && (e->fuse_mask & 1) && !e->debug_taps && nbands == 1 && !ext_qopt;   // (q_opt: one component at a time, each from the stored planes)
   const bool fuse_fin = fuse_seq && (e->fuse_mask & 2) && nbands == 1 && !ext_eob;
   if (!coef_src) {
     pr.mark("dct_quant");
@@ -1054,46 +1055,43 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     if (before_output) { HIPCHK(hipStreamWaitEvent(s, before_output, 0)); before_output = nullptr; }   // the hand-over also reads the scan control block
     mjh_launch_prog_reset(e->d_prog_ctl, e->nscans, n, s);   // (the scan pool is zeroed phase by phase, only what k_prog_alloc hands out)
   }
-  if (ext_qopt) HIPCHK(hipMemsetAsync(e->d_qsums, 0, (size_t)n * 4 * 64 * 2 * sizeof(long long), s));   // prepare_for_pass jcmaster.c:687-698
   // trellis_num_loops (statistics, trellis) rounds (jcmaster.c:451-466): every round gathers the statistics of the
   // current quantized coefficients and re-runs the trellis from the unquantized ones (components are independent,
   // so doing all of them per round equals the reference's component-major order); with use_scans_in_trellis a round
-  // is two such pass pairs, AC bands 1..split and split+1..63
+  // is two such pass pairs, AC bands 1..split and split+1..63.
+  // One (statistics, trellis) pass pair: for all components (CV = C) or, with trellis_q_opt, for ONE component through a
+  // one-component view of the geometry (MjhComp carries absolute offsets, so the view addresses the same buffers).
   const int nloops = p.trellis_quant ? (p.trellis_num_loops > 1 ? p.trellis_num_loops : 1) : 0;
-  bool first_pass = true;
-  for (int loop = 0; loop < nloops; loop++)
-  for (int band = 0; band < nbands; band++) {
-    const int Ss = nbands == 1 ? 1 : band == 0 ? 1 : e->freq_split + 1;
-    const int Se = nbands == 1 ? 63 : band == 0 ? e->freq_split : 63;
-    if (Se < Ss) continue;   // quantize_trellis returns at once (jcdctmgr.c:979-980); the statistics of that pass feed nothing
+  auto trellis_pass = [&](const MjhConst &CV, const int *sl_dc_seq, const int *sl_dc_prog, const int *sl_ac, const int *crst,
+                          const mjh_encoder::PList *plt, int Ss, int Se, bool first_pass, bool last_loop, int qstride) -> int {
     if (!first_pass)   // fresh (zero) statistics for this pass
       HIPCHK(hipMemcpyAsync(e->d_tabs, e->d_tabs_init, (size_t)n * spi * sizeof(MjhHuffTable), hipMemcpyDeviceToDevice, s));
+    const int *sl_dc = sl_dc_seq;
     if (!e->progressive) {
       // passes 0,2,4 of SURVEY 3.3 (statistics of the conventionally quantized component; the sequential coder's gather
       // counts whole blocks whatever the band, jchuff.c:812-915): AC part fused into the FDCT kernel in the first pass,
       // a pass over the previous result afterwards ...
       if (!first_pass || !fuse_pre) {
         pr.mark("stats_ac(pre-trellis)");
-        mjh_launch_stats_ac(C, e->d_q, nullptr, e->d_tabs, spi, tr_ac, 0, n, s);
+        mjh_launch_stats_ac(CV, e->d_q, nullptr, e->d_tabs, spi, sl_ac, 0, n, s);
       }
       pr.mark("stats_dc(pre-trellis)");
-      mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, tr_dc, 0, e->comp_restart, n, s);
+      mjh_launch_stats_dc(CV, e->d_q, e->d_tabs, spi, sl_dc, 0, crst, n, s);
       int slots[8], ns = 0;
-      for (int i = 0; i < C.ncomp; i++) { slots[ns++] = tr_dc[i]; slots[ns++] = tr_ac[i]; }
+      for (int i = 0; i < CV.ncomp; i++) { slots[ns++] = sl_dc[i]; slots[ns++] = sl_ac[i]; }
       pr.mark("gen_tables(trellis)");
       mjh_launch_gen_tables(e->d_tabs, spi, slots, ns, n, s);
     } else {
       // progressive: the trellis passes gather AC-first statistics (Ss..Se of the band, Al=0, seeded counts,
       // jcphuff.c:257-264); the DC rate table stays the STANDARD table
-      const mjh_encoder::PList &plt = e->pl_trellis[band];
       pr.mark("prog_stats(pre-trellis)");
-      if (plt.nseq)
-        mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + plt.seq_off, plt.nseq, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
-      mjh_launch_prog_stats_par(C, e->d_prog_scans, e->d_lists + plt.par_off, plt.npar, e->d_prog_ctl, e->d_q, e->d_tabs, spi,
-                                e->pe, plt.any_refine, nullptr, n, s);   // (the conventionally quantized planes: one per position)
+      if (plt->nseq)
+        mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + plt->seq_off, plt->nseq, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
+      mjh_launch_prog_stats_par(C, e->d_prog_scans, e->d_lists + plt->par_off, plt->npar, e->d_prog_ctl, e->d_q, e->d_tabs, spi,
+                                e->pe, plt->any_refine, nullptr, n, s);   // (the conventionally quantized planes: one per position)
       pr.mark("gen_tables(trellis)");
-      mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + plt.slot_off, plt.nslot, n, s);
-      for (int i = 0; i < 4; i++) tr_dc[i] = fin_dc[i];
+      mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + plt->slot_off, plt->nslot, n, s);
+      sl_dc = sl_dc_prog;
     }
     if (e->debug_taps && first_pass) {
       if (!e->d_q0) HIPCHK(hipMalloc((void **)&e->d_q0, (size_t)e->max_batch * C.coefs_per_image * 2));
@@ -1110,11 +1108,11 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
         while (e->side_events.size() < 2 * (size_t)(e->prof_calls + 1)) { hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); e->side_events.push_back(ev); }
         HIPCHK(hipEventRecord(e->side_events[2 * e->prof_calls], e->side_stream));
       }
-      mjh_launch_trellis_dc(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_dc, e->d_lambda, e->d_back, n, e->side_stream);
+      mjh_launch_trellis_dc(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, e->side_stream);   // (the DC entries never change: image 0's tables serve all)
       if (pr.enabled && e->profiling == 1) { HIPCHK(hipEventRecord(e->side_events[2 * e->prof_calls + 1], e->side_stream)); e->side_timed = true; }
       HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
     }
-    const bool extended = nbands > 1 || ext_eob;
+    const bool extended = nbands > 1 || ext_eob || qstride != 0;
     if (e->trellis_adapt && !extended && e->h_defer[0] != 0xFFFFFFFFu) {
       // The first tier's queue capacity trades LDS occupancy (16 entries: 14 waves per CU) against the share of blocks that
       // have to be redone by the slower big-capacity tier: few at q75 (the metric: ~5 %), a third of all blocks at q85.
@@ -1125,26 +1123,68 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       e->h_defer[0] = 0xFFFFFFFFu;
     }
     pr.mark("trellis_ac");
-    mjh_launch_trellis_ac(C, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, tr_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap,
-                          fuse_fin && p.optimize_coding && loop == nloops - 1 ? fin_ac : nullptr, e->trellis_variant,
-                          Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, nzm, n, s);
-    if (e->trellis_adapt && !extended && loop == 0) {
+    mjh_launch_trellis_ac(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap,
+                          fuse_fin && p.optimize_coding && last_loop ? fin_ac : nullptr, e->trellis_variant,
+                          Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, nzm, qstride, n, s);
+    if (e->trellis_adapt && !extended && first_pass) {
       e->h_defer[1] = (unsigned)n;
       HIPCHK(hipMemcpyAsync(&e->h_defer[0], e->d_worklist, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     }
     if (ext_eob) {   // jcdctmgr.c:1224-1297: end-of-band runs along every block row, with the band's AC rate table
       pr.mark("trellis_eob_runs");
-      mjh_launch_trellis_eob_chain(C, e->d_q, e->d_tabs, spi, tr_ac, e->d_eob_cost, e->d_eob_has, Ss, Se, n, s);
+      mjh_launch_trellis_eob_chain(CV, e->d_q, e->d_tabs, spi, sl_ac, e->d_eob_cost, e->d_eob_has, Ss, Se, n, s);
     }
     if (ext_qopt) {  // :1299-1306
       pr.mark("trellis_q_opt(sums)");
-      mjh_launch_qopt_accumulate(C, e->d_uq, e->d_q, e->d_qsums, n, s);
+      mjh_launch_qopt_accumulate(CV, e->d_uq, e->d_q, e->d_qsums, n, s);
     }
     if (p.trellis_quant_dc) {
       pr.mark("join(trellis_dc)");
       HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
     }
-    first_pass = false;
+    return MJH_OK;
+  };
+  auto band_limits = [&](int band, int &Ss, int &Se) {
+    Ss = nbands == 1 ? 1 : band == 0 ? 1 : e->freq_split + 1;
+    Se = nbands == 1 ? 63 : band == 0 ? e->freq_split : 63;
+  };
+  if (!ext_qopt) {
+    bool first_pass = true;
+    for (int loop = 0; loop < nloops; loop++)
+      for (int band = 0; band < nbands; band++) {
+        int Ss, Se;
+        band_limits(band, Ss, Se);
+        if (Se < Ss) continue;   // quantize_trellis returns at once (jcdctmgr.c:979-980); the statistics of that pass feed nothing
+        const int rc = trellis_pass(C, tr_dc, fin_dc, tr_ac, e->comp_restart, &e->pl_trellis[band], Ss, Se, first_pass, loop == nloops - 1, 0);
+        if (rc != MJH_OK) return rc;
+        first_pass = false;
+      }
+  } else {
+    // trellis_q_opt: the reference walks its passes component-major (component, round, band) and re-estimates the
+    // quantization tables after every group of num_components (component, round) units (prepare_for_pass jcmaster.c:687-698,
+    // finish_pass_master :1014-1030), so with more than one round a later component is quantized with tables estimated from
+    // earlier ones: the same order here, one component at a time, every image with its own table set.
+    for (int i = 0; i < n; i++)
+      HIPCHK(hipMemcpyAsync(e->d_quant + i, e->d_quant_init, sizeof(MjhQuant), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemsetAsync(e->d_qsums, 0, (size_t)n * 4 * 64 * 2 * sizeof(long long), s));
+    bool first_pass = true;
+    for (int u = 0; u < C.ncomp * nloops; u++) {
+      const int ci = u / nloops, loop = u % nloops;
+      MjhConst CV = C;
+      CV.ncomp = 1;
+      CV.c[0] = C.c[ci];
+      const int v_dc_seq[4] = { tr_dc[ci], 0, 0, 0 }, v_dc_prog[4] = { fin_dc[ci], 0, 0, 0 }, v_ac[4] = { tr_ac[ci], 0, 0, 0 };
+      const int v_rst[4] = { e->comp_restart[ci], 0, 0, 0 };
+      for (int band = 0; band < nbands; band++) {
+        int Ss, Se;
+        band_limits(band, Ss, Se);
+        if (Se < Ss) continue;
+        const int rc = trellis_pass(CV, v_dc_seq, v_dc_prog, v_ac, v_rst, &e->pl_trellis_c[band][ci], Ss, Se, first_pass, loop == nloops - 1, 1);
+        if (rc != MJH_OK) return rc;
+        first_pass = false;
+      }
+      if ((u + 1) % C.ncomp == 0) { pr.mark("trellis_q_opt(tables)"); mjh_launch_qopt_update(e->d_qsums, e->d_quant, n, s); }
+    }
   }
   if (e->progressive) {
     // every candidate scan of a phase: statistics -> optimal tables -> exact size -> headers, bits, stuffing
@@ -1178,7 +1218,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     if (before_output) HIPCHK(hipStreamWaitEvent(s, before_output, 0));
     pr.mark("prog_concat");
     mjh_launch_prog_concat(e->d_prog_ctl, e->d_prefix, e->file_hdr_len, e->d_outpool, e->outpool_bytes, e->d_out, e->out_stride, e->d_sizes, n, s);
-    if (ext_qopt) { pr.mark("trellis_q_opt(tables)"); mjh_launch_qopt_patch(e->d_qsums, e->d_out, e->out_stride, e->dqt_off, e->d_sizes, n, s); }   // jcmaster.c:1014-1030
+    if (ext_qopt) { pr.mark("trellis_q_opt(DQT)"); mjh_launch_qopt_patch(e->d_quant, e->d_out, e->out_stride, e->dqt_off, e->d_sizes, n, s); }   // jcmaster.c:1014-1030
     pr.mark(nullptr);
     pr.finish();
     HIPCHK(hipGetLastError());
@@ -1206,7 +1246,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   pr.mark("byte_stuff");
   mjh_launch_stuff(e->d_stream, e->stream_words, e->d_totals, e->d_ffsums, e->ff_chunks, e->d_fftotals, e->d_out, e->out_stride,
                    e->d_meta, e->d_sizes, e->d_mpos, e->nseg, n, s);
-  if (ext_qopt) { pr.mark("trellis_q_opt(tables)"); mjh_launch_qopt_patch(e->d_qsums, e->d_out, e->out_stride, e->dqt_off, e->d_sizes, n, s); }   // jcmaster.c:1014-1030
+  if (ext_qopt) { pr.mark("trellis_q_opt(DQT)"); mjh_launch_qopt_patch(e->d_quant, e->d_out, e->out_stride, e->dqt_off, e->d_sizes, n, s); }   // jcmaster.c:1014-1030
   pr.mark(nullptr);
   pr.finish();
   HIPCHK(hipGetLastError());

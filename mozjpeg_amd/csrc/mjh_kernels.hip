@@ -1081,8 +1081,10 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
                                                int qrow, int nq_in, float azd63, float lambda, bool active, int16_t *__restrict__ qo,
                                                int kstride, uint2 (*col)[64], unsigned short (*e_pk)[64], int lane, unsigned *counts,
                                                int Ss = 1, int Se = 63, float2 *__restrict__ eob_out = nullptr, int *__restrict__ eob_has = nullptr,
-                                               unsigned long long *__restrict__ nz_out = nullptr)
+                                               unsigned long long *__restrict__ nz_out = nullptr,
+                                               const int *__restrict__ dq_lane = nullptr, const float *__restrict__ lt_lane = nullptr)
 {
+  // dq_lane / lt_lane (EXT only): this lane's own quantizer rows in global memory instead of the LDS copies (per-image tables)
   static_assert(!(EXT && STATS), "the fused statistics exist for the plain 1..63 pass only");
   static_assert(!(COMPACT && (EXT || STATS)), "compact records exist for the plain pass without fused statistics");
   const int vstart = EXT ? Ss - 1 : 0;          // position of the virtual start entry
@@ -1109,7 +1111,8 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
       rec_n = col[qi < QN ? qi : QN - 1][lane];          // unconsumed slots are never overwritten (entry e lives in slot e-1 <= qi-1)
       i = (int)(rec.x & 63u); sgn = (int)((rec.x >> 6) & 1u); qval = (int)((rec.x >> 7) & 1023u); x = (int)(rec.x >> 17);
       azd_prev = __uint_as_float(rec.y);
-      dq = dqT[qrow][i]; lti = ltT[qrow][i];
+      if (EXT && dq_lane) { dq = dq_lane[i]; lti = lt_lane[i]; }
+      else { dq = dqT[qrow][i]; lti = ltT[qrow][i]; }
       float t = (float)(x * x) * lambda;
       t = t * lti;
       azd_cur = t + azd_prev;
@@ -1425,20 +1428,35 @@ k_qopt_accumulate(MjhConst C, const int16_t *__restrict__ coef_uq, const int16_t
   }
 }
 
-// new table entries -> the DQT bytes of every image's file (8-bit tables: one byte per entry at dqt_off[table] + k,
-// zig-zag order like the marker); out = first byte of image 0's frame header copy
+// end of a group of num_components passes (finish_pass_master jcmaster.c:1014-1030): new entries of every table with a
+// non-zero denominator into the image's own MjhQuant (all four derived rows); the sums start over (prepare_for_pass :687-698)
 __global__ void __launch_bounds__(64)
-k_qopt_patch(const long long *__restrict__ sums, uint8_t *__restrict__ out, size_t out_stride, int4 dqt_off, const unsigned *__restrict__ sizes)
+k_qopt_update(long long *__restrict__ sums, MjhQuant *__restrict__ Q)
+{
+  const int img = blockIdx.x, t = blockIdx.y, k = threadIdx.x;
+  long long *d = sums + (((size_t)img * 4 + t) * 64 + k) * 2;
+  const long long a = d[0], b = d[1];
+  d[0] = 0; d[1] = 0;
+  if (k == 0 || b == 0) return;
+  int q = (int)((double)a / (double)b + 0.5);
+  if (q > 254) q = 254;
+  if (q < 1) q = 1;
+  MjhQuant *Qi = Q + img;
+  Qi->q[t][k] = (uint16_t)q;
+  Qi->dq8[t][k] = 8 * q;
+  Qi->rcp8q[t][k] = 1.0f / (float)(8 * q);
+  Qi->lambda_tbl[t][k] = (float)(1.0 / (double)(q * q));
+}
+
+// the image's final tables -> the DQT bytes of its file (8-bit tables: one byte per entry at dqt_off[table] + k, zig-zag
+// order like the marker)
+__global__ void __launch_bounds__(64)
+k_qopt_patch(const MjhQuant *__restrict__ Q, uint8_t *__restrict__ out, size_t out_stride, int4 dqt_off, const unsigned *__restrict__ sizes)
 {
   const int img = blockIdx.x, t = blockIdx.y, k = threadIdx.x;
   const int off = t == 0 ? dqt_off.x : t == 1 ? dqt_off.y : t == 2 ? dqt_off.z : dqt_off.w;
   if (off < 0 || k == 0 || sizes[img] == 0) return;
-  const long long *d = sums + (((size_t)img * 4 + t) * 64 + k) * 2;
-  if (d[1] == 0) return;
-  int q = (int)((double)d[0] / (double)d[1] + 0.5);
-  if (q > 254) q = 254;
-  if (q < 1) q = 1;
-  out[(size_t)img * out_stride + off + k] = (uint8_t)q;
+  out[(size_t)img * out_stride + off + k] = (uint8_t)Q[img].q[t][k];
 }
 
 __global__ void k_zero_counters(unsigned *__restrict__ a, unsigned *__restrict__ b)
@@ -1483,6 +1501,7 @@ struct MjhTrellisExt {
   float2 *eob_cost;   // {cost of the all-zero band, cost of the chosen path without its EOB}; null: trellis_eob_opt off
   int *eob_has;       // has_eob 0 / 1 / 2 (jcdctmgr.c:1209)
   unsigned long long *nzmask;   // COMPACT instantiations: non-zero position mask per block, [image][real blocks of all components]
+  int qstride;        // EXT instantiations: 1 = one MjhQuant per image (trellis_q_opt re-estimates the tables between passes), 0 = shared
 };
 
 template <int QN, bool FSTATS, bool EXT = false, bool COMPACT = false>   // FSTATS: count the AC symbols of the final coefficients (sequential mode, last trellis round)
@@ -1517,6 +1536,7 @@ k_trellis_ac_q(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__rest
     si_rows[lane] = r;
     rate_rows[lane] = rate_row(r);
   }
+  if (EXT) Q += (size_t)img * ext.qstride;
   dqT[0][lane] = Q->dq8[cc.qtbl][lane];
   ltT[0][lane] = Q->lambda_tbl[cc.qtbl][lane];
   int nq;
@@ -1603,6 +1623,10 @@ k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
 #pragma unroll
         for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
       }
+      if (EXT && ext.qstride) {
+        const MjhQuant *Qi = Q + (size_t)img * ext.qstride;   // per-lane image: vector loads of its own rows
+        nq = trellis_q_phase1<QN2, EXT>(xs, Qi->dq8[cc.qtbl], Qi->rcp8q[cc.qtbl], Qi->lambda_tbl[cc.qtbl], lambda, col, lane, azd63, ext.Ss, ext.Se);
+      } else
       nq = trellis_q_phase1<QN2, EXT>(xs, dqT[cc.qtbl], Q->rcp8q[cc.qtbl], ltT[cc.qtbl], lambda, col, lane, azd63, ext.Ss, ext.Se);
       if (QN2 < 63) defer_blocks(active && nq > QN2, worklist_next, (unsigned)img, w, ds, xs, nullptr, 0u, false, lane);
     }
@@ -1612,7 +1636,9 @@ k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     const size_t gblk = (size_t)img * C.total_real_blocks + cc.blk_off + blk;
     trellis_q_walk<QN2, false, FSTATS ? 2 : 0, EXT, COMPACT>(reinterpret_cast<const uint4 *>(T->ehufsi), nullptr, dqT, ltT, cc.qtbl, nq, azd63, lambda, active, qo, cc.kstride,
                                                               col, e_pk, lane, cnt, ext.Ss, ext.Se, EXT && ext.eob_cost ? ext.eob_cost + gblk : nullptr,
-                                                              EXT && ext.eob_cost ? ext.eob_has + gblk : nullptr, COMPACT ? ext.nzmask + gblk : nullptr);
+                                                              EXT && ext.eob_cost ? ext.eob_has + gblk : nullptr, COMPACT ? ext.nzmask + gblk : nullptr,
+                                                              EXT && ext.qstride ? (Q + (size_t)img * ext.qstride)->dq8[cc.qtbl] : nullptr,
+                                                              EXT && ext.qstride ? (Q + (size_t)img * ext.qstride)->lambda_tbl[cc.qtbl] : nullptr);
     __syncthreads();   // the LDS columns are reused by the next round
   }
 }
@@ -2400,12 +2426,13 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
 
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
-                           int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int n, hipStream_t s)
+                           int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s)
 {
-  // band-limited pass (use_scans_in_trellis) and / or the per-block outputs of trellis_eob_opt: the EXT instantiations
-  const bool extended = Ss != 1 || Se != 63 || eob_cost != nullptr;
+  // band-limited pass (use_scans_in_trellis), the per-block outputs of trellis_eob_opt, per-image tables (trellis_q_opt):
+  // the EXT instantiations
+  const bool extended = Ss != 1 || Se != 63 || eob_cost != nullptr || qstride != 0;
   MjhTrellisExt ext;
-  ext.Ss = Ss; ext.Se = Se; ext.eob_cost = (float2 *)eob_cost; ext.eob_has = eob_has; ext.nzmask = nzmask;
+  ext.Ss = Ss; ext.Se = Se; ext.eob_cost = (float2 *)eob_cost; ext.eob_has = eob_has; ext.nzmask = nzmask; ext.qstride = qstride;
   const int4 sl = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
   // stat_slot != nullptr: the statistics of the final coefficients go to these table slots (one per component)
   MjhHuffTable *st = stat_slot ? tabs : nullptr;
@@ -2536,8 +2563,13 @@ void mjh_launch_qopt_accumulate(const MjhConst &C, const void *uq, const void *q
   hipLaunchKernelGGL(k_qopt_accumulate, dim3(63, C.ncomp, n), dim3(256), 0, s, C, (const int16_t *)uq, (const int16_t *)q, (long long *)sums);
 }
 
-void mjh_launch_qopt_patch(const void *sums, void *out, size_t out_stride, const int dqt_off[4], const unsigned *sizes, int n, hipStream_t s)
+void mjh_launch_qopt_update(void *sums, MjhQuant *Q, int n, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_qopt_patch, dim3(n, 4), dim3(64), 0, s, (const long long *)sums, (uint8_t *)out, out_stride,
+  hipLaunchKernelGGL(k_qopt_update, dim3(n, 4), dim3(64), 0, s, (long long *)sums, Q);
+}
+
+void mjh_launch_qopt_patch(const MjhQuant *Q, void *out, size_t out_stride, const int dqt_off[4], const unsigned *sizes, int n, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_qopt_patch, dim3(n, 4), dim3(64), 0, s, Q, (uint8_t *)out, out_stride,
                      make_int4(dqt_off[0], dqt_off[1], dqt_off[2], dqt_off[3]), sizes);
 }

@@ -16,13 +16,14 @@ void mjh_launch_stats_dc(const MjhConst &C, const void *q, MjhHuffTable *tabs, i
 void mjh_launch_gen_tables(MjhHuffTable *tabs, int spi, const int *slots, int nslots, int n, hipStream_t s);
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
-                           int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int n, hipStream_t s);
+                           int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s);
 // trellis_eob_opt: the block-row pass behind a (band-limited) AC trellis; eob_cost / eob_has as written by mjh_launch_trellis_ac
 void mjh_launch_trellis_eob_chain(const MjhConst &C, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const void *eob_cost, const int *eob_has,
                                   int Ss, int Se, int n, hipStream_t s);
 // trellis_q_opt: sums[image][4 tables][64][2] += over all blocks; new entries patched into the DQT bytes of the finished files
 void mjh_launch_qopt_accumulate(const MjhConst &C, const void *uq, const void *q, void *sums, int n, hipStream_t s);
-void mjh_launch_qopt_patch(const void *sums, void *out, size_t out_stride, const int dqt_off[4], const unsigned *sizes, int n, hipStream_t s);
+void mjh_launch_qopt_update(void *sums, MjhQuant *Q, int n, hipStream_t s);   // Q: one MjhQuant per image
+void mjh_launch_qopt_patch(const MjhQuant *Q, void *out, size_t out_stride, const int dqt_off[4], const unsigned *sizes, int n, hipStream_t s);
 void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s);
 void mjh_launch_encode(const MjhConst &C, const void *q, const unsigned long long *nzmask, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const int ac_slot[4],
                        void *len16, void *off32, unsigned *sums, int chunks_per_image, unsigned *totals,

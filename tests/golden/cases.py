@@ -88,18 +88,17 @@ CASES = [
     ("fastcrush_dc_scan_opt2", dict(fastcrush=True, dc_scan_opt=2), True),
     ("q30_444_dc_scan_opt2_restart1", dict(dc_scan_opt=2, quality=30, sample=(1, 1), restart=1), True),
     ("gray_dc_scan_opt1", dict(dc_scan_opt=1, gray=True), True),
-    # trellis_q_opt (JBOOLEAN_TRELLIS_Q_OPT, sums jcdctmgr.c:1299-1306, table update jcmaster.c:1014-1030): on the device with one
-    # trellis round per component (the update then sits behind the last pass); with more rounds the reference re-estimates
-    # the tables between components -- oracle only (the HIP path refuses that combination)
+    # trellis_q_opt (JBOOLEAN_TRELLIS_Q_OPT, sums jcdctmgr.c:1299-1306, table update jcmaster.c:1014-1030); with more than one
+    # trellis round the reference re-estimates the tables between groups of its component-major passes: same order on the device
     ("base_trellis_q_opt", dict(baseline=True, trellis_q_opt=True), True),
     ("default_progressive_trellis_q_opt", dict(trellis_q_opt=True), True),
-    ("base_422_trellis_q_opt_loops3", dict(baseline=True, trellis_q_opt=True, trellis_loops=3, sample=(2, 1)), False),
+    ("base_422_trellis_q_opt_loops3", dict(baseline=True, trellis_q_opt=True, trellis_loops=3, sample=(2, 1)), True),
     # trellis_eob_opt (jcdctmgr.c:1224-1297) and use_scans_in_trellis (jcmaster.c:451-460)
     ("default_progressive_eob_opt", dict(trellis_eob_opt=True), True),
     ("fastcrush_scans_in_trellis_eob_opt", dict(fastcrush=True, use_scans_in_trellis=True, trellis_eob_opt=True), True),
     ("base_scans_in_trellis", dict(baseline=True, use_scans_in_trellis=True), True),
     ("progressive_all_trellis_options", dict(use_scans_in_trellis=True, trellis_freq_split=5, trellis_eob_opt=True, trellis_q_opt=True,
-                                             trellis_loops=2), False),
+                                             trellis_loops=2), True),
     ("progressive_all_trellis_options_1loop", dict(use_scans_in_trellis=True, trellis_freq_split=5, trellis_eob_opt=True, trellis_q_opt=True,
                                                    dc_ver_weight=0.5), True),
     ("base_444_eob_opt_q90", dict(baseline=True, trellis_eob_opt=True, quality=90, sample=(1, 1)), True),

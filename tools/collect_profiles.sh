@@ -9,9 +9,9 @@ python tools/rocprof_summary.py "$(db stats)" > "${P}_kernel_stats_batch$BATCH.c
 python tools/pmc_traffic.py "$(db fetch)" "$(db write)" "$BATCH" $((3840*2160*3)) > "${P}_pmc_hbm_traffic_batch$BATCH.json"
 python tools/pmc_sq.py "$(db sq)" > "${P}_pmc_sq_batch$BATCH.json" 2>/dev/null
 if [ -f "$O/bench_c3.log" ]; then
-  tail -1 "$O/bench_c3.log" > "${P}_c3_bench_batch8.json"
-  python tools/rocprof_summary.py "$(db c3_stats)" > "${P}_c3_kernel_stats_batch8.csv"
-  python tools/pmc_traffic.py "$(db c3_fetch)" "$(db c3_write)" 8 $((3840*2160*3)) > "${P}_c3_pmc_hbm_traffic_batch8.json"
+  tail -1 "$O/bench_c3.log" > "${P}_c3_bench_batch32.json"
+  python tools/rocprof_summary.py "$(db c3_stats)" > "${P}_c3_kernel_stats_batch32.csv"
+  python tools/pmc_traffic.py "$(db c3_fetch)" "$(db c3_write)" 32 $((3840*2160*3)) > "${P}_c3_pmc_hbm_traffic_batch32.json"
 fi
 : > "${P}_configs.jsonl"
 for c in c2 c4 c5 c5t; do [ -f "$O/bench_$c.log" ] && tail -1 "$O/bench_$c.log" >> "${P}_configs.jsonl"; done
