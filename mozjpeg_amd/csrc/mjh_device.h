@@ -7,11 +7,16 @@
 
 __device__ __forceinline__ int bitlen(unsigned v) { return 32 - __clz((int)v); }  // JPEG_NBITS; clz(0)=32
 
-// exact floor(n/d) for 0 <= n < 2^24, 1 <= d < 2^24, rcp = RN(1/d)
+// 24-bit multiply (full rate on CDNA; the 32-bit v_mul_lo_u32 is quarter rate): exact low 32 bits of the product for
+// operands in [-2^23, 2^23) -- raw coefficients (|x| <= 2^15), quantizer steps 8q (< 2^20), candidates (<= 1023) and the
+// differences cand*8q - x (|.| < 2^21) all are
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+
+// exact floor(n/d) for 0 <= n < 2^23, 1 <= d < 2^23, rcp = RN(1/d)
 __device__ __forceinline__ int udiv_exact(int n, int d, float rcp)
 {
   int q = (int)((float)n * rcp);
-  int r = n - q * d;
+  int r = n - mul24(q, d);
   if (r < 0) q--; else if (r >= d) q++;
   return q;
 }

@@ -276,6 +276,7 @@ struct mjh_encoder {
   int16_t *d_dense = nullptr; unsigned dense_cap = 0;       // raw coefficients of deferred blocks, 64 int16 per work-list slot
   unsigned *d_worklist = nullptr, *d_worklist2 = nullptr;   // deferred trellis blocks: [0] = count, [4+3i..6+3i] = (image, comp<<28|block, dense slot)
   int trellis_variant = 0;           // first-tier queue capacity of the AC trellis: 0 = 16, 1 = 20, 2 = 24, 3 = 32 (all bit-identical)
+  int trellis_floor = 0, trellis_hold = 0;   // hysteresis of the adaptation
   bool trellis_adapt = true;         // no MJH_TRELLIS_VARIANT given: follow the share of deferred blocks of the previous batches
   unsigned *h_defer = nullptr;       // pinned: work-list count of the last finished trellis pass
   int fuse_mask = 1;                // MJH_FUSE: 1 = pre-trellis AC statistics inside the FDCT kernel (+ unread planes not stored), 2 = final AC statistics inside the trellis
@@ -1118,8 +1119,11 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       // have to be redone by the slower big-capacity tier: few at q75 (the metric: ~5 %), a third of all blocks at q85.
       // The share seen in the last finished batch (read back asynchronously, never waited for) moves it one notch.
       const double share = (double)e->h_defer[0] / ((double)e->h_defer[1] * (double)C.total_real_blocks + 1.0);
-      if (share > 0.12 && e->trellis_variant < 3) e->trellis_variant++;
-      else if (share < 0.03 && e->trellis_variant > 0) e->trellis_variant--;
+      // (hysteresis: a capacity that just proved too small is not tried again for the next 256 batches -- at q85..q90 the
+      // share is tiny at one capacity and a third of all blocks one notch below, which made the choice oscillate)
+      if (e->trellis_hold > 0) e->trellis_hold--;
+      if (share > 0.12 && e->trellis_variant < 3) { e->trellis_variant++; e->trellis_floor = e->trellis_variant; e->trellis_hold = 256; }
+      else if (share < 0.03 && e->trellis_variant > 0 && (e->trellis_variant > e->trellis_floor || e->trellis_hold == 0)) e->trellis_variant--;
       e->h_defer[0] = 0xFFFFFFFFu;
     }
     pr.mark("trellis_ac");

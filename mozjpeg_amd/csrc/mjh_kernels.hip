@@ -313,14 +313,15 @@ __device__ __forceinline__ void fdct8(int &d0, int &d1, int &d2, int &d3, int &d
   constexpr int SH = PASS == 0 ? 13 - P1 : 13 + P1;
   if (PASS == 0) { d0 = (t10 + t11) * (1 << P1); d4 = (t10 - t11) * (1 << P1); }
   else { d0 = DESCALE(t10 + t11, P1); d4 = DESCALE(t10 - t11, P1); }
-  int z1 = (t12 + t13) * 4433;
-  d2 = DESCALE(z1 + t13 * 6270, SH);
-  d6 = DESCALE(z1 + t12 * (-15137), SH);
+  // (every operand stays below 2^19 even for 12-bit samples in the second pass: 24-bit multiplies are exact and full rate)
+  int z1 = mul24(t12 + t13, 4433);
+  d2 = DESCALE(z1 + mul24(t13, 6270), SH);
+  d6 = DESCALE(z1 + mul24(t12, -15137), SH);
   z1 = t4 + t7;
   int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
-  const int z5 = (z3 + z4) * 9633;
-  const int a4 = t4 * 2446, a5 = t5 * 16819, a6 = t6 * 25172, a7 = t7 * 12299;
-  z1 *= -7373; z2 *= -20995; z3 *= -16069; z4 *= -3196;
+  const int z5 = mul24(z3 + z4, 9633);
+  const int a4 = mul24(t4, 2446), a5 = mul24(t5, 16819), a6 = mul24(t6, 25172), a7 = mul24(t7, 12299);
+  z1 = mul24(z1, -7373); z2 = mul24(z2, -20995); z3 = mul24(z3, -16069); z4 = mul24(z4, -3196);
   z3 += z5; z4 += z5;
   d7 = DESCALE(a4 + z1 + z3, SH);
   d5 = DESCALE(a5 + z2 + z4, SH);
@@ -441,7 +442,7 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
     // from the host libm.  Both trellis kernels consume it.
     float norm = 0.0f;
 #pragma unroll
-    for (int n = 1; n < 64; n++) norm = norm + (float)(d[n] * d[n]);
+    for (int n = 1; n < 64; n++) norm = norm + (float)mul24(d[n], d[n]);   // |raw coefficient| <= 2^15
     norm = (float)((double)norm / 63.0);
     float lambda;
     if (C.lambda_log_scale2 > 0.0f) lambda = (float)(C.pow_scale1 * 1.0 / (C.pow_scale2 + (double)norm));
@@ -937,8 +938,8 @@ __device__ __forceinline__ void pred_cost(const uint4 *si_rows, const float4 &rr
         const int cb = row_byte(row, k + 1);
         if (cb != 0) {
           const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
-          const int delta = cand * dq - x;
-          float d = (float)(delta * delta) * lambda;
+          const int delta = mul24(cand, dq) - x;
+          float d = (float)mul24(delta, delta) * lambda;
           d = d * lti;
           float cost = (float)(cb + (k + 1) + rbase) + d;
           cost = cost + rhs;
@@ -1008,8 +1009,8 @@ __device__ __forceinline__ void q_pair_step(const uint4 *si_rows, const float4 *
 #pragma unroll
   for (int k = 0; k < NC; k++) {
     const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
-    const int delta = cand * dq - x;
-    float d = (float)(delta * delta) * lambda;
+    const int delta = mul24(cand, dq) - x;
+    float d = (float)mul24(delta, delta) * lambda;
     dist[k] = k < ncd ? d * lti : 3e38f;
   }
   const float gap0 = azd_prev - a0.x, gap1 = azd_prev - a1.x;
@@ -1046,7 +1047,7 @@ __device__ __forceinline__ int trellis_q_phase1(const short (&xs)[64], const int
       const int xsg = xs[k];
       const int x = xsg < 0 ? -xsg : xsg;
       const int dq = dq8[k];
-      float t = (float)(x * x) * lambda;
+      float t = (float)mul24(x, x) * lambda;
       t = t * lt[k];
       const float azd_cur = t + azd;
       if (x + (dq >> 1) >= dq) {
@@ -1113,7 +1114,7 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
       azd_prev = __uint_as_float(rec.y);
       if (EXT && dq_lane) { dq = dq_lane[i]; lti = lt_lane[i]; }
       else { dq = dqT[qrow][i]; lti = ltT[qrow][i]; }
-      float t = (float)(x * x) * lambda;
+      float t = (float)mul24(x, x) * lambda;
       t = t * lti;
       azd_cur = t + azd_prev;
       ncd = bitlen((unsigned)qval);
@@ -1720,8 +1721,8 @@ k_trellis_dc(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restri
       const int qval = udiv_exact(x + (dq >> 1), dq, rcp);
       int cnd = qval - ncand / 2 + k;
       cnd = min(1023, max(-1023, cnd));
-      const int delta = cnd * dq - x;
-      float dist = (float)(delta * delta) * lambda_dc;
+      const int delta = mul24(cnd, dq) - x;
+      float dist = (float)mul24(delta, delta) * lambda_dc;
       if (xs < 0) cnd = -cnd;
       if (vert) {   // jcdctmgr.c:1069-1084
         const int ab = grp_shfl(above_l, bi & 15, lane);
@@ -2536,9 +2537,13 @@ void mjh_launch_header(const void *prefix, int prefix_len, const void *sos, int 
 void mjh_launch_stuff(const unsigned *stream, size_t stream_words_per_image, const unsigned *totals, unsigned *ffsums, int ff_chunks_per_image,
                       unsigned *ff_totals, void *out, size_t out_stride, void *meta, unsigned *sizes, const unsigned *mpos, int nseg, int n, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_ff_chunk_sums, dim3(ff_chunks_per_image < 128 ? ff_chunks_per_image : 128, n), dim3(256), 0, s, stream, stream_words_per_image, totals, ffsums, ff_chunks_per_image, mpos, nseg);
+  // workgroups per image: the chunks are walked with a grid stride; a small batch of big images gets more of them
+  int gx = 4096 / (n > 0 ? n : 1);
+  if (gx < 128) gx = 128;
+  if (gx > ff_chunks_per_image) gx = ff_chunks_per_image;
+  hipLaunchKernelGGL(k_ff_chunk_sums, dim3(gx, n), dim3(256), 0, s, stream, stream_words_per_image, totals, ffsums, ff_chunks_per_image, mpos, nseg);
   hipLaunchKernelGGL(k_scan_sums, dim3(n), dim3(256), 0, s, ffsums, ff_chunks_per_image, ff_totals, totals);
-  hipLaunchKernelGGL(k_stuff_write, dim3(ff_chunks_per_image < 128 ? ff_chunks_per_image : 128, n), dim3(256), 0, s, stream, stream_words_per_image, totals, ffsums, ff_chunks_per_image,
+  hipLaunchKernelGGL(k_stuff_write, dim3(gx, n), dim3(256), 0, s, stream, stream_words_per_image, totals, ffsums, ff_chunks_per_image,
                      ff_totals, (uint8_t *)out, out_stride, (MjhImageMeta *)meta, sizes, mpos, nseg);
 }
 
