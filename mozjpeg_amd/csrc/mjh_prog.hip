@@ -682,12 +682,20 @@ __device__ __forceinline__ void pp_band_nonzeros(const int16_t *__restrict__ qb,
 {
   if (Se < 63) mask &= (2ull << Se) - 1ull;
   const int n = active ? __popcll(mask) : 0;
+  if (__builtin_amdgcn_ballot_w64(0 < n) == 0ull) return;
+  // double-buffered bursts: the loads of burst b+1 are in flight while burst b is consumed (these kernels are bound by
+  // the latency of their dependent loads, not by bandwidth or issue)
+  int v[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) v[j] = (j < n) ? (int)qb[(size_t)(j + 1) * kstride] : 0;
 #pragma unroll 1
   for (int base = 0; base < 63; base += 8) {
-    if (__builtin_amdgcn_ballot_w64(base < n) == 0ull) break;
-    int v[8];
+    const bool more = __builtin_amdgcn_ballot_w64(base + 8 < n) != 0ull;
+    int w[8];
+    if (more) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = (base + j < n) ? (int)qb[(size_t)(base + j + 1) * kstride] : 0;
+      for (int j = 0; j < 8; j++) w[j] = (base + 8 + j < n && base + 8 + j < 63) ? (int)qb[(size_t)(base + 8 + j + 1) * kstride] : 0;
+    }
 #pragma unroll
     for (int j = 0; j < 8; j++)
       if (base + j < n) {
@@ -695,6 +703,9 @@ __device__ __forceinline__ void pp_band_nonzeros(const int16_t *__restrict__ qb,
         mask &= mask - 1ull;
         if (pos >= Ss) f(pos, v[j]);
       }
+    if (!more) break;
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = w[j];
   }
 }
 
@@ -1368,16 +1379,26 @@ k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
   s_tab[tid] = ((unsigned)T0->ehufsi[tid] << 16) | T0->ehufco[tid];
   if (tid < MJH_PSTAT_BLOCKS / 64) ne_bits[tid] = pe.ne2_bits[(pair * pe.chunks_per_scan + chunk) * (MJH_PSTAT_BLOCKS / 64) + tid];   // flush points
   __syncthreads();
+  // the record mask and the block's bit count of the NEXT round are fetched while this round is being written (the loop is
+  // bound by the latency of its dependent loads: count -> mask -> values)
+  const unsigned long long *nzm = COMPACT ? nzmask + (size_t)img * C.total_real_blocks + cc.blk_off + cb : nullptr;
+  unsigned long long mask_next = COMPACT ? nzm[tid < nb ? tid : nb - 1] : 0ull;
+  unsigned len_next = tid < nb ? len[tid] : 0u;
 #pragma unroll 1
   for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
     const int j = i * 256 + tid;
     if (i * 256 >= nb) break;   // uniform
+    const unsigned long long cmask = mask_next;
+    const unsigned len_j = len_next;
+    if ((i + 1) * 256 < nb) {
+      const int jn = j + 256 < nb ? j + 256 : nb - 1;
+      if (COMPACT) mask_next = nzm[jn];
+      len_next = j + 256 < nb ? len[j + 256] : 0u;
+    }
     // blocks without symbols or trailing correction bits of their own need no coefficients: a wave of such blocks skips the loads
-    const bool has_data = j < nb && (len[j] != 0 || (refine && pe.tail16[pair * pe.nblk_pad + cb + j] != 0));
+    const bool has_data = j < nb && (len_j != 0 || (refine && pe.tail16[pair * pe.nblk_pad + cb + j] != 0));
     if (__builtin_amdgcn_ballot_w64(has_data) == 0ull) continue;
     const int jb = cb + (j < nb ? j : nb - 1);
-    unsigned long long cmask = 0ull;
-    if (COMPACT) cmask = nzmask[(size_t)img * C.total_real_blocks + cc.blk_off + jb];
     int x[64];
     if (!COMPACT) {
       const int16_t *qs = qc + jb;
@@ -1385,7 +1406,7 @@ k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
     }
     if (COMPACT && !refine) {
       // AC-first scan from compact records: every lane of the wave takes part in the (wave-uniform) plane loads
-      const bool wr = has_data && len[j] != 0;
+      const bool wr = has_data && len_j != 0;
       BitWriter bw;
       bw.init(stream, base + (wr ? off[j] : 0u));
       if (wr) {
@@ -1417,7 +1438,7 @@ k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
     if (!has_data) continue;
     const bool flush_point = (ne_bits[j >> 6] >> (j & 63)) & 1ull;
     if (!refine) {
-      if (len[j] == 0) continue;          // nothing to write (a non-empty block has at least one bit of its own)
+      if (len_j == 0) continue;          // nothing to write (a non-empty block has at least one bit of its own)
       BitWriter bw;
       bw.init(stream, base + off[j]);
       const unsigned cnt = run[j];
