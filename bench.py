@@ -42,17 +42,17 @@ HBM_PEAK_GBS = 8000.0
 
 # BASELINE.json configs (SURVEY 8d "Config -> concrete runs").  batch = frames per step per GPU.
 CONFIGS = {
-    "metric": dict(w=3840, h=2160, kw=dict(quality=75, baseline=True), batch=64,
+    "metric": dict(w=3840, h=2160, kw=dict(quality=75, baseline=True), batch=64, steps=500,
                    name="3840x2160 synthetic RGB, q75 4:2:0 baseline, trellis+deringing+optimal Huffman (cjpeg -quality 75 -baseline)"),
-    "c2": dict(w=1920, h=1080, kw=dict(quality=75, baseline=True), batch=64,
+    "c2": dict(w=1920, h=1080, kw=dict(quality=75, baseline=True), batch=64, steps=1500,
                name="C2: 1920x1080 synthetic RGB, q75 4:2:0 baseline, trellis on (cjpeg -quality 75 -baseline)"),
-    "c3": dict(w=3840, h=2160, kw=dict(quality=85, sample=(2, 2)), batch=32,
+    "c3": dict(w=3840, h=2160, kw=dict(quality=85, sample=(2, 2)), batch=32, steps=150,
                name="C3: 3840x2160 synthetic RGB, q85 4:2:0 progressive + scan search (cjpeg -quality 85 -sample 2x2)"),
-    "c4": dict(w=1920, h=1080, kw=dict(quality=75, baseline=True), batch=128, total=1024,
+    "c4": dict(w=1920, h=1080, kw=dict(quality=75, baseline=True), batch=128, total=1024, steps=150,
                name="C4: batch of 1024 x 1920x1080 frames, q75 trellis baseline, sharded over the GPUs (128 per encode call)"),
-    "c5": dict(w=8192, h=8192, kw=dict(precision=12, baseline=True, notrellis=True, quality=90, sample=(1, 1), restart=1), batch=1,
+    "c5": dict(w=8192, h=8192, kw=dict(precision=12, baseline=True, notrellis=True, quality=90, sample=(1, 1), restart=1), batch=1, steps=600,
                name="C5: 8192x8192 12-bit, q90 4:4:4, restart interval = MCU row, -notrellis (the reference aborts on 12-bit + trellis, SURVEY F1)"),
-    "c5t": dict(w=8192, h=8192, kw=dict(baseline=True, quality=90, sample=(1, 1), restart=1), batch=1,
+    "c5t": dict(w=8192, h=8192, kw=dict(baseline=True, quality=90, sample=(1, 1), restart=1), batch=1, steps=400,
                 name="C5 8-bit twin: 8192x8192, q90 4:4:4 trellis, restart interval = MCU row"),
 }
 
@@ -222,8 +222,8 @@ def host_inclusive(M, params, frames, hb, device, min_s, ref_jpegs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (0 = the configuration's default: a timed region of about 3-5 s, BASELINE.md section 3)")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed steps before (-1 = a tenth of the steps)")
     ap.add_argument("--config", default="metric", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="frames per encode call per GPU (0 = the config's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -237,6 +237,10 @@ def main():
     import mozjpeg_amd as M
 
     cfg = CONFIGS[args.config]
+    if args.steps <= 0:
+        args.steps = cfg["steps"]
+    if args.warmup < 0:
+        args.warmup = max(3, args.steps // 10)
     w, h, kw = cfg["w"], cfg["h"], cfg["kw"]
     twelve = kw.get("precision", 8) == 12
     rank = int(os.environ.get("RANK", "0"))
