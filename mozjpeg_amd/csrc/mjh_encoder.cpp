@@ -293,7 +293,7 @@ struct mjh_encoder {
   void *d_prog_chunks = nullptr;     // chunk summaries of the parallel statistics / encode kernels
   int chunks_per_scan = 0;
   MjhProgPE pe{};                    // buffers of the parallel AC-first encode
-  PList pl_trellis[2]{}, pl_phase[2]{}, pl_trellis_c[2][4]{};   // pl_trellis_c: per component (trellis_q_opt walks component-major)   // pl_trellis: the statistics scans of the trellis passes, one list per band
+  PList pl_trellis[2]{}, pl_phase[4]{}, pl_trellis_c[2][4]{};   // pl_trellis_c: per component (trellis_q_opt walks component-major)   // pl_trellis: the statistics scans of the trellis passes, one list per band
   int nphases = 0;
   unsigned *d_pool = nullptr; size_t pool_words = 0;
   uint8_t *d_outpool = nullptr; size_t outpool_bytes = 0;
@@ -834,6 +834,8 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       if (p->optimize_scans) {   // jcmaster.c:487-497
         if (si >= lfs && si < nsl) d.al_sel = 1;
         if (si >= cfs) d.al_sel = 2;
+        if (si >= 6 && si <= 8) d.cond = 1;     // luma candidates of level Al = 2 / 3: coded only where the level below improved
+        if (si >= 9 && si <= 11) d.cond = 2;
       }
       for (int ci = 0; ci < ms.comps_in_scan; ci++) {
         const int c = ms.component_index[ci];
@@ -904,12 +906,20 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       for (int si : scn) if (ps[si].ri != 0) { e->h_lists.push_back(si); pl.nseq++; }
       return pl;
     };
-    std::vector<int> tr[2], a, b;
+    std::vector<int> tr[2], a, a2, a3, b;
     for (int band = 0; band < e->nbands; band++)
       for (int c = 0; c < C.ncomp; c++) tr[band].push_back(p->num_scans + band * C.ncomp + c);
-    if (p->optimize_scans) {   // phase A: everything the Al decisions need; phase B: the frequency-split candidates
-      for (int si = 0; si < p->num_scans; si++) ((si >= lfs && si < nsl) || si >= cfs ? b : a).push_back(si);
-      e->nphases = 2;
+    if (p->optimize_scans) {
+      // phase A: everything the Al decisions need, in three sub-phases -- the reference stops coding luma candidates at the
+      // first successive-approximation level that does not pay, so levels 2 and 3 (scans 6-8, 9-11) wait for the verdict on
+      // the level below and are skipped, image by image, where it was negative; phase B: the frequency-split candidates
+      for (int si = 0; si < p->num_scans; si++) {
+        if ((si >= lfs && si < nsl) || si >= cfs) b.push_back(si);
+        else if (si >= 6 && si <= 8) a2.push_back(si);
+        else if (si >= 9 && si <= 11) a3.push_back(si);
+        else a.push_back(si);
+      }
+      e->nphases = 4;
     } else {
       for (int si = 0; si < p->num_scans; si++) a.push_back(si);
       e->nphases = 1;
@@ -918,13 +928,13 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     e->pl_trellis[1] = add_list(tr[1]);
     for (int band = 0; band < e->nbands; band++)
       for (int c = 0; c < C.ncomp; c++) e->pl_trellis_c[band][c] = add_list(std::vector<int>{ p->num_scans + band * C.ncomp + c });
-    e->pl_phase[0] = add_list(a);
-    e->pl_phase[1] = add_list(b);
+    if (p->optimize_scans) { e->pl_phase[0] = add_list(a); e->pl_phase[1] = add_list(a2); e->pl_phase[2] = add_list(a3); e->pl_phase[3] = add_list(b); }
+    else e->pl_phase[0] = add_list(a);
     {
       int mx = 0, maxlist = 1;
       for (int c = 0; c < C.ncomp; c++) mx = C.c[c].nblk > mx ? C.c[c].nblk : mx;
       e->chunks_per_scan = (mx + MJH_PSTAT_BLOCKS - 1) / MJH_PSTAT_BLOCKS;
-      for (const mjh_encoder::PList *pl : { &e->pl_trellis[0], &e->pl_trellis[1], &e->pl_phase[0], &e->pl_phase[1] }) maxlist = pl->npar > maxlist ? pl->npar : maxlist;
+      for (const mjh_encoder::PList *pl : { &e->pl_trellis[0], &e->pl_trellis[1], &e->pl_phase[0], &e->pl_phase[1], &e->pl_phase[2], &e->pl_phase[3] }) maxlist = pl->npar > maxlist ? pl->npar : maxlist;
       HIPCHK_E(hipMalloc(&e->d_prog_chunks, B * (size_t)maxlist * e->chunks_per_scan * sizeof(MjhProgChunk)));
       // parallel encode of the AC-first scans: block lengths / runs / offsets per (scan, image) pair
       const int maxpar = maxlist;
@@ -1194,7 +1204,11 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     // every candidate scan of a phase: statistics -> optimal tables -> exact size -> headers, bits, stuffing
     for (int ph = 0; ph < e->nphases; ph++) {
       const mjh_encoder::PList &pl = e->pl_phase[ph];
-      pr.mark(ph == 0 ? "prog_stats(A)" : "prog_stats(B)");
+      static const char *const kStats[4] = { "prog_stats(A)", "prog_stats(A2)", "prog_stats(A3)", "prog_stats(B)" };
+      static const char *const kTabs[4] = { "gen_tables(A)", "gen_tables(A2)", "gen_tables(A3)", "gen_tables(B)" };
+      static const char *const kEnc[4] = { "prog_encode(A)", "prog_encode(A2)", "prog_encode(A3)", "prog_encode(B)" };
+      const int pn = p.optimize_scans ? ph : 0;
+      pr.mark(kStats[pn]);
       // the sequential walks (refinement / DC / restart scans: a few long workgroups) and the parallel AC-first
       // statistics touch different table slots: the latter run on the side stream underneath the former
       const bool both = pl.nseq > 0 && pl.npar > 0;
@@ -1210,9 +1224,9 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       if (pl.nseq)
         mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + pl.seq_off, pl.nseq, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
       if (both) HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
-      pr.mark(ph == 0 ? "gen_tables(A)" : "gen_tables(B)");
+      pr.mark(kTabs[pn]);
       mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + pl.slot_off, pl.nslot, n, s);
-      pr.mark(ph == 0 ? "prog_encode(A)" : "prog_encode(B)");
+      pr.mark(kEnc[pn]);
       mjh_launch_prog_encode(C, e->d_prog_scans, e->d_lists + pl.scan_off, pl.nscan, e->d_lists + pl.seq_off, pl.nseq, e->d_lists + pl.par_off, pl.npar,
                              e->pe, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_pool, e->pool_words,
                              e->d_frame_hdr, e->frame_hdr_len, p.compress_profile != MJH_PROFILE_FASTEST, e->d_outpool, e->outpool_bytes,

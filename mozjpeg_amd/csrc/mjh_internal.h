@@ -107,6 +107,8 @@ struct MjhProgScan {
   int td[MJH_MAXC], ta[MJH_MAXC];
   int Ss, Se, Ah, Al;
   int al_sel;              // 0: Al as given; 1: MjhProgCtl.best_Al_luma; 2: best_Al_chroma (jcmaster.c:487-497)
+  int cond;                // scan search: 0 = always coded; k > 0 = only for images whose luma Al search is still improving after level k
+                           // (MjhProgCtl.al_continue >= k) -- select_scans stops coding candidates at the first level that does not pay (jcmaster.c:799-818)
   int slot[2];             // DC scans: slot of DC table number 0 / 1; AC scans: slot[0] = AC table
   int seed;                // statistics of a trellis pass: every (run,size<12) count starts at 1 (jcphuff.c:257-264)
   int frame_header;        // 1: this scan's buffer starts with DQT + SOF (scan 0)
@@ -145,6 +147,7 @@ struct MjhProgPE {         // device buffers of that path, [image][scan of the l
 
 struct MjhProgCtl {        // per image, lives in HBM
   int best_Al_luma, best_Al_chroma, best_fs_luma, best_fs_chroma;
+  int al_continue;            // luma successive-approximation search: levels that improved so far (gates the scans with cond > 0)
   unsigned pool_words_used;   // running allocation in the bit-stream pool
   unsigned pool_zero_from;    // first word handed out by the current phase: [pool_zero_from, pool_words_used) is zeroed before the bit writers run
   unsigned out_bytes_used;    // running allocation in the scan-buffer pool

@@ -67,6 +67,9 @@ __device__ __forceinline__ int eobrun_symbol(unsigned eobrun, int *nextra)
 // waves per (scan, image) workgroup: the walk is latency-bound (one workgroup per CU, dependent LDS look-ups
 // and 63 plane loads per step), so as many waves as a workgroup can have: 16 = 4 per SIMD = 128 VGPRs each
 // (statistics 96; encode exactly 128 with 3 spilled registers -- still 10 % faster than 12 waves of 154)
+// scan search: a candidate of luma level k+1 is coded only for the images whose search still improved at level k
+__device__ __forceinline__ bool prog_skip(const MjhProgScan &sc, const MjhProgCtl *ct) { return sc.cond > 0 && ct->al_continue < sc.cond; }
+
 #define PROG_WAVES(ENCODE) 16
 template <int ENCODE>
 __global__ void __launch_bounds__(64 * PROG_WAVES(ENCODE))
@@ -87,6 +90,7 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
   const int sidx = scan_list[blockIdx.y];
   const MjhProgScan sc = scans[sidx];
   MjhProgCtl *ct = ctl + img;
+  if (prog_skip(sc, ct)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
   const int16_t *qimg = coef_q + (size_t)img * C.coefs_per_image;
@@ -817,6 +821,7 @@ k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
   if (cb >= nunits || kind == PP_DC_REFINE) return;
   const int nb = min(MJH_PSTAT_BLOCKS, nunits - cb);
   const MjhProgCtl *ct = ctl + img;
+  if (prog_skip(sc, ct)) return;
   const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
   const int16_t *qimg = coef_q + (size_t)img * C.coefs_per_image;
   hist[0][tid] = 0; hist[1][tid] = 0; hist[2][tid] = 0; hist[3][tid] = 0;
@@ -995,12 +1000,13 @@ __device__ __forceinline__ void pp_mark_cuts(const MjhProgPE &pe, size_t pair, i
 
 // per (scan, image) pair, before the marks: the last real non-empty block in front of every chunk; marks of the final gap
 __global__ void __launch_bounds__(64)
-k_pp_carry(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, MjhProgPE pe)
+k_pp_carry(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl, MjhProgPE pe)
 {
   const int img = blockIdx.y, li = blockIdx.x;
   if (threadIdx.x != 0) return;
   const size_t pair = (size_t)img * gridDim.x + li;
   const MjhProgScan sc = scans[scan_list[li]];
+  if (prog_skip(sc, ctl + img)) return;
   const int kind = pp_kind(sc);
   if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) return;
   const MjhComp cc = C.c[sc.comp[0]];
@@ -1016,12 +1022,13 @@ k_pp_carry(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
 
 // one thread per real non-empty block: the gap in front of it
 __global__ void __launch_bounds__(256)
-k_pp_cuts(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, MjhProgPE pe)
+k_pp_cuts(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl, MjhProgPE pe)
 {
   __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64], e_bits[MJH_PSTAT_BLOCKS / 64];
   const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const size_t pair = (size_t)img * gridDim.y + li;
   const MjhProgScan sc = scans[scan_list[li]];
+  if (prog_skip(sc, ctl + img)) return;
   const int kind = pp_kind(sc);
   if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) return;
   const MjhComp cc = C.c[sc.comp[0]];
@@ -1047,12 +1054,13 @@ k_pp_cuts(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restri
 
 // per (scan, image) pair, after the marks: what crosses chunk borders.  One lane walks the chunks (at most a few dozen).
 __global__ void __launch_bounds__(64)
-k_pp_resolve(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
+k_pp_resolve(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl,
              MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe)
 {
   const int img = blockIdx.y, li = blockIdx.x, lane = threadIdx.x;
   const size_t pair = (size_t)img * gridDim.x + li;
   const MjhProgScan sc = scans[scan_list[li]];
+  if (prog_skip(sc, ctl + img)) return;
   const int kind = pp_kind(sc);
   if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) return;
   const bool refine = kind == PP_AC_REFINE;
@@ -1099,7 +1107,7 @@ k_pp_resolve(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
 
 // every flush point that is not the first of its chunk: the run and the correction bits in front of it, EOBRUN statistics
 __global__ void __launch_bounds__(256)
-k_pp_runs(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, MjhHuffTable *__restrict__ tabs,
+k_pp_runs(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl, MjhHuffTable *__restrict__ tabs,
           int slots_per_image, MjhProgPE pe)
 {
   __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64], e_bits[MJH_PSTAT_BLOCKS / 64];
@@ -1107,6 +1115,7 @@ k_pp_runs(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restri
   const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const size_t pair = (size_t)img * gridDim.y + li;
   const MjhProgScan sc = scans[scan_list[li]];
+  if (prog_skip(sc, ctl + img)) return;
   const int kind = pp_kind(sc);
   if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) return;
   const bool refine = kind == PP_AC_REFINE;
@@ -1212,6 +1221,7 @@ k_pp_len(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restric
   }
   const int nb = min(MJH_PSTAT_BLOCKS, nunits - cb);
   const MjhProgCtl *ct = ctl + img;
+  if (prog_skip(sc, ct)) return;
   const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
   const int16_t *qimg = coef_q + (size_t)img * C.coefs_per_image;
   if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) {
@@ -1340,6 +1350,7 @@ k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
   const int nunits = pp_units(C, sc);
   const int cb = chunk * MJH_PSTAT_BLOCKS;
   const MjhProgCtl *ct = ctl + img;
+  if (prog_skip(sc, ct)) return;
   if (cb >= nunits || ct->error) return;
   const int nb = min(MJH_PSTAT_BLOCKS, nunits - cb);
   const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
@@ -1561,6 +1572,7 @@ k_pp_finish(const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_
   const MjhProgScan sc = scans[sidx];
   MjhProgCtl *ct = ctl + img;
   if (ct->error) return;
+  if (prog_skip(sc, ct)) return;
   unsigned *stream = pool + (size_t)img * pool_words_per_image;
   const unsigned base = ct->scan_words_off[sidx] * 32u;
   unsigned cur = base + pe.totals[pair];
@@ -1602,6 +1614,7 @@ k_prog_alloc(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int li = wave; li < nlist; li += 4) {
     const MjhProgScan sc = scans[scan_list[li]];
+    if (prog_skip(sc, ct)) { if (lane == 0) s_bits[li] = 0ull; continue; }   // not coded for this image: an empty stream
     unsigned long long bits = 0;
     if (sc.Ss == 0) {
       if (sc.Ah == 0) {
@@ -1681,6 +1694,7 @@ k_prog_header(const MjhProgScan *__restrict__ scans, const int *__restrict__ sca
   MjhProgCtl *ct = ctl + img;
   const int lane = threadIdx.x;
   if (ct->error) return;
+  if (prog_skip(sc, ct)) return;
   uint8_t *o = outpool + (size_t)img * out_bytes_per_image + ct->scan_out_off[sidx];
   int pos = 0;
   if (sc.frame_header) {
@@ -1757,6 +1771,7 @@ k_prog_stuff(const MjhProgScan *__restrict__ scans, const int *__restrict__ scan
   const unsigned *mp = mpos_pool + (size_t)img * mpos_per_image + scans[sidx].mpos_off;
   unsigned *fs = ffsums + ((size_t)img * gridDim.y + li) * PROG_STUFF_SPLIT;
   if (ct->error) return;
+  if (prog_skip(scans[sidx], ct)) return;
   const unsigned nbytes = (ct->scan_bits[sidx] + 7) >> 3;
   const unsigned nwords = (nbytes + 3) >> 2;
   unsigned w0, w1;
@@ -1840,6 +1855,27 @@ k_prog_select_al(MjhProgCtl *__restrict__ ctl, int ncomp, int nimg)
     }
     ct->best_Al_chroma = bestAl;
   }
+}
+
+// between the sub-phases of phase A: does the luma successive-approximation search go on?  select_scans (jcmaster.c:799-818)
+// compares, after the three scans of level Al, cost(Al) = the two band scans at Al + every refinement scan below with
+// the best cost so far and stops coding candidates at the first level that is not cheaper; the candidates of level
+// stage+1 (scans 3*stage+3 .. 3*stage+5, cond = stage) are therefore coded only where level `stage` improved.
+__global__ void __launch_bounds__(64)
+k_prog_select_stage(MjhProgCtl *__restrict__ ctl, int stage, int nimg)
+{
+  const int img = blockIdx.x * 64 + threadIdx.x;
+  if (img >= nimg) return;
+  MjhProgCtl *ct = ctl + img;
+  if (ct->al_continue != stage - 1) return;          // the search stopped at an earlier level
+  const unsigned *sz = ct->scan_size;
+  unsigned long long best = (unsigned long long)sz[1] + sz[2];
+  for (int Al = 1; Al <= stage; Al++) {
+    unsigned long long cost = (unsigned long long)sz[3 * Al + 1] + sz[3 * Al + 2];
+    for (int i = 0; i < Al; i++) cost += sz[3 + 3 * i];
+    if (cost < best) best = cost; else return;       // (levels below `stage` improved, or al_continue would be smaller)
+  }
+  ct->al_continue = stage;
 }
 
 __global__ void __launch_bounds__(64)
@@ -1927,7 +1963,7 @@ k_prog_reset(MjhProgCtl *__restrict__ ctl, int nscans, int nimg)
   const int img = blockIdx.x * 64 + threadIdx.x;
   if (img >= nimg) return;
   MjhProgCtl *ct = ctl + img;
-  ct->best_Al_luma = ct->best_Al_chroma = ct->best_fs_luma = ct->best_fs_chroma = 0;
+  ct->best_Al_luma = ct->best_Al_chroma = ct->best_fs_luma = ct->best_fs_chroma = 0; ct->al_continue = 0;
   ct->pool_words_used = 0; ct->pool_zero_from = 0; ct->out_bytes_used = 0; ct->error = 0;
   ct->norder = nscans;
   for (int i = 0; i < nscans; i++) ct->order[i] = i;
@@ -1961,10 +1997,10 @@ void mjh_launch_prog_stats_par(const MjhConst &C, const void *scans, const int *
   else hipLaunchKernelGGL((k_pp_stats<false>), gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, (const MjhProgCtl *)ctl, (const int16_t *)q,
                           nzmask, tabs, spi, pe);
   if (any_refine) mjh_launch_scan16(pe.tail16, pe.nblk_pad, pe.tsums, pe.chunks_per_scan, pe.ttotals, pe.T32, nlist * n, s);
-  hipLaunchKernelGGL(k_pp_carry, gpairs, dim3(64), 0, s, C, (const MjhProgScan *)scans, list, pe);
-  hipLaunchKernelGGL(k_pp_cuts, gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, pe);
-  hipLaunchKernelGGL(k_pp_runs, gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, tabs, spi, pe);
-  hipLaunchKernelGGL(k_pp_resolve, gpairs, dim3(64), 0, s, C, (const MjhProgScan *)scans, list, tabs, spi, pe);
+  hipLaunchKernelGGL(k_pp_carry, gpairs, dim3(64), 0, s, C, (const MjhProgScan *)scans, list, (const MjhProgCtl *)ctl, pe);
+  hipLaunchKernelGGL(k_pp_cuts, gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, (const MjhProgCtl *)ctl, pe);
+  hipLaunchKernelGGL(k_pp_runs, gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, (const MjhProgCtl *)ctl, tabs, spi, pe);
+  hipLaunchKernelGGL(k_pp_resolve, gpairs, dim3(64), 0, s, C, (const MjhProgScan *)scans, list, (const MjhProgCtl *)ctl, tabs, spi, pe);
 }
 
 void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *list, int nlist, const int *seq_list, int nseq,
@@ -2015,7 +2051,9 @@ void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *lis
 
 void mjh_launch_prog_select(void *ctl, int ncomp, int phase, int dc_scan_opt_mode, int n, hipStream_t s)
 {
-  if (phase == 0) hipLaunchKernelGGL(k_prog_select_al, dim3((n + 63) / 64), dim3(64), 0, s, (MjhProgCtl *)ctl, ncomp, n);
+  // phases of the scan search: 0, 1 = sub-phases A1, A2 (is the next luma level worth coding?), 2 = A3 (Al decisions), 3 = B (order)
+  if (phase < 2) hipLaunchKernelGGL(k_prog_select_stage, dim3((n + 63) / 64), dim3(64), 0, s, (MjhProgCtl *)ctl, phase + 1, n);
+  else if (phase == 2) hipLaunchKernelGGL(k_prog_select_al, dim3((n + 63) / 64), dim3(64), 0, s, (MjhProgCtl *)ctl, ncomp, n);
   else hipLaunchKernelGGL(k_prog_select_order, dim3((n + 63) / 64), dim3(64), 0, s, (MjhProgCtl *)ctl, ncomp, dc_scan_opt_mode, n);
 }
 
