@@ -58,8 +58,8 @@ typedef struct {
   int trellis_num_loops;          /* JINT_TRELLIS_NUM_LOOPS (jcparam.c:515 default 1; 0 is read as 1): trellis passes per component */
   int smoothing_factor;           /* cinfo->smoothing_factor 0..100 (cjpeg -smooth N): input smoothing in the downsampler, jcsample.c:306-455 */
   int trellis_q_opt;              /* JBOOLEAN_TRELLIS_Q_OPT: quantization tables re-estimated from the trellis result (jcmaster.c:1014-1030).
-                                   * ORACLE ONLY so far -- the HIP path refuses it */
-  /* the remaining trellis options of SURVEY 8f row 4 -- ORACLE ONLY so far, the HIP path refuses them */
+                                   *  */
+  /* the remaining trellis options of SURVEY 8f row 4 */
   int trellis_eob_opt;            /* JBOOLEAN_TRELLIS_EOB_OPT: EOB runs over all-zero blocks optimised along a block row, jcdctmgr.c:1224-1297 */
   int use_scans_in_trellis;       /* JBOOLEAN_USE_SCANS_IN_TRELLIS: two trellis passes per component, bands 1..split / split+1..63, jcmaster.c:453-460 */
   int trellis_freq_split;         /* JINT_TRELLIS_FREQ_SPLIT (0 is read as the default 8, jcparam.c:512) */
