@@ -228,6 +228,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per encode call per GPU (0 = the config's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true")
+    ap.add_argument("--no-inflight-leg", action="store_true", help="skip the three-batches-in-flight measurement (extra information)")
     ap.add_argument("--host-seconds", type=float, default=3.0)
     ap.add_argument("--host-batch", type=int, default=16)
     ap.add_argument("--verify", default="all", help="frames per batch to compare with the reference: all | N")
@@ -318,6 +319,43 @@ def main():
         step()
     ktimes = dict(enc.kernel_times())
     enc.set_profiling(0)
+
+    # Extra information, never `value`: the same steps with three batches in flight (three encoders, each on its own
+    # streams, taken round-robin), which is how a service keeps the device busy across the tails and the differently
+    # bound kernels of consecutive batches.  The contract line above stays the one-batch-at-a-time figure, so that the
+    # dominant kernel's event-timed duration is not inflated by concurrent launches.
+    pipelined = None
+    if not args.no_inflight_leg and world == 1:
+        extra = []
+        try:
+            extra = [M.Encoder(params, max_batch=B, device=local_rank) for _ in range(2)]
+            ring = [enc] + extra
+            same = True
+            for e2 in extra:
+                e2.encode_tensor(d_frames[0:calls[0][1]], stream="own")
+                e2.sync()
+                same = same and e2.get_jpeg(0) == jpegs[0]
+            ksteps = max(3, min(args.steps, 60))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            k = 0
+            for _ in range(ksteps):
+                for s0, cnt in calls:
+                    ring[k % 3].encode_tensor(d_frames[s0:s0 + cnt], stream="own")
+                    k += 1
+            for e2 in ring:
+                e2.sync()
+            dt = (time.perf_counter() - t0) / ksteps
+            pipelined = {"encoders_in_flight": 3, "steps": ksteps, "ms_per_step": round(dt * 1e3, 3),
+                         "value": round(float(w) * h * nframes / dt / 1e6, 2), "unit": "Mpixels/s",
+                         "files_identical_to_the_single_encoder_run": bool(same)}
+        except Exception as exc:   # extra information only: the contract line must still come out
+            pipelined = {"error": str(exc)}
+        for e2 in extra:
+            try:
+                e2.close()
+            except Exception:
+                pass
     enc.close()
     del d_frames
 
@@ -368,6 +406,8 @@ def main():
                          "kernel_ms_per_call(untimed pass, every kernel bracketed)":
                              {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])}},
         }
+        if pipelined is not None:
+            out["pipelined"] = pipelined
         if not args.no_host_leg and world == 1:
             try:
                 hb = min(args.host_batch, nframes)

@@ -1,5 +1,7 @@
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-timeout 1200 python -m pytest tests -q -m gpu --timeout 300 > gpurun_out/t_final.log 2>&1; tail -4 gpurun_out/t_final.log
-timeout 300 python tools/bench_variants.py --config c3 --batch 64 --env MJH_NOP --variants 0 --steps 5 > gpurun_out/exp_c3_64.log 2>&1; tail -1 gpurun_out/exp_c3_64.log | cut -c1-120
-timeout 300 python tools/bench_variants.py --config metric --batch 128 --env MJH_NOP --variants 0 --steps 10 > gpurun_out/exp_m128.log 2>&1; tail -1 gpurun_out/exp_m128.log | cut -c1-120
-timeout 300 python bench.py --config c3 --no-cpu-baseline --no-host-leg > gpurun_out/c3_final.log 2>&1; tail -1 gpurun_out/c3_final.log | cut -c1-300
+timeout 400 python bench.py > gpurun_out/bench_final.log 2>&1; tail -1 gpurun_out/bench_final.log | python -c "
+import sys, json
+j = json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'], j['steps'], j.get('pipelined'), j['roofline']['frac'], j['host_inclusive'].get('value'), j['cpu_baseline'].get('value'), j['bit_exact']['ok'])"
+timeout 200 python bench.py --config c4 --steps 5 --no-cpu-baseline --no-host-leg --verify 2 > gpurun_out/bench_c4_final.log 2>&1; tail -1 gpurun_out/bench_c4_final.log | cut -c1-100; tail -1 gpurun_out/bench_c4_final.log | python -c "
+import sys, json
+j = json.loads(sys.stdin.read()); print(j.get('pipelined'))"

@@ -9,7 +9,7 @@ BATCH=${2:-64}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/$TAG; mkdir -p "$O"
-Q="--no-cpu-baseline --no-host-leg --verify 1"
+Q="--no-cpu-baseline --no-host-leg --no-inflight-leg --verify 1"
 timeout 400 python bench.py > "$O/bench_default.log" 2>&1; tail -1 "$O/bench_default.log" | cut -c1-400
 timeout 200 rocprofv3 --kernel-trace --stats -d "$O" -o stats -- python bench.py --steps 20 --warmup 3 $Q --batch "$BATCH" > "$O/stats.log" 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$O" -o fetch -- python bench.py --steps 2 --warmup 1 $Q --batch "$BATCH" > "$O/fetch.log" 2>&1
