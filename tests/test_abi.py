@@ -132,3 +132,20 @@ def test_drop_in_without_gpu_fails_loudly_and_writes_nothing(tmp_path):
     assert r.returncode != 0
     assert b"no CPU fallback" in r.stderr
     assert not os.path.exists(out) or os.path.getsize(out) == 0
+
+
+def test_batch_shape_normalisation_of_the_binding():
+    """gray images may come with or without the channel axis; only the encoder's geometry tells a [n, H, W] gray batch from
+    one [H, W, C] image (a seeded fuzz case once encoded a two-image gray batch as one image)"""
+    import numpy as np
+    pg = M.make_params(7, 5, gray=True, grayin=True, baseline=True)
+    for shape, want in (((5, 7), (1, 5, 7, 1)), ((5, 7, 1), (1, 5, 7, 1)), ((2, 5, 7), (2, 5, 7, 1)), ((2, 5, 7, 1), (2, 5, 7, 1)), ((1, 5, 7), (1, 5, 7, 1))):
+        assert M._as_batch(pg, np.zeros(shape, np.uint8)).shape == want
+    pc = M.make_params(7, 5, baseline=True)
+    for shape, want in (((5, 7, 3), (1, 5, 7, 3)), ((2, 5, 7, 3), (2, 5, 7, 3)), ((5, 7, 4), (1, 5, 7, 4))):
+        assert M._as_batch(pc, np.zeros(shape, np.uint8)).shape == want
+    pw = M.make_params(1, 5, gray=True, grayin=True, baseline=True)   # one pixel wide: the channel axis is ambiguous by value, not by geometry
+    for shape, want in (((5, 1), (1, 5, 1, 1)), ((5, 1, 1), (1, 5, 1, 1)), ((3, 5, 1), (3, 5, 1, 1)), ((3, 5, 1, 1), (3, 5, 1, 1))):
+        assert M._as_batch(pw, np.zeros(shape, np.uint8)).shape == want
+    with pytest.raises(AssertionError):
+        M._as_batch(pc, np.zeros((6, 7, 3), np.uint8))
