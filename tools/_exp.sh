@@ -1,5 +1,4 @@
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-for c in c3 c5; do timeout 200 python bench.py --config $c --steps 10 --no-cpu-baseline --no-host-leg --verify 1 > gpurun_out/bench_${c}_fin.log 2>&1; tail -1 gpurun_out/bench_${c}_fin.log | python -c "
-import sys, json
-j = json.loads(sys.stdin.read()); print(j['config']['config_key'], j['value'], j['ms_per_step'], j.get('pipelined'), j['bit_exact']['ok'])"; done
-timeout 100 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+O=gpurun_out/r02e; mkdir -p $O
+timeout 150 rocprofv3 --kernel-trace --stats -d "$O" -o c3_stats -- python bench.py --config c3 --steps 10 --warmup 3 --no-cpu-baseline --no-host-leg --no-inflight-leg --verify 1 > "$O/c3_stats.log" 2>&1
+tail -1 $O/c3_stats.log | cut -c1-200
