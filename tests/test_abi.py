@@ -149,3 +149,32 @@ def test_batch_shape_normalisation_of_the_binding():
         assert M._as_batch(pw, np.zeros(shape, np.uint8)).shape == want
     with pytest.raises(AssertionError):
         M._as_batch(pc, np.zeros((6, 7, 3), np.uint8))
+
+
+def test_committed_bench_line_carries_the_contract_fields():
+    """the newest committed bench line (profiles/r*_bench_batch64.json, written by bench.py on the GPU box) has every field
+    the driver contract names, with the metric string of BASELINE.json"""
+    import glob
+    import json
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_batch64.json")))
+    assert lines
+    j = json.loads(open(lines[-1]).read())
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert j["metric"] == base["metric"]
+    for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in j, k
+    assert j["higher_is_better"] is True and j["scaling"] in ("weak", "strong") and j["vs_baseline"] is None and j["data"] == "synthetic"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = j["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port")
+    # consistency: the whole job's rate follows from the step time, and the dominant kernel fits inside a step
+    px = 3840 * 2160 * j["config"]["frames_per_step_per_gpu"] * j["n_gpus"]
+    assert abs(j["value"] - px / (j["ms_per_step"] * 1e-3) / 1e6) / j["value"] < 0.01
+    assert r["kernel_ms"] <= j["ms_per_step"]
+    assert j["bit_exact"]["ok"] and j["bit_exact"]["checked"] == j["bit_exact"]["identical"]
