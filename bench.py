@@ -9,6 +9,11 @@ tables = `cjpeg -quality 75 -baseline` = the configuration the metric is quoted 
 c2|c3|c4|c5|c5t selects the other BASELINE.json configurations (same JSON line, their own workload).
 N>1: one process per GPU, every rank encodes its own share of the batch (images are independent:
 weak scaling, no collective on the data path; c4 shards its 1024 frames: strong scaling).
+`python bench.py --gpus N` WITHOUT a launcher starts the N ranks itself (re-executes under
+torch.distributed.run on 127.0.0.1) and fails loudly when fewer than N devices are visible; under a
+launcher (WORLD_SIZE set) --gpus must agree with it.  At N>1 the line also carries `host_inclusive`
+measured on EVERY rank at the same time (sum, per-rank min/max, total input GB/s: the PCIe side is
+what can fail to scale) and `pool_host` (ONE process driving all N devices, mjh_pool_encode_host).
 
 Prints ONE JSON line (rank 0).  `value` is the DEVICE-RESIDENT rate (frames already in HBM when the
 timed region starts, complete JPEG files left in HBM), as the contract defines it.  Extra objects:
@@ -219,6 +224,70 @@ def host_inclusive(M, params, frames, hb, device, min_s, ref_jpegs):
                     "the device (mjh_encode_host / mjh_collect, double-buffered); one host thread"}
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def launch_plan(gpus, env, argv, visible_devices):
+    """What `bench.py --gpus N` does about its ranks.  Returns ("run", world) when this process IS a rank (or N == 1),
+    ("spawn", command) when it has to start the N ranks itself; raises SystemExit with the reason when the request cannot
+    be honoured.  (A function of its arguments only, so that the CPU suite can check it.)"""
+    world_env = env.get("WORLD_SIZE")
+    share = env.get("MJH_BENCH_DIST_BACKEND") == "gloo"     # test switch: ranks may share devices (numbers mean nothing)
+    if world_env is not None:
+        world = int(world_env)
+        if gpus != world and not (gpus == 1 and "--gpus" not in " ".join(argv)):
+            raise SystemExit("bench: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (gpus, world))
+        if world > visible_devices and not share and visible_devices >= 0:
+            raise SystemExit("bench: %d ranks but only %d GPU(s) visible" % (world, visible_devices))
+        return "run", world
+    if gpus <= 1:
+        return "run", 1
+    if gpus > visible_devices and not share and visible_devices >= 0:
+        raise SystemExit("bench: --gpus %d but only %d GPU(s) visible (no CPU fallback, no device sharing)" % (gpus, visible_devices))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return "spawn", cmd
+
+
+def gather_objects(obj, dist, world):
+    if dist is None:
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def pool_host_leg(M, params, frames, n_devices, per_device, min_s, ref_jpegs):
+    """ONE process, N devices: mjh_pool_encode_host deals the images of a call round-robin over its devices (one host
+    thread + one double-buffered encoder per device) and returns the files in image order."""
+    import torch
+    ndev = max(1, torch.cuda.device_count())
+    pool = M.Pool(params, max_batch_per_device=per_device, devices=[i % ndev for i in range(n_devices)])
+    n = frames.shape[0]
+    out = pool.encode_host(frames)                      # warm-up + check
+    same = sum(1 for i in range(n) if out[i] == ref_jpegs[i])
+    done = 0
+    t0 = time.perf_counter()
+    while True:
+        pool.encode_host(frames)
+        done += n
+        if time.perf_counter() - t0 >= min_s:
+            break
+    dt = time.perf_counter() - t0
+    pool.close()
+    h, w = frames.shape[1:3]
+    return {"value": round(done * w * h / dt / 1e6, 2), "unit": "Mpixels/s", "devices": n_devices, "frames": done,
+            "seconds": round(dt, 3), "input_GBps": round(done * frames[0].nbytes / dt / 1e9, 2),
+            "files_identical_to_device_run": "%d/%d" % (same, n),
+            "path": "one process, pageable host pixels -> mjh_pool_encode_host (one host thread + encoder per device)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,9 +301,33 @@ def main():
     ap.add_argument("--host-seconds", type=float, default=3.0)
     ap.add_argument("--host-batch", type=int, default=16)
     ap.add_argument("--verify", default="all", help="frames per batch to compare with the reference: all | N")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only start the ranks, form the process group (gloo) and print n_gpus: no GPU is touched (CPU test of the launch path)")
     args = ap.parse_args()
 
     import torch
+    if args.launch_check:
+        os.environ["MJH_BENCH_DIST_BACKEND"] = "gloo"
+    ndev = -1 if args.launch_check else (torch.cuda.device_count() if torch.cuda.is_available() else 0)
+    action, what = launch_plan(args.gpus, os.environ, sys.argv[1:], ndev)
+    if action == "spawn":     # --gpus N without a launcher: this process becomes the launcher of N ranks
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // args.gpus)))
+        sys.exit(subprocess.call(what, env=env))
+    if args.launch_check:
+        import torch.distributed as dist
+        rank, world = int(os.environ.get("RANK", "0")), what
+        seen = [rank]
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            seen = gather_objects(rank, dist, world)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": sorted(seen)}), flush=True)
+        return
     import mozjpeg_amd as M
 
     cfg = CONFIGS[args.config]
@@ -246,7 +339,7 @@ def main():
     twelve = kw.get("precision", 8) == 12
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = what
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -359,6 +452,34 @@ def main():
     enc.close()
     del d_frames
 
+    # PCIe-inclusive legs (never `value`).  N > 1: EVERY rank runs its host path at the same time -- the host side (N x
+    # pinned reads through one root complex, N result streams back) is the part of the job that can fail to scale.
+    host_all = None
+    if not args.no_host_leg:
+        try:
+            if dist is not None:
+                dist.barrier()
+            host_res = host_inclusive(M, params, frames, min(args.host_batch, nframes), local_rank, args.host_seconds, jpegs)
+        except Exception as exc:   # the leg is extra information: the contract line must still come out
+            host_res = {"error": str(exc)}
+        host_all = gather_objects(host_res, dist, world)
+    pool_res = None
+    if not args.no_host_leg and world > 1:
+        if dist is not None:
+            dist.barrier()          # the other ranks idle while rank 0 drives every device from one process
+        if rank == 0:
+            try:
+                ndev = max(1, torch.cuda.device_count())
+                sample = frames[:min(nframes, 8)]
+                big = np.concatenate([sample] * world)           # `world` x the sample, dealt over `world` devices
+                pool_res = pool_host_leg(M, params, big, world, min(args.host_batch, len(sample)), args.host_seconds,
+                                         [jpegs[i % len(sample)] for i in range(len(big))])
+                pool_res["device_ids"] = [i % ndev for i in range(world)]
+            except Exception as exc:
+                pool_res = {"error": str(exc)}
+        if dist is not None:
+            dist.barrier()
+
     if rank == 0:
         frames_per_step_all = total if total else B * world
         total_px = float(w) * h * frames_per_step_all * args.steps
@@ -408,12 +529,23 @@ def main():
         }
         if pipelined is not None:
             out["pipelined"] = pipelined
-        if not args.no_host_leg and world == 1:
-            try:
-                hb = min(args.host_batch, nframes)
-                out["host_inclusive"] = host_inclusive(M, params, frames, hb, local_rank, args.host_seconds, jpegs)
-            except Exception as exc:   # the leg is extra information: the contract line must still come out
-                out["host_inclusive"] = {"error": str(exc)}
+        if host_all is not None:
+            good = [h for h in host_all if h and "error" not in h]
+            if world == 1 or not good:
+                out["host_inclusive"] = host_all[0]
+            else:
+                vals = [h["value"] for h in good]
+                out["host_inclusive"] = {
+                    "value": round(sum(vals), 2), "unit": "Mpixels/s", "ranks_measured": len(good), "ranks": world,
+                    "per_rank_min": min(vals), "per_rank_max": max(vals),
+                    "input_GBps": round(sum(h["input_GBps"] for h in good), 2),
+                    "output_GBps": round(sum(h["output_GBps"] for h in good), 3),
+                    "frames_per_call": good[0]["frames_per_call"],
+                    "files_identical_to_device_run": [h["files_identical_to_device_run"] for h in good],
+                    "errors": [h["error"] for h in host_all if h and "error" in h],
+                    "path": "every rank at the same time: " + good[0]["path"]}
+        if pool_res is not None:
+            out["pool_host"] = pool_res
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(frames[0], kw)
         print(json.dumps(out), flush=True)
