@@ -356,7 +356,7 @@ template <class T, bool STATS>   // uint8_t: 8-bit samples; uint16_t: 12-bit sam
 __global__ void __launch_bounds__(64)
 k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ planes,
             int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
-            MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp)
+            MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out)
 {
   constexpr bool W12 = sizeof(T) == 2;
   __shared__ int lds[64][64];
@@ -461,7 +461,7 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
     __syncthreads();
   }
   unsigned *hh = hist + (lane & 15) * 256;
-  int run = 0;
+  int run = 0, nzc = 0;   // nzc: non-zero quantized AC coefficients = the AC trellis' queue length (its tile-sort key)
 #pragma unroll
   for (int k = 0; k < 64; k++) {
     const int x = d[kZZ.v[k]];
@@ -472,9 +472,11 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
     if (clampq) v = W12 ? max(-16383, min(16383, v)) : max(-1023, min(1023, v));
     if (!W12) uq[(size_t)k * cc.kstride] = (int16_t)x;   // raw x8 coefficients only feed the (8-bit only) trellis
     if (k == 0 || !STATS) qo[(size_t)k * cc.kstride] = (int16_t)v;   // STATS: the AC planes would never be read
+    if (!stats && !W12 && k > 0) nzc += (v != 0);
     if (stats && k > 0 && valid) {
       if (v == 0) run++;
       else {
+        nzc++;
         if (run > 15) { atomicAdd(&hh[0xF0], (unsigned)(run >> 4)); run &= 15; }
         const int nb = bitlen((unsigned)(v < 0 ? -v : v));
         atomicAdd(&hh[(run << 4) + nb], 1u);
@@ -482,6 +484,7 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
       }
     }
   }
+  if (!W12 && nq8_out && valid) nq8_out[(size_t)img * C.total_real_blocks + cc.blk_off + blk] = (uint8_t)nzc;
   if (stats) {
     if (valid && run > 0) atomicAdd(&hh[0], 1u);
     __syncthreads();
@@ -1645,6 +1648,289 @@ k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
 }
 
 // =============================================================================================
+// K5 v3  AC trellis, tile-sorted passes + lean walk (the plain 1..63 pass with compact record output: the metric's
+// configuration).  Same DP, same float recipe, same outputs as k_trellis_ac_q<.., COMPACT>; what changed is the shape:
+//  * TILE-SORTED PASSES.  A wave's walk lasts as long as its busiest lane (measured before: 29.5 of 64 lanes active per
+//    VALU instruction, profiles/r03a_pmc_sq_batch64.json; tools/model_trellis.py: 0.43 of the lane-steps useful).  One
+//    workgroup (= one wave) now owns a tile of 64*NPASS consecutive blocks, counting-sorts them by the number of non-zero
+//    conventionally quantized AC coefficients (one byte per block, written by the FDCT kernel) and runs NPASS passes,
+//    heaviest blocks first, so that a pass carries blocks of similar weight (model: 0.60 at 4 passes, 0.67 at 8).  Any
+//    assignment of blocks to lanes gives the same files; the tile's coefficients stay within the same cache lines.
+//    A pass whose blocks all have key 0 has nothing to decide (every AC coefficient stays zero): it only writes empty masks.
+//  * LEAN WALK.  Live entries carry their own position (info word: position | back ENTRY index | magnitude | sign), so a
+//    step is two entry loads instead of 64-bit mask arithmetic; the candidate distortions are computed once per
+//    position, not once per step; the end-of-block choice (jcdctmgr.c:1187-1207) is folded into the entry creation (entries
+//    are created in position order, strict '<' keeps the first minimum); the back-track follows entry indices.
+//    Blocks with a quantized magnitude >= 16 (more than 4 candidates) or more than QN queue records go to the work list
+//    of the general kernels above.
+// LDS per wave: QN * (8 + 4) * 64 + 256 bytes (12.25 KB at QN = 16); quantizer rows travel through ds_bpermute.
+// =============================================================================================
+template <int NC>
+__device__ __forceinline__ void v3_eval(const float4 &rr, float rb, float rhs, float d0, float d1, float d2, float d3, float &lb, int &lk)
+{
+  float c0 = (rr.x + rb) + d0;
+  c0 = c0 + rhs;
+  lb = c0; lk = 0;
+  if (NC >= 2) {
+    float c1 = (rr.y + rb) + d1;
+    c1 = c1 + rhs;
+    if (c1 < lb) { lb = c1; lk = 1; }
+  }
+  if (NC >= 3) {
+    float c2 = (rr.z + rb) + d2;
+    float c3 = (rr.w + rb) + d3;
+    c2 = c2 + rhs; c3 = c3 + rhs;
+    if (c2 < lb) { lb = c2; lk = 2; }
+    if (c3 < lb) { lb = c3; lk = 3; }
+  }
+}
+
+template <int NC>
+__device__ __forceinline__ float4 v3_rate(const float4 *rate_rows, int run)
+{
+  if (NC <= 2) { const float2 t = *reinterpret_cast<const float2 *>(&rate_rows[run & 15]); return make_float4(t.x, t.y, 0.f, 0.f); }
+  return rate_rows[run & 15];
+}
+
+// one step of the walk: the two newest live entries not looked at yet (e-1, e-2; entry 0 = the virtual start, not stored)
+template <int QN, int NC>
+__device__ __forceinline__ void v3_pair(const uint2 (*col)[64], const unsigned (*info)[64], const float4 *rate_rows, int lane, int e, int im1,
+                                        float azd_prev, float f0f, float d0, float d1, float d2, float d3,
+                                        float &best, int &beste, int &bestk, float &gap_old)
+{
+  const int ea = e - 1, eb = e >= 2 ? e - 2 : e - 1;
+  const int sa = ea > 0 ? ea - 1 : 0, sb = eb > 0 ? eb - 1 : 0;
+  const uint2 va = col[sa][lane], vb = col[sb][lane];
+  const unsigned ia = info[sa][lane], ib = info[sb][lane];
+  const float azd_a = ea > 0 ? __uint_as_float(va.x) : 0.0f, acc_a = ea > 0 ? __uint_as_float(va.y) : 0.0f;
+  const float azd_b = eb > 0 ? __uint_as_float(vb.x) : 0.0f, acc_b = eb > 0 ? __uint_as_float(vb.y) : 0.0f;
+  const int run_a = im1 - (ea > 0 ? (int)(ia & 63u) : 0), run_b = im1 - (eb > 0 ? (int)(ib & 63u) : 0);
+  const float4 ra = v3_rate<NC>(rate_rows, run_a), rb4 = v3_rate<NC>(rate_rows, run_b);
+  const float rba = (float)(run_a >> 4) * f0f, rbb = (float)(run_b >> 4) * f0f;
+  const float gap_a = azd_prev - azd_a, gap_b = azd_prev - azd_b;
+  const float rhs_a = gap_a + acc_a, rhs_b = gap_b + acc_b;
+  float lba, lbb;
+  int lka, lkb;
+  v3_eval<NC>(ra, rba, rhs_a, d0, d1, d2, d3, lba, lka);
+  v3_eval<NC>(rb4, rbb, rhs_b, d0, d1, d2, d3, lbb, lkb);
+  // newest first, '<=': on equal cost the OLDER predecessor wins, as in the reference's oldest-first strict '<' scan (a cost
+  // without a Huffman code is >= 3e38 and never reaches the initial 1e38); when e == 1, b repeats a (same entry: harmless)
+  if (lba <= best) { best = lba; beste = ea; bestk = lka; }
+  if (lbb <= best) { best = lbb; beste = eb; bestk = lkb; }
+  gap_old = gap_b;
+}
+
+template <int QN, int NPASS>
+__global__ void __launch_bounds__(64)
+k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q,
+                const MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 ac_slot_of_comp, int4 tile0_of_comp,
+                const float *__restrict__ lambda_in, const uint8_t *__restrict__ nq8, unsigned *__restrict__ worklist,
+                int16_t *__restrict__ dense, unsigned dense_cap, unsigned long long *__restrict__ nzmask)
+{
+  static_assert(QN >= 16 && QN <= 31 && NPASS >= 1 && NPASS <= 8, "queue capacity / passes");
+  constexpr int TILE = 64 * NPASS;
+  __shared__ uint2 col[QN][64];          // tile sort scratch; per pass: queue records -> live entries {azd, acc} -> value column
+  __shared__ unsigned info[QN][64];      // live entry e (>= 1) at [e-1]: position | back entry << 6 | magnitude << 11 | sign << 21
+  __shared__ float4 rate_rows[16];
+  typedef unsigned __attribute__((may_alias)) u_alias;
+  typedef unsigned short __attribute__((may_alias)) us_alias;
+  const int img = blockIdx.y, tl = blockIdx.x, lane = threadIdx.x;
+  const int comp = tl >= tile0_of_comp.w ? 3 : tl >= tile0_of_comp.z ? 2 : tl >= tile0_of_comp.y ? 1 : 0;
+  const int t0 = comp == 0 ? 0 : comp == 1 ? tile0_of_comp.y : comp == 2 ? tile0_of_comp.z : tile0_of_comp.w;
+  const MjhComp cc = C.c[comp];
+  const int tile_base = (tl - t0) * TILE;
+  const int slot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
+  const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+  const size_t gblk0 = (size_t)img * C.total_real_blocks + cc.blk_off;
+  if (lane < 16) rate_rows[lane] = rate_row(reinterpret_cast<const uint4 *>(T->ehufsi)[lane]);
+  const int si_f0 = (int)T->ehufsi[0xF0], si_eob = (int)T->ehufsi[0];
+  const float f0f = si_f0 ? (float)si_f0 : 3e38f, eobf = (float)si_eob;
+  const int dq_lane = Q->dq8[cc.qtbl][lane];                    // lane k holds the row entry of position k (ds_bpermute lookups)
+  const float lt_lane = Q->lambda_tbl[cc.qtbl][lane];
+
+  // ---- tile sort: descending key; perm entry = index in tile | key << 9 ----
+  unsigned long long mine0 = 0ull, mine1 = 0ull;
+  {
+    u_alias *hist = reinterpret_cast<u_alias *>(&col[0][0]);              // [64]
+    us_alias *perm = reinterpret_cast<us_alias *>(&col[0][0]) + 128;      // [TILE], behind the histogram
+    hist[lane] = 0u;
+    __syncthreads();
+    unsigned key[NPASS], rank[NPASS];
+#pragma unroll
+    for (int j = 0; j < NPASS; j++) {
+      const int b = tile_base + j * 64 + lane;
+      unsigned k = b < cc.nblk ? (unsigned)nq8[gblk0 + b] : 0u;
+      key[j] = k > 63u ? 63u : k;
+      rank[j] = atomicAdd(&hist[key[j]], 1u);
+    }
+    __syncthreads();
+    const unsigned h = hist[63 - lane];     // lane L: blocks with key 63-L; blocks with a larger key come first
+    unsigned inc = h;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned n = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += n;
+    }
+    __syncthreads();
+    hist[63 - lane] = inc - h;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NPASS; j++) perm[hist[key[j]] + rank[j]] = (unsigned short)((unsigned)(j * 64 + lane) | (key[j] << 9));
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NPASS; j++) {
+      const unsigned long long v = perm[j * 64 + lane];
+      if (j < 4) mine0 |= v << (16 * j); else mine1 |= v << (16 * (j - 4));
+    }
+    __syncthreads();
+  }
+
+  us_alias *colh = reinterpret_cast<us_alias *>(&col[0][0]);   // value of slot s: row s>>2, half-word s&3 of the lane's uint2
+#pragma unroll 1
+  for (int pass = 0; pass < NPASS; pass++) {
+    const unsigned pe = (unsigned)(((pass < 4 ? mine0 : mine1) >> (16 * (pass & 3))) & 0xFFFFull);
+    const int blk = tile_base + (int)(pe & 511u);
+    const bool inside = blk < cc.nblk;
+    const size_t gblk = gblk0 + (inside ? blk : 0);
+    if (__builtin_amdgcn_ballot_w64(inside && (pe >> 9) != 0u) == 0ull) {   // nothing quantizes to non-zero: all-zero blocks
+      if (inside) nzmask[gblk] = 0ull;
+      continue;
+    }
+    const float lambda = lambda_in[gblk0 + (inside ? blk : cc.nblk - 1)];
+    int nq = 0, qmax = 0;
+    float azd63;
+    {
+      const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + (inside ? blk : cc.nblk - 1);
+      short xs[64];
+#pragma unroll
+      for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
+      const int *dq8 = Q->dq8[cc.qtbl];
+      const float *rcp = Q->rcp8q[cc.qtbl], *lt = Q->lambda_tbl[cc.qtbl];
+      float azd = 0.0f;
+#pragma unroll
+      for (int k = 1; k < 64; k++) {
+        const int xsg = xs[k];
+        const int x = xsg < 0 ? -xsg : xsg;
+        const int dq = dq8[k];
+        float t = (float)mul24(x, x) * lambda;
+        t = t * lt[k];
+        const float azd_cur = t + azd;
+        if (x + (dq >> 1) >= dq) {
+          int qval = udiv_exact(x + (dq >> 1), dq, rcp[k]);
+          if (qval >= 1024) qval = 1023;
+          qmax = qval > qmax ? qval : qmax;
+          if (nq < QN) col[nq][lane] = make_uint2((unsigned)k | (xsg < 0 ? 64u : 0u) | ((unsigned)qval << 7) | ((unsigned)x << 17), __float_as_uint(azd));
+          nq++;
+        }
+        azd = azd_cur;
+      }
+      azd63 = azd;
+      defer_blocks(inside && (nq > QN || qmax >= 16), worklist, (unsigned)img, ((unsigned)comp << 28) | (unsigned)blk, 0u, xs, dense, dense_cap, true, lane);
+    }
+    const bool work = inside && nq <= QN && qmax < 16;
+
+    // ---- the walk: every lane consumes its own records; the next record is always one load ahead ----
+    int nlive = 1, qi = 0, last = 0;
+    bool act = work && nq > 0;
+    int i = 0, x = 0, qval = 0, ncd = 0, sgn = 0, e = 0, beste = -1, bestk = 0;
+    float azd_prev = 0.0f, azd_cur = 0.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f, best = 1e38f;
+    float end_best = azd63 + eobf;
+    uint2 rec_n = col[0][lane];
+    // quantizer constants of the NEXT record's position: lane k holds entry k of the component's rows, fetched with ds_bpermute
+    // at a point where every lane of the wave is enabled (a disabled source lane would read as 0)
+    int dq_n = 1;
+    float lt_n = 0.0f;
+    auto lookup = [&]() {
+      const int a = (int)(rec_n.x & 63u) << 2;
+      dq_n = __builtin_amdgcn_ds_bpermute(a, dq_lane) & 0x3FFFF;      // 8q <= 8 * 32767: tells the compiler the 24-bit multiplies are exact
+      lt_n = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(lt_lane)));
+    };
+    lookup();
+    auto setup = [&]() {
+      const uint2 rec = rec_n;
+      qi++;
+      rec_n = col[qi < QN ? qi : QN - 1][lane];      // (slots behind the consumed ones are never overwritten: entry e lives in slot e-1 <= qi-1)
+      i = (int)(rec.x & 63u); sgn = (int)((rec.x >> 6) & 1u); qval = (int)((rec.x >> 7) & 1023u); x = (int)(rec.x >> 17);
+      azd_prev = __uint_as_float(rec.y);
+      const int dq = dq_n;
+      const float lti = lt_n;
+      float t = (float)mul24(x, x) * lambda;
+      t = t * lti;
+      azd_cur = t + azd_prev;
+      ncd = bitlen((unsigned)qval);
+      float dd[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
+        const int delta = mul24(cand, dq) - x;
+        const float d = (float)mul24(delta, delta) * lambda;
+        dd[k] = k < ncd ? d * lti : 3e38f;
+      }
+      d0 = dd[0]; d1 = dd[1]; d2 = dd[2]; d3 = dd[3];
+      e = nlive; best = 1e38f; beste = -1; bestk = 0;
+    };
+    if (act) setup();
+    while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
+      lookup();
+      if (act) {
+        float gap_old;
+        if (__builtin_amdgcn_ballot_w64(ncd > 2) == 0ull)
+          v3_pair<QN, 2>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk, gap_old);
+        else
+          v3_pair<QN, 4>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk, gap_old);
+        e -= 2;
+        // cost >= rhs >= gap in float arithmetic, and the gap only grows towards older entries: once it exceeds the best cost
+        // no older predecessor can win or tie
+        if (e <= 0 || gap_old > best) {
+          if (beste >= 0) {
+            const int mag = (bestk < ncd - 1) ? (2 << bestk) - 1 : qval;
+            col[nlive - 1][lane] = make_uint2(__float_as_uint(azd_cur), __float_as_uint(best));     // live entry nlive
+            info[nlive - 1][lane] = (unsigned)i | ((unsigned)beste << 6) | ((unsigned)mag << 11) | ((unsigned)sgn << 21);
+            // end-of-block choice (jcdctmgr.c:1187-1207): entries appear in position order, strict '<' keeps the first minimum
+            float c = best + azd63;
+            c = c - azd_cur;
+            if (i < 63) c = c + eobf;
+            if (c < end_best) { end_best = c; last = nlive; }
+            nlive++;
+          }
+          if (qi >= nq) act = false;
+          else setup();
+        }
+      }
+    }
+
+    // ---- back-track (jcdctmgr.c:1211-1222) along the entry indices; values in visiting (descending position) order ----
+    unsigned long long pmask = 0ull;
+    int cnt = 0, e2 = work ? last : 0;
+    while (__builtin_amdgcn_ballot_w64(e2 > 0) != 0ull) {
+      if (e2 > 0) {
+        const unsigned inf = info[e2 - 1][lane];
+        const int mag = (int)((inf >> 11) & 1023u);
+        const int v = ((inf >> 21) & 1u) ? -mag : mag;
+        colh[((cnt >> 2) * 64 + lane) * 4 + (cnt & 3)] = (unsigned short)v;
+        pmask |= 1ull << (inf & 63u);
+        cnt++;
+        e2 = (int)((inf >> 6) & 31u);
+      }
+    }
+    if (work) nzmask[gblk] = pmask;
+    {
+      int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+      // plane i+1 <- the i-th non-zero in position order = slot cnt-1-i; a plane is stored only while some block has a value for it
+#pragma unroll
+      for (int i2 = 0; i2 < QN; i2++) {
+        if (__builtin_amdgcn_ballot_w64(i2 < cnt) == 0ull) break;
+        if (i2 < cnt) {
+          const int s2 = cnt - 1 - i2;
+          qo[(size_t)(i2 + 1) * cc.kstride] = (int16_t)colh[((s2 >> 2) * 64 + lane) * 4 + (s2 & 3)];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// =============================================================================================
 // K6  DC trellis (row a9, DC part): quantize_trellis jcdctmgr.c:1044-1118 + :1308-1327, driven
 // per iMCU row by compress_trellis_pass jccoefct.c:418-441 (lastDC = 0 at the start of each
 // iMCU row, chained over its v_samp_factor block rows).
@@ -2383,13 +2669,13 @@ static int max_nblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp;
 static int max_padblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp; i++) { int v = C.c[i].wpad * C.c[i].hpad; m = v > m ? v : m; } return m; }
 
 void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
-                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], int n, hipStream_t s)
+                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s)
 {
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
   const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
-  if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t, false>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl);
-  else if (stat_tabs) hipLaunchKernelGGL((k_dct_quant<uint8_t, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl);
-  else hipLaunchKernelGGL((k_dct_quant<uint8_t, false>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl);
+  if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t, false>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
+  else if (stat_tabs) hipLaunchKernelGGL((k_dct_quant<uint8_t, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
+  else hipLaunchKernelGGL((k_dct_quant<uint8_t, false>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
 }
 
 void mjh_launch_stats_ac(const MjhConst &C, const void *q, const unsigned long long *nzmask, MjhHuffTable *tabs, int spi, const int slot[4], int count_dummies, int n, hipStream_t s)
@@ -2427,7 +2713,8 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
 
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
-                           int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s)
+                           int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
+                           const uint8_t *nq8, int v3_passes)
 {
   // band-limited pass (use_scans_in_trellis), the per-block outputs of trellis_eob_opt, per-image tables (trellis_q_opt):
   // the EXT instantiations
@@ -2457,7 +2744,23 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   }
   // MJH_TRELLIS_VARIANT: queue capacity of the first tier (all bit-identical; LDS per wave = 10 * QN * 64 bytes);
   // second and third tier: blocks with more than QN (then 32) non-zero positions, from their dense copies
-  if (nzmask) {   // compact records out (the caller guarantees: plain pass, no fused statistics)
+  if (nzmask && nq8 && v3_passes > 0 && variant == 0) {
+    // the tile-sorted kernel: first tier of the plain compact pass; its work list (more than 16 records, or a magnitude >= 16)
+    // goes through the general tiers below
+    const int np = v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
+    int t0[5] = { 0, 0, 0, 0, 0 };
+    for (int i = 0; i < 4; i++) t0[i + 1] = t0[i] + (i < C.ncomp ? (C.c[i].nblk + 64 * np - 1) / (64 * np) : 0);
+    dim3 gridt(t0[C.ncomp], n);
+    for (int i = C.ncomp; i < 4; i++) t0[i] = 0x7FFFFFFF;
+    const int4 tv = make_int4(t0[0], t0[1], t0[2], t0[3]);
+#define LV3(NP) hipLaunchKernelGGL((k_trellis_ac_v3<16, NP>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask)
+    switch (np) { case 8: LV3(8); break; case 4: LV3(4); break; case 2: LV3(2); break; default: LV3(1); break; }
+#undef LV3
+    hipLaunchKernelGGL((k_trellis_ac_qd<32, false, false, true>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
+                       (const unsigned *)worklist, worklist2, (const int16_t *)dense, dense_cap, st, ss, ext);
+    hipLaunchKernelGGL((k_trellis_ac_qd<63, false, false, true>), dim3(1024), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
+                       (const unsigned *)worklist2, (unsigned *)nullptr, (const int16_t *)dense, dense_cap, st, ss, ext);
+  } else if (nzmask) {   // compact records out (the caller guarantees: plain pass, no fused statistics)
 #define LQC(QN) hipLaunchKernelGGL((k_trellis_ac_q<QN, false, false, true>), gridq, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, wv, lambda, worklist, (int16_t *)dense, dense_cap, st, ss, ext)
 #define LDC(QN, GRID, WL, WLN) hipLaunchKernelGGL((k_trellis_ac_qd<QN, false, false, true>), dim3(GRID), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda, (const unsigned *)WL, WLN, (const int16_t *)dense, dense_cap, st, ss, ext)
     switch (variant) { case 1: LQC(20); break; case 2: LQC(24); break; case 3: LQC(32); break; default: LQC(16); break; }
