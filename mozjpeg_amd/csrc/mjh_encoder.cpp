@@ -269,6 +269,8 @@ struct mjh_encoder {
   // the values live in the AC planes of d_q, plane i+1 = i-th non-zero.  compact_last: the last batch's d_q is in that form
   unsigned long long *d_nzmask = nullptr; bool use_compact = false, compact_last = false;
   uint8_t *d_nq8 = nullptr;          // per block: non-zero conventionally quantized AC coefficients (FDCT kernel) = tile-sort key of the AC trellis
+  int dc_mode = 0;
+  int dc_window_ok = 0;              // every component's DC quantizer step 8q >= 40: the DC trellis may use its sliding-window kernel
   int trellis_v3 = 4;                // passes per tile of the tile-sorted first tier (MJH_TRELLIS_V3; 0 = the general kernel)
   int dqt_off[4] = { -1, -1, -1, -1 };      // file offset of the first entry of every 8-bit DQT table
   int nbands = 1, freq_split = 8;
@@ -732,6 +734,10 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   e->h_defer[0] = 0xFFFFFFFFu;
   if (const char *v = getenv("MJH_FUSE")) e->fuse_mask = atoi(v);
   if (const char *v = getenv("MJH_TRELLIS_V3")) e->trellis_v3 = atoi(v);
+  e->dc_window_ok = 1;
+  for (int i = 0; i < C.ncomp; i++) if (p->quantval[p->quant_tbl_no[i]][0] < 5) e->dc_window_ok = 0;
+  e->dc_window_ok |= (getenv("MJH_DC_V2") ? atoi(getenv("MJH_DC_V2")) : 1) << 8;   // bits 8..: which DC trellis kernel (A/B runs)
+  if (const char *v = getenv("MJH_DC_MODE")) e->dc_mode = atoi(v);
   HIPCHK_E(hipMalloc((void **)&e->d_len16, B * (size_t)C.total_mcu_blocks * 2));
   HIPCHK_E(hipMalloc((void **)&e->d_off32, B * (size_t)C.total_mcu_blocks * 4));
   e->chunks = (C.total_mcu_blocks + 2047) / 2048;
@@ -1116,14 +1122,18 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     // latency-bound chains) and the AC DP (every block) touch disjoint coefficient planes, so the
     // DC kernel runs on a side stream underneath the AC kernel.
     e->side_timed = false;
-    if (p.trellis_quant_dc) {
+    const int dc_mode = e->dc_mode;   // experiments (MJH_DC_MODE): 1 = DC trellis on the main stream, before the AC kernel
+    if (p.trellis_quant_dc && dc_mode == 1) {
+      pr.mark("trellis_dc(serial)");
+      mjh_launch_trellis_dc(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, s, e->dc_window_ok);
+    } else if (p.trellis_quant_dc) {
       HIPCHK(hipEventRecord(e->ev_fork, s));
       HIPCHK(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
       if (pr.enabled && e->profiling == 1) {
         while (e->side_events.size() < 2 * (size_t)(e->prof_calls + 1)) { hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); e->side_events.push_back(ev); }
         HIPCHK(hipEventRecord(e->side_events[2 * e->prof_calls], e->side_stream));
       }
-      mjh_launch_trellis_dc(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, e->side_stream);   // (the DC entries never change: image 0's tables serve all)
+      mjh_launch_trellis_dc(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, e->side_stream, e->dc_window_ok);   // (the DC entries never change: image 0's tables serve all)
       if (pr.enabled && e->profiling == 1) { HIPCHK(hipEventRecord(e->side_events[2 * e->prof_calls + 1], e->side_stream)); e->side_timed = true; }
       HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
     }
@@ -1157,7 +1167,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       pr.mark("trellis_q_opt(sums)");
       mjh_launch_qopt_accumulate(CV, e->d_uq, e->d_q, e->d_qsums, n, s);
     }
-    if (p.trellis_quant_dc) {
+    if (p.trellis_quant_dc && dc_mode != 1) {
       pr.mark("join(trellis_dc)");
       HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
     }

@@ -13,6 +13,7 @@
 // Reference behaviour each kernel reproduces is cited as file:line under /root/reference.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "mjh_internal.h"
 #include "mjh_device.h"
 
@@ -1658,12 +1659,12 @@ k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
 //    assignment of blocks to lanes gives the same files; the tile's coefficients stay within the same cache lines.
 //    A pass whose blocks all have key 0 has nothing to decide (every AC coefficient stays zero): it only writes empty masks.
 //  * LEAN WALK.  Live entries carry their own position (info word: position | back ENTRY index | magnitude | sign), so a
-//    step is two entry loads instead of 64-bit mask arithmetic; the candidate distortions are computed once per
+//    step is two entry loads instead of 64-bit mask arithmetic (a 16-bit word: only magnitudes below 16 get here); the candidate distortions are computed once per
 //    position, not once per step; the end-of-block choice (jcdctmgr.c:1187-1207) is folded into the entry creation (entries
 //    are created in position order, strict '<' keeps the first minimum); the back-track follows entry indices.
 //    Blocks with a quantized magnitude >= 16 (more than 4 candidates) or more than QN queue records go to the work list
 //    of the general kernels above.
-// LDS per wave: QN * (8 + 4) * 64 + 256 bytes (12.25 KB at QN = 16); quantizer rows travel through ds_bpermute.
+// LDS per wave: QN * (8 + 2) * 64 + 256 bytes (10.25 KB at QN = 16: 15 waves per CU); quantizer rows travel through ds_bpermute.
 // =============================================================================================
 template <int NC>
 __device__ __forceinline__ void v3_eval(const float4 &rr, float rb, float rhs, float d0, float d1, float d2, float d3, float &lb, int &lk)
@@ -1694,7 +1695,7 @@ __device__ __forceinline__ float4 v3_rate(const float4 *rate_rows, int run)
 
 // one step of the walk: the two newest live entries not looked at yet (e-1, e-2; entry 0 = the virtual start, not stored)
 template <int QN, int NC>
-__device__ __forceinline__ void v3_pair(const uint2 (*col)[64], const unsigned (*info)[64], const float4 *rate_rows, int lane, int e, int im1,
+__device__ __forceinline__ void v3_pair(const uint2 (*col)[64], const unsigned short (*info)[64], const float4 *rate_rows, int lane, int e, int im1,
                                         float azd_prev, float f0f, float d0, float d1, float d2, float d3,
                                         float &best, int &beste, int &bestk, float &gap_old)
 {
@@ -1730,7 +1731,7 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
   static_assert(QN >= 16 && QN <= 31 && NPASS >= 1 && NPASS <= 8, "queue capacity / passes");
   constexpr int TILE = 64 * NPASS;
   __shared__ uint2 col[QN][64];          // tile sort scratch; per pass: queue records -> live entries {azd, acc} -> value column
-  __shared__ unsigned info[QN][64];      // live entry e (>= 1) at [e-1]: position | back entry << 6 | magnitude << 11 | sign << 21
+  __shared__ unsigned short info[QN][64];   // live entry e (>= 1) at [e-1]: position | back entry << 6 | magnitude (< 16) << 11 | sign << 15
   __shared__ float4 rate_rows[16];
   typedef unsigned __attribute__((may_alias)) u_alias;
   typedef unsigned short __attribute__((may_alias)) us_alias;
@@ -1885,7 +1886,7 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
           if (beste >= 0) {
             const int mag = (bestk < ncd - 1) ? (2 << bestk) - 1 : qval;
             col[nlive - 1][lane] = make_uint2(__float_as_uint(azd_cur), __float_as_uint(best));     // live entry nlive
-            info[nlive - 1][lane] = (unsigned)i | ((unsigned)beste << 6) | ((unsigned)mag << 11) | ((unsigned)sgn << 21);
+            info[nlive - 1][lane] = (unsigned short)((unsigned)i | ((unsigned)beste << 6) | ((unsigned)mag << 11) | ((unsigned)sgn << 15));
             // end-of-block choice (jcdctmgr.c:1187-1207): entries appear in position order, strict '<' keeps the first minimum
             float c = best + azd63;
             c = c - azd_cur;
@@ -1905,8 +1906,8 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     while (__builtin_amdgcn_ballot_w64(e2 > 0) != 0ull) {
       if (e2 > 0) {
         const unsigned inf = info[e2 - 1][lane];
-        const int mag = (int)((inf >> 11) & 1023u);
-        const int v = ((inf >> 21) & 1u) ? -mag : mag;
+        const int mag = (int)((inf >> 11) & 15u);
+        const int v = (inf >> 15) ? -mag : mag;
         colh[((cnt >> 2) * 64 + lane) * 4 + (cnt & 3)] = (unsigned short)v;
         pmask |= 1ull << (inf & 63u);
         cnt++;
@@ -2094,6 +2095,359 @@ k_trellis_dc(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restri
     if (C.delta_dc_weight > 0.0f) __threadfence();   // the next sub-row reads this row's final DC values back (other lanes of the group)
     else __threadfence_block();
     (void)live;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6 v2: the same recursion with the cross-lane traffic on DPP.  Measured on the first version (profiles/r03a): a luma chain
+// of 960 sequential steps ran at ~2250 cycles per step, because the compiler serialised its 18 ds_bpermute round trips (LDS
+// latency each) inside the dependent chain; 1.69 ms per 64 4K frames even with the GPU to itself -- longer than the AC kernel
+// it is supposed to hide under.  Here a 16-lane group is one DPP row: the nine predecessor (value, cost) pairs arrive through
+// `row_newbcast` (a VALU move, no LDS round trip), the per-step inputs are fetched one step ahead (their ds_bpermute latency
+// hides behind the previous step), the next 16 blocks' loads are issued before the current 16 are walked, and the arg-min
+// is a min3 tree on the critical path with the index (first minimum, as the reference's strict '<' scan) recovered beside it.
+// Same operations on the same values in the same order per candidate: bit-identical results.
+// ---------------------------------------------------------------------------------------------
+template <int L> __device__ __forceinline__ int row_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + L, 0xF, 0xF, false); }   // row_newbcast:L
+template <int L> __device__ __forceinline__ float row_bcast_f(float v) { return __int_as_float(row_bcast<L>(__float_as_int(v))); }
+
+__global__ void __launch_bounds__(64)
+k_trellis_dc2(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
+              int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
+              int4 dc_slot_of_comp, const float *__restrict__ lambda_in, uint8_t *__restrict__ back)
+{
+  const int img = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int k = lane & 15;
+  const int chain = blockIdx.x * 4 + (lane >> 4);
+  const int nchains = C.ncomp * C.mcu_rows;
+  if (chain >= nchains) return;   // whole 16-lane groups (= DPP rows) leave together
+  const int comp = chain / C.mcu_rows, imcu = chain - comp * C.mcu_rows;
+  const MjhComp cc = C.c[comp];
+  const int slot = comp == 0 ? dc_slot_of_comp.x : comp == 1 ? dc_slot_of_comp.y : comp == 2 ? dc_slot_of_comp.z : dc_slot_of_comp.w;
+  const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+  unsigned long long rsi = 0;   // 12 x 5 bits: category + its code length = the rate of a DC difference of that category
+  for (int s = 0; s < 12; s++) rsi |= (unsigned long long)((T->ehufsi[s] + s) & 31) << (5 * s);
+  const int q0 = Q->q[cc.qtbl][0];
+  const int dq = 8 * q0;
+  const float rcp = Q->rcp8q[cc.qtbl][0];
+  const float lt0 = Q->lambda_tbl[cc.qtbl][0];
+  int ncand = (2 + 60 / q0) | 1;                 // get_num_dc_trellis_candidates :930-933
+  if (ncand > 9) ncand = 9;
+  const int16_t *uq0 = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off;  // plane k = 0
+  int16_t *qo0 = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;
+  const float *lam = lambda_in + (size_t)img * C.total_real_blocks + cc.blk_off;
+  uint8_t *bk = back + ((size_t)img * C.total_real_blocks + cc.blk_off) * 16;
+  int last_dc = 0;
+  for (int sub = 0; sub < cc.v; sub++) {
+    const int br = imcu * cc.v + sub;
+    if (br >= cc.hib) break;
+    const int row0 = br * cc.wib;
+    int prev_c = 0;
+    float prev_cost = 0.0f;
+    const bool vert = sub > 0 && C.delta_dc_weight > 0.0f;
+    auto fetch = [&](int b, int &xs_o, float &lam_o, int &ab_o) {
+      xs_o = b < cc.wib ? (int)uq0[row0 + b] : 0;
+      lam_o = b < cc.wib ? lam[row0 + b] : 0.0f;
+      ab_o = 0;
+      if (vert && b < cc.wib)   // raw DC above (low half) and the final quantized DC above (high half): written by this group's own back-track
+        ab_o = ((int)uq0[row0 - cc.wib + b] & 0xFFFF) |
+               ((int)__hip_atomic_load(reinterpret_cast<const unsigned short *>(qo0 + row0 - cc.wib + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 16);
+    };
+    int xs_l, ab_l;
+    float lam_l;
+    fetch(k, xs_l, lam_l, ab_l);
+    for (int g = 0; g < cc.wib; g += 16) {
+      int xs_n, ab_n;
+      float lam_n;
+      fetch(g + 16 + k, xs_n, lam_n, ab_n);          // the next 16 blocks: in flight while these 16 are walked
+      const int steps = min(16, cc.wib - g);
+      int xs_s = grp_shfl(xs_l, 0, lane), ab_s = vert ? grp_shfl(ab_l, 0, lane) : 0;
+      float lam_s = grp_shfl_f(lam_l, 0, lane);
+      for (int s = 0; s < steps; s++) {
+        const int bi = g + s;
+        const int xs = xs_s, ab = ab_s;
+        const float lambda_dc = lam_s * lt0;
+        // the next step's inputs (their LDS round trip hides behind this step)
+        xs_s = grp_shfl(xs_l, (s + 1) & 15, lane);
+        lam_s = grp_shfl_f(lam_l, (s + 1) & 15, lane);
+        if (vert) ab_s = grp_shfl(ab_l, (s + 1) & 15, lane);
+        const int x = xs < 0 ? -xs : xs;
+        const int qval = udiv_exact(x + (dq >> 1), dq, rcp);
+        int cnd = qval - ncand / 2 + k;
+        cnd = min(1023, max(-1023, cnd));
+        const int delta = mul24(cnd, dq) - x;
+        float dist = (float)mul24(delta, delta) * lambda_dc;
+        if (xs < 0) cnd = -cnd;
+        if (vert) {   // jcdctmgr.c:1069-1084
+          const int dc_above_orig = (int)(short)(ab & 0xFFFF), dc_above_recon = (ab >> 16) * dq;
+          const int d2 = (dc_above_orig - xs) - (dc_above_recon - cnd * dq);
+          const float vertical_dist = (float)(d2 * d2) * lambda_dc;
+          float t = vertical_dist - dist;
+          t = C.delta_dc_weight * t;
+          dist = dist + t;
+        }
+        float best;
+        int bb = 0;
+        if (bi == 0) {
+          const int df = cnd - last_dc;
+          const int bits = bitlen((unsigned)(df < 0 ? -df : df));
+          best = (float)(int)((rsi >> (5 * bits)) & 31) + dist;
+        } else {
+          float costs[9];
+#define DC2_EVAL(L)                                                                       \
+          {                                                                               \
+            const int df = cnd - row_bcast<L>(prev_c);                                    \
+            const int bits = bitlen((unsigned)(df < 0 ? -df : df));                       \
+            const float cost = (float)(int)((rsi >> (5 * bits)) & 31) + dist;             \
+            costs[L] = L < ncand ? cost + row_bcast_f<L>(prev_cost) : 3e38f;              \
+          }
+          DC2_EVAL(0) DC2_EVAL(1) DC2_EVAL(2) DC2_EVAL(3) DC2_EVAL(4) DC2_EVAL(5) DC2_EVAL(6) DC2_EVAL(7) DC2_EVAL(8)
+#undef DC2_EVAL
+          const float m = fminf(fminf(fminf(costs[0], costs[1]), fminf(costs[2], costs[3])), fminf(fminf(fminf(costs[4], costs[5]), fminf(costs[6], costs[7])), costs[8]));
+          // the first l that attains the minimum = what the reference's strict '<' scan in increasing l keeps (:1100-1106)
+          bb = 8;
+#pragma unroll
+          for (int l = 7; l >= 0; l--) bb = costs[l] == m ? l : bb;
+          best = m;
+        }
+        prev_c = cnd;
+        prev_cost = best;
+        bk[(size_t)(row0 + bi) * 16 + k] = (uint8_t)bb;
+      }
+      xs_l = xs_n; lam_l = lam_n; ab_l = ab_n;
+    }
+    // first minimum over the live candidates (:1309-1313)
+    int j = 0;
+    {
+      float bc = row_bcast_f<0>(prev_cost);
+#define DC2_LAST(L) { const float c = row_bcast_f<L>(prev_cost); if (L < ncand && c < bc) { bc = c; j = L; } }
+      DC2_LAST(1) DC2_LAST(2) DC2_LAST(3) DC2_LAST(4) DC2_LAST(5) DC2_LAST(6) DC2_LAST(7) DC2_LAST(8)
+#undef DC2_LAST
+    }
+    __threadfence_block();
+    // back-track, 16 blocks per step: lane k owns block top-k; the next 16 blocks' loads are issued before these are walked
+    auto fetch_back = [&](int top, int &xs_o, uint4 &w_o) {
+      const int b = top - k;
+      xs_o = 0; w_o = make_uint4(0, 0, 0, 0);
+      if (top >= 0 && b >= 0) {
+        xs_o = uq0[row0 + b];
+        w_o = *reinterpret_cast<const uint4 *>(bk + (size_t)(row0 + b) * 16);
+      }
+    };
+    int bx;
+    uint4 w;
+    fetch_back(cc.wib - 1, bx, w);
+    for (int top = cc.wib - 1; top >= 0; top -= 16) {
+      int bx_n;
+      uint4 w_n;
+      fetch_back(top - 16, bx_n, w_n);
+      const int b = top - k;
+      const int x = bx < 0 ? -bx : bx;
+      const int qv = udiv_exact(x + (dq >> 1), dq, rcp);
+      int myj = 0;
+      const int steps = min(16, top + 1);
+#define DC2_BACK(S)                                                                        \
+      if (S < steps) {                                                                     \
+        if (k == S) myj = j;                                                               \
+        const unsigned word = j < 4 ? w.x : (j < 8 ? w.y : w.z);                           \
+        const int nj = (int)((word >> (8 * (j & 3))) & 0xFF);                              \
+        j = row_bcast<S>(nj);                                                              \
+      }
+      DC2_BACK(0) DC2_BACK(1) DC2_BACK(2) DC2_BACK(3) DC2_BACK(4) DC2_BACK(5) DC2_BACK(6) DC2_BACK(7)
+      DC2_BACK(8) DC2_BACK(9) DC2_BACK(10) DC2_BACK(11) DC2_BACK(12) DC2_BACK(13) DC2_BACK(14) DC2_BACK(15)
+#undef DC2_BACK
+      if (b >= 0) {
+        int cnd = qv - ncand / 2 + myj;
+        cnd = min(1023, max(-1023, cnd));
+        if (bx < 0) cnd = -cnd;
+        qo0[row0 + b] = (int16_t)cnd;
+        if (b == cc.wib - 1) last_dc = cnd;
+      }
+      bx = bx_n; w = w_n;
+    }
+    last_dc = row_bcast<0>(last_dc);        // owner of block wib-1 is lane 0 of the first step
+    if (C.delta_dc_weight > 0.0f) __threadfence();   // the next sub-row reads this row's final DC values back (other lanes of the group)
+    else __threadfence_block();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6 v3: the transition costs through a sliding window.  Every kernel of this pipeline turned out to be bound by VALU
+// issue (~4 cycles per wave instruction), and the recursion above spends most of its instructions on 9 x 9 = 81
+// (difference -> category -> code length) evaluations per block, one per (candidate, predecessor) pair.  The candidates
+// of a block are CONSECUTIVE integers (qv - h + k, jcdctmgr.c:1054-1062; the clamp to +-1023 cannot bind when 8q >= 40),
+// so with the lanes of a group ordered by candidate VALUE (lane = k for a non-negative raw DC, ncand-1-k for a negative
+// one, whose candidates are negated) lane L holds the value c0 + L and the difference to the predecessor in lane M is
+// (c0 - c0_prev) + (L - M): 17 distinct differences per block instead of 81.  Lane j evaluates the rate of difference
+// number j+1 (number 0 is needed by one pair only and is evaluated by every lane), and the nine rates a lane needs are
+// its neighbours' values, fetched with DPP row shifts.  Costs are the same sums of the same floats, so the minimum is the
+// same; "first minimum in candidate order" (the reference's strict '<' scan over l) is the lowest or the highest lane of
+// the equality mask, depending on the orientation of the predecessor block.
+// Used when every DC quantizer step 8q is >= 40 and the vertical-gradient term is off; k_trellis_dc2 otherwise.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dc_rate(unsigned long long rsi, int n)
+{
+  const int a = n < 0 ? -n : n;
+  return (float)(int)((rsi >> (5 * bitlen((unsigned)a))) & 31);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_f(float old, float v)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
+__global__ void __launch_bounds__(64)
+k_trellis_dc3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
+              int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
+              int4 dc_slot_of_comp, const float *__restrict__ lambda_in, uint8_t *__restrict__ back)
+{
+  const int img = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int k = lane & 15;                      // lane in the group = rank of its candidate VALUE
+  const int chain = blockIdx.x * 4 + (lane >> 4);
+  const int nchains = C.ncomp * C.mcu_rows;
+  if (chain >= nchains) return;   // whole 16-lane groups (= DPP rows) leave together
+  const int comp = chain / C.mcu_rows, imcu = chain - comp * C.mcu_rows;
+  const MjhComp cc = C.c[comp];
+  const int slot = comp == 0 ? dc_slot_of_comp.x : comp == 1 ? dc_slot_of_comp.y : comp == 2 ? dc_slot_of_comp.z : dc_slot_of_comp.w;
+  const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+  unsigned long long rsi = 0;   // 12 x 5 bits: category + its code length
+  for (int s = 0; s < 12; s++) rsi |= (unsigned long long)((T->ehufsi[s] + s) & 31) << (5 * s);
+  const int q0 = Q->q[cc.qtbl][0];
+  const int dq = 8 * q0;
+  const float rcp = Q->rcp8q[cc.qtbl][0];
+  const float lt0 = Q->lambda_tbl[cc.qtbl][0];
+  int ncand = (2 + 60 / q0) | 1;                 // get_num_dc_trellis_candidates :930-933
+  if (ncand > 9) ncand = 9;
+  const int h = ncand / 2;
+  const bool vlane = k < ncand;
+  const int16_t *uq0 = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off;  // plane k = 0
+  int16_t *qo0 = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;
+  const float *lam = lambda_in + (size_t)img * C.total_real_blocks + cc.blk_off;
+  uint8_t *bk = back + ((size_t)img * C.total_real_blocks + cc.blk_off) * 16;
+  int last_dc = 0;
+  for (int sub = 0; sub < cc.v; sub++) {
+    const int br = imcu * cc.v + sub;
+    if (br >= cc.hib) break;
+    const int row0 = br * cc.wib;
+    int prev_c0 = 0, prev_neg = 0;
+    float prev_cost = 0.0f;
+    // per block, computed 16 blocks at a time (lane j: block g+j): |raw DC| | conventional quantized value << 16 | negative << 26,
+    // and lambda * (1 / q0^2)
+    auto fetch = [&](int b, unsigned &pk_o, float &lam_o) {
+      const int xs = b < cc.wib ? (int)uq0[row0 + b] : 0;
+      const float l = b < cc.wib ? lam[row0 + b] : 0.0f;
+      const int x = xs < 0 ? -xs : xs;
+      const int qv = udiv_exact(x + (dq >> 1), dq, rcp);
+      pk_o = (unsigned)x | ((unsigned)qv << 16) | (xs < 0 ? 1u << 26 : 0u);
+      lam_o = l * lt0;
+    };
+    unsigned pk_l;
+    float lam_l;
+    fetch(k, pk_l, lam_l);
+    for (int g = 0; g < cc.wib; g += 16) {
+      unsigned pk_n;
+      float lam_n;
+      fetch(g + 16 + k, pk_n, lam_n);          // the next 16 blocks: in flight while these 16 are walked
+      const int steps = min(16, cc.wib - g);
+      unsigned pk_s = (unsigned)grp_shfl((int)pk_l, 0, lane);
+      float lam_s = grp_shfl_f(lam_l, 0, lane);
+      for (int s = 0; s < steps; s++) {
+        const int bi = g + s;
+        const unsigned pk = pk_s;
+        const float lambda_dc = lam_s;
+        pk_s = (unsigned)grp_shfl((int)pk_l, (s + 1) & 15, lane);     // the next step's inputs (their LDS round trip hides behind this step)
+        lam_s = grp_shfl_f(lam_l, (s + 1) & 15, lane);
+        const int x = (int)(pk & 0xFFFFu), qv = (int)((pk >> 16) & 1023u), neg = (int)(pk >> 26);
+        const int kk = neg ? ncand - 1 - k : k;            // candidate index held by this lane
+        const int c0 = neg ? -(qv + h) : qv - h;           // value of lane 0's candidate; this lane's is c0 + k
+        const int delta = mul24(qv - h + kk, dq) - x;
+        const float dist = (float)mul24(delta, delta) * lambda_dc;
+        float best;
+        int bb = 0;
+        if (bi == 0) {
+          best = dc_rate(rsi, c0 + k - last_dc) + dist;
+        } else {
+          const int D = c0 - prev_c0;
+          const float Rj = dc_rate(rsi, D + k - 7), R0 = dc_rate(rsi, D - 8);
+          // predecessor in lane M: rate of difference number k - M + 8 = the value of lane k + 7 - M (number 0: R0)
+          const float c_0 = (dpp_f<0x107>(0.0f, Rj) + dist) + row_bcast_f<0>(prev_cost);
+          const float c_1 = (dpp_f<0x106>(0.0f, Rj) + dist) + row_bcast_f<1>(prev_cost);
+          const float c_2 = (dpp_f<0x105>(0.0f, Rj) + dist) + row_bcast_f<2>(prev_cost);
+          const float c_3 = (dpp_f<0x104>(0.0f, Rj) + dist) + row_bcast_f<3>(prev_cost);
+          const float c_4 = (dpp_f<0x103>(0.0f, Rj) + dist) + row_bcast_f<4>(prev_cost);
+          const float c_5 = (dpp_f<0x102>(0.0f, Rj) + dist) + row_bcast_f<5>(prev_cost);
+          const float c_6 = (dpp_f<0x101>(0.0f, Rj) + dist) + row_bcast_f<6>(prev_cost);
+          const float c_7 = (Rj + dist) + row_bcast_f<7>(prev_cost);
+          const float c_8 = (dpp_f<0x111>(R0, Rj) + dist) + row_bcast_f<8>(prev_cost);     // row_shr:1; lane 0 keeps R0
+          const float m = fminf(fminf(fminf(c_0, c_1), fminf(c_2, c_3)), fminf(fminf(fminf(c_4, c_5), fminf(c_6, c_7)), c_8));
+          // first minimum in CANDIDATE order of the predecessor (:1100-1106): lanes of invalid candidates hold 3e38
+          unsigned e = (c_0 == m ? 1u : 0u) | (c_1 == m ? 2u : 0u) | (c_2 == m ? 4u : 0u) | (c_3 == m ? 8u : 0u) | (c_4 == m ? 16u : 0u) |
+                       (c_5 == m ? 32u : 0u) | (c_6 == m ? 64u : 0u) | (c_7 == m ? 128u : 0u) | (c_8 == m ? 256u : 0u);
+          bb = prev_neg ? ncand - 1 - (31 - __clz((int)e)) : __ffs((int)e) - 1;
+          best = m;
+        }
+        prev_cost = vlane ? best : 3e38f;
+        prev_c0 = c0;
+        prev_neg = neg;
+        if (vlane) bk[(size_t)(row0 + bi) * 16 + kk] = (uint8_t)bb;
+      }
+      pk_l = pk_n; lam_l = lam_n;
+    }
+    // first minimum over the candidates of the last block, in candidate order (:1309-1313)
+    int j;
+    {
+      const float p0 = row_bcast_f<0>(prev_cost), p1 = row_bcast_f<1>(prev_cost), p2 = row_bcast_f<2>(prev_cost), p3 = row_bcast_f<3>(prev_cost),
+                  p4 = row_bcast_f<4>(prev_cost), p5 = row_bcast_f<5>(prev_cost), p6 = row_bcast_f<6>(prev_cost), p7 = row_bcast_f<7>(prev_cost),
+                  p8 = row_bcast_f<8>(prev_cost);
+      const float m = fminf(fminf(fminf(p0, p1), fminf(p2, p3)), fminf(fminf(fminf(p4, p5), fminf(p6, p7)), p8));
+      const unsigned e = (p0 == m ? 1u : 0u) | (p1 == m ? 2u : 0u) | (p2 == m ? 4u : 0u) | (p3 == m ? 8u : 0u) | (p4 == m ? 16u : 0u) |
+                         (p5 == m ? 32u : 0u) | (p6 == m ? 64u : 0u) | (p7 == m ? 128u : 0u) | (p8 == m ? 256u : 0u);
+      j = prev_neg ? ncand - 1 - (31 - __clz((int)e)) : __ffs((int)e) - 1;
+    }
+    __threadfence_block();
+    // back-track, 16 blocks per step: lane k owns block top-k; the next 16 blocks' loads are issued before these are walked
+    auto fetch_back = [&](int top, int &xs_o, uint4 &w_o) {
+      const int b = top - k;
+      xs_o = 0; w_o = make_uint4(0, 0, 0, 0);
+      if (top >= 0 && b >= 0) {
+        xs_o = uq0[row0 + b];
+        w_o = *reinterpret_cast<const uint4 *>(bk + (size_t)(row0 + b) * 16);
+      }
+    };
+    int bx;
+    uint4 w;
+    fetch_back(cc.wib - 1, bx, w);
+    for (int top = cc.wib - 1; top >= 0; top -= 16) {
+      int bx_n;
+      uint4 w_n;
+      fetch_back(top - 16, bx_n, w_n);
+      const int b = top - k;
+      const int x = bx < 0 ? -bx : bx;
+      const int qv = udiv_exact(x + (dq >> 1), dq, rcp);
+      int myj = 0;
+      const int steps = min(16, top + 1);
+#define DC3_BACK(S)                                                                        \
+      if (S < steps) {                                                                     \
+        if (k == S) myj = j;                                                               \
+        const unsigned word = j < 4 ? w.x : (j < 8 ? w.y : w.z);                           \
+        const int nj = (int)((word >> (8 * (j & 3))) & 0xFF);                              \
+        j = row_bcast<S>(nj);                                                              \
+      }
+      DC3_BACK(0) DC3_BACK(1) DC3_BACK(2) DC3_BACK(3) DC3_BACK(4) DC3_BACK(5) DC3_BACK(6) DC3_BACK(7)
+      DC3_BACK(8) DC3_BACK(9) DC3_BACK(10) DC3_BACK(11) DC3_BACK(12) DC3_BACK(13) DC3_BACK(14) DC3_BACK(15)
+#undef DC3_BACK
+      if (b >= 0) {
+        int cnd = qv - h + myj;
+        cnd = min(1023, max(-1023, cnd));
+        if (bx < 0) cnd = -cnd;
+        qo0[row0 + b] = (int16_t)cnd;
+        if (b == cc.wib - 1) last_dc = cnd;
+      }
+      bx = bx_n; w = w_n;
+    }
+    last_dc = row_bcast<0>(last_dc);        // owner of block wib-1 is lane 0 of the first step
+    __threadfence_block();
   }
 }
 
@@ -2790,11 +3144,17 @@ void mjh_launch_scan16(const void *len16, int n_per, unsigned *sums, int chunks,
   hipLaunchKernelGGL((k_offsets<uint16_t>), dim3(chunks, npairs), dim3(256), 0, s, (const uint16_t *)len16, n_per, sums, chunks, off32);
 }
 
-void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s)
+void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s,
+                           int window_ok)
 {
   const int nchains = C.ncomp * C.mcu_rows;
   dim3 grid((nchains + 3) / 4, n);
-  hipLaunchKernelGGL(k_trellis_dc, grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]), lambda, (uint8_t *)back);
+  const int v2 = window_ok >> 8;   // A/B runs (MJH_DC_V2, read by the encoder): 0 = the first (ds_bpermute) version, 2 = DPP without the window
+  window_ok &= 1;
+  if (v2 >= 1 && v2 != 2 && window_ok && C.delta_dc_weight <= 0.0f)
+    hipLaunchKernelGGL(k_trellis_dc3, grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]), lambda, (uint8_t *)back);
+  else if (v2) hipLaunchKernelGGL(k_trellis_dc2, grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]), lambda, (uint8_t *)back);
+  else hipLaunchKernelGGL(k_trellis_dc, grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]), lambda, (uint8_t *)back);
 }
 
 void mjh_launch_encode(const MjhConst &C, const void *q, const unsigned long long *nzmask, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const int ac_slot[4],

@@ -25,7 +25,9 @@ void mjh_launch_trellis_eob_chain(const MjhConst &C, void *q, const MjhHuffTable
 void mjh_launch_qopt_accumulate(const MjhConst &C, const void *uq, const void *q, void *sums, int n, hipStream_t s);
 void mjh_launch_qopt_update(void *sums, MjhQuant *Q, int n, hipStream_t s);   // Q: one MjhQuant per image
 void mjh_launch_qopt_patch(const MjhQuant *Q, void *out, size_t out_stride, const int dqt_off[4], const unsigned *sizes, int n, hipStream_t s);
-void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s);
+// window_ok: every component's DC quantizer step 8q is >= 40 (candidate values are then never clamped: the sliding-window kernel applies)
+void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s,
+                           int window_ok = 0);
 void mjh_launch_encode(const MjhConst &C, const void *q, const unsigned long long *nzmask, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const int ac_slot[4],
                        void *len16, void *off32, unsigned *sums, int chunks_per_image, unsigned *totals,
                        unsigned *stream, size_t stream_words_per_image, void *meta,
