@@ -169,7 +169,12 @@ const char *mjh_pool_last_error(const mjh_pool *pool);
 /* ---- encode ---------------------------------------------------------------------------- */
 /* Encode n images that are ALREADY in device memory (interleaved samples, row_pitch bytes per
  * row, image_stride bytes between images).  `stream` is a hipStream_t passed as void*
- * (NULL = the encoder's own stream).  Asynchronous: results are valid after
+ * (NULL = the encoder's own stream, which is NOT ordered behind the null stream; (void *)1 =
+ * the encoder's own stream, made to wait for everything queued on the null stream so far -- for
+ * pixels produced on the legacy default stream).  With MJH_SPLIT=n in the environment (off by
+ * default, sequential mode only) a batch is split into n image ranges that run concurrently on
+ * streams of the encoder, forked from and joined into `stream`.
+ * Asynchronous: results are valid after
  * mjh_encoder_sync() or any later synchronising call. */
 int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t row_pitch, size_t image_stride,
                       int n, void *stream);
@@ -262,6 +267,11 @@ int mjh_component_geometry(const mjh_encoder *e, int c, int *width_in_blocks, in
  * last read; mjh_get_kernel_times synchronises, returns the AVERAGE milliseconds per call and starts a new
  * accumulation (names/ms arrays are owned by the encoder; *count entries). */
 int mjh_set_profiling(mjh_encoder *e, int level);
+/* Which interval level 2 brackets: a name returned by mjh_get_kernel_times (normally the largest entry of a level-1
+ * pass over the same workload, so that "dominant" is measured, not assumed); NULL or "" = the built-in choice.  Takes
+ * effect with the next mjh_set_profiling call.  When a batch runs as concurrent image ranges (mjh_encode_device), a
+ * kernel's time per call is the sum of its launches over the ranges. */
+int mjh_set_profiling_focus(mjh_encoder *e, const char *name);
 int mjh_get_kernel_times(mjh_encoder *e, const char *const **names, const float **ms, int *count);
 
 const char *mjh_last_error(void);

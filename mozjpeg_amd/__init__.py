@@ -107,6 +107,7 @@ def lib():
                                             C.POINTER(C.c_void_p)]
         L.mjh_set_debug_taps.argtypes = [C.c_void_p, C.c_int]
         L.mjh_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.mjh_set_profiling_focus.argtypes = [C.c_void_p, C.c_char_p]
         L.mjh_read_tap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                    C.POINTER(C.c_size_t)]
         L.mjh_component_geometry.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_int)] * 4
@@ -310,7 +311,10 @@ class Encoder:
             tuple(t.shape), p.image_height, p.image_width, px)
         assert 1 <= t.shape[0] <= self.max_batch
         if stream is None:
-            stream = torch.cuda.current_stream(t.device).cuda_stream or None
+            # the torch stream current on t's device; torch's default stream has handle 0, which the C ABI reads as "the
+            # encoder's own stream" -- 1 asks for that stream too, but ordered behind everything queued on the null stream
+            # so far, i.e. behind whatever produced `t` there
+            stream = torch.cuda.current_stream(t.device).cuda_stream or 1
         elif stream == "own":
             stream = None
         self.encode_device_ptr(t.data_ptr(), t.stride(1) * es, t.stride(0) * es, t.shape[0], stream)
@@ -383,7 +387,10 @@ class Encoder:
     def set_debug_taps(self, on=True):
         _chk(lib().mjh_set_debug_taps(self._h, int(on)))
 
-    def set_profiling(self, on=True):
+    def set_profiling(self, on=True, focus=None):
+        """0 off, 1 every kernel, 2 only the interval `focus` (a name out of kernel_times(); None = keep the current choice)"""
+        if focus is not None:
+            _chk(lib().mjh_set_profiling_focus(self._h, focus.encode()))
         _chk(lib().mjh_set_profiling(self._h, int(on)))
 
     def geometry(self, c):

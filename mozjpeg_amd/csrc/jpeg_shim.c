@@ -600,7 +600,10 @@ void jpeg_finish_compress(j_compress_ptr cinfo)
   }
   /* the device wrote a complete file; SOI(+APP0) went out in jpeg_start_compress already */
   {
-    const size_t skip = (size_t)(2 + (cinfo->write_JFIF_header ? 18 : 0) + (cinfo->write_Adobe_marker ? 16 : 0));
+    /* what the DEVICE wrote in front of DQT: SOI, APP0 when asked for, and always an Adobe APP14 for RGB output (build_prefix);
+     * the markers the application asked for went out from the cinfo flags in jpeg_start_compress (an application may clear
+     * write_Adobe_marker for JCS_RGB, which the reference honours: the device's APP14 is dropped all the same) */
+    const size_t skip = (size_t)(2 + (cinfo->write_JFIF_header ? 18 : 0) + (cinfo->jpeg_color_space == JCS_RGB ? 16 : 0));
     emit_bytes(cinfo, file + skip, n - skip);
   }
   free(copy);

@@ -17,6 +17,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <memory>
 #include <vector>
 
 #include "../../include/mozjpeg_hip.h"
@@ -36,6 +37,8 @@ static int fail(int code, const char *fmt, ...)
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MJH_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
 extern "C" const char *mjh_last_error(void) { return g_err; }
+// (for mjh_pool.cpp, which is otherwise built on the public ABI: lets its argument checks leave a message too)
+int mjh_internal_fail(int code, const char *msg) { return fail(code, "%s", msg); }
 extern "C" const char *mjh_version(void) { return "mozjpeg_hip 0.2 (gfx950)"; }
 extern "C" int mjh_device_count(void)
 {
@@ -319,6 +322,7 @@ struct mjh_encoder {
   // encode calls since the last read (prof_calls), every call records the same sequence of marks.
   int profiling = 0;
   const char *prof_focus = "trellis_ac";
+  std::string prof_focus_name;      // mjh_set_profiling_focus: the caller's choice (normally the largest entry of a level-1 breakdown)
   int prof_calls = 0;
   size_t prof_per_call = 0;
   std::vector<hipEvent_t> side_events;   // 2 per call: the DC trellis on the side stream
@@ -330,6 +334,16 @@ struct mjh_encoder {
   bool sizes_valid = false;
   bool coef_input = false;         // last batch came in through mjh_encode_coefficients_*: d_meta[].bad_coef is meaningful
   hipStream_t last_stream = nullptr;   // the stream the last batch was queued on (mjh_encoder_sync waits for it)
+  // Sub-batches (mjh_encode_device, sequential mode): VIEWS of this encoder over consecutive image ranges -- copies of this
+  // struct whose per-image pointers are advanced to the range's first image, each with its own streams / events / work
+  // lists -- so that the kernels of one range overlap the tails and the differently bound kernels of the others
+  // (measured before with three whole encoders in flight: 6.85 -> 6.04 ms per 64 4K frames).  The parent keeps every buffer
+  // at full size: every other entry point and all result accessors see one contiguous batch.
+  std::vector<mjh_encoder *> views;
+  std::vector<hipStream_t> pad_streams;
+  bool is_view = false, last_split = false;
+  int view_off = 0;
+  hipEvent_t ev_view_done = nullptr, ev_split_fork = nullptr, ev_null_in = nullptr;
 };
 
 static long div_round_up(long a, long b) { return (a + b - 1) / b; }
@@ -631,10 +645,27 @@ static void fill_std_table(MjhHuffTable *T, const uint8_t *bits, const uint8_t *
   }
 }
 
+static void free_view(mjh_encoder *v)
+{
+  for (hipEvent_t ev : v->prof_events) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : v->side_events) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : { v->ev_fork, v->ev_join, v->ev_view_done }) if (ev) (void)hipEventDestroy(ev);
+  if (v->h_defer) (void)hipHostFree(v->h_defer);
+  if (v->side_stream) (void)hipStreamDestroy(v->side_stream);
+  if (v->stream) (void)hipStreamDestroy(v->stream);
+  delete v;
+}
+
 static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
+  for (mjh_encoder *v : e->views) free_view(v);
+  e->views.clear();
+  for (hipStream_t d : e->pad_streams) (void)hipStreamDestroy(d);
+  e->pad_streams.clear();
+  if (e->ev_split_fork) (void)hipEventDestroy(e->ev_split_fork);
+  if (e->ev_null_in) (void)hipEventDestroy(e->ev_null_in);
   void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_nq8, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
@@ -662,6 +693,82 @@ static void free_all(mjh_encoder *e)
 extern "C" void mjh_encoder_destroy(mjh_encoder *e) { free_all(e); }
 
 #define HIPCHK_E(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { int rc_ = fail(MJH_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); free_all(e); return rc_; } } while (0)
+
+// views of `e` over S consecutive image ranges (see struct mjh_encoder): per-image pointers advanced, own execution resources
+static int make_views(mjh_encoder *e, int S)
+{
+  const MjhConst &C = e->C;
+  const mjh_params &p = e->p;
+  const size_t B = (size_t)e->max_batch, Bs = (B + S - 1) / S;
+  const size_t bps = C.precision == 12 ? 2 : 1, trb = (size_t)C.total_real_blocks, tmb = (size_t)C.total_mcu_blocks, ns = (size_t)e->nseg;
+  const unsigned dense_each = e->dense_cap / (unsigned)S;
+  HIPCHK(hipEventCreateWithFlags(&e->ev_split_fork, hipEventDisableTiming));
+  if (const char *pad = getenv("MJH_STREAM_PAD"))   // experiment: shift the stream -> hardware queue assignment of the views
+    for (int i = 0; i < atoi(pad); i++) { hipStream_t d; HIPCHK(hipStreamCreateWithFlags(&d, hipStreamNonBlocking)); e->pad_streams.push_back(d); }
+  for (int k = 0; k < S; k++) {
+    const size_t off = (size_t)k * Bs;
+    if (off >= B) break;
+    mjh_encoder *v = new mjh_encoder(*e);
+    e->views.push_back(v);
+    v->views.clear();
+    v->pad_streams.clear();
+    v->is_view = true;
+    v->view_off = (int)off;
+    v->max_batch = (int)(B - off < Bs ? B - off : Bs);
+    // execution resources of its own (everything host-path related stays with the parent and is never used through a view)
+    v->stream = v->side_stream = v->copy_stream = v->d2h_stream = nullptr;
+    v->copy_done = v->ev_fork = v->ev_join = v->ev_side0 = v->ev_side1 = v->ev_view_done = v->ev_split_fork = v->ev_null_in = nullptr;
+    for (int b = 0; b < 2; b++) { v->ev_h2d[b] = v->ev_pix_free[b] = v->ev_packed[b] = nullptr; v->d_pixb[b] = nullptr; v->h_stage[b] = v->h_res[b] = nullptr; v->h_tab[b] = nullptr; }
+    v->h_defer = nullptr;
+    v->prof_events.clear(); v->side_events.clear(); v->prof_names.clear(); v->prof_cnames.clear(); v->prof_ms.clear();
+    v->prof_calls = 0; v->prof_per_call = 0; v->profiling = 0;
+    HIPCHK(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&v->side_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&v->ev_view_done, hipEventDisableTiming));
+    HIPCHK(hipHostMalloc((void **)&v->h_defer, 64, hipHostMallocDefault));
+    v->h_defer[0] = 0xFFFFFFFFu;
+    // HIP multiplexes streams onto a handful of hardware queues (4 by default): with a main and a side stream per view, three
+    // views already collide there and serialise falsely (measured: 2 views 5.81 ms, 3 views 6.67 ms per 64 4K frames).  From
+    // three views on, a view keeps to ONE stream -- its DC trellis runs in line, the overlap comes from the other views
+    { const char *sd = getenv("MJH_SPLIT_DC"); if (sd ? atoi(sd) != 0 : S >= 3) v->dc_mode = 1; }
+    // per-image arrays: advanced to the view's first image
+    v->d_planes += off * C.planes_per_image * bps;
+    v->d_uq += off * C.coefs_per_image;
+    v->d_q += off * C.coefs_per_image;
+    v->d_q0 = nullptr;                                   // (debug taps: the encode then runs unsplit)
+    if (p.trellis_quant && p.trellis_q_opt) v->d_quant += off;
+    v->d_tabs += off * e->spi;
+    v->d_tabs_init += off * e->spi;
+    v->d_lambda += off * trb;
+    v->d_back += off * trb * 16;
+    v->d_worklist += (k * 16 + off * trb * 12) / 4;      // a work list of its own (entries hold image numbers relative to the view)
+    v->d_worklist2 += (k * 16 + off * trb * 12) / 4;
+    if (v->d_eob_cost) v->d_eob_cost = (uint8_t *)v->d_eob_cost + off * trb * 8;
+    if (v->d_eob_has) v->d_eob_has += off * trb;
+    if (v->d_qsums) v->d_qsums += off * 4 * 64 * 2;
+    if (v->d_nzmask) v->d_nzmask += off * trb;
+    if (v->d_nq8) v->d_nq8 += off * trb;
+    if (v->d_dense) { v->d_dense += (size_t)k * dense_each * 64; v->dense_cap = dense_each; }
+    v->d_len16 += off * tmb;
+    v->d_off32 += off * tmb;
+    v->d_sums += off * e->chunks;
+    v->d_ffsums += off * e->ff_chunks;
+    v->d_totals += off;
+    v->d_fftotals += off;
+    v->d_stream += off * e->stream_words;
+    v->d_out += off * e->out_stride;
+    v->d_sizes += off;
+    v->d_seg_x += off * ns;
+    v->d_seg_E += off * ns;
+    v->d_mpos += off * ns;
+    v->d_seg_sums += off * ((ns + 2047) / 2048);
+    v->d_seg_totals += off;
+    v->d_meta = (uint8_t *)v->d_meta + off * sizeof(MjhImageMeta);
+  }
+  return MJH_OK;
+}
 
 extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device, mjh_encoder **out)
 {
@@ -706,8 +813,8 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   HIPCHK_E(hipMalloc((void **)&e->d_tabs_init, B * e->spi * sizeof(MjhHuffTable)));
   HIPCHK_E(hipMalloc((void **)&e->d_lambda, B * C.total_real_blocks * sizeof(float)));
   HIPCHK_E(hipMalloc((void **)&e->d_back, B * (size_t)C.total_real_blocks * 16));
-  HIPCHK_E(hipMalloc((void **)&e->d_worklist, 16 + B * (size_t)C.total_real_blocks * 12));
-  HIPCHK_E(hipMalloc((void **)&e->d_worklist2, 16 + B * (size_t)C.total_real_blocks * 12));
+  HIPCHK_E(hipMalloc((void **)&e->d_worklist, 256 + B * (size_t)C.total_real_blocks * 12));   // (+ one 16-byte header per view)
+  HIPCHK_E(hipMalloc((void **)&e->d_worklist2, 256 + B * (size_t)C.total_real_blocks * 12));
   if (p->trellis_quant && p->trellis_eob_opt) {
     HIPCHK_E(hipMalloc(&e->d_eob_cost, B * (size_t)C.total_real_blocks * 8));
     HIPCHK_E(hipMalloc((void **)&e->d_eob_has, B * (size_t)C.total_real_blocks * 4));
@@ -977,6 +1084,21 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     e->outpool_bytes = (size_t)1280 * (p->num_scans + 1) + 8 * e->pool_words;
     HIPCHK_E(hipMalloc((void **)&e->d_pool, B * e->pool_words * 4 + 4096));   // slack: a bit writer may touch two words past its last offset
     HIPCHK_E(hipMalloc((void **)&e->d_outpool, B * e->outpool_bytes));
+  }
+  {
+    // sub-batches of the device entry (sequential mode): MJH_SPLIT ranges
+    // OFF by default.  Measured on 64 4K frames (profiles/r03e_split_*.log): one range 5.97-6.10 ms whatever else the
+    // process did; two ranges 5.72-5.83 ms OR 6.66-6.90 ms for the very same code, decided by which hardware queues the
+    // runtime happens to map the views' streams to (the result flips with the number of streams created before them,
+    // period 4 = the runtime's hardware-queue count); three and more ranges lose either way.  A 4 % gain that turns into a
+    // 13 % loss by luck is not a default: MJH_SPLIT=2 opts in.
+    int S = 1;
+    if (const char *v = getenv("MJH_SPLIT")) S = atoi(v);
+    if (S > 8) S = 8;
+    if (S > 1 && !e->progressive && max_batch >= 2 * S) {
+      rc = make_views(e, S);
+      if (rc) { free_all(e); return rc; }
+    }
   }
   HIPCHK_E(hipDeviceSynchronize());
   *out = e;
@@ -1288,6 +1410,14 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
 
 extern "C" const mjh_params *mjh_encoder_params(const mjh_encoder *e) { return e ? &e->p : nullptr; }
 
+// An entry other than mjh_encode_host behind a mjh_encode_host call: that batch's files may still be on their way out of
+// the (single) output buffers on the D2H stream -- nothing of the new batch may run before they have left
+static int wait_pending_pack(mjh_encoder *e, hipStream_t s)
+{
+  if (e->res_buf >= 0 && !e->res_waited[e->res_buf]) HIPCHK(hipStreamWaitEvent(s, e->ev_packed[e->res_buf], 0));
+  return MJH_OK;
+}
+
 extern "C" int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t row_pitch, size_t image_stride, int n, void *stream)
 {
   if (!e || !d_pixels || n < 1 || n > e->max_batch) return fail(MJH_EINVAL, "bad arguments (n=%d, max_batch=%d)", n, e ? e->max_batch : 0);
@@ -1297,7 +1427,36 @@ extern "C" int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t ro
       return fail(MJH_EINVAL, "row_pitch %zu / image_stride %zu too small for %dx%d images of %zu-byte rows", row_pitch, image_stride, e->C.W, e->C.H, row_bytes);
   }
   HIPCHK(hipSetDevice(e->device));
-  return run_pipeline(e, d_pixels, row_pitch, image_stride, n, stream ? (hipStream_t)stream : e->stream);
+  hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+  if (stream == (void *)1) {
+    // "behind the null stream": the encoder's own (non-blocking) stream does not synchronise with the legacy default stream
+    // by itself -- an event recorded there now orders the encode behind everything queued on it so far
+    if (!e->ev_null_in) HIPCHK(hipEventCreateWithFlags(&e->ev_null_in, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e->ev_null_in, nullptr));
+    s = e->stream;
+    HIPCHK(hipStreamWaitEvent(s, e->ev_null_in, 0));
+  }
+  e->last_split = false;
+  { const int rcw = wait_pending_pack(e, s); if (rcw) return rcw; }
+  if (e->views.size() > 1 && !e->debug_taps && n > e->views[0]->max_batch) {
+    // sub-batches: every view runs the whole schedule for its range on its own streams, forked from and joined into `s`
+    HIPCHK(hipEventRecord(e->ev_split_fork, s));
+    for (mjh_encoder *v : e->views) {
+      const int nk = n - v->view_off < v->max_batch ? n - v->view_off : v->max_batch;
+      if (nk <= 0) break;
+      v->profiling = e->profiling;
+      HIPCHK(hipStreamWaitEvent(v->stream, e->ev_split_fork, 0));
+      const int rc = run_pipeline(v, (const uint8_t *)d_pixels + (size_t)v->view_off * image_stride, row_pitch, image_stride, nk, v->stream);
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(v->ev_view_done, v->stream));
+      HIPCHK(hipStreamWaitEvent(s, v->ev_view_done, 0));
+    }
+    e->sizes_valid = false; e->last_n = n; e->res_buf = -1; e->coef_input = false; e->last_stream = s;
+    e->compact_last = e->views[0]->compact_last;
+    e->last_split = true;
+    return MJH_OK;
+  }
+  return run_pipeline(e, d_pixels, row_pitch, image_stride, n, s);
 }
 
 // ---- host entry: pixels in host memory -> JPEG files in host memory ----------------------------------
@@ -1317,17 +1476,27 @@ class CopyPool {
     if (njobs <= 0) return;
     if (nthreads_ <= 1 || njobs == 1) { for (int i = 0; i < njobs; i++) fn(i); return; }
     std::unique_lock<std::mutex> big(submit_);   // one batch of jobs at a time
+    // a batch is an object of its own: a worker that still holds the previous batch only ever sees THAT batch's
+    // (exhausted) counters, whatever the job counts of consecutive batches are
+    auto job = std::make_shared<Job>();
+    job->fn = &fn; job->njobs = njobs;
     {
       std::lock_guard<std::mutex> lk(m_);
-      fn_ = &fn; njobs_ = njobs; next_.store(0); done_ = 0; gen_++;
+      cur_ = job;
+      gen_++;
     }
     cv_.notify_all();
-    work();
+    work(*job);
     std::unique_lock<std::mutex> lk(m_);
-    cv_done_.wait(lk, [&] { return done_ == njobs_; });
-    fn_ = nullptr;
+    cv_done_.wait(lk, [&] { return job->done == job->njobs; });
+    cur_.reset();      // (fn dies with the caller's frame: nobody may start a job of this batch any more -- next is exhausted)
   }
  private:
+  struct Job {
+    const std::function<void(int)> *fn = nullptr;
+    int njobs = 0, done = 0;          // done: under m_
+    std::atomic<int> next{ 0 };
+  };
   CopyPool()
   {
     int n = 0;
@@ -1337,33 +1506,34 @@ class CopyPool {
     nthreads_ = n;
     for (int i = 1; i < n; i++) std::thread([this] { loop(); }).detach();
   }
-  void work()
+  void work(Job &job)
   {
     for (;;) {
-      const int i = next_.fetch_add(1);
-      if (i >= njobs_) break;
-      (*fn_)(i);
+      const int i = job.next.fetch_add(1);
+      if (i >= job.njobs) break;
+      (*job.fn)(i);
       std::lock_guard<std::mutex> lk(m_);
-      if (++done_ == njobs_) cv_done_.notify_all();
+      if (++job.done == job.njobs) cv_done_.notify_all();
     }
   }
   void loop()
   {
     unsigned long seen = 0;
     for (;;) {
+      std::shared_ptr<Job> job;
       {
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [&] { return gen_ != seen; });
         seen = gen_;
+        job = cur_;
       }
-      work();
+      if (job) work(*job);
     }
   }
   std::mutex m_, submit_;
   std::condition_variable cv_, cv_done_;
-  const std::function<void(int)> *fn_ = nullptr;
-  int njobs_ = 0, done_ = 0, nthreads_ = 1;
-  std::atomic<int> next_{ 0 };
+  std::shared_ptr<Job> cur_;
+  int nthreads_ = 1;
   unsigned long gen_ = 0;
 };
 }  // namespace
@@ -1438,6 +1608,9 @@ extern "C" int mjh_encode_host(mjh_encoder *e, const void *pixels, size_t row_pi
   HIPCHK(hipSetDevice(e->device));
   const size_t row_bytes = (size_t)e->C.W * e->C.px_size * (e->C.precision == 12 ? 2 : 1);
   if (row_pitch < row_bytes) return fail(MJH_EINVAL, "row_pitch %zu is smaller than a row (%zu bytes)", row_pitch, row_bytes);
+  if (n > 1 && image_stride < row_pitch * (size_t)(e->C.H - 1) + row_bytes)
+    return fail(MJH_EINVAL, "image_stride %zu is smaller than one image (%zu bytes): images would overlap", image_stride, row_pitch * (size_t)(e->C.H - 1) + row_bytes);
+  e->last_split = false;
   int rc = host_buffers(e);
   if (rc) return rc;
   const int b = (int)(e->host_calls++ & 1u);
@@ -1561,6 +1734,8 @@ extern "C" int mjh_encode_coefficients_device(mjh_encoder *e, const void *const 
     cs.base[c] = d_coefs[c]; cs.blocks_per_row[c] = (long long)blocks_per_row[c];
     cs.stride[c] = image_stride ? (long long)image_stride[c] : 0;
   }
+  { const int rcw = wait_pending_pack(e, stream ? (hipStream_t)stream : e->stream); if (rcw) return rcw; }
+  e->last_split = false;
   return run_pipeline(e, nullptr, 0, 0, n, stream ? (hipStream_t)stream : e->stream, nullptr, &cs);
 }
 
@@ -1593,6 +1768,8 @@ extern "C" int mjh_encode_coefficients_host(mjh_encoder *e, const void *const co
   MjhCoefSrc cs;
   memset(&cs, 0, sizeof(cs));
   for (int c = 0; c < e->C.ncomp; c++) { cs.base[c] = e->d_cfin + off[c]; cs.blocks_per_row[c] = e->C.c[c].wib; cs.stride[c] = (long long)per_image; }
+  { const int rcw = wait_pending_pack(e, e->stream); if (rcw) return rcw; }
+  e->last_split = false;
   return run_pipeline(e, nullptr, 0, 0, n, e->stream, nullptr, &cs);
 }
 
@@ -1622,6 +1799,8 @@ extern "C" int mjh_encode_planes_device(mjh_encoder *e, const void *const d_plan
     ps.base[c] = d_planes[c]; ps.pitch[c] = (long long)row_pitch[c]; ps.stride[c] = image_stride ? (long long)image_stride[c] : 0;
     ps.w[c] = plane_width[c]; ps.h[c] = plane_height[c];
   }
+  { const int rcw = wait_pending_pack(e, stream ? (hipStream_t)stream : e->stream); if (rcw) return rcw; }
+  e->last_split = false;
   return run_pipeline(e, nullptr, 0, 0, n, stream ? (hipStream_t)stream : e->stream, &ps);
 }
 
@@ -1662,6 +1841,8 @@ extern "C" int mjh_encode_planes_host(mjh_encoder *e, const void *const planes[M
   HIPCHK(hipEventRecord(e->copy_done, e->copy_stream));
   HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done, 0));
   for (int c = 0; c < e->C.ncomp; c++) { ps.base[c] = e->d_plin + off[c]; ps.stride[c] = (long long)per_image; }
+  { const int rcw = wait_pending_pack(e, e->stream); if (rcw) return rcw; }
+  e->last_split = false;
   return run_pipeline(e, nullptr, 0, 0, n, e->stream, &ps);
 }
 
@@ -1752,15 +1933,59 @@ extern "C" int mjh_set_profiling(mjh_encoder *e, int on)
   if (on < 0 || on > 2) return fail(MJH_EINVAL, "profiling level must be 0, 1 or 2");
   e->profiling = on;
   e->prof_calls = 0;
-  e->prof_focus = e->p.trellis_quant && !e->progressive ? "trellis_ac" : "dct_quant";
+  if (e->prof_focus_name.empty()) e->prof_focus = e->p.trellis_quant && !e->progressive ? "trellis_ac" : "dct_quant";
+  else e->prof_focus = e->prof_focus_name.c_str();
+  for (mjh_encoder *v : e->views) { v->profiling = on; v->prof_calls = 0; v->prof_focus = e->prof_focus; }
   return MJH_OK;
 }
+
+// which interval of the schedule profiling level 2 brackets: a name out of mjh_get_kernel_times (e.g. the largest entry of a
+// level-1 pass over the same workload); NULL or "" = the built-in choice.  Takes effect with the next mjh_set_profiling.
+extern "C" int mjh_set_profiling_focus(mjh_encoder *e, const char *name)
+{
+  if (!e) return fail(MJH_EINVAL, "null encoder");
+  e->prof_focus_name = name ? name : "";
+  return MJH_OK;
+}
+
+static int kernel_times_one(mjh_encoder *e);
 
 extern "C" int mjh_get_kernel_times(mjh_encoder *e, const char *const **names, const float **ms, int *count)
 {
   if (!e || !count) return fail(MJH_EINVAL, "bad arguments");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipDeviceSynchronize());
+  if (e->last_split) {
+    // the batch ran as sub-batches: a kernel's time per encode call = the sum of its launches over the ranges (the ranges
+    // run concurrently, so these are durations of launches that share the device, not a breakdown of the wall time)
+    e->prof_cnames.clear(); e->prof_ms.clear(); e->prof_names.clear();
+    for (mjh_encoder *v : e->views) {
+      if (v->prof_calls == 0) continue;
+      const int rc = kernel_times_one(v);
+      if (rc) return rc;
+      for (size_t i = 0; i < v->prof_cnames.size(); i++) {
+        size_t j = 0;
+        while (j < e->prof_names.size() && e->prof_names[j] != v->prof_cnames[i]) j++;
+        if (j == e->prof_names.size()) { e->prof_names.push_back(v->prof_cnames[i]); e->prof_ms.push_back(0.f); }
+        e->prof_ms[j] += v->prof_ms[i];
+      }
+    }
+    for (const std::string &nm : e->prof_names) e->prof_cnames.push_back(nm.c_str());
+    if (names) *names = e->prof_cnames.data();
+    if (ms) *ms = e->prof_ms.data();
+    *count = (int)e->prof_cnames.size();
+    return MJH_OK;
+  }
+  const int rc = kernel_times_one(e);
+  if (rc) return rc;
+  if (names) *names = e->prof_cnames.data();
+  if (ms) *ms = e->prof_ms.data();
+  *count = (int)e->prof_cnames.size();
+  return MJH_OK;
+}
+
+static int kernel_times_one(mjh_encoder *e)
+{
   const size_t n = e->prof_names.size();
   const int calls = e->prof_calls;
   e->prof_ms.assign(n, 0.f);
@@ -1786,9 +2011,6 @@ extern "C" int mjh_get_kernel_times(mjh_encoder *e, const char *const **names, c
     e->prof_ms.push_back(sum / (float)calls);
   }
   e->prof_calls = 0;   // the next encode call starts a new accumulation
-  if (names) *names = e->prof_cnames.data();
-  if (ms) *ms = e->prof_ms.data();
-  *count = (int)e->prof_cnames.size();
   return MJH_OK;
 }
 

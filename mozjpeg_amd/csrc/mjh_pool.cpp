@@ -15,6 +15,8 @@
 
 #include "../../include/mozjpeg_hip.h"
 
+int mjh_internal_fail(int code, const char *msg);   // mjh_encoder.cpp: sets mjh_last_error()
+
 struct mjh_pool {
   std::vector<mjh_encoder *> enc;
   std::vector<int> dev;
@@ -27,11 +29,11 @@ struct mjh_pool {
 
 extern "C" int mjh_pool_create(const mjh_params *p, int max_batch_per_device, const int *devices, int ndevices, mjh_pool **out)
 {
-  if (!p || !out || max_batch_per_device < 1) return MJH_EINVAL;
+  if (!p || !out || max_batch_per_device < 1) return mjh_internal_fail(MJH_EINVAL, "mjh_pool_create: bad arguments");
   std::vector<int> devs;
   if (devices && ndevices > 0) devs.assign(devices, devices + ndevices);
   else { const int n = mjh_device_count(); for (int i = 0; i < n; i++) devs.push_back(i); }
-  if (devs.empty()) return MJH_EHIP;
+  if (devs.empty()) return mjh_internal_fail(MJH_EHIP, "mjh_pool_create: no HIP device available (libmozjpeg_hip has no CPU fallback)");
   mjh_pool *pl = new mjh_pool;
   pl->max_batch = max_batch_per_device;
   for (int d : devs) {
@@ -71,7 +73,7 @@ void run_share(mjh_pool *pl, int d, const uint8_t *pixels, size_t row_pitch, siz
     const void *base; const mjh_result *res; int cnt = 0;
     const int rc = mjh_collect(e, age, &base, &res, &cnt);
     if (rc != MJH_OK) return rc;
-    if (cnt != count) return MJH_EINVAL;
+    if (cnt != count) return mjh_internal_fail(MJH_EINVAL, "pool: a batch came back with a different number of files than was queued");
     for (int i = 0; i < cnt; i++) {
       sh->off[first + i] = st.size(); sh->len[first + i] = (size_t)res[i].size;
       st.insert(st.end(), (const uint8_t *)base + res[i].offset, (const uint8_t *)base + res[i].offset + res[i].size);
@@ -106,10 +108,14 @@ void run_share(mjh_pool *pl, int d, const uint8_t *pixels, size_t row_pitch, siz
 extern "C" int mjh_pool_encode_host(mjh_pool *pl, const void *pixels, size_t row_pitch, size_t image_stride, int n,
                                     const uint8_t *const **jpegs, const size_t **sizes)
 {
-  if (!pl || !pixels || n < 1 || !jpegs || !sizes) return MJH_EINVAL;
+  if (!pl || !pixels || n < 1 || !jpegs || !sizes) return mjh_internal_fail(MJH_EINVAL, "mjh_pool_encode_host: bad arguments");
   const mjh_params *p = mjh_encoder_params(pl->enc[0]);
   const size_t row_bytes = (size_t)p->image_width * (p->input_components == 1 ? 1 : (p->input_pixel_size ? p->input_pixel_size : 3)) * (p->data_precision == 12 ? 2 : 1);
-  if (row_pitch < row_bytes) { pl->error = "row_pitch smaller than one row"; return MJH_EINVAL; }
+  if (row_pitch < row_bytes) { pl->error = "row_pitch smaller than one row"; return mjh_internal_fail(MJH_EINVAL, pl->error.c_str()); }
+  if (n > 1 && image_stride < row_pitch * (size_t)(p->image_height - 1) + row_bytes) {
+    pl->error = "image_stride smaller than one image: images would overlap";
+    return mjh_internal_fail(MJH_EINVAL, pl->error.c_str());
+  }
   const int nd = (int)pl->enc.size();
   std::vector<Share> shares(nd);
   for (int i = 0; i < n; i++) shares[i % nd].images.push_back(i);

@@ -97,6 +97,32 @@ def test_device_resident_input_via_torch_tensor():
         assert enc.get_jpeg(i) == O.encode(po, frames[i])
 
 
+def test_tensor_encode_is_ordered_behind_the_default_stream_producer():
+    """encode_tensor(stream=None) straight behind a producer on torch's default (null) stream, no synchronize in between:
+    the encode has to see the finished pixels (the null stream has handle 0, which the ABI reads as "own stream"; the
+    binding passes hipStreamLegacy instead)"""
+    import torch
+    w, h = 1920, 1080
+    kw = dict(quality=75, baseline=True)
+    frames = np.stack([O.synthetic_frame(w, h, 40 + i) for i in range(4)])
+    want = [O.encode(O.make_params(w, h, **kw), f) for f in frames]
+    src = torch.from_numpy(frames).cuda()
+    enc = M.Encoder(M.make_params(w, h, **kw), max_batch=4)
+    t = torch.zeros_like(src)
+    a = torch.randn(4096, 4096, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(3):
+        for _ in range(20):
+            a = (a @ a).clamp_(-1, 1)          # ~tens of ms of work queued on the default stream ...
+        t.copy_(src)                           # ... then the pixels, still queued behind it
+        enc.encode_tensor(t)                   # no synchronize: must be ordered behind the copy
+        enc.sync()
+        assert [enc.get_jpeg(i) for i in range(4)] == want
+        t.zero_()
+        torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 def test_jpeg_structure_properties():
     """size-independent properties: SOI/EOI, marker walk, no unstuffed 0xFF in the scan"""
     w, h = 1024, 768

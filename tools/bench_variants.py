@@ -22,6 +22,7 @@ if __name__ == "__main__":
     ap.add_argument("--variants", default="0,6")
     ap.add_argument("--env", default="MJH_TRELLIS_VARIANT")
     ap.add_argument("--config", default="metric")
+    ap.add_argument("--prof", type=int, default=0, help="profiling level inside the timed loop (0 off, 2 = the dominant interval bracketed)")
     a = ap.parse_args()
     cfg = bench.CONFIGS[a.config]
     w, h, kw = cfg["w"], cfg["h"], cfg["kw"]
@@ -35,7 +36,7 @@ if __name__ == "__main__":
         files = [enc.get_jpeg(i) for i in range(a.batch)]
         if base is None:
             base = files
-        enc.set_profiling(0)
+        enc.set_profiling(a.prof)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
