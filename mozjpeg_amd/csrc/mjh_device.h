@@ -22,6 +22,12 @@ __device__ __forceinline__ int udiv_exact(int n, int d, float rcp)
 }
 
 
+// exact floor(n / d) for 0 <= n < 2^16 through the per-entry constants of MjhQuant (mdiv, sdiv): one shift + one 24-bit multiply-high
+__device__ __forceinline__ int udiv_mh(int n, int sh, unsigned m)
+{
+  return (int)__umulhi(((unsigned)n << sh) & 0xFFFFFFu, m & 0xFFFFFFu);
+}
+
 __device__ __forceinline__ int dc_source_block(const MjhComp &cc, int r, int c)
 {
   if (r >= cc.hib) { c = (c / cc.h) * cc.h + cc.h - 1; r = cc.hib - 1; }

@@ -272,6 +272,7 @@ struct mjh_encoder {
   // the values live in the AC planes of d_q, plane i+1 = i-th non-zero.  compact_last: the last batch's d_q is in that form
   unsigned long long *d_nzmask = nullptr; bool use_compact = false, compact_last = false;
   uint8_t *d_nq8 = nullptr;          // per block: non-zero conventionally quantized AC coefficients (FDCT kernel) = tile-sort key of the AC trellis
+  int fastdiv_all = 0;               // every table in use has q <= 255: the kernels divide by 8q with one multiply-high (MjhQuant.mdiv)
   int dc_mode = 0;
   int dc_window_ok = 0;              // every component's DC quantizer step 8q >= 40: the DC trellis may use its sliding-window kernel
   int trellis_v3 = 4;                // passes per tile of the tile-sorted first tier (MJH_TRELLIS_V3; 0 = the general kernel)
@@ -722,8 +723,18 @@ static int make_views(mjh_encoder *e, int S)
     v->h_defer = nullptr;
     v->prof_events.clear(); v->side_events.clear(); v->prof_names.clear(); v->prof_cnames.clear(); v->prof_ms.clear();
     v->prof_calls = 0; v->prof_per_call = 0; v->profiling = 0;
-    HIPCHK(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&v->side_stream, hipStreamNonBlocking));
+    {
+      // odd views get streams of the least priority (MJH_SPLIT_PRIO: 0 = default priority everywhere, 1 = greatest instead):
+      // the runtime keeps one pool of hardware queues per priority, so those streams cannot land on the queues of the
+      // other views' streams
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      const char *pe = getenv("MJH_SPLIT_PRIO");
+      const int mode = pe ? atoi(pe) : 2;
+      const int prio = (mode == 1 && (k & 1)) ? hi : (mode == 2 && (k & 1)) ? lo : 0;
+      HIPCHK(hipStreamCreateWithPriority(&v->stream, hipStreamNonBlocking, prio));
+      HIPCHK(hipStreamCreateWithPriority(&v->side_stream, hipStreamNonBlocking, prio));
+    }
     HIPCHK(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&v->ev_view_done, hipEventDisableTiming));
@@ -890,7 +901,22 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       hq.dq8[t][k] = 8 * q;
       hq.rcp8q[t][k] = 1.0f / (float)(8 * q);
       hq.lambda_tbl[t][k] = (float)(1.0 / (double)(q * q));   // jcdctmgr.c:1017-1021
+      if (q <= 255) {
+        const unsigned d = 8u * (unsigned)q;
+        int b = 0;
+        while ((d >> b) != 0) b++;
+        const int kk = 22 + b < 32 ? 22 + b : 32;
+        hq.mdiv[t][k] = (uint32_t)((1ull << kk) / d + 1ull);
+        hq.sdiv[t][k] = 32 - kk;
+      }
     }
+  e->fastdiv_all = 1;
+  for (int t = 0; t < 4; t++) {
+    hq.fastdiv[t] = 1;
+    for (int k = 0; k < 64; k++) if (hq.q[t][k] > 255) hq.fastdiv[t] = 0;
+  }
+  for (int i = 0; i < C.ncomp; i++) if (!hq.fastdiv[p->quant_tbl_no[i]]) e->fastdiv_all = 0;
+  if (const char *v = getenv("MJH_FASTDIV")) if (atoi(v) == 0) e->fastdiv_all = 0;   // A/B runs
   HIPCHK_E(hipMemcpy(e->d_quant, &hq, sizeof(hq), hipMemcpyHostToDevice));
   HIPCHK_E(hipMemcpy(e->d_quant_init, &hq, sizeof(hq), hipMemcpyHostToDevice));
 
@@ -1087,12 +1113,14 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   }
   {
     // sub-batches of the device entry (sequential mode): MJH_SPLIT ranges
-    // OFF by default.  Measured on 64 4K frames (profiles/r03e_split_*.log): one range 5.97-6.10 ms whatever else the
-    // process did; two ranges 5.72-5.83 ms OR 6.66-6.90 ms for the very same code, decided by which hardware queues the
-    // runtime happens to map the views' streams to (the result flips with the number of streams created before them,
-    // period 4 = the runtime's hardware-queue count); three and more ranges lose either way.  A 4 % gain that turns into a
-    // 13 % loss by luck is not a default: MJH_SPLIT=2 opts in.
-    int S = 1;
+    // Two ranges by default for batches of 16 and more.  Which hardware queues the runtime maps the views' streams to decides
+    // whether the ranges really overlap: with every stream at the default priority the same code ran 64 4K frames in
+    // 5.72-5.83 ms OR 6.66-6.90 ms, flipping with the number of streams the process had created before (period 4 = the
+    // runtime's queue count; one range: 5.97-6.10 ms; three and more ranges lose either way).  The runtime keeps a separate
+    // pool of hardware queues per stream priority, so the second view's streams are created at the LEAST priority: its
+    // queues are then its own whatever else exists (measured: 5.15-5.22 ms for the first and for later encoders of a
+    // process, against 5.43 unsplit on the same tree; profiles/r03e_split_*.log, r03f_split_priority.log).
+    int S = max_batch >= 16 ? 2 : 1;
     if (const char *v = getenv("MJH_SPLIT")) S = atoi(v);
     if (S > 8) S = 8;
     if (S > 1 && !e->progressive && max_batch >= 2 * S) {
@@ -1191,7 +1219,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   const bool fuse_fin = fuse_seq && (e->fuse_mask & 2) && nbands == 1 && !ext_eob;
   if (!coef_src) {
     pr.mark("dct_quant");
-    mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, e->d_nq8, n, s);
+    mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, e->d_nq8, n, s, e->fastdiv_all);
   }
 
   if (e->progressive) {
@@ -1276,7 +1304,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     mjh_launch_trellis_ac(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap,
                           fuse_fin && p.optimize_coding && last_loop ? fin_ac : nullptr, e->trellis_variant,
                           Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, nzm, qstride, n, s,
-                          e->d_nq8, fuse_fin ? 0 : e->trellis_v3);
+                          e->d_nq8, fuse_fin ? 0 : e->trellis_v3, e->fastdiv_all);
     if (e->trellis_adapt && !extended && first_pass) {
       e->h_defer[1] = (unsigned)n;
       HIPCHK(hipMemcpyAsync(&e->h_defer[0], e->d_worklist, sizeof(unsigned), hipMemcpyDeviceToHost, s));

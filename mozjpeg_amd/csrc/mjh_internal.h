@@ -85,6 +85,13 @@ struct MjhQuant {
   int dq8[4][64];           // 8*q as a 32-bit word: wave-uniform reads become scalar loads (no 16-bit s_load)
   float rcp8q[4][64];       // 1.0f / (8*q) for the exact-division helper
   float lambda_tbl[4][64];  // (float)(1.0 / (q*q)), zig-zag order (jcdctmgr.c:1017-1021)
+  // exact division by 8q through ONE multiply-high (tables with every q <= 255 only: fastdiv[t] != 0):
+  // floor(n / 8q) == ((n << sdiv) * mdiv) >> 32 for 0 <= n < 2^16, with k = min(32, 22 + bitlen(8q)), mdiv = floor(2^k / 8q) + 1
+  // (< 2^24), sdiv = 32 - k (n << sdiv < 2^24: the full-rate 24-bit multiply-high applies); checked exhaustively for every
+  // q in 1..255 (tools/check_fastdiv.py)
+  uint32_t mdiv[4][64];
+  int sdiv[4][64];
+  int fastdiv[4];
 };
 
 // per-image bookkeeping written by the encode kernels

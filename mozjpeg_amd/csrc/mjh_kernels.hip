@@ -13,6 +13,7 @@
 // Reference behaviour each kernel reproduces is cited as file:line under /root/reference.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include <stdlib.h>
 #include "mjh_internal.h"
 #include "mjh_device.h"
@@ -353,14 +354,23 @@ __device__ __forceinline__ float catmull_rom(int v1, int v2, int v3, int v4, flo
 //    of by a k_stats_ac pass that re-reads all 63 planes;
 //    and, because the AC trellis recomputes every AC coefficient from coef_uq, the 63 quantized AC planes this kernel
 //    would write are then never read: only plane 0 (DC statistics / DC trellis) is stored.
-template <class T, bool STATS>   // uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
+// FD: every quantizer step of the tables in use fits 8 bits -- the division by 8q is one shift + one 24-bit multiply-high
+// (MjhQuant.mdiv / sdiv) instead of the float-reciprocal division with its integer fix-up; with STATS the AC coefficients are
+// quantized for the statistics only, which need the magnitude category and nothing else (no sign, no signed clamp).
+template <class T, bool STATS, bool FD = false>   // uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
 __global__ void __launch_bounds__(64)
 k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ planes,
             int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
             MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out)
 {
   constexpr bool W12 = sizeof(T) == 2;
-  __shared__ int lds[64][64];
+  // 8 KB per wave: the deringing columns (16-bit: level-shifted samples and overshoot values are small for 8-bit data; 12-bit
+  // data keeps 32-bit columns) and, afterwards, 8 interleaved copies of the 256-bin statistics histogram
+  constexpr int LW = W12 ? 64 : 32;
+  __shared__ int lds_raw[64][LW];
+  typedef typename std::conditional<W12, int, short>::type dcol_t;
+  typedef dcol_t __attribute__((may_alias)) dcol_alias;
+  dcol_alias (*lds)[64] = reinterpret_cast<dcol_alias (*)[64]>(&lds_raw[0][0]);
   const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
   const int lane = threadIdx.x;
@@ -398,7 +408,7 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
     for (int i = 0; i < 64; i++) { sum += d[i]; cnt += (d[i] >= maxsample); }
     if (cnt != 0 && cnt != 64) {
 #pragma unroll
-      for (int i = 0; i < 64; i++) lds[i][lane] = d[i];
+      for (int i = 0; i < 64; i++) lds[i][lane] = (dcol_t)d[i];
       const int q0 = qz[0];
       const int a = min(31, 2 * q0);
       const int b = (maxsample * 64 - sum) / cnt;   // C division truncates toward zero: negative for 12-bit data (T9)
@@ -422,7 +432,7 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
         float position = step;
         for (int i = start; i < end; i++, position += step) {
           const int tmp = (int)ceilf(catmull_rom(maxsample - fslope, maxsample, maxsample, maxsample - lslope, position, length));
-          lds[d_zz[i]][lane] = min(tmp, maxovershoot);
+          lds[d_zz[i]][lane] = (dcol_t)min(tmp, maxovershoot);
         }
         n++;
       } while (n < 64);
@@ -455,20 +465,38 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
   int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
   const bool clampq = C.deringing != 0;
   constexpr bool stats = STATS;
-  unsigned *hist = reinterpret_cast<unsigned *>(&lds[0][0]);   // 16 interleaved copies of 256 bins (the deringing columns are dead)
+  typedef unsigned __attribute__((may_alias)) hist_alias;
+  constexpr int NCOPY = W12 ? 16 : 8;
+  hist_alias *hist = reinterpret_cast<hist_alias *>(&lds_raw[0][0]);   // NCOPY interleaved copies of 256 bins (the deringing columns are dead)
   if (stats) {
 #pragma unroll
-    for (int j = 0; j < 64; j++) hist[j * 64 + lane] = 0u;
+    for (int j = 0; j < NCOPY * 4; j++) hist[j * 64 + lane] = 0u;
     __syncthreads();
   }
-  unsigned *hh = hist + (lane & 15) * 256;
+  hist_alias *hh = hist + (lane & (NCOPY - 1)) * 256;
   int run = 0, nzc = 0;   // nzc: non-zero quantized AC coefficients = the AC trellis' queue length (its tile-sort key)
 #pragma unroll
   for (int k = 0; k < 64; k++) {
     const int x = d[kZZ.v[k]];
     const int dq = Q->dq8[cc.qtbl][k];
     const int ax = x < 0 ? -x : x;
-    int v = udiv_exact(ax + (dq >> 1), dq, rcp[k]);
+    if (FD && STATS && k > 0) {
+      // statistics of the conventionally quantized block only (the trellis recomputes the values): magnitude category of
+      // min(floor((|x| + 4q) / 8q), 1023) -- the signed clamp to +-1023 (jcdctmgr.c:761-770) leaves the category of 1023
+      uq[(size_t)k * cc.kstride] = (int16_t)x;
+      if (valid) {
+        if (ax + (dq >> 1) >= dq) {
+          int qa = udiv_mh(ax + (dq >> 1), Q->sdiv[cc.qtbl][k], Q->mdiv[cc.qtbl][k]);
+          if (clampq) qa = min(qa, 1023);
+          nzc++;
+          if (run > 15) { atomicAdd(&hh[0xF0], (unsigned)(run >> 4)); run &= 15; }
+          atomicAdd(&hh[(run << 4) + bitlen((unsigned)qa)], 1u);
+          run = 0;
+        } else run++;
+      }
+      continue;
+    }
+    int v = FD ? udiv_mh(ax + (dq >> 1), Q->sdiv[cc.qtbl][k], Q->mdiv[cc.qtbl][k]) : udiv_exact(ax + (dq >> 1), dq, rcp[k]);
     if (x < 0) v = -v;
     if (clampq) v = W12 ? max(-16383, min(16383, v)) : max(-1023, min(1023, v));
     if (!W12) uq[(size_t)k * cc.kstride] = (int16_t)x;   // raw x8 coefficients only feed the (8-bit only) trellis
@@ -496,7 +524,7 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
       const int bin = lane + 64 * j;
       unsigned sum = 0;
 #pragma unroll
-      for (int c2 = 0; c2 < 16; c2++) sum += hist[c2 * 256 + bin];
+      for (int c2 = 0; c2 < NCOPY; c2++) sum += hist[c2 * 256 + bin];
       if (sum) atomicAdd(&T2->counts[bin], sum);
     }
   }
@@ -1451,6 +1479,12 @@ k_qopt_update(long long *__restrict__ sums, MjhQuant *__restrict__ Q)
   Qi->dq8[t][k] = 8 * q;
   Qi->rcp8q[t][k] = 1.0f / (float)(8 * q);
   Qi->lambda_tbl[t][k] = (float)(1.0 / (double)(q * q));
+  {   // (q <= 254: the multiply-high constants exist)
+    const unsigned dd = 8u * (unsigned)q;
+    const int kk = min(32, 22 + bitlen(dd));
+    Qi->mdiv[t][k] = (uint32_t)((1ull << kk) / dd + 1ull);
+    Qi->sdiv[t][k] = 32 - kk;
+  }
 }
 
 // the image's final tables -> the DQT bytes of its file (8-bit tables: one byte per entry at dqt_off[table] + k, zig-zag
@@ -1721,7 +1755,7 @@ __device__ __forceinline__ void v3_pair(const uint2 (*col)[64], const unsigned s
   gap_old = gap_b;
 }
 
-template <int QN, int NPASS>
+template <int QN, int NPASS, bool FD>
 __global__ void __launch_bounds__(64)
 k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q,
                 const MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 ac_slot_of_comp, int4 tile0_of_comp,
@@ -1817,10 +1851,11 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
         t = t * lt[k];
         const float azd_cur = t + azd;
         if (x + (dq >> 1) >= dq) {
-          int qval = udiv_exact(x + (dq >> 1), dq, rcp[k]);
+          int qval = FD ? udiv_mh(x + (dq >> 1), Q->sdiv[cc.qtbl][k], Q->mdiv[cc.qtbl][k]) : udiv_exact(x + (dq >> 1), dq, rcp[k]);
           if (qval >= 1024) qval = 1023;
           qmax = qval > qmax ? qval : qmax;
-          if (nq < QN) col[nq][lane] = make_uint2((unsigned)k | (xsg < 0 ? 64u : 0u) | ((unsigned)qval << 7) | ((unsigned)x << 17), __float_as_uint(azd));
+          // (a block with more than QN records is deferred: what its surplus records overwrite in the last slot is never read)
+          col[nq < QN ? nq : QN - 1][lane] = make_uint2((unsigned)k | (xsg < 0 ? 64u : 0u) | ((unsigned)qval << 7) | ((unsigned)x << 17), __float_as_uint(azd));
           nq++;
         }
         azd = azd_cur;
@@ -2739,6 +2774,173 @@ k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const unsigned long 
   bw.flush();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Bit writer, second form: the workgroup's window.  k_enc_write above ORs every finished 32-bit word of every block
+// straight into HBM with a memory-side atomic (measured: 635 MB of "write traffic" per 64 4K frames for a 53 MB stream, 84 %
+// of the wave time waiting).  Here the threads of a workgroup take 256 CONSECUTIVE positions of the scan (MCU order), so
+// the workgroup owns one contiguous bit range [offset of its first block, offset of the next workgroup's first block):
+// the range is assembled in LDS (ds_or, 16 KB window = 512 bits per block on average) and leaves as coalesced word stores;
+// only the two boundary words, shared with the neighbouring workgroups, are ORed into memory.  A range that does not fit
+// the window (possible in principle: 1665 bits per block worst case) takes the direct path, workgroup by workgroup.
+// Same bits at the same offsets: the stream is identical.
+// ---------------------------------------------------------------------------------------------
+#define ENCW_WIN 4096
+template <bool LDSW>   // (two instantiations so that the window's words become ds_or and the direct path's global atomics)
+struct BitSink {
+  unsigned *words;
+  unsigned long long acc;
+  int nacc;
+  unsigned widx;
+  __device__ __forceinline__ void init(unsigned *w, unsigned bitoff) { words = w; widx = bitoff >> 5; nacc = (int)(bitoff & 31); acc = 0; }
+  __device__ __forceinline__ void put(unsigned code, int n)
+  {
+    acc = (acc << n) | (unsigned long long)(code & ((1u << n) - 1u));
+    nacc += n;
+    if (nacc >= 32) {
+      const unsigned w = (unsigned)(acc >> (nacc - 32));
+      atomicOr(&words[widx], __builtin_bswap32(w));
+      widx++;
+      nacc -= 32;
+    }
+  }
+  __device__ __forceinline__ void flush()
+  {
+    if (nacc > 0) atomicOr(&words[widx], __builtin_bswap32((unsigned)(acc << (32 - nacc))));
+  }
+  __device__ __forceinline__ unsigned bitpos() const { return widx * 32u + (unsigned)nacc; }
+};
+
+template <bool COMPACT, class W>
+__device__ __forceinline__ void enc_write_block(const MjhConst &C, const MjhComp &cc, W &bw, const unsigned *s_ac, const unsigned *s_dc,
+                                                const int16_t *__restrict__ q, const unsigned long long *__restrict__ nzmask_img, int r, int c)
+{
+  const int dc = q[dc_source_block(cc, r, c)];
+  int pr, pc, pred = 0;
+  if (mcu_prev_block(C, cc, r, c, pr, pc)) pred = q[dc_source_block(cc, pr, pc)];
+  {
+    const int df = dc - pred;
+    const int a = df < 0 ? -df : df;
+    const int nb = bitlen((unsigned)a);
+    const unsigned e = s_dc[nb];
+    bw.put(e & 0xFFFF, (int)(e >> 16));
+    if (nb) bw.put((unsigned)(df < 0 ? df - 1 : df), nb);
+  }
+  const bool real = r < cc.hib && c < cc.wib;
+  const int b = real ? r * cc.wib + c : 0;
+  if (COMPACT) {
+    const unsigned long long m = nzmask_img[cc.blk_off + b];
+    int prev = 0;
+    for_each_nonzero(q + b, (size_t)cc.kstride, m, real, [&](int pos, int v) {
+      int run = pos - prev - 1;
+      prev = pos;
+      while (run > 15) { const unsigned e = s_ac[0xF0]; bw.put(e & 0xFFFF, (int)(e >> 16)); run -= 16; }
+      const int a = v < 0 ? -v : v;
+      const int nbv = bitlen((unsigned)a);
+      const unsigned e = s_ac[(run << 4) + nbv];
+      bw.put(e & 0xFFFF, (int)(e >> 16));
+      bw.put((unsigned)(v < 0 ? v - 1 : v), nbv);
+    });
+    if (!real || prev < 63) { const unsigned e = s_ac[0]; bw.put(e & 0xFFFF, (int)(e >> 16)); }
+  } else {
+    int x[64];
+#pragma unroll
+    for (int k = 1; k < 64; k++) x[k] = q[(size_t)k * cc.kstride + b];
+    if (real) {
+      int run = 0;
+#pragma unroll
+      for (int k = 1; k < 64; k++) {
+        const int v = x[k];
+        if (v == 0) run++;
+        else {
+          while (run > 15) { const unsigned e = s_ac[0xF0]; bw.put(e & 0xFFFF, (int)(e >> 16)); run -= 16; }
+          const int a = v < 0 ? -v : v;
+          const int nb = bitlen((unsigned)a);
+          const unsigned e = s_ac[(run << 4) + nb];
+          bw.put(e & 0xFFFF, (int)(e >> 16));
+          bw.put((unsigned)(v < 0 ? v - 1 : v), nb);
+          run = 0;
+        }
+      }
+      if (run > 0) { const unsigned e = s_ac[0]; bw.put(e & 0xFFFF, (int)(e >> 16)); }
+    } else {
+      const unsigned e = s_ac[0];
+      bw.put(e & 0xFFFF, (int)(e >> 16));
+    }
+  }
+}
+
+template <bool COMPACT>
+__global__ void __launch_bounds__(256)
+k_enc_write_mcu(MjhConst C, const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask, const MjhHuffTable *__restrict__ tabs,
+                int slots_per_image, int4 dc_slot_of_comp, int4 ac_slot_of_comp,
+                const unsigned *__restrict__ off32, unsigned *__restrict__ stream, size_t stream_words_per_image,
+                const unsigned *__restrict__ totals, const unsigned *__restrict__ seg_E, const unsigned *__restrict__ seg_totals,
+                unsigned *__restrict__ mpos, int nseg)
+{
+  __shared__ unsigned s_ac[MJH_MAXC][256];   // size << 16 | code, per component
+  __shared__ unsigned s_dc[MJH_MAXC][32];
+  __shared__ unsigned s_win[ENCW_WIN];
+  const int img = blockIdx.y, tid = threadIdx.x;
+  const int N = C.total_mcu_blocks, base = blockIdx.x * 256;
+  if (totals[img] == 0xFFFFFFFFu) return;     // scan beyond the 32-bit offset range: reported by k_finish_bits
+  for (int ci = 0; ci < C.ncomp; ci++) {
+    const int dslot = ci == 0 ? dc_slot_of_comp.x : ci == 1 ? dc_slot_of_comp.y : ci == 2 ? dc_slot_of_comp.z : dc_slot_of_comp.w;
+    const int aslot = ci == 0 ? ac_slot_of_comp.x : ci == 1 ? ac_slot_of_comp.y : ci == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
+    const MjhHuffTable *TD = tabs + (size_t)img * slots_per_image + dslot;
+    const MjhHuffTable *TA = tabs + (size_t)img * slots_per_image + aslot;
+    s_ac[ci][tid] = ((unsigned)TA->ehufsi[tid] << 16) | TA->ehufco[tid];
+    if (tid < 32) s_dc[ci][tid] = tid < 16 ? ((unsigned)TD->ehufsi[tid] << 16) | TD->ehufco[tid] : 0u;
+  }
+  // final bit offset of scan position p (restart intervals shift everything behind them by their pad + marker bits)
+  auto final_off = [&](int p) -> unsigned {
+    if (p >= N) return totals[img] + (nseg > 1 ? seg_totals[img] : 0u);
+    const int mcu = p / C.blocks_per_mcu;
+    return off32[(size_t)img * N + p] + (nseg > 1 ? seg_E[(size_t)img * nseg + mcu / C.restart_interval] : 0u);
+  };
+  const unsigned start = final_off(base), end = final_off(min(base + 256, N));
+  const unsigned w0 = start >> 5, nw = ((end + 31u) >> 5) - w0;
+  const bool window = nw <= (unsigned)ENCW_WIN;
+  if (window) for (unsigned i = tid; i < nw; i += 256) s_win[i] = 0u;
+  __syncthreads();
+  unsigned *g = stream + (size_t)img * stream_words_per_image;
+  const int p = base + tid;
+  if (p < N) {
+    const int mcu = p / C.blocks_per_mcu, bi = p - mcu * C.blocks_per_mcu;
+    int comp = 0;
+    for (int ci = 1; ci < C.ncomp; ci++) if (bi >= C.c[ci].mcu_blk0) comp = ci;
+    const MjhComp cc = C.c[comp];
+    const int local = bi - cc.mcu_blk0, yi = local / cc.h, xi = local - yi * cc.h;
+    const int mrow = mcu / C.mcus_per_row, mcol = mcu - mrow * C.mcus_per_row;
+    const int r = mrow * cc.v + yi, c = mcol * cc.h + xi;
+    const int16_t *q = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;
+    const unsigned long long *nzi = COMPACT ? nzmask + (size_t)img * C.total_real_blocks : nullptr;
+    const unsigned fo = final_off(p);
+    const int segi = C.restart_interval ? mcu / C.restart_interval : 0;
+    const bool seg_end = C.restart_interval && segi < nseg - 1 && (mcu + 1) % C.restart_interval == 0 && bi == C.blocks_per_mcu - 1;
+    auto emit = [&](auto &bw, unsigned wbase) {     // wbase: bit position of word 0 of the sink
+      enc_write_block<COMPACT>(C, cc, bw, s_ac[comp], s_dc[comp], q, nzi, r, c);
+      if (seg_end) {   // last block of a restart interval: pad with 1-bits, then RSTn (emit_restart jchuff.c:668-686)
+        const unsigned bitpos = bw.bitpos() + wbase;
+        const int pad = (int)((8u - (bitpos & 7u)) & 7u);
+        if (pad) bw.put((1u << pad) - 1u, pad);
+        mpos[(size_t)img * nseg + segi] = (bitpos + (unsigned)pad) >> 3;
+        bw.put(0xFFD0u + (unsigned)(segi & 7), 16);
+      }
+      bw.flush();
+    };
+    if (window) { BitSink<true> bw; bw.init(s_win, fo - (w0 << 5)); emit(bw, w0 << 5); }
+    else { BitSink<false> bw; bw.init(g, fo); emit(bw, 0u); }
+  }
+  __syncthreads();
+  if (window)
+    for (unsigned i = tid; i < nw; i += 256) {
+      const unsigned v = s_win[i];
+      if (v == 0u) continue;                        // (k_zero_stream has cleared the range)
+      if (i == 0u || i == nw - 1u) atomicOr(&g[w0 + i], v);   // shared with the neighbouring workgroup
+      else g[w0 + i] = v;
+    }
+}
+
 // zero exactly the words the entropy coder is going to OR its bits into (the buffer itself is sized for the
 // worst case of 1665 bits per block; clearing all of it would cost more HBM traffic than the whole encode)
 __global__ void __launch_bounds__(256)
@@ -3023,12 +3225,14 @@ static int max_nblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp;
 static int max_padblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp; i++) { int v = C.c[i].wpad * C.c[i].hpad; m = v > m ? v : m; } return m; }
 
 void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
-                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s)
+                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv)
 {
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
   const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
   if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t, false>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
+  else if (stat_tabs && fastdiv) hipLaunchKernelGGL((k_dct_quant<uint8_t, true, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else if (stat_tabs) hipLaunchKernelGGL((k_dct_quant<uint8_t, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
+  else if (fastdiv) hipLaunchKernelGGL((k_dct_quant<uint8_t, false, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else hipLaunchKernelGGL((k_dct_quant<uint8_t, false>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
 }
 
@@ -3068,7 +3272,7 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
-                           const uint8_t *nq8, int v3_passes)
+                           const uint8_t *nq8, int v3_passes, int fastdiv)
 {
   // band-limited pass (use_scans_in_trellis), the per-block outputs of trellis_eob_opt, per-image tables (trellis_q_opt):
   // the EXT instantiations
@@ -3101,14 +3305,15 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   if (nzmask && nq8 && v3_passes > 0 && variant == 0) {
     // the tile-sorted kernel: first tier of the plain compact pass; its work list (more than 16 records, or a magnitude >= 16)
     // goes through the general tiers below
-    const int np = v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
+    const int np = !fastdiv ? 4 : v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
     int t0[5] = { 0, 0, 0, 0, 0 };
     for (int i = 0; i < 4; i++) t0[i + 1] = t0[i] + (i < C.ncomp ? (C.c[i].nblk + 64 * np - 1) / (64 * np) : 0);
     dim3 gridt(t0[C.ncomp], n);
     for (int i = C.ncomp; i < 4; i++) t0[i] = 0x7FFFFFFF;
     const int4 tv = make_int4(t0[0], t0[1], t0[2], t0[3]);
-#define LV3(NP) hipLaunchKernelGGL((k_trellis_ac_v3<16, NP>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask)
-    switch (np) { case 8: LV3(8); break; case 4: LV3(4); break; case 2: LV3(2); break; default: LV3(1); break; }
+#define LV3(NP) hipLaunchKernelGGL((k_trellis_ac_v3<16, NP, true>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask)
+    if (!fastdiv) hipLaunchKernelGGL((k_trellis_ac_v3<16, 4, false>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask);
+    else switch (np) { case 8: LV3(8); break; case 4: LV3(4); break; case 2: LV3(2); break; default: LV3(1); break; }
 #undef LV3
     hipLaunchKernelGGL((k_trellis_ac_qd<32, false, false, true>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
                        (const unsigned *)worklist, worklist2, (const int16_t *)dense, dense_cap, st, ss, ext);
@@ -3181,7 +3386,14 @@ void mjh_launch_encode(const MjhConst &C, const void *q, const unsigned long lon
   }
   hipLaunchKernelGGL(k_zero_stream, dim3(64, n), dim3(256), 0, s, stream, stream_words_per_image, (const unsigned *)totals,
                      rst ? (const unsigned *)seg_totals : (const unsigned *)nullptr);
-  if (nzmask) hipLaunchKernelGGL((k_enc_write<true>), grid, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image,
+  const int encw = getenv("MJH_ENCW") ? atoi(getenv("MJH_ENCW")) : 1;   // 0: the direct (one memory atomic per word) writer, for A/B runs
+  if (encw) {
+    dim3 gridm((C.total_mcu_blocks + 255) / 256, n);
+    if (nzmask) hipLaunchKernelGGL((k_enc_write_mcu<true>), gridm, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image,
+                                   (const unsigned *)totals, (const unsigned *)seg_E, (const unsigned *)seg_totals, mpos, rst ? nseg : 1);
+    else hipLaunchKernelGGL((k_enc_write_mcu<false>), gridm, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image,
+                            (const unsigned *)totals, (const unsigned *)seg_E, (const unsigned *)seg_totals, mpos, rst ? nseg : 1);
+  } else if (nzmask) hipLaunchKernelGGL((k_enc_write<true>), grid, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image,
                                  (const unsigned *)seg_E, mpos, rst ? nseg : 1);
   else hipLaunchKernelGGL((k_enc_write<false>), grid, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image,
                           (const unsigned *)seg_E, mpos, rst ? nseg : 1);
