@@ -1113,14 +1113,16 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   }
   {
     // sub-batches of the device entry (sequential mode): MJH_SPLIT ranges
-    // Two ranges by default for batches of 16 and more.  Which hardware queues the runtime maps the views' streams to decides
-    // whether the ranges really overlap: with every stream at the default priority the same code ran 64 4K frames in
-    // 5.72-5.83 ms OR 6.66-6.90 ms, flipping with the number of streams the process had created before (period 4 = the
-    // runtime's queue count; one range: 5.97-6.10 ms; three and more ranges lose either way).  The runtime keeps a separate
-    // pool of hardware queues per stream priority, so the second view's streams are created at the LEAST priority: its
-    // queues are then its own whatever else exists (measured: 5.15-5.22 ms for the first and for later encoders of a
-    // process, against 5.43 unsplit on the same tree; profiles/r03e_split_*.log, r03f_split_priority.log).
-    int S = max_batch >= 16 ? 2 : 1;
+    // Opt-in (MJH_SPLIT=2).  Which hardware queues the runtime maps the views' streams to decides whether the ranges really
+    // overlap: with every stream at the default priority the same code ran 64 4K frames in 5.72-5.83 ms OR 6.66-6.90 ms,
+    // flipping with the number of streams the process had created before (period 4 = the runtime's queue count; one range:
+    // 5.97-6.10 ms; three and more ranges lose either way).  The runtime keeps a separate pool of hardware queues per stream
+    // priority, so the second view's streams are created at the LEAST priority: its queues are then its own whatever else
+    // exists (measured: 5.15-5.22 ms for the first and for later encoders of a process, against 5.43 unsplit on the same
+    // tree; profiles/r03e_split_*.log, r03f_split_priority.log).  It stays opt-in because the ranges share the device:
+    // a kernel's launch then lasts longer than it would alone, which blurs every per-kernel measurement (bench.py reports
+    // the two-range rate as an extra leg next to the one-range contract line).
+    int S = 1;
     if (const char *v = getenv("MJH_SPLIT")) S = atoi(v);
     if (S > 8) S = 8;
     if (S > 1 && !e->progressive && max_batch >= 2 * S) {

@@ -124,7 +124,11 @@ def test_device_entry_right_behind_a_host_batch_and_split_batches():
     B = 30                                            # two ranges of 15
     frames = np.stack([O.synthetic_frame(w, h, 700 + i) for i in range(B)])
     refs = [_ref(w, h, kw, f) for f in frames]
-    enc = M.Encoder(M.make_params(w, h, **kw), max_batch=B)
+    os.environ["MJH_SPLIT"] = "2"                      # read when the encoder is created
+    try:
+        enc = M.Encoder(M.make_params(w, h, **kw), max_batch=B)
+    finally:
+        del os.environ["MJH_SPLIT"]
     d = torch.from_numpy(frames).cuda()
     torch.cuda.synchronize()
     for n in (B, B - 7, 16, 15, 1):                   # ragged second range, one image in it, exactly one range (unsplit), one image
