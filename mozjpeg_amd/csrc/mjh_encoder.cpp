@@ -287,7 +287,7 @@ struct mjh_encoder {
   int trellis_floor = 0, trellis_hold = 0;   // hysteresis of the adaptation
   bool trellis_adapt = true;         // no MJH_TRELLIS_VARIANT given: follow the share of deferred blocks of the previous batches
   unsigned *h_defer = nullptr;       // pinned: work-list count of the last finished trellis pass
-  int fuse_mask = 1;                // MJH_FUSE: 1 = pre-trellis AC statistics inside the FDCT kernel (+ unread planes not stored), 2 = final AC statistics inside the trellis
+  int fuse_mask = 1;                // MJH_FUSE: 1 = pre-trellis AC statistics inside the FDCT kernel (+ unread planes not stored), 2 = final AC statistics inside the general trellis kernel, 4 = inside the tile-sorted one (both measured: they cost the trellis what the separate pass costs, 2.36 + 0.33 vs 2.77 ms)
   int spi = SLOTS_BASE;             // table slots per image (16 + 2 per progressive scan)
   // progressive mode
   bool progressive = false;
@@ -1235,6 +1235,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   // One (statistics, trellis) pass pair: for all components (CV = C) or, with trellis_q_opt, for ONE component through a
   // one-component view of the geometry (MjhComp carries absolute offsets, so the view addresses the same buffers).
   const int nloops = p.trellis_quant ? (p.trellis_num_loops > 1 ? p.trellis_num_loops : 1) : 0;
+  bool final_ac_counted = false;     // the last trellis pass has counted the AC statistics of the final coefficients
   auto trellis_pass = [&](const MjhConst &CV, const int *sl_dc_seq, const int *sl_dc_prog, const int *sl_ac, const int *crst,
                           const mjh_encoder::PList *plt, int Ss, int Se, bool first_pass, bool last_loop, int qstride) -> int {
     if (!first_pass)   // fresh (zero) statistics for this pass
@@ -1303,10 +1304,15 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       e->h_defer[0] = 0xFFFFFFFFu;
     }
     pr.mark("trellis_ac");
+    // the tile-sorted first tier (plain compact pass, 16-record capacity) can count the statistics of the final coefficients
+    // in its back-track (MJH_FUSE bit 4): sequential mode, optimal tables, last round
+    const bool v3 = nzm && e->d_nq8 && !fuse_fin && e->trellis_v3 > 0 && e->trellis_variant == 0 && !extended;
+    const bool v3_stats = v3 && (e->fuse_mask & 4) && !e->progressive && p.optimize_coding && last_loop;
+    if (v3_stats) final_ac_counted = true;
     mjh_launch_trellis_ac(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap,
-                          fuse_fin && p.optimize_coding && last_loop ? fin_ac : nullptr, e->trellis_variant,
+                          (v3_stats || (fuse_fin && p.optimize_coding && last_loop)) ? fin_ac : nullptr, e->trellis_variant,
                           Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, nzm, qstride, n, s,
-                          e->d_nq8, fuse_fin ? 0 : e->trellis_v3, e->fastdiv_all);
+                          e->d_nq8, v3 ? e->trellis_v3 : 0, e->fastdiv_all);
     if (e->trellis_adapt && !extended && first_pass) {
       e->h_defer[1] = (unsigned)n;
       HIPCHK(hipMemcpyAsync(&e->h_defer[0], e->d_worklist, sizeof(unsigned), hipMemcpyDeviceToHost, s));
@@ -1411,7 +1417,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   }
   if (p.optimize_coding) {
     // pass 6: statistics of the interleaved scan (dummy blocks included) -> final tables
-    if (!fuse_fin) {   // (else the last trellis round has counted the AC symbols already)
+    if (!fuse_fin && !final_ac_counted) {   // (else the last trellis round has counted the AC symbols already)
       pr.mark("stats_ac(final)");
       mjh_launch_stats_ac(C, e->d_q, nzm, e->d_tabs, spi, fin_ac, 1, n, s);
     }

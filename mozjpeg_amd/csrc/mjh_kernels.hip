@@ -607,19 +607,26 @@ __device__ __forceinline__ void for_each_nonzero(const int16_t *__restrict__ qb,
 }
 
 // k_stats_ac on compact records (the final statistics of the sequential scan)
+// `only` != nullptr: the deferred-only form behind the tile-sorted trellis with fused statistics -- only the blocks it
+// flagged (0xFF) are counted, a workgroup without one leaves at once; the dummy blocks were counted there as well
 __global__ void __launch_bounds__(256)
 k_stats_ac_compact(MjhConst C, const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask, MjhHuffTable *__restrict__ tabs,
-                   int slots_per_image, int4 slot_of_comp, int count_dummies)
+                   int slots_per_image, int4 slot_of_comp, int count_dummies, const uint8_t *__restrict__ only)
 {
   __shared__ unsigned h[16][256];   // 16 interleaved copies: the common symbols would otherwise serialise the LDS atomics
   const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
   const int tid = threadIdx.x;
+  const int blk = blockIdx.x * 256 + tid;
+  bool wanted = blk < cc.nblk;
+  if (only) {
+    wanted = wanted && only[(size_t)img * C.total_real_blocks + cc.blk_off + blk] == 0xFFu;
+    if (__syncthreads_or(wanted) == 0) return;
+  }
   for (int i = tid; i < 4096; i += 256) (&h[0][0])[i] = 0;
   __syncthreads();
-  const int blk = blockIdx.x * 256 + tid;
   {
-    const bool in = blk < cc.nblk;
+    const bool in = wanted;
     const int b = in ? blk : cc.nblk - 1;
     const int16_t *q = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + b;
     const unsigned long long m = nzmask[(size_t)img * C.total_real_blocks + cc.blk_off + b];
@@ -739,16 +746,30 @@ k_stats_dc(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restr
 //  * code-length limiting (K.2, :1073-1084) and pseudo-symbol removal are serial on lane 0.
 //  * huffval order = (codesize, symbol) via per-length ballots (bit_pos, :1060-1064,:1099-1102).
 // =============================================================================================
+// minimum of a 64-bit key over the wave, the same value in every lane.  DPP row shifts (a running minimum over 1, 2, 4, 8
+// lanes leaves each 16-lane row's minimum in its last lane) + four v_readlane: no LDS round trips -- the table
+// construction below is one long dependent chain of these reductions (two per merge step), and with six ds_bpermute
+// exchanges per reduction the two k_gen_tables launches cost 0.21 ms per batch although they do almost no work.
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const unsigned lo = __shfl_xor((unsigned)v, o, 64);
-    const unsigned hi = __shfl_xor((unsigned)(v >> 32), o, 64);
-    const unsigned long long w = ((unsigned long long)hi << 32) | lo;
-    v = w < v ? w : v;
+#define MJH_MIN_STEP(CTRL)                                                                                           \
+  {                                                                                                                   \
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)(unsigned)v, CTRL, 0xF, 0xF, false);            \
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, false);     \
+    const unsigned long long w = ((unsigned long long)hi << 32) | lo;                                                  \
+    v = w < v ? w : v;                                                                                                \
   }
-  return v;
+  MJH_MIN_STEP(0x111) MJH_MIN_STEP(0x112) MJH_MIN_STEP(0x114) MJH_MIN_STEP(0x118)   // row_shr:1, 2, 4, 8 (lanes without a source read the identity)
+#undef MJH_MIN_STEP
+  unsigned long long m = ~0ull;
+#pragma unroll
+  for (int r = 15; r < 64; r += 16) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, r);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), r);
+    const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+    m = w < m ? w : m;
+  }
+  return m;
 }
 
 __device__ __forceinline__ void gen_table_body(MjhHuffTable *__restrict__ T, int lane)
@@ -1755,15 +1776,22 @@ __device__ __forceinline__ void v3_pair(const uint2 (*col)[64], const unsigned s
   gap_old = gap_b;
 }
 
-template <int QN, int NPASS, bool FD>
+// FST (sequential mode, optimal tables): the AC symbol statistics of the FINAL coefficients (the reference's last gather
+// pass, jchuff.c:812-915) fall out of the back-track -- a path entry at position p whose predecessor sits at pp is the
+// symbol (run p-pp-1, category of its magnitude) -- so they are counted here (LDS histogram, flushed once per tile) instead
+// of by one more pass over the compact records; deferred blocks are flagged (nq8 = 0xFF) for k_stats_ac_compact's
+// deferred-only form.
+template <int QN, int NPASS, bool FD, bool FST>
 __global__ void __launch_bounds__(64)
 k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q,
                 const MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 ac_slot_of_comp, int4 tile0_of_comp,
-                const float *__restrict__ lambda_in, const uint8_t *__restrict__ nq8, unsigned *__restrict__ worklist,
-                int16_t *__restrict__ dense, unsigned dense_cap, unsigned long long *__restrict__ nzmask)
+                const float *__restrict__ lambda_in, uint8_t *__restrict__ nq8, unsigned *__restrict__ worklist,
+                int16_t *__restrict__ dense, unsigned dense_cap, unsigned long long *__restrict__ nzmask,
+                MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp)
 {
   static_assert(QN >= 16 && QN <= 31 && NPASS >= 1 && NPASS <= 8, "queue capacity / passes");
   constexpr int TILE = 64 * NPASS;
+  __shared__ unsigned fhist[FST ? 2 : 1][FST ? 256 : 1];   // FST: two interleaved copies of the symbol histogram of this tile
   __shared__ uint2 col[QN][64];          // tile sort scratch; per pass: queue records -> live entries {azd, acc} -> value column
   __shared__ unsigned short info[QN][64];   // live entry e (>= 1) at [e-1]: position | back entry << 6 | magnitude (< 16) << 11 | sign << 15
   __shared__ float4 rate_rows[16];
@@ -1783,6 +1811,10 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
   const int dq_lane = Q->dq8[cc.qtbl][lane];                    // lane k holds the row entry of position k (ds_bpermute lookups)
   const float lt_lane = Q->lambda_tbl[cc.qtbl][lane];
 
+  if (FST) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) (&fhist[0][0])[j * 64 + lane] = 0u;
+  }
   // ---- tile sort: descending key; perm entry = index in tile | key << 9 ----
   unsigned long long mine0 = 0ull, mine1 = 0ull;
   {
@@ -1829,6 +1861,7 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     const size_t gblk = gblk0 + (inside ? blk : 0);
     if (__builtin_amdgcn_ballot_w64(inside && (pe >> 9) != 0u) == 0ull) {   // nothing quantizes to non-zero: all-zero blocks
       if (inside) nzmask[gblk] = 0ull;
+      if (FST && inside) atomicAdd(&fhist[lane & 1][0], 1u);                  // every one of them codes an EOB
       continue;
     }
     const float lambda = lambda_in[gblk0 + (inside ? blk : cc.nblk - 1)];
@@ -1864,6 +1897,7 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
       defer_blocks(inside && (nq > QN || qmax >= 16), worklist, (unsigned)img, ((unsigned)comp << 28) | (unsigned)blk, 0u, xs, dense, dense_cap, true, lane);
     }
     const bool work = inside && nq <= QN && qmax < 16;
+    if (FST && inside && !work) nq8[gblk] = 0xFFu;     // deferred: its statistics are counted from its records (k_stats_ac_compact, deferred-only form)
 
     // ---- the walk: every lane consumes its own records; the next record is always one load ahead ----
     int nlive = 1, qi = 0, last = 0;
@@ -1938,16 +1972,31 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     // ---- back-track (jcdctmgr.c:1211-1222) along the entry indices; values in visiting (descending position) order ----
     unsigned long long pmask = 0ull;
     int cnt = 0, e2 = work ? last : 0;
+    int up_pos = -1, up_mag = 0;          // FST: the path entry visited before this one (the next higher position)
+    unsigned *hh = fhist[FST ? (lane & 1) : 0];
+    auto count = [&](int run, int mag) {  // symbol of a coefficient of magnitude `mag` behind `run` zeros (jchuff.c:833-868)
+      if (run > 15) { atomicAdd(&hh[0xF0], (unsigned)(run >> 4)); run &= 15; }
+      atomicAdd(&hh[(run << 4) + bitlen((unsigned)mag)], 1u);
+    };
     while (__builtin_amdgcn_ballot_w64(e2 > 0) != 0ull) {
       if (e2 > 0) {
         const unsigned inf = info[e2 - 1][lane];
-        const int mag = (int)((inf >> 11) & 15u);
+        const int mag = (int)((inf >> 11) & 15u), pos = (int)(inf & 63u);
         const int v = (inf >> 15) ? -mag : mag;
         colh[((cnt >> 2) * 64 + lane) * 4 + (cnt & 3)] = (unsigned short)v;
-        pmask |= 1ull << (inf & 63u);
+        pmask |= 1ull << pos;
         cnt++;
+        if (FST) {
+          if (up_pos >= 0) count(up_pos - pos - 1, up_mag);
+          else if (pos < 63) atomicAdd(&hh[0], 1u);          // the highest kept position is not 63: EOB
+          up_pos = pos; up_mag = mag;
+        }
         e2 = (int)((inf >> 6) & 31u);
       }
+    }
+    if (FST && work) {
+      if (up_pos >= 0) count(up_pos - 1, up_mag);            // the lowest kept position: its run starts behind the DC coefficient
+      else atomicAdd(&hh[0], 1u);                            // nothing kept: EOB
     }
     if (work) nzmask[gblk] = pmask;
     {
@@ -1963,6 +2012,18 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
       }
     }
     __syncthreads();
+  }
+  if (FST) {
+    const int sslot = comp == 0 ? stat_slot_of_comp.x : comp == 1 ? stat_slot_of_comp.y : comp == 2 ? stat_slot_of_comp.z : stat_slot_of_comp.w;
+    MjhHuffTable *TS = stat_tabs + (size_t)img * slots_per_image + sslot;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int bin = lane + 64 * j;
+      unsigned sum = fhist[0][bin] + fhist[1][bin];
+      // every dummy block of the interleaved scan codes one EOB (all-zero AC, jccoefct.c:312-345): counted once per component
+      if (bin == 0 && tl == t0) sum += (unsigned)(cc.wpad * cc.hpad - cc.nblk);
+      if (sum) atomicAdd(&TS->counts[bin], sum);
+    }
   }
 }
 
@@ -3239,7 +3300,7 @@ void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, vo
 void mjh_launch_stats_ac(const MjhConst &C, const void *q, const unsigned long long *nzmask, MjhHuffTable *tabs, int spi, const int slot[4], int count_dummies, int n, hipStream_t s)
 {
   dim3 grid((max_nblk(C) + 255) / 256, C.ncomp, n);
-  if (nzmask) hipLaunchKernelGGL(k_stats_ac_compact, grid, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, make_int4(slot[0], slot[1], slot[2], slot[3]), count_dummies);
+  if (nzmask) hipLaunchKernelGGL(k_stats_ac_compact, grid, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, make_int4(slot[0], slot[1], slot[2], slot[3]), count_dummies, (const uint8_t *)nullptr);
   else hipLaunchKernelGGL(k_stats_ac, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, make_int4(slot[0], slot[1], slot[2], slot[3]), count_dummies);
 }
 
@@ -3272,7 +3333,7 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
-                           const uint8_t *nq8, int v3_passes, int fastdiv)
+                           uint8_t *nq8, int v3_passes, int fastdiv)
 {
   // band-limited pass (use_scans_in_trellis), the per-block outputs of trellis_eob_opt, per-image tables (trellis_q_opt):
   // the EXT instantiations
@@ -3305,20 +3366,25 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   if (nzmask && nq8 && v3_passes > 0 && variant == 0) {
     // the tile-sorted kernel: first tier of the plain compact pass; its work list (more than 16 records, or a magnitude >= 16)
     // goes through the general tiers below
-    const int np = !fastdiv ? 4 : v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
+    const int np = (!fastdiv || st) ? 4 : v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
     int t0[5] = { 0, 0, 0, 0, 0 };
     for (int i = 0; i < 4; i++) t0[i + 1] = t0[i] + (i < C.ncomp ? (C.c[i].nblk + 64 * np - 1) / (64 * np) : 0);
     dim3 gridt(t0[C.ncomp], n);
     for (int i = C.ncomp; i < 4; i++) t0[i] = 0x7FFFFFFF;
     const int4 tv = make_int4(t0[0], t0[1], t0[2], t0[3]);
-#define LV3(NP) hipLaunchKernelGGL((k_trellis_ac_v3<16, NP, true>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask)
-    if (!fastdiv) hipLaunchKernelGGL((k_trellis_ac_v3<16, 4, false>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask);
-    else switch (np) { case 8: LV3(8); break; case 4: LV3(4); break; case 2: LV3(2); break; default: LV3(1); break; }
+#define LV3(NP, FDV, FSV) hipLaunchKernelGGL((k_trellis_ac_v3<16, NP, FDV, FSV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask, st, ss)
+    if (st) { if (fastdiv) LV3(4, true, true); else LV3(4, false, true); }     // statistics of the final coefficients counted in the back-track
+    else if (!fastdiv) LV3(4, false, false);
+    else switch (np) { case 8: LV3(8, true, false); break; case 4: LV3(4, true, false); break; case 2: LV3(2, true, false); break; default: LV3(1, true, false); break; }
 #undef LV3
     hipLaunchKernelGGL((k_trellis_ac_qd<32, false, false, true>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
-                       (const unsigned *)worklist, worklist2, (const int16_t *)dense, dense_cap, st, ss, ext);
+                       (const unsigned *)worklist, worklist2, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
     hipLaunchKernelGGL((k_trellis_ac_qd<63, false, false, true>), dim3(1024), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
-                       (const unsigned *)worklist2, (unsigned *)nullptr, (const int16_t *)dense, dense_cap, st, ss, ext);
+                       (const unsigned *)worklist2, (unsigned *)nullptr, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
+    if (st) {   // the deferred blocks' symbols, from the records the general tiers wrote
+      dim3 gridd((max_nblk(C) + 255) / 256, C.ncomp, n);
+      hipLaunchKernelGGL(k_stats_ac_compact, gridd, dim3(256), 0, s, C, (const int16_t *)q, (const unsigned long long *)nzmask, tabs, spi, ss, 0, (const uint8_t *)nq8);
+    }
   } else if (nzmask) {   // compact records out (the caller guarantees: plain pass, no fused statistics)
 #define LQC(QN) hipLaunchKernelGGL((k_trellis_ac_q<QN, false, false, true>), gridq, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, wv, lambda, worklist, (int16_t *)dense, dense_cap, st, ss, ext)
 #define LDC(QN, GRID, WL, WLN) hipLaunchKernelGGL((k_trellis_ac_qd<QN, false, false, true>), dim3(GRID), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda, (const unsigned *)WL, WLN, (const int16_t *)dense, dense_cap, st, ss, ext)
