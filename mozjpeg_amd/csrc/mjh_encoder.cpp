@@ -277,6 +277,8 @@ struct mjh_encoder {
   int dc_window_ok = 0;              // every component's DC quantizer step 8q >= 40: the DC trellis may use its sliding-window kernel
   int trellis_v3 = 4;                // passes per tile of the tile-sorted first tier (MJH_TRELLIS_V3; 0 = the general kernel)
   int dqt_off[4] = { -1, -1, -1, -1 };      // file offset of the first entry of every 8-bit DQT table
+  int dqt_tabs[4] = { 0, 0, 0, 0 }, dqt_ntab = 0;   // quantization tables in DQT marker order (first use by a component)
+  bool tbl_le1 = true;                      // every Huffman table number is 0 or 1 (a baseline-capable frame, jcmarker.c:699-710)
   int nbands = 1, freq_split = 8;
   unsigned *d_seg_x = nullptr, *d_seg_E = nullptr, *d_seg_sums = nullptr, *d_seg_totals = nullptr, *d_mpos = nullptr;
   int nseg = 1;
@@ -357,12 +359,6 @@ static int check_supported(const mjh_params *p)
   if (p->smoothing_factor < 0 || p->smoothing_factor > 100) return fail(MJH_EINVAL, "smoothing_factor %d (0..100)", p->smoothing_factor);
   if (p->trellis_num_loops < 0 || p->trellis_num_loops > 16) return fail(MJH_EINVAL, "trellis_num_loops %d (0..16)", p->trellis_num_loops);
   if (p->trellis_freq_split < 0 || p->trellis_freq_split > 63) return fail(MJH_EINVAL, "trellis_freq_split %d (0..63)", p->trellis_freq_split);
-  if (p->trellis_quant && p->trellis_q_opt) {
-    // (the new entries are at most 254, so 8-bit tables stay 8-bit and their DQT bytes can be rewritten in place)
-    for (int i = 0; i < p->num_components; i++)
-      for (int k = 0; k < 64; k++)
-        if (p->quantval[p->quant_tbl_no[i]][k] > 255) return fail(MJH_EUNSUPPORTED, "trellis_q_opt with 16-bit quantization tables (the DQT entries are rewritten in place)");
-  }
   if (p->dc_scan_opt_mode < 0 || p->dc_scan_opt_mode > 2) return fail(MJH_EINVAL, "dc_scan_opt_mode %d (0..2)", p->dc_scan_opt_mode);
   if (!(p->trellis_delta_dc_weight == p->trellis_delta_dc_weight)) return fail(MJH_EINVAL, "trellis_delta_dc_weight is not a number");
   if (p->data_precision == 12 && p->trellis_quant)
@@ -940,6 +936,14 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     std::vector<uint8_t> pre, sos;
     bool base;
     build_prefix(p, pre, &base, &e->file_hdr_len, e->dqt_off);
+    {
+      bool seen[4] = { false, false, false, false };
+      for (int ci = 0; ci < p->num_components; ci++) {
+        const int t = p->quant_tbl_no[ci];
+        if (!seen[t]) { e->dqt_tabs[e->dqt_ntab++] = t; seen[t] = true; }
+        if (p->dc_tbl_no[ci] > 1 || p->ac_tbl_no[ci] > 1) e->tbl_le1 = false;
+      }
+    }
     build_sos(p, C.restart_interval, sos);
     e->prefix_len = (int)pre.size();
     e->sos_len = (int)sos.size();
@@ -1306,7 +1310,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     pr.mark("trellis_ac");
     // the tile-sorted first tier (plain compact pass, 16-record capacity) can count the statistics of the final coefficients
     // in its back-track (MJH_FUSE bit 4): sequential mode, optimal tables, last round
-    const bool v3 = nzm && e->d_nq8 && !fuse_fin && e->trellis_v3 > 0 && e->trellis_variant == 0 && !extended;
+    const bool v3 = nzm && e->d_nq8 && !fuse_fin && e->trellis_v3 > 0 && e->trellis_variant <= 2 && !extended;
     const bool v3_stats = v3 && (e->fuse_mask & 4) && !e->progressive && p.optimize_coding && last_loop;
     if (v3_stats) final_ac_counted = true;
     mjh_launch_trellis_ac(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap,
@@ -1409,7 +1413,11 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     if (before_output) HIPCHK(hipStreamWaitEvent(s, before_output, 0));
     pr.mark("prog_concat");
     mjh_launch_prog_concat(e->d_prog_ctl, e->d_prefix, e->file_hdr_len, e->d_outpool, e->outpool_bytes, e->d_out, e->out_stride, e->d_sizes, n, s);
-    if (ext_qopt) { pr.mark("trellis_q_opt(DQT)"); mjh_launch_qopt_patch(e->d_quant, e->d_out, e->out_stride, e->dqt_off, e->d_sizes, n, s); }   // jcmaster.c:1014-1030
+    if (ext_qopt) {   // jcmaster.c:1014-1030 + the precision rule of jcmarker.c:189-254
+      pr.mark("trellis_q_opt(DQT)");
+      mjh_launch_qopt_fix(e->d_quant, e->d_out, e->out_stride, e->d_sizes, e->file_hdr_len, e->prefix_len - (10 + 3 * C.ncomp), e->dqt_tabs, e->dqt_ntab,
+                          p.compress_profile != MJH_PROFILE_FASTEST, !e->progressive && C.precision == 8 && e->tbl_le1, n, s);
+    }
     pr.mark(nullptr);
     pr.finish();
     HIPCHK(hipGetLastError());
@@ -1437,7 +1445,11 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   pr.mark("byte_stuff");
   mjh_launch_stuff(e->d_stream, e->stream_words, e->d_totals, e->d_ffsums, e->ff_chunks, e->d_fftotals, e->d_out, e->out_stride,
                    e->d_meta, e->d_sizes, e->d_mpos, e->nseg, n, s);
-  if (ext_qopt) { pr.mark("trellis_q_opt(DQT)"); mjh_launch_qopt_patch(e->d_quant, e->d_out, e->out_stride, e->dqt_off, e->d_sizes, n, s); }   // jcmaster.c:1014-1030
+  if (ext_qopt) {   // jcmaster.c:1014-1030 + the precision rule of jcmarker.c:189-254
+    pr.mark("trellis_q_opt(DQT)");
+    mjh_launch_qopt_fix(e->d_quant, e->d_out, e->out_stride, e->d_sizes, e->file_hdr_len, e->prefix_len - (10 + 3 * C.ncomp), e->dqt_tabs, e->dqt_ntab,
+                        p.compress_profile != MJH_PROFILE_FASTEST, !e->progressive && C.precision == 8 && e->tbl_le1, n, s);
+  }
   pr.mark(nullptr);
   pr.finish();
   HIPCHK(hipGetLastError());

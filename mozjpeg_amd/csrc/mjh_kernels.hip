@@ -1508,15 +1508,76 @@ k_qopt_update(long long *__restrict__ sums, MjhQuant *__restrict__ Q)
   }
 }
 
-// the image's final tables -> the DQT bytes of its file (8-bit tables: one byte per entry at dqt_off[table] + k, zig-zag
-// order like the marker)
-__global__ void __launch_bounds__(64)
-k_qopt_patch(const MjhQuant *__restrict__ Q, uint8_t *__restrict__ out, size_t out_stride, int4 dqt_off, const unsigned *__restrict__ sizes)
+// trellis_q_opt, end of the encode: the image's FINAL tables -> the DQT segment(s) of its finished file, rebuilt at the
+// precision the final values ask for (emit_multi_dqt / emit_dqt jcmarker.c:140-254 look at quantval > 255 when they WRITE the
+// marker, i.e. after finish_pass_master jcmaster.c:1014-1030 has replaced the estimated entries by values <= 254: a table that
+// started with 16-bit entries keeps those the estimate never touched -- the DC entry, coefficients no block quantizes to
+// non-zero -- and turns into an 8-bit table only if none of them is left).  The file was assembled with the DQT layout of the
+// ORIGINAL tables; if a table shrinks, everything behind the segment moves up and a baseline-capable frame gets SOF0
+// instead of SOF1 (write_frame_header :699-734).  One workgroup per image.
+struct MjhDqtLayout {
+  int dqt_start, sof_off;     // [dqt_start, sof_off): the DQT segment(s) as first written; the SOF marker follows
+  int ntab, tab[4];           // tables in marker order
+  int multi;                  // one DQT marker with all tables (max-compression profile) / one marker per table
+  int baseline_capable;       // sequential Huffman, 8-bit samples, table numbers <= 1: SOF0 unless a table is 16-bit
+};
+
+__global__ void __launch_bounds__(256)
+k_qopt_fix(const MjhQuant *__restrict__ Q, uint8_t *__restrict__ out, size_t out_stride, unsigned *__restrict__ sizes, MjhDqtLayout L)
 {
-  const int img = blockIdx.x, t = blockIdx.y, k = threadIdx.x;
-  const int off = t == 0 ? dqt_off.x : t == 1 ? dqt_off.y : t == 2 ? dqt_off.z : dqt_off.w;
-  if (off < 0 || k == 0 || sizes[img] == 0) return;
-  out[(size_t)img * out_stride + off + k] = (uint8_t)Q[img].q[t][k];
+  __shared__ uint8_t nd[4 * (4 + 1 + 128) + 16];
+  __shared__ int s_len, s_any16;
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const unsigned size = sizes[img];
+  if (size == 0) return;
+  uint8_t *f = out + (size_t)img * out_stride;
+  const MjhQuant *Qi = Q + img;
+  if (tid == 0) {
+    int prec[4], any = 0, n = 0;
+    for (int i = 0; i < L.ntab; i++) {
+      prec[i] = 0;
+      for (int k = 0; k < 64; k++) if (Qi->q[L.tab[i]][k] > 255) prec[i] = 1;
+      any |= prec[i];
+    }
+    if (L.multi) {
+      int sz = 2;
+      for (int i = 0; i < L.ntab; i++) sz += 64 * (prec[i] + 1) + 1;
+      nd[n++] = 0xFF; nd[n++] = 0xDB; nd[n++] = (uint8_t)(sz >> 8); nd[n++] = (uint8_t)sz;
+    }
+    for (int i = 0; i < L.ntab; i++) {
+      if (!L.multi) {
+        const int sz = 64 * (prec[i] + 1) + 1 + 2;
+        nd[n++] = 0xFF; nd[n++] = 0xDB; nd[n++] = (uint8_t)(sz >> 8); nd[n++] = (uint8_t)sz;
+      }
+      nd[n++] = (uint8_t)(L.tab[i] + (prec[i] << 4));
+      for (int k = 0; k < 64; k++) {          // MjhQuant.q is in zig-zag order, like the marker
+        const unsigned qv = Qi->q[L.tab[i]][k];
+        if (prec[i]) nd[n++] = (uint8_t)(qv >> 8);
+        nd[n++] = (uint8_t)(qv & 0xFF);
+      }
+    }
+    s_len = n; s_any16 = any;
+  }
+  __syncthreads();
+  const int old_len = L.sof_off - L.dqt_start, new_len = s_len, delta = old_len - new_len;   // (>= 0: entries only ever shrink)
+  if (delta > 0) {
+    // move [sof_off, size) up by delta: ascending chunks, every chunk read completely before it is written
+    for (unsigned base = (unsigned)L.sof_off; base < size; base += 256u * 16u) {
+      uint8_t v[16];
+      const unsigned at = base + (unsigned)tid * 16u;
+#pragma unroll
+      for (int j = 0; j < 16; j++) v[j] = at + j < size ? f[at + j] : (uint8_t)0;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 16; j++) if (at + j < size) f[at + j - delta] = v[j];
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < new_len; i += 256) f[L.dqt_start + i] = nd[i];
+  if (tid == 0) {
+    if (L.baseline_capable) f[L.sof_off - delta + 1] = s_any16 ? 0xC1 : 0xC0;
+    sizes[img] = size - (unsigned)delta;
+  }
 }
 
 __global__ void k_zero_counters(unsigned *__restrict__ a, unsigned *__restrict__ b)
@@ -3361,22 +3422,27 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
                        (const unsigned *)worklist2, (unsigned *)nullptr, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
     return;
   }
-  // MJH_TRELLIS_VARIANT: queue capacity of the first tier (all bit-identical; LDS per wave = 10 * QN * 64 bytes);
+  // MJH_TRELLIS_VARIANT: queue capacity of the first tier: 0 = 16, 1 = 20 (24 in the tile-sorted kernel), 2 = 24, 3 = 32 (all bit-identical);
   // second and third tier: blocks with more than QN (then 32) non-zero positions, from their dense copies
-  if (nzmask && nq8 && v3_passes > 0 && variant == 0) {
+  if (nzmask && nq8 && v3_passes > 0 && variant <= 2) {
     // the tile-sorted kernel: first tier of the plain compact pass; its work list (more than 16 records, or a magnitude >= 16)
     // goes through the general tiers below
-    const int np = (!fastdiv || st) ? 4 : v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
+    const int np = (!fastdiv || st || variant > 0) ? 4 : v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
     int t0[5] = { 0, 0, 0, 0, 0 };
     for (int i = 0; i < 4; i++) t0[i + 1] = t0[i] + (i < C.ncomp ? (C.c[i].nblk + 64 * np - 1) / (64 * np) : 0);
     dim3 gridt(t0[C.ncomp], n);
     for (int i = C.ncomp; i < 4; i++) t0[i] = 0x7FFFFFFF;
     const int4 tv = make_int4(t0[0], t0[1], t0[2], t0[3]);
-#define LV3(NP, FDV, FSV) hipLaunchKernelGGL((k_trellis_ac_v3<16, NP, FDV, FSV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask, st, ss)
-    if (st) { if (fastdiv) LV3(4, true, true); else LV3(4, false, true); }     // statistics of the final coefficients counted in the back-track
+#define LV3Q(QN, NP, FDV, FSV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, NP, FDV, FSV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask, st, ss)
+#define LV3(NP, FDV, FSV) LV3Q(16, NP, FDV, FSV)
+    if (variant > 0) {   // more records per block (higher qualities): the 24-record instantiation, 4 passes
+      if (st) { if (fastdiv) LV3Q(24, 4, true, true); else LV3Q(24, 4, false, true); }
+      else if (fastdiv) LV3Q(24, 4, true, false); else LV3Q(24, 4, false, false);
+    } else if (st) { if (fastdiv) LV3(4, true, true); else LV3(4, false, true); }     // statistics of the final coefficients counted in the back-track
     else if (!fastdiv) LV3(4, false, false);
     else switch (np) { case 8: LV3(8, true, false); break; case 4: LV3(4, true, false); break; case 2: LV3(2, true, false); break; default: LV3(1, true, false); break; }
 #undef LV3
+#undef LV3Q
     hipLaunchKernelGGL((k_trellis_ac_qd<32, false, false, true>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
                        (const unsigned *)worklist, worklist2, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
     hipLaunchKernelGGL((k_trellis_ac_qd<63, false, false, true>), dim3(1024), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
@@ -3514,8 +3580,11 @@ void mjh_launch_qopt_update(void *sums, MjhQuant *Q, int n, hipStream_t s)
   hipLaunchKernelGGL(k_qopt_update, dim3(n, 4), dim3(64), 0, s, (long long *)sums, Q);
 }
 
-void mjh_launch_qopt_patch(const MjhQuant *Q, void *out, size_t out_stride, const int dqt_off[4], const unsigned *sizes, int n, hipStream_t s)
+void mjh_launch_qopt_fix(const MjhQuant *Q, void *out, size_t out_stride, unsigned *sizes, int dqt_start, int sof_off, const int *tabs, int ntab,
+                         int multi, int baseline_capable, int n, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_qopt_patch, dim3(n, 4), dim3(64), 0, s, Q, (uint8_t *)out, out_stride,
-                     make_int4(dqt_off[0], dqt_off[1], dqt_off[2], dqt_off[3]), sizes);
+  MjhDqtLayout L;
+  L.dqt_start = dqt_start; L.sof_off = sof_off; L.ntab = ntab; L.multi = multi; L.baseline_capable = baseline_capable;
+  for (int i = 0; i < 4; i++) L.tab[i] = i < ntab ? tabs[i] : 0;
+  hipLaunchKernelGGL(k_qopt_fix, dim3(n), dim3(256), 0, s, Q, (uint8_t *)out, out_stride, sizes, L);
 }

@@ -24,7 +24,10 @@ void mjh_launch_trellis_eob_chain(const MjhConst &C, void *q, const MjhHuffTable
 // trellis_q_opt: sums[image][4 tables][64][2] += over all blocks; new entries patched into the DQT bytes of the finished files
 void mjh_launch_qopt_accumulate(const MjhConst &C, const void *uq, const void *q, void *sums, int n, hipStream_t s);
 void mjh_launch_qopt_update(void *sums, MjhQuant *Q, int n, hipStream_t s);   // Q: one MjhQuant per image
-void mjh_launch_qopt_patch(const MjhQuant *Q, void *out, size_t out_stride, const int dqt_off[4], const unsigned *sizes, int n, hipStream_t s);
+// the DQT segment(s) of the finished files rebuilt from every image's final tables ([dqt_start, sof_off) as first written; tabs: the
+// tables in marker order); shrinks the file and fixes SOF0/SOF1 when a 16-bit table has become an 8-bit one
+void mjh_launch_qopt_fix(const MjhQuant *Q, void *out, size_t out_stride, unsigned *sizes, int dqt_start, int sof_off, const int *tabs, int ntab,
+                         int multi, int baseline_capable, int n, hipStream_t s);
 // window_ok: every component's DC quantizer step 8q is >= 40 (candidate values are then never clamped: the sliding-window kernel applies)
 void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s,
                            int window_ok = 0);

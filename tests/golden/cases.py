@@ -104,6 +104,10 @@ CASES = [
     ("base_444_eob_opt_q90", dict(baseline=True, trellis_eob_opt=True, quality=90, sample=(1, 1)), True),
     ("base_scans_in_trellis_loops2_split20", dict(baseline=True, use_scans_in_trellis=True, trellis_loops=2, trellis_freq_split=20), True),
     ("base_q_opt_scans_split63", dict(baseline=True, trellis_q_opt=True, use_scans_in_trellis=True, trellis_freq_split=63), True),   # empty second band
+    # trellis_q_opt on 16-bit tables: the DQT is written at the precision of the FINAL values (jcmarker.c:189-254 behind
+    # jcmaster.c:1014-1030): both tables stay 16-bit / one 8-bit and one 16-bit table
+    ("q3_16bit_trellis_q_opt", dict(quality=3, fastcrush=True, trellis_q_opt=True), True),
+    ("q20_table0_mixed_precision_q_opt", dict(quality=20, fastcrush=True, quant_table=0, trellis_q_opt=True), True),
     ("q40_progressive_eob_opt_restart1", dict(trellis_eob_opt=True, quality=40, restart=1), True),
 ]
 

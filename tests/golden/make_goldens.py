@@ -17,6 +17,19 @@ from cases import CASES, CASES12, PLANE_CASES, TRANSCODE_CASES, images, images12
 
 def main():
     assert O.have_ref(), "build the reference first: make -C oracle ref"
+    if len(sys.argv) > 2 and sys.argv[1] == "--add":      # only the named cases, merged into the committed file
+        names = set(sys.argv[2:])
+        path = os.path.join(HERE, "goldens.json")
+        out = json.load(open(path))
+        for iname, img in images().items():
+            for cname, kw, _ in CASES:
+                if cname in names:
+                    data, _info = O.ref_encode(img, **kw)
+                    out["%s/%s" % (iname, cname)] = {"md5": O.md5(data), "bytes": len(data)}
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+        print("goldens.json now holds %d entries" % len(out))
+        return
     out = {}
     for iname, img in images().items():
         for cname, kw, _ in CASES:

@@ -97,6 +97,33 @@ def test_device_resident_input_via_torch_tensor():
         assert enc.get_jpeg(i) == O.encode(po, frames[i])
 
 
+@pytest.mark.parametrize("progressive", [False, True])
+def test_trellis_q_opt_with_16bit_tables_writes_the_final_precision(progressive):
+    """trellis_q_opt replaces the estimated entries by values <= 254 (jcmaster.c:1014-1030) and the DQT is written at the
+    precision of what is left (jcmarker.c:189-254): (a) a 16-bit entry the estimate replaces -> the table ends up 8-bit, the
+    file shrinks and a sequential frame is SOF0 again; (b) a 16-bit entry no block ever quantizes to non-zero stays -> the
+    table stays 16-bit (SOF1).  Byte for byte against the oracle (itself pinned to the reference by the q3 / q20 goldens)."""
+    from cases import images
+    img = images()["testorig"]                      # (a photograph: its low frequencies do get quantized to non-zero)
+    h, w = img.shape[:2]
+    kw = dict(quality=75, trellis_q_opt=True)       # (tables of quality 75 fit 8 bits; one entry is raised below)
+    kw.update(dict(fastcrush=True) if progressive else dict(baseline=True))
+    for nat_index, value, want_16 in ((1, 260, False), (63, 900, True)):
+        po, pg = O.make_params(w, h, **kw), M.make_params(w, h, **kw)
+        po.qtbl[0][nat_index] = value
+        pg.quantval[0][nat_index] = value
+        ref = O.encode(po, img)
+        enc = M.Encoder(pg, max_batch=3)
+        got = enc.encode_host(np.stack([img, img[::-1].copy(), img]))
+        assert got[0] == ref and got[2] == ref
+        i = ref.find(b"\xff\xdb")
+        dqt_len = int.from_bytes(ref[i + 2:i + 4], "big")
+        assert dqt_len == (2 + 129 + 65 if want_16 else 2 + 65 + 65), dqt_len
+        if not progressive:
+            assert (b"\xff\xc1" in ref[:i + dqt_len + 12]) == want_16
+        enc.close()
+
+
 def test_tensor_encode_is_ordered_behind_the_default_stream_producer():
     """encode_tensor(stream=None) straight behind a producer on torch's default (null) stream, no synchronize in between:
     the encode has to see the finished pixels (the null stream has handle 0, which the ABI reads as "own stream"; the
