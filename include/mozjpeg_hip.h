@@ -200,6 +200,16 @@ int mjh_wait_input(mjh_encoder *e);
  * a caller that produces pixels row by row (the libjpeg drop-in's jpeg_write_scanlines) writes them here and passes
  * the pointer to mjh_encode_host, which then copies nothing on the host. */
 int mjh_host_staging(mjh_encoder *e, void **buffer, size_t *bytes);
+/* The first `bytes` of that staging buffer (packed images, whole rows) are final: their host->device copy is queued now and
+ * runs while the caller produces the rest -- what jpeg_write_scanlines does with a client's rows (jcapistd.c:90-135 hands
+ * them on strip by strip as well).  The mjh_encode_host call for the buffer copies only the remainder. */
+int mjh_stage_commit(mjh_encoder *e, size_t bytes);
+/* One batch out of the images n OTHER encoders (same parameters, same device) have staged that way, one image each:
+ * image i of the batch = what members[i] holds.  For callers that get their images one at a time from several threads
+ * (the libjpeg shim coalesces concurrent jpeg_finish_compress calls): the device then runs ONE schedule for the lot
+ * instead of n single-image ones.  Results through mjh_collect / mjh_get_jpeg of `e`; nobody else may use the member
+ * encoders during the call. */
+int mjh_encode_gather(mjh_encoder *e, mjh_encoder *const *members, int n);
 /* Pinned host memory for zero-copy hand-over (hipHostMalloc / hipHostRegister underneath; no HIP types in the ABI). */
 void *mjh_host_alloc(size_t bytes);
 void mjh_host_free(void *p);

@@ -95,6 +95,8 @@ def lib():
         L.mjh_collect.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(Result)), C.POINTER(C.c_int)]
         L.mjh_wait_input.argtypes = [C.c_void_p]
         L.mjh_host_staging.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.mjh_stage_commit.argtypes = [C.c_void_p, C.c_size_t]
+        L.mjh_encode_gather.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]
         L.mjh_host_alloc.argtypes = [C.c_size_t]
         L.mjh_host_alloc.restype = C.c_void_p
         L.mjh_host_free.argtypes = [C.c_void_p]

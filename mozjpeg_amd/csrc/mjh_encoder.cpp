@@ -251,6 +251,7 @@ struct mjh_encoder {
   hipEvent_t ev_h2d[2] = { nullptr, nullptr }, ev_pix_free[2] = { nullptr, nullptr }, ev_packed[2] = { nullptr, nullptr };
   hipStream_t d2h_stream = nullptr;
   unsigned host_calls = 0;
+  size_t staged[2] = { 0, 0 };     // mjh_stage_commit: bytes of the staging buffer whose host->device copy is queued already
   int res_buf = -1;                // arena that holds the results of the last batch (-1: encoded through a *_device entry)
   int res_n[2] = { 0, 0 };         // images in each arena (0: nothing there)
   bool res_waited[2] = { false, false };
@@ -272,6 +273,7 @@ struct mjh_encoder {
   // the values live in the AC planes of d_q, plane i+1 = i-th non-zero.  compact_last: the last batch's d_q is in that form
   unsigned long long *d_nzmask = nullptr; bool use_compact = false, compact_last = false;
   uint8_t *d_nq8 = nullptr;          // per block: non-zero conventionally quantized AC coefficients (FDCT kernel) = tile-sort key of the AC trellis
+  int copy_prio = 0;
   int fastdiv_all = 0;               // every table in use has q <= 255: the kernels divide by 8q with one multiply-high (MjhQuant.mdiv)
   int dc_mode = 0;
   int dc_window_ok = 0;              // every component's DC quantizer step 8q >= 40: the DC trellis may use its sliding-window kernel
@@ -801,7 +803,17 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   e->freq_split = p->trellis_freq_split > 0 ? p->trellis_freq_split : 8;   // jcparam.c:512
   HIPCHK_E(hipSetDevice(device));
   HIPCHK_E(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-  HIPCHK_E(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  {
+    // MJH_COPY_PRIO=1 (experiment): copy and hand-over streams at the greatest priority, i.e. in a hardware-queue pool of their
+    // own.  Measured with 16 libjpeg client threads (tests/native/mt_bench, 4K): no gain with the coalescing shim (1143 vs 1162
+    // images/s), a loss without it and for a single client -- the limit there is the host side (every image is copied into
+    // pinned memory by its client thread and read again by the DMA engine: ~86 GB/s of host DRAM traffic at 1150 images/s).
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    const char *cp = getenv("MJH_COPY_PRIO");
+    e->copy_prio = (cp && atoi(cp) != 0) ? hi : 0;
+    HIPCHK_E(hipStreamCreateWithPriority(&e->copy_stream, hipStreamNonBlocking, e->copy_prio));
+  }
   HIPCHK_E(hipEventCreateWithFlags(&e->copy_done, hipEventDisableTiming));
   HIPCHK_E(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
   HIPCHK_E(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
@@ -1316,7 +1328,8 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     mjh_launch_trellis_ac(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap,
                           (v3_stats || (fuse_fin && p.optimize_coding && last_loop)) ? fin_ac : nullptr, e->trellis_variant,
                           Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, nzm, qstride, n, s,
-                          e->d_nq8, v3 ? e->trellis_v3 : 0, e->fastdiv_all);
+                          e->d_nq8, v3 ? ((size_t)n * C.total_real_blocks < 400000 ? 1 : e->trellis_v3) : 0,   // (a small batch: one pass per tile -- four times the workgroups, a quarter of their length: latency matters more than the sorting)
+                          e->fastdiv_all);
     if (e->trellis_adapt && !extended && first_pass) {
       e->h_defer[1] = (unsigned)n;
       HIPCHK(hipMemcpyAsync(&e->h_defer[0], e->d_worklist, sizeof(unsigned), hipMemcpyDeviceToHost, s));
@@ -1621,7 +1634,7 @@ static int host_buffers(mjh_encoder *e)
   // results: a JPEG file is normally a small fraction of its input; files that do not fit the arena are fetched from
   // the device buffer one by one (slow path, flagged in the table)
   e->res_cap = (size_t)e->max_batch * (e->pix_image_bytes / 2 + 65536);
-  HIPCHK(hipStreamCreateWithFlags(&e->d2h_stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithPriority(&e->d2h_stream, hipStreamNonBlocking, e->copy_prio));
   for (int b = 0; b < 2; b++) {
     HIPCHK(hipMalloc((void **)&e->d_pixb[b], in_bytes));
     HIPCHK(hipHostMalloc((void **)&e->h_res[b], e->res_cap, hipHostMallocMapped));
@@ -1667,12 +1680,19 @@ extern "C" int mjh_encode_host(mjh_encoder *e, const void *pixels, size_t row_pi
   const bool direct = own_staging || is_pinned(pixels);
   // d_pixb[b] was last read by the colour kernel of the call before the previous one
   HIPCHK(hipStreamWaitEvent(e->copy_stream, e->ev_pix_free[b], 0));
+  // (mjh_stage_commit: a prefix of the encoder's own packed staging buffer is on its way already)
+  const size_t done = (pixels == e->h_stage[b] && row_pitch == row_bytes && image_stride == e->pix_image_bytes) ? e->staged[b] : 0;
+  if (e->staged[b] != 0 && done == 0) return fail(MJH_EINVAL, "mjh_stage_commit was used: the batch has to come from the staging buffer, packed");
+  e->staged[b] = 0;
   if (direct) {
     // pinned source: the DMA engine reads the caller's memory; it must stay untouched until mjh_wait_input / mjh_collect
     for (int i = 0; i < n; i++) {
       const uint8_t *src = (const uint8_t *)pixels + (size_t)i * image_stride;
       uint8_t *dst = e->d_pixb[b] + (size_t)i * e->pix_image_bytes;
-      if (row_pitch == row_bytes) HIPCHK(hipMemcpyAsync(dst, src, e->pix_image_bytes, hipMemcpyHostToDevice, e->copy_stream));
+      const size_t lo = (size_t)i * e->pix_image_bytes, hi = lo + e->pix_image_bytes;
+      if (done >= hi) continue;
+      const size_t skip = done > lo ? done - lo : 0;
+      if (row_pitch == row_bytes) HIPCHK(hipMemcpyAsync(dst + skip, src + skip, e->pix_image_bytes - skip, hipMemcpyHostToDevice, e->copy_stream));
       else HIPCHK(hipMemcpy2DAsync(dst, row_bytes, src, row_pitch, row_bytes, (size_t)H, hipMemcpyHostToDevice, e->copy_stream));
     }
   } else {
@@ -1702,6 +1722,51 @@ extern "C" int mjh_encode_host(mjh_encoder *e, const void *pixels, size_t row_pi
   return queue_pack(e, b, n);
 }
 
+// One batch out of images that n OTHER encoders of the same parameters and device have staged (each through its own
+// mjh_host_staging buffer, possibly mjh_stage_commit'ted): what is left of every member's host->device copy is queued on the
+// member's copy stream, the images are gathered device-to-device into this encoder's input buffer, and the batch runs like a
+// mjh_encode_host batch (results through mjh_collect / mjh_get_jpeg of THIS encoder, image i = members[i]).  The members'
+// staging buffers flip as after a mjh_encode_host call of their own.  The caller guarantees that nobody else uses the member
+// encoders during the call (the libjpeg shim: their client threads are blocked in jpeg_finish_compress, waiting for this batch).
+extern "C" int mjh_encode_gather(mjh_encoder *e, mjh_encoder *const *members, int n)
+{
+  if (!e || !members || n < 1 || n > e->max_batch) return fail(MJH_EINVAL, "bad arguments");
+  HIPCHK(hipSetDevice(e->device));
+  int rc = host_buffers(e);
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) {
+    const mjh_encoder *m = members[i];
+    if (!m || m->device != e->device || m->pix_image_bytes != e->pix_image_bytes || memcmp(&m->p, &e->p, sizeof(mjh_params)) != 0)
+      return fail(MJH_EINVAL, "member %d does not match the batch encoder (parameters / device)", i);
+    if (!m->d_pixb[m->host_calls & 1u] || !m->h_stage[m->host_calls & 1u]) return fail(MJH_EINVAL, "member %d has nothing staged", i);
+  }
+  e->last_split = false;
+  const int b = (int)(e->host_calls++ & 1u);
+  HIPCHK(hipStreamWaitEvent(e->copy_stream, e->ev_pix_free[b], 0));   // this encoder's input buffer: its reader of two calls ago
+  for (int i = 0; i < n; i++) {
+    mjh_encoder *m = members[i];
+    const int mb = (int)(m->host_calls & 1u);
+    if (m->staged[mb] < m->pix_image_bytes) {
+      if (m->staged[mb] == 0) HIPCHK(hipStreamWaitEvent(m->copy_stream, m->ev_pix_free[mb], 0));
+      HIPCHK(hipMemcpyAsync(m->d_pixb[mb] + m->staged[mb], m->h_stage[mb] + m->staged[mb], m->pix_image_bytes - m->staged[mb], hipMemcpyHostToDevice, m->copy_stream));
+    }
+    m->staged[mb] = 0;
+    HIPCHK(hipEventRecord(m->ev_h2d[mb], m->copy_stream));
+    m->host_calls++;                                       // its next image goes to the other buffer
+    m->res_buf = -1; m->sizes_valid = false; m->last_n = 0;
+    HIPCHK(hipStreamWaitEvent(e->copy_stream, m->ev_h2d[mb], 0));
+    HIPCHK(hipMemcpyAsync(e->d_pixb[b] + (size_t)i * e->pix_image_bytes, m->d_pixb[mb], e->pix_image_bytes, hipMemcpyDeviceToDevice, e->copy_stream));
+    HIPCHK(hipEventRecord(m->ev_pix_free[mb], e->copy_stream));   // the member's device buffer is free once the gather copy has read it
+  }
+  HIPCHK(hipEventRecord(e->ev_h2d[b], e->copy_stream));
+  HIPCHK(hipStreamWaitEvent(e->stream, e->ev_h2d[b], 0));
+  const size_t row_bytes = (size_t)e->C.W * e->C.px_size * (e->C.precision == 12 ? 2 : 1);
+  rc = run_pipeline(e, e->d_pixb[b], row_bytes, e->pix_image_bytes, n, e->stream, nullptr, nullptr, e->ev_pix_free[b],
+                    e->host_calls > 1 ? e->ev_packed[b ^ 1] : nullptr);
+  if (rc) return rc;
+  return queue_pack(e, b, n);
+}
+
 extern "C" int mjh_host_staging(mjh_encoder *e, void **buffer, size_t *bytes)
 {
   if (!e || !buffer) return fail(MJH_EINVAL, "bad arguments");
@@ -1713,6 +1778,24 @@ extern "C" int mjh_host_staging(mjh_encoder *e, void **buffer, size_t *bytes)
   HIPCHK(hipEventSynchronize(e->ev_h2d[b]));
   *buffer = e->h_stage[b];
   if (bytes) *bytes = (size_t)e->max_batch * e->pix_image_bytes;
+  return MJH_OK;
+}
+
+// The first `bytes` of the staging buffer handed out by mjh_host_staging (packed images, whole rows) are final: their host->device
+// copy is queued now, so that the PCIe transfer runs while the caller is still producing the rest (a libjpeg client writes its
+// scanlines one call at a time).  The mjh_encode_host call for that buffer then copies only what is left.
+extern "C" int mjh_stage_commit(mjh_encoder *e, size_t bytes)
+{
+  if (!e) return fail(MJH_EINVAL, "null encoder");
+  const int b = (int)(e->host_calls & 1u);
+  if (!e->d_pixb[b] || !e->h_stage[b]) return fail(MJH_EINVAL, "mjh_stage_commit before mjh_host_staging");
+  const size_t cap = (size_t)e->max_batch * e->pix_image_bytes;
+  if (bytes > cap) bytes = cap;
+  if (bytes <= e->staged[b]) return MJH_OK;
+  HIPCHK(hipSetDevice(e->device));
+  if (e->staged[b] == 0) HIPCHK(hipStreamWaitEvent(e->copy_stream, e->ev_pix_free[b], 0));   // the device buffer's previous reader (two calls ago)
+  HIPCHK(hipMemcpyAsync(e->d_pixb[b] + e->staged[b], e->h_stage[b] + e->staged[b], bytes - e->staged[b], hipMemcpyHostToDevice, e->copy_stream));
+  e->staged[b] = bytes;
   return MJH_OK;
 }
 

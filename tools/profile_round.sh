@@ -15,6 +15,8 @@ timeout 200 rocprofv3 --kernel-trace --stats -d "$O" -o stats -- python bench.py
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$O" -o fetch -- python bench.py --steps 2 --warmup 1 $Q --batch "$BATCH" > "$O/fetch.log" 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$O" -o write -- python bench.py --steps 2 --warmup 1 $Q --batch "$BATCH" > "$O/write.log" 2>&1
 timeout 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --kernel-trace -d "$O" -o sq -- python bench.py --steps 2 --warmup 1 $Q --batch "$BATCH" > "$O/sq.log" 2>&1
+# lane activity (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU = active lanes per VALU instruction), LDS conflicts, memory instructions
+timeout 200 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --kernel-trace -d "$O" -o sq2 -- python bench.py --steps 2 --warmup 1 $Q --batch "$BATCH" > "$O/sq2.log" 2>&1
 # configuration 3 (progressive + scan search): bench line, kernel trace, traffic
 timeout 300 python bench.py --config c3 --no-cpu-baseline --no-host-leg > "$O/bench_c3.log" 2>&1; tail -1 "$O/bench_c3.log" | cut -c1-300
 timeout 200 rocprofv3 --kernel-trace --stats -d "$O" -o c3_stats -- python bench.py --config c3 --steps 10 --warmup 3 $Q > "$O/c3_stats.log" 2>&1
