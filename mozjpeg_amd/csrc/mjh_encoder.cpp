@@ -301,7 +301,7 @@ struct mjh_encoder {
   std::vector<int> h_lists;
   // scans of one phase + the table slots they build; for the statistics the scans are split into AC-first scans
   // without restart intervals (parallel kernel) and the rest (sequential per-scan walk)
-  struct PList { int scan_off, nscan, slot_off, nslot, par_off, npar, seq_off, nseq; bool any_refine; };
+  struct PList { int scan_off, nscan, slot_off, nslot, par_off, npar, nacf, seq_off, nseq; bool any_refine; };
   void *d_prog_chunks = nullptr;     // chunk summaries of the parallel statistics / encode kernels
   int chunks_per_scan = 0;
   MjhProgPE pe{};                    // buffers of the parallel AC-first encode
@@ -665,7 +665,7 @@ static void free_all(mjh_encoder *e)
   e->pad_streams.clear();
   if (e->ev_split_fork) (void)hipEventDestroy(e->ev_split_fork);
   if (e->ev_null_in) (void)hipEventDestroy(e->ev_null_in);
-  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_nq8, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->pe.chist, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_nq8, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -1059,8 +1059,10 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
         for (int t = 0; t < 2; t++)
           if (ps[si].slot[t] >= 0 && (ps[si].Ss != 0 || ps[si].Ah == 0)) { e->h_lists.push_back(ps[si].slot[t]); pl.nslot++; }
       // scans without a restart interval go through the parallel chain (mjh_prog.hip), the others are walked in order
-      pl.par_off = (int)e->h_lists.size(); pl.npar = 0; pl.any_refine = false;
-      for (int si : scn) if (ps[si].ri == 0) { e->h_lists.push_back(si); pl.npar++; if (ps[si].Ss != 0 && ps[si].Ah != 0) pl.any_refine = true; }
+      // (the first-pass AC scans first: the chain runs them in kernels of their own, mjh_launch_prog_encode)
+      pl.par_off = (int)e->h_lists.size(); pl.npar = 0; pl.nacf = 0; pl.any_refine = false;
+      for (int si : scn) if (ps[si].ri == 0 && ps[si].Ss != 0 && ps[si].Ah == 0) { e->h_lists.push_back(si); pl.npar++; pl.nacf++; }
+      for (int si : scn) if (ps[si].ri == 0 && !(ps[si].Ss != 0 && ps[si].Ah == 0)) { e->h_lists.push_back(si); pl.npar++; if (ps[si].Ss != 0 && ps[si].Ah != 0) pl.any_refine = true; }
       pl.seq_off = (int)e->h_lists.size(); pl.nseq = 0;
       for (int si : scn) if (ps[si].ri != 0) { e->h_lists.push_back(si); pl.nseq++; }
       return pl;
@@ -1116,6 +1118,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
         HIPCHK_E(hipMalloc((void **)&e->pe.e_bits, nch * (MJH_PSTAT_BLOCKS / 64) * 8));
         HIPCHK_E(hipMalloc((void **)&e->pe.ne2_bits, nch * (MJH_PSTAT_BLOCKS / 64) * 8));
         HIPCHK_E(hipMalloc((void **)&e->pe.info, pairs * sizeof(MjhProgPair)));
+        HIPCHK_E(hipMalloc((void **)&e->pe.chist, nch * 256 * 4));   // symbol counts per chunk: 1 KB per (scan, image, chunk of 2048 blocks)
       }
     }
     HIPCHK_E(hipMalloc((void **)&e->d_lists, e->h_lists.size() * sizeof(int) + 16));
@@ -1278,7 +1281,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       if (plt->nseq)
         mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + plt->seq_off, plt->nseq, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
       mjh_launch_prog_stats_par(C, e->d_prog_scans, e->d_lists + plt->par_off, plt->npar, e->d_prog_ctl, e->d_q, e->d_tabs, spi,
-                                e->pe, plt->any_refine, nullptr, n, s);   // (the conventionally quantized planes: one per position)
+                                e->pe, plt->any_refine, nullptr, n, s, plt->nacf);   // (the conventionally quantized planes: one per position)
       pr.mark("gen_tables(trellis)");
       mjh_launch_gen_tables_list(e->d_tabs, spi, e->d_lists + plt->slot_off, plt->nslot, n, s);
       sl_dc = sl_dc_prog;
@@ -1409,7 +1412,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
         ps = e->side_stream;
       }
       mjh_launch_prog_stats_par(C, e->d_prog_scans, e->d_lists + pl.par_off, pl.npar, e->d_prog_ctl, e->d_q, e->d_tabs, spi,
-                                e->pe, pl.any_refine, nzm, n, ps);
+                                e->pe, pl.any_refine, nzm, n, ps, pl.nacf);
       if (both) HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
       if (pl.nseq)
         mjh_launch_prog_stats(C, e->d_prog_scans, e->d_lists + pl.seq_off, pl.nseq, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_prog_mpos, e->mpos_per_image, n, s);
@@ -1420,7 +1423,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       mjh_launch_prog_encode(C, e->d_prog_scans, e->d_lists + pl.scan_off, pl.nscan, e->d_lists + pl.seq_off, pl.nseq, e->d_lists + pl.par_off, pl.npar,
                              e->pe, e->d_prog_ctl, e->d_q, e->d_tabs, spi, e->d_pool, e->pool_words,
                              e->d_frame_hdr, e->frame_hdr_len, p.compress_profile != MJH_PROFILE_FASTEST, e->d_outpool, e->outpool_bytes,
-                             e->d_prog_mpos, e->mpos_per_image, e->d_prog_ffsums, nzm, n, s, e->side_stream, e->ev_fork, e->ev_join);
+                             e->d_prog_mpos, e->mpos_per_image, e->d_prog_ffsums, nzm, n, s, e->side_stream, e->ev_fork, e->ev_join, pl.nacf);
       if (p.optimize_scans) { pr.mark("prog_select"); mjh_launch_prog_select(e->d_prog_ctl, C.ncomp, ph, p.dc_scan_opt_mode, n, s); }
     }
     if (before_output) HIPCHK(hipStreamWaitEvent(s, before_output, 0));

@@ -140,13 +140,14 @@ struct MjhProgChunk {
 // per (scan of the list, image) pair: the run / correction bits pending at the end of the scan and the total number of
 // correction bits of a refinement scan (sizes its bit stream)
 struct MjhProgPair { unsigned final_run, final_be; int fallback; unsigned corr_total; };
-struct MjhProgPE {         // device buffers of that path, [image][scan of the list][...]
+struct MjhProgPE {         // device buffers of that path, [scan of the list][image][...]
   uint16_t *len16, *run16; // bits of every block / unit (own symbols + the flush in front of it); the run it flushes
   uint16_t *tail16, *be16; // refinement scans: trailing correction bits of every block; correction bits in front of a non-empty block
   unsigned *off32, *sums, *totals;     // prefix sum of len16
   unsigned *T32, *tsums, *ttotals;     // prefix sum of tail16
   unsigned long long *ne_bits, *e_bits;   // [pair][chunk][32]: non-empty / ends-in-zeros bitmaps
   unsigned long long *ne2_bits;           // non-empty blocks + forced-flush marks = the flush points
+  unsigned *chist;                        // first-pass AC scans: [pair][chunk][256] symbol counts of the chunk (sizes its bits once the table exists)
   MjhProgPair *info;
   MjhProgChunk *chunks;
   int chunks_per_scan, nblk_pad;   // nblk_pad = chunks_per_scan * MJH_PSTAT_BLOCKS entries per pair

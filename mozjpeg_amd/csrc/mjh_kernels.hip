@@ -2907,30 +2907,7 @@ k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const unsigned long 
 // Same bits at the same offsets: the stream is identical.
 // ---------------------------------------------------------------------------------------------
 #define ENCW_WIN 4096
-template <bool LDSW>   // (two instantiations so that the window's words become ds_or and the direct path's global atomics)
-struct BitSink {
-  unsigned *words;
-  unsigned long long acc;
-  int nacc;
-  unsigned widx;
-  __device__ __forceinline__ void init(unsigned *w, unsigned bitoff) { words = w; widx = bitoff >> 5; nacc = (int)(bitoff & 31); acc = 0; }
-  __device__ __forceinline__ void put(unsigned code, int n)
-  {
-    acc = (acc << n) | (unsigned long long)(code & ((1u << n) - 1u));
-    nacc += n;
-    if (nacc >= 32) {
-      const unsigned w = (unsigned)(acc >> (nacc - 32));
-      atomicOr(&words[widx], __builtin_bswap32(w));
-      widx++;
-      nacc -= 32;
-    }
-  }
-  __device__ __forceinline__ void flush()
-  {
-    if (nacc > 0) atomicOr(&words[widx], __builtin_bswap32((unsigned)(acc << (32 - nacc))));
-  }
-  __device__ __forceinline__ unsigned bitpos() const { return widx * 32u + (unsigned)nacc; }
-};
+// (BitSink<LDSW>: mjh_device.h)
 
 template <bool COMPACT, class W>
 __device__ __forceinline__ void enc_write_block(const MjhConst &C, const MjhComp &cc, W &bw, const unsigned *s_ac, const unsigned *s_dc,

@@ -48,12 +48,13 @@ void mjh_launch_prog_reset(void *ctl, int nscans, int n, hipStream_t s);
 void mjh_launch_prog_stats(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
                            MjhHuffTable *tabs, int spi, unsigned *mpos, int mpos_per_image, int n, hipStream_t s);
 void mjh_launch_prog_stats_par(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
-                               MjhHuffTable *tabs, int spi, const MjhProgPE &pe, bool any_refine, const unsigned long long *nzmask, int n, hipStream_t s);
+                               MjhHuffTable *tabs, int spi, const MjhProgPE &pe, bool any_refine, const unsigned long long *nzmask, int n, hipStream_t s,
+                               int nacf);   // the list starts with its nacf first-pass AC scans
 void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *list, int nlist, const int *seq_list, int nseq,
                             const int *par_list, int npar, const MjhProgPE &pe, void *ctl, const void *q,
                             MjhHuffTable *tabs, int spi, unsigned *pool, size_t pool_words, const void *frame_hdr, int frame_hdr_len,
                             int multi_dht, void *outpool, size_t out_bytes, unsigned *mpos, int mpos_per_image, unsigned *ffsums, const unsigned long long *nzmask, int n, hipStream_t s,
-                            hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join);
+                            hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, int nacf);
 void mjh_launch_scan16(const void *len16, int n_per, unsigned *sums, int chunks, unsigned *totals, unsigned *off32, int npairs, hipStream_t s);
 void mjh_launch_prog_select(void *ctl, int ncomp, int phase, int dc_scan_opt_mode, int n, hipStream_t s);
 void mjh_launch_prog_concat(const void *ctl, const void *file_hdr, int file_hdr_len, const void *outpool, size_t out_bytes,

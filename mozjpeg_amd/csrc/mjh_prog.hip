@@ -802,20 +802,22 @@ k_pp_init(MjhProgPE pe, int npairs)
   if (i < npairs) { pe.info[i].final_run = 0; pe.info[i].final_be = 0; pe.info[i].fallback = 0; pe.info[i].corr_total = 0; }
 }
 
-template <bool COMPACT>
+template <bool COMPACT, int SEL>   // SEL as in k_pp_len
 __global__ void __launch_bounds__(256)
 k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
            const MjhProgCtl *__restrict__ ctl, const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask,
-           MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe)
+           MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe, int li0)
 {
   __shared__ unsigned hist[4][256];   // DC scans: [table 0 / 1]; AC scans: four interleaved copies (the hot symbols serialise the LDS atomics)
   __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64], e_bits[MJH_PSTAT_BLOCKS / 64];
   __shared__ unsigned s_corr;
-  const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const size_t pair = (size_t)img * gridDim.y + li;
+  const int img = blockIdx.z, li = li0 + blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;   // scans li0.. of the list
+  const size_t pair = (size_t)li * gridDim.z + img;   // (the pairs of a scan are contiguous: image index fastest)
   const int sidx = scan_list[li];
   const MjhProgScan sc = scans[sidx];
   const int kind = pp_kind(sc);
+  if (SEL == 1 && kind != PP_AC_FIRST) return;
+  if (SEL == 2 && kind == PP_AC_FIRST) return;
   const int nunits = pp_units(C, sc);
   const int cb = chunk * MJH_PSTAT_BLOCKS;
   if (cb >= nunits || kind == PP_DC_REFINE) return;
@@ -829,7 +831,7 @@ k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
   if (tid == 0) s_corr = 0;
   __syncthreads();
 
-  if (kind == PP_DC_FIRST) {
+  if (SEL != 1 && kind == PP_DC_FIRST) {
     // encode_mcu_DC_first jcphuff.c:468-555: category of the difference to the previous block of the component in scan order
     const bool inter = sc.ncomp > 1;
     for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
@@ -873,7 +875,7 @@ k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
 
   const MjhComp cc = C.c[sc.comp[0]];
   const int Ss = sc.Ss, Se = sc.Se;
-  const bool refine = kind == PP_AC_REFINE;
+  const bool refine = SEL == 1 ? false : (SEL == 2 ? true : kind == PP_AC_REFINE);
   const int16_t *qc = qimg + cc.coef_off;
   uint16_t *tail = pe.tail16 + pair * pe.nblk_pad + cb;
   unsigned corr = 0;
@@ -967,6 +969,7 @@ k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
   MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
   const unsigned hsum = hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid];
   if (hsum) atomicAdd(&T0->counts[tid], hsum);
+  if (SEL == 1) pe.chist[(pair * pe.chunks_per_scan + chunk) * 256 + tid] = hsum;   // k_pp_runs / k_pp_resolve add the EOBRUN symbols
 }
 
 // T at index i of a pair (exclusive prefix sum of the trailing-bit counts); the entry behind the last unit is the total
@@ -1004,7 +1007,7 @@ k_pp_carry(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
 {
   const int img = blockIdx.y, li = blockIdx.x;
   if (threadIdx.x != 0) return;
-  const size_t pair = (size_t)img * gridDim.x + li;
+  const size_t pair = (size_t)li * gridDim.y + img;
   const MjhProgScan sc = scans[scan_list[li]];
   if (prog_skip(sc, ctl + img)) return;
   const int kind = pp_kind(sc);
@@ -1026,7 +1029,7 @@ k_pp_cuts(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restri
 {
   __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64], e_bits[MJH_PSTAT_BLOCKS / 64];
   const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const size_t pair = (size_t)img * gridDim.y + li;
+  const size_t pair = (size_t)li * gridDim.z + img;
   const MjhProgScan sc = scans[scan_list[li]];
   if (prog_skip(sc, ctl + img)) return;
   const int kind = pp_kind(sc);
@@ -1058,7 +1061,7 @@ k_pp_resolve(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
              MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe)
 {
   const int img = blockIdx.y, li = blockIdx.x, lane = threadIdx.x;
-  const size_t pair = (size_t)img * gridDim.x + li;
+  const size_t pair = (size_t)li * gridDim.y + img;
   const MjhProgScan sc = scans[scan_list[li]];
   if (prog_skip(sc, ctl + img)) return;
   const int kind = pp_kind(sc);
@@ -1080,7 +1083,11 @@ k_pp_resolve(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
         const int b = c * MJH_PSTAT_BLOCKS + ch.first_ne;
         const unsigned r = pending + (unsigned)ch.first_ne;
         run[b] = (uint16_t)r;
-        if (r) T0->counts[eobrun_symbol(r, &nextra)] += 1;
+        if (r) {
+          const int sym = eobrun_symbol(r, &nextra);
+          T0->counts[sym] += 1;
+          if (!refine && pe.chist) pe.chist[(pair * pe.chunks_per_scan + c) * 256 + sym] += 1;
+        }
         if (refine) be16[b] = (uint16_t)(pp_T(pe, pair, b, true) - (last >= 0 ? pp_T(pe, pair, last, true) : 0u));
         last = c * MJH_PSTAT_BLOCKS + ch.last_ne; last_e = ch.e_last;
         pending = (unsigned)ch.e_last + (unsigned)(ch.nblk - 1 - ch.last_ne);
@@ -1113,7 +1120,7 @@ k_pp_runs(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restri
   __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64], e_bits[MJH_PSTAT_BLOCKS / 64];
   __shared__ unsigned hist[16];       // EOBRUN symbols: (nbits - 1) << 4, nbits - 1 = 0..14
   const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const size_t pair = (size_t)img * gridDim.y + li;
+  const size_t pair = (size_t)li * gridDim.z + img;
   const MjhProgScan sc = scans[scan_list[li]];
   if (prog_skip(sc, ctl + img)) return;
   const int kind = pp_kind(sc);
@@ -1142,7 +1149,10 @@ k_pp_runs(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restri
     if (cnt) { int nextra; atomicAdd(&hist[eobrun_symbol(cnt, &nextra) >> 4], 1u); }
   }
   __syncthreads();
-  if (tid < 16 && hist[tid]) atomicAdd(&tabs[(size_t)img * slots_per_image + sc.slot[0]].counts[tid << 4], hist[tid]);
+  if (tid < 16 && hist[tid]) {
+    atomicAdd(&tabs[(size_t)img * slots_per_image + sc.slot[0]].counts[tid << 4], hist[tid]);
+    if (!refine && pe.chist) pe.chist[(pair * pe.chunks_per_scan + chunk) * 256 + (tid << 4)] += hist[tid];   // (own symbols never have size 0)
+  }
   if (tid == 0) {   // first / last flush point of the chunk (real non-empty blocks and forced-flush marks) for k_pp_resolve
     MjhProgChunk *ch = pe.chunks + pair * pe.chunks_per_scan + chunk;
     int first = -1, last = -1;
@@ -1200,18 +1210,22 @@ __device__ __forceinline__ unsigned pp_dc_unit(const MjhConst &C, const MjhProgS
   return bits;
 }
 
-template <bool COMPACT>
+// SEL: 0 = every kind of scan; 1 = only the first-pass AC scans (most scans of a search; its own kernel needs half the
+// registers and no scratch, so twice the waves hide the dependent loads); 2 = the other kinds
+template <bool COMPACT, int SEL>
 __global__ void __launch_bounds__(256)
 k_pp_len(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl,
-         const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask, const MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe)
+         const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask, const MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe, int li0)
 {
   __shared__ unsigned char s_size[256];
   __shared__ unsigned s_dc[2][16];
-  const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const size_t pair = (size_t)img * gridDim.y + li;
+  const int img = blockIdx.z, li = li0 + blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;   // scans li0.. of the list
+  const size_t pair = (size_t)li * gridDim.z + img;   // (the pairs of a scan are contiguous: image index fastest)
   const int sidx = scan_list[li];
   const MjhProgScan sc = scans[sidx];
   const int kind = pp_kind(sc);
+  if (SEL == 1 && kind != PP_AC_FIRST) return;
+  if (SEL == 2 && kind == PP_AC_FIRST) return;
   const int nunits = pp_units(C, sc);
   const int cb = chunk * MJH_PSTAT_BLOCKS;
   uint16_t *len = pe.len16 + pair * pe.nblk_pad + cb;
@@ -1224,7 +1238,7 @@ k_pp_len(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restric
   if (prog_skip(sc, ct)) return;
   const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
   const int16_t *qimg = coef_q + (size_t)img * C.coefs_per_image;
-  if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) {
+  if (SEL != 1 && (kind == PP_DC_FIRST || kind == PP_DC_REFINE)) {
     if (tid < 32) {
       const int t = tid >> 4, sym = tid & 15;
       const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + (sc.slot[t] >= 0 ? sc.slot[t] : 0);
@@ -1239,7 +1253,7 @@ k_pp_len(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restric
   }
   const MjhComp cc = C.c[sc.comp[0]];
   const int Ss = sc.Ss, Se = sc.Se;
-  const bool refine = kind == PP_AC_REFINE;
+  const bool refine = SEL == 1 ? false : (SEL == 2 ? true : kind == PP_AC_REFINE);
   const MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
   const int16_t *qc = qimg + cc.coef_off;
   const uint16_t *run = pe.run16 + pair * pe.nblk_pad + cb;
@@ -1333,20 +1347,22 @@ k_pp_len(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restric
   }
 }
 
-template <bool COMPACT>
+template <bool COMPACT, int SEL>
 __global__ void __launch_bounds__(256)
 k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl,
            const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
-           unsigned *__restrict__ pool, size_t pool_words_per_image, MjhProgPE pe)
+           unsigned *__restrict__ pool, size_t pool_words_per_image, MjhProgPE pe, int li0)
 {
   __shared__ unsigned s_tab[256];   // size << 16 | code
   __shared__ unsigned s_dc[2][16];
   __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64];
-  const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const size_t pair = (size_t)img * gridDim.y + li;
+  const int img = blockIdx.z, li = li0 + blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;   // scans li0.. of the list
+  const size_t pair = (size_t)li * gridDim.z + img;   // (the pairs of a scan are contiguous: image index fastest)
   const int sidx = scan_list[li];
   const MjhProgScan sc = scans[sidx];
   const int kind = pp_kind(sc);
+  if (SEL == 1 && kind != PP_AC_FIRST) return;
+  if (SEL == 2 && kind == PP_AC_FIRST) return;
   const int nunits = pp_units(C, sc);
   const int cb = chunk * MJH_PSTAT_BLOCKS;
   const MjhProgCtl *ct = ctl + img;
@@ -1359,7 +1375,7 @@ k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
   const unsigned base = ct->scan_words_off[sidx] * 32u;
   const uint16_t *len = pe.len16 + pair * pe.nblk_pad + cb;
   const unsigned *off = pe.off32 + pair * pe.nblk_pad + cb;
-  if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) {
+  if (SEL != 1 && (kind == PP_DC_FIRST || kind == PP_DC_REFINE)) {
     if (tid < 32) {
       const int t = tid >> 4, sym = tid & 15;
       const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + (sc.slot[t] >= 0 ? sc.slot[t] : 0);
@@ -1378,7 +1394,7 @@ k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
   }
   const MjhComp cc = C.c[sc.comp[0]];
   const int Ss = sc.Ss, Se = sc.Se;
-  const bool refine = kind == PP_AC_REFINE;
+  const bool refine = SEL == 1 ? false : (SEL == 2 ? true : kind == PP_AC_REFINE);
   const MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
   const int16_t *qc = qimg + cc.coef_off;
   const uint16_t *run = pe.run16 + pair * pe.nblk_pad + cb;
@@ -1560,6 +1576,164 @@ k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
   }
 }
 
+// ---- first-pass AC scans from compact records: sizes and bits in ONE kernel ------------------------------------------
+// The bits of a chunk follow from its symbol counts (k_pp_stats<.,1> keeps them per chunk, k_pp_runs / k_pp_resolve add the
+// EOBRUN symbols of its flush points) and the code lengths, so the place of every chunk in the scan's stream is known
+// without a pass over the blocks: k_pp_chunk_bits.  k_pp_emit then sizes the blocks of a chunk, scans the sizes inside the
+// workgroup and writes the bits into a window of the stream kept in LDS -- no per-block length / offset arrays, no
+// device-wide prefix sums, and the stream receives whole words (only the two boundary words of a chunk are ORed).
+__global__ void __launch_bounds__(256)
+k_pp_chunk_bits(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl,
+                const MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe)
+{
+  __shared__ unsigned s_bits[256];
+  __shared__ unsigned sh[4];
+  const int img = blockIdx.y, li = blockIdx.x, tid = threadIdx.x;
+  const size_t pair = (size_t)li * gridDim.y + img;
+  const MjhProgScan sc = scans[scan_list[li]];
+  if (prog_skip(sc, ctl + img)) return;
+  const MjhComp cc = C.c[sc.comp[0]];
+  const int nchunks = (cc.nblk + MJH_PSTAT_BLOCKS - 1) / MJH_PSTAT_BLOCKS;
+  const MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
+  // bits of one symbol tid: its code + the value bits (size nibble) / the run bits of an EOBRUN symbol (run nibble)
+  const unsigned w = (unsigned)T0->ehufsi[tid] + (unsigned)((tid & 15) ? (tid & 15) : (tid == 0xF0 ? 0 : tid >> 4));
+  const unsigned *ch = pe.chist + pair * pe.chunks_per_scan * 256;
+  unsigned carry = 0;
+  for (int c0 = 0; c0 < nchunks; c0 += 256) {
+    const int nc = min(256, nchunks - c0);
+    s_bits[tid] = 0;
+    __syncthreads();
+    for (int c = 0; c < nc; c++) {
+      const unsigned v = ch[(size_t)(c0 + c) * 256 + tid];
+      if (v) atomicAdd(&s_bits[c], v * w);
+    }
+    __syncthreads();
+    unsigned tot;
+    const unsigned ex = block_excl_scan_256(tid < nc ? s_bits[tid] : 0u, sh, &tot);
+    if (tid < nc) pe.sums[pair * pe.chunks_per_scan + c0 + tid] = carry + ex;
+    carry += tot;
+  }
+  if (tid == 0) pe.totals[pair] = carry;
+}
+
+#define PPE_WIN 4096          // words of the LDS window (16 KB): a chunk of 2048 blocks with up to 64 bits per block on average
+template <bool LDSW>
+__device__ __forceinline__ void pp_emit_rounds(unsigned *dst, unsigned bit0, unsigned cbase, int nb, int Ss, int Se, int Al, const int16_t *__restrict__ qc,
+                                               size_t kstride, const unsigned long long *__restrict__ nzc, const uint16_t *__restrict__ run,
+                                               const unsigned long long *fp_bits, const unsigned long long *rn_bits, const unsigned *s_tab, unsigned *sh)
+{
+  const int tid = threadIdx.x;
+  const unsigned zrl = s_tab[0xF0];
+  unsigned running = cbase;
+#pragma unroll 1
+  for (int i = 0; i < MJH_PSTAT_BLOCKS / 256; i++) {
+    if (i * 256 >= nb) break;   // uniform
+    const int j = i * 256 + tid;
+    const bool has_own = j < nb && ((rn_bits[j >> 6] >> (j & 63)) & 1ull);
+    const int jj = j < nb ? j : nb - 1;
+    const unsigned long long m = has_own ? nzc[jj] : 0ull;
+    // the block's size: its own symbols ...
+    unsigned own = 0;
+    {
+      int prev = Ss - 1;
+      pp_band_nonzeros(qc + jj, kstride, m, Ss, Se, has_own, [&](int k, int v) {
+        const int a = (v < 0 ? -v : v) >> Al;
+        if (a == 0) return;
+        const int r = k - prev - 1;
+        prev = k;
+        const int nbits = bitlen((unsigned)a);
+        own += (unsigned)(r >> 4) * (zrl >> 16) + (s_tab[((r & 15) << 4) + nbits] >> 16) + (unsigned)nbits;
+      });
+    }
+    // ... and the pending run that goes out in front of a flush point (emit_eobrun jcphuff.c:409)
+    unsigned cnt = 0, fsym = 0;
+    int nextra = 0;
+    if (j < nb && ((fp_bits[j >> 6] >> (j & 63)) & 1ull)) {
+      cnt = run[j];
+      if (cnt) fsym = s_tab[eobrun_symbol(cnt, &nextra)];
+    }
+    const unsigned blen = own + (cnt ? (fsym >> 16) + (unsigned)nextra : 0u);
+    unsigned tot;
+    const unsigned ex = block_excl_scan_256(blen, sh, &tot);
+    // the same walk again (the records are in the L1 now), this time with the place of every bit known
+    BitSink<LDSW> bw;
+    bw.init(dst, running + ex - bit0);
+    if (cnt) {
+      bw.put(fsym & 0xFFFF, (int)(fsym >> 16));
+      if (nextra) bw.put(cnt & ((1u << nextra) - 1u), nextra);
+    }
+    {
+      int prev = Ss - 1;
+      pp_band_nonzeros(qc + jj, kstride, m, Ss, Se, has_own && own != 0, [&](int k, int v) {
+        const int a = (v < 0 ? -v : v) >> Al;
+        if (a == 0) return;
+        int r = k - prev - 1;
+        prev = k;
+        while (r > 15) { bw.put(zrl & 0xFFFF, (int)(zrl >> 16)); r -= 16; }
+        const int nbits = bitlen((unsigned)a);
+        const unsigned e = s_tab[(r << 4) + nbits];
+        bw.put(e & 0xFFFF, (int)(e >> 16));
+        bw.put((unsigned)(v < 0 ? ~a : a), nbits);
+      });
+    }
+    if (blen) bw.flush();
+    running += tot;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_pp_emit(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl,
+          const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
+          unsigned *__restrict__ pool, size_t pool_words_per_image, MjhProgPE pe)
+{
+  __shared__ unsigned s_tab[256];   // size << 16 | code
+  __shared__ unsigned s_win[PPE_WIN];
+  __shared__ unsigned long long fp_bits[MJH_PSTAT_BLOCKS / 64];   // flush points: real non-empty blocks + forced-flush marks
+  __shared__ unsigned long long rn_bits[MJH_PSTAT_BLOCKS / 64];   // real non-empty blocks
+  __shared__ unsigned sh[4];
+  const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;   // the list starts with these scans
+  const size_t pair = (size_t)li * gridDim.z + img;
+  const int sidx = scan_list[li];
+  const MjhProgScan sc = scans[sidx];
+  const MjhProgCtl *ct = ctl + img;
+  if (prog_skip(sc, ct)) return;
+  const MjhComp cc = C.c[sc.comp[0]];
+  const int cb = chunk * MJH_PSTAT_BLOCKS;
+  if (cb >= cc.nblk || ct->error) return;
+  const int nb = min(MJH_PSTAT_BLOCKS, cc.nblk - cb);
+  const bool last_chunk = cb + MJH_PSTAT_BLOCKS >= cc.nblk;
+  const unsigned base = ct->scan_words_off[sidx] * 32u;
+  const unsigned cbase = base + pe.sums[pair * pe.chunks_per_scan + chunk];
+  const unsigned cend = base + (last_chunk ? pe.totals[pair] : pe.sums[pair * pe.chunks_per_scan + chunk + 1]);
+  if (cend == cbase) return;        // uniform: the chunk has no bits
+  const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
+  const MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
+  const int16_t *qc = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + cb;
+  const unsigned long long *nzc = nzmask + (size_t)img * C.total_real_blocks + cc.blk_off + cb;
+  const uint16_t *run = pe.run16 + pair * pe.nblk_pad + cb;
+  unsigned *stream = pool + (size_t)img * pool_words_per_image;
+  const unsigned w0 = cbase >> 5, nw = ((cend - 1u) >> 5) - w0 + 1u;
+  const bool window = nw <= PPE_WIN;
+  s_tab[tid] = ((unsigned)T0->ehufsi[tid] << 16) | T0->ehufco[tid];
+  if (tid < MJH_PSTAT_BLOCKS / 64) {
+    fp_bits[tid] = pe.ne2_bits[(pair * pe.chunks_per_scan + chunk) * (MJH_PSTAT_BLOCKS / 64) + tid];
+    rn_bits[tid] = pe.ne_bits[(pair * pe.chunks_per_scan + chunk) * (MJH_PSTAT_BLOCKS / 64) + tid];
+  }
+  if (window) for (unsigned w = tid; w < nw; w += 256) s_win[w] = 0u;
+  __syncthreads();
+  if (window) {
+    pp_emit_rounds<true>(s_win, w0 << 5, cbase, nb, sc.Ss, sc.Se, Al, qc, (size_t)cc.kstride, nzc, run, fp_bits, rn_bits, s_tab, sh);
+    __syncthreads();
+    for (unsigned w = tid; w < nw; w += 256) {
+      const unsigned v = s_win[w];
+      if (!v) continue;                                  // (the pool is zeroed)
+      if (w == 0 || w == nw - 1) atomicOr(&stream[w0 + w], v);   // shared with the neighbouring chunk / the end of the scan
+      else stream[w0 + w] = v;
+    }
+  } else   // more than 64 bits per block on average: straight into the stream
+    pp_emit_rounds<false>(stream, 0u, cbase, nb, sc.Ss, sc.Se, Al, qc, (size_t)cc.kstride, nzc, run, fp_bits, rn_bits, s_tab, sh);
+}
+
 __global__ void __launch_bounds__(64)
 k_pp_finish(const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, MjhProgCtl *__restrict__ ctl,
             const MjhHuffTable *__restrict__ tabs, int slots_per_image, unsigned *__restrict__ pool, size_t pool_words_per_image,
@@ -1567,7 +1741,7 @@ k_pp_finish(const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_
 {
   if (threadIdx.x != 0) return;
   const int img = blockIdx.y, li = blockIdx.x;
-  const size_t pair = (size_t)img * gridDim.x + li;
+  const size_t pair = (size_t)li * gridDim.y + img;
   const int sidx = scan_list[li];
   const MjhProgScan sc = scans[sidx];
   MjhProgCtl *ct = ctl + img;
@@ -1987,15 +2161,22 @@ void mjh_launch_prog_stats(const MjhConst &C, const void *scans, const int *list
 
 // statistics of the parallel chain (every scan of the list has no restart interval)
 void mjh_launch_prog_stats_par(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
-                               MjhHuffTable *tabs, int spi, const MjhProgPE &pe, bool any_refine, const unsigned long long *nzmask, int n, hipStream_t s)
+                               MjhHuffTable *tabs, int spi, const MjhProgPE &pe, bool any_refine, const unsigned long long *nzmask, int n, hipStream_t s, int nacf)
 {
   if (nlist <= 0) return;
   const dim3 gchunks(pe.chunks_per_scan, nlist, n), gpairs(nlist, n);
   hipLaunchKernelGGL(k_pp_init, dim3((nlist * n + 63) / 64), dim3(64), 0, s, pe, nlist * n);
-  if (nzmask) hipLaunchKernelGGL((k_pp_stats<true>), gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, (const MjhProgCtl *)ctl, (const int16_t *)q,
-                                 nzmask, tabs, spi, pe);
-  else hipLaunchKernelGGL((k_pp_stats<false>), gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, (const MjhProgCtl *)ctl, (const int16_t *)q,
-                          nzmask, tabs, spi, pe);
+  const char *es = getenv("MJH_PP_SPLITK");       // A/B knob: 0 = one kernel for every kind of scan
+  const void *sv = scans; const int16_t *qv = (const int16_t *)q;
+  if (nzmask && !(es && atoi(es) == 0)) {         // the list starts with its nacf first-pass AC scans
+    if (nacf > 0) hipLaunchKernelGGL((k_pp_stats<true, 1>), dim3(pe.chunks_per_scan, nacf, n), dim3(256), 0, s, C, (const MjhProgScan *)sv, list, (const MjhProgCtl *)ctl, qv,
+                                     nzmask, tabs, spi, pe, 0);
+    if (nlist > nacf) hipLaunchKernelGGL((k_pp_stats<true, 2>), dim3(pe.chunks_per_scan, nlist - nacf, n), dim3(256), 0, s, C, (const MjhProgScan *)sv, list, (const MjhProgCtl *)ctl, qv,
+                                         nzmask, tabs, spi, pe, nacf);
+  } else if (nzmask) hipLaunchKernelGGL((k_pp_stats<true, 0>), gchunks, dim3(256), 0, s, C, (const MjhProgScan *)sv, list, (const MjhProgCtl *)ctl, qv,
+                                 nzmask, tabs, spi, pe, 0);
+  else hipLaunchKernelGGL((k_pp_stats<false, 0>), gchunks, dim3(256), 0, s, C, (const MjhProgScan *)sv, list, (const MjhProgCtl *)ctl, qv,
+                          nzmask, tabs, spi, pe, 0);
   if (any_refine) mjh_launch_scan16(pe.tail16, pe.nblk_pad, pe.tsums, pe.chunks_per_scan, pe.ttotals, pe.T32, nlist * n, s);
   hipLaunchKernelGGL(k_pp_carry, gpairs, dim3(64), 0, s, C, (const MjhProgScan *)scans, list, (const MjhProgCtl *)ctl, pe);
   hipLaunchKernelGGL(k_pp_cuts, gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, (const MjhProgCtl *)ctl, pe);
@@ -2008,7 +2189,7 @@ void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *lis
                             MjhHuffTable *tabs, int spi, unsigned *pool, size_t pool_words, const void *frame_hdr, int frame_hdr_len,
                             int multi_dht, void *outpool, size_t out_bytes, unsigned *mpos, int mpos_per_image, unsigned *ffsums,
                             const unsigned long long *nzmask, int n, hipStream_t s,
-                            hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join)
+                            hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, int nacf)
 {
   hipLaunchKernelGGL(k_prog_alloc, dim3(n), dim3(256), 0, s, C, (const MjhProgScan *)scans, list, nlist, (MjhProgCtl *)ctl,
                      (const MjhHuffTable *)tabs, spi, pool_words, out_bytes, n);
@@ -2026,15 +2207,31 @@ void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *lis
   }
   if (npar > 0) {
     const dim3 gchunks(pe.chunks_per_scan, npar, n), gpairs(npar, n);
-    if (nzmask) hipLaunchKernelGGL((k_pp_len<true>), gchunks, dim3(256), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhProgCtl *)ctl, (const int16_t *)q,
-                                   nzmask, (const MjhHuffTable *)tabs, spi, pe);
-    else hipLaunchKernelGGL((k_pp_len<false>), gchunks, dim3(256), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhProgCtl *)ctl, (const int16_t *)q,
-                            nzmask, (const MjhHuffTable *)tabs, spi, pe);
-    mjh_launch_scan16(pe.len16, pe.nblk_pad, pe.sums, pe.chunks_per_scan, pe.totals, pe.off32, npar * n, ps);
-    if (nzmask) hipLaunchKernelGGL((k_pp_write<true>), gchunks, dim3(256), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhProgCtl *)ctl, (const int16_t *)q,
-                                   nzmask, (const MjhHuffTable *)tabs, spi, pool, pool_words, pe);
-    else hipLaunchKernelGGL((k_pp_write<false>), gchunks, dim3(256), 0, ps, C, (const MjhProgScan *)scans, par_list, (const MjhProgCtl *)ctl, (const int16_t *)q,
-                            nzmask, (const MjhHuffTable *)tabs, spi, pool, pool_words, pe);
+    const char *es = getenv("MJH_PP_SPLITK");       // A/B knob: 0 = one kernel for every kind of scan
+    const bool splitk = nzmask && !(es && atoi(es) == 0);
+    const MjhProgScan *sv = (const MjhProgScan *)scans; const MjhProgCtl *cv = (const MjhProgCtl *)ctl; const int16_t *qv = (const int16_t *)q;
+    const MjhHuffTable *tv = (const MjhHuffTable *)tabs;
+    const dim3 gacf(pe.chunks_per_scan, nacf, n), goth(pe.chunks_per_scan, npar - nacf, n);   // the list starts with its nacf first-pass AC scans
+    if (splitk) {
+      // first-pass AC scans (the list starts with them): k_pp_chunk_bits + k_pp_emit; the other scans: sizes, prefix sums, bits
+      const size_t po = (size_t)nacf * n;      // their pairs come first
+      if (nacf > 0) {
+        hipLaunchKernelGGL(k_pp_chunk_bits, dim3(nacf, n), dim3(256), 0, ps, C, sv, par_list, cv, tv, spi, pe);
+        hipLaunchKernelGGL(k_pp_emit, gacf, dim3(256), 0, ps, C, sv, par_list, cv, qv, nzmask, tv, spi, pool, pool_words, pe);
+      }
+      if (npar > nacf) {
+        hipLaunchKernelGGL((k_pp_len<true, 2>), goth, dim3(256), 0, ps, C, sv, par_list, cv, qv, nzmask, tv, spi, pe, nacf);
+        mjh_launch_scan16(pe.len16 + po * pe.nblk_pad, pe.nblk_pad, pe.sums + po * pe.chunks_per_scan, pe.chunks_per_scan, pe.totals + po,
+                          pe.off32 + po * pe.nblk_pad, (npar - nacf) * n, ps);
+        hipLaunchKernelGGL((k_pp_write<true, 2>), goth, dim3(256), 0, ps, C, sv, par_list, cv, qv, nzmask, tv, spi, pool, pool_words, pe, nacf);
+      }
+    } else {
+      if (nzmask) hipLaunchKernelGGL((k_pp_len<true, 0>), gchunks, dim3(256), 0, ps, C, sv, par_list, cv, qv, nzmask, tv, spi, pe, 0);
+      else hipLaunchKernelGGL((k_pp_len<false, 0>), gchunks, dim3(256), 0, ps, C, sv, par_list, cv, qv, nzmask, tv, spi, pe, 0);
+      mjh_launch_scan16(pe.len16, pe.nblk_pad, pe.sums, pe.chunks_per_scan, pe.totals, pe.off32, npar * n, ps);
+      if (nzmask) hipLaunchKernelGGL((k_pp_write<true, 0>), gchunks, dim3(256), 0, ps, C, sv, par_list, cv, qv, nzmask, tv, spi, pool, pool_words, pe, 0);
+      else hipLaunchKernelGGL((k_pp_write<false, 0>), gchunks, dim3(256), 0, ps, C, sv, par_list, cv, qv, nzmask, tv, spi, pool, pool_words, pe, 0);
+    }
     hipLaunchKernelGGL(k_pp_finish, gpairs, dim3(64), 0, ps, (const MjhProgScan *)scans, par_list, (MjhProgCtl *)ctl, (const MjhHuffTable *)tabs, spi,
                        pool, pool_words, pe);
   }

@@ -156,7 +156,7 @@ def test_committed_bench_line_carries_the_contract_fields():
     the driver contract names, with the metric string of BASELINE.json"""
     import glob
     import json
-    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_batch64.json")))
+    lines = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r*_bench_batch64.json")) if "_c" not in os.path.basename(p).split("_bench")[0])
     assert lines
     j = json.loads(open(lines[-1]).read())
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
@@ -178,3 +178,30 @@ def test_committed_bench_line_carries_the_contract_fields():
     assert abs(j["value"] - px / (j["ms_per_step"] * 1e-3) / 1e6) / j["value"] < 0.01
     assert r["kernel_ms"] <= j["ms_per_step"]
     assert j["bit_exact"]["ok"] and j["bit_exact"]["checked"] == j["bit_exact"]["identical"]
+
+
+def test_committed_bench_lines_of_the_other_configurations_name_their_own_dominant_interval():
+    """every committed bench line (the metric and the other BASELINE configurations) reports as roofline.kernel the largest
+    entry of its OWN per-kernel table (side-stream kernels excluded: they overlap the interval they are listed beside), and
+    the traffic figure comes from PMC passes of the same configuration or is null"""
+    import glob
+    import json
+    newest = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03*bench*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r03*configs.jsonl"))):
+        for ln in open(path).read().strip().splitlines():
+            try:
+                j = json.loads(ln)
+            except ValueError:
+                continue
+            if "roofline" in j and j.get("n_gpus") == 1:
+                newest[j["config"]["config_key"]] = (path, j)
+    assert "metric" in newest
+    for key, (path, j) in newest.items():
+        r = j["roofline"]
+        table = {k: v for k, v in r["kernel_ms_per_call(untimed pass, every kernel bracketed)"].items()
+                 if "side stream" not in k and not k.startswith("join(")}
+        top = max(table.values())
+        assert table[r["kernel"]] >= 0.9 * top, (path, key, r["kernel"])     # (two passes: near-ties may swap)
+        src = r.get("traffic_source") or ""
+        if r["traffic"] is not None and key != "metric":
+            assert "_%s_" % key in src, (path, src)

@@ -144,3 +144,37 @@ def test_device_entry_right_behind_a_host_batch_and_split_batches():
     names = [k for k, _ in enc.kernel_times()]
     assert "trellis_ac" in names and "dct_quant" in names and len(names) == len(set(names))
     enc.close()
+
+
+def test_stage_commit_and_gather_of_member_encoders():
+    """What the libjpeg shim does with concurrent clients: every client stages its image in the pinned buffer of an encoder
+    of its own, sends the finished rows on their way while it is still writing (mjh_stage_commit), and one batch encoder
+    gathers the members' images on the device and encodes them together (mjh_encode_gather)."""
+    import ctypes as C
+    w, h = 512, 300
+    for kw in (dict(quality=75, baseline=True), dict(quality=80, fastcrush=True)):
+        p = M.make_params(w, h, **kw)
+        frames = [O.synthetic_frame(w, h, 900 + i) for i in range(5)]
+        refs = [_ref(w, h, kw, f) for f in frames]
+        members = [M.Encoder(p, max_batch=1) for _ in range(5)]
+        batch = M.Encoder(p, max_batch=8)
+        L = M.lib()
+        for rnd in range(3):                                   # the members' double buffers flip with every gather
+            order = list(range(5)) if rnd != 1 else [3, 1, 4]  # any subset, any order
+            for i in order:
+                buf, n = C.c_void_p(), C.c_size_t()
+                assert L.mjh_host_staging(members[i]._h, C.byref(buf), C.byref(n)) == 0
+                dst = np.frombuffer((C.c_uint8 * (w * h * 3)).from_address(buf.value), np.uint8).reshape(h, w, 3)
+                rows = [0, 77, 200, h] if i % 2 else [0, h]    # some members commit in chunks, some not at all
+                for a, b in zip(rows[:-1], rows[1:]):
+                    dst[a:b] = frames[i][a:b]
+                    if b < h:
+                        assert L.mjh_stage_commit(members[i]._h, b * w * 3) == 0
+            arr = (C.c_void_p * len(order))(*[members[i]._h for i in order])
+            assert L.mjh_encode_gather(batch._h, arr, len(order)) == 0, L.mjh_last_error()
+            assert batch.collect(age=0) == [refs[i] for i in order]
+        # a member is still a normal encoder afterwards
+        assert members[2].encode_host(frames[2]) == [refs[2]]
+        for m in members:
+            m.close()
+        batch.close()
