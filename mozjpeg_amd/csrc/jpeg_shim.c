@@ -566,6 +566,41 @@ static void __attribute__((destructor)) shim_report(void)
             1e3 * shim_t[0] / shim_images, 1e3 * shim_t[1] / shim_images, 1e3 * shim_t[2] / shim_images, 1e3 * shim_t[3] / shim_images);
 }
 
+/* a row into the pinned staging buffer.  The buffer is only ever read by the device's copy engine, so the row is written
+ * with non-temporal stores where the CPU has them (x86-64 AVX2): no read-for-ownership of the destination lines -- half
+ * the DRAM traffic of a plain memcpy, which is what bounds many client threads feeding one GPU -- and the client's own
+ * working set stays in its caches.  MOZJPEG_HIP_NT=0 keeps memcpy.  stage_fence() before the rows are handed on. */
+#if defined(__x86_64__) && defined(__GNUC__)
+#include <immintrin.h>
+static int stage_nt = -1;
+__attribute__((target("avx2"))) static void stage_copy_nt(unsigned char *dst, const unsigned char *src, size_t n)
+{
+  size_t head = (32 - ((uintptr_t)dst & 31)) & 31;
+  if (head > n) head = n;
+  if (head) { memcpy(dst, src, head); dst += head; src += head; n -= head; }
+  for (; n >= 128; n -= 128, dst += 128, src += 128) {
+    const __m256i a = _mm256_loadu_si256((const __m256i *)src), b = _mm256_loadu_si256((const __m256i *)(src + 32));
+    const __m256i c = _mm256_loadu_si256((const __m256i *)(src + 64)), d = _mm256_loadu_si256((const __m256i *)(src + 96));
+    _mm256_stream_si256((__m256i *)dst, a); _mm256_stream_si256((__m256i *)(dst + 32), b);
+    _mm256_stream_si256((__m256i *)(dst + 64), c); _mm256_stream_si256((__m256i *)(dst + 96), d);
+  }
+  if (n) memcpy(dst, src, n);
+}
+static void stage_copy(void *dst, const void *src, size_t n)
+{
+  if (stage_nt < 0) {
+    const char *e = getenv("MOZJPEG_HIP_NT");
+    stage_nt = (e ? atoi(e) != 0 : 1) && __builtin_cpu_supports("avx2");
+  }
+  if (stage_nt && n >= 1024) stage_copy_nt((unsigned char *)dst, (const unsigned char *)src, n);
+  else memcpy(dst, src, n);
+}
+static void stage_fence(void) { if (stage_nt > 0) _mm_sfence(); }
+#else
+static void stage_copy(void *dst, const void *src, size_t n) { memcpy(dst, src, n); }
+static void stage_fence(void) { }
+#endif
+
 static JDIMENSION write_rows(j_compress_ptr cinfo, void **scanlines, JDIMENSION num_lines, int precision, const char *name)
 {
   shim_state *s = find_state(cinfo, 0);
@@ -590,10 +625,13 @@ static JDIMENSION write_rows(j_compress_ptr cinfo, void **scanlines, JDIMENSION 
      * way to the device, so that the PCIe copy runs under the client's production of the rest of the image */
     const double t0 = shim_timing ? shim_now() : 0.0;
     for (i = 0; i < num_lines; i++) {
-      memcpy(s->pixels + (size_t)(cinfo->next_scanline + i) * s->row_bytes, scanlines[i], s->row_bytes);
-      if (((cinfo->next_scanline + i + 1) % STAGE_ROWS) == 0 && cinfo->next_scanline + i + 1 < cinfo->image_height)
+      stage_copy(s->pixels + (size_t)(cinfo->next_scanline + i) * s->row_bytes, scanlines[i], s->row_bytes);
+      if (((cinfo->next_scanline + i + 1) % STAGE_ROWS) == 0 && cinfo->next_scanline + i + 1 < cinfo->image_height) {
+        stage_fence();
         (void)mjh_stage_commit(s->enc, (size_t)(cinfo->next_scanline + i + 1) * s->row_bytes);
+      }
     }
+    stage_fence();
     if (shim_timing) shim_acc(0, shim_now() - t0, 0);
   }
   cinfo->next_scanline += num_lines;

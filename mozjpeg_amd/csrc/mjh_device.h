@@ -114,6 +114,41 @@ struct BitWriter {
 };
 
 
+// One round of the byte-stuffing passes (256 threads x 8 stream words -> up to 16 KB of output): the stuffed bytes are laid
+// out in LDS exactly as they will lie in memory (same alignment mod 4) and leave as whole, coalesced 32-bit stores -- a
+// thread's own bytes start at an arbitrary byte offset, so writing them directly costs one scattered byte store each.
+// dst0 / total: first output byte of the round and the round's output length (uniform); my_dst: where this thread's first
+// byte goes; nvalid: how many of its 32 input bytes exist; keep: bit (4 * i + b) set = byte b of word i is the 0xFF of a
+// marker (no zero byte behind it).  lds: STUFF_LDS_WORDS words.  Two barriers.
+#define STUFF_LDS_WORDS (4096 + 2)
+__device__ __forceinline__ void stuff_store_round(uint8_t *__restrict__ o, unsigned dst0, unsigned total, unsigned my_dst, const unsigned (&w)[8],
+                                                  int nvalid, unsigned keep, unsigned *lds)
+{
+  uint8_t *l8 = reinterpret_cast<uint8_t *>(lds);
+  const unsigned shift = (unsigned)((uintptr_t)(o + dst0) & 3u);
+  unsigned at = my_dst - dst0 + shift;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const unsigned byte = (w[i] >> (8 * b)) & 0xFFu;    // little-endian word = stream byte order
+      if (4 * i + b < nvalid) {
+        l8[at++] = (uint8_t)byte;
+        if (byte == 0xFFu && !((keep >> (4 * i + b)) & 1u)) l8[at++] = 0;
+      }
+    }
+  }
+  __syncthreads();
+  uint8_t *g = o + dst0 - shift;                           // 4-byte aligned
+  const unsigned end = shift + total, nw = (end + 3u) >> 2;
+  for (unsigned k = threadIdx.x; k < nw; k += 256) {
+    if (4 * k >= shift && 4 * k + 4 <= end) reinterpret_cast<unsigned *>(g)[k] = lds[k];
+    else
+      for (unsigned b = 4 * k; b < 4 * k + 4; b++) if (b >= shift && b < end) g[b] = l8[b];
+  }
+  __syncthreads();
+}
+
 // the same writer for a window of the stream kept in LDS (the words become ds_or) or, LDSW = false, for the stream itself
 template <bool LDSW>   // (two instantiations so that the window's words become ds_or and the direct path's global atomics)
 struct BitSink {

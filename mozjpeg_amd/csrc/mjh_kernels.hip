@@ -3168,6 +3168,7 @@ k_stuff_write(const unsigned *__restrict__ stream, size_t stream_words_per_image
               const unsigned *__restrict__ mpos_all, int nseg)
 {
   __shared__ unsigned sh[4];
+  __shared__ unsigned s_out[STUFF_LDS_WORDS];
   const int img = blockIdx.y;
   const unsigned nbytes = (totals[img] + 7) >> 3;
   const unsigned nwords = (nbytes + 3) >> 2;
@@ -3190,22 +3191,12 @@ k_stuff_write(const unsigned *__restrict__ stream, size_t stream_words_per_image
     }
     s += cnt;
   }
-  unsigned ex = block_excl_scan_256(s, sh, nullptr) + sums[(size_t)img * chunks_per_image + chunk];
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const unsigned wi = base + i;
-    if (wi < nwords) {
-      unsigned dst = wi * 4 + ex;
-#pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const unsigned byte = (w[i] >> (8 * b)) & 0xFF;   // little-endian word = stream byte order
-        if (wi * 4 + b < nbytes) {
-          o[dst++] = (uint8_t)byte;
-          if (byte == 0xFF && !((mk >> (4 * i + b)) & 1u)) { o[dst++] = 0; ex++; }
-        }
-      }
-    }
-  }
+  unsigned tot;
+  const unsigned before = sums[(size_t)img * chunks_per_image + chunk];      // stuffed bytes in front of the chunk
+  const unsigned ex = block_excl_scan_256(s, sh, &tot) + before;
+  const unsigned cfirst = chunk * SCAN_CHUNK * 4u, rend = min(cfirst + SCAN_CHUNK * 4u, nbytes);   // input bytes of the round
+  const int nvalid = base * 4u < rend ? (int)min(32u, rend - base * 4u) : 0;
+  stuff_store_round(o, cfirst + before, rend - cfirst + tot, base * 4u + ex, w, nvalid, mk, s_out);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     const unsigned stuffed = nbytes + ff_totals[img];

@@ -1938,6 +1938,7 @@ k_prog_stuff(const MjhProgScan *__restrict__ scans, const int *__restrict__ scan
              size_t out_bytes_per_image, const unsigned *__restrict__ mpos_pool, int mpos_per_image, unsigned *__restrict__ ffsums)
 {
   __shared__ unsigned sh[4];
+  __shared__ unsigned s_out[WRITE ? STUFF_LDS_WORDS : 1];
   const int img = blockIdx.z, li = blockIdx.y, part = blockIdx.x;
   const int sidx = scan_list[li];
   MjhProgCtl *ct = ctl + img;
@@ -1969,23 +1970,19 @@ k_prog_stuff(const MjhProgScan *__restrict__ scans, const int *__restrict__ scan
       }
     }
     unsigned tot;
-    unsigned ex = block_excl_scan_256(s, sh, &tot) + carry;
+    const unsigned ex = block_excl_scan_256(s, sh, &tot) + carry;
     if (WRITE) {
+      unsigned keep = 0;
+      if (nrst) {
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const unsigned wi = base + i;
-        if (wi < w1) {
-          unsigned dst = wi * 4 + ex;
+        for (int i = 0; i < 8; i++)
 #pragma unroll
-          for (int b = 0; b < 4; b++) {
-            const unsigned byte = (w[i] >> (8 * b)) & 0xFF;
-            if (wi * 4 + b < nbytes) {
-              o[dst++] = (uint8_t)byte;
-              if (byte == 0xFF && !(nrst && prog_is_marker(mp, nrst, wi * 4 + b))) { o[dst++] = 0; ex++; }
-            }
-          }
-        }
+          for (int b = 0; b < 4; b++)
+            if (((w[i] >> (8 * b)) & 0xFFu) == 0xFFu && prog_is_marker(mp, nrst, (base + i) * 4 + b)) keep |= 1u << (4 * i + b);
       }
+      const unsigned rend = min(min(w1, cb + 2048u) * 4u, nbytes);          // input bytes of the round: [cb * 4, rend)
+      const int nvalid = base * 4u < rend ? (int)min(32u, rend - base * 4u) : 0;
+      stuff_store_round(o, cb * 4u + carry, rend - cb * 4u + tot, base * 4u + ex, w, nvalid, keep, s_out);
     }
     carry += tot;
   }
