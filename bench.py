@@ -413,13 +413,15 @@ def main():
 
     # warm-up; its first steps run with every kernel bracketed (profiling level 1) so that the DOMINANT interval of the
     # schedule is measured on this workload, not assumed: the timed region then brackets exactly that one (level 2)
-    nprobe = min(2, max(0, args.warmup - 2))
-    focus = None
+    nprobe = min(3, max(0, args.warmup - 2))
+    focus, probe = None, {}
     for _ in range(max(0, args.warmup - 1 - nprobe)):
         step()
     if nprobe:
         enc.set_profiling(1)
-        for _ in range(nprobe):
+        for i in range(nprobe):
+            if i == 1:
+                enc.set_profiling(1)   # the first bracketed step creates the events: its intervals include that; start over
             step()
         probe = dict(enc.kernel_times())
         main_stream = {k: v for k, v in probe.items() if "side stream" not in k and not k.startswith("join(")}
@@ -585,6 +587,7 @@ def main():
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "kernel_ms": round(dom_ms, 4),
+                         "focus_probe_ms": {k: round(v, 4) for k, v in sorted(probe.items(), key=lambda kv: -kv[1])[:4]},
                          "kernel_ms_source": "HIP events around the interval in every encode call of the timed region; the interval was chosen as "
                                              "the largest of a per-kernel pass over the warm-up steps; with MJH_SPLIT=2 a batch runs as two "
                                              "concurrent image ranges and kernel_ms is the sum of the interval's launches over the ranges",

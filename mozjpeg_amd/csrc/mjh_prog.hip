@@ -1913,6 +1913,7 @@ k_prog_header(const MjhProgScan *__restrict__ scans, const int *__restrict__ sca
 // equal share of the scan's words; k_prog_stuff_count leaves the number of stuffed zero bytes of every share behind so
 // that k_prog_stuff knows where its share starts in the output
 #define PROG_STUFF_SPLIT 8
+#define PROG_CONCAT_PARTS 32
 __device__ __forceinline__ bool prog_is_marker(const unsigned *mp, int nrst, unsigned pos)
 { // the 0xFF of an RSTn marker is not entropy-coded data: no zero byte behind it (binary search in the sorted positions)
   int lo = 0, hi = nrst - 1;
@@ -2112,20 +2113,31 @@ k_prog_concat(const MjhProgCtl *__restrict__ ctl, const uint8_t *__restrict__ fi
               const uint8_t *__restrict__ outpool, size_t out_bytes_per_image, uint8_t *__restrict__ out, size_t out_stride,
               unsigned *__restrict__ sizes)
 {
-  const int img = blockIdx.x;
+  // PROG_CONCAT_PARTS workgroups per image, each copies its share of the file's byte range (the layout is a walk over at
+  // most MJH_MAX_PROG_SCANS sizes, repeated by every workgroup)
+  const int img = blockIdx.y, part = blockIdx.x;
   const MjhProgCtl *ct = ctl + img;
   uint8_t *o = out + (size_t)img * out_stride;
-  if (ct->error) { if (threadIdx.x == 0) sizes[img] = 0; return; }
-  for (int i = threadIdx.x; i < file_hdr_len; i += 256) o[i] = file_hdr[i];
+  if (ct->error) { if (threadIdx.x == 0 && part == 0) sizes[img] = 0; return; }
+  size_t total = file_hdr_len;
+  for (int s = 0; s < ct->norder; s++) total += ct->scan_size[ct->order[s]];
+  const size_t per = ((total + gridDim.x - 1) / gridDim.x + 255) & ~(size_t)255;
+  const size_t lo = (size_t)part * per, hi = lo + per < total ? lo + per : total;
+  if (part == 0) {
+    for (int i = threadIdx.x; i < file_hdr_len; i += 256) o[i] = file_hdr[i];
+    if (threadIdx.x == 0) { o[total] = 0xFF; o[total + 1] = 0xD9; sizes[img] = (unsigned)(total + 2); }
+  }
   size_t pos = file_hdr_len;
-  for (int s = 0; s < ct->norder; s++) {
+  for (int s = 0; s < ct->norder && pos < hi; s++) {
     const int sidx = ct->order[s];
-    const uint8_t *src = outpool + (size_t)img * out_bytes_per_image + ct->scan_out_off[sidx];
-    const unsigned n = ct->scan_size[sidx];
-    for (unsigned i = threadIdx.x; i < n; i += 256) o[pos + i] = src[i];
+    const size_t n = ct->scan_size[sidx];
+    if (pos + n > lo) {
+      const uint8_t *src = outpool + (size_t)img * out_bytes_per_image + ct->scan_out_off[sidx];
+      const size_t a = lo > pos ? lo - pos : 0, b = hi - pos < n ? hi - pos : n;
+      for (size_t i = a + threadIdx.x; i < b; i += 256) o[pos + i] = src[i];
+    }
     pos += n;
   }
-  if (threadIdx.x == 0) { o[pos] = 0xFF; o[pos + 1] = 0xD9; sizes[img] = (unsigned)(pos + 2); }
 }
 
 __global__ void __launch_bounds__(64)
@@ -2254,6 +2266,6 @@ void mjh_launch_prog_select(void *ctl, int ncomp, int phase, int dc_scan_opt_mod
 void mjh_launch_prog_concat(const void *ctl, const void *file_hdr, int file_hdr_len, const void *outpool, size_t out_bytes,
                             void *out, size_t out_stride, unsigned *sizes, int n, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_prog_concat, dim3(n), dim3(256), 0, s, (const MjhProgCtl *)ctl, (const uint8_t *)file_hdr, file_hdr_len,
+  hipLaunchKernelGGL(k_prog_concat, dim3(PROG_CONCAT_PARTS, n), dim3(256), 0, s, (const MjhProgCtl *)ctl, (const uint8_t *)file_hdr, file_hdr_len,
                      (const uint8_t *)outpool, out_bytes, (uint8_t *)out, out_stride, sizes);
 }
