@@ -149,7 +149,7 @@ INTERVAL_KERNELS = {
     "huff_encode": ("k_enc_len", "k_enc_write", "k_chunk_sums", "k_scan_sums", "k_offsets", "k_zero_stream", "k_seg_extra"),
     "byte_stuff": ("k_ff_chunk_sums", "k_stuff_write", "k_finish_bits"),
     "stats_ac(final)": ("k_stats_ac",), "stats_dc(final)": ("k_stats_dc",),
-    "prog_encode": ("k_pp_len", "k_pp_write", "k_pp_finish", "k_prog_", "k_chunk_sums", "k_scan_sums", "k_offsets"),
+    "prog_encode": ("k_pp_len", "k_pp_write", "k_pp_emit", "k_pp_chunk_bits", "k_pp_finish", "k_prog_", "k_chunk_sums", "k_scan_sums", "k_offsets"),
     "prog_stats": ("k_pp_init", "k_pp_stats", "k_pp_carry", "k_pp_cuts", "k_pp_runs", "k_pp_resolve", "k_prog_scan"),
 }
 

@@ -276,6 +276,7 @@ struct mjh_encoder {
   int copy_prio = 0;
   int fastdiv_all = 0;               // every table in use has q <= 255: the kernels divide by 8q with one multiply-high (MjhQuant.mdiv)
   int dc_mode = 0;
+  int dc_stats_side = 1;             // the final DC statistics run on the side stream behind the DC trellis (MJH_DC_STATS_SIDE=0: main stream)
   int dc_window_ok = 0;              // every component's DC quantizer step 8q >= 40: the DC trellis may use its sliding-window kernel
   int trellis_v3 = 4;                // passes per tile of the tile-sorted first tier (MJH_TRELLIS_V3; 0 = the general kernel)
   int dqt_off[4] = { -1, -1, -1, -1 };      // file offset of the first entry of every 8-bit DQT table
@@ -864,6 +865,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   for (int i = 0; i < C.ncomp; i++) if (p->quantval[p->quant_tbl_no[i]][0] < 5) e->dc_window_ok = 0;
   e->dc_window_ok |= (getenv("MJH_DC_V2") ? atoi(getenv("MJH_DC_V2")) : 1) << 8;   // bits 8..: which DC trellis kernel (A/B runs)
   if (const char *v = getenv("MJH_DC_MODE")) e->dc_mode = atoi(v);
+  if (const char *v = getenv("MJH_DC_STATS_SIDE")) e->dc_stats_side = atoi(v);
   HIPCHK_E(hipMalloc((void **)&e->d_len16, B * (size_t)C.total_mcu_blocks * 2));
   HIPCHK_E(hipMalloc((void **)&e->d_off32, B * (size_t)C.total_mcu_blocks * 4));
   e->chunks = (C.total_mcu_blocks + 2047) / 2048;
@@ -1255,6 +1257,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   // one-component view of the geometry (MjhComp carries absolute offsets, so the view addresses the same buffers).
   const int nloops = p.trellis_quant ? (p.trellis_num_loops > 1 ? p.trellis_num_loops : 1) : 0;
   bool final_ac_counted = false;     // the last trellis pass has counted the AC statistics of the final coefficients
+  bool final_dc_counted = false;     // ... and the side stream the DC statistics, right behind the DC trellis (under the AC kernel)
   auto trellis_pass = [&](const MjhConst &CV, const int *sl_dc_seq, const int *sl_dc_prog, const int *sl_ac, const int *crst,
                           const mjh_encoder::PList *plt, int Ss, int Se, bool first_pass, bool last_loop, int qstride) -> int {
     if (!first_pass)   // fresh (zero) statistics for this pass
@@ -1307,6 +1310,11 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       }
       mjh_launch_trellis_dc(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, e->side_stream, e->dc_window_ok);   // (the DC entries never change: image 0's tables serve all)
       if (pr.enabled && e->profiling == 1) { HIPCHK(hipEventRecord(e->side_events[2 * e->prof_calls + 1], e->side_stream)); e->side_timed = true; }
+      if (!e->progressive && p.optimize_coding && last_loop && nbands == 1 && qstride == 0 && !ext_eob && e->dc_stats_side) {
+        // the final DC statistics need nothing but the DC trellis's result: counted here, they cost no time of their own
+        mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, fin_dc, 1, zero4, n, e->side_stream);
+        final_dc_counted = true;
+      }
       HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
     }
     const bool extended = nbands > 1 || ext_eob || qstride != 0;
@@ -1445,8 +1453,10 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       pr.mark("stats_ac(final)");
       mjh_launch_stats_ac(C, e->d_q, nzm, e->d_tabs, spi, fin_ac, 1, n, s);
     }
-    pr.mark("stats_dc(final)");
-    mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, fin_dc, 1, zero4, n, s);
+    if (!final_dc_counted) {
+      pr.mark("stats_dc(final)");
+      mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, fin_dc, 1, zero4, n, s);
+    }
     pr.mark("gen_tables(final)");
     mjh_launch_gen_tables(e->d_tabs, spi, e->dht_slots, e->ndht, n, s);
   }
