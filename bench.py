@@ -417,12 +417,14 @@ def main():
     focus, probe = None, {}
     for _ in range(max(0, args.warmup - 1 - nprobe)):
         step()
+        enc.sync()     # (the encoder tunes itself from what the previous batch reported: let every warm-up batch finish)
     if nprobe:
         enc.set_profiling(1)
         for i in range(nprobe):
             if i == 1:
                 enc.set_profiling(1)   # the first bracketed step creates the events: its intervals include that; start over
             step()
+            enc.sync()
         probe = dict(enc.kernel_times())
         main_stream = {k: v for k, v in probe.items() if "side stream" not in k and not k.startswith("join(")}
         if main_stream:

@@ -41,6 +41,23 @@ def test_baseline_configurations_at_full_size_match_the_reference(name, w, h, kw
         assert got[i] == want, "%s frame %d differs from the %s (%d vs %d bytes)" % (name, i, kind, len(got[i]), len(want))
 
 
+@pytest.mark.parametrize("kw", [dict(quality=100, sample=(1, 1)), dict(quality=97), dict(quality=100, sample=(1, 1), fastcrush=True)])
+def test_dense_progressive_scans_take_the_direct_bit_writer(kw):
+    """Noise at very high quality: the first-pass AC scans of a 2048-block chunk exceed the 16 KB LDS window of k_pp_emit
+    (more than 64 bits per block on average), so the chunk is written straight into the stream; several chunks per scan,
+    so the chunk offsets from the per-chunk symbol counts (k_pp_chunk_bits) are exercised across chunk borders too."""
+    w, h = 768, 512                    # 6144 luma blocks = 3 chunks
+    rng = np.random.RandomState(99)
+    frames = np.stack([rng.randint(0, 256, (h, w, 3)).astype(np.uint8), O.synthetic_frame(w, h, 5)])
+    enc = M.Encoder(M.make_params(w, h, **kw), max_batch=len(frames))
+    got = enc.encode_host(frames)
+    enc.close()
+    for i, f in enumerate(frames):
+        want, kind = _reference(f, kw)
+        assert got[i] == want, "frame %d differs from the %s (%d vs %d bytes)" % (i, kind, len(got[i]), len(want))
+    assert len(got[0]) * 8 > 150 * (w // 8) * (h // 8)      # the noise frame is as dense as the test needs
+
+
 @pytest.mark.parametrize("devices", [None, [0, 0], [0, 0, 0]])
 @pytest.mark.parametrize("kw", [dict(baseline=True), dict(quality=85)])
 def test_one_process_pool_deals_images_over_devices(devices, kw):
