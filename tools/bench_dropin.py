@@ -54,7 +54,7 @@ def cjpeg_wall(mode, ppm, args, out):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", default="1,4,16")
-    ap.add_argument("--images", type=int, default=8)
+    ap.add_argument("--images", type=int, default=10)
     ap.add_argument("--ref-images", type=int, default=1)
     ap.add_argument("--tmp", default="/tmp")
     a = ap.parse_args()
@@ -65,7 +65,7 @@ if __name__ == "__main__":
         same = set()
         for mode in ("preload", "standalone"):
             for t in ths:
-                d = mt(mode, t, a.images, w, h, 75)
+                d = mt(mode, t, a.images * (4 if t == 1 else 2), w, h, 75)   # (images PER THREAD; a fraction of a second in all)
                 res["library_client"].append(d); same.add(d.get("fnv1a_first"))
                 print(json.dumps(d), file=sys.stderr, flush=True)
         d = mt("reference", max(ths), a.ref_images, w, h, 75)     # CPU: one image per thread on every requested thread
