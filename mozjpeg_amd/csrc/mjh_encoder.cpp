@@ -666,7 +666,7 @@ static void free_all(mjh_encoder *e)
   e->pad_streams.clear();
   if (e->ev_split_fork) (void)hipEventDestroy(e->ev_split_fork);
   if (e->ev_null_in) (void)hipEventDestroy(e->ev_null_in);
-  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->pe.chist, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_nq8, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->pe.chist, e->pe.rmask, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_nq8, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos };
   for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -1121,6 +1121,10 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
         HIPCHK_E(hipMalloc((void **)&e->pe.ne2_bits, nch * (MJH_PSTAT_BLOCKS / 64) * 8));
         HIPCHK_E(hipMalloc((void **)&e->pe.info, pairs * sizeof(MjhProgPair)));
         HIPCHK_E(hipMalloc((void **)&e->pe.chist, nch * 256 * 4));   // symbol counts per chunk: 1 KB per (scan, image, chunk of 2048 blocks)
+        int maxoth = 0;   // scans of a list that are not first-pass AC scans (refinement and DC scans): the refinement masks of their blocks
+        for (const mjh_encoder::PList *pl : { &e->pl_phase[0], &e->pl_phase[1], &e->pl_phase[2], &e->pl_phase[3] }) maxoth = pl->npar - pl->nacf > maxoth ? pl->npar - pl->nacf : maxoth;
+        const char *rv = getenv("MJH_PP_RMASK");   // A/B knob: 0 = the sizes and the bits of refinement scans walk the records again
+        if (maxoth > 0 && e->use_compact && !(rv && atoi(rv) == 0)) HIPCHK_E(hipMalloc((void **)&e->pe.rmask, B * (size_t)maxoth * 3 * e->pe.nblk_pad * 8));
       }
     }
     HIPCHK_E(hipMalloc((void **)&e->d_lists, e->h_lists.size() * sizeof(int) + 16));

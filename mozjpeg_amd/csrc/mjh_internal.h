@@ -147,6 +147,7 @@ struct MjhProgPE {         // device buffers of that path, [scan of the list][im
   unsigned *T32, *tsums, *ttotals;     // prefix sum of tail16
   unsigned long long *ne_bits, *e_bits;   // [pair][chunk][32]: non-empty / ends-in-zeros bitmaps
   unsigned long long *ne2_bits;           // non-empty blocks + forced-flush marks = the flush points
+  unsigned long long *rmask;              // refinement scans: [pair - first pair of the other kinds][3][nblk_pad] newly non-zero / already non-zero / sign-or-correction-bit masks of every block, kept by the statistics pass for the sizes and the bits
   unsigned *chist;                        // first-pass AC scans: [pair][chunk][256] symbol counts of the chunk (sizes its bits once the table exists)
   MjhProgPair *info;
   MjhProgChunk *chunks;

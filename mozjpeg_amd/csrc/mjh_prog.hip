@@ -731,6 +731,17 @@ __device__ __forceinline__ PPRefine pp_refine_block_compact(const int16_t *__res
   return pp_refine_finish<COUNT>(R, Ss, Se, s_size, hist);
 }
 
+// ... or from the masks the statistics pass of the same scan kept (pe.rmask: three arrays of nblk_pad entries per pair)
+template <bool COUNT>
+__device__ __forceinline__ PPRefine pp_refine_block_cached(const unsigned long long *__restrict__ rm, size_t stride, bool active,
+                                                           int Ss, int Se, const unsigned char *s_size, unsigned *hist)
+{
+  PPRefine R;
+  const unsigned long long nw = active ? rm[0] : 0ull, nz = active ? rm[stride] : 0ull, sc = active ? rm[2 * stride] : 0ull;
+  R.newm = nw; R.nzm = nz; R.posm = sc & nw; R.corrm = sc & nz; R.tailm = 0; R.own = 0;
+  return pp_refine_finish<COUNT>(R, Ss, Se, s_size, hist);
+}
+
 template <bool COUNT>
 __device__ __forceinline__ PPRefine pp_refine_block(const int (&x)[64], int Ss, int Se, int Al, const unsigned char *s_size, unsigned *hist)
 {
@@ -904,6 +915,10 @@ k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
       } else {
         const PPRefine R = pp_refine_block_compact<true>(qs, (size_t)cc.kstride, m, j < nb, Ss, Se, Al, nullptr, hist[tid & 3]);
         ne = R.ne; E = R.E; tc = R.tail_cnt;
+        if (SEL == 2 && pe.rmask && j < nb) {      // the sizes and the bits of this scan are made from these masks, not from the records again
+          unsigned long long *rm = pe.rmask + (pair - (size_t)li0 * gridDim.z) * 3 * pe.nblk_pad + cb + j;
+          rm[0] = R.newm; rm[pe.nblk_pad] = R.nzm; rm[2 * (size_t)pe.nblk_pad] = R.posm | R.corrm;
+        }
         corr += (unsigned)__popcll(R.nzm);
       }
       if (j < nb) {
@@ -1277,7 +1292,8 @@ k_pp_len(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restric
     if (COMPACT) {
       if (__builtin_amdgcn_ballot_w64(has_own) != 0ull) {
         const int jb = cb + (j < nb ? j : nb - 1);
-        const unsigned long long m = nzmask[(size_t)img * C.total_real_blocks + cc.blk_off + jb];
+        const bool cached = SEL == 2 && pe.rmask != nullptr;
+        const unsigned long long m = cached ? 0ull : nzmask[(size_t)img * C.total_real_blocks + cc.blk_off + jb];
         if (!refine) {
           int prev = Ss - 1;
           const unsigned zrl = s_size[0xF0];
@@ -1291,7 +1307,8 @@ k_pp_len(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restric
           });
           ne = prev != Ss - 1;
         } else {
-          const PPRefine R = pp_refine_block_compact<false>(qc + jb, (size_t)cc.kstride, m, has_own, Ss, Se, Al, s_size, nullptr);
+          const PPRefine R = cached ? pp_refine_block_cached<false>(pe.rmask + (pair - (size_t)li0 * gridDim.z) * 3 * pe.nblk_pad + jb, (size_t)pe.nblk_pad, has_own, Ss, Se, s_size, nullptr)
+                                    : pp_refine_block_compact<false>(qc + jb, (size_t)cc.kstride, m, has_own, Ss, Se, Al, s_size, nullptr);
           ne = R.ne; own = R.own;
         }
         if (!ne || !has_own) own = 0;
@@ -1461,7 +1478,10 @@ k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
       continue;
     }
     PPRefine Rc;
-    if (COMPACT) Rc = pp_refine_block_compact<false>(qc + jb, (size_t)cc.kstride, cmask, has_data, Ss, Se, Al, reinterpret_cast<const unsigned char *>(s_tab), nullptr);
+    if (COMPACT) {
+      if (SEL == 2 && pe.rmask) Rc = pp_refine_block_cached<false>(pe.rmask + (pair - (size_t)li0 * gridDim.z) * 3 * pe.nblk_pad + jb, (size_t)pe.nblk_pad, has_data, Ss, Se, reinterpret_cast<const unsigned char *>(s_tab), nullptr);
+      else Rc = pp_refine_block_compact<false>(qc + jb, (size_t)cc.kstride, cmask, has_data, Ss, Se, Al, reinterpret_cast<const unsigned char *>(s_tab), nullptr);
+    }
     if (!has_data) continue;
     const bool flush_point = (ne_bits[j >> 6] >> (j & 63)) & 1ull;
     if (!refine) {

@@ -13,6 +13,11 @@ if [ -f "$O/bench_c3.log" ]; then
   python tools/rocprof_summary.py "$(db c3_stats)" > "${P}_c3_kernel_stats_batch32.csv"
   python tools/pmc_traffic.py "$(db c3_fetch)" "$(db c3_write)" 32 $((3840*2160*3)) > "${P}_c3_pmc_hbm_traffic_batch32.json"
 fi
+# traffic of the other configurations: frames per encode call, input bytes per frame (the calibration kernel's input)
+for spec in "c2 64 $((1920*1080*3))" "c4 128 $((1920*1080*3))" "c5 1 $((8192*8192*6))" "c5t 1 $((8192*8192*3))"; do
+  set -- $spec
+  [ -n "$(db $1_fetch)" ] && [ -n "$(db $1_write)" ] && python tools/pmc_traffic.py "$(db $1_fetch)" "$(db $1_write)" $2 $3 > "${P}_$1_pmc_hbm_traffic_batch$2.json"
+done
 : > "${P}_configs.jsonl"
 for c in c2 c4 c5 c5t; do [ -f "$O/bench_$c.log" ] && tail -1 "$O/bench_$c.log" >> "${P}_configs.jsonl"; done
 [ -s "${P}_configs.jsonl" ] || rm -f "${P}_configs.jsonl"

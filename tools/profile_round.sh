@@ -26,6 +26,11 @@ if [ "$3" = "all" ]; then
   for c in c2 c4 c5 c5t; do
     timeout 400 python bench.py --config $c --no-cpu-baseline --no-host-leg > "$O/bench_$c.log" 2>&1; tail -1 "$O/bench_$c.log" | cut -c1-300
   done
+  # traffic passes of the other configurations (bench.py's roofline.traffic is looked up per configuration)
+  for c in c2 c4 c5 c5t; do
+    timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$O" -o ${c}_fetch -- python bench.py --config $c --steps 2 --warmup 1 $Q > "$O/${c}_fetch.log" 2>&1
+    timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$O" -o ${c}_write -- python bench.py --config $c --steps 2 --warmup 1 $Q > "$O/${c}_write.log" 2>&1
+  done
   timeout 200 rocprofv3 --kernel-trace --stats -d "$O" -o c5_stats -- python bench.py --config c5 --steps 5 --warmup 2 $Q > "$O/c5_stats.log" 2>&1
   timeout 200 rocprofv3 --kernel-trace --stats -d "$O" -o c5t_stats -- python bench.py --config c5t --steps 5 --warmup 2 $Q > "$O/c5t_stats.log" 2>&1
   timeout 600 python tools/bench_dropin.py > "$O/dropin.json" 2> "$O/dropin.err"; tail -5 "$O/dropin.err"
