@@ -819,7 +819,8 @@ k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
            const MjhProgCtl *__restrict__ ctl, const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask,
            MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe, int li0)
 {
-  __shared__ unsigned hist[4][256];   // DC scans: [table 0 / 1]; AC scans: four interleaved copies (the hot symbols serialise the LDS atomics)
+  constexpr int NH = SEL == 1 ? 16 : 4;   // (first-pass AC scans: a handful of symbols takes most of the counts)
+  __shared__ unsigned hist[NH][256];   // DC scans: [table 0 / 1]; AC scans: NH interleaved copies (the hot symbols serialise the LDS atomics)
   __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64], e_bits[MJH_PSTAT_BLOCKS / 64];
   __shared__ unsigned s_corr;
   const int img = blockIdx.z, li = li0 + blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;   // scans li0.. of the list
@@ -837,7 +838,8 @@ k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
   if (prog_skip(sc, ct)) return;
   const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
   const int16_t *qimg = coef_q + (size_t)img * C.coefs_per_image;
-  hist[0][tid] = 0; hist[1][tid] = 0; hist[2][tid] = 0; hist[3][tid] = 0;
+#pragma unroll
+  for (int c = 0; c < NH; c++) hist[c][tid] = 0;
   if (tid < MJH_PSTAT_BLOCKS / 64) { ne_bits[tid] = 0; e_bits[tid] = 0; }
   if (tid == 0) s_corr = 0;
   __syncthreads();
@@ -901,7 +903,7 @@ k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
       const unsigned long long m = nzmask[(size_t)img * C.total_real_blocks + cc.blk_off + cb + (j < nb ? j : nb - 1)];
       if (!refine) {
         int prev = Ss - 1;
-        unsigned *hh = hist[tid & 3];
+        unsigned *hh = hist[tid & (NH - 1)];
         pp_band_nonzeros(qs, (size_t)cc.kstride, m, Ss, Se, j < nb, [&](int k, int v) {
           const int a = (v < 0 ? -v : v) >> Al;
           if (a == 0) return;
@@ -982,7 +984,9 @@ k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
     if (refine && s_corr) atomicAdd(&pe.info[pair].corr_total, s_corr);
   }
   MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
-  const unsigned hsum = hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid];
+  unsigned hsum = 0;
+#pragma unroll
+  for (int c = 0; c < NH; c++) hsum += hist[c][tid];
   if (hsum) atomicAdd(&T0->counts[tid], hsum);
   if (SEL == 1) pe.chist[(pair * pe.chunks_per_scan + chunk) * 256 + tid] = hsum;   // k_pp_runs / k_pp_resolve add the EOBRUN symbols
 }
@@ -2206,7 +2210,11 @@ void mjh_launch_prog_stats_par(const MjhConst &C, const void *scans, const int *
                                  nzmask, tabs, spi, pe, 0);
   else hipLaunchKernelGGL((k_pp_stats<false, 0>), gchunks, dim3(256), 0, s, C, (const MjhProgScan *)sv, list, (const MjhProgCtl *)ctl, qv,
                           nzmask, tabs, spi, pe, 0);
-  if (any_refine) mjh_launch_scan16(pe.tail16, pe.nblk_pad, pe.tsums, pe.chunks_per_scan, pe.ttotals, pe.T32, nlist * n, s);
+  if (any_refine) {   // prefix sums of the trailing correction bits: only refinement scans have any, and they sit behind the first-pass AC scans
+    const size_t po = (nzmask && !(es && atoi(es) == 0)) ? (size_t)nacf * n : 0;
+    mjh_launch_scan16(pe.tail16 + po * pe.nblk_pad, pe.nblk_pad, pe.tsums + po * pe.chunks_per_scan, pe.chunks_per_scan, pe.ttotals + po,
+                      pe.T32 + po * pe.nblk_pad, nlist * n - (int)po, s);
+  }
   hipLaunchKernelGGL(k_pp_carry, gpairs, dim3(64), 0, s, C, (const MjhProgScan *)scans, list, (const MjhProgCtl *)ctl, pe);
   hipLaunchKernelGGL(k_pp_cuts, gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, (const MjhProgCtl *)ctl, pe);
   hipLaunchKernelGGL(k_pp_runs, gchunks, dim3(256), 0, s, C, (const MjhProgScan *)scans, list, (const MjhProgCtl *)ctl, tabs, spi, pe);
