@@ -85,6 +85,34 @@ __device__ __forceinline__ unsigned block_excl_scan_256(unsigned v, unsigned *sh
   return base + inc - v;
 }
 
+// inclusive prefix sum over the 64 lanes of a wave: four DPP row shifts (lanes in front of the row read 0), then the totals
+// of the rows in front (lanes 15, 31, 47) through scalar registers
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v)
+{
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);   // row_shr:8
+  const int t0 = __builtin_amdgcn_readlane(x, 15), t1 = __builtin_amdgcn_readlane(x, 31), t2 = __builtin_amdgcn_readlane(x, 47);
+  const int row = (int)(threadIdx.x & 63) >> 4;
+  x += row == 0 ? 0 : (row == 1 ? t0 : (row == 2 ? t0 + t1 : t0 + t1 + t2));
+  return (unsigned)x;
+}
+
+// exclusive prefix within a 256-thread workgroup with ONE barrier: sh holds 8 words, `parity` alternates between
+// consecutive calls (a wave cannot be two calls ahead of another: every call has its barrier)
+__device__ __forceinline__ unsigned block_excl_scan_256_1b(unsigned v, unsigned *sh, int parity, unsigned *total)
+{
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned inc = wave_incl_scan(v);
+  if (lane == 63) sh[parity * 4 + w] = inc;
+  __syncthreads();
+  const unsigned a = sh[parity * 4], b = sh[parity * 4 + 1], c = sh[parity * 4 + 2], d = sh[parity * 4 + 3];
+  *total = a + b + c + d;
+  return (w == 0 ? 0u : (w == 1 ? a : (w == 2 ? a + b : a + b + c))) + inc - v;
+}
+
 
 // bit writer: ORs big-endian bit strings into a zero-initialised word array
 struct BitWriter {

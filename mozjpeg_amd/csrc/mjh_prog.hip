@@ -1654,6 +1654,13 @@ __device__ __forceinline__ void pp_emit_rounds(unsigned *dst, unsigned bit0, uns
     if (i * 256 >= nb) break;   // uniform
     const int j = i * 256 + tid;
     const bool has_own = j < nb && ((rn_bits[j >> 6] >> (j & 63)) & 1ull);
+    const bool is_fp = j < nb && ((fp_bits[j >> 6] >> (j & 63)) & 1ull);
+    if (__builtin_amdgcn_ballot_w64(has_own || is_fp) == 0ull) {   // a wave of empty blocks (most waves of a sparse band): only the scan
+      unsigned tot0;
+      (void)block_excl_scan_256_1b(0u, sh, i & 1, &tot0);
+      running += tot0;
+      continue;
+    }
     const int jj = j < nb ? j : nb - 1;
     const unsigned long long m = has_own ? nzc[jj] : 0ull;
     // the block's size: its own symbols ...
@@ -1672,13 +1679,14 @@ __device__ __forceinline__ void pp_emit_rounds(unsigned *dst, unsigned bit0, uns
     // ... and the pending run that goes out in front of a flush point (emit_eobrun jcphuff.c:409)
     unsigned cnt = 0, fsym = 0;
     int nextra = 0;
-    if (j < nb && ((fp_bits[j >> 6] >> (j & 63)) & 1ull)) {
+    if (is_fp) {
       cnt = run[j];
       if (cnt) fsym = s_tab[eobrun_symbol(cnt, &nextra)];
     }
     const unsigned blen = own + (cnt ? (fsym >> 16) + (unsigned)nextra : 0u);
     unsigned tot;
-    const unsigned ex = block_excl_scan_256(blen, sh, &tot);
+    const unsigned ex = block_excl_scan_256_1b(blen, sh, i & 1, &tot);
+    if (__builtin_amdgcn_ballot_w64(blen != 0u) == 0ull) { running += tot; continue; }
     // the same walk again (the records are in the L1 now), this time with the place of every bit known
     BitSink<LDSW> bw;
     bw.init(dst, running + ex - bit0);
@@ -1714,7 +1722,7 @@ k_pp_emit(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restri
   __shared__ unsigned s_win[PPE_WIN];
   __shared__ unsigned long long fp_bits[MJH_PSTAT_BLOCKS / 64];   // flush points: real non-empty blocks + forced-flush marks
   __shared__ unsigned long long rn_bits[MJH_PSTAT_BLOCKS / 64];   // real non-empty blocks
-  __shared__ unsigned sh[4];
+  __shared__ unsigned sh[8];
   const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;   // the list starts with these scans
   const size_t pair = (size_t)li * gridDim.z + img;
   const int sidx = scan_list[li];
