@@ -58,6 +58,21 @@ def test_dense_progressive_scans_take_the_direct_bit_writer(kw):
     assert len(got[0]) * 8 > 150 * (w // 8) * (h // 8)      # the noise frame is as dense as the test needs
 
 
+def test_progressive_scans_of_more_than_256_chunks():
+    """A 36-Mpixel 4:4:4 frame: 565 504 blocks per component = 277 chunks of 2048 per scan, so k_pp_chunk_bits walks its
+    chunk offsets in more than one round of 256 and the per-pair arrays are indexed far beyond the 4K sizes"""
+    w = h = 6016
+    tile = O.synthetic_frame(512, 512, 77)
+    frame = np.ascontiguousarray(np.tile(tile, (12, 12, 1))[:h, :w])
+    frame[::7, ::5, 1] ^= 0x55                      # (no two tiles alike)
+    kw = dict(quality=60, sample=(1, 1))
+    enc = M.Encoder(M.make_params(w, h, **kw), max_batch=1)
+    got = enc.encode_host(frame[None])[0]
+    enc.close()
+    want, kind = _reference(frame, kw)
+    assert got == want, "differs from the %s (%d vs %d bytes)" % (kind, len(got), len(want))
+
+
 @pytest.mark.parametrize("devices", [None, [0, 0], [0, 0, 0]])
 @pytest.mark.parametrize("kw", [dict(baseline=True), dict(quality=85)])
 def test_one_process_pool_deals_images_over_devices(devices, kw):
