@@ -381,10 +381,12 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
   const int br = blk / cc.wib, bc = blk - br * cc.wib;
   const T *src = planes + (size_t)img * C.planes_per_image + cc.plane_off + (size_t)(br * 8) * cc.pw + bc * 8;
   int d[64];
+  unsigned ff = 0;     // 8-bit samples: some byte of the block is 255 (the only value that reaches maxsample after the level shift)
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     if (!W12) {
       const uint2 v = *reinterpret_cast<const uint2 *>(src + (size_t)r * cc.pw);
+      ff |= ((~v.x - 0x01010101u) & v.x) | ((~v.y - 0x01010101u) & v.y);     // bit 7 of a byte set: that byte (or one above a 255) is 255
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         d[r * 8 + i] = (int)((v.x >> (8 * i)) & 0xFF) - 128;
@@ -404,8 +406,10 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
   if (C.deringing) {
     const int maxsample = 127;
     int sum = 0, cnt = 0;
+    if (W12 || (ff & 0x80808080u) != 0u) {   // (most 8-bit blocks have no saturated sample: the word test above spares them 64 compares)
 #pragma unroll
-    for (int i = 0; i < 64; i++) { sum += d[i]; cnt += (d[i] >= maxsample); }
+      for (int i = 0; i < 64; i++) { sum += d[i]; cnt += (d[i] >= maxsample); }
+    }
     if (cnt != 0 && cnt != 64) {
 #pragma unroll
       for (int i = 0; i < 64; i++) lds[i][lane] = (dcol_t)d[i];
