@@ -95,6 +95,36 @@ def main():
                 sst = np.take_along_axis(stp, order, 1)
                 tot += sst.reshape(sst.shape[0], T // 64, 64).max(2).sum()
             print("sorted by pred(c=%.1f) tile %4d: wave-steps %.0f  efficiency %.3f" % (cc, T, tot, ideal / tot))
+    # What a producer-side placement could do without knowing the tile's counts in advance (ROUND_NOTES "next" 1): two
+    # buckets by a FIXED threshold on nq -- heavy blocks fill the tile from the front, light ones from the back (two atomic
+    # counters per tile) -- so that every pass of the trellis reads ONE line per plane row instead of four
+    ideal = sum(np.where(nq > QN, 0, st).sum() for nq, st in zip(allnq, allst)) / 64.0
+    T = 256
+    for thr in (2, 3, 4, 6, 8, 10):
+        tot = 0
+        for nq, st in zip(allnq, allst):
+            nqp, stp = pad(nq, T).reshape(-1, T), pad(st, T).reshape(-1, T)
+            stp = np.where(nqp > QN, 0, stp)
+            heavy = nqp >= thr
+            # stable partition: heavy first in natural order, then light in reverse natural order (filled from the back)
+            idx = np.arange(T)[None, :].repeat(nqp.shape[0], 0)
+            key = np.where(heavy, idx, 2 * T - idx)
+            order = np.argsort(key, axis=1, kind="stable")
+            sst = np.take_along_axis(stp, order, 1)
+            tot += sst.reshape(sst.shape[0], T // 64, 64).max(2).sum()
+        print("two buckets (nq >= %2d in front) tile %4d: wave-steps %.0f  efficiency %.3f" % (thr, T, tot, ideal / tot))
+    # three buckets with a guessed split of the tile (heavy from the front, light from the back, middle from slot 96 upward and
+    # spilling wherever room is left): modelled as a sort by bucket number only
+    for t1, t2 in ((3, 8), (4, 10), (2, 6), (4, 8)):
+        tot = 0
+        for nq, st in zip(allnq, allst):
+            nqp, stp = pad(nq, T).reshape(-1, T), pad(st, T).reshape(-1, T)
+            stp = np.where(nqp > QN, 0, stp)
+            b = (nqp < t2).astype(np.int32) + (nqp < t1).astype(np.int32)
+            order = np.argsort(b, axis=1, kind="stable")
+            sst = np.take_along_axis(stp, order, 1)
+            tot += sst.reshape(sst.shape[0], T // 64, 64).max(2).sum()
+        print("three buckets (nq >= %d | >= %d | rest) tile %4d: wave-steps %.0f  efficiency %.3f" % (t2, t1, T, tot, ideal / tot))
     print("blocks", tot_blocks)
 
 
