@@ -35,6 +35,17 @@ static int fail(int code, const char *fmt, ...)
   return code;
 }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MJH_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+// device memory starts out zeroed: no kernel may depend on that, but whatever a first call reads before it was written
+// (padding entries, table slots of unused components) is then the same in every process instead of the previous
+// tenant's bytes
+template <class T> static hipError_t mjh_dmalloc(T **p, size_t bytes)
+{
+  const hipError_t rc = hipMalloc(reinterpret_cast<void **>(p), bytes);   // (the one real allocation call of this file)
+  if (rc != hipSuccess) return rc;
+  if (!bytes) return hipSuccess;
+  const hipError_t rm = hipMemsetAsync(*p, 0, bytes, 0);
+  return rm != hipSuccess ? rm : hipStreamSynchronize(0);   // (the encoder's streams do not wait for the null stream)
+}
 
 extern "C" const char *mjh_last_error(void) { return g_err; }
 // (for mjh_pool.cpp, which is otherwise built on the public ABI: lets its argument checks leave a message too)
@@ -824,22 +835,22 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   const size_t B = (size_t)max_batch;
   const size_t bps = C.precision == 12 ? 2 : 1;   // bytes per sample
   e->pix_image_bytes = (size_t)C.W * C.H * C.px_size * bps;
-  HIPCHK_E(hipMalloc((void **)&e->d_planes, B * C.planes_per_image * bps));
-  HIPCHK_E(hipMalloc((void **)&e->d_uq, B * C.coefs_per_image * 2));
-  HIPCHK_E(hipMalloc((void **)&e->d_q, B * C.coefs_per_image * 2));
-  HIPCHK_E(hipMalloc((void **)&e->d_quant, sizeof(MjhQuant) * (p->trellis_quant && p->trellis_q_opt ? B : 1)));
-  HIPCHK_E(hipMalloc((void **)&e->d_quant_init, sizeof(MjhQuant)));
-  HIPCHK_E(hipMalloc((void **)&e->d_tabs, B * e->spi * sizeof(MjhHuffTable)));
-  HIPCHK_E(hipMalloc((void **)&e->d_tabs_init, B * e->spi * sizeof(MjhHuffTable)));
-  HIPCHK_E(hipMalloc((void **)&e->d_lambda, B * C.total_real_blocks * sizeof(float)));
-  HIPCHK_E(hipMalloc((void **)&e->d_back, B * (size_t)C.total_real_blocks * 16));
-  HIPCHK_E(hipMalloc((void **)&e->d_worklist, 256 + B * (size_t)C.total_real_blocks * 12));   // (+ one 16-byte header per view)
-  HIPCHK_E(hipMalloc((void **)&e->d_worklist2, 256 + B * (size_t)C.total_real_blocks * 12));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_planes, B * C.planes_per_image * bps));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_uq, B * C.coefs_per_image * 2));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_q, B * C.coefs_per_image * 2));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_quant, sizeof(MjhQuant) * (p->trellis_quant && p->trellis_q_opt ? B : 1)));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_quant_init, sizeof(MjhQuant)));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_tabs, B * e->spi * sizeof(MjhHuffTable)));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_tabs_init, B * e->spi * sizeof(MjhHuffTable)));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_lambda, B * C.total_real_blocks * sizeof(float)));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_back, B * (size_t)C.total_real_blocks * 16));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_worklist, 256 + B * (size_t)C.total_real_blocks * 12));   // (+ one 16-byte header per view)
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_worklist2, 256 + B * (size_t)C.total_real_blocks * 12));
   if (p->trellis_quant && p->trellis_eob_opt) {
-    HIPCHK_E(hipMalloc(&e->d_eob_cost, B * (size_t)C.total_real_blocks * 8));
-    HIPCHK_E(hipMalloc((void **)&e->d_eob_has, B * (size_t)C.total_real_blocks * 4));
+    HIPCHK_E(mjh_dmalloc(&e->d_eob_cost, B * (size_t)C.total_real_blocks * 8));
+    HIPCHK_E(mjh_dmalloc((void **)&e->d_eob_has, B * (size_t)C.total_real_blocks * 4));
   }
-  if (p->trellis_quant && p->trellis_q_opt) HIPCHK_E(hipMalloc((void **)&e->d_qsums, B * 4 * 64 * 2 * sizeof(long long)));
+  if (p->trellis_quant && p->trellis_q_opt) HIPCHK_E(mjh_dmalloc((void **)&e->d_qsums, B * 4 * 64 * 2 * sizeof(long long)));
   {
     // sequential mode, one plain trellis round: the trellis hands compact records to the final statistics, the bit-length
     // and the bit-writing pass (MJH_COMPACT=0 keeps the one-plane-per-position form; both are bit-identical)
@@ -849,12 +860,12 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     if (e->progressive && (p->restart_interval || p->restart_in_rows)) restart_scans = true;
     e->use_compact = !(v && atoi(v) == 0) && p->trellis_quant && nl == 1 && e->nbands == 1 && !p->trellis_eob_opt && !p->trellis_q_opt &&
                      (e->progressive ? !restart_scans : !(e->fuse_mask & 2));
-    if (e->use_compact) HIPCHK_E(hipMalloc((void **)&e->d_nzmask, B * (size_t)C.total_real_blocks * sizeof(unsigned long long)));
-    if (e->use_compact && p->trellis_quant) HIPCHK_E(hipMalloc((void **)&e->d_nq8, B * (size_t)C.total_real_blocks));
+    if (e->use_compact) HIPCHK_E(mjh_dmalloc((void **)&e->d_nzmask, B * (size_t)C.total_real_blocks * sizeof(unsigned long long)));
+    if (e->use_compact && p->trellis_quant) HIPCHK_E(mjh_dmalloc((void **)&e->d_nq8, B * (size_t)C.total_real_blocks));
   }
   if (p->trellis_quant) {   // room for a quarter of all blocks (typically 1-2 % overflow); the rest would be read from the planes
     e->dense_cap = (unsigned)(B * (size_t)C.total_real_blocks / 4 + 1024);
-    HIPCHK_E(hipMalloc((void **)&e->d_dense, (size_t)e->dense_cap * 128));
+    HIPCHK_E(mjh_dmalloc((void **)&e->d_dense, (size_t)e->dense_cap * 128));
   }
   if (const char *v = getenv("MJH_TRELLIS_VARIANT")) { e->trellis_variant = atoi(v); e->trellis_adapt = false; }
   HIPCHK_E(hipHostMalloc((void **)&e->h_defer, 64, hipHostMallocDefault));
@@ -866,8 +877,8 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   e->dc_window_ok |= (getenv("MJH_DC_V2") ? atoi(getenv("MJH_DC_V2")) : 1) << 8;   // bits 8..: which DC trellis kernel (A/B runs)
   if (const char *v = getenv("MJH_DC_MODE")) e->dc_mode = atoi(v);
   if (const char *v = getenv("MJH_DC_STATS_SIDE")) e->dc_stats_side = atoi(v);
-  HIPCHK_E(hipMalloc((void **)&e->d_len16, B * (size_t)C.total_mcu_blocks * 2));
-  HIPCHK_E(hipMalloc((void **)&e->d_off32, B * (size_t)C.total_mcu_blocks * 4));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_len16, B * (size_t)C.total_mcu_blocks * 2));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_off32, B * (size_t)C.total_mcu_blocks * 4));
   e->chunks = (C.total_mcu_blocks + 2047) / 2048;
   // worst case per block: DC 16+11, 63 x (16+10) = 1665 bits -> 53 words (12-bit: 16+15, 63 x (16+14) -> 61 words)
   size_t words = (size_t)C.total_mcu_blocks * (C.precision == 12 ? 61 : 53) + 64;
@@ -875,14 +886,14 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   if (words > (size_t)1 << 27) words = (size_t)1 << 27;   // bit offsets are 32-bit
   e->stream_words = (words + 63) & ~(size_t)63;
   e->ff_chunks = (int)((e->stream_words + 2047) / 2048);
-  HIPCHK_E(hipMalloc((void **)&e->d_sums, B * e->chunks * sizeof(unsigned)));
-  HIPCHK_E(hipMalloc((void **)&e->d_ffsums, B * e->ff_chunks * sizeof(unsigned)));
-  HIPCHK_E(hipMalloc((void **)&e->d_totals, B * sizeof(unsigned)));
-  HIPCHK_E(hipMalloc((void **)&e->d_fftotals, B * sizeof(unsigned)));
-  HIPCHK_E(hipMalloc((void **)&e->d_stream, B * e->stream_words * 4 + 4096));   // slack: a bit writer may touch two words past its last offset
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_sums, B * e->chunks * sizeof(unsigned)));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_ffsums, B * e->ff_chunks * sizeof(unsigned)));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_totals, B * sizeof(unsigned)));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_fftotals, B * sizeof(unsigned)));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_stream, B * e->stream_words * 4 + 4096));   // slack: a bit writer may touch two words past its last offset
   e->out_stride = ((size_t)2048 + e->stream_words * 8 + 255) & ~(size_t)255;
-  HIPCHK_E(hipMalloc((void **)&e->d_out, B * e->out_stride));
-  HIPCHK_E(hipMalloc((void **)&e->d_sizes, B * sizeof(unsigned)));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_out, B * e->out_stride));
+  HIPCHK_E(mjh_dmalloc((void **)&e->d_sizes, B * sizeof(unsigned)));
   {
     const int nmcu = C.mcus_per_row * C.mcu_rows;
     e->nseg = C.restart_interval ? (nmcu + C.restart_interval - 1) / C.restart_interval : 1;
@@ -892,13 +903,13 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       e->comp_restart[i] = (int)ri;
     }
     const size_t ns = (size_t)e->nseg;
-    HIPCHK_E(hipMalloc((void **)&e->d_seg_x, B * ns * 4));
-    HIPCHK_E(hipMalloc((void **)&e->d_seg_E, B * ns * 4));
-    HIPCHK_E(hipMalloc((void **)&e->d_mpos, B * ns * 4));
-    HIPCHK_E(hipMalloc((void **)&e->d_seg_sums, B * ((ns + 2047) / 2048) * 4));
-    HIPCHK_E(hipMalloc((void **)&e->d_seg_totals, B * 4));
+    HIPCHK_E(mjh_dmalloc((void **)&e->d_seg_x, B * ns * 4));
+    HIPCHK_E(mjh_dmalloc((void **)&e->d_seg_E, B * ns * 4));
+    HIPCHK_E(mjh_dmalloc((void **)&e->d_mpos, B * ns * 4));
+    HIPCHK_E(mjh_dmalloc((void **)&e->d_seg_sums, B * ((ns + 2047) / 2048) * 4));
+    HIPCHK_E(mjh_dmalloc((void **)&e->d_seg_totals, B * 4));
   }
-  HIPCHK_E(hipMalloc(&e->d_meta, B * sizeof(MjhImageMeta)));
+  HIPCHK_E(mjh_dmalloc(&e->d_meta, B * sizeof(MjhImageMeta)));
   e->h_sizes.resize(B);
 
   // quantizer constants
@@ -961,8 +972,8 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     build_sos(p, C.restart_interval, sos);
     e->prefix_len = (int)pre.size();
     e->sos_len = (int)sos.size();
-    HIPCHK_E(hipMalloc((void **)&e->d_prefix, pre.size()));
-    HIPCHK_E(hipMalloc((void **)&e->d_sos, sos.size()));
+    HIPCHK_E(mjh_dmalloc((void **)&e->d_prefix, pre.size()));
+    HIPCHK_E(mjh_dmalloc((void **)&e->d_sos, sos.size()));
     HIPCHK_E(hipMemcpy(e->d_prefix, pre.data(), pre.size(), hipMemcpyHostToDevice));
     HIPCHK_E(hipMemcpy(e->d_sos, sos.data(), sos.size(), hipMemcpyHostToDevice));
     bool dc_sent[4] = { false, false, false, false }, ac_sent[4] = { false, false, false, false };
@@ -979,7 +990,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     // frame header (DQT + SOF2) = prefix minus SOI/APP0; it opens scan 0's buffer (jcmaster.c:680-681)
     e->frame_hdr_len = e->prefix_len - e->file_hdr_len;
     e->d_frame_hdr = nullptr;
-    HIPCHK_E(hipMalloc((void **)&e->d_frame_hdr, (size_t)e->frame_hdr_len + 16));
+    HIPCHK_E(mjh_dmalloc((void **)&e->d_frame_hdr, (size_t)e->frame_hdr_len + 16));
     HIPCHK_E(hipMemcpy(e->d_frame_hdr, e->d_prefix + e->file_hdr_len, e->frame_hdr_len, hipMemcpyDeviceToDevice));
     // scan descriptors: the script, then one AC-first statistics scan per component for the trellis passes
     std::vector<MjhProgScan> ps(p->num_scans + C.ncomp * e->nbands);
@@ -1045,12 +1056,12 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
         if ((int)si < p->num_scans) { d.emit_dri = d.ri != last_ri; last_ri = d.ri; }   // the trellis statistics scans write no header
       }
       e->mpos_per_image = total;
-      HIPCHK_E(hipMalloc((void **)&e->d_prog_mpos, (B * (size_t)total + 16) * sizeof(unsigned)));
+      HIPCHK_E(mjh_dmalloc((void **)&e->d_prog_mpos, (B * (size_t)total + 16) * sizeof(unsigned)));
     }
-    HIPCHK_E(hipMalloc((void **)&e->d_prog_ffsums, B * ps.size() * 8 * sizeof(unsigned)));   // PROG_STUFF_SPLIT shares per (scan, image)
-    HIPCHK_E(hipMalloc(&e->d_prog_scans, ps.size() * sizeof(MjhProgScan)));
+    HIPCHK_E(mjh_dmalloc((void **)&e->d_prog_ffsums, B * ps.size() * 8 * sizeof(unsigned)));   // PROG_STUFF_SPLIT shares per (scan, image)
+    HIPCHK_E(mjh_dmalloc(&e->d_prog_scans, ps.size() * sizeof(MjhProgScan)));
     HIPCHK_E(hipMemcpy(e->d_prog_scans, ps.data(), ps.size() * sizeof(MjhProgScan), hipMemcpyHostToDevice));
-    HIPCHK_E(hipMalloc(&e->d_prog_ctl, B * sizeof(MjhProgCtl)));
+    HIPCHK_E(mjh_dmalloc(&e->d_prog_ctl, B * sizeof(MjhProgCtl)));
     // scan lists per phase (+ the table slots each phase has to build)
     auto add_list = [&](const std::vector<int> &scn) {
       mjh_encoder::PList pl;
@@ -1098,7 +1109,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       for (int c = 0; c < C.ncomp; c++) mx = C.c[c].nblk > mx ? C.c[c].nblk : mx;
       e->chunks_per_scan = (mx + MJH_PSTAT_BLOCKS - 1) / MJH_PSTAT_BLOCKS;
       for (const mjh_encoder::PList *pl : { &e->pl_trellis[0], &e->pl_trellis[1], &e->pl_phase[0], &e->pl_phase[1], &e->pl_phase[2], &e->pl_phase[3] }) maxlist = pl->npar > maxlist ? pl->npar : maxlist;
-      HIPCHK_E(hipMalloc(&e->d_prog_chunks, B * (size_t)maxlist * e->chunks_per_scan * sizeof(MjhProgChunk)));
+      HIPCHK_E(mjh_dmalloc(&e->d_prog_chunks, B * (size_t)maxlist * e->chunks_per_scan * sizeof(MjhProgChunk)));
       // parallel encode of the AC-first scans: block lengths / runs / offsets per (scan, image) pair
       const int maxpar = maxlist;
       e->pe.chunks_per_scan = e->chunks_per_scan;
@@ -1106,35 +1117,35 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       e->pe.chunks = (MjhProgChunk *)e->d_prog_chunks;
       if (maxpar > 0) {
         const size_t pairs = B * (size_t)maxpar, ent = pairs * (size_t)e->pe.nblk_pad, nch = pairs * (size_t)e->chunks_per_scan;
-        HIPCHK_E(hipMalloc((void **)&e->pe.len16, ent * 2));
-        HIPCHK_E(hipMalloc((void **)&e->pe.run16, ent * 2));
-        HIPCHK_E(hipMalloc((void **)&e->pe.tail16, ent * 2));
-        HIPCHK_E(hipMalloc((void **)&e->pe.be16, ent * 2));
-        HIPCHK_E(hipMalloc((void **)&e->pe.off32, ent * 4));
-        HIPCHK_E(hipMalloc((void **)&e->pe.T32, ent * 4));
-        HIPCHK_E(hipMalloc((void **)&e->pe.sums, nch * 4));
-        HIPCHK_E(hipMalloc((void **)&e->pe.tsums, nch * 4));
-        HIPCHK_E(hipMalloc((void **)&e->pe.totals, pairs * 4));
-        HIPCHK_E(hipMalloc((void **)&e->pe.ttotals, pairs * 4));
-        HIPCHK_E(hipMalloc((void **)&e->pe.ne_bits, nch * (MJH_PSTAT_BLOCKS / 64) * 8));
-        HIPCHK_E(hipMalloc((void **)&e->pe.e_bits, nch * (MJH_PSTAT_BLOCKS / 64) * 8));
-        HIPCHK_E(hipMalloc((void **)&e->pe.ne2_bits, nch * (MJH_PSTAT_BLOCKS / 64) * 8));
-        HIPCHK_E(hipMalloc((void **)&e->pe.info, pairs * sizeof(MjhProgPair)));
-        HIPCHK_E(hipMalloc((void **)&e->pe.chist, nch * 256 * 4));   // symbol counts per chunk: 1 KB per (scan, image, chunk of 2048 blocks)
+        HIPCHK_E(mjh_dmalloc((void **)&e->pe.len16, ent * 2));
+        HIPCHK_E(mjh_dmalloc((void **)&e->pe.run16, ent * 2));
+        HIPCHK_E(mjh_dmalloc((void **)&e->pe.tail16, ent * 2));
+        HIPCHK_E(mjh_dmalloc((void **)&e->pe.be16, ent * 2));
+        HIPCHK_E(mjh_dmalloc((void **)&e->pe.off32, ent * 4));
+        HIPCHK_E(mjh_dmalloc((void **)&e->pe.T32, ent * 4));
+        HIPCHK_E(mjh_dmalloc((void **)&e->pe.sums, nch * 4));
+        HIPCHK_E(mjh_dmalloc((void **)&e->pe.tsums, nch * 4));
+        HIPCHK_E(mjh_dmalloc((void **)&e->pe.totals, pairs * 4));
+        HIPCHK_E(mjh_dmalloc((void **)&e->pe.ttotals, pairs * 4));
+        HIPCHK_E(mjh_dmalloc((void **)&e->pe.ne_bits, nch * (MJH_PSTAT_BLOCKS / 64) * 8));
+        HIPCHK_E(mjh_dmalloc((void **)&e->pe.e_bits, nch * (MJH_PSTAT_BLOCKS / 64) * 8));
+        HIPCHK_E(mjh_dmalloc((void **)&e->pe.ne2_bits, nch * (MJH_PSTAT_BLOCKS / 64) * 8));
+        HIPCHK_E(mjh_dmalloc((void **)&e->pe.info, pairs * sizeof(MjhProgPair)));
+        HIPCHK_E(mjh_dmalloc((void **)&e->pe.chist, nch * 256 * 4));   // symbol counts per chunk: 1 KB per (scan, image, chunk of 2048 blocks)
         int maxoth = 0;   // scans of a list that are not first-pass AC scans (refinement and DC scans): the refinement masks of their blocks
         for (const mjh_encoder::PList *pl : { &e->pl_phase[0], &e->pl_phase[1], &e->pl_phase[2], &e->pl_phase[3] }) maxoth = pl->npar - pl->nacf > maxoth ? pl->npar - pl->nacf : maxoth;
         const char *rv = getenv("MJH_PP_RMASK");   // A/B knob: 0 = the sizes and the bits of refinement scans walk the records again
-        if (maxoth > 0 && e->use_compact && !(rv && atoi(rv) == 0)) HIPCHK_E(hipMalloc((void **)&e->pe.rmask, B * (size_t)maxoth * 3 * e->pe.nblk_pad * 8));
+        if (maxoth > 0 && e->use_compact && !(rv && atoi(rv) == 0)) HIPCHK_E(mjh_dmalloc((void **)&e->pe.rmask, B * (size_t)maxoth * 3 * e->pe.nblk_pad * 8));
       }
     }
-    HIPCHK_E(hipMalloc((void **)&e->d_lists, e->h_lists.size() * sizeof(int) + 16));
+    HIPCHK_E(mjh_dmalloc((void **)&e->d_lists, e->h_lists.size() * sizeof(int) + 16));
     HIPCHK_E(hipMemcpy(e->d_lists, e->h_lists.data(), e->h_lists.size() * sizeof(int), hipMemcpyHostToDevice));
     // every candidate scan of the search keeps its own bit stream: the bands are coded ~11 times over
     e->pool_words = e->stream_words * (p->optimize_scans ? 8 : 2);
     if (e->pool_words > ((size_t)1 << 27)) e->pool_words = (size_t)1 << 27;   // 32-bit bit offsets
     e->outpool_bytes = (size_t)1280 * (p->num_scans + 1) + 8 * e->pool_words;
-    HIPCHK_E(hipMalloc((void **)&e->d_pool, B * e->pool_words * 4 + 4096));   // slack: a bit writer may touch two words past its last offset
-    HIPCHK_E(hipMalloc((void **)&e->d_outpool, B * e->outpool_bytes));
+    HIPCHK_E(mjh_dmalloc((void **)&e->d_pool, B * e->pool_words * 4 + 4096));   // slack: a bit writer may touch two words past its last offset
+    HIPCHK_E(mjh_dmalloc((void **)&e->d_outpool, B * e->outpool_bytes));
   }
   {
     // sub-batches of the device entry (sequential mode): MJH_SPLIT ranges
@@ -1294,7 +1305,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       sl_dc = sl_dc_prog;
     }
     if (e->debug_taps && first_pass) {
-      if (!e->d_q0) HIPCHK(hipMalloc((void **)&e->d_q0, (size_t)e->max_batch * C.coefs_per_image * 2));
+      if (!e->d_q0) HIPCHK(mjh_dmalloc((void **)&e->d_q0, (size_t)e->max_batch * C.coefs_per_image * 2));
       HIPCHK(hipMemcpyAsync(e->d_q0, e->d_q, (size_t)n * C.coefs_per_image * 2, hipMemcpyDeviceToDevice, s));
     }
     // ... passes 1,3,5: trellis quantization with those tables.  The DC Viterbi (a few hundred
@@ -1653,7 +1664,7 @@ static int host_buffers(mjh_encoder *e)
   e->res_cap = (size_t)e->max_batch * (e->pix_image_bytes / 2 + 65536);
   HIPCHK(hipStreamCreateWithPriority(&e->d2h_stream, hipStreamNonBlocking, e->copy_prio));
   for (int b = 0; b < 2; b++) {
-    HIPCHK(hipMalloc((void **)&e->d_pixb[b], in_bytes));
+    HIPCHK(mjh_dmalloc((void **)&e->d_pixb[b], in_bytes));
     HIPCHK(hipHostMalloc((void **)&e->h_res[b], e->res_cap, hipHostMallocMapped));
     HIPCHK(hipHostMalloc((void **)&e->h_tab[b], (2 + 2 * (size_t)e->max_batch) * sizeof(unsigned long long), hipHostMallocMapped));
     HIPCHK(hipEventCreateWithFlags(&e->ev_h2d[b], hipEventDisableTiming));
@@ -1899,7 +1910,7 @@ extern "C" int mjh_encode_coefficients_host(mjh_encoder *e, const void *const co
   for (int c = 0; c < e->C.ncomp; c++) { off[c] = per_image; per_image += (size_t)e->C.c[c].nblk * 128; }
   HIPCHK(hipStreamSynchronize(e->stream));   // the staging buffers may still feed the previous batch
   if (!e->d_cfin) {
-    HIPCHK(hipMalloc((void **)&e->d_cfin, (size_t)e->max_batch * per_image));
+    HIPCHK(mjh_dmalloc((void **)&e->d_cfin, (size_t)e->max_batch * per_image));
     HIPCHK(hipHostMalloc((void **)&e->h_cfin, (size_t)e->max_batch * per_image, hipHostMallocDefault));
   }
   for (int i = 0; i < n; i++) {
@@ -1975,7 +1986,7 @@ extern "C" int mjh_encode_planes_host(mjh_encoder *e, const void *const planes[M
   const size_t cap = (size_t)e->C.planes_per_image * ss + 16 * MJH_MAXC;   // >= per_image by construction
   HIPCHK(hipStreamSynchronize(e->stream));   // the staging buffers may still feed the previous batch
   if (!e->d_plin) {
-    HIPCHK(hipMalloc((void **)&e->d_plin, (size_t)e->max_batch * cap));
+    HIPCHK(mjh_dmalloc((void **)&e->d_plin, (size_t)e->max_batch * cap));
     HIPCHK(hipHostMalloc((void **)&e->h_plin, (size_t)e->max_batch * cap, hipHostMallocDefault));
   }
   for (int i = 0; i < n; i++) {
