@@ -284,6 +284,16 @@ int mjh_set_profiling(mjh_encoder *e, int level);
 int mjh_set_profiling_focus(mjh_encoder *e, const char *name);
 int mjh_get_kernel_times(mjh_encoder *e, const char *const **names, const float **ms, int *count);
 
+/* Memory checking (debugging aid, environment MJH_GUARD read once per process):
+ * 0 = off (device buffers are plain hipMalloc blocks of exactly the size needed), 1 = canaries around every device
+ * buffer, 2 / 3 = every device buffer (and a private copy of the caller's device input) ends / starts at an unmapped
+ * page, so that a kernel that strays past it faults on the spot.  In the modes 1-3 the canaries are compared whenever
+ * a batch is waited for (the call fails with MJH_EHIP and names the buffer); mjh_debug_guard_check does it on demand. */
+int mjh_debug_guard_mode(void);
+int mjh_debug_guard_check(void);
+/* the checker's own test (tools/guard_probe.py): touches one byte at `offset` relative to the end of a 1000-byte buffer */
+int mjh_debug_guard_selftest(long offset, int write);
+
 const char *mjh_last_error(void);
 const char *mjh_version(void);
 

@@ -23,6 +23,7 @@
 #include "../../include/mozjpeg_hip.h"
 #include "mjh_internal.h"
 #include "mjh_launch.h"
+#include "mjh_guard.h"
 
 // ---- error plumbing ---------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -35,22 +36,21 @@ static int fail(int code, const char *fmt, ...)
   return code;
 }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MJH_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
-// device memory starts out zeroed: no kernel may depend on that, but whatever a first call reads before it was written
-// (padding entries, table slots of unused components) is then the same in every process instead of the previous
-// tenant's bytes
-// ... and carries 64 KB of slack behind its end: a vector access that strays a few bytes past a buffer stays in owned
-// memory wherever the allocator placed it (the one unexplained fault of round 3 hit a page-aligned address)
-template <class T> static hipError_t mjh_dmalloc(T **p, size_t bytes)
-{
-  if (bytes) bytes += 65536;
-  const hipError_t rc = hipMalloc(reinterpret_cast<void **>(p), bytes);   // (the one real allocation call of this file)
-  if (rc != hipSuccess) return rc;
-  if (!bytes) return hipSuccess;
-  const hipError_t rm = hipMemsetAsync(*p, 0, bytes, 0);
-  return rm != hipSuccess ? rm : hipStreamSynchronize(0);   // (the encoder's streams do not wait for the null stream)
-}
+// Every device allocation of this file goes through mjh_guard.cpp: exactly the bytes asked for, zero-filled -- or, with
+// MJH_GUARD=1..3, canaries / an unmapped page next to the buffer (the tool that replaced round 3's 64 KB of blind slack)
+#define mjh_dmalloc(pp, bytes) mjh_guard_alloc(reinterpret_cast<void **>(pp), (bytes), #pp, -1)
 
 extern "C" const char *mjh_last_error(void) { return g_err; }
+// MJH_GUARD modes: the canaries around every device buffer are compared whenever a batch is waited for
+static int guard_verify()
+{
+  if (mjh_guard_mode() == 0) return MJH_OK;
+  char msg[400];
+  const int bad = mjh_guard_check(msg, sizeof(msg));
+  return bad ? fail(MJH_EHIP, "MJH_GUARD: %d damaged canaries: %s", bad, msg) : MJH_OK;
+}
+extern "C" int mjh_debug_guard_check(void) { return guard_verify(); }
+extern "C" int mjh_debug_guard_mode(void) { return mjh_guard_mode(); }
 // (for mjh_pool.cpp, which is otherwise built on the public ABI: lets its argument checks leave a message too)
 int mjh_internal_fail(int code, const char *msg) { return fail(code, "%s", msg); }
 extern "C" const char *mjh_version(void) { return "mozjpeg_hip 0.2 (gfx950)"; }
@@ -364,6 +364,7 @@ struct mjh_encoder {
   bool is_view = false, last_split = false;
   int view_off = 0;
   hipEvent_t ev_view_done = nullptr, ev_split_fork = nullptr, ev_null_in = nullptr;
+  void *g_in[MJH_MAX_COMPS] = { nullptr, nullptr, nullptr, nullptr };   // MJH_GUARD=2/3: fenced copies of the caller's device input
 };
 
 static long div_round_up(long a, long b) { return (a + b - 1) / b; }
@@ -682,8 +683,8 @@ static void free_all(mjh_encoder *e)
   if (e->ev_null_in) (void)hipEventDestroy(e->ev_null_in);
   void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->pe.chist, e->pe.rmask, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_nq8, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
-                   e->d_meta, e->d_prefix, e->d_sos };
-  for (void *q : ptrs) if (q) (void)hipFree(q);
+                   e->d_meta, e->d_prefix, e->d_sos, e->g_in[0], e->g_in[1], e->g_in[2], e->g_in[3] };
+  for (void *q : ptrs) if (q) (void)mjh_guard_free(q);
   if (e->h_defer) (void)hipHostFree(e->h_defer);
   for (int b = 0; b < 2; b++) {
     if (e->h_stage[b]) (void)hipHostFree(e->h_stage[b]);
@@ -734,6 +735,7 @@ static int make_views(mjh_encoder *e, int S)
     v->copy_done = v->ev_fork = v->ev_join = v->ev_side0 = v->ev_side1 = v->ev_view_done = v->ev_split_fork = v->ev_null_in = nullptr;
     for (int b = 0; b < 2; b++) { v->ev_h2d[b] = v->ev_pix_free[b] = v->ev_packed[b] = nullptr; v->d_pixb[b] = nullptr; v->h_stage[b] = v->h_res[b] = nullptr; v->h_tab[b] = nullptr; }
     v->h_defer = nullptr;
+    for (int c = 0; c < MJH_MAX_COMPS; c++) v->g_in[c] = nullptr;
     v->prof_events.clear(); v->side_events.clear(); v->prof_names.clear(); v->prof_cnames.clear(); v->prof_ms.clear();
     v->prof_calls = 0; v->prof_per_call = 0; v->profiling = 0;
     {
@@ -1182,6 +1184,11 @@ struct Prof {
   bool first_call = true, enabled = false, prev_focus = false;
   void mark(const char *name)
   {
+    if (mjh_guard_serial()) {   // MJH_GUARD + MJH_GUARD_LOG: one step at a time, named in the log before it is queued
+      (void)hipStreamSynchronize(s);
+      (void)hipStreamSynchronize(e->side_stream);
+      mjh_guard_note(name);
+    }
     if (!enabled) return;
     const bool focus = name && strcmp(name, e->prof_focus) == 0;
     const bool closing = prev_focus && !focus;          // the mark that ends the focus kernel's interval
@@ -1510,6 +1517,19 @@ static int wait_pending_pack(mjh_encoder *e, hipStream_t s)
   return MJH_OK;
 }
 
+// MJH_GUARD=2/3: a device entry point works on a fenced copy of the caller's input that holds exactly the bytes the entry
+// may read (last image, last row, last sample), so that an over-read of the CALLER's memory faults like any other
+static int guard_input(mjh_encoder *e, int slot, const void **p, size_t bytes)
+{
+  if (mjh_guard_mode() < 2 || !*p || !bytes) return MJH_OK;
+  HIPCHK(hipDeviceSynchronize());
+  if (e->g_in[slot]) { HIPCHK(mjh_guard_free(e->g_in[slot])); e->g_in[slot] = nullptr; }
+  HIPCHK(mjh_dmalloc(&e->g_in[slot], bytes));
+  HIPCHK(hipMemcpy(e->g_in[slot], *p, bytes, hipMemcpyDeviceToDevice));
+  *p = e->g_in[slot];
+  return MJH_OK;
+}
+
 extern "C" int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t row_pitch, size_t image_stride, int n, void *stream)
 {
   if (!e || !d_pixels || n < 1 || n > e->max_batch) return fail(MJH_EINVAL, "bad arguments (n=%d, max_batch=%d)", n, e ? e->max_batch : 0);
@@ -1519,6 +1539,11 @@ extern "C" int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t ro
       return fail(MJH_EINVAL, "row_pitch %zu / image_stride %zu too small for %dx%d images of %zu-byte rows", row_pitch, image_stride, e->C.W, e->C.H, row_bytes);
   }
   HIPCHK(hipSetDevice(e->device));
+  {
+    const size_t row_bytes = (size_t)e->C.W * e->C.px_size * (e->C.precision == 12 ? 2 : 1);
+    const int rg = guard_input(e, 0, &d_pixels, (size_t)(n - 1) * image_stride + (size_t)(e->C.H - 1) * row_pitch + row_bytes);
+    if (rg) return rg;
+  }
   hipStream_t s = stream ? (hipStream_t)stream : e->stream;
   if (stream == (void *)1) {
     // "behind the null stream": the encoder's own (non-blocking) stream does not synchronise with the legacy default stream
@@ -1846,6 +1871,7 @@ static int wait_results(mjh_encoder *e, int b)
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipEventSynchronize(e->ev_packed[b]));
     e->res_waited[b] = true;
+    { const int rg = guard_verify(); if (rg) return rg; }
   }
   const unsigned long long err = e->h_tab[b][1];
   if (err & 1) return fail(MJH_ETOOSMALL, "entropy-coded data of an image exceeds the 32-bit bit-offset range of one scan / the bit-stream pool");
@@ -1895,6 +1921,8 @@ extern "C" int mjh_encode_coefficients_device(mjh_encoder *e, const void *const 
   for (int c = 0; c < e->C.ncomp; c++) {
     cs.base[c] = d_coefs[c]; cs.blocks_per_row[c] = (long long)blocks_per_row[c];
     cs.stride[c] = image_stride ? (long long)image_stride[c] : 0;
+    const int rg = guard_input(e, c, &cs.base[c], (size_t)(n - 1) * (size_t)cs.stride[c] + ((size_t)(e->C.c[c].hib - 1) * blocks_per_row[c] + (size_t)e->C.c[c].wib) * 128);
+    if (rg) return rg;
   }
   { const int rcw = wait_pending_pack(e, stream ? (hipStream_t)stream : e->stream); if (rcw) return rcw; }
   e->last_split = false;
@@ -1960,6 +1988,8 @@ extern "C" int mjh_encode_planes_device(mjh_encoder *e, const void *const d_plan
   for (int c = 0; c < e->C.ncomp; c++) {
     ps.base[c] = d_planes[c]; ps.pitch[c] = (long long)row_pitch[c]; ps.stride[c] = image_stride ? (long long)image_stride[c] : 0;
     ps.w[c] = plane_width[c]; ps.h[c] = plane_height[c];
+    const int rg = guard_input(e, c, &ps.base[c], (size_t)(n - 1) * (size_t)ps.stride[c] + (size_t)(ps.h[c] - 1) * row_pitch[c] + (size_t)ps.w[c] * (e->C.precision == 12 ? 2 : 1));
+    if (rg) return rg;
   }
   { const int rcw = wait_pending_pack(e, stream ? (hipStream_t)stream : e->stream); if (rcw) return rcw; }
   e->last_split = false;
@@ -2013,7 +2043,7 @@ extern "C" int mjh_encoder_sync(mjh_encoder *e)
   if (!e) return fail(MJH_EINVAL, "null encoder");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->last_stream ? e->last_stream : e->stream));
-  return MJH_OK;
+  return guard_verify();
 }
 
 static int fetch_sizes(mjh_encoder *e)
@@ -2028,6 +2058,7 @@ static int fetch_sizes(mjh_encoder *e)
   }
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipDeviceSynchronize());
+  { const int rg = guard_verify(); if (rg) return rg; }
   HIPCHK(hipMemcpy(e->h_sizes.data(), e->d_sizes, (size_t)e->last_n * sizeof(unsigned), hipMemcpyDeviceToHost));
   if (e->progressive) {
     std::vector<MjhProgCtl> ctl(e->last_n);
