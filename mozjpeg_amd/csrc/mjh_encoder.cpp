@@ -302,8 +302,7 @@ struct mjh_encoder {
   int comp_restart[4] = { 0, 0, 0, 0 };
   int16_t *d_dense = nullptr; unsigned dense_cap = 0;       // raw coefficients of deferred blocks, 64 int16 per work-list slot
   unsigned *d_worklist = nullptr, *d_worklist2 = nullptr;   // deferred trellis blocks: [0] = count, [4+3i..6+3i] = (image, comp<<28|block, dense slot)
-  int trellis_variant = 0;           // first-tier queue capacity of the AC trellis: 0 = 16, 1 = 20, 2 = 24, 3 = 32 (all bit-identical)
-  int trellis_floor = 0, trellis_hold = 0;   // hysteresis of the adaptation
+  int trellis_variant = 0;           // first-tier queue capacity of the AC trellis: 0 = 16, 1 = 20, 2 = 24, 3 = 32, 4 = 48 (all bit-identical)
   bool trellis_adapt = true;         // no MJH_TRELLIS_VARIANT given: follow the share of deferred blocks of the previous batches
   unsigned *h_defer = nullptr;       // pinned: work-list count of the last finished trellis pass
   int fuse_mask = 1;                // MJH_FUSE: 1 = pre-trellis AC statistics inside the FDCT kernel (+ unread planes not stored), 2 = final AC statistics inside the general trellis kernel, 4 = inside the tile-sorted one (both measured: they cost the trellis what the separate pass costs, 2.36 + 0.33 vs 2.77 ms)
@@ -364,7 +363,7 @@ struct mjh_encoder {
   bool is_view = false, last_split = false;
   int view_off = 0;
   hipEvent_t ev_view_done = nullptr, ev_split_fork = nullptr, ev_null_in = nullptr;
-  void *g_in[MJH_MAX_COMPS] = { nullptr, nullptr, nullptr, nullptr };   // MJH_GUARD=2/3: fenced copies of the caller's device input
+  void *g_in[MJH_MAX_COMPS] = { nullptr, nullptr, nullptr, nullptr }; size_t g_in_bytes[MJH_MAX_COMPS] = { 0, 0, 0, 0 }; std::vector<void *> g_in_old;   // MJH_GUARD=2/3: fenced copies of the caller's device input
 };
 
 static long div_round_up(long a, long b) { return (a + b - 1) / b; }
@@ -685,11 +684,12 @@ static void free_all(mjh_encoder *e)
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos, e->g_in[0], e->g_in[1], e->g_in[2], e->g_in[3] };
   for (void *q : ptrs) if (q) (void)mjh_guard_free(q);
+  for (void *q : e->g_in_old) (void)mjh_guard_free(q);
   if (e->h_defer) (void)hipHostFree(e->h_defer);
   for (int b = 0; b < 2; b++) {
     if (e->h_stage[b]) (void)hipHostFree(e->h_stage[b]);
-    if (e->h_res[b]) (void)hipHostFree(e->h_res[b]);
-    if (e->h_tab[b]) (void)hipHostFree(e->h_tab[b]);
+    if (e->h_res[b]) (void)mjh_guard_host_free(e->h_res[b]);
+    if (e->h_tab[b]) (void)mjh_guard_host_free(e->h_tab[b]);
     for (hipEvent_t ev : { e->ev_h2d[b], e->ev_pix_free[b], e->ev_packed[b] }) if (ev) (void)hipEventDestroy(ev);
   }
   if (e->d2h_stream) (void)hipStreamDestroy(e->d2h_stream);
@@ -736,6 +736,7 @@ static int make_views(mjh_encoder *e, int S)
     for (int b = 0; b < 2; b++) { v->ev_h2d[b] = v->ev_pix_free[b] = v->ev_packed[b] = nullptr; v->d_pixb[b] = nullptr; v->h_stage[b] = v->h_res[b] = nullptr; v->h_tab[b] = nullptr; }
     v->h_defer = nullptr;
     for (int c = 0; c < MJH_MAX_COMPS; c++) v->g_in[c] = nullptr;
+    v->g_in_old.clear();
     v->prof_events.clear(); v->side_events.clear(); v->prof_names.clear(); v->prof_cnames.clear(); v->prof_ms.clear();
     v->prof_calls = 0; v->prof_per_call = 0; v->profiling = 0;
     {
@@ -754,7 +755,7 @@ static int make_views(mjh_encoder *e, int S)
     HIPCHK(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&v->ev_view_done, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void **)&v->h_defer, 64, hipHostMallocDefault));
-    v->h_defer[0] = 0xFFFFFFFFu;
+    v->h_defer[0] = v->h_defer[3] = 0xFFFFFFFFu;
     // HIP multiplexes streams onto a handful of hardware queues (4 by default): with a main and a side stream per view, three
     // views already collide there and serialise falsely (measured: 2 views 5.81 ms, 3 views 6.67 ms per 64 4K frames).  From
     // three views on, a view keeps to ONE stream -- its DC trellis runs in line, the overlap comes from the other views
@@ -872,9 +873,18 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     e->dense_cap = (unsigned)(B * (size_t)C.total_real_blocks / 4 + 1024);
     HIPCHK_E(mjh_dmalloc((void **)&e->d_dense, (size_t)e->dense_cap * 128));
   }
+  {
+    // starting point of the first tier's capacity (the measured record counts of every finished batch correct it): the coarser
+    // the luma table, the fewer coefficients survive -- mean AC step >= 38 (q75 and below): 16 records, >= 22 (q85): 24,
+    // >= 13 (q90): 32, finer: 48
+    double m = 0.0;
+    for (int k = 1; k < 64; k++) m += p->quantval[p->quant_tbl_no[0]][k];
+    m /= 63.0;
+    e->trellis_variant = m >= 38.0 ? 0 : m >= 22.0 ? 2 : m >= 13.0 ? 3 : 4;
+  }
   if (const char *v = getenv("MJH_TRELLIS_VARIANT")) { e->trellis_variant = atoi(v); e->trellis_adapt = false; }
   HIPCHK_E(hipHostMalloc((void **)&e->h_defer, 64, hipHostMallocDefault));
-  e->h_defer[0] = 0xFFFFFFFFu;
+  e->h_defer[0] = e->h_defer[3] = 0xFFFFFFFFu;
   if (const char *v = getenv("MJH_FUSE")) e->fuse_mask = atoi(v);
   if (const char *v = getenv("MJH_TRELLIS_V3")) e->trellis_v3 = atoi(v);
   e->dc_window_ok = 1;
@@ -1343,22 +1353,26 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
     }
     const bool extended = nbands > 1 || ext_eob || qstride != 0;
-    if (e->trellis_adapt && !extended && e->h_defer[0] != 0xFFFFFFFFu) {
-      // The first tier's queue capacity trades LDS occupancy (16 entries: 14 waves per CU) against the share of blocks that
-      // have to be redone by the slower big-capacity tier: few at q75 (the metric: ~5 %), a third of all blocks at q85.
-      // The share seen in the last finished batch (read back asynchronously, never waited for) moves it one notch.
-      const double share = (double)e->h_defer[0] / ((double)e->h_defer[1] * (double)C.total_real_blocks + 1.0);
-      // (hysteresis: a capacity that just proved too small is not tried again for the next 256 batches -- at q85..q90 the
-      // share is tiny at one capacity and a third of all blocks one notch below, which made the choice oscillate)
-      if (e->trellis_hold > 0) e->trellis_hold--;
-      if (share > 0.12 && e->trellis_variant < 3) { e->trellis_variant++; e->trellis_floor = e->trellis_variant; e->trellis_hold = 256; }
-      else if (share < 0.03 && e->trellis_variant > 0 && (e->trellis_variant > e->trellis_floor || e->trellis_hold == 0)) e->trellis_variant--;
-      e->h_defer[0] = 0xFFFFFFFFu;
+    if (e->trellis_adapt && !extended && e->h_defer[0] != 0xFFFFFFFFu && e->h_defer[3] != 0xFFFFFFFFu) {
+      // The first tier's queue capacity trades LDS occupancy (16 records: 15 waves per CU, 48: 5) against the share of blocks
+      // that have to be redone by the general big-capacity tier.  The first tier counts, whatever its own capacity, how many
+      // blocks of the batch have more than 16 / 24 / 32 records (count_heavy); the last finished batch's counts (read back
+      // asynchronously, never waited for) give the capacity directly: the smallest one that leaves less than ~6 % of the
+      // blocks to the general tier.  The counts do not depend on the capacity in use, so a steady workload settles on ONE
+      // plan; a move down needs the share to fall to half the ceiling (a workload sitting on a ceiling does not alternate).
+      const double blocks = (double)e->h_defer[4] * (double)C.total_real_blocks + 1.0;
+      const double s16 = e->h_defer[1] / blocks, s24 = e->h_defer[2] / blocks, s32 = e->h_defer[3] / blocks;
+      const int cur = e->trellis_variant == 1 ? 2 : e->trellis_variant;
+      auto level_for = [&](double slack) { return s16 < 0.06 * slack ? 0 : s24 < 0.06 * slack ? 2 : s32 < 0.10 * slack ? 3 : 4; };
+      const int up = level_for(1.0), down = level_for(0.5);
+      if (up > cur) e->trellis_variant = up;
+      else if (down < cur) e->trellis_variant = down;
+      e->h_defer[0] = e->h_defer[3] = 0xFFFFFFFFu;
     }
     pr.mark("trellis_ac");
     // the tile-sorted first tier (plain compact pass, 16-record capacity) can count the statistics of the final coefficients
     // in its back-track (MJH_FUSE bit 4): sequential mode, optimal tables, last round
-    const bool v3 = nzm && e->d_nq8 && !fuse_fin && e->trellis_v3 > 0 && e->trellis_variant <= 2 && !extended;
+    const bool v3 = nzm && e->d_nq8 && !fuse_fin && e->trellis_v3 > 0 && e->trellis_variant <= 4 && !extended;
     const bool v3_stats = v3 && (e->fuse_mask & 4) && !e->progressive && p.optimize_coding && last_loop;
     if (v3_stats) final_ac_counted = true;
     mjh_launch_trellis_ac(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap,
@@ -1367,8 +1381,8 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
                           e->d_nq8, v3 ? ((size_t)n * C.total_real_blocks < 400000 ? 1 : e->trellis_v3) : 0,   // (a small batch: one pass per tile -- four times the workgroups, a quarter of their length: latency matters more than the sorting)
                           e->fastdiv_all);
     if (e->trellis_adapt && !extended && first_pass) {
-      e->h_defer[1] = (unsigned)n;
-      HIPCHK(hipMemcpyAsync(&e->h_defer[0], e->d_worklist, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+      e->h_defer[4] = (unsigned)n;
+      HIPCHK(hipMemcpyAsync(&e->h_defer[0], e->d_worklist, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     }
     if (ext_eob) {   // jcdctmgr.c:1224-1297: end-of-band runs along every block row, with the band's AC rate table
       pr.mark("trellis_eob_runs");
@@ -1522,10 +1536,25 @@ static int wait_pending_pack(mjh_encoder *e, hipStream_t s)
 static int guard_input(mjh_encoder *e, int slot, const void **p, size_t bytes)
 {
   if (mjh_guard_mode() < 2 || !*p || !bytes) return MJH_OK;
+  static const bool off = getenv("MJH_GUARD_INPUT") && atoi(getenv("MJH_GUARD_INPUT")) == 0;
+  if (off) return MJH_OK;
   HIPCHK(hipDeviceSynchronize());
-  if (e->g_in[slot]) { HIPCHK(mjh_guard_free(e->g_in[slot])); e->g_in[slot] = nullptr; }
-  HIPCHK(mjh_dmalloc(&e->g_in[slot], bytes));
+  // a copy buffer is kept for the next call of the same size, and outgrown ones live until the encoder goes: un-mapping a
+  // buffer and mapping the next one in the same call sequence gave copies that differed from their source on this runtime
+  // (profiles/r04a_guard_notes.md), so nothing is un-mapped while the encoder works
+  if (e->g_in[slot] && e->g_in_bytes[slot] != bytes) { e->g_in_old.push_back(e->g_in[slot]); e->g_in[slot] = nullptr; }
+  if (!e->g_in[slot]) HIPCHK(mjh_dmalloc(&e->g_in[slot], bytes));
+  e->g_in_bytes[slot] = bytes;
   HIPCHK(hipMemcpy(e->g_in[slot], *p, bytes, hipMemcpyDeviceToDevice));
+  HIPCHK(hipDeviceSynchronize());   // (a device-to-device copy returns before it is done, and the encoder's streams do not wait for the null stream)
+  if (getenv("MJH_GUARD_VERIFY_COPY") && bytes <= ((size_t)1 << 28)) {
+    std::vector<uint8_t> a(bytes), b(bytes);
+    HIPCHK(hipMemcpy(a.data(), *p, bytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(b.data(), e->g_in[slot], bytes, hipMemcpyDeviceToHost));
+    size_t bad = 0, first = 0;
+    for (size_t i = 0; i < bytes; i++) if (a[i] != b[i]) { if (!bad) first = i; bad++; }
+    fprintf(stderr, "guard_input: %zu bytes, %zu differ (first at %zu) src %p copy %p\n", bytes, bad, first, *p, e->g_in[slot]);
+  }
   *p = e->g_in[slot];
   return MJH_OK;
 }
@@ -1693,8 +1722,8 @@ static int host_buffers(mjh_encoder *e)
   HIPCHK(hipStreamCreateWithPriority(&e->d2h_stream, hipStreamNonBlocking, e->copy_prio));
   for (int b = 0; b < 2; b++) {
     HIPCHK(mjh_dmalloc((void **)&e->d_pixb[b], in_bytes));
-    HIPCHK(hipHostMalloc((void **)&e->h_res[b], e->res_cap, hipHostMallocMapped));
-    HIPCHK(hipHostMalloc((void **)&e->h_tab[b], (2 + 2 * (size_t)e->max_batch) * sizeof(unsigned long long), hipHostMallocMapped));
+    HIPCHK(mjh_guard_host_alloc((void **)&e->h_res[b], e->res_cap, hipHostMallocMapped, "h_res"));
+    HIPCHK(mjh_guard_host_alloc((void **)&e->h_tab[b], (2 + 2 * (size_t)e->max_batch) * sizeof(unsigned long long), hipHostMallocMapped, "h_tab"));
     HIPCHK(hipEventCreateWithFlags(&e->ev_h2d[b], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->ev_pix_free[b], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->ev_packed[b], hipEventDisableTiming));
@@ -1730,15 +1759,21 @@ extern "C" int mjh_encode_host(mjh_encoder *e, const void *pixels, size_t row_pi
   e->last_split = false;
   int rc = host_buffers(e);
   if (rc) return rc;
-  const int b = (int)(e->host_calls++ & 1u);
+  const int b = (int)(e->host_calls & 1u);
   const int H = e->C.H;
+  // (mjh_stage_commit: a prefix of the encoder's own packed staging buffer is on its way already)
+  const size_t done = (pixels == e->h_stage[b] && row_pitch == row_bytes && image_stride == e->pix_image_bytes) ? e->staged[b] : 0;
+  if (e->staged[b] != 0 && done == 0) {
+    // the committed prefix belongs to a batch that never came: forget it (its copies are waited for), refuse this call
+    HIPCHK(hipStreamSynchronize(e->copy_stream));
+    e->staged[b] = 0;
+    return fail(MJH_EINVAL, "mjh_stage_commit was used: the batch has to come from the staging buffer, packed");
+  }
+  e->host_calls++;
   const bool own_staging = pixels == e->h_stage[0] || pixels == e->h_stage[1];
   const bool direct = own_staging || is_pinned(pixels);
   // d_pixb[b] was last read by the colour kernel of the call before the previous one
   HIPCHK(hipStreamWaitEvent(e->copy_stream, e->ev_pix_free[b], 0));
-  // (mjh_stage_commit: a prefix of the encoder's own packed staging buffer is on its way already)
-  const size_t done = (pixels == e->h_stage[b] && row_pitch == row_bytes && image_stride == e->pix_image_bytes) ? e->staged[b] : 0;
-  if (e->staged[b] != 0 && done == 0) return fail(MJH_EINVAL, "mjh_stage_commit was used: the batch has to come from the staging buffer, packed");
   e->staged[b] = 0;
   if (direct) {
     // pinned source: the DMA engine reads the caller's memory; it must stay untouched until mjh_wait_input / mjh_collect
@@ -1832,6 +1867,12 @@ extern "C" int mjh_host_staging(mjh_encoder *e, void **buffer, size_t *bytes)
   const int b = (int)(e->host_calls & 1u);   // the buffer the NEXT mjh_encode_host call uses
   if (!e->h_stage[b]) HIPCHK(hipHostMalloc((void **)&e->h_stage[b], (size_t)e->max_batch * e->pix_image_bytes, hipHostMallocDefault));
   HIPCHK(hipEventSynchronize(e->ev_h2d[b]));
+  if (e->staged[b]) {
+    // an image was abandoned after part of it had been committed (jpeg_abort_compress behind >= 256 scanlines): its queued
+    // copies still read the buffer that is handed out again now, and the next image starts from byte 0
+    HIPCHK(hipStreamSynchronize(e->copy_stream));
+    e->staged[b] = 0;
+  }
   *buffer = e->h_stage[b];
   if (bytes) *bytes = (size_t)e->max_batch * e->pix_image_bytes;
   return MJH_OK;

@@ -21,6 +21,7 @@ struct Rec {
   uint8_t *map = nullptr;         // start of the mapping (modes 2, 3)
   hipMemGenericAllocationHandle_t handle{};
   int mode = 0, device = 0;
+  bool host = false;
   char name[48] = "";
 };
 std::mutex g_m;
@@ -128,29 +129,59 @@ hipError_t mjh_guard_free(void *p)
 {
   if (!p) return hipSuccess;
   if (mjh_guard_mode() == 0) return hipFree(p);
-  Rec r;
-  {
-    std::lock_guard<std::mutex> lk(g_m);
-    size_t i = 0;
-    while (i < g_recs.size() && g_recs[i].user != p) i++;
-    if (i == g_recs.size()) return hipErrorInvalidValue;
-    r = g_recs[i];
-    g_recs.erase(g_recs.begin() + i);
-  }
+  // (under the lock to the end: a canary check of another thread's encoder walks every live buffer)
+  std::lock_guard<std::mutex> lk(g_m);
+  size_t i = 0;
+  while (i < g_recs.size() && g_recs[i].user != p) i++;
+  if (i == g_recs.size()) return hipErrorInvalidValue;
+  const Rec r = g_recs[i];
+  g_recs.erase(g_recs.begin() + i);
   if (r.mode == 1) return hipFree(r.base);
   (void)hipDeviceSynchronize();
   hipError_t rc = hipMemUnmap(r.map, r.mapped);
   if (rc == hipSuccess) rc = hipMemRelease(r.handle);
-  if (rc == hipSuccess) rc = hipMemAddressFree(r.base, r.reserved);
+  // the address range stays reserved for the life of the process: a later buffer never lands on addresses an earlier one
+  // had (a re-used range gave stale reads on this runtime, see guard_input in mjh_encoder.cpp; the address space is 2^47)
   return rc;
+}
+
+hipError_t mjh_guard_host_alloc(void **p, size_t bytes, unsigned flags, const char *name)
+{
+  if (mjh_guard_mode() == 0) return hipHostMalloc(p, bytes, flags);
+  Rec r;
+  r.bytes = bytes; r.mode = 1; r.host = true;
+  snprintf(r.name, sizeof(r.name), "%s", name ? name : "?");
+  const hipError_t rc = hipHostMalloc((void **)&r.base, bytes + 2 * CANARY, flags);
+  if (rc != hipSuccess) return rc;
+  memset(r.base, CANARY_BYTE, bytes + 2 * CANARY);
+  r.user = r.base + CANARY;
+  memset(r.user, POISON_BYTE, bytes);
+  *p = r.user;
+  std::lock_guard<std::mutex> lk(g_m);
+  g_recs.push_back(r);
+  log_alloc(r);
+  return hipSuccess;
+}
+
+hipError_t mjh_guard_host_free(void *p)
+{
+  if (!p) return hipSuccess;
+  if (mjh_guard_mode() == 0) return hipHostFree(p);
+  std::lock_guard<std::mutex> lk(g_m);
+  size_t i = 0;
+  while (i < g_recs.size() && g_recs[i].user != p) i++;
+  if (i == g_recs.size()) return hipErrorInvalidValue;
+  uint8_t *base = g_recs[i].base;
+  g_recs.erase(g_recs.begin() + i);
+  return hipHostFree(base);
 }
 
 int mjh_guard_check(char *msg, size_t cap)
 {
   if (msg && cap) msg[0] = 0;
   if (mjh_guard_mode() == 0) return 0;
-  std::vector<Rec> recs;
-  { std::lock_guard<std::mutex> lk(g_m); recs = g_recs; }
+  std::lock_guard<std::mutex> lk(g_m);
+  const std::vector<Rec> &recs = g_recs;
   int bad = 0;
   size_t used = 0;
   std::vector<uint8_t> h(CANARY);
@@ -163,8 +194,11 @@ int mjh_guard_check(char *msg, size_t cap)
     for (int side = 0; side < 2; side++) {
       const uint8_t *b = side ? hi_begin : lo_begin, *e = side ? hi_end : lo_end;
       if (e <= b) continue;
-      (void)hipSetDevice(r.device);
-      if (hipMemcpy(h.data(), b, (size_t)(e - b), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); continue; }
+      if (r.host) memcpy(h.data(), b, (size_t)(e - b));
+      else {
+        (void)hipSetDevice(r.device);
+        if (hipMemcpy(h.data(), b, (size_t)(e - b), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); continue; }
+      }
       size_t first = (size_t)-1, last = 0, cnt = 0;
       for (size_t i = 0; i < (size_t)(e - b); i++)
         if (h[i] != CANARY_BYTE) { if (first == (size_t)-1) first = i; last = i; cnt++; }
@@ -176,7 +210,8 @@ int mjh_guard_check(char *msg, size_t cap)
                                  used ? "; " : "", r.name, cnt, side ? "behind" : "in front of", r.bytes, d0, d1, side ? "end" : "start");
       if (g_log) { fprintf(g_log, "DAMAGE %s side %d count %zu\n", r.name, side, cnt); fflush(g_log); }
       // repaired, so that the next check reports new damage only
-      (void)hipMemset((void *)b, CANARY_BYTE, (size_t)(e - b));
+      if (r.host) memset((void *)b, CANARY_BYTE, (size_t)(e - b));
+      else (void)hipMemset((void *)b, CANARY_BYTE, (size_t)(e - b));
     }
   }
   return bad;

@@ -16,6 +16,9 @@
 int mjh_guard_mode();
 hipError_t mjh_guard_alloc(void **p, size_t bytes, const char *name, int device);
 hipError_t mjh_guard_free(void *p);
+// pinned host memory the DEVICE writes (result arenas): modes 1-3 put 4 KB canaries around it, compared by mjh_guard_check
+hipError_t mjh_guard_host_alloc(void **p, size_t bytes, unsigned flags, const char *name);
+hipError_t mjh_guard_host_free(void *p);
 // canary comparison of every live allocation (modes 1-3: modes 2/3 keep canaries in the alignment padding);
 // returns the number of damaged allocations, a description of the first few in msg
 int mjh_guard_check(char *msg, size_t cap);

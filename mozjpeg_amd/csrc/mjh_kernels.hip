@@ -364,11 +364,11 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
             MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out)
 {
   constexpr bool W12 = sizeof(T) == 2;
-  // 8 KB per wave: the deringing columns (16-bit: level-shifted samples and overshoot values are small for 8-bit data; 12-bit
-  // data keeps 32-bit columns) and, afterwards, 8 interleaved copies of the 256-bin statistics histogram
-  constexpr int LW = W12 ? 64 : 32;
+  // 8 KB per wave: the deringing columns (the ORIGINAL level-shifted samples of the lane's block in zig-zag order, 16 bits
+  // each for 8- and 12-bit data) and, afterwards, 8 interleaved copies of the 256-bin statistics histogram
+  constexpr int LW = 32;
   __shared__ int lds_raw[64][LW];
-  typedef typename std::conditional<W12, int, short>::type dcol_t;
+  typedef short dcol_t;
   typedef dcol_t __attribute__((may_alias)) dcol_alias;
   dcol_alias (*lds)[64] = reinterpret_cast<dcol_alias (*)[64]>(&lds_raw[0][0]);
   const int comp = blockIdx.y, img = blockIdx.z;
@@ -411,37 +411,55 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
       for (int i = 0; i < 64; i++) { sum += d[i]; cnt += (d[i] >= maxsample); }
     }
     if (cnt != 0 && cnt != 64) {
+      // preprocess_deringing jcdctmgr.c:416-498, restated for lanes in lock step: ONE pass over the 64 zig-zag positions with
+      // the block in registers (the zig-zag order is a compile-time permutation of them).  A run of saturated samples needs
+      //  * the two samples in front of it as they are AFTER earlier runs were rewritten (f1, f2): the last two final values,
+      //    kept in registers as the pass goes;
+      //  * its length and the two ORIGINAL samples behind it (l1, l2): the length is a count of consecutive ones in the lane's
+      //    64-bit saturation mask, the samples are the only data-dependent reads -- they come from the lane's LDS column of
+      //    originals, once per run;
+      //  * the spline position, accumulated step by step in float exactly as the reference's loop does.
+      // (12-bit data, where maxsample stays 127 and nearly every block takes this path, walked its runs with LDS reads and
+      // lane-private loops before: 2.0 ms per 8192x8192 frame, 7 times the 8-bit kernel's time per block.)
+      unsigned mlo = 0u, mhi = 0u;
 #pragma unroll
-      for (int i = 0; i < 64; i++) lds[i][lane] = (dcol_t)d[i];
+      for (int i = 0; i < 64; i++) {
+        lds[i][lane] = (dcol_t)d[kZZ.v[i]];
+        if (i < 32) mlo |= (unsigned)(d[kZZ.v[i]] >= maxsample) << i;
+        else mhi |= (unsigned)(d[kZZ.v[i]] >= maxsample) << (i - 32);
+      }
+      const unsigned long long sat = ((unsigned long long)mhi << 32) | mlo;
       const int q0 = qz[0];
       const int a = min(31, 2 * q0);
       const int b = (maxsample * 64 - sum) / cnt;   // C division truncates toward zero: negative for 12-bit data (T9)
       const int maxovershoot = maxsample + min(a, b);
-      int n = 0;
-      do {
-        if (lds[d_zz[n]][lane] < maxsample) { n++; continue; }
-        const int start = n;
-        while (++n < 64 && lds[d_zz[n]][lane] >= maxsample) {}
-        const int end = n;
-        const int f1 = lds[d_zz[start >= 1 ? start - 1 : 0]][lane];
-        const int f2 = lds[d_zz[start >= 2 ? start - 2 : 0]][lane];
-        const int l1 = lds[d_zz[end < 63 ? end : 63]][lane];
-        const int l2 = lds[d_zz[end < 62 ? end + 1 : 63]][lane];
-        int fslope = max(f1 - f2, maxsample - f1);
-        int lslope = max(l1 - l2, maxsample - l1);
-        if (start == 0) fslope = lslope;
-        if (end == 64) lslope = fslope;
-        const int length = end - start;
-        const float step = 1.f / (float)(length + 1);
-        float position = step;
-        for (int i = start; i < end; i++, position += step) {
-          const int tmp = (int)ceilf(catmull_rom(maxsample - fslope, maxsample, maxsample, maxsample - lslope, position, length));
-          lds[d_zz[i]][lane] = (dcol_t)min(tmp, maxovershoot);
-        }
-        n++;
-      } while (n < 64);
+      int prev1 = 0, prev2 = 0, fslope = 0, lslope = 0, length = 0;
+      float step = 0.f, position = 0.f;
 #pragma unroll
-      for (int i = 0; i < 64; i++) d[i] = lds[i][lane];
+      for (int i = 0; i < 64; i++) {
+        int v = d[kZZ.v[i]];
+        if ((sat >> i) & 1ull) {
+          if (i == 0 || !((sat >> (i - 1)) & 1ull)) {          // first sample of a run
+            length = __builtin_ctzll(~(sat >> i));                // (zeros shifted in at the top end the count at position 64)
+            const int end = i + length;
+            const int f1 = i >= 1 ? prev1 : v;
+            const int f2 = i >= 2 ? prev2 : i == 1 ? prev1 : v;
+            const int l1 = lds[end < 63 ? end : 63][lane];
+            const int l2 = lds[end < 62 ? end + 1 : 63][lane];
+            fslope = max(f1 - f2, maxsample - f1);
+            lslope = max(l1 - l2, maxsample - l1);
+            if (i == 0) fslope = lslope;
+            if (end == 64) lslope = fslope;
+            step = 1.f / (float)(length + 1);
+            position = step;
+          }
+          const int tmp = (int)ceilf(catmull_rom(maxsample - fslope, maxsample, maxsample, maxsample - lslope, position, length));
+          v = min(tmp, maxovershoot);
+          position += step;
+          d[kZZ.v[i]] = v;
+        }
+        prev2 = prev1; prev1 = v;
+      }
     }
   }
 #pragma unroll
@@ -470,7 +488,7 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
   const bool clampq = C.deringing != 0;
   constexpr bool stats = STATS;
   typedef unsigned __attribute__((may_alias)) hist_alias;
-  constexpr int NCOPY = W12 ? 16 : 8;
+  constexpr int NCOPY = 8;
   hist_alias *hist = reinterpret_cast<hist_alias *>(&lds_raw[0][0]);   // NCOPY interleaved copies of 256 bins (the deringing columns are dead)
   if (stats) {
 #pragma unroll
@@ -1631,6 +1649,21 @@ __device__ __forceinline__ void defer_blocks(bool mine, unsigned *__restrict__ l
   }
 }
 
+// What the host sizes the first tier's queue capacity by (mjh_encoder.cpp, run_pipeline): list[1..3] = blocks of the batch with
+// more than 16 / 24 / 32 queue records, whatever the capacity of the kernel that counts them -- the SAME quantity at every
+// capacity, so the choice made from it is a fixed point for a steady workload.  Three atomics per wave and pass.
+__device__ __forceinline__ void count_heavy(unsigned *__restrict__ list, bool inside, int nq, int lane)
+{
+  const unsigned long long b16 = __ballot(inside && nq > 16);
+  if (b16 == 0ull) return;
+  const unsigned long long b24 = __ballot(inside && nq > 24), b32 = __ballot(inside && nq > 32);
+  if (lane == 0) {
+    atomicAdd(&list[1], (unsigned)__popcll(b16));
+    if (b24) atomicAdd(&list[2], (unsigned)__popcll(b24));
+    if (b32) atomicAdd(&list[3], (unsigned)__popcll(b32));
+  }
+}
+
 // band limits + the per-block outputs of trellis_eob_opt ([image][real blocks of all components]); EXT kernels only
 struct MjhTrellisExt {
   int Ss, Se;
@@ -1685,6 +1718,7 @@ k_trellis_ac_q(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__rest
     for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
     nq = trellis_q_phase1<QN, EXT>(xs, Q->dq8[cc.qtbl], Q->rcp8q[cc.qtbl], Q->lambda_tbl[cc.qtbl], lambda, col, lane, azd63, ext.Ss, ext.Se);
     defer_blocks(inside && nq > QN, worklist, (unsigned)img, ((unsigned)comp << 28) | (unsigned)blk, 0u, xs, dense, dense_cap, true, lane);
+    if (!EXT) count_heavy(worklist, inside, nq, lane);
   }
   __syncthreads();
   int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
@@ -1865,11 +1899,11 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
                 int16_t *__restrict__ dense, unsigned dense_cap, unsigned long long *__restrict__ nzmask,
                 MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp)
 {
-  static_assert(QN >= 16 && QN <= 31 && NPASS >= 1 && NPASS <= 8, "queue capacity / passes");
+  static_assert(QN >= 16 && QN <= 63 && NPASS >= 1 && NPASS <= 8, "queue capacity / passes");
   constexpr int TILE = 64 * NPASS;
   __shared__ unsigned fhist[FST ? 2 : 1][FST ? 256 : 1];   // FST: two interleaved copies of the symbol histogram of this tile
   __shared__ uint2 col[QN][64];          // tile sort scratch; per pass: queue records -> live entries {azd, acc} -> value column
-  __shared__ unsigned short info[QN][64];   // live entry e (>= 1) at [e-1]: position | back entry << 6 | magnitude (< 16) << 11 | sign << 15
+  __shared__ unsigned short info[QN][64];   // live entry e (>= 1) at [e-1]: position | back entry << 6 | magnitude (< 16) << 12 (the signs: one bit per position in a register)
   __shared__ float4 rate_rows[16];
   typedef unsigned __attribute__((may_alias)) u_alias;
   typedef unsigned short __attribute__((may_alias)) us_alias;
@@ -1971,12 +2005,14 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
       }
       azd63 = azd;
       defer_blocks(inside && (nq > QN || qmax >= 16), worklist, (unsigned)img, ((unsigned)comp << 28) | (unsigned)blk, 0u, xs, dense, dense_cap, true, lane);
+      count_heavy(worklist, inside, nq, lane);
     }
     const bool work = inside && nq <= QN && qmax < 16;
     if (FST && inside && !work) nq8[gblk] = 0xFFu;     // deferred: its statistics are counted from its records (k_stats_ac_compact, deferred-only form)
 
     // ---- the walk: every lane consumes its own records; the next record is always one load ahead ----
     int nlive = 1, qi = 0, last = 0;
+    unsigned long long neg = 0ull;          // positions whose coefficient is negative (of the entries created so far)
     bool act = work && nq > 0;
     int i = 0, x = 0, qval = 0, ncd = 0, sgn = 0, e = 0, beste = -1, bestk = 0;
     float azd_prev = 0.0f, azd_cur = 0.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f, best = 1e38f;
@@ -2031,7 +2067,8 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
           if (beste >= 0) {
             const int mag = (bestk < ncd - 1) ? (2 << bestk) - 1 : qval;
             col[nlive - 1][lane] = make_uint2(__float_as_uint(azd_cur), __float_as_uint(best));     // live entry nlive
-            info[nlive - 1][lane] = (unsigned short)((unsigned)i | ((unsigned)beste << 6) | ((unsigned)mag << 11) | ((unsigned)sgn << 15));
+            info[nlive - 1][lane] = (unsigned short)((unsigned)i | ((unsigned)beste << 6) | ((unsigned)mag << 12));
+            neg |= (unsigned long long)sgn << i;
             // end-of-block choice (jcdctmgr.c:1187-1207): entries appear in position order, strict '<' keeps the first minimum
             float c = best + azd63;
             c = c - azd_cur;
@@ -2057,8 +2094,8 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     while (__builtin_amdgcn_ballot_w64(e2 > 0) != 0ull) {
       if (e2 > 0) {
         const unsigned inf = info[e2 - 1][lane];
-        const int mag = (int)((inf >> 11) & 15u), pos = (int)(inf & 63u);
-        const int v = (inf >> 15) ? -mag : mag;
+        const int mag = (int)(inf >> 12), pos = (int)(inf & 63u);
+        const int v = ((neg >> pos) & 1ull) ? -mag : mag;
         colh[((cnt >> 2) * 64 + lane) * 4 + (cnt & 3)] = (unsigned short)v;
         pmask |= 1ull << pos;
         cnt++;
@@ -2067,7 +2104,7 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
           else if (pos < 63) atomicAdd(&hh[0], 1u);          // the highest kept position is not 63: EOB
           up_pos = pos; up_mag = mag;
         }
-        e2 = (int)((inf >> 6) & 31u);
+        e2 = (int)((inf >> 6) & 63u);
       }
     }
     if (FST && work) {
@@ -3407,7 +3444,7 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   }
   // MJH_TRELLIS_VARIANT: queue capacity of the first tier: 0 = 16, 1 = 20 (24 in the tile-sorted kernel), 2 = 24, 3 = 32 (all bit-identical);
   // second and third tier: blocks with more than QN (then 32) non-zero positions, from their dense copies
-  if (nzmask && nq8 && v3_passes > 0 && variant <= 2) {
+  if (nzmask && nq8 && v3_passes > 0 && variant <= 4) {
     // the tile-sorted kernel: first tier of the plain compact pass; its work list (more than 16 records, or a magnitude >= 16)
     // goes through the general tiers below
     const int np = (!fastdiv || st || variant > 0) ? 4 : v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
@@ -3418,7 +3455,10 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     const int4 tv = make_int4(t0[0], t0[1], t0[2], t0[3]);
 #define LV3Q(QN, NP, FDV, FSV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, NP, FDV, FSV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask, st, ss)
 #define LV3(NP, FDV, FSV) LV3Q(16, NP, FDV, FSV)
-    if (variant > 0) {   // more records per block (higher qualities): the 24-record instantiation, 4 passes
+    if (variant >= 3 && !st) {   // q90 and up: 32 / 48 records (20 / 30 KB of LDS per wave)
+      if (variant == 3) { if (fastdiv) LV3Q(32, 4, true, false); else LV3Q(32, 4, false, false); }
+      else if (fastdiv) LV3Q(48, 4, true, false); else LV3Q(48, 4, false, false);
+    } else if (variant > 0) {   // more records per block (higher qualities): the 24-record instantiation, 4 passes
       if (st) { if (fastdiv) LV3Q(24, 4, true, true); else LV3Q(24, 4, false, true); }
       else if (fastdiv) LV3Q(24, 4, true, false); else LV3Q(24, 4, false, false);
     } else if (st) { if (fastdiv) LV3(4, true, true); else LV3(4, false, true); }     // statistics of the final coefficients counted in the back-track
@@ -3426,15 +3466,21 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     else switch (np) { case 8: LV3(8, true, false); break; case 4: LV3(4, true, false); break; case 2: LV3(2, true, false); break; default: LV3(1, true, false); break; }
 #undef LV3
 #undef LV3Q
+    if (variant >= 3 && !st)   // what is left has more than 32 records or a magnitude >= 16: one general tier that takes everything
+      hipLaunchKernelGGL((k_trellis_ac_qd<63, false, false, true>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
+                         (const unsigned *)worklist, (unsigned *)nullptr, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
+    else {
     hipLaunchKernelGGL((k_trellis_ac_qd<32, false, false, true>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
                        (const unsigned *)worklist, worklist2, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
     hipLaunchKernelGGL((k_trellis_ac_qd<63, false, false, true>), dim3(1024), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
                        (const unsigned *)worklist2, (unsigned *)nullptr, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
+    }
     if (st) {   // the deferred blocks' symbols, from the records the general tiers wrote
       dim3 gridd((max_nblk(C) + 256 * STATS_AC_ITER - 1) / (256 * STATS_AC_ITER), C.ncomp, n);
       hipLaunchKernelGGL(k_stats_ac_compact, gridd, dim3(256), 0, s, C, (const int16_t *)q, (const unsigned long long *)nzmask, tabs, spi, ss, 0, (const uint8_t *)nq8);
     }
   } else if (nzmask) {   // compact records out (the caller guarantees: plain pass, no fused statistics)
+    if (variant > 3) variant = 3;   // (the general first tier stops at 32 records)
 #define LQC(QN) hipLaunchKernelGGL((k_trellis_ac_q<QN, false, false, true>), gridq, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, wv, lambda, worklist, (int16_t *)dense, dense_cap, st, ss, ext)
 #define LDC(QN, GRID, WL, WLN) hipLaunchKernelGGL((k_trellis_ac_qd<QN, false, false, true>), dim3(GRID), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda, (const unsigned *)WL, WLN, (const int16_t *)dense, dense_cap, st, ss, ext)
     switch (variant) { case 1: LQC(20); break; case 2: LQC(24); break; case 3: LQC(32); break; default: LQC(16); break; }
@@ -3443,10 +3489,12 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
 #undef LQC
 #undef LDC
   } else if (st) {
+    if (variant > 3) variant = 3;
     switch (variant) { case 1: LQ(20, true); break; case 2: LQ(24, true); break; case 3: LQ(32, true); break; default: LQ(16, true); break; }
     if (variant == 3) LD(63, true, 2048, worklist, (unsigned *)nullptr);
     else { LD(32, true, 2048, worklist, worklist2); LD(63, true, 1024, worklist2, (unsigned *)nullptr); }
   } else {
+    if (variant > 3) variant = 3;
     switch (variant) { case 1: LQ(20, false); break; case 2: LQ(24, false); break; case 3: LQ(32, false); break; default: LQ(16, false); break; }
     if (variant == 3) LD(63, false, 2048, worklist, (unsigned *)nullptr);
     else { LD(32, false, 2048, worklist, worklist2); LD(63, false, 1024, worklist2, (unsigned *)nullptr); }

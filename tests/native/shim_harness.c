@@ -106,6 +106,34 @@ int main(int argc, char **argv)
       jpeg_start_compress(&c, TRUE); rows(&c, img, 150); jpeg_finish_compress(&c);
       printf("abort_reuse again %lu %016lx\n", n, hash(o, n));
       jpeg_destroy_compress(&c); free(o); free(img);
+    } else if (!strcmp(sc, "abort_midway")) {
+      /* an image is abandoned after more than 512 of its scanlines were written (the drop-in has sent them to the device
+       * by then), then the same object compresses a DIFFERENT image: nothing of the abandoned one may show; the same again
+       * with the error_exit longjmp out of jpeg_finish_compress, and twice in a row (both staging buffers of the object) */
+      struct jpeg_compress_struct c;
+      unsigned char *o = NULL, *a = make_image(640, 700, 21), *b = make_image(640, 700, 22), *d = make_image(640, 700, 23);
+      unsigned long n = 0;
+      int k;
+      c.err = jpeg_std_error(&err);
+      err.error_exit = my_exit;
+      jpeg_create_compress(&c);
+      jpeg_mem_dest(&c, &o, &n);
+      setup(&c, 640, 700, 75, 1);
+      jpeg_start_compress(&c, TRUE); rows(&c, a, 600); jpeg_abort_compress(&c);
+      jpeg_mem_dest(&c, &o, &n);
+      jpeg_start_compress(&c, TRUE); rows(&c, b, 700); jpeg_finish_compress(&c);
+      printf("abort_midway first %lu %016lx\n", n, hash(o, n));
+      for (k = 0; k < 2; k++) {
+        if (!setjmp(env)) { jpeg_start_compress(&c, TRUE); rows(&c, k ? b : d, 520 + k * 100); jpeg_finish_compress(&c); printf("abort_midway: finish did not fail\n"); }
+        else jpeg_abort_compress(&c);
+      }
+      jpeg_mem_dest(&c, &o, &n);
+      jpeg_start_compress(&c, TRUE); rows(&c, a, 700); jpeg_finish_compress(&c);
+      printf("abort_midway second %lu %016lx\n", n, hash(o, n));
+      jpeg_mem_dest(&c, &o, &n);
+      jpeg_start_compress(&c, TRUE); rows(&c, d, 700); jpeg_finish_compress(&c);
+      printf("abort_midway third %lu %016lx\n", n, hash(o, n));
+      jpeg_destroy_compress(&c); free(o); free(a); free(b); free(d);
     } else if (!strcmp(sc, "markers")) {
       /* COM + APPn + ICC markers written by the application between start and the first scanline */
       struct jpeg_compress_struct c;

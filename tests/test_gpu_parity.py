@@ -374,3 +374,31 @@ def test_progressive_eob_run_longer_than_32767_blocks():
         out = enc.encode_host(img)[0]
         enc.close()
         assert out == O.encode(O.make_params(w, h, **kw), img), kw
+
+
+@pytest.mark.parametrize("quality,sample", [(75, (2, 2)), (88, (2, 2)), (92, (1, 1)), (97, (2, 1))])
+def test_every_first_tier_capacity_of_the_ac_trellis_gives_the_same_file(quality, sample):
+    """MJH_TRELLIS_VARIANT pins the queue capacity of the AC trellis' first tier (16 / 20 / 24 / 32 / 48 records, the last two
+    only in the tile-sorted kernel): whatever it is -- nearly every block deferred at 16 records and q97, none at 48 and q75 --
+    the file is the oracle's; so is the adaptive choice, from its starting point and after it has seen a batch.  Sequential
+    and progressive mode (the progressive trellis passes run the same kernel)."""
+    w, h = 600, 424
+    rng = np.random.default_rng(quality)
+    img = O.synthetic_frame(w, h, 60 + quality)
+    img[100:300, 200:500] = rng.integers(0, 256, (200, 300, 3), dtype=np.uint8)      # a busy region: blocks with 40+ records
+    for kw in (dict(quality=quality, baseline=True, sample=sample), dict(quality=quality, fastcrush=True, sample=sample)):
+        want = O.encode(O.make_params(w, h, **kw), img)
+        for variant in ("0", "1", "2", "3", "4", None):
+            if variant is None:
+                os.environ.pop("MJH_TRELLIS_VARIANT", None)
+            else:
+                os.environ["MJH_TRELLIS_VARIANT"] = variant
+            try:
+                enc = M.Encoder(M.make_params(w, h, **kw), max_batch=3)
+            finally:
+                os.environ.pop("MJH_TRELLIS_VARIANT", None)
+            frames = np.stack([img, img[::-1].copy(), img])
+            for rnd in range(3 if variant is None else 1):                             # adaptive: the choice moves between batches
+                got = enc.encode_host(frames)
+                assert got[0] == want and got[2] == want, (kw, variant, rnd)
+            enc.close()
