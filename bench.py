@@ -44,6 +44,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0
+PCIE_PEAK_GBS = 63.0   # PCIe Gen5 x16 per GPU (MI355X_MICROARCH.md)
 
 # BASELINE.json configs (SURVEY 8d "Config -> concrete runs").  batch = frames per step per GPU.
 CONFIGS = {
@@ -154,6 +155,19 @@ INTERVAL_KERNELS = {
 }
 
 
+def kernel_source_stamp():
+    """sha256 over the sources every kernel is built from (mozjpeg_amd/csrc/*.hip, *.h): tools/pmc_traffic.py writes it
+    into the traffic summaries it produces, and a summary whose stamp differs from the tree's is never quoted"""
+    import hashlib
+    hsh = hashlib.sha256()
+    src = os.path.join(ROOT, "mozjpeg_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h")):
+            hsh.update(name.encode())
+            hsh.update(open(os.path.join(src, name), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def dominant_traffic(config, dom, frames_per_call):
     """HBM bytes per launch of the dominant interval's kernels from the newest committed PMC passes of THIS configuration
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, fetch corrected by the factor calibrated on k_color;
@@ -162,15 +176,23 @@ def dominant_traffic(config, dom, frames_per_call):
     paths = [p for p in glob.glob(os.path.join(ROOT, "profiles", pat))
              if config != "metric" or not any(("_%s_" % c) in os.path.basename(p) for c in CONFIGS if c != "metric")]
     prefixes = INTERVAL_KERNELS.get(dom.split("(")[0] if dom.startswith("prog_") else dom, ())
+    stamp = kernel_source_stamp()
+    stale = None
     for path in sorted(paths, reverse=True):
         try:
             pmc = json.load(open(path))
+            if pmc.get("kernel_source_stamp") != stamp:     # taken on other kernels than the ones that run now
+                stale = stale or os.path.relpath(path, ROOT)
+                continue
             per_frame = sum(v["hbm_bytes_per_frame"] for k, v in pmc["kernels"].items() if any(k.startswith(pf) for pf in prefixes))
             if per_frame <= 0:
                 continue
-            return int(per_frame * frames_per_call), os.path.relpath(path, ROOT) + " (bytes per launch, scaled to this batch)"
+            return int(per_frame * frames_per_call), "%s (bytes per launch, scaled to this batch; passes taken at git %s, kernel sources %s)" % (
+                os.path.relpath(path, ROOT), pmc.get("profile_head", "?"), stamp)
         except Exception:
             continue
+    if stale:
+        return None, "stale: the kernel sources changed after the newest PMC passes of this configuration (%s) -- re-run tools/profile_round.sh" % stale
     return None, "no PMC passes committed for this configuration / interval"
 
 
@@ -327,6 +349,7 @@ def main():
     ap.add_argument("--config", default="metric", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="frames per encode call per GPU (0 = the config's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of host CPU work for the cpu_baseline leg")
     ap.add_argument("--no-host-leg", action="store_true")
     ap.add_argument("--no-inflight-leg", action="store_true", help="skip the three-batches-in-flight measurement (extra information)")
     ap.add_argument("--host-seconds", type=float, default=3.0)
@@ -612,15 +635,28 @@ def main():
                     "value": round(sum(vals), 2), "unit": "Mpixels/s", "ranks_measured": len(good), "ranks": world,
                     "per_rank_min": min(vals), "per_rank_max": max(vals),
                     "input_GBps": round(sum(h["input_GBps"] for h in good), 2),
+                    "per_rank_input_GBps": [h["input_GBps"] for h in good],
+                    "host_dram_read_GBps": round(sum(h["input_GBps"] for h in good), 2),   # pinned frames are read in place by the DMA engines: one pass over host DRAM
                     "output_GBps": round(sum(h["output_GBps"] for h in good), 3),
                     "frames_per_call": good[0]["frames_per_call"],
                     "files_identical_to_device_run": [h["files_identical_to_device_run"] for h in good],
                     "errors": [h["error"] for h in host_all if h and "error" in h],
                     "path": "every rank at the same time: " + good[0]["path"]}
+        hi = out.get("host_inclusive")
+        if isinstance(hi, dict) and "value" in hi:
+            # SURVEY 8d / BASELINE.md section 3 define the metric host -> host: this is that number, lifted to the top level;
+            # at one GPU it is bound by the host link, so its roofline is the link's, not HBM's
+            out["value_host_inclusive"] = hi["value"]
+            out["host_roofline"] = {"bound": "pcie", "achieved": hi.get("input_GBps"), "peak": PCIE_PEAK_GBS * world, "unit": "GB/s",
+                                    "frac": round(hi.get("input_GBps", 0.0) / (PCIE_PEAK_GBS * world), 4),
+                                    "what": "pinned host pixels read over PCIe Gen5 x16 (63 GB/s per GPU, MI355X_MICROARCH.md); the files going back add output_GBps"}
         if pool_res is not None:
             out["pool_host"] = pool_res
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(frames[0], kw)
+            out["cpu_baseline"] = cpu_baseline(frames[0], kw, args.cpu_budget)
+            out["cpu_baseline"]["simd_note"] = ("C-only build of the reference (no NASM in the image); SURVEY section 6 estimates its SIMD build at ~17 instead of "
+                                                "~14 Mpixels/s per core on the trellis encode (the trellis and the entropy coder are scalar either way, "
+                                                "simd/CMakeLists.txt:44-52), i.e. the ratio would move by ~20 %")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

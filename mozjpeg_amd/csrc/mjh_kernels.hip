@@ -2317,7 +2317,7 @@ k_trellis_dc(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restri
 // is a min3 tree on the critical path with the index (first minimum, as the reference's strict '<' scan) recovered beside it.
 // Same operations on the same values in the same order per candidate: bit-identical results.
 // ---------------------------------------------------------------------------------------------
-template <int L> __device__ __forceinline__ int row_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + L, 0xF, 0xF, false); }   // row_newbcast:L
+template <int L> __device__ __forceinline__ int row_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + L, 0xF, 0xF, true); }   // row_newbcast:L
 template <int L> __device__ __forceinline__ float row_bcast_f(float v) { return __int_as_float(row_bcast<L>(__float_as_int(v))); }
 
 __global__ void __launch_bounds__(64)
@@ -2504,6 +2504,12 @@ template <int CTRL> __device__ __forceinline__ float dpp_f(float old, float v)
 {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
+// the same with lanes that have no source reading 0 (bound_ctrl): a DPP operand the compiler may fold into the consuming
+// instruction instead of a v_mov_b32_dpp of its own (4 issue cycles each, profiles/r04a_valu_rate_summary.md)
+template <int CTRL> __device__ __forceinline__ float dpp_f0(float v)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 
 __global__ void __launch_bounds__(64)
 k_trellis_dc3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
@@ -2580,13 +2586,13 @@ k_trellis_dc3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restr
           const int D = c0 - prev_c0;
           const float Rj = dc_rate(rsi, D + k - 7), R0 = dc_rate(rsi, D - 8);
           // predecessor in lane M: rate of difference number k - M + 8 = the value of lane k + 7 - M (number 0: R0)
-          const float c_0 = (dpp_f<0x107>(0.0f, Rj) + dist) + row_bcast_f<0>(prev_cost);
-          const float c_1 = (dpp_f<0x106>(0.0f, Rj) + dist) + row_bcast_f<1>(prev_cost);
-          const float c_2 = (dpp_f<0x105>(0.0f, Rj) + dist) + row_bcast_f<2>(prev_cost);
-          const float c_3 = (dpp_f<0x104>(0.0f, Rj) + dist) + row_bcast_f<3>(prev_cost);
-          const float c_4 = (dpp_f<0x103>(0.0f, Rj) + dist) + row_bcast_f<4>(prev_cost);
-          const float c_5 = (dpp_f<0x102>(0.0f, Rj) + dist) + row_bcast_f<5>(prev_cost);
-          const float c_6 = (dpp_f<0x101>(0.0f, Rj) + dist) + row_bcast_f<6>(prev_cost);
+          const float c_0 = (dpp_f0<0x107>(Rj) + dist) + row_bcast_f<0>(prev_cost);
+          const float c_1 = (dpp_f0<0x106>(Rj) + dist) + row_bcast_f<1>(prev_cost);
+          const float c_2 = (dpp_f0<0x105>(Rj) + dist) + row_bcast_f<2>(prev_cost);
+          const float c_3 = (dpp_f0<0x104>(Rj) + dist) + row_bcast_f<3>(prev_cost);
+          const float c_4 = (dpp_f0<0x103>(Rj) + dist) + row_bcast_f<4>(prev_cost);
+          const float c_5 = (dpp_f0<0x102>(Rj) + dist) + row_bcast_f<5>(prev_cost);
+          const float c_6 = (dpp_f0<0x101>(Rj) + dist) + row_bcast_f<6>(prev_cost);
           const float c_7 = (Rj + dist) + row_bcast_f<7>(prev_cost);
           const float c_8 = (dpp_f<0x111>(R0, Rj) + dist) + row_bcast_f<8>(prev_cost);     // row_shr:1; lane 0 keeps R0
           const float m = fminf(fminf(fminf(c_0, c_1), fminf(c_2, c_3)), fminf(fminf(fminf(c_4, c_5), fminf(c_6, c_7)), c_8));

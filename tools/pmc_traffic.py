@@ -8,8 +8,12 @@ Both counters are reported in KB.  On gfx950 FETCH_SIZE under-reports coalesced 
 (64 B counted per 128-B request): the factor is not assumed but calibrated on k_color, whose only
 input is exactly IN_BYTES_PER_FRAME bytes per frame, and applied to every kernel's fetch."""
 import json
+import os
 import sqlite3
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def per_kernel(db_path, counter):
@@ -38,7 +42,17 @@ def main():
         kernels[k] = {"fetch_bytes_corrected": int(f), "write_bytes": int(w), "hbm_bytes": int(f + w),
                       "hbm_bytes_per_frame": int((f + w) / frames), "launches_sampled": fetch.get(k, (0, 0))[1]}
     kernels = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes"]))
+    # which tree the passes belong to: bench.py quotes a summary only while the kernel sources still hash to this stamp
+    sys.path.insert(0, ROOT)
+    import bench
+    try:
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+        if subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "mozjpeg_amd/csrc"], stderr=subprocess.DEVNULL).decode().strip():
+            head += "+uncommitted"
+    except Exception:
+        head = "unknown"
     print(json.dumps({
+        "profile_head": head, "kernel_source_stamp": bench.kernel_source_stamp(),
         "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate --kernel-trace passes; bytes per launch "
                 "(%d frames); fetch scaled by the factor calibrated on k_color's known input bytes" % frames,
         "frames_per_launch": frames, "fetch_calibration_factor": round(factor, 4), "kernels": kernels}, indent=1))
