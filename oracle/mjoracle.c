@@ -1285,6 +1285,525 @@ static void trellis_component(enc_t *e, int ci, const dtbl *dctbl, const dtbl *a
   free(azbc); free(abc); free(block_run_start); free(requires_eob);
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * f4  arithmetic entropy coding: jcarith.c.  The QM coder of ITU-T T.81 Annex D with the
+ * statistics models of F.1.4 / G.1.3; one adaptive state per scan, so a scan is ONE sequential chain.
+ * ------------------------------------------------------------------------------------------ */
+#include "mjo_arith_table.h"
+
+enum { ARI_DC_L = 0, ARI_DC_U = 1, ARI_AC_K = 5 };   /* conditioning defaults, jcparam.c:417-419 (the DAC marker carries them) */
+
+typedef struct {
+  long c, a, sc, zc;     /* code register, interval, stacked 0xFF bytes, pending 0x00 bytes (jcarith.c:31-38) */
+  int ct, buffer;
+  bytebuf *out;          /* NULL: nothing is written, only the statistics adapt (trellis passes, jcarith.c:127-129) */
+  unsigned char dc_stats[4][64], ac_stats[4][256];
+  unsigned char fixed_bin[4];
+  int last_dc_val[MJO_MAX_COMPS], dc_context[MJO_MAX_COMPS];
+} arith_t;
+
+static void ari_byte(arith_t *A, int v) { if (A->out) bb_put(A->out, v); }
+
+static void ari_zeros(arith_t *A) { while (A->zc) { ari_byte(A, 0x00); A->zc--; } }
+
+/* the byte that left the code register (renormalisation D.1.6) or is flushed at the end (D.1.8): `over` = a carry
+ * propagates into the bytes held back (jcarith.c:278-316 and :160-190 share this logic) */
+static void ari_shift_out(arith_t *A, long temp, int final)
+{
+  if (final ? (A->c & 0xF8000000L) != 0 : temp > 0xFF) {
+    if (A->buffer >= 0) {
+      ari_zeros(A);
+      ari_byte(A, A->buffer + 1);
+      if (A->buffer + 1 == 0xFF) ari_byte(A, 0x00);
+    }
+    A->zc += A->sc;        /* the carry turns the stacked 0xFF bytes into 0x00 */
+    A->sc = 0;
+    if (!final) A->buffer = (int)(temp & 0xFF);
+  } else if (!final && temp == 0xFF) {
+    A->sc++;
+  } else {
+    if (A->buffer == 0) A->zc++;
+    else if (A->buffer >= 0) { ari_zeros(A); ari_byte(A, A->buffer); }
+    if (A->sc) {
+      ari_zeros(A);
+      do { ari_byte(A, 0xFF); ari_byte(A, 0x00); } while (--A->sc);
+    }
+    if (!final) A->buffer = (int)(temp & 0xFF);
+  }
+}
+
+static void ari_finish(arith_t *A)
+{ /* finish_pass jcarith.c:142-203: the value in the interval with the most trailing zero bits, pending bytes, then
+   * the last two bytes unless they are zero ("Pacman" termination) */
+  long temp = (A->a - 1 + A->c) & 0xFFFF0000L;
+  A->c = temp < A->c ? temp + 0x8000L : temp;
+  A->c <<= A->ct;
+  ari_shift_out(A, 0, 1);
+  if (A->c & 0x7FFF800L) {
+    ari_zeros(A);
+    ari_byte(A, (int)((A->c >> 19) & 0xFF));
+    if (((A->c >> 19) & 0xFF) == 0xFF) ari_byte(A, 0x00);
+    if (A->c & 0x7F800L) {
+      ari_byte(A, (int)((A->c >> 11) & 0xFF));
+      if (((A->c >> 11) & 0xFF) == 0xFF) ari_byte(A, 0x00);
+    }
+  }
+}
+
+static void ari_encode(arith_t *A, unsigned char *st, int val)
+{ /* arith_encode jcarith.c:229-320 */
+  const int sv = *st, idx = sv & 0x7F;
+  const long qe = mjo_ari_qe[idx];
+  A->a -= qe;
+  if (val != (sv >> 7)) {                 /* less probable symbol */
+    if (A->a >= qe) { A->c += A->a; A->a = qe; }
+    *st = (unsigned char)((sv & 0x80) ^ mjo_ari_nlps[idx]);
+  } else {
+    if (A->a >= 0x8000L) return;          /* no renormalisation, no adaptation */
+    if (A->a < qe) { A->c += A->a; A->a = qe; }
+    *st = (unsigned char)((sv & 0x80) ^ mjo_ari_nmps[idx]);
+  }
+  do {
+    A->a <<= 1;
+    A->c <<= 1;
+    if (--A->ct == 0) {
+      ari_shift_out(A, A->c >> 19, 0);
+      A->c &= 0x7FFFFL;
+      A->ct += 8;
+    }
+  } while (A->a < 0x8000L);
+}
+
+static void ari_reset_coder(arith_t *A)
+{ /* start_pass jcarith.c:878-884, emit_restart :345-351 */
+  A->c = 0; A->a = 0x10000L; A->sc = 0; A->zc = 0; A->ct = 11; A->buffer = -1;
+}
+
+/* statistics areas of the scan's components: DC where the scan codes DC differences, AC where it has an AC band
+ * (`progressive` as the CALLER of the reference sees it: start_pass switches it off during trellis passes, :826,
+ * emit_restart does not, :328-341) */
+static void ari_reset_stats(arith_t *A, const enc_t *e, const scan_t *sc, int progressive)
+{
+  int i;
+  for (i = 0; i < sc->ncomp; i++) {
+    const int c = sc->comp[i];
+    if (!progressive || (sc->Ss == 0 && sc->Ah == 0)) {
+      memset(A->dc_stats[e->p->dc_tbl_no[c]], 0, 64);
+      A->last_dc_val[i] = 0;
+      A->dc_context[i] = 0;
+    }
+    if (!progressive || sc->Se) memset(A->ac_stats[e->p->ac_tbl_no[c]], 0, 256);
+  }
+}
+
+/* magnitude category + magnitude bits of v >= 1 (Figures F.8, F.9): st = the first magnitude bin (SP / SN / the bin behind
+ * the sign), x1 = where the category bins continue (X1 = 20 for DC; for AC the bin itself once more, then 189 / 217);
+ * returns the category mask m (the DC conditioning needs it) */
+static int ari_magnitude(arith_t *A, unsigned char *stats, unsigned char *st, int v, int ac, int k)
+{
+  int m = 0, v2;
+  if (v -= 1) {
+    ari_encode(A, st, 1);
+    m = 1;
+    v2 = v;
+    if (ac) {
+      if (v2 >>= 1) {
+        ari_encode(A, st, 1);
+        m <<= 1;
+        st = stats + (k <= ARI_AC_K ? 189 : 217);
+        while (v2 >>= 1) { ari_encode(A, st, 1); m <<= 1; st++; }
+      }
+    } else {
+      st = stats + 20;
+      while (v2 >>= 1) { ari_encode(A, st, 1); m <<= 1; st++; }
+    }
+  }
+  ari_encode(A, st, 0);
+  st += 14;
+  {
+    int mm = m;
+    while (mm >>= 1) ari_encode(A, st, (mm & v) ? 1 : 0);
+  }
+  return m;
+}
+
+static void ari_dc(arith_t *A, int tbl, int ci, int value)
+{ /* Encode_DC_DIFF, jcarith.c:402-448 / :715-762 */
+  unsigned char *stats = A->dc_stats[tbl], *st = stats + A->dc_context[ci];
+  int v = value - A->last_dc_val[ci], m;
+  if (v == 0) {
+    ari_encode(A, st, 0);
+    A->dc_context[ci] = 0;
+    return;
+  }
+  A->last_dc_val[ci] = value;
+  ari_encode(A, st, 1);
+  if (v > 0) { ari_encode(A, st + 1, 0); st += 2; A->dc_context[ci] = 4; }
+  else { v = -v; ari_encode(A, st + 1, 1); st += 3; A->dc_context[ci] = 8; }
+  m = ari_magnitude(A, stats, st, v, 0, 0);
+  if (m < (int)((1L << ARI_DC_L) >> 1)) A->dc_context[ci] = 0;
+  else if (m > (int)((1L << ARI_DC_U) >> 1)) A->dc_context[ci] += 8;
+}
+
+static void ari_ac_first(arith_t *A, int tbl, const int16_t *blk, int Ss, int Se, int Al)
+{ /* Encode_AC_Coefficients: encode_mcu_AC_first jcarith.c:456-552, and with Ss = 1, Se = 63, Al = 0 the AC part of
+   * the sequential encode_mcu :764-817 */
+  unsigned char *stats = A->ac_stats[tbl], *st;
+  int k, ke, v;
+  for (ke = Se; ke > 0; ke--) {
+    v = blk[ZZ[ke]];
+    if (v < 0) v = -v;
+    if (v >> Al) break;
+  }
+  for (k = Ss; k <= ke; k++) {
+    int neg;
+    st = stats + 3 * (k - 1);
+    ari_encode(A, st, 0);                 /* not the end of the block */
+    for (;;) {
+      v = blk[ZZ[k]];
+      neg = v < 0;
+      if (neg) v = -v;
+      v >>= Al;
+      if (v) break;
+      ari_encode(A, st + 1, 0);
+      st += 3;
+      k++;
+    }
+    ari_encode(A, st + 1, 1);
+    ari_encode(A, A->fixed_bin, neg);
+    ari_magnitude(A, stats, st + 2, v, 1, k);
+  }
+  if (k <= Se) ari_encode(A, stats + 3 * (k - 1), 1);
+}
+
+static void ari_ac_refine(arith_t *A, int tbl, const int16_t *blk, int Ss, int Se, int Ah, int Al)
+{ /* encode_mcu_AC_refine jcarith.c:596-687 */
+  unsigned char *stats = A->ac_stats[tbl], *st;
+  int k, ke, kex, v;
+  for (ke = Se; ke > 0; ke--) {
+    v = blk[ZZ[ke]];
+    if (v < 0) v = -v;
+    if (v >> Al) break;
+  }
+  for (kex = ke; kex > 0; kex--) {
+    v = blk[ZZ[kex]];
+    if (v < 0) v = -v;
+    if (v >> Ah) break;
+  }
+  for (k = Ss; k <= ke; k++) {
+    st = stats + 3 * (k - 1);
+    if (k > kex) ari_encode(A, st, 0);
+    for (;;) {
+      int neg;
+      v = blk[ZZ[k]];
+      neg = v < 0;
+      if (neg) v = -v;
+      v >>= Al;
+      if (v) {
+        if (v >> 1) ari_encode(A, st + 2, v & 1);          /* was non-zero before: its next bit */
+        else { ari_encode(A, st + 1, 1); ari_encode(A, A->fixed_bin, neg); }
+        break;
+      }
+      ari_encode(A, st + 1, 0);
+      st += 3;
+      k++;
+    }
+  }
+  if (k <= Se) ari_encode(A, stats + 3 * (k - 1), 1);
+}
+
+/* one scan (or, `sequential_blocks`: the whole blocks of a trellis pass, jcarith.c:824-826) over the MCU rows r0..r1-1 */
+static void ari_code_rows(enc_t *e, const scan_t *sc, arith_t *A, int sequential_blocks, int r0, int r1, int *restarts_to_go, int *next_restart)
+{
+  const mjo_params *p = e->p;
+  int mr, mc, ci;
+  for (mr = r0; mr < r1; mr++)
+    for (mc = 0; mc < sc->mcus_per_row; mc++) {
+      if (sc->restart_interval) {
+        if (*restarts_to_go == 0) { /* emit_restart :322-352 */
+          ari_finish(A);
+          ari_byte(A, 0xFF); ari_byte(A, 0xD0 + *next_restart);
+          ari_reset_stats(A, e, sc, e->progressive);
+          ari_reset_coder(A);
+          *restarts_to_go = sc->restart_interval;
+          *next_restart = (*next_restart + 1) & 7;
+        }
+        (*restarts_to_go)--;
+      }
+      for (ci = 0; ci < sc->ncomp; ci++) {
+        const int c = sc->comp[ci];
+        const int mw = sc->ncomp == 1 ? 1 : p->h_samp[c], mh = sc->ncomp == 1 ? 1 : p->v_samp[c];
+        int yi, xi;
+        for (yi = 0; yi < mh; yi++)
+          for (xi = 0; xi < mw; xi++) {
+            const int16_t *blk = e->q[c] + ((size_t)(mr * mh + yi) * e->g[c].wpad + (mc * mw + xi)) * 64;
+            if (sequential_blocks || !e->progressive) {
+              ari_dc(A, p->dc_tbl_no[c], ci, blk[0]);
+              ari_ac_first(A, p->ac_tbl_no[c], blk, 1, 63, 0);
+            } else if (sc->Ss == 0 && sc->Ah == 0) ari_dc(A, p->dc_tbl_no[c], ci, blk[0] >> sc->Al);   /* IRIGHT_SHIFT: arithmetic */
+            else if (sc->Ss == 0) ari_encode(A, A->fixed_bin, (blk[0] >> sc->Al) & 1);                  /* encode_mcu_DC_refine :560-590 */
+            else if (sc->Ah == 0) ari_ac_first(A, p->ac_tbl_no[c], blk, sc->Ss, sc->Se, sc->Al);
+            else ari_ac_refine(A, p->ac_tbl_no[c], blk, sc->Ss, sc->Se, sc->Ah, sc->Al);
+          }
+      }
+    }
+}
+
+static void ari_start(arith_t *A, const enc_t *e, const scan_t *sc, int progressive, bytebuf *out)
+{
+  memset(A, 0, sizeof(*A));
+  A->out = out;
+  A->fixed_bin[0] = 113;
+  ari_reset_stats(A, e, sc, progressive);
+  ari_reset_coder(A);
+}
+
+static void code_scan_arith(enc_t *e, const scan_t *sc, bytebuf *out)
+{
+  arith_t A;
+  int rtg = sc->restart_interval, nr = 0;
+  ari_start(&A, e, sc, e->progressive, out);
+  ari_code_rows(e, sc, &A, 0, 0, sc->mcu_rows, &rtg, &nr);
+  ari_finish(&A);
+}
+
+/* ---- quantize_trellis_arith jcdctmgr.c:1334-1667, driven by compress_trellis_pass jccoefct.c:356-486 ----------------
+ * Rate estimates come from the CURRENT state of the adaptive coder (jget_arith_rates jcarith.c:944-976), read once per
+ * iMCU row; after a row has been quantized it is run through the coder (its output discarded), which moves the state the
+ * next row's estimates are read from.  The pass sequencing of jcmaster.c only ever selects component 0 for these passes
+ * when arithmetic coding is on (prepare_for_pass's trellis_pass case does not re-select the scan, and no statistics pass
+ * sits in between: jcmaster.c:686-702, :1001-1005), every one of them starts from a zeroed state and the unquantized
+ * coefficients, so they all give the same result: ONE pass over component 0 is what the reference's passes amount to. */
+typedef struct { float dc[64][2], ac[256][2]; } ari_rates;
+
+static void ari_get_rates(const arith_t *A, int dctbl, int actbl, ari_rates *r)
+{
+  int i;
+  for (i = 0; i < 64 + 256; i++) {
+    const int state = i < 64 ? A->dc_stats[dctbl][i] : A->ac_stats[actbl][i - 64];
+    const int mps = state >> 7;
+    const float prob_lps = (float)((double)mjo_ari_qe[state & 0x7F] / 46340.95);
+    const float prob_0 = mps ? prob_lps : (float)(1.0 - (double)prob_lps);
+    const float prob_1 = (float)(1.0 - (double)prob_0);
+    float *o = i < 64 ? r->dc[i] : r->ac[i - 64];
+    o[0] = (float)(-log((double)prob_0) / log(2.0));
+    o[1] = (float)(-log((double)prob_1) / log(2.0));
+  }
+}
+
+static void trellis_row_arith(enc_t *e, int ci, const ari_rates *r, int br, int Ss, int Se, int *last_dc_io,
+                              float *acc_dc[9], int *back_dc[9], int16_t *cand_dc[9], int *ctx_dc[9])
+{
+  const mjo_params *p = e->p;
+  const mjo_geom *g = &e->g[ci];
+  const uint16_t *qt = p->qtbl[p->quant_tbl_no[ci]];
+  const int v = p->v_samp[ci];
+  int ncand = (2 + 60 / qt[0]) | 1;
+  float lambda_tbl[64];
+  int run_start[64];
+  int i, j, k, l, bi;
+  if (ncand > 9) ncand = 9;
+  memset(run_start, 0, sizeof(run_start));
+  for (i = 0; i < 64; i++) lambda_tbl[i] = (float)(1.0 / (double)((int)qt[i] * (int)qt[i]));
+  for (bi = 0; bi < g->wib; bi++) {
+    const int16_t *src = e->uq[ci] + ((size_t)br * g->wpad + bi) * 64;
+    int16_t *coef = e->q[ci] + ((size_t)br * g->wpad + bi) * 64;
+    float azd[64], acost[64];
+    float norm = 0.0f, lambda, lambda_dc, best_cost;
+    int last_coeff_idx;
+    for (i = 1; i < 64; i++) norm = norm + (float)((int)src[i] * (int)src[i]);
+    norm = (float)((double)norm / 63.0);
+    if (p->lambda_log_scale2 > 0.0f)
+      lambda = (float)(pow(2.0, (double)p->lambda_log_scale1) * (double)1.0f / (pow(2.0, (double)p->lambda_log_scale2) + (double)norm));
+    else
+      lambda = (float)(pow(2.0, (double)p->lambda_log_scale1 - 12.0) * (double)1.0f);
+    lambda_dc = lambda * lambda_tbl[0];
+    azd[Ss - 1] = 0.0f;
+    acost[Ss - 1] = 0.0f;
+
+    if (p->trellis_quant_dc) { /* :1416-1509 */
+      const int sign = src[0] < 0 ? -1 : 0;
+      const int x = src[0] < 0 ? -src[0] : src[0];
+      const int q = 8 * qt[0];
+      const int qval = (x + q / 2) / q;
+      for (k = 0; k < ncand; k++) {
+        int cnd = qval - ncand / 2 + k, delta;
+        float dist;
+        delta = cnd * q - x;
+        dist = (float)(delta * delta) * lambda_dc;
+        cnd *= 1 + 2 * sign;
+        cand_dc[k][bi] = (int16_t)cnd;
+        if (br % v != 0 && p->trellis_delta_dc_weight > 0.0f) {   /* :1440-1456 */
+          const int dc_above_orig = e->uq[ci][((size_t)(br - 1) * g->wpad + bi) * 64];
+          const int dc_above_recon = e->q[ci][((size_t)(br - 1) * g->wpad + bi) * 64] * q;
+          const int dc_orig = src[0], dc_recon = cnd * q;
+          float vertical_dist, t;
+          delta = (dc_above_orig - dc_orig) - (dc_above_recon - dc_recon);
+          vertical_dist = (float)(delta * delta) * lambda_dc;
+          t = vertical_dist - dist;
+          t = p->trellis_delta_dc_weight * t;
+          dist = dist + t;
+        }
+        for (l = 0; l < (bi == 0 ? 1 : ncand); l++) {
+          const int dc_pred = bi == 0 ? *last_dc_io : cand_dc[l][bi - 1];
+          int st = bi == 0 ? 0 : ctx_dc[l][bi - 1], upd = 0, dc_delta = cnd - dc_pred, m, v2;
+          float bits = r->dc[st][dc_delta != 0], cost;
+          if (dc_delta != 0) {
+            bits += r->dc[st + 1][dc_delta < 0];
+            st += 2 + (dc_delta < 0);
+            upd = dc_delta < 0 ? 8 : 4;
+            if (dc_delta < 0) dc_delta = -dc_delta;
+            m = 0;
+            if (dc_delta -= 1) {
+              bits += r->dc[st][1];
+              st = 20;
+              m = 1;
+              v2 = dc_delta;
+              while (v2 >>= 1) { bits += r->dc[st][1]; m <<= 1; st++; }
+            }
+            bits += r->dc[st][0];
+            if (m < (int)((1L << ARI_DC_L) >> 1)) upd = 0;
+            else if (m > (int)((1L << ARI_DC_U) >> 1)) upd += 8;
+            st += 14;
+            while (m >>= 1) bits += r->dc[st][(m & dc_delta) ? 1 : 0];
+          }
+          cost = bits + dist;
+          if (bi != 0) cost += acc_dc[l][bi - 1];
+          if (l == 0 || cost < acc_dc[k][bi]) {
+            acc_dc[k][bi] = cost;
+            back_dc[k][bi] = bi == 0 ? -1 : l;
+            ctx_dc[k][bi] = upd;
+          }
+        }
+      }
+    }
+
+    for (i = Ss; i <= Se; i++) { /* :1512-1601 */
+      const int z = ZZ[i];
+      const int sign = src[z] < 0 ? -1 : 0;
+      const int x = src[z] < 0 ? -src[z] : src[z];
+      const int q = 8 * qt[z];
+      int cand[2], ncd, qval, delta;
+      float cdist[2], t;
+      t = (float)(x * x) * lambda;
+      t = t * lambda_tbl[z];
+      azd[i] = t + azd[i - 1];
+      qval = (x + q / 2) / q;
+      if (qval == 0) { coef[z] = 0; acost[i] = 1e38f; continue; }
+      cand[0] = qval;
+      delta = cand[0] * q - x;
+      t = (float)(delta * delta) * lambda;
+      cdist[0] = t * lambda_tbl[z];
+      ncd = 1;
+      if (qval > 1) {
+        cand[1] = qval - 1;
+        delta = cand[1] * q - x;
+        t = (float)(delta * delta) * lambda;
+        cdist[1] = t * lambda_tbl[z];
+        ncd = 2;
+      }
+      acost[i] = 1e38f;
+      for (j = Ss - 1; j < i; j++) {
+        float run_bits;
+        if (j != Ss - 1 && coef[ZZ[j]] == 0) continue;
+        run_bits = r->ac[3 * j][0];
+        for (k = j + 1; k < i; k++) run_bits += r->ac[3 * (k - 1) + 1][0];
+        run_bits += r->ac[3 * (i - 1) + 1][1];
+        for (k = 0; k < ncd; k++) {
+          float coef_bits = 1.0f, cost, rhs;
+          int vv = cand[k], v2, m = 0, st = 3 * (i - 1) + 2, rate;
+          if (vv -= 1) {
+            coef_bits += r->ac[st][1];
+            m = 1;
+            v2 = vv;
+            if (v2 >>= 1) {
+              coef_bits += r->ac[st][1];
+              m <<= 1;
+              st = i <= ARI_AC_K ? 189 : 217;
+              while (v2 >>= 1) { coef_bits += r->ac[st][1]; m <<= 1; st++; }
+            }
+          }
+          coef_bits += r->ac[st][0];
+          st += 14;
+          while (m >>= 1) coef_bits += r->ac[st][(m & vv) ? 1 : 0];
+          rate = (int)(coef_bits + run_bits);       /* `int rate` in the reference: the estimate is truncated (:1349, :1583) */
+          cost = (float)rate + cdist[k];
+          rhs = azd[i - 1] - azd[j];
+          rhs = rhs + acost[j];
+          cost = cost + rhs;
+          if (cost < acost[i]) {
+            coef[z] = (int16_t)((cand[k] ^ sign) - sign);
+            acost[i] = cost;
+            run_start[i] = j;
+          }
+        }
+      }
+    }
+    last_coeff_idx = Ss - 1; /* :1603-1631 */
+    best_cost = azd[Se] + r->ac[0][1];
+    for (i = Ss; i <= Se; i++)
+      if (coef[ZZ[i]] != 0) {
+        float cost = acost[i] + azd[Se];
+        cost = cost - azd[i];
+        if (i < Se) cost = cost + r->ac[3 * (i - 1)][1];
+        if (cost < best_cost) { best_cost = cost; last_coeff_idx = i; }
+      }
+    i = Se;
+    while (i >= Ss) {
+      while (i > last_coeff_idx) { coef[ZZ[i]] = 0; i--; }
+      last_coeff_idx = run_start[i];
+      i--;
+    }
+  }
+  if (p->trellis_quant_dc) { /* :1643-1665 */
+    j = 0;
+    for (i = 1; i < ncand; i++)
+      if (acc_dc[i][g->wib - 1] < acc_dc[j][g->wib - 1]) j = i;
+    for (bi = g->wib - 1; bi >= 0; bi--) {
+      e->q[ci][((size_t)br * g->wpad + bi) * 64] = cand_dc[j][bi];
+      j = back_dc[j][bi];
+    }
+    *last_dc_io = e->q[ci][((size_t)br * g->wpad + g->wib - 1) * 64];
+  }
+}
+
+static void trellis_component_arith(enc_t *e, int ci, int Ss, int Se)
+{
+  const mjo_params *p = e->p;
+  const mjo_geom *g = &e->g[ci];
+  const int v = p->v_samp[ci];
+  float *acc_dc[9];
+  int *back_dc[9], *ctx_dc[9];
+  int16_t *cand_dc[9];
+  arith_t A;
+  ari_rates rates;
+  mjo_scan ms;
+  scan_t sc;
+  int i, br, rtg, nr = 0;
+  if (Se < Ss) return;
+  for (i = 0; i < 9; i++) {
+    acc_dc[i] = (float *)malloc(sizeof(float) * g->wib);
+    back_dc[i] = (int *)malloc(sizeof(int) * g->wib);
+    ctx_dc[i] = (int *)malloc(sizeof(int) * g->wib);
+    cand_dc[i] = (int16_t *)malloc(sizeof(int16_t) * g->wib);
+  }
+  memset(&ms, 0, sizeof(ms));
+  ms.comps_in_scan = 1; ms.component_index[0] = ci; ms.Ss = Ss; ms.Se = Se;
+  setup_scan(e, &sc, &ms);
+  ari_start(&A, e, &sc, 0, NULL);           /* start_pass: "progressive mode off" during trellis passes (:824-826) */
+  rtg = sc.restart_interval;
+  for (br = 0; br < g->hib; br += v) {
+    const int rows = br + v <= g->hib ? v : g->hib - br;
+    int last_dc = 0, rr;
+    ari_get_rates(&A, p->dc_tbl_no[ci], p->ac_tbl_no[ci], &rates);
+    for (rr = 0; rr < rows; rr++) trellis_row_arith(e, ci, &rates, br + rr, Ss, Se, &last_dc, acc_dc, back_dc, cand_dc, ctx_dc);
+    ari_code_rows(e, &sc, &A, 1, br, br + rows, &rtg, &nr);   /* compress_output of this iMCU row: the state moves on */
+  }
+  build_dummies(p, g, ci, e->q[ci]);
+  for (i = 0; i < 9; i++) { free(acc_dc[i]); free(back_dc[i]); free(ctx_dc[i]); free(cand_dc[i]); }
+}
+
 /* ------------------------------------------------------------------------------------------
  * a15  markers: jcmarker.c
  * ------------------------------------------------------------------------------------------ */
@@ -1362,7 +1881,8 @@ static void emit_frame_header(enc_t *e, bytebuf *o)
     if (prec_any) is_baseline = 0;
   }
   bb_put(o, 0xFF);
-  bb_put(o, e->progressive ? 0xC2 : (is_baseline ? 0xC0 : 0xC1));
+  if (p->arith_code) bb_put(o, e->progressive ? 0xCA : 0xC9);   /* SOF10 / SOF9, jcmarker.c:720-725 */
+  else bb_put(o, e->progressive ? 0xC2 : (is_baseline ? 0xC0 : 0xC1));
   bb_put2(o, 3 * p->num_components + 2 + 5 + 1);
   bb_put(o, prec_of(p));
   bb_put2(o, p->height);
@@ -1392,7 +1912,22 @@ static void emit_scan_header(enc_t *e, const scan_t *sc, bytebuf *o)
 { /* write_scan_header :744-784, emit_multi_dht :293-401, emit_dri :452, emit_sos :494-531 */
   const mjo_params *p = e->p;
   int i, j;
-  if (!p->fastest_profile) {
+  if (p->arith_code) { /* emit_dac jcmarker.c:404-448: the conditioning parameters of the tables this scan uses, in one marker */
+    int dc_in_use[4] = { 0, 0, 0, 0 }, ac_in_use[4] = { 0, 0, 0, 0 }, length = 0;
+    for (i = 0; i < sc->ncomp; i++) {
+      if (sc->Ss == 0 && sc->Ah == 0) dc_in_use[p->dc_tbl_no[sc->comp[i]]] = 1;
+      if (sc->Se) ac_in_use[p->ac_tbl_no[sc->comp[i]]] = 1;
+    }
+    for (i = 0; i < 4; i++) length += dc_in_use[i] + ac_in_use[i];
+    if (length) {
+      bb_put(o, 0xFF); bb_put(o, 0xCC);
+      bb_put2(o, length * 2 + 2);
+      for (i = 0; i < 4; i++) {
+        if (dc_in_use[i]) { bb_put(o, i); bb_put(o, ARI_DC_L + (ARI_DC_U << 4)); }
+        if (ac_in_use[i]) { bb_put(o, i + 0x10); bb_put(o, ARI_AC_K); }
+      }
+    }
+  } else if (!p->fastest_profile) {
     int length = 2, dclens[4] = { 0, 0, 0, 0 }, aclens[4] = { 0, 0, 0, 0 };
     htbl *dcseen[4] = { 0, 0, 0, 0 }, *acseen[4] = { 0, 0, 0, 0 };
     for (i = 0; i < sc->ncomp; i++) {
@@ -1470,6 +2005,7 @@ static void emit_scan_header(enc_t *e, const scan_t *sc, bytebuf *o)
 static void gather_and_build(enc_t *e, const scan_t *sc, int trellis_pass)
 {
   const mjo_params *p = e->p;
+  if (p->arith_code) return;   /* the arithmetic coder adapts while it codes: no statistics pass (jcmaster.c:1088-1089) */
   long dcc[4][257], acc[4][257];
   sink_t s;
   int t, i, j, ci;
@@ -1521,7 +2057,8 @@ static void output_scan(enc_t *e, const scan_t *sc, int first_scan, bytebuf *o)
   s.out = o;
   if (first_scan) emit_frame_header(e, o);
   emit_scan_header(e, sc, o);
-  code_scan(e, sc, &s);
+  if (p->arith_code) code_scan_arith(e, sc, o);
+  else code_scan(e, sc, &s);
 }
 
 static void bb_append(bytebuf *dst, const bytebuf *src)
@@ -1571,6 +2108,7 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
   mjo_params pp = *p_in;
   const mjo_params *p = &pp;
   if (prec_of(p) == 12) { pp.optimize_coding = 1; if (pp.trellis_quant) return 0; }   /* jcparam.c:452, SURVEY F1 */
+  if (p->arith_code) pp.optimize_coding = 0;                                           /* jcmaster.c:1088-1089 */
 
   memset(&e, 0, sizeof(e));
   e.p = p;
@@ -1616,7 +2154,13 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
   emit_file_header(&e, &o);
 
   /* trellis passes (pass numbers < pass_number_scan_opt_base): SURVEY 3.3 table */
-  if (p->trellis_quant) {
+  if (p->trellis_quant && p->arith_code) {
+    /* component 0 only, band of pass 0's scan selection (see trellis_component_arith); trellis_q_opt would re-estimate the
+     * tables from sums accumulated three times over: not restated */
+    const int split = p->trellis_freq_split > 0 ? p->trellis_freq_split : 8;
+    if (p->trellis_q_opt) return 0;
+    trellis_component_arith(&e, 0, 1, p->use_scans_in_trellis ? split : 63);
+  } else if (p->trellis_quant) {
     for (ci = 0; ci < p->num_components; ci++) {
       mjo_scan ms;
       scan_t sc;

@@ -70,6 +70,8 @@ typedef struct {
   int dc_scan_opt_mode;           /* JINT_DC_SCAN_OPT_MODE (cjpeg -dc-scan-opt N): 0 one DC scan for all components, 1 one per component,
                                    * 2 luma alone + chroma by the scan search's choice (jcparam.c:791,887-940, jcmaster.c:836-838,905-913);
                                    * set it through mjo_set_dc_scan_opt_mode (it rebuilds the script) */
+  int arith_code;                 /* cinfo->arith_code (cjpeg -arithmetic): QM-coder instead of Huffman, SOF9 / SOF10, DAC markers;
+                                   * with trellis_quant the rate model of quantize_trellis_arith */
 } mjo_params;
 /* jpeg_set_colorspace(cinfo, JCS_RGB) (jcparam.c:611-619): three 1x1 components 'R' 'G' 'B', tables 0, no JFIF marker */
 void mjo_set_rgb_output(mjo_params *p);

@@ -65,7 +65,7 @@ int main(int argc, char **argv)
   double l1 = -1e9, l2 = -1e9;
   int dc_scan_opt = -1;
   double dc_ver_weight = -1e9;
-  int precision = 8, yuvin = 0, trellis_loops = 0, smooth = 0, trellis_q_opt = 0, eob_opt = 0, scans_in_trellis = 0, freq_split = 0;
+  int precision = 8, yuvin = 0, arithmetic = 0, trellis_loops = 0, smooth = 0, trellis_q_opt = 0, eob_opt = 0, scans_in_trellis = 0, freq_split = 0;
   const char *dump = NULL, *in = NULL, *out = NULL;
   int i, w, h, nc;
   unsigned char *img;
@@ -108,6 +108,7 @@ int main(int argc, char **argv)
     else if (!strcmp(a, "-dc-scan-opt")) dc_scan_opt = atoi(argv[++i]);   /* cjpeg -dc-scan-opt N (cjpeg.c:494-499) */
     else if (!strcmp(a, "-trellis-dc-ver-weight")) dc_ver_weight = atof(argv[++i]);   /* cjpeg.c:667-672 */
     else if (!strcmp(a, "-smooth")) smooth = atoi(argv[++i]);   /* cjpeg -smooth N (cjpeg.c: cinfo->smoothing_factor) */
+    else if (!strcmp(a, "-arithmetic")) arithmetic = 1;   /* cjpeg -arithmetic (cjpeg.c:371-376): cinfo->arith_code */
     else if (!strcmp(a, "-yuvin")) yuvin = 1;   /* -raw W H input holds component planes: jpeg_write_raw_data */
     else if (!in) in = a;
     else out = a;
@@ -158,6 +159,7 @@ int main(int argc, char **argv)
     jpeg_set_quality(&cinfo, quality, baseline ? TRUE : FALSE);
     if (baseline) { cinfo.num_scans = 0; cinfo.scan_info = NULL; }
     if (optimize) cinfo.optimize_coding = TRUE;
+    if (arithmetic) cinfo.arith_code = TRUE;
     if (fastcrush) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_OPTIMIZE_SCANS, FALSE);
     if (dc_scan_opt >= 0) jpeg_c_set_int_param(&cinfo, JINT_DC_SCAN_OPT_MODE, dc_scan_opt);   /* a switch: before the script is rebuilt */
     if (dc_ver_weight > -1e8) jpeg_c_set_float_param(&cinfo, JFLOAT_TRELLIS_DELTA_DC_WEIGHT, (float)dc_ver_weight);

@@ -109,6 +109,23 @@ CASES = [
     ("q3_16bit_trellis_q_opt", dict(quality=3, fastcrush=True, trellis_q_opt=True), True),
     ("q20_table0_mixed_precision_q_opt", dict(quality=20, fastcrush=True, quant_table=0, trellis_q_opt=True), True),
     ("q40_progressive_eob_opt_restart1", dict(trellis_eob_opt=True, quality=40, restart=1), True),
+    # arithmetic entropy coding (cjpeg -arithmetic): jcarith.c (sequential SOF9, progressive SOF10, restarts,
+    # DAC markers), with the coder's own trellis rate model (quantize_trellis_arith jcdctmgr.c:1334-1667) where trellis is on
+    ("arith_revert", dict(arithmetic=True, revert=True), True),
+    ("arith_base_notrellis", dict(arithmetic=True, baseline=True, notrellis=True), True),
+    ("arith_base", dict(arithmetic=True, baseline=True), True),
+    ("arith_base_notrellis_dc", dict(arithmetic=True, baseline=True, notrellis_dc=True), True),
+    ("arith_base_q92_444", dict(arithmetic=True, baseline=True, quality=92, sample=(1, 1)), True),
+    ("arith_base_restart1", dict(arithmetic=True, baseline=True, restart=1), True),
+    ("arith_base_restart5b", dict(arithmetic=True, baseline=True, restart="5b"), True),
+    ("arith_base_gray", dict(arithmetic=True, baseline=True, gray=True), True),
+    ("arith_base_dc_ver_weight1", dict(arithmetic=True, baseline=True, dc_ver_weight=1.0), True),
+    ("arith_revert_progressive", dict(arithmetic=True, revert=True, progressive=True), True),
+    ("arith_fastcrush_notrellis", dict(arithmetic=True, fastcrush=True, notrellis=True), True),
+    ("arith_fastcrush", dict(arithmetic=True, fastcrush=True), True),
+    ("arith_fastcrush_restart2", dict(arithmetic=True, fastcrush=True, restart=2), True),
+    ("arith_default_progressive", dict(arithmetic=True), True),
+    ("arith_q40_422_progressive", dict(arithmetic=True, quality=40, sample=(2, 1)), True),
 ]
 
 

@@ -34,7 +34,8 @@ class Params(C.Structure):
                 ("write_jfif", C.c_int), ("data_precision", C.c_int), ("trellis_num_loops", C.c_int),
                 ("smoothing_factor", C.c_int), ("trellis_q_opt", C.c_int),
                 ("trellis_eob_opt", C.c_int), ("use_scans_in_trellis", C.c_int), ("trellis_freq_split", C.c_int),
-                ("rgb_output", C.c_int), ("trellis_delta_dc_weight", C.c_float), ("dc_scan_opt_mode", C.c_int)]
+                ("rgb_output", C.c_int), ("trellis_delta_dc_weight", C.c_float), ("dc_scan_opt_mode", C.c_int),
+                ("arith_code", C.c_int)]
 
 
 class Geom(C.Structure):
@@ -74,7 +75,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 noovershoot=False, sample=(2, 2), restart=None, gray=False, grayin=False,
                 quant_table=-1, lambda1=None, lambda2=None, precision=8, trellis_loops=1, smooth=0, trellis_q_opt=False,
                 trellis_eob_opt=False, use_scans_in_trellis=False, trellis_freq_split=0, rgb=False,
-                dc_scan_opt=None, dc_ver_weight=None):
+                dc_scan_opt=None, dc_ver_weight=None, arithmetic=False):
     """Same switch vocabulary as cjpeg / oracle/refenc.c.  Default (no switch) is cjpeg's default:
     max-compression profile, progressive with scan search."""
     p = Params()
@@ -100,6 +101,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     p.trellis_eob_opt = 1 if trellis_eob_opt else 0
     p.use_scans_in_trellis = 1 if use_scans_in_trellis else 0
     p.trellis_freq_split = trellis_freq_split
+    p.arith_code = 1 if arithmetic else 0
     if rgb:
         L.mjo_set_rgb_output(C.byref(p))
     if dc_ver_weight is not None:
@@ -318,6 +320,8 @@ def ref_switches(**kw):
         sw += ["-trellis-dc-ver-weight", repr(float(kw["dc_ver_weight"]))]
     if kw.get("trellis_loops", 1) != 1:
         sw += ["-trellis-loops", str(kw["trellis_loops"])]
+    if kw.get("arithmetic"):
+        sw.append("-arithmetic")
     return sw
 
 
