@@ -115,6 +115,11 @@ typedef struct {
   /* JBOOLEAN_TRELLIS_Q_OPT (jpeglib.h:327): quantization tables re-estimated from the trellis result
    * (sums jcdctmgr.c:1299-1306, update jcmaster.c:1014-1030) */
   int trellis_q_opt;
+  /* cinfo->arith_code (jpeglib.h:420, cjpeg -arithmetic): arithmetic entropy coding (jcarith.c) instead of Huffman -- SOF9 /
+   * SOF10 frames, DAC markers with the default conditioning (jcparam.c:417-419), no Huffman tables; with trellis_quant the
+   * coder's own rate model (quantize_trellis_arith jcdctmgr.c:1334-1667).  An adaptive coder is one dependent chain per
+   * scan: this mode is there for completeness, not for throughput.  Not combined with trellis_q_opt (MJH_EUNSUPPORTED). */
+  int arith_code;
 } mjh_params;
 
 #define MJH_COLOR_YCC  0

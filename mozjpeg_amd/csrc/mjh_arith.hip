@@ -1,0 +1,717 @@
+// mjh_arith.hip -- arithmetic entropy coding: jcarith.c (QM coder of ITU-T T.81 Annex D with the
+// statistics models of F.1.4 / G.1.3) and the coder's own trellis rate model, quantize_trellis_arith jcdctmgr.c:1334-1667.
+//
+// The coder is adaptive: every binary decision changes the probability state the next decision is coded with, so a scan
+// (between two restart markers) is ONE dependent chain -- there is no per-block parallelism to find, unlike the Huffman
+// paths.  What is parallel: the scans of a script (64 candidates with the scan search), the images of a batch, and the
+// loading of the coefficients.  Shape of every kernel here: one wave per chain; the 64 lanes fetch the next 64 blocks of
+// the scan (coalesced plane loads) into LDS, lane 0 runs the coder over them.  This path exists for completeness (files
+// identical to `cjpeg -arithmetic`); it is not a throughput path.
+//
+// With the scan search the candidates are only SIZED (the coder runs without writing); the scans the search keeps are then
+// coded once more straight into the file, at offsets that follow from the sizes -- no scan pool, no concatenation pass.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mjh_internal.h"
+#include "mjh_device.h"
+#include "mjh_arith_table.h"
+#include "mjh_launch.h"
+
+#define ARI_DC_L 0     // conditioning defaults (jcparam.c:417-419); the DAC marker carries them
+#define ARI_DC_U 1
+#define ARI_AC_K 5
+
+// zig-zag -> natural is not needed: the pipeline's coefficient planes are in zig-zag order already (plane k = position k)
+
+struct AriCoder {      // registers of the coding lane (jcarith.c:28-52)
+  unsigned c, a;
+  int sc, zc, ct, buffer;
+  uint8_t *out;        // nullptr: only sizes
+  unsigned pos, cap;
+  __device__ __forceinline__ void byte(int v)
+  {
+    if (out && pos < cap) out[pos] = (uint8_t)v;
+    pos++;
+  }
+  __device__ __forceinline__ void zeros() { while (zc) { byte(0x00); zc--; } }
+  __device__ __forceinline__ void reset() { c = 0; a = 0x10000u; sc = 0; zc = 0; ct = 11; buffer = -1; }
+  // a byte leaves the code register (D.1.6) or the register is flushed (D.1.8): jcarith.c:278-316 / :160-190
+  __device__ __attribute__((noinline)) void shift_out(unsigned temp, bool final)
+  {
+    if (final ? (c & 0xF8000000u) != 0u : temp > 0xFFu) {
+      if (buffer >= 0) {
+        zeros();
+        byte(buffer + 1);
+        if (buffer + 1 == 0xFF) byte(0x00);
+      }
+      zc += sc;
+      sc = 0;
+      if (!final) buffer = (int)(temp & 0xFFu);
+    } else if (!final && temp == 0xFFu) {
+      sc++;
+    } else {
+      if (buffer == 0) zc++;
+      else if (buffer >= 0) { zeros(); byte(buffer); }
+      if (sc) {
+        zeros();
+        do { byte(0xFF); byte(0x00); } while (--sc);
+      }
+      if (!final) buffer = (int)(temp & 0xFFu);
+    }
+  }
+  __device__ __forceinline__ void finish()      // finish_pass jcarith.c:142-203
+  {
+    const unsigned temp = (a - 1u + c) & 0xFFFF0000u;
+    c = temp < c ? temp + 0x8000u : temp;
+    c <<= ct;
+    shift_out(0u, true);
+    if (c & 0x7FFF800u) {
+      zeros();
+      byte((int)((c >> 19) & 0xFFu));
+      if (((c >> 19) & 0xFFu) == 0xFFu) byte(0x00);
+      if (c & 0x7F800u) {
+        byte((int)((c >> 11) & 0xFFu));
+        if (((c >> 11) & 0xFFu) == 0xFFu) byte(0x00);
+      }
+    }
+  }
+  // arith_encode jcarith.c:229-320; tab[state] = Qe << 16 | next state after an MPS << 8 | next state after an LPS (bit 7: MPS flips)
+  __device__ __attribute__((noinline)) void encode(const unsigned *tab, uint8_t *st, int val)
+  {
+    const unsigned sv = *st, t = tab[sv & 0x7Fu], qe = t >> 16;
+    a -= qe;
+    if ((unsigned)val != (sv >> 7)) {
+      if (a >= qe) { c += a; a = qe; }
+      *st = (uint8_t)((sv & 0x80u) ^ (t & 0xFFu));
+    } else {
+      if (a >= 0x8000u) return;
+      if (a < qe) { c += a; a = qe; }
+      *st = (uint8_t)((sv & 0x80u) ^ ((t >> 8) & 0xFFu));
+    }
+    do {
+      a <<= 1;
+      c <<= 1;
+      if (--ct == 0) {
+        shift_out(c >> 19, false);
+        c &= 0x7FFFFu;
+        ct += 8;
+      }
+    } while (a < 0x8000u);
+  }
+};
+
+struct AriModel {      // the statistics areas of one chain, in LDS
+  uint8_t dc[2][64];
+  uint8_t ac[2][256];
+  uint8_t fixed[4];
+};
+
+// Figures F.8 / F.9: magnitude category and magnitude bits of v >= 1.  st = first magnitude bin; DC: the category bins continue
+// at 20; AC: the bin itself once more, then 189 (k <= Kx) / 217.  Returns the category mask (the DC conditioning needs it).
+__device__ __forceinline__ int ari_magnitude(AriCoder &A, const unsigned *tab, uint8_t *stats, uint8_t *st, int v, bool ac, int k)
+{
+  int m = 0;
+  if (v -= 1) {
+    A.encode(tab, st, 1);
+    m = 1;
+    int v2 = v;
+    if (ac) {
+      if (v2 >>= 1) {
+        A.encode(tab, st, 1);
+        m <<= 1;
+        st = stats + (k <= ARI_AC_K ? 189 : 217);
+        while (v2 >>= 1) { A.encode(tab, st, 1); m <<= 1; st++; }
+      }
+    } else {
+      st = stats + 20;
+      while (v2 >>= 1) { A.encode(tab, st, 1); m <<= 1; st++; }
+    }
+  }
+  A.encode(tab, st, 0);
+  st += 14;
+  for (int mm = m >> 1; mm; mm >>= 1) A.encode(tab, st, (mm & v) ? 1 : 0);
+  return m;
+}
+
+// Encode_DC_DIFF (jcarith.c:402-448 / :715-762)
+__device__ __forceinline__ void ari_dc(AriCoder &A, const unsigned *tab, uint8_t *stats, int &last_dc, int &ctx, int value)
+{
+  uint8_t *st = stats + ctx;
+  int v = value - last_dc;
+  if (v == 0) { A.encode(tab, st, 0); ctx = 0; return; }
+  last_dc = value;
+  A.encode(tab, st, 1);
+  if (v > 0) { A.encode(tab, st + 1, 0); st += 2; ctx = 4; }
+  else { v = -v; A.encode(tab, st + 1, 1); st += 3; ctx = 8; }
+  const int m = ari_magnitude(A, tab, stats, st, v, false, 0);
+  if (m < (int)((1L << ARI_DC_L) >> 1)) ctx = 0;
+  else if (m > (int)((1L << ARI_DC_U) >> 1)) ctx += 8;
+}
+
+// Encode_AC_Coefficients: encode_mcu_AC_first jcarith.c:456-552; with Ss = 1, Se = 63, Al = 0 the AC part of encode_mcu :764-817.
+// blk: the block's coefficients in zig-zag order (LDS)
+__device__ __forceinline__ void ari_ac_first(AriCoder &A, const unsigned *tab, uint8_t *stats, uint8_t *fixed, const short *blk, int Ss, int Se, int Al)
+{
+  int k, ke, v;
+  for (ke = Se; ke > 0; ke--) {
+    v = blk[ke];
+    if (v < 0) v = -v;
+    if (v >> Al) break;
+  }
+  for (k = Ss; k <= ke; k++) {
+    uint8_t *st = stats + 3 * (k - 1);
+    int neg;
+    A.encode(tab, st, 0);
+    for (;;) {
+      v = blk[k];
+      neg = v < 0;
+      if (neg) v = -v;
+      v >>= Al;
+      if (v) break;
+      A.encode(tab, st + 1, 0);
+      st += 3;
+      k++;
+    }
+    A.encode(tab, st + 1, 1);
+    A.encode(tab, fixed, neg);
+    ari_magnitude(A, tab, stats, st + 2, v, true, k);
+  }
+  if (k <= Se) A.encode(tab, stats + 3 * (k - 1), 1);
+}
+
+// encode_mcu_AC_refine jcarith.c:596-687
+__device__ __forceinline__ void ari_ac_refine(AriCoder &A, const unsigned *tab, uint8_t *stats, uint8_t *fixed, const short *blk, int Ss, int Se, int Ah, int Al)
+{
+  int k, ke, kex, v;
+  for (ke = Se; ke > 0; ke--) {
+    v = blk[ke];
+    if (v < 0) v = -v;
+    if (v >> Al) break;
+  }
+  for (kex = ke; kex > 0; kex--) {
+    v = blk[kex];
+    if (v < 0) v = -v;
+    if (v >> Ah) break;
+  }
+  for (k = Ss; k <= ke; k++) {
+    uint8_t *st = stats + 3 * (k - 1);
+    if (k > kex) A.encode(tab, st, 0);
+    for (;;) {
+      v = blk[k];
+      const int neg = v < 0;
+      if (neg) v = -v;
+      v >>= Al;
+      if (v) {
+        if (v >> 1) A.encode(tab, st + 2, v & 1);
+        else { A.encode(tab, st + 1, 1); A.encode(tab, fixed, neg); }
+        break;
+      }
+      A.encode(tab, st + 1, 0);
+      st += 3;
+      k++;
+    }
+  }
+  if (k <= Se) A.encode(tab, stats + 3 * (k - 1), 1);
+}
+
+// the coefficient planes a lane has to fetch for one block of the scan, and where the block's DC comes from (dummy blocks of an
+// interleaved scan repeat a neighbour's DC and have no AC: compress_first_pass jccoefct.c:312-345)
+struct AriUnit { int comp_in_scan, comp, blk, dc_blk; bool dummy, valid; };
+
+__device__ __forceinline__ AriUnit ari_unit(const MjhConst &C, const MjhProgScan &sc, int bpm, long long u, long long nunits)
+{
+  AriUnit r;
+  r.valid = u < nunits;
+  if (!r.valid) u = nunits - 1;
+  if (sc.ncomp == 1) {
+    r.comp_in_scan = 0; r.comp = sc.comp[0]; r.blk = (int)u; r.dc_blk = (int)u; r.dummy = false;
+    return r;
+  }
+  const int m = (int)(u / bpm);
+  int j = (int)(u - (long long)m * bpm), ci = 0;
+  while (ci + 1 < sc.ncomp && j >= C.c[sc.comp[ci]].h * C.c[sc.comp[ci]].v) { j -= C.c[sc.comp[ci]].h * C.c[sc.comp[ci]].v; ci++; }
+  const MjhComp &cc = C.c[sc.comp[ci]];
+  const int yi = j / cc.h, xi = j - yi * cc.h;
+  const int my = m / C.mcus_per_row, mx = m - my * C.mcus_per_row;
+  const int row = my * cc.v + yi, col = mx * cc.h + xi;
+  r.comp_in_scan = ci; r.comp = sc.comp[ci];
+  r.dummy = row >= cc.hib || col >= cc.wib;
+  r.dc_blk = dc_source_block(cc, row, col);
+  r.blk = r.dummy ? r.dc_blk : row * cc.wib + col;
+  return r;
+}
+
+struct AriChain {      // what the coding lane carries from block to block
+  int last_dc[MJH_MAXC], ctx[MJH_MAXC];
+  int to_go, next_rst;
+};
+
+__device__ __forceinline__ void ari_reset_stats(AriModel &M, AriChain &ch, const MjhProgScan &sc, bool progressive)
+{ // start_pass jcarith.c:845-875, emit_restart :328-342 (called by lane 0)
+  for (int i = 0; i < sc.ncomp; i++) {
+    if (!progressive || (sc.Ss == 0 && sc.Ah == 0)) {
+      for (int b = 0; b < 64; b++) M.dc[sc.td[i] & 1][b] = 0;
+      ch.last_dc[i] = 0;
+      ch.ctx[i] = 0;
+    }
+    if (!progressive || sc.Se) for (int b = 0; b < 256; b++) M.ac[sc.ta[i] & 1][b] = 0;
+  }
+}
+
+// One chain: the units [u0, u1) of scan `sc` (an MCU = bpm units) run through the coder.  whole_blocks: DC + AC 1..63 of every
+// block whatever the scan parameters say (sequential files; the state updates of the trellis passes, jcarith.c:824-826).
+// dctbl / actbl of component i of the scan: sc.td[i] / sc.ta[i] (which hold the component's table numbers for whole_blocks).
+// All 64 lanes call this; lane 0 codes.  s_blk: 64 x 64 int16 of LDS.
+__device__ __forceinline__ void ari_run(const MjhConst &C, const MjhProgScan &sc, int Al, bool whole_blocks, bool progressive,
+                                        const int16_t *__restrict__ qimg, long long u0, long long u1, int bpm,
+                                        AriCoder &A, AriModel &M, AriChain &ch, const unsigned *tab, short *s_blk, int lane, bool loader = true)
+{
+  const int Ss = whole_blocks ? 0 : sc.Ss, Se = whole_blocks ? 63 : sc.Se;
+  for (long long base = u0; base < u1; base += 64) {
+    if (loader) {
+      const AriUnit un = ari_unit(C, sc, bpm, base + lane, u1);
+      const MjhComp &cc = C.c[un.comp];
+      const int16_t *q = qimg + cc.coef_off;
+      short *row = s_blk + lane * 64;
+      if (Ss == 0) row[0] = q[un.dc_blk];
+      if (Se > 0)   // (from position 1: the end-of-block searches of the AC scans look below Ss as well, jcarith.c:484-496)
+        for (int k = 1; k <= Se; k++) row[k] = un.dummy ? (short)0 : q[(size_t)k * cc.kstride + un.blk];
+    }
+    __syncthreads();
+    if (lane == 0) {
+      const int nb = (int)(u1 - base < 64 ? u1 - base : 64);
+      for (int b = 0; b < nb; b++) {
+        const long long u = base + b;
+        const AriUnit un = ari_unit(C, sc, bpm, u, u1);
+        const int ci = un.comp_in_scan;
+        if (sc.ri && (u % bpm) == 0) {          // first block of an MCU: restart bookkeeping (jcarith.c:371-379 and twins)
+          if (ch.to_go == 0) {
+            A.finish();
+            A.byte(0xFF); A.byte(0xD0 + ch.next_rst);
+            ari_reset_stats(M, ch, sc, progressive);
+            A.reset();
+            ch.to_go = sc.ri;
+            ch.next_rst = (ch.next_rst + 1) & 7;
+          }
+          ch.to_go--;
+        }
+        const short *blk = s_blk + b * 64;
+        uint8_t *dcs = M.dc[sc.td[ci] & 1], *acs = M.ac[sc.ta[ci] & 1];
+        if (whole_blocks) {
+          ari_dc(A, tab, dcs, ch.last_dc[ci], ch.ctx[ci], blk[0]);
+          ari_ac_first(A, tab, acs, M.fixed, blk, 1, 63, 0);
+        } else if (sc.Ss == 0 && sc.Ah == 0) ari_dc(A, tab, dcs, ch.last_dc[ci], ch.ctx[ci], (int)blk[0] >> Al);
+        else if (sc.Ss == 0) A.encode(tab, M.fixed, ((int)blk[0] >> Al) & 1);             // encode_mcu_DC_refine :560-590
+        else if (sc.Ah == 0) ari_ac_first(A, tab, acs, M.fixed, blk, sc.Ss, sc.Se, Al);
+        else ari_ac_refine(A, tab, acs, M.fixed, blk, sc.Ss, sc.Se, sc.Ah, Al);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void ari_load_tab(unsigned *tab, int lane)
+{
+  for (int i = lane; i < 114; i += 64) tab[i] = ((unsigned)mjh_ari_qe[i] << 16) | ((unsigned)mjh_ari_nmps[i] << 8) | (unsigned)mjh_ari_nlps[i];
+}
+
+__device__ __forceinline__ long long ari_scan_units(const MjhConst &C, const MjhProgScan &sc, int &bpm)
+{
+  if (sc.ncomp == 1) { bpm = 1; return C.c[sc.comp[0]].nblk; }
+  bpm = 0;
+  for (int i = 0; i < sc.ncomp; i++) bpm += C.c[sc.comp[i]].h * C.c[sc.comp[i]].v;
+  return (long long)C.mcus_per_row * C.mcu_rows * bpm;
+}
+
+// scan header: [DQT + SOF9/SOF10 for scan 0] DAC [DRI] SOS (write_scan_header jcmarker.c:744-784, emit_dac :404-448); o may be null (length only)
+__device__ __forceinline__ unsigned ari_scan_header(const MjhProgScan &sc, int Al, const uint8_t *frame_hdr, int frame_hdr_len, uint8_t *o)
+{
+  unsigned n = 0;
+  if (sc.frame_header) {
+    if (o) for (int i = 0; i < frame_hdr_len; i++) o[i] = frame_hdr[i];
+    n = (unsigned)frame_hdr_len;
+  }
+  int dc_use[2] = { 0, 0 }, ac_use[2] = { 0, 0 };
+  for (int i = 0; i < sc.ncomp; i++) {
+    if (sc.Ss == 0 && sc.Ah == 0) dc_use[sc.td[i] & 1] = 1;
+    if (sc.Se) ac_use[sc.ta[i] & 1] = 1;
+  }
+  const int ntab = dc_use[0] + dc_use[1] + ac_use[0] + ac_use[1];
+  uint8_t tmp[40];
+  int k = 0;
+  if (ntab) {
+    tmp[k++] = 0xFF; tmp[k++] = 0xCC; tmp[k++] = 0; tmp[k++] = (uint8_t)(ntab * 2 + 2);
+    for (int t = 0; t < 2; t++) {
+      if (dc_use[t]) { tmp[k++] = (uint8_t)t; tmp[k++] = (uint8_t)(ARI_DC_L + (ARI_DC_U << 4)); }
+      if (ac_use[t]) { tmp[k++] = (uint8_t)(t + 0x10); tmp[k++] = (uint8_t)ARI_AC_K; }
+    }
+  }
+  if (sc.emit_dri) { tmp[k++] = 0xFF; tmp[k++] = 0xDD; tmp[k++] = 0; tmp[k++] = 4; tmp[k++] = (uint8_t)(sc.ri >> 8); tmp[k++] = (uint8_t)sc.ri; }
+  tmp[k++] = 0xFF; tmp[k++] = 0xDA;
+  const int len = 2 * sc.ncomp + 2 + 1 + 3;
+  tmp[k++] = (uint8_t)(len >> 8); tmp[k++] = (uint8_t)len;
+  tmp[k++] = (uint8_t)sc.ncomp;
+  for (int i = 0; i < sc.ncomp; i++) { tmp[k++] = (uint8_t)sc.comp_id[i]; tmp[k++] = (uint8_t)((sc.td[i] << 4) + sc.ta[i]); }
+  tmp[k++] = (uint8_t)sc.Ss; tmp[k++] = (uint8_t)sc.Se; tmp[k++] = (uint8_t)((sc.Ah << 4) + Al);
+  if (o) for (int i = 0; i < k; i++) o[n + i] = tmp[i];
+  return n + (unsigned)k;
+}
+
+__device__ __forceinline__ bool ari_skip(const MjhProgScan &sc, const MjhProgCtl *ct) { return sc.cond > 0 && ct->al_continue < sc.cond; }
+
+// One scan of one image.  WRITE = false: its size (header + entropy-coded bytes) goes to ctl.scan_size (what the scan search
+// compares, jcmaster.c:773-962).  WRITE = true: grid.x walks the FINAL order (ctl.order); the scan is written at its place in
+// the file, ctl.scan_out_off (k_arith_layout) -- or, `single_pass`, behind the file header with EOI and the file size (a script
+// of one scan needs no sizing pass).  whole_blocks: a sequential file (SOF9).
+template <bool WRITE>
+__global__ void __launch_bounds__(64)
+k_arith_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, MjhProgCtl *__restrict__ ctl,
+             const int16_t *__restrict__ coef_q, const uint8_t *__restrict__ frame_hdr, int frame_hdr_len,
+             const uint8_t *__restrict__ file_hdr, int file_hdr_len, uint8_t *__restrict__ out, size_t out_stride,
+             unsigned *__restrict__ sizes, int whole_blocks, int single_pass)
+{
+  __shared__ short s_blk[64 * 64];
+  __shared__ unsigned tab[114];
+  __shared__ AriModel M;
+  const int img = blockIdx.y, lane = threadIdx.x;
+  MjhProgCtl *ct = ctl + img;
+  int sidx;
+  if (WRITE && !single_pass) {
+    if ((int)blockIdx.x >= ct->norder) return;
+    sidx = ct->order[blockIdx.x];
+  } else sidx = scan_list[blockIdx.x];
+  const MjhProgScan sc = scans[sidx];
+  if (!WRITE && ari_skip(sc, ct)) { if (lane == 0) ct->scan_size[sidx] = 0; return; }
+  if (WRITE && ct->error) { if (lane == 0 && (single_pass || blockIdx.x == 0)) sizes[img] = 0; return; }
+  const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
+  ari_load_tab(tab, lane);
+  int bpm;
+  const long long nunits = ari_scan_units(C, sc, bpm);
+  uint8_t *o = nullptr;
+  unsigned hdr = 0, cap = 0;
+  if (WRITE) {
+    const size_t off = single_pass ? (size_t)file_hdr_len : (size_t)ct->scan_out_off[sidx];
+    o = out + (size_t)img * out_stride + off;
+    cap = (unsigned)(out_stride - off > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : out_stride - off);
+    if (single_pass) for (int i = lane; i < file_hdr_len; i += 64) out[(size_t)img * out_stride + i] = file_hdr[i];
+  }
+  AriCoder A;
+  AriChain ch;
+  A.out = nullptr; A.pos = 0; A.cap = 0;
+  if (lane == 0) {
+    hdr = ari_scan_header(sc, Al, frame_hdr, frame_hdr_len, WRITE ? o : nullptr);
+    A.out = WRITE ? o + hdr : nullptr;
+    A.cap = WRITE ? (cap > hdr + 4 ? cap - hdr - 4 : 0) : 0;
+    A.reset();
+    M.fixed[0] = 113;
+    for (int i = 0; i < MJH_MAXC; i++) { ch.last_dc[i] = 0; ch.ctx[i] = 0; }
+    ari_reset_stats(M, ch, sc, !whole_blocks);
+    ch.to_go = sc.ri; ch.next_rst = 0;
+  }
+  __syncthreads();
+  ari_run(C, sc, Al, whole_blocks != 0, !whole_blocks, coef_q + (size_t)img * C.coefs_per_image, 0, nunits, bpm, A, M, ch, tab, s_blk, lane);
+  if (lane == 0) {
+    A.finish();
+    const unsigned total = hdr + A.pos;
+    if (!WRITE) ct->scan_size[sidx] = total;
+    else {
+      if (A.pos > A.cap) ct->error = 1;          // the file does not fit its buffer
+      if (single_pass) {
+        if (A.pos <= A.cap) { o[total] = 0xFF; o[total + 1] = 0xD9; }
+        sizes[img] = A.pos <= A.cap ? (unsigned)file_hdr_len + total + 2u : 0u;
+        ct->scan_size[sidx] = total;
+      }
+    }
+  }
+}
+
+// where the chosen scans go in the file (sizes are exact: the same coder sized them), SOI/APP0 in front, EOI behind
+__global__ void __launch_bounds__(64)
+k_arith_layout(MjhProgCtl *__restrict__ ctl, const uint8_t *__restrict__ file_hdr, int file_hdr_len, uint8_t *__restrict__ out, size_t out_stride,
+               unsigned *__restrict__ sizes, int nimg)
+{
+  const int img = blockIdx.x * 64 + threadIdx.x;
+  if (img >= nimg) return;
+  MjhProgCtl *ct = ctl + img;
+  unsigned long long off = (unsigned long long)file_hdr_len;
+  for (int s = 0; s < ct->norder; s++) {
+    const int sidx = ct->order[s];
+    ct->scan_out_off[sidx] = (unsigned)off;
+    off += ct->scan_size[sidx];
+  }
+  uint8_t *o = out + (size_t)img * out_stride;
+  if (off + 2 > out_stride || off + 2 >= (1ull << 32)) { ct->error = 1; sizes[img] = 0; return; }
+  for (int i = 0; i < file_hdr_len; i++) o[i] = file_hdr[i];
+  o[off] = 0xFF; o[off + 1] = 0xD9;
+  sizes[img] = (unsigned)(off + 2);
+}
+
+// =============================================================================================
+// quantize_trellis_arith (jcdctmgr.c:1334-1667) driven by compress_trellis_pass (jccoefct.c:356-486).
+// The rate estimates are read from the CURRENT state of the adaptive coder once per iMCU row (jget_arith_rates
+// jcarith.c:944-976); the row is quantized with them and then run through the coder (output discarded), which moves
+// the state the next row reads.  So a component is one chain of (rates, quantize a row group, code it) steps: one
+// workgroup of 256 threads per image --
+//   * rates: 320 bins looked up in a 256-entry table the host computed with its libm (the estimate depends on the bin's
+//     state byte only; -log(p)/log(2) in double like the reference);
+//   * AC: one thread per block of the row group, the reference's DP as it stands (two candidates per coefficient, `int rate`);
+//   * DC: lanes 0..8 of wave 0 = the candidates of a block, chained along each block row;
+//   * state update: wave 0 codes the row group's blocks (whole blocks, raster order) with lane 0.
+// Only component 0 is ever selected for these passes when arithmetic coding is on (jcmaster.c: prepare_for_pass's
+// trellis_pass case does not re-select the scan and no statistics pass sits between them, :686-702, :1001-1005), each pass
+// restarts from a zeroed state and the unquantized coefficients: one pass reproduces them all.
+// =============================================================================================
+struct MjhArithRates { float r[256][2]; };    // [state byte][decision]: -log2 of the decision's probability estimate
+
+__device__ __forceinline__ float ari_dc_bits(const float (*rdc)[2], int st, int dc_delta, int &upd)
+{ // the DC difference's estimated bits from context st (jcdctmgr.c:1464-1497); upd = the context it leaves behind
+  float bits = rdc[st][dc_delta != 0];
+  upd = 0;
+  if (dc_delta != 0) {
+    bits += rdc[st + 1][dc_delta < 0];
+    st += 2 + (dc_delta < 0);
+    upd = dc_delta < 0 ? 8 : 4;
+    if (dc_delta < 0) dc_delta = -dc_delta;
+    int m = 0;
+    if (dc_delta -= 1) {
+      bits += rdc[st][1];
+      st = 20;
+      m = 1;
+      int v2 = dc_delta;
+      while (v2 >>= 1) { bits += rdc[st][1]; m <<= 1; st++; }
+    }
+    bits += rdc[st][0];
+    if (m < (int)((1L << ARI_DC_L) >> 1)) upd = 0;
+    else if (m > (int)((1L << ARI_DC_U) >> 1)) upd += 8;
+    st += 14;
+    while (m >>= 1) bits += rdc[st][(m & dc_delta) ? 1 : 0];
+  }
+  return bits;
+}
+
+__global__ void __launch_bounds__(256)
+k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q,
+                const float *__restrict__ lambda_in, const MjhArithRates *__restrict__ rate_tab, uint8_t *__restrict__ back,
+                int Ss, int Se, int quant_dc, float delta_dc_weight, int restart_blocks, int prog_file)
+{
+  __shared__ short s_blk[64 * 64];
+  __shared__ unsigned tab[114];
+  __shared__ AriModel M;
+  __shared__ float rdc[64][2], rac[256][2];
+  __shared__ float dc_cost[2][9];
+  __shared__ int dc_ctx[2][9], dc_cand[2][9];
+  __shared__ int s_lastdc;
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const MjhComp cc = C.c[0];
+  const int qt = cc.qtbl;
+  const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off;
+  int16_t *q = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;
+  const float *lam = lambda_in + (size_t)img * C.total_real_blocks + cc.blk_off;
+  uint8_t *bk = back + ((size_t)img * C.total_real_blocks + cc.blk_off) * 16;
+  const int q0 = Q->q[qt][0];
+  int ncand = (2 + 60 / q0) | 1;
+  if (ncand > 9) ncand = 9;
+  if (tid < 64) ari_load_tab(tab, tid);
+  AriCoder A;
+  AriChain ch;
+  MjhProgScan sc;      // the single-component scan of the pass: whole blocks of component 0
+  sc.ncomp = 1; sc.comp[0] = 0; sc.td[0] = cc.dctbl; sc.ta[0] = cc.actbl; sc.Ss = Ss; sc.Se = Se; sc.Ah = 0; sc.Al = 0; sc.ri = restart_blocks;
+  A.out = nullptr; A.pos = 0; A.cap = 0;
+  if (tid == 0) {
+    A.reset();
+    M.fixed[0] = 113;
+    for (int i = 0; i < MJH_MAXC; i++) { ch.last_dc[i] = 0; ch.ctx[i] = 0; }
+    ari_reset_stats(M, ch, sc, false);
+    ch.to_go = restart_blocks; ch.next_rst = 0;
+  }
+  __syncthreads();
+  for (int br0 = 0; br0 < cc.hib; br0 += cc.v) {
+    const int rows = br0 + cc.v <= cc.hib ? cc.v : cc.hib - br0;
+    // ---- rates of this iMCU row (jget_arith_rates)
+    for (int i = tid; i < 64 + 256; i += 256) {
+      const int state = i < 64 ? M.dc[cc.dctbl & 1][i] : M.ac[cc.actbl & 1][i - 64];
+      float *o = i < 64 ? rdc[i] : rac[i - 64];
+      o[0] = rate_tab->r[state][0];
+      o[1] = rate_tab->r[state][1];
+    }
+    __syncthreads();
+    // ---- AC: one thread per block of the row group (jcdctmgr.c:1512-1631)
+    for (int idx = tid; idx < rows * cc.wib; idx += 256) {
+      const int blk = br0 * cc.wib + idx;
+      const float lambda = lam[blk];
+      float azd[64], acost[64];
+      short coef[64];
+      unsigned char run_start[64];
+      azd[Ss - 1] = 0.0f; acost[Ss - 1] = 0.0f;
+      for (int i = 0; i < 64; i++) { coef[i] = 0; run_start[i] = 0; }
+      for (int i = Ss; i <= Se; i++) {
+        const int xs = uq[(size_t)i * cc.kstride + blk];
+        const int sign = xs < 0 ? -1 : 0, x = xs < 0 ? -xs : xs;
+        const int dq = Q->dq8[qt][i];
+        const float lt = Q->lambda_tbl[qt][i];
+        float t = (float)mul24(x, x) * lambda;
+        t = t * lt;
+        azd[i] = t + azd[i - 1];
+        const int qval = (x + (dq >> 1)) / dq;
+        if (qval == 0) { coef[i] = 0; acost[i] = 1e38f; continue; }
+        int cand[2];
+        float cdist[2];
+        int ncd = 1;
+        cand[0] = qval;
+        { const int delta = cand[0] * dq - x; float d = (float)(delta * delta) * lambda; cdist[0] = d * lt; }
+        cand[1] = qval - 1; cdist[1] = 0.0f;
+        if (qval > 1) { const int delta = cand[1] * dq - x; float d = (float)(delta * delta) * lambda; cdist[1] = d * lt; ncd = 2; }
+        acost[i] = 1e38f;
+        for (int j = Ss - 1; j < i; j++) {
+          if (j != Ss - 1 && coef[j] == 0) continue;
+          float run_bits = rac[3 * j][0];
+          for (int k = j + 1; k < i; k++) run_bits += rac[3 * (k - 1) + 1][0];
+          run_bits += rac[3 * (i - 1) + 1][1];
+          for (int k = 0; k < ncd; k++) {
+            float coef_bits = 1.0f;
+            int vv = cand[k], m = 0, st = 3 * (i - 1) + 2;
+            if (vv -= 1) {
+              coef_bits += rac[st][1];
+              m = 1;
+              int v2 = vv;
+              if (v2 >>= 1) {
+                coef_bits += rac[st][1];
+                m <<= 1;
+                st = i <= ARI_AC_K ? 189 : 217;
+                while (v2 >>= 1) { coef_bits += rac[st][1]; m <<= 1; st++; }
+              }
+            }
+            coef_bits += rac[st][0];
+            st += 14;
+            while (m >>= 1) coef_bits += rac[st][(m & vv) ? 1 : 0];
+            const int rate = (int)(coef_bits + run_bits);      // `int rate` (jcdctmgr.c:1349, :1583): the estimate is truncated
+            float cost = (float)rate + cdist[k];
+            float rhs = azd[i - 1] - azd[j];
+            rhs = rhs + acost[j];
+            cost = cost + rhs;
+            if (cost < acost[i]) {
+              coef[i] = (short)((cand[k] ^ sign) - sign);
+              acost[i] = cost;
+              run_start[i] = (unsigned char)j;
+            }
+          }
+        }
+      }
+      int last = Ss - 1;
+      float best_cost = azd[Se] + rac[0][1];
+      for (int i = Ss; i <= Se; i++)
+        if (coef[i] != 0) {
+          float cost = acost[i] + azd[Se];
+          cost = cost - azd[i];
+          if (i < Se) cost = cost + rac[3 * (i - 1)][1];
+          if (cost < best_cost) { best_cost = cost; last = i; }
+        }
+      int i = Se;
+      while (i >= Ss) {
+        while (i > last) { coef[i] = 0; i--; }
+        last = run_start[i];
+        i--;
+      }
+      for (int k = Ss; k <= Se; k++) q[(size_t)k * cc.kstride + blk] = coef[k];
+    }
+    // ---- DC along each block row of the group (jcdctmgr.c:1416-1509, :1643-1665): lane k of wave 0 = candidate k
+    if (quant_dc) {
+      if (tid == 0) s_lastdc = 0;
+      __syncthreads();
+      for (int rr = 0; rr < rows; rr++) {
+        const int row0 = (br0 + rr) * cc.wib;
+        if (wave == 0) {
+          const int dq = 8 * q0;
+          const float lt0 = Q->lambda_tbl[qt][0];
+          for (int bi = 0; bi < cc.wib; bi++) {
+            const int cur = bi & 1, prv = cur ^ 1;
+            if (lane < ncand) {
+              const int xs = uq[row0 + bi];
+              const int sign = xs < 0 ? -1 : 0, x = xs < 0 ? -xs : xs;
+              const int qval = (x + (dq >> 1)) / dq;
+              const float lambda_dc = lam[row0 + bi] * lt0;
+              int cnd = qval - ncand / 2 + lane;
+              int delta = cnd * dq - x;
+              float dist = (float)(delta * delta) * lambda_dc;
+              cnd *= 1 + 2 * sign;
+              if (rr > 0 && delta_dc_weight > 0.0f) {       // the block above inside the iMCU row (jcdctmgr.c:1440-1456)
+                const int above_orig = uq[row0 - cc.wib + bi], above_recon = (int)q[row0 - cc.wib + bi] * dq;
+                delta = (above_orig - xs) - (above_recon - cnd * dq);
+                const float vertical = (float)(delta * delta) * lambda_dc;
+                float t = vertical - dist;
+                t = delta_dc_weight * t;
+                dist = dist + t;
+              }
+              float best = 0.0f;
+              int bb = -1, bctx = 0;
+              const int nl = bi == 0 ? 1 : ncand;
+              for (int l = 0; l < nl; l++) {
+                const int pred = bi == 0 ? s_lastdc : dc_cand[prv][l];
+                int upd;
+                const float bits = ari_dc_bits(rdc, bi == 0 ? 0 : dc_ctx[prv][l], cnd - pred, upd);
+                float cost = bits + dist;
+                if (bi != 0) cost += dc_cost[prv][l];
+                if (l == 0 || cost < best) { best = cost; bb = bi == 0 ? -1 : l; bctx = upd; }
+              }
+              dc_cost[cur][lane] = best; dc_ctx[cur][lane] = bctx; dc_cand[cur][lane] = cnd;
+              bk[(size_t)(row0 + bi) * 16 + lane] = (uint8_t)(bb < 0 ? 0 : bb);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+          }
+          if (lane == 0) {
+            const int cur = (cc.wib - 1) & 1;
+            int j = 0;
+            for (int i = 1; i < ncand; i++) if (dc_cost[cur][i] < dc_cost[cur][j]) j = i;
+            for (int bi = cc.wib - 1; bi >= 0; bi--) {
+              const int xs = uq[row0 + bi];
+              const int sign = xs < 0 ? -1 : 0, x = xs < 0 ? -xs : xs;
+              const int qval = (x + (dq >> 1)) / dq;
+              const int cnd = (qval - ncand / 2 + j) * (1 + 2 * sign);
+              q[row0 + bi] = (int16_t)cnd;
+              if (bi == cc.wib - 1) s_lastdc = cnd;
+              j = bk[(size_t)(row0 + bi) * 16 + j];
+            }
+          }
+        }
+        __threadfence_block();
+        __syncthreads();
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- the row group goes through the coder: its statistics move on (compress_output -> encode_mcu, output discarded)
+    // (wave 0 loads, thread 0 codes, every wave takes part in the barriers; emit_restart consults the FILE's mode, jcarith.c:328-341)
+    ari_run(C, sc, 0, true, prog_file != 0, coef_q + (size_t)img * C.coefs_per_image, (long long)br0 * cc.wib, (long long)(br0 + rows) * cc.wib, 1, A, M, ch, tab,
+            s_blk, tid, tid < 64);
+    __syncthreads();
+  }
+}
+
+// =============================================================================================
+// launch wrappers
+// =============================================================================================
+void mjh_launch_arith_scans(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
+                            const uint8_t *frame_hdr, int frame_hdr_len, const uint8_t *file_hdr, int file_hdr_len,
+                            uint8_t *out, size_t out_stride, unsigned *sizes, int whole_blocks, int mode, int n, hipStream_t s)
+{
+  // mode 0: size the scans of the list; 1: write the scans of the final order (nlist = upper bound of its length); 2: one scan, one pass
+  if (mode == 0)
+    hipLaunchKernelGGL((k_arith_scan<false>), dim3(nlist, n), dim3(64), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl, (const int16_t *)q,
+                       frame_hdr, frame_hdr_len, file_hdr, file_hdr_len, out, out_stride, sizes, whole_blocks, 0);
+  else
+    hipLaunchKernelGGL((k_arith_scan<true>), dim3(nlist, n), dim3(64), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl, (const int16_t *)q,
+                       frame_hdr, frame_hdr_len, file_hdr, file_hdr_len, out, out_stride, sizes, whole_blocks, mode == 2 ? 1 : 0);
+}
+
+void mjh_launch_arith_layout(void *ctl, const uint8_t *file_hdr, int file_hdr_len, uint8_t *out, size_t out_stride, unsigned *sizes, int n, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_arith_layout, dim3((n + 63) / 64), dim3(64), 0, s, (MjhProgCtl *)ctl, file_hdr, file_hdr_len, out, out_stride, sizes, n);
+}
+
+void mjh_launch_trellis_arith(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const float *lambda, const void *rate_tab, void *back,
+                              int Ss, int Se, int quant_dc, float delta_dc_weight, int restart_blocks, int prog_file, int n, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_trellis_arith, dim3(n), dim3(256), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, lambda, (const MjhArithRates *)rate_tab, (uint8_t *)back,
+                     Ss, Se, quant_dc, delta_dc_weight, restart_blocks, prog_file);
+}

@@ -24,6 +24,7 @@
 #include "mjh_internal.h"
 #include "mjh_launch.h"
 #include "mjh_guard.h"
+#include "mjh_arith_table.h"
 
 // ---- error plumbing ---------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -363,6 +364,11 @@ struct mjh_encoder {
   bool is_view = false, last_split = false;
   int view_off = 0;
   hipEvent_t ev_view_done = nullptr, ev_split_fork = nullptr, ev_null_in = nullptr;
+  // arithmetic coding (mjh_arith.hip): the scans to code (the script, or one synthetic whole-block scan for a sequential file),
+  // phase lists in d_lists (pl_phase[].scan_off / nscan), the rate table of quantize_trellis_arith
+  bool arith = false;
+  int arith_nscans = 0;
+  void *d_arith_rates = nullptr;
   void *g_in[MJH_MAX_COMPS] = { nullptr, nullptr, nullptr, nullptr }; size_t g_in_bytes[MJH_MAX_COMPS] = { 0, 0, 0, 0 }; std::vector<void *> g_in_old;   // MJH_GUARD=2/3: fenced copies of the caller's device input
 };
 
@@ -409,7 +415,7 @@ static int check_supported(const mjh_params *p)
   if (p->num_scans < 0 || p->num_scans > MJH_MAX_SCANS) return fail(p->num_scans < 0 ? MJH_EUNSUPPORTED : MJH_EINVAL, "num_scans %d", p->num_scans);
   if (p->num_scans > 0) {
     // progressive mode: the checks of validate_script (jcmaster.c:269-432) that matter here
-    if (!p->optimize_coding) return fail(MJH_EUNSUPPORTED, "progressive mode forces optimize_coding (jcmaster.c:1091-1094)");
+    if (!p->optimize_coding && !p->arith_code) return fail(MJH_EUNSUPPORTED, "progressive mode forces optimize_coding (jcmaster.c:1091-1094)");
 
     for (int i = 0; i < p->num_components; i++)
       if (p->dc_tbl_no[i] > 1 || p->ac_tbl_no[i] > 1) return fail(MJH_EUNSUPPORTED, "progressive mode: table numbers 0/1 only");
@@ -443,8 +449,14 @@ static int check_supported(const mjh_params *p)
     }
   }
   if (p->restart_interval > 65535u || p->restart_in_rows < 0) return fail(MJH_EINVAL, "bad restart interval");
-  if (p->trellis_quant && !p->optimize_coding) return fail(MJH_EUNSUPPORTED, "trellis_quant requires optimize_coding (jcmaster.c:686-702 never selects a component otherwise)");
-  if (!p->optimize_coding) {
+  if (p->arith_code) {
+    if (p->trellis_quant && p->trellis_q_opt)
+      return fail(MJH_EUNSUPPORTED, "trellis_q_opt with arithmetic coding (the reference accumulates its table estimate over three identical passes: not restated)");
+    for (int i = 0; i < p->num_components; i++)
+      if (p->dc_tbl_no[i] > 1 || p->ac_tbl_no[i] > 1) return fail(MJH_EUNSUPPORTED, "arithmetic coding: conditioning table numbers 0/1 only");
+  }
+  if (p->trellis_quant && !p->optimize_coding && !p->arith_code) return fail(MJH_EUNSUPPORTED, "trellis_quant requires optimize_coding (jcmaster.c:686-702 never selects a component otherwise)");
+  if (!p->optimize_coding && !p->arith_code) {
     for (int i = 0; i < p->num_components; i++)
       if (p->dc_tbl_no[i] > 1 || p->ac_tbl_no[i] > 1) return fail(MJH_EUNSUPPORTED, "standard Huffman tables exist only for table numbers 0 and 1");
   }
@@ -574,7 +586,8 @@ static void build_prefix(const mjh_params *p, std::vector<uint8_t> &o, bool *bas
     if (p->dc_tbl_no[ci] > 1 || p->ac_tbl_no[ci] > 1) is_baseline = false;
   if (prec_any || p->data_precision == 12) is_baseline = false;   // write_frame_header :699-703
   *baseline_sof = is_baseline;
-  o.push_back(0xFF); o.push_back(p->num_scans > 0 ? 0xC2 : (is_baseline ? 0xC0 : 0xC1));  // emit_sof :464-490 (SOF2 = progressive)
+  if (p->arith_code) { o.push_back(0xFF); o.push_back(p->num_scans > 0 ? 0xCA : 0xC9); }   // SOF10 / SOF9 (write_frame_header :720-725)
+  else { o.push_back(0xFF); o.push_back(p->num_scans > 0 ? 0xC2 : (is_baseline ? 0xC0 : 0xC1)); }  // emit_sof :464-490 (SOF2 = progressive)
   put2(o, 3 * p->num_components + 2 + 5 + 1);
   o.push_back(p->data_precision == 12 ? 12 : 8);
   put2(o, p->image_height); put2(o, p->image_width);
@@ -682,7 +695,7 @@ static void free_all(mjh_encoder *e)
   if (e->ev_null_in) (void)hipEventDestroy(e->ev_null_in);
   void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->pe.chist, e->pe.rmask, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_nq8, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
-                   e->d_meta, e->d_prefix, e->d_sos, e->g_in[0], e->g_in[1], e->g_in[2], e->g_in[3] };
+                   e->d_meta, e->d_prefix, e->d_sos, e->d_arith_rates, e->g_in[0], e->g_in[1], e->g_in[2], e->g_in[3] };
   for (void *q : ptrs) if (q) (void)mjh_guard_free(q);
   for (void *q : e->g_in_old) (void)mjh_guard_free(q);
   if (e->h_defer) (void)hipHostFree(e->h_defer);
@@ -864,7 +877,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     const int nl = p->trellis_num_loops > 1 ? p->trellis_num_loops : 1;
     bool restart_scans = false;   // progressive: scans with restart intervals go through the sequential walk, which reads one plane per position
     if (e->progressive && (p->restart_interval || p->restart_in_rows)) restart_scans = true;
-    e->use_compact = !(v && atoi(v) == 0) && p->trellis_quant && nl == 1 && e->nbands == 1 && !p->trellis_eob_opt && !p->trellis_q_opt &&
+    e->use_compact = !(v && atoi(v) == 0) && !p->arith_code && p->trellis_quant && nl == 1 && e->nbands == 1 && !p->trellis_eob_opt && !p->trellis_q_opt &&
                      (e->progressive ? !restart_scans : !(e->fuse_mask & 2));
     if (e->use_compact) HIPCHK_E(mjh_dmalloc((void **)&e->d_nzmask, B * (size_t)C.total_real_blocks * sizeof(unsigned long long)));
     if (e->use_compact && p->trellis_quant) HIPCHK_E(mjh_dmalloc((void **)&e->d_nq8, B * (size_t)C.total_real_blocks));
@@ -1001,7 +1014,96 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       if (!ac_sent[a] && e->ndht < 4) { e->dht_slots[e->ndht] = SLOT_FINAL + 2 * a + 1; e->dht_ids[e->ndht] = a + 0x10; e->ndht++; ac_sent[a] = true; }
     }
   }
-  if (e->progressive) {
+  if (p->arith_code) {
+    e->arith = true;
+    e->p.optimize_coding = 0;                                  // jcmaster.c:1088-1089
+    // frame header (DQT + SOF9 / SOF10) = prefix minus SOI/APP0; it opens scan 0
+    e->frame_hdr_len = e->prefix_len - e->file_hdr_len;
+    HIPCHK_E(mjh_dmalloc((void **)&e->d_frame_hdr, (size_t)e->frame_hdr_len + 16));
+    HIPCHK_E(hipMemcpy(e->d_frame_hdr, e->d_prefix + e->file_hdr_len, e->frame_hdr_len, hipMemcpyDeviceToDevice));
+    const int ns = p->num_scans > 0 ? p->num_scans : 1;
+    e->arith_nscans = ns;
+    std::vector<MjhProgScan> ps(ns);
+    memset(ps.data(), 0, ps.size() * sizeof(MjhProgScan));
+    const int nsl = 23, cfs = 42, lfs = 12;
+    for (int si = 0; si < ns; si++) {
+      MjhProgScan &d = ps[si];
+      d.frame_header = si == 0;
+      d.slot[0] = d.slot[1] = -1;
+      if (p->num_scans == 0) {    // sequential file: one scan of whole blocks, every component (the table selectors are the components' own)
+        d.ncomp = C.ncomp; d.Ss = 0; d.Se = 63;
+        for (int c = 0; c < C.ncomp; c++) { d.comp[c] = c; d.comp_id[c] = p->component_id[c]; d.td[c] = p->dc_tbl_no[c]; d.ta[c] = p->ac_tbl_no[c]; }
+        continue;
+      }
+      const mjh_scan &ms = p->scan_info[si];
+      d.ncomp = ms.comps_in_scan;
+      d.Ss = ms.Ss; d.Se = ms.Se; d.Ah = ms.Ah; d.Al = ms.Al;
+      if (p->optimize_scans) {   // jcmaster.c:487-497, :799-818 (as for the Huffman coder)
+        if (si >= lfs && si < nsl) d.al_sel = 1;
+        if (si >= cfs) d.al_sel = 2;
+        if (si >= 6 && si <= 8) d.cond = 1;
+        if (si >= 9 && si <= 11) d.cond = 2;
+      }
+      for (int ci = 0; ci < ms.comps_in_scan; ci++) {
+        const int c = ms.component_index[ci];
+        d.comp[ci] = c;
+        d.comp_id[ci] = p->component_id[c];
+        d.td[ci] = (ms.Ss == 0 && ms.Ah == 0) ? p->dc_tbl_no[c] : 0;   // emit_sos jcmarker.c:519-523
+        d.ta[ci] = ms.Se ? p->ac_tbl_no[c] : 0;
+      }
+    }
+    {
+      int last_ri = 0;   // write_file_header resets last_restart_interval to 0 (jcmarker.c:660)
+      for (int si = 0; si < ns; si++) {
+        MjhProgScan &d = ps[si];
+        const long per_row = d.ncomp > 1 ? C.mcus_per_row : C.c[d.comp[0]].wib;
+        long ri = p->restart_interval;
+        if (p->restart_in_rows > 0) { ri = (long)p->restart_in_rows * per_row; if (ri > 65535L) ri = 65535L; }
+        d.ri = (int)ri;
+        d.emit_dri = d.ri != last_ri;
+        last_ri = d.ri;
+      }
+    }
+    HIPCHK_E(mjh_dmalloc(&e->d_prog_scans, ps.size() * sizeof(MjhProgScan)));
+    HIPCHK_E(hipMemcpy(e->d_prog_scans, ps.data(), ps.size() * sizeof(MjhProgScan), hipMemcpyHostToDevice));
+    HIPCHK_E(mjh_dmalloc(&e->d_prog_ctl, B * sizeof(MjhProgCtl)));
+    // phase lists: everything at once, or the scan search's four phases (see the Huffman path below)
+    std::vector<int> ph[4];
+    e->nphases = 1;
+    for (int si = 0; si < ns; si++) {
+      int k = 0;
+      if (p->optimize_scans && p->num_scans > 0) {
+        e->nphases = 4;
+        if ((si >= lfs && si < nsl) || si >= cfs) k = 3;
+        else if (si >= 6 && si <= 8) k = 1;
+        else if (si >= 9 && si <= 11) k = 2;
+      }
+      ph[k].push_back(si);
+    }
+    for (int k = 0; k < 4; k++) {
+      e->pl_phase[k] = mjh_encoder::PList{};
+      e->pl_phase[k].scan_off = (int)e->h_lists.size();
+      e->pl_phase[k].nscan = (int)ph[k].size();
+      e->h_lists.insert(e->h_lists.end(), ph[k].begin(), ph[k].end());
+    }
+    HIPCHK_E(mjh_dmalloc((void **)&e->d_lists, e->h_lists.size() * sizeof(int) + 16));
+    HIPCHK_E(hipMemcpy(e->d_lists, e->h_lists.data(), e->h_lists.size() * sizeof(int), hipMemcpyHostToDevice));
+    {
+      // jget_arith_rates (jcarith.c:944-976): the estimated bits of a decision depend on the bin's state byte only; evaluated
+      // with the host libm in double like the reference (log), rounded to float where the reference assigns to float
+      std::vector<float> rt(512);
+      for (int st = 0; st < 256; st++) {
+        const int idx = (st & 0x7F) < 114 ? (st & 0x7F) : 0, mps = st >> 7;
+        const float prob_lps = (float)((double)mjh_ari_qe[idx] / 46340.95);
+        const float prob_0 = mps ? prob_lps : (float)(1.0 - (double)prob_lps);
+        const float prob_1 = (float)(1.0 - (double)prob_0);
+        rt[2 * st] = (float)(-log((double)prob_0) / log(2.0));
+        rt[2 * st + 1] = (float)(-log((double)prob_1) / log(2.0));
+      }
+      HIPCHK_E(mjh_dmalloc(&e->d_arith_rates, rt.size() * sizeof(float)));
+      HIPCHK_E(hipMemcpy(e->d_arith_rates, rt.data(), rt.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+  } else if (e->progressive) {
     // frame header (DQT + SOF2) = prefix minus SOI/APP0; it opens scan 0's buffer (jcmaster.c:680-681)
     e->frame_hdr_len = e->prefix_len - e->file_hdr_len;
     e->d_frame_hdr = nullptr;
@@ -1176,7 +1278,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     int S = 1;
     if (const char *v = getenv("MJH_SPLIT")) S = atoi(v);
     if (S > 8) S = 8;
-    if (S > 1 && !e->progressive && max_batch >= 2 * S) {
+    if (S > 1 && !e->progressive && !e->arith && max_batch >= 2 * S) {
       rc = make_views(e, S);
       if (rc) { free_all(e); return rc; }
     }
@@ -1261,7 +1363,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   // the FDCT kernel itself (no separate pass over the 63 planes), and the quantized AC planes it would write are never
   // read (the trellis recomputes them), so they are not stored; optionally the statistics of the final coefficients
   // are gathered by the trellis back-track.
-  const bool fuse_seq = !e->progressive && p.trellis_quant && !coef_src;
+  const bool fuse_seq = !e->progressive && p.trellis_quant && !coef_src && !e->arith;
   // (debug taps expose the pre-trellis quantized planes, so they keep the unfused schedule.)  Measured: the fused FDCT
   // kernel costs what the separate statistics pass cost (7.19 vs 7.23 ms per 64 4K frames) but moves 3.2 GB less; the
   // final statistics inside the trellis cost MORE than their own pass (3.83 vs 3.36 + 0.38 ms: the low-occupancy kernel
@@ -1280,6 +1382,48 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, e->d_nq8, n, s, e->fastdiv_all);
   }
 
+  if (e->arith) {
+    // Arithmetic coding: [trellis pass of component 0 with the coder's own rate model] -> size the scans (scan search: phase by
+    // phase, with the Huffman path's selection kernels) -> lay the chosen scans out -> code them into the file.  A script of
+    // one scan without search is coded in one pass.
+    if (before_output) { HIPCHK(hipStreamWaitEvent(s, before_output, 0)); before_output = nullptr; }
+    mjh_launch_prog_reset(e->d_prog_ctl, e->arith_nscans, n, s);
+    if (p.trellis_quant && !coef_src) {
+      if (e->debug_taps) {
+        if (!e->d_q0) HIPCHK(mjh_dmalloc((void **)&e->d_q0, (size_t)e->max_batch * C.coefs_per_image * 2));
+        HIPCHK(hipMemcpyAsync(e->d_q0, e->d_q, (size_t)n * C.coefs_per_image * 2, hipMemcpyDeviceToDevice, s));
+      }
+      pr.mark("trellis_arith");
+      const int split = p.trellis_freq_split > 0 ? p.trellis_freq_split : 8;
+      mjh_launch_trellis_arith(C, e->d_quant, e->d_uq, e->d_q, e->d_lambda, e->d_arith_rates, e->d_back, 1, p.use_scans_in_trellis ? split : 63,
+                               p.trellis_quant_dc, p.trellis_delta_dc_weight, e->comp_restart[0], e->progressive ? 1 : 0, n, s);
+    }
+    const int whole = e->progressive ? 0 : 1;
+    if (e->arith_nscans == 1) {
+      pr.mark("arith_encode");
+      mjh_launch_arith_scans(C, e->d_prog_scans, e->d_lists + e->pl_phase[0].scan_off, 1, e->d_prog_ctl, e->d_q, e->d_frame_hdr, e->frame_hdr_len,
+                             e->d_prefix, e->file_hdr_len, e->d_out, e->out_stride, e->d_sizes, whole, 2, n, s);
+    } else {
+      static const char *const kSize[4] = { "arith_size(A)", "arith_size(A2)", "arith_size(A3)", "arith_size(B)" };
+      for (int ph = 0; ph < e->nphases; ph++) {
+        const mjh_encoder::PList &pl = e->pl_phase[ph];
+        pr.mark(kSize[e->nphases == 4 ? ph : 0]);
+        if (pl.nscan)
+          mjh_launch_arith_scans(C, e->d_prog_scans, e->d_lists + pl.scan_off, pl.nscan, e->d_prog_ctl, e->d_q, e->d_frame_hdr, e->frame_hdr_len,
+                                 e->d_prefix, e->file_hdr_len, e->d_out, e->out_stride, e->d_sizes, whole, 0, n, s);
+        if (p.optimize_scans) { pr.mark("prog_select"); mjh_launch_prog_select(e->d_prog_ctl, C.ncomp, ph, p.dc_scan_opt_mode, n, s); }
+      }
+      pr.mark("arith_layout");
+      mjh_launch_arith_layout(e->d_prog_ctl, e->d_prefix, e->file_hdr_len, e->d_out, e->out_stride, e->d_sizes, n, s);
+      pr.mark("arith_encode");
+      mjh_launch_arith_scans(C, e->d_prog_scans, e->d_lists, e->arith_nscans, e->d_prog_ctl, e->d_q, e->d_frame_hdr, e->frame_hdr_len,
+                             e->d_prefix, e->file_hdr_len, e->d_out, e->out_stride, e->d_sizes, whole, 1, n, s);
+    }
+    pr.mark(nullptr);
+    pr.finish();
+    HIPCHK(hipGetLastError());
+    return MJH_OK;
+  }
   if (e->progressive) {
     if (before_output) { HIPCHK(hipStreamWaitEvent(s, before_output, 0)); before_output = nullptr; }   // the hand-over also reads the scan control block
     mjh_launch_prog_reset(e->d_prog_ctl, e->nscans, n, s);   // (the scan pool is zeroed phase by phase, only what k_prog_alloc hands out)
@@ -1290,7 +1434,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   // is two such pass pairs, AC bands 1..split and split+1..63.
   // One (statistics, trellis) pass pair: for all components (CV = C) or, with trellis_q_opt, for ONE component through a
   // one-component view of the geometry (MjhComp carries absolute offsets, so the view addresses the same buffers).
-  const int nloops = p.trellis_quant ? (p.trellis_num_loops > 1 ? p.trellis_num_loops : 1) : 0;
+  const int nloops = p.trellis_quant && !e->arith ? (p.trellis_num_loops > 1 ? p.trellis_num_loops : 1) : 0;   // (the arithmetic coder has its own trellis pass below)
   bool final_ac_counted = false;     // the last trellis pass has counted the AC statistics of the final coefficients
   bool final_dc_counted = false;     // ... and the side stream the DC statistics, right behind the DC trellis (under the AC kernel)
   auto trellis_pass = [&](const MjhConst &CV, const int *sl_dc_seq, const int *sl_dc_prog, const int *sl_ac, const int *crst,
@@ -1739,7 +1883,7 @@ static int queue_pack(mjh_encoder *e, int b, int n)
   void *d_res = nullptr, *d_tab = nullptr;
   HIPCHK(hipHostGetDevicePointer(&d_res, e->h_res[b], 0));
   HIPCHK(hipHostGetDevicePointer(&d_tab, e->h_tab[b], 0));
-  mjh_launch_pack_results(e->d_out, e->out_stride, e->d_sizes, e->progressive ? nullptr : e->d_meta, e->progressive ? e->d_prog_ctl : nullptr,
+  mjh_launch_pack_results(e->d_out, e->out_stride, e->d_sizes, (e->progressive || e->arith) ? nullptr : e->d_meta, (e->progressive || e->arith) ? e->d_prog_ctl : nullptr,
                           n, d_res, e->res_cap, d_tab, e->d2h_stream);
   HIPCHK(hipEventRecord(e->ev_packed[b], e->d2h_stream));
   e->res_buf = b;
@@ -2101,7 +2245,7 @@ static int fetch_sizes(mjh_encoder *e)
   HIPCHK(hipDeviceSynchronize());
   { const int rg = guard_verify(); if (rg) return rg; }
   HIPCHK(hipMemcpy(e->h_sizes.data(), e->d_sizes, (size_t)e->last_n * sizeof(unsigned), hipMemcpyDeviceToHost));
-  if (e->progressive) {
+  if (e->progressive || e->arith) {
     std::vector<MjhProgCtl> ctl(e->last_n);
     HIPCHK(hipMemcpy(ctl.data(), e->d_prog_ctl, (size_t)e->last_n * sizeof(MjhProgCtl), hipMemcpyDeviceToHost));
     for (int i = 0; i < e->last_n; i++)

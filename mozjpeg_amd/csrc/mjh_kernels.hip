@@ -20,13 +20,7 @@
 
 #define WAVE 64
 
-// zig-zag -> natural (jutils.c:59) and its inverse
-__device__ __constant__ const uint8_t d_zz[64] = {
-  0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
-  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
-  35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
-  58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63
-};
+// zig-zag -> natural (jutils.c:59)
 struct ZZTab { int v[64]; };
 static constexpr ZZTab make_zz() {
   ZZTab t{};

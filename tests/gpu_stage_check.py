@@ -57,7 +57,7 @@ def check_case(img, kw, verbose=True):
             ok = False
     bits = enc.read_tap(M.TAP_HUFF_BITS, 0)
     vals = enc.read_tap(M.TAP_HUFF_VALS, 0)
-    if pg.optimize_coding and pg.num_scans == 0:
+    if pg.optimize_coding and pg.num_scans == 0 and not kw.get("arithmetic"):   # (the arithmetic coder has no tables)
         used = sorted({pg.dc_tbl_no[i] for i in range(pg.num_components)})   # tables a component refers to (RGB output: only 0)
         for t in used:
             for nm, gb, gv, ob, ov in (("dc", bits[2 * t], vals[2 * t], taps["dc_bits"][t], taps["dc_vals"][t]),
