@@ -58,6 +58,11 @@ CONFIGS = {
                name="C4: batch of 1024 x 1920x1080 frames, q75 trellis baseline, sharded over the GPUs (128 per encode call)"),
     "c5": dict(w=8192, h=8192, kw=dict(precision=12, baseline=True, notrellis=True, quality=90, sample=(1, 1), restart=1), batch=1, steps=600,
                name="C5: 8192x8192 12-bit, q90 4:4:4, restart interval = MCU row, -notrellis (the reference aborts on 12-bit + trellis, SURVEY F1)"),
+    # SURVEY 8f row 4 (completeness path, not a throughput path: an adaptive coder is one dependent chain per scan)
+    "arith": dict(w=3840, h=2160, kw=dict(quality=75, baseline=True, arithmetic=True), batch=16, steps=3,
+                  name="4K q75 4:2:0 sequential, arithmetic coding + the coder's trellis (cjpeg -quality 75 -baseline -arithmetic)"),
+    "arith_prog": dict(w=3840, h=2160, kw=dict(quality=75, arithmetic=True), batch=16, steps=2,
+                       name="4K q75 4:2:0 progressive + scan search, arithmetic coding (cjpeg -quality 75 -arithmetic)"),
     "c5t": dict(w=8192, h=8192, kw=dict(baseline=True, quality=90, sample=(1, 1), restart=1), batch=1, steps=400,
                 name="C5 8-bit twin: 8192x8192, q90 4:4:4 trellis, restart interval = MCU row"),
 }

@@ -314,7 +314,12 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
   memset(p, 0, sizeof(*p));
   if (cinfo->data_precision != 8 && cinfo->data_precision != 12) return "data_precision other than 8 or 12";
   p->data_precision = cinfo->data_precision;
-  if (cinfo->arith_code) return "arithmetic coding";
+  if (cinfo->arith_code) {
+    /* cjpeg -arithmetic: the device path knows the default conditioning (jcparam.c:417-419), which is all cjpeg can produce */
+    for (i = 0; i < 2; i++)
+      if (cinfo->arith_dc_L[i] != 0 || cinfo->arith_dc_U[i] != 1 || cinfo->arith_ac_K[i] != 5) return "arithmetic coding with non-default conditioning";
+    p->arith_code = 1;
+  }
   if (cinfo->master->lossless) return "lossless mode";
   p->smoothing_factor = cinfo->smoothing_factor;   /* cjpeg -smooth N; ignored for raw data / coefficients like in the reference */
   if (cinfo->dct_method != JDCT_ISLOW) return "dct_method other than JDCT_ISLOW";
@@ -378,7 +383,8 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
   p->dc_scan_opt_mode = jpeg_c_get_int_param(cinfo, JINT_DC_SCAN_OPT_MODE);
   p->trellis_num_loops = jpeg_c_get_int_param(cinfo, JINT_TRELLIS_NUM_LOOPS);
   if (p->trellis_num_loops < 1 || p->trellis_num_loops > 16) return "trellis_num_loops outside 1..16";
-  if (p->trellis_quant && !p->optimize_coding) return "trellis without optimize_coding";
+  if (p->arith_code) p->optimize_coding = 0;   /* jinit_c_master_control, jcmaster.c:1088-1089 */
+  if (p->trellis_quant && !p->optimize_coding && !p->arith_code) return "trellis without optimize_coding";
   p->restart_interval = cinfo->restart_interval;
   p->restart_in_rows = cinfo->restart_in_rows;
   if (cinfo->scan_info != NULL && cinfo->num_scans > 0) {
@@ -396,9 +402,9 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
       ms->Ss = js->Ss; ms->Se = js->Se; ms->Ah = js->Ah; ms->Al = js->Al;
     }
     p->optimize_scans = jpeg_c_get_bool_param(cinfo, JBOOLEAN_OPTIMIZE_SCANS) && cinfo->master->num_scans_luma != 0;
-    p->optimize_coding = 1;   /* jcmaster.c:1091-1094 */
+    p->optimize_coding = p->arith_code ? 0 : 1;   /* jcmaster.c:1088-1094 */
   }
-  if (!cinfo->optimize_coding) {
+  if (!cinfo->optimize_coding && !cinfo->arith_code) {
     /* standard tables are baked into the GPU path; anything else needs optimize_coding */
     if (cinfo->dc_huff_tbl_ptrs[0] == NULL || cinfo->ac_huff_tbl_ptrs[0] == NULL) return "missing Huffman tables";
   }

@@ -11,7 +11,7 @@
  * Annex K tables scaled by jpeg_set_quality(q, TRUE), standard Huffman tables unless TJPARAM_OPTIMIZE / progressive /
  * 12-bit, no trellis -- with the sampling factors of TJSAMP_*, the byte order of TJPF_*, restart intervals, JFIF
  * density.  Exactly these are mapped onto mjh_params; the output is the byte stream the reference TurboJPEG produces.
- * Outside the GPU path (an ERROR, never a CPU fallback): CMYK / YCCK, arithmetic coding, lossless, and the FAST DCT --
+ * Outside the GPU path (an ERROR, never a CPU fallback): CMYK / YCCK, lossless, and the FAST DCT --
  * note that the LEGACY tjCompress2 selects the fast DCT unless quality >= 96 or TJFLAG_ACCURATEDCT is given
  * (processFlags turbojpeg.c:522-527); MOZJPEG_HIP_TJ_ACCURATE=1 makes this library use the accurate DCT regardless.
  */
@@ -264,7 +264,6 @@ static int build_params(tjs *t, const char *fn, int width, int height, int pixel
 {
   int subsamp = t->subsamp, gray_out, in_comps = 3;
   if (t->lossless) return fail(t, fn, "lossless mode is outside the GPU path (no CPU fallback)");
-  if (t->arithmetic) return fail(t, fn, "arithmetic coding is outside the GPU path (no CPU fallback)");
   if (t->fast_dct && !getenv("MOZJPEG_HIP_TJ_ACCURATE"))
     return fail(t, fn, "the fast DCT is outside the GPU path: pass TJFLAG_ACCURATEDCT / leave TJPARAM_FASTDCT unset, or set MOZJPEG_HIP_TJ_ACCURATE=1 (no CPU fallback)");
   if (pixelFormat == TJPF_CMYK || t->colorspace == TJCS_CMYK || t->colorspace == TJCS_YCCK) return fail(t, fn, "CMYK / YCCK are outside the GPU path (no CPU fallback)");
@@ -291,6 +290,7 @@ static int build_params(tjs *t, const char *fn, int width, int height, int pixel
   p->restart_interval = (unsigned)t->restart_blocks;
   p->restart_in_rows = t->restart_rows;
   if (t->progressive && mjh_params_simple_progression(p) != MJH_OK) return fail(t, fn, mjh_last_error());
+  if (t->arithmetic) { p->arith_code = 1; p->optimize_coding = 0; }   /* TJPARAM_ARITHMETIC -> cinfo->arith_code (turbojpeg.c setCompDefaults) */
   return 0;
 }
 

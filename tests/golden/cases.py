@@ -194,4 +194,8 @@ TRANSCODE_CASES = [
     ("tr_testorig_default_to_rescan", "testorig", dict(), ["-progressive"], dict()),
     ("tr_1x1_to_rescan", "syn1x1", dict(baseline=True), ["-progressive"], dict()),
     ("tr_640x480_to_rescan", "syn640x480", dict(baseline=True), ["-progressive"], dict()),
+    # jpegtran -arithmetic: Huffman-coded source re-coded with the arithmetic coder (and the scan search sizing its candidates with it)
+    ("tr_base_to_arith_rescan", "syn250x187", dict(baseline=True), ["-arithmetic", "-progressive"], dict(arithmetic=True)),
+    ("tr_base_to_arith_revert", "syn250x187", dict(baseline=True), ["-arithmetic", "-revert"], dict(arithmetic=True, revert=True)),
+    ("tr_revert422_to_arith_revert_restart2", "testorig", dict(revert=True, sample=(2, 1)), ["-arithmetic", "-revert", "-restart", "2"], dict(arithmetic=True, revert=True, restart=2)),
 ]

@@ -46,6 +46,14 @@ CJPEG_CASES = [
     ("fastcrush_dc_scan_opt2", ["-quality", "75", "-fastcrush", "-dc-scan-opt", "2", "-sample", "2x2"]),
     ("base_dc_ver_weight1", ["-quality", "75", "-baseline", "-trellis-dc-ver-weight", "1.0", "-sample", "2x2"]),
     ("q60_progressive_dc_ver_weight2", ["-quality", "60", "-trellis-dc-ver-weight", "2.0", "-sample", "2x2"]),
+    # cjpeg -arithmetic: sequential, progressive with and without the scan search, restarts
+    ("arith_revert", ["-revert", "-arithmetic", "-quality", "75", "-sample", "2x2"]),      # (-revert resets arith_code: it has to come first)
+    ("arith_base", ["-arithmetic", "-quality", "75", "-baseline", "-sample", "2x2"]),
+    ("arith_base_notrellis", ["-arithmetic", "-quality", "75", "-baseline", "-notrellis", "-sample", "2x2"]),
+    ("arith_base_restart1", ["-arithmetic", "-quality", "75", "-baseline", "-restart", "1", "-sample", "2x2"]),
+    ("arith_fastcrush", ["-arithmetic", "-quality", "75", "-fastcrush", "-sample", "2x2"]),
+    ("arith_default_progressive", ["-arithmetic", "-quality", "75", "-sample", "2x2"]),
+    ("arith_revert_progressive", ["-revert", "-arithmetic", "-progressive", "-quality", "75", "-sample", "2x2"]),
 ]
 
 
@@ -88,7 +96,7 @@ def test_unchanged_cjpeg_12bit_through_the_shim(args, tmp_path):
 @needs
 def test_unsupported_configuration_is_an_error_without_fallback(tmp_path):
     out = str(tmp_path / "o.jpg")
-    r = run_cjpeg(["-quality", "75", "-arithmetic"], out)          # arithmetic coding is outside the GPU path
+    r = run_cjpeg(["-quality", "75", "-dct", "float"], out)        # the float DCT is outside the GPU path
     assert r.returncode != 0
     assert b"no CPU fallback" in r.stderr
 
@@ -96,7 +104,7 @@ def test_unsupported_configuration_is_an_error_without_fallback(tmp_path):
 @needs
 def test_explicit_passthrough_is_logged(goldens, tmp_path):
     out = str(tmp_path / "o.jpg")
-    r = run_cjpeg(["-quality", "75", "-arithmetic"], out, {"MOZJPEG_HIP_PASSTHROUGH": "1"})   # arithmetic coding: outside the GPU path
+    r = run_cjpeg(["-quality", "75", "-dct", "float"], out, {"MOZJPEG_HIP_PASSTHROUGH": "1"})   # the float DCT: outside the GPU path
     assert r.returncode == 0, r.stderr.decode()
     assert b"handing over to the host libjpeg" in r.stderr
     assert open(out, "rb").read()[:2] == b"\xff\xd8"

@@ -154,3 +154,21 @@ def test_two_rank_sharded_run_with_the_hip_encoder():
     po = O.make_params(320, 200, baseline=True)
     for i in range(9):
         assert merged[i] == O.md5(O.encode(po, O.synthetic_frame(320, 200, 100 + i)))
+
+
+@pytest.mark.parametrize("name,w,h,kw", [
+    ("1080p sequential + the coder's trellis", 1920, 1080, dict(arithmetic=True, quality=75, baseline=True)),
+    ("1080p 4:4:4 q92 sequential, restart per row, no trellis", 1920, 1080, dict(arithmetic=True, quality=92, baseline=True, sample=(1, 1), notrellis=True, restart=1)),
+    ("1080p progressive with scan search (cjpeg -arithmetic)", 1920, 1080, dict(arithmetic=True, quality=85)),
+    ("odd size, 4:2:2, fixed script", 1283, 727, dict(arithmetic=True, quality=60, fastcrush=True, sample=(2, 1))),
+])
+def test_arithmetic_coding_at_larger_sizes_matches_the_reference(name, w, h, kw):
+    """cjpeg -arithmetic.  More than 64 blocks per scan row, several load batches per chain, interleaved MCUs
+    with dummy blocks (odd sizes), the trellis pass' rate refresh over many iMCU rows, a batch of two different frames."""
+    frames = np.stack([O.synthetic_frame(w, h, 77 + i) for i in range(2)])
+    enc = M.Encoder(M.make_params(w, h, **kw), max_batch=2)
+    got = enc.encode_host(frames)
+    enc.close()
+    for i, f in enumerate(frames):
+        want, kind = _reference(f, kw)
+        assert got[i] == want, "%s: frame %d differs from the %s (%d vs %d bytes)" % (name, i, kind, len(got[i]), len(want))
