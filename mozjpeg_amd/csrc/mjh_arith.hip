@@ -75,16 +75,22 @@ struct AriCoder {      // registers of the coding lane (jcarith.c:28-52)
       }
     }
   }
-  // arith_encode jcarith.c:229-320; tab[state] = Qe << 16 | next state after an MPS << 8 | next state after an LPS (bit 7: MPS flips)
-  __device__ __attribute__((noinline)) void encode(const unsigned *tab, uint8_t *st, int val)
+  // arith_encode jcarith.c:229-320; tab[state] = Qe << 16 | next state after an MPS << 8 | next state after an LPS (bit 7: MPS flips).
+  // The common case -- the more probable symbol, no renormalisation, no adaptation -- is inline; everything else is a call.
+  __device__ __forceinline__ void encode(const unsigned *tab, uint8_t *st, int val)
   {
     const unsigned sv = *st, t = tab[sv & 0x7Fu], qe = t >> 16;
     a -= qe;
+    if ((unsigned)val == (sv >> 7) && a >= 0x8000u) return;
+    encode_slow(st, val, sv, t);
+  }
+  __device__ __attribute__((noinline)) void encode_slow(uint8_t *st, int val, unsigned sv, unsigned t)
+  {
+    const unsigned qe = t >> 16;
     if ((unsigned)val != (sv >> 7)) {
       if (a >= qe) { c += a; a = qe; }
       *st = (uint8_t)((sv & 0x80u) ^ (t & 0xFFu));
     } else {
-      if (a >= 0x8000u) return;
       if (a < qe) { c += a; a = qe; }
       *st = (uint8_t)((sv & 0x80u) ^ ((t >> 8) & 0xFFu));
     }
@@ -150,14 +156,10 @@ __device__ __forceinline__ void ari_dc(AriCoder &A, const unsigned *tab, uint8_t
 
 // Encode_AC_Coefficients: encode_mcu_AC_first jcarith.c:456-552; with Ss = 1, Se = 63, Al = 0 the AC part of encode_mcu :764-817.
 // blk: the block's coefficients in zig-zag order (LDS)
-__device__ __forceinline__ void ari_ac_first(AriCoder &A, const unsigned *tab, uint8_t *stats, uint8_t *fixed, const short *blk, int Ss, int Se, int Al)
+// ke = the block's end-of-block index for this scan (jcarith.c:484-496), found by the lane that loaded the block
+__device__ __forceinline__ void ari_ac_first(AriCoder &A, const unsigned *tab, uint8_t *stats, uint8_t *fixed, const short *blk, int Ss, int Se, int Al, int ke)
 {
-  int k, ke, v;
-  for (ke = Se; ke > 0; ke--) {
-    v = blk[ke];
-    if (v < 0) v = -v;
-    if (v >> Al) break;
-  }
+  int k, v;
   for (k = Ss; k <= ke; k++) {
     uint8_t *st = stats + 3 * (k - 1);
     int neg;
@@ -180,19 +182,9 @@ __device__ __forceinline__ void ari_ac_first(AriCoder &A, const unsigned *tab, u
 }
 
 // encode_mcu_AC_refine jcarith.c:596-687
-__device__ __forceinline__ void ari_ac_refine(AriCoder &A, const unsigned *tab, uint8_t *stats, uint8_t *fixed, const short *blk, int Ss, int Se, int Ah, int Al)
+__device__ __forceinline__ void ari_ac_refine(AriCoder &A, const unsigned *tab, uint8_t *stats, uint8_t *fixed, const short *blk, int Ss, int Se, int Ah, int Al, int ke, int kex)
 {
-  int k, ke, kex, v;
-  for (ke = Se; ke > 0; ke--) {
-    v = blk[ke];
-    if (v < 0) v = -v;
-    if (v >> Al) break;
-  }
-  for (kex = ke; kex > 0; kex--) {
-    v = blk[kex];
-    if (v < 0) v = -v;
-    if (v >> Ah) break;
-  }
+  int k, v;
   for (k = Ss; k <= ke; k++) {
     uint8_t *st = stats + 3 * (k - 1);
     if (k > kex) A.encode(tab, st, 0);
@@ -264,7 +256,7 @@ __device__ __forceinline__ void ari_reset_stats(AriModel &M, AriChain &ch, const
 // All 64 lanes call this; lane 0 codes.  s_blk: 64 x 64 int16 of LDS.
 __device__ __forceinline__ void ari_run(const MjhConst &C, const MjhProgScan &sc, int Al, bool whole_blocks, bool progressive,
                                         const int16_t *__restrict__ qimg, long long u0, long long u1, int bpm,
-                                        AriCoder &A, AriModel &M, AriChain &ch, const unsigned *tab, short *s_blk, int lane, bool loader = true)
+                                        AriCoder &A, AriModel &M, AriChain &ch, const unsigned *tab, short *s_blk, unsigned char *s_ke, int lane, bool loader = true)
 {
   const int Ss = whole_blocks ? 0 : sc.Ss, Se = whole_blocks ? 63 : sc.Se;
   for (long long base = u0; base < u1; base += 64) {
@@ -274,8 +266,20 @@ __device__ __forceinline__ void ari_run(const MjhConst &C, const MjhProgScan &sc
       const int16_t *q = qimg + cc.coef_off;
       short *row = s_blk + lane * 64;
       if (Ss == 0) row[0] = q[un.dc_blk];
-      if (Se > 0)   // (from position 1: the end-of-block searches of the AC scans look below Ss as well, jcarith.c:484-496)
-        for (int k = 1; k <= Se; k++) row[k] = un.dummy ? (short)0 : q[(size_t)k * cc.kstride + un.blk];
+      int ke = 0, kex = 0;
+      if (Se > 0) {
+        // (from position 1: the end-of-block searches of the AC scans look below Ss as well, jcarith.c:484-496); the last
+        // position that is non-zero after the point transform by Al (ke), and by Ah below it (kex, refinement scans)
+        const int al = whole_blocks ? 0 : Al, ah = whole_blocks ? 0 : sc.Ah;
+        for (int k = 1; k <= Se; k++) {
+          const short v = un.dummy ? (short)0 : q[(size_t)k * cc.kstride + un.blk];
+          row[k] = v;
+          const int av = v < 0 ? -(int)v : (int)v;
+          if (av >> al) ke = k;
+        }
+        if (ah) { for (int k = 1; k <= ke; k++) { const int v = row[k], av = v < 0 ? -v : v; if (av >> ah) kex = k; } }
+      }
+      s_ke[lane] = (unsigned char)ke; s_ke[64 + lane] = (unsigned char)kex;
     }
     __syncthreads();
     if (lane == 0) {
@@ -299,11 +303,11 @@ __device__ __forceinline__ void ari_run(const MjhConst &C, const MjhProgScan &sc
         uint8_t *dcs = M.dc[sc.td[ci] & 1], *acs = M.ac[sc.ta[ci] & 1];
         if (whole_blocks) {
           ari_dc(A, tab, dcs, ch.last_dc[ci], ch.ctx[ci], blk[0]);
-          ari_ac_first(A, tab, acs, M.fixed, blk, 1, 63, 0);
+          ari_ac_first(A, tab, acs, M.fixed, blk, 1, 63, 0, s_ke[b]);
         } else if (sc.Ss == 0 && sc.Ah == 0) ari_dc(A, tab, dcs, ch.last_dc[ci], ch.ctx[ci], (int)blk[0] >> Al);
         else if (sc.Ss == 0) A.encode(tab, M.fixed, ((int)blk[0] >> Al) & 1);             // encode_mcu_DC_refine :560-590
-        else if (sc.Ah == 0) ari_ac_first(A, tab, acs, M.fixed, blk, sc.Ss, sc.Se, Al);
-        else ari_ac_refine(A, tab, acs, M.fixed, blk, sc.Ss, sc.Se, sc.Ah, Al);
+        else if (sc.Ah == 0) ari_ac_first(A, tab, acs, M.fixed, blk, sc.Ss, sc.Se, Al, s_ke[b]);
+        else ari_ac_refine(A, tab, acs, M.fixed, blk, sc.Ss, sc.Se, sc.Ah, Al, s_ke[b], s_ke[64 + b]);
       }
     }
     __syncthreads();
@@ -371,6 +375,7 @@ k_arith_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
              unsigned *__restrict__ sizes, int whole_blocks, int single_pass)
 {
   __shared__ short s_blk[64 * 64];
+  __shared__ unsigned char s_ke[128];
   __shared__ unsigned tab[114];
   __shared__ AriModel M;
   const int img = blockIdx.y, lane = threadIdx.x;
@@ -409,7 +414,7 @@ k_arith_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
     ch.to_go = sc.ri; ch.next_rst = 0;
   }
   __syncthreads();
-  ari_run(C, sc, Al, whole_blocks != 0, !whole_blocks, coef_q + (size_t)img * C.coefs_per_image, 0, nunits, bpm, A, M, ch, tab, s_blk, lane);
+  ari_run(C, sc, Al, whole_blocks != 0, !whole_blocks, coef_q + (size_t)img * C.coefs_per_image, 0, nunits, bpm, A, M, ch, tab, s_blk, s_ke, lane);
   if (lane == 0) {
     A.finish();
     const unsigned total = hdr + A.pos;
@@ -495,6 +500,7 @@ k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
                 int Ss, int Se, int quant_dc, float delta_dc_weight, int restart_blocks, int prog_file)
 {
   __shared__ short s_blk[64 * 64];
+  __shared__ unsigned char s_ke[128];
   __shared__ unsigned tab[114];
   __shared__ AriModel M;
   __shared__ float rdc[64][2], rac[256][2];
@@ -683,7 +689,7 @@ k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     // ---- the row group goes through the coder: its statistics move on (compress_output -> encode_mcu, output discarded)
     // (wave 0 loads, thread 0 codes, every wave takes part in the barriers; emit_restart consults the FILE's mode, jcarith.c:328-341)
     ari_run(C, sc, 0, true, prog_file != 0, coef_q + (size_t)img * C.coefs_per_image, (long long)br0 * cc.wib, (long long)(br0 + rows) * cc.wib, 1, A, M, ch, tab,
-            s_blk, tid, tid < 64);
+            s_blk, s_ke, tid, tid < 64);
     __syncthreads();
   }
 }
