@@ -23,20 +23,46 @@
 
 // zig-zag -> natural is not needed: the pipeline's coefficient planes are in zig-zag order already (plane k = position k)
 
-struct AriCoder {      // registers of the coding lane (jcarith.c:28-52)
+// ---- the wave as a scalar machine ---------------------------------------------------------------------------------
+// Every lane of the coding wave executes the coder with the same (wave-uniform) values, so the compiler keeps the coder's
+// registers in SGPRs and its branches are scalar jumps (a first version ran it on lane 0 alone: vector instructions with
+// one live lane, both sides of every branch issued, the statistics bins behind dependent LDS round trips -- 540 ns per
+// binary decision).  The coder's MEMORY -- statistics bins, the probability table, the block being coded -- lives in
+// vector registers used as 64-entry RAMs: entry i = lane i, read with v_readlane_b32, written with v_writelane_b32.
+__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ int wl(int val, int lane, int old)
+{ // (this compiler has no writelane builtin; the s_nop covers the lane-select hazard the hazard recognizer cannot see inside asm)
+  // (lane select through M0: a VALU instruction may read one SGPR over the constant bus, M0 does not count)
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(__builtin_amdgcn_readfirstlane(val)), "s"(__builtin_amdgcn_readfirstlane(lane)) : "m0");
+  return old;
+}
+
+struct AriModel {      // vector registers as RAM
+  int ac[2];           // AC statistics of table 0 / 1: 256 bins each, four per lane (byte j of lane i = bin 4i + j)
+  int dc;              // DC statistics: table 0 in lanes 0..15, table 1 in lanes 16..31 (64 bins each)
+  int tab[2];          // T.81 Table D.3, entries 0..63 / 64..113: Qe << 16 | next state after an MPS << 8 | after an LPS (bit 7: MPS flips)
+  int coef;            // the block being coded: lane k = coefficient k (zig-zag)
+};
+// a statistics bin: space << 8 | index; space 0 / 1 = AC table 0 / 1, 2 = DC (index = 64 * table + bin), 3 = the fixed 0.5 bin
+#define ARI_AC(t, i) (((t) << 8) | (i))
+#define ARI_DC(t, i) ((2 << 8) | ((t) << 6) | (i))
+#define ARI_FIXED (3 << 8)
+
+struct AriCoder {      // jcarith.c:28-52, all wave-uniform
   unsigned c, a;
   int sc, zc, ct, buffer;
   uint8_t *out;        // nullptr: only sizes
   unsigned pos, cap;
+  bool lane0;
   __device__ __forceinline__ void byte(int v)
   {
-    if (out && pos < cap) out[pos] = (uint8_t)v;
+    if (lane0 && out && pos < cap) out[pos] = (uint8_t)v;
     pos++;
   }
   __device__ __forceinline__ void zeros() { while (zc) { byte(0x00); zc--; } }
   __device__ __forceinline__ void reset() { c = 0; a = 0x10000u; sc = 0; zc = 0; ct = 11; buffer = -1; }
   // a byte leaves the code register (D.1.6) or the register is flushed (D.1.8): jcarith.c:278-316 / :160-190
-  __device__ __attribute__((noinline)) void shift_out(unsigned temp, bool final)
+  __device__ __forceinline__ void shift_out(unsigned temp, bool final)
   {
     if (final ? (c & 0xF8000000u) != 0u : temp > 0xFFu) {
       if (buffer >= 0) {
@@ -75,24 +101,34 @@ struct AriCoder {      // registers of the coding lane (jcarith.c:28-52)
       }
     }
   }
-  // arith_encode jcarith.c:229-320; tab[state] = Qe << 16 | next state after an MPS << 8 | next state after an LPS (bit 7: MPS flips).
-  // The common case -- the more probable symbol, no renormalisation, no adaptation -- is inline; everything else is a call.
-  __device__ __forceinline__ void encode(const unsigned *tab, uint8_t *st, int val)
+  // arith_encode jcarith.c:229-320
+  __device__ __forceinline__ void encode(AriModel &M, int bin, int val)
   {
-    const unsigned sv = *st, t = tab[sv & 0x7Fu], qe = t >> 16;
-    a -= qe;
-    if ((unsigned)val == (sv >> 7) && a >= 0x8000u) return;
-    encode_slow(st, val, sv, t);
-  }
-  __device__ __attribute__((noinline)) void encode_slow(uint8_t *st, int val, unsigned sv, unsigned t)
-  {
+    const int sp = bin >> 8, i = bin & 0xFF, sh = 8 * (i & 3);
+    int word = 0;
+    unsigned sv = 113u;
+    if (sp == 0) word = rl(M.ac[0], i >> 2);
+    else if (sp == 1) word = rl(M.ac[1], i >> 2);
+    else if (sp == 2) word = rl(M.dc, i >> 2);
+    if (sp != 3) sv = ((unsigned)word >> sh) & 0xFFu;
+    const int s = (int)(sv & 0x7Fu);
+    const unsigned t = (unsigned)(s < 64 ? rl(M.tab[0], s) : rl(M.tab[1], s - 64));
     const unsigned qe = t >> 16;
+    unsigned ns;
+    a -= qe;
     if ((unsigned)val != (sv >> 7)) {
       if (a >= qe) { c += a; a = qe; }
-      *st = (uint8_t)((sv & 0x80u) ^ (t & 0xFFu));
+      ns = (sv & 0x80u) ^ (t & 0xFFu);
     } else {
+      if (a >= 0x8000u) return;
       if (a < qe) { c += a; a = qe; }
-      *st = (uint8_t)((sv & 0x80u) ^ ((t >> 8) & 0xFFu));
+      ns = (sv & 0x80u) ^ ((t >> 8) & 0xFFu);
+    }
+    if (sp != 3) {
+      word = (int)(((unsigned)word & ~(0xFFu << sh)) | (ns << sh));
+      if (sp == 0) M.ac[0] = wl(word, i >> 2, M.ac[0]);
+      else if (sp == 1) M.ac[1] = wl(word, i >> 2, M.ac[1]);
+      else M.dc = wl(word, i >> 2, M.dc);
     }
     do {
       a <<= 1;
@@ -106,167 +142,206 @@ struct AriCoder {      // registers of the coding lane (jcarith.c:28-52)
   }
 };
 
-struct AriModel {      // the statistics areas of one chain, in LDS
-  uint8_t dc[2][64];
-  uint8_t ac[2][256];
-  uint8_t fixed[4];
-};
+__device__ __forceinline__ int ari_coef(const AriModel &M, int k) { return (int)(short)rl(M.coef, k); }
 
 // Figures F.8 / F.9: magnitude category and magnitude bits of v >= 1.  st = first magnitude bin; DC: the category bins continue
-// at 20; AC: the bin itself once more, then 189 (k <= Kx) / 217.  Returns the category mask (the DC conditioning needs it).
-__device__ __forceinline__ int ari_magnitude(AriCoder &A, const unsigned *tab, uint8_t *stats, uint8_t *st, int v, bool ac, int k)
+// at 20; AC: the bin itself once more, then 189 (k <= Kx) / 217.  base = the table's bin 0.  Returns the category mask.
+__device__ __forceinline__ int ari_magnitude(AriCoder &A, AriModel &M, int base, int st, int v, bool ac, int k)
 {
   int m = 0;
   if (v -= 1) {
-    A.encode(tab, st, 1);
+    A.encode(M, st, 1);
     m = 1;
     int v2 = v;
     if (ac) {
       if (v2 >>= 1) {
-        A.encode(tab, st, 1);
+        A.encode(M, st, 1);
         m <<= 1;
-        st = stats + (k <= ARI_AC_K ? 189 : 217);
-        while (v2 >>= 1) { A.encode(tab, st, 1); m <<= 1; st++; }
+        st = base + (k <= ARI_AC_K ? 189 : 217);
+        while (v2 >>= 1) { A.encode(M, st, 1); m <<= 1; st++; }
       }
     } else {
-      st = stats + 20;
-      while (v2 >>= 1) { A.encode(tab, st, 1); m <<= 1; st++; }
+      st = base + 20;
+      while (v2 >>= 1) { A.encode(M, st, 1); m <<= 1; st++; }
     }
   }
-  A.encode(tab, st, 0);
+  A.encode(M, st, 0);
   st += 14;
-  for (int mm = m >> 1; mm; mm >>= 1) A.encode(tab, st, (mm & v) ? 1 : 0);
+  for (int mm = m >> 1; mm; mm >>= 1) A.encode(M, st, (mm & v) ? 1 : 0);
   return m;
 }
 
 // Encode_DC_DIFF (jcarith.c:402-448 / :715-762)
-__device__ __forceinline__ void ari_dc(AriCoder &A, const unsigned *tab, uint8_t *stats, int &last_dc, int &ctx, int value)
+__device__ __forceinline__ void ari_dc(AriCoder &A, AriModel &M, int tbl, int &last_dc, int &ctx, int value)
 {
-  uint8_t *st = stats + ctx;
+  const int base = ARI_DC(tbl, 0);
+  int st = base + ctx;
   int v = value - last_dc;
-  if (v == 0) { A.encode(tab, st, 0); ctx = 0; return; }
+  if (v == 0) { A.encode(M, st, 0); ctx = 0; return; }
   last_dc = value;
-  A.encode(tab, st, 1);
-  if (v > 0) { A.encode(tab, st + 1, 0); st += 2; ctx = 4; }
-  else { v = -v; A.encode(tab, st + 1, 1); st += 3; ctx = 8; }
-  const int m = ari_magnitude(A, tab, stats, st, v, false, 0);
+  A.encode(M, st, 1);
+  if (v > 0) { A.encode(M, st + 1, 0); st += 2; ctx = 4; }
+  else { v = -v; A.encode(M, st + 1, 1); st += 3; ctx = 8; }
+  const int m = ari_magnitude(A, M, base, st, v, false, 0);
   if (m < (int)((1L << ARI_DC_L) >> 1)) ctx = 0;
   else if (m > (int)((1L << ARI_DC_U) >> 1)) ctx += 8;
 }
 
 // Encode_AC_Coefficients: encode_mcu_AC_first jcarith.c:456-552; with Ss = 1, Se = 63, Al = 0 the AC part of encode_mcu :764-817.
-// blk: the block's coefficients in zig-zag order (LDS)
 // ke = the block's end-of-block index for this scan (jcarith.c:484-496), found by the lane that loaded the block
-__device__ __forceinline__ void ari_ac_first(AriCoder &A, const unsigned *tab, uint8_t *stats, uint8_t *fixed, const short *blk, int Ss, int Se, int Al, int ke)
+__device__ __forceinline__ void ari_ac_first(AriCoder &A, AriModel &M, int tbl, int Ss, int Se, int Al, int ke)
 {
+  const int base = ARI_AC(tbl, 0);
   int k, v;
   for (k = Ss; k <= ke; k++) {
-    uint8_t *st = stats + 3 * (k - 1);
+    int st = base + 3 * (k - 1);
     int neg;
-    A.encode(tab, st, 0);
+    A.encode(M, st, 0);
     for (;;) {
-      v = blk[k];
+      v = ari_coef(M, k);
       neg = v < 0;
       if (neg) v = -v;
       v >>= Al;
       if (v) break;
-      A.encode(tab, st + 1, 0);
+      A.encode(M, st + 1, 0);
       st += 3;
       k++;
     }
-    A.encode(tab, st + 1, 1);
-    A.encode(tab, fixed, neg);
-    ari_magnitude(A, tab, stats, st + 2, v, true, k);
+    A.encode(M, st + 1, 1);
+    A.encode(M, ARI_FIXED, neg);
+    ari_magnitude(A, M, base, st + 2, v, true, k);
   }
-  if (k <= Se) A.encode(tab, stats + 3 * (k - 1), 1);
+  if (k <= Se) A.encode(M, base + 3 * (k - 1), 1);
 }
 
 // encode_mcu_AC_refine jcarith.c:596-687
-__device__ __forceinline__ void ari_ac_refine(AriCoder &A, const unsigned *tab, uint8_t *stats, uint8_t *fixed, const short *blk, int Ss, int Se, int Ah, int Al, int ke, int kex)
+__device__ __forceinline__ void ari_ac_refine(AriCoder &A, AriModel &M, int tbl, int Ss, int Se, int Ah, int Al, int ke, int kex)
 {
+  const int base = ARI_AC(tbl, 0);
   int k, v;
   for (k = Ss; k <= ke; k++) {
-    uint8_t *st = stats + 3 * (k - 1);
-    if (k > kex) A.encode(tab, st, 0);
+    int st = base + 3 * (k - 1);
+    if (k > kex) A.encode(M, st, 0);
     for (;;) {
-      v = blk[k];
+      v = ari_coef(M, k);
       const int neg = v < 0;
       if (neg) v = -v;
       v >>= Al;
       if (v) {
-        if (v >> 1) A.encode(tab, st + 2, v & 1);
-        else { A.encode(tab, st + 1, 1); A.encode(tab, fixed, neg); }
+        if (v >> 1) A.encode(M, st + 2, v & 1);
+        else { A.encode(M, st + 1, 1); A.encode(M, ARI_FIXED, neg); }
         break;
       }
-      A.encode(tab, st + 1, 0);
+      A.encode(M, st + 1, 0);
       st += 3;
       k++;
     }
   }
-  if (k <= Se) A.encode(tab, stats + 3 * (k - 1), 1);
+  if (k <= Se) A.encode(M, base + 3 * (k - 1), 1);
+}
+
+// The scan being coded, in registers and wave-uniform FOR THE COMPILER (readfirstlane): a MjhProgScan copied as a struct lands
+// in scratch memory as soon as one of its arrays is indexed dynamically, scratch loads count as divergent, and everything
+// computed from them would run on the vector unit.  Arrays are only ever indexed statically here (pick4 for a run-time index).
+struct AriScan {
+  int ncomp, Ss, Se, Ah, ri, frame_header, emit_dri;
+  int comp[4], td[4], ta[4], comp_id[4];
+  int h[4], v[4];      // sampling factors of the scan's components
+};
+#define ARI_U(x) __builtin_amdgcn_readfirstlane((int)(x))
+__device__ __forceinline__ int pick4(const int (&a)[4], int i) { return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : a[3]; }
+
+__device__ __forceinline__ AriScan ari_load_scan(const MjhConst &C, const MjhProgScan *__restrict__ p)
+{
+  AriScan s;
+  s.ncomp = ARI_U(p->ncomp); s.Ss = ARI_U(p->Ss); s.Se = ARI_U(p->Se); s.Ah = ARI_U(p->Ah); s.ri = ARI_U(p->ri);
+  s.frame_header = ARI_U(p->frame_header); s.emit_dri = ARI_U(p->emit_dri);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    s.comp[i] = ARI_U(p->comp[i]) & 3; s.td[i] = ARI_U(p->td[i]); s.ta[i] = ARI_U(p->ta[i]); s.comp_id[i] = ARI_U(p->comp_id[i]);
+    s.h[i] = ARI_U(C.c[s.comp[i]].h); s.v[i] = ARI_U(C.c[s.comp[i]].v);
+  }
+  return s;
 }
 
 // the coefficient planes a lane has to fetch for one block of the scan, and where the block's DC comes from (dummy blocks of an
 // interleaved scan repeat a neighbour's DC and have no AC: compress_first_pass jccoefct.c:312-345)
-struct AriUnit { int comp_in_scan, comp, blk, dc_blk; bool dummy, valid; };
+struct AriUnit { int comp_in_scan, comp, blk, dc_blk; bool dummy, mcu_start; };
 
-__device__ __forceinline__ AriUnit ari_unit(const MjhConst &C, const MjhProgScan &sc, int bpm, long long u, long long nunits)
+__device__ __forceinline__ AriUnit ari_unit(const MjhConst &C, const AriScan &sc, int bpm, long long u, long long nunits)
 {
   AriUnit r;
-  r.valid = u < nunits;
-  if (!r.valid) u = nunits - 1;
+  if (u >= nunits) u = nunits - 1;
   if (sc.ncomp == 1) {
-    r.comp_in_scan = 0; r.comp = sc.comp[0]; r.blk = (int)u; r.dc_blk = (int)u; r.dummy = false;
+    r.comp_in_scan = 0; r.comp = sc.comp[0]; r.blk = (int)u; r.dc_blk = (int)u; r.dummy = false; r.mcu_start = true;
     return r;
   }
   const int m = (int)(u / bpm);
   int j = (int)(u - (long long)m * bpm), ci = 0;
-  while (ci + 1 < sc.ncomp && j >= C.c[sc.comp[ci]].h * C.c[sc.comp[ci]].v) { j -= C.c[sc.comp[ci]].h * C.c[sc.comp[ci]].v; ci++; }
-  const MjhComp &cc = C.c[sc.comp[ci]];
-  const int yi = j / cc.h, xi = j - yi * cc.h;
+  r.mcu_start = j == 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int n = sc.h[i] * sc.v[i];
+    if (ci == i && i + 1 < sc.ncomp && j >= n) { j -= n; ci = i + 1; }
+  }
+  const int comp = pick4(sc.comp, ci), h = pick4(sc.h, ci), v = pick4(sc.v, ci);
+  const MjhComp &cc = C.c[comp];
+  const int yi = j / h, xi = j - yi * h;
   const int my = m / C.mcus_per_row, mx = m - my * C.mcus_per_row;
-  const int row = my * cc.v + yi, col = mx * cc.h + xi;
-  r.comp_in_scan = ci; r.comp = sc.comp[ci];
+  const int row = my * v + yi, col = mx * h + xi;
+  r.comp_in_scan = ci; r.comp = comp;
   r.dummy = row >= cc.hib || col >= cc.wib;
   r.dc_blk = dc_source_block(cc, row, col);
   r.blk = r.dummy ? r.dc_blk : row * cc.wib + col;
   return r;
 }
 
-struct AriChain {      // what the coding lane carries from block to block
+struct AriChain {      // what the coder carries from block to block (wave-uniform)
   int last_dc[MJH_MAXC], ctx[MJH_MAXC];
   int to_go, next_rst;
 };
 
-__device__ __forceinline__ void ari_reset_stats(AriModel &M, AriChain &ch, const MjhProgScan &sc, bool progressive)
-{ // start_pass jcarith.c:845-875, emit_restart :328-342 (called by lane 0)
-  for (int i = 0; i < sc.ncomp; i++) {
+__device__ __forceinline__ void ari_reset_stats(AriModel &M, AriChain &ch, const AriScan &sc, bool progressive, int lane)
+{ // start_pass jcarith.c:845-875, emit_restart :328-342
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (i >= sc.ncomp) continue;
     if (!progressive || (sc.Ss == 0 && sc.Ah == 0)) {
-      for (int b = 0; b < 64; b++) M.dc[sc.td[i] & 1][b] = 0;
+      const int t = sc.td[i] & 1;
+      if ((lane >> 4) == t) M.dc = 0;       // (lanes 32..63 of the DC register are unused)
       ch.last_dc[i] = 0;
       ch.ctx[i] = 0;
     }
-    if (!progressive || sc.Se) for (int b = 0; b < 256; b++) M.ac[sc.ta[i] & 1][b] = 0;
+    if (!progressive || sc.Se) { if (sc.ta[i] & 1) M.ac[1] = 0; else M.ac[0] = 0; }
   }
+}
+
+__device__ __forceinline__ void ari_init_model(AriModel &M, int lane)
+{
+  M.ac[0] = M.ac[1] = M.dc = M.coef = 0;
+  M.tab[0] = (int)(((unsigned)mjh_ari_qe[lane] << 16) | ((unsigned)mjh_ari_nmps[lane] << 8) | (unsigned)mjh_ari_nlps[lane]);
+  const int j = lane + 64 < 114 ? lane + 64 : 113;
+  M.tab[1] = (int)(((unsigned)mjh_ari_qe[j] << 16) | ((unsigned)mjh_ari_nmps[j] << 8) | (unsigned)mjh_ari_nlps[j]);
 }
 
 // One chain: the units [u0, u1) of scan `sc` (an MCU = bpm units) run through the coder.  whole_blocks: DC + AC 1..63 of every
 // block whatever the scan parameters say (sequential files; the state updates of the trellis passes, jcarith.c:824-826).
 // dctbl / actbl of component i of the scan: sc.td[i] / sc.ta[i] (which hold the component's table numbers for whole_blocks).
-// All 64 lanes call this; lane 0 codes.  s_blk: 64 x 64 int16 of LDS.
-__device__ __forceinline__ void ari_run(const MjhConst &C, const MjhProgScan &sc, int Al, bool whole_blocks, bool progressive,
+// Called by every thread of the workgroup (the barriers); `coder`: this thread belongs to the coding wave (wave 0), which also
+// loads.  s_blk: 64 x 64 int16 of LDS.
+__device__ __forceinline__ void ari_run(const MjhConst &C, const AriScan &sc, int Al, bool whole_blocks, bool progressive,
                                         const int16_t *__restrict__ qimg, long long u0, long long u1, int bpm,
-                                        AriCoder &A, AriModel &M, AriChain &ch, const unsigned *tab, short *s_blk, unsigned char *s_ke, int lane, bool loader = true)
+                                        AriCoder &A, AriModel &M, AriChain &ch, short *s_blk, int lane, bool coder)
 {
   const int Ss = whole_blocks ? 0 : sc.Ss, Se = whole_blocks ? 63 : sc.Se;
   for (long long base = u0; base < u1; base += 64) {
-    if (loader) {
+    int kev = 0, kexv = 0, infov = 0;      // per lane: end-of-block indices and component / MCU-start flag of ITS block
+    if (coder) {
       const AriUnit un = ari_unit(C, sc, bpm, base + lane, u1);
       const MjhComp &cc = C.c[un.comp];
       const int16_t *q = qimg + cc.coef_off;
       short *row = s_blk + lane * 64;
       if (Ss == 0) row[0] = q[un.dc_blk];
-      int ke = 0, kex = 0;
       if (Se > 0) {
         // (from position 1: the end-of-block searches of the AC scans look below Ss as well, jcarith.c:484-496); the last
         // position that is non-zero after the point transform by Al (ke), and by Ah below it (kex, refinement scans)
@@ -275,93 +350,93 @@ __device__ __forceinline__ void ari_run(const MjhConst &C, const MjhProgScan &sc
           const short v = un.dummy ? (short)0 : q[(size_t)k * cc.kstride + un.blk];
           row[k] = v;
           const int av = v < 0 ? -(int)v : (int)v;
-          if (av >> al) ke = k;
+          if (av >> al) kev = k;
         }
-        if (ah) { for (int k = 1; k <= ke; k++) { const int v = row[k], av = v < 0 ? -v : v; if (av >> ah) kex = k; } }
+        if (ah) { for (int k = 1; k <= kev; k++) { const int v = row[k], av = v < 0 ? -v : v; if (av >> ah) kexv = k; } }
       }
-      s_ke[lane] = (unsigned char)ke; s_ke[64 + lane] = (unsigned char)kex;
+      infov = un.comp_in_scan | (un.mcu_start ? 16 : 0);
     }
     __syncthreads();
-    if (lane == 0) {
+    if (coder) {
       const int nb = (int)(u1 - base < 64 ? u1 - base : 64);
       for (int b = 0; b < nb; b++) {
-        const long long u = base + b;
-        const AriUnit un = ari_unit(C, sc, bpm, u, u1);
-        const int ci = un.comp_in_scan;
-        if (sc.ri && (u % bpm) == 0) {          // first block of an MCU: restart bookkeeping (jcarith.c:371-379 and twins)
+        M.coef = s_blk[b * 64 + lane];            // lane k: coefficient k of block b
+        const int info = rl(infov, b), ke = rl(kev, b), kex = rl(kexv, b);
+        const int ci = info & 15;
+        if (sc.ri && (info & 16)) {               // first block of an MCU: restart bookkeeping (jcarith.c:371-379 and twins)
           if (ch.to_go == 0) {
             A.finish();
             A.byte(0xFF); A.byte(0xD0 + ch.next_rst);
-            ari_reset_stats(M, ch, sc, progressive);
+            ari_reset_stats(M, ch, sc, progressive, lane);
             A.reset();
             ch.to_go = sc.ri;
             ch.next_rst = (ch.next_rst + 1) & 7;
           }
           ch.to_go--;
         }
-        const short *blk = s_blk + b * 64;
-        uint8_t *dcs = M.dc[sc.td[ci] & 1], *acs = M.ac[sc.ta[ci] & 1];
+        // (component ci of the scan: its tables, its DC prediction)
+        const int td = pick4(sc.td, ci), ta = pick4(sc.ta, ci);
+        int last = pick4(ch.last_dc, ci), ctx = pick4(ch.ctx, ci);
+        const int dc = ari_coef(M, 0);
         if (whole_blocks) {
-          ari_dc(A, tab, dcs, ch.last_dc[ci], ch.ctx[ci], blk[0]);
-          ari_ac_first(A, tab, acs, M.fixed, blk, 1, 63, 0, s_ke[b]);
-        } else if (sc.Ss == 0 && sc.Ah == 0) ari_dc(A, tab, dcs, ch.last_dc[ci], ch.ctx[ci], (int)blk[0] >> Al);
-        else if (sc.Ss == 0) A.encode(tab, M.fixed, ((int)blk[0] >> Al) & 1);             // encode_mcu_DC_refine :560-590
-        else if (sc.Ah == 0) ari_ac_first(A, tab, acs, M.fixed, blk, sc.Ss, sc.Se, Al, s_ke[b]);
-        else ari_ac_refine(A, tab, acs, M.fixed, blk, sc.Ss, sc.Se, sc.Ah, Al, s_ke[b], s_ke[64 + b]);
+          ari_dc(A, M, td & 1, last, ctx, dc);
+          ari_ac_first(A, M, ta & 1, 1, 63, 0, ke);
+        } else if (sc.Ss == 0 && sc.Ah == 0) ari_dc(A, M, td & 1, last, ctx, dc >> Al);
+        else if (sc.Ss == 0) A.encode(M, ARI_FIXED, (dc >> Al) & 1);                    // encode_mcu_DC_refine :560-590
+        else if (sc.Ah == 0) ari_ac_first(A, M, ta & 1, sc.Ss, sc.Se, Al, ke);
+        else ari_ac_refine(A, M, ta & 1, sc.Ss, sc.Se, sc.Ah, Al, ke, kex);
+        if (ci == 0) { ch.last_dc[0] = last; ch.ctx[0] = ctx; } else if (ci == 1) { ch.last_dc[1] = last; ch.ctx[1] = ctx; }
+        else if (ci == 2) { ch.last_dc[2] = last; ch.ctx[2] = ctx; } else { ch.last_dc[3] = last; ch.ctx[3] = ctx; }
       }
     }
     __syncthreads();
   }
 }
 
-__device__ __forceinline__ void ari_load_tab(unsigned *tab, int lane)
-{
-  for (int i = lane; i < 114; i += 64) tab[i] = ((unsigned)mjh_ari_qe[i] << 16) | ((unsigned)mjh_ari_nmps[i] << 8) | (unsigned)mjh_ari_nlps[i];
-}
-
-__device__ __forceinline__ long long ari_scan_units(const MjhConst &C, const MjhProgScan &sc, int &bpm)
+__device__ __forceinline__ long long ari_scan_units(const MjhConst &C, const AriScan &sc, int &bpm)
 {
   if (sc.ncomp == 1) { bpm = 1; return C.c[sc.comp[0]].nblk; }
   bpm = 0;
-  for (int i = 0; i < sc.ncomp; i++) bpm += C.c[sc.comp[i]].h * C.c[sc.comp[i]].v;
+#pragma unroll
+  for (int i = 0; i < 4; i++) if (i < sc.ncomp) bpm += sc.h[i] * sc.v[i];
   return (long long)C.mcus_per_row * C.mcu_rows * bpm;
 }
 
 // scan header: [DQT + SOF9/SOF10 for scan 0] DAC [DRI] SOS (write_scan_header jcmarker.c:744-784, emit_dac :404-448); o may be null (length only)
-__device__ __forceinline__ unsigned ari_scan_header(const MjhProgScan &sc, int Al, const uint8_t *frame_hdr, int frame_hdr_len, uint8_t *o)
+__device__ __forceinline__ unsigned ari_scan_header(const AriScan &sc, int Al, const uint8_t *frame_hdr, int frame_hdr_len, uint8_t *o)
 {
   unsigned n = 0;
   if (sc.frame_header) {
     if (o) for (int i = 0; i < frame_hdr_len; i++) o[i] = frame_hdr[i];
     n = (unsigned)frame_hdr_len;
   }
-  int dc_use[2] = { 0, 0 }, ac_use[2] = { 0, 0 };
-  for (int i = 0; i < sc.ncomp; i++) {
-    if (sc.Ss == 0 && sc.Ah == 0) dc_use[sc.td[i] & 1] = 1;
-    if (sc.Se) ac_use[sc.ta[i] & 1] = 1;
+  auto put = [&](int b) { if (o) o[n] = (uint8_t)b; n++; };
+  int dc_use0 = 0, dc_use1 = 0, ac_use0 = 0, ac_use1 = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (i >= sc.ncomp) continue;
+    if (sc.Ss == 0 && sc.Ah == 0) { if (sc.td[i] & 1) dc_use1 = 1; else dc_use0 = 1; }
+    if (sc.Se) { if (sc.ta[i] & 1) ac_use1 = 1; else ac_use0 = 1; }
   }
-  const int ntab = dc_use[0] + dc_use[1] + ac_use[0] + ac_use[1];
-  uint8_t tmp[40];
-  int k = 0;
+  const int ntab = dc_use0 + dc_use1 + ac_use0 + ac_use1;
   if (ntab) {
-    tmp[k++] = 0xFF; tmp[k++] = 0xCC; tmp[k++] = 0; tmp[k++] = (uint8_t)(ntab * 2 + 2);
-    for (int t = 0; t < 2; t++) {
-      if (dc_use[t]) { tmp[k++] = (uint8_t)t; tmp[k++] = (uint8_t)(ARI_DC_L + (ARI_DC_U << 4)); }
-      if (ac_use[t]) { tmp[k++] = (uint8_t)(t + 0x10); tmp[k++] = (uint8_t)ARI_AC_K; }
-    }
+    put(0xFF); put(0xCC); put(0); put(ntab * 2 + 2);
+    if (dc_use0) { put(0); put(ARI_DC_L + (ARI_DC_U << 4)); }
+    if (ac_use0) { put(0x10); put(ARI_AC_K); }
+    if (dc_use1) { put(1); put(ARI_DC_L + (ARI_DC_U << 4)); }
+    if (ac_use1) { put(0x11); put(ARI_AC_K); }
   }
-  if (sc.emit_dri) { tmp[k++] = 0xFF; tmp[k++] = 0xDD; tmp[k++] = 0; tmp[k++] = 4; tmp[k++] = (uint8_t)(sc.ri >> 8); tmp[k++] = (uint8_t)sc.ri; }
-  tmp[k++] = 0xFF; tmp[k++] = 0xDA;
+  if (sc.emit_dri) { put(0xFF); put(0xDD); put(0); put(4); put(sc.ri >> 8); put(sc.ri & 0xFF); }
+  put(0xFF); put(0xDA);
   const int len = 2 * sc.ncomp + 2 + 1 + 3;
-  tmp[k++] = (uint8_t)(len >> 8); tmp[k++] = (uint8_t)len;
-  tmp[k++] = (uint8_t)sc.ncomp;
-  for (int i = 0; i < sc.ncomp; i++) { tmp[k++] = (uint8_t)sc.comp_id[i]; tmp[k++] = (uint8_t)((sc.td[i] << 4) + sc.ta[i]); }
-  tmp[k++] = (uint8_t)sc.Ss; tmp[k++] = (uint8_t)sc.Se; tmp[k++] = (uint8_t)((sc.Ah << 4) + Al);
-  if (o) for (int i = 0; i < k; i++) o[n + i] = tmp[i];
-  return n + (unsigned)k;
+  put(len >> 8); put(len & 0xFF);
+  put(sc.ncomp);
+#pragma unroll
+  for (int i = 0; i < 4; i++) if (i < sc.ncomp) { put(sc.comp_id[i]); put((sc.td[i] << 4) + sc.ta[i]); }
+  put(sc.Ss); put(sc.Se); put((sc.Ah << 4) + Al);
+  return n;
 }
 
-__device__ __forceinline__ bool ari_skip(const MjhProgScan &sc, const MjhProgCtl *ct) { return sc.cond > 0 && ct->al_continue < sc.cond; }
 
 // One scan of one image.  WRITE = false: its size (header + entropy-coded bytes) goes to ctl.scan_size (what the scan search
 // compares, jcmaster.c:773-962).  WRITE = true: grid.x walks the FINAL order (ctl.order); the scan is written at its place in
@@ -375,48 +450,46 @@ k_arith_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
              unsigned *__restrict__ sizes, int whole_blocks, int single_pass)
 {
   __shared__ short s_blk[64 * 64];
-  __shared__ unsigned char s_ke[128];
-  __shared__ unsigned tab[114];
-  __shared__ AriModel M;
   const int img = blockIdx.y, lane = threadIdx.x;
   MjhProgCtl *ct = ctl + img;
   int sidx;
   if (WRITE && !single_pass) {
-    if ((int)blockIdx.x >= ct->norder) return;
+    if ((int)blockIdx.x >= ARI_U(ct->norder)) return;
     sidx = ct->order[blockIdx.x];
   } else sidx = scan_list[blockIdx.x];
-  const MjhProgScan sc = scans[sidx];
-  if (!WRITE && ari_skip(sc, ct)) { if (lane == 0) ct->scan_size[sidx] = 0; return; }
-  if (WRITE && ct->error) { if (lane == 0 && (single_pass || blockIdx.x == 0)) sizes[img] = 0; return; }
-  const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
-  ari_load_tab(tab, lane);
+  sidx = ARI_U(sidx);
+  const MjhProgScan *sp = scans + sidx;
+  const int cond = ARI_U(sp->cond), al_sel = ARI_U(sp->al_sel);
+  if (!WRITE && cond > 0 && ARI_U(ct->al_continue) < cond) { if (lane == 0) ct->scan_size[sidx] = 0; return; }   // the search stopped below this level
+  if (WRITE && ARI_U(ct->error)) { if (lane == 0 && (single_pass || blockIdx.x == 0)) sizes[img] = 0; return; }
+  const int Al = ARI_U(al_sel == 1 ? ct->best_Al_luma : (al_sel == 2 ? ct->best_Al_chroma : sp->Al));
+  const AriScan sc = ari_load_scan(C, sp);
   int bpm;
   const long long nunits = ari_scan_units(C, sc, bpm);
   uint8_t *o = nullptr;
   unsigned hdr = 0, cap = 0;
   if (WRITE) {
-    const size_t off = single_pass ? (size_t)file_hdr_len : (size_t)ct->scan_out_off[sidx];
+    const size_t off = single_pass ? (size_t)file_hdr_len : (size_t)(unsigned)ARI_U(ct->scan_out_off[sidx]);
     o = out + (size_t)img * out_stride + off;
     cap = (unsigned)(out_stride - off > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : out_stride - off);
     if (single_pass) for (int i = lane; i < file_hdr_len; i += 64) out[(size_t)img * out_stride + i] = file_hdr[i];
   }
   AriCoder A;
   AriChain ch;
-  A.out = nullptr; A.pos = 0; A.cap = 0;
+  AriModel M;
+  ari_init_model(M, lane);
+  hdr = ari_scan_header(sc, Al, frame_hdr, frame_hdr_len, WRITE && lane == 0 ? o : nullptr);   // (every lane: the length is wave-uniform)
+  A.lane0 = lane == 0;
+  A.pos = 0;
+  A.out = WRITE ? o + hdr : nullptr;
+  A.cap = WRITE ? (cap > hdr + 4 ? cap - hdr - 4 : 0) : 0;
+  A.reset();
+  for (int i = 0; i < MJH_MAXC; i++) { ch.last_dc[i] = 0; ch.ctx[i] = 0; }
+  ari_reset_stats(M, ch, sc, !whole_blocks, lane);
+  ch.to_go = sc.ri; ch.next_rst = 0;
+  ari_run(C, sc, Al, whole_blocks != 0, !whole_blocks, coef_q + (size_t)img * C.coefs_per_image, 0, nunits, bpm, A, M, ch, s_blk, lane, true);
+  A.finish();
   if (lane == 0) {
-    hdr = ari_scan_header(sc, Al, frame_hdr, frame_hdr_len, WRITE ? o : nullptr);
-    A.out = WRITE ? o + hdr : nullptr;
-    A.cap = WRITE ? (cap > hdr + 4 ? cap - hdr - 4 : 0) : 0;
-    A.reset();
-    M.fixed[0] = 113;
-    for (int i = 0; i < MJH_MAXC; i++) { ch.last_dc[i] = 0; ch.ctx[i] = 0; }
-    ari_reset_stats(M, ch, sc, !whole_blocks);
-    ch.to_go = sc.ri; ch.next_rst = 0;
-  }
-  __syncthreads();
-  ari_run(C, sc, Al, whole_blocks != 0, !whole_blocks, coef_q + (size_t)img * C.coefs_per_image, 0, nunits, bpm, A, M, ch, tab, s_blk, s_ke, lane);
-  if (lane == 0) {
-    A.finish();
     const unsigned total = hdr + A.pos;
     if (!WRITE) ct->scan_size[sidx] = total;
     else {
@@ -500,14 +573,13 @@ k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
                 int Ss, int Se, int quant_dc, float delta_dc_weight, int restart_blocks, int prog_file)
 {
   __shared__ short s_blk[64 * 64];
-  __shared__ unsigned char s_ke[128];
-  __shared__ unsigned tab[114];
-  __shared__ AriModel M;
+  __shared__ unsigned char s_state[64 + 256];     // the coder's statistics bins, dumped by the coding wave once per iMCU row
   __shared__ float rdc[64][2], rac[256][2];
   __shared__ float dc_cost[2][9];
   __shared__ int dc_ctx[2][9], dc_cand[2][9];
   __shared__ int s_lastdc;
-  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // (uniform for the compiler too: the coding wave's branch is a scalar one)
   const MjhComp cc = C.c[0];
   const int qt = cc.qtbl;
   const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off;
@@ -517,25 +589,30 @@ k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
   const int q0 = Q->q[qt][0];
   int ncand = (2 + 60 / q0) | 1;
   if (ncand > 9) ncand = 9;
-  if (tid < 64) ari_load_tab(tab, tid);
   AriCoder A;
   AriChain ch;
-  MjhProgScan sc;      // the single-component scan of the pass: whole blocks of component 0
-  sc.ncomp = 1; sc.comp[0] = 0; sc.td[0] = cc.dctbl; sc.ta[0] = cc.actbl; sc.Ss = Ss; sc.Se = Se; sc.Ah = 0; sc.Al = 0; sc.ri = restart_blocks;
-  A.out = nullptr; A.pos = 0; A.cap = 0;
-  if (tid == 0) {
-    A.reset();
-    M.fixed[0] = 113;
-    for (int i = 0; i < MJH_MAXC; i++) { ch.last_dc[i] = 0; ch.ctx[i] = 0; }
-    ari_reset_stats(M, ch, sc, false);
-    ch.to_go = restart_blocks; ch.next_rst = 0;
-  }
-  __syncthreads();
+  AriModel M;
+  AriScan sc;          // the single-component scan of the pass: whole blocks of component 0
+  sc.ncomp = 1; sc.Ss = Ss; sc.Se = Se; sc.Ah = 0; sc.ri = restart_blocks; sc.frame_header = 0; sc.emit_dri = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { sc.comp[i] = 0; sc.td[i] = ARI_U(cc.dctbl); sc.ta[i] = ARI_U(cc.actbl); sc.comp_id[i] = 0; sc.h[i] = 1; sc.v[i] = 1; }
+  ari_init_model(M, lane);
+  A.lane0 = false; A.out = nullptr; A.pos = 0; A.cap = 0;     // nothing is written: only the statistics move
+  A.reset();
+  for (int i = 0; i < MJH_MAXC; i++) { ch.last_dc[i] = 0; ch.ctx[i] = 0; }
+  ari_reset_stats(M, ch, sc, false, lane);
+  ch.to_go = restart_blocks; ch.next_rst = 0;
   for (int br0 = 0; br0 < cc.hib; br0 += cc.v) {
     const int rows = br0 + cc.v <= cc.hib ? cc.v : cc.hib - br0;
-    // ---- rates of this iMCU row (jget_arith_rates)
+    // ---- rates of this iMCU row (jget_arith_rates): the coding wave's bins -> LDS -> 320 table look-ups
+    if (wave == 0) {
+      const int acw = (cc.actbl & 1) ? M.ac[1] : M.ac[0];
+      for (int j = 0; j < 4; j++) s_state[64 + 4 * lane + j] = (unsigned char)((unsigned)acw >> (8 * j));
+      if ((lane >> 4) == (cc.dctbl & 1)) for (int j = 0; j < 4; j++) s_state[4 * (lane & 15) + j] = (unsigned char)((unsigned)M.dc >> (8 * j));
+    }
+    __syncthreads();
     for (int i = tid; i < 64 + 256; i += 256) {
-      const int state = i < 64 ? M.dc[cc.dctbl & 1][i] : M.ac[cc.actbl & 1][i - 64];
+      const int state = s_state[i];
       float *o = i < 64 ? rdc[i] : rac[i - 64];
       o[0] = rate_tab->r[state][0];
       o[1] = rate_tab->r[state][1];
@@ -688,8 +765,8 @@ k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     __syncthreads();
     // ---- the row group goes through the coder: its statistics move on (compress_output -> encode_mcu, output discarded)
     // (wave 0 loads, thread 0 codes, every wave takes part in the barriers; emit_restart consults the FILE's mode, jcarith.c:328-341)
-    ari_run(C, sc, 0, true, prog_file != 0, coef_q + (size_t)img * C.coefs_per_image, (long long)br0 * cc.wib, (long long)(br0 + rows) * cc.wib, 1, A, M, ch, tab,
-            s_blk, s_ke, tid, tid < 64);
+    ari_run(C, sc, 0, true, prog_file != 0, coef_q + (size_t)img * C.coefs_per_image, (long long)br0 * cc.wib, (long long)(br0 + rows) * cc.wib, 1, A, M, ch,
+            s_blk, lane, wave == 0);
     __syncthreads();
   }
 }
