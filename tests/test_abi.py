@@ -187,7 +187,8 @@ def test_committed_bench_lines_of_the_other_configurations_name_their_own_domina
     import glob
     import json
     newest = {}
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03*bench*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r03*configs.jsonl"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]*bench*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]*configs.jsonl")),
+                       key=os.path.basename):
         for ln in open(path).read().strip().splitlines():
             try:
                 j = json.loads(ln)
@@ -205,3 +206,29 @@ def test_committed_bench_lines_of_the_other_configurations_name_their_own_domina
         src = r.get("traffic_source") or ""
         if r["traffic"] is not None and key != "metric":
             assert "_%s_" % key in src, (path, src)
+
+
+def test_traffic_figures_are_quoted_only_for_the_kernels_they_were_measured_on(monkeypatch):
+    """roofline.traffic comes from committed PMC passes, so it must not outlive the kernels it was
+    taken on.  tools/pmc_traffic.py stamps every summary with a hash of the kernel sources (and the git head); bench.py
+    quotes a summary only while the tree still hashes to its stamp, and says 'stale' otherwise."""
+    import glob
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    stamp = bench.kernel_source_stamp()
+    traffic, src = bench.dominant_traffic("metric", "trellis_ac", 64)
+    if traffic is not None:
+        path = os.path.join(ROOT, src.split(" ")[0])
+        assert json.load(open(path))["kernel_source_stamp"] == stamp and "git" in src
+    else:
+        assert src.startswith("stale") or src.startswith("no PMC passes")
+    monkeypatch.setattr(bench, "kernel_source_stamp", lambda: "0" * 16)           # any other tree
+    traffic, src = bench.dominant_traffic("metric", "trellis_ac", 64)
+    assert traffic is None and (src.startswith("stale") or src.startswith("no PMC passes"))
+    # the summaries of this round carry the stamp
+    new = [p for p in glob.glob(os.path.join(ROOT, "profiles", "r0[4-9]*pmc_hbm_traffic*.json"))]
+    for p in new:
+        j = json.load(open(p))
+        assert len(j.get("kernel_source_stamp", "")) == 16 and j.get("profile_head"), p
