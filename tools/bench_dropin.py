@@ -55,6 +55,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", default="1,4,16")
     ap.add_argument("--images", type=int, default=10)
+    ap.add_argument("--seconds", type=float, default=3.0, help="target duration of one measured point")
     ap.add_argument("--ref-images", type=int, default=1)
     ap.add_argument("--tmp", default="/tmp")
     a = ap.parse_args()
@@ -65,7 +66,10 @@ if __name__ == "__main__":
         same = set()
         for mode in ("preload", "standalone"):
             for t in ths:
-                d = mt(mode, t, a.images * (4 if t == 1 else 2), w, h, 75)   # (images PER THREAD; a fraction of a second in all)
+                # images PER THREAD, sized for about three seconds per point (0.07-s samples are too short to quote):
+                # ~550 (4K) / ~1100 (1080p) images/s from one thread, ~2x from 4, ~3x from 16 in round 3
+                per_thread = int(a.seconds * (550 if w > 2000 else 1100) * {1: 1.0, 4: 0.5}.get(t, 3.0 / max(t, 1)))
+                d = mt(mode, t, max(a.images, per_thread), w, h, 75)
                 res["library_client"].append(d); same.add(d.get("fnv1a_first"))
                 print(json.dumps(d), file=sys.stderr, flush=True)
         d = mt("reference", max(ths), a.ref_images, w, h, 75)     # CPU: one image per thread on every requested thread

@@ -18,13 +18,13 @@ timeout 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS S
 # lane activity (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU = active lanes per VALU instruction), LDS conflicts, memory instructions
 timeout 200 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --kernel-trace -d "$O" -o sq2 -- python bench.py --steps 2 --warmup 1 $Q --batch "$BATCH" > "$O/sq2.log" 2>&1
 # configuration 3 (progressive + scan search): bench line, kernel trace, traffic
-timeout 300 python bench.py --config c3 --no-cpu-baseline --no-host-leg > "$O/bench_c3.log" 2>&1; tail -1 "$O/bench_c3.log" | cut -c1-300
+timeout 300 python bench.py --config c3 --cpu-budget 10 --no-host-leg > "$O/bench_c3.log" 2>&1; tail -1 "$O/bench_c3.log" | cut -c1-300
 timeout 200 rocprofv3 --kernel-trace --stats -d "$O" -o c3_stats -- python bench.py --config c3 --steps 10 --warmup 3 $Q > "$O/c3_stats.log" 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$O" -o c3_fetch -- python bench.py --config c3 --steps 2 --warmup 1 $Q > "$O/c3_fetch.log" 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$O" -o c3_write -- python bench.py --config c3 --steps 2 --warmup 1 $Q > "$O/c3_write.log" 2>&1
 if [ "$3" = "all" ]; then
   for c in c2 c4 c5 c5t; do
-    timeout 400 python bench.py --config $c --no-cpu-baseline --no-host-leg > "$O/bench_$c.log" 2>&1; tail -1 "$O/bench_$c.log" | cut -c1-300
+    timeout 400 python bench.py --config $c --cpu-budget 10 --no-host-leg > "$O/bench_$c.log" 2>&1; tail -1 "$O/bench_$c.log" | cut -c1-300
   done
   # traffic passes of the other configurations (bench.py's roofline.traffic is looked up per configuration)
   for c in c2 c4 c5 c5t; do
