@@ -220,6 +220,17 @@ static int batched_encode(shim_state *s, const unsigned char **file, size_t *n, 
       }
       if (rc == MJH_OK) { b->readers[ar] += k; b->arena_next ^= 1; }
       if (rc == BATCH_PRIVATE) b->contended = -1;        /* no batch encoder: everybody keeps to the private path from now on */
+      else if (rc != MJH_OK && b->enc) {
+        /* a failed batch may have flipped the encoder's result arenas without this bookkeeping knowing (mjh_encode_gather counts
+         * the call before the steps that can still fail): start over with a fresh batch encoder, once nobody reads the old
+         * one's arenas any more */
+        mjh_encoder *old = b->enc;
+        while (b->readers[0] > 0 || b->readers[1] > 0) pthread_cond_wait(&b->cv, &b->m);
+        b->enc = NULL; b->arena_next = 0;
+        pthread_mutex_unlock(&b->m);
+        mjh_encoder_destroy(old);
+        pthread_mutex_lock(&b->m);
+      }
       b->busy = 0;
       pthread_cond_broadcast(&b->cv);
       continue;

@@ -1655,17 +1655,16 @@ __device__ __forceinline__ void pp_emit_rounds(unsigned *dst, unsigned bit0, uns
     const int j = i * 256 + tid;
     const bool has_own = j < nb && ((rn_bits[j >> 6] >> (j & 63)) & 1ull);
     const bool is_fp = j < nb && ((fp_bits[j >> 6] >> (j & 63)) & 1ull);
-    if (__builtin_amdgcn_ballot_w64(has_own || is_fp) == 0ull) {   // a wave of empty blocks (most waves of a sparse band): only the scan
-      unsigned tot0;
-      (void)block_excl_scan_256_1b(0u, sh, i & 1, &tot0);
-      running += tot0;
-      continue;
-    }
+    // a wave of empty blocks (most waves of a sparse band) skips the sizing and takes part in the scan with zeros: EVERY wave
+    // reaches the workgroup scan's barrier at the same call site
+    const bool wave_empty = __builtin_amdgcn_ballot_w64(has_own || is_fp) == 0ull;
     const int jj = j < nb ? j : nb - 1;
-    const unsigned long long m = has_own ? nzc[jj] : 0ull;
-    // the block's size: its own symbols ...
-    unsigned own = 0;
-    {
+    unsigned long long m = 0ull;
+    unsigned own = 0, cnt = 0, fsym = 0;
+    int nextra = 0;
+    if (!wave_empty) {
+      m = has_own ? nzc[jj] : 0ull;
+      // the block's size: its own symbols ...
       int prev = Ss - 1;
       pp_band_nonzeros(qc + jj, kstride, m, Ss, Se, has_own, [&](int k, int v) {
         const int a = (v < 0 ? -v : v) >> Al;
@@ -1675,18 +1674,16 @@ __device__ __forceinline__ void pp_emit_rounds(unsigned *dst, unsigned bit0, uns
         const int nbits = bitlen((unsigned)a);
         own += (unsigned)(r >> 4) * (zrl >> 16) + (s_tab[((r & 15) << 4) + nbits] >> 16) + (unsigned)nbits;
       });
-    }
-    // ... and the pending run that goes out in front of a flush point (emit_eobrun jcphuff.c:409)
-    unsigned cnt = 0, fsym = 0;
-    int nextra = 0;
-    if (is_fp) {
-      cnt = run[j];
-      if (cnt) fsym = s_tab[eobrun_symbol(cnt, &nextra)];
+      // ... and the pending run that goes out in front of a flush point (emit_eobrun jcphuff.c:409)
+      if (is_fp) {
+        cnt = run[j];
+        if (cnt) fsym = s_tab[eobrun_symbol(cnt, &nextra)];
+      }
     }
     const unsigned blen = own + (cnt ? (fsym >> 16) + (unsigned)nextra : 0u);
     unsigned tot;
     const unsigned ex = block_excl_scan_256_1b(blen, sh, i & 1, &tot);
-    if (__builtin_amdgcn_ballot_w64(blen != 0u) == 0ull) { running += tot; continue; }
+    if (wave_empty || __builtin_amdgcn_ballot_w64(blen != 0u) == 0ull) { running += tot; continue; }
     // the same walk again (the records are in the L1 now), this time with the place of every bit known
     BitSink<LDSW> bw;
     bw.init(dst, running + ex - bit0);

@@ -152,6 +152,9 @@ CASES12 = [
     ("p12_fastcrush", dict(precision=12, notrellis=True, fastcrush=True), True),
     ("p12_revert_q90", dict(precision=12, revert=True, quality=90), True),
     ("p12_base_gray", dict(precision=12, baseline=True, notrellis=True, gray=True), True),
+    # 12-bit samples through the arithmetic coder (magnitude categories up to 15 bits)
+    ("p12_arith_base_q90_444", dict(precision=12, arithmetic=True, baseline=True, notrellis=True, quality=90, sample=(1, 1)), True),
+    ("p12_arith_progressive", dict(precision=12, arithmetic=True, notrellis=True), True),
 ]
 
 # constants the REFERENCE itself pins for this path (CMakeLists.txt:1347-1420), cjpeg -revert ... testorig.ppm
