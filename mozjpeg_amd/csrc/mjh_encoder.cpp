@@ -366,6 +366,8 @@ struct mjh_encoder {
   hipEvent_t ev_view_done = nullptr, ev_split_fork = nullptr, ev_null_in = nullptr;
   // arithmetic coding (mjh_arith.hip): the scans to code (the script, or one synthetic whole-block scan for a sequential file),
   // phase lists in d_lists (pl_phase[].scan_off / nscan), the rate table of quantize_trellis_arith
+  // DC trellis of one or two frames: block rows walked speculatively (k_trellis_dc3_fwd / _resolve): scratch, and MJH_DC_SPEC=0 turns it off
+  uint8_t *d_back9 = nullptr; int *d_jfin = nullptr; int16_t *d_qspec = nullptr; int dc_spec = 1;
   bool arith = false;
   int arith_nscans = 0;
   void *d_arith_rates = nullptr;
@@ -695,7 +697,7 @@ static void free_all(mjh_encoder *e)
   if (e->ev_null_in) (void)hipEventDestroy(e->ev_null_in);
   void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->pe.chist, e->pe.rmask, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_nq8, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
-                   e->d_meta, e->d_prefix, e->d_sos, e->d_arith_rates, e->g_in[0], e->g_in[1], e->g_in[2], e->g_in[3] };
+                   e->d_meta, e->d_prefix, e->d_sos, e->d_arith_rates, e->d_back9, e->d_jfin, e->d_qspec, e->g_in[0], e->g_in[1], e->g_in[2], e->g_in[3] };
   for (void *q : ptrs) if (q) (void)mjh_guard_free(q);
   for (void *q : e->g_in_old) (void)mjh_guard_free(q);
   if (e->h_defer) (void)hipHostFree(e->h_defer);
@@ -905,6 +907,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   e->dc_window_ok |= (getenv("MJH_DC_V2") ? atoi(getenv("MJH_DC_V2")) : 1) << 8;   // bits 8..: which DC trellis kernel (A/B runs)
   if (const char *v = getenv("MJH_DC_MODE")) e->dc_mode = atoi(v);
   if (const char *v = getenv("MJH_DC_STATS_SIDE")) e->dc_stats_side = atoi(v);
+  if (const char *v = getenv("MJH_DC_SPEC")) e->dc_spec = atoi(v);
   HIPCHK_E(mjh_dmalloc((void **)&e->d_len16, B * (size_t)C.total_mcu_blocks * 2));
   HIPCHK_E(mjh_dmalloc((void **)&e->d_off32, B * (size_t)C.total_mcu_blocks * 4));
   e->chunks = (C.total_mcu_blocks + 2047) / 2048;
@@ -1487,6 +1490,20 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
         while (e->side_events.size() < 2 * (size_t)(e->prof_calls + 1)) { hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); e->side_events.push_back(ev); }
         HIPCHK(hipEventRecord(e->side_events[2 * e->prof_calls], e->side_stream));
       }
+      // one or two frames: the DC trellis is the critical path of the whole encode then (a luma chain = the block rows of an iMCU
+      // row one after the other): every block row is walked for every value the row above can end on, in parallel, and a second
+      // kernel back-tracks the walks whose hypothesis held (mjh_kernels.hip, K6 speculative)
+      const size_t spec_bytes = 2 * (size_t)C.total_real_blocks * 9 * 16;
+      const bool spec = e->dc_spec && n <= 2 && qstride == 0 && !e->is_view && spec_bytes <= ((size_t)256 << 20) && mjh_trellis_dc_speculative_ok(CV, e->dc_window_ok);
+      if (spec && !e->d_back9) {
+        int rows = 0;
+        for (int c = 0; c < C.ncomp; c++) rows += C.c[c].hib;
+        HIPCHK(mjh_dmalloc((void **)&e->d_back9, spec_bytes));
+        HIPCHK(mjh_dmalloc((void **)&e->d_jfin, 2 * (size_t)rows * 9 * sizeof(int)));
+        HIPCHK(mjh_dmalloc((void **)&e->d_qspec, 2 * (size_t)C.total_real_blocks * 9 * sizeof(int16_t)));
+      }
+      if (spec) mjh_launch_trellis_dc_speculative(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back9, e->d_jfin, e->d_qspec, n, e->side_stream);
+      else
       mjh_launch_trellis_dc(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, e->side_stream, e->dc_window_ok);   // (the DC entries never change: image 0's tables serve all)
       if (pr.enabled && e->profiling == 1) { HIPCHK(hipEventRecord(e->side_events[2 * e->prof_calls + 1], e->side_stream)); e->side_timed = true; }
       if (!e->progressive && p.optimize_coding && last_loop && nbands == 1 && qstride == 0 && !ext_eob && e->dc_stats_side) {

@@ -2660,6 +2660,193 @@ k_trellis_dc3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K6 for one or two frames: block rows walked SPECULATIVELY (round 4).  With a single 4K frame on the chip the DC trellis is
+// the critical path of the whole encode (402 of 690 us): a luma chain is the 2 block rows of an iMCU row walked one after the
+// other, because the first block of the second row is rated against the FINAL last value of the first row (lastDC,
+// jccoefct.c:418-441).  That value is one of the <= 9 candidates of the first row's last block, which depend on its raw DC
+// only -- so the second (third, fourth) row is walked once per candidate, in parallel with the first, on a chip that has
+// nothing else to do; k_trellis_dc3_resolve then back-tracks row after row, taking for every row the walk whose hypothesis came
+// true.  Same float sums in the same order as k_trellis_dc3: same files.  Scratch: 16 back-pointer bytes per (block, hypothesis).
+// ---------------------------------------------------------------------------------------------
+#define DC3_HYP 9
+__global__ void __launch_bounds__(64)
+k_trellis_dc3_fwd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
+                  const MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 dc_slot_of_comp,
+                  const float *__restrict__ lambda_in, uint8_t *__restrict__ back9, int *__restrict__ jfin, int16_t *__restrict__ qspec, int rows_total)
+{
+  const int img = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int k = lane & 15;
+  const int chain = blockIdx.x * 4 + (lane >> 4);          // (global block row of the image, hypothesis)
+  if (chain >= rows_total * DC3_HYP) return;
+  const int grow = chain / DC3_HYP, hyp = chain - grow * DC3_HYP;
+  int comp = 0, br = grow;
+  while (comp + 1 < C.ncomp && br >= C.c[comp].hib) { br -= C.c[comp].hib; comp++; }
+  const MjhComp cc = C.c[comp];
+  const int sub = br % cc.v;
+  const int slot = comp == 0 ? dc_slot_of_comp.x : comp == 1 ? dc_slot_of_comp.y : comp == 2 ? dc_slot_of_comp.z : dc_slot_of_comp.w;
+  const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+  const int q0 = Q->q[cc.qtbl][0];
+  const int dq = 8 * q0;
+  const float rcp = Q->rcp8q[cc.qtbl][0];
+  const float lt0 = Q->lambda_tbl[cc.qtbl][0];
+  int ncand = (2 + 60 / q0) | 1;
+  if (ncand > 9) ncand = 9;
+  const int h = ncand / 2;
+  if (hyp >= ncand || (sub == 0 && hyp > 0)) return;        // whole 16-lane groups leave together
+  unsigned long long rsi = 0;
+  for (int s = 0; s < 12; s++) rsi |= (unsigned long long)((T->ehufsi[s] + s) & 31) << (5 * s);
+  const bool vlane = k < ncand;
+  const int16_t *uq0 = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off;
+  const float *lam = lambda_in + (size_t)img * C.total_real_blocks + cc.blk_off;
+  const int row0 = br * cc.wib;
+  uint8_t *bk = back9 + (((size_t)img * C.total_real_blocks + cc.blk_off + row0) * DC3_HYP) * 16;   // + (bi * 9 + hyp) * 16 + kk
+  int last_dc = 0;
+  if (sub > 0) {     // the hypothesis: the row above ended on candidate `hyp` of its last block
+    const int xs = uq0[row0 - 1];
+    const int x = xs < 0 ? -xs : xs;
+    int cnd = udiv_exact(x + (dq >> 1), dq, rcp) - h + hyp;
+    cnd = min(1023, max(-1023, cnd));
+    last_dc = xs < 0 ? -cnd : cnd;
+  }
+  int prev_c0 = 0, prev_neg = 0;
+  float prev_cost = 0.0f;
+  auto fetch = [&](int b, unsigned &pk_o, float &lam_o) {
+    const int xs = b < cc.wib ? (int)uq0[row0 + b] : 0;
+    const float l = b < cc.wib ? lam[row0 + b] : 0.0f;
+    const int x = xs < 0 ? -xs : xs;
+    const int qv = udiv_exact(x + (dq >> 1), dq, rcp);
+    pk_o = (unsigned)x | ((unsigned)qv << 16) | (xs < 0 ? 1u << 26 : 0u);
+    lam_o = l * lt0;
+  };
+  unsigned pk_l;
+  float lam_l;
+  fetch(k, pk_l, lam_l);
+  for (int g = 0; g < cc.wib; g += 16) {
+    unsigned pk_n;
+    float lam_n;
+    fetch(g + 16 + k, pk_n, lam_n);
+    const int steps = min(16, cc.wib - g);
+    unsigned pk_s = (unsigned)grp_shfl((int)pk_l, 0, lane);
+    float lam_s = grp_shfl_f(lam_l, 0, lane);
+    for (int s = 0; s < steps; s++) {
+      const int bi = g + s;
+      const unsigned pk = pk_s;
+      const float lambda_dc = lam_s;
+      pk_s = (unsigned)grp_shfl((int)pk_l, (s + 1) & 15, lane);
+      lam_s = grp_shfl_f(lam_l, (s + 1) & 15, lane);
+      const int x = (int)(pk & 0xFFFFu), qv = (int)((pk >> 16) & 1023u), neg = (int)(pk >> 26);
+      const int kk = neg ? ncand - 1 - k : k;
+      const int c0 = neg ? -(qv + h) : qv - h;
+      const int delta = mul24(qv - h + kk, dq) - x;
+      const float dist = (float)mul24(delta, delta) * lambda_dc;
+      float best;
+      int bb = 0;
+      if (bi == 0) {
+        best = dc_rate(rsi, c0 + k - last_dc) + dist;
+      } else {
+        const int D = c0 - prev_c0;
+        const float Rj = dc_rate(rsi, D + k - 7), R0 = dc_rate(rsi, D - 8);
+        const float c_0 = (dpp_f0<0x107>(Rj) + dist) + row_bcast_f<0>(prev_cost);
+        const float c_1 = (dpp_f0<0x106>(Rj) + dist) + row_bcast_f<1>(prev_cost);
+        const float c_2 = (dpp_f0<0x105>(Rj) + dist) + row_bcast_f<2>(prev_cost);
+        const float c_3 = (dpp_f0<0x104>(Rj) + dist) + row_bcast_f<3>(prev_cost);
+        const float c_4 = (dpp_f0<0x103>(Rj) + dist) + row_bcast_f<4>(prev_cost);
+        const float c_5 = (dpp_f0<0x102>(Rj) + dist) + row_bcast_f<5>(prev_cost);
+        const float c_6 = (dpp_f0<0x101>(Rj) + dist) + row_bcast_f<6>(prev_cost);
+        const float c_7 = (Rj + dist) + row_bcast_f<7>(prev_cost);
+        const float c_8 = (dpp_f<0x111>(R0, Rj) + dist) + row_bcast_f<8>(prev_cost);
+        const float m = fminf(fminf(fminf(c_0, c_1), fminf(c_2, c_3)), fminf(fminf(fminf(c_4, c_5), fminf(c_6, c_7)), c_8));
+        unsigned e = (c_0 == m ? 1u : 0u) | (c_1 == m ? 2u : 0u) | (c_2 == m ? 4u : 0u) | (c_3 == m ? 8u : 0u) | (c_4 == m ? 16u : 0u) |
+                     (c_5 == m ? 32u : 0u) | (c_6 == m ? 64u : 0u) | (c_7 == m ? 128u : 0u) | (c_8 == m ? 256u : 0u);
+        bb = prev_neg ? ncand - 1 - (31 - __clz((int)e)) : __ffs((int)e) - 1;
+        best = m;
+      }
+      prev_cost = vlane ? best : 3e38f;
+      prev_c0 = c0;
+      prev_neg = neg;
+      if (vlane) bk[((size_t)bi * DC3_HYP + hyp) * 16 + kk] = (uint8_t)bb;
+    }
+    pk_l = pk_n; lam_l = lam_n;
+  }
+  {   // first minimum over the candidates of the last block, in candidate order (jcdctmgr.c:1309-1313)
+    const float p0 = row_bcast_f<0>(prev_cost), p1 = row_bcast_f<1>(prev_cost), p2 = row_bcast_f<2>(prev_cost), p3 = row_bcast_f<3>(prev_cost),
+                p4 = row_bcast_f<4>(prev_cost), p5 = row_bcast_f<5>(prev_cost), p6 = row_bcast_f<6>(prev_cost), p7 = row_bcast_f<7>(prev_cost),
+                p8 = row_bcast_f<8>(prev_cost);
+    const float m = fminf(fminf(fminf(p0, p1), fminf(p2, p3)), fminf(fminf(fminf(p4, p5), fminf(p6, p7)), p8));
+    const unsigned e = (p0 == m ? 1u : 0u) | (p1 == m ? 2u : 0u) | (p2 == m ? 4u : 0u) | (p3 == m ? 8u : 0u) | (p4 == m ? 16u : 0u) |
+                       (p5 == m ? 32u : 0u) | (p6 == m ? 64u : 0u) | (p7 == m ? 128u : 0u) | (p8 == m ? 256u : 0u);
+    int j = prev_neg ? ncand - 1 - (31 - __clz((int)e)) : __ffs((int)e) - 1;
+    if (k == 0) jfin[((size_t)img * rows_total + grow) * DC3_HYP + hyp] = j;
+    // ... and this walk's own back-track, 16 blocks per step, into the hypothesis' copy of the row (k_trellis_dc3_resolve keeps
+    // the copy whose hypothesis held)
+    __threadfence_block();
+    int16_t *qs = qspec + ((size_t)img * C.total_real_blocks + cc.blk_off + row0) * DC3_HYP;
+    auto fetch_back = [&](int top, int &xs_o, uint4 &w_o) {
+      const int b = top - k;
+      xs_o = 0; w_o = make_uint4(0, 0, 0, 0);
+      if (top >= 0 && b >= 0) {
+        xs_o = uq0[row0 + b];
+        w_o = *reinterpret_cast<const uint4 *>(bk + ((size_t)b * DC3_HYP + hyp) * 16);
+      }
+    };
+    int bx;
+    uint4 w;
+    fetch_back(cc.wib - 1, bx, w);
+    for (int top = cc.wib - 1; top >= 0; top -= 16) {
+      int bx_n;
+      uint4 w_n;
+      fetch_back(top - 16, bx_n, w_n);
+      const int b = top - k;
+      const int x = bx < 0 ? -bx : bx;
+      const int qv = udiv_exact(x + (dq >> 1), dq, rcp);
+      int myj = 0;
+      const int steps = min(16, top + 1);
+#define DC3_BACK(S)                                                                        \
+      if (S < steps) {                                                                     \
+        if (k == S) myj = j;                                                               \
+        const unsigned word = j < 4 ? w.x : (j < 8 ? w.y : w.z);                           \
+        const int nj = (int)((word >> (8 * (j & 3))) & 0xFF);                              \
+        j = row_bcast<S>(nj);                                                              \
+      }
+      DC3_BACK(0) DC3_BACK(1) DC3_BACK(2) DC3_BACK(3) DC3_BACK(4) DC3_BACK(5) DC3_BACK(6) DC3_BACK(7)
+      DC3_BACK(8) DC3_BACK(9) DC3_BACK(10) DC3_BACK(11) DC3_BACK(12) DC3_BACK(13) DC3_BACK(14) DC3_BACK(15)
+#undef DC3_BACK
+      if (b >= 0) {
+        int cnd = qv - h + myj;
+        cnd = min(1023, max(-1023, cnd));
+        if (bx < 0) cnd = -cnd;
+        qs[(size_t)b * DC3_HYP + hyp] = (int16_t)cnd;
+      }
+      bx = bx_n; w = w_n;
+    }
+  }
+}
+
+// row after row of an iMCU row: keep the copy of the walk whose hypothesis = the candidate the row above ended on (its last
+// block's candidate index is what k_trellis_dc3_fwd left in jfin).  One wave per (component, iMCU row).
+__global__ void __launch_bounds__(64)
+k_trellis_dc3_resolve(MjhConst C, int16_t *__restrict__ coef_q, const int *__restrict__ jfin, const int16_t *__restrict__ qspec, int rows_total)
+{
+  const int img = blockIdx.y, lane = threadIdx.x;
+  const int chain = blockIdx.x;
+  const int comp = chain / C.mcu_rows, imcu = chain - comp * C.mcu_rows;
+  const MjhComp cc = C.c[comp];
+  int grow0 = 0;
+  for (int c = 0; c < comp; c++) grow0 += C.c[c].hib;
+  int16_t *qo0 = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;
+  int hyp = 0;
+  for (int sub = 0; sub < cc.v; sub++) {
+    const int br = imcu * cc.v + sub;
+    if (br >= cc.hib) break;
+    const int row0 = br * cc.wib;
+    const int16_t *qs = qspec + ((size_t)img * C.total_real_blocks + cc.blk_off + row0) * DC3_HYP;
+    for (int b = lane; b < cc.wib; b += 64) qo0[row0 + b] = qs[(size_t)b * DC3_HYP + hyp];
+    hyp = jfin[((size_t)img * rows_total + grow0 + br) * DC3_HYP + hyp];
+  }
+}
+
 // =============================================================================================
 // K7  Huffman bit packing of the interleaved baseline scan (row a12): encode_one_block
 // jchuff.c:563-652, encode_mcu_huff :693-763, flush_bits :479-514 (pad with 1-bits),
@@ -3447,7 +3634,11 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   if (nzmask && nq8 && v3_passes > 0 && variant <= 4) {
     // the tile-sorted kernel: first tier of the plain compact pass; its work list (more than 16 records, or a magnitude >= 16)
     // goes through the general tiers below
-    const int np = (!fastdiv || st || variant > 0) ? 4 : v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
+    // one or two frames (the caller asks for one pass per tile then): occupancy is no concern on an empty chip, and with 24 records
+    // next to nothing is left for the general tiers, whose fixed latency (~80 us) would sit on the critical path
+    const bool small24 = v3_passes == 1 && variant <= 2 && !st && fastdiv;
+    if (small24) variant = 2;
+    const int np = small24 ? 1 : (!fastdiv || st || variant > 0) ? 4 : v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
     int t0[5] = { 0, 0, 0, 0, 0 };
     for (int i = 0; i < 4; i++) t0[i + 1] = t0[i] + (i < C.ncomp ? (C.c[i].nblk + 64 * np - 1) / (64 * np) : 0);
     dim3 gridt(t0[C.ncomp], n);
@@ -3455,7 +3646,8 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     const int4 tv = make_int4(t0[0], t0[1], t0[2], t0[3]);
 #define LV3Q(QN, NP, FDV, FSV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, NP, FDV, FSV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask, st, ss)
 #define LV3(NP, FDV, FSV) LV3Q(16, NP, FDV, FSV)
-    if (variant >= 3 && !st) {   // q90 and up: 32 / 48 records (20 / 30 KB of LDS per wave)
+    if (small24) LV3Q(24, 1, true, false);
+    else if (variant >= 3 && !st) {   // q90 and up: 32 / 48 records (20 / 30 KB of LDS per wave)
       if (variant == 3) { if (fastdiv) LV3Q(32, 4, true, false); else LV3Q(32, 4, false, false); }
       else if (fastdiv) LV3Q(48, 4, true, false); else LV3Q(48, 4, false, false);
     } else if (variant > 0) {   // more records per block (higher qualities): the 24-record instantiation, 4 passes
@@ -3510,6 +3702,21 @@ void mjh_launch_scan16(const void *len16, int n_per, unsigned *sums, int chunks,
   hipLaunchKernelGGL((k_chunk_sums<uint16_t>), dim3(chunks, npairs), dim3(256), 0, s, (const uint16_t *)len16, n_per, sums, chunks);
   hipLaunchKernelGGL(k_scan_sums, dim3(npairs), dim3(256), 0, s, sums, chunks, totals, (const unsigned *)nullptr);
   hipLaunchKernelGGL((k_offsets<uint16_t>), dim3(chunks, npairs), dim3(256), 0, s, (const uint16_t *)len16, n_per, sums, chunks, off32);
+}
+
+bool mjh_trellis_dc_speculative_ok(const MjhConst &C, int window_ok)
+{ // the window kernel's conditions, and a component with more than one block row per iMCU row (else there is nothing to speculate on)
+  return ((window_ok >> 8) >= 1) && ((window_ok >> 8) != 2) && (window_ok & 1) && C.delta_dc_weight <= 0.0f && C.maxv >= 2;
+}
+
+void mjh_launch_trellis_dc_speculative(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda,
+                                       void *back9, int *jfin, void *qspec, int n, hipStream_t s)
+{
+  int rows = 0;
+  for (int c = 0; c < C.ncomp; c++) rows += C.c[c].hib;
+  hipLaunchKernelGGL(k_trellis_dc3_fwd, dim3((rows * DC3_HYP + 3) / 4, n), dim3(64), 0, s, C, Q, (const int16_t *)uq, tabs, spi,
+                     make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]), lambda, (uint8_t *)back9, jfin, (int16_t *)qspec, rows);
+  hipLaunchKernelGGL(k_trellis_dc3_resolve, dim3(C.ncomp * C.mcu_rows, n), dim3(64), 0, s, C, (int16_t *)q, (const int *)jfin, (const int16_t *)qspec, rows);
 }
 
 void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s,

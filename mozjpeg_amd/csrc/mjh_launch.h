@@ -59,6 +59,9 @@ void mjh_launch_scan16(const void *len16, int n_per, unsigned *sums, int chunks,
 void mjh_launch_prog_select(void *ctl, int ncomp, int phase, int dc_scan_opt_mode, int n, hipStream_t s);
 void mjh_launch_prog_concat(const void *ctl, const void *file_hdr, int file_hdr_len, const void *outpool, size_t out_bytes,
                             void *out, size_t out_stride, unsigned *sizes, int n, hipStream_t s);
+bool mjh_trellis_dc_speculative_ok(const MjhConst &C, int window_ok);
+void mjh_launch_trellis_dc_speculative(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda,
+                                       void *back9, int *jfin, void *qspec, int n, hipStream_t s);
 // arithmetic entropy coding (mjh_arith.hip)
 void mjh_launch_arith_scans(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
                             const uint8_t *frame_hdr, int frame_hdr_len, const uint8_t *file_hdr, int file_hdr_len,
