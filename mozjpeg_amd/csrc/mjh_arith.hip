@@ -101,18 +101,23 @@ struct AriCoder {      // jcarith.c:28-52, all wave-uniform
       }
     }
   }
-  // arith_encode jcarith.c:229-320
+  // arith_encode jcarith.c:229-320.  The kind of bin is known at every call site: SP = 0 an AC bin (table in bit 8 of `bin`),
+  // 2 a DC bin, 3 the fixed 0.5 bin (state 113 never adapts: no RAM access at all, Qe = 0x5a1d)
+  template <int SP>
   __device__ __forceinline__ void encode(AriModel &M, int bin, int val)
   {
-    const int sp = bin >> 8, i = bin & 0xFF, sh = 8 * (i & 3);
+    const int i = bin & 0xFF, sh = 8 * (i & 3), t1 = (bin >> 8) & 1;
     int word = 0;
-    unsigned sv = 113u;
-    if (sp == 0) word = rl(M.ac[0], i >> 2);
-    else if (sp == 1) word = rl(M.ac[1], i >> 2);
-    else if (sp == 2) word = rl(M.dc, i >> 2);
-    if (sp != 3) sv = ((unsigned)word >> sh) & 0xFFu;
-    const int s = (int)(sv & 0x7Fu);
-    const unsigned t = (unsigned)(s < 64 ? rl(M.tab[0], s) : rl(M.tab[1], s - 64));
+    unsigned sv = 113u, t;
+    if (SP == 3) t = ((unsigned)mjh_ari_qe[113] << 16) | (113u << 8) | 113u;
+    else {
+      if (SP == 2) word = rl(M.dc, i >> 2);
+      else if (t1) word = rl(M.ac[1], i >> 2);
+      else word = rl(M.ac[0], i >> 2);
+      sv = ((unsigned)word >> sh) & 0xFFu;
+      const int s = (int)(sv & 0x7Fu);
+      t = (unsigned)(s < 64 ? rl(M.tab[0], s) : rl(M.tab[1], s - 64));
+    }
     const unsigned qe = t >> 16;
     unsigned ns;
     a -= qe;
@@ -124,11 +129,11 @@ struct AriCoder {      // jcarith.c:28-52, all wave-uniform
       if (a < qe) { c += a; a = qe; }
       ns = (sv & 0x80u) ^ ((t >> 8) & 0xFFu);
     }
-    if (sp != 3) {
+    if (SP != 3) {
       word = (int)(((unsigned)word & ~(0xFFu << sh)) | (ns << sh));
-      if (sp == 0) M.ac[0] = wl(word, i >> 2, M.ac[0]);
-      else if (sp == 1) M.ac[1] = wl(word, i >> 2, M.ac[1]);
-      else M.dc = wl(word, i >> 2, M.dc);
+      if (SP == 2) M.dc = wl(word, i >> 2, M.dc);
+      else if (t1) M.ac[1] = wl(word, i >> 2, M.ac[1]);
+      else M.ac[0] = wl(word, i >> 2, M.ac[0]);
     }
     do {
       a <<= 1;
@@ -146,28 +151,31 @@ __device__ __forceinline__ int ari_coef(const AriModel &M, int k) { return (int)
 
 // Figures F.8 / F.9: magnitude category and magnitude bits of v >= 1.  st = first magnitude bin; DC: the category bins continue
 // at 20; AC: the bin itself once more, then 189 (k <= Kx) / 217.  base = the table's bin 0.  Returns the category mask.
-__device__ __forceinline__ int ari_magnitude(AriCoder &A, AriModel &M, int base, int st, int v, bool ac, int k)
+template <bool AC>
+__device__ __forceinline__ int ari_magnitude(AriCoder &A, AriModel &M, int base, int st, int v, int k)
 {
+  constexpr int SP = AC ? 0 : 2;
+  const bool ac = AC;
   int m = 0;
   if (v -= 1) {
-    A.encode(M, st, 1);
+    A.encode<SP>(M, st, 1);
     m = 1;
     int v2 = v;
     if (ac) {
       if (v2 >>= 1) {
-        A.encode(M, st, 1);
+        A.encode<SP>(M, st, 1);
         m <<= 1;
         st = base + (k <= ARI_AC_K ? 189 : 217);
-        while (v2 >>= 1) { A.encode(M, st, 1); m <<= 1; st++; }
+        while (v2 >>= 1) { A.encode<SP>(M, st, 1); m <<= 1; st++; }
       }
     } else {
       st = base + 20;
-      while (v2 >>= 1) { A.encode(M, st, 1); m <<= 1; st++; }
+      while (v2 >>= 1) { A.encode<SP>(M, st, 1); m <<= 1; st++; }
     }
   }
-  A.encode(M, st, 0);
+  A.encode<SP>(M, st, 0);
   st += 14;
-  for (int mm = m >> 1; mm; mm >>= 1) A.encode(M, st, (mm & v) ? 1 : 0);
+  for (int mm = m >> 1; mm; mm >>= 1) A.encode<SP>(M, st, (mm & v) ? 1 : 0);
   return m;
 }
 
@@ -177,12 +185,12 @@ __device__ __forceinline__ void ari_dc(AriCoder &A, AriModel &M, int tbl, int &l
   const int base = ARI_DC(tbl, 0);
   int st = base + ctx;
   int v = value - last_dc;
-  if (v == 0) { A.encode(M, st, 0); ctx = 0; return; }
+  if (v == 0) { A.encode<2>(M, st, 0); ctx = 0; return; }
   last_dc = value;
-  A.encode(M, st, 1);
-  if (v > 0) { A.encode(M, st + 1, 0); st += 2; ctx = 4; }
-  else { v = -v; A.encode(M, st + 1, 1); st += 3; ctx = 8; }
-  const int m = ari_magnitude(A, M, base, st, v, false, 0);
+  A.encode<2>(M, st, 1);
+  if (v > 0) { A.encode<2>(M, st + 1, 0); st += 2; ctx = 4; }
+  else { v = -v; A.encode<2>(M, st + 1, 1); st += 3; ctx = 8; }
+  const int m = ari_magnitude<false>(A, M, base, st, v, 0);
   if (m < (int)((1L << ARI_DC_L) >> 1)) ctx = 0;
   else if (m > (int)((1L << ARI_DC_U) >> 1)) ctx += 8;
 }
@@ -196,22 +204,22 @@ __device__ __forceinline__ void ari_ac_first(AriCoder &A, AriModel &M, int tbl, 
   for (k = Ss; k <= ke; k++) {
     int st = base + 3 * (k - 1);
     int neg;
-    A.encode(M, st, 0);
+    A.encode<0>(M, st, 0);
     for (;;) {
       v = ari_coef(M, k);
       neg = v < 0;
       if (neg) v = -v;
       v >>= Al;
       if (v) break;
-      A.encode(M, st + 1, 0);
+      A.encode<0>(M, st + 1, 0);
       st += 3;
       k++;
     }
-    A.encode(M, st + 1, 1);
-    A.encode(M, ARI_FIXED, neg);
-    ari_magnitude(A, M, base, st + 2, v, true, k);
+    A.encode<0>(M, st + 1, 1);
+    A.encode<3>(M, ARI_FIXED, neg);
+    ari_magnitude<true>(A, M, base, st + 2, v, k);
   }
-  if (k <= Se) A.encode(M, base + 3 * (k - 1), 1);
+  if (k <= Se) A.encode<0>(M, base + 3 * (k - 1), 1);
 }
 
 // encode_mcu_AC_refine jcarith.c:596-687
@@ -221,23 +229,23 @@ __device__ __forceinline__ void ari_ac_refine(AriCoder &A, AriModel &M, int tbl,
   int k, v;
   for (k = Ss; k <= ke; k++) {
     int st = base + 3 * (k - 1);
-    if (k > kex) A.encode(M, st, 0);
+    if (k > kex) A.encode<0>(M, st, 0);
     for (;;) {
       v = ari_coef(M, k);
       const int neg = v < 0;
       if (neg) v = -v;
       v >>= Al;
       if (v) {
-        if (v >> 1) A.encode(M, st + 2, v & 1);
-        else { A.encode(M, st + 1, 1); A.encode(M, ARI_FIXED, neg); }
+        if (v >> 1) A.encode<0>(M, st + 2, v & 1);
+        else { A.encode<0>(M, st + 1, 1); A.encode<3>(M, ARI_FIXED, neg); }
         break;
       }
-      A.encode(M, st + 1, 0);
+      A.encode<0>(M, st + 1, 0);
       st += 3;
       k++;
     }
   }
-  if (k <= Se) A.encode(M, base + 3 * (k - 1), 1);
+  if (k <= Se) A.encode<0>(M, base + 3 * (k - 1), 1);
 }
 
 // The scan being coded, in registers and wave-uniform FOR THE COMPILER (readfirstlane): a MjhProgScan copied as a struct lands
@@ -382,7 +390,7 @@ __device__ __forceinline__ void ari_run(const MjhConst &C, const AriScan &sc, in
           ari_dc(A, M, td & 1, last, ctx, dc);
           ari_ac_first(A, M, ta & 1, 1, 63, 0, ke);
         } else if (sc.Ss == 0 && sc.Ah == 0) ari_dc(A, M, td & 1, last, ctx, dc >> Al);
-        else if (sc.Ss == 0) A.encode(M, ARI_FIXED, (dc >> Al) & 1);                    // encode_mcu_DC_refine :560-590
+        else if (sc.Ss == 0) A.encode<3>(M, ARI_FIXED, (dc >> Al) & 1);                    // encode_mcu_DC_refine :560-590
         else if (sc.Ah == 0) ari_ac_first(A, M, ta & 1, sc.Ss, sc.Se, Al, ke);
         else ari_ac_refine(A, M, ta & 1, sc.Ss, sc.Se, sc.Ah, Al, ke, kex);
         if (ci == 0) { ch.last_dc[0] = last; ch.ctx[0] = ctx; } else if (ci == 1) { ch.last_dc[1] = last; ch.ctx[1] = ctx; }

@@ -351,11 +351,10 @@ __device__ __forceinline__ float catmull_rom(int v1, int v2, int v3, int v4, flo
 // FD: every quantizer step of the tables in use fits 8 bits -- the division by 8q is one shift + one 24-bit multiply-high
 // (MjhQuant.mdiv / sdiv) instead of the float-reciprocal division with its integer fix-up; with STATS the AC coefficients are
 // quantized for the statistics only, which need the magnitude category and nothing else (no sign, no signed clamp).
-template <class T, bool STATS, bool FD = false>   // uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
-__global__ void __launch_bounds__(64)
-k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ planes,
-            int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
-            MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out)
+template <class T, bool STATS, bool FD>   // uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
+__device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant *__restrict__ Q, const T *__restrict__ planes,
+                                               int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
+                                               MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out)
 {
   constexpr bool W12 = sizeof(T) == 2;
   // 8 KB per wave: the deringing columns (the ORIGINAL level-shifted samples of the lane's block in zig-zag order, 16 bits
@@ -544,6 +543,24 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
       if (sum) atomicAdd(&T2->counts[bin], sum);
     }
   }
+}
+
+template <class T, bool STATS, bool FD = false>
+__global__ void __launch_bounds__(64)
+k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ planes,
+            int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
+            MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out)
+{
+  dct_quant_body<T, STATS, FD>(C, Q, planes, coef_uq, coef_q, lambda_out, stat_tabs, slots_per_image, stat_slot_of_comp, nq8_out);
+}
+// the same kernel held to 128 VGPRs (4 instead of 3 waves per SIMD; 11 dwords spill to scratch): MJH_DCT_OCC=4, an A/B knob
+template <class T, bool STATS, bool FD = false>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_dct_quant_o4(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ planes,
+               int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
+               MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out)
+{
+  dct_quant_body<T, STATS, FD>(C, Q, planes, coef_uq, coef_q, lambda_out, stat_tabs, slots_per_image, stat_slot_of_comp, nq8_out);
 }
 
 // =============================================================================================
@@ -3559,7 +3576,11 @@ void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, vo
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
   const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
   if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t, false>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
-  else if (stat_tabs && fastdiv) hipLaunchKernelGGL((k_dct_quant<uint8_t, true, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
+  else if (stat_tabs && fastdiv) {
+    const char *occ = getenv("MJH_DCT_OCC");     // A/B knob, read per call
+    if (occ && atoi(occ) == 4) hipLaunchKernelGGL((k_dct_quant_o4<uint8_t, true, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
+    else hipLaunchKernelGGL((k_dct_quant<uint8_t, true, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
+  }
   else if (stat_tabs) hipLaunchKernelGGL((k_dct_quant<uint8_t, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else if (fastdiv) hipLaunchKernelGGL((k_dct_quant<uint8_t, false, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else hipLaunchKernelGGL((k_dct_quant<uint8_t, false>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);

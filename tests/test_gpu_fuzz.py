@@ -82,3 +82,69 @@ def test_random_configuration_matches_the_oracle(idx, w, h, kw, kind):
     got = enc.encode_host(np.stack([img, img]))
     enc.close()
     assert got[0] == want and got[1] == want, (idx, w, h, kw)
+
+
+def _arith_cases():
+    """the same idea for arithmetic coding: its own seed, so the Huffman cases above keep their numbers"""
+    rng = np.random.default_rng(20260921)
+    out = []
+    samplings = [(1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (1, 4), (4, 2), (2, 4)]
+    for i in range(40):
+        w = int(rng.integers(1, 400)); h = int(rng.integers(1, 300))
+        kw = dict(arithmetic=True, quality=int(rng.choice([5, 20, 40, 60, 75, 85, 92, 98, 100])), sample=samplings[int(rng.integers(0, len(samplings)))])
+        mode = int(rng.integers(0, 4))        # 3 = cjpeg's default: progressive + scan search
+        if mode == 0:
+            kw["baseline"] = True
+        elif mode == 1:
+            kw["fastcrush"] = True
+        elif mode == 2:
+            kw["revert"] = True
+            if rng.random() < 0.5:
+                kw["progressive"] = True
+        if rng.random() < 0.25:
+            kw["gray"] = True
+            kw["sample"] = (1, 1)
+        if rng.random() < 0.35:
+            kw["restart"] = int(rng.integers(1, 4)) if rng.random() < 0.5 else "%db" % int(rng.integers(1, 40))
+        if not kw.get("revert"):
+            r = rng.random()
+            if r < 0.2:
+                kw["notrellis"] = True
+            elif r < 0.35:
+                kw["notrellis_dc"] = True
+            if not kw.get("notrellis"):
+                if rng.random() < 0.2:
+                    kw["use_scans_in_trellis"] = True          # (with arithmetic coding: only the first band is ever trellised)
+                    kw["trellis_freq_split"] = int(rng.choice([0, 1, 5, 8, 30, 62, 63]))
+                if rng.random() < 0.25:
+                    kw["dc_ver_weight"] = float(rng.choice([0.25, 1.0, 3.0]))
+                if rng.random() < 0.15:
+                    kw["trellis_loops"] = 2
+            if rng.random() < 0.2 and not kw.get("baseline"):
+                kw["dc_scan_opt"] = int(rng.integers(1, 3))
+        out.append((i, w, h, kw, int(rng.integers(0, 3))))
+    return out
+
+
+@pytest.mark.parametrize("idx,w,h,kw,kind", _arith_cases(), ids=lambda v: str(v) if isinstance(v, int) else None)
+def test_random_arithmetic_configuration_matches_the_oracle(idx, w, h, kw, kind):
+    rng = np.random.default_rng(5000 + idx)
+    if kind == 0:
+        img = O.synthetic_frame(max(w, 8), max(h, 8), 7000 + idx)[:h, :w].copy()
+    elif kind == 1:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    else:
+        img = np.full((h, w, 3), 255, np.uint8)
+        for _ in range(4):
+            y, x = int(rng.integers(0, h)), int(rng.integers(0, w))
+            img[y:y + 9, x:x + 9] = rng.integers(0, 64, 3, dtype=np.uint8)
+    if kw.get("gray") and rng.random() < 0.5:
+        kw = dict(kw, grayin=True)
+        img = img[:, :, 1].copy()
+    want = O.encode(O.make_params(w, h, **kw), img)
+    assert len(want) > 0, (idx, kw)
+    enc = M.Encoder(M.make_params(w, h, **kw), max_batch=2)
+    got = enc.encode_host(np.stack([img, img[::-1].copy()]))
+    enc.close()
+    assert got[0] == want, (idx, w, h, kw)
+    assert got[1] == O.encode(O.make_params(w, h, **kw), img[::-1].copy()), (idx, w, h, kw)
