@@ -553,16 +553,6 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
 {
   dct_quant_body<T, STATS, FD>(C, Q, planes, coef_uq, coef_q, lambda_out, stat_tabs, slots_per_image, stat_slot_of_comp, nq8_out);
 }
-// the same kernel held to 128 VGPRs (4 instead of 3 waves per SIMD; 11 dwords spill to scratch): MJH_DCT_OCC=4, an A/B knob
-template <class T, bool STATS, bool FD = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_dct_quant_o4(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ planes,
-               int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
-               MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out)
-{
-  dct_quant_body<T, STATS, FD>(C, Q, planes, coef_uq, coef_q, lambda_out, stat_tabs, slots_per_image, stat_slot_of_comp, nq8_out);
-}
-
 // =============================================================================================
 // K2b  coefficient import: jpeg_write_coefficients jctrans.c:44 entropy-codes blocks the
 // caller already has (jpegtran, "jpegrescan").  The caller's arrays are block-major, natural order
@@ -2521,6 +2511,24 @@ template <int CTRL> __device__ __forceinline__ float dpp_f0(float v)
 {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
+// dpp(v) + d in ONE instruction (v_add_f32 with a DPP source; this compiler does not fold a v_mov_b32_dpp into the add by
+// itself, and each costs a 4-cycle issue slot): SHL = row_shl:n (lane i reads lane i + n of its row) with lanes that have no source reading 0.0, BC = row_newbcast:n.
+// Same IEEE add as the two-instruction form.  `first`: the source may have been written by the instruction before (DPP read
+// hazard: 2 wait states), which the hazard recognizer cannot see across inline asm.
+template <int SHL> __device__ __forceinline__ float add_shl(float v, float d, bool first = false)
+{
+  float r;
+  if (first) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_shl:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(d), "n"(SHL));
+  else asm volatile("v_add_f32_dpp %0, %1, %2 row_shl:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(d), "n"(SHL));
+  return r;
+}
+template <int BC> __device__ __forceinline__ float add_bcast(float v, float d, bool first = false)
+{
+  float r;
+  if (first) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(d), "n"(BC));
+  else asm volatile("v_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(d), "n"(BC));
+  return r;
+}
 
 __global__ void __launch_bounds__(64)
 k_trellis_dc3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
@@ -2597,15 +2605,15 @@ k_trellis_dc3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restr
           const int D = c0 - prev_c0;
           const float Rj = dc_rate(rsi, D + k - 7), R0 = dc_rate(rsi, D - 8);
           // predecessor in lane M: rate of difference number k - M + 8 = the value of lane k + 7 - M (number 0: R0)
-          const float c_0 = (dpp_f0<0x107>(Rj) + dist) + row_bcast_f<0>(prev_cost);
-          const float c_1 = (dpp_f0<0x106>(Rj) + dist) + row_bcast_f<1>(prev_cost);
-          const float c_2 = (dpp_f0<0x105>(Rj) + dist) + row_bcast_f<2>(prev_cost);
-          const float c_3 = (dpp_f0<0x104>(Rj) + dist) + row_bcast_f<3>(prev_cost);
-          const float c_4 = (dpp_f0<0x103>(Rj) + dist) + row_bcast_f<4>(prev_cost);
-          const float c_5 = (dpp_f0<0x102>(Rj) + dist) + row_bcast_f<5>(prev_cost);
-          const float c_6 = (dpp_f0<0x101>(Rj) + dist) + row_bcast_f<6>(prev_cost);
-          const float c_7 = (Rj + dist) + row_bcast_f<7>(prev_cost);
-          const float c_8 = (dpp_f<0x111>(R0, Rj) + dist) + row_bcast_f<8>(prev_cost);     // row_shr:1; lane 0 keeps R0
+          const float c_0 = add_bcast<0>(prev_cost, add_shl<7>(Rj, dist, true), true);
+          const float c_1 = add_bcast<1>(prev_cost, add_shl<6>(Rj, dist));
+          const float c_2 = add_bcast<2>(prev_cost, add_shl<5>(Rj, dist));
+          const float c_3 = add_bcast<3>(prev_cost, add_shl<4>(Rj, dist));
+          const float c_4 = add_bcast<4>(prev_cost, add_shl<3>(Rj, dist));
+          const float c_5 = add_bcast<5>(prev_cost, add_shl<2>(Rj, dist));
+          const float c_6 = add_bcast<6>(prev_cost, add_shl<1>(Rj, dist));
+          const float c_7 = add_bcast<7>(prev_cost, Rj + dist);
+          const float c_8 = add_bcast<8>(prev_cost, dpp_f<0x111>(R0, Rj) + dist);     // row_shr:1; lane 0 keeps R0
           const float m = fminf(fminf(fminf(c_0, c_1), fminf(c_2, c_3)), fminf(fminf(fminf(c_4, c_5), fminf(c_6, c_7)), c_8));
           // first minimum in CANDIDATE order of the predecessor (:1100-1106): lanes of invalid candidates hold 3e38
           unsigned e = (c_0 == m ? 1u : 0u) | (c_1 == m ? 2u : 0u) | (c_2 == m ? 4u : 0u) | (c_3 == m ? 8u : 0u) | (c_4 == m ? 16u : 0u) |
@@ -2765,15 +2773,15 @@ k_trellis_dc3_fwd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__r
       } else {
         const int D = c0 - prev_c0;
         const float Rj = dc_rate(rsi, D + k - 7), R0 = dc_rate(rsi, D - 8);
-        const float c_0 = (dpp_f0<0x107>(Rj) + dist) + row_bcast_f<0>(prev_cost);
-        const float c_1 = (dpp_f0<0x106>(Rj) + dist) + row_bcast_f<1>(prev_cost);
-        const float c_2 = (dpp_f0<0x105>(Rj) + dist) + row_bcast_f<2>(prev_cost);
-        const float c_3 = (dpp_f0<0x104>(Rj) + dist) + row_bcast_f<3>(prev_cost);
-        const float c_4 = (dpp_f0<0x103>(Rj) + dist) + row_bcast_f<4>(prev_cost);
-        const float c_5 = (dpp_f0<0x102>(Rj) + dist) + row_bcast_f<5>(prev_cost);
-        const float c_6 = (dpp_f0<0x101>(Rj) + dist) + row_bcast_f<6>(prev_cost);
-        const float c_7 = (Rj + dist) + row_bcast_f<7>(prev_cost);
-        const float c_8 = (dpp_f<0x111>(R0, Rj) + dist) + row_bcast_f<8>(prev_cost);
+        const float c_0 = add_bcast<0>(prev_cost, add_shl<7>(Rj, dist, true), true);
+        const float c_1 = add_bcast<1>(prev_cost, add_shl<6>(Rj, dist));
+        const float c_2 = add_bcast<2>(prev_cost, add_shl<5>(Rj, dist));
+        const float c_3 = add_bcast<3>(prev_cost, add_shl<4>(Rj, dist));
+        const float c_4 = add_bcast<4>(prev_cost, add_shl<3>(Rj, dist));
+        const float c_5 = add_bcast<5>(prev_cost, add_shl<2>(Rj, dist));
+        const float c_6 = add_bcast<6>(prev_cost, add_shl<1>(Rj, dist));
+        const float c_7 = add_bcast<7>(prev_cost, Rj + dist);
+        const float c_8 = add_bcast<8>(prev_cost, dpp_f<0x111>(R0, Rj) + dist);
         const float m = fminf(fminf(fminf(c_0, c_1), fminf(c_2, c_3)), fminf(fminf(fminf(c_4, c_5), fminf(c_6, c_7)), c_8));
         unsigned e = (c_0 == m ? 1u : 0u) | (c_1 == m ? 2u : 0u) | (c_2 == m ? 4u : 0u) | (c_3 == m ? 8u : 0u) | (c_4 == m ? 16u : 0u) |
                      (c_5 == m ? 32u : 0u) | (c_6 == m ? 64u : 0u) | (c_7 == m ? 128u : 0u) | (c_8 == m ? 256u : 0u);
@@ -3576,11 +3584,7 @@ void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, vo
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
   const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
   if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t, false>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
-  else if (stat_tabs && fastdiv) {
-    const char *occ = getenv("MJH_DCT_OCC");     // A/B knob, read per call
-    if (occ && atoi(occ) == 4) hipLaunchKernelGGL((k_dct_quant_o4<uint8_t, true, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
-    else hipLaunchKernelGGL((k_dct_quant<uint8_t, true, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
-  }
+  else if (stat_tabs && fastdiv) hipLaunchKernelGGL((k_dct_quant<uint8_t, true, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else if (stat_tabs) hipLaunchKernelGGL((k_dct_quant<uint8_t, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else if (fastdiv) hipLaunchKernelGGL((k_dct_quant<uint8_t, false, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else hipLaunchKernelGGL((k_dct_quant<uint8_t, false>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
