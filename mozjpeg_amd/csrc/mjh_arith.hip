@@ -447,7 +447,7 @@ __device__ __forceinline__ unsigned ari_scan_header(const AriScan &sc, int Al, c
 
 
 // One scan of one image.  WRITE = false: its size (header + entropy-coded bytes) goes to ctl.scan_size (what the scan search
-// compares, jcmaster.c:773-962).  WRITE = true: grid.x walks the FINAL order (ctl.order); the scan is written at its place in
+// compares, jcmaster.c:773-962).  WRITE = true: grid.y walks the FINAL order (ctl.order); the scan is written at its place in
 // the file, ctl.scan_out_off (k_arith_layout) -- or, `single_pass`, behind the file header with EOI and the file size (a script
 // of one scan needs no sizing pass).  whole_blocks: a sequential file (SOF9).
 template <bool WRITE>
@@ -458,18 +458,21 @@ k_arith_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
              unsigned *__restrict__ sizes, int whole_blocks, int single_pass)
 {
   __shared__ short s_blk[64 * 64];
-  const int img = blockIdx.y, lane = threadIdx.x;
+  // image index fastest: consecutive workgroups go to consecutive XCDs, so the chains of one scan (equally long, image by
+  // image) spread evenly over the chip.  A coding wave keeps its SIMD's scalar issue slot busy by itself: where the long
+  // chains of a batch crowd onto a few XCDs (scan index fastest did that), two share a SIMD and both run at half speed.
+  const int img = blockIdx.x, li = blockIdx.y, lane = threadIdx.x;
   MjhProgCtl *ct = ctl + img;
   int sidx;
   if (WRITE && !single_pass) {
-    if ((int)blockIdx.x >= ARI_U(ct->norder)) return;
-    sidx = ct->order[blockIdx.x];
-  } else sidx = scan_list[blockIdx.x];
+    if (li >= ARI_U(ct->norder)) return;
+    sidx = ct->order[li];
+  } else sidx = scan_list[li];
   sidx = ARI_U(sidx);
   const MjhProgScan *sp = scans + sidx;
   const int cond = ARI_U(sp->cond), al_sel = ARI_U(sp->al_sel);
   if (!WRITE && cond > 0 && ARI_U(ct->al_continue) < cond) { if (lane == 0) ct->scan_size[sidx] = 0; return; }   // the search stopped below this level
-  if (WRITE && ARI_U(ct->error)) { if (lane == 0 && (single_pass || blockIdx.x == 0)) sizes[img] = 0; return; }
+  if (WRITE && ARI_U(ct->error)) { if (lane == 0 && (single_pass || li == 0)) sizes[img] = 0; return; }
   const int Al = ARI_U(al_sel == 1 ? ct->best_Al_luma : (al_sel == 2 ? ct->best_Al_chroma : sp->Al));
   const AriScan sc = ari_load_scan(C, sp);
   int bpm;
@@ -540,7 +543,8 @@ k_arith_layout(MjhProgCtl *__restrict__ ctl, const uint8_t *__restrict__ file_hd
 // workgroup of 256 threads per image --
 //   * rates: 320 bins looked up in a 256-entry table the host computed with its libm (the estimate depends on the bin's
 //     state byte only; -log(p)/log(2) in double like the reference);
-//   * AC: one thread per block of the row group, the reference's DP as it stands (two candidates per coefficient, `int rate`);
+//   * AC: one thread per block of the row group: the reference's DP (two candidates per coefficient, `int rate`) with the
+//     same float operations in the same order, walked over the live predecessors only (quadratic instead of cubic);
 //   * DC: lanes 0..8 of wave 0 = the candidates of a block, chained along each block row;
 //   * state update: wave 0 codes the row group's blocks (whole blocks, raster order) with lane 0.
 // Only component 0 is ever selected for these passes when arithmetic coding is on (jcmaster.c: prepare_for_pass's
@@ -626,15 +630,20 @@ k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
       o[1] = rate_tab->r[state][1];
     }
     __syncthreads();
-    // ---- AC: one thread per block of the row group (jcdctmgr.c:1512-1631)
+    // ---- AC: one thread per block of the row group (jcdctmgr.c:1512-1631).  The reference's DP with its float operations in
+    // the reference's order, arranged around the LIVE entries (the start and the positions given a non-zero value so far --
+    // the only predecessors its loop does not skip): the run's bits towards a predecessor j are a left-to-right float sum that
+    // starts at j, so each entry carries its own partial sum and is brought up to the current position when it is next
+    // consulted (the reference re-adds the whole run for every (j, i): cubic); a candidate's own bits do not depend on j.
     for (int idx = tid; idx < rows * cc.wib; idx += 256) {
       const int blk = br0 * cc.wib + idx;
       const float lambda = lam[blk];
-      float azd[64], acost[64];
-      short coef[64];
-      unsigned char run_start[64];
-      azd[Ss - 1] = 0.0f; acost[Ss - 1] = 0.0f;
-      for (int i = 0; i < 64; i++) { coef[i] = 0; run_start[i] = 0; }
+      float lsum[64], lazd[64], lcost[64];     // entry e: run bits from its position up to `upto`, azd and cost at its position
+      short lval[64], coef[64];
+      unsigned char lpos[64], lback[64];
+      int nl = 1, upto = Ss, fresh = 0;        // fresh: the newest entry was made at step `upto` (its run starts one position later)
+      lsum[0] = rac[3 * (Ss - 1)][0]; lazd[0] = 0.0f; lcost[0] = 0.0f; lpos[0] = (unsigned char)(Ss - 1); lval[0] = 0; lback[0] = 0;
+      float azd_run = 0.0f;
       for (int i = Ss; i <= Se; i++) {
         const int xs = uq[(size_t)i * cc.kstride + blk];
         const int sign = xs < 0 ? -1 : 0, x = xs < 0 ? -xs : xs;
@@ -642,67 +651,72 @@ k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
         const float lt = Q->lambda_tbl[qt][i];
         float t = (float)mul24(x, x) * lambda;
         t = t * lt;
-        azd[i] = t + azd[i - 1];
+        const float azd_im1 = azd_run;
+        azd_run = t + azd_run;
         const int qval = (x + (dq >> 1)) / dq;
-        if (qval == 0) { coef[i] = 0; acost[i] = 1e38f; continue; }
+        if (qval == 0) continue;
         int cand[2];
-        float cdist[2];
+        float cdist[2], cbits[2];
         int ncd = 1;
         cand[0] = qval;
         { const int delta = cand[0] * dq - x; float d = (float)(delta * delta) * lambda; cdist[0] = d * lt; }
-        cand[1] = qval - 1; cdist[1] = 0.0f;
+        cand[1] = qval - 1; cdist[1] = 0.0f; cbits[1] = 0.0f;
         if (qval > 1) { const int delta = cand[1] * dq - x; float d = (float)(delta * delta) * lambda; cdist[1] = d * lt; ncd = 2; }
-        acost[i] = 1e38f;
-        for (int j = Ss - 1; j < i; j++) {
-          if (j != Ss - 1 && coef[j] == 0) continue;
-          float run_bits = rac[3 * j][0];
-          for (int k = j + 1; k < i; k++) run_bits += rac[3 * (k - 1) + 1][0];
-          run_bits += rac[3 * (i - 1) + 1][1];
-          for (int k = 0; k < ncd; k++) {
-            float coef_bits = 1.0f;
-            int vv = cand[k], m = 0, st = 3 * (i - 1) + 2;
-            if (vv -= 1) {
+        for (int k = 0; k < ncd; k++) {
+          float coef_bits = 1.0f;
+          int vv = cand[k], m = 0, st = 3 * (i - 1) + 2;
+          if (vv -= 1) {
+            coef_bits += rac[st][1];
+            m = 1;
+            int v2 = vv;
+            if (v2 >>= 1) {
               coef_bits += rac[st][1];
-              m = 1;
-              int v2 = vv;
-              if (v2 >>= 1) {
-                coef_bits += rac[st][1];
-                m <<= 1;
-                st = i <= ARI_AC_K ? 189 : 217;
-                while (v2 >>= 1) { coef_bits += rac[st][1]; m <<= 1; st++; }
-              }
-            }
-            coef_bits += rac[st][0];
-            st += 14;
-            while (m >>= 1) coef_bits += rac[st][(m & vv) ? 1 : 0];
-            const int rate = (int)(coef_bits + run_bits);      // `int rate` (jcdctmgr.c:1349, :1583): the estimate is truncated
-            float cost = (float)rate + cdist[k];
-            float rhs = azd[i - 1] - azd[j];
-            rhs = rhs + acost[j];
-            cost = cost + rhs;
-            if (cost < acost[i]) {
-              coef[i] = (short)((cand[k] ^ sign) - sign);
-              acost[i] = cost;
-              run_start[i] = (unsigned char)j;
+              m <<= 1;
+              st = i <= ARI_AC_K ? 189 : 217;
+              while (v2 >>= 1) { coef_bits += rac[st][1]; m <<= 1; st++; }
             }
           }
+          coef_bits += rac[st][0];
+          st += 14;
+          while (m >>= 1) coef_bits += rac[st][(m & vv) ? 1 : 0];
+          cbits[k] = coef_bits;
+        }
+        const float nz_bit = rac[3 * (i - 1) + 1][1];
+        float best = 1e38f;
+        int bj = 0, bv = 0;
+        bool found = false;
+        for (int e = 0; e < nl; e++) {
+          float run_bits = lsum[e];
+          for (int k = upto + ((fresh && e == nl - 1) ? 1 : 0); k < i; k++) run_bits += rac[3 * (k - 1) + 1][0];
+          lsum[e] = run_bits;
+          run_bits += nz_bit;
+          float rhs = azd_im1 - lazd[e];
+          rhs = rhs + lcost[e];
+          for (int k = 0; k < ncd; k++) {
+            const int rate = (int)(cbits[k] + run_bits);        // `int rate` (jcdctmgr.c:1349, :1583): the estimate is truncated
+            float cost = (float)rate + cdist[k];
+            cost = cost + rhs;
+            if (cost < best) { best = cost; bv = (cand[k] ^ sign) - sign; bj = e; found = true; }
+          }
+        }
+        upto = i; fresh = 0;
+        if (found) {
+          lsum[nl] = rac[3 * i][0]; lazd[nl] = azd_run; lcost[nl] = best;
+          lpos[nl] = (unsigned char)i; lval[nl] = (short)bv; lback[nl] = (unsigned char)bj;
+          nl++; fresh = 1;
         }
       }
-      int last = Ss - 1;
-      float best_cost = azd[Se] + rac[0][1];
-      for (int i = Ss; i <= Se; i++)
-        if (coef[i] != 0) {
-          float cost = acost[i] + azd[Se];
-          cost = cost - azd[i];
-          if (i < Se) cost = cost + rac[3 * (i - 1)][1];
-          if (cost < best_cost) { best_cost = cost; last = i; }
-        }
-      int i = Se;
-      while (i >= Ss) {
-        while (i > last) { coef[i] = 0; i--; }
-        last = run_start[i];
-        i--;
+      int last = 0;
+      float best_cost = azd_run + rac[0][1];
+      for (int e = 1; e < nl; e++) {
+        const int i = lpos[e];
+        float cost = lcost[e] + azd_run;
+        cost = cost - lazd[e];
+        if (i < Se) cost = cost + rac[3 * (i - 1)][1];
+        if (cost < best_cost) { best_cost = cost; last = e; }
       }
+      for (int k = 0; k < 64; k++) coef[k] = 0;
+      for (int e = last; e > 0; e = lback[e]) coef[lpos[e]] = lval[e];
       for (int k = Ss; k <= Se; k++) q[(size_t)k * cc.kstride + blk] = coef[k];
     }
     // ---- DC along each block row of the group (jcdctmgr.c:1416-1509, :1643-1665): lane k of wave 0 = candidate k
@@ -788,10 +802,10 @@ void mjh_launch_arith_scans(const MjhConst &C, const void *scans, const int *lis
 {
   // mode 0: size the scans of the list; 1: write the scans of the final order (nlist = upper bound of its length); 2: one scan, one pass
   if (mode == 0)
-    hipLaunchKernelGGL((k_arith_scan<false>), dim3(nlist, n), dim3(64), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl, (const int16_t *)q,
+    hipLaunchKernelGGL((k_arith_scan<false>), dim3(n, nlist), dim3(64), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl, (const int16_t *)q,
                        frame_hdr, frame_hdr_len, file_hdr, file_hdr_len, out, out_stride, sizes, whole_blocks, 0);
   else
-    hipLaunchKernelGGL((k_arith_scan<true>), dim3(nlist, n), dim3(64), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl, (const int16_t *)q,
+    hipLaunchKernelGGL((k_arith_scan<true>), dim3(n, nlist), dim3(64), 0, s, C, (const MjhProgScan *)scans, list, (MjhProgCtl *)ctl, (const int16_t *)q,
                        frame_hdr, frame_hdr_len, file_hdr, file_hdr_len, out, out_stride, sizes, whole_blocks, mode == 2 ? 1 : 0);
 }
 
