@@ -59,11 +59,11 @@ CONFIGS = {
     "c5": dict(w=8192, h=8192, kw=dict(precision=12, baseline=True, notrellis=True, quality=90, sample=(1, 1), restart=1), batch=1, steps=600,
                name="C5: 8192x8192 12-bit, q90 4:4:4, restart interval = MCU row, -notrellis (the reference aborts on 12-bit + trellis, SURVEY F1)"),
     # SURVEY 8f row 4 (completeness path, not a throughput path: an adaptive coder is one dependent chain per scan)
-    # (arithmetic coding is one dependent chain per scan and image: a step takes the same ~4 s for 16 frames or 128, so the
+    # (arithmetic coding is one dependent chain per scan and image: a step takes the same ~4 s for 16 frames or 256, so the
     # batch is the throughput knob; `distinct` synthetic frames are generated and repeated to fill it)
-    "arith": dict(w=3840, h=2160, kw=dict(quality=75, baseline=True, arithmetic=True), batch=128, distinct=32, steps=2,
+    "arith": dict(w=3840, h=2160, kw=dict(quality=75, baseline=True, arithmetic=True), batch=256, distinct=32, steps=2,
                   name="4K q75 4:2:0 sequential, arithmetic coding + the coder's trellis (cjpeg -quality 75 -baseline -arithmetic)"),
-    "arith_prog": dict(w=3840, h=2160, kw=dict(quality=75, arithmetic=True), batch=128, distinct=32, steps=2,
+    "arith_prog": dict(w=3840, h=2160, kw=dict(quality=75, arithmetic=True), batch=256, distinct=32, steps=2,
                        name="4K q75 4:2:0 progressive + scan search, arithmetic coding (cjpeg -quality 75 -arithmetic)"),
     "c5t": dict(w=8192, h=8192, kw=dict(baseline=True, quality=90, sample=(1, 1), restart=1), batch=1, steps=400,
                 name="C5 8-bit twin: 8192x8192, q90 4:4:4 trellis, restart interval = MCU row"),
