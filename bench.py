@@ -163,13 +163,15 @@ INTERVAL_KERNELS = {
 
 
 def kernel_source_stamp():
-    """sha256 over the sources every kernel is built from (mozjpeg_amd/csrc/*.hip, *.h): tools/pmc_traffic.py writes it
-    into the traffic summaries it produces, and a summary whose stamp differs from the tree's is never quoted"""
+    """sha256 over the sources the kernels of every PROFILED configuration are built from (mozjpeg_amd/csrc/*.hip, *.h):
+    tools/pmc_traffic.py writes it into the traffic summaries it produces, and a summary whose stamp differs from the
+    tree's is never quoted.  mjh_arith.hip (+ its table) is left out: a translation unit of its own that holds only the
+    arithmetic-coding kernels, which no configuration with PMC passes launches (the arith lines carry traffic = null)."""
     import hashlib
     hsh = hashlib.sha256()
     src = os.path.join(ROOT, "mozjpeg_amd", "csrc")
     for name in sorted(os.listdir(src)):
-        if name.endswith((".hip", ".h")):
+        if name.endswith((".hip", ".h")) and not name.startswith("mjh_arith"):
             hsh.update(name.encode())
             hsh.update(open(os.path.join(src, name), "rb").read())
     return hsh.hexdigest()[:16]
