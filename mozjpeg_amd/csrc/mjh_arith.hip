@@ -39,12 +39,13 @@ __device__ __forceinline__ int wl(int val, int lane, int old)
 
 struct AriModel {      // vector registers as RAM
   int ac[2];           // AC statistics of table 0 / 1: 256 bins each, four per lane (byte j of lane i = bin 4i + j)
+  int cur;             // the AC statistics of the table of the block being coded (bound / put back around every block: the coder
+                       // itself never chooses between registers)
   int dc;              // DC statistics: table 0 in lanes 0..15, table 1 in lanes 16..31 (64 bins each)
   int tab[2];          // T.81 Table D.3, entries 0..63 / 64..113: Qe << 16 | next state after an MPS << 8 | after an LPS (bit 7: MPS flips)
   int coef;            // the block being coded: lane k = coefficient k (zig-zag)
 };
-// a statistics bin: space << 8 | index; space 0 / 1 = AC table 0 / 1, 2 = DC (index = 64 * table + bin), 3 = the fixed 0.5 bin
-#define ARI_AC(t, i) (((t) << 8) | (i))
+// a statistics bin: space << 8 | index; space 0 = AC (the bound table), 2 = DC (index = 64 * table + bin), 3 = the fixed 0.5 bin
 #define ARI_DC(t, i) ((2 << 8) | ((t) << 6) | (i))
 #define ARI_FIXED (3 << 8)
 
@@ -101,49 +102,49 @@ struct AriCoder {      // jcarith.c:28-52, all wave-uniform
       }
     }
   }
-  // arith_encode jcarith.c:229-320.  The kind of bin is known at every call site: SP = 0 an AC bin (table in bit 8 of `bin`),
-  // 2 a DC bin, 3 the fixed 0.5 bin (state 113 never adapts: no RAM access at all, Qe = 0x5a1d)
+  // arith_encode jcarith.c:229-320.  The kind of bin is known at every call site: SP = 0 an AC bin of the bound table, 2 a DC
+  // bin, 3 the fixed 0.5 bin (state 113 never adapts: no RAM access at all, Qe = 0x5a1d).  Written for a lone wave, whose taken
+  // branches cost several instruction slots each: both halves of the probability table are read and one is selected, the
+  // more / less probable paths share their arithmetic through selects, and the renormalisation shifts by the whole distance
+  // at once (count-leading-zeros) instead of bit by bit -- the same integer operations as the reference's loop, which only
+  // ever looks at the registers when the shift counter reaches a byte boundary.  One branch stays: the common exit of a more
+  // probable symbol that needs no renormalisation.
   template <int SP>
   __device__ __forceinline__ void encode(AriModel &M, int bin, int val)
   {
-    const int i = bin & 0xFF, sh = 8 * (i & 3), t1 = (bin >> 8) & 1;
+    const int i = bin & 0xFF, sh = 8 * (i & 3);
     int word = 0;
     unsigned sv = 113u, t;
     if (SP == 3) t = ((unsigned)mjh_ari_qe[113] << 16) | (113u << 8) | 113u;
     else {
-      if (SP == 2) word = rl(M.dc, i >> 2);
-      else if (t1) word = rl(M.ac[1], i >> 2);
-      else word = rl(M.ac[0], i >> 2);
+      word = SP == 2 ? rl(M.dc, i >> 2) : rl(M.cur, i >> 2);
       sv = ((unsigned)word >> sh) & 0xFFu;
       const int s = (int)(sv & 0x7Fu);
-      t = (unsigned)(s < 64 ? rl(M.tab[0], s) : rl(M.tab[1], s - 64));
+      const unsigned lo = (unsigned)rl(M.tab[0], s & 63), hi = (unsigned)rl(M.tab[1], s & 63);
+      t = s < 64 ? lo : hi;
     }
     const unsigned qe = t >> 16;
-    unsigned ns;
+    const bool lps = (unsigned)val != (sv >> 7);
     a -= qe;
-    if ((unsigned)val != (sv >> 7)) {
-      if (a >= qe) { c += a; a = qe; }
-      ns = (sv & 0x80u) ^ (t & 0xFFu);
-    } else {
-      if (a >= 0x8000u) return;
-      if (a < qe) { c += a; a = qe; }
-      ns = (sv & 0x80u) ^ ((t >> 8) & 0xFFu);
-    }
+    if (!lps && a >= 0x8000u) return;
+    const bool exchange = lps ? a >= qe : a < qe;      // conditional exchange (D.1.4 / D.1.5)
+    c += exchange ? a : 0u;
+    a = exchange ? qe : a;
     if (SP != 3) {
+      const unsigned ns = (sv & 0x80u) ^ ((lps ? t : t >> 8) & 0xFFu);
       word = (int)(((unsigned)word & ~(0xFFu << sh)) | (ns << sh));
       if (SP == 2) M.dc = wl(word, i >> 2, M.dc);
-      else if (t1) M.ac[1] = wl(word, i >> 2, M.ac[1]);
-      else M.ac[0] = wl(word, i >> 2, M.ac[0]);
+      else M.cur = wl(word, i >> 2, M.cur);
     }
-    do {
-      a <<= 1;
-      c <<= 1;
-      if (--ct == 0) {
-        shift_out(c >> 19, false);
-        c &= 0x7FFFFu;
-        ct += 8;
-      }
-    } while (a < 0x8000u);
+    // renormalisation (D.1.6): a is in [1, 0x7FFF] here, n >= 1 shifts bring it back to [0x8000, 0xFFFF]
+    int n = __builtin_clz(a) - 16;
+    while (n >= ct) {
+      a <<= ct; c <<= ct; n -= ct;
+      shift_out(c >> 19, false);
+      c &= 0x7FFFFu;
+      ct = 8;
+    }
+    a <<= n; c <<= n; ct -= n;
   }
 };
 
@@ -197,9 +198,9 @@ __device__ __forceinline__ void ari_dc(AriCoder &A, AriModel &M, int tbl, int &l
 
 // Encode_AC_Coefficients: encode_mcu_AC_first jcarith.c:456-552; with Ss = 1, Se = 63, Al = 0 the AC part of encode_mcu :764-817.
 // ke = the block's end-of-block index for this scan (jcarith.c:484-496), found by the lane that loaded the block
-__device__ __forceinline__ void ari_ac_first(AriCoder &A, AriModel &M, int tbl, int Ss, int Se, int Al, int ke)
+__device__ __forceinline__ void ari_ac_first(AriCoder &A, AriModel &M, int Ss, int Se, int Al, int ke)
 {
-  const int base = ARI_AC(tbl, 0);
+  const int base = 0;
   int k, v;
   for (k = Ss; k <= ke; k++) {
     int st = base + 3 * (k - 1);
@@ -223,9 +224,9 @@ __device__ __forceinline__ void ari_ac_first(AriCoder &A, AriModel &M, int tbl, 
 }
 
 // encode_mcu_AC_refine jcarith.c:596-687
-__device__ __forceinline__ void ari_ac_refine(AriCoder &A, AriModel &M, int tbl, int Ss, int Se, int Ah, int Al, int ke, int kex)
+__device__ __forceinline__ void ari_ac_refine(AriCoder &A, AriModel &M, int Ss, int Se, int Ah, int Al, int ke, int kex)
 {
-  const int base = ARI_AC(tbl, 0);
+  const int base = 0;
   int k, v;
   for (k = Ss; k <= ke; k++) {
     int st = base + 3 * (k - 1);
@@ -326,7 +327,7 @@ __device__ __forceinline__ void ari_reset_stats(AriModel &M, AriChain &ch, const
 
 __device__ __forceinline__ void ari_init_model(AriModel &M, int lane)
 {
-  M.ac[0] = M.ac[1] = M.dc = M.coef = 0;
+  M.ac[0] = M.ac[1] = M.cur = M.dc = M.coef = 0;
   M.tab[0] = (int)(((unsigned)mjh_ari_qe[lane] << 16) | ((unsigned)mjh_ari_nmps[lane] << 8) | (unsigned)mjh_ari_nlps[lane]);
   const int j = lane + 64 < 114 ? lane + 64 : 113;
   M.tab[1] = (int)(((unsigned)mjh_ari_qe[j] << 16) | ((unsigned)mjh_ari_nmps[j] << 8) | (unsigned)mjh_ari_nlps[j]);
@@ -386,13 +387,17 @@ __device__ __forceinline__ void ari_run(const MjhConst &C, const AriScan &sc, in
         const int td = pick4(sc.td, ci), ta = pick4(sc.ta, ci);
         int last = pick4(ch.last_dc, ci), ctx = pick4(ch.ctx, ci);
         const int dc = ari_coef(M, 0);
+        const int am = -(ta & 1);                 // all ones: the block's AC statistics are table 1's
+        M.cur = (M.ac[1] & am) | (M.ac[0] & ~am);
         if (whole_blocks) {
           ari_dc(A, M, td & 1, last, ctx, dc);
-          ari_ac_first(A, M, ta & 1, 1, 63, 0, ke);
+          ari_ac_first(A, M, 1, 63, 0, ke);
         } else if (sc.Ss == 0 && sc.Ah == 0) ari_dc(A, M, td & 1, last, ctx, dc >> Al);
         else if (sc.Ss == 0) A.encode<3>(M, ARI_FIXED, (dc >> Al) & 1);                    // encode_mcu_DC_refine :560-590
-        else if (sc.Ah == 0) ari_ac_first(A, M, ta & 1, sc.Ss, sc.Se, Al, ke);
-        else ari_ac_refine(A, M, ta & 1, sc.Ss, sc.Se, sc.Ah, Al, ke, kex);
+        else if (sc.Ah == 0) ari_ac_first(A, M, sc.Ss, sc.Se, Al, ke);
+        else ari_ac_refine(A, M, sc.Ss, sc.Se, sc.Ah, Al, ke, kex);
+        M.ac[0] = (M.cur & ~am) | (M.ac[0] & am);
+        M.ac[1] = (M.cur & am) | (M.ac[1] & ~am);
         if (ci == 0) { ch.last_dc[0] = last; ch.ctx[0] = ctx; } else if (ci == 1) { ch.last_dc[1] = last; ch.ctx[1] = ctx; }
         else if (ci == 2) { ch.last_dc[2] = last; ch.ctx[2] = ctx; } else { ch.last_dc[3] = last; ch.ctx[3] = ctx; }
       }
