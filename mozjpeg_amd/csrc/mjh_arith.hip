@@ -14,240 +14,11 @@
 #include <stdint.h>
 #include "mjh_internal.h"
 #include "mjh_device.h"
-#include "mjh_arith_table.h"
 #include "mjh_launch.h"
 
-#define ARI_DC_L 0     // conditioning defaults (jcparam.c:417-419); the DAC marker carries them
-#define ARI_DC_U 1
-#define ARI_AC_K 5
+#include "mjh_arith_coder.h"      // the coder itself and the decision sequences (compiles for the host too: tests/native/arith_coder_check.cpp)
 
 // zig-zag -> natural is not needed: the pipeline's coefficient planes are in zig-zag order already (plane k = position k)
-
-// ---- the wave as a scalar machine ---------------------------------------------------------------------------------
-// Every lane of the coding wave executes the coder with the same (wave-uniform) values, so the compiler keeps the coder's
-// registers in SGPRs and its branches are scalar jumps (a first version ran it on lane 0 alone: vector instructions with
-// one live lane, both sides of every branch issued, the statistics bins behind dependent LDS round trips -- 540 ns per
-// binary decision).  The coder's MEMORY -- statistics bins, the probability table, the block being coded -- lives in
-// vector registers used as 64-entry RAMs: entry i = lane i, read with v_readlane_b32, written with v_writelane_b32.
-__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ int wl(int val, int lane, int old)
-{ // (this compiler has no writelane builtin; the s_nop covers the lane-select hazard the hazard recognizer cannot see inside asm)
-  // (lane select through M0: a VALU instruction may read one SGPR over the constant bus, M0 does not count)
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(__builtin_amdgcn_readfirstlane(val)), "s"(__builtin_amdgcn_readfirstlane(lane)) : "m0");
-  return old;
-}
-
-struct AriModel {      // vector registers as RAM
-  int ac[2];           // AC statistics of table 0 / 1: 256 bins each, four per lane (byte j of lane i = bin 4i + j)
-  int cur;             // the AC statistics of the table of the block being coded (bound / put back around every block: the coder
-                       // itself never chooses between registers)
-  int dc;              // DC statistics: table 0 in lanes 0..15, table 1 in lanes 16..31 (64 bins each)
-  int tab[2];          // T.81 Table D.3, entries 0..63 / 64..113: Qe << 16 | next state after an MPS << 8 | after an LPS (bit 7: MPS flips)
-  int coef;            // the block being coded: lane k = coefficient k (zig-zag)
-};
-// a statistics bin: space << 8 | index; space 0 = AC (the bound table), 2 = DC (index = 64 * table + bin), 3 = the fixed 0.5 bin
-#define ARI_DC(t, i) ((2 << 8) | ((t) << 6) | (i))
-#define ARI_FIXED (3 << 8)
-
-struct AriCoder {      // jcarith.c:28-52, all wave-uniform
-  unsigned c, a;
-  int sc, zc, ct, buffer;
-  uint8_t *out;        // nullptr: only sizes
-  unsigned pos, cap;
-  bool lane0;
-  __device__ __forceinline__ void byte(int v)
-  {
-    if (lane0 && out && pos < cap) out[pos] = (uint8_t)v;
-    pos++;
-  }
-  __device__ __forceinline__ void zeros() { while (zc) { byte(0x00); zc--; } }
-  __device__ __forceinline__ void reset() { c = 0; a = 0x10000u; sc = 0; zc = 0; ct = 11; buffer = -1; }
-  // a byte leaves the code register (D.1.6) or the register is flushed (D.1.8): jcarith.c:278-316 / :160-190
-  __device__ __forceinline__ void shift_out(unsigned temp, bool final)
-  {
-    if (final ? (c & 0xF8000000u) != 0u : temp > 0xFFu) {
-      if (buffer >= 0) {
-        zeros();
-        byte(buffer + 1);
-        if (buffer + 1 == 0xFF) byte(0x00);
-      }
-      zc += sc;
-      sc = 0;
-      if (!final) buffer = (int)(temp & 0xFFu);
-    } else if (!final && temp == 0xFFu) {
-      sc++;
-    } else {
-      if (buffer == 0) zc++;
-      else if (buffer >= 0) { zeros(); byte(buffer); }
-      if (sc) {
-        zeros();
-        do { byte(0xFF); byte(0x00); } while (--sc);
-      }
-      if (!final) buffer = (int)(temp & 0xFFu);
-    }
-  }
-  __device__ __forceinline__ void finish()      // finish_pass jcarith.c:142-203
-  {
-    const unsigned temp = (a - 1u + c) & 0xFFFF0000u;
-    c = temp < c ? temp + 0x8000u : temp;
-    c <<= ct;
-    shift_out(0u, true);
-    if (c & 0x7FFF800u) {
-      zeros();
-      byte((int)((c >> 19) & 0xFFu));
-      if (((c >> 19) & 0xFFu) == 0xFFu) byte(0x00);
-      if (c & 0x7F800u) {
-        byte((int)((c >> 11) & 0xFFu));
-        if (((c >> 11) & 0xFFu) == 0xFFu) byte(0x00);
-      }
-    }
-  }
-  // arith_encode jcarith.c:229-320.  The kind of bin is known at every call site: SP = 0 an AC bin of the bound table, 2 a DC
-  // bin, 3 the fixed 0.5 bin (state 113 never adapts: no RAM access at all, Qe = 0x5a1d).  Written for a lone wave, whose taken
-  // branches cost several instruction slots each: both halves of the probability table are read and one is selected, the
-  // more / less probable paths share their arithmetic through selects, and the renormalisation shifts by the whole distance
-  // at once (count-leading-zeros) instead of bit by bit -- the same integer operations as the reference's loop, which only
-  // ever looks at the registers when the shift counter reaches a byte boundary.  One branch stays: the common exit of a more
-  // probable symbol that needs no renormalisation.
-  template <int SP>
-  __device__ __forceinline__ void encode(AriModel &M, int bin, int val)
-  {
-    const int i = bin & 0xFF, sh = 8 * (i & 3);
-    int word = 0;
-    unsigned sv = 113u, t;
-    if (SP == 3) t = ((unsigned)mjh_ari_qe[113] << 16) | (113u << 8) | 113u;
-    else {
-      word = SP == 2 ? rl(M.dc, i >> 2) : rl(M.cur, i >> 2);
-      sv = ((unsigned)word >> sh) & 0xFFu;
-      const int s = (int)(sv & 0x7Fu);
-      const unsigned lo = (unsigned)rl(M.tab[0], s & 63), hi = (unsigned)rl(M.tab[1], s & 63);
-      t = s < 64 ? lo : hi;
-    }
-    const unsigned qe = t >> 16;
-    const bool lps = (unsigned)val != (sv >> 7);
-    a -= qe;
-    if (!lps && a >= 0x8000u) return;
-    const bool exchange = lps ? a >= qe : a < qe;      // conditional exchange (D.1.4 / D.1.5)
-    c += exchange ? a : 0u;
-    a = exchange ? qe : a;
-    if (SP != 3) {
-      const unsigned ns = (sv & 0x80u) ^ ((lps ? t : t >> 8) & 0xFFu);
-      word = (int)(((unsigned)word & ~(0xFFu << sh)) | (ns << sh));
-      if (SP == 2) M.dc = wl(word, i >> 2, M.dc);
-      else M.cur = wl(word, i >> 2, M.cur);
-    }
-    // renormalisation (D.1.6): a is in [1, 0x7FFF] here, n >= 1 shifts bring it back to [0x8000, 0xFFFF]
-    int n = __builtin_clz(a) - 16;
-    while (n >= ct) {
-      a <<= ct; c <<= ct; n -= ct;
-      shift_out(c >> 19, false);
-      c &= 0x7FFFFu;
-      ct = 8;
-    }
-    a <<= n; c <<= n; ct -= n;
-  }
-};
-
-__device__ __forceinline__ int ari_coef(const AriModel &M, int k) { return (int)(short)rl(M.coef, k); }
-
-// Figures F.8 / F.9: magnitude category and magnitude bits of v >= 1.  st = first magnitude bin; DC: the category bins continue
-// at 20; AC: the bin itself once more, then 189 (k <= Kx) / 217.  base = the table's bin 0.  Returns the category mask.
-template <bool AC>
-__device__ __forceinline__ int ari_magnitude(AriCoder &A, AriModel &M, int base, int st, int v, int k)
-{
-  constexpr int SP = AC ? 0 : 2;
-  const bool ac = AC;
-  int m = 0;
-  if (v -= 1) {
-    A.encode<SP>(M, st, 1);
-    m = 1;
-    int v2 = v;
-    if (ac) {
-      if (v2 >>= 1) {
-        A.encode<SP>(M, st, 1);
-        m <<= 1;
-        st = base + (k <= ARI_AC_K ? 189 : 217);
-        while (v2 >>= 1) { A.encode<SP>(M, st, 1); m <<= 1; st++; }
-      }
-    } else {
-      st = base + 20;
-      while (v2 >>= 1) { A.encode<SP>(M, st, 1); m <<= 1; st++; }
-    }
-  }
-  A.encode<SP>(M, st, 0);
-  st += 14;
-  for (int mm = m >> 1; mm; mm >>= 1) A.encode<SP>(M, st, (mm & v) ? 1 : 0);
-  return m;
-}
-
-// Encode_DC_DIFF (jcarith.c:402-448 / :715-762)
-__device__ __forceinline__ void ari_dc(AriCoder &A, AriModel &M, int tbl, int &last_dc, int &ctx, int value)
-{
-  const int base = ARI_DC(tbl, 0);
-  int st = base + ctx;
-  int v = value - last_dc;
-  if (v == 0) { A.encode<2>(M, st, 0); ctx = 0; return; }
-  last_dc = value;
-  A.encode<2>(M, st, 1);
-  if (v > 0) { A.encode<2>(M, st + 1, 0); st += 2; ctx = 4; }
-  else { v = -v; A.encode<2>(M, st + 1, 1); st += 3; ctx = 8; }
-  const int m = ari_magnitude<false>(A, M, base, st, v, 0);
-  if (m < (int)((1L << ARI_DC_L) >> 1)) ctx = 0;
-  else if (m > (int)((1L << ARI_DC_U) >> 1)) ctx += 8;
-}
-
-// Encode_AC_Coefficients: encode_mcu_AC_first jcarith.c:456-552; with Ss = 1, Se = 63, Al = 0 the AC part of encode_mcu :764-817.
-// ke = the block's end-of-block index for this scan (jcarith.c:484-496), found by the lane that loaded the block
-__device__ __forceinline__ void ari_ac_first(AriCoder &A, AriModel &M, int Ss, int Se, int Al, int ke)
-{
-  const int base = 0;
-  int k, v;
-  for (k = Ss; k <= ke; k++) {
-    int st = base + 3 * (k - 1);
-    int neg;
-    A.encode<0>(M, st, 0);
-    for (;;) {
-      v = ari_coef(M, k);
-      neg = v < 0;
-      if (neg) v = -v;
-      v >>= Al;
-      if (v) break;
-      A.encode<0>(M, st + 1, 0);
-      st += 3;
-      k++;
-    }
-    A.encode<0>(M, st + 1, 1);
-    A.encode<3>(M, ARI_FIXED, neg);
-    ari_magnitude<true>(A, M, base, st + 2, v, k);
-  }
-  if (k <= Se) A.encode<0>(M, base + 3 * (k - 1), 1);
-}
-
-// encode_mcu_AC_refine jcarith.c:596-687
-__device__ __forceinline__ void ari_ac_refine(AriCoder &A, AriModel &M, int Ss, int Se, int Ah, int Al, int ke, int kex)
-{
-  const int base = 0;
-  int k, v;
-  for (k = Ss; k <= ke; k++) {
-    int st = base + 3 * (k - 1);
-    if (k > kex) A.encode<0>(M, st, 0);
-    for (;;) {
-      v = ari_coef(M, k);
-      const int neg = v < 0;
-      if (neg) v = -v;
-      v >>= Al;
-      if (v) {
-        if (v >> 1) A.encode<0>(M, st + 2, v & 1);
-        else { A.encode<0>(M, st + 1, 1); A.encode<3>(M, ARI_FIXED, neg); }
-        break;
-      }
-      A.encode<0>(M, st + 1, 0);
-      st += 3;
-      k++;
-    }
-  }
-  if (k <= Se) A.encode<0>(M, base + 3 * (k - 1), 1);
-}
 
 // The scan being coded, in registers and wave-uniform FOR THE COMPILER (readfirstlane): a MjhProgScan copied as a struct lands
 // in scratch memory as soon as one of its arrays is indexed dynamically, scratch loads count as divergent, and everything
@@ -311,26 +82,52 @@ struct AriChain {      // what the coder carries from block to block (wave-unifo
 };
 
 __device__ __forceinline__ void ari_reset_stats(AriModel &M, AriChain &ch, const AriScan &sc, bool progressive, int lane)
-{ // start_pass jcarith.c:845-875, emit_restart :328-342
+{ // start_pass jcarith.c:845-875, emit_restart :328-342 (every bin of the tables in use: state 0, MPS 0)
+  (void)lane;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     if (i >= sc.ncomp) continue;
     if (!progressive || (sc.Ss == 0 && sc.Ah == 0)) {
-      const int t = sc.td[i] & 1;
-      if ((lane >> 4) == t) M.dc = 0;       // (lanes 32..63 of the DC register are unused)
+      if (sc.td[i] & 1) M.dc[1] = ARI_BIN_RESET; else M.dc[0] = ARI_BIN_RESET;
       ch.last_dc[i] = 0;
       ch.ctx[i] = 0;
     }
-    if (!progressive || sc.Se) { if (sc.ta[i] & 1) M.ac[1] = 0; else M.ac[0] = 0; }
+    if (!progressive || sc.Se) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) { if (sc.ta[i] & 1) M.ac[1][r] = ARI_BIN_RESET; else M.ac[0][r] = ARI_BIN_RESET; }
+    }
   }
 }
 
 __device__ __forceinline__ void ari_init_model(AriModel &M, int lane)
 {
-  M.ac[0] = M.ac[1] = M.cur = M.dc = M.coef = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) { M.ac[0][r] = M.ac[1][r] = ARI_BIN_RESET; M.cur[r] = ARI_BIN_RESET; }
+  M.dc[0] = M.dc[1] = M.dcur = ARI_BIN_RESET;
+  M.coef = 0;
   M.tab[0] = (int)(((unsigned)mjh_ari_qe[lane] << 16) | ((unsigned)mjh_ari_nmps[lane] << 8) | (unsigned)mjh_ari_nlps[lane]);
   const int j = lane + 64 < 114 ? lane + 64 : 113;
   M.tab[1] = (int)(((unsigned)mjh_ari_qe[j] << 16) | ((unsigned)mjh_ari_nmps[j] << 8) | (unsigned)mjh_ari_nlps[j]);
+}
+
+// the statistics of the block's tables are bound to fixed registers while it is coded, and put back behind it
+__device__ __forceinline__ void ari_bind(AriModel &M, int ta, int td)
+{
+  const int am = -(ta & 1), dm = -(td & 1);      // all ones: table 1
+#pragma unroll
+  for (int r = 0; r < 4; r++) M.cur[r] = (M.ac[1][r] & am) | (M.ac[0][r] & ~am);
+  M.dcur = (M.dc[1] & dm) | (M.dc[0] & ~dm);
+}
+__device__ __forceinline__ void ari_unbind(AriModel &M, int ta, int td)
+{
+  const int am = -(ta & 1), dm = -(td & 1);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    M.ac[0][r] = (M.cur[r] & ~am) | (M.ac[0][r] & am);
+    M.ac[1][r] = (M.cur[r] & am) | (M.ac[1][r] & ~am);
+  }
+  M.dc[0] = (M.dcur & ~dm) | (M.dc[0] & dm);
+  M.dc[1] = (M.dcur & dm) | (M.dc[1] & ~dm);
 }
 
 // One chain: the units [u0, u1) of scan `sc` (an MCU = bpm units) run through the coder.  whole_blocks: DC + AC 1..63 of every
@@ -387,17 +184,15 @@ __device__ __forceinline__ void ari_run(const MjhConst &C, const AriScan &sc, in
         const int td = pick4(sc.td, ci), ta = pick4(sc.ta, ci);
         int last = pick4(ch.last_dc, ci), ctx = pick4(ch.ctx, ci);
         const int dc = ari_coef(M, 0);
-        const int am = -(ta & 1);                 // all ones: the block's AC statistics are table 1's
-        M.cur = (M.ac[1] & am) | (M.ac[0] & ~am);
+        ari_bind(M, ta, td);
         if (whole_blocks) {
-          ari_dc(A, M, td & 1, last, ctx, dc);
+          ari_dc(A, M, last, ctx, dc);
           ari_ac_first(A, M, 1, 63, 0, ke);
-        } else if (sc.Ss == 0 && sc.Ah == 0) ari_dc(A, M, td & 1, last, ctx, dc >> Al);
-        else if (sc.Ss == 0) A.encode<3>(M, ARI_FIXED, (dc >> Al) & 1);                    // encode_mcu_DC_refine :560-590
+        } else if (sc.Ss == 0 && sc.Ah == 0) ari_dc(A, M, last, ctx, dc >> Al);
+        else if (sc.Ss == 0) A.encode<ARI_F>(M, 0, (dc >> Al) & 1);                        // encode_mcu_DC_refine :560-590
         else if (sc.Ah == 0) ari_ac_first(A, M, sc.Ss, sc.Se, Al, ke);
         else ari_ac_refine(A, M, sc.Ss, sc.Se, sc.Ah, Al, ke, kex);
-        M.ac[0] = (M.cur & ~am) | (M.ac[0] & am);
-        M.ac[1] = (M.cur & am) | (M.ac[1] & ~am);
+        ari_unbind(M, ta, td);
         if (ci == 0) { ch.last_dc[0] = last; ch.ctx[0] = ctx; } else if (ci == 1) { ch.last_dc[1] = last; ch.ctx[1] = ctx; }
         else if (ci == 2) { ch.last_dc[2] = last; ch.ctx[2] = ctx; } else { ch.last_dc[3] = last; ch.ctx[3] = ctx; }
       }
@@ -614,6 +409,7 @@ k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
 #pragma unroll
   for (int i = 0; i < 4; i++) { sc.comp[i] = 0; sc.td[i] = ARI_U(cc.dctbl); sc.ta[i] = ARI_U(cc.actbl); sc.comp_id[i] = 0; sc.h[i] = 1; sc.v[i] = 1; }
   ari_init_model(M, lane);
+  for (int i = tid; i < 64 + 256; i += 256) s_state[i] = 0;   // (bins 245..255 do not exist: their rates are never read)
   A.lane0 = false; A.out = nullptr; A.pos = 0; A.cap = 0;     // nothing is written: only the statistics move
   A.reset();
   for (int i = 0; i < MJH_MAXC; i++) { ch.last_dc[i] = 0; ch.ctx[i] = 0; }
@@ -622,10 +418,15 @@ k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
   for (int br0 = 0; br0 < cc.hib; br0 += cc.v) {
     const int rows = br0 + cc.v <= cc.hib ? cc.v : cc.hib - br0;
     // ---- rates of this iMCU row (jget_arith_rates): the coding wave's bins -> LDS -> 320 table look-ups
-    if (wave == 0) {
-      const int acw = (cc.actbl & 1) ? M.ac[1] : M.ac[0];
-      for (int j = 0; j < 4; j++) s_state[64 + 4 * lane + j] = (unsigned char)((unsigned)acw >> (8 * j));
-      if ((lane >> 4) == (cc.dctbl & 1)) for (int j = 0; j < 4; j++) s_state[4 * (lane & 15) + j] = (unsigned char)((unsigned)M.dc >> (8 * j));
+    if (wave == 0) {      // bin 3 p + kind of jcarith.c's AC numbering = lane p of register `kind`, 189 + x = lane x of the tail register
+      const int am = -(cc.actbl & 1), dm = -(cc.dctbl & 1);
+      const int be = (M.ac[1][ARI_E] & am) | (M.ac[0][ARI_E] & ~am), bz = (M.ac[1][ARI_Z] & am) | (M.ac[0][ARI_Z] & ~am);
+      const int bm = (M.ac[1][ARI_M] & am) | (M.ac[0][ARI_M] & ~am), bx = (M.ac[1][ARI_X] & am) | (M.ac[0][ARI_X] & ~am);
+      if (lane < 63) {
+        s_state[64 + 3 * lane] = (unsigned char)be; s_state[64 + 3 * lane + 1] = (unsigned char)bz; s_state[64 + 3 * lane + 2] = (unsigned char)bm;
+      }
+      if (lane < 56) s_state[64 + 189 + lane] = (unsigned char)bx;
+      s_state[lane] = (unsigned char)((M.dc[1] & dm) | (M.dc[0] & ~dm));
     }
     __syncthreads();
     for (int i = tid; i < 64 + 256; i += 256) {

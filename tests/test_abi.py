@@ -232,3 +232,19 @@ def test_traffic_figures_are_quoted_only_for_the_kernels_they_were_measured_on(m
     for p in new:
         j = json.load(open(p))
         assert len(j.get("kernel_source_stamp", "")) == 16 and j.get("profile_head"), p
+
+
+def test_arithmetic_coder_on_the_host_matches_a_plain_restatement_of_jcarith(tmp_path):
+    """mozjpeg_amd/csrc/mjh_arith_coder.h compiles for the host (a vector register = an array of 64 ints):
+    tests/native/arith_coder_check.cpp runs the product's coder -- bins by kind, one per lane, Qe cached in the bin, bound
+    tables, renormalisation by count-leading-zeros -- against a plain restatement of jcarith.c (flat state bytes, bit-by-bit
+    renormalisation) on random whole-block / DC / AC first / AC refinement scans with restarts, and compares bytes, registers
+    and every statistics bin."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no host C++ compiler")
+    exe = str(tmp_path / "arith_coder_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "arith_coder_check.cpp")])
+    out = subprocess.run([exe, "300", "4242"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "identical" in out.stdout, out.stdout[-2000:]
