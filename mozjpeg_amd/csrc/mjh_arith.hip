@@ -144,19 +144,32 @@ __device__ __forceinline__ void ari_run(const MjhConst &C, const AriScan &sc, in
     int kev = 0, kexv = 0, infov = 0;      // per lane: end-of-block indices and component / MCU-start flag of ITS block
     if (coder) {
       const AriUnit un = ari_unit(C, sc, bpm, base + lane, u1);
-      const MjhComp &cc = C.c[un.comp];
-      const int16_t *q = qimg + cc.coef_off;
+      // (the component's layout once per group of blocks, in registers: read through the reference inside the loop below it
+      // was fetched again for every coefficient, one more memory round trip in front of each load)
+      const int ks = C.c[un.comp].kstride, coff = C.c[un.comp].coef_off;
+      const int16_t *q = qimg + coff;
       short *row = s_blk + lane * 64;
       if (Ss == 0) row[0] = q[un.dc_blk];
       if (Se > 0) {
         // (from position 1: the end-of-block searches of the AC scans look below Ss as well, jcarith.c:484-496); the last
-        // position that is non-zero after the point transform by Al (ke), and by Ah below it (kex, refinement scans)
+        // position that is non-zero after the point transform by Al (ke), and by Ah below it (kex, refinement scans).
+        // Eight loads in flight at a time, all unconditional (a dummy block's index is a real block's, positions behind Se
+        // read Se again): a wave that waits for every load separately spends 63 memory round trips per group of blocks here.
         const int al = whole_blocks ? 0 : Al, ah = whole_blocks ? 0 : sc.Ah;
-        for (int k = 1; k <= Se; k++) {
-          const short v = un.dummy ? (short)0 : q[(size_t)k * cc.kstride + un.blk];
-          row[k] = v;
-          const int av = v < 0 ? -(int)v : (int)v;
-          if (av >> al) kev = k;
+        const int16_t *qb = q + un.blk;
+        for (int k0 = 1; k0 <= Se; k0 += 8) {
+          short v[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) { const int kk = k0 + j <= Se ? k0 + j : Se; v[j] = qb[(size_t)kk * ks]; }
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            if (k0 + j <= Se) {
+              const short vv = un.dummy ? (short)0 : v[j];
+              row[k0 + j] = vv;
+              const int av = vv < 0 ? -(int)vv : (int)vv;
+              if (av >> al) kev = k0 + j;
+            }
+          }
         }
         if (ah) { for (int k = 1; k <= kev; k++) { const int v = row[k], av = v < 0 ? -v : v; if (av >> ah) kexv = k; } }
       }
@@ -534,56 +547,81 @@ k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
         if (wave == 0) {
           const int dq = 8 * q0;
           const float lt0 = Q->lambda_tbl[qt][0];
-          for (int bi = 0; bi < cc.wib; bi++) {
-            const int cur = bi & 1, prv = cur ^ 1;
-            if (lane < ncand) {
-              const int xs = uq[row0 + bi];
-              const int sign = xs < 0 ? -1 : 0, x = xs < 0 ? -xs : xs;
-              const int qval = (x + (dq >> 1)) / dq;
-              const float lambda_dc = lam[row0 + bi] * lt0;
-              int cnd = qval - ncand / 2 + lane;
-              int delta = cnd * dq - x;
-              float dist = (float)(delta * delta) * lambda_dc;
-              cnd *= 1 + 2 * sign;
-              if (rr > 0 && delta_dc_weight > 0.0f) {       // the block above inside the iMCU row (jcdctmgr.c:1440-1456)
-                const int above_orig = uq[row0 - cc.wib + bi], above_recon = (int)q[row0 - cc.wib + bi] * dq;
-                delta = (above_orig - xs) - (above_recon - cnd * dq);
-                const float vertical = (float)(delta * delta) * lambda_dc;
-                float t = vertical - dist;
-                t = delta_dc_weight * t;
-                dist = dist + t;
+          const bool vert = rr > 0 && delta_dc_weight > 0.0f;
+          // forward, 64 blocks at a time: the lanes fetch what the chunk's blocks need in one go, the steps of the chain
+          // read it with v_readlane (a global load per step would put its latency into every link of the chain)
+          for (int c0 = 0; c0 < cc.wib; c0 += 64) {
+            const int nb = cc.wib - c0 < 64 ? cc.wib - c0 : 64;
+            const int bl = c0 + (lane < nb ? lane : nb - 1);
+            const int xs_l = uq[row0 + bl];
+            const float lam_l = lam[row0 + bl] * lt0;
+            int ao_l = 0, ar_l = 0;
+            if (vert) { ao_l = uq[row0 - cc.wib + bl]; ar_l = (int)q[row0 - cc.wib + bl] * dq; }
+            for (int b = 0; b < nb; b++) {
+              const int bi = c0 + b;
+              const int cur = bi & 1, prv = cur ^ 1;
+              const int xs = rl(xs_l, b);
+              const float lambda_dc = __int_as_float(rl(__float_as_int(lam_l), b));
+              const int above_orig = rl(ao_l, b), above_recon = rl(ar_l, b);
+              if (lane < ncand) {
+                const int sign = xs < 0 ? -1 : 0, x = xs < 0 ? -xs : xs;
+                const int qval = (x + (dq >> 1)) / dq;
+                int cnd = qval - ncand / 2 + lane;
+                int delta = cnd * dq - x;
+                float dist = (float)(delta * delta) * lambda_dc;
+                cnd *= 1 + 2 * sign;
+                if (vert) {       // the block above inside the iMCU row (jcdctmgr.c:1440-1456)
+                  delta = (above_orig - xs) - (above_recon - cnd * dq);
+                  const float vertical = (float)(delta * delta) * lambda_dc;
+                  float t = vertical - dist;
+                  t = delta_dc_weight * t;
+                  dist = dist + t;
+                }
+                float best = 0.0f;
+                int bb = -1, bctx = 0;
+                const int nl = bi == 0 ? 1 : ncand;
+                for (int l = 0; l < nl; l++) {
+                  const int pred = bi == 0 ? s_lastdc : dc_cand[prv][l];
+                  int upd;
+                  const float bits = ari_dc_bits(rdc, bi == 0 ? 0 : dc_ctx[prv][l], cnd - pred, upd);
+                  float cost = bits + dist;
+                  if (bi != 0) cost += dc_cost[prv][l];
+                  if (l == 0 || cost < best) { best = cost; bb = bi == 0 ? -1 : l; bctx = upd; }
+                }
+                dc_cost[cur][lane] = best; dc_ctx[cur][lane] = bctx; dc_cand[cur][lane] = cnd;
+                bk[(size_t)(row0 + bi) * 16 + lane] = (uint8_t)(bb < 0 ? 0 : bb);
               }
-              float best = 0.0f;
-              int bb = -1, bctx = 0;
-              const int nl = bi == 0 ? 1 : ncand;
-              for (int l = 0; l < nl; l++) {
-                const int pred = bi == 0 ? s_lastdc : dc_cand[prv][l];
-                int upd;
-                const float bits = ari_dc_bits(rdc, bi == 0 ? 0 : dc_ctx[prv][l], cnd - pred, upd);
-                float cost = bits + dist;
-                if (bi != 0) cost += dc_cost[prv][l];
-                if (l == 0 || cost < best) { best = cost; bb = bi == 0 ? -1 : l; bctx = upd; }
-              }
-              dc_cost[cur][lane] = best; dc_ctx[cur][lane] = bctx; dc_cand[cur][lane] = cnd;
-              bk[(size_t)(row0 + bi) * 16 + lane] = (uint8_t)(bb < 0 ? 0 : bb);
+              __builtin_amdgcn_wave_barrier();
+              __threadfence_block();
             }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
           }
-          if (lane == 0) {
+          // back-track, 64 blocks at a time from the end of the row: the chunk's back pointers (16 bytes per block) and
+          // values are fetched by the lanes, the walk itself touches registers only
+          int j = 0;
+          {
             const int cur = (cc.wib - 1) & 1;
-            int j = 0;
             for (int i = 1; i < ncand; i++) if (dc_cost[cur][i] < dc_cost[cur][j]) j = i;
-            for (int bi = cc.wib - 1; bi >= 0; bi--) {
-              const int xs = uq[row0 + bi];
-              const int sign = xs < 0 ? -1 : 0, x = xs < 0 ? -xs : xs;
-              const int qval = (x + (dq >> 1)) / dq;
-              const int cnd = (qval - ncand / 2 + j) * (1 + 2 * sign);
-              q[row0 + bi] = (int16_t)cnd;
-              if (bi == cc.wib - 1) s_lastdc = cnd;
-              j = bk[(size_t)(row0 + bi) * 16 + j];
-            }
+            j = __builtin_amdgcn_readfirstlane(j);
           }
+          int lastdc_new = 0;
+          for (int c0 = ((cc.wib - 1) >> 6) << 6; c0 >= 0; c0 -= 64) {
+            const int nb = cc.wib - c0 < 64 ? cc.wib - c0 : 64;
+            const int bl = c0 + (lane < nb ? lane : nb - 1);
+            const int xs_l = uq[row0 + bl];
+            const int sign_l = xs_l < 0 ? -1 : 0, x_l = xs_l < 0 ? -xs_l : xs_l;
+            const int base_l = (x_l + (dq >> 1)) / dq - ncand / 2;          // candidate 0 of the lane's block, before the sign
+            const uint4 bk4 = *reinterpret_cast<const uint4 *>(bk + (size_t)(row0 + bl) * 16);
+            int qout = 0;
+            for (int b = nb - 1; b >= 0; b--) {
+              const int cnd = (rl(base_l, b) + j) * (1 + 2 * rl(sign_l, b));
+              if (lane == b) qout = cnd;
+              if (c0 + b == cc.wib - 1) lastdc_new = cnd;
+              const unsigned w = j < 4 ? bk4.x : (j < 8 ? bk4.y : bk4.z);       // (j <= 8: nine candidates at most)
+              j = (int)(((unsigned)rl((int)w, b) >> (8 * (j & 3))) & 0xFFu);
+            }
+            if (lane < nb) q[row0 + c0 + lane] = (int16_t)qout;
+          }
+          if (lane == 0) s_lastdc = lastdc_new;
         }
         __threadfence_block();
         __syncthreads();
