@@ -12,6 +12,8 @@
 //
 // Reference behaviour each kernel reproduces is cited as file:line under /root/reference.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <type_traits>
 #include <stdlib.h>
@@ -351,24 +353,33 @@ __device__ __forceinline__ float catmull_rom(int v1, int v2, int v3, int v4, flo
 // FD: every quantizer step of the tables in use fits 8 bits -- the division by 8q is one shift + one 24-bit multiply-high
 // (MjhQuant.mdiv / sdiv) instead of the float-reciprocal division with its integer fix-up; with STATS the AC coefficients are
 // quantized for the statistics only, which need the magnitude category and nothing else (no sign, no signed clamp).
-template <class T, bool STATS, bool FD>   // uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
+// SORTED (8-bit samples feeding the tile-sorted AC trellis, k_trellis_ac_v3<.., SORTED>): the workgroup has FOUR waves = the
+// four 64-block lines of one trellis tile, every lane still owns one block; the waves exchange only the blocks' sort keys
+// (min(non-zero quantized AC coefficients, 63)) through LDS and store planes 1..63 of coef_uq at the block's place in the
+// tile's descending-key order instead of its natural place, plus perm_out[tile_base + place] = index in tile | key << 9 (the
+// trellis kernel's own permutation entry).  A pass of the trellis kernel then reads ONE line of every plane, each line once
+// (unsorted planes: every pass touches all four lines of the tile).  Plane 0 (DC), lambda, nq8 and coef_q stay in natural order.
+template <class T, bool STATS, bool FD, bool SORTED = false>   // uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
 __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant *__restrict__ Q, const T *__restrict__ planes,
                                                int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
-                                               MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out)
+                                               MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out,
+                                               uint16_t *__restrict__ perm_out = nullptr)
 {
   constexpr bool W12 = sizeof(T) == 2;
+  static_assert(!SORTED || !W12, "the tile-sorted layout feeds the (8-bit only) trellis");
   // 8 KB per wave: the deringing columns (the ORIGINAL level-shifted samples of the lane's block in zig-zag order, 16 bits
   // each for 8- and 12-bit data) and, afterwards, 8 interleaved copies of the 256-bin statistics histogram
   constexpr int LW = 32;
-  __shared__ int lds_raw[64][LW];
+  constexpr int NW = SORTED ? 4 : 1;      // waves per workgroup
+  __shared__ int lds_raw[NW][64][LW];
   typedef short dcol_t;
   typedef dcol_t __attribute__((may_alias)) dcol_alias;
-  dcol_alias (*lds)[64] = reinterpret_cast<dcol_alias (*)[64]>(&lds_raw[0][0]);
+  const int lane = threadIdx.x & 63, wv = SORTED ? (int)(threadIdx.x >> 6) : 0;
+  dcol_alias (*lds)[64] = reinterpret_cast<dcol_alias (*)[64]>(&lds_raw[wv][0][0]);
   const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
-  const int lane = threadIdx.x;
-  const int blk_raw = blockIdx.x * 64 + lane;
-  if (blockIdx.x * 64 >= cc.nblk) return;              // whole wave outside (grid is sized for the largest component)
+  const int blk_raw = blockIdx.x * (64 * NW) + wv * 64 + lane;
+  if (blockIdx.x * (64 * NW) >= cc.nblk) return;       // whole workgroup outside (grid is sized for the largest component)
   const bool valid = blk_raw < cc.nblk;                  // tail lanes redo the last block (identical stores), they only stay out of the statistics
   const int blk = valid ? blk_raw : cc.nblk - 1;
   const int br = blk / cc.wib, bc = blk - br * cc.wib;
@@ -482,7 +493,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
   constexpr bool stats = STATS;
   typedef unsigned __attribute__((may_alias)) hist_alias;
   constexpr int NCOPY = 8;
-  hist_alias *hist = reinterpret_cast<hist_alias *>(&lds_raw[0][0]);   // NCOPY interleaved copies of 256 bins (the deringing columns are dead)
+  hist_alias *hist = reinterpret_cast<hist_alias *>(&lds_raw[wv][0][0]);   // NCOPY interleaved copies of 256 bins (the deringing columns are dead)
   if (stats) {
 #pragma unroll
     for (int j = 0; j < NCOPY * 4; j++) hist[j * 64 + lane] = 0u;
@@ -498,7 +509,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
     if (FD && STATS && k > 0) {
       // statistics of the conventionally quantized block only (the trellis recomputes the values): magnitude category of
       // min(floor((|x| + 4q) / 8q), 1023) -- the signed clamp to +-1023 (jcdctmgr.c:761-770) leaves the category of 1023
-      uq[(size_t)k * cc.kstride] = (int16_t)x;
+      if (!SORTED) uq[(size_t)k * cc.kstride] = (int16_t)x;
       if (valid) {
         if (ax + (dq >> 1) >= dq) {
           int qa = udiv_mh(ax + (dq >> 1), Q->sdiv[cc.qtbl][k], Q->mdiv[cc.qtbl][k]);
@@ -514,7 +525,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
     int v = FD ? udiv_mh(ax + (dq >> 1), Q->sdiv[cc.qtbl][k], Q->mdiv[cc.qtbl][k]) : udiv_exact(ax + (dq >> 1), dq, rcp[k]);
     if (x < 0) v = -v;
     if (clampq) v = W12 ? max(-16383, min(16383, v)) : max(-1023, min(1023, v));
-    if (!W12) uq[(size_t)k * cc.kstride] = (int16_t)x;   // raw x8 coefficients only feed the (8-bit only) trellis
+    if (!W12 && (k == 0 || !SORTED)) uq[(size_t)k * cc.kstride] = (int16_t)x;   // raw x8 coefficients only feed the (8-bit only) trellis
     if (k == 0 || !STATS) qo[(size_t)k * cc.kstride] = (int16_t)v;   // STATS: the AC planes would never be read
     if (!stats && !W12 && k > 0) nzc += (v != 0);
     if (stats && k > 0 && valid) {
@@ -529,6 +540,36 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
     }
   }
   if (!W12 && nq8_out && valid) nq8_out[(size_t)img * C.total_real_blocks + cc.blk_off + blk] = (uint8_t)nzc;
+  if (SORTED) {
+    // counting sort of the tile's real blocks by descending key, as k_trellis_ac_v3's own prelude does it (equal keys in
+    // arrival order: the result does not depend on it); blocks behind the component's last one take no place
+    __shared__ unsigned s_sort[64];
+    const int tid = (int)threadIdx.x;
+    if (tid < 64) s_sort[tid] = 0u;
+    __syncthreads();
+    const unsigned key = (unsigned)(nzc > 63 ? 63 : nzc);
+    unsigned rank = 0u;
+    if (valid) rank = atomicAdd(&s_sort[key], 1u);
+    __syncthreads();
+    if (tid < 64) {                               // lane L: blocks with key 63-L; blocks with a larger key come first
+      const unsigned h = s_sort[63 - tid];
+      unsigned inc = h;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned nn = __shfl_up(inc, o, 64);
+        if (tid >= o) inc += nn;
+      }
+      s_sort[63 - tid] = inc - h;
+    }
+    __syncthreads();
+    if (valid) {
+      const unsigned place = s_sort[key] + rank;
+      int16_t *us = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + (size_t)blockIdx.x * 256 + place;
+#pragma unroll
+      for (int k = 1; k < 64; k++) us[(size_t)k * cc.kstride] = (int16_t)d[kZZ.v[k]];
+      perm_out[(size_t)img * C.total_real_blocks + cc.blk_off + (size_t)blockIdx.x * 256 + place] = (uint16_t)((unsigned)(wv * 64 + lane) | (key << 9));
+    }
+  }
   if (stats) {
     if (valid && run > 0) atomicAdd(&hh[0], 1u);
     __syncthreads();
@@ -552,6 +593,16 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
             MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out)
 {
   dct_quant_body<T, STATS, FD>(C, Q, planes, coef_uq, coef_q, lambda_out, stat_tabs, slots_per_image, stat_slot_of_comp, nq8_out);
+}
+
+template <bool STATS, bool FD>
+__global__ void __launch_bounds__(256)
+k_dct_quant_sorted(MjhConst C, const MjhQuant *__restrict__ Q, const uint8_t *__restrict__ planes,
+                   int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
+                   MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out,
+                   uint16_t *__restrict__ perm_out)
+{
+  dct_quant_body<uint8_t, STATS, FD, true>(C, Q, planes, coef_uq, coef_q, lambda_out, stat_tabs, slots_per_image, stat_slot_of_comp, nq8_out, perm_out);
 }
 // =============================================================================================
 // K2b  coefficient import: jpeg_write_coefficients jctrans.c:44 entropy-codes blocks the
@@ -1892,15 +1943,18 @@ __device__ __forceinline__ void v3_pair(const uint2 (*col)[64], const unsigned s
 // symbol (run p-pp-1, category of its magnitude) -- so they are counted here (LDS histogram, flushed once per tile) instead
 // of by one more pass over the compact records; deferred blocks are flagged (nq8 = 0xFF) for k_stats_ac_compact's
 // deferred-only form.
-template <int QN, int NPASS, bool FD, bool FST>
+// SORTED: planes 1..63 of coef_uq hold every tile's blocks in descending-key order already and perm16 holds the tile's
+// permutation (k_dct_quant_sorted): no sort here, pass p reads line p of every plane.
+template <int QN, int NPASS, bool FD, bool FST, bool SORTED = false>
 __global__ void __launch_bounds__(64)
 k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q,
                 const MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 ac_slot_of_comp, int4 tile0_of_comp,
                 const float *__restrict__ lambda_in, uint8_t *__restrict__ nq8, unsigned *__restrict__ worklist,
                 int16_t *__restrict__ dense, unsigned dense_cap, unsigned long long *__restrict__ nzmask,
-                MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp)
+                MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp, const uint16_t *__restrict__ perm16 = nullptr)
 {
   static_assert(QN >= 16 && QN <= 63 && NPASS >= 1 && NPASS <= 8, "queue capacity / passes");
+  static_assert(!SORTED || NPASS == 4, "the producer sorts tiles of 256 blocks");
   constexpr int TILE = 64 * NPASS;
   __shared__ unsigned fhist[FST ? 2 : 1][FST ? 256 : 1];   // FST: two interleaved copies of the symbol histogram of this tile
   __shared__ uint2 col[QN][64];          // tile sort scratch; per pass: queue records -> live entries {azd, acc} -> value column
@@ -1928,7 +1982,7 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
   }
   // ---- tile sort: descending key; perm entry = index in tile | key << 9 ----
   unsigned long long mine0 = 0ull, mine1 = 0ull;
-  {
+  if (!SORTED) {
     u_alias *hist = reinterpret_cast<u_alias *>(&col[0][0]);              // [64]
     us_alias *perm = reinterpret_cast<us_alias *>(&col[0][0]) + 128;      // [TILE], behind the histogram
     hist[lane] = 0u;
@@ -1966,9 +2020,11 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
   us_alias *colh = reinterpret_cast<us_alias *>(&col[0][0]);   // value of slot s: row s>>2, half-word s&3 of the lane's uint2
 #pragma unroll 1
   for (int pass = 0; pass < NPASS; pass++) {
-    const unsigned pe = (unsigned)(((pass < 4 ? mine0 : mine1) >> (16 * (pass & 3))) & 0xFFFFull);
+    const int spos = tile_base + pass * 64 + lane;         // SORTED: the lane's place in the tile's sorted order
+    const unsigned pe = SORTED ? (spos < cc.nblk ? (unsigned)perm16[gblk0 + spos] : 0u)
+                               : (unsigned)(((pass < 4 ? mine0 : mine1) >> (16 * (pass & 3))) & 0xFFFFull);
     const int blk = tile_base + (int)(pe & 511u);
-    const bool inside = blk < cc.nblk;
+    const bool inside = SORTED ? spos < cc.nblk : blk < cc.nblk;
     const size_t gblk = gblk0 + (inside ? blk : 0);
     if (__builtin_amdgcn_ballot_w64(inside && (pe >> 9) != 0u) == 0ull) {   // nothing quantizes to non-zero: all-zero blocks
       if (inside) nzmask[gblk] = 0ull;
@@ -1979,7 +2035,7 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     int nq = 0, qmax = 0;
     float azd63;
     {
-      const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + (inside ? blk : cc.nblk - 1);
+      const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + (inside ? (SORTED ? spos : blk) : cc.nblk - 1);
       short xs[64];
 #pragma unroll
       for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
@@ -3579,10 +3635,17 @@ static int max_nblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp;
 static int max_padblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp; i++) { int v = C.c[i].wpad * C.c[i].hpad; m = v > m ? v : m; } return m; }
 
 void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
-                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv)
+                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv, uint16_t *perm16)
 {
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
   const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
+  if (perm16) {   // tile-sorted coefficient planes for the tile-sorted trellis: one workgroup of four waves per 256-block tile
+    if (C.precision == 12 || !fastdiv || !nq8) { fprintf(stderr, "mjh_launch_dct: tile-sorted planes need 8-bit samples, the fast division and the key array\n"); abort(); }
+    dim3 gridt((max_nblk(C) + 255) / 256, C.ncomp, n);
+    if (stat_tabs) hipLaunchKernelGGL((k_dct_quant_sorted<true, true>), gridt, dim3(256), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8, perm16);
+    else hipLaunchKernelGGL((k_dct_quant_sorted<false, true>), gridt, dim3(256), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8, perm16);
+    return;
+  }
   if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t, false>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else if (stat_tabs && fastdiv) hipLaunchKernelGGL((k_dct_quant<uint8_t, true, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else if (stat_tabs) hipLaunchKernelGGL((k_dct_quant<uint8_t, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
@@ -3626,7 +3689,7 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
-                           uint8_t *nq8, int v3_passes, int fastdiv)
+                           uint8_t *nq8, int v3_passes, int fastdiv, const uint16_t *perm16)
 {
   // band-limited pass (use_scans_in_trellis), the per-block outputs of trellis_eob_opt, per-image tables (trellis_q_opt):
   // the EXT instantiations
@@ -3670,7 +3733,15 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     for (int i = C.ncomp; i < 4; i++) t0[i] = 0x7FFFFFFF;
     const int4 tv = make_int4(t0[0], t0[1], t0[2], t0[3]);
 #define LV3Q(QN, NP, FDV, FSV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, NP, FDV, FSV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask, st, ss)
+#define LV3S(QN, FSV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, 4, true, FSV, true>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask, st, ss, perm16)
 #define LV3(NP, FDV, FSV) LV3Q(16, NP, FDV, FSV)
+    if (perm16) {   // the planes are tile-sorted already (mjh_launch_dct with the same array): only the four-pass kernels read that layout
+      if (np != 4 || !fastdiv || small24) { fprintf(stderr, "mjh_launch_trellis_ac: tile-sorted planes with a plan that cannot read them\n"); abort(); }
+      if (variant >= 3 && !st) { if (variant == 3) LV3S(32, false); else LV3S(48, false); }
+      else if (variant > 0) { if (st) LV3S(24, true); else LV3S(24, false); }
+      else if (st) LV3S(16, true);
+      else LV3S(16, false);
+    } else
     if (small24) LV3Q(24, 1, true, false);
     else if (variant >= 3 && !st) {   // q90 and up: 32 / 48 records (20 / 30 KB of LDS per wave)
       if (variant == 3) { if (fastdiv) LV3Q(32, 4, true, false); else LV3Q(32, 4, false, false); }
@@ -3682,6 +3753,7 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     else if (!fastdiv) LV3(4, false, false);
     else switch (np) { case 8: LV3(8, true, false); break; case 4: LV3(4, true, false); break; case 2: LV3(2, true, false); break; default: LV3(1, true, false); break; }
 #undef LV3
+#undef LV3S
 #undef LV3Q
     if (variant >= 3 && !st)   // what is left has more than 32 records or a magnitude >= 16: one general tier that takes everything
       hipLaunchKernelGGL((k_trellis_ac_qd<63, false, false, true>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
