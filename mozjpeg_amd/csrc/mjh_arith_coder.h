@@ -39,12 +39,20 @@ static inline ari_reg &wl(int val, int lane, ari_reg &old) { old.v[lane & 63] = 
 #define ARI_MFN __device__ __forceinline__
 typedef int ari_reg;
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+#ifdef MJH_SIMT_HOST   // (tools/simt: v_writelane spelled out)
+__device__ __forceinline__ int wl(int val, int lane, int old)
+{
+  const int v = __builtin_amdgcn_readfirstlane(val), l = __builtin_amdgcn_readfirstlane(lane) & 63;
+  return simt::cur->lane == l ? v : old;
+}
+#else
 __device__ __forceinline__ int wl(int val, int lane, int old)
 { // (this compiler has no writelane builtin; the s_nop covers the lane-select hazard the hazard recognizer cannot see inside asm)
   // (lane select through M0: a VALU instruction may read one SGPR over the constant bus, M0 does not count)
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(__builtin_amdgcn_readfirstlane(val)), "s"(__builtin_amdgcn_readfirstlane(lane)) : "m0");
   return old;
 }
+#endif
 #endif
 
 // a bin's word when its state is 0 with MPS 0 (what a reset leaves behind): Qe of state 0 above the state byte

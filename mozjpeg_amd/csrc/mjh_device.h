@@ -1,6 +1,19 @@
 // mjh_device.h -- device helpers shared by the gfx950 kernel files (mjh_kernels.hip, mjh_prog.hip)
 #ifndef MJH_DEVICE_H
 #define MJH_DEVICE_H
+// MJH_DIVERGENT_SCOPE marks a divergent region (`if (act) { ... }`) that holds a cross-lane operation.  Nothing on the device;
+// the host emulator (tools/simt, test infrastructure) needs it to know that the lanes inside go before the lanes that
+// skipped the region and already wait where the wave reconverges.
+// MJH_WAVE_GROUPS(16) at the top of a kernel: its wave holds independent groups of 16 lanes (one chain per DPP row, cross-lane
+// operations never leave the row) that follow their own control flow.  Nothing on the device either.
+#ifndef MJH_SIMT_HOST
+#define MJH_DIVERGENT_SCOPE
+#define MJH_WAVE_GROUPS(n) ((void)0)
+#define MJH_WAVE_SYNC() ((void)0)
+#endif
+// MJH_WAVE_SYNC(): the lanes of a wave execute in lock step, so "every lane reads an LDS word, then lane 0 overwrites it" needs
+// no barrier on the device; the emulator runs the lanes one after the other between cross-lane operations and needs the point
+// between the reads and the write marked.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mjh_internal.h"

@@ -495,6 +495,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
   constexpr int NCOPY = 8;
   hist_alias *hist = reinterpret_cast<hist_alias *>(&lds_raw[wv][0][0]);   // NCOPY interleaved copies of 256 bins (the deringing columns are dead)
   if (stats) {
+    MJH_WAVE_SYNC();        // (the histogram lies over the other lanes' deringing columns, which they have all read by now)
 #pragma unroll
     for (int j = 0; j < NCOPY * 4; j++) hist[j * 64 + lane] = 0u;
     __syncthreads();
@@ -1260,6 +1261,7 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
       m = live; e = nlive; first = true; need = false;
     }
     if (!done) {
+      MJH_DIVERGENT_SCOPE;
       bool fin = false;
       if (__builtin_amdgcn_ballot_w64(ncd > 1) == 0ull)
         q_pair_step<1, LDS_ROWS>(si_rows, rate_rows, col, lane, m, e, first, n0, n1, azd_prev, i, x, dq, qval, ncd, lambda, lti, si_f0, f0f, best, bestp, bestk, fin);
@@ -1449,7 +1451,7 @@ __global__ void __launch_bounds__(64)
 k_trellis_eob_chain(MjhConst C, int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
                     int4 ac_slot_of_comp, int4 row0_of_comp, const float2 *__restrict__ eob_cost, const int *__restrict__ eob_has, int Ss, int Se)
 {
-  extern __shared__ unsigned char dyn_lds[];
+  HIP_DYNAMIC_SHARED(unsigned char, dyn_lds);
   const int img = blockIdx.y, row = blockIdx.x, lane = threadIdx.x;
   const int comp = row >= row0_of_comp.w ? 3 : row >= row0_of_comp.z ? 2 : row >= row0_of_comp.y ? 1 : 0;
   const int r0 = comp == 0 ? 0 : comp == 1 ? row0_of_comp.y : comp == 2 ? row0_of_comp.z : row0_of_comp.w;
@@ -2112,6 +2114,7 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
       lookup();
       if (act) {
+        MJH_DIVERGENT_SCOPE;
         float gap_old;
         if (__builtin_amdgcn_ballot_w64(ncd > 2) == 0ull)
           v3_pair<QN, 2>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk, gap_old);
@@ -2223,6 +2226,7 @@ k_trellis_dc(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restri
 {
   const int img = blockIdx.y;
   const int lane = threadIdx.x;
+  MJH_WAVE_GROUPS(16);
   const int k = lane & 15;
   const int chain = blockIdx.x * 4 + (lane >> 4);
   const int nchains = C.ncomp * C.mcu_rows;
@@ -2384,6 +2388,7 @@ k_trellis_dc2(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restr
 {
   const int img = blockIdx.y;
   const int lane = threadIdx.x;
+  MJH_WAVE_GROUPS(16);
   const int k = lane & 15;
   const int chain = blockIdx.x * 4 + (lane >> 4);
   const int nchains = C.ncomp * C.mcu_rows;
@@ -2573,17 +2578,25 @@ template <int CTRL> __device__ __forceinline__ float dpp_f0(float v)
 // hazard: 2 wait states), which the hazard recognizer cannot see across inline asm.
 template <int SHL> __device__ __forceinline__ float add_shl(float v, float d, bool first = false)
 {
+#ifdef MJH_SIMT_HOST   // (tools/simt: the same operation spelled with the builtin)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + SHL, 0xF, 0xF, true)) + d;
+#else
   float r;
   if (first) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_shl:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(d), "n"(SHL));
   else asm volatile("v_add_f32_dpp %0, %1, %2 row_shl:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(d), "n"(SHL));
   return r;
+#endif
 }
 template <int BC> __device__ __forceinline__ float add_bcast(float v, float d, bool first = false)
 {
+#ifdef MJH_SIMT_HOST
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + BC, 0xF, 0xF, false)) + d;
+#else
   float r;
   if (first) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(d), "n"(BC));
   else asm volatile("v_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(d), "n"(BC));
   return r;
+#endif
 }
 
 __global__ void __launch_bounds__(64)
@@ -2593,6 +2606,7 @@ k_trellis_dc3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restr
 {
   const int img = blockIdx.y;
   const int lane = threadIdx.x;
+  MJH_WAVE_GROUPS(16);
   const int k = lane & 15;                      // lane in the group = rank of its candidate VALUE
   const int chain = blockIdx.x * 4 + (lane >> 4);
   const int nchains = C.ncomp * C.mcu_rows;
@@ -2756,6 +2770,7 @@ k_trellis_dc3_fwd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__r
                   const MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 dc_slot_of_comp,
                   const float *__restrict__ lambda_in, uint8_t *__restrict__ back9, int *__restrict__ jfin, int16_t *__restrict__ qspec, int rows_total)
 {
+  MJH_WAVE_GROUPS(16);
   const int img = blockIdx.y;
   const int lane = threadIdx.x;
   const int k = lane & 15;

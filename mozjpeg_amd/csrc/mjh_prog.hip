@@ -144,6 +144,7 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
           while (__hip_atomic_load(&st_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)step) __builtin_amdgcn_s_sleep(1);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
           cur = st_cur;
+          MJH_WAVE_SYNC();          // (lane 0 overwrites st_cur below)
           unsigned cur_out = cur + tot;
           if (step_has_rst) {       // offsets depend on the byte alignment at every marker: walk the units in order
             unsigned c2 = cur;
@@ -400,6 +401,7 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
       while (__hip_atomic_load(&st_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)step) __builtin_amdgcn_s_sleep(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       EOBRUN = st_eobrun; BE = st_be; cur = st_cur;
+      MJH_WAVE_SYNC();              // (lane 0 overwrites the three below)
       unsigned out_off = 0;
       const int mrst = ri ? ((base + nvalid - 1) / ri) * ri : 0;          // a restart boundary inside this step?
       const bool step_has_rst = ri && mrst > 0 && mrst >= base;

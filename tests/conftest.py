@@ -20,8 +20,29 @@ except Exception:  # torch absent or no GPU: nothing to order
     pass
 
 
+def pytest_addoption(parser):
+    parser.addoption("--simt", action="store_true", default=False,
+                     help="development aid for a container without a GPU: run the -m gpu tests against the kernel SOURCES "
+                          "executed by the lock-step wave64 emulator (tools/simt) instead of libmozjpeg_hip.so")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if config.getoption("--simt"):
+        # test-side switch only: the package itself knows no other library than libmozjpeg_hip.so
+        sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools", "simt"))
+        import build_simt
+        import mozjpeg_amd
+        mozjpeg_amd.LIB_PATH = build_simt.build()
+        os.environ.setdefault("SIMT_STRICT", "1")
+
+
+def pytest_collection_modifyitems(config, items):
+    if config.getoption("--simt"):
+        skip = pytest.mark.skip(reason="needs a real device (torch tensors / the shim libraries linked to libmozjpeg_hip.so)")
+        for it in items:
+            if "torch" in it.name or "tensor" in it.name or "device_batch" in it.name or it.fspath.basename in ("test_gpu_dropin.py", "test_standalone_api.py"):
+                it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,53 @@
+"""Build tools/simt/_build/libmozjpeg_hip_simt.so: the product's kernel and host sources (mozjpeg_amd/csrc) compiled as plain
+C++ against the lock-step wave64 emulator (tools/simt/include/hip/hip_runtime.h + simt.cpp).
+
+Development / test infrastructure: lets a kernel edit be parity-checked against the oracle in a container without a GPU.
+Nothing in mozjpeg_amd/ loads this library; tests opt in with `pytest --simt` (tests/conftest.py)."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "mozjpeg_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libmozjpeg_hip_simt.so")
+SOURCES = ["mjh_kernels.hip", "mjh_prog.hip", "mjh_arith.hip", "mjh_encoder.cpp", "mjh_pool.cpp", "mjh_guard.cpp"]
+# the same floating-point contract as the device build (mozjpeg_amd/build.py): no FMA contraction
+FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-g1", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-fno-strict-aliasing",
+         "-I" + os.path.join(HERE, "include"), "-I" + CSRC]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OUT, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + \
+        [os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "mozjpeg_hip.h")]
+    jobs = []
+    for s in SOURCES + ["simt.cpp"]:
+        src = os.path.join(HERE if s == "simt.cpp" else CSRC, s)
+        obj = os.path.join(OUT, os.path.splitext(s)[0] + ".o")
+        if force or _newer(obj, [src] + hdrs):
+            jobs.append(["g++"] + FLAGS + ["-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            for cmd, rc in zip(jobs, ex.map(lambda c: subprocess.call(c), jobs)):
+                if verbose:
+                    print(" ".join(cmd))
+                if rc:
+                    raise RuntimeError("simt build failed: " + " ".join(cmd))
+    objs = [os.path.join(OUT, os.path.splitext(s)[0] + ".o") for s in SOURCES + ["simt.cpp"]]
+    if force or _newer(LIB, objs):
+        subprocess.check_call(["g++", "-shared", "-o", LIB] + objs + ["-lpthread"])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))
