@@ -287,6 +287,9 @@ struct mjh_encoder {
   // compact coefficient records between the AC trellis and the sequential coder: non-zero position masks;
   // the values live in the AC planes of d_q, plane i+1 = i-th non-zero.  compact_last: the last batch's d_q is in that form
   unsigned long long *d_nzmask = nullptr; bool use_compact = false, compact_last = false;
+  uint16_t *d_perm16 = nullptr;      // tile-sorted coefficient planes (MJH_SORTED_UQ): per block place, the block's index in its tile of 256 | sort key << 9
+  size_t sorted_uq_min = 400000;     // MJH_SORTED_UQ=n (n > 1): tile-sorted planes for batches of at least n blocks (tests: 2 = every batch)
+  bool sorted_uq = true;             // MJH_SORTED_UQ=0: the FDCT kernel writes every coefficient plane in natural order (the trellis sorts its tiles itself)
   uint8_t *d_nq8 = nullptr;          // per block: non-zero conventionally quantized AC coefficients (FDCT kernel) = tile-sort key of the AC trellis
   int copy_prio = 0;
   int fastdiv_all = 0;               // every table in use has q <= 255: the kernels divide by 8q with one multiply-high (MjhQuant.mdiv)
@@ -695,7 +698,7 @@ static void free_all(mjh_encoder *e)
   e->pad_streams.clear();
   if (e->ev_split_fork) (void)hipEventDestroy(e->ev_split_fork);
   if (e->ev_null_in) (void)hipEventDestroy(e->ev_null_in);
-  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->pe.chist, e->pe.rmask, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_nq8, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->pe.chist, e->pe.rmask, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_nq8, e->d_perm16, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos, e->d_arith_rates, e->d_back9, e->d_jfin, e->d_qspec, e->g_in[0], e->g_in[1], e->g_in[2], e->g_in[3] };
   for (void *q : ptrs) if (q) (void)mjh_guard_free(q);
@@ -792,6 +795,7 @@ static int make_views(mjh_encoder *e, int S)
     if (v->d_qsums) v->d_qsums += off * 4 * 64 * 2;
     if (v->d_nzmask) v->d_nzmask += off * trb;
     if (v->d_nq8) v->d_nq8 += off * trb;
+    if (v->d_perm16) v->d_perm16 += off * trb;
     if (v->d_dense) { v->d_dense += (size_t)k * dense_each * 64; v->dense_cap = dense_each; }
     v->d_len16 += off * tmb;
     v->d_off32 += off * tmb;
@@ -883,9 +887,12 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
                      (e->progressive ? !restart_scans : !(e->fuse_mask & 2));
     if (e->use_compact) HIPCHK_E(mjh_dmalloc((void **)&e->d_nzmask, B * (size_t)C.total_real_blocks * sizeof(unsigned long long)));
     if (e->use_compact && p->trellis_quant) HIPCHK_E(mjh_dmalloc((void **)&e->d_nq8, B * (size_t)C.total_real_blocks));
+    if (const char *sv = getenv("MJH_SORTED_UQ")) { e->sorted_uq = atoi(sv) != 0; if (atoi(sv) > 1) e->sorted_uq_min = (size_t)atoi(sv); }
+    if (e->use_compact && p->trellis_quant && e->sorted_uq) HIPCHK_E(mjh_dmalloc((void **)&e->d_perm16, B * (size_t)C.total_real_blocks * sizeof(uint16_t)));
   }
   if (p->trellis_quant) {   // room for a quarter of all blocks (typically 1-2 % overflow); the rest would be read from the planes
     e->dense_cap = (unsigned)(B * (size_t)C.total_real_blocks / 4 + 1024);
+    if (const char *dv = getenv("MJH_DENSE_CAP")) e->dense_cap = (unsigned)atoi(dv) + 1u;   // tests: deferred blocks beyond the dense copies come from the planes
     HIPCHK_E(mjh_dmalloc((void **)&e->d_dense, (size_t)e->dense_cap * 128));
   }
   {
@@ -1380,9 +1387,17 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   const int nbands = p.trellis_quant ? e->nbands : 1;
   const bool fuse_pre = fuse_seq && (e->fuse_mask & 1) && !e->debug_taps && nbands == 1 && !ext_qopt;   // (q_opt: one component at a time, each from the stored planes)
   const bool fuse_fin = fuse_seq && (e->fuse_mask & 2) && nbands == 1 && !ext_eob;
+  // Tile-sorted coefficient planes: when the AC trellis will run its tile-sorted first tier with four passes per tile of 256
+  // blocks (a batch large enough to fill the chip), the FDCT kernel sorts every tile by the blocks' key itself and stores
+  // planes 1..63 of coef_uq in that order, so that a pass of the trellis reads ONE line of every plane instead of all four
+  // (the passes of a tile it sorted itself re-read every line, 4.6x the algorithmic bytes of the interval).  Debug taps expose
+  // coef_uq in natural order, so they keep the natural layout.
+  const bool sort_uq = compact && e->d_perm16 && e->d_nq8 && e->fastdiv_all && C.precision == 8 && !fuse_fin && e->trellis_v3 == 4 && e->trellis_variant <= 4 &&
+                       nbands == 1 && !ext_eob && !ext_qopt && !e->arith && !e->debug_taps && (size_t)n * C.total_real_blocks >= e->sorted_uq_min;
+  uint16_t *const perm16 = sort_uq ? e->d_perm16 : nullptr;
   if (!coef_src) {
     pr.mark("dct_quant");
-    mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, e->d_nq8, n, s, e->fastdiv_all);
+    mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, e->d_nq8, n, s, e->fastdiv_all, perm16);
   }
 
   if (e->arith) {
@@ -1540,7 +1555,8 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
                           (v3_stats || (fuse_fin && p.optimize_coding && last_loop)) ? fin_ac : nullptr, e->trellis_variant,
                           Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, nzm, qstride, n, s,
                           e->d_nq8, v3 ? ((size_t)n * C.total_real_blocks < 400000 ? 1 : e->trellis_v3) : 0,   // (a small batch: one pass per tile -- four times the workgroups, a quarter of their length: latency matters more than the sorting)
-                          e->fastdiv_all);
+                          e->fastdiv_all, v3 ? perm16 : nullptr);
+    if (perm16 && !v3) return fail(MJH_EINVAL, "internal: tile-sorted coefficient planes without the tile-sorted trellis");
     if (e->trellis_adapt && !extended && first_pass) {
       e->h_defer[4] = (unsigned)n;
       HIPCHK(hipMemcpyAsync(&e->h_defer[0], e->d_worklist, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));

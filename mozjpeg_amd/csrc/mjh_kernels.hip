@@ -1673,8 +1673,11 @@ __global__ void k_zero_counters(unsigned *__restrict__ a, unsigned *__restrict__
 }
 
 // work-list entries: 3 words per deferred block at [4 + 3i]: image, component << 28 | block, slot of its dense copy
+// compblk_nocopy: the entry of a block that got no dense copy (the list outgrew the dense array) -- the tile-sorted planes
+// name such a block by its PLACE in them (bit 27 set; k_trellis_ac_qd finds the block through the tile's permutation)
 __device__ __forceinline__ void defer_blocks(bool mine, unsigned *__restrict__ list, unsigned img, unsigned compblk, unsigned dense_slot_in,
-                                             const short (&xs)[64], int16_t *__restrict__ dense, unsigned dense_cap, bool make_copy, int lane)
+                                             const short (&xs)[64], int16_t *__restrict__ dense, unsigned dense_cap, bool make_copy, int lane,
+                                             unsigned compblk_nocopy = 0xFFFFFFFFu)
 {
   const unsigned long long over = __ballot(mine);
   if (over == 0ull) return;
@@ -1684,7 +1687,7 @@ __device__ __forceinline__ void defer_blocks(bool mine, unsigned *__restrict__ l
   if (!mine) return;
   const unsigned idx = base + (unsigned)__popcll(over & ((1ull << lane) - 1ull));
   list[4 + 3 * (size_t)idx] = img;
-  list[5 + 3 * (size_t)idx] = compblk;
+  list[5 + 3 * (size_t)idx] = (make_copy && idx >= dense_cap && compblk_nocopy != 0xFFFFFFFFu) ? compblk_nocopy : compblk;
   list[6 + 3 * (size_t)idx] = make_copy ? idx : dense_slot_in;
   if (make_copy && idx < dense_cap) {
     // the raw coefficients are still in registers: one 128-byte line per block for the next kernel, instead of 63
@@ -1725,6 +1728,7 @@ struct MjhTrellisExt {
   int *eob_has;       // has_eob 0 / 1 / 2 (jcdctmgr.c:1209)
   unsigned long long *nzmask;   // COMPACT instantiations: non-zero position mask per block, [image][real blocks of all components]
   int qstride;        // EXT instantiations: 1 = one MjhQuant per image (trellis_q_opt re-estimates the tables between passes), 0 = shared
+  const uint16_t *perm16;       // tile-sorted coefficient planes (k_dct_quant_sorted): the tiles' permutations, [image][real blocks of all components]; null: natural order
 };
 
 template <int QN, bool FSTATS, bool EXT = false, bool COMPACT = false>   // FSTATS: count the AC symbols of the final coefficients (sequential mode, last trellis round)
@@ -1824,8 +1828,13 @@ k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     const int img = (int)worklist[4 + 3 * (size_t)ii];
     const unsigned w = worklist[5 + 3 * (size_t)ii];
     const unsigned ds = worklist[6 + 3 * (size_t)ii];
-    const int comp = (int)(w >> 28), blk = (int)(w & 0x0FFFFFFFu);
+    const int comp = (int)(w >> 28);
     const MjhComp cc = C.c[comp];
+    // bit 27: the entry names the block's PLACE in the tile-sorted planes (no dense copy was made); the tile's permutation
+    // gives the block
+    const int place = (int)(w & 0x07FFFFFFu);
+    int blk = place;
+    if (w & 0x08000000u) blk = (place & ~255) + (int)(ext.perm16[(size_t)img * C.total_real_blocks + cc.blk_off + place] & 511u);
     const int slot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
     const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
     const float lambda = lambda_in[(size_t)img * C.total_real_blocks + cc.blk_off + blk];
@@ -1843,7 +1852,7 @@ k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
           for (int j = 0; j < 4; j++) { xs[8 * v + 2 * j] = (short)(ww[j] & 0xFFFFu); xs[8 * v + 2 * j + 1] = (short)(ww[j] >> 16); }
         }
       } else {
-        const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+        const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + place;   // (= blk in natural order)
 #pragma unroll
         for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
       }
@@ -2063,7 +2072,8 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
         azd = azd_cur;
       }
       azd63 = azd;
-      defer_blocks(inside && (nq > QN || qmax >= 16), worklist, (unsigned)img, ((unsigned)comp << 28) | (unsigned)blk, 0u, xs, dense, dense_cap, true, lane);
+      defer_blocks(inside && (nq > QN || qmax >= 16), worklist, (unsigned)img, ((unsigned)comp << 28) | (unsigned)blk, 0u, xs, dense, dense_cap, true, lane,
+                   SORTED ? ((unsigned)comp << 28) | 0x08000000u | (unsigned)spos : 0xFFFFFFFFu);
       count_heavy(worklist, inside, nq, lane);
     }
     const bool work = inside && nq <= QN && qmax < 16;
@@ -3710,7 +3720,7 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   // the EXT instantiations
   const bool extended = Ss != 1 || Se != 63 || eob_cost != nullptr || qstride != 0;
   MjhTrellisExt ext;
-  ext.Ss = Ss; ext.Se = Se; ext.eob_cost = (float2 *)eob_cost; ext.eob_has = eob_has; ext.nzmask = nzmask; ext.qstride = qstride;
+  ext.Ss = Ss; ext.Se = Se; ext.eob_cost = (float2 *)eob_cost; ext.eob_has = eob_has; ext.nzmask = nzmask; ext.qstride = qstride; ext.perm16 = perm16;
   const int4 sl = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
   // stat_slot != nullptr: the statistics of the final coefficients go to these table slots (one per component)
   MjhHuffTable *st = stat_slot ? tabs : nullptr;
@@ -3739,9 +3749,10 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     // goes through the general tiers below
     // one or two frames (the caller asks for one pass per tile then): occupancy is no concern on an empty chip, and with 24 records
     // next to nothing is left for the general tiers, whose fixed latency (~80 us) would sit on the critical path
-    const bool small24 = v3_passes == 1 && variant <= 2 && !st && fastdiv;
+    const bool small24 = !perm16 && v3_passes == 1 && variant <= 2 && !st && fastdiv;
     if (small24) variant = 2;
-    const int np = small24 ? 1 : (!fastdiv || st || variant > 0) ? 4 : v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
+    // (tile-sorted planes, perm16: written for tiles of 256 blocks -- four passes whatever else the arguments say)
+    const int np = perm16 ? 4 : small24 ? 1 : (!fastdiv || st || variant > 0) ? 4 : v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
     int t0[5] = { 0, 0, 0, 0, 0 };
     for (int i = 0; i < 4; i++) t0[i + 1] = t0[i] + (i < C.ncomp ? (C.c[i].nblk + 64 * np - 1) / (64 * np) : 0);
     dim3 gridt(t0[C.ncomp], n);
@@ -3751,7 +3762,7 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
 #define LV3S(QN, FSV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, 4, true, FSV, true>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask, st, ss, perm16)
 #define LV3(NP, FDV, FSV) LV3Q(16, NP, FDV, FSV)
     if (perm16) {   // the planes are tile-sorted already (mjh_launch_dct with the same array): only the four-pass kernels read that layout
-      if (np != 4 || !fastdiv || small24) { fprintf(stderr, "mjh_launch_trellis_ac: tile-sorted planes with a plan that cannot read them\n"); abort(); }
+      if (!fastdiv) { fprintf(stderr, "mjh_launch_trellis_ac: tile-sorted planes need the fast division\n"); abort(); }
       if (variant >= 3 && !st) { if (variant == 3) LV3S(32, false); else LV3S(48, false); }
       else if (variant > 0) { if (st) LV3S(24, true); else LV3S(24, false); }
       else if (st) LV3S(16, true);

@@ -402,3 +402,36 @@ def test_every_first_tier_capacity_of_the_ac_trellis_gives_the_same_file(quality
                 got = enc.encode_host(frames)
                 assert got[0] == want and got[2] == want, (kw, variant, rnd)
             enc.close()
+
+
+@pytest.mark.parametrize("quality,sample", [(75, (2, 2)), (90, (1, 1)), (97, (1, 1))])
+def test_tile_sorted_coefficient_planes_give_the_same_file(quality, sample):
+    """MJH_SORTED_UQ: the FDCT kernel (four waves = one trellis tile of 256 blocks) sorts each tile by the blocks' keys and
+    stores planes 1..63 of coef_uq in that order; a pass of the tile-sorted trellis then reads one line per plane.  Same files
+    as the natural layout and as the oracle -- at every first-tier capacity, with ragged last tiles (600x424: 3975 luma blocks
+    = 15 tiles + 135), when the deferred blocks outgrow their dense copies (MJH_DENSE_CAP: the general tiers then find a block
+    through its tile's permutation), with the statistics fused into either kernel, sequential and progressive."""
+    w, h = 600, 424
+    rng = np.random.default_rng(quality)
+    img = O.synthetic_frame(w, h, 60 + quality)
+    img[100:300, 200:500] = rng.integers(0, 256, (200, 300, 3), dtype=np.uint8)
+    frames = np.stack([img, img[::-1].copy(), img])
+    knobs = ("MJH_SORTED_UQ", "MJH_TRELLIS_VARIANT", "MJH_DENSE_CAP", "MJH_FUSE")
+    for kw in (dict(quality=quality, baseline=True, sample=sample), dict(quality=quality, fastcrush=True, sample=sample),
+               dict(quality=quality, baseline=True, sample=sample, trellis_loops=2)):
+        want = O.encode(O.make_params(w, h, **kw), img)
+        for variant, dense, fuse in (("0", None, None), ("2", None, None), ("3", None, None), ("4", None, None), (None, None, None),
+                                     ("0", "8", None), (None, "0", None), ("0", None, "5"), ("2", "40", "5")):
+            env = {"MJH_SORTED_UQ": "2", "MJH_TRELLIS_VARIANT": variant, "MJH_DENSE_CAP": dense, "MJH_FUSE": fuse}
+            try:
+                for k, v in env.items():
+                    if v is not None:
+                        os.environ[k] = v
+                enc = M.Encoder(M.make_params(w, h, **kw), max_batch=3)
+            finally:
+                for k in knobs:
+                    os.environ.pop(k, None)
+            for rnd in range(2 if variant is None else 1):
+                got = enc.encode_host(frames)
+                assert got[0] == want and got[2] == want, (kw, env, rnd)
+            enc.close()
