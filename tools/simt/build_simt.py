@@ -4,6 +4,7 @@ C++ against the lock-step wave64 emulator (tools/simt/include/hip/hip_runtime.h 
 Development / test infrastructure: lets a kernel edit be parity-checked against the oracle in a container without a GPU.
 Nothing in mozjpeg_amd/ loads this library; tests opt in with `pytest --simt` (tests/conftest.py)."""
 import os
+import shutil
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -26,16 +27,39 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _sources():
+    """The kernel sources to compile.  A tree whose sources carry the emulator's annotations (MJH_DIVERGENT_SCOPE,
+    MJH_WAVE_GROUPS, MJH_WAVE_SYNC: nothing on the device, see mjh_device.h) is compiled as it is.  A tree that predates them
+    keeps its kernel sources untouched (the PMC traffic summaries under profiles/ are stamped with a hash of those files):
+    tools/simt/annotations.patch inserts the same annotations into a COPY under _build/src, which is what gets compiled."""
+    patch = os.path.join(HERE, "annotations.patch")
+    if "MJH_WAVE_SYNC" in open(os.path.join(CSRC, "mjh_device.h")).read() or not os.path.exists(patch):
+        return CSRC
+    dst = os.path.join(OUT, "src")
+    stamp = os.path.join(dst, ".stamp")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [patch]
+    if _newer(stamp, deps):
+        shutil.rmtree(dst, ignore_errors=True)
+        os.makedirs(os.path.join(dst, "mozjpeg_amd"))
+        shutil.copytree(CSRC, os.path.join(dst, "mozjpeg_amd", "csrc"))
+        shutil.copytree(os.path.join(ROOT, "include"), os.path.join(dst, "include"))     # (the sources include ../../include/mozjpeg_hip.h)
+        subprocess.check_call(["patch", "-p1", "-s", "-i", patch], cwd=dst)               # fails loudly when a hunk no longer fits
+        open(stamp, "w").close()
+    return os.path.join(dst, "mozjpeg_amd", "csrc")
+
+
 def build(force=False, verbose=False):
     os.makedirs(OUT, exist_ok=True)
-    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + \
+    csrc = _sources()
+    flags = [f for f in FLAGS if f != "-I" + CSRC] + ["-I" + csrc]
+    hdrs = [os.path.join(csrc, h) for h in os.listdir(csrc) if h.endswith(".h")] + \
         [os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "mozjpeg_hip.h")]
     jobs = []
     for s in SOURCES + ["simt.cpp"]:
-        src = os.path.join(HERE if s == "simt.cpp" else CSRC, s)
+        src = os.path.join(HERE if s == "simt.cpp" else csrc, s)
         obj = os.path.join(OUT, os.path.splitext(s)[0] + ".o")
         if force or _newer(obj, [src] + hdrs):
-            jobs.append(["g++"] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append(["g++"] + flags + ["-c", src, "-o", obj])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
             for cmd, rc in zip(jobs, ex.map(lambda c: subprocess.call(c), jobs)):
