@@ -41,7 +41,7 @@ def pytest_collection_modifyitems(config, items):
     if config.getoption("--simt"):
         skip = pytest.mark.skip(reason="needs a real device (torch tensors / the shim libraries linked to libmozjpeg_hip.so)")
         for it in items:
-            if "torch" in it.name or "tensor" in it.name or "device_batch" in it.name or "device_entry" in it.name or it.fspath.basename in ("test_gpu_dropin.py", "test_standalone_api.py"):
+            if "torch" in it.name or "tensor" in it.name or "device_batch" in it.name or "device_entry" in it.name or "two_rank" in it.name or it.fspath.basename in ("test_gpu_dropin.py", "test_standalone_api.py"):
                 it.add_marker(skip)
 
 

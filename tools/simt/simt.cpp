@@ -70,6 +70,7 @@ struct Worker {
   std::vector<char *> stacks;
   std::vector<Xch> xch;
   std::vector<char> dyn;
+  std::vector<int> worder;
   void *sched_sp = nullptr;
   Fiber *running = nullptr;
   const Job *job = nullptr;
@@ -173,13 +174,26 @@ static void run_group(Worker *w, const Job &job, unsigned bx, unsigned by, unsig
   }
   int done = 0;
   long idle_spins = 0;
+  // SIMT_ORDER: the order in which the waves of a workgroup get their turn (the hardware promises none: a result that changes
+  // with it is a race between waves, i.e. a missing barrier).  0 ascending, 1 descending, 2 a different shuffle every round;
+  // +4: the lanes of a wave run from 63 down to 0 between two rendezvous (a difference there = lock-step order the kernel
+  // relies on without MJH_WAVE_SYNC: an emulator artefact, not a device bug).
+  static const int order_mode = getenv("SIMT_ORDER") ? atoi(getenv("SIMT_ORDER")) : 0;
+  unsigned rng = 12345u + bx * 7919u + by * 104729u + bz * 1299709u;
+  std::vector<int> &worder = w->worder;
+  worder.resize(nw);
+  for (int i = 0; i < nw; i++) worder[i] = (order_mode & 3) == 1 ? nw - 1 - i : i;
   while (done < n) {
     bool progress = false, any_spin = false;
-    for (int wv = 0; wv < nw; wv++) {
+    if ((order_mode & 3) == 2)
+      for (int i = nw - 1; i > 0; i--) { rng = rng * 1664525u + 1013904223u; std::swap(worder[i], worder[(rng >> 8) % (unsigned)(i + 1)]); }
+    for (int wi = 0; wi < nw; wi++) {
+      const int wv = worder[wi];
       const int t0 = wv * 64, t1 = std::min(n, t0 + 64);
       for (;;) {
         bool ran = false;
-        for (int t = t0; t < t1; t++) {
+        for (int tt = t0; tt < t1; tt++) {
+          const int t = (order_mode & 4) ? t0 + t1 - 1 - tt : tt;
           Fiber &f = w->fibers[t];
           if (f.state != RUNNABLE) continue;
           w->running = &f; cur = &f.L;
