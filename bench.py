@@ -164,9 +164,10 @@ INTERVAL_KERNELS = {
 
 def kernel_source_stamp():
     """sha256 over the sources the kernels of every PROFILED configuration are built from (mozjpeg_amd/csrc/*.hip, *.h):
-    tools/pmc_traffic.py writes it into the traffic summaries it produces, and a summary whose stamp differs from the
-    tree's is never quoted.  mjh_arith.hip (+ its table) is left out: a translation unit of its own that holds only the
-    arithmetic-coding kernels, which no configuration with PMC passes launches (the arith lines carry traffic = null)."""
+    tools/pmc_traffic.py writes it into the traffic summaries it produces.  mjh_arith.hip (+ its table) is left out: a
+    translation unit of its own that holds only the arithmetic-coding kernels, which no configuration with PMC passes
+    launches (the arith lines carry traffic = null).  A summary whose stamp equals the tree's is quoted as it is; one whose
+    stamp differs is quoted only for kernels whose MACHINE CODE is still the same (kernel_fingerprints below)."""
     import hashlib
     hsh = hashlib.sha256()
     src = os.path.join(ROOT, "mozjpeg_amd", "csrc")
@@ -177,31 +178,55 @@ def kernel_source_stamp():
     return hsh.hexdigest()[:16]
 
 
+def kernel_fingerprints():
+    """{kernel: fingerprint of its gfx950 machine code} of the library that runs, from mozjpeg_amd/kernel_isa.json
+    (tools/kernel_isa.py, run by build(): the compiler's assembly per kernel with labels and comments normalised).  Trusted
+    only while the file was computed from the sources in the tree; {} otherwise."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import kernel_isa
+        j = json.load(open(os.path.join(ROOT, "mozjpeg_amd", "kernel_isa.json")))
+        if j.get("source_stamp") != kernel_isa.source_stamp():
+            return {}
+        return {k: v["sha"] for k, v in j["kernels"].items()}
+    except Exception:
+        return {}
+
+
 def dominant_traffic(config, dom, frames_per_call):
     """HBM bytes per launch of the dominant interval's kernels from the newest committed PMC passes of THIS configuration
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, fetch corrected by the factor calibrated on k_color;
-    tools/pmc_traffic.py), scaled to this batch; (None, reason) when no passes of the configuration are committed."""
+    tools/pmc_traffic.py), scaled to this batch; (None, reason) when no passes of the configuration are committed or the
+    interval's kernels are no longer the ones the passes were taken on."""
     pat = "r*_pmc_hbm_traffic_batch*.json" if config == "metric" else "r*_%s_pmc_hbm_traffic_batch*.json" % config
     paths = [p for p in glob.glob(os.path.join(ROOT, "profiles", pat))
              if config != "metric" or not any(("_%s_" % c) in os.path.basename(p) for c in CONFIGS if c != "metric")]
     prefixes = INTERVAL_KERNELS.get(dom.split("(")[0] if dom.startswith("prog_") else dom, ())
     stamp = kernel_source_stamp()
+    now = None
     stale = None
     for path in sorted(paths, reverse=True):
         try:
             pmc = json.load(open(path))
-            if pmc.get("kernel_source_stamp") != stamp:     # taken on other kernels than the ones that run now
-                stale = stale or os.path.relpath(path, ROOT)
-                continue
-            per_frame = sum(v["hbm_bytes_per_frame"] for k, v in pmc["kernels"].items() if any(k.startswith(pf) for pf in prefixes))
+            mine = {k: v for k, v in pmc["kernels"].items() if any(k.startswith(pf) for pf in prefixes)}
+            per_frame = sum(v["hbm_bytes_per_frame"] for v in mine.values())
             if per_frame <= 0:
                 continue
-            return int(per_frame * frames_per_call), "%s (bytes per launch, scaled to this batch; passes taken at git %s, kernel sources %s)" % (
-                os.path.relpath(path, ROOT), pmc.get("profile_head", "?"), stamp)
+            how = "kernel sources %s" % stamp
+            if pmc.get("kernel_source_stamp") != stamp:     # other sources than the ones in the tree: same machine code, kernel by kernel?
+                if now is None:
+                    now = kernel_fingerprints()
+                then = pmc.get("kernel_isa") or {}
+                if not (mine and all(k in then and now.get(k) == then[k] for k in mine)):
+                    stale = stale or os.path.relpath(path, ROOT)
+                    continue
+                how = "machine code of the interval's %d kernels identical to the profiled tree's (tools/kernel_isa.py)" % len(mine)
+            return int(per_frame * frames_per_call), "%s (bytes per launch, scaled to this batch; passes taken at git %s, %s)" % (
+                os.path.relpath(path, ROOT), pmc.get("profile_head", "?"), how)
         except Exception:
             continue
     if stale:
-        return None, "stale: the kernel sources changed after the newest PMC passes of this configuration (%s) -- re-run tools/profile_round.sh" % stale
+        return None, "stale: the kernels of this interval changed after the newest PMC passes of this configuration (%s) -- re-run tools/profile_round.sh" % stale
     return None, "no PMC passes committed for this configuration / interval"
 
 

@@ -289,7 +289,8 @@ struct mjh_encoder {
   unsigned long long *d_nzmask = nullptr; bool use_compact = false, compact_last = false;
   uint16_t *d_perm16 = nullptr;      // tile-sorted coefficient planes (MJH_SORTED_UQ): per block place, the block's index in its tile of 256 | sort key << 9
   size_t sorted_uq_min = 400000;     // MJH_SORTED_UQ=n (n > 1): tile-sorted planes for batches of at least n blocks (tests: 2 = every batch)
-  bool sorted_uq = true;             // MJH_SORTED_UQ=0: the FDCT kernel writes every coefficient plane in natural order (the trellis sorts its tiles itself)
+  bool sorted_uq = false;            // MJH_SORTED_UQ=1: opt-in until it has been timed on the chip (bit-exact in the emulator, tools/simt); off: the FDCT kernel
+                                     // writes every coefficient plane in natural order and the trellis sorts its tiles itself
   uint8_t *d_nq8 = nullptr;          // per block: non-zero conventionally quantized AC coefficients (FDCT kernel) = tile-sort key of the AC trellis
   int copy_prio = 0;
   int fastdiv_all = 0;               // every table in use has q <= 255: the kernels divide by 8q with one multiply-high (MjhQuant.mdiv)

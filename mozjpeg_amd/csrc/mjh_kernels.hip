@@ -36,6 +36,7 @@ static constexpr ZZTab make_zz() {
 }
 static constexpr ZZTab kZZ = make_zz();    // kZZ.v[k]  = natural index of zig-zag position k
 
+#ifndef MJH_TU_SORTED   // (mjh_sorted.hip includes this file for the shared device functions only)
 // =============================================================================================
 // K1  colour conversion + chroma downsampling + edge replication  
 //   rgb_ycc_convert jccolext.c:30-75 (tables jccolor.c:213-246), h2v2/h2v1/int_downsample
@@ -291,6 +292,7 @@ k_import_planes(MjhConst C, MjhPlaneSrc S, T *__restrict__ planes)
 #pragma unroll
   for (int j = 0; j < 4; j++) dst[j] = v[j];
 }
+#endif  // MJH_TU_SORTED
 // =============================================================================================
 // K2  convsamp + overshoot deringing + islow FDCT + quantize   (rows a4-a8)
 //   convsamp jcdctmgr.c:576, preprocess_deringing :416-498 (catmull_rom :387), jpeg_fdct_islow
@@ -374,7 +376,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
   __shared__ int lds_raw[NW][64][LW];
   typedef short dcol_t;
   typedef dcol_t __attribute__((may_alias)) dcol_alias;
-  const int lane = threadIdx.x & 63, wv = SORTED ? (int)(threadIdx.x >> 6) : 0;
+  const int lane = SORTED ? (int)(threadIdx.x & 63) : (int)threadIdx.x, wv = SORTED ? (int)(threadIdx.x >> 6) : 0;   // (one wave per workgroup unless SORTED)
   dcol_alias (*lds)[64] = reinterpret_cast<dcol_alias (*)[64]>(&lds_raw[wv][0][0]);
   const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
@@ -596,15 +598,7 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
   dct_quant_body<T, STATS, FD>(C, Q, planes, coef_uq, coef_q, lambda_out, stat_tabs, slots_per_image, stat_slot_of_comp, nq8_out);
 }
 
-template <bool STATS, bool FD>
-__global__ void __launch_bounds__(256)
-k_dct_quant_sorted(MjhConst C, const MjhQuant *__restrict__ Q, const uint8_t *__restrict__ planes,
-                   int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
-                   MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out,
-                   uint16_t *__restrict__ perm_out)
-{
-  dct_quant_body<uint8_t, STATS, FD, true>(C, Q, planes, coef_uq, coef_q, lambda_out, stat_tabs, slots_per_image, stat_slot_of_comp, nq8_out, perm_out);
-}
+#ifndef MJH_TU_SORTED   // (mjh_sorted.hip includes this file for the shared device functions only)
 // =============================================================================================
 // K2b  coefficient import: jpeg_write_coefficients jctrans.c:44 entropy-codes blocks the
 // caller already has (jpegtran, "jpegrescan").  The caller's arrays are block-major, natural order
@@ -1003,6 +997,7 @@ k_gen_tables_list(MjhHuffTable *__restrict__ tabs, int slots_per_image, const in
   gen_table_body(tabs + (size_t)blockIdx.y * slots_per_image + slot_list[blockIdx.x], threadIdx.x);
 }
 
+#endif  // MJH_TU_SORTED
 // =============================================================================================
 // K5  AC trellis quantization (row a9): quantize_trellis jcdctmgr.c:1120-1222 (+ norm/lambda
 // :1011-1037).  One lane = one block.  The rate-distortion DP only ever looks back at
@@ -1428,6 +1423,7 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
   }
 }
 
+#ifndef MJH_TU_SORTED   // (mjh_sorted.hip includes this file for the shared device functions only)
 // =============================================================================================
 // trellis_eob_opt: jcdctmgr.c:1224-1297.  After the per-block DP of a band the reference walks
 // every block row once more: the cheapest way to reach block bi through runs of blocks whose band is all zero (coded as
@@ -1672,6 +1668,7 @@ __global__ void k_zero_counters(unsigned *__restrict__ a, unsigned *__restrict__
   if (threadIdx.x < 4) { a[threadIdx.x] = 0; b[threadIdx.x] = 0; }
 }
 
+#endif  // MJH_TU_SORTED
 // work-list entries: 3 words per deferred block at [4 + 3i]: image, component << 28 | block, slot of its dense copy
 // compblk_nocopy: the entry of a block that got no dense copy (the list outgrew the dense array) -- the tile-sorted planes
 // name such a block by its PLACE in them (bit 27 set; k_trellis_ac_qd finds the block through the tile's permutation)
@@ -1728,7 +1725,6 @@ struct MjhTrellisExt {
   int *eob_has;       // has_eob 0 / 1 / 2 (jcdctmgr.c:1209)
   unsigned long long *nzmask;   // COMPACT instantiations: non-zero position mask per block, [image][real blocks of all components]
   int qstride;        // EXT instantiations: 1 = one MjhQuant per image (trellis_q_opt re-estimates the tables between passes), 0 = shared
-  const uint16_t *perm16;       // tile-sorted coefficient planes (k_dct_quant_sorted): the tiles' permutations, [image][real blocks of all components]; null: natural order
 };
 
 template <int QN, bool FSTATS, bool EXT = false, bool COMPACT = false>   // FSTATS: count the AC symbols of the final coefficients (sequential mode, last trellis round)
@@ -1812,68 +1808,9 @@ k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
                 unsigned *__restrict__ worklist_next, const int16_t *__restrict__ dense, unsigned dense_cap,
                 MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp, MjhTrellisExt ext)
 {
-  __shared__ uint2 col[QN2][64];
-  __shared__ unsigned short e_pk[QN2 + 1][64];
-  __shared__ int dqT[4][64];
-  __shared__ float ltT[4][64];
-  const int lane = threadIdx.x;
-#pragma unroll
-  for (int t = 0; t < 4; t++) { dqT[t][lane] = Q->dq8[t][lane]; ltT[t][lane] = Q->lambda_tbl[t][lane]; }
-  __syncthreads();
-  const unsigned count = worklist[0];
-  for (unsigned base = blockIdx.x * 64; base < count; base += gridDim.x * 64) {   // wave-uniform trip count
-    const unsigned it = base + lane;
-    const bool active = it < count;
-    const unsigned ii = active ? it : count - 1;
-    const int img = (int)worklist[4 + 3 * (size_t)ii];
-    const unsigned w = worklist[5 + 3 * (size_t)ii];
-    const unsigned ds = worklist[6 + 3 * (size_t)ii];
-    const int comp = (int)(w >> 28);
-    const MjhComp cc = C.c[comp];
-    // bit 27: the entry names the block's PLACE in the tile-sorted planes (no dense copy was made); the tile's permutation
-    // gives the block
-    const int place = (int)(w & 0x07FFFFFFu);
-    int blk = place;
-    if (w & 0x08000000u) blk = (place & ~255) + (int)(ext.perm16[(size_t)img * C.total_real_blocks + cc.blk_off + place] & 511u);
-    const int slot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
-    const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
-    const float lambda = lambda_in[(size_t)img * C.total_real_blocks + cc.blk_off + blk];
-    int nq;
-    float azd63;
-    {
-      short xs[64];
-      if (ds < dense_cap) {
-        const uint4 *d = reinterpret_cast<const uint4 *>(dense + (size_t)ds * 64);
-#pragma unroll
-        for (int v = 0; v < 8; v++) {
-          const uint4 q4 = d[v];
-          const unsigned ww[4] = { q4.x, q4.y, q4.z, q4.w };
-#pragma unroll
-          for (int j = 0; j < 4; j++) { xs[8 * v + 2 * j] = (short)(ww[j] & 0xFFFFu); xs[8 * v + 2 * j + 1] = (short)(ww[j] >> 16); }
-        }
-      } else {
-        const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + place;   // (= blk in natural order)
-#pragma unroll
-        for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
-      }
-      if (EXT && ext.qstride) {
-        const MjhQuant *Qi = Q + (size_t)img * ext.qstride;   // per-lane image: vector loads of its own rows
-        nq = trellis_q_phase1<QN2, EXT>(xs, Qi->dq8[cc.qtbl], Qi->rcp8q[cc.qtbl], Qi->lambda_tbl[cc.qtbl], lambda, col, lane, azd63, ext.Ss, ext.Se);
-      } else
-      nq = trellis_q_phase1<QN2, EXT>(xs, dqT[cc.qtbl], Q->rcp8q[cc.qtbl], ltT[cc.qtbl], lambda, col, lane, azd63, ext.Ss, ext.Se);
-      if (QN2 < 63) defer_blocks(active && nq > QN2, worklist_next, (unsigned)img, w, ds, xs, nullptr, 0u, false, lane);
-    }
-    int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
-    const int sslot = comp == 0 ? stat_slot_of_comp.x : comp == 1 ? stat_slot_of_comp.y : comp == 2 ? stat_slot_of_comp.z : stat_slot_of_comp.w;
-    unsigned *cnt = FSTATS ? stat_tabs[(size_t)img * slots_per_image + sslot].counts : nullptr;
-    const size_t gblk = (size_t)img * C.total_real_blocks + cc.blk_off + blk;
-    trellis_q_walk<QN2, false, FSTATS ? 2 : 0, EXT, COMPACT>(reinterpret_cast<const uint4 *>(T->ehufsi), nullptr, dqT, ltT, cc.qtbl, nq, azd63, lambda, active, qo, cc.kstride,
-                                                              col, e_pk, lane, cnt, ext.Ss, ext.Se, EXT && ext.eob_cost ? ext.eob_cost + gblk : nullptr,
-                                                              EXT && ext.eob_cost ? ext.eob_has + gblk : nullptr, COMPACT ? ext.nzmask + gblk : nullptr,
-                                                              EXT && ext.qstride ? (Q + (size_t)img * ext.qstride)->dq8[cc.qtbl] : nullptr,
-                                                              EXT && ext.qstride ? (Q + (size_t)img * ext.qstride)->lambda_tbl[cc.qtbl] : nullptr);
-    __syncthreads();   // the LDS columns are reused by the next round
-  }
+  constexpr bool PERM = false;
+  const uint16_t *const perm16 = nullptr;
+#include "mjh_trellis_qd.inc"
 }
 
 // =============================================================================================
@@ -1956,260 +1893,20 @@ __device__ __forceinline__ void v3_pair(const uint2 (*col)[64], const unsigned s
 // deferred-only form.
 // SORTED: planes 1..63 of coef_uq hold every tile's blocks in descending-key order already and perm16 holds the tile's
 // permutation (k_dct_quant_sorted): no sort here, pass p reads line p of every plane.
-template <int QN, int NPASS, bool FD, bool FST, bool SORTED = false>
+template <int QN, int NPASS, bool FD, bool FST>
 __global__ void __launch_bounds__(64)
 k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q,
                 const MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 ac_slot_of_comp, int4 tile0_of_comp,
                 const float *__restrict__ lambda_in, uint8_t *__restrict__ nq8, unsigned *__restrict__ worklist,
                 int16_t *__restrict__ dense, unsigned dense_cap, unsigned long long *__restrict__ nzmask,
-                MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp, const uint16_t *__restrict__ perm16 = nullptr)
+                MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp)
 {
-  static_assert(QN >= 16 && QN <= 63 && NPASS >= 1 && NPASS <= 8, "queue capacity / passes");
-  static_assert(!SORTED || NPASS == 4, "the producer sorts tiles of 256 blocks");
-  constexpr int TILE = 64 * NPASS;
-  __shared__ unsigned fhist[FST ? 2 : 1][FST ? 256 : 1];   // FST: two interleaved copies of the symbol histogram of this tile
-  __shared__ uint2 col[QN][64];          // tile sort scratch; per pass: queue records -> live entries {azd, acc} -> value column
-  __shared__ unsigned short info[QN][64];   // live entry e (>= 1) at [e-1]: position | back entry << 6 | magnitude (< 16) << 12 (the signs: one bit per position in a register)
-  __shared__ float4 rate_rows[16];
-  typedef unsigned __attribute__((may_alias)) u_alias;
-  typedef unsigned short __attribute__((may_alias)) us_alias;
-  const int img = blockIdx.y, tl = blockIdx.x, lane = threadIdx.x;
-  const int comp = tl >= tile0_of_comp.w ? 3 : tl >= tile0_of_comp.z ? 2 : tl >= tile0_of_comp.y ? 1 : 0;
-  const int t0 = comp == 0 ? 0 : comp == 1 ? tile0_of_comp.y : comp == 2 ? tile0_of_comp.z : tile0_of_comp.w;
-  const MjhComp cc = C.c[comp];
-  const int tile_base = (tl - t0) * TILE;
-  const int slot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
-  const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
-  const size_t gblk0 = (size_t)img * C.total_real_blocks + cc.blk_off;
-  if (lane < 16) rate_rows[lane] = rate_row(reinterpret_cast<const uint4 *>(T->ehufsi)[lane]);
-  const int si_f0 = (int)T->ehufsi[0xF0], si_eob = (int)T->ehufsi[0];
-  const float f0f = si_f0 ? (float)si_f0 : 3e38f, eobf = (float)si_eob;
-  const int dq_lane = Q->dq8[cc.qtbl][lane];                    // lane k holds the row entry of position k (ds_bpermute lookups)
-  const float lt_lane = Q->lambda_tbl[cc.qtbl][lane];
-
-  if (FST) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) (&fhist[0][0])[j * 64 + lane] = 0u;
-  }
-  // ---- tile sort: descending key; perm entry = index in tile | key << 9 ----
-  unsigned long long mine0 = 0ull, mine1 = 0ull;
-  if (!SORTED) {
-    u_alias *hist = reinterpret_cast<u_alias *>(&col[0][0]);              // [64]
-    us_alias *perm = reinterpret_cast<us_alias *>(&col[0][0]) + 128;      // [TILE], behind the histogram
-    hist[lane] = 0u;
-    __syncthreads();
-    unsigned key[NPASS], rank[NPASS];
-#pragma unroll
-    for (int j = 0; j < NPASS; j++) {
-      const int b = tile_base + j * 64 + lane;
-      unsigned k = b < cc.nblk ? (unsigned)nq8[gblk0 + b] : 0u;
-      key[j] = k > 63u ? 63u : k;
-      rank[j] = atomicAdd(&hist[key[j]], 1u);
-    }
-    __syncthreads();
-    const unsigned h = hist[63 - lane];     // lane L: blocks with key 63-L; blocks with a larger key come first
-    unsigned inc = h;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const unsigned n = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += n;
-    }
-    __syncthreads();
-    hist[63 - lane] = inc - h;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NPASS; j++) perm[hist[key[j]] + rank[j]] = (unsigned short)((unsigned)(j * 64 + lane) | (key[j] << 9));
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NPASS; j++) {
-      const unsigned long long v = perm[j * 64 + lane];
-      if (j < 4) mine0 |= v << (16 * j); else mine1 |= v << (16 * (j - 4));
-    }
-    __syncthreads();
-  }
-
-  us_alias *colh = reinterpret_cast<us_alias *>(&col[0][0]);   // value of slot s: row s>>2, half-word s&3 of the lane's uint2
-#pragma unroll 1
-  for (int pass = 0; pass < NPASS; pass++) {
-    const int spos = tile_base + pass * 64 + lane;         // SORTED: the lane's place in the tile's sorted order
-    const unsigned pe = SORTED ? (spos < cc.nblk ? (unsigned)perm16[gblk0 + spos] : 0u)
-                               : (unsigned)(((pass < 4 ? mine0 : mine1) >> (16 * (pass & 3))) & 0xFFFFull);
-    const int blk = tile_base + (int)(pe & 511u);
-    const bool inside = SORTED ? spos < cc.nblk : blk < cc.nblk;
-    const size_t gblk = gblk0 + (inside ? blk : 0);
-    if (__builtin_amdgcn_ballot_w64(inside && (pe >> 9) != 0u) == 0ull) {   // nothing quantizes to non-zero: all-zero blocks
-      if (inside) nzmask[gblk] = 0ull;
-      if (FST && inside) atomicAdd(&fhist[lane & 1][0], 1u);                  // every one of them codes an EOB
-      continue;
-    }
-    const float lambda = lambda_in[gblk0 + (inside ? blk : cc.nblk - 1)];
-    int nq = 0, qmax = 0;
-    float azd63;
-    {
-      const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + (inside ? (SORTED ? spos : blk) : cc.nblk - 1);
-      short xs[64];
-#pragma unroll
-      for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
-      const int *dq8 = Q->dq8[cc.qtbl];
-      const float *rcp = Q->rcp8q[cc.qtbl], *lt = Q->lambda_tbl[cc.qtbl];
-      float azd = 0.0f;
-#pragma unroll
-      for (int k = 1; k < 64; k++) {
-        const int xsg = xs[k];
-        const int x = xsg < 0 ? -xsg : xsg;
-        const int dq = dq8[k];
-        float t = (float)mul24(x, x) * lambda;
-        t = t * lt[k];
-        const float azd_cur = t + azd;
-        if (x + (dq >> 1) >= dq) {
-          int qval = FD ? udiv_mh(x + (dq >> 1), Q->sdiv[cc.qtbl][k], Q->mdiv[cc.qtbl][k]) : udiv_exact(x + (dq >> 1), dq, rcp[k]);
-          if (qval >= 1024) qval = 1023;
-          qmax = qval > qmax ? qval : qmax;
-          // (a block with more than QN records is deferred: what its surplus records overwrite in the last slot is never read)
-          col[nq < QN ? nq : QN - 1][lane] = make_uint2((unsigned)k | (xsg < 0 ? 64u : 0u) | ((unsigned)qval << 7) | ((unsigned)x << 17), __float_as_uint(azd));
-          nq++;
-        }
-        azd = azd_cur;
-      }
-      azd63 = azd;
-      defer_blocks(inside && (nq > QN || qmax >= 16), worklist, (unsigned)img, ((unsigned)comp << 28) | (unsigned)blk, 0u, xs, dense, dense_cap, true, lane,
-                   SORTED ? ((unsigned)comp << 28) | 0x08000000u | (unsigned)spos : 0xFFFFFFFFu);
-      count_heavy(worklist, inside, nq, lane);
-    }
-    const bool work = inside && nq <= QN && qmax < 16;
-    if (FST && inside && !work) nq8[gblk] = 0xFFu;     // deferred: its statistics are counted from its records (k_stats_ac_compact, deferred-only form)
-
-    // ---- the walk: every lane consumes its own records; the next record is always one load ahead ----
-    int nlive = 1, qi = 0, last = 0;
-    unsigned long long neg = 0ull;          // positions whose coefficient is negative (of the entries created so far)
-    bool act = work && nq > 0;
-    int i = 0, x = 0, qval = 0, ncd = 0, sgn = 0, e = 0, beste = -1, bestk = 0;
-    float azd_prev = 0.0f, azd_cur = 0.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f, best = 1e38f;
-    float end_best = azd63 + eobf;
-    uint2 rec_n = col[0][lane];
-    // quantizer constants of the NEXT record's position: lane k holds entry k of the component's rows, fetched with ds_bpermute
-    // at a point where every lane of the wave is enabled (a disabled source lane would read as 0)
-    int dq_n = 1;
-    float lt_n = 0.0f;
-    auto lookup = [&]() {
-      const int a = (int)(rec_n.x & 63u) << 2;
-      dq_n = __builtin_amdgcn_ds_bpermute(a, dq_lane) & 0x3FFFF;      // 8q <= 8 * 32767: tells the compiler the 24-bit multiplies are exact
-      lt_n = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(lt_lane)));
-    };
-    lookup();
-    auto setup = [&]() {
-      const uint2 rec = rec_n;
-      qi++;
-      rec_n = col[qi < QN ? qi : QN - 1][lane];      // (slots behind the consumed ones are never overwritten: entry e lives in slot e-1 <= qi-1)
-      i = (int)(rec.x & 63u); sgn = (int)((rec.x >> 6) & 1u); qval = (int)((rec.x >> 7) & 1023u); x = (int)(rec.x >> 17);
-      azd_prev = __uint_as_float(rec.y);
-      const int dq = dq_n;
-      const float lti = lt_n;
-      float t = (float)mul24(x, x) * lambda;
-      t = t * lti;
-      azd_cur = t + azd_prev;
-      ncd = bitlen((unsigned)qval);
-      float dd[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
-        const int delta = mul24(cand, dq) - x;
-        const float d = (float)mul24(delta, delta) * lambda;
-        dd[k] = k < ncd ? d * lti : 3e38f;
-      }
-      d0 = dd[0]; d1 = dd[1]; d2 = dd[2]; d3 = dd[3];
-      e = nlive; best = 1e38f; beste = -1; bestk = 0;
-    };
-    if (act) setup();
-    while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
-      lookup();
-      if (act) {
-        MJH_DIVERGENT_SCOPE;
-        float gap_old;
-        if (__builtin_amdgcn_ballot_w64(ncd > 2) == 0ull)
-          v3_pair<QN, 2>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk, gap_old);
-        else
-          v3_pair<QN, 4>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk, gap_old);
-        e -= 2;
-        // cost >= rhs >= gap in float arithmetic, and the gap only grows towards older entries: once it exceeds the best cost
-        // no older predecessor can win or tie
-        if (e <= 0 || gap_old > best) {
-          if (beste >= 0) {
-            const int mag = (bestk < ncd - 1) ? (2 << bestk) - 1 : qval;
-            col[nlive - 1][lane] = make_uint2(__float_as_uint(azd_cur), __float_as_uint(best));     // live entry nlive
-            info[nlive - 1][lane] = (unsigned short)((unsigned)i | ((unsigned)beste << 6) | ((unsigned)mag << 12));
-            neg |= (unsigned long long)sgn << i;
-            // end-of-block choice (jcdctmgr.c:1187-1207): entries appear in position order, strict '<' keeps the first minimum
-            float c = best + azd63;
-            c = c - azd_cur;
-            if (i < 63) c = c + eobf;
-            if (c < end_best) { end_best = c; last = nlive; }
-            nlive++;
-          }
-          if (qi >= nq) act = false;
-          else setup();
-        }
-      }
-    }
-
-    // ---- back-track (jcdctmgr.c:1211-1222) along the entry indices; values in visiting (descending position) order ----
-    unsigned long long pmask = 0ull;
-    int cnt = 0, e2 = work ? last : 0;
-    int up_pos = -1, up_mag = 0;          // FST: the path entry visited before this one (the next higher position)
-    unsigned *hh = fhist[FST ? (lane & 1) : 0];
-    auto count = [&](int run, int mag) {  // symbol of a coefficient of magnitude `mag` behind `run` zeros (jchuff.c:833-868)
-      if (run > 15) { atomicAdd(&hh[0xF0], (unsigned)(run >> 4)); run &= 15; }
-      atomicAdd(&hh[(run << 4) + bitlen((unsigned)mag)], 1u);
-    };
-    while (__builtin_amdgcn_ballot_w64(e2 > 0) != 0ull) {
-      if (e2 > 0) {
-        const unsigned inf = info[e2 - 1][lane];
-        const int mag = (int)(inf >> 12), pos = (int)(inf & 63u);
-        const int v = ((neg >> pos) & 1ull) ? -mag : mag;
-        colh[((cnt >> 2) * 64 + lane) * 4 + (cnt & 3)] = (unsigned short)v;
-        pmask |= 1ull << pos;
-        cnt++;
-        if (FST) {
-          if (up_pos >= 0) count(up_pos - pos - 1, up_mag);
-          else if (pos < 63) atomicAdd(&hh[0], 1u);          // the highest kept position is not 63: EOB
-          up_pos = pos; up_mag = mag;
-        }
-        e2 = (int)((inf >> 6) & 63u);
-      }
-    }
-    if (FST && work) {
-      if (up_pos >= 0) count(up_pos - 1, up_mag);            // the lowest kept position: its run starts behind the DC coefficient
-      else atomicAdd(&hh[0], 1u);                            // nothing kept: EOB
-    }
-    if (work) nzmask[gblk] = pmask;
-    {
-      int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
-      // plane i+1 <- the i-th non-zero in position order = slot cnt-1-i; a plane is stored only while some block has a value for it
-#pragma unroll
-      for (int i2 = 0; i2 < QN; i2++) {
-        if (__builtin_amdgcn_ballot_w64(i2 < cnt) == 0ull) break;
-        if (i2 < cnt) {
-          const int s2 = cnt - 1 - i2;
-          qo[(size_t)(i2 + 1) * cc.kstride] = (int16_t)colh[((s2 >> 2) * 64 + lane) * 4 + (s2 & 3)];
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (FST) {
-    const int sslot = comp == 0 ? stat_slot_of_comp.x : comp == 1 ? stat_slot_of_comp.y : comp == 2 ? stat_slot_of_comp.z : stat_slot_of_comp.w;
-    MjhHuffTable *TS = stat_tabs + (size_t)img * slots_per_image + sslot;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int bin = lane + 64 * j;
-      unsigned sum = fhist[0][bin] + fhist[1][bin];
-      // every dummy block of the interleaved scan codes one EOB (all-zero AC, jccoefct.c:312-345): counted once per component
-      if (bin == 0 && tl == t0) sum += (unsigned)(cc.wpad * cc.hpad - cc.nblk);
-      if (sum) atomicAdd(&TS->counts[bin], sum);
-    }
-  }
+  constexpr bool SORTED = false;
+  const uint16_t *const perm16 = nullptr;
+#include "mjh_trellis_v3.inc"
 }
 
+#ifndef MJH_TU_SORTED   // (mjh_sorted.hip includes this file for the shared device functions only)
 // =============================================================================================
 // K6  DC trellis (row a9, DC part): quantize_trellis jcdctmgr.c:1044-1118 + :1308-1327, driven
 // per iMCU row by compress_trellis_pass jccoefct.c:418-441 (lastDC = 0 at the start of each
@@ -3664,11 +3361,9 @@ void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, vo
 {
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
   const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
-  if (perm16) {   // tile-sorted coefficient planes for the tile-sorted trellis: one workgroup of four waves per 256-block tile
+  if (perm16) {   // tile-sorted coefficient planes for the tile-sorted trellis (mjh_sorted.hip)
     if (C.precision == 12 || !fastdiv || !nq8) { fprintf(stderr, "mjh_launch_dct: tile-sorted planes need 8-bit samples, the fast division and the key array\n"); abort(); }
-    dim3 gridt((max_nblk(C) + 255) / 256, C.ncomp, n);
-    if (stat_tabs) hipLaunchKernelGGL((k_dct_quant_sorted<true, true>), gridt, dim3(256), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8, perm16);
-    else hipLaunchKernelGGL((k_dct_quant_sorted<false, true>), gridt, dim3(256), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8, perm16);
+    mjh_launch_dct_sorted(C, Q, planes, uq, q, lambda, stat_tabs, spi, stat_slot, nq8, n, s, perm16);
     return;
   }
   if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t, false>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
@@ -3720,7 +3415,7 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   // the EXT instantiations
   const bool extended = Ss != 1 || Se != 63 || eob_cost != nullptr || qstride != 0;
   MjhTrellisExt ext;
-  ext.Ss = Ss; ext.Se = Se; ext.eob_cost = (float2 *)eob_cost; ext.eob_has = eob_has; ext.nzmask = nzmask; ext.qstride = qstride; ext.perm16 = perm16;
+  ext.Ss = Ss; ext.Se = Se; ext.eob_cost = (float2 *)eob_cost; ext.eob_has = eob_has; ext.nzmask = nzmask; ext.qstride = qstride;
   const int4 sl = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
   // stat_slot != nullptr: the statistics of the final coefficients go to these table slots (one per component)
   MjhHuffTable *st = stat_slot ? tabs : nullptr;
@@ -3759,14 +3454,10 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     for (int i = C.ncomp; i < 4; i++) t0[i] = 0x7FFFFFFF;
     const int4 tv = make_int4(t0[0], t0[1], t0[2], t0[3]);
 #define LV3Q(QN, NP, FDV, FSV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, NP, FDV, FSV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask, st, ss)
-#define LV3S(QN, FSV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, 4, true, FSV, true>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask, st, ss, perm16)
 #define LV3(NP, FDV, FSV) LV3Q(16, NP, FDV, FSV)
-    if (perm16) {   // the planes are tile-sorted already (mjh_launch_dct with the same array): only the four-pass kernels read that layout
+    if (perm16) {   // the planes are tile-sorted already (mjh_launch_dct with the same array): the kernels of mjh_sorted.hip read that layout
       if (!fastdiv) { fprintf(stderr, "mjh_launch_trellis_ac: tile-sorted planes need the fast division\n"); abort(); }
-      if (variant >= 3 && !st) { if (variant == 3) LV3S(32, false); else LV3S(48, false); }
-      else if (variant > 0) { if (st) LV3S(24, true); else LV3S(24, false); }
-      else if (st) LV3S(16, true);
-      else LV3S(16, false);
+      mjh_launch_trellis_ac_sorted(C, Q, uq, q, tabs, spi, ac_slot, lambda, worklist, worklist2, dense, dense_cap, stat_slot, variant, nzmask, n, s, nq8, perm16);
     } else
     if (small24) LV3Q(24, 1, true, false);
     else if (variant >= 3 && !st) {   // q90 and up: 32 / 48 records (20 / 30 KB of LDS per wave)
@@ -3779,8 +3470,9 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     else if (!fastdiv) LV3(4, false, false);
     else switch (np) { case 8: LV3(8, true, false); break; case 4: LV3(4, true, false); break; case 2: LV3(2, true, false); break; default: LV3(1, true, false); break; }
 #undef LV3
-#undef LV3S
 #undef LV3Q
+    if (perm16) ;   // (mjh_launch_trellis_ac_sorted launched its general tiers itself: entries without a dense copy name a place in the sorted planes)
+    else
     if (variant >= 3 && !st)   // what is left has more than 32 records or a magnitude >= 16: one general tier that takes everything
       hipLaunchKernelGGL((k_trellis_ac_qd<63, false, false, true>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
                          (const unsigned *)worklist, (unsigned *)nullptr, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
@@ -3949,3 +3641,4 @@ void mjh_launch_qopt_fix(const MjhQuant *Q, void *out, size_t out_stride, unsign
   for (int i = 0; i < 4; i++) L.tab[i] = i < ntab ? tabs[i] : 0;
   hipLaunchKernelGGL(k_qopt_fix, dim3(n), dim3(256), 0, s, Q, (uint8_t *)out, out_stride, sizes, L);
 }
+#endif  // MJH_TU_SORTED

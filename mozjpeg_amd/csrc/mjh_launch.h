@@ -10,6 +10,12 @@ void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size
 void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
                     MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv = 0,   // fastdiv: every table in use has q <= 255 (MjhQuant.mdiv)
                     uint16_t *perm16 = nullptr);   // perm16: planes 1..63 of uq in tile-sorted order (8-bit samples, fastdiv; mjh_launch_trellis_ac gets the same array)
+// mjh_sorted.hip (called by mjh_launch_dct / mjh_launch_trellis_ac when perm16 is given)
+void mjh_launch_dct_sorted(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
+                           MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, uint16_t *perm16);
+void mjh_launch_trellis_ac_sorted(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
+                                  unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
+                                  unsigned long long *nzmask, int n, hipStream_t s, uint8_t *nq8, const uint16_t *perm16);
 // nzmask != nullptr (here and in mjh_launch_encode / mjh_launch_trellis_ac): the AC planes hold COMPACT records (plane i+1 = the block's i-th
 // non-zero value in position order, nzmask = its non-zero positions) instead of one plane per position
 void mjh_launch_stats_ac(const MjhConst &C, const void *q, const unsigned long long *nzmask, MjhHuffTable *tabs, int spi, const int slot[4], int count_dummies, int n, hipStream_t s);

@@ -210,28 +210,78 @@ def test_committed_bench_lines_of_the_other_configurations_name_their_own_domina
 
 def test_traffic_figures_are_quoted_only_for_the_kernels_they_were_measured_on(monkeypatch):
     """roofline.traffic comes from committed PMC passes, so it must not outlive the kernels it was
-    taken on.  tools/pmc_traffic.py stamps every summary with a hash of the kernel sources (and the git head); bench.py
-    quotes a summary only while the tree still hashes to its stamp, and says 'stale' otherwise."""
+    taken on.  tools/pmc_traffic.py stamps every summary with a hash of the kernel sources, the git head and a fingerprint
+    of each kernel's machine code (tools/kernel_isa.py); bench.py quotes a summary while the sources hash to its stamp, or
+    -- when only comments, annotations or other kernels changed -- while every kernel of the focus interval still compiles
+    to the fingerprinted code, and says 'stale' otherwise."""
     import glob
     import json
     import sys
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench
+    import kernel_isa
     stamp = bench.kernel_source_stamp()
     traffic, src = bench.dominant_traffic("metric", "trellis_ac", 64)
     if traffic is not None:
-        path = os.path.join(ROOT, src.split(" ")[0])
-        assert json.load(open(path))["kernel_source_stamp"] == stamp and "git" in src
+        pmc = json.load(open(os.path.join(ROOT, src.split(" ")[0])))
+        assert "git" in src
+        if pmc["kernel_source_stamp"] != stamp:
+            now = bench.kernel_fingerprints()
+            focus = [k for k in pmc["kernels"] if k.startswith("k_trellis_ac")]
+            assert focus and all(now[k] == pmc["kernel_isa"][k] for k in focus) and "machine code" in src
     else:
         assert src.startswith("stale") or src.startswith("no PMC passes")
-    monkeypatch.setattr(bench, "kernel_source_stamp", lambda: "0" * 16)           # any other tree
+    # any other tree: other sources AND other machine code
+    monkeypatch.setattr(bench, "kernel_source_stamp", lambda: "0" * 16)
+    monkeypatch.setattr(bench, "kernel_fingerprints", lambda: {})
     traffic, src = bench.dominant_traffic("metric", "trellis_ac", 64)
     assert traffic is None and (src.startswith("stale") or src.startswith("no PMC passes"))
-    # the summaries of this round carry the stamp
+    # one kernel of the interval recompiled to something else: stale, whatever the others do
+    real = json.load(open(os.path.join(ROOT, "mozjpeg_amd", "kernel_isa.json")))
+    fp = {k: v["sha"] for k, v in real["kernels"].items()}
+    fp["k_trellis_ac_qd<32, false, false, true>"] = "f" * 16
+    monkeypatch.setattr(bench, "kernel_fingerprints", lambda: fp)
+    traffic, src = bench.dominant_traffic("metric", "trellis_ac", 64)
+    assert traffic is None and src.startswith("stale")
+    # ... while an interval that kernel does not belong to is still quoted (when its passes are committed at all)
+    t2, s2 = bench.dominant_traffic("metric", "dct_quant", 64)
+    assert t2 is not None or s2.startswith("no PMC passes") or s2.startswith("stale")
+    # the committed fingerprints belong to the sources in the tree (build() refreshes them; `python tools/kernel_isa.py`)
+    assert real["source_stamp"] == kernel_isa.source_stamp(), "mozjpeg_amd/kernel_isa.json is older than mozjpeg_amd/csrc: run python tools/kernel_isa.py"
+    # the summaries of this round carry the stamps
     new = [p for p in glob.glob(os.path.join(ROOT, "profiles", "r0[4-9]*pmc_hbm_traffic*.json"))]
     for p in new:
         j = json.load(open(p))
         assert len(j.get("kernel_source_stamp", "")) == 16 and j.get("profile_head"), p
+
+
+def test_kernel_fingerprints_ignore_labels_and_comments_but_not_code():
+    """tools/kernel_isa.py: the per-kernel text that gets hashed"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_isa as K
+    asm = """
+\t.text
+\t.globl\t_Z3k_av
+_Z3k_av:                                ; @_Z3k_av
+; %bb.0:
+\ts_load_dword s0, s[0:1], 0x0          ; a comment
+.LBB7_2:
+\tv_add_u32_e32 v1, s0, v0
+\ts_cbranch_execz .LBB7_2
+\ts_endpgm
+.Lfunc_end7:
+\t.amdhsa_kernel _Z3k_av
+\t\t.amdhsa_next_free_vgpr 2
+\t.end_amdhsa_kernel
+"""
+    a = K.split_kernels(asm)["_Z3k_av"]
+    b = K.split_kernels(asm.replace(".LBB7_2", ".LBB12_2").replace("Lfunc_end7", "Lfunc_end12").replace("a comment", "another"))["_Z3k_av"]
+    c = K.split_kernels(asm.replace("v_add_u32_e32 v1", "v_add_u32_e32 v2"))["_Z3k_av"]
+    d = K.split_kernels(asm.replace("next_free_vgpr 2", "next_free_vgpr 3"))["_Z3k_av"]
+    assert a == b and a != c and a != d and len(a) == 6
+    assert K.short("void k_x<16, 4, true>(MjhConst, int*)") == "k_x<16, 4, true>"
 
 
 def test_arithmetic_coder_on_the_host_matches_a_plain_restatement_of_jcarith(tmp_path):

@@ -405,12 +405,16 @@ def test_every_first_tier_capacity_of_the_ac_trellis_gives_the_same_file(quality
 
 
 @pytest.mark.parametrize("quality,sample", [(75, (2, 2)), (90, (1, 1)), (97, (1, 1))])
-def test_tile_sorted_coefficient_planes_give_the_same_file(quality, sample):
+def test_tile_sorted_coefficient_planes_give_the_same_file(quality, sample, request):
     """MJH_SORTED_UQ: the FDCT kernel (four waves = one trellis tile of 256 blocks) sorts each tile by the blocks' keys and
     stores planes 1..63 of coef_uq in that order; a pass of the tile-sorted trellis then reads one line per plane.  Same files
     as the natural layout and as the oracle -- at every first-tier capacity, with ragged last tiles (600x424: 3975 luma blocks
     = 15 tiles + 135), when the deferred blocks outgrow their dense copies (MJH_DENSE_CAP: the general tiers then find a block
-    through its tile's permutation), with the statistics fused into either kernel, sequential and progressive."""
+    through its tile's permutation), with the statistics fused into either kernel, sequential and progressive.
+    The layout is OPT-IN (it was written after round 4's GPU minutes were spent): this test runs under the emulator
+    (`--simt`, where it passes) and, on the chip, only when asked for (MJH_TEST_SORTED=1) -- round 5's first GPU call."""
+    if not request.config.getoption("--simt") and os.environ.get("MJH_TEST_SORTED") != "1":
+        pytest.skip("opt-in kernels (MJH_SORTED_UQ) that have only run under tools/simt so far: set MJH_TEST_SORTED=1 to run them on the chip")
     w, h = 600, 424
     rng = np.random.default_rng(quality)
     img = O.synthetic_frame(w, h, 60 + quality)

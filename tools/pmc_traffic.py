@@ -51,8 +51,11 @@ def main():
             head += "+uncommitted"
     except Exception:
         head = "unknown"
+    # ... or, kernel by kernel, while the machine code is still the one that ran here (tools/kernel_isa.py; build() writes the file)
+    now = bench.kernel_fingerprints()
     print(json.dumps({
         "profile_head": head, "kernel_source_stamp": bench.kernel_source_stamp(),
+        "kernel_isa": {k: now[k] for k in kernels if k in now},
         "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate --kernel-trace passes; bytes per launch "
                 "(%d frames); fetch scaled by the factor calibrated on k_color's known input bytes" % frames,
         "frames_per_launch": frames, "fetch_calibration_factor": round(factor, 4), "kernels": kernels}, indent=1))
