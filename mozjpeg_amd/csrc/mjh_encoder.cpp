@@ -287,8 +287,9 @@ struct mjh_encoder {
   // compact coefficient records between the AC trellis and the sequential coder: non-zero position masks;
   // the values live in the AC planes of d_q, plane i+1 = i-th non-zero.  compact_last: the last batch's d_q is in that form
   unsigned long long *d_nzmask = nullptr; bool use_compact = false, compact_last = false;
-  uint16_t *d_perm16 = nullptr;      // tile-sorted coefficient planes (MJH_SORTED_UQ): per block place, the block's index in its tile of 256 | sort key << 9
+  uint16_t *d_perm16 = nullptr;      // tile-sorted coefficient planes (MJH_SORTED_UQ): per block place, the block's index in its tile | sort key << 9
   size_t sorted_uq_min = 400000;     // MJH_SORTED_UQ=n (n > 1): tile-sorted planes for batches of at least n blocks (tests: 2 = every batch)
+  int sorted_tile = 256;             // MJH_SORTED_TILE=128|256|512: blocks per sorted tile = 64 x the waves of the FDCT workgroup = 64 x the trellis kernel's passes
   bool sorted_uq = false;            // MJH_SORTED_UQ=1: opt-in until it has been timed on the chip (bit-exact in the emulator, tools/simt); off: the FDCT kernel
                                      // writes every coefficient plane in natural order and the trellis sorts its tiles itself
   uint8_t *d_nq8 = nullptr;          // per block: non-zero conventionally quantized AC coefficients (FDCT kernel) = tile-sort key of the AC trellis
@@ -889,6 +890,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     if (e->use_compact) HIPCHK_E(mjh_dmalloc((void **)&e->d_nzmask, B * (size_t)C.total_real_blocks * sizeof(unsigned long long)));
     if (e->use_compact && p->trellis_quant) HIPCHK_E(mjh_dmalloc((void **)&e->d_nq8, B * (size_t)C.total_real_blocks));
     if (const char *sv = getenv("MJH_SORTED_UQ")) { e->sorted_uq = atoi(sv) != 0; if (atoi(sv) > 1) e->sorted_uq_min = (size_t)atoi(sv); }
+    if (const char *tv = getenv("MJH_SORTED_TILE")) { const int t = atoi(tv); if (t == 128 || t == 256 || t == 512) e->sorted_tile = t; }
     if (e->use_compact && p->trellis_quant && e->sorted_uq) HIPCHK_E(mjh_dmalloc((void **)&e->d_perm16, B * (size_t)C.total_real_blocks * sizeof(uint16_t)));
   }
   if (p->trellis_quant) {   // room for a quarter of all blocks (typically 1-2 % overflow); the rest would be read from the planes
@@ -1393,12 +1395,12 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   // planes 1..63 of coef_uq in that order, so that a pass of the trellis reads ONE line of every plane instead of all four
   // (the passes of a tile it sorted itself re-read every line, 4.6x the algorithmic bytes of the interval).  Debug taps expose
   // coef_uq in natural order, so they keep the natural layout.
-  const bool sort_uq = compact && e->d_perm16 && e->d_nq8 && e->fastdiv_all && C.precision == 8 && !fuse_fin && e->trellis_v3 == 4 && e->trellis_variant <= 4 &&
+  const bool sort_uq = compact && e->d_perm16 && e->d_nq8 && e->fastdiv_all && C.precision == 8 && !fuse_fin && e->trellis_v3 > 0 && e->trellis_variant <= 4 &&
                        nbands == 1 && !ext_eob && !ext_qopt && !e->arith && !e->debug_taps && (size_t)n * C.total_real_blocks >= e->sorted_uq_min;
   uint16_t *const perm16 = sort_uq ? e->d_perm16 : nullptr;
   if (!coef_src) {
     pr.mark("dct_quant");
-    mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, e->d_nq8, n, s, e->fastdiv_all, perm16);
+    mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, e->d_nq8, n, s, e->fastdiv_all, perm16, e->sorted_tile);
   }
 
   if (e->arith) {
@@ -1556,7 +1558,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
                           (v3_stats || (fuse_fin && p.optimize_coding && last_loop)) ? fin_ac : nullptr, e->trellis_variant,
                           Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, nzm, qstride, n, s,
                           e->d_nq8, v3 ? ((size_t)n * C.total_real_blocks < 400000 ? 1 : e->trellis_v3) : 0,   // (a small batch: one pass per tile -- four times the workgroups, a quarter of their length: latency matters more than the sorting)
-                          e->fastdiv_all, v3 ? perm16 : nullptr);
+                          e->fastdiv_all, v3 ? perm16 : nullptr, e->sorted_tile);
     if (perm16 && !v3) return fail(MJH_EINVAL, "internal: tile-sorted coefficient planes without the tile-sorted trellis");
     if (e->trellis_adapt && !extended && first_pass) {
       e->h_defer[4] = (unsigned)n;

@@ -355,13 +355,13 @@ __device__ __forceinline__ float catmull_rom(int v1, int v2, int v3, int v4, flo
 // FD: every quantizer step of the tables in use fits 8 bits -- the division by 8q is one shift + one 24-bit multiply-high
 // (MjhQuant.mdiv / sdiv) instead of the float-reciprocal division with its integer fix-up; with STATS the AC coefficients are
 // quantized for the statistics only, which need the magnitude category and nothing else (no sign, no signed clamp).
-// SORTED (8-bit samples feeding the tile-sorted AC trellis, k_trellis_ac_v3<.., SORTED>): the workgroup has FOUR waves = the
-// four 64-block lines of one trellis tile, every lane still owns one block; the waves exchange only the blocks' sort keys
+// SORTED (8-bit samples feeding the tile-sorted AC trellis, k_trellis_ac_v3s): the workgroup has SORTED (2 / 4 / 8) waves = the
+// 64-block lines of one trellis tile, every lane still owns one block; the waves exchange only the blocks' sort keys
 // (min(non-zero quantized AC coefficients, 63)) through LDS and store planes 1..63 of coef_uq at the block's place in the
 // tile's descending-key order instead of its natural place, plus perm_out[tile_base + place] = index in tile | key << 9 (the
 // trellis kernel's own permutation entry).  A pass of the trellis kernel then reads ONE line of every plane, each line once
 // (unsorted planes: every pass touches all four lines of the tile).  Plane 0 (DC), lambda, nq8 and coef_q stay in natural order.
-template <class T, bool STATS, bool FD, bool SORTED = false>   // uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
+template <class T, bool STATS, bool FD, int SORTED = 0>   // SORTED: waves per workgroup of the tile-sorted form (2 / 4 / 8 = tiles of 128 / 256 / 512 blocks), 0 = natural order; uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
 __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant *__restrict__ Q, const T *__restrict__ planes,
                                                int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
                                                MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out,
@@ -372,7 +372,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
   // 8 KB per wave: the deringing columns (the ORIGINAL level-shifted samples of the lane's block in zig-zag order, 16 bits
   // each for 8- and 12-bit data) and, afterwards, 8 interleaved copies of the 256-bin statistics histogram
   constexpr int LW = 32;
-  constexpr int NW = SORTED ? 4 : 1;      // waves per workgroup
+  constexpr int NW = SORTED ? SORTED : 1;      // waves per workgroup
   __shared__ int lds_raw[NW][64][LW];
   typedef short dcol_t;
   typedef dcol_t __attribute__((may_alias)) dcol_alias;
@@ -567,10 +567,10 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
     __syncthreads();
     if (valid) {
       const unsigned place = s_sort[key] + rank;
-      int16_t *us = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + (size_t)blockIdx.x * 256 + place;
+      int16_t *us = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + (size_t)blockIdx.x * (64 * NW) + place;
 #pragma unroll
       for (int k = 1; k < 64; k++) us[(size_t)k * cc.kstride] = (int16_t)d[kZZ.v[k]];
-      perm_out[(size_t)img * C.total_real_blocks + cc.blk_off + (size_t)blockIdx.x * 256 + place] = (uint16_t)((unsigned)(wv * 64 + lane) | (key << 9));
+      perm_out[(size_t)img * C.total_real_blocks + cc.blk_off + (size_t)blockIdx.x * (64 * NW) + place] = (uint16_t)((unsigned)(wv * 64 + lane) | (key << 9));
     }
   }
   if (stats) {
@@ -1809,6 +1809,7 @@ k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
                 MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp, MjhTrellisExt ext)
 {
   constexpr bool PERM = false;
+  constexpr int perm_tile = 256;
   const uint16_t *const perm16 = nullptr;
 #include "mjh_trellis_qd.inc"
 }
@@ -3357,13 +3358,13 @@ static int max_nblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp;
 static int max_padblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp; i++) { int v = C.c[i].wpad * C.c[i].hpad; m = v > m ? v : m; } return m; }
 
 void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
-                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv, uint16_t *perm16)
+                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv, uint16_t *perm16, int sorted_tile)
 {
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
   const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
   if (perm16) {   // tile-sorted coefficient planes for the tile-sorted trellis (mjh_sorted.hip)
     if (C.precision == 12 || !fastdiv || !nq8) { fprintf(stderr, "mjh_launch_dct: tile-sorted planes need 8-bit samples, the fast division and the key array\n"); abort(); }
-    mjh_launch_dct_sorted(C, Q, planes, uq, q, lambda, stat_tabs, spi, stat_slot, nq8, n, s, perm16);
+    mjh_launch_dct_sorted(C, Q, planes, uq, q, lambda, stat_tabs, spi, stat_slot, nq8, n, s, perm16, sorted_tile);
     return;
   }
   if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t, false>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
@@ -3409,7 +3410,7 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
-                           uint8_t *nq8, int v3_passes, int fastdiv, const uint16_t *perm16)
+                           uint8_t *nq8, int v3_passes, int fastdiv, const uint16_t *perm16, int sorted_tile)
 {
   // band-limited pass (use_scans_in_trellis), the per-block outputs of trellis_eob_opt, per-image tables (trellis_q_opt):
   // the EXT instantiations
@@ -3446,7 +3447,7 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     // next to nothing is left for the general tiers, whose fixed latency (~80 us) would sit on the critical path
     const bool small24 = !perm16 && v3_passes == 1 && variant <= 2 && !st && fastdiv;
     if (small24) variant = 2;
-    // (tile-sorted planes, perm16: written for tiles of 256 blocks -- four passes whatever else the arguments say)
+    // (tile-sorted planes, perm16: mjh_launch_trellis_ac_sorted sizes its own grid from sorted_tile; np only matters for the kernels below)
     const int np = perm16 ? 4 : small24 ? 1 : (!fastdiv || st || variant > 0) ? 4 : v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
     int t0[5] = { 0, 0, 0, 0, 0 };
     for (int i = 0; i < 4; i++) t0[i + 1] = t0[i] + (i < C.ncomp ? (C.c[i].nblk + 64 * np - 1) / (64 * np) : 0);
@@ -3457,7 +3458,7 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
 #define LV3(NP, FDV, FSV) LV3Q(16, NP, FDV, FSV)
     if (perm16) {   // the planes are tile-sorted already (mjh_launch_dct with the same array): the kernels of mjh_sorted.hip read that layout
       if (!fastdiv) { fprintf(stderr, "mjh_launch_trellis_ac: tile-sorted planes need the fast division\n"); abort(); }
-      mjh_launch_trellis_ac_sorted(C, Q, uq, q, tabs, spi, ac_slot, lambda, worklist, worklist2, dense, dense_cap, stat_slot, variant, nzmask, n, s, nq8, perm16);
+      mjh_launch_trellis_ac_sorted(C, Q, uq, q, tabs, spi, ac_slot, lambda, worklist, worklist2, dense, dense_cap, stat_slot, variant, nzmask, n, s, nq8, perm16, sorted_tile);
     } else
     if (small24) LV3Q(24, 1, true, false);
     else if (variant >= 3 && !st) {   // q90 and up: 32 / 48 records (20 / 30 KB of LDS per wave)

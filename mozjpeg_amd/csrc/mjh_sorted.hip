@@ -17,18 +17,19 @@
 #include "mjh_kernels.hip"
 #include "mjh_launch.h"
 
-template <bool STATS, bool FD>
-__global__ void __launch_bounds__(256)
+template <bool STATS, int NW>   // NW waves = one trellis tile of 64 * NW blocks per workgroup
+__global__ void __launch_bounds__(64 * NW)
 k_dct_quant_sorted(MjhConst C, const MjhQuant *__restrict__ Q, const uint8_t *__restrict__ planes,
                    int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
                    MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out,
                    uint16_t *__restrict__ perm_out)
 {
-  dct_quant_body<uint8_t, STATS, FD, true>(C, Q, planes, coef_uq, coef_q, lambda_out, stat_tabs, slots_per_image, stat_slot_of_comp, nq8_out, perm_out);
+  dct_quant_body<uint8_t, STATS, true, NW>(C, Q, planes, coef_uq, coef_q, lambda_out, stat_tabs, slots_per_image, stat_slot_of_comp, nq8_out, perm_out);
 }
 
-// the same passes over tile-sorted coefficient planes (k_dct_quant_sorted wrote them and perm16): four passes, fast division
-template <int QN, bool FST>
+// the same passes over tile-sorted coefficient planes (k_dct_quant_sorted wrote them and perm16): NPASS passes per tile of
+// 64 * NPASS blocks, fast division
+template <int QN, bool FST, int NPASS>
 __global__ void __launch_bounds__(64)
 k_trellis_ac_v3s(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q,
                  const MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 ac_slot_of_comp, int4 tile0_of_comp,
@@ -37,59 +38,67 @@ k_trellis_ac_v3s(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__re
                  MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp, const uint16_t *__restrict__ perm16)
 {
   constexpr bool SORTED = true, FD = true;
-  constexpr int NPASS = 4;
 #include "mjh_trellis_v3.inc"
 }
 
-template <int QN2>   // the general tiers behind k_trellis_ac_v3s (plain compact pass, no fused statistics)
+template <int QN2>   // the general tiers behind k_trellis_ac_v3s (plain compact pass, no fused statistics); perm_tile: blocks per sorted tile
 __global__ void __launch_bounds__(64)
 k_trellis_ac_qds(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
                  int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
                  int4 ac_slot_of_comp, const float *__restrict__ lambda_in, const unsigned *__restrict__ worklist,
                  unsigned *__restrict__ worklist_next, const int16_t *__restrict__ dense, unsigned dense_cap,
-                 MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp, MjhTrellisExt ext, const uint16_t *__restrict__ perm16)
+                 MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp, MjhTrellisExt ext, const uint16_t *__restrict__ perm16, int perm_tile)
 {
   constexpr bool PERM = true, FSTATS = false, EXT = false, COMPACT = true;
 #include "mjh_trellis_qd.inc"
 }
 
-
 static int sorted_max_nblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp; i++) m = C.c[i].nblk > m ? C.c[i].nblk : m; return m; }
+static void bad_tile(int t) { fprintf(stderr, "mjh_sorted: tiles of %d blocks do not exist (128, 256, 512)\n", t); abort(); }
 
 void mjh_launch_dct_sorted(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
-                           MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, uint16_t *perm16)
+                           MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, uint16_t *perm16, int sorted_tile)
 {
-  // one workgroup of four waves per 256-block tile
+  // one workgroup of sorted_tile / 64 waves per tile
   const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
-  dim3 gridt((sorted_max_nblk(C) + 255) / 256, C.ncomp, n);
-  if (stat_tabs) hipLaunchKernelGGL((k_dct_quant_sorted<true, true>), gridt, dim3(256), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8, perm16);
-  else hipLaunchKernelGGL((k_dct_quant_sorted<false, true>), gridt, dim3(256), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8, perm16);
+  dim3 gridt((sorted_max_nblk(C) + sorted_tile - 1) / sorted_tile, C.ncomp, n);
+#define LDCT(ST, NW) hipLaunchKernelGGL((k_dct_quant_sorted<ST, NW>), gridt, dim3(64 * NW), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8, perm16)
+  switch (sorted_tile) {
+    case 128: if (stat_tabs) LDCT(true, 2); else LDCT(false, 2); break;
+    case 256: if (stat_tabs) LDCT(true, 4); else LDCT(false, 4); break;
+    case 512: if (stat_tabs) LDCT(true, 8); else LDCT(false, 8); break;
+    default: bad_tile(sorted_tile);
+  }
+#undef LDCT
 }
 
-// first tier (four passes per tile of 256 blocks, whatever else the caller would choose) + the general tiers; the caller has
+// first tier (sorted_tile / 64 passes per tile, whatever else the caller would choose) + the general tiers; the caller has
 // zeroed the work-list counters and counts the deferred blocks' statistics afterwards (mjh_launch_trellis_ac)
 void mjh_launch_trellis_ac_sorted(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                                   unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
-                                  unsigned long long *nzmask, int n, hipStream_t s, uint8_t *nq8, const uint16_t *perm16)
+                                  unsigned long long *nzmask, int n, hipStream_t s, uint8_t *nq8, const uint16_t *perm16, int sorted_tile)
 {
   MjhTrellisExt ext;
   ext.Ss = 1; ext.Se = 63; ext.eob_cost = nullptr; ext.eob_has = nullptr; ext.nzmask = nzmask; ext.qstride = 0;
   const int4 sl = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
   MjhHuffTable *st = stat_slot ? tabs : nullptr;
   const int4 ss = stat_slot ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
+  if (sorted_tile != 128 && sorted_tile != 256 && sorted_tile != 512) bad_tile(sorted_tile);
   int t0[5] = { 0, 0, 0, 0, 0 };
-  for (int i = 0; i < 4; i++) t0[i + 1] = t0[i] + (i < C.ncomp ? (C.c[i].nblk + 255) / 256 : 0);
+  for (int i = 0; i < 4; i++) t0[i + 1] = t0[i] + (i < C.ncomp ? (C.c[i].nblk + sorted_tile - 1) / sorted_tile : 0);
   dim3 gridt(t0[C.ncomp], n);
   for (int i = C.ncomp; i < 4; i++) t0[i] = 0x7FFFFFFF;   // components that do not exist never match
   const int4 tv = make_int4(t0[0], t0[1], t0[2], t0[3]);
-#define LV3S(QN, FSV) hipLaunchKernelGGL((k_trellis_ac_v3s<QN, FSV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask, st, ss, perm16)
-  if (variant >= 3 && !st) { if (variant == 3) LV3S(32, false); else LV3S(48, false); }
-  else if (variant > 0) { if (st) LV3S(24, true); else LV3S(24, false); }
-  else if (st) LV3S(16, true);
-  else LV3S(16, false);
+#define LV3S(QN, FSV, NP) hipLaunchKernelGGL((k_trellis_ac_v3s<QN, FSV, NP>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask, st, ss, perm16)
+#define LV3T(QN, FSV) do { if (sorted_tile == 128) LV3S(QN, FSV, 2); else if (sorted_tile == 512) LV3S(QN, FSV, 8); else LV3S(QN, FSV, 4); } while (0)
+  if (variant >= 3 && !st) { if (variant == 3) LV3T(32, false); else LV3T(48, false); }
+  else if (variant > 0) { if (st) LV3T(24, true); else LV3T(24, false); }
+  else if (st) LV3T(16, true);
+  else LV3T(16, false);
+#undef LV3T
 #undef LV3S
 #define LDS_(QN, GRID, WL, WLN) hipLaunchKernelGGL((k_trellis_ac_qds<QN>), dim3(GRID), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda, \
-                                                   (const unsigned *)WL, WLN, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext, perm16)
+                                                   (const unsigned *)WL, WLN, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext, perm16, sorted_tile)
   if (variant >= 3 && !st) LDS_(63, 2048, worklist, (unsigned *)nullptr);   // what is left has more than 32 records or a magnitude >= 16
   else { LDS_(32, 2048, worklist, worklist2); LDS_(63, 1024, worklist2, (unsigned *)nullptr); }
 #undef LDS_

@@ -420,13 +420,16 @@ def test_tile_sorted_coefficient_planes_give_the_same_file(quality, sample, requ
     img = O.synthetic_frame(w, h, 60 + quality)
     img[100:300, 200:500] = rng.integers(0, 256, (200, 300, 3), dtype=np.uint8)
     frames = np.stack([img, img[::-1].copy(), img])
-    knobs = ("MJH_SORTED_UQ", "MJH_TRELLIS_VARIANT", "MJH_DENSE_CAP", "MJH_FUSE")
+    knobs = ("MJH_SORTED_UQ", "MJH_TRELLIS_VARIANT", "MJH_DENSE_CAP", "MJH_FUSE", "MJH_SORTED_TILE")
     for kw in (dict(quality=quality, baseline=True, sample=sample), dict(quality=quality, fastcrush=True, sample=sample),
                dict(quality=quality, baseline=True, sample=sample, trellis_loops=2)):
         want = O.encode(O.make_params(w, h, **kw), img)
-        for variant, dense, fuse in (("0", None, None), ("2", None, None), ("3", None, None), ("4", None, None), (None, None, None),
-                                     ("0", "8", None), (None, "0", None), ("0", None, "5"), ("2", "40", "5")):
-            env = {"MJH_SORTED_UQ": "2", "MJH_TRELLIS_VARIANT": variant, "MJH_DENSE_CAP": dense, "MJH_FUSE": fuse}
+        # (tiles of 128 / 256 / 512 blocks = FDCT workgroups of 2 / 4 / 8 waves and as many passes of the trellis kernel)
+        for variant, dense, fuse, tile in (("0", None, None, None), ("2", None, None, None), ("3", None, None, None), ("4", None, None, None), (None, None, None, None),
+                                           ("0", "8", None, None), (None, "0", None, None), ("0", None, "5", None), ("2", "40", "5", None),
+                                           ("0", None, None, "128"), ("0", "8", "5", "128"), ("3", "0", None, "128"), (None, None, None, "128"),
+                                           ("0", None, None, "512"), ("2", "8", "5", "512"), ("4", "0", None, "512"), (None, None, None, "512")):
+            env = {"MJH_SORTED_UQ": "2", "MJH_TRELLIS_VARIANT": variant, "MJH_DENSE_CAP": dense, "MJH_FUSE": fuse, "MJH_SORTED_TILE": tile}
             try:
                 for k, v in env.items():
                     if v is not None:
@@ -439,3 +442,21 @@ def test_tile_sorted_coefficient_planes_give_the_same_file(quality, sample, requ
                 got = enc.encode_host(frames)
                 assert got[0] == want and got[2] == want, (kw, env, rnd)
             enc.close()
+
+
+@pytest.mark.parametrize("w,h", [(65500, 9), (9, 65500), (65500, 1), (1, 65500)])
+def test_frames_at_the_largest_dimension_jpeg_allows(w, h):
+    """JPEG_MAX_DIMENSION (jmorecfg.h:215) is 65500: one-MCU-high frames of that width and one-MCU-wide frames of that height
+    (8188 blocks in a row / 4094 iMCU rows of one MCU; plane heights of 65504 rows along grid.y) through the sequential
+    trellis path, cjpeg's default progressive mode with its scan search, the plain libjpeg mode, restart markers every MCU row
+    in 4:4:4 and, for the flat shapes, the arithmetic coder -- byte for byte what the oracle writes."""
+    img = O.synthetic_frame(max(w, 64), max(h, 64), 5)[:h, :w].copy()
+    kws = [dict(quality=75, baseline=True), dict(quality=85), dict(revert=True), dict(quality=75, baseline=True, sample=(1, 1), restart=1)]
+    if min(w, h) == 1:
+        kws.append(dict(arithmetic=True, quality=75))
+    for kw in kws:
+        want = O.encode(O.make_params(w, h, **kw), img)
+        enc = M.Encoder(M.make_params(w, h, **kw), max_batch=2)
+        got = enc.encode_host(np.stack([img, img[::-1, ::-1].copy()]))
+        enc.close()
+        assert got[0] == want, (w, h, kw)

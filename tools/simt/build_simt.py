@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "mozjpeg_amd", "csrc")
-OUT = os.path.join(HERE, "_build")
+OUT = os.environ.get("SIMT_BUILD_DIR") or os.path.join(HERE, "_build")     # (a second directory lets a build go on while tests run from the first)
 LIB = os.path.join(OUT, "libmozjpeg_hip_simt.so")
 SOURCES = ["mjh_kernels.hip", "mjh_sorted.hip", "mjh_prog.hip", "mjh_arith.hip", "mjh_encoder.cpp", "mjh_pool.cpp", "mjh_guard.cpp"]
 # the same floating-point contract as the device build (mozjpeg_amd/build.py): no FMA contraction

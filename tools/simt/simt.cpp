@@ -321,6 +321,16 @@ void launch(const char *name, dim3 grid, dim3 block, size_t dyn_lds, void (*tram
 {
   static const bool trace = getenv("SIMT_TRACE") != nullptr;
   if (cur) { fprintf(stderr, "simt: kernel launch from inside a kernel\n"); abort(); }
+  // what the device would refuse (hipErrorInvalidConfiguration; the sources launch without looking at the return value, so on
+  // the chip such a launch simply does not happen): a dimension of zero, more than 1024 threads per workgroup, grid.y / grid.z
+  // beyond 65535, 2^32 or more threads along x
+  {
+    const unsigned long long tx = (unsigned long long)grid.x * block.x, nthr = (unsigned long long)block.x * block.y * block.z;
+    if (grid.x == 0 || grid.y == 0 || grid.z == 0 || nthr == 0 || nthr > 1024 || grid.y > 65535u || grid.z > 65535u || tx >= (1ull << 32)) {
+      fprintf(stderr, "simt: launch of %s with grid (%u,%u,%u) block (%u,%u,%u): the device refuses this configuration\n", name, grid.x, grid.y, grid.z, block.x, block.y, block.z);
+      abort();
+    }
+  }
   std::lock_guard<std::mutex> g(launch_mutex);
   Job j{name, grid, block, dyn_lds, tramp, closure};
   n_launches++;
