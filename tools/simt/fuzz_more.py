@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""More random configurations than tests/test_gpu_fuzz.py carries, through the kernel SOURCES on the emulator against the CPU
+oracle (development aid: correctness only).  The generator is test_gpu_fuzz.py's with the seed as an argument, plus
+arithmetic coding and the opt-in tile-sorted planes (every batch, a random tile size) on a share of the cases.
+usage: python tools/simt/fuzz_more.py SEED COUNT [--sorted-share 0.5]        prints one line per failure and a summary"""
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
+import numpy as np  # noqa: E402
+import build_simt  # noqa: E402
+import mozjpeg_amd as M  # noqa: E402
+M.LIB_PATH = build_simt.build()
+os.environ.setdefault("SIMT_STRICT", "1")
+import oracle_lib as O  # noqa: E402
+
+SAMPLINGS = [(1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (1, 4), (4, 2), (2, 4)]
+
+
+def draw(rng):
+    w = int(rng.integers(1, 500)); h = int(rng.integers(1, 400))
+    if rng.random() < 0.1:
+        w, h = (int(rng.integers(1, 4000)), int(rng.integers(1, 20))) if rng.random() < 0.5 else (int(rng.integers(1, 20)), int(rng.integers(1, 4000)))
+    kw = dict(quality=int(rng.choice([1, 5, 20, 40, 60, 75, 85, 90, 92, 95, 98, 100])), sample=SAMPLINGS[int(rng.integers(0, len(SAMPLINGS)))])
+    if rng.random() < 0.2:
+        kw["arithmetic"] = True
+    mode = int(rng.integers(0, 4))
+    if mode == 0:
+        kw["baseline"] = True
+    elif mode == 1:
+        kw["fastcrush"] = True
+    elif mode == 2:
+        kw["revert"] = True
+        if rng.random() < 0.5:
+            kw["progressive"] = True
+    if rng.random() < 0.25:
+        kw["gray"] = True
+        kw["sample"] = (1, 1)
+    if rng.random() < 0.3:
+        kw["restart"] = int(rng.integers(1, 4)) if rng.random() < 0.5 else "%db" % int(rng.integers(1, 40))
+    if not kw.get("revert"):
+        r = rng.random()
+        if r < 0.12:
+            kw["notrellis"] = True
+        elif r < 0.2:
+            kw["notrellis_dc"] = True
+        if not kw.get("notrellis"):
+            if rng.random() < 0.2:
+                kw["trellis_loops"] = int(rng.integers(2, 4))
+            if not kw.get("arithmetic"):
+                if rng.random() < 0.2:
+                    kw["use_scans_in_trellis"] = True
+                    kw["trellis_freq_split"] = int(rng.choice([0, 1, 5, 8, 30, 62, 63]))
+                if rng.random() < 0.2:
+                    kw["trellis_eob_opt"] = True
+                if rng.random() < 0.25 and kw["quality"] >= 40:
+                    kw["trellis_q_opt"] = True
+            if rng.random() < 0.2:
+                kw["dc_ver_weight"] = float(rng.choice([0.25, 1.0, 3.0]))
+        if rng.random() < 0.2 and not kw.get("baseline") and not kw.get("arithmetic"):
+            kw["dc_scan_opt"] = int(rng.integers(1, 3))
+        if rng.random() < 0.15:
+            kw["smooth"] = int(rng.integers(1, 101))
+            if kw["sample"] not in ((1, 1), (2, 2)):
+                kw["sample"] = (2, 2)
+    if rng.random() < 0.15:
+        kw["noovershoot"] = True
+    return w, h, kw, int(rng.integers(0, 3))
+
+
+def main():
+    seed, count = int(sys.argv[1]), int(sys.argv[2])
+    share = float(sys.argv[sys.argv.index("--sorted-share") + 1]) if "--sorted-share" in sys.argv else 0.5
+    rng = np.random.default_rng(seed)
+    bad = refused = 0
+    t0 = time.time()
+    for i in range(count):
+        w, h, kw, kind = draw(rng)
+        r2 = np.random.default_rng(seed * 100003 + i)
+        if kind == 0:
+            img = O.synthetic_frame(max(w, 8), max(h, 8), 3000 + i + seed)[:h, :w].copy()
+        elif kind == 1:
+            img = r2.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        else:
+            img = np.full((h, w, 3), 255, np.uint8)
+            for _ in range(4):
+                y, x = int(r2.integers(0, h)), int(r2.integers(0, w))
+                img[y:y + 9, x:x + 9] = r2.integers(0, 64, 3, dtype=np.uint8)
+        if kw.get("gray") and r2.random() < 0.5:
+            kw = dict(kw, grayin=True)
+            img = img[:, :, 1].copy()
+        env = {}
+        if r2.random() < share:
+            env = {"MJH_SORTED_UQ": "2", "MJH_SORTED_TILE": str(int(r2.choice([128, 256, 512])))}
+            if r2.random() < 0.3:
+                env["MJH_DENSE_CAP"] = str(int(r2.integers(0, 30)))
+        try:
+            want = O.encode(O.make_params(w, h, **kw), img)
+        except Exception as exc:      # the oracle refuses what the reference refuses
+            refused += 1
+            continue
+        try:
+            os.environ.update(env)
+            enc = M.Encoder(M.make_params(w, h, **kw), max_batch=3)
+        except Exception as exc:
+            print("REFUSED by the encoder but not by the oracle:", seed, i, w, h, kw, repr(exc)[:200], flush=True)
+            bad += 1
+            continue
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        try:
+            got = enc.encode_host(np.stack([img, img[::-1].copy(), img]))
+            ok = got[0] == want and got[2] == want
+        except Exception as exc:
+            ok = False
+            print("EXCEPTION", repr(exc)[:200], flush=True)
+        enc.close()
+        if not ok:
+            bad += 1
+            print("DIFFERENT:", seed, i, w, h, kw, env, flush=True)
+    print("seed %d: %d cases, %d refused by the oracle, %d failures, %.0f s" % (seed, count, refused, bad, time.time() - t0), flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
