@@ -79,6 +79,8 @@ def main():
     rng = np.random.default_rng(seed)
     bad = refused = 0
     t0 = time.time()
+    verbose = "--verbose" in sys.argv
+    first = int(sys.argv[sys.argv.index("--from") + 1]) if "--from" in sys.argv else 0
     for i in range(count):
         w, h, kw, kind = draw(rng)
         r2 = np.random.default_rng(seed * 100003 + i)
@@ -99,6 +101,10 @@ def main():
             env = {"MJH_SORTED_UQ": "2", "MJH_SORTED_TILE": str(int(r2.choice([128, 256, 512])))}
             if r2.random() < 0.3:
                 env["MJH_DENSE_CAP"] = str(int(r2.integers(0, 30)))
+        if i < first:
+            continue
+        if verbose:
+            print("case", i, w, h, kind, kw, env, "%.0f s" % (time.time() - t0), flush=True)
         try:
             want = O.encode(O.make_params(w, h, **kw), img)
         except Exception as exc:      # the oracle refuses what the reference refuses
