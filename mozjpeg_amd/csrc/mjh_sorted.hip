@@ -63,6 +63,16 @@ void mjh_launch_dct_sorted(const MjhConst &C, const MjhQuant *Q, const void *pla
   const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
   dim3 gridt((sorted_max_nblk(C) + sorted_tile - 1) / sorted_tile, C.ncomp, n);
 #define LDCT(ST, NW) hipLaunchKernelGGL((k_dct_quant_sorted<ST, NW>), gridt, dim3(64 * NW), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8, perm16)
+  if (sorted_tile == 512) {   // 8 waves x 8 KB + the sort's counters: 65792 bytes of LDS per workgroup (gfx950: up to 160 KB)
+    static int lds_ok = -1;
+    if (lds_ok < 0) {
+      int dev = 0, lim = 0;
+      (void)hipGetDevice(&dev);
+      lds_ok = hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && lim >= 65792;
+      if (!lds_ok) fprintf(stderr, "mjh_sorted: tiles of 512 blocks need 65792 bytes of LDS per workgroup, the device allows %d\n", lim);
+    }
+    if (!lds_ok) abort();
+  }
   switch (sorted_tile) {
     case 128: if (stat_tabs) LDCT(true, 2); else LDCT(false, 2); break;
     case 256: if (stat_tabs) LDCT(true, 4); else LDCT(false, 4); break;

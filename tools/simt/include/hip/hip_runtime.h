@@ -232,6 +232,8 @@ extern "C++" {
 hipError_t hipGetDeviceCount(int *n);
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int *d);
+enum hipDeviceAttribute_t { hipDeviceAttributeMaxSharedMemoryPerBlock = 74 };
+hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t a, int dev);
 hipError_t hipGetLastError();
 const char *hipGetErrorString(hipError_t e);
 hipError_t hipDeviceSynchronize();

@@ -393,6 +393,7 @@ hipError_t fenced_free(void *p)
 hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
 hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t a, int) { *v = a == hipDeviceAttributeMaxSharedMemoryPerBlock ? 163840 : 0; return hipSuccess; }   // gfx950: 160 KB of LDS per workgroup
 hipError_t hipGetLastError() { return hipSuccess; }
 const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : e == hipErrorNotSupported ? "not supported by the emulator" : "error (simt emulator)"; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
