@@ -288,7 +288,12 @@ struct mjh_encoder {
   // the values live in the AC planes of d_q, plane i+1 = i-th non-zero.  compact_last: the last batch's d_q is in that form
   unsigned long long *d_nzmask = nullptr; bool use_compact = false, compact_last = false;
   uint16_t *d_perm16 = nullptr;      // tile-sorted coefficient planes (MJH_SORTED_UQ): per block place, the block's index in its tile | sort key << 9
+  size_t small_batch = 400000;       // batches of fewer blocks run the AC trellis' first tier with one pass per tile (MJH_SMALL_BATCH=n: a test knob)
   size_t sorted_uq_min = 400000;     // MJH_SORTED_UQ=n (n > 1): tile-sorted planes for batches of at least n blocks (tests: 2 = every batch)
+  // queue records from the FDCT kernel (MJH_TRELLIS_REC=1, opt-in like the sorted planes; mjh_sorted.hip): rows x blocks records
+  // of 8 bytes + the all-zero distortion per block; used for the plain sequential configuration with fused statistics
+  unsigned long long *d_rec = nullptr; float *d_azd = nullptr; size_t rec_stride = 0; bool rec_mode = false;
+  static constexpr int REC_ROWS = 24;
   int sorted_tile = 256;             // MJH_SORTED_TILE=128|256|512: blocks per sorted tile = 64 x the waves of the FDCT workgroup = 64 x the trellis kernel's passes
   bool sorted_uq = false;            // MJH_SORTED_UQ=1: opt-in until it has been timed on the chip (bit-exact in the emulator, tools/simt); off: the FDCT kernel
                                      // writes every coefficient plane in natural order and the trellis sorts its tiles itself
@@ -700,7 +705,7 @@ static void free_all(mjh_encoder *e)
   e->pad_streams.clear();
   if (e->ev_split_fork) (void)hipEventDestroy(e->ev_split_fork);
   if (e->ev_null_in) (void)hipEventDestroy(e->ev_null_in);
-  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->pe.chist, e->pe.rmask, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_nq8, e->d_perm16, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->pe.chist, e->pe.rmask, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_nq8, e->d_perm16, e->d_rec, e->d_azd, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos, e->d_arith_rates, e->d_back9, e->d_jfin, e->d_qspec, e->g_in[0], e->g_in[1], e->g_in[2], e->g_in[3] };
   for (void *q : ptrs) if (q) (void)mjh_guard_free(q);
@@ -798,6 +803,8 @@ static int make_views(mjh_encoder *e, int S)
     if (v->d_nzmask) v->d_nzmask += off * trb;
     if (v->d_nq8) v->d_nq8 += off * trb;
     if (v->d_perm16) v->d_perm16 += off * trb;
+    if (v->d_rec) v->d_rec += off * trb;       // (every row of the records starts rec_stride further on: the view keeps the stride)
+    if (v->d_azd) v->d_azd += off * trb;
     if (v->d_dense) { v->d_dense += (size_t)k * dense_each * 64; v->dense_cap = dense_each; }
     v->d_len16 += off * tmb;
     v->d_off32 += off * tmb;
@@ -890,6 +897,13 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     if (e->use_compact) HIPCHK_E(mjh_dmalloc((void **)&e->d_nzmask, B * (size_t)C.total_real_blocks * sizeof(unsigned long long)));
     if (e->use_compact && p->trellis_quant) HIPCHK_E(mjh_dmalloc((void **)&e->d_nq8, B * (size_t)C.total_real_blocks));
     if (const char *sv = getenv("MJH_SORTED_UQ")) { e->sorted_uq = atoi(sv) != 0; if (atoi(sv) > 1) e->sorted_uq_min = (size_t)atoi(sv); }
+    if (const char *bv = getenv("MJH_SMALL_BATCH")) e->small_batch = (size_t)atol(bv);
+    if (const char *rv = getenv("MJH_TRELLIS_REC")) e->rec_mode = atoi(rv) != 0;
+    if (e->use_compact && p->trellis_quant && e->rec_mode) {
+      e->rec_stride = B * (size_t)C.total_real_blocks;
+      HIPCHK_E(mjh_dmalloc((void **)&e->d_rec, (size_t)mjh_encoder::REC_ROWS * e->rec_stride * sizeof(unsigned long long)));
+      HIPCHK_E(mjh_dmalloc((void **)&e->d_azd, e->rec_stride * sizeof(float)));
+    }
     if (const char *tv = getenv("MJH_SORTED_TILE")) { const int t = atoi(tv); if (t == 128 || t == 256 || t == 512) e->sorted_tile = t; }
     if (e->use_compact && p->trellis_quant && e->sorted_uq) HIPCHK_E(mjh_dmalloc((void **)&e->d_perm16, B * (size_t)C.total_real_blocks * sizeof(uint16_t)));
   }
@@ -1398,9 +1412,40 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   const bool sort_uq = compact && e->d_perm16 && e->d_nq8 && e->fastdiv_all && C.precision == 8 && !fuse_fin && e->trellis_v3 > 0 && e->trellis_variant <= 4 &&
                        nbands == 1 && !ext_eob && !ext_qopt && !e->arith && !e->debug_taps && (size_t)n * C.total_real_blocks >= e->sorted_uq_min;
   uint16_t *const perm16 = sort_uq ? e->d_perm16 : nullptr;
+  // Queue records from the FDCT kernel (opt-in): the plain sequential configuration whose FDCT kernel quantizes every
+  // coefficient for its fused statistics anyway -- it then also does phase 1 of the tile-sorted AC trellis (records, all-zero
+  // distortion, deferral of the blocks the first tier cannot take), and the trellis kernel starts from the records.  The
+  // capacity of the first tier has to be known in front of the FDCT kernel: the adaptive choice is made here, not at the trellis.
+  MjhRecOut rec_out;
+  const MjhRecOut *rec = nullptr;
+  auto adapt_first_tier = [&]() {
+    if (!(e->trellis_adapt && e->h_defer[0] != 0xFFFFFFFFu && e->h_defer[3] != 0xFFFFFFFFu)) return;
+    // (the rule of trellis_pass below, see there)
+    const double blocks = (double)e->h_defer[4] * (double)C.total_real_blocks + 1.0;
+    const double s16 = e->h_defer[1] / blocks, s24 = e->h_defer[2] / blocks, s32 = e->h_defer[3] / blocks;
+    const int cur = e->trellis_variant == 1 ? 2 : e->trellis_variant;
+    auto level_for = [&](double slack) { return s16 < 0.06 * slack ? 0 : s24 < 0.06 * slack ? 2 : s32 < 0.10 * slack ? 3 : 4; };
+    const int up = level_for(1.0), down = level_for(0.5);
+    if (up > cur) e->trellis_variant = up;
+    else if (down < cur) e->trellis_variant = down;
+    e->h_defer[0] = e->h_defer[3] = 0xFFFFFFFFu;
+  };
+  if (e->rec_mode && e->d_rec && !coef_src && compact && e->d_nq8 && e->fastdiv_all && C.precision == 8 && fuse_pre && !fuse_fin && !(e->fuse_mask & 4) &&
+      e->trellis_v3 > 0 && nbands == 1 && !ext_eob && !ext_qopt && !e->arith && !e->debug_taps && !e->progressive && p.trellis_quant && p.trellis_num_loops <= 1 && !sort_uq) {
+    adapt_first_tier();
+    if (e->trellis_variant <= 2) {
+      // (mjh_launch_trellis_ac: one pass per tile -- a small batch, or MJH_TRELLIS_V3=1 -- comes with 24 records)
+      const bool small = (size_t)n * C.total_real_blocks < e->small_batch || e->trellis_v3 == 1;
+      rec_out.records = e->d_rec; rec_out.row_stride = e->rec_stride; rec_out.azd = e->d_azd;
+      rec_out.worklist = e->d_worklist; rec_out.dense = (int16_t *)e->d_dense; rec_out.dense_cap = e->dense_cap;
+      rec_out.qn = (small || e->trellis_variant > 0) ? 24 : 16;
+      rec = &rec_out;
+      mjh_launch_zero_counters(e->d_worklist, e->d_worklist2, s);
+    }
+  }
   if (!coef_src) {
     pr.mark("dct_quant");
-    mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, e->d_nq8, n, s, e->fastdiv_all, perm16, e->sorted_tile);
+    mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, e->d_nq8, n, s, e->fastdiv_all, perm16, e->sorted_tile, rec);
   }
 
   if (e->arith) {
@@ -1557,8 +1602,9 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     mjh_launch_trellis_ac(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap,
                           (v3_stats || (fuse_fin && p.optimize_coding && last_loop)) ? fin_ac : nullptr, e->trellis_variant,
                           Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, nzm, qstride, n, s,
-                          e->d_nq8, v3 ? ((size_t)n * C.total_real_blocks < 400000 ? 1 : e->trellis_v3) : 0,   // (a small batch: one pass per tile -- four times the workgroups, a quarter of their length: latency matters more than the sorting)
-                          e->fastdiv_all, v3 ? perm16 : nullptr, e->sorted_tile);
+                          e->d_nq8, v3 ? ((size_t)n * C.total_real_blocks < e->small_batch ? 1 : e->trellis_v3) : 0,   // (a small batch: one pass per tile -- four times the workgroups, a quarter of their length: latency matters more than the sorting)
+                          e->fastdiv_all, v3 ? perm16 : nullptr, e->sorted_tile, v3 ? rec : nullptr);
+    if (rec && !v3) return fail(MJH_EINVAL, "internal: queue records without the tile-sorted trellis");
     if (perm16 && !v3) return fail(MJH_EINVAL, "internal: tile-sorted coefficient planes without the tile-sorted trellis");
     if (e->trellis_adapt && !extended && first_pass) {
       e->h_defer[4] = (unsigned)n;

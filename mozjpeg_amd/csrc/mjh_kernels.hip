@@ -361,14 +361,26 @@ __device__ __forceinline__ float catmull_rom(int v1, int v2, int v3, int v4, flo
 // tile's descending-key order instead of its natural place, plus perm_out[tile_base + place] = index in tile | key << 9 (the
 // trellis kernel's own permutation entry).  A pass of the trellis kernel then reads ONE line of every plane, each line once
 // (unsorted planes: every pass touches all four lines of the tile).  Plane 0 (DC), lambda, nq8 and coef_q stay in natural order.
-template <class T, bool STATS, bool FD, int SORTED = 0>   // SORTED: waves per workgroup of the tile-sorted form (2 / 4 / 8 = tiles of 128 / 256 / 512 blocks), 0 = natural order; uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
+// REC (k_dct_quant_rec, mjh_sorted.hip; 8-bit samples, FD, STATS, natural order): the kernel also does phase 1 of the
+// tile-sorted AC trellis -- it has every |x|, the comparison and the division for its own statistics already: the trellis'
+// queue records (position | sign | quantized value | |x|, distortion of the zeros in front) go to rec.records row by row (row r
+// = every block's r-th record), the all-zero distortion to rec.azd, blocks the first tier cannot take (more than rec.qn records,
+// a quantized magnitude >= 16) to the work list with their dense copy (and their raw planes, the general tiers' fallback);
+// planes 1..63 of coef_uq are not written for the others.  nq8 carries bit 7 for a deferred block.
+// (struct MjhRecOut: mjh_internal.h)
+__device__ __forceinline__ void defer_blocks(bool mine, unsigned *__restrict__ list, unsigned img, unsigned compblk, unsigned dense_slot_in,
+                                             const short (&xs)[64], int16_t *__restrict__ dense, unsigned dense_cap, bool make_copy, int lane,
+                                             unsigned compblk_nocopy);
+__device__ __forceinline__ void count_heavy(unsigned *__restrict__ list, bool inside, int nq, int lane);
+template <class T, bool STATS, bool FD, int SORTED = 0, bool REC = false>   // SORTED: waves per workgroup of the tile-sorted form (2 / 4 / 8 = tiles of 128 / 256 / 512 blocks), 0 = natural order; uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
 __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant *__restrict__ Q, const T *__restrict__ planes,
                                                int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
                                                MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out,
-                                               uint16_t *__restrict__ perm_out = nullptr)
+                                               uint16_t *__restrict__ perm_out = nullptr, const MjhRecOut *rec = nullptr)
 {
   constexpr bool W12 = sizeof(T) == 2;
   static_assert(!SORTED || !W12, "the tile-sorted layout feeds the (8-bit only) trellis");
+  static_assert(!REC || (FD && STATS && !W12 && !SORTED), "records come out of the 8-bit fast-division kernel with fused statistics, natural order");
   // 8 KB per wave: the deringing columns (the ORIGINAL level-shifted samples of the lane's block in zig-zag order, 16 bits
   // each for 8- and 12-bit data) and, afterwards, 8 interleaved copies of the 256-bin statistics histogram
   constexpr int LW = 32;
@@ -475,6 +487,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
   for (int c = 0; c < 8; c++)
     fdct8<1, W12 ? 1 : 2>(d[c], d[8 + c], d[16 + c], d[24 + c], d[32 + c], d[40 + c], d[48 + c], d[56 + c]);
 
+  float lambda_blk = 0.0f;
   if (!W12 && C.trellis) {
     // per-block trellis lambda (jcdctmgr.c:1027-1037): norm of the 63 AC coefficients summed in
     // NATURAL index order in float, /63 in double, then lambda in double -> float.  pow(2, .) comes
@@ -487,6 +500,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
     if (C.lambda_log_scale2 > 0.0f) lambda = (float)(C.pow_scale1 * 1.0 / (C.pow_scale2 + (double)norm));
     else lambda = (float)(C.pow_scale1 * 1.0);
     lambda_out[(size_t)img * C.total_real_blocks + cc.blk_off + blk] = lambda;
+    lambda_blk = lambda;
   }
   const float *rcp = Q->rcp8q[cc.qtbl];
   int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
@@ -504,6 +518,9 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
   }
   hist_alias *hh = hist + (lane & (NCOPY - 1)) * 256;
   int run = 0, nzc = 0;   // nzc: non-zero quantized AC coefficients = the AC trellis' queue length (its tile-sort key)
+  float azd = 0.0f;       // REC: distortion of the block with positions 1..k all zero (k_trellis_ac_v3's phase 1: same operations, same order)
+  int qmax = 0;
+  const size_t gblk_rec = (size_t)img * C.total_real_blocks + cc.blk_off + blk;
 #pragma unroll
   for (int k = 0; k < 64; k++) {
     const int x = d[kZZ.v[k]];
@@ -512,10 +529,23 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
     if (FD && STATS && k > 0) {
       // statistics of the conventionally quantized block only (the trellis recomputes the values): magnitude category of
       // min(floor((|x| + 4q) / 8q), 1023) -- the signed clamp to +-1023 (jcdctmgr.c:761-770) leaves the category of 1023
-      if (!SORTED) uq[(size_t)k * cc.kstride] = (int16_t)x;
+      if (!SORTED && !REC) uq[(size_t)k * cc.kstride] = (int16_t)x;
+      float azd_cur = 0.0f;
+      if (REC) {
+        float t = (float)mul24(ax, ax) * lambda_blk;
+        t = t * Q->lambda_tbl[cc.qtbl][k];
+        azd_cur = t + azd;
+      }
       if (valid) {
         if (ax + (dq >> 1) >= dq) {
           int qa = udiv_mh(ax + (dq >> 1), Q->sdiv[cc.qtbl][k], Q->mdiv[cc.qtbl][k]);
+          if (REC) {
+            const int qv = qa >= 1024 ? 1023 : qa;
+            qmax = qv > qmax ? qv : qmax;
+            // (a block with more than rec->qn records is deferred: its surplus records are not stored)
+            if (nzc < rec->qn)
+              reinterpret_cast<uint2 *>(rec->records)[(size_t)nzc * rec->row_stride + gblk_rec] = make_uint2((unsigned)k | (x < 0 ? 64u : 0u) | ((unsigned)qv << 7) | ((unsigned)ax << 17), __float_as_uint(azd));
+          }
           if (clampq) qa = min(qa, 1023);
           nzc++;
           if (run > 15) { atomicAdd(&hh[0xF0], (unsigned)(run >> 4)); run &= 15; }
@@ -523,6 +553,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
           run = 0;
         } else run++;
       }
+      if (REC) azd = azd_cur;
       continue;
     }
     int v = FD ? udiv_mh(ax + (dq >> 1), Q->sdiv[cc.qtbl][k], Q->mdiv[cc.qtbl][k]) : udiv_exact(ax + (dq >> 1), dq, rcp[k]);
@@ -542,6 +573,20 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
       }
     }
   }
+  if (REC) {
+    const bool def = valid && (nzc > rec->qn || qmax >= 16);
+    rec->azd[gblk_rec] = azd;      // (tail lanes: the last block's own value once more)
+    short xs[64];
+#pragma unroll
+    for (int k = 0; k < 64; k++) xs[k] = (short)d[kZZ.v[k]];
+    defer_blocks(def, rec->worklist, (unsigned)img, ((unsigned)comp << 28) | (unsigned)blk, 0u, xs, rec->dense, rec->dense_cap, true, lane, 0xFFFFFFFFu);
+    count_heavy(rec->worklist, valid, nzc, lane);
+    if (def) {      // the general tiers read the planes when the list has outgrown the dense copies
+#pragma unroll
+      for (int k = 1; k < 64; k++) uq[(size_t)k * cc.kstride] = xs[k];
+    }
+    if (nq8_out && valid) nq8_out[gblk_rec] = (uint8_t)(def ? (0x80 | (nzc > 63 ? 63 : nzc)) : nzc);
+  } else
   if (!W12 && nq8_out && valid) nq8_out[(size_t)img * C.total_real_blocks + cc.blk_off + blk] = (uint8_t)nzc;
   if (SORTED) {
     // counting sort of the tile's real blocks by descending key, as k_trellis_ac_v3's own prelude does it (equal keys in
@@ -1902,8 +1947,9 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
                 int16_t *__restrict__ dense, unsigned dense_cap, unsigned long long *__restrict__ nzmask,
                 MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp)
 {
-  constexpr bool SORTED = false;
+  constexpr bool SORTED = false, RECORDS = false;
   const uint16_t *const perm16 = nullptr;
+  const uint2 *const rec_in = nullptr; const float *const azd_in = nullptr; constexpr size_t rec_stride = 0;
 #include "mjh_trellis_v3.inc"
 }
 
@@ -3358,10 +3404,15 @@ static int max_nblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp;
 static int max_padblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp; i++) { int v = C.c[i].wpad * C.c[i].hpad; m = v > m ? v : m; } return m; }
 
 void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
-                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv, uint16_t *perm16, int sorted_tile)
+                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv, uint16_t *perm16, int sorted_tile, const MjhRecOut *rec)
 {
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
   const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
+  if (rec) {      // the FDCT kernel also writes the AC trellis' queue records (mjh_sorted.hip: k_dct_quant_rec)
+    if (C.precision == 12 || !fastdiv || !nq8 || !stat_tabs || perm16) { fprintf(stderr, "mjh_launch_dct: queue records need 8-bit samples, the fast division, fused statistics and natural order\n"); abort(); }
+    mjh_launch_dct_rec(C, Q, planes, uq, q, lambda, stat_tabs, spi, stat_slot, nq8, n, s, *rec);
+    return;
+  }
   if (perm16) {   // tile-sorted coefficient planes for the tile-sorted trellis (mjh_sorted.hip)
     if (C.precision == 12 || !fastdiv || !nq8) { fprintf(stderr, "mjh_launch_dct: tile-sorted planes need 8-bit samples, the fast division and the key array\n"); abort(); }
     mjh_launch_dct_sorted(C, Q, planes, uq, q, lambda, stat_tabs, spi, stat_slot, nq8, n, s, perm16, sorted_tile);
@@ -3407,10 +3458,15 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
   if (nslots > 0) hipLaunchKernelGGL(k_gen_tables_list, dim3(nslots, n), dim3(64), 0, s, tabs, spi, d_slots);
 }
 
+void mjh_launch_zero_counters(unsigned *worklist, unsigned *worklist2, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, worklist, worklist2);
+}
+
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
-                           uint8_t *nq8, int v3_passes, int fastdiv, const uint16_t *perm16, int sorted_tile)
+                           uint8_t *nq8, int v3_passes, int fastdiv, const uint16_t *perm16, int sorted_tile, const MjhRecOut *rec)
 {
   // band-limited pass (use_scans_in_trellis), the per-block outputs of trellis_eob_opt, per-image tables (trellis_q_opt):
   // the EXT instantiations
@@ -3421,7 +3477,7 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   // stat_slot != nullptr: the statistics of the final coefficients go to these table slots (one per component)
   MjhHuffTable *st = stat_slot ? tabs : nullptr;
   const int4 ss = stat_slot ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
-  hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, worklist, worklist2);   // (a 16-byte hipMemsetAsync costs ~80 us of stream time)
+  if (!rec) hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, worklist, worklist2);   // (a 16-byte hipMemsetAsync costs ~80 us of stream time; rec: the FDCT kernel has filled the list already, mjh_launch_zero_counters ran in front of it)
   int w0[5] = { 0, 0, 0, 0, 0 };
   for (int i = 0; i < 4; i++) w0[i + 1] = w0[i] + (i < C.ncomp ? (C.c[i].nblk + 63) / 64 : 0);
   dim3 gridq(w0[C.ncomp], n);
@@ -3456,6 +3512,12 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     const int4 tv = make_int4(t0[0], t0[1], t0[2], t0[3]);
 #define LV3Q(QN, NP, FDV, FSV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, NP, FDV, FSV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask, st, ss)
 #define LV3(NP, FDV, FSV) LV3Q(16, NP, FDV, FSV)
+    if (rec) {      // phase 1 happened in the FDCT kernel (mjh_launch_dct with the same MjhRecOut): the first tier reads its records
+      if (!fastdiv || perm16 || variant >= 3 || rec->qn != ((small24 || variant > 0) ? 24 : 16)) {
+        fprintf(stderr, "mjh_launch_trellis_ac: queue records come with the fast division, natural order and the capacity (16 / 24) of the first tier chosen here\n"); abort();
+      }
+      mjh_launch_trellis_ac_rec(C, Q, q, tabs, spi, ac_slot, lambda, stat_slot, nzmask, n, s, nq8, *rec, small24 ? 1 : np);
+    } else
     if (perm16) {   // the planes are tile-sorted already (mjh_launch_dct with the same array): the kernels of mjh_sorted.hip read that layout
       if (!fastdiv) { fprintf(stderr, "mjh_launch_trellis_ac: tile-sorted planes need the fast division\n"); abort(); }
       mjh_launch_trellis_ac_sorted(C, Q, uq, q, tabs, spi, ac_slot, lambda, worklist, worklist2, dense, dense_cap, stat_slot, variant, nzmask, n, s, nq8, perm16, sorted_tile);

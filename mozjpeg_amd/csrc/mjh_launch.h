@@ -9,8 +9,13 @@ void mjh_launch_import_planes(const MjhConst &C, const MjhPlaneSrc &S, void *pla
 void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size_t img_stride, void *planes, int n, hipStream_t s);
 void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
                     MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv = 0,   // fastdiv: every table in use has q <= 255 (MjhQuant.mdiv)
-                    uint16_t *perm16 = nullptr, int sorted_tile = 256);   // perm16: planes 1..63 of uq in tile-sorted order, tiles of sorted_tile (128 / 256 / 512) blocks (8-bit samples, fastdiv; mjh_launch_trellis_ac gets the same)
-// mjh_sorted.hip (called by mjh_launch_dct / mjh_launch_trellis_ac when perm16 is given)
+                    uint16_t *perm16 = nullptr, int sorted_tile = 256, const MjhRecOut *rec = nullptr);   // rec: the kernel also writes the AC trellis' queue records (MjhRecOut); perm16: planes 1..63 of uq in tile-sorted order, tiles of sorted_tile (128 / 256 / 512) blocks (8-bit samples, fastdiv; mjh_launch_trellis_ac gets the same)
+void mjh_launch_zero_counters(unsigned *worklist, unsigned *worklist2, hipStream_t s);   // (rec: in front of mjh_launch_dct)
+// mjh_sorted.hip (called by mjh_launch_dct / mjh_launch_trellis_ac when rec / perm16 is given)
+void mjh_launch_dct_rec(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
+                        MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, const MjhRecOut &rec);
+void mjh_launch_trellis_ac_rec(const MjhConst &C, const MjhQuant *Q, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
+                               const int *stat_slot, unsigned long long *nzmask, int n, hipStream_t s, uint8_t *nq8, const MjhRecOut &rec, int npass);
 void mjh_launch_dct_sorted(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
                            MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, uint16_t *perm16, int sorted_tile);
 void mjh_launch_trellis_ac_sorted(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
@@ -24,7 +29,7 @@ void mjh_launch_gen_tables(MjhHuffTable *tabs, int spi, const int *slots, int ns
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
-                           uint8_t *nq8 = nullptr, int v3_passes = 0, int fastdiv = 0, const uint16_t *perm16 = nullptr, int sorted_tile = 256);   // (with stat_slot and the tile-sorted kernel: the final AC statistics are counted in its back-track)   // v3_passes > 0 (plain compact pass, variant 0): the tile-sorted kernel with that many passes
+                           uint8_t *nq8 = nullptr, int v3_passes = 0, int fastdiv = 0, const uint16_t *perm16 = nullptr, int sorted_tile = 256, const MjhRecOut *rec = nullptr);   // (with stat_slot and the tile-sorted kernel: the final AC statistics are counted in its back-track)   // v3_passes > 0 (plain compact pass, variant 0): the tile-sorted kernel with that many passes
 // trellis_eob_opt: the block-row pass behind a (band-limited) AC trellis; eob_cost / eob_has as written by mjh_launch_trellis_ac
 void mjh_launch_trellis_eob_chain(const MjhConst &C, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const void *eob_cost, const int *eob_has,
                                   int Ss, int Se, int n, hipStream_t s);

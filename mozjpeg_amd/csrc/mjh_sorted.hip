@@ -37,7 +37,31 @@ k_trellis_ac_v3s(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__re
                  int16_t *__restrict__ dense, unsigned dense_cap, unsigned long long *__restrict__ nzmask,
                  MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp, const uint16_t *__restrict__ perm16)
 {
-  constexpr bool SORTED = true, FD = true;
+  constexpr bool SORTED = true, FD = true, RECORDS = false;
+  const uint2 *const rec_in = nullptr; const float *const azd_in = nullptr; constexpr size_t rec_stride = 0;
+#include "mjh_trellis_v3.inc"
+}
+
+// ---- queue records from the FDCT kernel (MJH_TRELLIS_REC=1; natural block order, the trellis kernel sorts its tiles itself) ----
+__global__ void __launch_bounds__(64)
+k_dct_quant_rec(MjhConst C, const MjhQuant *__restrict__ Q, const uint8_t *__restrict__ planes,
+                int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
+                MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out, MjhRecOut rec)
+{
+  dct_quant_body<uint8_t, true, true, 0, true>(C, Q, planes, coef_uq, coef_q, lambda_out, stat_tabs, slots_per_image, stat_slot_of_comp, nq8_out, nullptr, &rec);
+}
+
+template <int QN, bool FST, int NPASS>
+__global__ void __launch_bounds__(64)
+k_trellis_ac_v3r(MjhConst C, const MjhQuant *__restrict__ Q, int16_t *__restrict__ coef_q,
+                 const MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 ac_slot_of_comp, int4 tile0_of_comp,
+                 const float *__restrict__ lambda_in, uint8_t *__restrict__ nq8, unsigned long long *__restrict__ nzmask,
+                 MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp,
+                 const uint2 *__restrict__ rec_in, size_t rec_stride, const float *__restrict__ azd_in)
+{
+  constexpr bool SORTED = false, FD = true, RECORDS = true;
+  const uint16_t *const perm16 = nullptr;
+  const int16_t *const coef_uq = nullptr; unsigned *const worklist = nullptr; int16_t *const dense = nullptr; constexpr unsigned dense_cap = 0u;   // (phase 1's inputs and outputs: not used)
 #include "mjh_trellis_v3.inc"
 }
 
@@ -112,4 +136,42 @@ void mjh_launch_trellis_ac_sorted(const MjhConst &C, const MjhQuant *Q, const vo
   if (variant >= 3 && !st) LDS_(63, 2048, worklist, (unsigned *)nullptr);   // what is left has more than 32 records or a magnitude >= 16
   else { LDS_(32, 2048, worklist, worklist2); LDS_(63, 1024, worklist2, (unsigned *)nullptr); }
 #undef LDS_
+}
+
+void mjh_launch_dct_rec(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
+                        MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, const MjhRecOut &rec)
+{
+  const int4 sl = make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]);
+  dim3 grid((sorted_max_nblk(C) + 63) / 64, C.ncomp, n);
+  hipLaunchKernelGGL(k_dct_quant_rec, grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8, rec);
+}
+
+// the first tier over the FDCT kernel's records (npass passes per tile of 64 * npass blocks, sorted here); the general tiers and
+// the deferred blocks' statistics stay with the caller (mjh_launch_trellis_ac: natural order, nothing special about them)
+void mjh_launch_trellis_ac_rec(const MjhConst &C, const MjhQuant *Q, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
+                               const int *stat_slot, unsigned long long *nzmask, int n, hipStream_t s, uint8_t *nq8, const MjhRecOut &rec, int npass)
+{
+  const int4 sl = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
+  MjhHuffTable *st = stat_slot ? tabs : nullptr;
+  const int4 ss = stat_slot ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
+  const int tile = 64 * npass;
+  int t0[5] = { 0, 0, 0, 0, 0 };
+  for (int i = 0; i < 4; i++) t0[i + 1] = t0[i] + (i < C.ncomp ? (C.c[i].nblk + tile - 1) / tile : 0);
+  dim3 gridt(t0[C.ncomp], n);
+  for (int i = C.ncomp; i < 4; i++) t0[i] = 0x7FFFFFFF;   // components that do not exist never match
+  const int4 tv = make_int4(t0[0], t0[1], t0[2], t0[3]);
+#define LV3R(QN, FSV, NP) hipLaunchKernelGGL((k_trellis_ac_v3r<QN, FSV, NP>), gridt, dim3(64), 0, s, C, Q, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, nzmask, st, ss, \
+                                             (const uint2 *)rec.records, rec.row_stride, (const float *)rec.azd)
+  bool ok = true;
+  if (rec.qn == 24) {
+    if (st) { if (npass == 4) LV3R(24, true, 4); else ok = false; }
+    else if (npass == 4) LV3R(24, false, 4);
+    else if (npass == 1) LV3R(24, false, 1);
+    else ok = false;
+  } else if (rec.qn == 16) {
+    if (st) { if (npass == 4) LV3R(16, true, 4); else ok = false; }
+    else switch (npass) { case 8: LV3R(16, false, 8); break; case 4: LV3R(16, false, 4); break; case 2: LV3R(16, false, 2); break; case 1: LV3R(16, false, 1); break; default: ok = false; }
+  } else ok = false;
+#undef LV3R
+  if (!ok) { fprintf(stderr, "mjh_sorted: no record-reading first tier for %d records, %d passes%s\n", rec.qn, npass, st ? ", fused statistics" : ""); abort(); }
 }

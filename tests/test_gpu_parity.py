@@ -460,3 +460,42 @@ def test_frames_at_the_largest_dimension_jpeg_allows(w, h):
         got = enc.encode_host(np.stack([img, img[::-1, ::-1].copy()]))
         enc.close()
         assert got[0] == want, (w, h, kw)
+
+
+@pytest.mark.parametrize("quality,sample", [(75, (2, 2)), (85, (1, 1)), (60, (2, 1))])
+def test_queue_records_from_the_fdct_kernel_give_the_same_file(quality, sample, request):
+    """MJH_TRELLIS_REC=1 (opt-in, mjh_sorted.hip): in the plain sequential configuration the FDCT kernel, which quantizes every
+    coefficient for its fused statistics anyway, also does phase 1 of the tile-sorted AC trellis -- queue records row by row,
+    the all-zero distortion, the deferral of the blocks the first tier cannot take -- and k_trellis_ac_v3r starts from the
+    records.  Same files as the default path and the oracle: one / two / four / eight passes per tile (MJH_SMALL_BATCH=0 takes a
+    small batch down the large-batch plan), 16 and 24 records, a work list that outgrows its dense copies (the general tiers
+    then read the planes the FDCT kernel wrote for deferred blocks), grey and subsampled frames, ragged tiles; configurations the
+    mode does not cover (capacities of 32 / 48 records, trellis loops, progressive) fall back to the default kernels.
+    Written after round 4's GPU minutes were spent: runs under the emulator (`--simt`), on the chip only with MJH_TEST_SORTED=1."""
+    if not request.config.getoption("--simt") and os.environ.get("MJH_TEST_SORTED") != "1":
+        pytest.skip("opt-in kernels (MJH_TRELLIS_REC) that have only run under tools/simt so far: set MJH_TEST_SORTED=1 to run them on the chip")
+    w, h = 600, 424
+    rng = np.random.default_rng(quality)
+    img = O.synthetic_frame(w, h, 90 + quality)
+    img[100:300, 200:500] = rng.integers(0, 256, (200, 300, 3), dtype=np.uint8)
+    frames = np.stack([img, img[::-1].copy(), img])
+    knobs = ("MJH_TRELLIS_REC", "MJH_TRELLIS_VARIANT", "MJH_DENSE_CAP", "MJH_SMALL_BATCH", "MJH_TRELLIS_V3", "MJH_FUSE")
+    for kw in (dict(quality=quality, baseline=True, sample=sample), dict(quality=quality, baseline=True, gray=True),
+               dict(quality=quality, baseline=True, sample=sample, trellis_loops=2), dict(quality=quality, fastcrush=True, sample=sample)):
+        want = O.encode(O.make_params(w, h, **kw), img)
+        for variant, dense, small, v3, fuse in ((None, None, None, None, None), ("0", None, "0", "4", None), ("0", "8", "0", "1", None), ("0", None, "0", "2", None),
+                                                 ("0", "0", "0", "8", None), ("2", None, "0", "4", None), ("2", "40", None, None, None), ("3", None, "0", "4", None),
+                                                 (None, None, "0", None, None), ("0", None, "0", "4", "5")):
+            env = {"MJH_TRELLIS_REC": "1", "MJH_TRELLIS_VARIANT": variant, "MJH_DENSE_CAP": dense, "MJH_SMALL_BATCH": small, "MJH_TRELLIS_V3": v3, "MJH_FUSE": fuse}
+            try:
+                for k, v in env.items():
+                    if v is not None:
+                        os.environ[k] = v
+                enc = M.Encoder(M.make_params(w, h, **kw), max_batch=3)
+            finally:
+                for k in knobs:
+                    os.environ.pop(k, None)
+            for rnd in range(2 if variant is None else 1):
+                got = enc.encode_host(frames)
+                assert got[0] == want and got[2] == want, (kw, env, rnd)
+            enc.close()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """More random configurations than tests/test_gpu_fuzz.py carries, through the kernel SOURCES on the emulator against the CPU
 oracle (development aid: correctness only).  The generator is test_gpu_fuzz.py's with the seed as an argument, plus
-arithmetic coding and the opt-in tile-sorted planes (every batch, a random tile size) on a share of the cases.
+arithmetic coding and the two opt-in variants (tile-sorted planes: every batch, a random tile size; queue records from the
+FDCT kernel) on a share of the cases.
 usage: python tools/simt/fuzz_more.py SEED COUNT [--sorted-share 0.5]        prints one line per failure and a summary"""
 import os
 import sys
@@ -99,6 +100,13 @@ def main():
         env = {}
         if r2.random() < share:
             env = {"MJH_SORTED_UQ": "2", "MJH_SORTED_TILE": str(int(r2.choice([128, 256, 512])))}
+            if r2.random() < 0.3:
+                env["MJH_DENSE_CAP"] = str(int(r2.integers(0, 30)))
+        elif r2.random() < 0.6:     # the other opt-in variant: queue records from the FDCT kernel (where the configuration is covered; else the default kernels)
+            env = {"MJH_TRELLIS_REC": "1"}
+            if r2.random() < 0.6:
+                env["MJH_SMALL_BATCH"] = "0"
+                env["MJH_TRELLIS_V3"] = str(int(r2.choice([1, 2, 4, 8])))
             if r2.random() < 0.3:
                 env["MJH_DENSE_CAP"] = str(int(r2.integers(0, 30)))
         if i < first:
