@@ -1412,8 +1412,8 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   const bool sort_uq = compact && e->d_perm16 && e->d_nq8 && e->fastdiv_all && C.precision == 8 && !fuse_fin && e->trellis_v3 > 0 && e->trellis_variant <= 4 &&
                        nbands == 1 && !ext_eob && !ext_qopt && !e->arith && !e->debug_taps && (size_t)n * C.total_real_blocks >= e->sorted_uq_min;
   uint16_t *const perm16 = sort_uq ? e->d_perm16 : nullptr;
-  // Queue records from the FDCT kernel (opt-in): the plain sequential configuration whose FDCT kernel quantizes every
-  // coefficient for its fused statistics anyway -- it then also does phase 1 of the tile-sorted AC trellis (records, all-zero
+  // Queue records from the FDCT kernel (opt-in): the FDCT kernel quantizes every coefficient anyway (for its fused statistics in
+  // the sequential configuration, for coef_q otherwise) -- it then also does phase 1 of the tile-sorted AC trellis (records, all-zero
   // distortion, deferral of the blocks the first tier cannot take), and the trellis kernel starts from the records.  The
   // capacity of the first tier has to be known in front of the FDCT kernel: the adaptive choice is made here, not at the trellis.
   MjhRecOut rec_out;
@@ -1430,8 +1430,8 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     else if (down < cur) e->trellis_variant = down;
     e->h_defer[0] = e->h_defer[3] = 0xFFFFFFFFu;
   };
-  if (e->rec_mode && e->d_rec && !coef_src && compact && e->d_nq8 && e->fastdiv_all && C.precision == 8 && fuse_pre && !fuse_fin && !(e->fuse_mask & 4) &&
-      e->trellis_v3 > 0 && nbands == 1 && !ext_eob && !ext_qopt && !e->arith && !e->debug_taps && !e->progressive && p.trellis_quant && p.trellis_num_loops <= 1 && !sort_uq) {
+  if (e->rec_mode && e->d_rec && !coef_src && compact && e->d_nq8 && e->fastdiv_all && C.precision == 8 && !fuse_fin && !(e->fuse_mask & 4) &&
+      e->trellis_v3 > 0 && nbands == 1 && !ext_eob && !ext_qopt && !e->arith && !e->debug_taps && p.trellis_quant && p.trellis_num_loops <= 1 && !sort_uq) {
     adapt_first_tier();
     if (e->trellis_variant <= 2) {
       // (mjh_launch_trellis_ac: one pass per tile -- a small batch, or MJH_TRELLIS_V3=1 -- comes with 24 records)

@@ -380,7 +380,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
 {
   constexpr bool W12 = sizeof(T) == 2;
   static_assert(!SORTED || !W12, "the tile-sorted layout feeds the (8-bit only) trellis");
-  static_assert(!REC || (FD && STATS && !W12 && !SORTED), "records come out of the 8-bit fast-division kernel with fused statistics, natural order");
+  static_assert(!REC || (FD && !W12 && !SORTED), "records come out of the 8-bit fast-division kernel, natural order");
   // 8 KB per wave: the deringing columns (the ORIGINAL level-shifted samples of the lane's block in zig-zag order, 16 bits
   // each for 8- and 12-bit data) and, afterwards, 8 interleaved copies of the 256-bin statistics histogram
   constexpr int LW = 32;
@@ -557,9 +557,21 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
       continue;
     }
     int v = FD ? udiv_mh(ax + (dq >> 1), Q->sdiv[cc.qtbl][k], Q->mdiv[cc.qtbl][k]) : udiv_exact(ax + (dq >> 1), dq, rcp[k]);
+    if (REC && k > 0) {     // (the kernel without fused statistics: the same records from the division it does for every coefficient)
+      float t = (float)mul24(ax, ax) * lambda_blk;
+      t = t * Q->lambda_tbl[cc.qtbl][k];
+      const float azd_cur = t + azd;
+      if (valid && v != 0) {
+        const int qv = v >= 1024 ? 1023 : v;
+        qmax = qv > qmax ? qv : qmax;
+        if (nzc < rec->qn)
+          reinterpret_cast<uint2 *>(rec->records)[(size_t)nzc * rec->row_stride + gblk_rec] = make_uint2((unsigned)k | (x < 0 ? 64u : 0u) | ((unsigned)qv << 7) | ((unsigned)ax << 17), __float_as_uint(azd));
+      }
+      azd = azd_cur;
+    }
     if (x < 0) v = -v;
     if (clampq) v = W12 ? max(-16383, min(16383, v)) : max(-1023, min(1023, v));
-    if (!W12 && (k == 0 || !SORTED)) uq[(size_t)k * cc.kstride] = (int16_t)x;   // raw x8 coefficients only feed the (8-bit only) trellis
+    if (!W12 && (k == 0 || (!SORTED && !REC))) uq[(size_t)k * cc.kstride] = (int16_t)x;   // raw x8 coefficients only feed the (8-bit only) trellis
     if (k == 0 || !STATS) qo[(size_t)k * cc.kstride] = (int16_t)v;   // STATS: the AC planes would never be read
     if (!stats && !W12 && k > 0) nzc += (v != 0);
     if (stats && k > 0 && valid) {
@@ -3409,7 +3421,7 @@ void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, vo
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
   const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
   if (rec) {      // the FDCT kernel also writes the AC trellis' queue records (mjh_sorted.hip: k_dct_quant_rec)
-    if (C.precision == 12 || !fastdiv || !nq8 || !stat_tabs || perm16) { fprintf(stderr, "mjh_launch_dct: queue records need 8-bit samples, the fast division, fused statistics and natural order\n"); abort(); }
+    if (C.precision == 12 || !fastdiv || !nq8 || perm16) { fprintf(stderr, "mjh_launch_dct: queue records need 8-bit samples, the fast division and natural order\n"); abort(); }
     mjh_launch_dct_rec(C, Q, planes, uq, q, lambda, stat_tabs, spi, stat_slot, nq8, n, s, *rec);
     return;
   }

@@ -43,12 +43,13 @@ k_trellis_ac_v3s(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__re
 }
 
 // ---- queue records from the FDCT kernel (MJH_TRELLIS_REC=1; natural block order, the trellis kernel sorts its tiles itself) ----
+template <bool STATS>
 __global__ void __launch_bounds__(64)
 k_dct_quant_rec(MjhConst C, const MjhQuant *__restrict__ Q, const uint8_t *__restrict__ planes,
                 int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
                 MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out, MjhRecOut rec)
 {
-  dct_quant_body<uint8_t, true, true, 0, true>(C, Q, planes, coef_uq, coef_q, lambda_out, stat_tabs, slots_per_image, stat_slot_of_comp, nq8_out, nullptr, &rec);
+  dct_quant_body<uint8_t, STATS, true, 0, true>(C, Q, planes, coef_uq, coef_q, lambda_out, stat_tabs, slots_per_image, stat_slot_of_comp, nq8_out, nullptr, &rec);
 }
 
 template <int QN, bool FST, int NPASS>
@@ -141,9 +142,10 @@ void mjh_launch_trellis_ac_sorted(const MjhConst &C, const MjhQuant *Q, const vo
 void mjh_launch_dct_rec(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
                         MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, const MjhRecOut &rec)
 {
-  const int4 sl = make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]);
+  const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
   dim3 grid((sorted_max_nblk(C) + 63) / 64, C.ncomp, n);
-  hipLaunchKernelGGL(k_dct_quant_rec, grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8, rec);
+  if (stat_tabs) hipLaunchKernelGGL(k_dct_quant_rec<true>, grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8, rec);
+  else hipLaunchKernelGGL(k_dct_quant_rec<false>, grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8, rec);
 }
 
 // the first tier over the FDCT kernel's records (npass passes per tile of 64 * npass blocks, sorted here); the general tiers and
