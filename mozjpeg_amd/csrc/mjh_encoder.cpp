@@ -293,7 +293,7 @@ struct mjh_encoder {
   // queue records from the FDCT kernel (MJH_TRELLIS_REC=1, opt-in like the sorted planes; mjh_sorted.hip): rows x blocks records
   // of 8 bytes + the all-zero distortion per block; used for the plain sequential configuration with fused statistics
   unsigned long long *d_rec = nullptr; float *d_azd = nullptr; size_t rec_stride = 0; bool rec_mode = false;
-  static constexpr int REC_ROWS = 24;
+  static constexpr int REC_ROWS = 48;      // the largest first-tier capacity
   int sorted_tile = 256;             // MJH_SORTED_TILE=128|256|512: blocks per sorted tile = 64 x the waves of the FDCT workgroup = 64 x the trellis kernel's passes
   bool sorted_uq = false;            // MJH_SORTED_UQ=1: opt-in until it has been timed on the chip (bit-exact in the emulator, tools/simt); off: the FDCT kernel
                                      // writes every coefficient plane in natural order and the trellis sorts its tiles itself
@@ -1433,12 +1433,12 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   if (e->rec_mode && e->d_rec && !coef_src && compact && e->d_nq8 && e->fastdiv_all && C.precision == 8 && !fuse_fin && !(e->fuse_mask & 4) &&
       e->trellis_v3 > 0 && nbands == 1 && !ext_eob && !ext_qopt && !e->arith && !e->debug_taps && p.trellis_quant && p.trellis_num_loops <= 1 && !sort_uq) {
     adapt_first_tier();
-    if (e->trellis_variant <= 2) {
+    if (e->trellis_variant <= 4) {
       // (mjh_launch_trellis_ac: one pass per tile -- a small batch, or MJH_TRELLIS_V3=1 -- comes with 24 records)
       const bool small = (size_t)n * C.total_real_blocks < e->small_batch || e->trellis_v3 == 1;
       rec_out.records = e->d_rec; rec_out.row_stride = e->rec_stride; rec_out.azd = e->d_azd;
       rec_out.worklist = e->d_worklist; rec_out.dense = (int16_t *)e->d_dense; rec_out.dense_cap = e->dense_cap;
-      rec_out.qn = (small || e->trellis_variant > 0) ? 24 : 16;
+      rec_out.qn = e->trellis_variant >= 4 ? 48 : e->trellis_variant == 3 ? 32 : (small || e->trellis_variant > 0) ? 24 : 16;
       rec = &rec_out;
       mjh_launch_zero_counters(e->d_worklist, e->d_worklist2, s);
     }

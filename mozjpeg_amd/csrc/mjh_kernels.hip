@@ -3525,8 +3525,8 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
 #define LV3Q(QN, NP, FDV, FSV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, NP, FDV, FSV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask, st, ss)
 #define LV3(NP, FDV, FSV) LV3Q(16, NP, FDV, FSV)
     if (rec) {      // phase 1 happened in the FDCT kernel (mjh_launch_dct with the same MjhRecOut): the first tier reads its records
-      if (!fastdiv || perm16 || variant >= 3 || rec->qn != ((small24 || variant > 0) ? 24 : 16)) {
-        fprintf(stderr, "mjh_launch_trellis_ac: queue records come with the fast division, natural order and the capacity (16 / 24) of the first tier chosen here\n"); abort();
+      if (!fastdiv || perm16 || st || rec->qn != (variant >= 4 ? 48 : variant == 3 ? 32 : (small24 || variant > 0) ? 24 : 16)) {
+        fprintf(stderr, "mjh_launch_trellis_ac: queue records come with the fast division, natural order, no fused statistics and the capacity of the first tier chosen here\n"); abort();
       }
       mjh_launch_trellis_ac_rec(C, Q, q, tabs, spi, ac_slot, lambda, stat_slot, nzmask, n, s, nq8, *rec, small24 ? 1 : np);
     } else

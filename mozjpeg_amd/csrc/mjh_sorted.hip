@@ -165,6 +165,11 @@ void mjh_launch_trellis_ac_rec(const MjhConst &C, const MjhQuant *Q, void *q, Mj
 #define LV3R(QN, FSV, NP) hipLaunchKernelGGL((k_trellis_ac_v3r<QN, FSV, NP>), gridt, dim3(64), 0, s, C, Q, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, nzmask, st, ss, \
                                              (const uint2 *)rec.records, rec.row_stride, (const float *)rec.azd)
   bool ok = true;
+  if (rec.qn == 32 || rec.qn == 48) {       // q90 and up (20 / 30 KB of LDS per wave): four passes, no fused statistics
+    if (st || npass != 4) ok = false;
+    else if (rec.qn == 32) LV3R(32, false, 4);
+    else LV3R(48, false, 4);
+  } else
   if (rec.qn == 24) {
     if (st) { if (npass == 4) LV3R(24, true, 4); else ok = false; }
     else if (npass == 4) LV3R(24, false, 4);

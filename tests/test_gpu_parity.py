@@ -462,15 +462,15 @@ def test_frames_at_the_largest_dimension_jpeg_allows(w, h):
         assert got[0] == want, (w, h, kw)
 
 
-@pytest.mark.parametrize("quality,sample", [(75, (2, 2)), (85, (1, 1)), (60, (2, 1))])
+@pytest.mark.parametrize("quality,sample", [(75, (2, 2)), (85, (1, 1)), (60, (2, 1)), (95, (1, 1))])
 def test_queue_records_from_the_fdct_kernel_give_the_same_file(quality, sample, request):
     """MJH_TRELLIS_REC=1 (opt-in, mjh_sorted.hip): the FDCT kernel, which quantizes every coefficient anyway (for its fused
     statistics in the sequential configuration, for coef_q in the progressive one), also does phase 1 of the tile-sorted AC trellis -- queue records row by row,
     the all-zero distortion, the deferral of the blocks the first tier cannot take -- and k_trellis_ac_v3r starts from the
     records.  Same files as the default path and the oracle: one / two / four / eight passes per tile (MJH_SMALL_BATCH=0 takes a
-    small batch down the large-batch plan), 16 and 24 records, a work list that outgrows its dense copies (the general tiers
+    small batch down the large-batch plan), 16 / 24 / 32 / 48 records, a work list that outgrows its dense copies (the general tiers
     then read the planes the FDCT kernel wrote for deferred blocks), grey and subsampled frames, ragged tiles; configurations the
-    mode does not cover (capacities of 32 / 48 records, trellis loops) fall back to the default kernels.
+    mode does not cover (trellis loops, fused back-track statistics) fall back to the default kernels.
     Written after round 4's GPU minutes were spent: runs under the emulator (`--simt`), on the chip only with MJH_TEST_SORTED=1."""
     if not request.config.getoption("--simt") and os.environ.get("MJH_TEST_SORTED") != "1":
         pytest.skip("opt-in kernels (MJH_TRELLIS_REC) that have only run under tools/simt so far: set MJH_TEST_SORTED=1 to run them on the chip")
@@ -485,6 +485,7 @@ def test_queue_records_from_the_fdct_kernel_give_the_same_file(quality, sample, 
         want = O.encode(O.make_params(w, h, **kw), img)
         for variant, dense, small, v3, fuse in ((None, None, None, None, None), ("0", None, "0", "4", None), ("0", "8", "0", "1", None), ("0", None, "0", "2", None),
                                                  ("0", "0", "0", "8", None), ("2", None, "0", "4", None), ("2", "40", None, None, None), ("3", None, "0", "4", None),
+                                                 ("4", None, "0", "4", None), ("3", "5", None, None, None), ("4", "0", "0", "2", None),
                                                  (None, None, "0", None, None), ("0", None, "0", "4", "5")):
             env = {"MJH_TRELLIS_REC": "1", "MJH_TRELLIS_VARIANT": variant, "MJH_DENSE_CAP": dense, "MJH_SMALL_BATCH": small, "MJH_TRELLIS_V3": v3, "MJH_FUSE": fuse}
             try:
