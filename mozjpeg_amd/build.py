@@ -13,7 +13,7 @@ LIB = os.path.join(HERE, "libmozjpeg_hip.so")
 SHIM = os.path.join(HERE, "libmozjpeg_hip_jpeg62.so")
 STANDALONE = os.path.join(HERE, "standalone", "libjpeg.so.62")
 TJSHIM = os.path.join(HERE, "libmozjpeg_hip_turbojpeg.so")
-SOURCES = ["mjh_kernels.hip", "mjh_sorted.hip", "mjh_prog.hip", "mjh_arith.hip", "mjh_encoder.cpp", "mjh_pool.cpp", "mjh_guard.cpp"]
+SOURCES = ["mjh_kernels.hip", "mjh_sorted.hip", "mjh_prog.hip", "mjh_prog_sl.hip", "mjh_arith.hip", "mjh_encoder.cpp", "mjh_pool.cpp", "mjh_guard.cpp"]
 # -ffp-contract=off: the trellis / deringing float recipes must not be fused into FMAs
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
@@ -29,7 +29,7 @@ def _newer(target, deps):
 def build(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + \
+    deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".h", ".inc"))] + \
         [os.path.join(HERE, "..", "include", "mozjpeg_hip.h")]
     if force or _newer(LIB, deps):
         objs = []

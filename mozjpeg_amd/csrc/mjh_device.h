@@ -24,6 +24,11 @@ __device__ __forceinline__ int bitlen(unsigned v) { return 32 - __clz((int)v); }
 // operands in [-2^23, 2^23) -- raw coefficients (|x| <= 2^15), quantizer steps 8q (< 2^20), candidates (<= 1023) and the
 // differences cand*8q - x (|.| < 2^21) all are
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+// (float)(v * v) for |v| < 2^15 without the integer multiply: (float)v is exact, the float product rounds the exact square once,
+// as the conversion of the integer square does -- v_cvt + v_mul_f32 (4 + 2 issue cycles) instead of v_mul_i32_i24 + v_cvt (4 + 4;
+// profiles/r04a_valu_rate_summary.md).  Used by the opt-in kernels only (mjh_sorted.hip: record mode and tile-sorted planes): the default kernels keep
+// the machine code they were validated with.
+__device__ __forceinline__ float squaref(int v) { const float f = (float)v; return f * f; }
 
 // exact floor(n/d) for 0 <= n < 2^23, 1 <= d < 2^23, rcp = RN(1/d)
 __device__ __forceinline__ int udiv_exact(int n, int d, float rcp)

@@ -494,7 +494,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
     // from the host libm.  Both trellis kernels consume it.
     float norm = 0.0f;
 #pragma unroll
-    for (int n = 1; n < 64; n++) norm = norm + (float)mul24(d[n], d[n]);   // |raw coefficient| <= 2^15
+    for (int n = 1; n < 64; n++) norm = norm + ((REC || SORTED) ? squaref(d[n]) : (float)mul24(d[n], d[n]));   // |raw coefficient| <= 2^15
     norm = (float)((double)norm / 63.0);
     float lambda;
     if (C.lambda_log_scale2 > 0.0f) lambda = (float)(C.pow_scale1 * 1.0 / (C.pow_scale2 + (double)norm));
@@ -532,7 +532,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
       if (!SORTED && !REC) uq[(size_t)k * cc.kstride] = (int16_t)x;
       float azd_cur = 0.0f;
       if (REC) {
-        float t = (float)mul24(ax, ax) * lambda_blk;
+        float t = squaref(ax) * lambda_blk;
         t = t * Q->lambda_tbl[cc.qtbl][k];
         azd_cur = t + azd;
       }
@@ -558,7 +558,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
     }
     int v = FD ? udiv_mh(ax + (dq >> 1), Q->sdiv[cc.qtbl][k], Q->mdiv[cc.qtbl][k]) : udiv_exact(ax + (dq >> 1), dq, rcp[k]);
     if (REC && k > 0) {     // (the kernel without fused statistics: the same records from the division it does for every coefficient)
-      float t = (float)mul24(ax, ax) * lambda_blk;
+      float t = squaref(ax) * lambda_blk;
       t = t * Q->lambda_tbl[cc.qtbl][k];
       const float azd_cur = t + azd;
       if (valid && v != 0) {

@@ -67,6 +67,11 @@ void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *lis
                             MjhHuffTable *tabs, int spi, unsigned *pool, size_t pool_words, const void *frame_hdr, int frame_hdr_len,
                             int multi_dht, void *outpool, size_t out_bytes, unsigned *mpos, int mpos_per_image, unsigned *ffsums, const unsigned long long *nzmask, int n, hipStream_t s,
                             hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, int nacf);
+// opt-in variants of the first-pass AC scans' statistics / emit kernels (mjh_prog_sl.hip, MJH_PP_SKIPLOW=1)
+void mjh_launch_pp_stats_sl(const MjhConst &C, const void *scans, const int *list, const void *ctl, const void *q, const unsigned long long *nzmask,
+                            MjhHuffTable *tabs, int spi, const MjhProgPE &pe, int nacf, int n, hipStream_t s);
+void mjh_launch_pp_emit_sl(const MjhConst &C, const void *scans, const int *par_list, const void *ctl, const void *q, const unsigned long long *nzmask,
+                           const MjhHuffTable *tabs, int spi, unsigned *pool, size_t pool_words, const MjhProgPE &pe, int nacf, int n, hipStream_t s);
 void mjh_launch_scan16(const void *len16, int n_per, unsigned *sums, int chunks, unsigned *totals, unsigned *off32, int npairs, hipStream_t s);
 void mjh_launch_prog_select(void *ctl, int ncomp, int phase, int dc_scan_opt_mode, int n, hipStream_t s);
 void mjh_launch_prog_concat(const void *ctl, const void *file_hdr, int file_hdr_len, const void *outpool, size_t out_bytes,

@@ -500,3 +500,35 @@ def test_queue_records_from_the_fdct_kernel_give_the_same_file(quality, sample, 
                 got = enc.encode_host(frames)
                 assert got[0] == want and got[2] == want, (kw, env, rnd)
             enc.close()
+
+
+@pytest.mark.parametrize("quality,sample", [(85, (2, 2)), (75, (1, 1)), (95, (2, 1)), (40, (2, 2))])
+def test_skiplow_walks_of_the_scan_search_give_the_same_file(quality, sample, request):
+    """MJH_PP_SKIPLOW=1 (opt-in, mjh_prog_sl.hip): the statistics and emit kernels of the first-pass AC scans take the non-zeros
+    below the band out of a block's mask up front instead of visiting and dropping them (pp_band_nonzeros<true>), and skip
+    bursts no lane needs.  Same files as the default path and the oracle for the scan search (cjpeg's default), the fixed
+    nine-scan script, a notrellis search (dense coefficient planes: the knob must change nothing), grey and subsampled frames,
+    frames whose upper bands are empty (flat) or full (noise), and more than one chunk of 2048 blocks per component.
+    Written after round 4's GPU minutes were spent: runs under the emulator (`--simt`), on the chip only with MJH_TEST_SORTED=1."""
+    if not request.config.getoption("--simt") and os.environ.get("MJH_TEST_SORTED") != "1":
+        pytest.skip("opt-in kernels (MJH_PP_SKIPLOW) that have only run under tools/simt so far: set MJH_TEST_SORTED=1 to run them on the chip")
+    w, h = 616, 440            # 77 x 55 = 4235 luma blocks at 1x1 sampling: three chunks, the last one ragged
+    rng = np.random.default_rng(1000 + quality)
+    img = O.synthetic_frame(w, h, 7 + quality)
+    img[40:200, 300:560] = rng.integers(0, 256, (160, 260, 3), dtype=np.uint8)     # noise: every band of these blocks is busy
+    img[260:420, 20:280] = 131                                                      # flat: nothing but DC
+    flat = np.full_like(img, 77)
+    frames = np.stack([img, flat, img[::-1, ::-1].copy()])
+    for kw in (dict(quality=quality, sample=sample), dict(quality=quality, sample=sample, fastcrush=True), dict(quality=quality, gray=True),
+               dict(quality=quality, sample=sample, notrellis=True), dict(quality=quality, sample=sample, dc_scan_opt=2, trellis_eob_opt=True)):
+        want = [O.encode(O.make_params(w, h, **kw), f) for f in frames]
+        try:
+            os.environ["MJH_PP_SKIPLOW"] = "1"
+            enc = M.Encoder(M.make_params(w, h, **kw), max_batch=3)
+            for rnd in range(2):
+                got = enc.encode_host(frames)
+                assert [bytes(g) for g in got] == want, (kw, rnd)
+            enc.close()
+        finally:
+            os.environ.pop("MJH_PP_SKIPLOW", None)
+

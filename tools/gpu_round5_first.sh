@@ -19,4 +19,6 @@ echo "== 3a'. the record mode on C3 and C5t"; for c in c3 c5t; do timeout 400 py
 echo "== 3a''. the record mode with tiles of 512 blocks (eight passes: the gathers are rows of records now, not 63 planes)"; MJH_TRELLIS_REC=1 timeout 400 python tools/bench_variants.py --env MJH_TRELLIS_V3 --variants 4,8 --steps 10 > "$O/variants_rec_v3.log" 2>&1; grep '^{' "$O/variants_rec_v3.log" | cut -c1-400
 echo "== 3. A/B on the metric workload"; timeout 400 python tools/bench_variants.py --env MJH_SORTED_UQ --variants 0,1 --steps 10 > "$O/variants.log" 2>&1; grep '^{' "$O/variants.log" | cut -c1-520
 echo "== 3b. tile sizes (sorted on)"; MJH_SORTED_UQ=1 timeout 400 python tools/bench_variants.py --env MJH_SORTED_TILE --variants 128,256,512 --steps 10 > "$O/variants_tile.log" 2>&1; grep '^{' "$O/variants_tile.log" | cut -c1-520
+echo "== 3c. MJH_PP_SKIPLOW (mjh_prog_sl.hip): own test, then A/B on C3"; MJH_TEST_SORTED=1 timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k skiplow > "$O/skiplow_own.log" 2>&1; tail -1 "$O/skiplow_own.log"
+timeout 400 python tools/bench_variants.py --config c3 --env MJH_PP_SKIPLOW --variants 0,1 --steps 6 > "$O/variants_skiplow_c3.log" 2>&1; grep '^{' "$O/variants_skiplow_c3.log" | cut -c1-400
 echo "== 4. bench"; timeout 300 python bench.py --no-cpu-baseline --no-host-leg --no-inflight-leg > "$O/bench.log" 2>&1; tail -1 "$O/bench.log" | cut -c1-600

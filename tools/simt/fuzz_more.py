@@ -109,6 +109,9 @@ def main():
                 env["MJH_TRELLIS_V3"] = str(int(r2.choice([1, 2, 4, 8])))
             if r2.random() < 0.3:
                 env["MJH_DENSE_CAP"] = str(int(r2.integers(0, 30)))
+        # MJH_PP_SKIPLOW (mjh_prog_sl.hip) is read at every launch: it stays set for the whole case (own generator: the cases of
+        # earlier seeds stay what they were)
+        skiplow = np.random.default_rng(seed * 7919 + i).random() < 0.4
         if i < first:
             continue
         if verbose:
@@ -129,11 +132,16 @@ def main():
             for k in env:
                 os.environ.pop(k, None)
         try:
+            if skiplow:
+                os.environ["MJH_PP_SKIPLOW"] = "1"
+                env = dict(env, MJH_PP_SKIPLOW="1")
             got = enc.encode_host(np.stack([img, img[::-1].copy(), img]))
             ok = got[0] == want and got[2] == want
         except Exception as exc:
             ok = False
             print("EXCEPTION", repr(exc)[:200], flush=True)
+        finally:
+            os.environ.pop("MJH_PP_SKIPLOW", None)
         enc.close()
         if not ok:
             bad += 1
