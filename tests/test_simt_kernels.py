@@ -71,6 +71,28 @@ def test_emulated_12bit_kernels_reproduce_the_reference_goldens(simt, cname, gol
         assert (len(data), O.md5(data)) == (g["bytes"], g["md5"]), (iname, cname)
 
 
+# the opt-in kernel variants (never run on the chip when round 4 ended): their own translation units, switched on by
+# the environment; the files must be the default path's = the reference's
+OPT_IN = [("MJH_SORTED_UQ", "2", "base"), ("MJH_SORTED_UQ", "2", "base_q90_444"), ("MJH_TRELLIS_REC", "1", "base"),
+          ("MJH_TRELLIS_REC", "1", "default_progressive"), ("MJH_PP_SKIPLOW", "1", "default_progressive"), ("MJH_PP_SKIPLOW", "1", "dc_scan_opt2")]
+
+
+@pytest.mark.parametrize("knob,value,cname", OPT_IN)
+def test_emulated_opt_in_variants_reproduce_the_reference_goldens(simt, knob, value, cname, goldens):
+    kw = [k for c, k, _ in CASES if c == cname][0]
+    for iname, img in images().items():
+        h, w = img.shape[:2]
+        try:
+            os.environ[knob] = value          # (read when the encoder is made or, MJH_PP_SKIPLOW, at every launch)
+            enc = M.Encoder(M.make_params(w, h, **kw))
+            data = enc.encode_host(img)[0]
+            enc.close()
+        finally:
+            os.environ.pop(knob, None)
+        g = goldens["%s/%s" % (iname, cname)]
+        assert (len(data), O.md5(data)) == (g["bytes"], g["md5"]), (knob, iname, cname)
+
+
 def test_emulated_batch_of_1080p_frames_matches_the_oracle(simt):
     """BASELINE config 2's frame size, a batch of three (distinct frames, one encoder), against the oracle"""
     w, h = 1920, 1080
