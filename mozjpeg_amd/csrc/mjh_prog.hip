@@ -683,7 +683,7 @@ struct PPRefine { unsigned long long newm, nzm, corrm, posm, tailm; int tail_cnt
 // plane i+1 = its i-th non-zero value in position order): f(position, value) for the non-zero coefficients at positions
 // Ss..Se in position order.  Every lane of a wave reads the same plane at a time (coalesced), bursts of 8, up to the
 // rank of the last position <= Se the busiest block of the wave has; positions below Ss are read and dropped.
-// SKIPLOW (opt-in, MJH_PP_SKIPLOW=1: k_pp_stats<true, 1, true>, k_pp_emit_sl): the non-zeros below Ss -- for the upper band of a
+// SKIPLOW (opt-in, MJH_PP_SKIPLOW=1: k_pp_stats<true, 3> and k_pp_emit_sl, both in mjh_prog_sl.hip): the non-zeros below Ss -- for the upper band of a
 // frequency split most of a block's non-zeros -- are taken out of the mask up front instead of being visited and dropped one by
 // one, and bursts in which no lane of the wave has anything to visit are not even loaded; f sees the same sequence.
 template <bool SKIPLOW = false, class F>
