@@ -151,6 +151,59 @@ def cpu_baseline(frame, kw, budget_s=20.0):
             "sample": "1 encode of one %dx%d frame with oracle/libmjoracle.so (scalar C port)" % (w, h)}
 
 
+def other_config_line(M, torch, key, device, budget_s, t_end):
+    """Compact driver-visible evidence for a BASELINE configuration other than the metric's (never `value`): a few device-
+    resident steps of the configuration with its own frames, the first frame(s) compared with the real reference (outside
+    the timed steps), the dominant interval's roofline fraction.  Bounded: frames and steps shrink to fit `budget_s`."""
+    cfg = CONFIGS[key]
+    w, h, kw = cfg["w"], cfg["h"], cfg["kw"]
+    twelve = kw.get("precision", 8) == 12
+    B = min(cfg["batch"], 32 if w * h > 4000000 else 64)
+    t_start = time.perf_counter()
+    distinct = min(B, 4)                       # synthetic frames are the expensive part on the host: 4 distinct, repeated
+    frames = make_frames(w, h, [1234 + i for i in range(distinct)], twelve, 1)
+    reps = B // distinct
+    batch = np.concatenate([frames] * reps) if reps > 1 else frames
+    d = torch.from_numpy(batch.view(np.int16) if twelve else batch).to(device)
+    enc = M.Encoder(M.make_params(w, h, **kw), max_batch=len(batch), device=device.index or 0)
+    try:
+        for _ in range(2):
+            enc.encode_tensor(d, stream="own")
+            enc.sync()
+        jp = [enc.get_jpeg(i) for i in range(len(batch))]
+        nver = 1 if w * h > 30000000 else 2
+        be = verify_frames(frames, jp, w, h, kw, nver)
+        be["repeats_identical_to_first_copy"] = all(jp[i] == jp[i % distinct] for i in range(len(jp)))
+        be["ok"] = bool(be["ok"] and be["repeats_identical_to_first_copy"])
+        enc.set_profiling(1)
+        enc.encode_tensor(d, stream="own"); enc.sync()          # creates the events
+        enc.set_profiling(1)
+        enc.encode_tensor(d, stream="own"); enc.sync()
+        kt = {k: v for k, v in dict(enc.kernel_times()).items() if "side stream" not in k and not k.startswith("join(")}
+        focus = max(kt, key=kt.get) if kt else None
+        enc.set_profiling(2, focus=focus)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        steps = 0
+        left = min(budget_s - (t0 - t_start), t_end - t0)
+        while steps < 3 or (time.perf_counter() - t0 < min(1.5, left) and steps < 400):
+            enc.encode_tensor(d, stream="own")
+            steps += 1
+        enc.sync()
+        dt = (time.perf_counter() - t0) / steps
+        dom = dict(enc.kernel_times())
+        dom_ms = dom.get(focus) if focus else None
+        algo = float(batch.nbytes) + float(sum(len(j) for j in jp))
+        out = {"workload": cfg["name"], "frames_per_step": int(len(batch)), "steps": steps, "ms_per_step": round(dt * 1e3, 3),
+               "value": round(float(w) * h * len(batch) / dt / 1e6, 1), "unit": "Mpixels/s", "bit_exact": be}
+        if dom_ms:
+            out["roofline"] = {"kernel": focus, "kernel_ms": round(dom_ms, 4), "achieved": round(algo / (dom_ms * 1e-3) / 1e9, 1),
+                               "unit": "GB/s", "frac": round(algo / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        return out
+    finally:
+        enc.close()
+
+
 # kernels behind each interval name of the schedule (mjh_get_kernel_times), for the PMC traffic lookup
 INTERVAL_KERNELS = {
     "trellis_ac": ("k_trellis_ac",), "dct_quant": ("k_dct_quant",), "color": ("k_color",),
@@ -389,6 +442,8 @@ def main():
     ap.add_argument("--host-seconds", type=float, default=3.0)
     ap.add_argument("--host-batch", type=int, default=16)
     ap.add_argument("--verify", default="all", help="frames per batch to compare with the reference: all | N")
+    ap.add_argument("--other-configs", default="auto", help="auto: the default N=1 run of the metric configuration appends a compact line per other BASELINE configuration (c2, c3, c5, c5t) under --other-budget seconds; none: skip")
+    ap.add_argument("--other-budget", type=float, default=60.0)
     ap.add_argument("--launch-check", action="store_true",
                     help="only start the ranks, form the process group (gloo) and print n_gpus: no GPU is touched (CPU test of the launch path)")
     args = ap.parse_args()
@@ -609,6 +664,24 @@ def main():
     enc.close()
     del d_frames
 
+    # Driver-visible evidence for the other BASELINE configurations (extra information, never `value`): only in the
+    # default run of the metric configuration on one GPU, under a wall-clock budget
+    others = None
+    if args.other_configs == "auto" and args.config == "metric" and world == 1 and not args.no_inflight_leg:
+        others = {}
+        t_end = time.perf_counter() + args.other_budget
+        keys = ["c2", "c3", "c5t", "c5"]
+        for i, key in enumerate(keys):
+            left = t_end - time.perf_counter()
+            if left < 4.0:
+                others[key] = {"skipped": "budget of %.0f s used up" % args.other_budget}
+                continue
+            try:
+                others[key] = other_config_line(M, torch, key, dev, left / (len(keys) - i), t_end)
+            except Exception as exc:
+                others[key] = {"error": str(exc)}
+        torch.cuda.empty_cache()
+
     # PCIe-inclusive legs (never `value`).  N > 1: EVERY rank runs its host path at the same time -- the host side (N x
     # pinned reads through one root complex, N result streams back) is the part of the job that can fail to scale.
     host_all = None
@@ -679,6 +752,8 @@ def main():
                          "kernel_ms_per_call(untimed pass, every kernel bracketed)":
                              {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])}},
         }
+        if others is not None:
+            out["other_configs"] = others
         if pipelined is not None:
             out["pipelined"] = pipelined
         if two_ranges is not None:

@@ -1443,6 +1443,14 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       mjh_launch_zero_counters(e->d_worklist, e->d_worklist2, s);
     }
   }
+  if (ext_qopt) {
+    // trellis_q_opt re-estimates d_quant per image during the encode: the FDCT and the conventional quantization of THIS
+    // encode start from the parameters' tables again (the reference's tables of a new jpeg_start_compress), not from what
+    // the previous call of this encoder left
+    for (int i = 0; i < n; i++)
+      HIPCHK(hipMemcpyAsync(e->d_quant + i, e->d_quant_init, sizeof(MjhQuant), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemsetAsync(e->d_qsums, 0, (size_t)n * 4 * 64 * 2 * sizeof(long long), s));
+  }
   if (!coef_src) {
     pr.mark("dct_quant");
     mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, e->d_nq8, n, s, e->fastdiv_all, perm16, e->sorted_tile, rec);
@@ -1644,9 +1652,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     // quantization tables after every group of num_components (component, round) units (prepare_for_pass jcmaster.c:687-698,
     // finish_pass_master :1014-1030), so with more than one round a later component is quantized with tables estimated from
     // earlier ones: the same order here, one component at a time, every image with its own table set.
-    for (int i = 0; i < n; i++)
-      HIPCHK(hipMemcpyAsync(e->d_quant + i, e->d_quant_init, sizeof(MjhQuant), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemsetAsync(e->d_qsums, 0, (size_t)n * 4 * 64 * 2 * sizeof(long long), s));
+    // (every image's table set was reset to the parameters' tables in front of the FDCT launch)
     bool first_pass = true;
     for (int u = 0; u < C.ncomp * nloops; u++) {
       const int ci = u / nloops, loop = u % nloops;

@@ -833,7 +833,7 @@ k_stats_ac(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restr
 }
 
 #define STATS_DC_ITER 16
-template <int MCU_ORDER>
+// component raster order (the per-component passes): one lane per block
 __global__ void __launch_bounds__(256)
 k_stats_dc(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restrict__ tabs,
            int slots_per_image, int4 slot_of_comp, int4 comp_restart)
@@ -842,7 +842,7 @@ k_stats_dc(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restr
   const MjhComp cc = C.c[comp];
   const int16_t *q0 = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;  // plane k = 0
   const int lane = threadIdx.x & 63;
-  const int nitems = MCU_ORDER ? cc.wpad * cc.hpad : cc.nblk;
+  const int nitems = cc.nblk;
   const int ri = comp == 0 ? comp_restart.x : comp == 1 ? comp_restart.y : comp == 2 ? comp_restart.z : comp_restart.w;
   unsigned cnt = 0;   // lane s (< 16) counts symbol s for this wave
   for (int it = 0; it < STATS_DC_ITER; it++) {
@@ -850,16 +850,8 @@ k_stats_dc(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restr
     if ((int)(blockIdx.x * STATS_DC_ITER + it) * 256 >= nitems) break;   // uniform
     int nb = -1;
     if (t < nitems) {
-      int dc, pred = 0;
-      if (MCU_ORDER) {
-        const int r = t / cc.wpad, c = t - r * cc.wpad;
-        dc = q0[dc_source_block(cc, r, c)];
-        int pr, pc;
-        if (mcu_prev_block(C, cc, r, c, pr, pc)) pred = q0[dc_source_block(cc, pr, pc)];
-      } else {
-        dc = q0[t];
-        pred = (t == 0 || (ri && (t % ri) == 0)) ? 0 : q0[t - 1];
-      }
+      const int dc = q0[t];
+      const int pred = (t == 0 || (ri && (t % ri) == 0)) ? 0 : q0[t - 1];
       const int df = dc - pred;
       nb = bitlen((unsigned)(df < 0 ? -df : df));
     }
@@ -872,6 +864,74 @@ k_stats_dc(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restr
   const int slot = comp == 0 ? slot_of_comp.x : comp == 1 ? slot_of_comp.y : comp == 2 ? slot_of_comp.z : slot_of_comp.w;
   MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
   if (lane < 16 && cnt) atomicAdd(&T->counts[lane], cnt);
+}
+
+// interleaved MCU order incl. dummy blocks (the final scan; encode_mcu_gather jchuff.c:866-915 walks the MCUs, the blocks of
+// a component inside an MCU row by row): ONE LANE PER MCU of one component.  blockIdx.x = MCU row, the threads stride
+// the MCUs of the row, so no thread divides anything; the lane loads the last block of the MCU in front (the prediction of
+// its first block) and its own h x v blocks -- every load is issued before the first use, the other predictions are the
+// lane's previous value.  Counts per symbol are wave-uniform (ballot + s_bcnt1) until the single atomic per symbol.
+__global__ void __launch_bounds__(256)
+k_stats_dc_mcu(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restrict__ tabs,
+               int slots_per_image, int4 slot_of_comp)
+{
+  const int comp = blockIdx.y, img = blockIdx.z, my = blockIdx.x;
+  const MjhComp cc = C.c[comp];
+  const int16_t *q0 = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;  // plane k = 0
+  const int lane = threadIdx.x & 63;
+  const int h = cc.h, v = cc.v, wib = cc.wib, hib = cc.hib, mpr = C.mcus_per_row, ri = C.restart_interval;
+  unsigned cnt[16];
+#pragma unroll
+  for (int s = 0; s < 16; s++) cnt[s] = 0;
+  for (int mx0 = 0; mx0 < mpr; mx0 += 256) {   // uniform
+    const int mx = mx0 + (int)threadIdx.x;
+    const bool in = mx < mpr;
+    const int mxc = in ? mx : mpr - 1;
+    // prediction of the MCU's first block: the last block (row v-1, column h-1) of the MCU in front
+    const int m = my * mpr + mxc;
+    bool has = m != 0;
+    if (ri) has = has && (m % ri) != 0;
+    int pmy = my, pmx = mxc - 1;
+    if (pmx < 0) { pmx = mpr - 1; pmy = my - 1; }
+    if (pmy < 0) { pmy = 0; pmx = 0; }
+    int pr = pmy * v + v - 1, pc = pmx * h + h - 1;     // dc_source_block of it: a last column stays one under the row clamp
+    if (pr >= hib) pr = hib - 1;
+    if (pc > wib - 1) pc = wib - 1;
+    int pred = q0[pr * wib + pc];
+    if (!has) pred = 0;
+#pragma unroll 1
+    for (int yi = 0; yi < v; yi++) {
+      int r = my * v + yi;
+      const bool below = r >= hib;                      // dummy rows copy the DC of the MCU's last real column in the last row
+      if (below) r = hib - 1;
+#pragma unroll 1
+      for (int xi0 = 0; xi0 < h; xi0 += 4) {
+        int dcv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          int c = mxc * h + (below ? h - 1 : (xi0 + j < h ? xi0 + j : h - 1));
+          if (c > wib - 1) c = wib - 1;
+          dcv[j] = q0[r * wib + c];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (xi0 + j < h) {                            // uniform
+            const int df = dcv[j] - pred;
+            pred = dcv[j];
+            const int nb = in ? bitlen((unsigned)(df < 0 ? -df : df)) : -1;
+#pragma unroll
+            for (int s = 0; s < 16; s++) cnt[s] += (unsigned)__popcll(__ballot(nb == s));   // DC categories 0..11 (8-bit), ..15 (12-bit)
+          }
+        }
+      }
+    }
+  }
+  const int slot = comp == 0 ? slot_of_comp.x : comp == 1 ? slot_of_comp.y : comp == 2 ? slot_of_comp.z : slot_of_comp.w;
+  MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+  unsigned mine = 0;
+#pragma unroll
+  for (int s = 0; s < 16; s++) mine = lane == s ? cnt[s] : mine;
+  if (lane < 16 && mine) atomicAdd(&T->counts[lane], mine);
 }
 
 // =============================================================================================
@@ -3450,11 +3510,11 @@ void mjh_launch_stats_dc(const MjhConst &C, const void *q, MjhHuffTable *tabs, i
   const int4 cr = make_int4(comp_restart[0], comp_restart[1], comp_restart[2], comp_restart[3]);
   const int per_wg = 256 * STATS_DC_ITER;
   if (mcu_order) {
-    dim3 grid((max_padblk(C) + per_wg - 1) / per_wg, C.ncomp, n);
-    hipLaunchKernelGGL((k_stats_dc<1>), grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, sl, cr);
+    dim3 grid(C.mcu_rows, C.ncomp, n);
+    hipLaunchKernelGGL(k_stats_dc_mcu, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, sl);
   } else {
     dim3 grid((max_nblk(C) + per_wg - 1) / per_wg, C.ncomp, n);
-    hipLaunchKernelGGL((k_stats_dc<0>), grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, sl, cr);
+    hipLaunchKernelGGL(k_stats_dc, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, sl, cr);
   }
 }
 

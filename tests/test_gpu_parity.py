@@ -124,6 +124,28 @@ def test_trellis_q_opt_with_16bit_tables_writes_the_final_precision(progressive)
         enc.close()
 
 
+@pytest.mark.parametrize("kw", [dict(baseline=True), dict(fastcrush=True), dict(baseline=True, gray=True),
+                                dict(baseline=True, restart=2)])
+def test_trellis_q_opt_encoder_can_be_reused(kw):
+    """trellis_q_opt re-estimates the per-image quantization tables during an encode (jcmaster.c:1014-1030); the next call of
+    the same encoder must start from the parameters' tables again (a new jpeg_start_compress in the reference): the
+    second and third encode of one encoder, with different images and batch sizes, against the oracle"""
+    from cases import images
+    imgs = images()
+    base = imgs["testorig"]
+    h, w = base.shape[:2]
+    kw = dict(kw, quality=75, trellis_q_opt=True)
+    po, pg = O.make_params(w, h, **kw), M.make_params(w, h, **kw)
+    a, b, c = base, base[::-1].copy(), np.roll(base, 37, axis=1).copy()
+    want = {id(x): O.encode(po, x) for x in (a, b, c)}
+    enc = M.Encoder(pg, max_batch=3)
+    for batch in ([a], [b, a], [c, b, a], [a]):
+        got = enc.encode_host(np.stack(batch))
+        for g, x in zip(got, batch):
+            assert g == want[id(x)]
+    enc.close()
+
+
 def test_tensor_encode_is_ordered_behind_the_default_stream_producer():
     """encode_tensor(stream=None) straight behind a producer on torch's default (null) stream, no synchronize in between:
     the encode has to see the finished pixels (the null stream has handle 0, which the ABI reads as "own stream"; the
