@@ -153,6 +153,14 @@ int mjh_params_search_progression(mjh_params *p);
 int mjh_encoder_create(const mjh_params *p, int max_batch, int device, mjh_encoder **out);
 /* number of visible HIP devices (0 if there is none: every mjh_encoder_create then fails with MJH_EHIP) */
 int mjh_device_count(void);
+/* Host-side placement of a device (one compress object per thread, libjpeg.txt:2198-2200): the NUMA node the
+ * device's PCIe root belongs to (-1: unknown, one-node host, or MJH_NUMA=0), and "run the calling thread on that node's
+ * CPUs" (returns the node, or -1 when nothing was changed).  The encoder pins its own staging / result buffers on that
+ * node; a client that fills mjh_host_staging buffers or owns pinned frames should do so from a bound thread.
+ * mjh_device_placement writes a one-line description (for logs / bench lines) and returns its length. */
+int mjh_device_numa_node(int device);
+int mjh_bind_thread_to_device(int device);
+int mjh_device_placement(int device, char *buf, size_t n);
 void mjh_encoder_destroy(mjh_encoder *e);
 /* the parameters the encoder was created with (owned by the encoder) */
 const mjh_params *mjh_encoder_params(const mjh_encoder *e);
@@ -301,6 +309,10 @@ int mjh_debug_guard_selftest(long offset, int write);
 
 const char *mjh_last_error(void);
 const char *mjh_version(void);
+/* sizeof(mjh_params) of THIS library.  mjh_params has grown at its end between versions (0.3: arith_code); a caller built
+ * against an older header would pass a shorter struct.  Bindings compare their own sizeof with this before the first
+ * mjh_encoder_create (the Python binding and both shims do) and fill the struct through mjh_params_defaults, which zeroes it. */
+size_t mjh_params_size(void);
 
 #ifdef __cplusplus
 }

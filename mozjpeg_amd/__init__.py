@@ -68,6 +68,11 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.mjh_last_error.restype = C.c_char_p
         L.mjh_version.restype = C.c_char_p
+        L.mjh_params_size.restype = C.c_size_t
+        if L.mjh_params_size() != C.sizeof(Params):     # mjh_params grows at its end between versions (include/mozjpeg_hip.h)
+            raise MjhError(EINVAL, "%s (%s) has a %d-byte mjh_params, this binding a %d-byte one: rebuild"
+                           % (LIB_PATH, L.mjh_version().decode(), L.mjh_params_size(), C.sizeof(Params)))
+        L.mjh_device_placement.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         L.mjh_params_defaults.argtypes = [C.POINTER(Params)] + [C.c_int] * 7
         L.mjh_params_set_quality.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int]
         L.mjh_params_simple_progression.argtypes = [C.POINTER(Params)]

@@ -13,7 +13,7 @@ LIB = os.path.join(HERE, "libmozjpeg_hip.so")
 SHIM = os.path.join(HERE, "libmozjpeg_hip_jpeg62.so")
 STANDALONE = os.path.join(HERE, "standalone", "libjpeg.so.62")
 TJSHIM = os.path.join(HERE, "libmozjpeg_hip_turbojpeg.so")
-SOURCES = ["mjh_kernels.hip", "mjh_sorted.hip", "mjh_prog.hip", "mjh_prog_sl.hip", "mjh_arith.hip", "mjh_encoder.cpp", "mjh_pool.cpp", "mjh_guard.cpp"]
+SOURCES = ["mjh_kernels.hip", "mjh_prog.hip", "mjh_arith.hip", "mjh_encoder.cpp", "mjh_pool.cpp", "mjh_guard.cpp", "mjh_numa.cpp"]
 # -ffp-contract=off: the trellis / deringing float recipes must not be fused into FMAs
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
@@ -31,15 +31,24 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".h", ".inc"))] + \
         [os.path.join(HERE, "..", "include", "mozjpeg_hip.h")]
-    if force or _newer(LIB, deps):
-        objs = []
-        for s in srcs:
-            o = os.path.join(CSRC, os.path.splitext(os.path.basename(s))[0] + ".o")
-            cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
-            objs.append(o)
+    # one object per source, rebuilt when its source or any shared header / .inc is newer; the translation units compile
+    # side by side (the five kernel files take ~40-60 s each)
+    hdrs = [d for d in deps if d not in srcs]
+    objs, jobs = [], []
+    for s in srcs:
+        o = os.path.join(CSRC, os.path.splitext(os.path.basename(s))[0] + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + hdrs):
+            jobs.append([hipcc] + FLAGS + ["-x", "hip", "-c", s, "-o", o])
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            for cmd, rc in zip(jobs, ex.map(subprocess.call, jobs)):
+                if verbose:
+                    print(" ".join(cmd))
+                if rc:
+                    raise subprocess.CalledProcessError(rc, cmd)
+    if force or _newer(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd))

@@ -78,6 +78,13 @@ static int pick_device(void)
       t_device = g_next_device++ % n;
       pthread_mutex_unlock(&g_lock);
     }
+    /* several GPUs: this client thread stages its rows into ITS device's pinned buffers from now on -- it runs on the CPUs
+     * of that device's NUMA node (mjh_numa.cpp; MOZJPEG_HIP_BIND=0 leaves the thread where the application put it, =1 binds
+     * on a one-GPU host too) */
+    {
+      const char *b = getenv("MOZJPEG_HIP_BIND");
+      if (b ? atoi(b) != 0 : n > 1) (void)mjh_bind_thread_to_device(t_device);
+    }
   }
   return t_device;
 }
@@ -451,6 +458,8 @@ static void shim_begin(j_compress_ptr cinfo, boolean write_all_tables, int mode,
   s->reading_arena = -1;
   if (mode == 2) cinfo->input_components = 1;   /* transencode_master_selection jctrans.c:186 */
   why = capture_params(cinfo, &s->p, mode);
+  if (!why && mjh_params_size() != sizeof(mjh_params))   /* (mjh_params grows at its end between versions: a stale library next to a new shim) */
+    why = "libmozjpeg_hip.so was built with another mjh_params layout than this shim (rebuild both)";
   if (!why) {
     /* the encoder validates too (geometry limits, sampling factors ...) and is this object's until finish / abort */
     s->enc = cache_acquire(&s->p, pick_device());

@@ -24,6 +24,7 @@
 #include "mjh_internal.h"
 #include "mjh_launch.h"
 #include "mjh_guard.h"
+#include "mjh_numa.h"
 #include "mjh_arith_table.h"
 
 // ---- error plumbing ---------------------------------------------------------------------------
@@ -54,13 +55,17 @@ extern "C" int mjh_debug_guard_check(void) { return guard_verify(); }
 extern "C" int mjh_debug_guard_mode(void) { return mjh_guard_mode(); }
 // (for mjh_pool.cpp, which is otherwise built on the public ABI: lets its argument checks leave a message too)
 int mjh_internal_fail(int code, const char *msg) { return fail(code, "%s", msg); }
-extern "C" const char *mjh_version(void) { return "mozjpeg_hip 0.2 (gfx950)"; }
+extern "C" const char *mjh_version(void) { return "mozjpeg_hip 0.3 (gfx950)"; }
+extern "C" size_t mjh_params_size(void) { return sizeof(mjh_params); }
 extern "C" int mjh_device_count(void)
 {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
   return n;
 }
+extern "C" int mjh_device_numa_node(int device) { return mjh_numa_node_of_device(device); }
+extern "C" int mjh_bind_thread_to_device(int device) { return mjh_numa_bind_thread(device); }
+extern "C" int mjh_device_placement(int device, char *buf, size_t n) { return buf && n ? mjh_numa_describe(device, buf, n) : 0; }
 
 // zig-zag (jutils.c:59)
 static const int kZZ[64] = {
@@ -287,16 +292,7 @@ struct mjh_encoder {
   // compact coefficient records between the AC trellis and the sequential coder: non-zero position masks;
   // the values live in the AC planes of d_q, plane i+1 = i-th non-zero.  compact_last: the last batch's d_q is in that form
   unsigned long long *d_nzmask = nullptr; bool use_compact = false, compact_last = false;
-  uint16_t *d_perm16 = nullptr;      // tile-sorted coefficient planes (MJH_SORTED_UQ): per block place, the block's index in its tile | sort key << 9
-  size_t small_batch = 400000;       // batches of fewer blocks run the AC trellis' first tier with one pass per tile (MJH_SMALL_BATCH=n: a test knob)
-  size_t sorted_uq_min = 400000;     // MJH_SORTED_UQ=n (n > 1): tile-sorted planes for batches of at least n blocks (tests: 2 = every batch)
-  // queue records from the FDCT kernel (MJH_TRELLIS_REC=1, opt-in like the sorted planes; mjh_sorted.hip): rows x blocks records
-  // of 8 bytes + the all-zero distortion per block; used for the plain sequential configuration with fused statistics
-  unsigned long long *d_rec = nullptr; float *d_azd = nullptr; size_t rec_stride = 0; bool rec_mode = false;
-  static constexpr int REC_ROWS = 48;      // the largest first-tier capacity
-  int sorted_tile = 256;             // MJH_SORTED_TILE=128|256|512: blocks per sorted tile = 64 x the waves of the FDCT workgroup = 64 x the trellis kernel's passes
-  bool sorted_uq = false;            // MJH_SORTED_UQ=1: opt-in until it has been timed on the chip (bit-exact in the emulator, tools/simt); off: the FDCT kernel
-                                     // writes every coefficient plane in natural order and the trellis sorts its tiles itself
+  size_t small_batch = 400000;       // batches of fewer blocks run the AC trellis' first tier with one pass per tile
   uint8_t *d_nq8 = nullptr;          // per block: non-zero conventionally quantized AC coefficients (FDCT kernel) = tile-sort key of the AC trellis
   int copy_prio = 0;
   int fastdiv_all = 0;               // every table in use has q <= 255: the kernels divide by 8q with one multiply-high (MjhQuant.mdiv)
@@ -315,7 +311,8 @@ struct mjh_encoder {
   unsigned *d_worklist = nullptr, *d_worklist2 = nullptr;   // deferred trellis blocks: [0] = count, [4+3i..6+3i] = (image, comp<<28|block, dense slot)
   int trellis_variant = 0;           // first-tier queue capacity of the AC trellis: 0 = 16, 1 = 20, 2 = 24, 3 = 32, 4 = 48 (all bit-identical)
   bool trellis_adapt = true;         // no MJH_TRELLIS_VARIANT given: follow the share of deferred blocks of the previous batches
-  unsigned *h_defer = nullptr;       // pinned: work-list count of the last finished trellis pass
+  unsigned *h_defer = nullptr;       // pinned: work-list counters of an earlier trellis pass (count_heavy), read back asynchronously
+  hipEvent_t ev_defer = nullptr; bool defer_pending = false; int defer_frames = 0;   // ... valid once ev_defer has completed; the frames they were counted over
   int fuse_mask = 1;                // MJH_FUSE: 1 = pre-trellis AC statistics inside the FDCT kernel (+ unread planes not stored), 2 = final AC statistics inside the general trellis kernel, 4 = inside the tile-sorted one (both measured: they cost the trellis what the separate pass costs, 2.36 + 0.33 vs 2.77 ms)
   int spi = SLOTS_BASE;             // table slots per image (16 + 2 per progressive scan)
   // progressive mode
@@ -689,6 +686,7 @@ static void free_view(mjh_encoder *v)
   for (hipEvent_t ev : v->prof_events) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : v->side_events) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : { v->ev_fork, v->ev_join, v->ev_view_done }) if (ev) (void)hipEventDestroy(ev);
+  if (v->ev_defer) (void)hipEventDestroy(v->ev_defer);
   if (v->h_defer) (void)hipHostFree(v->h_defer);
   if (v->side_stream) (void)hipStreamDestroy(v->side_stream);
   if (v->stream) (void)hipStreamDestroy(v->stream);
@@ -705,11 +703,12 @@ static void free_all(mjh_encoder *e)
   e->pad_streams.clear();
   if (e->ev_split_fork) (void)hipEventDestroy(e->ev_split_fork);
   if (e->ev_null_in) (void)hipEventDestroy(e->ev_null_in);
-  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->pe.chist, e->pe.rmask, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_nq8, e->d_perm16, e->d_rec, e->d_azd, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
+  void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->pe.chist, e->pe.rmask, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_nq8, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
                    e->d_meta, e->d_prefix, e->d_sos, e->d_arith_rates, e->d_back9, e->d_jfin, e->d_qspec, e->g_in[0], e->g_in[1], e->g_in[2], e->g_in[3] };
   for (void *q : ptrs) if (q) (void)mjh_guard_free(q);
   for (void *q : e->g_in_old) (void)mjh_guard_free(q);
+  if (e->ev_defer) (void)hipEventDestroy(e->ev_defer);
   if (e->h_defer) (void)hipHostFree(e->h_defer);
   for (int b = 0; b < 2; b++) {
     if (e->h_stage[b]) (void)hipHostFree(e->h_stage[b]);
@@ -759,7 +758,7 @@ static int make_views(mjh_encoder *e, int S)
     v->stream = v->side_stream = v->copy_stream = v->d2h_stream = nullptr;
     v->copy_done = v->ev_fork = v->ev_join = v->ev_side0 = v->ev_side1 = v->ev_view_done = v->ev_split_fork = v->ev_null_in = nullptr;
     for (int b = 0; b < 2; b++) { v->ev_h2d[b] = v->ev_pix_free[b] = v->ev_packed[b] = nullptr; v->d_pixb[b] = nullptr; v->h_stage[b] = v->h_res[b] = nullptr; v->h_tab[b] = nullptr; }
-    v->h_defer = nullptr;
+    v->h_defer = nullptr; v->ev_defer = nullptr; v->defer_pending = false;
     for (int c = 0; c < MJH_MAX_COMPS; c++) v->g_in[c] = nullptr;
     v->g_in_old.clear();
     v->prof_events.clear(); v->side_events.clear(); v->prof_names.clear(); v->prof_cnames.clear(); v->prof_ms.clear();
@@ -780,7 +779,6 @@ static int make_views(mjh_encoder *e, int S)
     HIPCHK(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&v->ev_view_done, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void **)&v->h_defer, 64, hipHostMallocDefault));
-    v->h_defer[0] = v->h_defer[3] = 0xFFFFFFFFu;
     // HIP multiplexes streams onto a handful of hardware queues (4 by default): with a main and a side stream per view, three
     // views already collide there and serialise falsely (measured: 2 views 5.81 ms, 3 views 6.67 ms per 64 4K frames).  From
     // three views on, a view keeps to ONE stream -- its DC trellis runs in line, the overlap comes from the other views
@@ -802,9 +800,6 @@ static int make_views(mjh_encoder *e, int S)
     if (v->d_qsums) v->d_qsums += off * 4 * 64 * 2;
     if (v->d_nzmask) v->d_nzmask += off * trb;
     if (v->d_nq8) v->d_nq8 += off * trb;
-    if (v->d_perm16) v->d_perm16 += off * trb;
-    if (v->d_rec) v->d_rec += off * trb;       // (every row of the records starts rec_stride further on: the view keeps the stride)
-    if (v->d_azd) v->d_azd += off * trb;
     if (v->d_dense) { v->d_dense += (size_t)k * dense_each * 64; v->dense_cap = dense_each; }
     v->d_len16 += off * tmb;
     v->d_off32 += off * tmb;
@@ -896,16 +891,6 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
                      (e->progressive ? !restart_scans : !(e->fuse_mask & 2));
     if (e->use_compact) HIPCHK_E(mjh_dmalloc((void **)&e->d_nzmask, B * (size_t)C.total_real_blocks * sizeof(unsigned long long)));
     if (e->use_compact && p->trellis_quant) HIPCHK_E(mjh_dmalloc((void **)&e->d_nq8, B * (size_t)C.total_real_blocks));
-    if (const char *sv = getenv("MJH_SORTED_UQ")) { e->sorted_uq = atoi(sv) != 0; if (atoi(sv) > 1) e->sorted_uq_min = (size_t)atoi(sv); }
-    if (const char *bv = getenv("MJH_SMALL_BATCH")) e->small_batch = (size_t)atol(bv);
-    if (const char *rv = getenv("MJH_TRELLIS_REC")) e->rec_mode = atoi(rv) != 0;
-    if (e->use_compact && p->trellis_quant && e->rec_mode) {
-      e->rec_stride = B * (size_t)C.total_real_blocks;
-      HIPCHK_E(mjh_dmalloc((void **)&e->d_rec, (size_t)mjh_encoder::REC_ROWS * e->rec_stride * sizeof(unsigned long long)));
-      HIPCHK_E(mjh_dmalloc((void **)&e->d_azd, e->rec_stride * sizeof(float)));
-    }
-    if (const char *tv = getenv("MJH_SORTED_TILE")) { const int t = atoi(tv); if (t == 128 || t == 256 || t == 512) e->sorted_tile = t; }
-    if (e->use_compact && p->trellis_quant && e->sorted_uq) HIPCHK_E(mjh_dmalloc((void **)&e->d_perm16, B * (size_t)C.total_real_blocks * sizeof(uint16_t)));
   }
   if (p->trellis_quant) {   // room for a quarter of all blocks (typically 1-2 % overflow); the rest would be read from the planes
     e->dense_cap = (unsigned)(B * (size_t)C.total_real_blocks / 4 + 1024);
@@ -923,7 +908,6 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   }
   if (const char *v = getenv("MJH_TRELLIS_VARIANT")) { e->trellis_variant = atoi(v); e->trellis_adapt = false; }
   HIPCHK_E(hipHostMalloc((void **)&e->h_defer, 64, hipHostMallocDefault));
-  e->h_defer[0] = e->h_defer[3] = 0xFFFFFFFFu;
   if (const char *v = getenv("MJH_FUSE")) e->fuse_mask = atoi(v);
   if (const char *v = getenv("MJH_TRELLIS_V3")) e->trellis_v3 = atoi(v);
   e->dc_window_ok = 1;
@@ -1404,45 +1388,29 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   const int nbands = p.trellis_quant ? e->nbands : 1;
   const bool fuse_pre = fuse_seq && (e->fuse_mask & 1) && !e->debug_taps && nbands == 1 && !ext_qopt;   // (q_opt: one component at a time, each from the stored planes)
   const bool fuse_fin = fuse_seq && (e->fuse_mask & 2) && nbands == 1 && !ext_eob;
-  // Tile-sorted coefficient planes: when the AC trellis will run its tile-sorted first tier with four passes per tile of 256
-  // blocks (a batch large enough to fill the chip), the FDCT kernel sorts every tile by the blocks' key itself and stores
-  // planes 1..63 of coef_uq in that order, so that a pass of the trellis reads ONE line of every plane instead of all four
-  // (the passes of a tile it sorted itself re-read every line, 4.6x the algorithmic bytes of the interval).  Debug taps expose
-  // coef_uq in natural order, so they keep the natural layout.
-  const bool sort_uq = compact && e->d_perm16 && e->d_nq8 && e->fastdiv_all && C.precision == 8 && !fuse_fin && e->trellis_v3 > 0 && e->trellis_variant <= 4 &&
-                       nbands == 1 && !ext_eob && !ext_qopt && !e->arith && !e->debug_taps && (size_t)n * C.total_real_blocks >= e->sorted_uq_min;
-  uint16_t *const perm16 = sort_uq ? e->d_perm16 : nullptr;
-  // Queue records from the FDCT kernel (opt-in): the FDCT kernel quantizes every coefficient anyway (for its fused statistics in
-  // the sequential configuration, for coef_q otherwise) -- it then also does phase 1 of the tile-sorted AC trellis (records, all-zero
-  // distortion, deferral of the blocks the first tier cannot take), and the trellis kernel starts from the records.  The
-  // capacity of the first tier has to be known in front of the FDCT kernel: the adaptive choice is made here, not at the trellis.
-  MjhRecOut rec_out;
-  const MjhRecOut *rec = nullptr;
-  auto adapt_first_tier = [&]() {
-    if (!(e->trellis_adapt && e->h_defer[0] != 0xFFFFFFFFu && e->h_defer[3] != 0xFFFFFFFFu)) return;
-    // (the rule of trellis_pass below, see there)
-    const double blocks = (double)e->h_defer[4] * (double)C.total_real_blocks + 1.0;
+  // The first tier's queue capacity of the AC trellis trades LDS occupancy (16 records: 15 waves per CU, 48: 5) against the
+  // share of blocks that have to be redone by the general big-capacity tier.  The first tier counts, whatever its own
+  // capacity, how many blocks of the batch have more than 16 / 24 / 32 records (count_heavy); the counts of an earlier
+  // batch (copied back asynchronously together with the number of frames they belong to, looked at only once the
+  // event behind the copy has completed, never waited for) give the capacity directly: the smallest one that leaves less
+  // than ~6 % of the blocks to the general tier.  The counts do not depend on the capacity in use, so a steady workload
+  // settles on ONE plan; a move down needs the share to fall to half the ceiling (a workload sitting on a ceiling does not
+  // alternate).  Every capacity gives the same bytes: this is a performance choice only.
+  auto adapt_first_tier = [&]() -> int {
+    if (!e->trellis_adapt || !e->defer_pending) return MJH_OK;
+    const hipError_t qs = hipEventQuery(e->ev_defer);
+    if (qs == hipErrorNotReady) { (void)hipGetLastError(); return MJH_OK; }
+    HIPCHK(qs);
+    e->defer_pending = false;
+    const double blocks = (double)e->defer_frames * (double)C.total_real_blocks + 1.0;
     const double s16 = e->h_defer[1] / blocks, s24 = e->h_defer[2] / blocks, s32 = e->h_defer[3] / blocks;
     const int cur = e->trellis_variant == 1 ? 2 : e->trellis_variant;
     auto level_for = [&](double slack) { return s16 < 0.06 * slack ? 0 : s24 < 0.06 * slack ? 2 : s32 < 0.10 * slack ? 3 : 4; };
     const int up = level_for(1.0), down = level_for(0.5);
     if (up > cur) e->trellis_variant = up;
     else if (down < cur) e->trellis_variant = down;
-    e->h_defer[0] = e->h_defer[3] = 0xFFFFFFFFu;
+    return MJH_OK;
   };
-  if (e->rec_mode && e->d_rec && !coef_src && compact && e->d_nq8 && e->fastdiv_all && C.precision == 8 && !fuse_fin && !(e->fuse_mask & 4) &&
-      e->trellis_v3 > 0 && nbands == 1 && !ext_eob && !ext_qopt && !e->arith && !e->debug_taps && p.trellis_quant && p.trellis_num_loops <= 1 && !sort_uq) {
-    adapt_first_tier();
-    if (e->trellis_variant <= 4) {
-      // (mjh_launch_trellis_ac: one pass per tile -- a small batch, or MJH_TRELLIS_V3=1 -- comes with 24 records)
-      const bool small = (size_t)n * C.total_real_blocks < e->small_batch || e->trellis_v3 == 1;
-      rec_out.records = e->d_rec; rec_out.row_stride = e->rec_stride; rec_out.azd = e->d_azd;
-      rec_out.worklist = e->d_worklist; rec_out.dense = (int16_t *)e->d_dense; rec_out.dense_cap = e->dense_cap;
-      rec_out.qn = e->trellis_variant >= 4 ? 48 : e->trellis_variant == 3 ? 32 : (small || e->trellis_variant > 0) ? 24 : 16;
-      rec = &rec_out;
-      mjh_launch_zero_counters(e->d_worklist, e->d_worklist2, s);
-    }
-  }
   if (ext_qopt) {
     // trellis_q_opt re-estimates d_quant per image during the encode: the FDCT and the conventional quantization of THIS
     // encode start from the parameters' tables again (the reference's tables of a new jpeg_start_compress), not from what
@@ -1453,7 +1421,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   }
   if (!coef_src) {
     pr.mark("dct_quant");
-    mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, e->d_nq8, n, s, e->fastdiv_all, perm16, e->sorted_tile, rec);
+    mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, e->d_nq8, n, s, e->fastdiv_all);
   }
 
   if (e->arith) {
@@ -1585,22 +1553,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
     }
     const bool extended = nbands > 1 || ext_eob || qstride != 0;
-    if (e->trellis_adapt && !extended && e->h_defer[0] != 0xFFFFFFFFu && e->h_defer[3] != 0xFFFFFFFFu) {
-      // The first tier's queue capacity trades LDS occupancy (16 records: 15 waves per CU, 48: 5) against the share of blocks
-      // that have to be redone by the general big-capacity tier.  The first tier counts, whatever its own capacity, how many
-      // blocks of the batch have more than 16 / 24 / 32 records (count_heavy); the last finished batch's counts (read back
-      // asynchronously, never waited for) give the capacity directly: the smallest one that leaves less than ~6 % of the
-      // blocks to the general tier.  The counts do not depend on the capacity in use, so a steady workload settles on ONE
-      // plan; a move down needs the share to fall to half the ceiling (a workload sitting on a ceiling does not alternate).
-      const double blocks = (double)e->h_defer[4] * (double)C.total_real_blocks + 1.0;
-      const double s16 = e->h_defer[1] / blocks, s24 = e->h_defer[2] / blocks, s32 = e->h_defer[3] / blocks;
-      const int cur = e->trellis_variant == 1 ? 2 : e->trellis_variant;
-      auto level_for = [&](double slack) { return s16 < 0.06 * slack ? 0 : s24 < 0.06 * slack ? 2 : s32 < 0.10 * slack ? 3 : 4; };
-      const int up = level_for(1.0), down = level_for(0.5);
-      if (up > cur) e->trellis_variant = up;
-      else if (down < cur) e->trellis_variant = down;
-      e->h_defer[0] = e->h_defer[3] = 0xFFFFFFFFu;
-    }
+    if (!extended) { const int rc = adapt_first_tier(); if (rc != MJH_OK) return rc; }
     pr.mark("trellis_ac");
     // the tile-sorted first tier (plain compact pass, 16-record capacity) can count the statistics of the final coefficients
     // in its back-track (MJH_FUSE bit 4): sequential mode, optimal tables, last round
@@ -1611,12 +1564,13 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
                           (v3_stats || (fuse_fin && p.optimize_coding && last_loop)) ? fin_ac : nullptr, e->trellis_variant,
                           Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, nzm, qstride, n, s,
                           e->d_nq8, v3 ? ((size_t)n * C.total_real_blocks < e->small_batch ? 1 : e->trellis_v3) : 0,   // (a small batch: one pass per tile -- four times the workgroups, a quarter of their length: latency matters more than the sorting)
-                          e->fastdiv_all, v3 ? perm16 : nullptr, e->sorted_tile, v3 ? rec : nullptr);
-    if (rec && !v3) return fail(MJH_EINVAL, "internal: queue records without the tile-sorted trellis");
-    if (perm16 && !v3) return fail(MJH_EINVAL, "internal: tile-sorted coefficient planes without the tile-sorted trellis");
-    if (e->trellis_adapt && !extended && first_pass) {
-      e->h_defer[4] = (unsigned)n;
+                          e->fastdiv_all);
+    if (e->trellis_adapt && !extended && first_pass && !e->defer_pending) {   // (one read-back in flight at a time; its frame count travels with it)
+      if (!e->ev_defer) HIPCHK(hipEventCreateWithFlags(&e->ev_defer, hipEventDisableTiming));
+      e->defer_frames = n;
       HIPCHK(hipMemcpyAsync(&e->h_defer[0], e->d_worklist, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipEventRecord(e->ev_defer, s));
+      e->defer_pending = true;
     }
     if (ext_eob) {   // jcdctmgr.c:1224-1297: end-of-band runs along every block row, with the band's AC rate table
       pr.mark("trellis_eob_runs");
@@ -1919,7 +1873,10 @@ class CopyPool {
 extern "C" void *mjh_host_alloc(size_t bytes)
 {
   void *p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); fail(MJH_ENOMEM, "hipHostMalloc(%zu) failed", bytes); return nullptr; }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  // (pinned on the NUMA node of the calling thread's current device: the frames are read by that device's DMA engines)
+  if (mjh_numa_host_alloc(&p, bytes ? bytes : 1, hipHostMallocDefault, dev) != hipSuccess) { (void)hipGetLastError(); fail(MJH_ENOMEM, "hipHostMalloc(%zu) failed", bytes); return nullptr; }
   return p;
 }
 extern "C" void mjh_host_free(void *p) { if (p) (void)hipHostFree(p); }
@@ -2019,7 +1976,7 @@ extern "C" int mjh_encode_host(mjh_encoder *e, const void *pixels, size_t row_pi
       else HIPCHK(hipMemcpy2DAsync(dst, row_bytes, src, row_pitch, row_bytes, (size_t)H, hipMemcpyHostToDevice, e->copy_stream));
     }
   } else {
-    if (!e->h_stage[b]) HIPCHK(hipHostMalloc((void **)&e->h_stage[b], (size_t)e->max_batch * e->pix_image_bytes, hipHostMallocDefault));
+    if (!e->h_stage[b]) HIPCHK(mjh_numa_host_alloc((void **)&e->h_stage[b], (size_t)e->max_batch * e->pix_image_bytes, hipHostMallocDefault, e->device));
     HIPCHK(hipEventSynchronize(e->ev_h2d[b]));   // the staging buffer's previous H2D copy (two calls ago)
     CopyPool &pool = CopyPool::get();
     const int parts = pool.threads() > 1 ? pool.threads() * 2 : 1;   // row bands per image
@@ -2097,7 +2054,7 @@ extern "C" int mjh_host_staging(mjh_encoder *e, void **buffer, size_t *bytes)
   int rc = host_buffers(e);
   if (rc) return rc;
   const int b = (int)(e->host_calls & 1u);   // the buffer the NEXT mjh_encode_host call uses
-  if (!e->h_stage[b]) HIPCHK(hipHostMalloc((void **)&e->h_stage[b], (size_t)e->max_batch * e->pix_image_bytes, hipHostMallocDefault));
+  if (!e->h_stage[b]) HIPCHK(mjh_numa_host_alloc((void **)&e->h_stage[b], (size_t)e->max_batch * e->pix_image_bytes, hipHostMallocDefault, e->device));
   HIPCHK(hipEventSynchronize(e->ev_h2d[b]));
   if (e->staged[b]) {
     // an image was abandoned after part of it had been committed (jpeg_abort_compress behind >= 256 scanlines): its queued
@@ -2215,7 +2172,7 @@ extern "C" int mjh_encode_coefficients_host(mjh_encoder *e, const void *const co
   HIPCHK(hipStreamSynchronize(e->stream));   // the staging buffers may still feed the previous batch
   if (!e->d_cfin) {
     HIPCHK(mjh_dmalloc((void **)&e->d_cfin, (size_t)e->max_batch * per_image));
-    HIPCHK(hipHostMalloc((void **)&e->h_cfin, (size_t)e->max_batch * per_image, hipHostMallocDefault));
+    HIPCHK(mjh_numa_host_alloc((void **)&e->h_cfin, (size_t)e->max_batch * per_image, hipHostMallocDefault, e->device));
   }
   for (int i = 0; i < n; i++) {
     for (int c = 0; c < e->C.ncomp; c++) {
@@ -2293,7 +2250,7 @@ extern "C" int mjh_encode_planes_host(mjh_encoder *e, const void *const planes[M
   HIPCHK(hipStreamSynchronize(e->stream));   // the staging buffers may still feed the previous batch
   if (!e->d_plin) {
     HIPCHK(mjh_dmalloc((void **)&e->d_plin, (size_t)e->max_batch * cap));
-    HIPCHK(hipHostMalloc((void **)&e->h_plin, (size_t)e->max_batch * cap, hipHostMallocDefault));
+    HIPCHK(mjh_numa_host_alloc((void **)&e->h_plin, (size_t)e->max_batch * cap, hipHostMallocDefault, e->device));
   }
   for (int i = 0; i < n; i++) {
     for (int c = 0; c < e->C.ncomp; c++) {

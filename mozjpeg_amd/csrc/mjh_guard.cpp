@@ -3,6 +3,7 @@
 // that the page next to it is a hole in the address space; a kernel that strays there dies with a memory access fault
 // whose address this file's table (MJH_GUARD_LOG) resolves to "N bytes past the end of <buffer>".
 #include "mjh_guard.h"
+#include "mjh_numa.h"
 
 #include <stdint.h>
 #include <stdio.h>
@@ -147,7 +148,11 @@ hipError_t mjh_guard_free(void *p)
 
 hipError_t mjh_guard_host_alloc(void **p, size_t bytes, unsigned flags, const char *name)
 {
-  if (mjh_guard_mode() == 0) return hipHostMalloc(p, bytes, flags);
+  if (mjh_guard_mode() == 0) {   // the product path: pinned on the NUMA node of the current device (mjh_numa.cpp)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return mjh_numa_host_alloc(p, bytes, flags, dev);
+  }
   Rec r;
   r.bytes = bytes; r.mode = 1; r.host = true;
   snprintf(r.name, sizeof(r.name), "%s", name ? name : "?");

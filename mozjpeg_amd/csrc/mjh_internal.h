@@ -173,15 +173,4 @@ struct MjhProgCtl {        // per image, lives in HBM
   unsigned scan_us[2][MJH_MAX_PROG_SCANS];     // introspection: duration of the statistics [0] / encode [1] workgroup of each scan, microseconds
 };
 
-// What k_dct_quant_rec (mjh_sorted.hip, opt-in: MJH_TRELLIS_REC=1) leaves for the tile-sorted AC trellis instead of planes 1..63 of
-// coef_uq: the blocks' queue records, row r = every block's r-th record (8 bytes: position | sign << 6 | quantized value << 7 |
-// |x| << 17, distortion of the zeros in front), the all-zero distortion per block, and the work list of the blocks the first tier
-// cannot take (filled there, so the list's counters are zeroed in front of the FDCT kernel).
-struct MjhRecOut {
-  unsigned long long *records; size_t row_stride;   // [rows][images x real blocks of all components]
-  float *azd;                                       // [images x real blocks]
-  unsigned *worklist; int16_t *dense; unsigned dense_cap;
-  int qn;                                           // queue capacity of the first tier that will read the records (<= rows)
-};
-
 #endif

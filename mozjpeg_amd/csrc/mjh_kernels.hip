@@ -36,7 +36,6 @@ static constexpr ZZTab make_zz() {
 }
 static constexpr ZZTab kZZ = make_zz();    // kZZ.v[k]  = natural index of zig-zag position k
 
-#ifndef MJH_TU_SORTED   // (mjh_sorted.hip includes this file for the shared device functions only)
 // =============================================================================================
 // K1  colour conversion + chroma downsampling + edge replication  
 //   rgb_ycc_convert jccolext.c:30-75 (tables jccolor.c:213-246), h2v2/h2v1/int_downsample
@@ -292,7 +291,6 @@ k_import_planes(MjhConst C, MjhPlaneSrc S, T *__restrict__ planes)
 #pragma unroll
   for (int j = 0; j < 4; j++) dst[j] = v[j];
 }
-#endif  // MJH_TU_SORTED
 // =============================================================================================
 // K2  convsamp + overshoot deringing + islow FDCT + quantize   (rows a4-a8)
 //   convsamp jcdctmgr.c:576, preprocess_deringing :416-498 (catmull_rom :387), jpeg_fdct_islow
@@ -355,45 +353,24 @@ __device__ __forceinline__ float catmull_rom(int v1, int v2, int v3, int v4, flo
 // FD: every quantizer step of the tables in use fits 8 bits -- the division by 8q is one shift + one 24-bit multiply-high
 // (MjhQuant.mdiv / sdiv) instead of the float-reciprocal division with its integer fix-up; with STATS the AC coefficients are
 // quantized for the statistics only, which need the magnitude category and nothing else (no sign, no signed clamp).
-// SORTED (8-bit samples feeding the tile-sorted AC trellis, k_trellis_ac_v3s): the workgroup has SORTED (2 / 4 / 8) waves = the
-// 64-block lines of one trellis tile, every lane still owns one block; the waves exchange only the blocks' sort keys
-// (min(non-zero quantized AC coefficients, 63)) through LDS and store planes 1..63 of coef_uq at the block's place in the
-// tile's descending-key order instead of its natural place, plus perm_out[tile_base + place] = index in tile | key << 9 (the
-// trellis kernel's own permutation entry).  A pass of the trellis kernel then reads ONE line of every plane, each line once
-// (unsorted planes: every pass touches all four lines of the tile).  Plane 0 (DC), lambda, nq8 and coef_q stay in natural order.
-// REC (k_dct_quant_rec, mjh_sorted.hip; 8-bit samples, FD, STATS, natural order): the kernel also does phase 1 of the
-// tile-sorted AC trellis -- it has every |x|, the comparison and the division for its own statistics already: the trellis'
-// queue records (position | sign | quantized value | |x|, distortion of the zeros in front) go to rec.records row by row (row r
-// = every block's r-th record), the all-zero distortion to rec.azd, blocks the first tier cannot take (more than rec.qn records,
-// a quantized magnitude >= 16) to the work list with their dense copy (and their raw planes, the general tiers' fallback);
-// planes 1..63 of coef_uq are not written for the others.  nq8 carries bit 7 for a deferred block.
-// (struct MjhRecOut: mjh_internal.h)
-__device__ __forceinline__ void defer_blocks(bool mine, unsigned *__restrict__ list, unsigned img, unsigned compblk, unsigned dense_slot_in,
-                                             const short (&xs)[64], int16_t *__restrict__ dense, unsigned dense_cap, bool make_copy, int lane,
-                                             unsigned compblk_nocopy);
-__device__ __forceinline__ void count_heavy(unsigned *__restrict__ list, bool inside, int nq, int lane);
-template <class T, bool STATS, bool FD, int SORTED = 0, bool REC = false>   // SORTED: waves per workgroup of the tile-sorted form (2 / 4 / 8 = tiles of 128 / 256 / 512 blocks), 0 = natural order; uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
+template <class T, bool STATS, bool FD>   // uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
 __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant *__restrict__ Q, const T *__restrict__ planes,
                                                int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
-                                               MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out,
-                                               uint16_t *__restrict__ perm_out = nullptr, const MjhRecOut *rec = nullptr)
+                                               MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out)
 {
   constexpr bool W12 = sizeof(T) == 2;
-  static_assert(!SORTED || !W12, "the tile-sorted layout feeds the (8-bit only) trellis");
-  static_assert(!REC || (FD && !W12 && !SORTED), "records come out of the 8-bit fast-division kernel, natural order");
   // 8 KB per wave: the deringing columns (the ORIGINAL level-shifted samples of the lane's block in zig-zag order, 16 bits
   // each for 8- and 12-bit data) and, afterwards, 8 interleaved copies of the 256-bin statistics histogram
   constexpr int LW = 32;
-  constexpr int NW = SORTED ? SORTED : 1;      // waves per workgroup
-  __shared__ int lds_raw[NW][64][LW];
+  __shared__ int lds_raw[64][LW];
   typedef short dcol_t;
   typedef dcol_t __attribute__((may_alias)) dcol_alias;
-  const int lane = SORTED ? (int)(threadIdx.x & 63) : (int)threadIdx.x, wv = SORTED ? (int)(threadIdx.x >> 6) : 0;   // (one wave per workgroup unless SORTED)
-  dcol_alias (*lds)[64] = reinterpret_cast<dcol_alias (*)[64]>(&lds_raw[wv][0][0]);
+  const int lane = (int)threadIdx.x;      // one wave per workgroup
+  dcol_alias (*lds)[64] = reinterpret_cast<dcol_alias (*)[64]>(&lds_raw[0][0]);
   const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
-  const int blk_raw = blockIdx.x * (64 * NW) + wv * 64 + lane;
-  if (blockIdx.x * (64 * NW) >= cc.nblk) return;       // whole workgroup outside (grid is sized for the largest component)
+  const int blk_raw = blockIdx.x * 64 + lane;
+  if (blockIdx.x * 64 >= cc.nblk) return;       // whole workgroup outside (grid is sized for the largest component)
   const bool valid = blk_raw < cc.nblk;                  // tail lanes redo the last block (identical stores), they only stay out of the statistics
   const int blk = valid ? blk_raw : cc.nblk - 1;
   const int br = blk / cc.wib, bc = blk - br * cc.wib;
@@ -494,7 +471,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
     // from the host libm.  Both trellis kernels consume it.
     float norm = 0.0f;
 #pragma unroll
-    for (int n = 1; n < 64; n++) norm = norm + ((REC || SORTED) ? squaref(d[n]) : (float)mul24(d[n], d[n]));   // |raw coefficient| <= 2^15
+    for (int n = 1; n < 64; n++) norm = norm + (float)mul24(d[n], d[n]);   // |raw coefficient| <= 2^15
     norm = (float)((double)norm / 63.0);
     float lambda;
     if (C.lambda_log_scale2 > 0.0f) lambda = (float)(C.pow_scale1 * 1.0 / (C.pow_scale2 + (double)norm));
@@ -509,18 +486,17 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
   constexpr bool stats = STATS;
   typedef unsigned __attribute__((may_alias)) hist_alias;
   constexpr int NCOPY = 8;
-  hist_alias *hist = reinterpret_cast<hist_alias *>(&lds_raw[wv][0][0]);   // NCOPY interleaved copies of 256 bins (the deringing columns are dead)
+  hist_alias *hist = reinterpret_cast<hist_alias *>(&lds_raw[0][0]);   // NCOPY interleaved copies of 256 bins (the deringing columns are dead)
   if (stats) {
     MJH_WAVE_SYNC();        // (the histogram lies over the other lanes' deringing columns, which they have all read by now)
 #pragma unroll
     for (int j = 0; j < NCOPY * 4; j++) hist[j * 64 + lane] = 0u;
     __syncthreads();
   }
-  hist_alias *hh = hist + (lane & (NCOPY - 1)) * 256;
+  // copy c of bin b lives at word b * NCOPY + c: the lanes that count the same symbol in different copies hit different banks
+  // (with copy-major storage every copy of a bin shares one bank: 3.9 conflict cycles per LDS instruction, profiles/r04e_pmc_sq)
+  hist_alias *hh = hist + (lane & (NCOPY - 1));
   int run = 0, nzc = 0;   // nzc: non-zero quantized AC coefficients = the AC trellis' queue length (its tile-sort key)
-  float azd = 0.0f;       // REC: distortion of the block with positions 1..k all zero (k_trellis_ac_v3's phase 1: same operations, same order)
-  int qmax = 0;
-  const size_t gblk_rec = (size_t)img * C.total_real_blocks + cc.blk_off + blk;
 #pragma unroll
   for (int k = 0; k < 64; k++) {
     const int x = d[kZZ.v[k]];
@@ -529,107 +505,37 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
     if (FD && STATS && k > 0) {
       // statistics of the conventionally quantized block only (the trellis recomputes the values): magnitude category of
       // min(floor((|x| + 4q) / 8q), 1023) -- the signed clamp to +-1023 (jcdctmgr.c:761-770) leaves the category of 1023
-      if (!SORTED && !REC) uq[(size_t)k * cc.kstride] = (int16_t)x;
-      float azd_cur = 0.0f;
-      if (REC) {
-        float t = squaref(ax) * lambda_blk;
-        t = t * Q->lambda_tbl[cc.qtbl][k];
-        azd_cur = t + azd;
-      }
+      uq[(size_t)k * cc.kstride] = (int16_t)x;
       if (valid) {
         if (ax + (dq >> 1) >= dq) {
           int qa = udiv_mh(ax + (dq >> 1), Q->sdiv[cc.qtbl][k], Q->mdiv[cc.qtbl][k]);
-          if (REC) {
-            const int qv = qa >= 1024 ? 1023 : qa;
-            qmax = qv > qmax ? qv : qmax;
-            // (a block with more than rec->qn records is deferred: its surplus records are not stored)
-            if (nzc < rec->qn)
-              reinterpret_cast<uint2 *>(rec->records)[(size_t)nzc * rec->row_stride + gblk_rec] = make_uint2((unsigned)k | (x < 0 ? 64u : 0u) | ((unsigned)qv << 7) | ((unsigned)ax << 17), __float_as_uint(azd));
-          }
           if (clampq) qa = min(qa, 1023);
           nzc++;
-          if (run > 15) { atomicAdd(&hh[0xF0], (unsigned)(run >> 4)); run &= 15; }
-          atomicAdd(&hh[(run << 4) + bitlen((unsigned)qa)], 1u);
+          if (run > 15) { atomicAdd(&hh[0xF0 * NCOPY], (unsigned)(run >> 4)); run &= 15; }
+          atomicAdd(&hh[((run << 4) + bitlen((unsigned)qa)) * NCOPY], 1u);
           run = 0;
         } else run++;
       }
-      if (REC) azd = azd_cur;
       continue;
     }
     int v = FD ? udiv_mh(ax + (dq >> 1), Q->sdiv[cc.qtbl][k], Q->mdiv[cc.qtbl][k]) : udiv_exact(ax + (dq >> 1), dq, rcp[k]);
-    if (REC && k > 0) {     // (the kernel without fused statistics: the same records from the division it does for every coefficient)
-      float t = squaref(ax) * lambda_blk;
-      t = t * Q->lambda_tbl[cc.qtbl][k];
-      const float azd_cur = t + azd;
-      if (valid && v != 0) {
-        const int qv = v >= 1024 ? 1023 : v;
-        qmax = qv > qmax ? qv : qmax;
-        if (nzc < rec->qn)
-          reinterpret_cast<uint2 *>(rec->records)[(size_t)nzc * rec->row_stride + gblk_rec] = make_uint2((unsigned)k | (x < 0 ? 64u : 0u) | ((unsigned)qv << 7) | ((unsigned)ax << 17), __float_as_uint(azd));
-      }
-      azd = azd_cur;
-    }
     if (x < 0) v = -v;
     if (clampq) v = W12 ? max(-16383, min(16383, v)) : max(-1023, min(1023, v));
-    if (!W12 && (k == 0 || (!SORTED && !REC))) uq[(size_t)k * cc.kstride] = (int16_t)x;   // raw x8 coefficients only feed the (8-bit only) trellis
+    if (!W12) uq[(size_t)k * cc.kstride] = (int16_t)x;   // raw x8 coefficients only feed the (8-bit only) trellis
     if (k == 0 || !STATS) qo[(size_t)k * cc.kstride] = (int16_t)v;   // STATS: the AC planes would never be read
     if (!stats && !W12 && k > 0) nzc += (v != 0);
     if (stats && k > 0 && valid) {
       if (v == 0) run++;
       else {
         nzc++;
-        if (run > 15) { atomicAdd(&hh[0xF0], (unsigned)(run >> 4)); run &= 15; }
+        if (run > 15) { atomicAdd(&hh[0xF0 * NCOPY], (unsigned)(run >> 4)); run &= 15; }
         const int nb = bitlen((unsigned)(v < 0 ? -v : v));
-        atomicAdd(&hh[(run << 4) + nb], 1u);
+        atomicAdd(&hh[((run << 4) + nb) * NCOPY], 1u);
         run = 0;
       }
     }
   }
-  if (REC) {
-    const bool def = valid && (nzc > rec->qn || qmax >= 16);
-    rec->azd[gblk_rec] = azd;      // (tail lanes: the last block's own value once more)
-    short xs[64];
-#pragma unroll
-    for (int k = 0; k < 64; k++) xs[k] = (short)d[kZZ.v[k]];
-    defer_blocks(def, rec->worklist, (unsigned)img, ((unsigned)comp << 28) | (unsigned)blk, 0u, xs, rec->dense, rec->dense_cap, true, lane, 0xFFFFFFFFu);
-    count_heavy(rec->worklist, valid, nzc, lane);
-    if (def) {      // the general tiers read the planes when the list has outgrown the dense copies
-#pragma unroll
-      for (int k = 1; k < 64; k++) uq[(size_t)k * cc.kstride] = xs[k];
-    }
-    if (nq8_out && valid) nq8_out[gblk_rec] = (uint8_t)(def ? (0x80 | (nzc > 63 ? 63 : nzc)) : nzc);
-  } else
   if (!W12 && nq8_out && valid) nq8_out[(size_t)img * C.total_real_blocks + cc.blk_off + blk] = (uint8_t)nzc;
-  if (SORTED) {
-    // counting sort of the tile's real blocks by descending key, as k_trellis_ac_v3's own prelude does it (equal keys in
-    // arrival order: the result does not depend on it); blocks behind the component's last one take no place
-    __shared__ unsigned s_sort[64];
-    const int tid = (int)threadIdx.x;
-    if (tid < 64) s_sort[tid] = 0u;
-    __syncthreads();
-    const unsigned key = (unsigned)(nzc > 63 ? 63 : nzc);
-    unsigned rank = 0u;
-    if (valid) rank = atomicAdd(&s_sort[key], 1u);
-    __syncthreads();
-    if (tid < 64) {                               // lane L: blocks with key 63-L; blocks with a larger key come first
-      const unsigned h = s_sort[63 - tid];
-      unsigned inc = h;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const unsigned nn = __shfl_up(inc, o, 64);
-        if (tid >= o) inc += nn;
-      }
-      s_sort[63 - tid] = inc - h;
-    }
-    __syncthreads();
-    if (valid) {
-      const unsigned place = s_sort[key] + rank;
-      int16_t *us = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + (size_t)blockIdx.x * (64 * NW) + place;
-#pragma unroll
-      for (int k = 1; k < 64; k++) us[(size_t)k * cc.kstride] = (int16_t)d[kZZ.v[k]];
-      perm_out[(size_t)img * C.total_real_blocks + cc.blk_off + (size_t)blockIdx.x * (64 * NW) + place] = (uint16_t)((unsigned)(wv * 64 + lane) | (key << 9));
-    }
-  }
   if (stats) {
     if (valid && run > 0) atomicAdd(&hh[0], 1u);
     __syncthreads();
@@ -640,7 +546,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
       const int bin = lane + 64 * j;
       unsigned sum = 0;
 #pragma unroll
-      for (int c2 = 0; c2 < NCOPY; c2++) sum += hist[c2 * 256 + bin];
+      for (int c2 = 0; c2 < NCOPY; c2++) sum += hist[bin * NCOPY + c2];
       if (sum) atomicAdd(&T2->counts[bin], sum);
     }
   }
@@ -655,7 +561,6 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
   dct_quant_body<T, STATS, FD>(C, Q, planes, coef_uq, coef_q, lambda_out, stat_tabs, slots_per_image, stat_slot_of_comp, nq8_out);
 }
 
-#ifndef MJH_TU_SORTED   // (mjh_sorted.hip includes this file for the shared device functions only)
 // =============================================================================================
 // K2b  coefficient import: jpeg_write_coefficients jctrans.c:44 entropy-codes blocks the
 // caller already has (jpegtran, "jpegrescan").  The caller's arrays are block-major, natural order
@@ -740,7 +645,7 @@ __global__ void __launch_bounds__(256)
 k_stats_ac_compact(MjhConst C, const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask, MjhHuffTable *__restrict__ tabs,
                    int slots_per_image, int4 slot_of_comp, int count_dummies, const uint8_t *__restrict__ only)
 {
-  __shared__ unsigned h[16][256];   // 16 interleaved copies: the common symbols would otherwise serialise the LDS atomics
+  __shared__ unsigned h[256][16];   // 16 copies of every bin side by side (copy c of bin b in bank (16 b + c) mod 32): the common symbols would otherwise serialise the LDS atomics, and copy-major storage would put all copies of a bin in one bank
   const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
   const int tid = threadIdx.x;
@@ -767,13 +672,13 @@ k_stats_ac_compact(MjhConst C, const int16_t *__restrict__ coef_q, const unsigne
     const int b = blk < cc.nblk ? blk : cc.nblk - 1;
     const int16_t *q = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + b;
     const unsigned long long m = in ? nzmask[(size_t)img * C.total_real_blocks + cc.blk_off + b] : 0ull;
-    unsigned *hh = h[tid & 15];
+    unsigned *hh = &h[0][tid & 15];
     int prev = 0;
     for_each_nonzero(q, (size_t)cc.kstride, m, in, [&](int pos, int v) {
       int r = pos - prev - 1;
       prev = pos;
-      if (r > 15) { atomicAdd(&hh[0xF0], (unsigned)(r >> 4)); r &= 15; }
-      atomicAdd(&hh[(r << 4) + bitlen((unsigned)(v < 0 ? -v : v))], 1u);
+      if (r > 15) { atomicAdd(&hh[0xF0 * 16], (unsigned)(r >> 4)); r &= 15; }
+      atomicAdd(&hh[((r << 4) + bitlen((unsigned)(v < 0 ? -v : v))) * 16], 1u);
     });
     if (in && prev < 63) atomicAdd(&hh[0], 1u);
   }
@@ -782,7 +687,7 @@ k_stats_ac_compact(MjhConst C, const int16_t *__restrict__ coef_q, const unsigne
   MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
   unsigned s = 0;
 #pragma unroll
-  for (int c2 = 0; c2 < 16; c2++) s += h[c2][tid];
+  for (int c2 = 0; c2 < 16; c2++) s += h[tid][c2];
   if (count_dummies && tid == 0 && blockIdx.x == 0)
     s += (unsigned)(cc.wpad * cc.hpad - cc.nblk);  // every dummy block codes one EOB (all-zero AC)
   if (s) atomicAdd(&T->counts[tid], s);
@@ -1114,7 +1019,6 @@ k_gen_tables_list(MjhHuffTable *__restrict__ tabs, int slots_per_image, const in
   gen_table_body(tabs + (size_t)blockIdx.y * slots_per_image + slot_list[blockIdx.x], threadIdx.x);
 }
 
-#endif  // MJH_TU_SORTED
 // =============================================================================================
 // K5  AC trellis quantization (row a9): quantize_trellis jcdctmgr.c:1120-1222 (+ norm/lambda
 // :1011-1037).  One lane = one block.  The rate-distortion DP only ever looks back at
@@ -1350,14 +1254,17 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
   int nlive = 1;
   float2 n0 = make_float2(0.0f, 0.0f), n1 = n0;
   int qi = 0;
-  bool need = true, done = nq == 0;
+  bool done = nq == 0;
   int i = 0, x = 0, dq = 1, qval = 0, ncd = 0, sgn = 0, e = 0, bestp = -1, bestk = 0;
   float lti = 0.0f, azd_prev = 0.0f, azd_cur = 0.0f, best = 1e38f;
   unsigned long long m = 0ull;
   bool first = true;
   uint2 rec_n = col[0][lane];
+  // one ROUND per queue record, as in k_trellis_ac_v3: every working lane sets its record up, the wave scans (pair steps)
+  // until the last lane's scan has ended, every working lane commits -- each part runs with all of the round's lanes instead
+  // of a handful per iteration (tools/model_sched.py).  The same operations per lane in the same order.
   while (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
-    if (need && !done) {
+    if (!done) {
       const uint2 rec = rec_n;
       qi++;
       rec_n = col[qi < QN ? qi : QN - 1][lane];          // unconsumed slots are never overwritten (entry e lives in slot e-1 <= qi-1)
@@ -1370,31 +1277,34 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
       azd_cur = t + azd_prev;
       ncd = bitlen((unsigned)qval);
       best = 1e38f; bestp = -1; bestk = 0;
-      m = live; e = nlive; first = true; need = false;
+      m = live; e = nlive; first = true;
+    }
+    const bool any2 = __builtin_amdgcn_ballot_w64(!done && ncd > 1) != 0ull, any4 = __builtin_amdgcn_ballot_w64(!done && ncd > 2) != 0ull;
+    bool scan = !done;
+    while (__builtin_amdgcn_ballot_w64(scan) != 0ull) {
+      if (scan) {
+        bool fin = false;
+        if (!any2)
+          q_pair_step<1, LDS_ROWS>(si_rows, rate_rows, col, lane, m, e, first, n0, n1, azd_prev, i, x, dq, qval, ncd, lambda, lti, si_f0, f0f, best, bestp, bestk, fin);
+        else if (!any4)
+          q_pair_step<2, LDS_ROWS>(si_rows, rate_rows, col, lane, m, e, first, n0, n1, azd_prev, i, x, dq, qval, ncd, lambda, lti, si_f0, f0f, best, bestp, bestk, fin);
+        else
+          q_pair_step<4, LDS_ROWS>(si_rows, rate_rows, col, lane, m, e, first, n0, n1, azd_prev, i, x, dq, qval, ncd, lambda, lti, si_f0, f0f, best, bestp, bestk, fin);
+        if (fin) scan = false;
+      }
     }
     if (!done) {
-      MJH_DIVERGENT_SCOPE;
-      bool fin = false;
-      if (__builtin_amdgcn_ballot_w64(ncd > 1) == 0ull)
-        q_pair_step<1, LDS_ROWS>(si_rows, rate_rows, col, lane, m, e, first, n0, n1, azd_prev, i, x, dq, qval, ncd, lambda, lti, si_f0, f0f, best, bestp, bestk, fin);
-      else if (__builtin_amdgcn_ballot_w64(ncd > 2) == 0ull)
-        q_pair_step<2, LDS_ROWS>(si_rows, rate_rows, col, lane, m, e, first, n0, n1, azd_prev, i, x, dq, qval, ncd, lambda, lti, si_f0, f0f, best, bestp, bestk, fin);
-      else
-        q_pair_step<4, LDS_ROWS>(si_rows, rate_rows, col, lane, m, e, first, n0, n1, azd_prev, i, x, dq, qval, ncd, lambda, lti, si_f0, f0f, best, bestp, bestk, fin);
-      if (fin) {
-        if (bestp >= 0) {
-          const int mag = (bestk < ncd - 1) ? (2 << bestk) - 1 : qval;
-          n1 = n0;
-          n0 = make_float2(azd_cur, best);
-          col[nlive - 1][lane] = make_uint2(__float_as_uint(azd_cur), __float_as_uint(best));   // live entry nlive
-          e_pk[nlive][lane] = (unsigned short)(bestp | (mag << 6));
-          live |= 1ull << i;
-          if (sgn) neg |= 1ull << i;
-          nlive++;
-        }
-        need = true;
-        done = qi >= nq;
+      if (bestp >= 0) {
+        const int mag = (bestk < ncd - 1) ? (2 << bestk) - 1 : qval;
+        n1 = n0;
+        n0 = make_float2(azd_cur, best);
+        col[nlive - 1][lane] = make_uint2(__float_as_uint(azd_cur), __float_as_uint(best));   // live entry nlive
+        e_pk[nlive][lane] = (unsigned short)(bestp | (mag << 6));
+        live |= 1ull << i;
+        if (sgn) neg |= 1ull << i;
+        nlive++;
       }
+      done = qi >= nq;
     }
   }
   const bool work = active && !over_q;
@@ -1540,7 +1450,6 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
   }
 }
 
-#ifndef MJH_TU_SORTED   // (mjh_sorted.hip includes this file for the shared device functions only)
 // =============================================================================================
 // trellis_eob_opt: jcdctmgr.c:1224-1297.  After the per-block DP of a band the reference walks
 // every block row once more: the cheapest way to reach block bi through runs of blocks whose band is all zero (coded as
@@ -1785,13 +1694,9 @@ __global__ void k_zero_counters(unsigned *__restrict__ a, unsigned *__restrict__
   if (threadIdx.x < 4) { a[threadIdx.x] = 0; b[threadIdx.x] = 0; }
 }
 
-#endif  // MJH_TU_SORTED
 // work-list entries: 3 words per deferred block at [4 + 3i]: image, component << 28 | block, slot of its dense copy
-// compblk_nocopy: the entry of a block that got no dense copy (the list outgrew the dense array) -- the tile-sorted planes
-// name such a block by its PLACE in them (bit 27 set; k_trellis_ac_qd finds the block through the tile's permutation)
 __device__ __forceinline__ void defer_blocks(bool mine, unsigned *__restrict__ list, unsigned img, unsigned compblk, unsigned dense_slot_in,
-                                             const short (&xs)[64], int16_t *__restrict__ dense, unsigned dense_cap, bool make_copy, int lane,
-                                             unsigned compblk_nocopy = 0xFFFFFFFFu)
+                                             const short (&xs)[64], int16_t *__restrict__ dense, unsigned dense_cap, bool make_copy, int lane)
 {
   const unsigned long long over = __ballot(mine);
   if (over == 0ull) return;
@@ -1801,7 +1706,7 @@ __device__ __forceinline__ void defer_blocks(bool mine, unsigned *__restrict__ l
   if (!mine) return;
   const unsigned idx = base + (unsigned)__popcll(over & ((1ull << lane) - 1ull));
   list[4 + 3 * (size_t)idx] = img;
-  list[5 + 3 * (size_t)idx] = (make_copy && idx >= dense_cap && compblk_nocopy != 0xFFFFFFFFu) ? compblk_nocopy : compblk;
+  list[5 + 3 * (size_t)idx] = compblk;
   list[6 + 3 * (size_t)idx] = make_copy ? idx : dense_slot_in;
   if (make_copy && idx < dense_cap) {
     // the raw coefficients are still in registers: one 128-byte line per block for the next kernel, instead of 63
@@ -1925,10 +1830,64 @@ k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
                 unsigned *__restrict__ worklist_next, const int16_t *__restrict__ dense, unsigned dense_cap,
                 MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp, MjhTrellisExt ext)
 {
-  constexpr bool PERM = false;
-  constexpr int perm_tile = 256;
-  const uint16_t *const perm16 = nullptr;
-#include "mjh_trellis_qd.inc"
+  __shared__ uint2 col[QN2][64];
+  __shared__ unsigned short e_pk[QN2 + 1][64];
+  __shared__ int dqT[4][64];
+  __shared__ float ltT[4][64];
+  const int lane = threadIdx.x;
+#pragma unroll
+  for (int t = 0; t < 4; t++) { dqT[t][lane] = Q->dq8[t][lane]; ltT[t][lane] = Q->lambda_tbl[t][lane]; }
+  __syncthreads();
+  const unsigned count = worklist[0];
+  for (unsigned base = blockIdx.x * 64; base < count; base += gridDim.x * 64) {   // wave-uniform trip count
+    const unsigned it = base + lane;
+    const bool active = it < count;
+    const unsigned ii = active ? it : count - 1;
+    const int img = (int)worklist[4 + 3 * (size_t)ii];
+    const unsigned w = worklist[5 + 3 * (size_t)ii];
+    const unsigned ds = worklist[6 + 3 * (size_t)ii];
+    const int comp = (int)(w >> 28);
+    const MjhComp cc = C.c[comp];
+    const int blk = (int)(w & 0x0FFFFFFFu);
+    const int slot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
+    const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+    const float lambda = lambda_in[(size_t)img * C.total_real_blocks + cc.blk_off + blk];
+    int nq;
+    float azd63;
+    {
+      short xs[64];
+      if (ds < dense_cap) {
+        const uint4 *d = reinterpret_cast<const uint4 *>(dense + (size_t)ds * 64);
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+          const uint4 q4 = d[v];
+          const unsigned ww[4] = { q4.x, q4.y, q4.z, q4.w };
+#pragma unroll
+          for (int j = 0; j < 4; j++) { xs[8 * v + 2 * j] = (short)(ww[j] & 0xFFFFu); xs[8 * v + 2 * j + 1] = (short)(ww[j] >> 16); }
+        }
+      } else {
+        const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+#pragma unroll
+        for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
+      }
+      if (EXT && ext.qstride) {
+        const MjhQuant *Qi = Q + (size_t)img * ext.qstride;   // per-lane image: vector loads of its own rows
+        nq = trellis_q_phase1<QN2, EXT>(xs, Qi->dq8[cc.qtbl], Qi->rcp8q[cc.qtbl], Qi->lambda_tbl[cc.qtbl], lambda, col, lane, azd63, ext.Ss, ext.Se);
+      } else
+      nq = trellis_q_phase1<QN2, EXT>(xs, dqT[cc.qtbl], Q->rcp8q[cc.qtbl], ltT[cc.qtbl], lambda, col, lane, azd63, ext.Ss, ext.Se);
+      if (QN2 < 63) defer_blocks(active && nq > QN2, worklist_next, (unsigned)img, w, ds, xs, nullptr, 0u, false, lane);
+    }
+    int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+    const int sslot = comp == 0 ? stat_slot_of_comp.x : comp == 1 ? stat_slot_of_comp.y : comp == 2 ? stat_slot_of_comp.z : stat_slot_of_comp.w;
+    unsigned *cnt = FSTATS ? stat_tabs[(size_t)img * slots_per_image + sslot].counts : nullptr;
+    const size_t gblk = (size_t)img * C.total_real_blocks + cc.blk_off + blk;
+    trellis_q_walk<QN2, false, FSTATS ? 2 : 0, EXT, COMPACT>(reinterpret_cast<const uint4 *>(T->ehufsi), nullptr, dqT, ltT, cc.qtbl, nq, azd63, lambda, active, qo, cc.kstride,
+                                                              col, e_pk, lane, cnt, ext.Ss, ext.Se, EXT && ext.eob_cost ? ext.eob_cost + gblk : nullptr,
+                                                              EXT && ext.eob_cost ? ext.eob_has + gblk : nullptr, COMPACT ? ext.nzmask + gblk : nullptr,
+                                                              EXT && ext.qstride ? (Q + (size_t)img * ext.qstride)->dq8[cc.qtbl] : nullptr,
+                                                              EXT && ext.qstride ? (Q + (size_t)img * ext.qstride)->lambda_tbl[cc.qtbl] : nullptr);
+    __syncthreads();   // the LDS columns are reused by the next round
+  }
 }
 
 // =============================================================================================
@@ -2009,8 +1968,6 @@ __device__ __forceinline__ void v3_pair(const uint2 (*col)[64], const unsigned s
 // symbol (run p-pp-1, category of its magnitude) -- so they are counted here (LDS histogram, flushed once per tile) instead
 // of by one more pass over the compact records; deferred blocks are flagged (nq8 = 0xFF) for k_stats_ac_compact's
 // deferred-only form.
-// SORTED: planes 1..63 of coef_uq hold every tile's blocks in descending-key order already and perm16 holds the tile's
-// permutation (k_dct_quant_sorted): no sort here, pass p reads line p of every plane.
 template <int QN, int NPASS, bool FD, bool FST>
 __global__ void __launch_bounds__(64)
 k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q,
@@ -2019,13 +1976,256 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
                 int16_t *__restrict__ dense, unsigned dense_cap, unsigned long long *__restrict__ nzmask,
                 MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp)
 {
-  constexpr bool SORTED = false, RECORDS = false;
-  const uint16_t *const perm16 = nullptr;
-  const uint2 *const rec_in = nullptr; const float *const azd_in = nullptr; constexpr size_t rec_stride = 0;
-#include "mjh_trellis_v3.inc"
+  static_assert(QN >= 16 && QN <= 63 && NPASS >= 1 && NPASS <= 8, "queue capacity / passes");
+  constexpr int TILE = 64 * NPASS;
+  __shared__ unsigned fhist[FST ? 2 : 1][FST ? 256 : 1];   // FST: two interleaved copies of the symbol histogram of this tile
+  __shared__ uint2 col[QN][64];          // tile sort scratch; per pass: queue records -> live entries {azd, acc} -> value column
+  __shared__ unsigned short info[QN][64];   // live entry e (>= 1) at [e-1]: position | back entry << 6 | magnitude (< 16) << 12 (the signs: one bit per position in a register)
+  __shared__ float4 rate_rows[16];
+  typedef unsigned __attribute__((may_alias)) u_alias;
+  typedef unsigned short __attribute__((may_alias)) us_alias;
+  const int img = blockIdx.y, tl = blockIdx.x, lane = threadIdx.x;
+  const int comp = tl >= tile0_of_comp.w ? 3 : tl >= tile0_of_comp.z ? 2 : tl >= tile0_of_comp.y ? 1 : 0;
+  const int t0 = comp == 0 ? 0 : comp == 1 ? tile0_of_comp.y : comp == 2 ? tile0_of_comp.z : tile0_of_comp.w;
+  const MjhComp cc = C.c[comp];
+  const int tile_base = (tl - t0) * TILE;
+  const int slot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
+  const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
+  const size_t gblk0 = (size_t)img * C.total_real_blocks + cc.blk_off;
+  if (lane < 16) rate_rows[lane] = rate_row(reinterpret_cast<const uint4 *>(T->ehufsi)[lane]);
+  const int si_f0 = (int)T->ehufsi[0xF0], si_eob = (int)T->ehufsi[0];
+  const float f0f = si_f0 ? (float)si_f0 : 3e38f, eobf = (float)si_eob;
+  const int dq_lane = Q->dq8[cc.qtbl][lane];                    // lane k holds the row entry of position k (ds_bpermute lookups)
+  const float lt_lane = Q->lambda_tbl[cc.qtbl][lane];
+
+  if (FST) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) (&fhist[0][0])[j * 64 + lane] = 0u;
+  }
+  // ---- tile sort: descending key; perm entry = index in tile | key << 9 ----
+  unsigned long long mine0 = 0ull, mine1 = 0ull;
+  {
+    u_alias *hist = reinterpret_cast<u_alias *>(&col[0][0]);              // [64]
+    us_alias *perm = reinterpret_cast<us_alias *>(&col[0][0]) + 128;      // [TILE], behind the histogram
+    hist[lane] = 0u;
+    __syncthreads();
+    unsigned key[NPASS], rank[NPASS];
+#pragma unroll
+    for (int j = 0; j < NPASS; j++) {
+      const int b = tile_base + j * 64 + lane;
+      unsigned k = b < cc.nblk ? (unsigned)nq8[gblk0 + b] : 0u;
+      key[j] = k > 63u ? 63u : k;
+      rank[j] = atomicAdd(&hist[key[j]], 1u);
+    }
+    __syncthreads();
+    const unsigned h = hist[63 - lane];     // lane L: blocks with key 63-L; blocks with a larger key come first
+    unsigned inc = h;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned n = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += n;
+    }
+    __syncthreads();
+    hist[63 - lane] = inc - h;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NPASS; j++) perm[hist[key[j]] + rank[j]] = (unsigned short)((unsigned)(j * 64 + lane) | (key[j] << 9));
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NPASS; j++) {
+      const unsigned long long v = perm[j * 64 + lane];
+      if (j < 4) mine0 |= v << (16 * j); else mine1 |= v << (16 * (j - 4));
+    }
+    __syncthreads();
+  }
+
+  us_alias *colh = reinterpret_cast<us_alias *>(&col[0][0]);   // value of slot s: row s>>2, half-word s&3 of the lane's uint2
+#pragma unroll 1
+  for (int pass = 0; pass < NPASS; pass++) {
+    const unsigned pe = (unsigned)(((pass < 4 ? mine0 : mine1) >> (16 * (pass & 3))) & 0xFFFFull);
+    const int blk = tile_base + (int)(pe & 511u);
+    const bool inside = blk < cc.nblk;
+    const size_t gblk = gblk0 + (inside ? blk : 0);
+    if (__builtin_amdgcn_ballot_w64(inside && (pe >> 9) != 0u) == 0ull) {   // nothing quantizes to non-zero: all-zero blocks
+      if (inside) nzmask[gblk] = 0ull;
+      if (FST && inside) atomicAdd(&fhist[lane & 1][0], 1u);                  // every one of them codes an EOB
+      continue;
+    }
+    const float lambda = lambda_in[gblk0 + (inside ? blk : cc.nblk - 1)];
+    int nq = 0, qmax = 0;
+    float azd63;
+    {
+      const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + (inside ? blk : cc.nblk - 1);
+      short xs[64];
+#pragma unroll
+      for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
+      const int *dq8 = Q->dq8[cc.qtbl];
+      const float *rcp = Q->rcp8q[cc.qtbl], *lt = Q->lambda_tbl[cc.qtbl];
+      float azd = 0.0f;
+#pragma unroll
+      for (int k = 1; k < 64; k++) {
+        const int xsg = xs[k];
+        const int x = xsg < 0 ? -xsg : xsg;
+        const int dq = dq8[k];
+        float t = (float)mul24(x, x) * lambda;
+        t = t * lt[k];
+        const float azd_cur = t + azd;
+        if (x + (dq >> 1) >= dq) {
+          int qval = FD ? udiv_mh(x + (dq >> 1), Q->sdiv[cc.qtbl][k], Q->mdiv[cc.qtbl][k]) : udiv_exact(x + (dq >> 1), dq, rcp[k]);
+          if (qval >= 1024) qval = 1023;
+          qmax = qval > qmax ? qval : qmax;
+          // (a block with more than QN records is deferred: what its surplus records overwrite in the last slot is never read)
+          col[nq < QN ? nq : QN - 1][lane] = make_uint2((unsigned)k | (xsg < 0 ? 64u : 0u) | ((unsigned)qval << 7) | ((unsigned)x << 17), __float_as_uint(azd));
+          nq++;
+        }
+        azd = azd_cur;
+      }
+      azd63 = azd;
+      defer_blocks(inside && (nq > QN || qmax >= 16), worklist, (unsigned)img, ((unsigned)comp << 28) | (unsigned)blk, 0u, xs, dense, dense_cap, true, lane);
+      count_heavy(worklist, inside, nq, lane);
+    }
+    const bool work = inside && nq <= QN && qmax < 16;
+    if (FST && inside && !work) nq8[gblk] = 0xFFu;     // deferred: its statistics are counted from its records (k_stats_ac_compact, deferred-only form)
+
+    // ---- the walk: every lane consumes its own records, one record per round; the next record is always one load ahead ----
+    int nlive = 1, qi = 0, last = 0;
+    unsigned long long neg = 0ull;          // positions whose coefficient is negative (of the entries created so far)
+    bool act = work && nq > 0;
+    int i = 0, x = 0, qval = 0, ncd = 0, sgn = 0, e = 0, beste = -1, bestk = 0;
+    float azd_prev = 0.0f, azd_cur = 0.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f, best = 1e38f;
+    float end_best = azd63 + eobf;
+    uint2 rec_n = col[0][lane];
+    // quantizer constants of the NEXT record's position: lane k holds entry k of the component's rows, fetched with ds_bpermute
+    // at a point where every lane of the wave is enabled (a disabled source lane would read as 0)
+    int dq_n = 1;
+    float lt_n = 0.0f;
+    auto lookup = [&]() {
+      const int a = (int)(rec_n.x & 63u) << 2;
+      dq_n = __builtin_amdgcn_ds_bpermute(a, dq_lane) & 0x3FFFF;      // 8q <= 8 * 32767: tells the compiler the 24-bit multiplies are exact
+      lt_n = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(lt_lane)));
+    };
+    lookup();
+    auto setup = [&]() {
+      const uint2 rec = rec_n;
+      qi++;
+      rec_n = col[qi < QN ? qi : QN - 1][lane];      // (slots behind the consumed ones are never overwritten: entry e lives in slot e-1 <= qi-1)
+      i = (int)(rec.x & 63u); sgn = (int)((rec.x >> 6) & 1u); qval = (int)((rec.x >> 7) & 1023u); x = (int)(rec.x >> 17);
+      azd_prev = __uint_as_float(rec.y);
+      const int dq = dq_n;
+      const float lti = lt_n;
+      float t = (float)mul24(x, x) * lambda;
+      t = t * lti;
+      azd_cur = t + azd_prev;
+      ncd = bitlen((unsigned)qval);
+      float dd[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
+        const int delta = mul24(cand, dq) - x;
+        const float d = (float)mul24(delta, delta) * lambda;      // (|delta| <= x < 2^15)
+        dd[k] = k < ncd ? d * lti : 3e38f;
+      }
+      d0 = dd[0]; d1 = dd[1]; d2 = dd[2]; d3 = dd[3];
+      e = nlive; best = 1e38f; beste = -1; bestk = 0;
+    };
+    if (act) setup();
+    // One ROUND per queue record.  A round is the scan of the lane's live entries for its current record (pair steps, run
+    // until the last lane's scan has ended) and then, at a point where the wave is whole again, the commit of the new entry and
+    // the setup of the next record for every working lane at once.  (Until round 5 a lane committed and set up as soon as its own
+    // scan ended: with 64 lanes some lane nearly always did, so those ~100 instructions were issued in almost every iteration
+    // for a handful of lanes -- tools/model_sched.py: 0.74 of the issued instructions this way.)  The same operations per lane
+    // in the same order: the files do not change.  Every working lane is at record `qi` of its queue in the same round.
+    while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
+      const bool wide = __builtin_amdgcn_ballot_w64(act && ncd > 2) != 0ull;     // some lane has more than two candidates this round
+      bool scan = act;
+      while (__builtin_amdgcn_ballot_w64(scan) != 0ull) {
+        if (scan) {
+          float gap_old;
+          if (!wide) v3_pair<QN, 2>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk, gap_old);
+          else v3_pair<QN, 4>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk, gap_old);
+          e -= 2;
+          // cost >= rhs >= gap in float arithmetic, and the gap only grows towards older entries: once it exceeds the best cost
+          // no older predecessor can win or tie
+          if (e <= 0 || gap_old > best) scan = false;
+        }
+      }
+      lookup();
+      if (act) {
+        if (beste >= 0) {
+          const int mag = (bestk < ncd - 1) ? (2 << bestk) - 1 : qval;
+          col[nlive - 1][lane] = make_uint2(__float_as_uint(azd_cur), __float_as_uint(best));     // live entry nlive
+          info[nlive - 1][lane] = (unsigned short)((unsigned)i | ((unsigned)beste << 6) | ((unsigned)mag << 12));
+          neg |= (unsigned long long)sgn << i;
+          // end-of-block choice (jcdctmgr.c:1187-1207): entries appear in position order, strict '<' keeps the first minimum
+          float c = best + azd63;
+          c = c - azd_cur;
+          if (i < 63) c = c + eobf;
+          if (c < end_best) { end_best = c; last = nlive; }
+          nlive++;
+        }
+        if (qi >= nq) act = false;
+        else setup();
+      }
+    }
+
+    // ---- back-track (jcdctmgr.c:1211-1222) along the entry indices; values in visiting (descending position) order ----
+    unsigned long long pmask = 0ull;
+    int cnt = 0, e2 = work ? last : 0;
+    int up_pos = -1, up_mag = 0;          // FST: the path entry visited before this one (the next higher position)
+    unsigned *hh = fhist[FST ? (lane & 1) : 0];
+    auto count = [&](int run, int mag) {  // symbol of a coefficient of magnitude `mag` behind `run` zeros (jchuff.c:833-868)
+      if (run > 15) { atomicAdd(&hh[0xF0], (unsigned)(run >> 4)); run &= 15; }
+      atomicAdd(&hh[(run << 4) + bitlen((unsigned)mag)], 1u);
+    };
+    while (__builtin_amdgcn_ballot_w64(e2 > 0) != 0ull) {
+      if (e2 > 0) {
+        const unsigned inf = info[e2 - 1][lane];
+        const int mag = (int)(inf >> 12), pos = (int)(inf & 63u);
+        const int v = ((neg >> pos) & 1ull) ? -mag : mag;
+        colh[((cnt >> 2) * 64 + lane) * 4 + (cnt & 3)] = (unsigned short)v;
+        pmask |= 1ull << pos;
+        cnt++;
+        if (FST) {
+          if (up_pos >= 0) count(up_pos - pos - 1, up_mag);
+          else if (pos < 63) atomicAdd(&hh[0], 1u);          // the highest kept position is not 63: EOB
+          up_pos = pos; up_mag = mag;
+        }
+        e2 = (int)((inf >> 6) & 63u);
+      }
+    }
+    if (FST && work) {
+      if (up_pos >= 0) count(up_pos - 1, up_mag);            // the lowest kept position: its run starts behind the DC coefficient
+      else atomicAdd(&hh[0], 1u);                            // nothing kept: EOB
+    }
+    if (work) nzmask[gblk] = pmask;
+    {
+      int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
+      // plane i+1 <- the i-th non-zero in position order = slot cnt-1-i; a plane is stored only while some block has a value for it
+#pragma unroll
+      for (int i2 = 0; i2 < QN; i2++) {
+        if (__builtin_amdgcn_ballot_w64(i2 < cnt) == 0ull) break;
+        if (i2 < cnt) {
+          const int s2 = cnt - 1 - i2;
+          qo[(size_t)(i2 + 1) * cc.kstride] = (int16_t)colh[((s2 >> 2) * 64 + lane) * 4 + (s2 & 3)];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (FST) {
+    const int sslot = comp == 0 ? stat_slot_of_comp.x : comp == 1 ? stat_slot_of_comp.y : comp == 2 ? stat_slot_of_comp.z : stat_slot_of_comp.w;
+    MjhHuffTable *TS = stat_tabs + (size_t)img * slots_per_image + sslot;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int bin = lane + 64 * j;
+      unsigned sum = fhist[0][bin] + fhist[1][bin];
+      // every dummy block of the interleaved scan codes one EOB (all-zero AC, jccoefct.c:312-345): counted once per component
+      if (bin == 0 && tl == t0) sum += (unsigned)(cc.wpad * cc.hpad - cc.nblk);
+      if (sum) atomicAdd(&TS->counts[bin], sum);
+    }
+  }
 }
 
-#ifndef MJH_TU_SORTED   // (mjh_sorted.hip includes this file for the shared device functions only)
 // =============================================================================================
 // K6  DC trellis (row a9, DC part): quantize_trellis jcdctmgr.c:1044-1118 + :1308-1327, driven
 // per iMCU row by compress_trellis_pass jccoefct.c:418-441 (lastDC = 0 at the start of each
@@ -3476,20 +3676,10 @@ static int max_nblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp;
 static int max_padblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp; i++) { int v = C.c[i].wpad * C.c[i].hpad; m = v > m ? v : m; } return m; }
 
 void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
-                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv, uint16_t *perm16, int sorted_tile, const MjhRecOut *rec)
+                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv)
 {
   dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
   const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
-  if (rec) {      // the FDCT kernel also writes the AC trellis' queue records (mjh_sorted.hip: k_dct_quant_rec)
-    if (C.precision == 12 || !fastdiv || !nq8 || perm16) { fprintf(stderr, "mjh_launch_dct: queue records need 8-bit samples, the fast division and natural order\n"); abort(); }
-    mjh_launch_dct_rec(C, Q, planes, uq, q, lambda, stat_tabs, spi, stat_slot, nq8, n, s, *rec);
-    return;
-  }
-  if (perm16) {   // tile-sorted coefficient planes for the tile-sorted trellis (mjh_sorted.hip)
-    if (C.precision == 12 || !fastdiv || !nq8) { fprintf(stderr, "mjh_launch_dct: tile-sorted planes need 8-bit samples, the fast division and the key array\n"); abort(); }
-    mjh_launch_dct_sorted(C, Q, planes, uq, q, lambda, stat_tabs, spi, stat_slot, nq8, n, s, perm16, sorted_tile);
-    return;
-  }
   if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t, false>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else if (stat_tabs && fastdiv) hipLaunchKernelGGL((k_dct_quant<uint8_t, true, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else if (stat_tabs) hipLaunchKernelGGL((k_dct_quant<uint8_t, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
@@ -3530,15 +3720,10 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
   if (nslots > 0) hipLaunchKernelGGL(k_gen_tables_list, dim3(nslots, n), dim3(64), 0, s, tabs, spi, d_slots);
 }
 
-void mjh_launch_zero_counters(unsigned *worklist, unsigned *worklist2, hipStream_t s)
-{
-  hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, worklist, worklist2);
-}
-
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
-                           uint8_t *nq8, int v3_passes, int fastdiv, const uint16_t *perm16, int sorted_tile, const MjhRecOut *rec)
+                           uint8_t *nq8, int v3_passes, int fastdiv)
 {
   // band-limited pass (use_scans_in_trellis), the per-block outputs of trellis_eob_opt, per-image tables (trellis_q_opt):
   // the EXT instantiations
@@ -3549,7 +3734,7 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   // stat_slot != nullptr: the statistics of the final coefficients go to these table slots (one per component)
   MjhHuffTable *st = stat_slot ? tabs : nullptr;
   const int4 ss = stat_slot ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
-  if (!rec) hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, worklist, worklist2);   // (a 16-byte hipMemsetAsync costs ~80 us of stream time; rec: the FDCT kernel has filled the list already, mjh_launch_zero_counters ran in front of it)
+  hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, worklist, worklist2);   // (a 16-byte hipMemsetAsync costs ~80 us of stream time)
   int w0[5] = { 0, 0, 0, 0, 0 };
   for (int i = 0; i < 4; i++) w0[i + 1] = w0[i] + (i < C.ncomp ? (C.c[i].nblk + 63) / 64 : 0);
   dim3 gridq(w0[C.ncomp], n);
@@ -3573,10 +3758,9 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     // goes through the general tiers below
     // one or two frames (the caller asks for one pass per tile then): occupancy is no concern on an empty chip, and with 24 records
     // next to nothing is left for the general tiers, whose fixed latency (~80 us) would sit on the critical path
-    const bool small24 = !perm16 && v3_passes == 1 && variant <= 2 && !st && fastdiv;
+    const bool small24 = v3_passes == 1 && variant <= 2 && !st && fastdiv;
     if (small24) variant = 2;
-    // (tile-sorted planes, perm16: mjh_launch_trellis_ac_sorted sizes its own grid from sorted_tile; np only matters for the kernels below)
-    const int np = perm16 ? 4 : small24 ? 1 : (!fastdiv || st || variant > 0) ? 4 : v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
+    const int np = small24 ? 1 : (!fastdiv || st || variant > 0) ? 4 : v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
     int t0[5] = { 0, 0, 0, 0, 0 };
     for (int i = 0; i < 4; i++) t0[i + 1] = t0[i] + (i < C.ncomp ? (C.c[i].nblk + 64 * np - 1) / (64 * np) : 0);
     dim3 gridt(t0[C.ncomp], n);
@@ -3584,16 +3768,6 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     const int4 tv = make_int4(t0[0], t0[1], t0[2], t0[3]);
 #define LV3Q(QN, NP, FDV, FSV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, NP, FDV, FSV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask, st, ss)
 #define LV3(NP, FDV, FSV) LV3Q(16, NP, FDV, FSV)
-    if (rec) {      // phase 1 happened in the FDCT kernel (mjh_launch_dct with the same MjhRecOut): the first tier reads its records
-      if (!fastdiv || perm16 || st || rec->qn != (variant >= 4 ? 48 : variant == 3 ? 32 : (small24 || variant > 0) ? 24 : 16)) {
-        fprintf(stderr, "mjh_launch_trellis_ac: queue records come with the fast division, natural order, no fused statistics and the capacity of the first tier chosen here\n"); abort();
-      }
-      mjh_launch_trellis_ac_rec(C, Q, q, tabs, spi, ac_slot, lambda, stat_slot, nzmask, n, s, nq8, *rec, small24 ? 1 : np);
-    } else
-    if (perm16) {   // the planes are tile-sorted already (mjh_launch_dct with the same array): the kernels of mjh_sorted.hip read that layout
-      if (!fastdiv) { fprintf(stderr, "mjh_launch_trellis_ac: tile-sorted planes need the fast division\n"); abort(); }
-      mjh_launch_trellis_ac_sorted(C, Q, uq, q, tabs, spi, ac_slot, lambda, worklist, worklist2, dense, dense_cap, stat_slot, variant, nzmask, n, s, nq8, perm16, sorted_tile);
-    } else
     if (small24) LV3Q(24, 1, true, false);
     else if (variant >= 3 && !st) {   // q90 and up: 32 / 48 records (20 / 30 KB of LDS per wave)
       if (variant == 3) { if (fastdiv) LV3Q(32, 4, true, false); else LV3Q(32, 4, false, false); }
@@ -3606,8 +3780,6 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     else switch (np) { case 8: LV3(8, true, false); break; case 4: LV3(4, true, false); break; case 2: LV3(2, true, false); break; default: LV3(1, true, false); break; }
 #undef LV3
 #undef LV3Q
-    if (perm16) ;   // (mjh_launch_trellis_ac_sorted launched its general tiers itself: entries without a dense copy name a place in the sorted planes)
-    else
     if (variant >= 3 && !st)   // what is left has more than 32 records or a magnitude >= 16: one general tier that takes everything
       hipLaunchKernelGGL((k_trellis_ac_qd<63, false, false, true>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
                          (const unsigned *)worklist, (unsigned *)nullptr, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
@@ -3776,4 +3948,3 @@ void mjh_launch_qopt_fix(const MjhQuant *Q, void *out, size_t out_stride, unsign
   for (int i = 0; i < 4; i++) L.tab[i] = i < ntab ? tabs[i] : 0;
   hipLaunchKernelGGL(k_qopt_fix, dim3(n), dim3(256), 0, s, Q, (uint8_t *)out, out_stride, sizes, L);
 }
-#endif  // MJH_TU_SORTED

@@ -8,19 +8,7 @@ void mjh_launch_import_coefs(const MjhConst &C, const MjhCoefSrc &S, void *coef_
 void mjh_launch_import_planes(const MjhConst &C, const MjhPlaneSrc &S, void *planes, int n, hipStream_t s);
 void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size_t img_stride, void *planes, int n, hipStream_t s);
 void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
-                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv = 0,   // fastdiv: every table in use has q <= 255 (MjhQuant.mdiv)
-                    uint16_t *perm16 = nullptr, int sorted_tile = 256, const MjhRecOut *rec = nullptr);   // rec: the kernel also writes the AC trellis' queue records (MjhRecOut); perm16: planes 1..63 of uq in tile-sorted order, tiles of sorted_tile (128 / 256 / 512) blocks (8-bit samples, fastdiv; mjh_launch_trellis_ac gets the same)
-void mjh_launch_zero_counters(unsigned *worklist, unsigned *worklist2, hipStream_t s);   // (rec: in front of mjh_launch_dct)
-// mjh_sorted.hip (called by mjh_launch_dct / mjh_launch_trellis_ac when rec / perm16 is given)
-void mjh_launch_dct_rec(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
-                        MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, const MjhRecOut &rec);
-void mjh_launch_trellis_ac_rec(const MjhConst &C, const MjhQuant *Q, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
-                               const int *stat_slot, unsigned long long *nzmask, int n, hipStream_t s, uint8_t *nq8, const MjhRecOut &rec, int npass);
-void mjh_launch_dct_sorted(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
-                           MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, uint16_t *perm16, int sorted_tile);
-void mjh_launch_trellis_ac_sorted(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
-                                  unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
-                                  unsigned long long *nzmask, int n, hipStream_t s, uint8_t *nq8, const uint16_t *perm16, int sorted_tile);
+                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv = 0);   // fastdiv: every table in use has q <= 255 (MjhQuant.mdiv)
 // nzmask != nullptr (here and in mjh_launch_encode / mjh_launch_trellis_ac): the AC planes hold COMPACT records (plane i+1 = the block's i-th
 // non-zero value in position order, nzmask = its non-zero positions) instead of one plane per position
 void mjh_launch_stats_ac(const MjhConst &C, const void *q, const unsigned long long *nzmask, MjhHuffTable *tabs, int spi, const int slot[4], int count_dummies, int n, hipStream_t s);
@@ -29,7 +17,7 @@ void mjh_launch_gen_tables(MjhHuffTable *tabs, int spi, const int *slots, int ns
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
-                           uint8_t *nq8 = nullptr, int v3_passes = 0, int fastdiv = 0, const uint16_t *perm16 = nullptr, int sorted_tile = 256, const MjhRecOut *rec = nullptr);   // (with stat_slot and the tile-sorted kernel: the final AC statistics are counted in its back-track)   // v3_passes > 0 (plain compact pass, variant 0): the tile-sorted kernel with that many passes
+                           uint8_t *nq8 = nullptr, int v3_passes = 0, int fastdiv = 0);   // (with stat_slot and the tile-sorted kernel: the final AC statistics are counted in its back-track)   // v3_passes > 0 (plain compact pass, variant 0): the tile-sorted kernel with that many passes
 // trellis_eob_opt: the block-row pass behind a (band-limited) AC trellis; eob_cost / eob_has as written by mjh_launch_trellis_ac
 void mjh_launch_trellis_eob_chain(const MjhConst &C, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const void *eob_cost, const int *eob_has,
                                   int Ss, int Se, int n, hipStream_t s);
@@ -67,11 +55,6 @@ void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *lis
                             MjhHuffTable *tabs, int spi, unsigned *pool, size_t pool_words, const void *frame_hdr, int frame_hdr_len,
                             int multi_dht, void *outpool, size_t out_bytes, unsigned *mpos, int mpos_per_image, unsigned *ffsums, const unsigned long long *nzmask, int n, hipStream_t s,
                             hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, int nacf);
-// opt-in variants of the first-pass AC scans' statistics / emit kernels (mjh_prog_sl.hip, MJH_PP_SKIPLOW=1)
-void mjh_launch_pp_stats_sl(const MjhConst &C, const void *scans, const int *list, const void *ctl, const void *q, const unsigned long long *nzmask,
-                            MjhHuffTable *tabs, int spi, const MjhProgPE &pe, int nacf, int n, hipStream_t s);
-void mjh_launch_pp_emit_sl(const MjhConst &C, const void *scans, const int *par_list, const void *ctl, const void *q, const unsigned long long *nzmask,
-                           const MjhHuffTable *tabs, int spi, unsigned *pool, size_t pool_words, const MjhProgPE &pe, int nacf, int n, hipStream_t s);
 void mjh_launch_scan16(const void *len16, int n_per, unsigned *sums, int chunks, unsigned *totals, unsigned *off32, int npairs, hipStream_t s);
 void mjh_launch_prog_select(void *ctl, int ncomp, int phase, int dc_scan_opt_mode, int n, hipStream_t s);
 void mjh_launch_prog_concat(const void *ctl, const void *file_hdr, int file_hdr_len, const void *outpool, size_t out_bytes,

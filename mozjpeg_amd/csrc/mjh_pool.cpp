@@ -65,6 +65,9 @@ struct Share { std::vector<int> images; std::vector<size_t> off, len; int rc = M
 void run_share(mjh_pool *pl, int d, const uint8_t *pixels, size_t row_pitch, size_t image_stride, size_t row_bytes, int rows, Share *sh)
 {
   mjh_encoder *e = pl->enc[d];
+  // this thread gathers the device's images into its pinned staging buffer: it runs on the CPUs of the device's NUMA node
+  // (the staging buffer was pinned there), so the copy's stores stay on the socket the DMA engine reads from
+  (void)mjh_bind_thread_to_device(pl->dev[d]);
   std::vector<uint8_t> &st = pl->store[d];
   st.clear();
   const int total = (int)sh->images.size();

@@ -683,9 +683,10 @@ struct PPRefine { unsigned long long newm, nzm, corrm, posm, tailm; int tail_cnt
 // plane i+1 = its i-th non-zero value in position order): f(position, value) for the non-zero coefficients at positions
 // Ss..Se in position order.  Every lane of a wave reads the same plane at a time (coalesced), bursts of 8, up to the
 // rank of the last position <= Se the busiest block of the wave has; positions below Ss are read and dropped.
-// SKIPLOW (opt-in, MJH_PP_SKIPLOW=1: k_pp_stats<true, 3> and k_pp_emit_sl, both in mjh_prog_sl.hip): the non-zeros below Ss -- for the upper band of a
-// frequency split most of a block's non-zeros -- are taken out of the mask up front instead of being visited and dropped one by
-// one, and bursts in which no lane of the wave has anything to visit are not even loaded; f sees the same sequence.
+// SKIPLOW (the first-pass AC scans of the parallel chain, k_pp_stats<true, 1> and k_pp_emit; Ss >= 1): the non-zeros below Ss -- for the
+// upper band of a frequency split most of a block's non-zeros, about a third of all visits of the scan search at q85 -- are taken
+// out of the mask up front instead of being visited and dropped one by one, and bursts in which no lane of the wave has anything
+// to visit are not even loaded; f sees the same sequence (C3 on the chip: 24.79 -> 23.82 ms per 32 frames, profiles/r05a_optin_kernels_ab.md).
 template <bool SKIPLOW = false, class F>
 __device__ __forceinline__ void pp_band_nonzeros(const int16_t *__restrict__ qb, size_t kstride, unsigned long long mask, int Ss, int Se, bool active, F &&f)
 {
@@ -819,7 +820,6 @@ __device__ __forceinline__ int pp_next_ne(const unsigned long long *ne_bits, int
   return m ? w * 64 + __builtin_ctzll(m) : -1;
 }
 
-#ifndef MJH_TU_PROG_SL
 __global__ void __launch_bounds__(64)
 k_pp_init(MjhProgPE pe, int npairs)
 {
@@ -827,16 +827,15 @@ k_pp_init(MjhProgPE pe, int npairs)
   if (i < npairs) { pe.info[i].final_run = 0; pe.info[i].final_be = 0; pe.info[i].fallback = 0; pe.info[i].corr_total = 0; }
 }
 
-#endif
 
-template <bool COMPACT, int SELX>   // SELX: SEL as in k_pp_len; 3 = SEL 1 with pp_band_nonzeros' SKIPLOW walks (opt-in, instantiated in mjh_prog_sl.hip only)
+template <bool COMPACT, int SELX>   // SELX: SEL as in k_pp_len
 __global__ void __launch_bounds__(256)
 k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list,
            const MjhProgCtl *__restrict__ ctl, const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask,
            MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe, int li0)
 {
-  constexpr int SEL = SELX == 3 ? 1 : SELX;
-  constexpr bool SKIPLOW = SELX == 3;
+  constexpr int SEL = SELX;
+  constexpr bool SKIPLOW = SELX == 1;     // first-pass AC scans: the non-zeros below the band leave the mask up front (pp_band_nonzeros)
   constexpr int NH = SEL == 1 ? 16 : 4;   // (first-pass AC scans: a handful of symbols takes most of the counts)
   __shared__ unsigned hist[NH][256];   // DC scans: [table 0 / 1]; AC scans: NH interleaved copies (the hot symbols serialise the LDS atomics)
   __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64], e_bits[MJH_PSTAT_BLOCKS / 64];
@@ -1038,7 +1037,6 @@ __device__ __forceinline__ void pp_mark_cuts(const MjhProgPE &pe, size_t pair, i
   }
 }
 
-#ifndef MJH_TU_PROG_SL
 // per (scan, image) pair, before the marks: the last real non-empty block in front of every chunk; marks of the final gap
 __global__ void __launch_bounds__(64)
 k_pp_carry(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl, MjhProgPE pe)
@@ -1201,7 +1199,6 @@ k_pp_runs(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restri
   }
 }
 
-#endif
 
 // ---- encode -------------------------------------------------------------------------------------------------------
 // DC units: bits of one unit (all its blocks) / writing them
@@ -1627,7 +1624,6 @@ k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
 // without a pass over the blocks: k_pp_chunk_bits.  k_pp_emit then sizes the blocks of a chunk, scans the sizes inside the
 // workgroup and writes the bits into a window of the stream kept in LDS -- no per-block length / offset arrays, no
 // device-wide prefix sums, and the stream receives whole words (only the two boundary words of a chunk are ORed).
-#ifndef MJH_TU_PROG_SL
 __global__ void __launch_bounds__(256)
 k_pp_chunk_bits(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl,
                 const MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhProgPE pe)
@@ -1662,7 +1658,6 @@ k_pp_chunk_bits(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__
   if (tid == 0) pe.totals[pair] = carry;
 }
 
-#endif
 
 #define PPE_WIN 4096          // words of the LDS window (16 KB): a chunk of 2048 blocks with up to 64 bits per block on average
 template <bool LDSW, bool SKIPLOW = false>
@@ -1734,14 +1729,58 @@ __device__ __forceinline__ void pp_emit_rounds(unsigned *dst, unsigned bit0, uns
   }
 }
 
-#ifndef MJH_TU_PROG_SL
 __global__ void __launch_bounds__(256)
 k_pp_emit(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_list, const MjhProgCtl *__restrict__ ctl,
           const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
           unsigned *__restrict__ pool, size_t pool_words_per_image, MjhProgPE pe)
 {
-  constexpr bool SKIPLOW = false;
-#include "mjh_pp_emit.inc"
+  constexpr bool SKIPLOW = true;
+  __shared__ unsigned s_tab[256];   // size << 16 | code
+  __shared__ unsigned s_win[PPE_WIN];
+  __shared__ unsigned long long fp_bits[MJH_PSTAT_BLOCKS / 64];   // flush points: real non-empty blocks + forced-flush marks
+  __shared__ unsigned long long rn_bits[MJH_PSTAT_BLOCKS / 64];   // real non-empty blocks
+  __shared__ unsigned sh[8];
+  const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;   // the list starts with these scans
+  const size_t pair = (size_t)li * gridDim.z + img;
+  const int sidx = scan_list[li];
+  const MjhProgScan sc = scans[sidx];
+  const MjhProgCtl *ct = ctl + img;
+  if (prog_skip(sc, ct)) return;
+  const MjhComp cc = C.c[sc.comp[0]];
+  const int cb = chunk * MJH_PSTAT_BLOCKS;
+  if (cb >= cc.nblk || ct->error) return;
+  const int nb = min(MJH_PSTAT_BLOCKS, cc.nblk - cb);
+  const bool last_chunk = cb + MJH_PSTAT_BLOCKS >= cc.nblk;
+  const unsigned base = ct->scan_words_off[sidx] * 32u;
+  const unsigned cbase = base + pe.sums[pair * pe.chunks_per_scan + chunk];
+  const unsigned cend = base + (last_chunk ? pe.totals[pair] : pe.sums[pair * pe.chunks_per_scan + chunk + 1]);
+  if (cend == cbase) return;        // uniform: the chunk has no bits
+  const int Al = sc.al_sel == 1 ? ct->best_Al_luma : (sc.al_sel == 2 ? ct->best_Al_chroma : sc.Al);
+  const MjhHuffTable *T0 = tabs + (size_t)img * slots_per_image + sc.slot[0];
+  const int16_t *qc = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + cb;
+  const unsigned long long *nzc = nzmask + (size_t)img * C.total_real_blocks + cc.blk_off + cb;
+  const uint16_t *run = pe.run16 + pair * pe.nblk_pad + cb;
+  unsigned *stream = pool + (size_t)img * pool_words_per_image;
+  const unsigned w0 = cbase >> 5, nw = ((cend - 1u) >> 5) - w0 + 1u;
+  const bool window = nw <= PPE_WIN;
+  s_tab[tid] = ((unsigned)T0->ehufsi[tid] << 16) | T0->ehufco[tid];
+  if (tid < MJH_PSTAT_BLOCKS / 64) {
+    fp_bits[tid] = pe.ne2_bits[(pair * pe.chunks_per_scan + chunk) * (MJH_PSTAT_BLOCKS / 64) + tid];
+    rn_bits[tid] = pe.ne_bits[(pair * pe.chunks_per_scan + chunk) * (MJH_PSTAT_BLOCKS / 64) + tid];
+  }
+  if (window) for (unsigned w = tid; w < nw; w += 256) s_win[w] = 0u;
+  __syncthreads();
+  if (window) {
+    pp_emit_rounds<true, SKIPLOW>(s_win, w0 << 5, cbase, nb, sc.Ss, sc.Se, Al, qc, (size_t)cc.kstride, nzc, run, fp_bits, rn_bits, s_tab, sh);
+    __syncthreads();
+    for (unsigned w = tid; w < nw; w += 256) {
+      const unsigned v = s_win[w];
+      if (!v) continue;                                  // (the pool is zeroed)
+      if (w == 0 || w == nw - 1) atomicOr(&stream[w0 + w], v);   // shared with the neighbouring chunk / the end of the scan
+      else stream[w0 + w] = v;
+    }
+  } else   // more than 64 bits per block on average: straight into the stream
+    pp_emit_rounds<false, SKIPLOW>(stream, 0u, cbase, nb, sc.Ss, sc.Se, Al, qc, (size_t)cc.kstride, nzc, run, fp_bits, rn_bits, s_tab, sh);
 }
 
 __global__ void __launch_bounds__(64)
@@ -2178,11 +2217,6 @@ void mjh_launch_prog_stats(const MjhConst &C, const void *scans, const int *list
                      (const int16_t *)q, tabs, spi, (unsigned *)nullptr, (size_t)0, mpos, mpos_per_image, (const MjhProgPair *)nullptr);
 }
 
-// MJH_PP_SKIPLOW=1 (opt-in, untimed on the chip: round 4 ended without GPU minutes for it): the first-pass AC scans of the
-// parallel chain run k_pp_stats<true, 3> / k_pp_emit_sl (mjh_prog_sl.hip: pp_band_nonzeros' SKIPLOW form); read per call so that a test
-// can switch it inside one process
-static bool pp_skiplow() { const char *e = getenv("MJH_PP_SKIPLOW"); return e && atoi(e) != 0; }
-
 // statistics of the parallel chain (every scan of the list has no restart interval)
 void mjh_launch_prog_stats_par(const MjhConst &C, const void *scans, const int *list, int nlist, void *ctl, const void *q,
                                MjhHuffTable *tabs, int spi, const MjhProgPE &pe, bool any_refine, const unsigned long long *nzmask, int n, hipStream_t s, int nacf)
@@ -2193,8 +2227,6 @@ void mjh_launch_prog_stats_par(const MjhConst &C, const void *scans, const int *
   const char *es = getenv("MJH_PP_SPLITK");       // A/B knob: 0 = one kernel for every kind of scan
   const void *sv = scans; const int16_t *qv = (const int16_t *)q;
   if (nzmask && !(es && atoi(es) == 0)) {         // the list starts with its nacf first-pass AC scans
-    if (nacf > 0 && pp_skiplow()) mjh_launch_pp_stats_sl(C, scans, list, ctl, q, nzmask, tabs, spi, pe, nacf, n, s);
-    else
     if (nacf > 0) hipLaunchKernelGGL((k_pp_stats<true, 1>), dim3(pe.chunks_per_scan, nacf, n), dim3(256), 0, s, C, (const MjhProgScan *)sv, list, (const MjhProgCtl *)ctl, qv,
                                      nzmask, tabs, spi, pe, 0);
     if (nlist > nacf) hipLaunchKernelGGL((k_pp_stats<true, 2>), dim3(pe.chunks_per_scan, nlist - nacf, n), dim3(256), 0, s, C, (const MjhProgScan *)sv, list, (const MjhProgCtl *)ctl, qv,
@@ -2247,8 +2279,6 @@ void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *lis
       const size_t po = (size_t)nacf * n;      // their pairs come first
       if (nacf > 0) {
         hipLaunchKernelGGL(k_pp_chunk_bits, dim3(nacf, n), dim3(256), 0, ps, C, sv, par_list, cv, tv, spi, pe);
-        if (pp_skiplow()) mjh_launch_pp_emit_sl(C, scans, par_list, ctl, q, nzmask, tabs, spi, pool, pool_words, pe, nacf, n, ps);
-        else
         hipLaunchKernelGGL(k_pp_emit, gacf, dim3(256), 0, ps, C, sv, par_list, cv, qv, nzmask, tv, spi, pool, pool_words, pe);
       }
       if (npar > nacf) {
@@ -2292,4 +2322,3 @@ void mjh_launch_prog_concat(const void *ctl, const void *file_hdr, int file_hdr_
   hipLaunchKernelGGL(k_prog_concat, dim3(PROG_CONCAT_PARTS, n), dim3(256), 0, s, (const MjhProgCtl *)ctl, (const uint8_t *)file_hdr, file_hdr_len,
                      (const uint8_t *)outpool, out_bytes, (uint8_t *)out, out_stride, sizes);
 }
-#endif   // MJH_TU_PROG_SL

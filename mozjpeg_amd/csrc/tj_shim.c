@@ -298,6 +298,7 @@ static int get_encoder(tjs *t, const char *fn, const mjh_params *p)
 {
   if (t->enc && memcmp(&t->enc_params, p, sizeof(*p)) == 0) return 0;
   if (t->enc) { mjh_encoder_destroy(t->enc); t->enc = NULL; }
+  if (mjh_params_size() != sizeof(mjh_params)) return fail(t, fn, "libmozjpeg_hip.so was built with another mjh_params layout than this shim (rebuild both)");
   if (mjh_encoder_create(p, 1, t->device, &t->enc) != MJH_OK) return fail(t, fn, mjh_last_error());
   t->enc_params = *p;
   return 0;

@@ -298,3 +298,31 @@ def test_arithmetic_coder_on_the_host_matches_a_plain_restatement_of_jcarith(tmp
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "arith_coder_check.cpp")])
     out = subprocess.run([exe, "300", "4242"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "identical" in out.stdout, out.stdout[-2000:]
+
+
+def test_numa_placement_helpers_parse_and_degrade():
+    """mjh_numa.cpp: the cpulist parser behind mjh_bind_thread_to_device, and "no placement" without a device (this
+    container has no GPU: the node is unknown, nothing is bound, the description says so)"""
+    L = M.lib()
+    import ctypes.util  # noqa: F401
+
+    class CpuSet(C.Structure):
+        _fields_ = [("bits", C.c_ulong * 16)]     # cpu_set_t: 1024 bits
+    L.mjh_numa_parse_cpulist.argtypes = [C.c_char_p, C.POINTER(CpuSet)]
+
+    def parse(s):
+        cs = CpuSet()
+        n = L.mjh_numa_parse_cpulist(s.encode(), C.byref(cs))
+        return n, [i for i in range(1024) if (cs.bits[i // 64] >> (i % 64)) & 1]
+    assert parse("0-7\n") == (8, list(range(8)))
+    assert parse("0-3,64-67") == (8, [0, 1, 2, 3, 64, 65, 66, 67])
+    assert parse("5") == (1, [5])
+    assert parse("3,3,2-4") == (3, [2, 3, 4])
+    assert parse("") == (0, [])
+    assert parse("7-3")[0] == -1 and parse("0-99999")[0] == -1
+    if not _gpu_present():
+        assert L.mjh_device_numa_node(0) == -1
+        assert L.mjh_bind_thread_to_device(0) == -1
+        buf = C.create_string_buffer(256)
+        L.mjh_device_placement.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+        assert L.mjh_device_placement(0, buf, 256) > 0 and b"no NUMA placement" in buf.value

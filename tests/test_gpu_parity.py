@@ -426,46 +426,6 @@ def test_every_first_tier_capacity_of_the_ac_trellis_gives_the_same_file(quality
             enc.close()
 
 
-@pytest.mark.parametrize("quality,sample", [(75, (2, 2)), (90, (1, 1)), (97, (1, 1))])
-def test_tile_sorted_coefficient_planes_give_the_same_file(quality, sample, request):
-    """MJH_SORTED_UQ: the FDCT kernel (four waves = one trellis tile of 256 blocks) sorts each tile by the blocks' keys and
-    stores planes 1..63 of coef_uq in that order; a pass of the tile-sorted trellis then reads one line per plane.  Same files
-    as the natural layout and as the oracle -- at every first-tier capacity, with ragged last tiles (600x424: 3975 luma blocks
-    = 15 tiles + 135), when the deferred blocks outgrow their dense copies (MJH_DENSE_CAP: the general tiers then find a block
-    through its tile's permutation), with the statistics fused into either kernel, sequential and progressive.
-    The layout is OPT-IN (it was written after round 4's GPU minutes were spent): this test runs under the emulator
-    (`--simt`, where it passes) and, on the chip, only when asked for (MJH_TEST_SORTED=1) -- round 5's first GPU call."""
-    if not request.config.getoption("--simt") and os.environ.get("MJH_TEST_SORTED") != "1":
-        pytest.skip("opt-in kernels (MJH_SORTED_UQ) that have only run under tools/simt so far: set MJH_TEST_SORTED=1 to run them on the chip")
-    w, h = 600, 424
-    rng = np.random.default_rng(quality)
-    img = O.synthetic_frame(w, h, 60 + quality)
-    img[100:300, 200:500] = rng.integers(0, 256, (200, 300, 3), dtype=np.uint8)
-    frames = np.stack([img, img[::-1].copy(), img])
-    knobs = ("MJH_SORTED_UQ", "MJH_TRELLIS_VARIANT", "MJH_DENSE_CAP", "MJH_FUSE", "MJH_SORTED_TILE")
-    for kw in (dict(quality=quality, baseline=True, sample=sample), dict(quality=quality, fastcrush=True, sample=sample),
-               dict(quality=quality, baseline=True, sample=sample, trellis_loops=2)):
-        want = O.encode(O.make_params(w, h, **kw), img)
-        # (tiles of 128 / 256 / 512 blocks = FDCT workgroups of 2 / 4 / 8 waves and as many passes of the trellis kernel)
-        for variant, dense, fuse, tile in (("0", None, None, None), ("2", None, None, None), ("3", None, None, None), ("4", None, None, None), (None, None, None, None),
-                                           ("0", "8", None, None), (None, "0", None, None), ("0", None, "5", None), ("2", "40", "5", None),
-                                           ("0", None, None, "128"), ("0", "8", "5", "128"), ("3", "0", None, "128"), (None, None, None, "128"),
-                                           ("0", None, None, "512"), ("2", "8", "5", "512"), ("4", "0", None, "512"), (None, None, None, "512")):
-            env = {"MJH_SORTED_UQ": "2", "MJH_TRELLIS_VARIANT": variant, "MJH_DENSE_CAP": dense, "MJH_FUSE": fuse, "MJH_SORTED_TILE": tile}
-            try:
-                for k, v in env.items():
-                    if v is not None:
-                        os.environ[k] = v
-                enc = M.Encoder(M.make_params(w, h, **kw), max_batch=3)
-            finally:
-                for k in knobs:
-                    os.environ.pop(k, None)
-            for rnd in range(2 if variant is None else 1):
-                got = enc.encode_host(frames)
-                assert got[0] == want and got[2] == want, (kw, env, rnd)
-            enc.close()
-
-
 @pytest.mark.parametrize("w,h", [(65500, 9), (9, 65500), (65500, 1), (1, 65500)])
 def test_frames_at_the_largest_dimension_jpeg_allows(w, h):
     """JPEG_MAX_DIMENSION (jmorecfg.h:215) is 65500: one-MCU-high frames of that width and one-MCU-wide frames of that height
@@ -484,56 +444,14 @@ def test_frames_at_the_largest_dimension_jpeg_allows(w, h):
         assert got[0] == want, (w, h, kw)
 
 
-@pytest.mark.parametrize("quality,sample", [(75, (2, 2)), (85, (1, 1)), (60, (2, 1)), (95, (1, 1))])
-def test_queue_records_from_the_fdct_kernel_give_the_same_file(quality, sample, request):
-    """MJH_TRELLIS_REC=1 (opt-in, mjh_sorted.hip): the FDCT kernel, which quantizes every coefficient anyway (for its fused
-    statistics in the sequential configuration, for coef_q in the progressive one), also does phase 1 of the tile-sorted AC trellis -- queue records row by row,
-    the all-zero distortion, the deferral of the blocks the first tier cannot take -- and k_trellis_ac_v3r starts from the
-    records.  Same files as the default path and the oracle: one / two / four / eight passes per tile (MJH_SMALL_BATCH=0 takes a
-    small batch down the large-batch plan), 16 / 24 / 32 / 48 records, a work list that outgrows its dense copies (the general tiers
-    then read the planes the FDCT kernel wrote for deferred blocks), grey and subsampled frames, ragged tiles; configurations the
-    mode does not cover (trellis loops, fused back-track statistics) fall back to the default kernels.
-    Written after round 4's GPU minutes were spent: runs under the emulator (`--simt`), on the chip only with MJH_TEST_SORTED=1."""
-    if not request.config.getoption("--simt") and os.environ.get("MJH_TEST_SORTED") != "1":
-        pytest.skip("opt-in kernels (MJH_TRELLIS_REC) that have only run under tools/simt so far: set MJH_TEST_SORTED=1 to run them on the chip")
-    w, h = 600, 424
-    rng = np.random.default_rng(quality)
-    img = O.synthetic_frame(w, h, 90 + quality)
-    img[100:300, 200:500] = rng.integers(0, 256, (200, 300, 3), dtype=np.uint8)
-    frames = np.stack([img, img[::-1].copy(), img])
-    knobs = ("MJH_TRELLIS_REC", "MJH_TRELLIS_VARIANT", "MJH_DENSE_CAP", "MJH_SMALL_BATCH", "MJH_TRELLIS_V3", "MJH_FUSE")
-    for kw in (dict(quality=quality, baseline=True, sample=sample), dict(quality=quality, baseline=True, gray=True),
-               dict(quality=quality, baseline=True, sample=sample, trellis_loops=2), dict(quality=quality, fastcrush=True, sample=sample)):
-        want = O.encode(O.make_params(w, h, **kw), img)
-        for variant, dense, small, v3, fuse in ((None, None, None, None, None), ("0", None, "0", "4", None), ("0", "8", "0", "1", None), ("0", None, "0", "2", None),
-                                                 ("0", "0", "0", "8", None), ("2", None, "0", "4", None), ("2", "40", None, None, None), ("3", None, "0", "4", None),
-                                                 ("4", None, "0", "4", None), ("3", "5", None, None, None), ("4", "0", "0", "2", None),
-                                                 (None, None, "0", None, None), ("0", None, "0", "4", "5")):
-            env = {"MJH_TRELLIS_REC": "1", "MJH_TRELLIS_VARIANT": variant, "MJH_DENSE_CAP": dense, "MJH_SMALL_BATCH": small, "MJH_TRELLIS_V3": v3, "MJH_FUSE": fuse}
-            try:
-                for k, v in env.items():
-                    if v is not None:
-                        os.environ[k] = v
-                enc = M.Encoder(M.make_params(w, h, **kw), max_batch=3)
-            finally:
-                for k in knobs:
-                    os.environ.pop(k, None)
-            for rnd in range(2 if variant is None else 1):
-                got = enc.encode_host(frames)
-                assert got[0] == want and got[2] == want, (kw, env, rnd)
-            enc.close()
-
-
 @pytest.mark.parametrize("quality,sample", [(85, (2, 2)), (75, (1, 1)), (95, (2, 1)), (40, (2, 2))])
-def test_skiplow_walks_of_the_scan_search_give_the_same_file(quality, sample, request):
-    """MJH_PP_SKIPLOW=1 (opt-in, mjh_prog_sl.hip): the statistics and emit kernels of the first-pass AC scans take the non-zeros
-    below the band out of a block's mask up front instead of visiting and dropping them (pp_band_nonzeros<true>), and skip
-    bursts no lane needs.  Same files as the default path and the oracle for the scan search (cjpeg's default), the fixed
-    nine-scan script, a notrellis search (dense coefficient planes: the knob must change nothing), grey and subsampled frames,
-    frames whose upper bands are empty (flat) or full (noise), and more than one chunk of 2048 blocks per component.
-    Written after round 4's GPU minutes were spent: runs under the emulator (`--simt`), on the chip only with MJH_TEST_SORTED=1."""
-    if not request.config.getoption("--simt") and os.environ.get("MJH_TEST_SORTED") != "1":
-        pytest.skip("opt-in kernels (MJH_PP_SKIPLOW) that have only run under tools/simt so far: set MJH_TEST_SORTED=1 to run them on the chip")
+def test_skiplow_walks_of_the_scan_search_give_the_same_file(quality, sample):
+    """The statistics and emit kernels of the first-pass AC scans (k_pp_stats<true, 1>, k_pp_emit) take the non-zeros below the band
+    out of a block's mask up front instead of visiting and dropping them (pp_band_nonzeros<true>), and skip bursts no lane
+    needs.  The oracle's files for the scan search (cjpeg's default), the fixed nine-scan script, a notrellis search (dense
+    coefficient planes), grey and subsampled frames, frames whose upper bands are empty (flat) or full (noise), and more
+    than one chunk of 2048 blocks per component.  (Round 4 wrote these walks as an opt-in variant; round 5 timed them on the
+    chip -- C3 24.79 -> 23.82 ms per 32 frames, profiles/r05a_optin_kernels_ab.md -- and made them the only form.)"""
     w, h = 616, 440            # 77 x 55 = 4235 luma blocks at 1x1 sampling: three chunks, the last one ragged
     rng = np.random.default_rng(1000 + quality)
     img = O.synthetic_frame(w, h, 7 + quality)
@@ -544,13 +462,8 @@ def test_skiplow_walks_of_the_scan_search_give_the_same_file(quality, sample, re
     for kw in (dict(quality=quality, sample=sample), dict(quality=quality, sample=sample, fastcrush=True), dict(quality=quality, gray=True),
                dict(quality=quality, sample=sample, notrellis=True), dict(quality=quality, sample=sample, dc_scan_opt=2, trellis_eob_opt=True)):
         want = [O.encode(O.make_params(w, h, **kw), f) for f in frames]
-        try:
-            os.environ["MJH_PP_SKIPLOW"] = "1"
-            enc = M.Encoder(M.make_params(w, h, **kw), max_batch=3)
-            for rnd in range(2):
-                got = enc.encode_host(frames)
-                assert [bytes(g) for g in got] == want, (kw, rnd)
-            enc.close()
-        finally:
-            os.environ.pop("MJH_PP_SKIPLOW", None)
-
+        enc = M.Encoder(M.make_params(w, h, **kw), max_batch=3)
+        for rnd in range(2):
+            got = enc.encode_host(frames)
+            assert [bytes(g) for g in got] == want, (kw, rnd)
+        enc.close()

@@ -78,3 +78,47 @@ def test_shard_indices_partition():
             assert allidx == list(range(n))
             sizes = [len(shard.shard_indices(n, r, world)) for r in range(world)]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker8(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch
+    import torch.distributed as dist
+    from mozjpeg_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard.shard_indices(1024, rank, world)          # BASELINE config 4: 1024 frames over the ranks
+    # what bench.py --config c4 does with its share: encode calls of at most 128 frames, seeds 1234 + frame index
+    calls = [(s, min(128, len(mine) - s)) for s in range(0, len(mine), 128)]
+    seeds = [1234 + i for i in mine]
+    worst = shard.max_over_ranks(0.5 + 0.01 * rank, dist, torch.device("cpu"))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (mine, calls, seeds))
+    if rank == 0:
+        q.put((worst, gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_shard_1024_frames_exactly_once():
+    """BASELINE config 4 as the driver launches it at N = 8 (one process per GPU, no collective on the data path): every one of
+    the 1024 frames belongs to exactly one rank, every rank gets 128 = one encode call, the reported time is the slowest rank's"""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    worst, gathered = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert abs(worst - 0.57) < 1e-9
+    seen = []
+    for mine, calls, seeds in gathered:
+        assert len(mine) == 128 and calls == [(0, 128)]
+        assert seeds == [1234 + i for i in mine]
+        seen.extend(mine)
+    assert sorted(seen) == list(range(1024))

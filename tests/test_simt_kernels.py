@@ -71,19 +71,18 @@ def test_emulated_12bit_kernels_reproduce_the_reference_goldens(simt, cname, gol
         assert (len(data), O.md5(data)) == (g["bytes"], g["md5"]), (iname, cname)
 
 
-# the opt-in kernel variants (never run on the chip when round 4 ended): their own translation units, switched on by
-# the environment; the files must be the default path's = the reference's
-OPT_IN = [("MJH_SORTED_UQ", "2", "base"), ("MJH_SORTED_UQ", "2", "base_q90_444"), ("MJH_TRELLIS_REC", "1", "base"),
-          ("MJH_TRELLIS_REC", "1", "default_progressive"), ("MJH_PP_SKIPLOW", "1", "default_progressive"), ("MJH_PP_SKIPLOW", "1", "dc_scan_opt2")]
+# kernel variants switched by the environment (A/B knobs that survive: every setting is bit-identical): the files must be the
+# default path's = the reference's
+KNOBS = [("MJH_TRELLIS_VARIANT", "3", "base_q90_444"), ("MJH_TRELLIS_V3", "2", "base"), ("MJH_DC_SPEC", "0", "default_progressive")]
 
 
-@pytest.mark.parametrize("knob,value,cname", OPT_IN)
-def test_emulated_opt_in_variants_reproduce_the_reference_goldens(simt, knob, value, cname, goldens):
+@pytest.mark.parametrize("knob,value,cname", KNOBS)
+def test_emulated_knob_settings_reproduce_the_reference_goldens(simt, knob, value, cname, goldens):
     kw = [k for c, k, _ in CASES if c == cname][0]
     for iname, img in images().items():
         h, w = img.shape[:2]
         try:
-            os.environ[knob] = value          # (read when the encoder is made or, MJH_PP_SKIPLOW, at every launch)
+            os.environ[knob] = value          # (read when the encoder is made)
             enc = M.Encoder(M.make_params(w, h, **kw))
             data = enc.encode_host(img)[0]
             enc.close()

@@ -209,13 +209,14 @@ static inline size_t min(size_t a, int b) { return a < (size_t)b ? a : (size_t)b
 
 // ------------------------------------------------------------------------------------------------ runtime API (simt.cpp)
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotSupported = 801, hipErrorUnknown = 999 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorNotSupported = 801, hipErrorUnknown = 999 };
 typedef struct simt_stream *hipStream_t;
 typedef struct simt_event *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum { hipStreamDefault = 0, hipStreamNonBlocking = 1 };
 enum { hipEventDefault = 0, hipEventDisableTiming = 2 };
-enum { hipHostMallocDefault = 0, hipHostMallocMapped = 2 };
+enum { hipHostMallocDefault = 0, hipHostMallocMapped = 2, hipHostMallocNumaUser = 0x20000000 };
+static inline hipError_t hipDeviceGetPCIBusId(char *, int, int) { return hipErrorNotSupported; }   // (no placement in the emulator: mjh_numa.cpp)
 enum { hipHostRegisterDefault = 0 };
 enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
 struct hipPointerAttribute_t { hipMemoryType type; int device; void *devicePointer; void *hostPointer; };
@@ -266,6 +267,7 @@ hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
 hipError_t hipEventSynchronize(hipEvent_t e);
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }   // (the emulator runs every launch to completion)
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipFuncSetAttribute(const void *f, hipFuncAttribute a, int v);
 hipError_t hipMemGetAllocationGranularity(size_t *g, const hipMemAllocationProp *p, int opt);
