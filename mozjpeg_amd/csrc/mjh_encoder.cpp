@@ -845,14 +845,9 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   HIPCHK_E(hipSetDevice(device));
   HIPCHK_E(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   {
-    // MJH_COPY_PRIO=1 (experiment): copy and hand-over streams at the greatest priority, i.e. in a hardware-queue pool of their
-    // own.  Measured with 16 libjpeg client threads (tests/native/mt_bench, 4K): no gain with the coalescing shim (1143 vs 1162
-    // images/s), a loss without it and for a single client -- the limit there is the host side (every image is copied into
-    // pinned memory by its client thread and read again by the DMA engine: ~86 GB/s of host DRAM traffic at 1150 images/s).
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    const char *cp = getenv("MJH_COPY_PRIO");
-    e->copy_prio = (cp && atoi(cp) != 0) ? hi : 0;
+    // (copy and hand-over streams at the greatest priority, i.e. in a hardware-queue pool of their own, were measured in round 3
+    // with 16 libjpeg client threads: no gain with the coalescing shim, a loss without it -- default priority)
+    e->copy_prio = 0;
     HIPCHK_E(hipStreamCreateWithPriority(&e->copy_stream, hipStreamNonBlocking, e->copy_prio));
   }
   HIPCHK_E(hipEventCreateWithFlags(&e->copy_done, hipEventDisableTiming));
@@ -882,12 +877,11 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   if (p->trellis_quant && p->trellis_q_opt) HIPCHK_E(mjh_dmalloc((void **)&e->d_qsums, B * 4 * 64 * 2 * sizeof(long long)));
   {
     // sequential mode, one plain trellis round: the trellis hands compact records to the final statistics, the bit-length
-    // and the bit-writing pass (MJH_COMPACT=0 keeps the one-plane-per-position form; both are bit-identical)
-    const char *v = getenv("MJH_COMPACT");
+    // and the bit-writing pass (the one-plane-per-position form serves the configurations below; both are bit-identical)
     const int nl = p->trellis_num_loops > 1 ? p->trellis_num_loops : 1;
     bool restart_scans = false;   // progressive: scans with restart intervals go through the sequential walk, which reads one plane per position
     if (e->progressive && (p->restart_interval || p->restart_in_rows)) restart_scans = true;
-    e->use_compact = !(v && atoi(v) == 0) && !p->arith_code && p->trellis_quant && nl == 1 && e->nbands == 1 && !p->trellis_eob_opt && !p->trellis_q_opt &&
+    e->use_compact = !p->arith_code && p->trellis_quant && nl == 1 && e->nbands == 1 && !p->trellis_eob_opt && !p->trellis_q_opt &&
                      (e->progressive ? !restart_scans : !(e->fuse_mask & 2));
     if (e->use_compact) HIPCHK_E(mjh_dmalloc((void **)&e->d_nzmask, B * (size_t)C.total_real_blocks * sizeof(unsigned long long)));
     if (e->use_compact && p->trellis_quant) HIPCHK_E(mjh_dmalloc((void **)&e->d_nq8, B * (size_t)C.total_real_blocks));
@@ -912,9 +906,6 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   if (const char *v = getenv("MJH_TRELLIS_V3")) e->trellis_v3 = atoi(v);
   e->dc_window_ok = 1;
   for (int i = 0; i < C.ncomp; i++) if (p->quantval[p->quant_tbl_no[i]][0] < 5) e->dc_window_ok = 0;
-  e->dc_window_ok |= (getenv("MJH_DC_V2") ? atoi(getenv("MJH_DC_V2")) : 1) << 8;   // bits 8..: which DC trellis kernel (A/B runs)
-  if (const char *v = getenv("MJH_DC_MODE")) e->dc_mode = atoi(v);
-  if (const char *v = getenv("MJH_DC_STATS_SIDE")) e->dc_stats_side = atoi(v);
   if (const char *v = getenv("MJH_DC_SPEC")) e->dc_spec = atoi(v);
   HIPCHK_E(mjh_dmalloc((void **)&e->d_len16, B * (size_t)C.total_mcu_blocks * 2));
   HIPCHK_E(mjh_dmalloc((void **)&e->d_off32, B * (size_t)C.total_mcu_blocks * 4));
@@ -976,7 +967,6 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     for (int k = 0; k < 64; k++) if (hq.q[t][k] > 255) hq.fastdiv[t] = 0;
   }
   for (int i = 0; i < C.ncomp; i++) if (!hq.fastdiv[p->quant_tbl_no[i]]) e->fastdiv_all = 0;
-  if (const char *v = getenv("MJH_FASTDIV")) if (atoi(v) == 0) e->fastdiv_all = 0;   // A/B runs
   HIPCHK_E(hipMemcpy(e->d_quant, &hq, sizeof(hq), hipMemcpyHostToDevice));
   HIPCHK_E(hipMemcpy(e->d_quant_init, &hq, sizeof(hq), hipMemcpyHostToDevice));
 
@@ -1262,8 +1252,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
         HIPCHK_E(mjh_dmalloc((void **)&e->pe.chist, nch * 256 * 4));   // symbol counts per chunk: 1 KB per (scan, image, chunk of 2048 blocks)
         int maxoth = 0;   // scans of a list that are not first-pass AC scans (refinement and DC scans): the refinement masks of their blocks
         for (const mjh_encoder::PList *pl : { &e->pl_phase[0], &e->pl_phase[1], &e->pl_phase[2], &e->pl_phase[3] }) maxoth = pl->npar - pl->nacf > maxoth ? pl->npar - pl->nacf : maxoth;
-        const char *rv = getenv("MJH_PP_RMASK");   // A/B knob: 0 = the sizes and the bits of refinement scans walk the records again
-        if (maxoth > 0 && e->use_compact && !(rv && atoi(rv) == 0)) HIPCHK_E(mjh_dmalloc((void **)&e->pe.rmask, B * (size_t)maxoth * 3 * e->pe.nblk_pad * 8));
+        if (maxoth > 0 && e->use_compact) HIPCHK_E(mjh_dmalloc((void **)&e->pe.rmask, B * (size_t)maxoth * 3 * e->pe.nblk_pad * 8));
       }
     }
     HIPCHK_E(mjh_dmalloc((void **)&e->d_lists, e->h_lists.size() * sizeof(int) + 16));

@@ -1218,11 +1218,6 @@ __device__ __forceinline__ int trellis_q_phase1(const short (&xs)[64], const int
   return nq;
 }
 
-// STATS: the AC symbol statistics of the FINAL coefficients (the reference's last gather pass, jchuff.c:812-915) fall out
-// of the back-track -- a path entry at position pos with predecessor p is the symbol (run = pos-p-1, size of its
-// magnitude) -- so they are counted here instead of by one more pass over the 63 planes: 1 = into an LDS histogram
-// (2 interleaved copies in the dead e_pk rows; the caller zeroes and flushes it), 2 = straight into the global table
-// `counts` of this lane's image/component (deferred tiers: few blocks, any table per lane), 0 = not at all.
 // phases 2.. : nq_in = what phase 1 returned.  `active` false or nq_in > QN: the lane has nothing to do but still takes
 // part in the wave-level loop.
 // EXT: band Ss..Se (the virtual start sits at position Ss-1, positions outside the band are neither read nor written)
@@ -1232,17 +1227,16 @@ __device__ __forceinline__ int trellis_q_phase1(const short (&xs)[64], const int
 // *nz_out = 64-bit mask of its non-zero positions, plane i+1 of the block = its i-th non-zero value in position order --
 // which is all the statistics / bit-length / bit-writing passes behind the trellis need: they then touch as many
 // planes as the busiest block of a wave has non-zero coefficients (~20 at q75) instead of 63.
-template <int QN, bool LDS_ROWS, int STATS, bool EXT = false, bool COMPACT = false>
+template <int QN, bool LDS_ROWS, bool EXT = false, bool COMPACT = false>
 __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float4 *rate_rows, const int (*dqT)[64], const float (*ltT)[64],
                                                int qrow, int nq_in, float azd63, float lambda, bool active, int16_t *__restrict__ qo,
-                                               int kstride, uint2 (*col)[64], unsigned short (*e_pk)[64], int lane, unsigned *counts,
+                                               int kstride, uint2 (*col)[64], unsigned short (*e_pk)[64], int lane,
                                                int Ss = 1, int Se = 63, float2 *__restrict__ eob_out = nullptr, int *__restrict__ eob_has = nullptr,
                                                unsigned long long *__restrict__ nz_out = nullptr,
                                                const int *__restrict__ dq_lane = nullptr, const float *__restrict__ lt_lane = nullptr)
 {
   // dq_lane / lt_lane (EXT only): this lane's own quantizer rows in global memory instead of the LDS copies (per-image tables)
-  static_assert(!(EXT && STATS), "the fused statistics exist for the plain 1..63 pass only");
-  static_assert(!(COMPACT && (EXT || STATS)), "compact records exist for the plain pass without fused statistics");
+  static_assert(!(COMPACT && EXT), "compact records exist for the plain pass");
   const int vstart = EXT ? Ss - 1 : 0;          // position of the virtual start entry
   const int si_f0 = (int)(si_rows[15].x & 0xFFu), si_eob = (int)(si_rows[0].x & 0xFFu);
   const float f0f = si_f0 ? (float)si_f0 : 3e38f;
@@ -1313,15 +1307,7 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
 #pragma unroll
     for (int e2 = 1; e2 <= QN; e2++) pk[e2] = e_pk[e2][lane];
   }
-  if (STATS == 1) {   // every lane of the wave: the e_pk rows are dead now (their words are in registers), they become the histogram
-    typedef unsigned __attribute__((may_alias)) u_alias;
-    u_alias *hz = reinterpret_cast<u_alias *>(&e_pk[0][0]);
-#pragma unroll
-    for (int j = 0; j < 8; j++) hz[j * 64 + lane] = 0u;
-    __syncthreads();
-  }
   if (!work) return;
-  unsigned *hh = STATS == 1 ? counts + (lane & 1) * 256 : counts;
 
   // ---- end-of-block choice (jcdctmgr.c:1187-1207): independent loads of every live entry, then the scan in position order
   float best_cost = azd63 + (float)si_eob;
@@ -1374,7 +1360,6 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
     int p = last;
     unsigned long long pmask = 0ull;   // COMPACT: positions on the path; their values go to slots 0,1,.. in visiting (descending) order
     int cnt = 0;
-    if (STATS) { if (last < 63) atomicAdd(&hh[0], 1u); }      // trailing zeros (or an all-zero block): EOB
     if (QN <= 24) {
       if (!COMPACT) {
 #pragma unroll
@@ -1392,11 +1377,6 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
             colh[((slot >> 2) * 64 + lane) * 4 + (slot & 3)] = (unsigned short)v;
             if (COMPACT) { pmask |= 1ull << pos; cnt++; }
             p = (int)(pk[e2] & 63u);
-            if (STATS) {
-              const int run = pos - p - 1;
-              if (run > 15) atomicAdd(&hh[0xF0], (unsigned)(run >> 4));
-              atomicAdd(&hh[((run & 15) << 4) + bitlen((unsigned)mag)], 1u);
-            }
           }
         }
       }
@@ -1416,11 +1396,6 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
           colh[((slot >> 2) * 64 + lane) * 4 + (slot & 3)] = (unsigned short)v;
           if (COMPACT) { pmask |= 1ull << pos; cnt++; }
           p = (int)(pkv & 63u);
-          if (STATS) {
-            const int run = pos - p - 1;
-            if (run > 15) atomicAdd(&hh[0xF0], (unsigned)(run >> 4));
-            atomicAdd(&hh[((run & 15) << 4) + bitlen((unsigned)mag)], 1u);
-          }
         }
       }
     }
@@ -1749,17 +1724,16 @@ struct MjhTrellisExt {
   int qstride;        // EXT instantiations: 1 = one MjhQuant per image (trellis_q_opt re-estimates the tables between passes), 0 = shared
 };
 
-template <int QN, bool FSTATS, bool EXT = false, bool COMPACT = false>   // FSTATS: count the AC symbols of the final coefficients (sequential mode, last trellis round)
+template <int QN, bool EXT = false, bool COMPACT = false>
 __global__ void __launch_bounds__(64)
 k_trellis_ac_q(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
                int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
                int4 ac_slot_of_comp, int4 wave0_of_comp, const float *__restrict__ lambda_in, unsigned *__restrict__ worklist,
-               int16_t *__restrict__ dense, unsigned dense_cap, MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp,
-               MjhTrellisExt ext)
+               int16_t *__restrict__ dense, unsigned dense_cap, MjhTrellisExt ext)
 {
   static_assert(QN >= 16 && QN <= 63, "queue capacity");
   __shared__ uint2 col[QN][64];                  // queue records, then live entries {azd, acc}, then the value column
-  __shared__ unsigned short e_pk[QN + 1][64];    // back position | magnitude << 6 of live entry e; then the symbol histogram
+  __shared__ unsigned short e_pk[QN + 1][64];    // back position | magnitude << 6 of live entry e
   __shared__ uint4 si_rows[16];
   __shared__ float4 rate_rows[16];
   __shared__ int dqT[1][64];
@@ -1798,37 +1772,21 @@ k_trellis_ac_q(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__rest
   }
   __syncthreads();
   int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
-  typedef unsigned __attribute__((may_alias)) u_alias;
-  u_alias *hist = reinterpret_cast<u_alias *>(&e_pk[0][0]);   // 2 x 256 bins, zeroed inside once the e_pk words are in registers
   const size_t gblk = (size_t)img * C.total_real_blocks + cc.blk_off + (inside ? blk : 0);
-  trellis_q_walk<QN, true, FSTATS ? 1 : 0, EXT, COMPACT>(si_rows, rate_rows, dqT, ltT, 0, nq, azd63, lambda, inside, qo, cc.kstride, col, e_pk, lane, (unsigned *)hist,
-                                                         ext.Ss, ext.Se, EXT && ext.eob_cost ? ext.eob_cost + gblk : nullptr, EXT && ext.eob_cost ? ext.eob_has + gblk : nullptr,
-                                                         COMPACT ? ext.nzmask + gblk : nullptr);
-  if (FSTATS) {
-    __syncthreads();
-    const int sslot = comp == 0 ? stat_slot_of_comp.x : comp == 1 ? stat_slot_of_comp.y : comp == 2 ? stat_slot_of_comp.z : stat_slot_of_comp.w;
-    MjhHuffTable *TS = stat_tabs + (size_t)img * slots_per_image + sslot;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int bin = lane + 64 * j;
-      unsigned sum = hist[bin] + hist[256 + bin];
-      // every dummy block of the interleaved scan codes one EOB (all-zero AC, jccoefct.c:312-345): counted once per component
-      if (bin == 0 && wv == w0) sum += (unsigned)(cc.wpad * cc.hpad - cc.nblk);
-      if (sum) atomicAdd(&TS->counts[bin], sum);
-    }
-  }
+  trellis_q_walk<QN, true, EXT, COMPACT>(si_rows, rate_rows, dqT, ltT, 0, nq, azd63, lambda, inside, qo, cc.kstride, col, e_pk, lane,
+                                         ext.Ss, ext.Se, EXT && ext.eob_cost ? ext.eob_cost + gblk : nullptr, EXT && ext.eob_cost ? ext.eob_has + gblk : nullptr,
+                                         COMPACT ? ext.nzmask + gblk : nullptr);
 }
 
 // Deferred blocks (any image / component per lane), same walk with a longer queue: raw coefficients come from the dense
 // copies (one line per block), code lengths from the image's table in global memory (L2-resident), quantizer constants
 // of all four tables from LDS.  Blocks beyond QN2 non-zero positions go to the next list (QN2 = 63 takes everything).
-template <int QN2, bool FSTATS, bool EXT = false, bool COMPACT = false>
+template <int QN2, bool EXT = false, bool COMPACT = false>
 __global__ void __launch_bounds__(64)
 k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
                 int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
                 int4 ac_slot_of_comp, const float *__restrict__ lambda_in, const unsigned *__restrict__ worklist,
-                unsigned *__restrict__ worklist_next, const int16_t *__restrict__ dense, unsigned dense_cap,
-                MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp, MjhTrellisExt ext)
+                unsigned *__restrict__ worklist_next, const int16_t *__restrict__ dense, unsigned dense_cap, MjhTrellisExt ext)
 {
   __shared__ uint2 col[QN2][64];
   __shared__ unsigned short e_pk[QN2 + 1][64];
@@ -1878,11 +1836,9 @@ k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
       if (QN2 < 63) defer_blocks(active && nq > QN2, worklist_next, (unsigned)img, w, ds, xs, nullptr, 0u, false, lane);
     }
     int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
-    const int sslot = comp == 0 ? stat_slot_of_comp.x : comp == 1 ? stat_slot_of_comp.y : comp == 2 ? stat_slot_of_comp.z : stat_slot_of_comp.w;
-    unsigned *cnt = FSTATS ? stat_tabs[(size_t)img * slots_per_image + sslot].counts : nullptr;
     const size_t gblk = (size_t)img * C.total_real_blocks + cc.blk_off + blk;
-    trellis_q_walk<QN2, false, FSTATS ? 2 : 0, EXT, COMPACT>(reinterpret_cast<const uint4 *>(T->ehufsi), nullptr, dqT, ltT, cc.qtbl, nq, azd63, lambda, active, qo, cc.kstride,
-                                                              col, e_pk, lane, cnt, ext.Ss, ext.Se, EXT && ext.eob_cost ? ext.eob_cost + gblk : nullptr,
+    trellis_q_walk<QN2, false, EXT, COMPACT>(reinterpret_cast<const uint4 *>(T->ehufsi), nullptr, dqT, ltT, cc.qtbl, nq, azd63, lambda, active, qo, cc.kstride,
+                                                              col, e_pk, lane, ext.Ss, ext.Se, EXT && ext.eob_cost ? ext.eob_cost + gblk : nullptr,
                                                               EXT && ext.eob_cost ? ext.eob_has + gblk : nullptr, COMPACT ? ext.nzmask + gblk : nullptr,
                                                               EXT && ext.qstride ? (Q + (size_t)img * ext.qstride)->dq8[cc.qtbl] : nullptr,
                                                               EXT && ext.qstride ? (Q + (size_t)img * ext.qstride)->lambda_tbl[cc.qtbl] : nullptr);
@@ -1935,19 +1891,20 @@ __device__ __forceinline__ float4 v3_rate(const float4 *rate_rows, int run)
   return rate_rows[run & 15];
 }
 
-// one step of the walk: the two newest live entries not looked at yet (e-1, e-2; entry 0 = the virtual start, not stored)
+// one step of the walk: the two newest live entries not looked at yet (e-1, e-2).  Entry e lives in slot e; entry 0, the
+// virtual start (position 0, no distortion, no cost), is a slot like the others, written before the walk -- a step has no
+// special case for it (until round 5 it was not stored and every step selected around it: ~10 of its 58 instructions)
 template <int QN, int NC>
 __device__ __forceinline__ void v3_pair(const uint2 (*col)[64], const unsigned short (*info)[64], const float4 *rate_rows, int lane, int e, int im1,
                                         float azd_prev, float f0f, float d0, float d1, float d2, float d3,
                                         float &best, int &beste, int &bestk, float &gap_old)
 {
-  const int ea = e - 1, eb = e >= 2 ? e - 2 : e - 1;
-  const int sa = ea > 0 ? ea - 1 : 0, sb = eb > 0 ? eb - 1 : 0;
-  const uint2 va = col[sa][lane], vb = col[sb][lane];
-  const unsigned ia = info[sa][lane], ib = info[sb][lane];
-  const float azd_a = ea > 0 ? __uint_as_float(va.x) : 0.0f, acc_a = ea > 0 ? __uint_as_float(va.y) : 0.0f;
-  const float azd_b = eb > 0 ? __uint_as_float(vb.x) : 0.0f, acc_b = eb > 0 ? __uint_as_float(vb.y) : 0.0f;
-  const int run_a = im1 - (ea > 0 ? (int)(ia & 63u) : 0), run_b = im1 - (eb > 0 ? (int)(ib & 63u) : 0);
+  const int ea = e - 1, eb = e >= 2 ? e - 2 : 0;        // (e == 1: b repeats a, the same entry: harmless)
+  const uint2 va = col[ea][lane], vb = col[eb][lane];
+  const unsigned ia = info[ea][lane], ib = info[eb][lane];
+  const float azd_a = __uint_as_float(va.x), acc_a = __uint_as_float(va.y);
+  const float azd_b = __uint_as_float(vb.x), acc_b = __uint_as_float(vb.y);
+  const int run_a = im1 - (int)(ia & 63u), run_b = im1 - (int)(ib & 63u);
   const float4 ra = v3_rate<NC>(rate_rows, run_a), rb4 = v3_rate<NC>(rate_rows, run_b);
   const float rba = (float)(run_a >> 4) * f0f, rbb = (float)(run_b >> 4) * f0f;
   const float gap_a = azd_prev - azd_a, gap_b = azd_prev - azd_b;
@@ -1957,30 +1914,25 @@ __device__ __forceinline__ void v3_pair(const uint2 (*col)[64], const unsigned s
   v3_eval<NC>(ra, rba, rhs_a, d0, d1, d2, d3, lba, lka);
   v3_eval<NC>(rb4, rbb, rhs_b, d0, d1, d2, d3, lbb, lkb);
   // newest first, '<=': on equal cost the OLDER predecessor wins, as in the reference's oldest-first strict '<' scan (a cost
-  // without a Huffman code is >= 3e38 and never reaches the initial 1e38); when e == 1, b repeats a (same entry: harmless)
+  // without a Huffman code is >= 3e38 and never reaches the initial 1e38)
   if (lba <= best) { best = lba; beste = ea; bestk = lka; }
   if (lbb <= best) { best = lbb; beste = eb; bestk = lkb; }
   gap_old = gap_b;
 }
 
-// FST (sequential mode, optimal tables): the AC symbol statistics of the FINAL coefficients (the reference's last gather
-// pass, jchuff.c:812-915) fall out of the back-track -- a path entry at position p whose predecessor sits at pp is the
-// symbol (run p-pp-1, category of its magnitude) -- so they are counted here (LDS histogram, flushed once per tile) instead
-// of by one more pass over the compact records; deferred blocks are flagged (nq8 = 0xFF) for k_stats_ac_compact's
-// deferred-only form.
-template <int QN, int NPASS, bool FD, bool FST>
+// (Round 3 also counted the AC symbol statistics of the final coefficients in this kernel's back-track, MJH_FUSE bit 4: the
+// trellis paid 0.4 ms for the 0.33 ms of the separate pass over the compact records; removed in round 5.)
+template <int QN, int NPASS, bool FD>
 __global__ void __launch_bounds__(64)
 k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q,
                 const MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 ac_slot_of_comp, int4 tile0_of_comp,
                 const float *__restrict__ lambda_in, uint8_t *__restrict__ nq8, unsigned *__restrict__ worklist,
-                int16_t *__restrict__ dense, unsigned dense_cap, unsigned long long *__restrict__ nzmask,
-                MjhHuffTable *__restrict__ stat_tabs, int4 stat_slot_of_comp)
+                int16_t *__restrict__ dense, unsigned dense_cap, unsigned long long *__restrict__ nzmask)
 {
   static_assert(QN >= 16 && QN <= 63 && NPASS >= 1 && NPASS <= 8, "queue capacity / passes");
   constexpr int TILE = 64 * NPASS;
-  __shared__ unsigned fhist[FST ? 2 : 1][FST ? 256 : 1];   // FST: two interleaved copies of the symbol histogram of this tile
-  __shared__ uint2 col[QN][64];          // tile sort scratch; per pass: queue records -> live entries {azd, acc} -> value column
-  __shared__ unsigned short info[QN][64];   // live entry e (>= 1) at [e-1]: position | back entry << 6 | magnitude (< 16) << 12 (the signs: one bit per position in a register)
+  __shared__ uint2 col[QN + 1][64];      // tile sort scratch; per pass: queue records (record r in slot r) -> live entries {azd, acc} (entry e in slot e; 0 = the virtual start) -> value column
+  __shared__ unsigned short info[QN + 1][64];   // live entry e at [e]: position | back entry << 6 | magnitude (< 16) << 12 (the signs: one bit per position in a register)
   __shared__ float4 rate_rows[16];
   typedef unsigned __attribute__((may_alias)) u_alias;
   typedef unsigned short __attribute__((may_alias)) us_alias;
@@ -1998,10 +1950,6 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
   const int dq_lane = Q->dq8[cc.qtbl][lane];                    // lane k holds the row entry of position k (ds_bpermute lookups)
   const float lt_lane = Q->lambda_tbl[cc.qtbl][lane];
 
-  if (FST) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) (&fhist[0][0])[j * 64 + lane] = 0u;
-  }
   // ---- tile sort: descending key; perm entry = index in tile | key << 9 ----
   unsigned long long mine0 = 0ull, mine1 = 0ull;
   {
@@ -2048,7 +1996,6 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     const size_t gblk = gblk0 + (inside ? blk : 0);
     if (__builtin_amdgcn_ballot_w64(inside && (pe >> 9) != 0u) == 0ull) {   // nothing quantizes to non-zero: all-zero blocks
       if (inside) nzmask[gblk] = 0ull;
-      if (FST && inside) atomicAdd(&fhist[lane & 1][0], 1u);                  // every one of them codes an EOB
       continue;
     }
     const float lambda = lambda_in[gblk0 + (inside ? blk : cc.nblk - 1)];
@@ -2085,7 +2032,6 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
       count_heavy(worklist, inside, nq, lane);
     }
     const bool work = inside && nq <= QN && qmax < 16;
-    if (FST && inside && !work) nq8[gblk] = 0xFFu;     // deferred: its statistics are counted from its records (k_stats_ac_compact, deferred-only form)
 
     // ---- the walk: every lane consumes its own records, one record per round; the next record is always one load ahead ----
     int nlive = 1, qi = 0, last = 0;
@@ -2095,6 +2041,8 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     float azd_prev = 0.0f, azd_cur = 0.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f, best = 1e38f;
     float end_best = azd63 + eobf;
     uint2 rec_n = col[0][lane];
+    col[0][lane] = make_uint2(0u, 0u);     // record 0 is in registers: its slot becomes entry 0, the virtual start (position 0, azd 0, cost 0)
+    info[0][lane] = (unsigned short)0;
     // quantizer constants of the NEXT record's position: lane k holds entry k of the component's rows, fetched with ds_bpermute
     // at a point where every lane of the wave is enabled (a disabled source lane would read as 0)
     int dq_n = 1;
@@ -2105,10 +2053,12 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
       lt_n = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(lt_lane)));
     };
     lookup();
-    auto setup = [&]() {
+    // `wide`: some lane of the round has a record with more than two candidates (quantized magnitude >= 4); without one, the
+    // round's steps evaluate two candidates and the distortions of the other two are not computed
+    auto setup = [&](bool wide) {
       const uint2 rec = rec_n;
       qi++;
-      rec_n = col[qi < QN ? qi : QN - 1][lane];      // (slots behind the consumed ones are never overwritten: entry e lives in slot e-1 <= qi-1)
+      rec_n = col[qi][lane];      // qi <= nq <= QN: slot QN exists (a slot is overwritten only after its record was consumed: entry e lives in slot e <= qi - 1 when it is written, and record qi - 1 is in registers by then)
       i = (int)(rec.x & 63u); sgn = (int)((rec.x >> 6) & 1u); qval = (int)((rec.x >> 7) & 1023u); x = (int)(rec.x >> 17);
       azd_prev = __uint_as_float(rec.y);
       const int dq = dq_n;
@@ -2117,9 +2067,10 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
       t = t * lti;
       azd_cur = t + azd_prev;
       ncd = bitlen((unsigned)qval);
-      float dd[4];
+      float dd[4] = { 3e38f, 3e38f, 3e38f, 3e38f };
 #pragma unroll
       for (int k = 0; k < 4; k++) {
+        if (k >= 2 && !wide) break;      // uniform
         const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
         const int delta = mul24(cand, dq) - x;
         const float d = (float)mul24(delta, delta) * lambda;      // (|delta| <= x < 2^15)
@@ -2128,7 +2079,9 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
       d0 = dd[0]; d1 = dd[1]; d2 = dd[2]; d3 = dd[3];
       e = nlive; best = 1e38f; beste = -1; bestk = 0;
     };
-    if (act) setup();
+    auto next_wide = [&]() { return __builtin_amdgcn_ballot_w64(act && qi < nq && ((rec_n.x >> 7) & 1023u) >= 4u) != 0ull; };   // of the records about to be set up
+    bool wide = next_wide();
+    if (act) setup(wide);
     // One ROUND per queue record.  A round is the scan of the lane's live entries for its current record (pair steps, run
     // until the last lane's scan has ended) and then, at a point where the wave is whole again, the commit of the new entry and
     // the setup of the next record for every working lane at once.  (Until round 5 a lane committed and set up as soon as its own
@@ -2136,7 +2089,6 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     // for a handful of lanes -- tools/model_sched.py: 0.74 of the issued instructions this way.)  The same operations per lane
     // in the same order: the files do not change.  Every working lane is at record `qi` of its queue in the same round.
     while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
-      const bool wide = __builtin_amdgcn_ballot_w64(act && ncd > 2) != 0ull;     // some lane has more than two candidates this round
       bool scan = act;
       while (__builtin_amdgcn_ballot_w64(scan) != 0ull) {
         if (scan) {
@@ -2150,11 +2102,12 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
         }
       }
       lookup();
+      const bool wide_n = next_wide();
       if (act) {
         if (beste >= 0) {
           const int mag = (bestk < ncd - 1) ? (2 << bestk) - 1 : qval;
-          col[nlive - 1][lane] = make_uint2(__float_as_uint(azd_cur), __float_as_uint(best));     // live entry nlive
-          info[nlive - 1][lane] = (unsigned short)((unsigned)i | ((unsigned)beste << 6) | ((unsigned)mag << 12));
+          col[nlive][lane] = make_uint2(__float_as_uint(azd_cur), __float_as_uint(best));     // live entry nlive
+          info[nlive][lane] = (unsigned short)((unsigned)i | ((unsigned)beste << 6) | ((unsigned)mag << 12));
           neg |= (unsigned long long)sgn << i;
           // end-of-block choice (jcdctmgr.c:1187-1207): entries appear in position order, strict '<' keeps the first minimum
           float c = best + azd63;
@@ -2164,38 +2117,24 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
           nlive++;
         }
         if (qi >= nq) act = false;
-        else setup();
+        else setup(wide_n);
       }
+      wide = wide_n;
     }
 
     // ---- back-track (jcdctmgr.c:1211-1222) along the entry indices; values in visiting (descending position) order ----
     unsigned long long pmask = 0ull;
     int cnt = 0, e2 = work ? last : 0;
-    int up_pos = -1, up_mag = 0;          // FST: the path entry visited before this one (the next higher position)
-    unsigned *hh = fhist[FST ? (lane & 1) : 0];
-    auto count = [&](int run, int mag) {  // symbol of a coefficient of magnitude `mag` behind `run` zeros (jchuff.c:833-868)
-      if (run > 15) { atomicAdd(&hh[0xF0], (unsigned)(run >> 4)); run &= 15; }
-      atomicAdd(&hh[(run << 4) + bitlen((unsigned)mag)], 1u);
-    };
     while (__builtin_amdgcn_ballot_w64(e2 > 0) != 0ull) {
       if (e2 > 0) {
-        const unsigned inf = info[e2 - 1][lane];
+        const unsigned inf = info[e2][lane];
         const int mag = (int)(inf >> 12), pos = (int)(inf & 63u);
         const int v = ((neg >> pos) & 1ull) ? -mag : mag;
         colh[((cnt >> 2) * 64 + lane) * 4 + (cnt & 3)] = (unsigned short)v;
         pmask |= 1ull << pos;
         cnt++;
-        if (FST) {
-          if (up_pos >= 0) count(up_pos - pos - 1, up_mag);
-          else if (pos < 63) atomicAdd(&hh[0], 1u);          // the highest kept position is not 63: EOB
-          up_pos = pos; up_mag = mag;
-        }
         e2 = (int)((inf >> 6) & 63u);
       }
-    }
-    if (FST && work) {
-      if (up_pos >= 0) count(up_pos - 1, up_mag);            // the lowest kept position: its run starts behind the DC coefficient
-      else atomicAdd(&hh[0], 1u);                            // nothing kept: EOB
     }
     if (work) nzmask[gblk] = pmask;
     {
@@ -2211,18 +2150,6 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
       }
     }
     __syncthreads();
-  }
-  if (FST) {
-    const int sslot = comp == 0 ? stat_slot_of_comp.x : comp == 1 ? stat_slot_of_comp.y : comp == 2 ? stat_slot_of_comp.z : stat_slot_of_comp.w;
-    MjhHuffTable *TS = stat_tabs + (size_t)img * slots_per_image + sslot;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int bin = lane + 64 * j;
-      unsigned sum = fhist[0][bin] + fhist[1][bin];
-      // every dummy block of the interleaved scan codes one EOB (all-zero AC, jccoefct.c:312-345): counted once per component
-      if (bin == 0 && tl == t0) sum += (unsigned)(cc.wpad * cc.hpad - cc.nblk);
-      if (sum) atomicAdd(&TS->counts[bin], sum);
-    }
   }
 }
 
@@ -2245,157 +2172,8 @@ __device__ __forceinline__ float grp_shfl_f(float v, int srclane_in_group, int l
   return __shfl(v, (lane & ~15) | srclane_in_group, 64);
 }
 
-__global__ void __launch_bounds__(64)
-k_trellis_dc(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
-             int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
-             int4 dc_slot_of_comp, const float *__restrict__ lambda_in, uint8_t *__restrict__ back)
-{
-  const int img = blockIdx.y;
-  const int lane = threadIdx.x;
-  MJH_WAVE_GROUPS(16);
-  const int k = lane & 15;
-  const int chain = blockIdx.x * 4 + (lane >> 4);
-  const int nchains = C.ncomp * C.mcu_rows;
-  if (chain >= nchains) return;   // whole 16-lane groups leave together
-  const int comp = chain / C.mcu_rows, imcu = chain - comp * C.mcu_rows;
-  const MjhComp cc = C.c[comp];
-  const int slot = comp == 0 ? dc_slot_of_comp.x : comp == 1 ? dc_slot_of_comp.y : comp == 2 ? dc_slot_of_comp.z : dc_slot_of_comp.w;
-  const MjhHuffTable *T = tabs + (size_t)img * slots_per_image + slot;
-  unsigned long long dsi = 0;   // 12 DC code lengths, 5 bits each
-  for (int s = 0; s < 12; s++) dsi |= (unsigned long long)(T->ehufsi[s] & 31) << (5 * s);
-  const int q0 = Q->q[cc.qtbl][0];
-  const int dq = 8 * q0;
-  const float rcp = Q->rcp8q[cc.qtbl][0];
-  const float lt0 = Q->lambda_tbl[cc.qtbl][0];
-  int ncand = (2 + 60 / q0) | 1;                 // get_num_dc_trellis_candidates :930-933
-  if (ncand > 9) ncand = 9;
-  const int16_t *uq0 = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off;  // plane k = 0
-  int16_t *qo0 = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;
-  const float *lam = lambda_in + (size_t)img * C.total_real_blocks + cc.blk_off;
-  uint8_t *bk = back + ((size_t)img * C.total_real_blocks + cc.blk_off) * 16;
-  const bool live = k < ncand;
-  int last_dc = 0;
-  for (int sub = 0; sub < cc.v; sub++) {
-    const int br = imcu * cc.v + sub;
-    if (br >= cc.hib) break;
-    const int row0 = br * cc.wib;
-    int prev_c = 0;
-    float prev_cost = 0.0f;
-    int xs_l = 0, above_l = 0;
-    float lam_l = 0.0f;
-    // trellis_delta_dc_weight: the block above counts only inside an iMCU row (compress_trellis_pass jccoefct.c:426-427
-    // passes buffer[block_row-1], NULL for the first row); its quantized DC was written by this group's own back-track
-    // of the previous sub-row (made visible by the fence below)
-    const bool vert = sub > 0 && C.delta_dc_weight > 0.0f;
-    for (int bi = 0; bi < cc.wib; bi++) {
-      // every 16 blocks the group fetches the next 16 (DC, lambda) pairs with one coalesced load
-      // per lane; the sequential recursion then only sees cross-lane shuffles, never HBM latency
-      if ((bi & 15) == 0) {
-        const int b = bi + k;
-        xs_l = b < cc.wib ? (int)uq0[row0 + b] : 0;
-        lam_l = b < cc.wib ? lam[row0 + b] : 0.0f;
-        if (vert && b < cc.wib)   // raw DC above (low half) and the gradient's reconstructed part: final quantized DC above * 8q (high half)
-          above_l = ((int)uq0[row0 - cc.wib + b] & 0xFFFF) |
-                    ((int)__hip_atomic_load(reinterpret_cast<const unsigned short *>(qo0 + row0 - cc.wib + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 16);
-      }
-      const int xs = grp_shfl(xs_l, bi & 15, lane);
-      const float lambda_dc = grp_shfl_f(lam_l, bi & 15, lane) * lt0;
-      const int x = xs < 0 ? -xs : xs;
-      const int qval = udiv_exact(x + (dq >> 1), dq, rcp);
-      int cnd = qval - ncand / 2 + k;
-      cnd = min(1023, max(-1023, cnd));
-      const int delta = mul24(cnd, dq) - x;
-      float dist = (float)mul24(delta, delta) * lambda_dc;
-      if (xs < 0) cnd = -cnd;
-      if (vert) {   // jcdctmgr.c:1069-1084
-        const int ab = grp_shfl(above_l, bi & 15, lane);
-        const int dc_above_orig = (int)(short)(ab & 0xFFFF), dc_above_recon = (ab >> 16) * dq;
-        const int d2 = (dc_above_orig - xs) - (dc_above_recon - cnd * dq);
-        const float vertical_dist = (float)(d2 * d2) * lambda_dc;
-        float t = vertical_dist - dist;
-        t = C.delta_dc_weight * t;
-        dist = dist + t;
-      }
-      float best;
-      int bb = 0;
-      if (bi == 0) {
-        const int df = cnd - last_dc;
-        const int bits = bitlen((unsigned)(df < 0 ? -df : df));
-        best = (float)(bits + (int)((dsi >> (5 * bits)) & 31)) + dist;
-      } else {
-        // all 18 cross-lane reads are issued back to back (fully unrolled), then 9 independent
-        // cost evaluations; the first-minimum scan over l keeps the reference's strict '<' order
-        int pcs[9];
-        float pcosts[9];
-#pragma unroll
-        for (int l = 0; l < 9; l++) {
-          pcs[l] = grp_shfl(prev_c, l, lane);
-          pcosts[l] = grp_shfl_f(prev_cost, l, lane);
-        }
-        float costs[9];
-#pragma unroll
-        for (int l = 0; l < 9; l++) {
-          const int df = cnd - pcs[l];
-          const int bits = bitlen((unsigned)(df < 0 ? -df : df));
-          float cost = (float)(bits + (int)((dsi >> (5 * bits)) & 31)) + dist;
-          costs[l] = cost + pcosts[l];
-        }
-        best = costs[0];
-#pragma unroll
-        for (int l = 1; l < 9; l++)
-          if (l < ncand && costs[l] < best) { best = costs[l]; bb = l; }
-      }
-      prev_c = cnd;
-      prev_cost = best;
-      bk[(size_t)(row0 + bi) * 16 + k] = (uint8_t)bb;
-    }
-    // first minimum over the live candidates (:1309-1313)
-    int j = 0;
-    {
-      float bc = grp_shfl_f(prev_cost, 0, lane);
-      for (int l = 1; l < ncand; l++) {
-        const float c = grp_shfl_f(prev_cost, l, lane);
-        if (c < bc) { bc = c; j = l; }
-      }
-    }
-    __threadfence_block();
-    // back-track, 16 blocks per step: lane k owns block top-k
-    for (int top = cc.wib - 1; top >= 0; top -= 16) {
-      const int b = top - k;
-      int qv = 0, neg = 0;
-      uint4 w = make_uint4(0, 0, 0, 0);
-      if (b >= 0) {
-        const int xs = uq0[row0 + b];
-        const int x = xs < 0 ? -xs : xs;
-        neg = xs < 0;
-        qv = udiv_exact(x + (dq >> 1), dq, rcp);
-        w = *reinterpret_cast<const uint4 *>(bk + (size_t)(row0 + b) * 16);
-      }
-      int myj = 0;
-      const int steps = min(16, top + 1);
-      for (int s = 0; s < steps; s++) {
-        if (k == s) myj = j;
-        const unsigned word = j < 4 ? w.x : (j < 8 ? w.y : w.z);
-        const int nj = (int)((word >> (8 * (j & 3))) & 0xFF);
-        j = grp_shfl(nj, s, lane);
-      }
-      if (b >= 0) {
-        int cnd = qv - ncand / 2 + myj;
-        cnd = min(1023, max(-1023, cnd));
-        if (neg) cnd = -cnd;
-        qo0[row0 + b] = (int16_t)cnd;
-        if (b == cc.wib - 1) last_dc = cnd;
-      }
-    }
-    last_dc = grp_shfl(last_dc, 0, lane);  // owner of block wib-1 is lane 0 of the first step
-    if (C.delta_dc_weight > 0.0f) __threadfence();   // the next sub-row reads this row's final DC values back (other lanes of the group)
-    else __threadfence_block();
-    (void)live;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// K6 v2: the same recursion with the cross-lane traffic on DPP.  Measured on the first version (profiles/r03a): a luma chain
+// K6 v2: the recursion with the cross-lane traffic on DPP.  Measured on the first version (ds_bpermute shuffles, removed in round 5; profiles/r03a): a luma chain
 // of 960 sequential steps ran at ~2250 cycles per step, because the compiler serialised its 18 ds_bpermute round trips (LDS
 // latency each) inside the dependent chain; 1.69 ms per 64 4K frames even with the GPU to itself -- longer than the AC kernel
 // it is supposed to hide under.  Here a 16-lane group is one DPP row: the nine predecessor (value, cost) pairs arrive through
@@ -3160,105 +2938,8 @@ struct MarkerCursor {
   }
 };
 
-template <bool COMPACT>
-__global__ void __launch_bounds__(256)
-k_enc_write(MjhConst C, const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask, const MjhHuffTable *__restrict__ tabs,
-            int slots_per_image, int4 dc_slot_of_comp, int4 ac_slot_of_comp,
-            const unsigned *__restrict__ off32, unsigned *__restrict__ stream, size_t stream_words_per_image,
-            const unsigned *__restrict__ seg_E, unsigned *__restrict__ mpos, int nseg)
-{
-  __shared__ unsigned s_ac[256];   // size << 16 | code
-  __shared__ unsigned s_dc[32];
-  const int comp = blockIdx.y, img = blockIdx.z;
-  const MjhComp cc = C.c[comp];
-  const int tid = threadIdx.x;
-  const int dslot = comp == 0 ? dc_slot_of_comp.x : comp == 1 ? dc_slot_of_comp.y : comp == 2 ? dc_slot_of_comp.z : dc_slot_of_comp.w;
-  const int aslot = comp == 0 ? ac_slot_of_comp.x : comp == 1 ? ac_slot_of_comp.y : comp == 2 ? ac_slot_of_comp.z : ac_slot_of_comp.w;
-  const MjhHuffTable *TD = tabs + (size_t)img * slots_per_image + dslot;
-  const MjhHuffTable *TA = tabs + (size_t)img * slots_per_image + aslot;
-  s_ac[tid] = ((unsigned)TA->ehufsi[tid] << 16) | TA->ehufco[tid];
-  if (tid < 32) s_dc[tid] = tid < 16 ? ((unsigned)TD->ehufsi[tid] << 16) | TD->ehufco[tid] : 0u;
-  __syncthreads();
-  const int t = blockIdx.x * 256 + tid;
-  if (t >= cc.wpad * cc.hpad) return;
-  const int r = t / cc.wpad, c = t - r * cc.wpad;
-  const int16_t *q = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;
-  const int dc = q[dc_source_block(cc, r, c)];
-  int pr, pc, pred = 0;
-  if (mcu_prev_block(C, cc, r, c, pr, pc)) pred = q[dc_source_block(cc, pr, pc)];
-  BitWriter bw;
-  const int mcu = (r / cc.v) * C.mcus_per_row + c / cc.h;
-  const int segi = C.restart_interval ? mcu / C.restart_interval : 0;
-  bw.init(stream + (size_t)img * stream_words_per_image,
-          off32[(size_t)img * C.total_mcu_blocks + mcu_position(C, cc, r, c)] +
-          (nseg > 1 ? seg_E[(size_t)img * nseg + segi] : 0u));
-  {
-    const int df = dc - pred;
-    const int a = df < 0 ? -df : df;
-    const int nb = bitlen((unsigned)a);
-    const unsigned e = s_dc[nb];
-    bw.put(e & 0xFFFF, (int)(e >> 16));
-    if (nb) bw.put((unsigned)(df < 0 ? df - 1 : df), nb);
-  }
-  const bool real = r < cc.hib && c < cc.wib;
-  if (COMPACT) {
-    const int b = real ? r * cc.wib + c : 0;
-    const unsigned long long m = nzmask[(size_t)img * C.total_real_blocks + cc.blk_off + b];
-    int prev = 0;
-    for_each_nonzero(q + b, (size_t)cc.kstride, m, real, [&](int pos, int v) {
-      int run = pos - prev - 1;
-      prev = pos;
-      while (run > 15) { const unsigned e = s_ac[0xF0]; bw.put(e & 0xFFFF, (int)(e >> 16)); run -= 16; }
-      const int a = v < 0 ? -v : v;
-      const int nbv = bitlen((unsigned)a);
-      const unsigned e = s_ac[(run << 4) + nbv];
-      bw.put(e & 0xFFFF, (int)(e >> 16));
-      bw.put((unsigned)(v < 0 ? v - 1 : v), nbv);
-    });
-    if (!real || prev < 63) { const unsigned e = s_ac[0]; bw.put(e & 0xFFFF, (int)(e >> 16)); }
-  } else {
-  int x[64];
-  {
-    const int16_t *qb = q + (real ? r * cc.wib + c : 0);
-#pragma unroll
-    for (int k = 1; k < 64; k++) x[k] = qb[(size_t)k * cc.kstride];
-  }
-  if (real) {
-    int run = 0;
-#pragma unroll
-    for (int k = 1; k < 64; k++) {
-      const int v = x[k];
-      if (v == 0) run++;
-      else {
-        while (run > 15) { const unsigned e = s_ac[0xF0]; bw.put(e & 0xFFFF, (int)(e >> 16)); run -= 16; }
-        const int a = v < 0 ? -v : v;
-        const int nb = bitlen((unsigned)a);
-        const unsigned e = s_ac[(run << 4) + nb];
-        bw.put(e & 0xFFFF, (int)(e >> 16));
-        bw.put((unsigned)(v < 0 ? v - 1 : v), nb);
-        run = 0;
-      }
-    }
-    if (run > 0) { const unsigned e = s_ac[0]; bw.put(e & 0xFFFF, (int)(e >> 16)); }
-  } else {
-    const unsigned e = s_ac[0];
-    bw.put(e & 0xFFFF, (int)(e >> 16));
-  }
-  }
-  if (C.restart_interval && segi < nseg - 1 && (mcu + 1) % C.restart_interval == 0 &&
-      cc.mcu_blk0 + (r % cc.v) * cc.h + (c % cc.h) == C.blocks_per_mcu - 1) {
-    // last block of a restart interval: pad with 1-bits, then RSTn (n = interval index mod 8)
-    const unsigned bitpos = bw.widx * 32u + (unsigned)bw.nacc;
-    const int pad = (int)((8u - (bitpos & 7u)) & 7u);
-    if (pad) bw.put((1u << pad) - 1u, pad);
-    mpos[(size_t)img * nseg + segi] = (bitpos + (unsigned)pad) >> 3;
-    bw.put(0xFFD0u + (unsigned)(segi & 7), 16);
-  }
-  bw.flush();
-}
-
 // ---------------------------------------------------------------------------------------------
-// Bit writer, second form: the workgroup's window.  k_enc_write above ORs every finished 32-bit word of every block
+// Bit writer: the workgroup's window.  The first form (k_enc_write, removed in round 5) ORed every finished 32-bit word of every block
 // straight into HBM with a memory-side atomic (measured: 635 MB of "write traffic" per 64 4K frames for a 53 MB stream, 84 %
 // of the wave time waiting).  Here the threads of a workgroup take 256 CONSECUTIVE positions of the scan (MCU order), so
 // the workgroup owns one contiguous bit range [offset of its first block, offset of the next workgroup's first block):
@@ -3721,7 +3402,7 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
 }
 
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
-                           unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
+                           unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
                            uint8_t *nq8, int v3_passes, int fastdiv)
 {
@@ -3731,87 +3412,53 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   MjhTrellisExt ext;
   ext.Ss = Ss; ext.Se = Se; ext.eob_cost = (float2 *)eob_cost; ext.eob_has = eob_has; ext.nzmask = nzmask; ext.qstride = qstride;
   const int4 sl = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
-  // stat_slot != nullptr: the statistics of the final coefficients go to these table slots (one per component)
-  MjhHuffTable *st = stat_slot ? tabs : nullptr;
-  const int4 ss = stat_slot ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
   hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, worklist, worklist2);   // (a 16-byte hipMemsetAsync costs ~80 us of stream time)
   int w0[5] = { 0, 0, 0, 0, 0 };
   for (int i = 0; i < 4; i++) w0[i + 1] = w0[i] + (i < C.ncomp ? (C.c[i].nblk + 63) / 64 : 0);
   dim3 gridq(w0[C.ncomp], n);
   for (int i = C.ncomp; i < 4; i++) w0[i] = 0x7FFFFFFF;   // components that do not exist never match
   const int4 wv = make_int4(w0[0], w0[1], w0[2], w0[3]);
-#define LQ(QN, FS) hipLaunchKernelGGL((k_trellis_ac_q<QN, FS>), gridq, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, wv, lambda, worklist, (int16_t *)dense, dense_cap, st, ss, ext)
-#define LD(QN, FS, GRID, WL, WLN) hipLaunchKernelGGL((k_trellis_ac_qd<QN, FS>), dim3(GRID), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda, (const unsigned *)WL, WLN, (const int16_t *)dense, dense_cap, st, ss, ext)
-  if (extended) {   // the rarely used options take one fixed tiering (16 -> 32 -> 63); the fused statistics do not exist here
-    hipLaunchKernelGGL((k_trellis_ac_q<16, false, true>), gridq, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, wv, lambda,
-                       worklist, (int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
-    hipLaunchKernelGGL((k_trellis_ac_qd<32, false, true>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
-                       (const unsigned *)worklist, worklist2, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
-    hipLaunchKernelGGL((k_trellis_ac_qd<63, false, true>), dim3(1024), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
-                       (const unsigned *)worklist2, (unsigned *)nullptr, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
-    return;
-  }
-  // MJH_TRELLIS_VARIANT: queue capacity of the first tier: 0 = 16, 1 = 20 (24 in the tile-sorted kernel), 2 = 24, 3 = 32 (all bit-identical);
-  // second and third tier: blocks with more than QN (then 32) non-zero positions, from their dense copies
-  if (nzmask && nq8 && v3_passes > 0 && variant <= 4) {
-    // the tile-sorted kernel: first tier of the plain compact pass; its work list (more than 16 records, or a magnitude >= 16)
-    // goes through the general tiers below
-    // one or two frames (the caller asks for one pass per tile then): occupancy is no concern on an empty chip, and with 24 records
+  // the general tiers behind a first tier: blocks with more than its capacity (then 32) queue records, from their dense copies
+#define LQ(QN, EXTV, CMP) hipLaunchKernelGGL((k_trellis_ac_q<QN, EXTV, CMP>), gridq, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, wv, lambda, worklist, (int16_t *)dense, dense_cap, ext)
+#define LD(QN, EXTV, CMP, GRID, WL, WLN) hipLaunchKernelGGL((k_trellis_ac_qd<QN, EXTV, CMP>), dim3(GRID), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda, (const unsigned *)WL, WLN, (const int16_t *)dense, dense_cap, ext)
+  if (extended) {   // the rarely used options take one fixed tiering (16 -> 32 -> 63)
+    LQ(16, true, false);
+    LD(32, true, false, 2048, worklist, worklist2);
+    LD(63, true, false, 1024, worklist2, (unsigned *)nullptr);
+  } else if (nzmask && nq8 && v3_passes > 0 && variant <= 4) {
+    // MJH_TRELLIS_VARIANT: queue capacity of the first tier: 0 = 16, 1 / 2 = 24, 3 = 32, 4 = 48 (all bit-identical).
+    // The tile-sorted kernel: first tier of the plain compact pass; its work list (more records than its capacity, or a
+    // magnitude >= 16) goes through the general tiers below.
+    // One or two frames (the caller asks for one pass per tile then): occupancy is no concern on an empty chip, and with 24 records
     // next to nothing is left for the general tiers, whose fixed latency (~80 us) would sit on the critical path
-    const bool small24 = v3_passes == 1 && variant <= 2 && !st && fastdiv;
+    const bool small24 = v3_passes == 1 && variant <= 2 && fastdiv;
     if (small24) variant = 2;
-    const int np = small24 ? 1 : (!fastdiv || st || variant > 0) ? 4 : v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
+    const int np = small24 ? 1 : (!fastdiv || variant > 0) ? 4 : v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
     int t0[5] = { 0, 0, 0, 0, 0 };
     for (int i = 0; i < 4; i++) t0[i + 1] = t0[i] + (i < C.ncomp ? (C.c[i].nblk + 64 * np - 1) / (64 * np) : 0);
     dim3 gridt(t0[C.ncomp], n);
     for (int i = C.ncomp; i < 4; i++) t0[i] = 0x7FFFFFFF;
     const int4 tv = make_int4(t0[0], t0[1], t0[2], t0[3]);
-#define LV3Q(QN, NP, FDV, FSV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, NP, FDV, FSV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask, st, ss)
-#define LV3(NP, FDV, FSV) LV3Q(16, NP, FDV, FSV)
-    if (small24) LV3Q(24, 1, true, false);
-    else if (variant >= 3 && !st) {   // q90 and up: 32 / 48 records (20 / 30 KB of LDS per wave)
-      if (variant == 3) { if (fastdiv) LV3Q(32, 4, true, false); else LV3Q(32, 4, false, false); }
-      else if (fastdiv) LV3Q(48, 4, true, false); else LV3Q(48, 4, false, false);
-    } else if (variant > 0) {   // more records per block (higher qualities): the 24-record instantiation, 4 passes
-      if (st) { if (fastdiv) LV3Q(24, 4, true, true); else LV3Q(24, 4, false, true); }
-      else if (fastdiv) LV3Q(24, 4, true, false); else LV3Q(24, 4, false, false);
-    } else if (st) { if (fastdiv) LV3(4, true, true); else LV3(4, false, true); }     // statistics of the final coefficients counted in the back-track
-    else if (!fastdiv) LV3(4, false, false);
-    else switch (np) { case 8: LV3(8, true, false); break; case 4: LV3(4, true, false); break; case 2: LV3(2, true, false); break; default: LV3(1, true, false); break; }
+#define LV3(QN, NP, FDV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, NP, FDV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask)
+    if (small24) LV3(24, 1, true);
+    else if (variant >= 4) { if (fastdiv) LV3(48, 4, true); else LV3(48, 4, false); }      // q90 and up: 32 / 48 records (21 / 31 KB of LDS per wave)
+    else if (variant == 3) { if (fastdiv) LV3(32, 4, true); else LV3(32, 4, false); }
+    else if (variant > 0) { if (fastdiv) LV3(24, 4, true); else LV3(24, 4, false); }       // more records per block (higher qualities)
+    else if (!fastdiv) LV3(16, 4, false);
+    else switch (np) { case 8: LV3(16, 8, true); break; case 4: LV3(16, 4, true); break; case 2: LV3(16, 2, true); break; default: LV3(16, 1, true); break; }
 #undef LV3
-#undef LV3Q
-    if (variant >= 3 && !st)   // what is left has more than 32 records or a magnitude >= 16: one general tier that takes everything
-      hipLaunchKernelGGL((k_trellis_ac_qd<63, false, false, true>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
-                         (const unsigned *)worklist, (unsigned *)nullptr, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
-    else {
-    hipLaunchKernelGGL((k_trellis_ac_qd<32, false, false, true>), dim3(2048), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
-                       (const unsigned *)worklist, worklist2, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
-    hipLaunchKernelGGL((k_trellis_ac_qd<63, false, false, true>), dim3(1024), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda,
-                       (const unsigned *)worklist2, (unsigned *)nullptr, (const int16_t *)dense, dense_cap, (MjhHuffTable *)nullptr, ss, ext);
-    }
-    if (st) {   // the deferred blocks' symbols, from the records the general tiers wrote
-      dim3 gridd((max_nblk(C) + 256 * STATS_AC_ITER - 1) / (256 * STATS_AC_ITER), C.ncomp, n);
-      hipLaunchKernelGGL(k_stats_ac_compact, gridd, dim3(256), 0, s, C, (const int16_t *)q, (const unsigned long long *)nzmask, tabs, spi, ss, 0, (const uint8_t *)nq8);
-    }
-  } else if (nzmask) {   // compact records out (the caller guarantees: plain pass, no fused statistics)
+    if (variant >= 3) LD(63, false, true, 2048, worklist, (unsigned *)nullptr);   // what is left has more than 32 records or a magnitude >= 16: one general tier that takes everything
+    else { LD(32, false, true, 2048, worklist, worklist2); LD(63, false, true, 1024, worklist2, (unsigned *)nullptr); }
+  } else if (nzmask) {   // compact records out of the general first tier (the caller guarantees: plain pass)
     if (variant > 3) variant = 3;   // (the general first tier stops at 32 records)
-#define LQC(QN) hipLaunchKernelGGL((k_trellis_ac_q<QN, false, false, true>), gridq, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, wv, lambda, worklist, (int16_t *)dense, dense_cap, st, ss, ext)
-#define LDC(QN, GRID, WL, WLN) hipLaunchKernelGGL((k_trellis_ac_qd<QN, false, false, true>), dim3(GRID), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda, (const unsigned *)WL, WLN, (const int16_t *)dense, dense_cap, st, ss, ext)
-    switch (variant) { case 1: LQC(20); break; case 2: LQC(24); break; case 3: LQC(32); break; default: LQC(16); break; }
-    if (variant == 3) LDC(63, 2048, worklist, (unsigned *)nullptr);
-    else { LDC(32, 2048, worklist, worklist2); LDC(63, 1024, worklist2, (unsigned *)nullptr); }
-#undef LQC
-#undef LDC
-  } else if (st) {
+    switch (variant) { case 1: LQ(20, false, true); break; case 2: LQ(24, false, true); break; case 3: LQ(32, false, true); break; default: LQ(16, false, true); break; }
+    if (variant == 3) LD(63, false, true, 2048, worklist, (unsigned *)nullptr);
+    else { LD(32, false, true, 2048, worklist, worklist2); LD(63, false, true, 1024, worklist2, (unsigned *)nullptr); }
+  } else {               // one plane per position (trellis loops, progressive scans with restart intervals ...)
     if (variant > 3) variant = 3;
-    switch (variant) { case 1: LQ(20, true); break; case 2: LQ(24, true); break; case 3: LQ(32, true); break; default: LQ(16, true); break; }
-    if (variant == 3) LD(63, true, 2048, worklist, (unsigned *)nullptr);
-    else { LD(32, true, 2048, worklist, worklist2); LD(63, true, 1024, worklist2, (unsigned *)nullptr); }
-  } else {
-    if (variant > 3) variant = 3;
-    switch (variant) { case 1: LQ(20, false); break; case 2: LQ(24, false); break; case 3: LQ(32, false); break; default: LQ(16, false); break; }
-    if (variant == 3) LD(63, false, 2048, worklist, (unsigned *)nullptr);
-    else { LD(32, false, 2048, worklist, worklist2); LD(63, false, 1024, worklist2, (unsigned *)nullptr); }
+    switch (variant) { case 1: LQ(20, false, false); break; case 2: LQ(24, false, false); break; case 3: LQ(32, false, false); break; default: LQ(16, false, false); break; }
+    if (variant == 3) LD(63, false, false, 2048, worklist, (unsigned *)nullptr);
+    else { LD(32, false, false, 2048, worklist, worklist2); LD(63, false, false, 1024, worklist2, (unsigned *)nullptr); }
   }
 #undef LQ
 #undef LD
@@ -3828,7 +3475,7 @@ void mjh_launch_scan16(const void *len16, int n_per, unsigned *sums, int chunks,
 
 bool mjh_trellis_dc_speculative_ok(const MjhConst &C, int window_ok)
 { // the window kernel's conditions, and a component with more than one block row per iMCU row (else there is nothing to speculate on)
-  return ((window_ok >> 8) >= 1) && ((window_ok >> 8) != 2) && (window_ok & 1) && C.delta_dc_weight <= 0.0f && C.maxv >= 2;
+  return window_ok && C.delta_dc_weight <= 0.0f && C.maxv >= 2;
 }
 
 void mjh_launch_trellis_dc_speculative(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda,
@@ -3846,12 +3493,10 @@ void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq,
 {
   const int nchains = C.ncomp * C.mcu_rows;
   dim3 grid((nchains + 3) / 4, n);
-  const int v2 = window_ok >> 8;   // A/B runs (MJH_DC_V2, read by the encoder): 0 = the first (ds_bpermute) version, 2 = DPP without the window
-  window_ok &= 1;
-  if (v2 >= 1 && v2 != 2 && window_ok && C.delta_dc_weight <= 0.0f)
+  // the sliding-window kernel when every DC quantizer step 8q is >= 40 and the vertical-gradient term is off; the general DPP kernel otherwise
+  if (window_ok && C.delta_dc_weight <= 0.0f)
     hipLaunchKernelGGL(k_trellis_dc3, grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]), lambda, (uint8_t *)back);
-  else if (v2) hipLaunchKernelGGL(k_trellis_dc2, grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]), lambda, (uint8_t *)back);
-  else hipLaunchKernelGGL(k_trellis_dc, grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]), lambda, (uint8_t *)back);
+  else hipLaunchKernelGGL(k_trellis_dc2, grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]), lambda, (uint8_t *)back);
 }
 
 void mjh_launch_encode(const MjhConst &C, const void *q, const unsigned long long *nzmask, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const int ac_slot[4],
@@ -3878,17 +3523,11 @@ void mjh_launch_encode(const MjhConst &C, const void *q, const unsigned long lon
   }
   hipLaunchKernelGGL(k_zero_stream, dim3(64, n), dim3(256), 0, s, stream, stream_words_per_image, (const unsigned *)totals,
                      rst ? (const unsigned *)seg_totals : (const unsigned *)nullptr);
-  const int encw = getenv("MJH_ENCW") ? atoi(getenv("MJH_ENCW")) : 1;   // 0: the direct (one memory atomic per word) writer, for A/B runs
-  if (encw) {
-    dim3 gridm((C.total_mcu_blocks + 255) / 256, n);
-    if (nzmask) hipLaunchKernelGGL((k_enc_write_mcu<true>), gridm, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image,
-                                   (const unsigned *)totals, (const unsigned *)seg_E, (const unsigned *)seg_totals, mpos, rst ? nseg : 1);
-    else hipLaunchKernelGGL((k_enc_write_mcu<false>), gridm, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image,
-                            (const unsigned *)totals, (const unsigned *)seg_E, (const unsigned *)seg_totals, mpos, rst ? nseg : 1);
-  } else if (nzmask) hipLaunchKernelGGL((k_enc_write<true>), grid, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image,
-                                 (const unsigned *)seg_E, mpos, rst ? nseg : 1);
-  else hipLaunchKernelGGL((k_enc_write<false>), grid, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image,
-                          (const unsigned *)seg_E, mpos, rst ? nseg : 1);
+  dim3 gridm((C.total_mcu_blocks + 255) / 256, n);
+  if (nzmask) hipLaunchKernelGGL((k_enc_write_mcu<true>), gridm, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image,
+                                 (const unsigned *)totals, (const unsigned *)seg_E, (const unsigned *)seg_totals, mpos, rst ? nseg : 1);
+  else hipLaunchKernelGGL((k_enc_write_mcu<false>), gridm, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, ds, as, (const unsigned *)off32, stream, stream_words_per_image,
+                          (const unsigned *)totals, (const unsigned *)seg_E, (const unsigned *)seg_totals, mpos, rst ? nseg : 1);
   hipLaunchKernelGGL(k_finish_bits, dim3((n + 63) / 64), dim3(64), 0, s, totals, rst ? (const unsigned *)seg_totals : (const unsigned *)nullptr, stream,
                      stream_words_per_image, (MjhImageMeta *)meta, n);
 }

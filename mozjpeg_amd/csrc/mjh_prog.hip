@@ -2224,9 +2224,8 @@ void mjh_launch_prog_stats_par(const MjhConst &C, const void *scans, const int *
   if (nlist <= 0) return;
   const dim3 gchunks(pe.chunks_per_scan, nlist, n), gpairs(nlist, n);
   hipLaunchKernelGGL(k_pp_init, dim3((nlist * n + 63) / 64), dim3(64), 0, s, pe, nlist * n);
-  const char *es = getenv("MJH_PP_SPLITK");       // A/B knob: 0 = one kernel for every kind of scan
   const void *sv = scans; const int16_t *qv = (const int16_t *)q;
-  if (nzmask && !(es && atoi(es) == 0)) {         // the list starts with its nacf first-pass AC scans
+  if (nzmask) {         // compact records: one kernel per kind of scan; the list starts with its nacf first-pass AC scans
     if (nacf > 0) hipLaunchKernelGGL((k_pp_stats<true, 1>), dim3(pe.chunks_per_scan, nacf, n), dim3(256), 0, s, C, (const MjhProgScan *)sv, list, (const MjhProgCtl *)ctl, qv,
                                      nzmask, tabs, spi, pe, 0);
     if (nlist > nacf) hipLaunchKernelGGL((k_pp_stats<true, 2>), dim3(pe.chunks_per_scan, nlist - nacf, n), dim3(256), 0, s, C, (const MjhProgScan *)sv, list, (const MjhProgCtl *)ctl, qv,
@@ -2269,8 +2268,7 @@ void mjh_launch_prog_encode(const MjhConst &C, const void *scans, const int *lis
   }
   if (npar > 0) {
     const dim3 gchunks(pe.chunks_per_scan, npar, n), gpairs(npar, n);
-    const char *es = getenv("MJH_PP_SPLITK");       // A/B knob: 0 = one kernel for every kind of scan
-    const bool splitk = nzmask && !(es && atoi(es) == 0);
+    const bool splitk = nzmask != nullptr;       // compact records: one kernel per kind of scan
     const MjhProgScan *sv = (const MjhProgScan *)scans; const MjhProgCtl *cv = (const MjhProgCtl *)ctl; const int16_t *qv = (const int16_t *)q;
     const MjhHuffTable *tv = (const MjhHuffTable *)tabs;
     const dim3 gacf(pe.chunks_per_scan, nacf, n), goth(pe.chunks_per_scan, npar - nacf, n);   // the list starts with its nacf first-pass AC scans
