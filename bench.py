@@ -632,35 +632,6 @@ def main():
                 e2.close()
             except Exception:
                 pass
-    # Extra information, never `value`: the library's two-range mode (MJH_SPLIT=2: the batch runs as two image ranges on
-    # streams of their own, so that the tails and the latency-bound small kernels of one range hide under the other)
-    two_ranges = None
-    if not args.no_inflight_leg and world == 1 and nframes >= 16:
-        e2 = None
-        try:
-            os.environ["MJH_SPLIT"] = "2"
-            e2 = M.Encoder(params, max_batch=B, device=local_rank)
-            del os.environ["MJH_SPLIT"]
-            e2.encode_tensor(d_frames[0:calls[0][1]], stream="own")
-            e2.sync()
-            same = all(e2.get_jpeg(i) == jpegs[i] for i in range(min(4, calls[0][1])))
-            ksteps = max(3, min(args.steps, 60))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(ksteps):
-                for s0, cnt in calls:
-                    e2.encode_tensor(d_frames[s0:s0 + cnt], stream="own")
-            e2.sync()
-            dt = (time.perf_counter() - t0) / ksteps
-            two_ranges = {"ranges": 2, "steps": ksteps, "ms_per_step": round(dt * 1e3, 3),
-                          "value": round(float(w) * h * nframes / dt / 1e6, 2), "unit": "Mpixels/s",
-                          "files_identical_to_the_contract_run": bool(same)}
-        except Exception as exc:
-            two_ranges = {"error": str(exc)}
-        finally:
-            os.environ.pop("MJH_SPLIT", None)
-            if e2 is not None:
-                e2.close()
     enc.close()
     del d_frames
 
@@ -745,8 +716,7 @@ def main():
                          "kernel_ms": round(dom_ms, 4),
                          "focus_probe_ms": {k: round(v, 4) for k, v in sorted(probe.items(), key=lambda kv: -kv[1])[:4]},
                          "kernel_ms_source": "HIP events around the interval in every encode call of the timed region; the interval was chosen as "
-                                             "the largest of a per-kernel pass over the warm-up steps; with MJH_SPLIT=2 a batch runs as two "
-                                             "concurrent image ranges and kernel_ms is the sum of the interval's launches over the ranges",
+                                             "the largest of a per-kernel pass over the warm-up steps",
                          "algorithmic_bytes": "input samples + JPEG bytes of one encode call (SURVEY 8d)",
                          "whole_step_GBps": round(algo_bytes * len(calls) / (elapsed / args.steps) / 1e9, 1),
                          "kernel_ms_per_call(untimed pass, every kernel bracketed)":
@@ -756,8 +726,6 @@ def main():
             out["other_configs"] = others
         if pipelined is not None:
             out["pipelined"] = pipelined
-        if two_ranges is not None:
-            out["two_ranges"] = two_ranges
         if host_all is not None:
             good = [h for h in host_all if h and "error" not in h]
             if world == 1 or not good:

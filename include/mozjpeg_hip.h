@@ -116,10 +116,16 @@ typedef struct {
    * (sums jcdctmgr.c:1299-1306, update jcmaster.c:1014-1030) */
   int trellis_q_opt;
   /* cinfo->arith_code (jpeglib.h:420, cjpeg -arithmetic): arithmetic entropy coding (jcarith.c) instead of Huffman -- SOF9 /
-   * SOF10 frames, DAC markers with the default conditioning (jcparam.c:417-419), no Huffman tables; with trellis_quant the
-   * coder's own rate model (quantize_trellis_arith jcdctmgr.c:1334-1667).  An adaptive coder is one dependent chain per
-   * scan: this mode is there for completeness, not for throughput.  Not combined with trellis_q_opt (MJH_EUNSUPPORTED). */
+   * SOF10 frames, DAC markers, no Huffman tables; with trellis_quant the coder's own rate model (quantize_trellis_arith
+   * jcdctmgr.c:1334-1667).  An adaptive coder is one dependent chain per scan: this mode is there for completeness, not for
+   * throughput.  Not combined with trellis_q_opt (MJH_EUNSUPPORTED). */
   int arith_code;
+  /* cinfo->arith_dc_L / arith_dc_U / arith_ac_K (jpeglib.h:447-449) of conditioning tables 0 and 1: the DC category thresholds
+   * (jcarith.c:442-445, :757-760) and the AC position Kx that switches the magnitude bins (:533, :802), written into the DAC
+   * marker (emit_dac jcmarker.c:404-448) and read by the coder's trellis (jget_arith_rates jcarith.c:949-951).
+   * mjh_params_defaults sets the library defaults 0 / 1 / 5 (jcparam.c:417-419); a table whose three values are all 0 (a
+   * zeroed struct of an older caller; Kx = 0 is not a valid conditioning) is read as those defaults.  0 <= L <= U <= 15, 1 <= K <= 63. */
+  int arith_dc_L[2], arith_dc_U[2], arith_ac_K[2];
 } mjh_params;
 
 #define MJH_COLOR_YCC  0

@@ -48,7 +48,8 @@ class Params(C.Structure):
                 ("trellis_num_loops", C.c_int), ("smoothing_factor", C.c_int), ("color_transform", C.c_int),
                 ("dc_scan_opt_mode", C.c_int), ("trellis_delta_dc_weight", C.c_float),
                 ("use_scans_in_trellis", C.c_int), ("trellis_freq_split", C.c_int),
-                ("trellis_eob_opt", C.c_int), ("trellis_q_opt", C.c_int), ("arith_code", C.c_int)]
+                ("trellis_eob_opt", C.c_int), ("trellis_q_opt", C.c_int), ("arith_code", C.c_int),
+                ("arith_dc_L", C.c_int * 2), ("arith_dc_U", C.c_int * 2), ("arith_ac_K", C.c_int * 2)]
 
 
 class Result(C.Structure):
@@ -134,7 +135,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 grayin=False, quant_table=-1, lambda1=None, lambda2=None, restart=None,
                 progressive=False, fastcrush=False, precision=8, trellis_loops=1, smooth=0, rgb=False,
                 dc_scan_opt=None, dc_ver_weight=None, use_scans_in_trellis=False, trellis_freq_split=0,
-                trellis_eob_opt=False, trellis_q_opt=False, arithmetic=False):
+                trellis_eob_opt=False, trellis_q_opt=False, arithmetic=False, arith_cond=None):
     """Parameters with cjpeg's switch vocabulary (cjpeg.c:371-714).  Without `baseline` or
     `revert` this is cjpeg's default: progressive with scan search (`fastcrush`: fixed 9-scan script)."""
     p = Params()
@@ -166,6 +167,9 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     p.trellis_eob_opt = 1 if trellis_eob_opt else 0
     p.trellis_q_opt = 1 if trellis_q_opt else 0
     p.arith_code = 1 if arithmetic else 0
+    if arith_cond is not None:     # ((L, U, K) of conditioning table 0, (L, U, K) of table 1): cinfo->arith_dc_L / arith_dc_U / arith_ac_K
+        for t, (lo, up, kx) in enumerate(arith_cond):
+            p.arith_dc_L[t], p.arith_dc_U[t], p.arith_ac_K[t] = lo, up, kx
     if rgb:   # cjpeg -rgb: jpeg_set_colorspace(JCS_RGB) (jcparam.c:611-619): all components 1x1 / table 0, ids 'R' 'G' 'B', no JFIF
         p.color_transform = COLOR_NONE
         p.write_JFIF_header = 0

@@ -333,9 +333,8 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
   if (cinfo->data_precision != 8 && cinfo->data_precision != 12) return "data_precision other than 8 or 12";
   p->data_precision = cinfo->data_precision;
   if (cinfo->arith_code) {
-    /* cjpeg -arithmetic: the device path knows the default conditioning (jcparam.c:417-419), which is all cjpeg can produce */
-    for (i = 0; i < 2; i++)
-      if (cinfo->arith_dc_L[i] != 0 || cinfo->arith_dc_U[i] != 1 || cinfo->arith_ac_K[i] != 5) return "arithmetic coding with non-default conditioning";
+    /* cjpeg -arithmetic; the conditioning of tables 0 / 1 as the application set it (jpeg_set_defaults: 0 / 1 / 5, jcparam.c:417-419) */
+    for (i = 0; i < 2; i++) { p->arith_dc_L[i] = cinfo->arith_dc_L[i]; p->arith_dc_U[i] = cinfo->arith_dc_U[i]; p->arith_ac_K[i] = cinfo->arith_ac_K[i]; }
     p->arith_code = 1;
   }
   if (cinfo->master->lossless) return "lossless mode";

@@ -111,9 +111,10 @@ __device__ __forceinline__ void ari_init_model(AriModel &M, int lane)
 }
 
 // the statistics of the block's tables are bound to fixed registers while it is coded, and put back behind it
-__device__ __forceinline__ void ari_bind(AriModel &M, int ta, int td)
+__device__ __forceinline__ void ari_bind(AriModel &M, int ta, int td, const MjhConst &C)
 {
   const int am = -(ta & 1), dm = -(td & 1);      // all ones: table 1
+  M.dc_lo = (int)((1L << C.ari_L[td & 1]) >> 1); M.dc_hi = (int)((1L << C.ari_U[td & 1]) >> 1); M.ac_k = C.ari_K[ta & 1];
 #pragma unroll
   for (int r = 0; r < 4; r++) M.cur[r] = (M.ac[1][r] & am) | (M.ac[0][r] & ~am);
   M.dcur = (M.dc[1] & dm) | (M.dc[0] & ~dm);
@@ -197,7 +198,7 @@ __device__ __forceinline__ void ari_run(const MjhConst &C, const AriScan &sc, in
         const int td = pick4(sc.td, ci), ta = pick4(sc.ta, ci);
         int last = pick4(ch.last_dc, ci), ctx = pick4(ch.ctx, ci);
         const int dc = ari_coef(M, 0);
-        ari_bind(M, ta, td);
+        ari_bind(M, ta, td, C);
         if (whole_blocks) {
           ari_dc(A, M, last, ctx, dc);
           ari_ac_first(A, M, 1, 63, 0, ke);
@@ -224,7 +225,7 @@ __device__ __forceinline__ long long ari_scan_units(const MjhConst &C, const Ari
 }
 
 // scan header: [DQT + SOF9/SOF10 for scan 0] DAC [DRI] SOS (write_scan_header jcmarker.c:744-784, emit_dac :404-448); o may be null (length only)
-__device__ __forceinline__ unsigned ari_scan_header(const AriScan &sc, int Al, const uint8_t *frame_hdr, int frame_hdr_len, uint8_t *o)
+__device__ __forceinline__ unsigned ari_scan_header(const MjhConst &C, const AriScan &sc, int Al, const uint8_t *frame_hdr, int frame_hdr_len, uint8_t *o)
 {
   unsigned n = 0;
   if (sc.frame_header) {
@@ -242,10 +243,10 @@ __device__ __forceinline__ unsigned ari_scan_header(const AriScan &sc, int Al, c
   const int ntab = dc_use0 + dc_use1 + ac_use0 + ac_use1;
   if (ntab) {
     put(0xFF); put(0xCC); put(0); put(ntab * 2 + 2);
-    if (dc_use0) { put(0); put(ARI_DC_L + (ARI_DC_U << 4)); }
-    if (ac_use0) { put(0x10); put(ARI_AC_K); }
-    if (dc_use1) { put(1); put(ARI_DC_L + (ARI_DC_U << 4)); }
-    if (ac_use1) { put(0x11); put(ARI_AC_K); }
+    if (dc_use0) { put(0); put(C.ari_L[0] + (C.ari_U[0] << 4)); }
+    if (ac_use0) { put(0x10); put(C.ari_K[0]); }
+    if (dc_use1) { put(1); put(C.ari_L[1] + (C.ari_U[1] << 4)); }
+    if (ac_use1) { put(0x11); put(C.ari_K[1]); }
   }
   if (sc.emit_dri) { put(0xFF); put(0xDD); put(0); put(4); put(sc.ri >> 8); put(sc.ri & 0xFF); }
   put(0xFF); put(0xDA);
@@ -302,7 +303,7 @@ k_arith_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
   AriChain ch;
   AriModel M;
   ari_init_model(M, lane);
-  hdr = ari_scan_header(sc, Al, frame_hdr, frame_hdr_len, WRITE && lane == 0 ? o : nullptr);   // (every lane: the length is wave-uniform)
+  hdr = ari_scan_header(C, sc, Al, frame_hdr, frame_hdr_len, WRITE && lane == 0 ? o : nullptr);   // (every lane: the length is wave-uniform)
   A.lane0 = lane == 0;
   A.pos = 0;
   A.out = WRITE ? o + hdr : nullptr;
@@ -366,7 +367,7 @@ k_arith_layout(MjhProgCtl *__restrict__ ctl, const uint8_t *__restrict__ file_hd
 // =============================================================================================
 struct MjhArithRates { float r[256][2]; };    // [state byte][decision]: -log2 of the decision's probability estimate
 
-__device__ __forceinline__ float ari_dc_bits(const float (*rdc)[2], int st, int dc_delta, int &upd)
+__device__ __forceinline__ float ari_dc_bits(const float (*rdc)[2], int st, int dc_delta, int &upd, int dc_lo, int dc_hi)
 { // the DC difference's estimated bits from context st (jcdctmgr.c:1464-1497); upd = the context it leaves behind
   float bits = rdc[st][dc_delta != 0];
   upd = 0;
@@ -384,8 +385,8 @@ __device__ __forceinline__ float ari_dc_bits(const float (*rdc)[2], int st, int 
       while (v2 >>= 1) { bits += rdc[st][1]; m <<= 1; st++; }
     }
     bits += rdc[st][0];
-    if (m < (int)((1L << ARI_DC_L) >> 1)) upd = 0;
-    else if (m > (int)((1L << ARI_DC_U) >> 1)) upd += 8;
+    if (m < dc_lo) upd = 0;
+    else if (m > dc_hi) upd += 8;
     st += 14;
     while (m >>= 1) bits += rdc[st][(m & dc_delta) ? 1 : 0];
   }
@@ -414,6 +415,8 @@ k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
   const int q0 = Q->q[qt][0];
   int ncand = (2 + 60 / q0) | 1;
   if (ncand > 9) ncand = 9;
+  // conditioning of component 0's tables (jget_arith_rates jcarith.c:949-951)
+  const int dc_lo = (int)((1L << C.ari_L[cc.dctbl & 1]) >> 1), dc_hi = (int)((1L << C.ari_U[cc.dctbl & 1]) >> 1), ac_k = C.ari_K[cc.actbl & 1];
   AriCoder A;
   AriChain ch;
   AriModel M;
@@ -491,7 +494,7 @@ k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
             if (v2 >>= 1) {
               coef_bits += rac[st][1];
               m <<= 1;
-              st = i <= ARI_AC_K ? 189 : 217;
+              st = i <= ac_k ? 189 : 217;
               while (v2 >>= 1) { coef_bits += rac[st][1]; m <<= 1; st++; }
             }
           }
@@ -583,7 +586,7 @@ k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
                 for (int l = 0; l < nl; l++) {
                   const int pred = bi == 0 ? s_lastdc : dc_cand[prv][l];
                   int upd;
-                  const float bits = ari_dc_bits(rdc, bi == 0 ? 0 : dc_ctx[prv][l], cnd - pred, upd);
+                  const float bits = ari_dc_bits(rdc, bi == 0 ? 0 : dc_ctx[prv][l], cnd - pred, upd, dc_lo, dc_hi);
                   float cost = bits + dist;
                   if (bi != 0) cost += dc_cost[prv][l];
                   if (l == 0 || cost < best) { best = cost; bb = bi == 0 ? -1 : l; bctx = upd; }

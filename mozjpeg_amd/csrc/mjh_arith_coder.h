@@ -24,9 +24,8 @@
 #include <stdint.h>
 #include "mjh_arith_table.h"
 
-#define ARI_DC_L 0     // conditioning defaults (jcparam.c:417-419); the DAC marker carries them
-#define ARI_DC_U 1
-#define ARI_AC_K 5
+// conditioning (cinfo->arith_dc_L / arith_dc_U / arith_ac_K, defaults 0 / 1 / 5: jcparam.c:417-419; the DAC marker carries
+// them): thresholds of the bound tables live in the model (AriModel.dc_lo / dc_hi / ac_k)
 
 #ifdef MJH_ARI_HOST
 #define ARI_FN static inline
@@ -67,6 +66,9 @@ struct AriModel {      // vector registers as RAM
   ari_reg dcur;        // ... of the bound table
   ari_reg tab[2];      // T.81 Table D.3, entries 0..63 / 64..113: Qe << 16 | next state after an MPS << 8 | after an LPS (bit 7: MPS flips)
   ari_reg coef;        // the block being coded: lane k = coefficient k (zig-zag)
+  // conditioning of the bound tables (wave-uniform): the DC category thresholds (1 << L) >> 1 and (1 << U) >> 1
+  // (jcarith.c:442-445), the AC position Kx up to which the low magnitude bins are used (:533)
+  int dc_lo, dc_hi, ac_k;
 };
 
 struct AriCoder {      // jcarith.c:28-52, all wave-uniform
@@ -171,7 +173,7 @@ ARI_FN void ari_ac_magnitude(AriCoder &A, AriModel &M, int p, int v, int k)
     int v2 = v;
     if (v2 >>= 1) {
       A.encode<ARI_M>(M, p, 1);
-      int m = 2, x = k <= ARI_AC_K ? 0 : 28;
+      int m = 2, x = k <= M.ac_k ? 0 : 28;
       while (v2 >>= 1) { A.encode<ARI_X>(M, x, 1); m <<= 1; x++; }
       A.encode<ARI_X>(M, x, 0);
       x += 14;
@@ -210,8 +212,8 @@ ARI_FN void ari_dc(AriCoder &A, AriModel &M, int &last_dc, int &ctx, int value)
   if (v > 0) { A.encode<ARI_D>(M, st + 1, 0); st += 2; ctx = 4; }
   else { v = -v; A.encode<ARI_D>(M, st + 1, 1); st += 3; ctx = 8; }
   const int m = ari_dc_magnitude(A, M, st, v);
-  if (m < (int)((1L << ARI_DC_L) >> 1)) ctx = 0;
-  else if (m > (int)((1L << ARI_DC_U) >> 1)) ctx += 8;
+  if (m < M.dc_lo) ctx = 0;
+  else if (m > M.dc_hi) ctx += 8;
 }
 
 // Encode_AC_Coefficients: encode_mcu_AC_first jcarith.c:456-552; with Ss = 1, Se = 63, Al = 0 the AC part of encode_mcu :764-817.

@@ -129,6 +129,7 @@ extern "C" int mjh_params_defaults(mjh_params *p, int width, int height, int inp
     p->h_samp_factor[0] = hsamp;
     p->v_samp_factor[0] = vsamp;
   }
+  for (int t = 0; t < 2; t++) { p->arith_dc_L[t] = 0; p->arith_dc_U[t] = 1; p->arith_ac_K[t] = 5; }   // jcparam.c:417-419
   p->optimize_coding = maxc;        // jcparam.c:436-444
   p->trellis_quant = maxc;          // :505
   p->trellis_quant_dc = 1;          // :516
@@ -313,7 +314,6 @@ struct mjh_encoder {
   bool trellis_adapt = true;         // no MJH_TRELLIS_VARIANT given: follow the share of deferred blocks of the previous batches
   unsigned *h_defer = nullptr;       // pinned: work-list counters of an earlier trellis pass (count_heavy), read back asynchronously
   hipEvent_t ev_defer = nullptr; bool defer_pending = false; int defer_frames = 0;   // ... valid once ev_defer has completed; the frames they were counted over
-  int fuse_mask = 1;                // MJH_FUSE: 1 = pre-trellis AC statistics inside the FDCT kernel (+ unread planes not stored), 2 = final AC statistics inside the general trellis kernel, 4 = inside the tile-sorted one (both measured: they cost the trellis what the separate pass costs, 2.36 + 0.33 vs 2.77 ms)
   int spi = SLOTS_BASE;             // table slots per image (16 + 2 per progressive scan)
   // progressive mode
   bool progressive = false;
@@ -361,16 +361,7 @@ struct mjh_encoder {
   bool sizes_valid = false;
   bool coef_input = false;         // last batch came in through mjh_encode_coefficients_*: d_meta[].bad_coef is meaningful
   hipStream_t last_stream = nullptr;   // the stream the last batch was queued on (mjh_encoder_sync waits for it)
-  // Sub-batches (mjh_encode_device, sequential mode): VIEWS of this encoder over consecutive image ranges -- copies of this
-  // struct whose per-image pointers are advanced to the range's first image, each with its own streams / events / work
-  // lists -- so that the kernels of one range overlap the tails and the differently bound kernels of the others
-  // (measured before with three whole encoders in flight: 6.85 -> 6.04 ms per 64 4K frames).  The parent keeps every buffer
-  // at full size: every other entry point and all result accessors see one contiguous batch.
-  std::vector<mjh_encoder *> views;
-  std::vector<hipStream_t> pad_streams;
-  bool is_view = false, last_split = false;
-  int view_off = 0;
-  hipEvent_t ev_view_done = nullptr, ev_split_fork = nullptr, ev_null_in = nullptr;
+  hipEvent_t ev_null_in = nullptr;
   // arithmetic coding (mjh_arith.hip): the scans to code (the script, or one synthetic whole-block scan for a sequential file),
   // phase lists in d_lists (pl_phase[].scan_off / nscan), the rate table of quantize_trellis_arith
   // DC trellis of one or two frames: block rows walked speculatively (k_trellis_dc3_fwd / _resolve): scratch, and MJH_DC_SPEC=0 turns it off
@@ -463,6 +454,11 @@ static int check_supported(const mjh_params *p)
       return fail(MJH_EUNSUPPORTED, "trellis_q_opt with arithmetic coding (the reference accumulates its table estimate over three identical passes: not restated)");
     for (int i = 0; i < p->num_components; i++)
       if (p->dc_tbl_no[i] > 1 || p->ac_tbl_no[i] > 1) return fail(MJH_EUNSUPPORTED, "arithmetic coding: conditioning table numbers 0/1 only");
+    for (int t = 0; t < 2; t++) {
+      if (p->arith_dc_L[t] == 0 && p->arith_dc_U[t] == 0 && p->arith_ac_K[t] == 0) continue;   // a zeroed table: the defaults (mozjpeg_hip.h)
+      if (p->arith_dc_L[t] < 0 || p->arith_dc_U[t] > 15 || p->arith_dc_L[t] > p->arith_dc_U[t] || p->arith_ac_K[t] < 1 || p->arith_ac_K[t] > 63)
+        return fail(MJH_EINVAL, "arithmetic conditioning of table %d: L %d, U %d, K %d (0 <= L <= U <= 15, 1 <= K <= 63: T.81 B.2.4.3)", t, p->arith_dc_L[t], p->arith_dc_U[t], p->arith_ac_K[t]);
+    }
   }
   if (p->trellis_quant && !p->optimize_coding && !p->arith_code) return fail(MJH_EUNSUPPORTED, "trellis_quant requires optimize_coding (jcmaster.c:686-702 never selects a component otherwise)");
   if (!p->optimize_coding && !p->arith_code) {
@@ -527,6 +523,10 @@ static void build_const(const mjh_params *p, MjhConst *C)
   if (p->restart_in_rows > 0) {
     const long nominal = (long)p->restart_in_rows * C->mcus_per_row;
     C->restart_interval = (int)(nominal < 65535L ? nominal : 65535L);
+  }
+  for (int t = 0; t < 2; t++) {   // arithmetic conditioning (a zeroed table = the defaults 0 / 1 / 5, jcparam.c:417-419)
+    const bool zeroed = p->arith_dc_L[t] == 0 && p->arith_dc_U[t] == 0 && p->arith_ac_K[t] == 0;
+    C->ari_L[t] = zeroed ? 0 : p->arith_dc_L[t]; C->ari_U[t] = zeroed ? 1 : p->arith_dc_U[t]; C->ari_K[t] = zeroed ? 5 : p->arith_ac_K[t];
   }
   C->lambda_log_scale1 = p->lambda_log_scale1;
   C->lambda_log_scale2 = p->lambda_log_scale2;
@@ -681,27 +681,10 @@ static void fill_std_table(MjhHuffTable *T, const uint8_t *bits, const uint8_t *
   }
 }
 
-static void free_view(mjh_encoder *v)
-{
-  for (hipEvent_t ev : v->prof_events) (void)hipEventDestroy(ev);
-  for (hipEvent_t ev : v->side_events) (void)hipEventDestroy(ev);
-  for (hipEvent_t ev : { v->ev_fork, v->ev_join, v->ev_view_done }) if (ev) (void)hipEventDestroy(ev);
-  if (v->ev_defer) (void)hipEventDestroy(v->ev_defer);
-  if (v->h_defer) (void)hipHostFree(v->h_defer);
-  if (v->side_stream) (void)hipStreamDestroy(v->side_stream);
-  if (v->stream) (void)hipStreamDestroy(v->stream);
-  delete v;
-}
-
 static void free_all(mjh_encoder *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  for (mjh_encoder *v : e->views) free_view(v);
-  e->views.clear();
-  for (hipStream_t d : e->pad_streams) (void)hipStreamDestroy(d);
-  e->pad_streams.clear();
-  if (e->ev_split_fork) (void)hipEventDestroy(e->ev_split_fork);
   if (e->ev_null_in) (void)hipEventDestroy(e->ev_null_in);
   void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->pe.chist, e->pe.rmask, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_nq8, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
@@ -732,93 +715,6 @@ static void free_all(mjh_encoder *e)
 extern "C" void mjh_encoder_destroy(mjh_encoder *e) { free_all(e); }
 
 #define HIPCHK_E(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { int rc_ = fail(MJH_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); free_all(e); return rc_; } } while (0)
-
-// views of `e` over S consecutive image ranges (see struct mjh_encoder): per-image pointers advanced, own execution resources
-static int make_views(mjh_encoder *e, int S)
-{
-  const MjhConst &C = e->C;
-  const mjh_params &p = e->p;
-  const size_t B = (size_t)e->max_batch, Bs = (B + S - 1) / S;
-  const size_t bps = C.precision == 12 ? 2 : 1, trb = (size_t)C.total_real_blocks, tmb = (size_t)C.total_mcu_blocks, ns = (size_t)e->nseg;
-  const unsigned dense_each = e->dense_cap / (unsigned)S;
-  HIPCHK(hipEventCreateWithFlags(&e->ev_split_fork, hipEventDisableTiming));
-  if (const char *pad = getenv("MJH_STREAM_PAD"))   // experiment: shift the stream -> hardware queue assignment of the views
-    for (int i = 0; i < atoi(pad); i++) { hipStream_t d; HIPCHK(hipStreamCreateWithFlags(&d, hipStreamNonBlocking)); e->pad_streams.push_back(d); }
-  for (int k = 0; k < S; k++) {
-    const size_t off = (size_t)k * Bs;
-    if (off >= B) break;
-    mjh_encoder *v = new mjh_encoder(*e);
-    e->views.push_back(v);
-    v->views.clear();
-    v->pad_streams.clear();
-    v->is_view = true;
-    v->view_off = (int)off;
-    v->max_batch = (int)(B - off < Bs ? B - off : Bs);
-    // execution resources of its own (everything host-path related stays with the parent and is never used through a view)
-    v->stream = v->side_stream = v->copy_stream = v->d2h_stream = nullptr;
-    v->copy_done = v->ev_fork = v->ev_join = v->ev_side0 = v->ev_side1 = v->ev_view_done = v->ev_split_fork = v->ev_null_in = nullptr;
-    for (int b = 0; b < 2; b++) { v->ev_h2d[b] = v->ev_pix_free[b] = v->ev_packed[b] = nullptr; v->d_pixb[b] = nullptr; v->h_stage[b] = v->h_res[b] = nullptr; v->h_tab[b] = nullptr; }
-    v->h_defer = nullptr; v->ev_defer = nullptr; v->defer_pending = false;
-    for (int c = 0; c < MJH_MAX_COMPS; c++) v->g_in[c] = nullptr;
-    v->g_in_old.clear();
-    v->prof_events.clear(); v->side_events.clear(); v->prof_names.clear(); v->prof_cnames.clear(); v->prof_ms.clear();
-    v->prof_calls = 0; v->prof_per_call = 0; v->profiling = 0;
-    {
-      // odd views get streams of the least priority (MJH_SPLIT_PRIO: 0 = default priority everywhere, 1 = greatest instead):
-      // the runtime keeps one pool of hardware queues per priority, so those streams cannot land on the queues of the
-      // other views' streams
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      const char *pe = getenv("MJH_SPLIT_PRIO");
-      const int mode = pe ? atoi(pe) : 2;
-      const int prio = (mode == 1 && (k & 1)) ? hi : (mode == 2 && (k & 1)) ? lo : 0;
-      HIPCHK(hipStreamCreateWithPriority(&v->stream, hipStreamNonBlocking, prio));
-      HIPCHK(hipStreamCreateWithPriority(&v->side_stream, hipStreamNonBlocking, prio));
-    }
-    HIPCHK(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&v->ev_view_done, hipEventDisableTiming));
-    HIPCHK(hipHostMalloc((void **)&v->h_defer, 64, hipHostMallocDefault));
-    // HIP multiplexes streams onto a handful of hardware queues (4 by default): with a main and a side stream per view, three
-    // views already collide there and serialise falsely (measured: 2 views 5.81 ms, 3 views 6.67 ms per 64 4K frames).  From
-    // three views on, a view keeps to ONE stream -- its DC trellis runs in line, the overlap comes from the other views
-    { const char *sd = getenv("MJH_SPLIT_DC"); if (sd ? atoi(sd) != 0 : S >= 3) v->dc_mode = 1; }
-    // per-image arrays: advanced to the view's first image
-    v->d_planes += off * C.planes_per_image * bps;
-    v->d_uq += off * C.coefs_per_image;
-    v->d_q += off * C.coefs_per_image;
-    v->d_q0 = nullptr;                                   // (debug taps: the encode then runs unsplit)
-    if (p.trellis_quant && p.trellis_q_opt) v->d_quant += off;
-    v->d_tabs += off * e->spi;
-    v->d_tabs_init += off * e->spi;
-    v->d_lambda += off * trb;
-    v->d_back += off * trb * 16;
-    v->d_worklist += (k * 16 + off * trb * 12) / 4;      // a work list of its own (entries hold image numbers relative to the view)
-    v->d_worklist2 += (k * 16 + off * trb * 12) / 4;
-    if (v->d_eob_cost) v->d_eob_cost = (uint8_t *)v->d_eob_cost + off * trb * 8;
-    if (v->d_eob_has) v->d_eob_has += off * trb;
-    if (v->d_qsums) v->d_qsums += off * 4 * 64 * 2;
-    if (v->d_nzmask) v->d_nzmask += off * trb;
-    if (v->d_nq8) v->d_nq8 += off * trb;
-    if (v->d_dense) { v->d_dense += (size_t)k * dense_each * 64; v->dense_cap = dense_each; }
-    v->d_len16 += off * tmb;
-    v->d_off32 += off * tmb;
-    v->d_sums += off * e->chunks;
-    v->d_ffsums += off * e->ff_chunks;
-    v->d_totals += off;
-    v->d_fftotals += off;
-    v->d_stream += off * e->stream_words;
-    v->d_out += off * e->out_stride;
-    v->d_sizes += off;
-    v->d_seg_x += off * ns;
-    v->d_seg_E += off * ns;
-    v->d_mpos += off * ns;
-    v->d_seg_sums += off * ((ns + 2047) / 2048);
-    v->d_seg_totals += off;
-    v->d_meta = (uint8_t *)v->d_meta + off * sizeof(MjhImageMeta);
-  }
-  return MJH_OK;
-}
 
 extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device, mjh_encoder **out)
 {
@@ -882,7 +778,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     bool restart_scans = false;   // progressive: scans with restart intervals go through the sequential walk, which reads one plane per position
     if (e->progressive && (p->restart_interval || p->restart_in_rows)) restart_scans = true;
     e->use_compact = !p->arith_code && p->trellis_quant && nl == 1 && e->nbands == 1 && !p->trellis_eob_opt && !p->trellis_q_opt &&
-                     (e->progressive ? !restart_scans : !(e->fuse_mask & 2));
+                     (e->progressive ? !restart_scans : true);
     if (e->use_compact) HIPCHK_E(mjh_dmalloc((void **)&e->d_nzmask, B * (size_t)C.total_real_blocks * sizeof(unsigned long long)));
     if (e->use_compact && p->trellis_quant) HIPCHK_E(mjh_dmalloc((void **)&e->d_nq8, B * (size_t)C.total_real_blocks));
   }
@@ -902,7 +798,6 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   }
   if (const char *v = getenv("MJH_TRELLIS_VARIANT")) { e->trellis_variant = atoi(v); e->trellis_adapt = false; }
   HIPCHK_E(hipHostMalloc((void **)&e->h_defer, 64, hipHostMallocDefault));
-  if (const char *v = getenv("MJH_FUSE")) e->fuse_mask = atoi(v);
   if (const char *v = getenv("MJH_TRELLIS_V3")) e->trellis_v3 = atoi(v);
   e->dc_window_ok = 1;
   for (int i = 0; i < C.ncomp; i++) if (p->quantval[p->quant_tbl_no[i]][0] < 5) e->dc_window_ok = 0;
@@ -1264,25 +1159,6 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     HIPCHK_E(mjh_dmalloc((void **)&e->d_pool, B * e->pool_words * 4 + 4096));   // slack: a bit writer may touch two words past its last offset
     HIPCHK_E(mjh_dmalloc((void **)&e->d_outpool, B * e->outpool_bytes));
   }
-  {
-    // sub-batches of the device entry (sequential mode): MJH_SPLIT ranges
-    // Opt-in (MJH_SPLIT=2).  Which hardware queues the runtime maps the views' streams to decides whether the ranges really
-    // overlap: with every stream at the default priority the same code ran 64 4K frames in 5.72-5.83 ms OR 6.66-6.90 ms,
-    // flipping with the number of streams the process had created before (period 4 = the runtime's queue count; one range:
-    // 5.97-6.10 ms; three and more ranges lose either way).  The runtime keeps a separate pool of hardware queues per stream
-    // priority, so the second view's streams are created at the LEAST priority: its queues are then its own whatever else
-    // exists (measured: 5.15-5.22 ms for the first and for later encoders of a process, against 5.43 unsplit on the same
-    // tree; profiles/r03e_split_*.log, r03f_split_priority.log).  It stays opt-in because the ranges share the device:
-    // a kernel's launch then lasts longer than it would alone, which blurs every per-kernel measurement (bench.py reports
-    // the two-range rate as an extra leg next to the one-range contract line).
-    int S = 1;
-    if (const char *v = getenv("MJH_SPLIT")) S = atoi(v);
-    if (S > 8) S = 8;
-    if (S > 1 && !e->progressive && !e->arith && max_batch >= 2 * S) {
-      rc = make_views(e, S);
-      if (rc) { free_all(e); return rc; }
-    }
-  }
   HIPCHK_E(hipDeviceSynchronize());
   *out = e;
   return MJH_OK;
@@ -1364,10 +1240,10 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   // read (the trellis recomputes them), so they are not stored; optionally the statistics of the final coefficients
   // are gathered by the trellis back-track.
   const bool fuse_seq = !e->progressive && p.trellis_quant && !coef_src && !e->arith;
-  // (debug taps expose the pre-trellis quantized planes, so they keep the unfused schedule.)  Measured: the fused FDCT
-  // kernel costs what the separate statistics pass cost (7.19 vs 7.23 ms per 64 4K frames) but moves 3.2 GB less; the
-  // final statistics inside the trellis cost MORE than their own pass (3.83 vs 3.36 + 0.38 ms: the low-occupancy kernel
-  // pays for every extra instruction), so that fusion exists (MJH_FUSE=3) but is off by default.
+  // The pre-trellis AC statistics are gathered inside the FDCT kernel (debug taps expose the pre-trellis quantized planes, so
+  // they keep the unfused schedule).  Measured: the fused FDCT kernel costs what the separate statistics pass cost (7.19 vs
+  // 7.23 ms per 64 4K frames) but moves 3.2 GB less.  The FINAL statistics inside either trellis kernel cost more than their
+  // own pass over the compact records (rounds 2 and 3: 3.83 vs 3.36 + 0.38 ms; 2.77 vs 2.36 + 0.33 ms) and were removed in round 5.
   // band-limited passes (use_scans_in_trellis) keep the other band's quantized planes, and the block-row
   // pass of trellis_eob_opt changes coefficients behind the per-block DP: neither fusion applies then
   const bool ext_eob = p.trellis_quant && p.trellis_eob_opt, ext_qopt = p.trellis_quant && p.trellis_q_opt;
@@ -1375,8 +1251,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   unsigned long long *const nzm = compact ? e->d_nzmask : nullptr;
   e->compact_last = compact;
   const int nbands = p.trellis_quant ? e->nbands : 1;
-  const bool fuse_pre = fuse_seq && (e->fuse_mask & 1) && !e->debug_taps && nbands == 1 && !ext_qopt;   // (q_opt: one component at a time, each from the stored planes)
-  const bool fuse_fin = fuse_seq && (e->fuse_mask & 2) && nbands == 1 && !ext_eob;
+  const bool fuse_pre = fuse_seq && !e->debug_taps && nbands == 1 && !ext_qopt;   // (q_opt: one component at a time, each from the stored planes)
   // The first tier's queue capacity of the AC trellis trades LDS occupancy (16 records: 15 waves per CU, 48: 5) against the
   // share of blocks that have to be redone by the general big-capacity tier.  The first tier counts, whatever its own
   // capacity, how many blocks of the batch have more than 16 / 24 / 32 records (count_heavy); the counts of an earlier
@@ -1466,7 +1341,6 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   // One (statistics, trellis) pass pair: for all components (CV = C) or, with trellis_q_opt, for ONE component through a
   // one-component view of the geometry (MjhComp carries absolute offsets, so the view addresses the same buffers).
   const int nloops = p.trellis_quant && !e->arith ? (p.trellis_num_loops > 1 ? p.trellis_num_loops : 1) : 0;   // (the arithmetic coder has its own trellis pass below)
-  bool final_ac_counted = false;     // the last trellis pass has counted the AC statistics of the final coefficients
   bool final_dc_counted = false;     // ... and the side stream the DC statistics, right behind the DC trellis (under the AC kernel)
   auto trellis_pass = [&](const MjhConst &CV, const int *sl_dc_seq, const int *sl_dc_prog, const int *sl_ac, const int *crst,
                           const mjh_encoder::PList *plt, int Ss, int Se, bool first_pass, bool last_loop, int qstride) -> int {
@@ -1522,7 +1396,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       // row one after the other): every block row is walked for every value the row above can end on, in parallel, and a second
       // kernel back-tracks the walks whose hypothesis held (mjh_kernels.hip, K6 speculative)
       const size_t spec_bytes = 2 * (size_t)C.total_real_blocks * 9 * 16;
-      const bool spec = e->dc_spec && n <= 2 && qstride == 0 && !e->is_view && spec_bytes <= ((size_t)256 << 20) && mjh_trellis_dc_speculative_ok(CV, e->dc_window_ok);
+      const bool spec = e->dc_spec && n <= 2 && qstride == 0 && spec_bytes <= ((size_t)256 << 20) && mjh_trellis_dc_speculative_ok(CV, e->dc_window_ok);
       if (spec && !e->d_back9) {
         int rows = 0;
         for (int c = 0; c < C.ncomp; c++) rows += C.c[c].hib;
@@ -1544,13 +1418,9 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     const bool extended = nbands > 1 || ext_eob || qstride != 0;
     if (!extended) { const int rc = adapt_first_tier(); if (rc != MJH_OK) return rc; }
     pr.mark("trellis_ac");
-    // the tile-sorted first tier (plain compact pass, 16-record capacity) can count the statistics of the final coefficients
-    // in its back-track (MJH_FUSE bit 4): sequential mode, optimal tables, last round
-    const bool v3 = nzm && e->d_nq8 && !fuse_fin && e->trellis_v3 > 0 && e->trellis_variant <= 4 && !extended;
-    const bool v3_stats = v3 && (e->fuse_mask & 4) && !e->progressive && p.optimize_coding && last_loop;
-    if (v3_stats) final_ac_counted = true;
+    const bool v3 = nzm && e->d_nq8 && e->trellis_v3 > 0 && e->trellis_variant <= 4 && !extended;     // the tile-sorted first tier (plain compact pass)
     mjh_launch_trellis_ac(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap,
-                          (v3_stats || (fuse_fin && p.optimize_coding && last_loop)) ? fin_ac : nullptr, e->trellis_variant,
+                          e->trellis_variant,
                           Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, nzm, qstride, n, s,
                           e->d_nq8, v3 ? ((size_t)n * C.total_real_blocks < e->small_batch ? 1 : e->trellis_v3) : 0,   // (a small batch: one pass per tile -- four times the workgroups, a quarter of their length: latency matters more than the sorting)
                           e->fastdiv_all);
@@ -1663,10 +1533,8 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   }
   if (p.optimize_coding) {
     // pass 6: statistics of the interleaved scan (dummy blocks included) -> final tables
-    if (!fuse_fin && !final_ac_counted) {   // (else the last trellis round has counted the AC symbols already)
-      pr.mark("stats_ac(final)");
-      mjh_launch_stats_ac(C, e->d_q, nzm, e->d_tabs, spi, fin_ac, 1, n, s);
-    }
+    pr.mark("stats_ac(final)");
+    mjh_launch_stats_ac(C, e->d_q, nzm, e->d_tabs, spi, fin_ac, 1, n, s);
     if (!final_dc_counted) {
       pr.mark("stats_dc(final)");
       mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, fin_dc, 1, zero4, n, s);
@@ -1757,26 +1625,7 @@ extern "C" int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t ro
     s = e->stream;
     HIPCHK(hipStreamWaitEvent(s, e->ev_null_in, 0));
   }
-  e->last_split = false;
   { const int rcw = wait_pending_pack(e, s); if (rcw) return rcw; }
-  if (e->views.size() > 1 && !e->debug_taps && n > e->views[0]->max_batch) {
-    // sub-batches: every view runs the whole schedule for its range on its own streams, forked from and joined into `s`
-    HIPCHK(hipEventRecord(e->ev_split_fork, s));
-    for (mjh_encoder *v : e->views) {
-      const int nk = n - v->view_off < v->max_batch ? n - v->view_off : v->max_batch;
-      if (nk <= 0) break;
-      v->profiling = e->profiling;
-      HIPCHK(hipStreamWaitEvent(v->stream, e->ev_split_fork, 0));
-      const int rc = run_pipeline(v, (const uint8_t *)d_pixels + (size_t)v->view_off * image_stride, row_pitch, image_stride, nk, v->stream);
-      if (rc) return rc;
-      HIPCHK(hipEventRecord(v->ev_view_done, v->stream));
-      HIPCHK(hipStreamWaitEvent(s, v->ev_view_done, 0));
-    }
-    e->sizes_valid = false; e->last_n = n; e->res_buf = -1; e->coef_input = false; e->last_stream = s;
-    e->compact_last = e->views[0]->compact_last;
-    e->last_split = true;
-    return MJH_OK;
-  }
   return run_pipeline(e, d_pixels, row_pitch, image_stride, n, s);
 }
 
@@ -1934,7 +1783,6 @@ extern "C" int mjh_encode_host(mjh_encoder *e, const void *pixels, size_t row_pi
   if (row_pitch < row_bytes) return fail(MJH_EINVAL, "row_pitch %zu is smaller than a row (%zu bytes)", row_pitch, row_bytes);
   if (n > 1 && image_stride < row_pitch * (size_t)(e->C.H - 1) + row_bytes)
     return fail(MJH_EINVAL, "image_stride %zu is smaller than one image (%zu bytes): images would overlap", image_stride, row_pitch * (size_t)(e->C.H - 1) + row_bytes);
-  e->last_split = false;
   int rc = host_buffers(e);
   if (rc) return rc;
   const int b = (int)(e->host_calls & 1u);
@@ -2009,7 +1857,6 @@ extern "C" int mjh_encode_gather(mjh_encoder *e, mjh_encoder *const *members, in
       return fail(MJH_EINVAL, "member %d does not match the batch encoder (parameters / device)", i);
     if (!m->d_pixb[m->host_calls & 1u] || !m->h_stage[m->host_calls & 1u]) return fail(MJH_EINVAL, "member %d has nothing staged", i);
   }
-  e->last_split = false;
   const int b = (int)(e->host_calls++ & 1u);
   HIPCHK(hipStreamWaitEvent(e->copy_stream, e->ev_pix_free[b], 0));   // this encoder's input buffer: its reader of two calls ago
   for (int i = 0; i < n; i++) {
@@ -2144,7 +1991,6 @@ extern "C" int mjh_encode_coefficients_device(mjh_encoder *e, const void *const 
     if (rg) return rg;
   }
   { const int rcw = wait_pending_pack(e, stream ? (hipStream_t)stream : e->stream); if (rcw) return rcw; }
-  e->last_split = false;
   return run_pipeline(e, nullptr, 0, 0, n, stream ? (hipStream_t)stream : e->stream, nullptr, &cs);
 }
 
@@ -2178,7 +2024,6 @@ extern "C" int mjh_encode_coefficients_host(mjh_encoder *e, const void *const co
   memset(&cs, 0, sizeof(cs));
   for (int c = 0; c < e->C.ncomp; c++) { cs.base[c] = e->d_cfin + off[c]; cs.blocks_per_row[c] = e->C.c[c].wib; cs.stride[c] = (long long)per_image; }
   { const int rcw = wait_pending_pack(e, e->stream); if (rcw) return rcw; }
-  e->last_split = false;
   return run_pipeline(e, nullptr, 0, 0, n, e->stream, nullptr, &cs);
 }
 
@@ -2211,7 +2056,6 @@ extern "C" int mjh_encode_planes_device(mjh_encoder *e, const void *const d_plan
     if (rg) return rg;
   }
   { const int rcw = wait_pending_pack(e, stream ? (hipStream_t)stream : e->stream); if (rcw) return rcw; }
-  e->last_split = false;
   return run_pipeline(e, nullptr, 0, 0, n, stream ? (hipStream_t)stream : e->stream, &ps);
 }
 
@@ -2253,7 +2097,6 @@ extern "C" int mjh_encode_planes_host(mjh_encoder *e, const void *const planes[M
   HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done, 0));
   for (int c = 0; c < e->C.ncomp; c++) { ps.base[c] = e->d_plin + off[c]; ps.stride[c] = (long long)per_image; }
   { const int rcw = wait_pending_pack(e, e->stream); if (rcw) return rcw; }
-  e->last_split = false;
   return run_pipeline(e, nullptr, 0, 0, n, e->stream, &ps);
 }
 
@@ -2347,7 +2190,6 @@ extern "C" int mjh_set_profiling(mjh_encoder *e, int on)
   e->prof_calls = 0;
   if (e->prof_focus_name.empty()) e->prof_focus = e->p.trellis_quant && !e->progressive ? "trellis_ac" : "dct_quant";
   else e->prof_focus = e->prof_focus_name.c_str();
-  for (mjh_encoder *v : e->views) { v->profiling = on; v->prof_calls = 0; v->prof_focus = e->prof_focus; }
   return MJH_OK;
 }
 
@@ -2367,27 +2209,6 @@ extern "C" int mjh_get_kernel_times(mjh_encoder *e, const char *const **names, c
   if (!e || !count) return fail(MJH_EINVAL, "bad arguments");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipDeviceSynchronize());
-  if (e->last_split) {
-    // the batch ran as sub-batches: a kernel's time per encode call = the sum of its launches over the ranges (the ranges
-    // run concurrently, so these are durations of launches that share the device, not a breakdown of the wall time)
-    e->prof_cnames.clear(); e->prof_ms.clear(); e->prof_names.clear();
-    for (mjh_encoder *v : e->views) {
-      if (v->prof_calls == 0) continue;
-      const int rc = kernel_times_one(v);
-      if (rc) return rc;
-      for (size_t i = 0; i < v->prof_cnames.size(); i++) {
-        size_t j = 0;
-        while (j < e->prof_names.size() && e->prof_names[j] != v->prof_cnames[i]) j++;
-        if (j == e->prof_names.size()) { e->prof_names.push_back(v->prof_cnames[i]); e->prof_ms.push_back(0.f); }
-        e->prof_ms[j] += v->prof_ms[i];
-      }
-    }
-    for (const std::string &nm : e->prof_names) e->prof_cnames.push_back(nm.c_str());
-    if (names) *names = e->prof_cnames.data();
-    if (ms) *ms = e->prof_ms.data();
-    *count = (int)e->prof_cnames.size();
-    return MJH_OK;
-  }
   const int rc = kernel_times_one(e);
   if (rc) return rc;
   if (names) *names = e->prof_cnames.data();

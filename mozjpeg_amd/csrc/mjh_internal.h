@@ -57,6 +57,7 @@ struct MjhConst {
   int trellis_dc;
   float delta_dc_weight;  // trellis_delta_dc_weight (> 0: the DC trellis adds the vertical-gradient term, jcdctmgr.c:1069-1084)
   int restart_interval;   // of the final interleaved scan, in MCUs (0 = none)
+  int ari_L[2], ari_U[2], ari_K[2];   // arithmetic coding: conditioning of tables 0 / 1 (cinfo->arith_dc_L / arith_dc_U / arith_ac_K)
   float lambda_log_scale1, lambda_log_scale2;
   double pow_scale1, pow_scale2;  // pow(2, s1) [or pow(2, s1-12) when s2 <= 0], pow(2, s2): host libm
   long long planes_per_image;     // samples

@@ -638,12 +638,10 @@ __device__ __forceinline__ void for_each_nonzero(const int16_t *__restrict__ qb,
 }
 
 // k_stats_ac on compact records (the final statistics of the sequential scan)
-// `only` != nullptr: the deferred-only form behind the tile-sorted trellis with fused statistics -- only the blocks it
-// flagged (0xFF) are counted, a workgroup without one leaves at once; the dummy blocks were counted there as well
 #define STATS_AC_ITER 4
 __global__ void __launch_bounds__(256)
 k_stats_ac_compact(MjhConst C, const int16_t *__restrict__ coef_q, const unsigned long long *__restrict__ nzmask, MjhHuffTable *__restrict__ tabs,
-                   int slots_per_image, int4 slot_of_comp, int count_dummies, const uint8_t *__restrict__ only)
+                   int slots_per_image, int4 slot_of_comp, int count_dummies)
 {
   __shared__ unsigned h[256][16];   // 16 copies of every bin side by side (copy c of bin b in bank (16 b + c) mod 32): the common symbols would otherwise serialise the LDS atomics, and copy-major storage would put all copies of a bin in one bank
   const int comp = blockIdx.y, img = blockIdx.z;
@@ -651,24 +649,13 @@ k_stats_ac_compact(MjhConst C, const int16_t *__restrict__ coef_q, const unsigne
   const int tid = threadIdx.x;
   // STATS_AC_ITER rounds of 256 blocks per workgroup: zeroing and reducing the 16 KB of histograms costs as much as
   // counting one round
-  const uint8_t *flag = only ? only + (size_t)img * C.total_real_blocks + cc.blk_off : nullptr;
-  if (only) {
-    bool any = false;
-#pragma unroll
-    for (int it = 0; it < STATS_AC_ITER; it++) {
-      const int blk = (blockIdx.x * STATS_AC_ITER + it) * 256 + tid;
-      any = any || (blk < cc.nblk && flag[blk] == 0xFFu);
-    }
-    if (__syncthreads_or(any) == 0) return;
-  }
   for (int i = tid; i < 4096; i += 256) (&h[0][0])[i] = 0;
   __syncthreads();
 #pragma unroll 1
   for (int it = 0; it < STATS_AC_ITER; it++) {
     const int blk = (blockIdx.x * STATS_AC_ITER + it) * 256 + tid;
     if ((blockIdx.x * STATS_AC_ITER + it) * 256 >= cc.nblk) break;   // uniform
-    const bool in = blk < cc.nblk && (!only || flag[blk] == 0xFFu);
-    if (only && __builtin_amdgcn_ballot_w64(in) == 0ull) continue;
+    const bool in = blk < cc.nblk;
     const int b = blk < cc.nblk ? blk : cc.nblk - 1;
     const int16_t *q = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + b;
     const unsigned long long m = in ? nzmask[(size_t)img * C.total_real_blocks + cc.blk_off + b] : 0ull;
@@ -3371,7 +3358,7 @@ void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, vo
 void mjh_launch_stats_ac(const MjhConst &C, const void *q, const unsigned long long *nzmask, MjhHuffTable *tabs, int spi, const int slot[4], int count_dummies, int n, hipStream_t s)
 {
   dim3 grid((max_nblk(C) + 255) / 256, C.ncomp, n), gridc((max_nblk(C) + 256 * STATS_AC_ITER - 1) / (256 * STATS_AC_ITER), C.ncomp, n);
-  if (nzmask) hipLaunchKernelGGL(k_stats_ac_compact, gridc, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, make_int4(slot[0], slot[1], slot[2], slot[3]), count_dummies, (const uint8_t *)nullptr);
+  if (nzmask) hipLaunchKernelGGL(k_stats_ac_compact, gridc, dim3(256), 0, s, C, (const int16_t *)q, nzmask, tabs, spi, make_int4(slot[0], slot[1], slot[2], slot[3]), count_dummies);
   else hipLaunchKernelGGL(k_stats_ac, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, make_int4(slot[0], slot[1], slot[2], slot[3]), count_dummies);
 }
 

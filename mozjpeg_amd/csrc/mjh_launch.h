@@ -15,9 +15,9 @@ void mjh_launch_stats_ac(const MjhConst &C, const void *q, const unsigned long l
 void mjh_launch_stats_dc(const MjhConst &C, const void *q, MjhHuffTable *tabs, int spi, const int slot[4], int mcu_order, const int comp_restart[4], int n, hipStream_t s);
 void mjh_launch_gen_tables(MjhHuffTable *tabs, int spi, const int *slots, int nslots, int n, hipStream_t s);
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
-                           unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, const int *stat_slot, int variant,
+                           unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
-                           uint8_t *nq8 = nullptr, int v3_passes = 0, int fastdiv = 0);   // (with stat_slot and the tile-sorted kernel: the final AC statistics are counted in its back-track)   // v3_passes > 0 (plain compact pass, variant 0): the tile-sorted kernel with that many passes
+                           uint8_t *nq8 = nullptr, int v3_passes = 0, int fastdiv = 0);   // v3_passes > 0 (plain compact pass): the tile-sorted kernel with that many passes per tile
 // trellis_eob_opt: the block-row pass behind a (band-limited) AC trellis; eob_cost / eob_has as written by mjh_launch_trellis_ac
 void mjh_launch_trellis_eob_chain(const MjhConst &C, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const void *eob_cost, const int *eob_has,
                                   int Ss, int Se, int n, hipStream_t s);

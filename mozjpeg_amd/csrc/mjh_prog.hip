@@ -2235,7 +2235,7 @@ void mjh_launch_prog_stats_par(const MjhConst &C, const void *scans, const int *
   else hipLaunchKernelGGL((k_pp_stats<false, 0>), gchunks, dim3(256), 0, s, C, (const MjhProgScan *)sv, list, (const MjhProgCtl *)ctl, qv,
                           nzmask, tabs, spi, pe, 0);
   if (any_refine) {   // prefix sums of the trailing correction bits: only refinement scans have any, and they sit behind the first-pass AC scans
-    const size_t po = (nzmask && !(es && atoi(es) == 0)) ? (size_t)nacf * n : 0;
+    const size_t po = nzmask ? (size_t)nacf * n : 0;
     mjh_launch_scan16(pe.tail16 + po * pe.nblk_pad, pe.nblk_pad, pe.tsums + po * pe.chunks_per_scan, pe.chunks_per_scan, pe.ttotals + po,
                       pe.T32 + po * pe.nblk_pad, nlist * n - (int)po, s);
   }

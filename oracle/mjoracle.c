@@ -111,6 +111,7 @@ void mjo_default_params(mjo_params *p, int width, int height, int input_componen
   p->optimize_coding = !profile_fastest;
   p->trellis_quant = !profile_fastest;
   p->trellis_quant_dc = 1;
+  { int t; for (t = 0; t < 4; t++) { p->arith_dc_L[t] = 0; p->arith_dc_U[t] = 1; p->arith_ac_K[t] = 5; } }   /* jcparam.c:417-419 */
   p->overshoot_deringing = !profile_fastest;
   p->lambda_log_scale1 = 14.75f;
   p->lambda_log_scale2 = 16.5f;
@@ -1292,7 +1293,7 @@ static void trellis_component(enc_t *e, int ci, const dtbl *dctbl, const dtbl *a
  * ------------------------------------------------------------------------------------------ */
 #include "mjo_arith_table.h"
 
-enum { ARI_DC_L = 0, ARI_DC_U = 1, ARI_AC_K = 5 };   /* conditioning defaults, jcparam.c:417-419 (the DAC marker carries them) */
+/* conditioning: mjo_params.arith_dc_L / arith_dc_U / arith_ac_K (defaults 0 / 1 / 5, jcparam.c:417-419; the DAC marker carries them) */
 
 typedef struct {
   long c, a, sc, zc;     /* code register, interval, stacked 0xFF bytes, pending 0x00 bytes (jcarith.c:31-38) */
@@ -1301,6 +1302,7 @@ typedef struct {
   unsigned char dc_stats[4][64], ac_stats[4][256];
   unsigned char fixed_bin[4];
   int last_dc_val[MJO_MAX_COMPS], dc_context[MJO_MAX_COMPS];
+  const mjo_params *p;   /* the conditioning values */
 } arith_t;
 
 static void ari_byte(arith_t *A, int v) { if (A->out) bb_put(A->out, v); }
@@ -1400,7 +1402,7 @@ static void ari_reset_stats(arith_t *A, const enc_t *e, const scan_t *sc, int pr
 /* magnitude category + magnitude bits of v >= 1 (Figures F.8, F.9): st = the first magnitude bin (SP / SN / the bin behind
  * the sign), x1 = where the category bins continue (X1 = 20 for DC; for AC the bin itself once more, then 189 / 217);
  * returns the category mask m (the DC conditioning needs it) */
-static int ari_magnitude(arith_t *A, unsigned char *stats, unsigned char *st, int v, int ac, int k)
+static int ari_magnitude(arith_t *A, unsigned char *stats, unsigned char *st, int v, int ac, int k, int kx)
 {
   int m = 0, v2;
   if (v -= 1) {
@@ -1411,7 +1413,7 @@ static int ari_magnitude(arith_t *A, unsigned char *stats, unsigned char *st, in
       if (v2 >>= 1) {
         ari_encode(A, st, 1);
         m <<= 1;
-        st = stats + (k <= ARI_AC_K ? 189 : 217);
+        st = stats + (k <= kx ? 189 : 217);
         while (v2 >>= 1) { ari_encode(A, st, 1); m <<= 1; st++; }
       }
     } else {
@@ -1441,9 +1443,9 @@ static void ari_dc(arith_t *A, int tbl, int ci, int value)
   ari_encode(A, st, 1);
   if (v > 0) { ari_encode(A, st + 1, 0); st += 2; A->dc_context[ci] = 4; }
   else { v = -v; ari_encode(A, st + 1, 1); st += 3; A->dc_context[ci] = 8; }
-  m = ari_magnitude(A, stats, st, v, 0, 0);
-  if (m < (int)((1L << ARI_DC_L) >> 1)) A->dc_context[ci] = 0;
-  else if (m > (int)((1L << ARI_DC_U) >> 1)) A->dc_context[ci] += 8;
+  m = ari_magnitude(A, stats, st, v, 0, 0, 0);
+  if (m < (int)((1L << A->p->arith_dc_L[tbl]) >> 1)) A->dc_context[ci] = 0;
+  else if (m > (int)((1L << A->p->arith_dc_U[tbl]) >> 1)) A->dc_context[ci] += 8;
 }
 
 static void ari_ac_first(arith_t *A, int tbl, const int16_t *blk, int Ss, int Se, int Al)
@@ -1472,7 +1474,7 @@ static void ari_ac_first(arith_t *A, int tbl, const int16_t *blk, int Ss, int Se
     }
     ari_encode(A, st + 1, 1);
     ari_encode(A, A->fixed_bin, neg);
-    ari_magnitude(A, stats, st + 2, v, 1, k);
+    ari_magnitude(A, stats, st + 2, v, 1, k, A->p->arith_ac_K[tbl]);
   }
   if (k <= Se) ari_encode(A, stats + 3 * (k - 1), 1);
 }
@@ -1553,6 +1555,7 @@ static void ari_code_rows(enc_t *e, const scan_t *sc, arith_t *A, int sequential
 static void ari_start(arith_t *A, const enc_t *e, const scan_t *sc, int progressive, bytebuf *out)
 {
   memset(A, 0, sizeof(*A));
+  A->p = e->p;
   A->out = out;
   A->fixed_bin[0] = 113;
   ari_reset_stats(A, e, sc, progressive);
@@ -1663,8 +1666,8 @@ static void trellis_row_arith(enc_t *e, int ci, const ari_rates *r, int br, int 
               while (v2 >>= 1) { bits += r->dc[st][1]; m <<= 1; st++; }
             }
             bits += r->dc[st][0];
-            if (m < (int)((1L << ARI_DC_L) >> 1)) upd = 0;
-            else if (m > (int)((1L << ARI_DC_U) >> 1)) upd += 8;
+            if (m < (int)((1L << p->arith_dc_L[p->dc_tbl_no[ci]]) >> 1)) upd = 0;
+            else if (m > (int)((1L << p->arith_dc_U[p->dc_tbl_no[ci]]) >> 1)) upd += 8;
             st += 14;
             while (m >>= 1) bits += r->dc[st][(m & dc_delta) ? 1 : 0];
           }
@@ -1720,7 +1723,7 @@ static void trellis_row_arith(enc_t *e, int ci, const ari_rates *r, int br, int 
             if (v2 >>= 1) {
               coef_bits += r->ac[st][1];
               m <<= 1;
-              st = i <= ARI_AC_K ? 189 : 217;
+              st = i <= p->arith_ac_K[p->ac_tbl_no[ci]] ? 189 : 217;
               while (v2 >>= 1) { coef_bits += r->ac[st][1]; m <<= 1; st++; }
             }
           }
@@ -1923,8 +1926,8 @@ static void emit_scan_header(enc_t *e, const scan_t *sc, bytebuf *o)
       bb_put(o, 0xFF); bb_put(o, 0xCC);
       bb_put2(o, length * 2 + 2);
       for (i = 0; i < 4; i++) {
-        if (dc_in_use[i]) { bb_put(o, i); bb_put(o, ARI_DC_L + (ARI_DC_U << 4)); }
-        if (ac_in_use[i]) { bb_put(o, i + 0x10); bb_put(o, ARI_AC_K); }
+        if (dc_in_use[i]) { bb_put(o, i); bb_put(o, p->arith_dc_L[i] + (p->arith_dc_U[i] << 4)); }
+        if (ac_in_use[i]) { bb_put(o, i + 0x10); bb_put(o, p->arith_ac_K[i]); }
       }
     }
   } else if (!p->fastest_profile) {

@@ -72,6 +72,8 @@ typedef struct {
                                    * set it through mjo_set_dc_scan_opt_mode (it rebuilds the script) */
   int arith_code;                 /* cinfo->arith_code (cjpeg -arithmetic): QM-coder instead of Huffman, SOF9 / SOF10, DAC markers;
                                    * with trellis_quant the rate model of quantize_trellis_arith */
+  int arith_dc_L[4], arith_dc_U[4], arith_ac_K[4];   /* cinfo->arith_dc_L / arith_dc_U / arith_ac_K of conditioning tables 0 / 1 (jpeglib.h:447-449;
+                                   * defaults 0 / 1 / 5, jcparam.c:417-419): jcarith.c:442-445,533,757-760,802,949-951, jcmarker.c:440-444 */
 } mjo_params;
 /* jpeg_set_colorspace(cinfo, JCS_RGB) (jcparam.c:611-619): three 1x1 components 'R' 'G' 'B', tables 0, no JFIF marker */
 void mjo_set_rgb_output(mjo_params *p);

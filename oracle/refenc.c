@@ -66,6 +66,7 @@ int main(int argc, char **argv)
   int dc_scan_opt = -1;
   double dc_ver_weight = -1e9;
   int precision = 8, yuvin = 0, arithmetic = 0, trellis_loops = 0, smooth = 0, trellis_q_opt = 0, eob_opt = 0, scans_in_trellis = 0, freq_split = 0;
+  const char *arith_cond = NULL;
   const char *dump = NULL, *in = NULL, *out = NULL;
   int i, w, h, nc;
   unsigned char *img;
@@ -109,6 +110,7 @@ int main(int argc, char **argv)
     else if (!strcmp(a, "-trellis-dc-ver-weight")) dc_ver_weight = atof(argv[++i]);   /* cjpeg.c:667-672 */
     else if (!strcmp(a, "-smooth")) smooth = atoi(argv[++i]);   /* cjpeg -smooth N (cjpeg.c: cinfo->smoothing_factor) */
     else if (!strcmp(a, "-arithmetic")) arithmetic = 1;   /* cjpeg -arithmetic (cjpeg.c:371-376): cinfo->arith_code */
+    else if (!strcmp(a, "-arith-cond")) arith_cond = argv[++i];   /* L0,U0,K0,L1,U1,K1: cinfo->arith_dc_L / arith_dc_U / arith_ac_K of tables 0 and 1 (API-only fields, jpeglib.h:447-449) */
     else if (!strcmp(a, "-yuvin")) yuvin = 1;   /* -raw W H input holds component planes: jpeg_write_raw_data */
     else if (!in) in = a;
     else out = a;
@@ -160,6 +162,11 @@ int main(int argc, char **argv)
     if (baseline) { cinfo.num_scans = 0; cinfo.scan_info = NULL; }
     if (optimize) cinfo.optimize_coding = TRUE;
     if (arithmetic) cinfo.arith_code = TRUE;
+    if (arith_cond) {
+      int v[6] = { 0, 1, 5, 0, 1, 5 }, t;
+      sscanf(arith_cond, "%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]);
+      for (t = 0; t < 2; t++) { cinfo.arith_dc_L[t] = (UINT8)v[3 * t]; cinfo.arith_dc_U[t] = (UINT8)v[3 * t + 1]; cinfo.arith_ac_K[t] = (UINT8)v[3 * t + 2]; }
+    }
     if (fastcrush) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_OPTIMIZE_SCANS, FALSE);
     if (dc_scan_opt >= 0) jpeg_c_set_int_param(&cinfo, JINT_DC_SCAN_OPT_MODE, dc_scan_opt);   /* a switch: before the script is rebuilt */
     if (dc_ver_weight > -1e8) jpeg_c_set_float_param(&cinfo, JFLOAT_TRELLIS_DELTA_DC_WEIGHT, (float)dc_ver_weight);

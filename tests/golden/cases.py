@@ -126,6 +126,11 @@ CASES = [
     ("arith_fastcrush_restart2", dict(arithmetic=True, fastcrush=True, restart=2), True),
     ("arith_default_progressive", dict(arithmetic=True), True),
     ("arith_q40_422_progressive", dict(arithmetic=True, quality=40, sample=(2, 1)), True),
+    # non-default conditioning (cinfo->arith_dc_L / arith_dc_U / arith_ac_K, API-only fields; refenc -arith-cond): DC category
+    # thresholds and the AC position Kx, per table, in the coder, its trellis rate model and the DAC marker
+    ("arith_base_cond", dict(arithmetic=True, baseline=True, arith_cond=((1, 3, 9), (0, 2, 20))), True),
+    ("arith_fastcrush_cond", dict(arithmetic=True, fastcrush=True, arith_cond=((2, 5, 1), (1, 1, 63))), True),
+    ("arith_default_progressive_cond", dict(arithmetic=True, quality=85, arith_cond=((0, 15, 12), (3, 4, 2))), True),
 ]
 
 

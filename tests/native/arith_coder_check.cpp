@@ -12,6 +12,9 @@
 #define MJH_ARI_HOST 1
 #include "../../mozjpeg_amd/csrc/mjh_arith_coder.h"
 
+// conditioning of tables 0 / 1 (cinfo->arith_dc_L / arith_dc_U / arith_ac_K), redrawn for every scan of the check
+static int CHK_DC_L[2] = { 0, 0 }, CHK_DC_U[2] = { 1, 1 }, CHK_AC_K[2] = { 5, 5 };
+
 // ---- plain restatement ------------------------------------------------------------------------------------------------
 struct Ref {
   unsigned char ac[2][256], dc[2][64], fixed_bin;
@@ -120,8 +123,8 @@ struct Ref {
       while (v2 >>= 1) { encode(st, 1); m <<= 1; st += 1; }
     }
     encode(st, 0);
-    if (m < (int)((1L << ARI_DC_L) >> 1)) ctx[ci] = 0;
-    else if (m > (int)((1L << ARI_DC_U) >> 1)) ctx[ci] += 8;
+    if (m < (int)((1L << CHK_DC_L[tbl]) >> 1)) ctx[ci] = 0;
+    else if (m > (int)((1L << CHK_DC_U[tbl]) >> 1)) ctx[ci] += 8;
     st += 14;
     while (m >>= 1) encode(st, (m & v) ? 1 : 0);
   }
@@ -154,7 +157,7 @@ struct Ref {
         if (v2 >>= 1) {
           encode(st, 1);
           m <<= 1;
-          st = base + (k <= ARI_AC_K ? 189 : 217);
+          st = base + (k <= CHK_AC_K[tbl] ? 189 : 217);
           while (v2 >>= 1) { encode(st, 1); m <<= 1; st += 1; }
         }
       }
@@ -211,7 +214,12 @@ struct Dev {
     A.lane0 = true; A.out = buf.data(); A.pos = 0; A.cap = (unsigned)buf.size();
     A.reset();
   }
-  void bind(int ta, int td) { for (int r = 0; r < 4; r++) M.cur[r] = M.ac[ta][r]; M.dcur = M.dc[td]; }
+  void bind(int ta, int td)
+  {
+    for (int r = 0; r < 4; r++) M.cur[r] = M.ac[ta][r];
+    M.dcur = M.dc[td];
+    M.dc_lo = (int)((1L << CHK_DC_L[td]) >> 1); M.dc_hi = (int)((1L << CHK_DC_U[td]) >> 1); M.ac_k = CHK_AC_K[ta];
+  }
   void unbind(int ta, int td) { for (int r = 0; r < 4; r++) M.ac[ta][r] = M.cur[r]; M.dc[td] = M.dcur; }
   void load(const short *blk) { for (int k = 0; k < 64; k++) M.coef.v[k] = blk[k]; }
 };
@@ -262,6 +270,10 @@ int main(int argc, char **argv)
     memset(R.ac, 0, sizeof R.ac); memset(R.dc, 0, sizeof R.dc); R.fixed_bin = 113;
     for (int i = 0; i < 4; i++) { R.last_dc[i] = R.ctx[i] = D.last_dc[i] = D.ctx[i] = 0; }
     R.reset_coder();
+    for (int t = 0; t < 2; t++) {           // every third scan with the defaults, the others with random legal values (0 <= L <= U <= 15, 1 <= K <= 63)
+      const bool def = scan % 3 == 0;
+      CHK_DC_L[t] = def ? 0 : (int)(rnd() % 6); CHK_DC_U[t] = def ? 1 : CHK_DC_L[t] + (int)(rnd() % (unsigned)(16 - CHK_DC_L[t])); CHK_AC_K[t] = def ? 5 : 1 + (int)(rnd() % 63);
+    }
     const int mode = (int)(rnd() % 5);      // 0 whole blocks, 1 DC first, 2 DC refine, 3 AC first, 4 AC refine
     const int ncomp = mode <= 2 ? 1 + (int)(rnd() % 3) : 1;
     int ta[4], td[4];

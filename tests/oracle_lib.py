@@ -35,7 +35,7 @@ class Params(C.Structure):
                 ("smoothing_factor", C.c_int), ("trellis_q_opt", C.c_int),
                 ("trellis_eob_opt", C.c_int), ("use_scans_in_trellis", C.c_int), ("trellis_freq_split", C.c_int),
                 ("rgb_output", C.c_int), ("trellis_delta_dc_weight", C.c_float), ("dc_scan_opt_mode", C.c_int),
-                ("arith_code", C.c_int)]
+                ("arith_code", C.c_int), ("arith_dc_L", C.c_int * 4), ("arith_dc_U", C.c_int * 4), ("arith_ac_K", C.c_int * 4)]
 
 
 class Geom(C.Structure):
@@ -75,7 +75,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 noovershoot=False, sample=(2, 2), restart=None, gray=False, grayin=False,
                 quant_table=-1, lambda1=None, lambda2=None, precision=8, trellis_loops=1, smooth=0, trellis_q_opt=False,
                 trellis_eob_opt=False, use_scans_in_trellis=False, trellis_freq_split=0, rgb=False,
-                dc_scan_opt=None, dc_ver_weight=None, arithmetic=False):
+                dc_scan_opt=None, dc_ver_weight=None, arithmetic=False, arith_cond=None):
     """Same switch vocabulary as cjpeg / oracle/refenc.c.  Default (no switch) is cjpeg's default:
     max-compression profile, progressive with scan search."""
     p = Params()
@@ -102,6 +102,9 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     p.use_scans_in_trellis = 1 if use_scans_in_trellis else 0
     p.trellis_freq_split = trellis_freq_split
     p.arith_code = 1 if arithmetic else 0
+    if arith_cond is not None:     # ((L, U, K) of conditioning table 0, (L, U, K) of table 1)
+        for t, (lo, up, kx) in enumerate(arith_cond):
+            p.arith_dc_L[t], p.arith_dc_U[t], p.arith_ac_K[t] = lo, up, kx
     if rgb:
         L.mjo_set_rgb_output(C.byref(p))
     if dc_ver_weight is not None:
@@ -322,6 +325,8 @@ def ref_switches(**kw):
         sw += ["-trellis-loops", str(kw["trellis_loops"])]
     if kw.get("arithmetic"):
         sw.append("-arithmetic")
+    if kw.get("arith_cond") is not None:      # (refenc's own switch: the API fields cinfo->arith_dc_L / arith_dc_U / arith_ac_K have no cjpeg switch)
+        sw += ["-arith-cond", ",".join(str(v) for t in kw["arith_cond"] for v in t)]
     return sw
 
 

@@ -114,31 +114,27 @@ def test_collect_errors():
     enc.close()
 
 
-def test_device_entry_right_behind_a_host_batch_and_split_batches():
+def test_device_entry_right_behind_a_host_batch():
     """(a) mjh_encode_device straight behind mjh_encode_host on the same encoder, nothing collected in between: the host
     batch's files are still being packed out of the single output buffers, the device batch has to wait for them and both
-    come out right.  (b) a batch large enough to be split into concurrent image ranges gives the files of an unsplit run."""
+    come out right, for several batch sizes of one encoder."""
     import torch
     w, h = 640, 360
     kw = dict(quality=75, baseline=True)
-    B = 30                                            # two ranges of 15
+    B = 30
     frames = np.stack([O.synthetic_frame(w, h, 700 + i) for i in range(B)])
     refs = [_ref(w, h, kw, f) for f in frames]
-    os.environ["MJH_SPLIT"] = "2"                      # read when the encoder is created
-    try:
-        enc = M.Encoder(M.make_params(w, h, **kw), max_batch=B)
-    finally:
-        del os.environ["MJH_SPLIT"]
+    enc = M.Encoder(M.make_params(w, h, **kw), max_batch=B)
     d = torch.from_numpy(frames).cuda()
     torch.cuda.synchronize()
-    for n in (B, B - 7, 16, 15, 1):                   # ragged second range, one image in it, exactly one range (unsplit), one image
+    for n in (B, B - 7, 16, 15, 1):
         enc.submit_host(frames[::-1][:n].copy())      # host batch (the frames reversed) ...
         enc.encode_tensor(d[:n], stream="own")        # ... and a device batch right behind it
         enc.sync()
         assert [enc.get_jpeg(i) for i in range(n)] == refs[:n]
         enc.submit_host(frames[:n])                   # and a host batch behind a device batch
         assert enc.collect(age=0) == refs[:n]
-    # profiling works through the split: every kernel of the schedule is reported once per call
+    # every kernel of the schedule is reported once per call
     enc.set_profiling(1)
     enc.encode_tensor(d, stream="own")
     names = [k for k, _ in enc.kernel_times()]
