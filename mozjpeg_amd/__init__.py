@@ -140,8 +140,13 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     `revert` this is cjpeg's default: progressive with scan search (`fastcrush`: fixed 9-scan script)."""
     p = Params()
     L = lib()
+    per_comp = isinstance(sample[0], (tuple, list))      # ((h, v) of Y, (h, v) of Cb, (h, v) of Cr): cjpeg -sample HxV,HxV,HxV
+    s0 = sample[0] if per_comp else sample
     _chk(L.mjh_params_defaults(C.byref(p), width, height, 1 if grayin else 3, 1 if gray else 0,
-                               PROFILE_FASTEST if revert else PROFILE_MAX_COMPRESSION, sample[0], sample[1]))
+                               PROFILE_FASTEST if revert else PROFILE_MAX_COMPRESSION, s0[0], s0[1]))
+    if per_comp and p.num_components == 3:
+        for i in range(3):
+            p.h_samp_factor[i], p.v_samp_factor[i] = sample[i]
     _chk(L.mjh_params_set_quality(C.byref(p), quality, 1 if baseline else 0, quant_table))
     if optimize:
         p.optimize_coding = 1

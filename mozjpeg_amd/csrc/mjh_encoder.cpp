@@ -394,12 +394,20 @@ static int check_supported(const mjh_params *p)
   if (p->num_components == 1 && (p->h_samp_factor[0] != 1 || p->v_samp_factor[0] != 1))
     return fail(MJH_EUNSUPPORTED, "grayscale must be sampled 1x1");
   if (p->num_components == 3) {
-    const int h = p->h_samp_factor[0], v = p->v_samp_factor[0];
-    // 1x1 chroma with luma 1/2/4 in either direction, at most 10 blocks per MCU (C_MAX_BLOCKS_IN_MCU, jcmaster.c:540-544):
-    // 4:4:4, 4:2:2, 4:4:0, 4:2:0, 4:1:1, 4:4:1 and the 4x2 / 2x4 ratios
-    if (!((h == 1 || h == 2 || h == 4) && (v == 1 || v == 2 || v == 4) && h * v + 2 <= 10)) return fail(MJH_EUNSUPPORTED, "luma sampling %dx%d", h, v);
-    for (int i = 1; i < 3; i++)
-      if (p->h_samp_factor[i] != 1 || p->v_samp_factor[i] != 1) return fail(MJH_EUNSUPPORTED, "chroma sampling must be 1x1");
+    // any sampling factors the reference takes (initial_setup jcmaster.c:210-259, jinit_downsampler jcsample.c:486-535): 1..4 each,
+    // every component's factor divides the largest (no fractional downsampling), at most 10 blocks per MCU
+    // (C_MAX_BLOCKS_IN_MCU, jcmaster.c:540-544).  4:4:4, 4:2:2, 4:4:0, 4:2:0, 4:1:1, 4:4:1 and the 4x2 / 2x4 ratios have their own
+    // colour kernels; everything else (chroma other than 1x1, luma smaller than chroma) takes the generic one.
+    int maxh = 1, maxv = 1, blocks = 0;
+    for (int i = 0; i < 3; i++) {
+      const int h = p->h_samp_factor[i], v = p->v_samp_factor[i];
+      if (h < 1 || h > 4 || v < 1 || v > 4) return fail(MJH_EINVAL, "sampling factors %dx%d of component %d (1..4, jcmaster.c:216-218)", h, v, i);
+      maxh = h > maxh ? h : maxh; maxv = v > maxv ? v : maxv;
+      blocks += h * v;
+    }
+    for (int i = 0; i < 3; i++)
+      if (maxh % p->h_samp_factor[i] || maxv % p->v_samp_factor[i]) return fail(MJH_EUNSUPPORTED, "fractional sampling ratio (the reference: JERR_FRACT_SAMPLE_NOTIMPL, jcsample.c:531)");
+    if (blocks > 10) return fail(MJH_EINVAL, "%d blocks per MCU (at most 10, jcmaster.c:540-544)", blocks);
   }
   if (p->input_components == 3) {
     const int ps = p->input_pixel_size ? p->input_pixel_size : 3;

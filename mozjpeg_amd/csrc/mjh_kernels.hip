@@ -181,6 +181,35 @@ k_color_smooth(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, si
   planes[(size_t)img * C.planes_per_image + cc.plane_off + (size_t)r * cc.pw + c] = (T)val;
 }
 
+// Any legal set of sampling factors (cjpeg -sample HxV,HxV,HxV with chroma other than 1x1, or luma that is not the largest
+// component): one lane = one output sample of one component, its hexp x vexp box converted pixel by pixel.  Row r of a
+// component comes from input rows (r / v) * maxv + (r % v) * vexp ..., the rows behind the last real row group replicate the
+// last DOWNSAMPLED row (jcprepct.c:180-190), input rows / columns beyond the image repeat the last one (jcprepct.c:161-168,
+// jcsample.c:98-116); fullsize / h2v1 / h2v2 / int_downsample roundings (jcsample.c:199,226,263,151).  A rare configuration:
+// clarity over speed (the common ones keep k_color / k_color_vec).
+template <class T>
+__global__ void __launch_bounds__(256)
+k_color_generic(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, size_t img_stride, T *__restrict__ planes)
+{
+  const int comp = blockIdx.z % C.ncomp, img = blockIdx.z / C.ncomp;
+  const MjhComp cc = C.c[comp];
+  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (r >= cc.ph || c >= cc.pw) return;
+  const uint8_t *p = pix + (size_t)img * img_stride;
+  const int real_rows = C.real_groups_y * cc.v;
+  const int rr = r < real_rows ? r : real_rows - 1;
+  const int in_row0 = (rr / cc.v) * C.maxv + (rr % cc.v) * cc.vexp;
+  int sum = 0;
+  for (int vv = 0; vv < cc.vexp; vv++)
+    for (int hh = 0; hh < cc.hexp; hh++) sum += smooth_px<T>(C, p, row_pitch, comp, in_row0 + vv, c * cc.hexp + hh);   // (clamps to the image)
+  int val;
+  if (cc.hexp == 1 && cc.vexp == 1) val = sum;
+  else if (cc.hexp == 2 && cc.vexp == 1) val = (sum + (c & 1)) >> 1;
+  else if (cc.hexp == 2 && cc.vexp == 2) val = (sum + 1 + (c & 1)) >> 2;
+  else { const int n = cc.hexp * cc.vexp; val = (sum + n / 2) / n; }
+  planes[(size_t)img * C.planes_per_image + cc.plane_off + (size_t)r * cc.pw + c] = (T)val;
+}
+
 // Vectorised variant for the common case (8-bit, 3 bytes per pixel, 2:1 horizontal chroma
 // subsampling, 8-byte aligned rows): one lane converts 8 pixels x V0 rows = 4 chroma samples.  The
 // 24 bytes per row arrive as three 8-byte loads, Y leaves as one 8-byte store per row, Cb/Cr as one
@@ -3317,6 +3346,17 @@ void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size
     dim3 grid((pw + 255) / 256, ph, n * C.ncomp);
     if (C.precision == 12) hipLaunchKernelGGL((k_color_smooth<uint16_t>), grid, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint16_t *)planes);
     else hipLaunchKernelGGL((k_color_smooth<uint8_t>), grid, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint8_t *)planes);
+    return;
+  }
+  bool plain = true;       // luma at full resolution, chroma 1x1: what k_color / k_color_vec are written for
+  for (int i = 0; i < C.ncomp; i++) plain = plain && (i == 0 ? (C.c[i].h == H0 && C.c[i].v == V0) : (C.c[i].h == 1 && C.c[i].v == 1));
+  plain = plain && (H0 == 1 || H0 == 2 || H0 == 4) && (V0 == 1 || V0 == 2 || V0 == 4);      // (3x1 and the like: the generic kernel)
+  if (!plain) {
+    int pw = 0, ph = 0;
+    for (int i = 0; i < C.ncomp; i++) { pw = C.c[i].pw > pw ? C.c[i].pw : pw; ph = C.c[i].ph > ph ? C.c[i].ph : ph; }
+    dim3 grid((pw + 255) / 256, ph, n * C.ncomp);
+    if (C.precision == 12) hipLaunchKernelGGL((k_color_generic<uint16_t>), grid, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint16_t *)planes);
+    else hipLaunchKernelGGL((k_color_generic<uint8_t>), grid, dim3(256), 0, s, C, (const uint8_t *)pix, row_pitch, img_stride, (uint8_t *)planes);
     return;
   }
   if (!C.no_ycc && C.precision == 8 && C.in_comps == 3 && C.ncomp == 3 && C.px_size == 3 && H0 == 2 && V0 <= 2 && (row_pitch & 7) == 0 &&

@@ -61,7 +61,7 @@ int main(int argc, char **argv)
 {
   int quality = 75, baseline = 0, revert = 0, optimize = 0, progressive = 0, fastcrush = 0;
   int notrellis = 0, notrellis_dc = 0, noovershoot = 0, gray = 0, rgbout = 0, grayin = 0, qtbl = -1;
-  int hs = 2, vs = 2, restart = 0, restart_blocks = 0, reps = 1, rawW = 0, rawH = 0;
+  int hs = 2, vs = 2, hs1 = 1, vs1 = 1, hs2 = 1, vs2 = 1, nsamp = 2, restart = 0, restart_blocks = 0, reps = 1, rawW = 0, rawH = 0;
   double l1 = -1e9, l2 = -1e9;
   int dc_scan_opt = -1;
   double dc_ver_weight = -1e9;
@@ -91,7 +91,9 @@ int main(int argc, char **argv)
     else if (!strcmp(a, "-quant-table")) qtbl = atoi(argv[++i]);
     else if (!strcmp(a, "-lambda1")) l1 = atof(argv[++i]);
     else if (!strcmp(a, "-lambda2")) l2 = atof(argv[++i]);
-    else if (!strcmp(a, "-sample")) { sscanf(argv[++i], "%dx%d", &hs, &vs); }
+    else if (!strcmp(a, "-sample")) {   /* cjpeg -sample HxV[,HxV,HxV] (set_sample_factors rdswitch.c): the luma factors, or all three components' */
+      nsamp = sscanf(argv[++i], "%dx%d,%dx%d,%dx%d", &hs, &vs, &hs1, &vs1, &hs2, &vs2);
+    }
     else if (!strcmp(a, "-restart")) {
       char ch = 'x'; long v = 0;
       sscanf(argv[++i], "%ld%c", &v, &ch);
@@ -187,6 +189,10 @@ int main(int argc, char **argv)
       cinfo.comp_info[0].v_samp_factor = vs;
       cinfo.comp_info[1].h_samp_factor = cinfo.comp_info[1].v_samp_factor = 1;
       cinfo.comp_info[2].h_samp_factor = cinfo.comp_info[2].v_samp_factor = 1;
+      if (nsamp == 6) {
+        cinfo.comp_info[1].h_samp_factor = hs1; cinfo.comp_info[1].v_samp_factor = vs1;
+        cinfo.comp_info[2].h_samp_factor = hs2; cinfo.comp_info[2].v_samp_factor = vs2;
+      }
     }
     if (restart) {
       if (restart_blocks) { cinfo.restart_interval = restart; cinfo.restart_in_rows = 0; }

@@ -109,6 +109,13 @@ CASES = [
     ("q3_16bit_trellis_q_opt", dict(quality=3, fastcrush=True, trellis_q_opt=True), True),
     ("q20_table0_mixed_precision_q_opt", dict(quality=20, fastcrush=True, quant_table=0, trellis_q_opt=True), True),
     ("q40_progressive_eob_opt_restart1", dict(trellis_eob_opt=True, quality=40, restart=1), True),
+    # sampling factors beyond "luma HxV, chroma 1x1" (cjpeg -sample HxV,HxV,HxV; initial_setup jcmaster.c:210-259): chroma that is
+    # itself subsampled unevenly, luma smaller than chroma, a 3:1 ratio (int_downsample jcsample.c:151), all components 2x1
+    ("base_samp_22_21_11", dict(baseline=True, sample=((2, 2), (2, 1), (1, 1))), True),
+    ("default_samp_21_11_12", dict(sample=((2, 1), (1, 1), (1, 2))), True),
+    ("revert_samp_12_22_11", dict(revert=True, sample=((1, 2), (2, 2), (1, 1))), True),
+    ("base_samp_31_11_11", dict(baseline=True, sample=((3, 1), (1, 1), (1, 1))), True),
+    ("fastcrush_samp_21_21_21_restart1", dict(fastcrush=True, restart=1, sample=((2, 1), (2, 1), (2, 1))), True),
     # arithmetic entropy coding (cjpeg -arithmetic): jcarith.c (sequential SOF9, progressive SOF10, restarts,
     # DAC markers), with the coder's own trellis rate model (quantize_trellis_arith jcdctmgr.c:1334-1667) where trellis is on
     ("arith_revert", dict(arithmetic=True, revert=True), True),

@@ -80,8 +80,13 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     max-compression profile, progressive with scan search."""
     p = Params()
     L = lib()
+    per_comp = isinstance(sample[0], (tuple, list))      # ((h, v) of Y, (h, v) of Cb, (h, v) of Cr): cjpeg -sample HxV,HxV,HxV
+    s0 = sample[0] if per_comp else sample
     L.mjo_default_params(C.byref(p), width, height, 1 if grayin else 3, 1 if gray else 0, quality,
-                         1 if baseline else 0, 1 if revert else 0, sample[0], sample[1], quant_table)
+                         1 if baseline else 0, 1 if revert else 0, s0[0], s0[1], quant_table)
+    if per_comp and p.num_components == 3:
+        for i in range(3):
+            p.h_samp[i], p.v_samp[i] = sample[i]
     if optimize:
         p.optimize_coding = 1
     if notrellis:
@@ -296,7 +301,7 @@ def ref_switches(**kw):
     if kw.get("notrellis_dc"):
         sw.append("-notrellis-dc")
     s = kw.get("sample", (2, 2))
-    sw += ["-sample", "%dx%d" % s]
+    sw += ["-sample", ",".join("%dx%d" % tuple(t) for t in s) if isinstance(s[0], (tuple, list)) else "%dx%d" % s]
     if kw.get("restart") is not None:
         sw += ["-restart", str(kw["restart"])]
     if kw.get("quant_table", -1) >= 0:

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+int g_tight = 0;   /* 1: stop the scan once gap + (smallest possible rate + distortion of any candidate) exceeds the best cost */
 static int bitlen(unsigned v) { int n = 0; while (v) { n++; v >>= 1; } return n; }
 
 /* steps_out: [nblk][64] pair-steps of record r (0 = no such record); ncd4_out[nblk][64]: 1 when the record has more than two candidates */
@@ -38,6 +39,17 @@ void trellis_records(const int16_t *coef, int nblk, const uint16_t *q, const uin
       const int ncd = bitlen(qval);
       double best = 1e38; int bestp = -1;
       int e = nlive - 1, st = 0;
+      double lb = 0;
+      if (g_tight) {
+        lb = 1e38;
+        for (int cd = 0; cd < ncd && cd < 4; cd++) {
+          const int cand = cd < ncd - 1 ? (2 << cd) - 1 : qval;
+          double rmin = 1e38;
+          for (int run = 0; run < 16; run++) { const int sz = ehufsi[(run << 4) + cd + 1]; if (sz && sz + cd + 1 < rmin) rmin = sz + cd + 1; }
+          const double d = (double)(cand * dq - x) * (cand * dq - x) * lambda * lt;
+          if (rmin + d < lb) lb = rmin + d;
+        }
+      }
       while (e >= 0) {
         double gap_last = 0;
         for (int t = 0; t < 2 && e >= 0; t++, e--) {
@@ -55,7 +67,7 @@ void trellis_records(const int16_t *coef, int nblk, const uint16_t *q, const uin
           }
         }
         st++;
-        if (gap_last > best) break;
+        if (gap_last + lb > best) break;
       }
       steps_out[(size_t)b * 64 + nq] = (uint8_t)st;
       ncd4_out[(size_t)b * 64 + nq] = (uint8_t)(ncd > 2);

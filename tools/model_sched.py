@@ -21,6 +21,7 @@ def main():
         os.system("gcc -O2 -shared -fPIC -o %s %s -lm" % (so, so.replace("libtrellis_sched.so", "trellis_sched.c")))
     lib = C.CDLL(so)
     lib.wave_cost.restype = C.c_double
+    C.c_int.in_dll(lib, "g_tight").value = int(os.environ.get("TIGHT", "0"))
     img = O.synthetic_frame(w, h, 1234)
     p = O.make_params(w, h, quality=q, baseline=True, **({"sample": (1, 1)} if q >= 90 else {}))
     _, taps = O.encode(p, img, want_taps=True)
