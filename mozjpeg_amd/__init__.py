@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmozjpeg_hip.so")
+LIB_PATH = os.environ.get("MOZJPEG_AMD_LIB") or os.path.join(_HERE, "libmozjpeg_hip.so")   # (the override: A/B runs of a differently built library, tools/gpu_*.sh)
 
 MAX_COMPS, MAX_SCANS = 4, 64
 PROFILE_MAX_COMPRESSION = 0x5D083AAD

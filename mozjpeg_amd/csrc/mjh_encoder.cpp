@@ -298,6 +298,7 @@ struct mjh_encoder {
   int copy_prio = 0;
   int fastdiv_all = 0;               // every table in use has q <= 255: the kernels divide by 8q with one multiply-high (MjhQuant.mdiv)
   int dc_mode = 0;
+  bool dc_late = true;               // large sequential batches: the chroma DC chains run behind the AC kernel, under the tail of small kernels (MJH_DC_LATE=0: all next to it)
   int dc_stats_side = 1;             // the final DC statistics run on the side stream behind the DC trellis (MJH_DC_STATS_SIDE=0: main stream)
   int dc_window_ok = 0;              // every component's DC quantizer step 8q >= 40: the DC trellis may use its sliding-window kernel
   int trellis_v3 = 4;                // passes per tile of the tile-sorted first tier (MJH_TRELLIS_V3; 0 = the general kernel)
@@ -807,6 +808,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   if (const char *v = getenv("MJH_TRELLIS_VARIANT")) { e->trellis_variant = atoi(v); e->trellis_adapt = false; }
   HIPCHK_E(hipHostMalloc((void **)&e->h_defer, 64, hipHostMallocDefault));
   if (const char *v = getenv("MJH_TRELLIS_V3")) e->trellis_v3 = atoi(v);
+  if (const char *v = getenv("MJH_DC_LATE")) e->dc_late = atoi(v) != 0;   // A/B knob
   e->dc_window_ok = 1;
   for (int i = 0; i < C.ncomp; i++) if (p->quantval[p->quant_tbl_no[i]][0] < 5) e->dc_window_ok = 0;
   if (const char *v = getenv("MJH_DC_SPEC")) e->dc_spec = atoi(v);
@@ -1349,6 +1351,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   // One (statistics, trellis) pass pair: for all components (CV = C) or, with trellis_q_opt, for ONE component through a
   // one-component view of the geometry (MjhComp carries absolute offsets, so the view addresses the same buffers).
   const int nloops = p.trellis_quant && !e->arith ? (p.trellis_num_loops > 1 ? p.trellis_num_loops : 1) : 0;   // (the arithmetic coder has its own trellis pass below)
+  bool join_late = false;            // the side stream (late DC chains + final DC statistics) is joined in front of the final tables
   bool final_dc_counted = false;     // ... and the side stream the DC statistics, right behind the DC trellis (under the AC kernel)
   auto trellis_pass = [&](const MjhConst &CV, const int *sl_dc_seq, const int *sl_dc_prog, const int *sl_ac, const int *crst,
                           const mjh_encoder::PList *plt, int Ss, int Se, bool first_pass, bool last_loop, int qstride) -> int {
@@ -1389,6 +1392,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     // latency-bound chains) and the AC DP (every block) touch disjoint coefficient planes, so the
     // DC kernel runs on a side stream underneath the AC kernel.
     e->side_timed = false;
+    bool dc_late = false;
     const int dc_mode = e->dc_mode;   // experiments (MJH_DC_MODE): 1 = DC trellis on the main stream, before the AC kernel
     if (p.trellis_quant_dc && dc_mode == 1) {
       pr.mark("trellis_dc(serial)");
@@ -1412,16 +1416,24 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
         HIPCHK(mjh_dmalloc((void **)&e->d_jfin, 2 * (size_t)rows * 9 * sizeof(int)));
         HIPCHK(mjh_dmalloc((void **)&e->d_qspec, 2 * (size_t)C.total_real_blocks * 9 * sizeof(int16_t)));
       }
+      // The AC and the DC trellis share one VALU budget while they run side by side, and behind the big AC kernel the main
+      // stream has ~0.4 ms of small, latency-bound kernels (the general tiers, the final AC statistics) that leave the chip
+      // mostly idle.  So, for a large sequential batch, only the LUMA chains (two thirds of the DC work) start next to the AC
+      // kernel; the chroma chains and the final DC statistics start when it has finished and run under that tail, and the
+      // main stream joins the side stream in front of the final tables instead of behind the trellis.
+      const bool final_dc_here = !e->progressive && p.optimize_coding && last_loop && nbands == 1 && qstride == 0 && !ext_eob && e->dc_stats_side;
+      dc_late = e->dc_late && !spec && final_dc_here && nloops == 1 && CV.ncomp == 3 && !e->debug_taps && (size_t)n * C.total_real_blocks >= e->small_batch;
       if (spec) mjh_launch_trellis_dc_speculative(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back9, e->d_jfin, e->d_qspec, n, e->side_stream);
       else
-      mjh_launch_trellis_dc(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, e->side_stream, e->dc_window_ok);   // (the DC entries never change: image 0's tables serve all)
+      mjh_launch_trellis_dc(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, e->side_stream, e->dc_window_ok,
+                            0, dc_late ? CV.mcu_rows : -1);   // (the DC entries never change: image 0's tables serve all)
       if (pr.enabled && e->profiling == 1) { HIPCHK(hipEventRecord(e->side_events[2 * e->prof_calls + 1], e->side_stream)); e->side_timed = true; }
-      if (!e->progressive && p.optimize_coding && last_loop && nbands == 1 && qstride == 0 && !ext_eob && e->dc_stats_side) {
+      if (final_dc_here && !dc_late) {
         // the final DC statistics need nothing but the DC trellis's result: counted here, they cost no time of their own
         mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, fin_dc, 1, zero4, n, e->side_stream);
         final_dc_counted = true;
       }
-      HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
+      if (!dc_late) HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
     }
     const bool extended = nbands > 1 || ext_eob || qstride != 0;
     if (!extended) { const int rc = adapt_first_tier(); if (rc != MJH_OK) return rc; }
@@ -1431,7 +1443,16 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
                           e->trellis_variant,
                           Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, nzm, qstride, n, s,
                           e->d_nq8, v3 ? ((size_t)n * C.total_real_blocks < e->small_batch ? 1 : e->trellis_v3) : 0,   // (a small batch: one pass per tile -- four times the workgroups, a quarter of their length: latency matters more than the sorting)
-                          e->fastdiv_all);
+                          e->fastdiv_all, dc_late ? e->ev_side0 : nullptr);
+    if (dc_late) {
+      if (!v3) return fail(MJH_EINVAL, "internal: the late DC chains need the tile-sorted trellis' event");
+      HIPCHK(hipStreamWaitEvent(e->side_stream, e->ev_side0, 0));
+      mjh_launch_trellis_dc(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, e->side_stream, e->dc_window_ok, CV.mcu_rows, -1);
+      mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, fin_dc, 1, zero4, n, e->side_stream);
+      final_dc_counted = true;
+      HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
+      join_late = true;
+    }
     if (e->trellis_adapt && !extended && first_pass && !e->defer_pending) {   // (one read-back in flight at a time; its frame count travels with it)
       if (!e->ev_defer) HIPCHK(hipEventCreateWithFlags(&e->ev_defer, hipEventDisableTiming));
       e->defer_frames = n;
@@ -1447,7 +1468,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       pr.mark("trellis_q_opt(sums)");
       mjh_launch_qopt_accumulate(CV, e->d_uq, e->d_q, e->d_qsums, n, s);
     }
-    if (p.trellis_quant_dc && dc_mode != 1) {
+    if (p.trellis_quant_dc && dc_mode != 1 && !dc_late) {
       pr.mark("join(trellis_dc)");
       HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
     }
@@ -1546,6 +1567,10 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     if (!final_dc_counted) {
       pr.mark("stats_dc(final)");
       mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, fin_dc, 1, zero4, n, s);
+    }
+    if (join_late) {
+      pr.mark("join(trellis_dc)");
+      HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
     }
     pr.mark("gen_tables(final)");
     mjh_launch_gen_tables(e->d_tabs, spi, e->dht_slots, e->ndht, n, s);

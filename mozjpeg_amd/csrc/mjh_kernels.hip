@@ -382,34 +382,64 @@ __device__ __forceinline__ float catmull_rom(int v1, int v2, int v3, int v4, flo
 // FD: every quantizer step of the tables in use fits 8 bits -- the division by 8q is one shift + one 24-bit multiply-high
 // (MjhQuant.mdiv / sdiv) instead of the float-reciprocal division with its integer fix-up; with STATS the AC coefficients are
 // quantized for the statistics only, which need the magnitude category and nothing else (no sign, no signed clamp).
+#define DCTQ_NB 4      // sets of 64 blocks per wave of the FDCT kernel
 template <class T, bool STATS, bool FD>   // uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
 __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant *__restrict__ Q, const T *__restrict__ planes,
                                                int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
                                                MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out)
 {
   constexpr bool W12 = sizeof(T) == 2;
-  // 8 KB per wave: the deringing columns (the ORIGINAL level-shifted samples of the lane's block in zig-zag order, 16 bits
-  // each for 8- and 12-bit data) and, afterwards, 8 interleaved copies of the 256-bin statistics histogram
+  // A wave takes DCTQ_NB consecutive sets of 64 blocks (round 5; one set per wave before): the statistics histogram is zeroed and
+  // flushed once per wave instead of once per set, and a quarter of the workgroups are launched (1.12 -> 1.07 ms per 64 frames;
+  // 8 sets: the same; prefetching the next set's pixel rows into registers: 1.06 at 211 VGPRs = two waves per SIMD, 1.12 when held
+  // to three waves with spills -- not kept; gpurun_out/r5h, profiles/r05h_fdct_variants.md).
+  // LDS per wave: 8 KB of deringing columns (the ORIGINAL level-shifted samples of the lane's block in zig-zag order, 16 bits
+  // each for 8- and 12-bit data) + 4 KB = 4 interleaved copies of the 256-bin statistics histogram (12 KB: 13 waves per CU).
   constexpr int LW = 32;
   __shared__ int lds_raw[64][LW];
+  constexpr int NCOPY = 4;
+  __shared__ unsigned hist_raw[STATS ? NCOPY * 256 : 1];
   typedef short dcol_t;
   typedef dcol_t __attribute__((may_alias)) dcol_alias;
   const int lane = (int)threadIdx.x;      // one wave per workgroup
   dcol_alias (*lds)[64] = reinterpret_cast<dcol_alias (*)[64]>(&lds_raw[0][0]);
   const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
-  const int blk_raw = blockIdx.x * 64 + lane;
-  if (blockIdx.x * 64 >= cc.nblk) return;       // whole workgroup outside (grid is sized for the largest component)
+  const int set0 = blockIdx.x * DCTQ_NB;
+  if (set0 * 64 >= cc.nblk) return;       // whole workgroup outside (grid is sized for the largest component)
+  constexpr bool stats = STATS;
+  unsigned *hist = hist_raw;
+  if (stats) {
+#pragma unroll
+    for (int j = 0; j < NCOPY * 4; j++) hist[j * 64 + lane] = 0u;
+    __syncthreads();
+  }
+  // copy c of bin b lives at word b * NCOPY + c: the lanes that count the same symbol in different copies hit different banks
+  unsigned *hh = hist + (lane & (NCOPY - 1));
+  typedef typename std::conditional<W12, uint4, uint2>::type row_t;
+  auto load_rows = [&](int set, row_t (&rows)[8]) {
+    const int braw = set * 64 + lane;
+    const int b = braw < cc.nblk ? braw : cc.nblk - 1;
+    const int r0 = b / cc.wib, c0 = b - r0 * cc.wib;
+    const T *src = planes + (size_t)img * C.planes_per_image + cc.plane_off + (size_t)(r0 * 8) * cc.pw + c0 * 8;
+#pragma unroll
+    for (int r = 0; r < 8; r++) rows[r] = *reinterpret_cast<const row_t *>(src + (size_t)r * cc.pw);
+  };
+  row_t rows_cur[8];
+#pragma unroll 1
+  for (int it = 0; it < DCTQ_NB; it++) {
+  const int set = set0 + it;
+  if (set * 64 >= cc.nblk) break;                        // uniform
+  load_rows(set, rows_cur);
+  const int blk_raw = set * 64 + lane;
   const bool valid = blk_raw < cc.nblk;                  // tail lanes redo the last block (identical stores), they only stay out of the statistics
   const int blk = valid ? blk_raw : cc.nblk - 1;
-  const int br = blk / cc.wib, bc = blk - br * cc.wib;
-  const T *src = planes + (size_t)img * C.planes_per_image + cc.plane_off + (size_t)(br * 8) * cc.pw + bc * 8;
   int d[64];
   unsigned ff = 0;     // 8-bit samples: some byte of the block is 255 (the only value that reaches maxsample after the level shift)
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     if (!W12) {
-      const uint2 v = *reinterpret_cast<const uint2 *>(src + (size_t)r * cc.pw);
+      const uint2 v = *reinterpret_cast<const uint2 *>(&rows_cur[r]);
       ff |= ((~v.x - 0x01010101u) & v.x) | ((~v.y - 0x01010101u) & v.y);     // bit 7 of a byte set: that byte (or one above a 255) is 255
 #pragma unroll
       for (int i = 0; i < 4; i++) {
@@ -417,7 +447,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
         d[r * 8 + 4 + i] = (int)((v.y >> (8 * i)) & 0xFF) - 128;
       }
     } else {
-      const uint4 v = *reinterpret_cast<const uint4 *>(src + (size_t)r * cc.pw);
+      const uint4 v = *reinterpret_cast<const uint4 *>(&rows_cur[r]);
       const unsigned w4[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
       for (int i = 0; i < 4; i++) {
@@ -512,19 +542,6 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
   int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
   int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
   const bool clampq = C.deringing != 0;
-  constexpr bool stats = STATS;
-  typedef unsigned __attribute__((may_alias)) hist_alias;
-  constexpr int NCOPY = 8;
-  hist_alias *hist = reinterpret_cast<hist_alias *>(&lds_raw[0][0]);   // NCOPY interleaved copies of 256 bins (the deringing columns are dead)
-  if (stats) {
-    MJH_WAVE_SYNC();        // (the histogram lies over the other lanes' deringing columns, which they have all read by now)
-#pragma unroll
-    for (int j = 0; j < NCOPY * 4; j++) hist[j * 64 + lane] = 0u;
-    __syncthreads();
-  }
-  // copy c of bin b lives at word b * NCOPY + c: the lanes that count the same symbol in different copies hit different banks
-  // (with copy-major storage every copy of a bin shares one bank: 3.9 conflict cycles per LDS instruction, profiles/r04e_pmc_sq)
-  hist_alias *hh = hist + (lane & (NCOPY - 1));
   int run = 0, nzc = 0;   // nzc: non-zero quantized AC coefficients = the AC trellis' queue length (its tile-sort key)
 #pragma unroll
   for (int k = 0; k < 64; k++) {
@@ -565,8 +582,9 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
     }
   }
   if (!W12 && nq8_out && valid) nq8_out[(size_t)img * C.total_real_blocks + cc.blk_off + blk] = (uint8_t)nzc;
+  if (stats && valid && run > 0) atomicAdd(&hh[0], 1u);
+  }   // (sets of this wave)
   if (stats) {
-    if (valid && run > 0) atomicAdd(&hh[0], 1u);
     __syncthreads();
     const int slot = comp == 0 ? stat_slot_of_comp.x : comp == 1 ? stat_slot_of_comp.y : comp == 2 ? stat_slot_of_comp.z : stat_slot_of_comp.w;
     MjhHuffTable *T2 = stat_tabs + (size_t)img * slots_per_image + slot;
@@ -2204,15 +2222,14 @@ template <int L> __device__ __forceinline__ float row_bcast_f(float v) { return 
 __global__ void __launch_bounds__(64)
 k_trellis_dc2(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
               int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
-              int4 dc_slot_of_comp, const float *__restrict__ lambda_in, uint8_t *__restrict__ back)
+              int4 dc_slot_of_comp, const float *__restrict__ lambda_in, uint8_t *__restrict__ back, int chain0, int chain1)
 {
   const int img = blockIdx.y;
   const int lane = threadIdx.x;
   MJH_WAVE_GROUPS(16);
   const int k = lane & 15;
-  const int chain = blockIdx.x * 4 + (lane >> 4);
-  const int nchains = C.ncomp * C.mcu_rows;
-  if (chain >= nchains) return;   // whole 16-lane groups (= DPP rows) leave together
+  const int chain = chain0 + blockIdx.x * 4 + (lane >> 4);     // chains [chain0, chain1) of the image: component-major, one per iMCU row
+  if (chain >= chain1) return;   // whole 16-lane groups (= DPP rows) leave together
   const int comp = chain / C.mcu_rows, imcu = chain - comp * C.mcu_rows;
   const MjhComp cc = C.c[comp];
   const int slot = comp == 0 ? dc_slot_of_comp.x : comp == 1 ? dc_slot_of_comp.y : comp == 2 ? dc_slot_of_comp.z : dc_slot_of_comp.w;
@@ -2422,15 +2439,14 @@ template <int BC> __device__ __forceinline__ float add_bcast(float v, float d, b
 __global__ void __launch_bounds__(64)
 k_trellis_dc3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq,
               int16_t *__restrict__ coef_q, const MjhHuffTable *__restrict__ tabs, int slots_per_image,
-              int4 dc_slot_of_comp, const float *__restrict__ lambda_in, uint8_t *__restrict__ back)
+              int4 dc_slot_of_comp, const float *__restrict__ lambda_in, uint8_t *__restrict__ back, int chain0, int chain1)
 {
   const int img = blockIdx.y;
   const int lane = threadIdx.x;
   MJH_WAVE_GROUPS(16);
   const int k = lane & 15;                      // lane in the group = rank of its candidate VALUE
-  const int chain = blockIdx.x * 4 + (lane >> 4);
-  const int nchains = C.ncomp * C.mcu_rows;
-  if (chain >= nchains) return;   // whole 16-lane groups (= DPP rows) leave together
+  const int chain = chain0 + blockIdx.x * 4 + (lane >> 4);     // chains [chain0, chain1) of the image: component-major, one per iMCU row
+  if (chain >= chain1) return;   // whole 16-lane groups (= DPP rows) leave together
   const int comp = chain / C.mcu_rows, imcu = chain - comp * C.mcu_rows;
   const MjhComp cc = C.c[comp];
   const int slot = comp == 0 ? dc_slot_of_comp.x : comp == 1 ? dc_slot_of_comp.y : comp == 2 ? dc_slot_of_comp.z : dc_slot_of_comp.w;
@@ -3386,7 +3402,7 @@ static int max_padblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncom
 void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
                     MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv)
 {
-  dim3 grid((max_nblk(C) + 63) / 64, C.ncomp, n);
+  dim3 grid(((max_nblk(C) + 63) / 64 + DCTQ_NB - 1) / DCTQ_NB, C.ncomp, n);
   const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
   if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t, false>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else if (stat_tabs && fastdiv) hipLaunchKernelGGL((k_dct_quant<uint8_t, true, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
@@ -3431,7 +3447,7 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
-                           uint8_t *nq8, int v3_passes, int fastdiv)
+                           uint8_t *nq8, int v3_passes, int fastdiv, hipEvent_t after_first_tier)
 {
   // band-limited pass (use_scans_in_trellis), the per-block outputs of trellis_eob_opt, per-image tables (trellis_q_opt):
   // the EXT instantiations
@@ -3474,6 +3490,7 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     else if (!fastdiv) LV3(16, 4, false);
     else switch (np) { case 8: LV3(16, 8, true); break; case 4: LV3(16, 4, true); break; case 2: LV3(16, 2, true); break; default: LV3(16, 1, true); break; }
 #undef LV3
+    if (after_first_tier) (void)hipEventRecord(after_first_tier, s);      // (what only waits for the big kernel starts here, next to the general tiers)
     if (variant >= 3) LD(63, false, true, 2048, worklist, (unsigned *)nullptr);   // what is left has more than 32 records or a magnitude >= 16: one general tier that takes everything
     else { LD(32, false, true, 2048, worklist, worklist2); LD(63, false, true, 1024, worklist2, (unsigned *)nullptr); }
   } else if (nzmask) {   // compact records out of the general first tier (the caller guarantees: plain pass)
@@ -3516,14 +3533,16 @@ void mjh_launch_trellis_dc_speculative(const MjhConst &C, const MjhQuant *Q, con
 }
 
 void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s,
-                           int window_ok)
+                           int window_ok, int chain0, int chain1)
 {
   const int nchains = C.ncomp * C.mcu_rows;
-  dim3 grid((nchains + 3) / 4, n);
+  if (chain1 < 0 || chain1 > nchains) chain1 = nchains;      // (default: every chain)
+  if (chain0 >= chain1) return;
+  dim3 grid((chain1 - chain0 + 3) / 4, n);
   // the sliding-window kernel when every DC quantizer step 8q is >= 40 and the vertical-gradient term is off; the general DPP kernel otherwise
   if (window_ok && C.delta_dc_weight <= 0.0f)
-    hipLaunchKernelGGL(k_trellis_dc3, grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]), lambda, (uint8_t *)back);
-  else hipLaunchKernelGGL(k_trellis_dc2, grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]), lambda, (uint8_t *)back);
+    hipLaunchKernelGGL(k_trellis_dc3, grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]), lambda, (uint8_t *)back, chain0, chain1);
+  else hipLaunchKernelGGL(k_trellis_dc2, grid, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, tabs, spi, make_int4(dc_slot[0], dc_slot[1], dc_slot[2], dc_slot[3]), lambda, (uint8_t *)back, chain0, chain1);
 }
 
 void mjh_launch_encode(const MjhConst &C, const void *q, const unsigned long long *nzmask, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const int ac_slot[4],

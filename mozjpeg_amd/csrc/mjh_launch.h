@@ -17,7 +17,7 @@ void mjh_launch_gen_tables(MjhHuffTable *tabs, int spi, const int *slots, int ns
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
-                           uint8_t *nq8 = nullptr, int v3_passes = 0, int fastdiv = 0);   // v3_passes > 0 (plain compact pass): the tile-sorted kernel with that many passes per tile
+                           uint8_t *nq8 = nullptr, int v3_passes = 0, int fastdiv = 0, hipEvent_t after_first_tier = nullptr);   // after_first_tier: recorded behind the tile-sorted kernel, in front of the general tiers   // v3_passes > 0 (plain compact pass): the tile-sorted kernel with that many passes per tile
 // trellis_eob_opt: the block-row pass behind a (band-limited) AC trellis; eob_cost / eob_has as written by mjh_launch_trellis_ac
 void mjh_launch_trellis_eob_chain(const MjhConst &C, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const void *eob_cost, const int *eob_has,
                                   int Ss, int Se, int n, hipStream_t s);
@@ -30,7 +30,7 @@ void mjh_launch_qopt_fix(const MjhQuant *Q, void *out, size_t out_stride, unsign
                          int multi, int baseline_capable, int n, hipStream_t s);
 // window_ok: every component's DC quantizer step 8q is >= 40 (candidate values are then never clamped: the sliding-window kernel applies)
 void mjh_launch_trellis_dc(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const float *lambda, void *back, int n, hipStream_t s,
-                           int window_ok = 0);
+                           int window_ok = 0, int chain0 = 0, int chain1 = -1);   // chains [chain0, chain1) of every image (component-major, one per iMCU row); -1: all
 void mjh_launch_encode(const MjhConst &C, const void *q, const unsigned long long *nzmask, const MjhHuffTable *tabs, int spi, const int dc_slot[4], const int ac_slot[4],
                        void *len16, void *off32, unsigned *sums, int chunks_per_image, unsigned *totals,
                        unsigned *stream, size_t stream_words_per_image, void *meta,
