@@ -135,7 +135,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 grayin=False, quant_table=-1, lambda1=None, lambda2=None, restart=None,
                 progressive=False, fastcrush=False, precision=8, trellis_loops=1, smooth=0, rgb=False,
                 dc_scan_opt=None, dc_ver_weight=None, use_scans_in_trellis=False, trellis_freq_split=0,
-                trellis_eob_opt=False, trellis_q_opt=False, arithmetic=False, arith_cond=None):
+                trellis_eob_opt=False, trellis_q_opt=False, arithmetic=False, arith_cond=None, scans=None):
     """Parameters with cjpeg's switch vocabulary (cjpeg.c:371-714).  Without `baseline` or
     `revert` this is cjpeg's default: progressive with scan search (`fastcrush`: fixed 9-scan script)."""
     p = Params()
@@ -196,6 +196,16 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
             _chk(L.mjh_params_simple_progression(C.byref(p)))
         else:
             _chk(L.mjh_params_search_progression(C.byref(p)))
+    if scans is not None:      # cjpeg -scans: [(component indices, Ss, Se, Ah, Al), ...] replaces the script, no scan search
+        p.optimize_scans = 0
+        p.num_scans = len(scans)
+        if not (scans[0][1] == 0 and scans[0][2] == 63):
+            p.optimize_coding = 1          # a progressive script forces optimal tables (jcmaster.c:1091-1094)
+        for i, (comps, ss, se, ah, al) in enumerate(scans):
+            p.scan_info[i].comps_in_scan = len(comps)
+            for j, c in enumerate(comps):
+                p.scan_info[i].component_index[j] = c
+            p.scan_info[i].Ss, p.scan_info[i].Se, p.scan_info[i].Ah, p.scan_info[i].Al = ss, se, ah, al
     return p
 
 

@@ -419,7 +419,9 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
       ms->Ss = js->Ss; ms->Se = js->Se; ms->Ah = js->Ah; ms->Al = js->Al;
     }
     p->optimize_scans = jpeg_c_get_bool_param(cinfo, JBOOLEAN_OPTIMIZE_SCANS) && cinfo->master->num_scans_luma != 0;
-    p->optimize_coding = p->arith_code ? 0 : 1;   /* jcmaster.c:1088-1094 */
+    /* a progressive script forces optimal tables (jcmaster.c:1088-1094); a script of whole-block scans is a sequential
+     * multi-scan file (validate_script :309-330) and keeps the application's choice */
+    if (p->optimize_scans || !(p->scan_info[0].Ss == 0 && p->scan_info[0].Se == 63)) p->optimize_coding = p->arith_code ? 0 : 1;
   }
   if (!cinfo->optimize_coding && !cinfo->arith_code) {
     /* standard tables are baked into the GPU path; anything else needs optimize_coding */

@@ -298,7 +298,7 @@ struct mjh_encoder {
   int copy_prio = 0;
   int fastdiv_all = 0;               // every table in use has q <= 255: the kernels divide by 8q with one multiply-high (MjhQuant.mdiv)
   int dc_mode = 0;
-  bool dc_late = true;               // large sequential batches: the chroma DC chains run behind the AC kernel, under the tail of small kernels (MJH_DC_LATE=0: all next to it)
+  int dc_late = 1;                   // large sequential batches: the DC chains of components >= dc_late (1: both chroma components, 2: Cr only) run behind the AC kernel, under the tail of small kernels (MJH_DC_LATE=0: all next to it)
   int dc_stats_side = 1;             // the final DC statistics run on the side stream behind the DC trellis (MJH_DC_STATS_SIDE=0: main stream)
   int dc_window_ok = 0;              // every component's DC quantizer step 8q >= 40: the DC trellis may use its sliding-window kernel
   int trellis_v3 = 4;                // passes per tile of the tile-sorted first tier (MJH_TRELLIS_V3; 0 = the general kernel)
@@ -344,6 +344,11 @@ struct mjh_encoder {
   void *d_meta = nullptr;
   uint8_t *d_prefix = nullptr, *d_sos = nullptr;
   int prefix_len = 0, sos_len = 0;
+  // a SEQUENTIAL script of several scans (cjpeg -scans with whole-block scans, validate_script jcmaster.c:309-330): every scan is
+  // coded through a view of the geometry that holds its components, with its own statistics / tables / restart interval;
+  // its [DRI +] SOS bytes lie at sos_off of d_sos
+  struct SeqScan { int ncomp; int comp[4]; int sos_off, sos_len; int dht_slots[4], dht_ids[4], ndht; int ri, nseg; };
+  std::vector<SeqScan> seq_scans;
   int dht_slots[4] = { 0, 0, 0, 0 }, dht_ids[4] = { 0, 0, 0, 0 }, ndht = 0;
   bool debug_taps = false;
   // profiling: 0 off, 1 every kernel, 2 only the dominant kernel (prof_focus).  Events accumulate over the
@@ -725,10 +730,63 @@ extern "C" void mjh_encoder_destroy(mjh_encoder *e) { free_all(e); }
 
 #define HIPCHK_E(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { int rc_ = fail(MJH_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); free_all(e); return rc_; } } while (0)
 
+// The geometry as ONE SCAN of a sequential script sees it (per_scan_setup jcmaster.c:548-626): its components in scan order; a
+// single-component scan is non-interleaved -- an MCU is one block, the MCU rows are the component's block rows, there are no
+// dummy blocks; a scan of several components keeps the frame's MCU grid with only its own blocks in an MCU.  The restart
+// interval is the scan's own (restart_in_rows counts rows of ITS MCUs, :595-600).  MjhComp carries absolute offsets, so the
+// view addresses the same buffers as the frame.
+static MjhConst scan_view(const MjhConst &C, const mjh_params &p, const int *comps, int k)
+{
+  MjhConst V = C;
+  V.ncomp = k;
+  int mb = 0;
+  for (int j = 0; j < k; j++) {
+    V.c[j] = C.c[comps[j]];
+    if (k == 1) {
+      V.c[j].h = V.c[j].v = 1;
+      V.c[j].wpad = V.c[j].wib; V.c[j].hpad = V.c[j].hib;
+      V.mcus_per_row = V.c[j].wib; V.mcu_rows = V.c[j].hib;
+    }
+    V.c[j].mcu_blk0 = mb;
+    mb += V.c[j].h * V.c[j].v;
+  }
+  V.blocks_per_mcu = mb;
+  V.total_mcu_blocks = V.mcus_per_row * V.mcu_rows * mb;
+  long ri = p.restart_interval;
+  if (p.restart_in_rows > 0) { ri = (long)p.restart_in_rows * V.mcus_per_row; if (ri > 65535L) ri = 65535L; }
+  V.restart_interval = (int)ri;
+  return V;
+}
+
 extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device, mjh_encoder **out)
 {
   if (!p || !out || max_batch < 1) return fail(MJH_EINVAL, "bad arguments");
   *out = nullptr;
+  // A script whose scans are all whole-block scans (Ss = 0, Se = 63) is a sequential multi-scan file, not a progressive one
+  // (validate_script jcmaster.c:309-330, :386-398): every component in exactly one scan, components in ascending order.  It is
+  // taken out of the parameters here -- everything in front of the entropy stage is the sequential pipeline.
+  mjh_params pn = *p;
+  std::vector<mjh_scan> seq_script;
+  if (p->num_scans > 0 && p->num_scans <= MJH_MAX_SCANS && !p->optimize_scans && p->scan_info[0].Ss == 0 && p->scan_info[0].Se == 63) {
+    bool sent[MJH_MAX_COMPS] = { false, false, false, false };
+    for (int si = 0; si < p->num_scans; si++) {
+      const mjh_scan &sc = p->scan_info[si];
+      if (sc.Ss != 0 || sc.Se != 63 || sc.Ah != 0 || sc.Al != 0) return fail(MJH_EINVAL, "scan %d: a sequential script holds whole-block scans only (Ss 0, Se 63, Ah 0, Al 0; JERR_BAD_PROG_SCRIPT)", si);
+      if (sc.comps_in_scan < 1 || sc.comps_in_scan > p->num_components) return fail(MJH_EINVAL, "scan %d: component count", si);
+      for (int ci = 0; ci < sc.comps_in_scan; ci++) {
+        const int c = sc.component_index[ci];
+        if (c < 0 || c >= p->num_components || (ci > 0 && c <= sc.component_index[ci - 1])) return fail(MJH_EINVAL, "scan %d: component order", si);
+        if (sent[c]) return fail(MJH_EINVAL, "scan %d: component %d is coded twice (JERR_BAD_SCAN_SCRIPT)", si, c);
+        sent[c] = true;
+      }
+      seq_script.push_back(sc);
+    }
+    for (int c = 0; c < p->num_components; c++) if (!sent[c]) return fail(MJH_EINVAL, "the script leaves component %d out (JERR_MISSING_DATA)", c);
+    if (p->arith_code) return fail(MJH_EUNSUPPORTED, "sequential multi-scan scripts with arithmetic coding");
+    pn.num_scans = 0;
+    if (seq_script.size() == 1) seq_script.clear();      // one scan of all components: the plain sequential file
+    p = &pn;
+  }
   int rc = check_supported(p);
   if (rc) return rc;
   int ndev = 0;
@@ -808,7 +866,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   if (const char *v = getenv("MJH_TRELLIS_VARIANT")) { e->trellis_variant = atoi(v); e->trellis_adapt = false; }
   HIPCHK_E(hipHostMalloc((void **)&e->h_defer, 64, hipHostMallocDefault));
   if (const char *v = getenv("MJH_TRELLIS_V3")) e->trellis_v3 = atoi(v);
-  if (const char *v = getenv("MJH_DC_LATE")) e->dc_late = atoi(v) != 0;   // A/B knob
+  if (const char *v = getenv("MJH_DC_LATE")) { e->dc_late = atoi(v); if (e->dc_late < 0 || e->dc_late > 2) e->dc_late = 1; }   // A/B knob
   e->dc_window_ok = 1;
   for (int i = 0; i < C.ncomp; i++) if (p->quantval[p->quant_tbl_no[i]][0] < 5) e->dc_window_ok = 0;
   if (const char *v = getenv("MJH_DC_SPEC")) e->dc_spec = atoi(v);
@@ -826,18 +884,24 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   HIPCHK_E(mjh_dmalloc((void **)&e->d_totals, B * sizeof(unsigned)));
   HIPCHK_E(mjh_dmalloc((void **)&e->d_fftotals, B * sizeof(unsigned)));
   HIPCHK_E(mjh_dmalloc((void **)&e->d_stream, B * e->stream_words * 4 + 4096));   // slack: a bit writer may touch two words past its last offset
-  e->out_stride = ((size_t)2048 + e->stream_words * 8 + 255) & ~(size_t)255;
+  e->out_stride = ((size_t)2048 + 1024 * seq_script.size() + e->stream_words * 8 + 255) & ~(size_t)255;   // (every scan of a sequential script brings its own DHT + SOS)
   HIPCHK_E(mjh_dmalloc((void **)&e->d_out, B * e->out_stride));
   HIPCHK_E(mjh_dmalloc((void **)&e->d_sizes, B * sizeof(unsigned)));
   {
     const int nmcu = C.mcus_per_row * C.mcu_rows;
     e->nseg = C.restart_interval ? (nmcu + C.restart_interval - 1) / C.restart_interval : 1;
+    int max_nseg = e->nseg;
+    for (const mjh_scan &sc : seq_script) {     // a scan of a sequential script has its own MCU grid and restart interval
+      const MjhConst V = scan_view(C, *p, sc.component_index, sc.comps_in_scan);
+      const int nm = V.mcus_per_row * V.mcu_rows, ns1 = V.restart_interval ? (nm + V.restart_interval - 1) / V.restart_interval : 1;
+      max_nseg = ns1 > max_nseg ? ns1 : max_nseg;
+    }
     for (int i = 0; i < C.ncomp; i++) {     // restart interval of the per-component statistics passes, in blocks
       long ri = p->restart_interval;
       if (p->restart_in_rows > 0) { ri = (long)p->restart_in_rows * C.c[i].wib; if (ri > 65535L) ri = 65535L; }
       e->comp_restart[i] = (int)ri;
     }
-    const size_t ns = (size_t)e->nseg;
+    const size_t ns = (size_t)max_nseg;
     HIPCHK_E(mjh_dmalloc((void **)&e->d_seg_x, B * ns * 4));
     HIPCHK_E(mjh_dmalloc((void **)&e->d_seg_E, B * ns * 4));
     HIPCHK_E(mjh_dmalloc((void **)&e->d_mpos, B * ns * 4));
@@ -910,6 +974,46 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     HIPCHK_E(mjh_dmalloc((void **)&e->d_sos, sos.size()));
     HIPCHK_E(hipMemcpy(e->d_prefix, pre.data(), pre.size(), hipMemcpyHostToDevice));
     HIPCHK_E(hipMemcpy(e->d_sos, sos.data(), sos.size(), hipMemcpyHostToDevice));
+    if (!seq_script.empty()) {
+      // per scan: [DRI when the interval differs from the previous scan's, write_scan_header jcmarker.c:778-781] SOS, and the
+      // tables its DHT carries: those of its components, DC then AC, each once -- with optimal tables every scan's are rebuilt and
+      // sent again, the standard tables only until they have been sent (emit_multi_dht / emit_dht's sent_table, :257-401)
+      std::vector<uint8_t> blob;
+      bool dsent[4] = { false, false, false, false }, asent[4] = { false, false, false, false };
+      int last_ri = 0;
+      for (const mjh_scan &sc : seq_script) {
+        mjh_encoder::SeqScan q;
+        memset(&q, 0, sizeof(q));
+        q.ncomp = sc.comps_in_scan;
+        for (int j = 0; j < q.ncomp; j++) q.comp[j] = sc.component_index[j];
+        const MjhConst V = scan_view(C, *p, q.comp, q.ncomp);
+        const int nm = V.mcus_per_row * V.mcu_rows;
+        q.ri = V.restart_interval;
+        q.nseg = q.ri ? (nm + q.ri - 1) / q.ri : 1;
+        q.sos_off = (int)blob.size();
+        if (q.ri != last_ri) { blob.push_back(0xFF); blob.push_back(0xDD); put2(blob, 4); put2(blob, q.ri); last_ri = q.ri; }
+        blob.push_back(0xFF); blob.push_back(0xDA);
+        put2(blob, 2 * q.ncomp + 2 + 1 + 3);
+        blob.push_back((uint8_t)q.ncomp);
+        for (int j = 0; j < q.ncomp; j++) {
+          blob.push_back((uint8_t)p->component_id[q.comp[j]]);
+          blob.push_back((uint8_t)((p->dc_tbl_no[q.comp[j]] << 4) + p->ac_tbl_no[q.comp[j]]));
+        }
+        blob.push_back(0); blob.push_back(63); blob.push_back(0);
+        q.sos_len = (int)blob.size() - q.sos_off;
+        if (p->optimize_coding) for (int t = 0; t < 4; t++) dsent[t] = asent[t] = false;
+        for (int j = 0; j < q.ncomp; j++) {
+          const int d = p->dc_tbl_no[q.comp[j]], a = p->ac_tbl_no[q.comp[j]];
+          if (!dsent[d] && q.ndht < 4) { q.dht_slots[q.ndht] = SLOT_FINAL + 2 * d; q.dht_ids[q.ndht] = d; q.ndht++; dsent[d] = true; }
+          if (!asent[a] && q.ndht < 4) { q.dht_slots[q.ndht] = SLOT_FINAL + 2 * a + 1; q.dht_ids[q.ndht] = a + 0x10; q.ndht++; asent[a] = true; }
+        }
+        e->seq_scans.push_back(q);
+      }
+      (void)mjh_guard_free(e->d_sos);
+      e->d_sos = nullptr;
+      HIPCHK_E(mjh_dmalloc((void **)&e->d_sos, blob.size()));
+      HIPCHK_E(hipMemcpy(e->d_sos, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    }
     bool dc_sent[4] = { false, false, false, false }, ac_sent[4] = { false, false, false, false };
     e->ndht = 0;
     for (int ci = 0; ci < p->num_components; ci++) {
@@ -1421,12 +1525,12 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       // mostly idle.  So, for a large sequential batch, only the LUMA chains (two thirds of the DC work) start next to the AC
       // kernel; the chroma chains and the final DC statistics start when it has finished and run under that tail, and the
       // main stream joins the side stream in front of the final tables instead of behind the trellis.
-      const bool final_dc_here = !e->progressive && p.optimize_coding && last_loop && nbands == 1 && qstride == 0 && !ext_eob && e->dc_stats_side;
-      dc_late = e->dc_late && !spec && final_dc_here && nloops == 1 && CV.ncomp == 3 && !e->debug_taps && (size_t)n * C.total_real_blocks >= e->small_batch;
+      const bool final_dc_here = !e->progressive && p.optimize_coding && last_loop && nbands == 1 && qstride == 0 && !ext_eob && e->dc_stats_side && e->seq_scans.empty();
+      dc_late = e->dc_late > 0 && !spec && final_dc_here && nloops == 1 && CV.ncomp == 3 && !e->debug_taps && (size_t)n * C.total_real_blocks >= e->small_batch;
       if (spec) mjh_launch_trellis_dc_speculative(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back9, e->d_jfin, e->d_qspec, n, e->side_stream);
       else
       mjh_launch_trellis_dc(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, e->side_stream, e->dc_window_ok,
-                            0, dc_late ? CV.mcu_rows : -1);   // (the DC entries never change: image 0's tables serve all)
+                            0, dc_late ? e->dc_late * CV.mcu_rows : -1);   // (the DC entries never change: image 0's tables serve all)
       if (pr.enabled && e->profiling == 1) { HIPCHK(hipEventRecord(e->side_events[2 * e->prof_calls + 1], e->side_stream)); e->side_timed = true; }
       if (final_dc_here && !dc_late) {
         // the final DC statistics need nothing but the DC trellis's result: counted here, they cost no time of their own
@@ -1447,7 +1551,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     if (dc_late) {
       if (!v3) return fail(MJH_EINVAL, "internal: the late DC chains need the tile-sorted trellis' event");
       HIPCHK(hipStreamWaitEvent(e->side_stream, e->ev_side0, 0));
-      mjh_launch_trellis_dc(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, e->side_stream, e->dc_window_ok, CV.mcu_rows, -1);
+      mjh_launch_trellis_dc(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, e->side_stream, e->dc_window_ok, e->dc_late * CV.mcu_rows, -1);
       mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, fin_dc, 1, zero4, n, e->side_stream);
       final_dc_counted = true;
       HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
@@ -1560,32 +1664,70 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     HIPCHK(hipGetLastError());
     return MJH_OK;
   }
-  if (p.optimize_coding) {
-    // pass 6: statistics of the interleaved scan (dummy blocks included) -> final tables
-    pr.mark("stats_ac(final)");
-    mjh_launch_stats_ac(C, e->d_q, nzm, e->d_tabs, spi, fin_ac, 1, n, s);
-    if (!final_dc_counted) {
-      pr.mark("stats_dc(final)");
-      mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, fin_dc, 1, zero4, n, s);
+  if (!e->seq_scans.empty()) {
+    // A sequential script of several scans: per scan, through its view of the geometry, the statistics of ITS MCU order -> its
+    // tables -> its header behind the file so far -> its entropy-coded data (jcmaster.c:1090-1101: two passes per scan with
+    // optimal tables).  The scans reuse the table slots and the buffers of the one-scan path, one after the other.
+    if (before_output) HIPCHK(hipStreamWaitEvent(s, before_output, 0));
+    for (size_t si = 0; si < e->seq_scans.size(); si++) {
+      const mjh_encoder::SeqScan &q = e->seq_scans[si];
+      const MjhConst V = scan_view(C, p, q.comp, q.ncomp);
+      int v_dc[4] = { 0, 0, 0, 0 }, v_ac[4] = { 0, 0, 0, 0 };
+      for (int j = 0; j < q.ncomp; j++) { v_dc[j] = fin_dc[q.comp[j]]; v_ac[j] = fin_ac[q.comp[j]]; }
+      if (p.optimize_coding) {
+        HIPCHK(hipMemcpyAsync(e->d_tabs, e->d_tabs_init, (size_t)n * spi * sizeof(MjhHuffTable), hipMemcpyDeviceToDevice, s));   // fresh counts
+        pr.mark("stats_ac(final)");
+        mjh_launch_stats_ac(V, e->d_q, nzm, e->d_tabs, spi, v_ac, 1, n, s);
+        pr.mark("stats_dc(final)");
+        mjh_launch_stats_dc(V, e->d_q, e->d_tabs, spi, v_dc, 1, zero4, n, s);
+        pr.mark("gen_tables(final)");
+        int slots[8], ns = 0;
+        for (int j = 0; j < q.ncomp; j++) {
+          bool have_d = false, have_a = false;
+          for (int t = 0; t < ns; t++) { have_d = have_d || slots[t] == v_dc[j]; have_a = have_a || slots[t] == v_ac[j]; }
+          if (!have_d) slots[ns++] = v_dc[j];
+          if (!have_a) slots[ns++] = v_ac[j];
+        }
+        mjh_launch_gen_tables(e->d_tabs, spi, slots, ns, n, s);
+      }
+      pr.mark("header");
+      mjh_launch_header(si == 0 ? e->d_prefix : nullptr, si == 0 ? e->prefix_len : 0, e->d_sos + q.sos_off, q.sos_len, e->d_tabs, spi, q.dht_slots, q.dht_ids, q.ndht,
+                        p.compress_profile != MJH_PROFILE_FASTEST, e->d_out, e->out_stride, e->d_meta, n, s, si == 0 ? nullptr : e->d_sizes);
+      pr.mark("huff_encode");
+      mjh_launch_encode(V, e->d_q, nzm, e->d_tabs, spi, v_dc, v_ac, e->d_len16, e->d_off32, e->d_sums, e->chunks, e->d_totals,
+                        e->d_stream, e->stream_words, e->d_meta, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos, q.nseg, n, s);
+      pr.mark("byte_stuff");
+      mjh_launch_stuff(e->d_stream, e->stream_words, e->d_totals, e->d_ffsums, e->ff_chunks, e->d_fftotals, e->d_out, e->out_stride,
+                       e->d_meta, e->d_sizes, e->d_mpos, q.nseg, n, s);
     }
-    if (join_late) {
-      pr.mark("join(trellis_dc)");
-      HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
+  } else {
+    if (p.optimize_coding) {
+      // pass 6: statistics of the interleaved scan (dummy blocks included) -> final tables
+      pr.mark("stats_ac(final)");
+      mjh_launch_stats_ac(C, e->d_q, nzm, e->d_tabs, spi, fin_ac, 1, n, s);
+      if (!final_dc_counted) {
+        pr.mark("stats_dc(final)");
+        mjh_launch_stats_dc(C, e->d_q, e->d_tabs, spi, fin_dc, 1, zero4, n, s);
+      }
+      if (join_late) {
+        pr.mark("join(trellis_dc)");
+        HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
+      }
+      pr.mark("gen_tables(final)");
+      mjh_launch_gen_tables(e->d_tabs, spi, e->dht_slots, e->ndht, n, s);
     }
-    pr.mark("gen_tables(final)");
-    mjh_launch_gen_tables(e->d_tabs, spi, e->dht_slots, e->ndht, n, s);
+    // pass 7: headers + entropy-coded data
+    if (before_output) HIPCHK(hipStreamWaitEvent(s, before_output, 0));
+    pr.mark("header");
+    mjh_launch_header(e->d_prefix, e->prefix_len, e->d_sos, e->sos_len, e->d_tabs, spi, e->dht_slots, e->dht_ids, e->ndht,
+                      p.compress_profile != MJH_PROFILE_FASTEST, e->d_out, e->out_stride, e->d_meta, n, s);
+    pr.mark("huff_encode");
+    mjh_launch_encode(C, e->d_q, nzm, e->d_tabs, spi, fin_dc, fin_ac, e->d_len16, e->d_off32, e->d_sums, e->chunks, e->d_totals,
+                      e->d_stream, e->stream_words, e->d_meta, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos, e->nseg, n, s);
+    pr.mark("byte_stuff");
+    mjh_launch_stuff(e->d_stream, e->stream_words, e->d_totals, e->d_ffsums, e->ff_chunks, e->d_fftotals, e->d_out, e->out_stride,
+                     e->d_meta, e->d_sizes, e->d_mpos, e->nseg, n, s);
   }
-  // pass 7: headers + entropy-coded data
-  if (before_output) HIPCHK(hipStreamWaitEvent(s, before_output, 0));
-  pr.mark("header");
-  mjh_launch_header(e->d_prefix, e->prefix_len, e->d_sos, e->sos_len, e->d_tabs, spi, e->dht_slots, e->dht_ids, e->ndht,
-                    p.compress_profile != MJH_PROFILE_FASTEST, e->d_out, e->out_stride, e->d_meta, n, s);
-  pr.mark("huff_encode");
-  mjh_launch_encode(C, e->d_q, nzm, e->d_tabs, spi, fin_dc, fin_ac, e->d_len16, e->d_off32, e->d_sums, e->chunks, e->d_totals,
-                    e->d_stream, e->stream_words, e->d_meta, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos, e->nseg, n, s);
-  pr.mark("byte_stuff");
-  mjh_launch_stuff(e->d_stream, e->stream_words, e->d_totals, e->d_ffsums, e->ff_chunks, e->d_fftotals, e->d_out, e->out_stride,
-                   e->d_meta, e->d_sizes, e->d_mpos, e->nseg, n, s);
   if (ext_qopt) {   // jcmaster.c:1014-1030 + the precision rule of jcmarker.c:189-254
     pr.mark("trellis_q_opt(DQT)");
     mjh_launch_qopt_fix(e->d_quant, e->d_out, e->out_stride, e->d_sizes, e->file_hdr_len, e->prefix_len - (10 + 3 * C.ncomp), e->dqt_tabs, e->dqt_ntab,

@@ -3136,13 +3136,15 @@ k_zero_stream(unsigned *__restrict__ stream, size_t stream_words_per_image, cons
 __global__ void __launch_bounds__(64)
 k_header(const uint8_t *__restrict__ prefix, int prefix_len, const uint8_t *__restrict__ sos, int sos_len,
          const MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 dht_slots, int4 dht_ids, int ndht,
-         int multi_dht, uint8_t *__restrict__ out, size_t out_stride, MjhImageMeta *__restrict__ meta)
+         int multi_dht, uint8_t *__restrict__ out, size_t out_stride, MjhImageMeta *__restrict__ meta, const unsigned *__restrict__ append_sizes)
 {
+  // append_sizes (the later scans of a sequential multi-scan file): the header goes over the EOI of the file so far
   const int img = blockIdx.x;
   const int lane = threadIdx.x;
   uint8_t *o = out + (size_t)img * out_stride;
-  for (int i = lane; i < prefix_len; i += 64) o[i] = prefix[i];
-  int pos = prefix_len;
+  const int start = append_sizes ? (int)append_sizes[img] - 2 : 0;
+  for (int i = lane; i < prefix_len; i += 64) o[start + i] = prefix[i];
+  int pos = start + prefix_len;
   const int slots[4] = { dht_slots.x, dht_slots.y, dht_slots.z, dht_slots.w };
   const int ids[4] = { dht_ids.x, dht_ids.y, dht_ids.z, dht_ids.w };
   if (multi_dht) {
@@ -3491,8 +3493,9 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     else switch (np) { case 8: LV3(16, 8, true); break; case 4: LV3(16, 4, true); break; case 2: LV3(16, 2, true); break; default: LV3(16, 1, true); break; }
 #undef LV3
     if (after_first_tier) (void)hipEventRecord(after_first_tier, s);      // (what only waits for the big kernel starts here, next to the general tiers)
-    if (variant >= 3) LD(63, false, true, 2048, worklist, (unsigned *)nullptr);   // what is left has more than 32 records or a magnitude >= 16: one general tier that takes everything
-    else { LD(32, false, true, 2048, worklist, worklist2); LD(63, false, true, 1024, worklist2, (unsigned *)nullptr); }
+    const int qd_grid = 2048;     // (1024 ... 8192 workgroups: no difference beyond noise, gpurun_out/r5j)
+    if (variant >= 3) LD(63, false, true, qd_grid, worklist, (unsigned *)nullptr);   // what is left has more than 32 records or a magnitude >= 16: one general tier that takes everything
+    else { LD(32, false, true, qd_grid, worklist, worklist2); LD(63, false, true, 1024, worklist2, (unsigned *)nullptr); }
   } else if (nzmask) {   // compact records out of the general first tier (the caller guarantees: plain pass)
     if (variant > 3) variant = 3;   // (the general first tier stops at 32 records)
     switch (variant) { case 1: LQ(20, false, true); break; case 2: LQ(24, false, true); break; case 3: LQ(32, false, true); break; default: LQ(16, false, true); break; }
@@ -3579,11 +3582,12 @@ void mjh_launch_encode(const MjhConst &C, const void *q, const unsigned long lon
 }
 
 void mjh_launch_header(const void *prefix, int prefix_len, const void *sos, int sos_len, const MjhHuffTable *tabs, int spi,
-                       const int dht_slots[4], const int dht_ids[4], int ndht, int multi_dht, void *out, size_t out_stride, void *meta, int n, hipStream_t s)
+                       const int dht_slots[4], const int dht_ids[4], int ndht, int multi_dht, void *out, size_t out_stride, void *meta, int n, hipStream_t s,
+                       const unsigned *append_sizes)
 {
   hipLaunchKernelGGL(k_header, dim3(n), dim3(64), 0, s, (const uint8_t *)prefix, prefix_len, (const uint8_t *)sos, sos_len, tabs, spi,
                      make_int4(dht_slots[0], dht_slots[1], dht_slots[2], dht_slots[3]), make_int4(dht_ids[0], dht_ids[1], dht_ids[2], dht_ids[3]),
-                     ndht, multi_dht, (uint8_t *)out, out_stride, (MjhImageMeta *)meta);
+                     ndht, multi_dht, (uint8_t *)out, out_stride, (MjhImageMeta *)meta, append_sizes);
 }
 
 void mjh_launch_stuff(const unsigned *stream, size_t stream_words_per_image, const unsigned *totals, unsigned *ffsums, int ff_chunks_per_image,

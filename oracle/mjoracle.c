@@ -2115,7 +2115,9 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
 
   memset(&e, 0, sizeof(e));
   e.p = p;
-  e.progressive = p->num_scans > 0;
+  /* validate_script jcmaster.c:309-330: a script whose scans are all Ss = 0, Se = 63 is a SEQUENTIAL multi-scan file (SOF0 / SOF1,
+   * whole blocks per scan); any other script is progressive */
+  e.progressive = p->num_scans > 0 && !(p->scans[0].Ss == 0 && p->scans[0].Se == 63 && !p->optimize_scans);
   mjo_geometry(p, e.g, &e.mcus_per_row, &e.mcu_rows);
   for (ci = 0; ci < p->num_components; ci++) {
     planes[ci] = (uint16_t *)malloc((size_t)e.g[ci].pw * e.g[ci].ph * 2);
@@ -2219,7 +2221,17 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
     for (ci = 0; ci < p->num_components; ci++)
       if (taps->coef_q[ci]) memcpy(taps->coef_q[ci], e.q[ci], (size_t)e.g[ci].hpad * e.g[ci].wpad * 128);
 
-  if (!e.progressive) {
+  if (!e.progressive && p->num_scans > 0) {
+    /* sequential, several scans: every scan has its statistics pass and its own tables (jcmaster.c:1090-1101: two passes per scan
+     * with optimize_coding), whole blocks of its components in its own MCU order */
+    int si;
+    for (si = 0; si < p->num_scans; si++) {
+      scan_t sc;
+      setup_scan(&e, &sc, &p->scans[si]);
+      if (p->optimize_coding) gather_and_build(&e, &sc, 0);
+      output_scan(&e, &sc, si == 0, &o);
+    }
+  } else if (!e.progressive) {
     mjo_scan ms;
     scan_t sc;
     memset(&ms, 0, sizeof(ms));

@@ -66,7 +66,8 @@ int main(int argc, char **argv)
   int dc_scan_opt = -1;
   double dc_ver_weight = -1e9;
   int precision = 8, yuvin = 0, arithmetic = 0, trellis_loops = 0, smooth = 0, trellis_q_opt = 0, eob_opt = 0, scans_in_trellis = 0, freq_split = 0;
-  const char *arith_cond = NULL;
+  const char *arith_cond = NULL, *scanspec = NULL;
+  static jpeg_scan_info user_scans[64];
   const char *dump = NULL, *in = NULL, *out = NULL;
   int i, w, h, nc;
   unsigned char *img;
@@ -112,6 +113,7 @@ int main(int argc, char **argv)
     else if (!strcmp(a, "-trellis-dc-ver-weight")) dc_ver_weight = atof(argv[++i]);   /* cjpeg.c:667-672 */
     else if (!strcmp(a, "-smooth")) smooth = atoi(argv[++i]);   /* cjpeg -smooth N (cjpeg.c: cinfo->smoothing_factor) */
     else if (!strcmp(a, "-arithmetic")) arithmetic = 1;   /* cjpeg -arithmetic (cjpeg.c:371-376): cinfo->arith_code */
+    else if (!strcmp(a, "-scanspec")) scanspec = argv[++i];   /* a scan script (cjpeg -scans file, read_scan_script rdswitch.c) on the command line: "c[,c..]:Ss-Se:Ah:Al;..." */
     else if (!strcmp(a, "-arith-cond")) arith_cond = argv[++i];   /* L0,U0,K0,L1,U1,K1: cinfo->arith_dc_L / arith_dc_U / arith_ac_K of tables 0 and 1 (API-only fields, jpeglib.h:447-449) */
     else if (!strcmp(a, "-yuvin")) yuvin = 1;   /* -raw W H input holds component planes: jpeg_write_raw_data */
     else if (!in) in = a;
@@ -197,6 +199,22 @@ int main(int argc, char **argv)
     if (restart) {
       if (restart_blocks) { cinfo.restart_interval = restart; cinfo.restart_in_rows = 0; }
       else cinfo.restart_in_rows = restart;
+    }
+    if (scanspec) {      /* cjpeg -scans: the script replaces whatever the profile chose, the scan search is off (cjpeg.c:738-743) */
+      const char *s = scanspec;
+      int ns = 0;
+      while (*s && ns < 64) {
+        jpeg_scan_info *sc = &user_scans[ns];
+        int nc = 0, Ss = 0, Se = 63, Ah = 0, Al = 0, used = 0;
+        while (*s >= '0' && *s <= '9') { sc->component_index[nc++] = (int)strtol(s, (char **)&s, 10); if (*s == ',') s++; }
+        if (sscanf(s, ":%d-%d:%d:%d%n", &Ss, &Se, &Ah, &Al, &used) == 4) s += used;
+        sc->comps_in_scan = nc; sc->Ss = Ss; sc->Se = Se; sc->Ah = Ah; sc->Al = Al;
+        ns++;
+        if (*s == ';') s++;
+      }
+      jpeg_c_set_bool_param(&cinfo, JBOOLEAN_OPTIMIZE_SCANS, FALSE);
+      cinfo.scan_info = user_scans;
+      cinfo.num_scans = ns;
     }
     jpeg_mem_dest(&cinfo, &jbuf, &jsize);
     if (yuvin) {

@@ -116,6 +116,14 @@ CASES = [
     ("revert_samp_12_22_11", dict(revert=True, sample=((1, 2), (2, 2), (1, 1))), True),
     ("base_samp_31_11_11", dict(baseline=True, sample=((3, 1), (1, 1), (1, 1))), True),
     ("fastcrush_samp_21_21_21_restart1", dict(fastcrush=True, restart=1, sample=((2, 1), (2, 1), (2, 1))), True),
+    # scan scripts given by the application (cjpeg -scans; refenc -scanspec): sequential files of several whole-block scans
+    # (validate_script jcmaster.c:309-330: every scan has its own MCU order, statistics pass, tables and restart interval) and a
+    # progressive script that is neither jpeg_simple_progression's nor the search's
+    ("script_seq_y_cbcr", dict(scans=[((0,), 0, 63, 0, 0), ((1, 2), 0, 63, 0, 0)]), True),
+    ("script_seq_each_restart1", dict(restart=1, scans=[((0,), 0, 63, 0, 0), ((1,), 0, 63, 0, 0), ((2,), 0, 63, 0, 0)]), True),
+    ("script_seq_ycb_cr_revert_422", dict(revert=True, sample=(2, 1), scans=[((0, 1), 0, 63, 0, 0), ((2,), 0, 63, 0, 0)]), True),
+    ("script_prog_custom", dict(scans=[((0, 1, 2), 0, 0, 0, 1), ((0,), 1, 63, 0, 1), ((1,), 1, 63, 0, 0), ((2,), 1, 63, 0, 0),
+                                       ((0, 1, 2), 0, 0, 1, 0), ((0,), 1, 63, 1, 0)]), True),
     # arithmetic entropy coding (cjpeg -arithmetic): jcarith.c (sequential SOF9, progressive SOF10, restarts,
     # DAC markers), with the coder's own trellis rate model (quantize_trellis_arith jcdctmgr.c:1334-1667) where trellis is on
     ("arith_revert", dict(arithmetic=True, revert=True), True),

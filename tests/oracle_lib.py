@@ -75,7 +75,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 noovershoot=False, sample=(2, 2), restart=None, gray=False, grayin=False,
                 quant_table=-1, lambda1=None, lambda2=None, precision=8, trellis_loops=1, smooth=0, trellis_q_opt=False,
                 trellis_eob_opt=False, use_scans_in_trellis=False, trellis_freq_split=0, rgb=False,
-                dc_scan_opt=None, dc_ver_weight=None, arithmetic=False, arith_cond=None):
+                dc_scan_opt=None, dc_ver_weight=None, arithmetic=False, arith_cond=None, scans=None):
     """Same switch vocabulary as cjpeg / oracle/refenc.c.  Default (no switch) is cjpeg's default:
     max-compression profile, progressive with scan search."""
     p = Params()
@@ -131,6 +131,16 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
         else:
             L.mjo_search_progression(C.byref(p))
         p.optimize_coding = 1
+    if scans is not None:      # cjpeg -scans: [(component indices, Ss, Se, Ah, Al), ...] replaces the script, no scan search
+        p.optimize_scans = 0
+        p.num_scans = len(scans)
+        if not (scans[0][1] == 0 and scans[0][2] == 63):
+            p.optimize_coding = 1          # a progressive script forces optimal tables (jcmaster.c:1091-1094)
+        for i, (comps, ss, se, ah, al) in enumerate(scans):
+            p.scans[i].comps_in_scan = len(comps)
+            for j, c in enumerate(comps):
+                p.scans[i].component_index[j] = c
+            p.scans[i].Ss, p.scans[i].Se, p.scans[i].Ah, p.scans[i].Al = ss, se, ah, al
     return p
 
 
@@ -330,6 +340,8 @@ def ref_switches(**kw):
         sw += ["-trellis-loops", str(kw["trellis_loops"])]
     if kw.get("arithmetic"):
         sw.append("-arithmetic")
+    if kw.get("scans") is not None:           # (refenc's own switch: cjpeg reads the script from a file)
+        sw += ["-scanspec", ";".join("%s:%d-%d:%d:%d" % (",".join(str(c) for c in comps), ss, se, ah, al) for comps, ss, se, ah, al in kw["scans"])]
     if kw.get("arith_cond") is not None:      # (refenc's own switch: the API fields cinfo->arith_dc_L / arith_dc_U / arith_ac_K have no cjpeg switch)
         sw += ["-arith-cond", ",".join(str(v) for t in kw["arith_cond"] for v in t)]
     return sw

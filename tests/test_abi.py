@@ -64,7 +64,19 @@ def test_unsupported_configurations_are_errors_not_fallbacks():
         M.Encoder(p)
     assert ei.value.code == M.EUNSUPPORTED
     p = M.make_params(64, 64, baseline=True, sample=(2, 2))
-    p.h_samp_factor[1] = 2                                  # chroma sampling other than 1x1
+    p.h_samp_factor[1] = 3                                  # a fractional ratio (2 against 3): JERR_FRACT_SAMPLE_NOTIMPL in the reference
+    with pytest.raises(M.MjhError) as ei:
+        M.Encoder(p)
+    assert ei.value.code == M.EUNSUPPORTED
+    p = M.make_params(64, 64, baseline=True, sample=((2, 2), (2, 2), (2, 2)))   # 12 blocks per MCU (at most 10)
+    with pytest.raises(M.MjhError) as ei:
+        M.Encoder(p)
+    assert ei.value.code == M.EINVAL
+    p = M.make_params(64, 64, scans=[((0,), 0, 63, 0, 0), ((0, 1, 2), 0, 63, 0, 0)])   # a sequential script that codes component 0 twice
+    with pytest.raises(M.MjhError) as ei:
+        M.Encoder(p)
+    assert ei.value.code == M.EINVAL
+    p = M.make_params(64, 64, arithmetic=True, baseline=True, scans=[((0,), 0, 63, 0, 0), ((1, 2), 0, 63, 0, 0)])   # not restated for the arithmetic coder
     with pytest.raises(M.MjhError) as ei:
         M.Encoder(p)
     assert ei.value.code == M.EUNSUPPORTED
@@ -88,10 +100,10 @@ def test_unsupported_configurations_are_errors_not_fallbacks():
         with pytest.raises(M.MjhError) as ei:
             M.Encoder(p)
         assert ei.value.code == M.EINVAL, field
-    p = M.make_params(64, 64, baseline=True, sample=(4, 4))     # 16 + 2 blocks per MCU > 10 (jcmaster.c:540-544)
+    p = M.make_params(64, 64, baseline=True, sample=(4, 4))     # 16 + 2 blocks per MCU > 10 (jcmaster.c:540-544: the reference errors out too)
     with pytest.raises(M.MjhError) as ei:
         M.Encoder(p)
-    assert ei.value.code == M.EUNSUPPORTED
+    assert ei.value.code == M.EINVAL
 
 
 @pytest.mark.skipif(_gpu_present(), reason="only meaningful on a machine without a GPU")

@@ -93,6 +93,36 @@ def test_unchanged_cjpeg_12bit_through_the_shim(args, tmp_path):
     assert open(gpu, "rb").read() == open(ref, "rb").read()
 
 
+SCRIPT_SEQ = "0;\n1,2;\n"                                   # sequential: luma, then both chroma components interleaved
+SCRIPT_SEQ_EACH = "0;\n1;\n2;\n"
+SCRIPT_PROG = "0,1,2: 0-0, 0, 1;\n0: 1-63, 0, 1;\n1: 1-63, 0, 0;\n2: 1-63, 0, 0;\n0,1,2: 0-0, 1, 0;\n0: 1-63, 1, 0;\n"
+
+
+@needs
+@pytest.mark.parametrize("script,args", [(SCRIPT_SEQ, ["-quality", "75", "-sample", "2x2"]),
+                                         (SCRIPT_SEQ_EACH, ["-quality", "75", "-restart", "1", "-sample", "2x2"]),
+                                         (SCRIPT_SEQ, ["-revert", "-quality", "75", "-sample", "2x1"]),
+                                         (SCRIPT_PROG, ["-quality", "75", "-sample", "2x2"]),
+                                         (None, ["-quality", "75", "-baseline", "-sample", "2x2,2x1,1x1"]),
+                                         (None, ["-quality", "75", "-sample", "2x1,1x1,1x2"]),
+                                         (None, ["-revert", "-quality", "75", "-sample", "1x2,2x2,1x1"])])
+def test_unchanged_cjpeg_scan_scripts_and_sampling_factors_through_the_shim(script, args, tmp_path):
+    """cjpeg -scans FILE (read_scan_script rdswitch.c: sequential files of several whole-block scans, a progressive script of the
+    application's own) and cjpeg -sample HxV,HxV,HxV (chroma other than 1x1, luma smaller than chroma) -- configurations the shim
+    refused until round 5.  Reference = the same binary without the shim."""
+    ref, gpu = str(tmp_path / "ref.jpg"), str(tmp_path / "gpu.jpg")
+    if script is not None:
+        f = str(tmp_path / "script.txt")
+        with open(f, "w") as fh:
+            fh.write(script)
+        args = args + ["-scans", f]
+    r1 = run_cjpeg(args, gpu)
+    r0 = subprocess.run([CJPEG, "-dct", "int"] + args + ["-outfile", ref, PPM], env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r0.returncode == 0, r0.stderr.decode()
+    assert r1.returncode == 0, r1.stderr.decode()
+    assert open(gpu, "rb").read() == open(ref, "rb").read()
+
+
 @needs
 def test_unsupported_configuration_is_an_error_without_fallback(tmp_path):
     out = str(tmp_path / "o.jpg")

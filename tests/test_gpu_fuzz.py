@@ -148,3 +148,62 @@ def test_random_arithmetic_configuration_matches_the_oracle(idx, w, h, kw, kind)
     enc.close()
     assert got[0] == want, (idx, w, h, kw)
     assert got[1] == O.encode(O.make_params(w, h, **kw), img[::-1].copy()), (idx, w, h, kw)
+
+
+def _round5_cases():
+    """what round 5 added to the configuration space, its own seed: per-component sampling factors (chroma other than 1x1, luma
+    smaller than chroma, 3:1 ratios), scan scripts of the application's own (sequential files of several whole-block scans in every
+    grouping of three components, small progressive scripts), arithmetic conditioning values"""
+    rng = np.random.default_rng(20260922)
+    out = []
+    factor_sets = [((2, 2), (2, 1), (1, 1)), ((2, 1), (1, 1), (1, 2)), ((1, 2), (2, 2), (1, 1)), ((3, 1), (1, 1), (1, 1)), ((2, 1), (2, 1), (2, 1)),
+                   ((1, 1), (2, 2), (2, 2)), ((2, 2), (1, 2), (2, 1)), ((1, 3), (1, 1), (1, 3)), ((4, 1), (2, 1), (1, 1)), ((2, 2), (2, 2), (1, 1))]
+    seq_scripts = [[(0,), (1, 2)], [(0,), (1,), (2,)], [(0, 1), (2,)], [(0, 2), (1,)], [(0, 1, 2)], [(0,), (1,), (2,)][::1]]
+    prog_scripts = [[((0, 1, 2), 0, 0, 0, 0), ((0,), 1, 63, 0, 0), ((1,), 1, 63, 0, 0), ((2,), 1, 63, 0, 0)],
+                    [((0,), 0, 0, 0, 1), ((1, 2), 0, 0, 0, 0), ((0,), 1, 5, 0, 2), ((0,), 6, 63, 0, 2), ((1,), 1, 63, 0, 1), ((2,), 1, 63, 0, 1),
+                     ((0,), 1, 63, 2, 1), ((0,), 0, 0, 1, 0), ((0,), 1, 63, 1, 0), ((1,), 1, 63, 1, 0), ((2,), 1, 63, 1, 0)]]
+    for i in range(48):
+        w = int(rng.integers(1, 360)); h = int(rng.integers(1, 280))
+        kw = dict(quality=int(rng.choice([10, 40, 75, 85, 95])))
+        what = int(rng.integers(0, 4))
+        kw["sample"] = factor_sets[int(rng.integers(0, len(factor_sets)))] if what != 1 or rng.random() < 0.5 else (2, 2)
+        if what == 1:          # a sequential script
+            groups = seq_scripts[int(rng.integers(0, len(seq_scripts)))]
+            kw["scans"] = [(g, 0, 63, 0, 0) for g in groups]
+            if rng.random() < 0.4:
+                kw["revert"] = True
+        elif what == 2:        # a progressive script
+            kw["scans"] = prog_scripts[int(rng.integers(0, len(prog_scripts)))]
+        elif what == 3:        # arithmetic coding with conditioning values
+            lo = int(rng.integers(0, 4))
+            kw.update(arithmetic=True, arith_cond=((lo, lo + int(rng.integers(0, 8)), int(rng.integers(1, 64))), (0, int(rng.integers(0, 3)), int(rng.integers(1, 64)))))
+            m = int(rng.integers(0, 3))
+            kw.update({0: dict(baseline=True), 1: dict(fastcrush=True), 2: dict()}[m])
+        else:
+            m = int(rng.integers(0, 3))
+            kw.update({0: dict(baseline=True), 1: dict(fastcrush=True), 2: dict(revert=True)}[m])
+        if rng.random() < 0.35:
+            kw["restart"] = int(rng.integers(1, 3)) if rng.random() < 0.6 else "%db" % int(rng.integers(1, 30))
+        if not kw.get("revert") and rng.random() < 0.2:
+            kw["notrellis"] = True
+        out.append((i, w, h, kw, int(rng.integers(0, 3))))
+    return out
+
+
+@pytest.mark.parametrize("idx,w,h,kw,kind", _round5_cases(), ids=lambda v: str(v) if isinstance(v, int) else None)
+def test_random_sampling_factors_scripts_and_conditioning_match_the_oracle(idx, w, h, kw, kind):
+    rng = np.random.default_rng(5000 + idx)
+    if kind == 0:
+        img = O.synthetic_frame(max(w, 8), max(h, 8), 7000 + idx)[:h, :w].copy()
+    elif kind == 1:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    else:
+        img = np.full((h, w, 3), 255, np.uint8)
+        for _ in range(4):
+            y, x = int(rng.integers(0, h)), int(rng.integers(0, w))
+            img[y:y + 9, x:x + 9] = rng.integers(0, 64, 3, dtype=np.uint8)
+    want = O.encode(O.make_params(w, h, **kw), img)
+    enc = M.Encoder(M.make_params(w, h, **kw), max_batch=2)
+    got = enc.encode_host(np.stack([img, img[::-1].copy()]))
+    enc.close()
+    assert got[0] == want, (idx, w, h, kw)
