@@ -464,8 +464,12 @@ static int check_supported(const mjh_params *p)
   }
   if (p->restart_interval > 65535u || p->restart_in_rows < 0) return fail(MJH_EINVAL, "bad restart interval");
   if (p->arith_code) {
-    if (p->trellis_quant && p->trellis_q_opt)
-      return fail(MJH_EUNSUPPORTED, "trellis_q_opt with arithmetic coding (the reference accumulates its table estimate over three identical passes: not restated)");
+    // trellis_q_opt with the arithmetic coder: with ONE trellis loop the pass that re-estimates the tables never comes (the coder's
+    // trellis passes are num_components in number, the estimate sits behind pass number 2 * num_components - 1:
+    // jcmaster.c:687-698, :1016-1030), so the option changes nothing -- mjh_encoder_create drops it; with more loops the estimate
+    // is made from sums accumulated over identical passes of component 0: not restated
+    if (p->trellis_quant && p->trellis_q_opt && p->trellis_num_loops > 1)
+      return fail(MJH_EUNSUPPORTED, "trellis_q_opt with arithmetic coding and more than one trellis loop (the reference re-estimates table 0 from sums accumulated over identical passes of component 0: not restated)");
     for (int i = 0; i < p->num_components; i++)
       if (p->dc_tbl_no[i] > 1 || p->ac_tbl_no[i] > 1) return fail(MJH_EUNSUPPORTED, "arithmetic coding: conditioning table numbers 0/1 only");
     for (int t = 0; t < 2; t++) {
@@ -782,10 +786,13 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       seq_script.push_back(sc);
     }
     for (int c = 0; c < p->num_components; c++) if (!sent[c]) return fail(MJH_EINVAL, "the script leaves component %d out (JERR_MISSING_DATA)", c);
-    if (p->arith_code) return fail(MJH_EUNSUPPORTED, "sequential multi-scan scripts with arithmetic coding");
     pn.num_scans = 0;
     if (seq_script.size() == 1) seq_script.clear();      // one scan of all components: the plain sequential file
     p = &pn;
+  }
+  if (p->arith_code && p->trellis_quant && p->trellis_q_opt && p->trellis_num_loops <= 1) {   // (see check_supported: no effect in the reference)
+    if (p != &pn) { pn = *p; p = &pn; }
+    pn.trellis_q_opt = 0;
   }
   int rc = check_supported(p);
   if (rc) return rc;
@@ -1031,7 +1038,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     e->frame_hdr_len = e->prefix_len - e->file_hdr_len;
     HIPCHK_E(mjh_dmalloc((void **)&e->d_frame_hdr, (size_t)e->frame_hdr_len + 16));
     HIPCHK_E(hipMemcpy(e->d_frame_hdr, e->d_prefix + e->file_hdr_len, e->frame_hdr_len, hipMemcpyDeviceToDevice));
-    const int ns = p->num_scans > 0 ? p->num_scans : 1;
+    const int ns = p->num_scans > 0 ? p->num_scans : seq_script.empty() ? 1 : (int)seq_script.size();
     e->arith_nscans = ns;
     std::vector<MjhProgScan> ps(ns);
     memset(ps.data(), 0, ps.size() * sizeof(MjhProgScan));
@@ -1040,9 +1047,15 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       MjhProgScan &d = ps[si];
       d.frame_header = si == 0;
       d.slot[0] = d.slot[1] = -1;
-      if (p->num_scans == 0) {    // sequential file: one scan of whole blocks, every component (the table selectors are the components' own)
+      if (p->num_scans == 0 && seq_script.empty()) {    // sequential file: one scan of whole blocks, every component (the table selectors are the components' own)
         d.ncomp = C.ncomp; d.Ss = 0; d.Se = 63;
         for (int c = 0; c < C.ncomp; c++) { d.comp[c] = c; d.comp_id[c] = p->component_id[c]; d.td[c] = p->dc_tbl_no[c]; d.ta[c] = p->ac_tbl_no[c]; }
+        continue;
+      }
+      if (p->num_scans == 0) {    // a sequential script: whole blocks of the scan's components, in the scan's own MCU order
+        const mjh_scan &ms = seq_script[si];
+        d.ncomp = ms.comps_in_scan; d.Ss = 0; d.Se = 63;
+        for (int ci = 0; ci < ms.comps_in_scan; ci++) { const int c = ms.component_index[ci]; d.comp[ci] = c; d.comp_id[ci] = p->component_id[c]; d.td[ci] = p->dc_tbl_no[c]; d.ta[ci] = p->ac_tbl_no[c]; }
         continue;
       }
       const mjh_scan &ms = p->scan_info[si];
@@ -1664,7 +1677,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     HIPCHK(hipGetLastError());
     return MJH_OK;
   }
-  if (!e->seq_scans.empty()) {
+  if (!e->seq_scans.empty() && !e->arith) {
     // A sequential script of several scans: per scan, through its view of the geometry, the statistics of ITS MCU order -> its
     // tables -> its header behind the file so far -> its entropy-coded data (jcmaster.c:1090-1101: two passes per scan with
     // optimal tables).  The scans reuse the table slots and the buffers of the one-scan path, one after the other.

@@ -2160,10 +2160,13 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
 
   /* trellis passes (pass numbers < pass_number_scan_opt_base): SURVEY 3.3 table */
   if (p->trellis_quant && p->arith_code) {
-    /* component 0 only, band of pass 0's scan selection (see trellis_component_arith); trellis_q_opt would re-estimate the
-     * tables from sums accumulated three times over: not restated */
+    /* component 0 only, band of pass 0's scan selection (see trellis_component_arith).  trellis_q_opt: the sums are zeroed in
+     * front of trellis pass 1 and the tables re-estimated behind pass number 2 * num_components - 1 (4 * ... with
+     * use_scans_in_trellis; prepare_for_pass jcmaster.c:687-698, finish_pass_master :1016-1030) -- with one trellis loop there are
+     * only num_components (2 * ...) trellis passes, so that pass never comes and the option changes nothing; with more loops
+     * the estimate would be made from sums accumulated over identical passes of component 0: not restated */
     const int split = p->trellis_freq_split > 0 ? p->trellis_freq_split : 8;
-    if (p->trellis_q_opt) return 0;
+    if (p->trellis_q_opt && p->trellis_num_loops > 1) return 0;
     trellis_component_arith(&e, 0, 1, p->use_scans_in_trellis ? split : 63);
   } else if (p->trellis_quant) {
     for (ci = 0; ci < p->num_components; ci++) {

@@ -122,6 +122,7 @@ CASES = [
     ("script_seq_y_cbcr", dict(scans=[((0,), 0, 63, 0, 0), ((1, 2), 0, 63, 0, 0)]), True),
     ("script_seq_each_restart1", dict(restart=1, scans=[((0,), 0, 63, 0, 0), ((1,), 0, 63, 0, 0), ((2,), 0, 63, 0, 0)]), True),
     ("script_seq_ycb_cr_revert_422", dict(revert=True, sample=(2, 1), scans=[((0, 1), 0, 63, 0, 0), ((2,), 0, 63, 0, 0)]), True),
+    ("script_seq_arith_y_cbcr_restart1", dict(arithmetic=True, restart=1, scans=[((0,), 0, 63, 0, 0), ((1, 2), 0, 63, 0, 0)]), True),
     ("script_prog_custom", dict(scans=[((0, 1, 2), 0, 0, 0, 1), ((0,), 1, 63, 0, 1), ((1,), 1, 63, 0, 0), ((2,), 1, 63, 0, 0),
                                        ((0, 1, 2), 0, 0, 1, 0), ((0,), 1, 63, 1, 0)]), True),
     # arithmetic entropy coding (cjpeg -arithmetic): jcarith.c (sequential SOF9, progressive SOF10, restarts,
@@ -141,6 +142,10 @@ CASES = [
     ("arith_fastcrush_restart2", dict(arithmetic=True, fastcrush=True, restart=2), True),
     ("arith_default_progressive", dict(arithmetic=True), True),
     ("arith_q40_422_progressive", dict(arithmetic=True, quality=40, sample=(2, 1)), True),
+    # trellis_q_opt with the arithmetic coder and one trellis loop: the pass that would re-estimate the tables never comes
+    # (jcmaster.c:687-698, :1016-1030) -- the reference writes the file it writes without the option
+    ("arith_base_q_opt", dict(arithmetic=True, baseline=True, trellis_q_opt=True), True),
+    ("arith_default_progressive_q_opt_scans_in_trellis", dict(arithmetic=True, trellis_q_opt=True, use_scans_in_trellis=True), True),
     # non-default conditioning (cinfo->arith_dc_L / arith_dc_U / arith_ac_K, API-only fields; refenc -arith-cond): DC category
     # thresholds and the AC position Kx, per table, in the coder, its trellis rate model and the DAC marker
     ("arith_base_cond", dict(arithmetic=True, baseline=True, arith_cond=((1, 3, 9), (0, 2, 20))), True),

@@ -76,10 +76,6 @@ def test_unsupported_configurations_are_errors_not_fallbacks():
     with pytest.raises(M.MjhError) as ei:
         M.Encoder(p)
     assert ei.value.code == M.EINVAL
-    p = M.make_params(64, 64, arithmetic=True, baseline=True, scans=[((0,), 0, 63, 0, 0), ((1, 2), 0, 63, 0, 0)])   # not restated for the arithmetic coder
-    with pytest.raises(M.MjhError) as ei:
-        M.Encoder(p)
-    assert ei.value.code == M.EUNSUPPORTED
     p = M.make_params(64, 64)
     p.scan_info[5].Ss = 2                                  # optimize_scans with a script that is not jpeg_search_progression's
     with pytest.raises(M.MjhError) as ei:
