@@ -1949,14 +1949,21 @@ static int host_buffers(mjh_encoder *e)
 // after a batch has been queued on e->stream: pack its files into the pinned arena `b` on the D2H stream
 static int queue_pack(mjh_encoder *e, int b, int n)
 {
-  HIPCHK(hipEventRecord(e->ev_join, e->stream));
-  HIPCHK(hipStreamWaitEvent(e->d2h_stream, e->ev_join, 0));
+  // The files leave for the host on a stream of their own so that batch k's hand-over runs under batch k + 1's kernels.  One
+  // image at a time (a synchronous libjpeg client) has nothing to overlap with: there the hand-over stays on the main stream
+  // and saves the cross-stream hop (an event wait between hardware queues costs tens of microseconds of a ~1.4 ms image).
+  static const bool pack_main_ok = !(getenv("MJH_PACK_MAIN") && atoi(getenv("MJH_PACK_MAIN")) == 0);
+  hipStream_t ps = (n == 1 && pack_main_ok) ? e->stream : e->d2h_stream;
+  if (ps != e->stream) {
+    HIPCHK(hipEventRecord(e->ev_join, e->stream));
+    HIPCHK(hipStreamWaitEvent(ps, e->ev_join, 0));
+  }
   void *d_res = nullptr, *d_tab = nullptr;
   HIPCHK(hipHostGetDevicePointer(&d_res, e->h_res[b], 0));
   HIPCHK(hipHostGetDevicePointer(&d_tab, e->h_tab[b], 0));
   mjh_launch_pack_results(e->d_out, e->out_stride, e->d_sizes, (e->progressive || e->arith) ? nullptr : e->d_meta, (e->progressive || e->arith) ? e->d_prog_ctl : nullptr,
-                          n, d_res, e->res_cap, d_tab, e->d2h_stream);
-  HIPCHK(hipEventRecord(e->ev_packed[b], e->d2h_stream));
+                          n, d_res, e->res_cap, d_tab, ps);
+  HIPCHK(hipEventRecord(e->ev_packed[b], ps));
   e->res_buf = b;
   e->res_n[b] = n;
   e->res_waited[b] = false;

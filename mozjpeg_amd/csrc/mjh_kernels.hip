@@ -382,7 +382,7 @@ __device__ __forceinline__ float catmull_rom(int v1, int v2, int v3, int v4, flo
 // FD: every quantizer step of the tables in use fits 8 bits -- the division by 8q is one shift + one 24-bit multiply-high
 // (MjhQuant.mdiv / sdiv) instead of the float-reciprocal division with its integer fix-up; with STATS the AC coefficients are
 // quantized for the statistics only, which need the magnitude category and nothing else (no sign, no signed clamp).
-#define DCTQ_NB 4      // sets of 64 blocks per wave of the FDCT kernel
+#define DCTQ_NB 4      // sets of 64 blocks per wave of the FDCT kernel with fused statistics (the others: one set -- a loop only cost them: 12-bit C5 477 -> 532 us)
 template <class T, bool STATS, bool FD>   // uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
 __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant *__restrict__ Q, const T *__restrict__ planes,
                                                int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
@@ -405,7 +405,8 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
   dcol_alias (*lds)[64] = reinterpret_cast<dcol_alias (*)[64]>(&lds_raw[0][0]);
   const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
-  const int set0 = blockIdx.x * DCTQ_NB;
+  constexpr int NB = STATS ? DCTQ_NB : 1;
+  const int set0 = blockIdx.x * NB;
   if (set0 * 64 >= cc.nblk) return;       // whole workgroup outside (grid is sized for the largest component)
   constexpr bool stats = STATS;
   unsigned *hist = hist_raw;
@@ -427,7 +428,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
   };
   row_t rows_cur[8];
 #pragma unroll 1
-  for (int it = 0; it < DCTQ_NB; it++) {
+  for (int it = 0; it < NB; it++) {
   const int set = set0 + it;
   if (set * 64 >= cc.nblk) break;                        // uniform
   load_rows(set, rows_cur);
@@ -806,15 +807,18 @@ k_stats_dc(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restr
 }
 
 // interleaved MCU order incl. dummy blocks (the final scan; encode_mcu_gather jchuff.c:866-915 walks the MCUs, the blocks of
-// a component inside an MCU row by row): ONE LANE PER MCU of one component.  blockIdx.x = MCU row, the threads stride
-// the MCUs of the row, so no thread divides anything; the lane loads the last block of the MCU in front (the prediction of
+// a component inside an MCU row by row): ONE LANE PER MCU of one component.  A workgroup takes `rows_per_wg` MCU rows, the threads
+// stride the MCUs of a row, so no thread divides anything; the lane loads the last block of the MCU in front (the prediction of
 // its first block) and its own h x v blocks -- every load is issued before the first use, the other predictions are the
-// lane's previous value.  Counts per symbol are wave-uniform (ballot + s_bcnt1) until the single atomic per symbol.
+// lane's previous value.  Counts per symbol are wave-uniform (ballot + s_bcnt1); the four waves meet in LDS, so a (component,
+// image) table sees at most ~128 atomics per symbol (one 8192 x 8192 frame with a workgroup per MCU row and an atomic per wave:
+// 12 288 waves on 48 addresses = 119 us of serialised L2 atomics, profiles/r05m_c5_kernel_stats.csv).
 __global__ void __launch_bounds__(256)
 k_stats_dc_mcu(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__restrict__ tabs,
-               int slots_per_image, int4 slot_of_comp)
+               int slots_per_image, int4 slot_of_comp, int rows_per_wg)
 {
-  const int comp = blockIdx.y, img = blockIdx.z, my = blockIdx.x;
+  __shared__ unsigned s_cnt[16];
+  const int comp = blockIdx.y, img = blockIdx.z;
   const MjhComp cc = C.c[comp];
   const int16_t *q0 = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off;  // plane k = 0
   const int lane = threadIdx.x & 63;
@@ -822,6 +826,9 @@ k_stats_dc_mcu(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__r
   unsigned cnt[16];
 #pragma unroll
   for (int s = 0; s < 16; s++) cnt[s] = 0;
+  if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  for (int my = blockIdx.x * rows_per_wg; my < (int)(blockIdx.x + 1) * rows_per_wg && my < C.mcu_rows; my++)      // uniform
   for (int mx0 = 0; mx0 < mpr; mx0 += 256) {   // uniform
     const int mx = mx0 + (int)threadIdx.x;
     const bool in = mx < mpr;
@@ -870,7 +877,9 @@ k_stats_dc_mcu(MjhConst C, const int16_t *__restrict__ coef_q, MjhHuffTable *__r
   unsigned mine = 0;
 #pragma unroll
   for (int s = 0; s < 16; s++) mine = lane == s ? cnt[s] : mine;
-  if (lane < 16 && mine) atomicAdd(&T->counts[lane], mine);
+  if (lane < 16 && mine) atomicAdd(&s_cnt[lane], mine);
+  __syncthreads();
+  if (threadIdx.x < 16 && s_cnt[threadIdx.x]) atomicAdd(&T->counts[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
 // =============================================================================================
@@ -3404,7 +3413,8 @@ static int max_padblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncom
 void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
                     MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv)
 {
-  dim3 grid(((max_nblk(C) + 63) / 64 + DCTQ_NB - 1) / DCTQ_NB, C.ncomp, n);
+  const int nb = (stat_tabs && C.precision != 12) ? DCTQ_NB : 1;      // (= the kernel's NB: the STATS instantiations)
+  dim3 grid(((max_nblk(C) + 63) / 64 + nb - 1) / nb, C.ncomp, n);
   const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
   if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t, false>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else if (stat_tabs && fastdiv) hipLaunchKernelGGL((k_dct_quant<uint8_t, true, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
@@ -3426,8 +3436,9 @@ void mjh_launch_stats_dc(const MjhConst &C, const void *q, MjhHuffTable *tabs, i
   const int4 cr = make_int4(comp_restart[0], comp_restart[1], comp_restart[2], comp_restart[3]);
   const int per_wg = 256 * STATS_DC_ITER;
   if (mcu_order) {
-    dim3 grid(C.mcu_rows, C.ncomp, n);
-    hipLaunchKernelGGL(k_stats_dc_mcu, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, sl);
+    const int rpw = (C.mcu_rows + 127) / 128;       // at most 128 workgroups per (component, image)
+    dim3 grid((C.mcu_rows + rpw - 1) / rpw, C.ncomp, n);
+    hipLaunchKernelGGL(k_stats_dc_mcu, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, sl, rpw);
   } else {
     dim3 grid((max_nblk(C) + per_wg - 1) / per_wg, C.ncomp, n);
     hipLaunchKernelGGL(k_stats_dc, grid, dim3(256), 0, s, C, (const int16_t *)q, tabs, spi, sl, cr);
