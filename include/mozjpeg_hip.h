@@ -118,7 +118,8 @@ typedef struct {
   /* cinfo->arith_code (jpeglib.h:420, cjpeg -arithmetic): arithmetic entropy coding (jcarith.c) instead of Huffman -- SOF9 /
    * SOF10 frames, DAC markers, no Huffman tables; with trellis_quant the coder's own rate model (quantize_trellis_arith
    * jcdctmgr.c:1334-1667).  An adaptive coder is one dependent chain per scan: this mode is there for completeness, not for
-   * throughput.  Not combined with trellis_q_opt (MJH_EUNSUPPORTED). */
+   * throughput.  With trellis_q_opt the reference's pass arithmetic decides whether component 0's table is ever re-estimated
+   * (jcmaster.c:687-698, :1016-1030, :1135-1138): reproduced for any number of loops. */
   int arith_code;
   /* cinfo->arith_dc_L / arith_dc_U / arith_ac_K (jpeglib.h:447-449) of conditioning tables 0 and 1: the DC category thresholds
    * (jcarith.c:442-445, :757-760) and the AC position Kx that switches the magnitude bins (:533, :802), written into the DAC

@@ -394,7 +394,7 @@ __device__ __forceinline__ float ari_dc_bits(const float (*rdc)[2], int st, int 
 }
 
 __global__ void __launch_bounds__(256)
-k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q,
+k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, int qstride, const int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q,
                 const float *__restrict__ lambda_in, const MjhArithRates *__restrict__ rate_tab, uint8_t *__restrict__ back,
                 int Ss, int Se, int quant_dc, float delta_dc_weight, int restart_blocks, int prog_file)
 {
@@ -406,6 +406,7 @@ k_trellis_arith(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
   __shared__ int s_lastdc;
   const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // (uniform for the compiler too: the coding wave's branch is a scalar one)
+  Q += (size_t)img * qstride;    // trellis_q_opt: every image has its own table set
   const MjhComp cc = C.c[0];
   const int qt = cc.qtbl;
   const int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off;
@@ -661,9 +662,9 @@ void mjh_launch_arith_layout(void *ctl, const uint8_t *file_hdr, int file_hdr_le
   hipLaunchKernelGGL(k_arith_layout, dim3((n + 63) / 64), dim3(64), 0, s, (MjhProgCtl *)ctl, file_hdr, file_hdr_len, out, out_stride, sizes, n);
 }
 
-void mjh_launch_trellis_arith(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const float *lambda, const void *rate_tab, void *back,
+void mjh_launch_trellis_arith(const MjhConst &C, const MjhQuant *Q, int qstride, const void *uq, void *q, const float *lambda, const void *rate_tab, void *back,
                               int Ss, int Se, int quant_dc, float delta_dc_weight, int restart_blocks, int prog_file, int n, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_trellis_arith, dim3(n), dim3(256), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, lambda, (const MjhArithRates *)rate_tab, (uint8_t *)back,
+  hipLaunchKernelGGL(k_trellis_arith, dim3(n), dim3(256), 0, s, C, Q, qstride, (const int16_t *)uq, (int16_t *)q, lambda, (const MjhArithRates *)rate_tab, (uint8_t *)back,
                      Ss, Se, quant_dc, delta_dc_weight, restart_blocks, prog_file);
 }

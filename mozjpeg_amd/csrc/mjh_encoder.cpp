@@ -380,6 +380,17 @@ struct mjh_encoder {
 
 static long div_round_up(long a, long b) { return (a + b - 1) / b; }
 
+// trellis_q_opt with the arithmetic coder.  The coder's trellis passes all select component 0 (no statistics pass sits between
+// them and prepare_for_pass's trellis_pass case does not re-select the scan: jcmaster.c:686-702, :1001-1005); they are passes
+// 0 .. T-1 with T = pass_number_scan_opt_base = (1 or 2) * num_components * trellis_num_loops + 1 (jcmaster.c:1135-1138, :1010), the
+// sums are zeroed in front of every pass with number % M == 1 and the tables re-estimated behind every pass with
+// (number + 1) % M == 0, M = (2 or 4) * num_components (:687-698, :1016-1030).  Passes with the same tables repeat each other and
+// sums of k identical passes give the same quotient as the sums of one, so what the reference does amounts to: U = T / M times
+// [trellis pass, estimate component 0's table from it], then one more pass with the last estimate if T > U * M (else the last
+// estimate only reaches the DQT marker: a gray image with an odd number of loops).
+static int arith_qopt_passes(const mjh_params *p) { return (p->use_scans_in_trellis ? 2 : 1) * p->num_components * (p->trellis_num_loops > 1 ? p->trellis_num_loops : 1) + 1; }
+static int arith_qopt_updates(const mjh_params *p) { return arith_qopt_passes(p) / ((p->use_scans_in_trellis ? 4 : 2) * p->num_components); }
+
 static int check_supported(const mjh_params *p)
 {
   if (p->image_width <= 0 || p->image_height <= 0 || p->image_width > 65500 || p->image_height > 65500)
@@ -464,12 +475,6 @@ static int check_supported(const mjh_params *p)
   }
   if (p->restart_interval > 65535u || p->restart_in_rows < 0) return fail(MJH_EINVAL, "bad restart interval");
   if (p->arith_code) {
-    // trellis_q_opt with the arithmetic coder: with ONE trellis loop the pass that re-estimates the tables never comes (the coder's
-    // trellis passes are num_components in number, the estimate sits behind pass number 2 * num_components - 1:
-    // jcmaster.c:687-698, :1016-1030), so the option changes nothing -- mjh_encoder_create drops it; with more loops the estimate
-    // is made from sums accumulated over identical passes of component 0: not restated
-    if (p->trellis_quant && p->trellis_q_opt && p->trellis_num_loops > 1)
-      return fail(MJH_EUNSUPPORTED, "trellis_q_opt with arithmetic coding and more than one trellis loop (the reference re-estimates table 0 from sums accumulated over identical passes of component 0: not restated)");
     for (int i = 0; i < p->num_components; i++)
       if (p->dc_tbl_no[i] > 1 || p->ac_tbl_no[i] > 1) return fail(MJH_EUNSUPPORTED, "arithmetic coding: conditioning table numbers 0/1 only");
     for (int t = 0; t < 2; t++) {
@@ -790,7 +795,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     if (seq_script.size() == 1) seq_script.clear();      // one scan of all components: the plain sequential file
     p = &pn;
   }
-  if (p->arith_code && p->trellis_quant && p->trellis_q_opt && p->trellis_num_loops <= 1) {   // (see check_supported: no effect in the reference)
+  if (p->arith_code && p->trellis_quant && p->trellis_q_opt && arith_qopt_updates(p) == 0) {   // no pass re-estimates the tables: no effect in the reference
     if (p != &pn) { pn = *p; p = &pn; }
     pn.trellis_q_opt = 0;
   }
@@ -1426,10 +1431,22 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
         if (!e->d_q0) HIPCHK(mjh_dmalloc((void **)&e->d_q0, (size_t)e->max_batch * C.coefs_per_image * 2));
         HIPCHK(hipMemcpyAsync(e->d_q0, e->d_q, (size_t)n * C.coefs_per_image * 2, hipMemcpyDeviceToDevice, s));
       }
-      pr.mark("trellis_arith");
       const int split = p.trellis_freq_split > 0 ? p.trellis_freq_split : 8;
-      mjh_launch_trellis_arith(C, e->d_quant, e->d_uq, e->d_q, e->d_lambda, e->d_arith_rates, e->d_back, 1, p.use_scans_in_trellis ? split : 63,
-                               p.trellis_quant_dc, p.trellis_delta_dc_weight, e->comp_restart[0], e->progressive ? 1 : 0, n, s);
+      const int updates = ext_qopt ? arith_qopt_updates(&p) : 0;
+      const int runs = ext_qopt ? updates + (arith_qopt_passes(&p) > updates * (p.use_scans_in_trellis ? 4 : 2) * C.ncomp ? 1 : 0) : 1;   // (see arith_qopt_passes)
+      MjhConst C0 = C;       // component 0 alone: the sums of trellis_q_opt
+      C0.ncomp = 1;
+      for (int r = 0; r < runs; r++) {
+        pr.mark("trellis_arith");
+        mjh_launch_trellis_arith(C, e->d_quant, ext_qopt ? 1 : 0, e->d_uq, e->d_q, e->d_lambda, e->d_arith_rates, e->d_back, 1, p.use_scans_in_trellis ? split : 63,
+                                 p.trellis_quant_dc, p.trellis_delta_dc_weight, e->comp_restart[0], e->progressive ? 1 : 0, n, s);
+        if (r < updates) {
+          pr.mark("trellis_q_opt(sums)");
+          mjh_launch_qopt_accumulate(C0, e->d_uq, e->d_q, e->d_qsums, n, s);
+          pr.mark("trellis_q_opt(tables)");
+          mjh_launch_qopt_update(e->d_qsums, e->d_quant, n, s);
+        }
+      }
     }
     const int whole = e->progressive ? 0 : 1;
     if (e->arith_nscans == 1) {
@@ -1451,6 +1468,11 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       pr.mark("arith_encode");
       mjh_launch_arith_scans(C, e->d_prog_scans, e->d_lists, e->arith_nscans, e->d_prog_ctl, e->d_q, e->d_frame_hdr, e->frame_hdr_len,
                              e->d_prefix, e->file_hdr_len, e->d_out, e->out_stride, e->d_sizes, whole, 1, n, s);
+    }
+    if (ext_qopt && !coef_src) {   // the final tables into the DQT marker(s) (jcmaster.c:1014-1030; SOF9 / SOF10 whatever their precision)
+      pr.mark("trellis_q_opt(DQT)");
+      mjh_launch_qopt_fix(e->d_quant, e->d_out, e->out_stride, e->d_sizes, e->file_hdr_len, e->prefix_len - (10 + 3 * C.ncomp), e->dqt_tabs, e->dqt_ntab,
+                          p.compress_profile != MJH_PROFILE_FASTEST, 0, n, s);
     }
     pr.mark(nullptr);
     pr.finish();
@@ -1951,9 +1973,9 @@ static int queue_pack(mjh_encoder *e, int b, int n)
 {
   // The files leave for the host on a stream of their own so that batch k's hand-over runs under batch k + 1's kernels.  One
   // image at a time (a synchronous libjpeg client) has nothing to overlap with: there the hand-over stays on the main stream
-  // and saves the cross-stream hop (an event wait between hardware queues costs tens of microseconds of a ~1.4 ms image).
-  static const bool pack_main_ok = !(getenv("MJH_PACK_MAIN") && atoi(getenv("MJH_PACK_MAIN")) == 0);
-  hipStream_t ps = (n == 1 && pack_main_ok) ? e->stream : e->d2h_stream;
+  // and saves the cross-stream hop (an event wait between hardware queues costs tens of microseconds of a ~1.4 ms image;
+  // measured A/B on one client thread, 4K: 720 / 721 images/s against 673 / 697 with the hop, profiles/r05n_dropin_handover_ab.md).
+  hipStream_t ps = n == 1 ? e->stream : e->d2h_stream;
   if (ps != e->stream) {
     HIPCHK(hipEventRecord(e->ev_join, e->stream));
     HIPCHK(hipStreamWaitEvent(ps, e->ev_join, 0));

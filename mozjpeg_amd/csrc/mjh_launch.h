@@ -67,6 +67,6 @@ void mjh_launch_arith_scans(const MjhConst &C, const void *scans, const int *lis
                             const uint8_t *frame_hdr, int frame_hdr_len, const uint8_t *file_hdr, int file_hdr_len,
                             uint8_t *out, size_t out_stride, unsigned *sizes, int whole_blocks, int mode, int n, hipStream_t s);
 void mjh_launch_arith_layout(void *ctl, const uint8_t *file_hdr, int file_hdr_len, uint8_t *out, size_t out_stride, unsigned *sizes, int n, hipStream_t s);
-void mjh_launch_trellis_arith(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, const float *lambda, const void *rate_tab, void *back,
+void mjh_launch_trellis_arith(const MjhConst &C, const MjhQuant *Q, int qstride, const void *uq, void *q, const float *lambda, const void *rate_tab, void *back,
                               int Ss, int Se, int quant_dc, float delta_dc_weight, int restart_blocks, int prog_file, int n, hipStream_t s);
 #endif

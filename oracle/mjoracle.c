@@ -2160,14 +2160,40 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
 
   /* trellis passes (pass numbers < pass_number_scan_opt_base): SURVEY 3.3 table */
   if (p->trellis_quant && p->arith_code) {
-    /* component 0 only, band of pass 0's scan selection (see trellis_component_arith).  trellis_q_opt: the sums are zeroed in
-     * front of trellis pass 1 and the tables re-estimated behind pass number 2 * num_components - 1 (4 * ... with
-     * use_scans_in_trellis; prepare_for_pass jcmaster.c:687-698, finish_pass_master :1016-1030) -- with one trellis loop there are
-     * only num_components (2 * ...) trellis passes, so that pass never comes and the option changes nothing; with more loops
-     * the estimate would be made from sums accumulated over identical passes of component 0: not restated */
+    /* component 0 only, band of pass 0's scan selection (see trellis_component_arith): passes 0 .. T-1 with
+     * T = pass_number_scan_opt_base = (1 or 2) * num_components * trellis_num_loops + 1 (jcmaster.c:1135-1138, :1010), all of them
+     * the same pass as long as the tables stay what they are.  trellis_q_opt: the sums are zeroed in front of every pass with
+     * pass_number % M == 1 and the tables re-estimated behind every pass with (pass_number + 1) % M == 0, M = (2 or 4) *
+     * num_components (prepare_for_pass jcmaster.c:687-698, finish_pass_master :1016-1030) -- whether such a pass exists depends
+     * on T: none for three components and one loop, one for a gray image and one loop (the estimate then only reaches the
+     * DQT marker: no trellis pass follows it), one or more with further loops; component 0's table is the only one with
+     * non-zero sums.  Restated pass by pass, as the reference runs them. */
     const int split = p->trellis_freq_split > 0 ? p->trellis_freq_split : 8;
-    if (p->trellis_q_opt && p->trellis_num_loops > 1) return 0;
-    trellis_component_arith(&e, 0, 1, p->use_scans_in_trellis ? split : 63);
+    const int nb = p->use_scans_in_trellis ? 2 : 1;
+    const int nloops = p->trellis_num_loops > 1 ? p->trellis_num_loops : 1;
+    const int T = nb * p->num_components * nloops + 1, M = 2 * nb * p->num_components;
+    const int Se = p->use_scans_in_trellis ? split : 63;
+    if (!p->trellis_q_opt) trellis_component_arith(&e, 0, 1, Se);
+    else {
+      int pass, stale = 1;
+      for (pass = 0; pass < T; pass++) {
+        if (pass % M == 1) { memset(e.norm_src, 0, sizeof(e.norm_src)); memset(e.norm_coef, 0, sizeof(e.norm_coef)); }
+        if (stale) { trellis_component_arith(&e, 0, 1, Se); stale = 0; }   /* (a pass with unchanged tables repeats the previous one) */
+        if (Se >= 1) q_opt_accumulate(&e, 0);
+        if ((pass + 1) % M == 0) {
+          int ti, j;
+          for (ti = 0; ti < 4; ti++)
+            for (j = 1; j < 64; j++)
+              if (e.norm_coef[ti][j] != 0.0) {
+                int q = (int)(e.norm_src[ti][j] / e.norm_coef[ti][j] + 0.5);
+                if (q > 254) q = 254;
+                if (q < 1) q = 1;
+                pp.qtbl[ti][j] = (uint16_t)q;
+              }
+          stale = 1;
+        }
+      }
+    }
   } else if (p->trellis_quant) {
     for (ci = 0; ci < p->num_components; ci++) {
       mjo_scan ms;

@@ -142,10 +142,19 @@ CASES = [
     ("arith_fastcrush_restart2", dict(arithmetic=True, fastcrush=True, restart=2), True),
     ("arith_default_progressive", dict(arithmetic=True), True),
     ("arith_q40_422_progressive", dict(arithmetic=True, quality=40, sample=(2, 1)), True),
-    # trellis_q_opt with the arithmetic coder and one trellis loop: the pass that would re-estimate the tables never comes
-    # (jcmaster.c:687-698, :1016-1030) -- the reference writes the file it writes without the option
+    # trellis_q_opt with the arithmetic coder: T = (1 or 2) * components * loops + 1 trellis passes of component 0, tables
+    # re-estimated behind every pass with (pass + 1) % ((2 or 4) * components) == 0 (jcmaster.c:687-698, :1016-1030, :1135-1138):
+    # never with three components and one loop (the reference writes the file it writes without the option) ...
     ("arith_base_q_opt", dict(arithmetic=True, baseline=True, trellis_q_opt=True), True),
     ("arith_default_progressive_q_opt_scans_in_trellis", dict(arithmetic=True, trellis_q_opt=True, use_scans_in_trellis=True), True),
+    # ... once for a gray image and one loop (the estimate only reaches the DQT marker: no trellis pass follows it), once or
+    # more with further loops (later passes quantize component 0 with the estimated table); a 16-bit table that turns 8-bit
+    ("arith_gray_q_opt", dict(arithmetic=True, baseline=True, gray=True, trellis_q_opt=True), True),
+    ("arith_base_q_opt_loops2", dict(arithmetic=True, baseline=True, trellis_q_opt=True, trellis_loops=2), True),
+    ("arith_gray_q_opt_loops4_restart2", dict(arithmetic=True, baseline=True, gray=True, trellis_q_opt=True, trellis_loops=4, restart=2), True),
+    ("arith_default_progressive_q_opt_loops4", dict(arithmetic=True, trellis_q_opt=True, trellis_loops=4), True),
+    ("arith_fastcrush_q_opt_loops3_scans_in_trellis_444", dict(arithmetic=True, fastcrush=True, trellis_q_opt=True, trellis_loops=3, use_scans_in_trellis=True, sample=(1, 1)), True),
+    ("arith_q3_16bit_q_opt_loops2", dict(arithmetic=True, quality=3, trellis_q_opt=True, trellis_loops=2), True),
     # non-default conditioning (cinfo->arith_dc_L / arith_dc_U / arith_ac_K, API-only fields; refenc -arith-cond): DC category
     # thresholds and the AC position Kx, per table, in the coder, its trellis rate model and the DAC marker
     ("arith_base_cond", dict(arithmetic=True, baseline=True, arith_cond=((1, 3, 9), (0, 2, 20))), True),

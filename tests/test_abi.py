@@ -248,7 +248,8 @@ def test_traffic_figures_are_quoted_only_for_the_kernels_they_were_measured_on(m
     # one kernel of the interval recompiled to something else: stale, whatever the others do
     real = json.load(open(os.path.join(ROOT, "mozjpeg_amd", "kernel_isa.json")))
     fp = {k: v["sha"] for k, v in real["kernels"].items()}
-    fp["k_trellis_ac_qd<32, false, false, true>"] = "f" * 16
+    newest = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc_hbm_traffic_batch64.json") and p.count("_") == 4)[-1]
+    fp[next(k for k in json.load(open(os.path.join(ROOT, "profiles", newest)))["kernels"] if k.startswith("k_trellis_ac_qd"))] = "f" * 16
     monkeypatch.setattr(bench, "kernel_fingerprints", lambda: fp)
     traffic, src = bench.dominant_traffic("metric", "trellis_ac", 64)
     assert traffic is None and src.startswith("stale")

@@ -207,3 +207,49 @@ def test_random_sampling_factors_scripts_and_conditioning_match_the_oracle(idx, 
     got = enc.encode_host(np.stack([img, img[::-1].copy()]))
     enc.close()
     assert got[0] == want, (idx, w, h, kw)
+
+
+def _arith_qopt_cases():
+    """trellis_q_opt with the arithmetic coder (round 5, late): gray and colour, 1-5 trellis loops, with and without the two
+    trellis bands -- whether and how often the reference re-estimates component 0's table depends on all three (and a gray
+    image with an odd number of loops gets its last estimate in the DQT marker only)"""
+    rng = np.random.default_rng(20260923)
+    out = []
+    for i in range(24):
+        w = int(rng.integers(1, 300)); h = int(rng.integers(1, 220))
+        kw = dict(arithmetic=True, trellis_q_opt=True, quality=int(rng.choice([3, 10, 25, 50, 75, 90, 97])), trellis_loops=int(rng.integers(1, 6)),
+                  sample=[(1, 1), (2, 1), (2, 2), (1, 2)][int(rng.integers(0, 4))])
+        kw.update({0: dict(baseline=True), 1: dict(fastcrush=True), 2: dict()}[int(rng.integers(0, 3))])
+        if rng.random() < 0.45:
+            kw["gray"] = True
+            kw["sample"] = (1, 1)
+        if rng.random() < 0.35:
+            kw["use_scans_in_trellis"] = True
+            kw["trellis_freq_split"] = int(rng.choice([0, 1, 8, 30, 63]))
+        if rng.random() < 0.3:
+            kw["restart"] = int(rng.integers(1, 3)) if rng.random() < 0.6 else "%db" % int(rng.integers(1, 30))
+        if rng.random() < 0.2:
+            kw["notrellis_dc"] = True
+        out.append((i, w, h, kw, int(rng.integers(0, 3))))
+    return out
+
+
+@pytest.mark.parametrize("idx,w,h,kw,kind", _arith_qopt_cases(), ids=lambda v: str(v) if isinstance(v, int) else None)
+def test_random_arithmetic_q_opt_configuration_matches_the_oracle(idx, w, h, kw, kind):
+    rng = np.random.default_rng(9000 + idx)
+    if kind == 0:
+        img = O.synthetic_frame(max(w, 8), max(h, 8), 9100 + idx)[:h, :w].copy()
+    elif kind == 1:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    else:
+        img = np.full((h, w, 3), 255, np.uint8)
+        for _ in range(4):
+            y, x = int(rng.integers(0, h)), int(rng.integers(0, w))
+            img[y:y + 9, x:x + 9] = rng.integers(0, 64, 3, dtype=np.uint8)
+    want = O.encode(O.make_params(w, h, **kw), img)
+    enc = M.Encoder(M.make_params(w, h, **kw), max_batch=2)
+    got = enc.encode_host(np.stack([img, img[::-1].copy()]))
+    again = enc.encode_host(np.stack([img[::-1].copy(), img]))      # (the tables of a call start from the parameters' again)
+    enc.close()
+    assert got[0] == want and again[1] == want, (idx, w, h, kw)
+    assert got[1] == again[0] == O.encode(O.make_params(w, h, **kw), img[::-1].copy()), (idx, w, h, kw)
