@@ -210,6 +210,65 @@ k_color_generic(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, s
   planes[(size_t)img * C.planes_per_image + cc.plane_off + (size_t)r * cc.pw + c] = (T)val;
 }
 
+// 8 pixels of 3 bytes (six dwords of one row) -> 8 luma bytes, and the 4 x 2 chroma values of the row added to the running sums.
+// Round 5: the bytes are taken out of the dwords as they are used (a byte array in between made the compiler pack and unpack
+// 16-bit halves: 33 lane-instructions per pixel), RGB / BGR is a choice of COEFFICIENTS (uniform scalars) instead of two selects per
+// pixel, and the luma bytes -- byte 2 of the 24-bit sums -- are gathered by v_perm_b32.
+struct MjhYccCoef { int y0, y1, y2, cb0, cb1, cb2, cr0, cr1, cr2; };    // per byte position of the pixel
+__device__ __forceinline__ MjhYccCoef ycc_coef(bool bgr)
+{
+  MjhYccCoef k;
+  k.y0 = bgr ? FIXC(0.11400) : FIXC(0.29900);   k.y1 = FIXC(0.58700);   k.y2 = bgr ? FIXC(0.29900) : FIXC(0.11400);
+  k.cb0 = bgr ? FIXC(0.50000) : -FIXC(0.16874); k.cb1 = -FIXC(0.33126); k.cb2 = bgr ? -FIXC(0.16874) : FIXC(0.50000);
+  k.cr0 = bgr ? -FIXC(0.08131) : FIXC(0.50000); k.cr1 = -FIXC(0.41869); k.cr2 = bgr ? FIXC(0.50000) : -FIXC(0.08131);
+  return k;
+}
+__device__ __forceinline__ uint2 ycc_row8(const unsigned (&w)[6], const MjhYccCoef &k, int (&cbs)[4], int (&crs)[4])
+{
+  unsigned ys[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int a = (int)((w[(3 * j) >> 2] >> (8 * ((3 * j) & 3))) & 0xFFu);
+    const int g = (int)((w[(3 * j + 1) >> 2] >> (8 * ((3 * j + 1) & 3))) & 0xFFu);
+    const int c = (int)((w[(3 * j + 2) >> 2] >> (8 * ((3 * j + 2) & 3))) & 0xFFu);
+    ys[j] = (unsigned)(mul24(a, k.y0) + mul24(g, k.y1) + mul24(c, k.y2) + 32768);                      // < 2^24: Y is byte 2
+    cbs[j >> 1] += (mul24(a, k.cb0) + mul24(g, k.cb1) + mul24(c, k.cb2) + (128 << 16) + 32767) >> 16;
+    crs[j >> 1] += (mul24(a, k.cr0) + mul24(g, k.cr1) + mul24(c, k.cr2) + (128 << 16) + 32767) >> 16;
+  }
+  uint2 o;
+  o.x = __builtin_amdgcn_perm(__builtin_amdgcn_perm(ys[3], ys[2], 0x0c0c0602u), __builtin_amdgcn_perm(ys[1], ys[0], 0x0c0c0602u), 0x05040100u);
+  o.y = __builtin_amdgcn_perm(__builtin_amdgcn_perm(ys[7], ys[6], 0x0c0c0602u), __builtin_amdgcn_perm(ys[5], ys[4], 0x0c0c0602u), 0x05040100u);
+  return o;
+}
+// the six dwords of 8 pixels: three 8-byte loads inside the image, clamped byte loads for a run that touches the right edge
+__device__ __forceinline__ void load_px8(const uint8_t *row, int x0, int W, bool interior, unsigned (&w)[6])
+{
+  if (interior) {
+    const uint2 *rv = reinterpret_cast<const uint2 *>(row + (size_t)x0 * 3);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { const uint2 v = rv[i]; w[2 * i] = v.x; w[2 * i + 1] = v.y; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; i++) w[i] = 0u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      int ix = x0 + j;
+      if (ix > W - 1) ix = W - 1;
+#pragma unroll
+      for (int c = 0; c < 3; c++) w[(3 * j + c) >> 2] |= (unsigned)row[ix * 3 + c] << (8 * ((3 * j + c) & 3));
+    }
+  }
+}
+// h2v2 / h2v1 roundings of four consecutive chroma samples (the first one at an even column): bias 1,2,1,2 / 0,1,0,1
+template <int V0>
+__device__ __forceinline__ unsigned chroma4(const int (&sum)[4])
+{
+  unsigned o = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) o |= (unsigned)(V0 == 2 ? (sum[j] + 1 + (j & 1)) >> 2 : (sum[j] + (j & 1)) >> 1) << (8 * j);
+  return o;
+}
+
 // Vectorised variant for the common case (8-bit, 3 bytes per pixel, 2:1 horizontal chroma
 // subsampling, 8-byte aligned rows): one lane converts 8 pixels x V0 rows = 4 chroma samples.  The
 // 24 bytes per row arrive as three 8-byte loads, Y leaves as one 8-byte store per row, Cb/Cr as one
@@ -229,69 +288,39 @@ k_color_vec(MjhConst C, const uint8_t *__restrict__ pix, size_t row_pitch, size_
   const int gys = below ? C.real_groups_y - 1 : gy;
   const int x0 = g4 * 8;
   const bool interior = x0 + 7 <= C.W - 1;
-  const bool bgr = C.off_r == 2;
-  int yv[V0][8];
+  const MjhYccCoef k = ycc_coef(C.off_r == 2);
+  uint2 yv[V0];
   int cbs[4] = { 0, 0, 0, 0 }, crs[4] = { 0, 0, 0, 0 };
+  unsigned w[V0][6];
+  const uint8_t *rowp[V0];
 #pragma unroll
   for (int vy = 0; vy < V0; vy++) {
     int iy = gys * V0 + vy;
     if (iy > C.H - 1) iy = C.H - 1;
-    const uint8_t *row = p + (size_t)iy * row_pitch;
-    unsigned char px[24];
-    if (interior) {
-      const uint2 *rv = reinterpret_cast<const uint2 *>(row + (size_t)x0 * 3);
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const uint2 v = rv[i];
-#pragma unroll
-        for (int b = 0; b < 4; b++) { px[8 * i + b] = (unsigned char)(v.x >> (8 * b)); px[8 * i + 4 + b] = (unsigned char)(v.y >> (8 * b)); }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        int ix = x0 + j;
-        if (ix > C.W - 1) ix = C.W - 1;
-        px[3 * j] = row[ix * 3]; px[3 * j + 1] = row[ix * 3 + 1]; px[3 * j + 2] = row[ix * 3 + 2];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      // static indices only (a runtime channel offset would push px[] to scratch): RGB or BGR by a uniform select
-      const int c0v = px[3 * j], g = px[3 * j + 1], c2v = px[3 * j + 2];
-      const int r = bgr ? c2v : c0v, b = bgr ? c0v : c2v;
-      yv[vy][j] = (FIXC(0.29900) * r + FIXC(0.58700) * g + FIXC(0.11400) * b + 32768) >> 16;
-      cbs[j >> 1] += (-FIXC(0.16874) * r - FIXC(0.33126) * g + FIXC(0.50000) * b + (128 << 16) + 32767) >> 16;
-      crs[j >> 1] += (FIXC(0.50000) * r - FIXC(0.41869) * g - FIXC(0.08131) * b + (128 << 16) + 32767) >> 16;
-    }
+    rowp[vy] = p + (size_t)iy * row_pitch;
   }
+  if (interior) {          // every load of the lane in flight before the first use (the kernel runs at the HBM rate)
+#pragma unroll
+    for (int vy = 0; vy < V0; vy++) load_px8(rowp[vy], x0, C.W, true, w[vy]);
+  } else {
+#pragma unroll
+    for (int vy = 0; vy < V0; vy++) load_px8(rowp[vy], x0, C.W, false, w[vy]);
+  }
+#pragma unroll
+  for (int vy = 0; vy < V0; vy++) yv[vy] = ycc_row8(w[vy], k, cbs, crs);
   const MjhComp &c0 = C.c[0];
   if (x0 < c0.pw) {
 #pragma unroll
     for (int vy = 0; vy < V0; vy++) {
       const int r = gy * V0 + vy;
-      const int svy = below ? V0 - 1 : vy;
-      if (r < c0.ph) {
-        uint2 o;
-        o.x = (unsigned)yv[svy][0] | ((unsigned)yv[svy][1] << 8) | ((unsigned)yv[svy][2] << 16) | ((unsigned)yv[svy][3] << 24);
-        o.y = (unsigned)yv[svy][4] | ((unsigned)yv[svy][5] << 8) | ((unsigned)yv[svy][6] << 16) | ((unsigned)yv[svy][7] << 24);
-        *reinterpret_cast<uint2 *>(pl + c0.plane_off + (size_t)r * c0.pw + x0) = o;
-      }
+      if (r < c0.ph) *reinterpret_cast<uint2 *>(pl + c0.plane_off + (size_t)r * c0.pw + x0) = below ? yv[V0 - 1] : yv[vy];
     }
   }
   const MjhComp &c1 = C.c[1];
   const MjhComp &c2 = C.c[2];
   if (gy < c1.ph && g4 * 4 < c1.pw) {
-    unsigned ocb = 0, ocr = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      int cb, cr;
-      if (V0 == 2) { const int bias = 1 + (j & 1); cb = (cbs[j] + bias) >> 2; cr = (crs[j] + bias) >> 2; }   // h2v2, bias 1,2,1,2 (4*g4 is even)
-      else { const int bias = j & 1; cb = (cbs[j] + bias) >> 1; cr = (crs[j] + bias) >> 1; }                 // h2v1, bias 0,1,0,1
-      ocb |= (unsigned)cb << (8 * j);
-      ocr |= (unsigned)cr << (8 * j);
-    }
-    *reinterpret_cast<unsigned *>(pl + c1.plane_off + (size_t)gy * c1.pw + g4 * 4) = ocb;
-    *reinterpret_cast<unsigned *>(pl + c2.plane_off + (size_t)gy * c2.pw + g4 * 4) = ocr;
+    *reinterpret_cast<unsigned *>(pl + c1.plane_off + (size_t)gy * c1.pw + g4 * 4) = chroma4<V0>(cbs);
+    *reinterpret_cast<unsigned *>(pl + c2.plane_off + (size_t)gy * c2.pw + g4 * 4) = chroma4<V0>(crs);
   }
 }
 

@@ -467,3 +467,43 @@ def test_skiplow_walks_of_the_scan_search_give_the_same_file(quality, sample):
             got = enc.encode_host(frames)
             assert [bytes(g) for g in got] == want, (kw, rnd)
         enc.close()
+
+
+def _front_image(w, h, seed, kind):
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    img = O.synthetic_frame(max(w, 8), max(h, 8), seed)[:h, :w].copy()
+    for _ in range(6):       # saturated patches: the deringing walk, also across block and strip borders
+        y, x = int(rng.integers(0, h)), int(rng.integers(0, w))
+        img[y:y + int(rng.integers(1, 20)), x:x + int(rng.integers(1, 40))] = 255
+    return img
+
+
+@pytest.mark.parametrize("w,h,kw", [
+    (8, 8, dict(baseline=True)), (16, 16, dict(baseline=True)), (24, 9, dict()), (512, 33, dict(baseline=True)),
+    (520, 40, dict(baseline=True, quality=90)),              # 32.5 MCUs: an odd number of luma block columns
+    (1024, 16, dict(baseline=True)), (1032, 24, dict(fastcrush=True, sample=(2, 1))), (1040, 57, dict(baseline=True, restart=1)),
+    (2056, 17, dict(baseline=True, notrellis=True)), (2304, 72, dict(quality=60)), (1048, 136, dict(baseline=True, quality=40, trellis_loops=2)),
+    (640, 200, dict(revert=True)), (1104, 50, dict(arithmetic=True, baseline=True, sample=(2, 1))), (776, 95, dict(baseline=True, trellis_q_opt=True)),
+])
+def test_vector_colour_kernel_at_its_edges(w, h, kw):
+    """k_color_vec (packed RGB / BGR rows of a multiple of 8 bytes, 2:1 horizontal chroma): widths of one to a few hundred 8-pixel
+    runs, heights around the MCU rows, saturated patches and noise, RGB and BGR byte order -- bytes against the oracle, and stage by
+    stage (plane tap included).  (Round 5 also built these sizes for a one-kernel front end, pixel rows -> coefficients through an
+    LDS tile; it tied with the two kernels on the metric and lost on 1080p frames -- profiles/r05q_front_end_fusion_ab.md -- and
+    is not in the tree.)"""
+    for kind in ("photo", "noise"):
+        img = _front_image(w, h, 100 + w + h, kind)
+        want = O.encode(O.make_params(w, h, **kw), img)
+        enc = M.Encoder(M.make_params(w, h, **kw), max_batch=3)
+        got = enc.encode_host(np.stack([img, img[::-1].copy(), img]))
+        enc.close()
+        assert got[0] == want and got[2] == want, (w, h, kw, kind)
+        assert got[1] == O.encode(O.make_params(w, h, **kw), img[::-1].copy()), (w, h, kw, kind)
+        p = M.make_params(w, h, **kw)                     # BGR rows of the same picture
+        p.rgb_offset[0], p.rgb_offset[1], p.rgb_offset[2] = 2, 1, 0
+        enc = M.Encoder(p, max_batch=1)
+        assert enc.encode_host(np.ascontiguousarray(img[:, :, ::-1])[None])[0] == want, (w, h, kw, kind, "bgr")
+        enc.close()
+    assert check_case(img, kw, verbose=False), (w, h, kw)

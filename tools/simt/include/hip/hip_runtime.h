@@ -160,6 +160,20 @@ static inline void __builtin_amdgcn_wave_barrier(SIMT_HERE) { (void)simt::exchan
 // fences order one lane's LDS / memory traffic for the rest of its wave or workgroup: a rendezvous of the wave here
 #define __builtin_amdgcn_fence(order, scope) ((void)simt::exchange(0, "fence", __FILE__, __LINE__))
 static inline void __builtin_amdgcn_s_sleep(int) { simt::spin(); }
+// v_perm_b32: byte i of the result = byte sel[i] of the 8 bytes { b (0-3), a (4-7) }; 0x0c = 0x00, >= 0x0d = 0xff (8-11: sign bytes, unused here)
+static inline unsigned __builtin_amdgcn_perm(unsigned a, unsigned b, unsigned sel) {
+  const unsigned long long both = ((unsigned long long)a << 32) | b;
+  unsigned r = 0;
+  for (int i = 0; i < 4; i++) {
+    const unsigned s = (sel >> (8 * i)) & 0xFFu;
+    unsigned v;
+    if (s < 8) v = (unsigned)(both >> (8 * s)) & 0xFFu;
+    else if (s < 12) v = ((both >> (16 * (s - 8) + 15)) & 1ull) ? 0xFFu : 0u;
+    else v = s == 12 ? 0u : 0xFFu;
+    r |= v << (8 * i);
+  }
+  return r;
+}
 unsigned long long wall_clock64();            // the 100 MHz constant clock
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
 #define __HIP_MEMORY_SCOPE_AGENT 3
