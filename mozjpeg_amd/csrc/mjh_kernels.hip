@@ -568,15 +568,29 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
     lambda_out[(size_t)img * C.total_real_blocks + cc.blk_off + blk] = lambda;
     lambda_blk = lambda;
   }
-  const float *rcp = Q->rcp8q[cc.qtbl];
   int16_t *uq = coef_uq + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
   int16_t *qo = coef_q + (size_t)img * C.coefs_per_image + cc.coef_off + blk;
   const bool clampq = C.deringing != 0;
   int run = 0, nzc = 0;   // nzc: non-zero quantized AC coefficients = the AC trellis' queue length (its tile-sort key)
+  // The quantizer's constants are wave-uniform (scalar loads).  Fetched where they are used -- inside the per-position branches --
+  // every position paid two scalar-memory round trips (s_waitcnt lgkmcnt(0) on 8q, then on the divider pair) that two waves per
+  // SIMD cannot hide; they are fetched for QCH positions at a time, unconditionally: one round trip per QCH positions.
+  constexpr int QCH = 8;
+  int dq_c[QCH], sdiv_c[QCH];
+  unsigned mdiv_c[QCH];
+  float rcp_c[QCH];
 #pragma unroll
   for (int k = 0; k < 64; k++) {
+    if ((k % QCH) == 0) {
+#pragma unroll
+      for (int j = 0; j < QCH; j++) {
+        dq_c[j] = Q->dq8[cc.qtbl][k + j];
+        if (FD) { sdiv_c[j] = Q->sdiv[cc.qtbl][k + j]; mdiv_c[j] = Q->mdiv[cc.qtbl][k + j]; }
+        else rcp_c[j] = Q->rcp8q[cc.qtbl][k + j];
+      }
+    }
     const int x = d[kZZ.v[k]];
-    const int dq = Q->dq8[cc.qtbl][k];
+    const int dq = dq_c[k % QCH];
     const int ax = x < 0 ? -x : x;
     if (FD && STATS && k > 0) {
       // statistics of the conventionally quantized block only (the trellis recomputes the values): magnitude category of
@@ -584,7 +598,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
       uq[(size_t)k * cc.kstride] = (int16_t)x;
       if (valid) {
         if (ax + (dq >> 1) >= dq) {
-          int qa = udiv_mh(ax + (dq >> 1), Q->sdiv[cc.qtbl][k], Q->mdiv[cc.qtbl][k]);
+          int qa = udiv_mh(ax + (dq >> 1), sdiv_c[k % QCH], mdiv_c[k % QCH]);
           if (clampq) qa = min(qa, 1023);
           nzc++;
           if (run > 15) { atomicAdd(&hh[0xF0 * NCOPY], (unsigned)(run >> 4)); run &= 15; }
@@ -594,7 +608,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
       }
       continue;
     }
-    int v = FD ? udiv_mh(ax + (dq >> 1), Q->sdiv[cc.qtbl][k], Q->mdiv[cc.qtbl][k]) : udiv_exact(ax + (dq >> 1), dq, rcp[k]);
+    int v = FD ? udiv_mh(ax + (dq >> 1), sdiv_c[k % QCH], mdiv_c[k % QCH]) : udiv_exact(ax + (dq >> 1), dq, rcp_c[k % QCH]);
     if (x < 0) v = -v;
     if (clampq) v = W12 ? max(-16383, min(16383, v)) : max(-1023, min(1023, v));
     if (!W12) uq[(size_t)k * cc.kstride] = (int16_t)x;   // raw x8 coefficients only feed the (8-bit only) trellis
@@ -2078,19 +2092,33 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
       short xs[64];
 #pragma unroll
       for (int k = 1; k < 64; k++) xs[k] = uq[(size_t)k * cc.kstride];
-      const int *dq8 = Q->dq8[cc.qtbl];
-      const float *rcp = Q->rcp8q[cc.qtbl], *lt = Q->lambda_tbl[cc.qtbl];
+      // (the rows' wave-uniform constants: fetched for eight positions at a time, outside the per-position branch -- one scalar-memory
+      // round trip per eight positions instead of two per position; see dct_quant_body)
+      constexpr int QCH = 8;
+      int dq_c[QCH], sdiv_c[QCH];
+      unsigned mdiv_c[QCH];
+      float lt_c[QCH], rcp_c[QCH];
       float azd = 0.0f;
 #pragma unroll
       for (int k = 1; k < 64; k++) {
+        if (k == 1 || (k % QCH) == 0) {
+#pragma unroll
+          for (int j = 0; j < QCH; j++) {
+            const int kk = (k / QCH) * QCH + j;
+            dq_c[j] = Q->dq8[cc.qtbl][kk];
+            lt_c[j] = Q->lambda_tbl[cc.qtbl][kk];
+            if (FD) { sdiv_c[j] = Q->sdiv[cc.qtbl][kk]; mdiv_c[j] = Q->mdiv[cc.qtbl][kk]; }
+            else rcp_c[j] = Q->rcp8q[cc.qtbl][kk];
+          }
+        }
         const int xsg = xs[k];
         const int x = xsg < 0 ? -xsg : xsg;
-        const int dq = dq8[k];
+        const int dq = dq_c[k % QCH];
         float t = (float)mul24(x, x) * lambda;
-        t = t * lt[k];
+        t = t * lt_c[k % QCH];
         const float azd_cur = t + azd;
         if (x + (dq >> 1) >= dq) {
-          int qval = FD ? udiv_mh(x + (dq >> 1), Q->sdiv[cc.qtbl][k], Q->mdiv[cc.qtbl][k]) : udiv_exact(x + (dq >> 1), dq, rcp[k]);
+          int qval = FD ? udiv_mh(x + (dq >> 1), sdiv_c[k % QCH], mdiv_c[k % QCH]) : udiv_exact(x + (dq >> 1), dq, rcp_c[k % QCH]);
           if (qval >= 1024) qval = 1023;
           qmax = qval > qmax ? qval : qmax;
           // (a block with more than QN records is deferred: what its surplus records overwrite in the last slot is never read)
