@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the A/B switch MJH_PACK_MAIN used below is gone: profiles/r05n_dropin_handover_ab.md)
 # Round 5: after the C5 fixes (k_stats_dc_mcu atomics, FDCT loop only with fused statistics) and the single-image hand-over on the
 # main stream: C5 / metric timings, drop-in A/B (MJH_PACK_MAIN), the whole suite, C5's traffic passes
 cd "$GRAFT_REPO_ROOT" || exit 1

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (kept as the record of the A/B: k_front420 and MJH_FRONT_FUSE are NOT in the tree -- profiles/r05q_front_end_fusion_ab.md)
 # Round 5: the one-kernel front end (k_front420: pixel rows -> coefficients) on the chip: its tests, A/B against the two-kernel
 # front end on the metric / C2 / C3, kernel stats of both
 cd "$GRAFT_REPO_ROOT" || exit 1

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (kept as the record of the A/B: k_front420 and MJH_FRONT_FUSE are NOT in the tree -- profiles/r05q_front_end_fusion_ab.md)
 # Round 5: second A/B of the one-kernel front end after both front ends issue all their pixel loads before the first use
 cd "$GRAFT_REPO_ROOT" || exit 1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
