@@ -1360,18 +1360,16 @@ __device__ __forceinline__ void trellis_q_walk(const uint4 *si_rows, const float
       m = live; e = nlive; first = true;
     }
     const bool any2 = __builtin_amdgcn_ballot_w64(!done && ncd > 1) != 0ull, any4 = __builtin_amdgcn_ballot_w64(!done && ncd > 2) != 0ull;
-    bool scan = !done;
-    while (__builtin_amdgcn_ballot_w64(scan) != 0ull) {
-      if (scan) {
-        bool fin = false;
+    if (!done) {      // (a plain divergent loop, as in k_trellis_ac_v3: lanes whose scan has ended wait masked for the last one)
+      bool fin = false;
+      do {
         if (!any2)
           q_pair_step<1, LDS_ROWS>(si_rows, rate_rows, col, lane, m, e, first, n0, n1, azd_prev, i, x, dq, qval, ncd, lambda, lti, si_f0, f0f, best, bestp, bestk, fin);
         else if (!any4)
           q_pair_step<2, LDS_ROWS>(si_rows, rate_rows, col, lane, m, e, first, n0, n1, azd_prev, i, x, dq, qval, ncd, lambda, lti, si_f0, f0f, best, bestp, bestk, fin);
         else
           q_pair_step<4, LDS_ROWS>(si_rows, rate_rows, col, lane, m, e, first, n0, n1, azd_prev, i, x, dq, qval, ncd, lambda, lti, si_f0, f0f, best, bestp, bestk, fin);
-        if (fin) scan = false;
-      }
+      } while (!fin);
     }
     if (!done) {
       if (bestp >= 0) {
@@ -2189,17 +2187,18 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     // for a handful of lanes -- tools/model_sched.py: 0.74 of the issued instructions this way.)  The same operations per lane
     // in the same order: the files do not change.  Every working lane is at record `qi` of its queue in the same round.
     while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
-      bool scan = act;
-      while (__builtin_amdgcn_ballot_w64(scan) != 0ull) {
-        if (scan) {
-          float gap_old;
+      if (act) {
+        // (a plain divergent loop: lanes whose scan has ended wait masked until the last one is done.  Written as
+        // `while (ballot(scan)) if (scan) {..}` until late in round 5, the loop carried its state through a bypass block: eight
+        // register copies plus a flag materialised and re-tested per pair step, 10 of its ~75 instructions)
+        float gap_old;
+        do {
           if (!wide) v3_pair<QN, 2>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk, gap_old);
           else v3_pair<QN, 4>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk, gap_old);
           e -= 2;
           // cost >= rhs >= gap in float arithmetic, and the gap only grows towards older entries: once it exceeds the best cost
           // no older predecessor can win or tie
-          if (e <= 0 || gap_old > best) scan = false;
-        }
+        } while (e > 0 && !(gap_old > best));
       }
       lookup();
       const bool wide_n = next_wide();
