@@ -351,6 +351,7 @@ struct mjh_encoder {
   std::vector<SeqScan> seq_scans;
   int dht_slots[4] = { 0, 0, 0, 0 }, dht_ids[4] = { 0, 0, 0, 0 }, ndht = 0;
   bool debug_taps = false;
+  bool fdct_div_zero = false;   // a quantization step of 8192 / 16384 / 24576 with 8-bit samples: the reference's FDCT manager divides by zero (pixel / plane input is refused, coefficient input is fine)
   // profiling: 0 off, 1 every kernel, 2 only the dominant kernel (prof_focus).  Events accumulate over the
   // encode calls since the last read (prof_calls), every call records the same sequence of marks.
   int profiling = 0;
@@ -933,6 +934,13 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       hq.dq8[t][k] = 8 * q;
       hq.rcp8q[t][k] = 1.0f / (float)(8 * q);
       hq.lambda_tbl[t][k] = (float)(1.0 / (double)(q * q));   // jcdctmgr.c:1017-1021
+      {   // the conventional quantizer's divisor: a UINT16 argument in the reference's 8-bit build (see MjhQuant)
+        const int dc = C.precision == 12 ? 8 * q : (int)((8u * (unsigned)q) & 0xFFFFu);
+        if (dc == 0)      // q = 8192, 16384, 24576: compute_reciprocal(0) divides by zero -- the reference dies
+          for (int i = 0; i < C.ncomp; i++) if (p->quant_tbl_no[i] == t) e->fdct_div_zero = true;
+        hq.dqc8[t][k] = dc ? dc : 8;
+        hq.rcpc8q[t][k] = 1.0f / (float)(dc ? dc : 8);
+      }
       if (q <= 255) {
         const unsigned d = 8u * (unsigned)q;
         int b = 0;
@@ -1348,6 +1356,8 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     pr.next = (size_t)e->prof_calls * e->prof_per_call;
   }
   HIPCHK(hipMemcpyAsync(e->d_tabs, e->d_tabs_init, (size_t)n * spi * sizeof(MjhHuffTable), hipMemcpyDeviceToDevice, s));
+  if (!coef_src && e->fdct_div_zero)
+    return fail(MJH_EINVAL, "a quantization step of 8192, 16384 or 24576 with 8-bit samples: the reference's FDCT manager divides by zero there (compute_reciprocal, jcdctmgr.c:182-203 with `quantval << 3` as its UINT16 argument)");
   if (coef_src) {    // jpeg_write_coefficients: the caller's quantized blocks go straight to the entropy-coding passes
     pr.mark("import_coefs");
     mjh_launch_import_coefs(C, *coef_src, e->d_q, e->d_meta, n, s);

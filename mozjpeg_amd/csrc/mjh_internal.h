@@ -93,6 +93,13 @@ struct MjhQuant {
   uint32_t mdiv[4][64];
   int sdiv[4][64];
   int fastdiv[4];
+  // The divisor of the CONVENTIONAL quantizer (forward_DCT).  For 8-bit samples the reference hands `quantval << 3` to
+  // compute_reciprocal(UINT16 divisor, ..) (jcdctmgr.c:182, :278-282): a step of 8192 or more wraps -- q = 8450 (quality 1) divides
+  // by 67600 mod 65536 = 2064 -- and that is what its files contain; 12-bit samples keep the full value (:284).  The trellis reads
+  // quantval itself (8 * q as an int, :1009-1015): dq8 / rcp8q above stay unwrapped.  (At the end: the offsets of the fields
+  // above, and with them the machine code of the kernels that do not quantize conventionally, stay what they were.)
+  int dqc8[4][64];
+  float rcpc8q[4][64];
 };
 
 // per-image bookkeeping written by the encode kernels

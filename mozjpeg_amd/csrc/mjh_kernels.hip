@@ -584,9 +584,9 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
     if ((k % QCH) == 0) {
 #pragma unroll
       for (int j = 0; j < QCH; j++) {
-        dq_c[j] = Q->dq8[cc.qtbl][k + j];
-        if (FD) { sdiv_c[j] = Q->sdiv[cc.qtbl][k + j]; mdiv_c[j] = Q->mdiv[cc.qtbl][k + j]; }
-        else rcp_c[j] = Q->rcp8q[cc.qtbl][k + j];
+        // (FD: every step <= 255, nothing wraps; otherwise the conventional quantizer's own divisor -- MjhQuant.dqc8)
+        if (FD) { dq_c[j] = Q->dq8[cc.qtbl][k + j]; sdiv_c[j] = Q->sdiv[cc.qtbl][k + j]; mdiv_c[j] = Q->mdiv[cc.qtbl][k + j]; }
+        else { dq_c[j] = Q->dqc8[cc.qtbl][k + j]; rcp_c[j] = Q->rcpc8q[cc.qtbl][k + j]; }
       }
     }
     const int x = d[kZZ.v[k]];
@@ -1667,6 +1667,8 @@ k_qopt_update(long long *__restrict__ sums, MjhQuant *__restrict__ Q)
   Qi->q[t][k] = (uint16_t)q;
   Qi->dq8[t][k] = 8 * q;
   Qi->rcp8q[t][k] = 1.0f / (float)(8 * q);
+  Qi->dqc8[t][k] = 8 * q;                       // (q <= 254: nothing wraps)
+  Qi->rcpc8q[t][k] = 1.0f / (float)(8 * q);
   Qi->lambda_tbl[t][k] = (float)(1.0 / (double)(q * q));
   {   // (q <= 254: the multiply-high constants exist)
     const unsigned dd = 8u * (unsigned)q;

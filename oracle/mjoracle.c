@@ -593,7 +593,11 @@ static void forward16(const mjo_params *p, uint16_t *const planes[MJO_MAX_COMPS]
         if (p->overshoot_deringing) mjo_deringing(ws, qt[0]);
         fdct_islow_p(ws, P == 12 ? 1 : 2);
         for (i = 0; i < 64; i++) {
-          int d = 8 * qt[i], x = ws[i], v;
+          /* 8-bit build: the divisor reaches compute_reciprocal as a UINT16 (jcdctmgr.c:182, :278-282), so a step of 8192 or more
+           * wraps -- q = 8450 (quality 1) divides by 67600 mod 65536 = 2064; the 12-bit build keeps the value (:284).  (A wrapped
+           * divisor of 0 makes the reference divide by zero: mjo_encode refuses such tables.)  The reciprocal form equals this
+           * rounding division for every divisor 8 .. 65528 and |x| <= 32767 (checked exhaustively). */
+          int d = P == 12 ? 8 * qt[i] : (int)((8u * (unsigned)qt[i]) & 0xFFFFu), x = ws[i], v;
           uq[i] = (int16_t)x;   /* (12-bit: may wrap; only the 8-bit trellis reads it) */
           v = ((x < 0 ? -x : x) + d / 2) / d;
           if (x < 0) v = -v;
@@ -2143,6 +2147,11 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
       build_dummies(p, &e.g[ci], ci, e.q[ci]);
     }
   } else {
+    if (prec_of(p) != 12)     /* compute_reciprocal(0): the reference divides by zero (see forward16) */
+      for (ci = 0; ci < p->num_components; ci++) {
+        int k;
+        for (k = 0; k < 64; k++) if (((8u * (unsigned)p->qtbl[p->quant_tbl_no[ci]][k]) & 0xFFFFu) == 0u) return 0;
+      }
     if (ps->src) import_planes16(p, ps, planes);
     else color_downsample16(p, ps->pixels, ps->row_stride, planes);
     forward16(p, planes, e.uq, e.q);

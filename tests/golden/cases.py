@@ -48,6 +48,12 @@ CASES = [
     ("q85_420_progressive", dict(quality=85), True),
     ("revert_progressive", dict(revert=True, progressive=True), True),
     ("q5_16bit_tables", dict(quality=5, fastcrush=True), True),
+    # quality 1: ten steps of table 0 are 8192 or more, and the reference's 8-bit FDCT manager hands `quantval << 3` to
+    # compute_reciprocal as a UINT16 (jcdctmgr.c:182, :278-282) -- q = 8450 divides by 67600 mod 65536 = 2064 there, while the DQT
+    # marker and the trellis see 8450.  Part of the reference's files (the noise fixture has coefficients that show it).
+    ("q1_wrapped_divisors", dict(quality=1), True),
+    ("q1_wrapped_divisors_gray_fastcrush_notrellis", dict(quality=1, gray=True, fastcrush=True, notrellis=True), True),
+    ("q1_wrapped_divisors_revert_422", dict(quality=1, revert=True, progressive=True, sample=(2, 1)), True),
     # restart intervals inside progressive scans (emit_restart jcphuff.c:438; per-scan interval T10, DRI per scan)
     ("prog_search_restart1", dict(restart=1), True),
     ("fastcrush_restart2", dict(fastcrush=True, restart=2), True),

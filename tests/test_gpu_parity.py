@@ -507,3 +507,26 @@ def test_vector_colour_kernel_at_its_edges(w, h, kw):
         assert enc.encode_host(np.ascontiguousarray(img[:, :, ::-1])[None])[0] == want, (w, h, kw, kind, "bgr")
         enc.close()
     assert check_case(img, kw, verbose=False), (w, h, kw)
+
+
+def test_quantization_steps_of_8192_and_more_follow_the_reference():
+    """The reference's 8-bit FDCT manager takes `quantval << 3` as a UINT16 (compute_reciprocal, jcdctmgr.c:182, :278-282): steps of
+    8192 and more divide by (8 q) mod 65536 -- quality 1 has ten such steps in table 0 (goldens `q1_wrapped_divisors*`) -- and a step
+    of exactly 8192 / 16384 / 24576 makes it divide by zero: refused for pixel input, with the reason"""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    for q in (8191, 8193, 9000, 20000, 32767):              # around and beyond the wrap: bytes equal the oracle's (= the reference's rule)
+        po, pg = O.make_params(64, 48, quality=1, notrellis=True), M.make_params(64, 48, quality=1, notrellis=True)
+        for t in range(2):
+            for k in (40, 50, 63):
+                po.qtbl[t][k] = q
+                pg.quantval[t][k] = q
+        enc = M.Encoder(pg)
+        assert enc.encode_host(img)[0] == O.encode(po, img), q
+        enc.close()
+    pg = M.make_params(64, 48, quality=1, notrellis=True)
+    pg.quantval[0][63] = 8192
+    enc = M.Encoder(pg)
+    with pytest.raises(Exception, match="divides by zero"):
+        enc.encode_host(img)
+    enc.close()

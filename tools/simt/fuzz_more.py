@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """More random configurations than tests/test_gpu_fuzz.py carries, through the kernel SOURCES on the emulator against the CPU
 oracle (development aid: correctness only).  The generator is test_gpu_fuzz.py's with the seed as an argument, plus
-arithmetic coding and the two opt-in variants (tile-sorted planes: every batch, a random tile size; queue records from the
-FDCT kernel) on a share of the cases.
-usage: python tools/simt/fuzz_more.py SEED COUNT [--sorted-share 0.5]        prints one line per failure and a summary"""
+arithmetic coding (conditioning values, trellis_q_opt with several loops), round 5's sampling-factor sets and scan scripts,
+and, on a share of the cases, the encoder's remaining plan knobs (first-tier capacity and passes of the AC trellis, dense-copy
+capacity, where the DC chains run, the speculative DC rows) -- every plan has to give the same bytes.
+usage: python tools/simt/fuzz_more.py SEED COUNT [--knob-share 0.5] [--ref]        prints one line per failure and a summary
+(--ref: also the oracle against the reference binary oracle/_ref/refenc on every case)"""
 import os
 import sys
 import time
@@ -71,16 +73,37 @@ def draw(rng):
                 kw["sample"] = (2, 2)
     if rng.random() < 0.15:
         kw["noovershoot"] = True
+    # round 5's configuration space (drawn last: the cases of a seed keep everything above)
+    r = rng.random()
+    if r < 0.12 and not kw.get("gray") and not kw.get("smooth"):
+        kw["sample"] = FACTOR_SETS[int(rng.integers(0, len(FACTOR_SETS)))]
+    elif r < 0.2 and not kw.get("gray") and not kw.get("progressive") and (kw.get("baseline") or kw.get("revert")):
+        groups = SEQ_SCRIPTS[int(rng.integers(0, len(SEQ_SCRIPTS)))]
+        kw["scans"] = [(g, 0, 63, 0, 0) for g in groups]
+        kw.pop("dc_scan_opt", None)
+    if kw.get("arithmetic"):
+        if rng.random() < 0.3:
+            lo = int(rng.integers(0, 4))
+            kw["arith_cond"] = ((lo, lo + int(rng.integers(0, 8)), int(rng.integers(1, 64))), (0, int(rng.integers(0, 3)), int(rng.integers(1, 64))))
+        if rng.random() < 0.3 and not kw.get("revert") and not kw.get("notrellis"):
+            kw["trellis_q_opt"] = True
+            kw["trellis_loops"] = int(rng.integers(1, 5))
     return w, h, kw, int(rng.integers(0, 3))
+
+
+FACTOR_SETS = [((2, 2), (2, 1), (1, 1)), ((2, 1), (1, 1), (1, 2)), ((1, 2), (2, 2), (1, 1)), ((3, 1), (1, 1), (1, 1)), ((2, 1), (2, 1), (2, 1)),
+               ((1, 1), (2, 2), (2, 2)), ((2, 2), (1, 2), (2, 1)), ((1, 3), (1, 1), (1, 3)), ((4, 1), (2, 1), (1, 1)), ((2, 2), (2, 2), (1, 1))]
+SEQ_SCRIPTS = [[(0,), (1, 2)], [(0,), (1,), (2,)], [(0, 1), (2,)], [(0, 2), (1,)]]
 
 
 def main():
     seed, count = int(sys.argv[1]), int(sys.argv[2])
-    share = float(sys.argv[sys.argv.index("--sorted-share") + 1]) if "--sorted-share" in sys.argv else 0.5
+    share = float(sys.argv[sys.argv.index("--knob-share") + 1]) if "--knob-share" in sys.argv else 0.5
     rng = np.random.default_rng(seed)
     bad = refused = 0
     t0 = time.time()
     verbose = "--verbose" in sys.argv
+    with_ref = "--ref" in sys.argv and O.have_ref()
     first = int(sys.argv[sys.argv.index("--from") + 1]) if "--from" in sys.argv else 0
     for i in range(count):
         w, h, kw, kind = draw(rng)
@@ -98,20 +121,17 @@ def main():
             kw = dict(kw, grayin=True)
             img = img[:, :, 1].copy()
         env = {}
-        if r2.random() < share:
-            env = {"MJH_SORTED_UQ": "2", "MJH_SORTED_TILE": str(int(r2.choice([128, 256, 512])))}
-            if r2.random() < 0.3:
-                env["MJH_DENSE_CAP"] = str(int(r2.integers(0, 30)))
-        elif r2.random() < 0.6:     # the other opt-in variant: queue records from the FDCT kernel (where the configuration is covered; else the default kernels)
-            env = {"MJH_TRELLIS_REC": "1"}
-            if r2.random() < 0.6:
-                env["MJH_SMALL_BATCH"] = "0"
+        if r2.random() < share:       # another plan of the same encode: same bytes expected
+            if r2.random() < 0.5:
+                env["MJH_TRELLIS_VARIANT"] = str(int(r2.choice([0, 2, 3, 4])))
+            if r2.random() < 0.4:
                 env["MJH_TRELLIS_V3"] = str(int(r2.choice([1, 2, 4, 8])))
             if r2.random() < 0.3:
                 env["MJH_DENSE_CAP"] = str(int(r2.integers(0, 30)))
-        # MJH_PP_SKIPLOW (mjh_prog_sl.hip) is read at every launch: it stays set for the whole case (own generator: the cases of
-        # earlier seeds stay what they were)
-        skiplow = np.random.default_rng(seed * 7919 + i).random() < 0.4
+            if r2.random() < 0.3:
+                env["MJH_DC_LATE"] = str(int(r2.integers(0, 3)))
+            if r2.random() < 0.3:
+                env["MJH_DC_SPEC"] = str(int(r2.integers(0, 2)))
         if i < first:
             continue
         if verbose:
@@ -121,6 +141,15 @@ def main():
         except Exception as exc:      # the oracle refuses what the reference refuses
             refused += 1
             continue
+        if with_ref:                  # (build container only: the oracle itself against the reference binary on the same case)
+            try:
+                rkw = {k: v for k, v in kw.items() if k != "grayin"}
+                if O.ref_encode(img, **rkw)[0] != want:
+                    bad += 1
+                    print("ORACLE != REFERENCE:", seed, i, w, h, kw, flush=True)
+                    continue
+            except Exception as exc:
+                print("reference run failed:", seed, i, kw, repr(exc)[:200], flush=True)
         try:
             os.environ.update(env)
             enc = M.Encoder(M.make_params(w, h, **kw), max_batch=3)
@@ -132,16 +161,11 @@ def main():
             for k in env:
                 os.environ.pop(k, None)
         try:
-            if skiplow:
-                os.environ["MJH_PP_SKIPLOW"] = "1"
-                env = dict(env, MJH_PP_SKIPLOW="1")
             got = enc.encode_host(np.stack([img, img[::-1].copy(), img]))
             ok = got[0] == want and got[2] == want
         except Exception as exc:
             ok = False
             print("EXCEPTION", repr(exc)[:200], flush=True)
-        finally:
-            os.environ.pop("MJH_PP_SKIPLOW", None)
         enc.close()
         if not ok:
             bad += 1
