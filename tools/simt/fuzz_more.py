@@ -88,6 +88,12 @@ def draw(rng):
         if rng.random() < 0.3 and not kw.get("revert") and not kw.get("notrellis"):
             kw["trellis_q_opt"] = True
             kw["trellis_loops"] = int(rng.integers(1, 5))
+    # 12-bit samples (drawn last of all): no trellis in the reference (jccoefct.c:132-138), whatever else was drawn stays
+    if rng.random() < 0.08 and not kw.get("smooth"):
+        kw["precision"] = 12
+        kw["notrellis"] = True
+        for k in ("notrellis_dc", "trellis_loops", "use_scans_in_trellis", "trellis_freq_split", "trellis_eob_opt", "trellis_q_opt", "dc_ver_weight"):
+            kw.pop(k, None)
     return w, h, kw, int(rng.integers(0, 3))
 
 
@@ -117,6 +123,8 @@ def main():
             for _ in range(4):
                 y, x = int(r2.integers(0, h)), int(r2.integers(0, w))
                 img[y:y + 9, x:x + 9] = r2.integers(0, 64, 3, dtype=np.uint8)
+        if kw.get("precision") == 12:      # the same picture with 12-bit samples (noise: the full range)
+            img = r2.integers(0, 4096, img.shape).astype(np.uint16) if kind == 1 else (img.astype(np.uint16) << 4) | (img >> 4)
         if kw.get("gray") and r2.random() < 0.5:
             kw = dict(kw, grayin=True)
             img = img[:, :, 1].copy()
