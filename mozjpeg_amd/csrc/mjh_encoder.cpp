@@ -809,6 +809,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   mjh_encoder *e = new mjh_encoder();
   e->p = *p;
   if (p->data_precision == 12) e->p.optimize_coding = 1;   // standard tables are 8-bit only (jcparam.c:452-453, jcmaster.c:1102-1105)
+  p = &e->p;     // (everything below reads the parameters as the encoder runs them: a 12-bit sequential scan script sends its scans' tables with every scan)
   e->device = device;
   e->max_batch = max_batch;
   build_const(p, &e->C);

@@ -192,6 +192,10 @@ CASES12 = [
     ("p12_fastcrush", dict(precision=12, notrellis=True, fastcrush=True), True),
     ("p12_revert_q90", dict(precision=12, revert=True, quality=90), True),
     ("p12_base_gray", dict(precision=12, baseline=True, notrellis=True, gray=True), True),
+    # 12-bit sequential scan scripts: optimal tables are forced (the standard ones are 8-bit), so EVERY scan carries its tables
+    # (tools/simt/fuzz_more.py found the encoder sending them only once)
+    ("p12_script_seq_ycr_cb", dict(precision=12, notrellis=True, revert=True, scans=[((0, 2), 0, 63, 0, 0), ((1,), 0, 63, 0, 0)]), True),
+    ("p12_script_seq_y_cb_cr_restart1", dict(precision=12, notrellis=True, baseline=True, restart=1, scans=[((0,), 0, 63, 0, 0), ((1,), 0, 63, 0, 0), ((2,), 0, 63, 0, 0)]), True),
     # 12-bit samples through the arithmetic coder (magnitude categories up to 15 bits)
     ("p12_arith_base_q90_444", dict(precision=12, arithmetic=True, baseline=True, notrellis=True, quality=90, sample=(1, 1)), True),
     ("p12_arith_progressive", dict(precision=12, arithmetic=True, notrellis=True), True),

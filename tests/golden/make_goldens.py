@@ -26,6 +26,11 @@ def main():
                 if cname in names:
                     data, _info = O.ref_encode(img, **kw)
                     out["%s/%s" % (iname, cname)] = {"md5": O.md5(data), "bytes": len(data)}
+        for iname, img in images12().items():
+            for cname, kw, _ in CASES12:
+                if cname in names:
+                    data, _info = O.ref_encode(img, **kw)
+                    out["%s/%s" % (iname, cname)] = {"md5": O.md5(data), "bytes": len(data)}
         with open(path, "w") as f:
             json.dump(out, f, indent=1, sort_keys=True)
         print("goldens.json now holds %d entries" % len(out))
