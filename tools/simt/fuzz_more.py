@@ -88,6 +88,10 @@ def draw(rng):
         if rng.random() < 0.3 and not kw.get("revert") and not kw.get("notrellis"):
             kw["trellis_q_opt"] = True
             kw["trellis_loops"] = int(rng.integers(1, 5))
+    # a progressive scan script of the application's own (any script validate_script, jcmaster.c:270-432, accepts)
+    if "scans" not in kw and not kw.get("baseline") and not kw.get("revert") and rng.random() < 0.15:
+        kw["scans"] = progressive_script(rng, 1 if kw.get("gray") else 3)
+        kw.pop("dc_scan_opt", None)
     # 12-bit samples (drawn last of all): no trellis in the reference (jccoefct.c:132-138), whatever else was drawn stays
     if rng.random() < 0.08 and not kw.get("smooth"):
         kw["precision"] = 12
@@ -95,6 +99,40 @@ def draw(rng):
         for k in ("notrellis_dc", "trellis_loops", "use_scans_in_trellis", "trellis_freq_split", "trellis_eob_opt", "trellis_q_opt", "dc_ver_weight"):
             kw.pop(k, None)
     return w, h, kw, int(rng.integers(0, 3))
+
+
+def progressive_script(rng, ncomp):
+    """DC first (interleaved or per component, point transform 0-2), every component's AC positions in 1-3 bands with their own
+    point transforms, then the refinement scans bit by bit -- in a random order that keeps every refinement behind its predecessor"""
+    first, later = [], []      # later: chains of refinement scans, each chain in order
+    al = int(rng.integers(0, 3))
+    if ncomp == 1 or rng.random() < 0.6:
+        first.append((tuple(range(ncomp)), 0, 0, 0, al))
+        later.append([(tuple(range(ncomp)), 0, 0, a + 1, a) for a in range(al - 1, -1, -1)])
+    else:
+        for c in range(ncomp):
+            a0 = int(rng.integers(0, 3))
+            first.append(((c,), 0, 0, 0, a0))
+            later.append([((c,), 0, 0, a + 1, a) for a in range(a0 - 1, -1, -1)])
+    ac_first = []
+    for c in range(ncomp):
+        cuts = sorted(set(int(v) for v in rng.integers(1, 63, int(rng.integers(0, 3)))))
+        lo = 1
+        for hi in cuts + [63]:
+            if hi < lo:
+                continue
+            a0 = int(rng.integers(0, 3))
+            ac_first.append(((c,), lo, hi, 0, a0))
+            later.append([((c,), lo, hi, a + 1, a) for a in range(a0 - 1, -1, -1)])
+            lo = hi + 1
+    order = [int(v) for v in rng.permutation(len(ac_first))]
+    scans = first + [ac_first[j] for j in order]
+    chains = [ch for ch in later if ch]
+    while chains:
+        j = int(rng.integers(0, len(chains)))
+        scans.append(chains[j].pop(0))
+        chains = [ch for ch in chains if ch]
+    return scans
 
 
 FACTOR_SETS = [((2, 2), (2, 1), (1, 1)), ((2, 1), (1, 1), (1, 2)), ((1, 2), (2, 2), (1, 1)), ((3, 1), (1, 1), (1, 1)), ((2, 1), (2, 1), (2, 1)),
