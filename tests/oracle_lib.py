@@ -95,6 +95,18 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
         p.trellis_quant_dc = 0
     if noovershoot:
         p.overshoot_deringing = 0
+    if quant_table not in (-1, 0, 3):
+        # the other presets of cjpeg -quant-table N: base tables read back from the reference (tests/golden/quant_presets.json,
+        # made by tests/golden/make_quant_presets.py), scaled by jpeg_add_quant_table's rule (jcparam.c:30-68)
+        import json
+        base = json.load(open(os.path.join(ROOT, "tests", "golden", "quant_presets.json")))[str(quant_table)]
+        q = float(min(max(quality, 1), 100))
+        scale = int(5000.0 / q) if q < 50 else int(200.0 - q * 2.0)
+        for t, name in ((0, "luma"), (1, "chroma")):
+            for k in range(64):
+                v = (base[name][k] * scale + 50) // 100
+                v = min(max(v, 1), 32767)
+                p.qtbl[t][k] = min(v, 255) if baseline else v
     if lambda1 is not None:
         p.lambda_log_scale1 = lambda1
     if lambda2 is not None:

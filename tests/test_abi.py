@@ -335,3 +335,26 @@ def test_numa_placement_helpers_parse_and_degrade():
         buf = C.create_string_buffer(256)
         L.mjh_device_placement.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         assert L.mjh_device_placement(0, buf, 256) > 0 and b"no NUMA placement" in buf.value
+
+
+def test_quantization_table_presets_match_the_reference():
+    """mjh_params_set_quality(.., base_idx): the nine tables of `cjpeg -quant-table N` (mjh_quant_presets.h) at several qualities,
+    with and without the baseline clamp, against the base tables read back from the reference's DQT markers
+    (tests/golden/quant_presets.json) scaled by jpeg_add_quant_table's rule -- and the test harness' own tables (oracle_lib) with them"""
+    import json
+    import oracle_lib as O
+    base = json.load(open(os.path.join(ROOT, "tests", "golden", "quant_presets.json")))
+    for idx in range(9):
+        for quality in (1, 3, 10, 25, 50, 75, 90, 95, 100):
+            scale = int(5000.0 / quality) if quality < 50 else int(200.0 - quality * 2.0)
+            for baseline in (False, True):
+                kw = dict(quality=quality, quant_table=idx, baseline=baseline)
+                if not baseline:
+                    kw["fastcrush"] = True
+                pm, po = M.make_params(16, 16, **kw), O.make_params(16, 16, **kw)
+                for t, name in ((0, "luma"), (1, "chroma")):
+                    want = [min(max((b * scale + 50) // 100, 1), 32767) for b in base[str(idx)][name]]
+                    if baseline:
+                        want = [min(v, 255) for v in want]
+                    assert [pm.quantval[t][k] for k in range(64)] == want, (idx, quality, baseline, name)
+                    assert [po.qtbl[t][k] for k in range(64)] == want, (idx, quality, baseline, name, "oracle_lib")

@@ -98,6 +98,12 @@ def draw(rng):
         kw["notrellis"] = True
         for k in ("notrellis_dc", "trellis_loops", "use_scans_in_trellis", "trellis_freq_split", "trellis_eob_opt", "trellis_q_opt", "dc_ver_weight"):
             kw.pop(k, None)
+    # the other base tables of cjpeg -quant-table N (jcparam.c) and the trellis' lambda scales (cjpeg -lambda1 / -lambda2)
+    if rng.random() < 0.2:
+        kw["quant_table"] = int(rng.integers(0, 9))
+    if rng.random() < 0.12 and not kw.get("notrellis") and not kw.get("revert"):
+        kw["lambda1"] = float(rng.choice([-2.0, 0.0, 8.5, 14.75, 20.0]))
+        kw["lambda2"] = float(rng.choice([0.0, 8.0, 16.5, 22.0]))
     return w, h, kw, int(rng.integers(0, 3))
 
 
