@@ -135,7 +135,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 grayin=False, quant_table=-1, lambda1=None, lambda2=None, restart=None,
                 progressive=False, fastcrush=False, precision=8, trellis_loops=1, smooth=0, rgb=False,
                 dc_scan_opt=None, dc_ver_weight=None, use_scans_in_trellis=False, trellis_freq_split=0,
-                trellis_eob_opt=False, trellis_q_opt=False, arithmetic=False, arith_cond=None, scans=None):
+                trellis_eob_opt=False, trellis_q_opt=False, arithmetic=False, arith_cond=None, scans=None, gray_sample=None):
     """Parameters with cjpeg's switch vocabulary (cjpeg.c:371-714).  Without `baseline` or
     `revert` this is cjpeg's default: progressive with scan search (`fastcrush`: fixed 9-scan script)."""
     p = Params()
@@ -147,6 +147,8 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     if per_comp and p.num_components == 3:
         for i in range(3):
             p.h_samp_factor[i], p.v_samp_factor[i] = sample[i]
+    if gray_sample is not None and p.num_components == 1:   # (h, v) of a gray image's one component: cjpeg sets 2x1 for qualities 80..89 (rdswitch.c:566-570)
+        p.h_samp_factor[0], p.v_samp_factor[0] = gray_sample
     _chk(L.mjh_params_set_quality(C.byref(p), quality, 1 if baseline else 0, quant_table))
     if optimize:
         p.optimize_coding = 1

@@ -536,9 +536,12 @@ static void shim_begin(j_compress_ptr cinfo, boolean write_all_tables, int mode,
                                           ((long)cinfo->max_v_samp_factor * DCTSIZE));
   }
   s->row_bytes = (size_t)cinfo->image_width * cinfo->input_components * (cinfo->data_precision == 12 ? 2 : 1);
+  /* arrays requested from this object's memory manager get realised here, as in the reference (jinit_compress_master
+   * jcinit.c:143 / transencode_master_selection jctrans.c:214): an application may have asked for its own before starting --
+   * cjpeg's BMP and bottom-up Targa readers keep the whole picture in one (rdbmp.c:605-609, rdtarga.c) */
+  (*cinfo->mem->realize_virt_arrays) ((j_common_ptr)cinfo);
   if (mode == 2) {
-    /* arrays requested from this object's memory manager get realised here, as in the reference (jctrans.c:214) */
-    (*cinfo->mem->realize_virt_arrays) ((j_common_ptr)cinfo);
+    /* (coefficients in: nothing to stage) */
   } else if (s->raw) {
     int ci, bad = 0;
     for (ci = 0; ci < cinfo->num_components; ci++) {

@@ -351,6 +351,7 @@ struct mjh_encoder {
   std::vector<SeqScan> seq_scans;
   int dht_slots[4] = { 0, 0, 0, 0 }, dht_ids[4] = { 0, 0, 0, 0 }, ndht = 0;
   bool debug_taps = false;
+  int sof_hv0 = 0;              // one component sampled other than 1x1: the SOF's sampling byte (the geometry is 1x1's, see check_supported)
   bool fdct_div_zero = false;   // a quantization step of 8192 / 16384 / 24576 with 8-bit samples: the reference's FDCT manager divides by zero (pixel / plane input is refused, coefficient input is fine)
   // profiling: 0 off, 1 every kernel, 2 only the dominant kernel (prof_focus).  Events accumulate over the
   // encode calls since the last read (prof_calls), every call records the same sequence of marks.
@@ -409,8 +410,16 @@ static int check_supported(const mjh_params *p)
   if (p->num_components == 3 && p->input_components != 3) return fail(MJH_EUNSUPPORTED, "gray input cannot produce 3 components");
   if (p->color_transform != MJH_COLOR_YCC && p->color_transform != MJH_COLOR_NONE) return fail(MJH_EINVAL, "color_transform %d", p->color_transform);
   if (p->color_transform == MJH_COLOR_NONE && p->num_components != 3) return fail(MJH_EUNSUPPORTED, "MJH_COLOR_NONE needs three components");
-  if (p->num_components == 1 && (p->h_samp_factor[0] != 1 || p->v_samp_factor[0] != 1))
-    return fail(MJH_EUNSUPPORTED, "grayscale must be sampled 1x1");
+  if (p->num_components == 1) {
+    // One component: its only scans are non-interleaved (per_scan_setup jcmaster.c:548-575: an MCU is one block, no dummy blocks) and
+    // max_samp = its own factors (initial_setup :210-259), so the factors change nothing but the SOF byte -- cjpeg sets 2x1 on a
+    // gray image for qualities 80..89 (set_quality_ratings rdswitch.c:566-570) -- EXCEPT through the trellis passes: they walk iMCU
+    // rows of V block rows (compress_trellis_pass jccoefct.c:418-441: lastDC and the row above chain over the V rows).
+    const int h = p->h_samp_factor[0], v = p->v_samp_factor[0];
+    if (h < 1 || h > 4 || v < 1 || v > 4) return fail(MJH_EINVAL, "sampling factor %dx%d outside 1..4 (JERR_BAD_SAMPLING)", h, v);
+    if (v != 1 && p->trellis_quant)
+      return fail(MJH_EUNSUPPORTED, "one component with a vertical sampling factor of %d and trellis quantization (the DC trellis' chains would span %d block rows, jccoefct.c:418-441): use V = 1 or switch the trellis off", v, v);
+  }
   if (p->num_components == 3) {
     // any sampling factors the reference takes (initial_setup jcmaster.c:210-259, jinit_downsampler jcsample.c:486-535): 1..4 each,
     // every component's factor divides the largest (no fractional downsampling), at most 10 blocks per MCU
@@ -808,6 +817,10 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   if (device < 0 || device >= ndev) return fail(MJH_EINVAL, "device %d out of range (%d devices)", device, ndev);
   mjh_encoder *e = new mjh_encoder();
   e->p = *p;
+  if (p->num_components == 1 && (p->h_samp_factor[0] != 1 || p->v_samp_factor[0] != 1)) {   // (check_supported: only the SOF byte differs)
+    e->sof_hv0 = (p->h_samp_factor[0] << 4) + p->v_samp_factor[0];
+    e->p.h_samp_factor[0] = e->p.v_samp_factor[0] = 1;
+  }
   if (p->data_precision == 12) e->p.optimize_coding = 1;   // standard tables are 8-bit only (jcparam.c:452-453, jcmaster.c:1102-1105)
   p = &e->p;     // (everything below reads the parameters as the encoder runs them: a 12-bit sequential scan script sends its scans' tables with every scan)
   e->device = device;
@@ -980,6 +993,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     std::vector<uint8_t> pre, sos;
     bool base;
     build_prefix(p, pre, &base, &e->file_hdr_len, e->dqt_off);
+    if (e->sof_hv0) pre[pre.size() - 2] = (uint8_t)e->sof_hv0;     // (the prefix ends with the SOF's one component: id, HV, Tq)
     {
       bool seen[4] = { false, false, false, false };
       for (int ci = 0; ci < p->num_components; ci++) {

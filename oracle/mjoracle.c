@@ -280,6 +280,14 @@ void mjo_geometry(const mjo_params *p, mjo_geom g[MJO_MAX_COMPS], int *mcus_per_
     if (p->h_samp[ci] > maxh) maxh = p->h_samp[ci];
     if (p->v_samp[ci] > maxv) maxv = p->v_samp[ci];
   }
+  if (p->num_components == 1) {   /* one component: never interleaved -- no dummy blocks, an MCU is a block (per_scan_setup jcmaster.c:548-575; encode_core) */
+    g[0].wib = g[0].wpad = (int)div_round_up((long)p->width, 8);
+    g[0].hib = g[0].hpad = (int)div_round_up((long)p->height, 8);
+    g[0].pw = g[0].wib * 8; g[0].ph = g[0].hib * 8;
+    if (mcus_per_row) *mcus_per_row = g[0].wib;
+    if (mcu_rows) *mcu_rows = g[0].hib;
+    return;
+  }
   for (ci = 0; ci < p->num_components; ci++) {
     g[ci].wib = (int)div_round_up((long)p->width * p->h_samp[ci], (long)maxh * 8);
     g[ci].hib = (int)div_round_up((long)p->height * p->v_samp[ci], (long)maxv * 8);
@@ -770,6 +778,7 @@ typedef struct {
   int qsent[4];
   int last_restart_interval; /* jcmarker.c:660 */
   int progressive;
+  int sof_hv0;     /* one component sampled other than 1x1: the SOF's sampling byte (encode_core) */
   /* trellis_q_opt: sums over the blocks of sum(raw * quantized) and sum(8 * quantized^2) per table and coefficient
    * (jcdctmgr.c:1299-1306).  Every term is an integer and the totals stay far below 2^53, so the double sums are
    * exact in ANY order -- a parallel reduction reproduces them bit for bit */
@@ -1897,7 +1906,7 @@ static void emit_frame_header(enc_t *e, bytebuf *o)
   bb_put(o, p->num_components);
   for (ci = 0; ci < p->num_components; ci++) {
     bb_put(o, p->component_id[ci]);
-    bb_put(o, (p->h_samp[ci] << 4) + p->v_samp[ci]);
+    bb_put(o, e->sof_hv0 ? e->sof_hv0 : (p->h_samp[ci] << 4) + p->v_samp[ci]);
     bb_put(o, p->quant_tbl_no[ci]);
   }
 }
@@ -2119,6 +2128,18 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
 
   memset(&e, 0, sizeof(e));
   e.p = p;
+  if (pp.num_components == 1 && (pp.h_samp[0] != 1 || pp.v_samp[0] != 1)) {
+    /* ONE component sampled HxV (cjpeg gives a gray image 2x1 for qualities 80..89, set_quality_ratings rdswitch.c:566-570): its
+     * scans are non-interleaved -- an MCU is one block, MCUs_per_row = width_in_blocks, no dummy blocks (per_scan_setup
+     * jcmaster.c:548-575) -- and max_samp = its own factors (initial_setup :210-259), so width / height_in_blocks, the
+     * downsampler (h_expand = v_expand = 1: fullsize_downsample / fullsize_smooth_downsample, jcsample.c:507-518) and the restart
+     * rows are those of 1x1: only the SOF byte differs.  The exception is the trellis: compress_trellis_pass walks iMCU rows
+     * of V block rows (lastDC and the row above chain over them, jccoefct.c:418-441) -- V > 1 with the trellis is not restated. */
+    if (pp.h_samp[0] < 1 || pp.h_samp[0] > 4 || pp.v_samp[0] < 1 || pp.v_samp[0] > 4) return 0;
+    if (pp.v_samp[0] != 1 && pp.trellis_quant) return 0;
+    e.sof_hv0 = (pp.h_samp[0] << 4) + pp.v_samp[0];
+    pp.h_samp[0] = pp.v_samp[0] = 1;
+  }
   /* validate_script jcmaster.c:309-330: a script whose scans are all Ss = 0, Se = 63 is a SEQUENTIAL multi-scan file (SOF0 / SOF1,
    * whole blocks per scan); any other script is progressive */
   e.progressive = p->num_scans > 0 && !(p->scans[0].Ss == 0 && p->scans[0].Se == 63 && !p->optimize_scans);

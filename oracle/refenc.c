@@ -15,6 +15,7 @@
  *   -grayin         raw input has 1 component
  *   -quality N  -baseline  -revert  -optimize  -progressive  -fastcrush
  *   -notrellis  -notrellis-dc  -noovershoot  -sample HxV  -restart N[B]  -gray
+ *   -graysample HxV sampling factors of a gray image's one component (-sample is applied to three-component images only)
  *   -quant-table N  -lambda1 F -lambda2 F
  *   -reps N         encode N times, report best and mean wall time
  *   -dumpcoef FILE  dump quantized coefficients of the output
@@ -61,6 +62,7 @@ int main(int argc, char **argv)
 {
   int quality = 75, baseline = 0, revert = 0, optimize = 0, progressive = 0, fastcrush = 0;
   int notrellis = 0, notrellis_dc = 0, noovershoot = 0, gray = 0, rgbout = 0, grayin = 0, qtbl = -1;
+  int ghs = 0, gvs = 0;
   int hs = 2, vs = 2, hs1 = 1, vs1 = 1, hs2 = 1, vs2 = 1, nsamp = 2, restart = 0, restart_blocks = 0, reps = 1, rawW = 0, rawH = 0;
   double l1 = -1e9, l2 = -1e9;
   int dc_scan_opt = -1;
@@ -101,6 +103,7 @@ int main(int argc, char **argv)
       restart = (int)v; restart_blocks = (ch == 'b' || ch == 'B');
     }
     else if (!strcmp(a, "-reps")) reps = atoi(argv[++i]);
+    else if (!strcmp(a, "-graysample")) sscanf(argv[++i], "%dx%d", &ghs, &gvs);   /* factors of a gray image's component (-sample is only applied to three) */
     else if (!strcmp(a, "-precision")) precision = atoi(argv[++i]);   /* 12: raw input is uint16 samples */
     else if (!strcmp(a, "-raw")) { rawW = atoi(argv[++i]); rawH = atoi(argv[++i]); }
     else if (!strcmp(a, "-dumpcoef")) dump = argv[++i];
@@ -186,6 +189,10 @@ int main(int argc, char **argv)
     if (notrellis) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_TRELLIS_QUANT, FALSE);
     if (notrellis_dc) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_TRELLIS_QUANT_DC, FALSE);
     if (noovershoot) jpeg_c_set_bool_param(&cinfo, JBOOLEAN_OVERSHOOT_DERINGING, FALSE);
+    if (cinfo.num_components == 1 && ghs > 0) {   /* -graysample HxV: the one component's factors (cjpeg: -sample on a gray image, or quality 80..89) */
+      cinfo.comp_info[0].h_samp_factor = ghs;
+      cinfo.comp_info[0].v_samp_factor = gvs;
+    }
     if (cinfo.num_components == 3 && !rgbout) {
       cinfo.comp_info[0].h_samp_factor = hs;
       cinfo.comp_info[0].v_samp_factor = vs;

@@ -166,6 +166,17 @@ CASES = [
     ("arith_base_cond", dict(arithmetic=True, baseline=True, arith_cond=((1, 3, 9), (0, 2, 20))), True),
     ("arith_fastcrush_cond", dict(arithmetic=True, fastcrush=True, arith_cond=((2, 5, 1), (1, 1, 63))), True),
     ("arith_default_progressive_cond", dict(arithmetic=True, quality=85, arith_cond=((0, 15, 12), (3, 4, 2))), True),
+    # ONE component sampled other than 1x1 (SOF byte only: its scans are non-interleaved, per_scan_setup jcmaster.c:548-575).  cjpeg
+    # does this to every gray image at qualities 80..89 (set_quality_ratings rdswitch.c:566-570 sets 2x1 on component 0) --
+    # tools/simt/fuzz_cjpeg.py found the encoder refusing `cjpeg -quality 85 -grayscale`.  V > 1 only without the trellis
+    # (compress_trellis_pass chains the DC trellis over the V block rows of an iMCU row: not built, refused).
+    ("gray_2x1_q85_progressive", dict(gray=True, quality=85, gray_sample=(2, 1)), True),
+    ("gray_2x1_q85_base", dict(gray=True, baseline=True, quality=85, gray_sample=(2, 1)), True),
+    ("gray_2x1_revert_restart1", dict(gray=True, revert=True, restart=1, gray_sample=(2, 1)), True),
+    ("gray_4x1_base_smooth30_restart3b", dict(gray=True, baseline=True, smooth=30, restart="3b", gray_sample=(4, 1)), True),
+    ("gray_2x1_arith_fastcrush", dict(gray=True, arithmetic=True, fastcrush=True, gray_sample=(2, 1)), True),
+    ("gray_2x2_base_notrellis", dict(gray=True, baseline=True, notrellis=True, gray_sample=(2, 2)), True),
+    ("gray_1x2_revert_progressive", dict(gray=True, revert=True, progressive=True, gray_sample=(1, 2)), True),
 ]
 
 

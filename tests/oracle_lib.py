@@ -75,7 +75,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 noovershoot=False, sample=(2, 2), restart=None, gray=False, grayin=False,
                 quant_table=-1, lambda1=None, lambda2=None, precision=8, trellis_loops=1, smooth=0, trellis_q_opt=False,
                 trellis_eob_opt=False, use_scans_in_trellis=False, trellis_freq_split=0, rgb=False,
-                dc_scan_opt=None, dc_ver_weight=None, arithmetic=False, arith_cond=None, scans=None):
+                dc_scan_opt=None, dc_ver_weight=None, arithmetic=False, arith_cond=None, scans=None, gray_sample=None):
     """Same switch vocabulary as cjpeg / oracle/refenc.c.  Default (no switch) is cjpeg's default:
     max-compression profile, progressive with scan search."""
     p = Params()
@@ -87,6 +87,8 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     if per_comp and p.num_components == 3:
         for i in range(3):
             p.h_samp[i], p.v_samp[i] = sample[i]
+    if gray_sample is not None and p.num_components == 1:      # (h, v) of a gray image's one component (cjpeg: 2x1 for qualities 80..89)
+        p.h_samp[0], p.v_samp[0] = gray_sample
     if optimize:
         p.optimize_coding = 1
     if notrellis:
@@ -324,6 +326,8 @@ def ref_switches(**kw):
         sw.append("-notrellis-dc")
     s = kw.get("sample", (2, 2))
     sw += ["-sample", ",".join("%dx%d" % tuple(t) for t in s) if isinstance(s[0], (tuple, list)) else "%dx%d" % s]
+    if kw.get("gray_sample") is not None:
+        sw += ["-graysample", "%dx%d" % tuple(kw["gray_sample"])]
     if kw.get("restart") is not None:
         sw += ["-restart", str(kw["restart"])]
     if kw.get("quant_table", -1) >= 0:

@@ -172,6 +172,43 @@ def test_unchanged_cjpeg_against_the_standalone_library(cname, args, goldens, tm
     assert (len(data), hashlib.md5(data).hexdigest()) == (g["bytes"], g["md5"])
 
 
+# ---- cjpeg's other readers and one-component sampling (found by tools/simt/fuzz_cjpeg.py, round 5): the BMP / bottom-up Targa
+# readers keep the picture in a virtual array that jpeg_start_compress has to realise (rdbmp.c:605-609, jcinit.c:143); a gray image
+# at quality 80..89 gets component 0 sampled 2x1 (set_quality_ratings rdswitch.c:566-570).  The same cases run on the emulator in
+# tests/test_simt_dropin.py; expected bytes = the same binary on the reference's own library ----------------------------------
+from test_simt_dropin import CASES as READER_CASES, write_bmp, write_tga  # noqa: E402
+
+
+@needs
+@needs_sa
+@pytest.mark.parametrize("kind,args", READER_CASES)
+def test_unchanged_cjpeg_readers_and_one_component_sampling(kind, args, tmp_path, fixture_images):
+    img = fixture_images["testorig"]
+    src = str(tmp_path / ("in." + kind.split("_")[0]))
+    if kind == "bmp":
+        write_bmp(src, img)
+    elif kind.startswith("tga"):
+        write_tga(src, img, kind.endswith("bottom_up"))
+    elif kind == "pgm":
+        with open(src, "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]) + img[:, :, 1].tobytes())
+    else:
+        src = PPM
+    ref, gpu, alone = (str(tmp_path / n) for n in ("ref.jpg", "gpu.jpg", "alone.jpg"))
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    env["LD_LIBRARY_PATH"] = O.REF_DIR
+    r0 = subprocess.run([CJPEG, "-dct", "int"] + args + ["-outfile", ref, src], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r0.returncode == 0, r0.stderr.decode()
+    env["LD_PRELOAD"] = SHIM
+    r1 = subprocess.run([CJPEG, "-dct", "int"] + args + ["-outfile", gpu, src], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r1.returncode == 0, r1.stderr.decode()
+    assert open(gpu, "rb").read() == open(ref, "rb").read()
+    r2 = run_cjpeg_standalone(args, alone, inp=src)
+    assert r2.returncode == 0, r2.stderr.decode()[-2000:]
+    assert open(alone, "rb").read() == open(ref, "rb").read()
+
+
 ICC = os.path.join(ROOT, "tests", "golden", "test1.icc")
 
 

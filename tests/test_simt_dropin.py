@@ -1,0 +1,107 @@
+"""CPU suite: the drop-in boundary without a GPU.  The reference's UNCHANGED cjpeg / jpegtran run with the SHIPPED interposing
+library (mozjpeg_amd/libmozjpeg_hip_jpeg62.so) in front of the reference's libjpeg, and against the SHIPPED stand-alone
+libjpeg.so.62, while those libraries' `libmozjpeg_hip.so` is the kernel sources on the wave64 emulator (tools/simt: test
+infrastructure like oracle/; see tests/test_simt_kernels.py for what that is and is not).  What is under test is the host C
+code between the libjpeg API and the C ABI -- jpeg_shim.c, jpeg_api.c -- on command lines the fixed lists of
+tests/test_gpu_dropin.py do not hold; expected bytes = the same binary on the reference's own library.
+Build container only (needs oracle/_ref); the same cases run on the chip in tests/test_gpu_dropin.py."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools", "simt"))
+CJPEG = os.path.join(O.REF_DIR, "cjpeg")
+SHIM = os.path.join(ROOT, "mozjpeg_amd", "libmozjpeg_hip_jpeg62.so")
+STANDALONE = os.path.join(ROOT, "mozjpeg_amd", "standalone", "libjpeg.so.62")
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(CJPEG) and os.path.exists(SHIM) and os.path.exists(STANDALONE)),
+                                reason="reference binaries (oracle/_ref) or the shim libraries are not built")
+
+
+@pytest.fixture(scope="module")
+def fz():
+    import fuzz_cjpeg
+    return fuzz_cjpeg, fuzz_cjpeg.dropin_dir()
+
+
+def write_bmp(path, img):
+    """24-bit bottom-up BMP: cjpeg's reader keeps the whole picture in a virtual array it REQUESTS before jpeg_start_compress
+    and that jpeg_start_compress has to realise (rdbmp.c:605-609, jcinit.c:143)"""
+    h, w = img.shape[:2]
+    row = (w * 3 + 3) & ~3
+    body = b"".join(img[y, :, ::-1].tobytes() + b"\0" * (row - 3 * w) for y in range(h - 1, -1, -1))
+    le = lambda v, n: int(v).to_bytes(n, "little")   # noqa: E731
+    hdr = b"BM" + le(54 + len(body), 4) + le(0, 4) + le(54, 4) + le(40, 4) + le(w, 4) + le(h, 4) + le(1, 2) + le(24, 2) + le(0, 4) + le(len(body), 4) + le(2835, 4) * 2 + le(0, 4) * 2
+    with open(path, "wb") as f:
+        f.write(hdr + body)
+
+
+def write_tga(path, img, bottom_up):
+    h, w = img.shape[:2]
+    hdr = bytearray(18)
+    hdr[2] = 2
+    hdr[12:14] = w.to_bytes(2, "little"); hdr[14:16] = h.to_bytes(2, "little")
+    hdr[16] = 24
+    hdr[17] = 0 if bottom_up else 0x20
+    with open(path, "wb") as f:
+        f.write(bytes(hdr) + (img[::-1] if bottom_up else img)[:, :, ::-1].tobytes())
+
+
+CASES = [
+    ("bmp", ["-quality", "75", "-baseline"]),                       # the reader's virtual array
+    ("bmp", ["-quality", "75"]),
+    ("tga_bottom_up", ["-quality", "75", "-baseline", "-targa"]),   # the same in rdtarga.c
+    ("tga", ["-revert", "-quality", "75", "-targa"]),
+    ("pgm", ["-quality", "85"]),                                    # a gray image at quality 80..89: component 0 sampled 2x1 (rdswitch.c:566-570)
+    ("ppm", ["-quality", "85", "-grayscale", "-baseline"]),
+    ("ppm", ["-quality", "88", "-grayscale", "-arithmetic", "-restart", "1"]),
+    ("pgm", ["-revert", "-quality", "75", "-sample", "2x2"]),       # V > 1 on one component: fine without the trellis
+    ("pgm", ["-quality", "75", "-baseline", "-sample", "4x1", "-smooth", "20"]),
+]
+
+
+@pytest.mark.parametrize("kind,args", CASES)
+def test_unchanged_cjpeg_on_the_emulator_readers_and_one_component_sampling(fz, kind, args, tmp_path, fixture_images):
+    F, d = fz
+    img = fixture_images["testorig"]
+    src = str(tmp_path / ("in." + kind.split("_")[0]))
+    if kind == "bmp":
+        write_bmp(src, img)
+    elif kind.startswith("tga"):
+        write_tga(src, img, kind.endswith("bottom_up"))
+    elif kind == "pgm":
+        with open(src, "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]) + img[:, :, 1].tobytes())
+    else:
+        src = os.path.join(ROOT, "tests", "golden", "testorig.ppm")
+    bad, r0 = F.three_ways(lambda out: [CJPEG, "-dct", "int"] + args + ["-outfile", out, src], d, str(tmp_path), False)
+    assert bad is not None, r0.stderr.decode()
+    assert bad == []
+
+
+def test_one_component_with_vertical_factor_and_trellis_is_refused_with_the_reason(fz, tmp_path, fixture_images):
+    """compress_trellis_pass chains the DC trellis over the V block rows of an iMCU row (jccoefct.c:418-441): not built for one
+    component -- an error with the reason, never other bytes"""
+    F, d = fz
+    img = fixture_images["syn96x64"]
+    src = str(tmp_path / "in.pgm")
+    with open(src, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]) + img[:, :, 1].tobytes())
+    r = F.run([CJPEG, "-quality", "75", "-baseline", "-sample", "2x2", "-outfile", str(tmp_path / "o.jpg"), src], {},
+              preload=os.path.join(d, "libmozjpeg_hip_jpeg62.so"))
+    assert r.returncode != 0 and b"vertical sampling factor" in r.stderr and b"no CPU fallback" in r.stderr
+
+
+def test_random_command_lines_through_the_shipped_libraries_on_the_emulator():
+    """a slice of tools/simt/fuzz_cjpeg.py (random cjpeg / jpegtran command lines, three ways each); the tool's longer runs are
+    recorded in profiles/r05z_*"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "simt", "fuzz_cjpeg.py"), "11", "60"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    assert b" 0 failures" in r.stdout
