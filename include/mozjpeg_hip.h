@@ -95,7 +95,8 @@ typedef struct {
   /* colour transform between input pixels and JPEG components: MJH_COLOR_YCC (0) = RGB -> YCbCr / gray (rgb_ycc_convert,
    * rgb_gray_convert, grayscale_convert of jccolor.c), MJH_COLOR_NONE = the three input samples become the three
    * components unconverted (null_convert jccolor.c:479, JCS_RGB output = `cjpeg -rgb`; an Adobe APP14 marker with
-   * transform 0 replaces the JFIF APP0, component ids are whatever component_id[] says, 'R' 'G' 'B' for cjpeg) */
+   * transform 0 replaces the JFIF APP0, component ids are whatever component_id[] says, 'R' 'G' 'B' for cjpeg),
+   * MJH_COLOR_YCC_IN = input pixels that are YCbCr already (what an application sets with in_color_space = JCS_YCbCr) */
   int color_transform;
   /* JINT_DC_SCAN_OPT_MODE (jpeglib.h:349, cjpeg -dc-scan-opt N; library default 0, jcparam.c:495): 0 = one DC scan for
    * all components, 1 = one DC scan per component, 2 = luma alone, then chroma interleaved or separate -- with the scan
@@ -131,6 +132,9 @@ typedef struct {
 
 #define MJH_COLOR_YCC  0
 #define MJH_COLOR_NONE 1
+#define MJH_COLOR_YCC_IN 2   /* the input samples ARE Y, Cb, Cr (in_color_space = JCS_YCbCr, jpeg_color_space = JCS_YCbCr: null_convert
+                              * jccolor.c:479 via jinit_color_converter :687-692): unconverted like MJH_COLOR_NONE, but the file is an
+                              * ordinary YCbCr one -- JFIF APP0, no Adobe marker, YCbCr's progressive scripts */
 
 typedef struct mjh_encoder mjh_encoder;
 

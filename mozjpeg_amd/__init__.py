@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MOZJPEG_AMD_LIB") or os.path.join(_HERE, "libmozjpeg_
 MAX_COMPS, MAX_SCANS = 4, 64
 PROFILE_MAX_COMPRESSION = 0x5D083AAD
 PROFILE_FASTEST = 0x2AEA5CB4
-COLOR_YCC, COLOR_NONE = 0, 1
+COLOR_YCC, COLOR_NONE, COLOR_YCC_IN = 0, 1, 2
 OK, EINVAL, EUNSUPPORTED, EHIP, ENOMEM, ETOOSMALL = 0, -1, -2, -3, -4, -5
 TAP_PLANE, TAP_COEF_UQ, TAP_COEF_Q, TAP_COEF_Q0, TAP_HUFF_BITS, TAP_HUFF_VALS, TAP_PROG_SCAN_US = 1, 2, 3, 4, 5, 6, 7
 
@@ -135,7 +135,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 grayin=False, quant_table=-1, lambda1=None, lambda2=None, restart=None,
                 progressive=False, fastcrush=False, precision=8, trellis_loops=1, smooth=0, rgb=False,
                 dc_scan_opt=None, dc_ver_weight=None, use_scans_in_trellis=False, trellis_freq_split=0,
-                trellis_eob_opt=False, trellis_q_opt=False, arithmetic=False, arith_cond=None, scans=None, gray_sample=None):
+                trellis_eob_opt=False, trellis_q_opt=False, arithmetic=False, arith_cond=None, scans=None, gray_sample=None, yccin=False):
     """Parameters with cjpeg's switch vocabulary (cjpeg.c:371-714).  Without `baseline` or
     `revert` this is cjpeg's default: progressive with scan search (`fastcrush`: fixed 9-scan script)."""
     p = Params()
@@ -177,6 +177,8 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     if arith_cond is not None:     # ((L, U, K) of conditioning table 0, (L, U, K) of table 1): cinfo->arith_dc_L / arith_dc_U / arith_ac_K
         for t, (lo, up, kx) in enumerate(arith_cond):
             p.arith_dc_L[t], p.arith_dc_U[t], p.arith_ac_K[t] = lo, up, kx
+    if yccin and p.num_components == 3:    # in_color_space = JCS_YCbCr: the pixels are Y, Cb, Cr already (null_convert jccolor.c:479)
+        p.color_transform = COLOR_YCC_IN
     if rgb:   # cjpeg -rgb: jpeg_set_colorspace(JCS_RGB) (jcparam.c:611-619): all components 1x1 / table 0, ids 'R' 'G' 'B', no JFIF
         p.color_transform = COLOR_NONE
         p.write_JFIF_header = 0

@@ -351,6 +351,7 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
     case JCS_EXT_XBGR: case JCS_EXT_ABGR: ps = 4; ro = 3; go = 2; bo = 1; break;
     case JCS_EXT_XRGB: case JCS_EXT_ARGB: ps = 4; ro = 1; go = 2; bo = 3; break;
     case JCS_GRAYSCALE: ps = 1; break;
+    case JCS_YCbCr: ps = 3; break;     /* samples that are YCbCr already: only into a YCbCr file (below) */
     default:
       if (!no_pixels) return "input colour space (RGB family / grayscale only)";
       ps = 3;
@@ -361,7 +362,13 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
     if (ps == 1) p->input_components = 1;
     else { p->input_components = 3; p->input_pixel_size = ps; p->rgb_offset[0] = ro; p->rgb_offset[1] = go; p->rgb_offset[2] = bo; }
   }
-  if (cinfo->jpeg_color_space == JCS_YCbCr && cinfo->num_components == 3) p->num_components = 3;
+  if (!no_pixels && cinfo->in_color_space == JCS_YCbCr) {
+    /* jinit_color_converter jccolor.c:687-692: YCbCr in -> YCbCr out is null_convert (:479); -> grayscale takes the Y samples
+     * (grayscale_convert :448-466), which the device's colour kernels have no mode for */
+    if (!(cinfo->jpeg_color_space == JCS_YCbCr && cinfo->num_components == 3)) return "YCbCr input into anything but a YCbCr file";
+    p->num_components = 3;
+    p->color_transform = MJH_COLOR_YCC_IN;
+  } else if (cinfo->jpeg_color_space == JCS_YCbCr && cinfo->num_components == 3) p->num_components = 3;
   else if (cinfo->jpeg_color_space == JCS_GRAYSCALE && cinfo->num_components == 1) p->num_components = 1;
   else if (cinfo->jpeg_color_space == JCS_RGB && cinfo->num_components == 3 && (no_pixels || p->input_components == 3)) {
     p->num_components = 3;           /* cjpeg -rgb: null_convert (jccolor.c:479), the samples go through unconverted */

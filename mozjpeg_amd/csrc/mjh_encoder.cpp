@@ -408,8 +408,8 @@ static int check_supported(const mjh_params *p)
   if (p->input_components != 1 && p->input_components != 3) return fail(MJH_EUNSUPPORTED, "input_components %d (RGB or gray only)", p->input_components);
   if (p->num_components != 1 && p->num_components != 3) return fail(MJH_EUNSUPPORTED, "num_components %d", p->num_components);
   if (p->num_components == 3 && p->input_components != 3) return fail(MJH_EUNSUPPORTED, "gray input cannot produce 3 components");
-  if (p->color_transform != MJH_COLOR_YCC && p->color_transform != MJH_COLOR_NONE) return fail(MJH_EINVAL, "color_transform %d", p->color_transform);
-  if (p->color_transform == MJH_COLOR_NONE && p->num_components != 3) return fail(MJH_EUNSUPPORTED, "MJH_COLOR_NONE needs three components");
+  if (p->color_transform != MJH_COLOR_YCC && p->color_transform != MJH_COLOR_NONE && p->color_transform != MJH_COLOR_YCC_IN) return fail(MJH_EINVAL, "color_transform %d", p->color_transform);
+  if (p->color_transform != MJH_COLOR_YCC && p->num_components != 3) return fail(MJH_EUNSUPPORTED, "MJH_COLOR_NONE / MJH_COLOR_YCC_IN need three components");
   if (p->num_components == 1) {
     // One component: its only scans are non-interleaved (per_scan_setup jcmaster.c:548-575: an MCU is one block, no dummy blocks) and
     // max_samp = its own factors (initial_setup :210-259), so the factors change nothing but the SOF byte -- cjpeg sets 2x1 on a
@@ -510,7 +510,7 @@ static void build_const(const mjh_params *p, MjhConst *C)
   C->off_r = p->rgb_offset[0]; C->off_g = p->rgb_offset[1]; C->off_b = p->rgb_offset[2];
   if (C->off_r == 0 && C->off_g == 0 && C->off_b == 0) { C->off_g = 1; C->off_b = 2; }
   C->precision = p->data_precision == 12 ? 12 : 8;
-  C->no_ycc = p->color_transform == MJH_COLOR_NONE;
+  C->no_ycc = p->color_transform != MJH_COLOR_YCC;      // (MJH_COLOR_YCC_IN: the same null conversion, only the headers / scripts are YCbCr's)
   C->maxh = C->maxv = 1;
   for (int i = 0; i < C->ncomp; i++) {
     if (p->h_samp_factor[i] > C->maxh) C->maxh = p->h_samp_factor[i];

@@ -327,7 +327,11 @@ static void convert_pixel(const mjo_params *p, const uint8_t *px, int out[3])
     out[0] = P == 12 ? ((const uint16_t *)px)[0] : v[0];   /* grayscale_convert / null path: no masking */
     return;
   }
-  if (p->rgb_output) {   /* null_convert jccolor.c:479: samples copied as they are */
+  if (p->ycc_input && p->num_components == 1) {   /* YCbCr in, grayscale out: grayscale_convert takes the Y samples (jccolor.c:448-466) */
+    out[0] = P == 12 ? ((const uint16_t *)px)[0] : px[0];
+    return;
+  }
+  if (p->rgb_output || (p->ycc_input && p->num_components == 3)) {   /* null_convert jccolor.c:479: samples copied as they are */
     for (i = 0; i < 3; i++) out[i] = P == 12 ? ((const uint16_t *)px)[i] : px[i];
     return;
   }

@@ -74,6 +74,8 @@ typedef struct {
                                    * with trellis_quant the rate model of quantize_trellis_arith */
   int arith_dc_L[4], arith_dc_U[4], arith_ac_K[4];   /* cinfo->arith_dc_L / arith_dc_U / arith_ac_K of conditioning tables 0 / 1 (jpeglib.h:447-449;
                                    * defaults 0 / 1 / 5, jcparam.c:417-419): jcarith.c:442-445,533,757-760,802,949-951, jcmarker.c:440-444 */
+  int ycc_input;                  /* in_color_space = JCS_YCbCr with jpeg_color_space = JCS_YCbCr: the three input samples are Y, Cb, Cr already
+                                   * (jinit_color_converter jccolor.c:687-692 -> null_convert :479); everything else is an ordinary YCbCr file */
 } mjo_params;
 /* jpeg_set_colorspace(cinfo, JCS_RGB) (jcparam.c:611-619): three 1x1 components 'R' 'G' 'B', tables 0, no JFIF marker */
 void mjo_set_rgb_output(mjo_params *p);

@@ -15,6 +15,7 @@
  *   -grayin         raw input has 1 component
  *   -quality N  -baseline  -revert  -optimize  -progressive  -fastcrush
  *   -notrellis  -notrellis-dc  -noovershoot  -sample HxV  -restart N[B]  -gray
+ *   -yccin          the input samples are Y, Cb, Cr already (in_color_space = JCS_YCbCr)
  *   -graysample HxV sampling factors of a gray image's one component (-sample is applied to three-component images only)
  *   -quant-table N  -lambda1 F -lambda2 F
  *   -reps N         encode N times, report best and mean wall time
@@ -62,7 +63,7 @@ int main(int argc, char **argv)
 {
   int quality = 75, baseline = 0, revert = 0, optimize = 0, progressive = 0, fastcrush = 0;
   int notrellis = 0, notrellis_dc = 0, noovershoot = 0, gray = 0, rgbout = 0, grayin = 0, qtbl = -1;
-  int ghs = 0, gvs = 0;
+  int ghs = 0, gvs = 0, yccin = 0;
   int hs = 2, vs = 2, hs1 = 1, vs1 = 1, hs2 = 1, vs2 = 1, nsamp = 2, restart = 0, restart_blocks = 0, reps = 1, rawW = 0, rawH = 0;
   double l1 = -1e9, l2 = -1e9;
   int dc_scan_opt = -1;
@@ -91,6 +92,7 @@ int main(int argc, char **argv)
     else if (!strcmp(a, "-gray")) gray = 1;
     else if (!strcmp(a, "-rgb")) rgbout = 1;   /* cjpeg -rgb: jpeg_set_colorspace(JCS_RGB), samples unconverted */
     else if (!strcmp(a, "-grayin")) grayin = 1;
+    else if (!strcmp(a, "-yccin")) yccin = 1;   /* the three input samples are Y, Cb, Cr: in_color_space = JCS_YCbCr (set before jpeg_set_defaults) */
     else if (!strcmp(a, "-quant-table")) qtbl = atoi(argv[++i]);
     else if (!strcmp(a, "-lambda1")) l1 = atof(argv[++i]);
     else if (!strcmp(a, "-lambda2")) l2 = atof(argv[++i]);
@@ -151,7 +153,7 @@ int main(int argc, char **argv)
     t0 = now();
     cinfo.err = jpeg_std_error(&jerr);
     jpeg_create_compress(&cinfo);
-    cinfo.in_color_space = (nc == 3) ? JCS_RGB : JCS_GRAYSCALE;
+    cinfo.in_color_space = (nc == 3) ? (yccin ? JCS_YCbCr : JCS_RGB) : JCS_GRAYSCALE;
     cinfo.input_components = nc;
     if (revert)
       jpeg_c_set_int_param(&cinfo, JINT_COMPRESS_PROFILE, JCP_FASTEST);

@@ -177,6 +177,11 @@ CASES = [
     ("gray_2x1_arith_fastcrush", dict(gray=True, arithmetic=True, fastcrush=True, gray_sample=(2, 1)), True),
     ("gray_2x2_base_notrellis", dict(gray=True, baseline=True, notrellis=True, gray_sample=(2, 2)), True),
     ("gray_1x2_revert_progressive", dict(gray=True, revert=True, progressive=True, gray_sample=(1, 2)), True),
+    # input samples that are Y, Cb, Cr already (in_color_space = JCS_YCbCr -> null_convert, jccolor.c:687-692, :479): MJH_COLOR_YCC_IN;
+    # the fixtures' bytes are simply read as YCbCr
+    ("yccin_base", dict(baseline=True, yccin=True), True),
+    ("yccin_progressive_422", dict(yccin=True, sample=(2, 1)), True),
+    ("yccin_revert_restart1", dict(revert=True, yccin=True, restart=1), True),
 ]
 
 

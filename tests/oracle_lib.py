@@ -35,7 +35,8 @@ class Params(C.Structure):
                 ("smoothing_factor", C.c_int), ("trellis_q_opt", C.c_int),
                 ("trellis_eob_opt", C.c_int), ("use_scans_in_trellis", C.c_int), ("trellis_freq_split", C.c_int),
                 ("rgb_output", C.c_int), ("trellis_delta_dc_weight", C.c_float), ("dc_scan_opt_mode", C.c_int),
-                ("arith_code", C.c_int), ("arith_dc_L", C.c_int * 4), ("arith_dc_U", C.c_int * 4), ("arith_ac_K", C.c_int * 4)]
+                ("arith_code", C.c_int), ("arith_dc_L", C.c_int * 4), ("arith_dc_U", C.c_int * 4), ("arith_ac_K", C.c_int * 4),
+                ("ycc_input", C.c_int)]
 
 
 class Geom(C.Structure):
@@ -75,7 +76,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 noovershoot=False, sample=(2, 2), restart=None, gray=False, grayin=False,
                 quant_table=-1, lambda1=None, lambda2=None, precision=8, trellis_loops=1, smooth=0, trellis_q_opt=False,
                 trellis_eob_opt=False, use_scans_in_trellis=False, trellis_freq_split=0, rgb=False,
-                dc_scan_opt=None, dc_ver_weight=None, arithmetic=False, arith_cond=None, scans=None, gray_sample=None):
+                dc_scan_opt=None, dc_ver_weight=None, arithmetic=False, arith_cond=None, scans=None, gray_sample=None, yccin=False):
     """Same switch vocabulary as cjpeg / oracle/refenc.c.  Default (no switch) is cjpeg's default:
     max-compression profile, progressive with scan search."""
     p = Params()
@@ -124,6 +125,8 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     if arith_cond is not None:     # ((L, U, K) of conditioning table 0, (L, U, K) of table 1)
         for t, (lo, up, kx) in enumerate(arith_cond):
             p.arith_dc_L[t], p.arith_dc_U[t], p.arith_ac_K[t] = lo, up, kx
+    if yccin and not grayin:      # in_color_space = JCS_YCbCr (refenc -yccin): the pixels are Y, Cb, Cr already
+        p.ycc_input = 1
     if rgb:
         L.mjo_set_rgb_output(C.byref(p))
     if dc_ver_weight is not None:
@@ -319,7 +322,7 @@ def ref_switches(**kw):
     """Translate make_params keywords into refenc/cjpeg switches."""
     sw = ["-quality", str(kw.get("quality", 75))]
     for k in ("baseline", "revert", "optimize", "progressive", "fastcrush", "notrellis",
-              "noovershoot", "gray", "grayin", "rgb"):
+              "noovershoot", "gray", "grayin", "rgb", "yccin"):
         if kw.get(k):
             sw.append("-" + k)
     if kw.get("notrellis_dc"):

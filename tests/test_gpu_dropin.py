@@ -231,7 +231,7 @@ needs_h = pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(SHI
 
 @needs_h
 @pytest.mark.parametrize("mode", ["preload", "standalone"])
-@pytest.mark.parametrize("scenario", ["interleaved", "abort_reuse", "abort_midway", "markers", "stdio", "ext_params"])
+@pytest.mark.parametrize("scenario", ["interleaved", "abort_reuse", "abort_midway", "markers", "stdio", "ext_params", "color_spaces"])
 def test_libjpeg_client_scenarios(scenario, mode):
     """two interleaved compress objects on one thread; error_exit longjmp -> jpeg_abort_compress -> reuse, and hundreds
     of start/abort and create/destroy cycles without growth; COM / APPn / ICC markers and JFIF density fields; the stdio

@@ -98,6 +98,24 @@ def test_one_component_with_vertical_factor_and_trellis_is_refused_with_the_reas
     assert r.returncode != 0 and b"vertical sampling factor" in r.stderr and b"no CPU fallback" in r.stderr
 
 
+HARNESS = os.path.join(ROOT, "tests", "native", "shim_harness")
+
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="tests/native/shim_harness not built")
+@pytest.mark.parametrize("scenario", ["interleaved", "abort_reuse", "abort_midway", "markers", "stdio", "ext_params", "color_spaces"])
+def test_libjpeg_client_scenarios_on_the_emulator(fz, scenario):
+    """tests/native/shim_harness.c (two objects interleaved, abort + reuse, markers, stdio destination, the extension parameters,
+    in_color_space = JCS_YCbCr / an extended pixel order / one component with the application's sampling factors) against the
+    reference's library, the shipped shim in front of it, and the shipped stand-alone library"""
+    F, d = fz
+    want = F.run([HARNESS, scenario], {})
+    assert want.returncode == 0, want.stderr.decode()
+    for kw in (dict(preload=os.path.join(d, "libmozjpeg_hip_jpeg62.so")), dict(libpath=os.path.join(d, "standalone"))):
+        got = F.run([HARNESS, scenario], {}, **kw)
+        assert got.returncode == 0, got.stderr.decode()[-2000:]
+        assert got.stdout == want.stdout, (kw, got.stdout, want.stdout)
+
+
 def test_random_command_lines_through_the_shipped_libraries_on_the_emulator():
     """a slice of tools/simt/fuzz_cjpeg.py (random cjpeg / jpegtran command lines, three ways each); the tool's longer runs are
     recorded in profiles/r05z_*"""
