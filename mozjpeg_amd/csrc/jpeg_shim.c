@@ -430,9 +430,23 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
      * multi-scan file (validate_script :309-330) and keeps the application's choice */
     if (p->optimize_scans || !(p->scan_info[0].Ss == 0 && p->scan_info[0].Se == 63)) p->optimize_coding = p->arith_code ? 0 : 1;
   }
-  if (!cinfo->optimize_coding && !cinfo->arith_code) {
-    /* standard tables are baked into the GPU path; anything else needs optimize_coding */
-    if (cinfo->dc_huff_tbl_ptrs[0] == NULL || cinfo->ac_huff_tbl_ptrs[0] == NULL) return "missing Huffman tables";
+  if (!p->optimize_coding && !p->arith_code) {
+    /* the device codes with the Annex K tables (std_huff_tables jstdhuff.c:31-131, what jpeg_set_defaults installs) when the
+     * application does not ask for optimal ones: tables of the application's own in the slots its components use would be what
+     * the reference codes with (jchuff.c start_pass_huff: jpeg_make_c_derived_tbl of dc/ac_huff_tbl_ptrs) -- never other bytes */
+    for (ci = 0; ci < cinfo->num_components; ci++) {
+      int which;
+      for (which = 0; which < 2; which++) {
+        const int t = which ? cinfo->comp_info[ci].ac_tbl_no : cinfo->comp_info[ci].dc_tbl_no;
+        const JHUFF_TBL *h = t >= 0 && t < NUM_HUFF_TBLS ? (which ? cinfo->ac_huff_tbl_ptrs[t] : cinfo->dc_huff_tbl_ptrs[t]) : NULL;
+        const uint8_t *bits, *vals;
+        int nv;
+        if (!h) return "missing Huffman tables";
+        if (t > 1 || mjh_std_huffman_table(which, t, &bits, &vals, &nv) != MJH_OK || memcmp(h->bits + 1, bits + 1, 16) != 0 ||
+            memcmp(h->huffval, vals, (size_t)nv) != 0)
+          return "Huffman tables of the application's own without optimize_coding (the device path codes with the Annex K tables or with optimal ones)";
+      }
+    }
   }
   p->write_JFIF_header = cinfo->write_JFIF_header;
   return NULL;

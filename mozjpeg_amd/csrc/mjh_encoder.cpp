@@ -393,6 +393,25 @@ static long div_round_up(long a, long b) { return (a + b - 1) / b; }
 static int arith_qopt_passes(const mjh_params *p) { return (p->use_scans_in_trellis ? 2 : 1) * p->num_components * (p->trellis_num_loops > 1 ? p->trellis_num_loops : 1) + 1; }
 static int arith_qopt_updates(const mjh_params *p) { return arith_qopt_passes(p) / ((p->use_scans_in_trellis ? 4 : 2) * p->num_components); }
 
+// The reference's one-marker DHT writer of the max-compression profile (emit_multi_dht jcmarker.c:293-401) sizes the marker in a
+// loop that `continue`s past a component's AC table when its DC table was seen (or sent) before, and then writes every table not
+// yet sent with the value count of THAT loop: a component whose DC table is an earlier component's while its AC table is new gets
+// the AC table's 17 header bytes written with no values, outside the marker's length -- a corrupt file (djpeg: "17 extraneous bytes
+// before marker 0xda"; found by tools/simt/fuzz_api.py, dc tables 1,1,1 with ac tables 0,0,1).  Such a table assignment is
+// refused here rather than answered with a file of either kind.  comps: the components of one whole-block scan, in scan order.
+// dseen / aseen: the tables seen in this scan or sent by an earlier one (optimal tables are made anew for every scan, the Annex K
+// tables are sent once: jchuff.c finish_pass_gather / emit_dht's sent_table).
+static bool dht_writer_would_corrupt(const mjh_params *p, const int *comps, int k, bool dseen[4], bool aseen[4])
+{
+  for (int j = 0; j < k; j++) {
+    const int d = p->dc_tbl_no[comps[j]] & 3, a = p->ac_tbl_no[comps[j]] & 3;
+    if (dseen[d]) { if (!aseen[a]) return true; continue; }
+    dseen[d] = true;
+    aseen[a] = true;
+  }
+  return false;
+}
+
 static int check_supported(const mjh_params *p)
 {
   if (p->image_width <= 0 || p->image_height <= 0 || p->image_width > 65500 || p->image_height > 65500)
@@ -811,6 +830,16 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   }
   int rc = check_supported(p);
   if (rc) return rc;
+  if (!p->arith_code && p->compress_profile != MJH_PROFILE_FASTEST && p->num_scans == 0) {     // (sequential Huffman files: the scans that carry DC and AC tables of several components)
+    const int all[MJH_MAX_COMPS] = { 0, 1, 2, 3 };
+    bool dseen[4] = { false, false, false, false }, aseen[4] = { false, false, false, false };
+    bool bad = seq_script.empty() && dht_writer_would_corrupt(p, all, p->num_components, dseen, aseen);
+    for (const mjh_scan &sc : seq_script) {
+      if (p->optimize_coding || p->data_precision == 12) for (int t = 0; t < 4; t++) dseen[t] = aseen[t] = false;
+      bad = bad || dht_writer_would_corrupt(p, sc.component_index, sc.comps_in_scan, dseen, aseen);
+    }
+    if (bad) return fail(MJH_EUNSUPPORTED, "dc_tbl_no / ac_tbl_no: a component reuses an earlier component's DC table with an AC table no earlier component had -- the reference's DHT writer (emit_multi_dht, jcmarker.c:293-401) writes a corrupt marker for this assignment");
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(MJH_EHIP, "no HIP device available: libmozjpeg_hip has no CPU fallback");

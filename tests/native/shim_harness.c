@@ -194,6 +194,23 @@ int main(int argc, char **argv)
         jpeg_destroy_compress(&c);
         free(o); free(img);
       }
+    } else if (!strcmp(sc, "custom_huffman")) {
+      /* Huffman tables of the application's own with optimize_coding off (two symbols of equal code length swapped in AC table 0):
+       * the reference codes with them; the device path has the Annex K tables or optimal ones -- it must refuse, never code with others */
+      struct jpeg_compress_struct c;
+      unsigned char *o = NULL, *img = make_image(96, 64, 31), t;
+      unsigned long n = 0;
+      c.err = jpeg_std_error(&err);
+      jpeg_create_compress(&c);
+      jpeg_mem_dest(&c, &o, &n);
+      jpeg_c_set_int_param(&c, JINT_COMPRESS_PROFILE, JCP_FASTEST);
+      setup(&c, 96, 64, 75, 1);
+      c.optimize_coding = FALSE;
+      t = c.ac_huff_tbl_ptrs[0]->huffval[0]; c.ac_huff_tbl_ptrs[0]->huffval[0] = c.ac_huff_tbl_ptrs[0]->huffval[1]; c.ac_huff_tbl_ptrs[0]->huffval[1] = t;
+      jpeg_start_compress(&c, TRUE); rows(&c, img, 64); jpeg_finish_compress(&c);
+      printf("custom_huffman %lu %016lx\n", n, hash(o, n));
+      jpeg_destroy_compress(&c);
+      free(o); free(img);
     } else if (!strcmp(sc, "color_spaces")) {
       /* what an application sets in in_color_space / per component besides plain RGB: samples that are YCbCr already (null_convert,
        * jccolor.c:687-692 -- e.g. Pillow's "YCbCr" mode), an extended pixel order with a pad byte, and ONE component whose sampling

@@ -250,6 +250,22 @@ def test_libjpeg_client_scenarios(scenario, mode):
     assert got.stdout == want.stdout, (got.stdout, want.stdout, got.stderr[-500:])
 
 
+@needs_h
+@pytest.mark.parametrize("mode", ["preload", "standalone"])
+def test_huffman_tables_of_the_applications_own_without_optimize_coding_are_refused(mode):
+    """the reference codes with them (jchuff.c start_pass_huff); the device has the Annex K tables or optimal ones: an error with
+    the reason, never a file coded with other tables than the application asked for"""
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    env["LD_LIBRARY_PATH"] = O.REF_DIR
+    if mode == "preload":
+        env["LD_PRELOAD"] = SHIM
+    else:
+        env["LD_LIBRARY_PATH"] = STANDALONE_DIR
+    got = subprocess.run([HARNESS, "custom_huffman"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert got.returncode != 0 and b"Huffman tables of the application's own" in got.stderr and got.stdout == b"", (got.stdout, got.stderr[-500:])
+
+
 @needs
 def test_device_selection_by_environment(goldens, tmp_path):
     """MOZJPEG_HIP_DEVICE pins the drop-in to a GPU (taken modulo the device count, so any value works on a 1-GPU box)"""

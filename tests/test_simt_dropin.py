@@ -116,6 +116,18 @@ def test_libjpeg_client_scenarios_on_the_emulator(fz, scenario):
         assert got.stdout == want.stdout, (kw, got.stdout, want.stdout)
 
 
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="tests/native/shim_harness not built")
+def test_huffman_tables_of_the_applications_own_without_optimize_coding_are_refused(fz):
+    """the reference codes with them (jchuff.c start_pass_huff); the device has the Annex K tables or optimal ones: an error with
+    the reason, never a file coded with other tables than the application asked for"""
+    F, d = fz
+    want = F.run([HARNESS, "custom_huffman"], {})
+    assert want.returncode == 0 and want.stdout.startswith(b"custom_huffman ")
+    for kw in (dict(preload=os.path.join(d, "libmozjpeg_hip_jpeg62.so")), dict(libpath=os.path.join(d, "standalone"))):
+        got = F.run([HARNESS, "custom_huffman"], {}, **kw)
+        assert got.returncode != 0 and b"Huffman tables of the application's own" in got.stderr and got.stdout == b"", (kw, got.stdout, got.stderr)
+
+
 def test_random_command_lines_through_the_shipped_libraries_on_the_emulator():
     """a slice of tools/simt/fuzz_cjpeg.py (random cjpeg / jpegtran command lines, three ways each); the tool's longer runs are
     recorded in profiles/r05z_*"""
