@@ -80,7 +80,7 @@ static void one_image(struct jpeg_compress_struct *c, int tag, int k)
     for (ci = 0; ci < 3; ci++) { c->comp_info[ci].h_samp_factor = f[2 * ci]; c->comp_info[ci].v_samp_factor = f[2 * ci + 1]; }
   } else if (c->num_components == 1 && chance(30)) { c->comp_info[0].h_samp_factor = ri(1, 4); c->comp_info[0].v_samp_factor = chance(70) ? 1 : ri(1, 4); }
   if (chance(15)) for (ci = 0; ci < c->num_components; ci++) { c->comp_info[ci].dc_tbl_no = ri(0, 1); c->comp_info[ci].ac_tbl_no = ri(0, 1); }
-  if (chance(25)) c->optimize_coding = !c->optimize_coding;
+  if (chance(c->optimize_coding ? 6 : 25)) c->optimize_coding = !c->optimize_coding;   /* (switching it OFF under the max-compression profile leaves the trellis without optimal tables: refused, INTEGRATION.md 1a') */
   if (chance(12)) c->arith_code = TRUE;
   i = ri(0, 9);
   if (i <= 2) { c->num_scans = 0; c->scan_info = NULL; }
