@@ -134,7 +134,8 @@ typedef struct {
 #define MJH_COLOR_NONE 1
 #define MJH_COLOR_YCC_IN 2   /* the input samples ARE Y, Cb, Cr (in_color_space = JCS_YCbCr, jpeg_color_space = JCS_YCbCr: null_convert
                               * jccolor.c:479 via jinit_color_converter :687-692): unconverted like MJH_COLOR_NONE, but the file is an
-                              * ordinary YCbCr one -- JFIF APP0, no Adobe marker, YCbCr's progressive scripts */
+                              * ordinary YCbCr one -- JFIF APP0, no Adobe marker, YCbCr's progressive scripts; with num_components = 1 the Y
+                              * samples become a grayscale file (grayscale_convert :448-466) */
 
 typedef struct mjh_encoder mjh_encoder;
 

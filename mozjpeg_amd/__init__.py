@@ -177,7 +177,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     if arith_cond is not None:     # ((L, U, K) of conditioning table 0, (L, U, K) of table 1): cinfo->arith_dc_L / arith_dc_U / arith_ac_K
         for t, (lo, up, kx) in enumerate(arith_cond):
             p.arith_dc_L[t], p.arith_dc_U[t], p.arith_ac_K[t] = lo, up, kx
-    if yccin and p.num_components == 3:    # in_color_space = JCS_YCbCr: the pixels are Y, Cb, Cr already (null_convert jccolor.c:479)
+    if yccin and not grayin:    # in_color_space = JCS_YCbCr: the pixels are Y, Cb, Cr already (null_convert jccolor.c:479)
         p.color_transform = COLOR_YCC_IN
     if rgb:   # cjpeg -rgb: jpeg_set_colorspace(JCS_RGB) (jcparam.c:611-619): all components 1x1 / table 0, ids 'R' 'G' 'B', no JFIF
         p.color_transform = COLOR_NONE

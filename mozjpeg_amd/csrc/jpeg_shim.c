@@ -364,9 +364,10 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
   }
   if (!no_pixels && cinfo->in_color_space == JCS_YCbCr) {
     /* jinit_color_converter jccolor.c:687-692: YCbCr in -> YCbCr out is null_convert (:479); -> grayscale takes the Y samples
-     * (grayscale_convert :448-466), which the device's colour kernels have no mode for */
-    if (!(cinfo->jpeg_color_space == JCS_YCbCr && cinfo->num_components == 3)) return "YCbCr input into anything but a YCbCr file";
-    p->num_components = 3;
+     * (grayscale_convert :448-466): the same null conversion with one component kept */
+    if (cinfo->jpeg_color_space == JCS_YCbCr && cinfo->num_components == 3) p->num_components = 3;
+    else if (cinfo->jpeg_color_space == JCS_GRAYSCALE && cinfo->num_components == 1) p->num_components = 1;
+    else return "YCbCr input into anything but a YCbCr or a grayscale file";
     p->color_transform = MJH_COLOR_YCC_IN;
   } else if (cinfo->jpeg_color_space == JCS_YCbCr && cinfo->num_components == 3) p->num_components = 3;
   else if (cinfo->jpeg_color_space == JCS_GRAYSCALE && cinfo->num_components == 1) p->num_components = 1;
@@ -374,7 +375,8 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
     p->num_components = 3;           /* cjpeg -rgb: null_convert (jccolor.c:479), the samples go through unconverted */
     p->color_transform = MJH_COLOR_NONE;
   } else return "JPEG colour space (only YCbCr / grayscale / RGB)";
-  if (cinfo->write_Adobe_marker && cinfo->jpeg_color_space != JCS_RGB) return "Adobe marker for this colour space";
+  /* an Adobe APP14 marker the application asks for is written by this shim (shim_begin) with the transform code of the file's
+   * colour space; the device writes its own only into RGB files, where it is dropped like the APP0 */
   /* JFIF version / density: the APP0 segment is written by this shim from the cinfo fields (emit_jfif_app0
    * jcmarker.c:422-449), the device's fixed APP0 is dropped, so any values are fine */
   p->image_width = (int)cinfo->image_width;
@@ -529,9 +531,10 @@ static void shim_begin(j_compress_ptr cinfo, boolean write_all_tables, int mode,
     emit_bytes(cinfo, app0, sizeof(app0));
     s->header_bytes += 18;   /* the device file carries the default APP0 at the same place: skipped on output */
   }
-  if (cinfo->write_Adobe_marker) {  /* emit_adobe_app14 jcmarker.c:452-486: version 100, flags 0, transform 0 = RGB */
-    static const unsigned char app14[16] = { 0xFF, 0xEE, 0, 14, 'A', 'd', 'o', 'b', 'e', 0, 100, 0, 0, 0, 0, 0 };
-    emit_bytes(cinfo, app14, sizeof(app14));   /* the device file carries the same 16 bytes: skipped on output */
+  if (cinfo->write_Adobe_marker) {  /* emit_adobe_app14 jcmarker.c:452-486: version 100, flags 0, transform 1 = YCbCr, 2 = YCCK, 0 = anything else */
+    unsigned char app14[16] = { 0xFF, 0xEE, 0, 14, 'A', 'd', 'o', 'b', 'e', 0, 100, 0, 0, 0, 0, 0 };
+    app14[15] = cinfo->jpeg_color_space == JCS_YCbCr ? 1 : cinfo->jpeg_color_space == JCS_YCCK ? 2 : 0;
+    emit_bytes(cinfo, app14, sizeof(app14));   /* (an RGB file from the device carries its own 16 bytes: skipped on output) */
   }
   {
     /* the geometry fields callers read back after jpeg_start_compress (initial_setup jcmaster.c:237-259);

@@ -428,7 +428,8 @@ static int check_supported(const mjh_params *p)
   if (p->num_components != 1 && p->num_components != 3) return fail(MJH_EUNSUPPORTED, "num_components %d", p->num_components);
   if (p->num_components == 3 && p->input_components != 3) return fail(MJH_EUNSUPPORTED, "gray input cannot produce 3 components");
   if (p->color_transform != MJH_COLOR_YCC && p->color_transform != MJH_COLOR_NONE && p->color_transform != MJH_COLOR_YCC_IN) return fail(MJH_EINVAL, "color_transform %d", p->color_transform);
-  if (p->color_transform != MJH_COLOR_YCC && p->num_components != 3) return fail(MJH_EUNSUPPORTED, "MJH_COLOR_NONE / MJH_COLOR_YCC_IN need three components");
+  if (p->color_transform == MJH_COLOR_NONE && p->num_components != 3) return fail(MJH_EUNSUPPORTED, "MJH_COLOR_NONE needs three components");
+  if (p->color_transform == MJH_COLOR_YCC_IN && p->input_components != 3) return fail(MJH_EINVAL, "MJH_COLOR_YCC_IN needs three input samples per pixel");   // (one component out: grayscale_convert takes the Y samples, jccolor.c:448-466)
   if (p->num_components == 1) {
     // One component: its only scans are non-interleaved (per_scan_setup jcmaster.c:548-575: an MCU is one block, no dummy blocks) and
     // max_samp = its own factors (initial_setup :210-259), so the factors change nothing but the SOF byte -- cjpeg sets 2x1 on a

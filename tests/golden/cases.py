@@ -182,6 +182,7 @@ CASES = [
     ("yccin_base", dict(baseline=True, yccin=True), True),
     ("yccin_progressive_422", dict(yccin=True, sample=(2, 1)), True),
     ("yccin_revert_restart1", dict(revert=True, yccin=True, restart=1), True),
+    ("yccin_gray_progressive", dict(yccin=True, gray=True), True),        # YCbCr samples into a grayscale file: the Y samples (grayscale_convert jccolor.c:448-466)
 ]
 
 

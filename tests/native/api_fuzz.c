@@ -64,7 +64,11 @@ static void one_image(struct jpeg_compress_struct *c, int tag, int k)
   jpeg_set_defaults(c);
   jpeg_c_set_bool_param(c, JBOOLEAN_TRELLIS_EOB_OPT, FALSE);    /* (the one extension parameter jpeg_set_defaults leaves as the previous image set it, jcparam.c:495-518) */
   c->dct_method = JDCT_ISLOW;
-  if (chance(20) && ps != 1 && in_cs != JCS_YCbCr) jpeg_set_colorspace(c, chance(50) ? JCS_GRAYSCALE : JCS_RGB);
+  if (chance(20) && ps != 1) {      /* (the script is rebuilt for the new components, as cjpeg does after its colour-space switches) */
+    jpeg_set_colorspace(c, in_cs == JCS_YCbCr || chance(50) ? JCS_GRAYSCALE : JCS_RGB);
+    if (c->num_scans > 0) jpeg_simple_progression(c);
+  }
+  if (chance(8)) c->write_Adobe_marker = !c->write_Adobe_marker;
   if (chance(15)) jpeg_c_set_int_param(c, JINT_BASE_QUANT_TBL_IDX, ri(0, 8));
   i = ri(0, 9);
   if (i <= 5) jpeg_set_quality(c, ri(1, 100), chance(60));

@@ -214,11 +214,11 @@ int main(int argc, char **argv)
     } else if (!strcmp(sc, "color_spaces")) {
       /* what an application sets in in_color_space / per component besides plain RGB: samples that are YCbCr already (null_convert,
        * jccolor.c:687-692 -- e.g. Pillow's "YCbCr" mode), an extended pixel order with a pad byte, and ONE component whose sampling
-       * factors the application chose (cjpeg itself: 2x1 at qualities 80..89) */
+       * factors the application chose (cjpeg itself: 2x1 at qualities 80..89), YCbCr samples into a grayscale file, an Adobe marker on a YCbCr file */
       int v;
-      for (v = 0; v < 5; v++) {
+      for (v = 0; v < 7; v++) {
         struct jpeg_compress_struct c;
-        const int w = 173, h = 121, ps = v == 2 ? 4 : (v >= 3 ? 1 : 3);
+        const int w = 173, h = 121, ps = v == 2 ? 4 : (v == 3 || v == 4 ? 1 : 3);
         unsigned char *o = NULL, *rgb = make_image(w, h, 20 + v), *img = (unsigned char *)malloc((size_t)w * h * 4);
         unsigned long n = 0;
         int x, y;
@@ -234,13 +234,15 @@ int main(int argc, char **argv)
         jpeg_create_compress(&c);
         jpeg_mem_dest(&c, &o, &n);
         c.image_width = w; c.image_height = h; c.input_components = ps;
-        c.in_color_space = v < 2 ? JCS_YCbCr : v == 2 ? JCS_EXT_XBGR : JCS_GRAYSCALE;
+        c.in_color_space = v < 2 || v == 5 ? JCS_YCbCr : v == 2 ? JCS_EXT_XBGR : v == 6 ? JCS_RGB : JCS_GRAYSCALE;
         jpeg_set_defaults(&c);
         c.dct_method = JDCT_ISLOW;
         jpeg_set_quality(&c, 70 + 4 * v, TRUE);
         if (v == 0 || v == 3) { c.num_scans = 0; c.scan_info = NULL; }
         if (v == 1) { c.comp_info[0].h_samp_factor = 2; c.comp_info[0].v_samp_factor = 1; c.restart_in_rows = 2; }
         if (v == 3) { c.comp_info[0].h_samp_factor = 2; c.comp_info[0].v_samp_factor = 1; }
+        if (v == 5) { jpeg_set_colorspace(&c, JCS_GRAYSCALE); jpeg_simple_progression(&c); }      /* (the script is rebuilt for the new component count, as cjpeg does) YCbCr samples into a grayscale file: the Y samples (grayscale_convert jccolor.c:448-466) */
+        if (v == 6) c.write_Adobe_marker = TRUE;                 /* an Adobe APP14 marker next to the JFIF one on a YCbCr file (transform 1, jcmarker.c:597-598) */
         if (v == 4) { c.comp_info[0].h_samp_factor = 1; c.comp_info[0].v_samp_factor = 2; jpeg_c_set_bool_param(&c, JBOOLEAN_TRELLIS_QUANT, FALSE); }
         jpeg_start_compress(&c, TRUE);
         while (c.next_scanline < c.image_height) { JSAMPROW r = img + (size_t)c.next_scanline * w * ps; jpeg_write_scanlines(&c, &r, 1); }

@@ -90,11 +90,6 @@ def test_unsupported_configurations_are_errors_not_fallbacks():
     with pytest.raises(M.MjhError) as ei:
         M.Encoder(p)
     assert ei.value.code == M.EUNSUPPORTED and "vertical sampling factor" in str(ei.value)
-    p = M.make_params(64, 64, baseline=True, gray=True, yccin=True)
-    p.color_transform = M.COLOR_YCC_IN                      # YCbCr samples into a one-component file: no colour-kernel mode takes "the first sample"
-    with pytest.raises(M.MjhError) as ei:
-        M.Encoder(p)
-    assert ei.value.code == M.EUNSUPPORTED
     for dc, ac in (((1, 1, 1), (0, 0, 1)), ((0, 1, 0), (1, 1, 0))):
         # a component reuses an earlier one's DC table with an AC table nobody had: the reference's one-marker DHT writer
         # (emit_multi_dht jcmarker.c:293-401) writes that AC table without its values, outside the marker's length -- a corrupt file
