@@ -351,6 +351,7 @@ struct mjh_encoder {
   std::vector<SeqScan> seq_scans;
   int dht_slots[4] = { 0, 0, 0, 0 }, dht_ids[4] = { 0, 0, 0, 0 }, ndht = 0;
   bool debug_taps = false;
+  int dc_chain_v = 1;           // ... and its vertical factor: the trellis passes' iMCU rows hold that many block rows (the DC chains span them)
   int sof_hv0 = 0;              // one component sampled other than 1x1: the SOF's sampling byte (the geometry is 1x1's, see check_supported)
   bool fdct_div_zero = false;   // a quantization step of 8192 / 16384 / 24576 with 8-bit samples: the reference's FDCT manager divides by zero (pixel / plane input is refused, coefficient input is fine)
   // profiling: 0 off, 1 every kernel, 2 only the dominant kernel (prof_focus).  Events accumulate over the
@@ -434,11 +435,10 @@ static int check_supported(const mjh_params *p)
     // One component: its only scans are non-interleaved (per_scan_setup jcmaster.c:548-575: an MCU is one block, no dummy blocks) and
     // max_samp = its own factors (initial_setup :210-259), so the factors change nothing but the SOF byte -- cjpeg sets 2x1 on a
     // gray image for qualities 80..89 (set_quality_ratings rdswitch.c:566-570) -- EXCEPT through the trellis passes: they walk iMCU
-    // rows of V block rows (compress_trellis_pass jccoefct.c:418-441: lastDC and the row above chain over the V rows).
+    // rows of V block rows (compress_trellis_pass jccoefct.c:418-441: lastDC and the row above chain over the V rows), which is
+    // what the DC trellis kernels do for a component with v > 1 anyway: they get a view of the geometry with that v (dc_chain_v).
     const int h = p->h_samp_factor[0], v = p->v_samp_factor[0];
     if (h < 1 || h > 4 || v < 1 || v > 4) return fail(MJH_EINVAL, "sampling factor %dx%d outside 1..4 (JERR_BAD_SAMPLING)", h, v);
-    if (v != 1 && p->trellis_quant)
-      return fail(MJH_EUNSUPPORTED, "one component with a vertical sampling factor of %d and trellis quantization (the DC trellis' chains would span %d block rows, jccoefct.c:418-441): use V = 1 or switch the trellis off", v, v);
   }
   if (p->num_components == 3) {
     // any sampling factors the reference takes (initial_setup jcmaster.c:210-259, jinit_downsampler jcsample.c:486-535): 1..4 each,
@@ -849,6 +849,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   e->p = *p;
   if (p->num_components == 1 && (p->h_samp_factor[0] != 1 || p->v_samp_factor[0] != 1)) {   // (check_supported: only the SOF byte differs)
     e->sof_hv0 = (p->h_samp_factor[0] << 4) + p->v_samp_factor[0];
+    e->dc_chain_v = p->v_samp_factor[0];
     e->p.h_samp_factor[0] = e->p.v_samp_factor[0] = 1;
   }
   if (p->data_precision == 12) e->p.optimize_coding = 1;   // standard tables are 8-bit only (jcparam.c:452-453, jcmaster.c:1102-1105)
@@ -1381,6 +1382,15 @@ struct Prof {
 
 // input_read (optional) is recorded once the kernels that read the caller's input have been queued; before_output
 // (optional) is waited for before the first kernel that overwrites the output files of the previous batch
+// One component sampled with V > 1: its trellis passes walk iMCU rows of V block rows (compress_trellis_pass jccoefct.c:418-441) although
+// nothing else in the file knows about V -- the kernels that chain the DC trellis get the geometry with that v and its iMCU row count.
+static MjhConst dc_chain_view(const mjh_encoder *e, const MjhConst &CV)
+{
+  MjhConst D = CV;
+  if (e->dc_chain_v > 1 && CV.ncomp == 1) { D.c[0].v = e->dc_chain_v; D.mcu_rows = (CV.c[0].hib + e->dc_chain_v - 1) / e->dc_chain_v; }
+  return D;
+}
+
 static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, size_t image_stride, int n, hipStream_t s,
                         const MjhPlaneSrc *plane_src = nullptr, const MjhCoefSrc *coef_src = nullptr,
                         hipEvent_t input_read = nullptr, hipEvent_t before_output = nullptr)
@@ -1493,7 +1503,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       C0.ncomp = 1;
       for (int r = 0; r < runs; r++) {
         pr.mark("trellis_arith");
-        mjh_launch_trellis_arith(C, e->d_quant, ext_qopt ? 1 : 0, e->d_uq, e->d_q, e->d_lambda, e->d_arith_rates, e->d_back, 1, p.use_scans_in_trellis ? split : 63,
+        mjh_launch_trellis_arith(dc_chain_view(e, C), e->d_quant, ext_qopt ? 1 : 0, e->d_uq, e->d_q, e->d_lambda, e->d_arith_rates, e->d_back, 1, p.use_scans_in_trellis ? split : 63,
                                  p.trellis_quant_dc, p.trellis_delta_dc_weight, e->comp_restart[0], e->progressive ? 1 : 0, n, s);
         if (r < updates) {
           pr.mark("trellis_q_opt(sums)");
@@ -1590,7 +1600,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     const int dc_mode = e->dc_mode;   // experiments (MJH_DC_MODE): 1 = DC trellis on the main stream, before the AC kernel
     if (p.trellis_quant_dc && dc_mode == 1) {
       pr.mark("trellis_dc(serial)");
-      mjh_launch_trellis_dc(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, s, e->dc_window_ok);
+      mjh_launch_trellis_dc(dc_chain_view(e, CV), e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, s, e->dc_window_ok);
     } else if (p.trellis_quant_dc) {
       HIPCHK(hipEventRecord(e->ev_fork, s));
       HIPCHK(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
@@ -1619,7 +1629,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       dc_late = e->dc_late > 0 && !spec && final_dc_here && nloops == 1 && CV.ncomp == 3 && !e->debug_taps && (size_t)n * C.total_real_blocks >= e->small_batch;
       if (spec) mjh_launch_trellis_dc_speculative(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back9, e->d_jfin, e->d_qspec, n, e->side_stream);
       else
-      mjh_launch_trellis_dc(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, e->side_stream, e->dc_window_ok,
+      mjh_launch_trellis_dc(dc_chain_view(e, CV), e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, e->side_stream, e->dc_window_ok,
                             0, dc_late ? e->dc_late * CV.mcu_rows : -1);   // (the DC entries never change: image 0's tables serve all)
       if (pr.enabled && e->profiling == 1) { HIPCHK(hipEventRecord(e->side_events[2 * e->prof_calls + 1], e->side_stream)); e->side_timed = true; }
       if (final_dc_here && !dc_late) {

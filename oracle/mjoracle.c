@@ -783,6 +783,7 @@ typedef struct {
   int last_restart_interval; /* jcmarker.c:660 */
   int progressive;
   int sof_hv0;     /* one component sampled other than 1x1: the SOF's sampling byte (encode_core) */
+  int chain_v;     /* ... and its V: the trellis passes walk iMCU rows of V block rows (0: the component's own v_samp) */
   /* trellis_q_opt: sums over the blocks of sum(raw * quantized) and sum(8 * quantized^2) per table and coefficient
    * (jcdctmgr.c:1299-1306).  Every term is an integer and the totals stay far below 2^53, so the double sums are
    * exact in ANY order -- a parallel reduction reproduces them bit for bit */
@@ -1063,7 +1064,7 @@ static void trellis_component(enc_t *e, int ci, const dtbl *dctbl, const dtbl *a
   const mjo_params *p = e->p;
   const mjo_geom *g = &e->g[ci];
   const uint16_t *qt = p->qtbl[p->quant_tbl_no[ci]];
-  const int v = p->v_samp[ci];
+  const int v = e->chain_v ? e->chain_v : p->v_samp[ci];
   /* trellis_eob_opt state of one block row (jcdctmgr.c:977-993) */
   float *azbc = NULL, *abc = NULL;
   int *block_run_start = NULL, *requires_eob = NULL;
@@ -1618,7 +1619,7 @@ static void trellis_row_arith(enc_t *e, int ci, const ari_rates *r, int br, int 
   const mjo_params *p = e->p;
   const mjo_geom *g = &e->g[ci];
   const uint16_t *qt = p->qtbl[p->quant_tbl_no[ci]];
-  const int v = p->v_samp[ci];
+  const int v = e->chain_v ? e->chain_v : p->v_samp[ci];
   int ncand = (2 + 60 / qt[0]) | 1;
   float lambda_tbl[64];
   int run_start[64];
@@ -1792,7 +1793,7 @@ static void trellis_component_arith(enc_t *e, int ci, int Ss, int Se)
 {
   const mjo_params *p = e->p;
   const mjo_geom *g = &e->g[ci];
-  const int v = p->v_samp[ci];
+  const int v = e->chain_v ? e->chain_v : p->v_samp[ci];
   float *acc_dc[9];
   int *back_dc[9], *ctx_dc[9];
   int16_t *cand_dc[9];
@@ -2138,9 +2139,9 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
      * jcmaster.c:548-575) -- and max_samp = its own factors (initial_setup :210-259), so width / height_in_blocks, the
      * downsampler (h_expand = v_expand = 1: fullsize_downsample / fullsize_smooth_downsample, jcsample.c:507-518) and the restart
      * rows are those of 1x1: only the SOF byte differs.  The exception is the trellis: compress_trellis_pass walks iMCU rows
-     * of V block rows (lastDC and the row above chain over them, jccoefct.c:418-441) -- V > 1 with the trellis is not restated. */
+     * of V block rows (lastDC and the row above chain over them, jccoefct.c:418-441): chain_v. */
     if (pp.h_samp[0] < 1 || pp.h_samp[0] > 4 || pp.v_samp[0] < 1 || pp.v_samp[0] > 4) return 0;
-    if (pp.v_samp[0] != 1 && pp.trellis_quant) return 0;
+    e.chain_v = pp.v_samp[0];
     e.sof_hv0 = (pp.h_samp[0] << 4) + pp.v_samp[0];
     pp.h_samp[0] = pp.v_samp[0] = 1;
   }

@@ -169,7 +169,8 @@ CASES = [
     # ONE component sampled other than 1x1 (SOF byte only: its scans are non-interleaved, per_scan_setup jcmaster.c:548-575).  cjpeg
     # does this to every gray image at qualities 80..89 (set_quality_ratings rdswitch.c:566-570 sets 2x1 on component 0) --
     # tools/simt/fuzz_cjpeg.py found the encoder refusing `cjpeg -quality 85 -grayscale`.  V > 1 only without the trellis
-    # (compress_trellis_pass chains the DC trellis over the V block rows of an iMCU row: not built, refused).
+    # (compress_trellis_pass chains the DC trellis over the V block rows of an iMCU row: the DC trellis kernels get a view of the
+    # geometry with that V -- the gray_*x2* / *x4* cases with the trellis on).
     ("gray_2x1_q85_progressive", dict(gray=True, quality=85, gray_sample=(2, 1)), True),
     ("gray_2x1_q85_base", dict(gray=True, baseline=True, quality=85, gray_sample=(2, 1)), True),
     ("gray_2x1_revert_restart1", dict(gray=True, revert=True, restart=1, gray_sample=(2, 1)), True),
@@ -177,6 +178,10 @@ CASES = [
     ("gray_2x1_arith_fastcrush", dict(gray=True, arithmetic=True, fastcrush=True, gray_sample=(2, 1)), True),
     ("gray_2x2_base_notrellis", dict(gray=True, baseline=True, notrellis=True, gray_sample=(2, 2)), True),
     ("gray_1x2_revert_progressive", dict(gray=True, revert=True, progressive=True, gray_sample=(1, 2)), True),
+    ("gray_2x2_base_trellis", dict(gray=True, baseline=True, gray_sample=(2, 2)), True),
+    ("gray_1x2_progressive_dc_ver_weight2", dict(gray=True, dc_ver_weight=2.0, gray_sample=(1, 2)), True),
+    ("gray_1x4_fastcrush_restart1_eob_opt_loops2", dict(gray=True, fastcrush=True, restart=1, trellis_eob_opt=True, trellis_loops=2, gray_sample=(1, 4)), True),
+    ("gray_2x2_arith_base_q_opt", dict(gray=True, baseline=True, arithmetic=True, trellis_q_opt=True, gray_sample=(2, 2)), True),
     # input samples that are Y, Cb, Cr already (in_color_space = JCS_YCbCr -> null_convert, jccolor.c:687-692, :479): MJH_COLOR_YCC_IN;
     # the fixtures' bytes are simply read as YCbCr
     ("yccin_base", dict(baseline=True, yccin=True), True),

@@ -61,7 +61,9 @@ CASES = [
     ("pgm", ["-quality", "85"]),                                    # a gray image at quality 80..89: component 0 sampled 2x1 (rdswitch.c:566-570)
     ("ppm", ["-quality", "85", "-grayscale", "-baseline"]),
     ("ppm", ["-quality", "88", "-grayscale", "-arithmetic", "-restart", "1"]),
-    ("pgm", ["-revert", "-quality", "75", "-sample", "2x2"]),       # V > 1 on one component: fine without the trellis
+    ("pgm", ["-revert", "-quality", "75", "-sample", "2x2"]),       # V > 1 on one component
+    ("pgm", ["-quality", "75", "-baseline", "-sample", "2x2"]),     # ... with the trellis: its passes walk iMCU rows of V block rows (jccoefct.c:418-441)
+    ("ppm", ["-quality", "75", "-grayscale", "-sample", "1x2", "-trellis-dc-ver-weight", "2.0"]),
     ("pgm", ["-quality", "75", "-baseline", "-sample", "4x1", "-smooth", "20"]),
 ]
 
@@ -83,19 +85,6 @@ def test_unchanged_cjpeg_on_the_emulator_readers_and_one_component_sampling(fz, 
     bad, r0 = F.three_ways(lambda out: [CJPEG, "-dct", "int"] + args + ["-outfile", out, src], d, str(tmp_path), False)
     assert bad is not None, r0.stderr.decode()
     assert bad == []
-
-
-def test_one_component_with_vertical_factor_and_trellis_is_refused_with_the_reason(fz, tmp_path, fixture_images):
-    """compress_trellis_pass chains the DC trellis over the V block rows of an iMCU row (jccoefct.c:418-441): not built for one
-    component -- an error with the reason, never other bytes"""
-    F, d = fz
-    img = fixture_images["syn96x64"]
-    src = str(tmp_path / "in.pgm")
-    with open(src, "wb") as f:
-        f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]) + img[:, :, 1].tobytes())
-    r = F.run([CJPEG, "-quality", "75", "-baseline", "-sample", "2x2", "-outfile", str(tmp_path / "o.jpg"), src], {},
-              preload=os.path.join(d, "libmozjpeg_hip_jpeg62.so"))
-    assert r.returncode != 0 and b"vertical sampling factor" in r.stderr and b"no CPU fallback" in r.stderr
 
 
 HARNESS = os.path.join(ROOT, "tests", "native", "shim_harness")

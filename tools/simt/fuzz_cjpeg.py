@@ -281,7 +281,7 @@ def three_ways(cmd_of, d, tmp, verbose, standalone=True):
             continue
         r = run(cmd_of(out), {}, **kw)
         if r.returncode != 0 and b"vertical sampling factor" in r.stderr and b"no CPU fallback" in r.stderr:
-            KNOWN_REFUSALS.append(name)       # one component, V > 1, trellis on: refused with the reason (check_supported, mjh_encoder.cpp)
+            KNOWN_REFUSALS.append(name)       # (until the end of round 5: one component, V > 1, trellis on; encoded now -- the count has to stay 0)
             continue
         if r.returncode == 0 and [l for l in r.stderr.splitlines() if l.startswith(b"Compressed size")] != [l for l in r0.stderr.splitlines() if l.startswith(b"Compressed size")]:
             bad.append("%s: -memdst reports %r, the reference %r" % (name, r.stderr[-60:], r0.stderr[-60:]))

@@ -105,11 +105,11 @@ def draw(rng):
         kw["lambda1"] = float(rng.choice([-2.0, 0.0, 8.5, 14.75, 20.0]))
         kw["lambda2"] = float(rng.choice([0.0, 8.0, 16.5, 22.0]))
     # (drawn after everything else, so that the earlier draws of a seed stay what they were)  input samples that are YCbCr already;
-    # one component with sampling factors of its own (cjpeg: 2x1 at qualities 80..89) -- V > 1 only where no trellis pass runs
+    # one component with sampling factors of its own (cjpeg: 2x1 at qualities 80..89)
     if rng.random() < 0.08 and not kw.get("gray"):
         kw["yccin"] = True
     if kw.get("gray") and rng.random() < 0.3:
-        kw["gray_sample"] = (int(rng.integers(1, 5)), int(rng.integers(1, 5)) if (kw.get("revert") or kw.get("notrellis")) else 1)
+        kw["gray_sample"] = (int(rng.integers(1, 5)), int(rng.integers(1, 5)))
     return w, h, kw, int(rng.integers(0, 3))
 
 
