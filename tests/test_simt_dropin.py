@@ -117,6 +117,28 @@ def test_huffman_tables_of_the_applications_own_without_optimize_coding_are_refu
         assert got.returncode != 0 and b"Huffman tables of the application's own" in got.stderr and got.stdout == b"", (kw, got.stdout, got.stderr)
 
 
+MT_BENCH = os.path.join(ROOT, "tests", "native", "mt_bench")
+
+
+@pytest.mark.skipif(not os.path.exists(MT_BENCH), reason="tests/native/mt_bench not built")
+@pytest.mark.parametrize("cfg", [["8", "6", "97", "61", "75", "baseline"], ["6", "4", "200", "130", "85"], ["16", "3", "64", "64", "60", "baseline"]])
+def test_many_client_threads_through_the_batcher_on_the_emulator(fz, cfg):
+    """tests/native/mt_bench.c: T threads, each with its own compress object, N images each -- through the shim's cross-thread
+    batcher (and with MOZJPEG_HIP_BATCH=0) and through the stand-alone library; every thread's first file and the byte total equal
+    the reference's"""
+    import json
+    F, d = fz
+    want = F.run([MT_BENCH] + cfg, {})
+    assert want.returncode == 0, want.stderr.decode()
+    w = json.loads(want.stdout.decode().strip().splitlines()[-1])
+    for kw, env in ((dict(preload=os.path.join(d, "libmozjpeg_hip_jpeg62.so")), {}), (dict(preload=os.path.join(d, "libmozjpeg_hip_jpeg62.so")), {"MOZJPEG_HIP_BATCH": "0"}),
+                    (dict(libpath=os.path.join(d, "standalone")), {})):
+        got = F.run([MT_BENCH] + cfg, env, **kw)
+        assert got.returncode == 0, got.stderr.decode()[-1500:]
+        g = json.loads(got.stdout.decode().strip().splitlines()[-1])
+        assert (g["jpeg_bytes_per_image"], g["fnv1a_first"]) == (w["jpeg_bytes_per_image"], w["fnv1a_first"]), (kw, env)
+
+
 def test_random_command_lines_through_the_shipped_libraries_on_the_emulator():
     """a slice of tools/simt/fuzz_cjpeg.py (random cjpeg / jpegtran command lines, three ways each); the tool's longer runs are
     recorded in profiles/r05z_*"""
