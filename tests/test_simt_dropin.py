@@ -146,3 +146,14 @@ def test_random_command_lines_through_the_shipped_libraries_on_the_emulator():
                        stderr=subprocess.STDOUT, timeout=900)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
     assert b" 0 failures" in r.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "tests", "native", "api_fuzz")), reason="tests/native/api_fuzz not built")
+def test_random_libjpeg_calls_through_the_shipped_libraries_on_the_emulator():
+    """a slice of tools/simt/fuzz_api.py (tests/native/api_fuzz.c: parameters and calls drawn from a seed; the reference with a new
+    object per image, INTEGRATION.md 1a'); refusals with a reason are tallied by the tool, anything else is a failure"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "simt", "fuzz_api.py"), "7", "50"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    assert b" 0 failures" in r.stdout
+
