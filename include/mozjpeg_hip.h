@@ -128,6 +128,28 @@ typedef struct {
    * mjh_params_defaults sets the library defaults 0 / 1 / 5 (jcparam.c:417-419); a table whose three values are all 0 (a
    * zeroed struct of an older caller; Kx = 0 is not a valid conditioning) is read as those defaults.  0 <= L <= U <= 15, 1 <= K <= 63. */
   int arith_dc_L[2], arith_dc_U[2], arith_ac_K[2];
+  /* cinfo->Ah / cinfo->Al as the compress object holds them when the image STARTS.  The trellis passes of a progressive image
+   * gather their statistics through jcphuff.c with whatever these fields hold -- select_scan_parameters sets Ss / Se for those
+   * passes and nothing else (jcmaster.c:451-466): 0 / 0 in a new object, the last coded scan's values when the
+   * object has compressed an image before (refinement statistics after a script that ends with a refinement scan, first-pass
+   * statistics at the best chroma Al after a scan search).  Read only with num_scans > 0 and trellis_quant. */
+  int trellis_stats_Ah, trellis_stats_Al;
+  /* cinfo->dc_huff_tbl_ptrs[t] / ac_huff_tbl_ptrs[t] as the object holds them when the image starts, for the two uses the
+   * reference has for them: (1) optimize_coding off: the tables the scans are coded with and the DHT markers carry
+   * (start_pass_huff -> jpeg_make_c_derived_tbl jchuff.c:190-196, :231-318); (2) a progressive image with the DC trellis: the
+   * rates of the DC candidates, because no pass in front of the trellis makes a DC table (compress_trellis_pass
+   * jccoefct.c:388-389).  Bit 2 t + is_ac of huff_tables_given says slot t's DC / AC table is given in
+   * huff_bits[2 t + is_ac][0..16] (counts per code length, [0] unused) and huff_vals[2 t + is_ac][] (symbols in code order);
+   * a slot not given holds the Annex K.3 table for t = 0, 1 (what jpeg_set_defaults installs) and nothing for t = 2, 3.
+   * A table must be a legal code (the checks of jpeg_make_c_derived_tbl: JERR_BAD_HUFF_TABLE), DC symbols 0..15; a symbol the
+   * image needs and the table lacks is coded with no bits, as jchuff.c does. */
+  int huff_tables_given;
+  uint8_t huff_bits[8][17];
+  uint8_t huff_vals[8][256];
+  /* cinfo->dct_method (jpeglib.h:456): 0 = JDCT_ISLOW (jfdctint.c), 1 = JDCT_IFAST (jfdctfst.c: AA&N with 8-bit constants,
+   * its scale factors folded into the divisors, jcdctmgr.c:291-345) -- what the legacy TurboJPEG calls select below quality 96
+   * (turbojpeg.c:522-527) and `cjpeg -dct fast`.  8-bit samples only. */
+  int dct_method;
 } mjh_params;
 
 #define MJH_COLOR_YCC  0
@@ -277,6 +299,13 @@ int mjh_get_jpeg(mjh_encoder *e, int i, void *dst, size_t cap, size_t *size);
 /* Device-side view of the outputs of the last batch: file i starts at base + i*stride and is
  * sizes[i] bytes long (sizes is a device pointer to uint32). */
 int mjh_get_output_device(mjh_encoder *e, void **d_base, size_t *stride, void **d_sizes);
+
+/* The Huffman table entry `scan` of the scan script was coded with in image `image` of the last batch: bits[0..16] (counts per
+ * code length) and the symbols in code order.  Progressive encoders only; tblno selects the DC table of a DC scan (the number its
+ * components carry in dc_tbl_no, 0 or 1) and is ignored for AC scans.  A scan search codes all its candidates, also those the file
+ * leaves out: the libjpeg drop-in keeps the object's table slots as the reference's last coded scans leave them
+ * (jpeg_gen_optimal_table writes into cinfo->dc_huff_tbl_ptrs / ac_huff_tbl_ptrs, jchuff.c:1092-1105).  Synchronises. */
+int mjh_get_scan_table(mjh_encoder *e, int image, int scan, int tblno, uint8_t bits[17], uint8_t vals[256]);
 
 /* ---- introspection for parity tests and profiling ------------------------------------- */
 enum {

@@ -49,7 +49,9 @@ class Params(C.Structure):
                 ("dc_scan_opt_mode", C.c_int), ("trellis_delta_dc_weight", C.c_float),
                 ("use_scans_in_trellis", C.c_int), ("trellis_freq_split", C.c_int),
                 ("trellis_eob_opt", C.c_int), ("trellis_q_opt", C.c_int), ("arith_code", C.c_int),
-                ("arith_dc_L", C.c_int * 2), ("arith_dc_U", C.c_int * 2), ("arith_ac_K", C.c_int * 2)]
+                ("arith_dc_L", C.c_int * 2), ("arith_dc_U", C.c_int * 2), ("arith_ac_K", C.c_int * 2),
+                ("trellis_stats_Ah", C.c_int), ("trellis_stats_Al", C.c_int), ("huff_tables_given", C.c_int),
+                ("huff_bits", (C.c_uint8 * 17) * 8), ("huff_vals", (C.c_uint8 * 256) * 8), ("dct_method", C.c_int)]
 
 
 class Result(C.Structure):

@@ -448,8 +448,7 @@ static void install_std_table(j_compress_ptr cinfo, JHUFF_TBL **slot, int is_ac,
 { /* add_huff_table jstdhuff.c:20-47 */
   const uint8_t *bits, *vals;
   int n;
-  if (*slot == NULL) *slot = jpeg_alloc_huff_table((j_common_ptr)cinfo);
-  else return;   /* jstdhuff.c:28-29: an existing table is left alone */
+  if (*slot == NULL) *slot = jpeg_alloc_huff_table((j_common_ptr)cinfo);   /* (jstdhuff.c:26-29: only a DEcompressor leaves an existing table alone -- a compressor gets the Annex K table back, unsent) */
   mjh_std_huffman_table(is_ac, tblno, &bits, &vals, &n);
   memcpy((*slot)->bits, bits, 17);
   memset((*slot)->huffval, 0, sizeof((*slot)->huffval));

@@ -45,6 +45,8 @@ typedef struct shim_state {
   int total_passes;          /* what the reference's master would report to a progress monitor */
   struct batcher *bt;        /* pixel input: the batcher of this parameter set (concurrent clients are coalesced, below) */
   int reading_arena;         /* >= 0: this object's file lies in that result arena of the batch encoder until it has been handed over */
+  int end_dc;                /* scan search: bit t = end_dc_bits / vals[t] is the DC table the search's last coded DC scan left in slot t */
+  unsigned char end_dc_bits[2][17], end_dc_vals[2][256];
   struct shim_state *next;
 } shim_state;
 
@@ -78,12 +80,12 @@ static int pick_device(void)
       t_device = g_next_device++ % n;
       pthread_mutex_unlock(&g_lock);
     }
-    /* several GPUs: this client thread stages its rows into ITS device's pinned buffers from now on -- it runs on the CPUs
-     * of that device's NUMA node (mjh_numa.cpp; MOZJPEG_HIP_BIND=0 leaves the thread where the application put it, =1 binds
-     * on a one-GPU host too) */
+    /* MOZJPEG_HIP_BIND=1: this client thread stages its rows into ITS device's pinned buffers from now on, so it may be moved
+     * to the CPUs of that device's NUMA node (mjh_numa.cpp).  Opt-in: the reference never touches a caller's scheduling, and an
+     * affinity mask set on an application thread is inherited by every thread it starts afterwards. */
     {
       const char *b = getenv("MOZJPEG_HIP_BIND");
-      if (b ? atoi(b) != 0 : n > 1) (void)mjh_bind_thread_to_device(t_device);
+      if (b && atoi(b) != 0) (void)mjh_bind_thread_to_device(t_device);
     }
   }
   return t_device;
@@ -191,6 +193,33 @@ static void batcher_done_reading(batcher *b, int arena)
   pthread_mutex_unlock(&b->m);
 }
 
+/* A scan search codes every candidate scan, and what the object's DC table slots hold afterwards is the table of the LAST CODED
+ * scan that used the slot -- chroma: the Cr-alone candidate (jcparam.c:817-822), whether or not the file carries it.  The file
+ * tells the other slots; these come from the encoder while the image's tables are still there (image `index` of enc's last batch). */
+static void fetch_end_tables(shim_state *s, mjh_encoder *enc, int index)
+{
+  int si, k, t;
+  s->end_dc = 0;
+  if (!s->p.optimize_scans || s->p.arith_code) return;
+  for (t = 0; t < 2; t++) {
+    int last = -1;
+    for (si = 0; si < s->p.num_scans; si++) {
+      const mjh_scan *sc = &s->p.scan_info[si];
+      if (sc->Ss != 0 || sc->Ah != 0) continue;
+      for (k = 0; k < sc->comps_in_scan; k++) if (s->p.dc_tbl_no[sc->component_index[k]] == t) last = si;
+    }
+    if (last >= 0 && mjh_get_scan_table(enc, index, last, t, s->end_dc_bits[t], s->end_dc_vals[t]) == MJH_OK) s->end_dc |= 1 << t;
+  }
+  if (getenv("SHIM_DEBUG_TABLES")) {
+    static const int cand[4] = { 0, 23, 24, 25 };
+    for (k = 0; k < 4; k++) for (t = 0; t < 2; t++) {
+      unsigned char b[17], v[256]; int j;
+      if (mjh_get_scan_table(enc, index, cand[k], t, b, v) != MJH_OK) continue;
+      fprintf(stderr, "scan %d t %d:", cand[k], t); for (j = 0; j < 17; j++) fprintf(stderr, " %d", b[j]); fprintf(stderr, " |"); for (j = 0; j < 12; j++) fprintf(stderr, " %d", v[j]); fprintf(stderr, "\n");
+    }
+  }
+}
+
 /* jpeg_finish_compress of a pixel-input object whose batcher has seen company: returns MJH_OK with *file / *n pointing into the
  * batch encoder's result arena (valid until batcher_done_reading(b, *arena)), BATCH_PRIVATE, or an encoder error */
 static int batched_encode(shim_state *s, const unsigned char **file, size_t *n, int *arena)
@@ -219,6 +248,7 @@ static int batched_encode(shim_state *s, const unsigned char **file, size_t *n, 
       if (rc == MJH_OK) rc = mjh_encode_gather(b->enc, encs, k);
       if (rc == MJH_OK) rc = mjh_collect(b->enc, 0, &base, &res, &cnt);
       if (rc == MJH_OK && cnt != k) rc = MJH_EHIP;
+      for (i = 0; rc == MJH_OK && i < k; i++) fetch_end_tables(mem[i]->s, b->enc, i);   /* (before the next batch overwrites them) */
       pthread_mutex_lock(&b->m);
       for (i = 0; i < k; i++) {
         mem[i]->rc = rc; mem[i]->arena = ar;
@@ -303,6 +333,251 @@ static void emit_bytes(j_compress_ptr cinfo, const unsigned char *p, size_t n)
   }
 }
 
+/* ---- DQT / DHT markers under the reference's sent_table protocol ----------------------------------------------------------
+ * The device writes a COMPLETE file: every table in front of the first scan that needs it, as a compress object does whose
+ * tables are all unsent.  What a libjpeg client may ask for on top of that lives in the object, not in the image: a table whose
+ * `sent_table` flag is set is left out (abbreviated datastreams: jpeg_write_tables / jpeg_suppress_tables /
+ * jpeg_start_compress(cinfo, FALSE); libjpeg.txt "Abbreviated datastreams and multiple images"), every table written gets the
+ * flag, and the two marker layouts (one marker per table, or mozjpeg's one marker for all of them) are chosen per call from
+ * the flags.  The shim therefore writes the table markers itself, from the object's table slots, with the reference's own
+ * rules; the device's file supplies the table CONTENTS (optimal Huffman tables, re-estimated quantization tables: copied into
+ * the slots first, unsent, as jpeg_gen_optimal_table leaves them, jchuff.c:1104-1105) and everything that is not a table.
+ * Restated from jcmarker.c: emit_dqt :149-186, emit_multi_dqt :189-254, emit_dht :257-290, emit_multi_dht :293-401 (including
+ * the way its sizing loop skips a component's AC table behind a DC table that was sent or seen -- the reference's bytes, whatever
+ * one thinks of them), write_frame_header :674-697, write_scan_header :757-775. */
+static const unsigned char shim_zz[DCTSIZE2] = {
+  0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+  35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
+
+static void emit_2(j_compress_ptr cinfo, int v) { emit_byte(cinfo, (v >> 8) & 0xFF); emit_byte(cinfo, v & 0xFF); }
+
+static int qtbl_wide(const JQUANT_TBL *q)
+{
+  int i, wide = 0;
+  for (i = 0; i < DCTSIZE2; i++) if (q->quantval[i] > 255) wide = 1;
+  return wide;
+}
+
+static void tw_qtbl_body(j_compress_ptr cinfo, JQUANT_TBL *q, int index, int wide)
+{
+  int i;
+  emit_byte(cinfo, index + (wide << 4));
+  for (i = 0; i < DCTSIZE2; i++) {
+    const unsigned int v = q->quantval[shim_zz[i]];
+    if (wide) emit_byte(cinfo, (int)(v >> 8));
+    emit_byte(cinfo, (int)(v & 0xFF));
+  }
+  q->sent_table = TRUE;
+}
+
+static void tw_frame_tables(j_compress_ptr cinfo)
+{
+  int ci, one_marker = cinfo->master->compress_profile != JCP_FASTEST;
+  for (ci = 0; ci < cinfo->num_components && one_marker; ci++) {   /* one marker for all: only while nothing has been sent */
+    const JQUANT_TBL *q = cinfo->quant_tbl_ptrs[cinfo->comp_info[ci].quant_tbl_no];
+    if (q == NULL || q->sent_table) one_marker = 0;
+  }
+  if (one_marker) {
+    int size = 2, counted[NUM_QUANT_TBLS] = { 0, 0, 0, 0 };
+    for (ci = 0; ci < cinfo->num_components; ci++) {
+      const int t = cinfo->comp_info[ci].quant_tbl_no;
+      if (!counted[t]) { size += DCTSIZE2 * (qtbl_wide(cinfo->quant_tbl_ptrs[t]) + 1) + 1; counted[t] = 1; }
+    }
+    emit_byte(cinfo, 0xFF); emit_byte(cinfo, 0xDB);
+    emit_2(cinfo, size);
+    for (ci = 0; ci < cinfo->num_components; ci++) {
+      const int t = cinfo->comp_info[ci].quant_tbl_no;
+      JQUANT_TBL *q = cinfo->quant_tbl_ptrs[t];
+      if (!q->sent_table) tw_qtbl_body(cinfo, q, t, qtbl_wide(q));
+    }
+    return;
+  }
+  for (ci = 0; ci < cinfo->num_components; ci++) {
+    const int t = cinfo->comp_info[ci].quant_tbl_no;
+    JQUANT_TBL *q = cinfo->quant_tbl_ptrs[t];
+    if (q == NULL) FAIL_WITH_STATE(cinfo, ERREXIT1(cinfo, JERR_NO_QUANT_TABLE, t));
+    if (!q->sent_table) {
+      const int wide = qtbl_wide(q);
+      emit_byte(cinfo, 0xFF); emit_byte(cinfo, 0xDB);
+      emit_2(cinfo, wide ? DCTSIZE2 * 2 + 1 + 2 : DCTSIZE2 + 1 + 2);
+      tw_qtbl_body(cinfo, q, t, wide);
+    }
+  }
+}
+
+static int htbl_count(const JHUFF_TBL *h) { int l, n = 0; for (l = 1; l <= 16; l++) n += h->bits[l]; return n; }
+
+static void tw_htbl_body(j_compress_ptr cinfo, JHUFF_TBL *h, int id, int nvals)
+{
+  int i;
+  emit_byte(cinfo, id);
+  for (i = 1; i <= 16; i++) emit_byte(cinfo, h->bits[i]);
+  for (i = 0; i < nvals; i++) emit_byte(cinfo, h->huffval[i]);
+  h->sent_table = TRUE;
+}
+
+/* the tables in front of one scan's SOS: comps in scan order */
+static void tw_scan_tables(j_compress_ptr cinfo, jpeg_component_info *const *comps, int n, int Ss, int Se, int Ah)
+{
+  const int want_dc = Ss == 0 && Ah == 0, want_ac = Se != 0;
+  int i, j;
+  if (cinfo->master->compress_profile != JCP_FASTEST) {
+    /* one marker: sized in a first loop over the components, written in a second one */
+    int length = 2, nd[MAX_COMPS_IN_SCAN] = { 0, 0, 0, 0 }, na[MAX_COMPS_IN_SCAN] = { 0, 0, 0, 0 };
+    const JHUFF_TBL *dseen[NUM_HUFF_TBLS] = { NULL, NULL, NULL, NULL }, *aseen[NUM_HUFF_TBLS] = { NULL, NULL, NULL, NULL };
+    for (i = 0; i < n; i++) {
+      const int d = comps[i]->dc_tbl_no, a = comps[i]->ac_tbl_no;
+      const JHUFF_TBL *dt = cinfo->dc_huff_tbl_ptrs[d], *at = cinfo->ac_huff_tbl_ptrs[a];
+      int dup = 0;
+      if (want_dc) {
+        if (dt == NULL) FAIL_WITH_STATE(cinfo, ERREXIT1(cinfo, JERR_NO_HUFF_TABLE, d));
+        if (dt->sent_table) continue;                       /* (past this component's AC table as well) */
+        for (j = 0; j < NUM_HUFF_TBLS; j++) dup += dt == dseen[j];
+        if (dup) continue;
+        dseen[i] = dt;
+        length += (nd[i] = htbl_count(dt)) + 16 + 1;
+      }
+      if (want_ac) {
+        if (at == NULL) FAIL_WITH_STATE(cinfo, ERREXIT1(cinfo, JERR_NO_HUFF_TABLE, a + 0x10));
+        if (at->sent_table) continue;
+        for (dup = 0, j = 0; j < NUM_HUFF_TBLS; j++) dup += at == aseen[j];
+        if (dup) continue;
+        aseen[i] = at;
+        length += (na[i] = htbl_count(at)) + 16 + 1;
+      }
+    }
+    if (length <= 65535) {
+      emit_byte(cinfo, 0xFF); emit_byte(cinfo, 0xC4);
+      emit_2(cinfo, length);
+      for (i = 0; i < n; i++) {
+        JHUFF_TBL *dt = cinfo->dc_huff_tbl_ptrs[comps[i]->dc_tbl_no], *at = cinfo->ac_huff_tbl_ptrs[comps[i]->ac_tbl_no];
+        if (want_dc && !dt->sent_table) tw_htbl_body(cinfo, dt, comps[i]->dc_tbl_no, nd[i]);
+        if (want_ac && !at->sent_table) tw_htbl_body(cinfo, at, comps[i]->ac_tbl_no + 0x10, na[i]);
+      }
+      return;
+    }
+  }
+  for (i = 0; i < n; i++) {          /* one marker per table not sent yet */
+    int which;
+    for (which = 0; which < 2; which++) {
+      const int t = which ? comps[i]->ac_tbl_no : comps[i]->dc_tbl_no;
+      JHUFF_TBL *h = which ? cinfo->ac_huff_tbl_ptrs[t] : cinfo->dc_huff_tbl_ptrs[t];
+      if (which ? !want_ac : !want_dc) continue;
+      if (h == NULL) FAIL_WITH_STATE(cinfo, ERREXIT1(cinfo, JERR_NO_HUFF_TABLE, t + (which ? 0x10 : 0)));
+      if (!h->sent_table) {
+        const int nv = htbl_count(h);
+        emit_byte(cinfo, 0xFF); emit_byte(cinfo, 0xC4);
+        emit_2(cinfo, nv + 2 + 1 + 16);
+        tw_htbl_body(cinfo, h, t + (which ? 0x10 : 0), nv);
+      }
+    }
+  }
+}
+
+/* first marker at or behind p that is neither a stuffed zero, a fill byte nor RSTn: the end of a scan's entropy-coded data */
+static const unsigned char *scan_data_end(const unsigned char *p, const unsigned char *end)
+{
+  while (p < end && (p = (const unsigned char *)memchr(p, 0xFF, (size_t)(end - p))) != NULL) {
+    if (p + 1 >= end) break;
+    if (p[1] == 0 || (p[1] >= 0xD0 && p[1] <= 0xD7)) p += 2;
+    else if (p[1] == 0xFF) p++;
+    else return p;
+  }
+  return end;
+}
+
+/* The device's file from its frame header on (p: the first DQT) goes to the destination manager: tables through the writers
+ * above, the rest as it is.  own_tables: this image's Huffman tables were made for it on the device (optimize_coding, forced or
+ * asked for) -- they replace what the slots hold, and count as unsent; otherwise the file's tables ARE the slots' (the encoder got
+ * them from there) and only the flags decide.  The quantization tables are copied back where the device re-estimated them
+ * (trellis_q_opt: jcmaster.c:1016-1030 writes cinfo->quant_tbl_ptrs too, flags untouched).  On return cinfo->Ss / Se / Ah / Al are
+ * what the reference's last select_scan_parameters call of the image leaves (jcmaster.c:468-512). */
+static void hand_over_file(j_compress_ptr cinfo, const shim_state *s, const unsigned char *p, const unsigned char *end)
+{
+  const int own_tables = !cinfo->arith_code && (s->p.optimize_coding || s->p.data_precision == 12);
+  const int one_scan = s->p.num_scans == 0;
+  int search_al = -1, last[4] = { 0, DCTSIZE2 - 1, 0, 0 };
+  const unsigned char *held[4];
+  int nheld = 0, k;
+  /* frame header: DQT ... SOF */
+  while (p + 4 <= end && p[0] == 0xFF && p[1] == 0xDB) {
+    const unsigned char *q = p + 4, *qe = p + 2 + ((p[2] << 8) | p[3]);
+    if (s->p.trellis_quant && s->p.trellis_q_opt)
+      while (q < qe) {
+        const int wide = q[0] >> 4, t = q[0] & 15;
+        JQUANT_TBL *qt = t < NUM_QUANT_TBLS ? cinfo->quant_tbl_ptrs[t] : NULL;
+        q++;
+        for (k = 0; k < DCTSIZE2; k++, q += 1 + wide) if (qt) qt->quantval[shim_zz[k]] = (UINT16)(wide ? (q[0] << 8) | q[1] : q[0]);
+      }
+    p = qe;
+  }
+  tw_frame_tables(cinfo);
+  for (;;) {
+    /* one scan: DHT / DAC / DRI ... SOS, entropy-coded data */
+    jpeg_component_info *comps[MAX_COMPS_IN_SCAN];
+    int n, Ss, Se, Ah, Al;
+    nheld = 0;
+    while (p + 4 <= end && p[0] == 0xFF && p[1] != 0xDA && p[1] != 0xD9) {
+      const unsigned char *seg_end = p + 2 + ((p[2] << 8) | p[3]);
+      if (seg_end > end) seg_end = end;
+      if (p[1] == 0xC4) {
+        const unsigned char *q = p + 4;
+        while (own_tables && q + 17 <= seg_end) {
+          const int ac = q[0] >> 4, t = q[0] & 15;
+          JHUFF_TBL **slot = t < NUM_HUFF_TBLS ? (ac ? &cinfo->ac_huff_tbl_ptrs[t] : &cinfo->dc_huff_tbl_ptrs[t]) : NULL;
+          int nv = 0;
+          for (k = 1; k <= 16; k++) nv += q[k];
+          if (slot) {
+            if (*slot == NULL) *slot = jpeg_alloc_huff_table((j_common_ptr)cinfo);
+            (*slot)->bits[0] = 0;
+            memcpy((*slot)->bits + 1, q + 1, 16);
+            memcpy((*slot)->huffval, q + 17, (size_t)(nv < 256 ? nv : 256));
+            (*slot)->sent_table = FALSE;
+          }
+          q += 17 + nv;
+        }
+      } else if (nheld < 4) held[nheld++] = p;      /* SOF in front of the first scan, DAC, DRI: behind the tables, in the device's order */
+      p = seg_end;
+    }
+    if (p + 4 > end || p[1] == 0xD9) {
+      for (k = 0; k < nheld; k++) emit_bytes(cinfo, held[k], (size_t)(2 + ((held[k][2] << 8) | held[k][3])));
+      if (p + 2 <= end) emit_bytes(cinfo, p, 2);
+      break;
+    }
+    /* p: SOS -- Ls, Ns, (Cs, Td/Ta) x Ns, Ss, Se, Ah/Al */
+    n = p[4] <= MAX_COMPS_IN_SCAN ? p[4] : MAX_COMPS_IN_SCAN;
+    for (k = 0; k < n; k++) {
+      int ci;
+      comps[k] = &cinfo->comp_info[0];
+      for (ci = 0; ci < cinfo->num_components; ci++) if (cinfo->comp_info[ci].component_id == p[5 + 2 * k]) { comps[k] = &cinfo->comp_info[ci]; break; }
+    }
+    Ss = p[5 + 2 * n]; Se = p[6 + 2 * n]; Ah = p[7 + 2 * n] >> 4; Al = p[7 + 2 * n] & 15;
+    /* the SOF travels with the frame header, in front of the first scan's tables */
+    k = 0;
+    if (nheld && held[0][1] >= 0xC0 && held[0][1] <= 0xCF && held[0][1] != 0xC4 && held[0][1] != 0xCC) { emit_bytes(cinfo, held[0], (size_t)(2 + ((held[0][2] << 8) | held[0][3]))); k = 1; }
+    if (!cinfo->arith_code) tw_scan_tables(cinfo, comps, n, Ss, Se, Ah);
+    for (; k < nheld; k++) emit_bytes(cinfo, held[k], (size_t)(2 + ((held[k][2] << 8) | held[k][3])));
+    last[0] = Ss; last[1] = Se; last[2] = Ah; last[3] = Al;
+    if (Ss > 0 && Ah == 0 && comps[0] == &cinfo->comp_info[cinfo->num_components - 1]) search_al = Al;
+    if (one_scan) { emit_bytes(cinfo, p, (size_t)(end - p)); break; }
+    {
+      const unsigned char *e = scan_data_end(p + 2 + ((p[2] << 8) | p[3]), end);
+      emit_bytes(cinfo, p, (size_t)(e - p));
+      p = e;
+    }
+  }
+  for (k = 0; k < 2; k++)
+    if (s->end_dc >> k & 1) {
+      JHUFF_TBL **slot = &cinfo->dc_huff_tbl_ptrs[k];
+      if (*slot == NULL) *slot = jpeg_alloc_huff_table((j_common_ptr)cinfo);
+      memcpy((*slot)->bits, s->end_dc_bits[k], 17);
+      memcpy((*slot)->huffval, s->end_dc_vals[k], 256);
+      (*slot)->sent_table = TRUE;
+    }
+  if (s->p.optimize_scans && search_al >= 0) { last[2] = 0; last[3] = search_al; }   /* the search's last coded scan: a frequency split of the last component at its best Al (jcmaster.c:482-495) */
+  cinfo->Ss = last[0]; cinfo->Se = last[1]; cinfo->Ah = last[2]; cinfo->Al = last[3];
+}
+
 /* minimal marker writer so that jpeg_write_marker / jpeg_write_m_header keep working
  * (jcmarker.c:590-615) between jpeg_start_compress and the first scanline */
 static void mw_header(j_compress_ptr cinfo, int marker, unsigned int datalen)
@@ -336,6 +611,13 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
     /* cjpeg -arithmetic; the conditioning of tables 0 / 1 as the application set it (jpeg_set_defaults: 0 / 1 / 5, jcparam.c:417-419) */
     for (i = 0; i < 2; i++) { p->arith_dc_L[i] = cinfo->arith_dc_L[i]; p->arith_dc_U[i] = cinfo->arith_dc_U[i]; p->arith_ac_K[i] = cinfo->arith_ac_K[i]; }
     p->arith_code = 1;
+    /* (mjh_params reads a table with L = U = K = 0 as "not set: the defaults 0 / 1 / 5"; an application that really conditions a
+     * table it uses that way would get other bytes than the reference writes) */
+    for (ci = 0; ci < cinfo->num_components; ci++) {
+      const int td = cinfo->comp_info[ci].dc_tbl_no, ta = cinfo->comp_info[ci].ac_tbl_no;
+      if ((td >= 0 && td < 2 && ta >= 0 && ta < 2) && ((!cinfo->arith_dc_L[td] && !cinfo->arith_dc_U[td] && !cinfo->arith_ac_K[td]) || (!cinfo->arith_dc_L[ta] && !cinfo->arith_dc_U[ta] && !cinfo->arith_ac_K[ta])))
+        return "arithmetic conditioning L = U = K = 0 for a table in use";
+    }
   }
   if (cinfo->master->lossless) return "lossless mode";
   p->smoothing_factor = cinfo->smoothing_factor;   /* cjpeg -smooth N; ignored for raw data / coefficients like in the reference */
@@ -410,7 +692,6 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
   p->trellis_num_loops = jpeg_c_get_int_param(cinfo, JINT_TRELLIS_NUM_LOOPS);
   if (p->trellis_num_loops < 1 || p->trellis_num_loops > 16) return "trellis_num_loops outside 1..16";
   if (p->arith_code) p->optimize_coding = 0;   /* jinit_c_master_control, jcmaster.c:1088-1089 */
-  if (p->trellis_quant && !p->optimize_coding && !p->arith_code) return "trellis without optimize_coding";
   p->restart_interval = cinfo->restart_interval;
   p->restart_in_rows = cinfo->restart_in_rows;
   if (cinfo->scan_info != NULL && cinfo->num_scans > 0) {
@@ -432,24 +713,42 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
      * multi-scan file (validate_script :309-330) and keeps the application's choice */
     if (p->optimize_scans || !(p->scan_info[0].Ss == 0 && p->scan_info[0].Se == 63)) p->optimize_coding = p->arith_code ? 0 : 1;
   }
-  if (!p->optimize_coding && !p->arith_code) {
-    /* the device codes with the Annex K tables (std_huff_tables jstdhuff.c:31-131, what jpeg_set_defaults installs) when the
-     * application does not ask for optimal ones: tables of the application's own in the slots its components use would be what
-     * the reference codes with (jchuff.c start_pass_huff: jpeg_make_c_derived_tbl of dc/ac_huff_tbl_ptrs) -- never other bytes */
-    for (ci = 0; ci < cinfo->num_components; ci++) {
-      int which;
-      for (which = 0; which < 2; which++) {
-        const int t = which ? cinfo->comp_info[ci].ac_tbl_no : cinfo->comp_info[ci].dc_tbl_no;
-        const JHUFF_TBL *h = t >= 0 && t < NUM_HUFF_TBLS ? (which ? cinfo->ac_huff_tbl_ptrs[t] : cinfo->dc_huff_tbl_ptrs[t]) : NULL;
-        const uint8_t *bits, *vals;
-        int nv;
-        if (!h) return "missing Huffman tables";
-        if (t > 1 || mjh_std_huffman_table(which, t, &bits, &vals, &nv) != MJH_OK || memcmp(h->bits + 1, bits + 1, 16) != 0 ||
-            memcmp(h->huffval, vals, (size_t)nv) != 0)
-          return "Huffman tables of the application's own without optimize_coding (the device path codes with the Annex K tables or with optimal ones)";
+  {
+    /* what the reference reads from the object's Huffman table slots (mozjpeg_hip.h: huff_tables_given): the coding tables when the
+     * application does not ask for optimal ones (start_pass_huff: jpeg_make_c_derived_tbl of dc / ac_huff_tbl_ptrs, jchuff.c:190-196)
+     * -- for 12-bit samples only tables of its own, the Annex K ones are replaced by optimal tables (jcmaster.c:1096-1105) -- and the DC
+     * tables a progressive image's DC trellis takes its rates from (jccoefct.c:388-389).  A slot that holds the Annex K
+     * table travels as "not given". */
+    const int progressive = p->num_scans > 0 && (p->optimize_scans || !(p->scan_info[0].Ss == 0 && p->scan_info[0].Se == 63));
+    int coding = !p->optimize_coding && !p->arith_code, own = 0;
+    const int dc_rates = progressive && !p->arith_code && p->trellis_quant && p->trellis_quant_dc;
+    if (coding || dc_rates)
+      for (ci = 0; ci < cinfo->num_components; ci++) {
+        int which;
+        for (which = 0; which < (coding ? 2 : 1); which++) {
+          const int t = which ? cinfo->comp_info[ci].ac_tbl_no : cinfo->comp_info[ci].dc_tbl_no;
+          const JHUFF_TBL *h = t >= 0 && t < NUM_HUFF_TBLS ? (which ? cinfo->ac_huff_tbl_ptrs[t] : cinfo->dc_huff_tbl_ptrs[t]) : NULL;
+          const uint8_t *bits, *vals;
+          int nv = 0, l;
+          if (!h) return "a component's Huffman table slot is empty (JERR_NO_HUFF_TABLE)";
+          for (l = 1; l <= 16; l++) nv += h->bits[l];
+          if (nv > 256) return "Huffman table with more than 256 symbols (JERR_BAD_HUFF_TABLE)";
+          if (t <= 1 && mjh_std_huffman_table(which, t, &bits, &vals, &l) == MJH_OK && nv == l && memcmp(h->bits + 1, bits + 1, 16) == 0 &&
+              memcmp(h->huffval, vals, (size_t)nv) == 0)
+            continue;
+          own = 1;
+          p->huff_tables_given |= 1 << (2 * t + which);
+          p->huff_bits[2 * t + which][0] = 0;
+          memcpy(p->huff_bits[2 * t + which] + 1, h->bits + 1, 16);
+          memset(p->huff_vals[2 * t + which], 0, 256);
+          memcpy(p->huff_vals[2 * t + which], h->huffval, (size_t)nv);
+        }
       }
-    }
+    if (coding && cinfo->data_precision == 12 && !own) p->optimize_coding = 1, coding = 0;   /* (and nothing of the slots is read) */
   }
+  if (p->trellis_quant && !p->optimize_coding && !p->arith_code)
+    return "trellis without optimize_coding (the reference codes such an image with tables no pass made for it: its own djpeg rejects the colour files)";
+  if (p->num_scans > 0 && p->optimize_coding && p->trellis_quant && no_pixels != 2) { p->trellis_stats_Ah = cinfo->Ah; p->trellis_stats_Al = cinfo->Al; }   /* SURVEY T15 */
   p->write_JFIF_header = cinfo->write_JFIF_header;
   return NULL;
 }
@@ -856,6 +1155,7 @@ void jpeg_finish_compress(j_compress_ptr cinfo)
     encoder_failed(cinfo);
     return;
   }
+  if (!batched) fetch_end_tables(s, s->enc, 0);
   if (shim_timing) { const double t = shim_now(); shim_acc(2, t - t_wait0, 0); t_wait0 = t; }
   /* the device wrote a complete file; SOI(+APP0) went out in jpeg_start_compress already */
   {
@@ -863,7 +1163,7 @@ void jpeg_finish_compress(j_compress_ptr cinfo)
      * the markers the application asked for went out from the cinfo flags in jpeg_start_compress (an application may clear
      * write_Adobe_marker for JCS_RGB, which the reference honours: the device's APP14 is dropped all the same) */
     const size_t skip = (size_t)(2 + (cinfo->write_JFIF_header ? 18 : 0) + (cinfo->jpeg_color_space == JCS_RGB ? 16 : 0));
-    emit_bytes(cinfo, file + skip, n - skip);
+    hand_over_file(cinfo, s, file + skip, file + n);     /* (table markers under the object's sent_table flags) */
   }
   free(copy);
   if (shim_timing) shim_acc(3, shim_now() - t_wait0, 0);

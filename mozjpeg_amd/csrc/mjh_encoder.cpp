@@ -514,10 +514,30 @@ static int check_supported(const mjh_params *p)
     }
   }
   if (p->trellis_quant && !p->optimize_coding && !p->arith_code) return fail(MJH_EUNSUPPORTED, "trellis_quant requires optimize_coding (jcmaster.c:686-702 never selects a component otherwise)");
-  if (!p->optimize_coding && !p->arith_code) {
-    for (int i = 0; i < p->num_components; i++)
-      if (p->dc_tbl_no[i] > 1 || p->ac_tbl_no[i] > 1) return fail(MJH_EUNSUPPORTED, "standard Huffman tables exist only for table numbers 0 and 1");
+  if (p->huff_tables_given & ~0xFF) return fail(MJH_EINVAL, "huff_tables_given 0x%x", p->huff_tables_given);
+  for (int k = 0; k < 8; k++) {
+    if (!(p->huff_tables_given >> k & 1)) continue;
+    // the checks of jpeg_make_c_derived_tbl (jchuff.c:262-316): at most 256 symbols, no code of all ones, no symbol twice, DC symbols 0..15
+    int n = 0;
+    unsigned code = 0;
+    bool seen[256] = { false };
+    for (int l = 1; l <= 16; l++) {
+      if (n + p->huff_bits[k][l] > 256) return fail(MJH_EINVAL, "Huffman table %s %d: more than 256 symbols (JERR_BAD_HUFF_TABLE)", k & 1 ? "AC" : "DC", k >> 1);
+      for (int i = 0; i < p->huff_bits[k][l]; i++, n++, code++) {
+        const int sym = p->huff_vals[k][n];
+        if (seen[sym] || (!(k & 1) && sym > 15)) return fail(MJH_EINVAL, "Huffman table %s %d: symbol 0x%02x twice or out of range (JERR_BAD_HUFF_TABLE)", k & 1 ? "AC" : "DC", k >> 1, sym);
+        seen[sym] = true;
+      }
+      if (p->huff_bits[k][l] && code >= (1u << l)) return fail(MJH_EINVAL, "Huffman table %s %d: not a prefix code (JERR_BAD_HUFF_TABLE)", k & 1 ? "AC" : "DC", k >> 1);
+      code <<= 1;
+    }
   }
+  if (!p->optimize_coding && !p->arith_code && p->data_precision != 12) {
+    for (int i = 0; i < p->num_components; i++)
+      if ((p->dc_tbl_no[i] > 1 && !(p->huff_tables_given >> (2 * p->dc_tbl_no[i]) & 1)) || (p->ac_tbl_no[i] > 1 && !(p->huff_tables_given >> (2 * p->ac_tbl_no[i] + 1) & 1)))
+        return fail(MJH_EUNSUPPORTED, "no Huffman table in slot 2 / 3 (the Annex K tables exist for table numbers 0 and 1; others come through huff_tables_given; JERR_NO_HUFF_TABLE)");
+  }
+  if (p->trellis_stats_Ah < 0 || p->trellis_stats_Ah > 13 || p->trellis_stats_Al < 0 || p->trellis_stats_Al > 13) return fail(MJH_EINVAL, "trellis_stats_Ah / Al %d / %d", p->trellis_stats_Ah, p->trellis_stats_Al);
   return MJH_OK;
 }
 
@@ -852,7 +872,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     e->dc_chain_v = p->v_samp_factor[0];
     e->p.h_samp_factor[0] = e->p.v_samp_factor[0] = 1;
   }
-  if (p->data_precision == 12) e->p.optimize_coding = 1;   // standard tables are 8-bit only (jcparam.c:452-453, jcmaster.c:1102-1105)
+  if (p->data_precision == 12 && !p->huff_tables_given) e->p.optimize_coding = 1;   // standard tables are 8-bit only (jcparam.c:452-453, jcmaster.c:1102-1105: tables of the caller's own are kept)
   p = &e->p;     // (everything below reads the parameters as the encoder runs them: a 12-bit sequential scan script sends its scans' tables with every scan)
   e->device = device;
   e->max_batch = max_batch;
@@ -1015,6 +1035,12 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
         fill_std_table(&T[1], kStdAcLBits, kStdAcLVal, 162);
         fill_std_table(&T[2], kStdDcCBits, kStdDcVal, 12);
         fill_std_table(&T[3], kStdAcCBits, kStdAcCVal, 162);
+        for (int k = 0; k < 8; k++)         // what the caller's table slots hold instead (mozjpeg_hip.h: huff_tables_given)
+          if (p->huff_tables_given >> k & 1) {
+            int nv = 0;
+            for (int l = 1; l <= 16; l++) nv += p->huff_bits[k][l];
+            fill_std_table(&T[k], p->huff_bits[k], p->huff_vals[k], nv);
+          }
       }
     }
     HIPCHK_E(hipMemcpy(e->d_tabs_init, ht.data(), ht.size() * sizeof(MjhHuffTable), hipMemcpyHostToDevice));
@@ -1231,7 +1257,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     for (int band = 0; band < e->nbands; band++)
       for (int c = 0; c < C.ncomp; c++) {
         MjhProgScan &d = ps[p->num_scans + band * C.ncomp + c];
-        d.ncomp = 1; d.comp[0] = c; d.Ah = 0; d.Al = 0;   // jcmaster.c:451-466, T15
+        d.ncomp = 1; d.comp[0] = c; d.Ah = p->trellis_stats_Ah; d.Al = p->trellis_stats_Al;   // jcmaster.c:451-466, T15: whatever the object's last coded scan left
         d.Ss = e->nbands == 1 ? 1 : band == 0 ? 1 : e->freq_split + 1;
         d.Se = e->nbands == 1 ? 63 : band == 0 ? e->freq_split : 63;
         if (d.Se < d.Ss) { d.Ss = 1; d.Se = 63; }         // empty band: its passes are skipped, the descriptor only has to be valid
@@ -1626,7 +1652,10 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
       // kernel; the chroma chains and the final DC statistics start when it has finished and run under that tail, and the
       // main stream joins the side stream in front of the final tables instead of behind the trellis.
       const bool final_dc_here = !e->progressive && p.optimize_coding && last_loop && nbands == 1 && qstride == 0 && !ext_eob && e->dc_stats_side && e->seq_scans.empty();
-      dc_late = e->dc_late > 0 && !spec && final_dc_here && nloops == 1 && CV.ncomp == 3 && !e->debug_taps && (size_t)n * C.total_real_blocks >= e->small_batch;
+      // (the late chains hang on the tile-sorted AC kernel's event: without that kernel -- MJH_TRELLIS_V3=0, a capacity beyond its tiers --
+      // every chain starts here, the older schedule)
+      const bool sorted_tier = nzm && e->d_nq8 && e->trellis_v3 > 0 && e->trellis_variant <= 4;
+      dc_late = e->dc_late > 0 && sorted_tier && !spec && final_dc_here && nloops == 1 && CV.ncomp == 3 && !e->debug_taps && (size_t)n * C.total_real_blocks >= e->small_batch;
       if (spec) mjh_launch_trellis_dc_speculative(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back9, e->d_jfin, e->d_qspec, n, e->side_stream);
       else
       mjh_launch_trellis_dc(dc_chain_view(e, CV), e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_dc, e->d_lambda, e->d_back, n, e->side_stream, e->dc_window_ok,
@@ -2536,6 +2565,24 @@ extern "C" int mjh_component_geometry(const mjh_encoder *e, int c, int *wib, int
   if (hib) *hib = e->C.c[c].hib;
   if (pw) *pw = e->C.c[c].pw;
   if (ph) *ph = e->C.c[c].ph;
+  return MJH_OK;
+}
+
+// The Huffman table one entry of the scan script was coded with in image `image` of the last batch (progressive encoders; a scan
+// search codes every candidate, also the ones its file leaves out).  For the libjpeg drop-in, whose compress object keeps in its
+// table slots what the LAST CODED scan put there (jpeg_gen_optimal_table writes into cinfo->dc / ac_huff_tbl_ptrs, jchuff.c:1092-1105).
+extern "C" int mjh_get_scan_table(mjh_encoder *e, int image, int scan, int tblno, uint8_t bits[17], uint8_t vals[256])
+{
+  if (!e || !bits || !vals || image < 0 || image >= e->last_n) return fail(MJH_EINVAL, "bad arguments");
+  if (!e->progressive || e->arith || scan < 0 || scan >= e->nscans || tblno < 0 || tblno > 1) return fail(MJH_EINVAL, "no such scan table");
+  const mjh_scan &sc = e->p.scan_info[scan];
+  if (sc.Ss == 0 && sc.Ah != 0) return fail(MJH_EINVAL, "a DC refinement scan has no table");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  MjhHuffTable t;
+  HIPCHK(hipMemcpy(&t, e->d_tabs + (size_t)image * e->spi + SLOT_PROG + 2 * scan + (sc.Ss == 0 ? tblno : 0), sizeof(t), hipMemcpyDeviceToHost));
+  memcpy(bits, t.bits, 17);
+  memcpy(vals, t.huffval, 256);
   return MJH_OK;
 }
 

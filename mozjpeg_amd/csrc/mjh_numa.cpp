@@ -107,7 +107,16 @@ extern "C" int mjh_numa_bind_thread(int dev)
 extern "C" hipError_t mjh_numa_host_alloc(void **ptr, size_t bytes, unsigned flags, int dev)
 {
   const Place &p = place_of(dev);
-  if (p.node >= 0 && set_mempolicy_preferred(p.node) == 0) {
+  // the calling thread may be the application's (mjh_host_alloc, the first mjh_encode_host): its own policy (numactl --interleave,
+  // set_mempolicy of its own) is read first and put back afterwards; if it cannot be read the placement is skipped
+  int old_mode = 0;
+  unsigned long old_mask[16] = { 0 };
+#ifdef SYS_get_mempolicy
+  const bool have_old = syscall(SYS_get_mempolicy, &old_mode, old_mask, sizeof(old_mask) * 8, nullptr, 0) == 0;
+#else
+  const bool have_old = false;
+#endif
+  if (p.node >= 0 && have_old && set_mempolicy_preferred(p.node) == 0) {
     const hipError_t rc = hipHostMalloc(ptr, bytes, flags | hipHostMallocNumaUser);
     if (rc == hipSuccess) {
       // first touch under the policy: one write per page (pinning faults the pages in, this makes it explicit)
@@ -115,7 +124,10 @@ extern "C" hipError_t mjh_numa_host_alloc(void **ptr, size_t bytes, unsigned fla
       const long pg = sysconf(_SC_PAGESIZE) > 0 ? sysconf(_SC_PAGESIZE) : 4096;
       for (size_t o = 0; o < bytes; o += (size_t)pg) c[o] = 0;
     }
-    (void)set_mempolicy_preferred(-1);
+#ifdef SYS_set_mempolicy
+    if (old_mode == 0) (void)syscall(SYS_set_mempolicy, 0, nullptr, 0);
+    else (void)syscall(SYS_set_mempolicy, old_mode, old_mask, sizeof(old_mask) * 8);
+#endif
     if (rc == hipSuccess) return rc;
     (void)hipGetLastError();
   }

@@ -4,8 +4,11 @@
  * switches do not: every in_color_space / jpeg_set_colorspace pair of the path, quantization tables and table slots of the
  * application's own, jpeg_set_linear_quality, dc / ac table numbers, the extension parameters in any combination, JFIF fields,
  * COM / APPn markers, rows handed over in uneven chunks, jpeg_write_raw_data, a small destination buffer, a second image from the
- * same object.
- *   usage: api_fuzz SEED INDEX     -> one line per image: "<index>.<k> <bytes> <fnv64>"                                         */
+ * same object; abbreviated datastreams (jpeg_write_tables, jpeg_suppress_tables and flags of single tables, jpeg_start_compress
+ * with write_all_tables FALSE) and further images from the object WITHOUT setting the parameters again (libjpeg.txt "Abbreviated
+ * datastreams and multiple images") -- those decisions come from a second generator, so that the cases of older seeds keep
+ * their parameters.
+ *   usage: api_fuzz SEED INDEX     -> one line per image: "<index>.<k> <bytes> <fnv64>" ("<index>.<k>t ..." for a tables-only stream) */
 #include <setjmp.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,6 +20,9 @@ static unsigned long long rs;
 static unsigned rnd(void) { rs = rs * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(rs >> 33); }
 static int ri(int lo, int hi) { return lo + (int)(rnd() % (unsigned)(hi - lo + 1)); }      /* inclusive */
 static int chance(int pct) { return (int)(rnd() % 100u) < pct; }
+static unsigned long long rs2;       /* the table / re-use decisions */
+static unsigned rnd2(void) { rs2 = rs2 * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(rs2 >> 33); }
+static int chance2(int pct) { return (int)(rnd2() % 100u) < pct; }
 
 static unsigned long long fnv(const unsigned char *b, size_t n) { unsigned long long h = 1469598103934665603ull; size_t i; for (i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull; return h; }
 
@@ -36,28 +42,38 @@ static const int kRgbSize[] = { 3, 3, 4, 3, 4, 4, 4, 4, 4, 4, 4 };
 static const int kFactors[][6] = { { 1, 1, 1, 1, 1, 1 }, { 2, 1, 1, 1, 1, 1 }, { 2, 2, 1, 1, 1, 1 }, { 1, 2, 1, 1, 1, 1 }, { 4, 1, 1, 1, 1, 1 }, { 2, 2, 2, 1, 1, 1 },
                                    { 2, 1, 1, 1, 1, 2 }, { 1, 1, 2, 2, 2, 2 }, { 4, 2, 1, 1, 1, 1 }, { 2, 2, 1, 2, 2, 1 }, { 3, 1, 1, 1, 1, 1 }, { 2, 4, 1, 1, 1, 1 } };
 
-static void one_image(struct jpeg_compress_struct *c, int tag, int k)
+/* keep: the object's parameters stay as the previous image left them (same size and pixel format, new pixels) */
+static void one_image(struct jpeg_compress_struct *c, int tag, int k, int keep)
 {
-  const int w = chance(10) ? ri(1, 900) : ri(1, 150), h = chance(10) ? ri(1, 12) : ri(1, 120);
-  int cs_kind = ri(0, 9), ps, x, y, i, ci, raw = 0, small = chance(30), noise = chance(35);
-  J_COLOR_SPACE in_cs;
+  static int w, h, ps, raw;
+  static J_COLOR_SPACE in_cs;
+  int x, y, i, ci, small, noise, all_tables = TRUE;
   unsigned char *img, *out = NULL;
   unsigned long outn = 0;
   small_dest sd;
-  if (cs_kind <= 5) { i = ri(0, 10); in_cs = kRgbFamily[i]; ps = kRgbSize[i]; }
-  else if (cs_kind <= 7) { in_cs = JCS_GRAYSCALE; ps = 1; }
-  else { in_cs = JCS_YCbCr; ps = 3; }
+  if (!keep) {
+    int cs_kind;
+    w = chance(10) ? ri(1, 900) : ri(1, 150); h = chance(10) ? ri(1, 12) : ri(1, 120);
+    cs_kind = ri(0, 9); raw = 0; small = chance(30); noise = chance(35);
+    if (cs_kind <= 5) { i = ri(0, 10); in_cs = kRgbFamily[i]; ps = kRgbSize[i]; }
+    else if (cs_kind <= 7) { in_cs = JCS_GRAYSCALE; ps = 1; }
+    else { in_cs = JCS_YCbCr; ps = 3; }
+  } else { small = chance2(30); noise = chance2(35); }
   img = (unsigned char *)malloc((size_t)w * h * ps + 16);
   for (y = 0; y < h; y++)
     for (x = 0; x < w; x++)
-      for (i = 0; i < ps; i++)
-        img[((size_t)y * w + x) * ps + i] = noise ? (unsigned char)rnd() : (unsigned char)(((x * (3 + i) + y * (5 - i)) & 0xFF) / 2 + (rnd() & 0x1F) + (((x / 16 + y / 16) % 5) == 0 ? 64 : 0));
+      for (i = 0; i < ps; i++) {
+        const unsigned r = keep ? rnd2() : rnd();
+        img[((size_t)y * w + x) * ps + i] = noise ? (unsigned char)r : (unsigned char)(((x * (3 + i) + y * (5 - i)) & 0xFF) / 2 + (r & 0x1F) + (((x / 16 + y / 16) % 5) == 0 ? 64 : 0));
+      }
   memset(&sd, 0, sizeof(sd));
   if (small) {
-    sd.chunk_size = (size_t)ri(1, 700); sd.chunk = (unsigned char *)malloc(sd.chunk_size);
+    sd.chunk_size = keep ? (size_t)(1 + rnd2() % 700u) : (size_t)ri(1, 700); sd.chunk = (unsigned char *)malloc(sd.chunk_size);
     sd.pub.init_destination = sd_init; sd.pub.empty_output_buffer = sd_empty; sd.pub.term_destination = sd_term;
-    c->dest = &sd.pub;
-  } else { c->dest = NULL; jpeg_mem_dest(c, &out, &outn); }
+  }
+  if (keep) goto start;
+  if (small) c->dest = &sd.pub;
+  else { c->dest = NULL; jpeg_mem_dest(c, &out, &outn); }
   if (chance(35)) jpeg_c_set_int_param(c, JINT_COMPRESS_PROFILE, JCP_FASTEST);
   else jpeg_c_set_int_param(c, JINT_COMPRESS_PROFILE, JCP_MAX_COMPRESSION);
   c->image_width = w; c->image_height = h; c->input_components = ps; c->in_color_space = in_cs;
@@ -117,6 +133,34 @@ static void one_image(struct jpeg_compress_struct *c, int tag, int k)
             jpeg_c_get_float_param(c, JFLOAT_TRELLIS_DELTA_DC_WEIGHT), jpeg_c_get_int_param(c, JINT_DC_SCAN_OPT_MODE), c->write_JFIF_header);
     for (ci = 0; ci < c->num_components; ci++) fprintf(stderr, "   comp %d: %dx%d q %d dc %d ac %d\n", ci, c->comp_info[ci].h_samp_factor, c->comp_info[ci].v_samp_factor, c->comp_info[ci].quant_tbl_no, c->comp_info[ci].dc_tbl_no, c->comp_info[ci].ac_tbl_no);
   }
+start:
+  {
+    /* tables: mostly the whole file; otherwise a tables-only stream first, flags of single tables, or write_all_tables FALSE */
+    const int mode = (int)(rnd2() % 100u);
+    int t;
+    if (mode >= 60 && mode < 72) {
+      unsigned char *tb = NULL;
+      unsigned long tn = 0;
+      c->dest = NULL; jpeg_mem_dest(c, &tb, &tn);
+      jpeg_write_tables(c);
+      printf("%d.%dt %lu %016llx\n", tag, k, tn, fnv(tb, tn));
+      free(tb);
+      all_tables = chance2(15);
+    } else if (mode >= 72 && mode < 84) {
+      jpeg_suppress_tables(c, chance2(70));
+      for (t = 0; t < NUM_QUANT_TBLS; t++) {
+        if (c->quant_tbl_ptrs[t] && chance2(25)) c->quant_tbl_ptrs[t]->sent_table = chance2(50);
+        if (c->dc_huff_tbl_ptrs[t] && chance2(25)) c->dc_huff_tbl_ptrs[t]->sent_table = chance2(50);
+        if (c->ac_huff_tbl_ptrs[t] && chance2(25)) c->ac_huff_tbl_ptrs[t]->sent_table = chance2(50);
+      }
+      all_tables = FALSE;
+    } else if (mode >= 84) all_tables = FALSE;
+    if (keep || mode >= 60) {       /* (the destination again: a tables-only stream used it, or this is a further image) */
+      if (small) c->dest = &sd.pub;
+      else { c->dest = NULL; jpeg_mem_dest(c, &out, &outn); }
+    }
+    if (getenv("API_FUZZ_VERBOSE")) fprintf(stderr, "image %d.%d: keep %d tables mode %d write_all_tables %d\n", tag, k, keep, mode, all_tables);
+  }
   if (getenv("API_FUZZ_DUMP") && k == 1) {     /* (debugging aid: the object's state in front of the second image) */
     FILE *f = fopen(getenv("API_FUZZ_DUMP"), "w");
     const unsigned char *b = (const unsigned char *)c;
@@ -131,7 +175,7 @@ static void one_image(struct jpeg_compress_struct *c, int tag, int k)
     { const unsigned char *m = (const unsigned char *)c->master; for (j = 0; j < 4400; j += 8) { unsigned long long v; memcpy(&v, m + j, 8); fprintf(f, "master+%zu: %016llx\n", j, v); } }
     fclose(f);
   }
-  jpeg_start_compress(c, TRUE);
+  jpeg_start_compress(c, all_tables);
   if (chance(25)) { unsigned char com[300]; const int n = ri(0, 300); for (i = 0; i < n; i++) com[i] = (unsigned char)rnd(); jpeg_write_marker(c, chance(50) ? JPEG_COM : JPEG_APP0 + ri(1, 15), com, (unsigned)n); }
   if (chance(10)) { const int n = ri(1, 40); jpeg_write_m_header(c, JPEG_APP0 + 5, (unsigned)n); for (i = 0; i < n; i++) jpeg_write_m_byte(c, ri(0, 255)); }
   if (!raw) {
@@ -173,6 +217,12 @@ static void one_image(struct jpeg_compress_struct *c, int tag, int k)
     for (ci = 0; ci < 3; ci++) free(buf[ci]);
   }
   jpeg_finish_compress(c);
+  if (getenv("API_FUZZ_SAVE")) {      /* (debugging aid: the files themselves) */
+    char name[512];
+    FILE *f;
+    snprintf(name, sizeof(name), "%s.%d.jpg", getenv("API_FUZZ_SAVE"), k);
+    if ((f = fopen(name, "wb")) != NULL) { fwrite(small ? sd.all : out, 1, small ? sd.n : (size_t)outn, f); fclose(f); }
+  }
   if (small) { printf("%d.%d %lu %016llx\n", tag, k, (unsigned long)sd.n, fnv(sd.all, sd.n)); free(sd.all); free(sd.chunk); }
   else { printf("%d.%d %lu %016llx\n", tag, k, outn, fnv(out, outn)); free(out); }
   fflush(stdout);
@@ -183,14 +233,16 @@ int main(int argc, char **argv)
 {
   struct jpeg_compress_struct c;
   struct jpeg_error_mgr err;
-  int index, k, nimg;
+  int index, k, nimg, keep_from = 1000;
   if (argc != 3) { fprintf(stderr, "usage: api_fuzz SEED INDEX\n"); return 2; }
   index = atoi(argv[2]);
   rs = (unsigned long long)atoll(argv[1]) * 1000003ull + (unsigned long long)index * 7919ull + 12345ull;
-  for (k = 0; k < 4; k++) rnd();
+  rs2 = rs ^ 0x9E3779B97F4A7C15ull;
+  for (k = 0; k < 4; k++) { rnd(); rnd2(); }
   c.err = jpeg_std_error(&err);
   jpeg_create_compress(&c);
   nimg = chance(30) ? 2 : 1;          /* a second image from the same object (parameters set anew, as libjpeg.txt asks) */
+  if (chance2(35)) { nimg += 1 + (int)(rnd2() % 2u); keep_from = nimg - (chance2(50) ? 1 : 2); if (keep_from < 1) keep_from = 1; }   /* further images with the parameters left alone */
   for (k = 0; k < nimg; k++) {
     /* API_FUZZ_FRESH=1: a new object for the second image.  The REFERENCE's bytes for a second image from the same object depend on
      * the first one: select_scan_parameters sets Ss / Se for the trellis passes but not Ah / Al (jcmaster.c:451-466), so the trellis'
@@ -199,7 +251,7 @@ int main(int argc, char **argv)
      * 0 / 0.  The device path codes every image as a fresh object would (known divergences): tools/simt/fuzz_api.py
      * runs the reference with API_FUZZ_FRESH=1 and the libraries under test without it. */
     if (k > 0 && getenv("API_FUZZ_FRESH")) { jpeg_destroy_compress(&c); jpeg_create_compress(&c); }
-    one_image(&c, index, k);
+    one_image(&c, index, k, k >= keep_from);
   }
   jpeg_destroy_compress(&c);
   return 0;

@@ -4,7 +4,7 @@ from a seed) three ways per case -- the reference's libjpeg (expected output), t
 the SHIPPED stand-alone library -- with the kernels on the emulator (see fuzz_cjpeg.py).  A run the device path refuses with a
 reason ("unsupported configuration (...); no CPU fallback") is tallied by reason, not counted as a failure: that list is what an
 application can still ask the reference for and not this library.  Development aid, correctness only; build container only.
-usage: python tools/simt/fuzz_api.py SEED COUNT [--verbose]"""
+usage: python tools/simt/fuzz_api.py SEED COUNT [--verbose] [--fresh]"""
 import collections
 import os
 import re
@@ -27,7 +27,7 @@ def main():
     t0 = time.time()
     for i in range(count):
         cmd = [BIN, str(seed), str(i)]
-        r0 = F.run(cmd, {"API_FUZZ_FRESH": "1"})      # (a new object per image: see tests/native/api_fuzz.c on what the reference carries over)
+        r0 = F.run(cmd, {"API_FUZZ_FRESH": "1"} if "--fresh" in sys.argv else {})     # (--fresh: a new object per image, for telling what an object carries from image to image)
         if r0.returncode != 0:
             ref_refused += 1
             if verbose:
