@@ -347,9 +347,9 @@ struct mjh_encoder {
   // a SEQUENTIAL script of several scans (cjpeg -scans with whole-block scans, validate_script jcmaster.c:309-330): every scan is
   // coded through a view of the geometry that holds its components, with its own statistics / tables / restart interval;
   // its [DRI +] SOS bytes lie at sos_off of d_sos
-  struct SeqScan { int ncomp; int comp[4]; int sos_off, sos_len; int dht_slots[4], dht_ids[4], ndht; int ri, nseg; };
+  struct SeqScan { int ncomp; int comp[4]; int sos_off, sos_len; int dht_slots[8], dht_ids[8], ndht; int ri, nseg; };
   std::vector<SeqScan> seq_scans;
-  int dht_slots[4] = { 0, 0, 0, 0 }, dht_ids[4] = { 0, 0, 0, 0 }, ndht = 0;
+  int dht_slots[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, dht_ids[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, ndht = 0;
   bool debug_taps = false;
   int dc_chain_v = 1;           // ... and its vertical factor: the trellis passes' iMCU rows hold that many block rows (the DC chains span them)
   int sof_hv0 = 0;              // one component sampled other than 1x1: the SOF's sampling byte (the geometry is 1x1's, see check_supported)
@@ -1096,8 +1096,8 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
         if (p->optimize_coding) for (int t = 0; t < 4; t++) dsent[t] = asent[t] = false;
         for (int j = 0; j < q.ncomp; j++) {
           const int d = p->dc_tbl_no[q.comp[j]], a = p->ac_tbl_no[q.comp[j]];
-          if (!dsent[d] && q.ndht < 4) { q.dht_slots[q.ndht] = SLOT_FINAL + 2 * d; q.dht_ids[q.ndht] = d; q.ndht++; dsent[d] = true; }
-          if (!asent[a] && q.ndht < 4) { q.dht_slots[q.ndht] = SLOT_FINAL + 2 * a + 1; q.dht_ids[q.ndht] = a + 0x10; q.ndht++; asent[a] = true; }
+          if (!dsent[d] && q.ndht < 8) { q.dht_slots[q.ndht] = SLOT_FINAL + 2 * d; q.dht_ids[q.ndht] = d; q.ndht++; dsent[d] = true; }
+          if (!asent[a] && q.ndht < 8) { q.dht_slots[q.ndht] = SLOT_FINAL + 2 * a + 1; q.dht_ids[q.ndht] = a + 0x10; q.ndht++; asent[a] = true; }
         }
         e->seq_scans.push_back(q);
       }
@@ -1112,8 +1112,8 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       const int d = p->dc_tbl_no[ci], a = p->ac_tbl_no[ci];
       // max-compression: the reference's loop `continue`s past the AC table when the DC table was
       // already sent (jcmarker.c:371-376); tables are shared pairwise here so the result is the same.
-      if (!dc_sent[d] && e->ndht < 4) { e->dht_slots[e->ndht] = SLOT_FINAL + 2 * d; e->dht_ids[e->ndht] = d; e->ndht++; dc_sent[d] = true; }
-      if (!ac_sent[a] && e->ndht < 4) { e->dht_slots[e->ndht] = SLOT_FINAL + 2 * a + 1; e->dht_ids[e->ndht] = a + 0x10; e->ndht++; ac_sent[a] = true; }
+      if (!dc_sent[d] && e->ndht < 8) { e->dht_slots[e->ndht] = SLOT_FINAL + 2 * d; e->dht_ids[e->ndht] = d; e->ndht++; dc_sent[d] = true; }
+      if (!ac_sent[a] && e->ndht < 8) { e->dht_slots[e->ndht] = SLOT_FINAL + 2 * a + 1; e->dht_ids[e->ndht] = a + 0x10; e->ndht++; ac_sent[a] = true; }
     }
   }
   if (p->arith_code) {

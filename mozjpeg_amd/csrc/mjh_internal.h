@@ -11,6 +11,8 @@
 // Huffman table slot as it lives in HBM (one per image and per role).
 // counts[] is the gather histogram (a10), bits/huffval the JHUFF_TBL content (a11),
 // ehufsi/ehufco the derived code lengths / codes (jchuff.c:231-318).
+struct MjhDhtPlan { int slots[8], ids[8]; };   // the tables one DHT position of a sequential file carries: table slot, Tc/Th byte
+
 struct alignas(16) MjhHuffTable {
   uint32_t counts[260];   // 257 used
   uint8_t ehufsi[256];    // 16-byte aligned: the trellis reads whole 16-symbol rows (run r: symbols 16r..16r+15)

@@ -3202,7 +3202,7 @@ k_zero_stream(unsigned *__restrict__ stream, size_t stream_words_per_image, cons
 // the scan needs, in component order) / emit_dht :257-290 (fastest profile: one marker per table).
 __global__ void __launch_bounds__(64)
 k_header(const uint8_t *__restrict__ prefix, int prefix_len, const uint8_t *__restrict__ sos, int sos_len,
-         const MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 dht_slots, int4 dht_ids, int ndht,
+         const MjhHuffTable *__restrict__ tabs, int slots_per_image, MjhDhtPlan dht, int ndht,
          int multi_dht, uint8_t *__restrict__ out, size_t out_stride, MjhImageMeta *__restrict__ meta, const unsigned *__restrict__ append_sizes)
 {
   // append_sizes (the later scans of a sequential multi-scan file): the header goes over the EOI of the file so far
@@ -3212,8 +3212,7 @@ k_header(const uint8_t *__restrict__ prefix, int prefix_len, const uint8_t *__re
   const int start = append_sizes ? (int)append_sizes[img] - 2 : 0;
   for (int i = lane; i < prefix_len; i += 64) o[start + i] = prefix[i];
   int pos = start + prefix_len;
-  const int slots[4] = { dht_slots.x, dht_slots.y, dht_slots.z, dht_slots.w };
-  const int ids[4] = { dht_ids.x, dht_ids.y, dht_ids.z, dht_ids.w };
+  const int *slots = dht.slots, *ids = dht.ids;      // (up to six tables: three components with DC and AC tables of their own)
   if (multi_dht) {
     int length = 2;
     for (int i = 0; i < ndht; i++) length += (int)tabs[(size_t)img * slots_per_image + slots[i]].nsyms + 17;
@@ -3651,12 +3650,13 @@ void mjh_launch_encode(const MjhConst &C, const void *q, const unsigned long lon
 }
 
 void mjh_launch_header(const void *prefix, int prefix_len, const void *sos, int sos_len, const MjhHuffTable *tabs, int spi,
-                       const int dht_slots[4], const int dht_ids[4], int ndht, int multi_dht, void *out, size_t out_stride, void *meta, int n, hipStream_t s,
+                       const int dht_slots[8], const int dht_ids[8], int ndht, int multi_dht, void *out, size_t out_stride, void *meta, int n, hipStream_t s,
                        const unsigned *append_sizes)
 {
+  MjhDhtPlan plan;
+  for (int i = 0; i < 8; i++) { plan.slots[i] = i < ndht ? dht_slots[i] : 0; plan.ids[i] = i < ndht ? dht_ids[i] : 0; }
   hipLaunchKernelGGL(k_header, dim3(n), dim3(64), 0, s, (const uint8_t *)prefix, prefix_len, (const uint8_t *)sos, sos_len, tabs, spi,
-                     make_int4(dht_slots[0], dht_slots[1], dht_slots[2], dht_slots[3]), make_int4(dht_ids[0], dht_ids[1], dht_ids[2], dht_ids[3]),
-                     ndht, multi_dht, (uint8_t *)out, out_stride, (MjhImageMeta *)meta, append_sizes);
+                     plan, ndht, multi_dht, (uint8_t *)out, out_stride, (MjhImageMeta *)meta, append_sizes);
 }
 
 void mjh_launch_stuff(const unsigned *stream, size_t stream_words_per_image, const unsigned *totals, unsigned *ffsums, int ff_chunks_per_image,

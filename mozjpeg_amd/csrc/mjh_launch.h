@@ -37,7 +37,7 @@ void mjh_launch_encode(const MjhConst &C, const void *q, const unsigned long lon
                        unsigned *seg_x, unsigned *seg_E, unsigned *seg_sums, unsigned *seg_totals, unsigned *mpos, int nseg,
                        int n, hipStream_t s);
 void mjh_launch_header(const void *prefix, int prefix_len, const void *sos, int sos_len, const MjhHuffTable *tabs, int spi,
-                       const int dht_slots[4], const int dht_ids[4], int ndht, int multi_dht, void *out, size_t out_stride, void *meta, int n, hipStream_t s, const unsigned *append_sizes = nullptr);   // append_sizes: write over the EOI of the files so far (later scans of a sequential script)
+                       const int dht_slots[8], const int dht_ids[8], int ndht, int multi_dht, void *out, size_t out_stride, void *meta, int n, hipStream_t s, const unsigned *append_sizes = nullptr);   // append_sizes: write over the EOI of the files so far (later scans of a sequential script)
 void mjh_launch_stuff(const unsigned *stream, size_t stream_words_per_image, const unsigned *totals, unsigned *ffsums, int ff_chunks_per_image,
                       unsigned *ff_totals, void *out, size_t out_stride, void *meta, unsigned *sizes, const unsigned *mpos, int nseg, int n, hipStream_t s);
 void mjh_launch_pack_results(const void *out, size_t out_stride, const unsigned *sizes, const void *meta, const void *prog_ctl, int n,

@@ -42,6 +42,25 @@ static const int kRgbSize[] = { 3, 3, 4, 3, 4, 4, 4, 4, 4, 4, 4 };
 static const int kFactors[][6] = { { 1, 1, 1, 1, 1, 1 }, { 2, 1, 1, 1, 1, 1 }, { 2, 2, 1, 1, 1, 1 }, { 1, 2, 1, 1, 1, 1 }, { 4, 1, 1, 1, 1, 1 }, { 2, 2, 2, 1, 1, 1 },
                                    { 2, 1, 1, 1, 1, 2 }, { 1, 1, 2, 2, 2, 2 }, { 4, 2, 1, 1, 1, 1 }, { 2, 2, 1, 2, 2, 1 }, { 3, 1, 1, 1, 1, 1 }, { 2, 4, 1, 1, 1, 1 } };
 
+/* a Huffman table of the application's own in slot t: the Annex K table of that kind with its symbols dealt anew over the code words
+ * (any assignment of symbols to a legal set of code lengths is a legal table), now and then with its last symbols missing */
+static void own_huff_table(struct jpeg_compress_struct *c, int t, int is_ac)
+{
+  JHUFF_TBL **slot = is_ac ? &c->ac_huff_tbl_ptrs[t] : &c->dc_huff_tbl_ptrs[t];
+  const JHUFF_TBL *std = is_ac ? c->ac_huff_tbl_ptrs[t & 1] : c->dc_huff_tbl_ptrs[t & 1];
+  JHUFF_TBL tmp;
+  int nv = 0, l, i;
+  if (std == NULL) return;
+  tmp = *std;
+  for (l = 1; l <= 16; l++) nv += tmp.bits[l];
+  for (i = nv - 1; i > 0; i--) { const int j = (int)(rnd2() % (unsigned)(i + 1)); const UINT8 v = tmp.huffval[i]; tmp.huffval[i] = tmp.huffval[j]; tmp.huffval[j] = v; }
+  if (chance2(20)) { int drop = 1 + (int)(rnd2() % 3u); for (l = 16; l >= 1 && drop > 0; l--) while (tmp.bits[l] > 0 && drop > 0 && nv > 2) { tmp.bits[l]--; nv--; drop--; } }
+  if (*slot == NULL) *slot = jpeg_alloc_huff_table((j_common_ptr)c);
+  memcpy((*slot)->bits, tmp.bits, sizeof(tmp.bits));
+  memcpy((*slot)->huffval, tmp.huffval, sizeof(tmp.huffval));
+  (*slot)->sent_table = FALSE;
+}
+
 /* keep: the object's parameters stay as the previous image left them (same size and pixel format, new pixels) */
 static void one_image(struct jpeg_compress_struct *c, int tag, int k, int keep)
 {
@@ -132,6 +151,13 @@ static void one_image(struct jpeg_compress_struct *c, int tag, int k, int keep)
             jpeg_c_get_int_param(c, JINT_TRELLIS_NUM_LOOPS), jpeg_c_get_bool_param(c, JBOOLEAN_OVERSHOOT_DERINGING), jpeg_c_get_float_param(c, JFLOAT_LAMBDA_LOG_SCALE1), jpeg_c_get_float_param(c, JFLOAT_LAMBDA_LOG_SCALE2),
             jpeg_c_get_float_param(c, JFLOAT_TRELLIS_DELTA_DC_WEIGHT), jpeg_c_get_int_param(c, JINT_DC_SCAN_OPT_MODE), c->write_JFIF_header);
     for (ci = 0; ci < c->num_components; ci++) fprintf(stderr, "   comp %d: %dx%d q %d dc %d ac %d\n", ci, c->comp_info[ci].h_samp_factor, c->comp_info[ci].v_samp_factor, c->comp_info[ci].quant_tbl_no, c->comp_info[ci].dc_tbl_no, c->comp_info[ci].ac_tbl_no);
+  }
+  if (chance2(14)) {      /* Huffman tables of its own, table numbers up to 3 */
+    const int hi = chance2(50) ? 1 : 3;
+    int t;
+    for (t = 0; t <= hi; t++) { if (t > 1 || chance2(60)) own_huff_table(c, t, 0); if (t > 1 || chance2(60)) own_huff_table(c, t, 1); }
+    if (chance2(60)) for (ci = 0; ci < c->num_components; ci++) { c->comp_info[ci].dc_tbl_no = (int)(rnd2() % (unsigned)(hi + 1)); c->comp_info[ci].ac_tbl_no = (int)(rnd2() % (unsigned)(hi + 1)); }
+    if (chance2(50)) c->optimize_coding = FALSE;
   }
 start:
   {
