@@ -137,7 +137,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 grayin=False, quant_table=-1, lambda1=None, lambda2=None, restart=None,
                 progressive=False, fastcrush=False, precision=8, trellis_loops=1, smooth=0, rgb=False,
                 dc_scan_opt=None, dc_ver_weight=None, use_scans_in_trellis=False, trellis_freq_split=0,
-                trellis_eob_opt=False, trellis_q_opt=False, arithmetic=False, arith_cond=None, scans=None, gray_sample=None, yccin=False):
+                trellis_eob_opt=False, trellis_q_opt=False, arithmetic=False, arith_cond=None, scans=None, gray_sample=None, yccin=False, dct=None):
     """Parameters with cjpeg's switch vocabulary (cjpeg.c:371-714).  Without `baseline` or
     `revert` this is cjpeg's default: progressive with scan search (`fastcrush`: fixed 9-scan script)."""
     p = Params()
@@ -176,6 +176,8 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     p.trellis_eob_opt = 1 if trellis_eob_opt else 0
     p.trellis_q_opt = 1 if trellis_q_opt else 0
     p.arith_code = 1 if arithmetic else 0
+    if dct == "fast":              # cjpeg -dct fast: JDCT_IFAST
+        p.dct_method = 1
     if arith_cond is not None:     # ((L, U, K) of conditioning table 0, (L, U, K) of table 1): cinfo->arith_dc_L / arith_dc_U / arith_ac_K
         for t, (lo, up, kx) in enumerate(arith_cond):
             p.arith_dc_L[t], p.arith_dc_U[t], p.arith_ac_K[t] = lo, up, kx

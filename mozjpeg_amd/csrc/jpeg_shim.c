@@ -621,7 +621,10 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
   }
   if (cinfo->master->lossless) return "lossless mode";
   p->smoothing_factor = cinfo->smoothing_factor;   /* cjpeg -smooth N; ignored for raw data / coefficients like in the reference */
-  if (cinfo->dct_method != JDCT_ISLOW) return "dct_method other than JDCT_ISLOW";
+  if (cinfo->dct_method == JDCT_IFAST) {
+    if (cinfo->data_precision != 8) return "JDCT_IFAST with 12-bit samples";
+    p->dct_method = 1;      /* jfdctfst.c: what TurboJPEG's legacy calls select below quality 96, `cjpeg -dct fast` */
+  } else if (cinfo->dct_method != JDCT_ISLOW) return "dct_method JDCT_FLOAT (floating point: not a bit-exact path, SURVEY F5)";
   {
     /* rgb_red/green/blue/pixelsize of jccolor.c / jmorecfg.h for the extended colour spaces */
     int ps = 0, ro = 0, go = 1, bo = 2;
@@ -680,7 +683,7 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
   p->overshoot_deringing = jpeg_c_get_bool_param(cinfo, JBOOLEAN_OVERSHOOT_DERINGING);
   p->lambda_log_scale1 = jpeg_c_get_float_param(cinfo, JFLOAT_LAMBDA_LOG_SCALE1);
   p->lambda_log_scale2 = jpeg_c_get_float_param(cinfo, JFLOAT_LAMBDA_LOG_SCALE2);
-  if (no_pixels == 2) p->trellis_quant = p->trellis_quant_dc = p->overshoot_deringing = 0;   /* no trellis passes when transcoding (jcmaster.c transcode_only) */
+  if (no_pixels == 2) { p->trellis_quant = p->trellis_quant_dc = p->overshoot_deringing = 0; p->dct_method = 0; }   /* no trellis passes when transcoding (jcmaster.c transcode_only) */
   if (cinfo->data_precision == 12 && p->trellis_quant) return "12-bit trellis (the reference itself aborts: jccoefct.c:132-138)";
   /* the remaining extension parameters travel as they are; mjh_encoder_create refuses what the device path lacks */
   p->trellis_eob_opt = jpeg_c_get_bool_param(cinfo, JBOOLEAN_TRELLIS_EOB_OPT);

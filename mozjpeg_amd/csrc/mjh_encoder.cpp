@@ -537,6 +537,8 @@ static int check_supported(const mjh_params *p)
       if ((p->dc_tbl_no[i] > 1 && !(p->huff_tables_given >> (2 * p->dc_tbl_no[i]) & 1)) || (p->ac_tbl_no[i] > 1 && !(p->huff_tables_given >> (2 * p->ac_tbl_no[i] + 1) & 1)))
         return fail(MJH_EUNSUPPORTED, "no Huffman table in slot 2 / 3 (the Annex K tables exist for table numbers 0 and 1; others come through huff_tables_given; JERR_NO_HUFF_TABLE)");
   }
+  if (p->dct_method != 0 && p->dct_method != 1) return fail(MJH_EUNSUPPORTED, "dct_method %d (0 = JDCT_ISLOW, 1 = JDCT_IFAST; the float DCT is outside the bit-exact path)", p->dct_method);
+  if (p->dct_method == 1 && p->data_precision == 12) return fail(MJH_EUNSUPPORTED, "JDCT_IFAST with 12-bit samples");
   if (p->trellis_stats_Ah < 0 || p->trellis_stats_Ah > 13 || p->trellis_stats_Al < 0 || p->trellis_stats_Al > 13) return fail(MJH_EINVAL, "trellis_stats_Ah / Al %d / %d", p->trellis_stats_Ah, p->trellis_stats_Al);
   return MJH_OK;
 }
@@ -1000,7 +1002,13 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       hq.rcp8q[t][k] = 1.0f / (float)(8 * q);
       hq.lambda_tbl[t][k] = (float)(1.0 / (double)(q * q));   // jcdctmgr.c:1017-1021
       {   // the conventional quantizer's divisor: a UINT16 argument in the reference's 8-bit build (see MjhQuant)
-        const int dc = C.precision == 12 ? 8 * q : (int)((8u * (unsigned)q) & 0xFFFFu);
+        // JDCT_IFAST: quantval x the AA&N scale factors of the position (natural order) x 8, rounded at 11 bits (jcdctmgr.c:291-345)
+        static const int aan[64] = { 16384, 22725, 21407, 19266, 16384, 12873, 8867, 4520, 22725, 31521, 29692, 26722, 22725, 17855, 12299, 6270,
+                                     21407, 29692, 27969, 25172, 21407, 16819, 11585, 5906, 19266, 26722, 25172, 22654, 19266, 15137, 10426, 5315,
+                                     16384, 22725, 21407, 19266, 16384, 12873, 8867, 4520, 12873, 17855, 16819, 15137, 12873, 10114, 6967, 3552,
+                                     8867, 12299, 11585, 10426, 8867, 6967, 4799, 2446, 4520, 6270, 5906, 5315, 4520, 3552, 2446, 1247 };
+        const int dc = p->dct_method == 1 ? (int)((((long)q * aan[kZZ[k]] + 1024L) >> 11) & 0xFFFF)
+                                          : C.precision == 12 ? 8 * q : (int)((8u * (unsigned)q) & 0xFFFFu);
         if (dc == 0)      // q = 8192, 16384, 24576: compute_reciprocal(0) divides by zero -- the reference dies
           for (int i = 0; i < C.ncomp; i++) if (p->quant_tbl_no[i] == t) e->fdct_div_zero = true;
         hq.dqc8[t][k] = dc ? dc : 8;
@@ -1474,7 +1482,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   unsigned long long *const nzm = compact ? e->d_nzmask : nullptr;
   e->compact_last = compact;
   const int nbands = p.trellis_quant ? e->nbands : 1;
-  const bool fuse_pre = fuse_seq && !e->debug_taps && nbands == 1 && !ext_qopt;   // (q_opt: one component at a time, each from the stored planes)
+  const bool fuse_pre = fuse_seq && !e->debug_taps && nbands == 1 && !ext_qopt && p.dct_method == 0;   // (q_opt: one component at a time, each from the stored planes)
   // The first tier's queue capacity of the AC trellis trades LDS occupancy (16 records: 15 waves per CU, 48: 5) against the
   // share of blocks that have to be redone by the general big-capacity tier.  The first tier counts, whatever its own
   // capacity, how many blocks of the batch have more than 16 / 24 / 32 records (count_heavy); the counts of an earlier
@@ -1508,7 +1516,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   }
   if (!coef_src) {
     pr.mark("dct_quant");
-    mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, e->d_nq8, n, s, e->fastdiv_all);
+    mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, e->d_nq8, n, s, e->fastdiv_all, p.dct_method == 1);
   }
 
   if (e->arith) {

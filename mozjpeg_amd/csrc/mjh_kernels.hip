@@ -385,6 +385,54 @@ __device__ __forceinline__ void fdct8(int &d0, int &d1, int &d2, int &d3, int &d
   d1 = DESCALE(a7 + z1 + z4, SH);
 }
 
+// jpeg_fdct_ifast jfdctfst.c:117-227: the AA&N butterflies, both passes alike; five multiplies by constants of 8 fractional bits,
+// the products shifted down without rounding (DESCALE is a plain arithmetic shift there, :101-104).  DCTELEM is an int in the C
+// build: nothing is narrowed between the steps.  |operand| < 2^15 and constants < 2^9: 24-bit multiplies are exact.
+__device__ __forceinline__ void fdct8_ifast(int &d0, int &d1, int &d2, int &d3, int &d4, int &d5, int &d6, int &d7)
+{
+  const int t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
+  const int t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+  const int e0 = t0 + t3, e3 = t0 - t3, e1 = t1 + t2, e2 = t1 - t2;
+  d0 = e0 + e1;
+  d4 = e0 - e1;
+  const int z1 = mul24(e2 + e3, 181) >> 8;
+  d2 = e3 + z1;
+  d6 = e3 - z1;
+  const int o0 = t4 + t5, o1 = t5 + t6, o2 = t6 + t7;
+  const int z5 = mul24(o0 - o2, 98) >> 8;
+  const int z2 = (mul24(o0, 139) >> 8) + z5;
+  const int z4 = (mul24(o2, 334) >> 8) + z5;
+  const int z3 = mul24(o1, 181) >> 8;
+  const int z11 = t7 + z3, z13 = t7 - z3;
+  d5 = z13 + z2;
+  d3 = z13 - z2;
+  d1 = z11 + z4;
+  d7 = z11 - z4;
+}
+// scalefactor[row] * scalefactor[col] * 2^14 in natural order (jcdctmgr.c:302-312 and again :733-743)
+struct AanTab { int v[64]; };
+static constexpr AanTab kAan = { {
+  16384, 22725, 21407, 19266, 16384, 12873, 8867, 4520, 22725, 31521, 29692, 26722, 22725, 17855, 12299, 6270,
+  21407, 29692, 27969, 25172, 21407, 16819, 11585, 5906, 19266, 26722, 25172, 22654, 19266, 15137, 10426, 5315,
+  16384, 22725, 21407, 19266, 16384, 12873, 8867, 4520, 12873, 17855, 16819, 15137, 12873, 10114, 6967, 3552,
+  8867, 12299, 11585, 10426, 8867, 6967, 4799, 2446, 4520, 6270, 5906, 5315, 4520, 3552, 2446, 1247 } };
+// what the trellis gets to see of an AA&N coefficient: the scale factor taken out again (forward_DCT jcdctmgr.c:745-750; C division,
+// towards zero; stored as a JCOEF).  N: natural index, a compile-time constant -- the division becomes a multiply-high.
+template <int N>
+__device__ __forceinline__ int aan_unscale(int x)
+{
+  constexpr int sc = kAan.v[N];
+  return (int)(short)(x >= 0 ? (x * 32768 + sc) / (2 * sc) : (x * 32768 - sc) / (2 * sc));
+}
+
+template <int N = 0>
+__device__ __forceinline__ void aan_unscale_all(const int (&d)[64], int (&du)[64])
+{
+  du[N] = aan_unscale<N>(d[N]);
+  if constexpr (N < 63) aan_unscale_all<N + 1>(d, du);
+}
+__device__ __forceinline__ void aan_unscale_all(const int (&)[64], int (&)[1]) { }
+
 __device__ __forceinline__ float catmull_rom(int v1, int v2, int v3, int v4, float t, int size)
 {
   const int tan1 = (v3 - v1) * size;
@@ -412,7 +460,9 @@ __device__ __forceinline__ float catmull_rom(int v1, int v2, int v3, int v4, flo
 // (MjhQuant.mdiv / sdiv) instead of the float-reciprocal division with its integer fix-up; with STATS the AC coefficients are
 // quantized for the statistics only, which need the magnitude category and nothing else (no sign, no signed clamp).
 #define DCTQ_NB 4      // sets of 64 blocks per wave of the FDCT kernel with fused statistics (the others: one set -- a loop only cost them: 12-bit C5 477 -> 532 us)
-template <class T, bool STATS, bool FD>   // uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
+// IFAST: dct_method JDCT_IFAST -- the AA&N transform; the host put its divisors (quantval x scale factors, jcdctmgr.c:291-345) where
+// the conventional quantizer reads them (MjhQuant.dqc8 / rcpc8q), and the trellis' copy of the coefficients is unscaled again.
+template <class T, bool STATS, bool FD, bool IFAST = false>   // uint8_t: 8-bit samples; uint16_t: 12-bit samples (no trellis: coef_uq / lambda are not produced)
 __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant *__restrict__ Q, const T *__restrict__ planes,
                                                int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out,
                                                MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out)
@@ -546,12 +596,22 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
       }
     }
   }
+  if (IFAST) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) fdct8_ifast(d[r * 8], d[r * 8 + 1], d[r * 8 + 2], d[r * 8 + 3], d[r * 8 + 4], d[r * 8 + 5], d[r * 8 + 6], d[r * 8 + 7]);
+#pragma unroll
+    for (int c = 0; c < 8; c++) fdct8_ifast(d[c], d[8 + c], d[16 + c], d[24 + c], d[32 + c], d[40 + c], d[48 + c], d[56 + c]);
+  } else {
 #pragma unroll
   for (int r = 0; r < 8; r++)
     fdct8<0, W12 ? 1 : 2>(d[r * 8], d[r * 8 + 1], d[r * 8 + 2], d[r * 8 + 3], d[r * 8 + 4], d[r * 8 + 5], d[r * 8 + 6], d[r * 8 + 7]);
 #pragma unroll
   for (int c = 0; c < 8; c++)
     fdct8<1, W12 ? 1 : 2>(d[c], d[8 + c], d[16 + c], d[24 + c], d[32 + c], d[40 + c], d[48 + c], d[56 + c]);
+  }
+  // IFAST with the trellis: the raw coefficients as the trellis reads them (natural order; the quantizer below keeps the scaled ones)
+  int du[IFAST ? 64 : 1];
+  if (IFAST) aan_unscale_all(d, du);
 
   float lambda_blk = 0.0f;
   if (!W12 && C.trellis) {
@@ -560,7 +620,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
     // from the host libm.  Both trellis kernels consume it.
     float norm = 0.0f;
 #pragma unroll
-    for (int n = 1; n < 64; n++) norm = norm + (float)mul24(d[n], d[n]);   // |raw coefficient| <= 2^15
+    for (int n = 1; n < 64; n++) { const int rc = IFAST ? du[IFAST ? n : 0] : d[n]; norm = norm + (float)mul24(rc, rc); }   // |raw coefficient| <= 2^15
     norm = (float)((double)norm / 63.0);
     float lambda;
     if (C.lambda_log_scale2 > 0.0f) lambda = (float)(C.pow_scale1 * 1.0 / (C.pow_scale2 + (double)norm));
@@ -611,7 +671,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
     int v = FD ? udiv_mh(ax + (dq >> 1), sdiv_c[k % QCH], mdiv_c[k % QCH]) : udiv_exact(ax + (dq >> 1), dq, rcp_c[k % QCH]);
     if (x < 0) v = -v;
     if (clampq) v = W12 ? max(-16383, min(16383, v)) : max(-1023, min(1023, v));
-    if (!W12) uq[(size_t)k * cc.kstride] = (int16_t)x;   // raw x8 coefficients only feed the (8-bit only) trellis
+    if (!W12) uq[(size_t)k * cc.kstride] = (int16_t)(IFAST ? du[IFAST ? kZZ.v[k] : 0] : x);   // raw x8 coefficients only feed the (8-bit only) trellis
     if (k == 0 || !STATS) qo[(size_t)k * cc.kstride] = (int16_t)v;   // STATS: the AC planes would never be read
     if (!stats && !W12 && k > 0) nzc += (v != 0);
     if (stats && k > 0 && valid) {
@@ -650,6 +710,14 @@ k_dct_quant(MjhConst C, const MjhQuant *__restrict__ Q, const T *__restrict__ pl
             MjhHuffTable *__restrict__ stat_tabs, int slots_per_image, int4 stat_slot_of_comp, uint8_t *__restrict__ nq8_out)
 {
   dct_quant_body<T, STATS, FD>(C, Q, planes, coef_uq, coef_q, lambda_out, stat_tabs, slots_per_image, stat_slot_of_comp, nq8_out);
+}
+
+// JDCT_IFAST (legacy TurboJPEG calls below quality 96, `cjpeg -dct fast`): its own kernel name, the body above
+__global__ void __launch_bounds__(64)
+k_dct_quant_ifast(MjhConst C, const MjhQuant *__restrict__ Q, const uint8_t *__restrict__ planes,
+                  int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out, uint8_t *__restrict__ nq8_out)
+{
+  dct_quant_body<uint8_t, false, false, true>(C, Q, planes, coef_uq, coef_q, lambda_out, nullptr, 0, make_int4(0, 0, 0, 0), nq8_out);
 }
 
 // =============================================================================================
@@ -3468,12 +3536,13 @@ static int max_nblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp;
 static int max_padblk(const MjhConst &C) { int m = 0; for (int i = 0; i < C.ncomp; i++) { int v = C.c[i].wpad * C.c[i].hpad; m = v > m ? v : m; } return m; }
 
 void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
-                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv)
+                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv, int ifast)
 {
   const int nb = (stat_tabs && C.precision != 12) ? DCTQ_NB : 1;      // (= the kernel's NB: the STATS instantiations)
   dim3 grid(((max_nblk(C) + 63) / 64 + nb - 1) / nb, C.ncomp, n);
   const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
-  if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t, false>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
+  if (ifast) hipLaunchKernelGGL(k_dct_quant_ifast, grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, nq8);   // (8-bit samples, no fused statistics: the caller's business)
+  else if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t, false>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else if (stat_tabs && fastdiv) hipLaunchKernelGGL((k_dct_quant<uint8_t, true, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else if (stat_tabs) hipLaunchKernelGGL((k_dct_quant<uint8_t, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else if (fastdiv) hipLaunchKernelGGL((k_dct_quant<uint8_t, false, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);

@@ -8,7 +8,7 @@ void mjh_launch_import_coefs(const MjhConst &C, const MjhCoefSrc &S, void *coef_
 void mjh_launch_import_planes(const MjhConst &C, const MjhPlaneSrc &S, void *planes, int n, hipStream_t s);
 void mjh_launch_color(const MjhConst &C, const void *pix, size_t row_pitch, size_t img_stride, void *planes, int n, hipStream_t s);
 void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, void *uq, void *q, float *lambda,
-                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv = 0);   // fastdiv: every table in use has q <= 255 (MjhQuant.mdiv)
+                    MjhHuffTable *stat_tabs, int spi, const int stat_slot[4], uint8_t *nq8, int n, hipStream_t s, int fastdiv = 0, int ifast = 0);   // ifast: JDCT_IFAST (its own kernel); fastdiv: every table in use has q <= 255 (MjhQuant.mdiv)
 // nzmask != nullptr (here and in mjh_launch_encode / mjh_launch_trellis_ac): the AC planes hold COMPACT records (plane i+1 = the block's i-th
 // non-zero value in position order, nzmask = its non-zero positions) instead of one plane per position
 void mjh_launch_stats_ac(const MjhConst &C, const void *q, const unsigned long long *nzmask, MjhHuffTable *tabs, int spi, const int slot[4], int count_dummies, int n, hipStream_t s);

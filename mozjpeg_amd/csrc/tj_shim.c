@@ -11,9 +11,9 @@
  * Annex K tables scaled by jpeg_set_quality(q, TRUE), standard Huffman tables unless TJPARAM_OPTIMIZE / progressive /
  * 12-bit, no trellis -- with the sampling factors of TJSAMP_*, the byte order of TJPF_*, restart intervals, JFIF
  * density.  Exactly these are mapped onto mjh_params; the output is the byte stream the reference TurboJPEG produces.
- * Outside the GPU path (an ERROR, never a CPU fallback): CMYK / YCCK, lossless, and the FAST DCT --
- * note that the LEGACY tjCompress2 selects the fast DCT unless quality >= 96 or TJFLAG_ACCURATEDCT is given
- * (processFlags turbojpeg.c:522-527); MOZJPEG_HIP_TJ_ACCURATE=1 makes this library use the accurate DCT regardless.
+ * The LEGACY tjCompress2 selects the fast DCT (JDCT_IFAST, jfdctfst.c) unless quality >= 96 or TJFLAG_ACCURATEDCT is given
+ * (processFlags turbojpeg.c:522-527), the 3.x API through TJPARAM_FASTDCT: mjh_params.dct_method, coded bit-exactly like the
+ * accurate one.  Outside the GPU path (an ERROR, never a CPU fallback): CMYK / YCCK, lossless, the fast DCT on 12-bit samples.
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -264,8 +264,7 @@ static int build_params(tjs *t, const char *fn, int width, int height, int pixel
 {
   int subsamp = t->subsamp, gray_out, in_comps = 3;
   if (t->lossless) return fail(t, fn, "lossless mode is outside the GPU path (no CPU fallback)");
-  if (t->fast_dct && !getenv("MOZJPEG_HIP_TJ_ACCURATE"))
-    return fail(t, fn, "the fast DCT is outside the GPU path: pass TJFLAG_ACCURATEDCT / leave TJPARAM_FASTDCT unset, or set MOZJPEG_HIP_TJ_ACCURATE=1 (no CPU fallback)");
+  if (t->fast_dct && precision == 12) return fail(t, fn, "the fast DCT on 12-bit samples is outside the GPU path (no CPU fallback)");
   if (pixelFormat == TJPF_CMYK || t->colorspace == TJCS_CMYK || t->colorspace == TJCS_YCCK) return fail(t, fn, "CMYK / YCCK are outside the GPU path (no CPU fallback)");
   if (pixelFormat == TJPF_GRAY) in_comps = 1;
   gray_out = t->colorspace == TJCS_GRAY || (t->colorspace < 0 && subsamp == TJSAMP_GRAY) || in_comps == 1;
@@ -286,6 +285,7 @@ static int build_params(tjs *t, const char *fn, int width, int height, int pixel
     p->h_samp_factor[0] = kMcuW[subsamp] / 8; p->v_samp_factor[0] = kMcuH[subsamp] / 8;   /* set after the colour space, like setCompDefaults */
   }
   p->data_precision = precision;
+  p->dct_method = t->fast_dct ? 1 : 0;                        /* cinfo->dct_method = JDCT_FASTEST / JDCT_ISLOW, turbojpeg.c:358 */
   p->optimize_coding = precision == 12 ? 1 : t->optimize;     /* turbojpeg.c:375-376; 12-bit: jcparam.c:452-453 */
   p->restart_interval = (unsigned)t->restart_blocks;
   p->restart_in_rows = t->restart_rows;

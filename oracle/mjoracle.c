@@ -559,6 +559,49 @@ static void fdct_islow_p(int data[64], int p1)
 void mjo_fdct_islow(int data[64]) { fdct_islow_p(data, 2); }
 
 /* ------------------------------------------------------------------------------------------
+ * jpeg_fdct_ifast jfdctfst.c:117-227: Arai / Agui / Nakajima, five multiplies per 1-D pass by constants of 8 fractional
+ * bits, the product shifted down WITHOUT rounding (DESCALE is a plain right shift there, :101-104); both passes alike, no
+ * scaling between them.  DCTELEM is an int in the C build (jdct.h), nothing wraps.  The output carries the AA&N scale
+ * factors, which the divisors absorb (mjo_ifast_divisor).
+ * ------------------------------------------------------------------------------------------ */
+static void fdct_ifast_1d(int *d, int stride)
+{
+  const int t0 = d[0] + d[7 * stride], t7 = d[0] - d[7 * stride], t1 = d[stride] + d[6 * stride], t6 = d[stride] - d[6 * stride];
+  const int t2 = d[2 * stride] + d[5 * stride], t5 = d[2 * stride] - d[5 * stride], t3 = d[3 * stride] + d[4 * stride], t4 = d[3 * stride] - d[4 * stride];
+  const int e0 = t0 + t3, e3 = t0 - t3, e1 = t1 + t2, e2 = t1 - t2;
+  const int o0 = t4 + t5, o1 = t5 + t6, o2 = t6 + t7;
+  int z1, z2, z3, z4, z5, z11, z13;
+  d[0] = e0 + e1;
+  d[4 * stride] = e0 - e1;
+  z1 = ((e2 + e3) * 181) >> 8;
+  d[2 * stride] = e3 + z1;
+  d[6 * stride] = e3 - z1;
+  z5 = ((o0 - o2) * 98) >> 8;
+  z2 = ((o0 * 139) >> 8) + z5;
+  z4 = ((o2 * 334) >> 8) + z5;
+  z3 = (o1 * 181) >> 8;
+  z11 = t7 + z3; z13 = t7 - z3;
+  d[5 * stride] = z13 + z2;
+  d[3 * stride] = z13 - z2;
+  d[stride] = z11 + z4;
+  d[7 * stride] = z11 - z4;
+}
+static void fdct_ifast(int data[64])
+{
+  int i;
+  for (i = 0; i < 8; i++) fdct_ifast_1d(data + 8 * i, 1);
+  for (i = 0; i < 8; i++) fdct_ifast_1d(data + i, 8);
+}
+/* scalefactor[row] * scalefactor[col] * 2^14, natural order (jcdctmgr.c:302-312, the same table again at :733-743) */
+static const short kAanScales[64] = {
+  16384, 22725, 21407, 19266, 16384, 12873, 8867, 4520, 22725, 31521, 29692, 26722, 22725, 17855, 12299, 6270,
+  21407, 29692, 27969, 25172, 21407, 16819, 11585, 5906, 19266, 26722, 25172, 22654, 19266, 15137, 10426, 5315,
+  16384, 22725, 21407, 19266, 16384, 12873, 8867, 4520, 12873, 17855, 16819, 15137, 12873, 10114, 6967, 3552,
+  8867, 12299, 11585, 10426, 8867, 6967, 4799, 2446, 4520, 6270, 5906, 5315, 4520, 3552, 2446, 1247 };
+/* the divisor of natural-order position i: quantval * aanscale * 8 / 2^14, rounded (:327-335), as compute_reciprocal's UINT16 argument */
+int mjo_ifast_divisor(int quantval, int i) { return (int)((((long)quantval * kAanScales[i] + 1024L) >> 11) & 0xFFFF); }
+
+/* ------------------------------------------------------------------------------------------
  * a4,a7,a8  convsamp jcdctmgr.c:576, quantize :611 (the reciprocal form there is, for d = 8*q,
  * identical to sign(x)*((|x| + d/2) / d): SURVEY 8a row a7), forward_DCT :693-772,
  * compress_first_pass jccoefct.c:262-353 (dummy blocks :312-345).
@@ -603,14 +646,19 @@ static void forward16(const mjo_params *p, uint16_t *const planes[MJO_MAX_COMPS]
         for (i = 0; i < 64; i++)
           ws[i] = (int)planes[ci][(size_t)(br * 8 + i / 8) * g[ci].pw + bc * 8 + (i & 7)] - center;
         if (p->overshoot_deringing) mjo_deringing(ws, qt[0]);
-        fdct_islow_p(ws, P == 12 ? 1 : 2);
+        if (p->dct_method == 1) fdct_ifast(ws);
+        else fdct_islow_p(ws, P == 12 ? 1 : 2);
         for (i = 0; i < 64; i++) {
           /* 8-bit build: the divisor reaches compute_reciprocal as a UINT16 (jcdctmgr.c:182, :278-282), so a step of 8192 or more
            * wraps -- q = 8450 (quality 1) divides by 67600 mod 65536 = 2064; the 12-bit build keeps the value (:284).  (A wrapped
            * divisor of 0 makes the reference divide by zero: mjo_encode refuses such tables.)  The reciprocal form equals this
            * rounding division for every divisor 8 .. 65528 and |x| <= 32767 (checked exhaustively). */
-          int d = P == 12 ? 8 * qt[i] : (int)((8u * (unsigned)qt[i]) & 0xFFFFu), x = ws[i], v;
+          int d = p->dct_method == 1 ? mjo_ifast_divisor(qt[i], i) : P == 12 ? 8 * qt[i] : (int)((8u * (unsigned)qt[i]) & 0xFFFFu), x = ws[i], v;
           uq[i] = (int16_t)x;   /* (12-bit: may wrap; only the 8-bit trellis reads it) */
+          if (p->dct_method == 1) {   /* what the trellis gets to see: the AA&N factors taken out again, forward_DCT jcdctmgr.c:745-750 (C division: towards zero) */
+            const int sc = kAanScales[i];
+            uq[i] = (int16_t)(x >= 0 ? (x * 32768 + sc) / (2 * sc) : (x * 32768 - sc) / (2 * sc));
+          }
           v = ((x < 0 ? -x : x) + d / 2) / d;
           if (x < 0) v = -v;
           if (p->overshoot_deringing) { /* jcdctmgr.c:761-770 */
@@ -2176,7 +2224,7 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
     if (prec_of(p) != 12)     /* compute_reciprocal(0): the reference divides by zero (see forward16) */
       for (ci = 0; ci < p->num_components; ci++) {
         int k;
-        for (k = 0; k < 64; k++) if (((8u * (unsigned)p->qtbl[p->quant_tbl_no[ci]][k]) & 0xFFFFu) == 0u) return 0;
+        for (k = 0; k < 64; k++) if ((p->dct_method == 1 ? (unsigned)mjo_ifast_divisor(p->qtbl[p->quant_tbl_no[ci]][k], k) : (8u * (unsigned)p->qtbl[p->quant_tbl_no[ci]][k]) & 0xFFFFu) == 0u) return 0;
       }
     if (ps->src) import_planes16(p, ps, planes);
     else color_downsample16(p, ps->pixels, ps->row_stride, planes);

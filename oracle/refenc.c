@@ -68,7 +68,7 @@ int main(int argc, char **argv)
   double l1 = -1e9, l2 = -1e9;
   int dc_scan_opt = -1;
   double dc_ver_weight = -1e9;
-  int precision = 8, yuvin = 0, arithmetic = 0, trellis_loops = 0, smooth = 0, trellis_q_opt = 0, eob_opt = 0, scans_in_trellis = 0, freq_split = 0;
+  int precision = 8, yuvin = 0, dct_fast = 0, arithmetic = 0, trellis_loops = 0, smooth = 0, trellis_q_opt = 0, eob_opt = 0, scans_in_trellis = 0, freq_split = 0;
   const char *arith_cond = NULL, *scanspec = NULL;
   static jpeg_scan_info user_scans[64];
   const char *dump = NULL, *in = NULL, *out = NULL;
@@ -119,6 +119,7 @@ int main(int argc, char **argv)
     else if (!strcmp(a, "-smooth")) smooth = atoi(argv[++i]);   /* cjpeg -smooth N (cjpeg.c: cinfo->smoothing_factor) */
     else if (!strcmp(a, "-arithmetic")) arithmetic = 1;   /* cjpeg -arithmetic (cjpeg.c:371-376): cinfo->arith_code */
     else if (!strcmp(a, "-scanspec")) scanspec = argv[++i];   /* a scan script (cjpeg -scans file, read_scan_script rdswitch.c) on the command line: "c[,c..]:Ss-Se:Ah:Al;..." */
+    else if (!strcmp(a, "-dct")) dct_fast = !strcmp(argv[++i], "fast");
     else if (!strcmp(a, "-arith-cond")) arith_cond = argv[++i];   /* L0,U0,K0,L1,U1,K1: cinfo->arith_dc_L / arith_dc_U / arith_ac_K of tables 0 and 1 (API-only fields, jpeglib.h:447-449) */
     else if (!strcmp(a, "-yuvin")) yuvin = 1;   /* -raw W H input holds component planes: jpeg_write_raw_data */
     else if (!in) in = a;
@@ -160,7 +161,7 @@ int main(int argc, char **argv)
     jpeg_set_defaults(&cinfo);
     cinfo.image_width = w;
     cinfo.image_height = h;
-    cinfo.dct_method = JDCT_ISLOW;
+    cinfo.dct_method = dct_fast ? JDCT_IFAST : JDCT_ISLOW;    /* cjpeg -dct fast / -dct int (cjpeg.c:389-404) */
     cinfo.data_precision = precision;   /* cjpeg.c:533 sets it after jpeg_set_defaults as well */
     if (qtbl >= 0) jpeg_c_set_int_param(&cinfo, JINT_BASE_QUANT_TBL_IDX, qtbl);
     if (l1 > -1e8) jpeg_c_set_float_param(&cinfo, JFLOAT_LAMBDA_LOG_SCALE1, (float)l1);

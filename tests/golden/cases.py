@@ -25,6 +25,10 @@ def images():
     }
 
 
+# testimages/test.scan of the reference (a scan script its CTest suite feeds to `cjpeg -scans`): (components, Ss, Se, Ah, Al)
+TEST_SCAN = [((0, 1, 2), 0, 0, 0, 0), ((0,), 1, 9, 0, 0), ((0,), 10, 41, 0, 2), ((0,), 10, 41, 2, 1), ((0,), 10, 41, 1, 0), ((0,), 42, 63, 0, 0),
+             ((1,), 1, 63, 0, 0), ((2,), 1, 63, 0, 0)]
+
 # switch sets (cjpeg vocabulary, see oracle_lib.make_params).  "gpu": covered by the HIP path today.
 CASES = [
     ("revert", dict(revert=True), True),
@@ -188,6 +192,21 @@ CASES = [
     ("yccin_progressive_422", dict(yccin=True, sample=(2, 1)), True),
     ("yccin_revert_restart1", dict(revert=True, yccin=True, restart=1), True),
     ("yccin_gray_progressive", dict(yccin=True, gray=True), True),        # YCbCr samples into a grayscale file: the Y samples (grayscale_convert jccolor.c:448-466)
+    # JDCT_IFAST (cjpeg -dct fast; what the legacy tjCompress2 selects below quality 96): jfdctfst.c, divisors jcdctmgr.c:291-345, and
+    # under the max-compression profile the trellis on the unscaled coefficients (:731-750).  The first three are the reference's own
+    # bit tests on testorig (CMakeLists.txt:1459, :1498 with testimages/test.scan, :1561)
+    ("ifast_revert_422_opt", dict(revert=True, sample=(2, 1), dct="fast", optimize=True), True),
+    ("ifast_revert_q100_testscan", dict(revert=True, quality=100, dct="fast", scans=TEST_SCAN), True),
+    ("ifast_revert_3x2_prog", dict(revert=True, sample=(3, 2), dct="fast", progressive=True), True),
+    ("ifast_revert", dict(revert=True, dct="fast"), True),                       # tjCompress2(..., TJSAMP_420, 75, 0)
+    ("ifast_revert_q30_444", dict(revert=True, dct="fast", quality=30, sample=(1, 1)), True),
+    ("ifast_revert_gray_restart1", dict(revert=True, dct="fast", gray=True, restart=1), True),
+    ("ifast_base", dict(baseline=True, dct="fast"), True),                       # cjpeg -baseline -dct fast: trellis + deringing on AA&N coefficients
+    ("ifast_default_progressive", dict(dct="fast"), True),
+    ("ifast_q1_wrapped_divisors", dict(quality=1, dct="fast", baseline=True), True),
+    ("ifast_base_q92_444_notrellis_dc", dict(baseline=True, dct="fast", quality=92, sample=(1, 1), notrellis_dc=True), True),
+    ("ifast_arith_base", dict(arithmetic=True, baseline=True, dct="fast"), True),
+    ("ifast_base_trellis_q_opt", dict(baseline=True, dct="fast", trellis_q_opt=True), True),
 ]
 
 
@@ -229,6 +248,9 @@ REFERENCE_PINNED = {
     ("testorig", "revert_440"): "538bc02bd4b4658fd85de6ece6cbeda6",    # MD5_JPEG_440_ISLOW   :1354
     ("testorig", "revert_gray"): "72b51f894b8f4a10b3ee3066770aa38d",   # MD5_JPEG_GRAY_ISLOW  :1362
     ("testorig", "revert_opt_smooth1"): "388708217ac46273ca33086b22827ed8",   # MD5_JPEG_420S_IFAST_OPT :1367 (-sample 2x2 -smooth 1 -dct int -opt)
+    ("testorig", "ifast_revert_422_opt"): "2540287b79d913f91665e660303ab2c8",         # MD5_JPEG_422_IFAST_OPT :1352 (-revert -sample 2x1 -dct fast -opt)
+    ("testorig", "ifast_revert_q100_testscan"): "0ba15f9dab81a703505f835f9dbbac6d",   # MD5_JPEG_420_IFAST_Q100_PROG :1359 (-revert -sample 2x2 -quality 100 -dct fast -scans test.scan)
+    ("testorig", "ifast_revert_3x2_prog"): "1ee5d2c1a77f2da495f993c8c7cceca5",        # MD5_JPEG_3x2_IFAST_PROG :1386 (-revert -sample 3x2 -dct fast -prog)
 }
 
 

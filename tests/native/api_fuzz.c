@@ -159,6 +159,7 @@ static void one_image(struct jpeg_compress_struct *c, int tag, int k, int keep)
     if (chance2(60)) for (ci = 0; ci < c->num_components; ci++) { c->comp_info[ci].dc_tbl_no = (int)(rnd2() % (unsigned)(hi + 1)); c->comp_info[ci].ac_tbl_no = (int)(rnd2() % (unsigned)(hi + 1)); }
     if (chance2(50)) c->optimize_coding = FALSE;
   }
+  if (chance2(25)) c->dct_method = JDCT_IFAST;
 start:
   {
     /* tables: mostly the whole file; otherwise a tables-only stream first, flags of single tables, or write_all_tables FALSE */

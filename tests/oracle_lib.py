@@ -36,7 +36,7 @@ class Params(C.Structure):
                 ("trellis_eob_opt", C.c_int), ("use_scans_in_trellis", C.c_int), ("trellis_freq_split", C.c_int),
                 ("rgb_output", C.c_int), ("trellis_delta_dc_weight", C.c_float), ("dc_scan_opt_mode", C.c_int),
                 ("arith_code", C.c_int), ("arith_dc_L", C.c_int * 4), ("arith_dc_U", C.c_int * 4), ("arith_ac_K", C.c_int * 4),
-                ("ycc_input", C.c_int)]
+                ("ycc_input", C.c_int), ("dct_method", C.c_int)]
 
 
 class Geom(C.Structure):
@@ -76,7 +76,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 noovershoot=False, sample=(2, 2), restart=None, gray=False, grayin=False,
                 quant_table=-1, lambda1=None, lambda2=None, precision=8, trellis_loops=1, smooth=0, trellis_q_opt=False,
                 trellis_eob_opt=False, use_scans_in_trellis=False, trellis_freq_split=0, rgb=False,
-                dc_scan_opt=None, dc_ver_weight=None, arithmetic=False, arith_cond=None, scans=None, gray_sample=None, yccin=False):
+                dc_scan_opt=None, dc_ver_weight=None, arithmetic=False, arith_cond=None, scans=None, gray_sample=None, yccin=False, dct=None):
     """Same switch vocabulary as cjpeg / oracle/refenc.c.  Default (no switch) is cjpeg's default:
     max-compression profile, progressive with scan search."""
     p = Params()
@@ -122,6 +122,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     p.use_scans_in_trellis = 1 if use_scans_in_trellis else 0
     p.trellis_freq_split = trellis_freq_split
     p.arith_code = 1 if arithmetic else 0
+    p.dct_method = 1 if dct == "fast" else 0      # cjpeg -dct fast: JDCT_IFAST
     if arith_cond is not None:     # ((L, U, K) of conditioning table 0, (L, U, K) of table 1)
         for t, (lo, up, kx) in enumerate(arith_cond):
             p.arith_dc_L[t], p.arith_dc_U[t], p.arith_ac_K[t] = lo, up, kx
@@ -359,6 +360,8 @@ def ref_switches(**kw):
         sw += ["-trellis-loops", str(kw["trellis_loops"])]
     if kw.get("arithmetic"):
         sw.append("-arithmetic")
+    if kw.get("dct") is not None:
+        sw += ["-dct", kw["dct"]]
     if kw.get("scans") is not None:           # (refenc's own switch: cjpeg reads the script from a file)
         sw += ["-scanspec", ";".join("%s:%d-%d:%d:%d" % (",".join(str(c) for c in comps), ss, se, ah, al) for comps, ss, se, ah, al in kw["scans"])]
     if kw.get("arith_cond") is not None:      # (refenc's own switch: the API fields cinfo->arith_dc_L / arith_dc_U / arith_ac_K have no cjpeg switch)

@@ -4,6 +4,7 @@ libmozjpeg_hip_jpeg62.so in front of it; its output files must equal the referen
 import hashlib
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -225,6 +226,28 @@ def test_rgb_output_with_icc_profile_reproduces_the_references_pinned_md5(standa
     assert hashlib.md5(open(out, "rb").read()).hexdigest() == "1d44a406f61da743b5fd31c0a9abdca3"
 
 
+@needs
+@pytest.mark.parametrize("standalone", [False, True])
+@pytest.mark.parametrize("name,args,md5", [
+    ("422-ifast-opt", ["-revert", "-sample", "2x1", "-dct", "fast", "-opt"], "2540287b79d913f91665e660303ab2c8"),
+    ("420-q100-ifast-prog", ["-revert", "-sample", "2x2", "-quality", "100", "-dct", "fast", "-scans", "TEST_SCAN"], "0ba15f9dab81a703505f835f9dbbac6d"),
+    ("3x2-ifast-prog", ["-revert", "-sample", "3x2", "-dct", "fast", "-prog"], "1ee5d2c1a77f2da495f993c8c7cceca5")])
+def test_fast_dct_reproduces_the_references_pinned_md5s(name, args, md5, standalone, tmp_path):
+    """the reference's own bit tests of `cjpeg -dct fast` on testorig.ppm (CMakeLists.txt:1459, :1498, :1561: MD5_JPEG_422_IFAST_OPT,
+    MD5_JPEG_420_IFAST_Q100_PROG with testimages/test.scan, MD5_JPEG_3x2_IFAST_PROG) through the unchanged cjpeg on the GPU path"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from cases import TEST_SCAN
+    scan = str(tmp_path / "test.scan")
+    with open(scan, "w") as f:
+        for comps, ss, se, ah, al in TEST_SCAN:
+            f.write("%s: %d %d %d %d;\n" % (" ".join(str(c) for c in comps), ss, se, ah, al))
+    args = [scan if a == "TEST_SCAN" else a for a in args]
+    out = str(tmp_path / "o.jpg")
+    r = run_cjpeg_standalone(args, out) if standalone else run_cjpeg(args, out)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == md5
+
+
 HARNESS = os.path.join(ROOT, "tests", "native", "shim_harness")
 needs_h = pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(SHIM)), reason="tests/native/shim_harness not built")
 
@@ -287,6 +310,12 @@ ACCURATE, BOTTOMUP, PROGRESSIVE = 4096, 2, 16384
 
 
 TJSHIM = os.path.join(ROOT, "mozjpeg_amd", "libmozjpeg_hip_turbojpeg.so")
+# (subsampling, quality, flags) of a legacy tjCompress2 call.  Without TJFLAG_ACCURATEDCT and below quality 96 the call selects
+# JDCT_FASTEST = JDCT_IFAST (processFlags turbojpeg.c:522-527) -- its most common form: every set is run both ways
+_TJ_ACCURATE_CALLS = [("420", 75, ACCURATE), ("444", 96, 0), ("422", 80, ACCURATE | BOTTOMUP), ("GRAY", 75, ACCURATE), ("440", 60, ACCURATE),
+                      ("420", 85, ACCURATE | PROGRESSIVE), ("411", 75, ACCURATE), ("441", 90, ACCURATE | PROGRESSIVE)]
+TJ_DEFAULT_CALLS = [(ss, q if q < 96 else 95, f & ~ACCURATE) for ss, q, f in _TJ_ACCURATE_CALLS]
+TJ_CALLS = _TJ_ACCURATE_CALLS + TJ_DEFAULT_CALLS
 
 
 def tj_run(raw, w, h, pf, ss, q, flags, out, preload):
@@ -304,9 +333,7 @@ def tj_run(raw, w, h, pf, ss, q, flags, out, preload):
 
 @needs_tj
 @pytest.mark.parametrize("pfname", list(TJPF))
-@pytest.mark.parametrize("ssname,q,flags", [("420", 75, ACCURATE), ("444", 96, 0), ("422", 80, ACCURATE | BOTTOMUP),
-                                            ("GRAY", 75, ACCURATE), ("440", 60, ACCURATE), ("420", 85, ACCURATE | PROGRESSIVE),
-                                            ("411", 75, ACCURATE), ("441", 90, ACCURATE | PROGRESSIVE)])
+@pytest.mark.parametrize("ssname,q,flags", TJ_CALLS)
 def test_unchanged_tjcompress2_through_the_shim(pfname, ssname, q, flags, tmp_path):
     import numpy as np
     rgb = O.read_ppm(PPM)
@@ -327,9 +354,7 @@ def test_unchanged_tjcompress2_through_the_shim(pfname, ssname, q, flags, tmp_pa
 
 @needs_tj
 @pytest.mark.parametrize("pfname", ["RGB", "BGRX", "XRGB"])
-@pytest.mark.parametrize("ssname,q,flags", [("420", 75, ACCURATE), ("444", 96, 0), ("422", 80, ACCURATE | BOTTOMUP),
-                                            ("GRAY", 75, ACCURATE), ("440", 60, ACCURATE), ("420", 85, ACCURATE | PROGRESSIVE),
-                                            ("411", 75, ACCURATE), ("441", 90, ACCURATE | PROGRESSIVE)])
+@pytest.mark.parametrize("ssname,q,flags", TJ_CALLS)
 def test_turbojpeg_signature_exports_match_the_reference_turbojpeg(pfname, ssname, q, flags, tmp_path):
     """libmozjpeg_hip_turbojpeg.so: tjInitCompress / tjCompress2 / tjDestroy served directly by the batch encoder"""
     if not os.path.exists(TJSHIM):
@@ -353,7 +378,8 @@ def test_turbojpeg_signature_exports_match_the_reference_turbojpeg(pfname, ssnam
 
 @needs_tj
 @pytest.mark.parametrize("w,h,ssname,q,flags", [(227, 149, "420", 75, ACCURATE), (64, 48, "444", 96, 0), (50, 33, "GRAY", 75, ACCURATE),
-                                                (229, 151, "411", 75, ACCURATE), (227, 149, "420", 85, ACCURATE | PROGRESSIVE)])
+                                                (229, 151, "411", 75, ACCURATE), (227, 149, "420", 85, ACCURATE | PROGRESSIVE),
+                                                (227, 149, "420", 75, 0), (101, 77, "422", 50, 0), (229, 151, "411", 85, PROGRESSIVE)])
 def test_turbojpeg_signature_yuv_exports_match_the_reference_turbojpeg(w, h, ssname, q, flags, tmp_path):
     if not os.path.exists(TJSHIM):
         pytest.skip("TurboJPEG-signature library not built")
@@ -373,16 +399,20 @@ def test_turbojpeg_signature_yuv_exports_match_the_reference_turbojpeg(w, h, ssn
 
 @needs_tj
 @pytest.mark.parametrize("preload", [True, "tj"])
-def test_tjcompress2_fast_dct_is_refused_not_emulated(preload, tmp_path):
-    """without TJFLAG_ACCURATEDCT and quality < 96 TurboJPEG selects JDCT_FASTEST (turbojpeg.c:523-526):
-    outside the integer-DCT hot path, so the drop-in must fail loudly"""
+@pytest.mark.parametrize("ssname,q,flags", TJ_DEFAULT_CALLS)
+def test_tjcompress2_default_flags_select_the_fast_dct_bit_exactly(ssname, q, flags, preload, tmp_path):
+    """tjCompress2(..., flags without TJFLAG_ACCURATEDCT) below quality 96 = JDCT_IFAST (turbojpeg.c:522-527, jfdctfst.c): the
+    reference TurboJPEG's bytes, through the libjpeg drop-in underneath it and through the TurboJPEG-signature library"""
     rgb = O.read_ppm(PPM)
     h, w = rgb.shape[:2]
     raw = str(tmp_path / "in.raw")
     rgb.tofile(raw)
-    r = tj_run(raw, w, h, 0, 2, 75, 0, str(tmp_path / "o.jpg"), preload=preload)
-    assert r.returncode != 0
-    assert b"no CPU fallback" in r.stderr
+    ref, gpu = str(tmp_path / "ref.jpg"), str(tmp_path / "gpu.jpg")
+    r0 = tj_run(raw, w, h, 0, TJSAMP[ssname], q, flags, ref, preload=False)
+    r1 = tj_run(raw, w, h, 0, TJSAMP[ssname], q, flags, gpu, preload=preload)
+    assert r0.returncode == 0, r0.stderr.decode()
+    assert r1.returncode == 0, r1.stderr.decode()
+    assert open(gpu, "rb").read() == open(ref, "rb").read()
 
 
 @needs_tj

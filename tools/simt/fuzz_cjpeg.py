@@ -315,9 +315,11 @@ def main():
             if i < first:
                 continue
             if not transcode:
-                def cmd_of(out, a=a, src=src):
-                    return [CJPEG, "-dct", "int"] + a + ["-outfile", out, src]
-                what = " ".join(a)
+                # (a generator of its own for the DCT method: the cases of older seeds keep their other switches)
+                dct = "fast" if (not twelve and np.random.default_rng(seed * 7919 + i).random() < 0.25) else "int"
+                def cmd_of(out, a=a, src=src, dct=dct):
+                    return [CJPEG, "-dct", dct] + a + ["-outfile", out, src]
+                what = " ".join((["-dct", "fast"] if dct == "fast" else []) + a)
             else:
                 # jpegtran: a reference-made file of the drawn settings, re-coded with random jpegtran switches
                 mid = os.path.join(tmp, "mid.jpg")

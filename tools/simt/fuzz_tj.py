@@ -43,6 +43,8 @@ def main():
         ss = int(rng.integers(0, 7))
         q = int(rng.choice([1, 5, 30, 50, 75, 80, 85, 90, 95, 96, 100])) if rng.random() < 0.7 else int(rng.integers(1, 101))
         flags = ACCURATE if rng.random() < 0.9 else (FASTDCT if rng.random() < 0.5 else 0)
+        if np.random.default_rng(seed * 7919 + i).random() < 0.5:      # (its own generator: half of the calls as an application makes them -- no TJFLAG_ACCURATEDCT: JDCT_IFAST below quality 96)
+            flags &= ~ACCURATE
         if rng.random() < 0.3:
             flags |= PROGRESSIVE
         kind = int(rng.integers(0, 3))
