@@ -70,5 +70,26 @@ def main():
     print("wrote %d transcode goldens" % len(outt))
 
 
+def calls():
+    """goldens_calls.json: what the test clients of the libjpeg API (tests/native) print when they run on the REFERENCE's library --
+    call sequences no switch set reaches: abbreviated datastreams, several images from one object, tables of the client's own"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(HERE))
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+    env["LD_LIBRARY_PATH"] = O.REF_DIR
+    out = {}
+    for sc in ("abbreviated", "custom_huffman"):
+        out["shim_harness " + sc] = subprocess.check_output([os.path.join(root, "tests", "native", "shim_harness"), sc], env=env).decode()
+    for i in range(40):
+        r = subprocess.run([os.path.join(root, "tests", "native", "api_fuzz"), "2026", str(i)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        out["api_fuzz 2026 %d" % i] = r.stdout.decode() if r.returncode == 0 else None      # None: the reference itself refuses the draw
+    with open(os.path.join(HERE, "goldens_calls.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote %d call-sequence goldens" % len(out))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--calls":
+        calls()
+    else:
+        main()

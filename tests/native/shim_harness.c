@@ -196,7 +196,7 @@ int main(int argc, char **argv)
       }
     } else if (!strcmp(sc, "custom_huffman")) {
       /* Huffman tables of the application's own with optimize_coding off (two symbols of equal code length swapped in AC table 0):
-       * the reference codes with them; the device path has the Annex K tables or optimal ones -- it must refuse, never code with others */
+       * the reference codes with them (start_pass_huff, jchuff.c:190-196), and so does the device path (mjh_params.huff_tables_given) */
       struct jpeg_compress_struct c;
       unsigned char *o = NULL, *img = make_image(96, 64, 31), t;
       unsigned long n = 0;
@@ -211,6 +211,41 @@ int main(int argc, char **argv)
       printf("custom_huffman %lu %016lx\n", n, hash(o, n));
       jpeg_destroy_compress(&c);
       free(o); free(img);
+    } else if (!strcmp(sc, "abbreviated")) {
+      /* libjpeg.txt "Abbreviated datastreams and multiple images": the tables once, then frames without them -- how an MJPEG writer
+       * or libtiff's JPEG codec drives the library.  (a) jpeg_write_tables + three frames with write_all_tables FALSE, parameters set
+       * once (fastest profile: Annex K Huffman tables); (b) the same with optimal Huffman tables: each frame carries its own DHT, no
+       * DQT; (c) mozjpeg's defaults (progressive, scan search, trellis): the first frame whole, then two with FALSE -- what the object
+       * keeps from frame to frame (table flags, optimal DC tables, Ah / Al) decides the bytes; (d) jpeg_suppress_tables(TRUE) with
+       * the luminance quantization table alone marked unsent again */
+      int v, k;
+      for (v = 0; v < 4; v++) {
+        struct jpeg_compress_struct c;
+        unsigned char *o = NULL;
+        unsigned long n = 0;
+        c.err = jpeg_std_error(&err);
+        jpeg_create_compress(&c);
+        jpeg_mem_dest(&c, &o, &n);
+        if (v != 2) jpeg_c_set_int_param(&c, JINT_COMPRESS_PROFILE, JCP_FASTEST);
+        setup(&c, 176, 112, v == 2 ? 85 : 70, v != 2);
+        if (v == 1) c.optimize_coding = TRUE;
+        if (v == 0 || v == 1) {
+          jpeg_write_tables(&c);
+          printf("abbreviated %d tables %lu %016lx\n", v, n, hash(o, n));
+        }
+        if (v == 3) { jpeg_suppress_tables(&c, TRUE); c.quant_tbl_ptrs[0]->sent_table = FALSE; }
+        for (k = 0; k < 3; k++) {
+          unsigned char *img = make_image(176, 112, 40 + 4 * v + k);
+          free(o); o = NULL; n = 0;
+          c.dest = NULL;
+          jpeg_mem_dest(&c, &o, &n);
+          jpeg_start_compress(&c, v == 2 && k == 0 ? TRUE : FALSE); rows(&c, img, 112); jpeg_finish_compress(&c);
+          printf("abbreviated %d frame %d %lu %016lx\n", v, k, n, hash(o, n));
+          free(img);
+        }
+        jpeg_destroy_compress(&c);
+        free(o);
+      }
     } else if (!strcmp(sc, "color_spaces")) {
       /* what an application sets in in_color_space / per component besides plain RGB: samples that are YCbCr already (null_convert,
        * jccolor.c:687-692 -- e.g. Pillow's "YCbCr" mode), an extended pixel order with a pad byte, and ONE component whose sampling

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_params_struct_layout_matches_header():
     # sizeof(mjh_params) computed from the header's field list: ints/floats are 4 bytes
-    assert C.sizeof(M.Params) == 4 * (4 + 6 * 4) + 2 * 64 * 4 + 4 * 5 + 4 * 2 + 4 * 3 + C.sizeof(M.Scan) * 64 + 8 + 16 + 4 + 4 + 4 + 4 + 6 * 4 + 4 + 6 * 4   # (+ arith_code, + arith_dc_L / arith_dc_U / arith_ac_K of two tables)
+    assert C.sizeof(M.Params) == 4 * (4 + 6 * 4) + 2 * 64 * 4 + 4 * 5 + 4 * 2 + 4 * 3 + C.sizeof(M.Scan) * 64 + 8 + 16 + 4 + 4 + 4 + 4 + 6 * 4 + 4 + 6 * 4 + 2 * 4 + 4 + 8 * 17 + 8 * 256 + 4   # (+ arith_code, + arith_dc_L / arith_dc_U / arith_ac_K of two tables; round 6: + trellis_stats_Ah / Al, huff_tables_given, huff_bits, huff_vals, dct_method)
     assert C.sizeof(M.Scan) == 4 * 9
 
 

@@ -91,10 +91,11 @@ HARNESS = os.path.join(ROOT, "tests", "native", "shim_harness")
 
 
 @pytest.mark.skipif(not os.path.exists(HARNESS), reason="tests/native/shim_harness not built")
-@pytest.mark.parametrize("scenario", ["interleaved", "abort_reuse", "abort_midway", "markers", "stdio", "ext_params", "color_spaces"])
+@pytest.mark.parametrize("scenario", ["interleaved", "abort_reuse", "abort_midway", "markers", "stdio", "ext_params", "color_spaces", "custom_huffman", "abbreviated"])
 def test_libjpeg_client_scenarios_on_the_emulator(fz, scenario):
     """tests/native/shim_harness.c (two objects interleaved, abort + reuse, markers, stdio destination, the extension parameters,
-    in_color_space = JCS_YCbCr / an extended pixel order / one component with the application's sampling factors) against the
+    in_color_space = JCS_YCbCr / an extended pixel order / one component with the application's sampling factors, Huffman tables of
+    the application's own with optimize_coding off, abbreviated datastreams over several frames of one object) against the
     reference's library, the shipped shim in front of it, and the shipped stand-alone library"""
     F, d = fz
     want = F.run([HARNESS, scenario], {})
@@ -103,18 +104,6 @@ def test_libjpeg_client_scenarios_on_the_emulator(fz, scenario):
         got = F.run([HARNESS, scenario], {}, **kw)
         assert got.returncode == 0, got.stderr.decode()[-2000:]
         assert got.stdout == want.stdout, (kw, got.stdout, want.stdout)
-
-
-@pytest.mark.skipif(not os.path.exists(HARNESS), reason="tests/native/shim_harness not built")
-def test_huffman_tables_of_the_applications_own_without_optimize_coding_are_refused(fz):
-    """the reference codes with them (jchuff.c start_pass_huff); the device has the Annex K tables or optimal ones: an error with
-    the reason, never a file coded with other tables than the application asked for"""
-    F, d = fz
-    want = F.run([HARNESS, "custom_huffman"], {})
-    assert want.returncode == 0 and want.stdout.startswith(b"custom_huffman ")
-    for kw in (dict(preload=os.path.join(d, "libmozjpeg_hip_jpeg62.so")), dict(libpath=os.path.join(d, "standalone"))):
-        got = F.run([HARNESS, "custom_huffman"], {}, **kw)
-        assert got.returncode != 0 and b"Huffman tables of the application's own" in got.stderr and got.stdout == b"", (kw, got.stdout, got.stderr)
 
 
 MT_BENCH = os.path.join(ROOT, "tests", "native", "mt_bench")
@@ -150,8 +139,9 @@ def test_random_command_lines_through_the_shipped_libraries_on_the_emulator():
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "tests", "native", "api_fuzz")), reason="tests/native/api_fuzz not built")
 def test_random_libjpeg_calls_through_the_shipped_libraries_on_the_emulator():
-    """a slice of tools/simt/fuzz_api.py (tests/native/api_fuzz.c: parameters and calls drawn from a seed; the reference with a new
-    object per image, INTEGRATION.md 1a'); refusals with a reason are tallied by the tool, anything else is a failure"""
+    """a slice of tools/simt/fuzz_api.py (tests/native/api_fuzz.c: parameters and calls drawn from a seed -- abbreviated datastreams,
+    several images from ONE object on the reference's side too, tables of its own, the fast DCT); refusals with a reason are tallied
+    by the tool, anything else is a failure"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "simt", "fuzz_api.py"), "7", "50"], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=900)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
