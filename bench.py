@@ -159,6 +159,10 @@ def other_config_line(M, torch, key, device, budget_s, t_end):
     w, h, kw = cfg["w"], cfg["h"], cfg["kw"]
     twelve = kw.get("precision", 8) == 12
     B = min(cfg["batch"], 32 if w * h > 4000000 else 64)
+    calls_per_step = 1
+    if cfg.get("total"):                       # C4: the whole job of `total` frames = total / batch encode calls of `batch` frames
+        B = cfg["batch"]
+        calls_per_step = cfg["total"] // cfg["batch"]
     t_start = time.perf_counter()
     distinct = min(B, 4)                       # synthetic frames are the expensive part on the host: 4 distinct, repeated
     frames = make_frames(w, h, [1234 + i for i in range(distinct)], twelve, 1)
@@ -187,15 +191,18 @@ def other_config_line(M, torch, key, device, budget_s, t_end):
         steps = 0
         left = min(budget_s - (t0 - t_start), t_end - t0)
         while steps < 3 or (time.perf_counter() - t0 < min(1.5, left) and steps < 400):
-            enc.encode_tensor(d, stream="own")
+            for _ in range(calls_per_step):
+                enc.encode_tensor(d, stream="own")
             steps += 1
         enc.sync()
         dt = (time.perf_counter() - t0) / steps
         dom = dict(enc.kernel_times())
         dom_ms = dom.get(focus) if focus else None
         algo = float(batch.nbytes) + float(sum(len(j) for j in jp))
-        out = {"workload": cfg["name"], "frames_per_step": int(len(batch)), "steps": steps, "ms_per_step": round(dt * 1e3, 3),
-               "value": round(float(w) * h * len(batch) / dt / 1e6, 1), "unit": "Mpixels/s", "bit_exact": be}
+        out = {"workload": cfg["name"], "frames_per_step": int(len(batch)) * calls_per_step, "steps": steps, "ms_per_step": round(dt * 1e3, 3),
+               "value": round(float(w) * h * len(batch) * calls_per_step / dt / 1e6, 1), "unit": "Mpixels/s", "bit_exact": be}
+        if calls_per_step > 1:
+            out["encode_calls_per_step"] = calls_per_step
         if dom_ms:
             out["roofline"] = {"kernel": focus, "kernel_ms": round(dom_ms, 4), "achieved": round(algo / (dom_ms * 1e-3) / 1e9, 1),
                                "unit": "GB/s", "frac": round(algo / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
@@ -281,6 +288,36 @@ def dominant_traffic(config, dom, frames_per_call):
     if stale:
         return None, "stale: the kernels of this interval changed after the newest PMC passes of this configuration (%s) -- re-run tools/profile_round.sh" % stale
     return None, "no PMC passes committed for this configuration / interval"
+
+
+def dominant_issue(config, dom, frames_per_call, dom_ms):
+    """What bounds the dominant interval when it is not the memory system: VALU issue.  From the newest committed SQ counter
+    passes of this configuration (profiles/r*_pmc_sq_batch*.json, tools/pmc_sq.py): wave-instructions per launch of the interval's
+    kernels, scaled to this batch; a SIMD issues one wave64 VALU instruction per 4 cycles (1024 SIMDs x 2.4 GHz,
+    MI355X_MICROARCH.md), so issue_frac = instructions x 4 / (1024 x 2.4e9 x the interval's measured time).  lanes_per_inst =
+    SQ_THREAD_CYCLES_VALU / (4 SQ_ACTIVE_INST_VALU).  None when the interval's kernels are not the profiled machine code."""
+    if config != "metric":
+        return None
+    prefixes = INTERVAL_KERNELS.get(dom, ())
+    now = kernel_fingerprints()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_batch*.json")), reverse=True):
+        try:
+            j = json.load(open(path))
+            meta = j.get("_meta") or {}
+            batch = float(meta.get("frames_per_launch") or os.path.basename(path).split("batch")[1].split(".")[0])
+            mine = {k: v for k, v in j.items() if k != "_meta" and any(k.startswith(pf) for pf in prefixes)}
+            then = meta.get("kernel_isa") or {}
+            if not mine or not all(k in then and now.get(k) == then[k] for k in mine):
+                continue
+            insts = sum(v["SQ_INSTS_VALU"] * v.get("launches_per_step", 1) for v in mine.values()) * frames_per_call / batch
+            thr = sum(v.get("SQ_THREAD_CYCLES_VALU", 0.0) for v in mine.values())
+            act = sum(v.get("SQ_ACTIVE_INST_VALU", 0.0) for v in mine.values())
+            return {"valu_wave_instructions_per_launch": int(insts), "issue_frac": round(insts * 4.0 / (1024 * 2.4e9 * dom_ms * 1e-3), 4),
+                    "lanes_per_instruction": round(thr / (4.0 * act), 1) if act else None,
+                    "source": "%s (SQ_INSTS_VALU per launch, scaled to this batch; machine code of the interval's kernels identical to the profiled tree's)" % os.path.relpath(path, ROOT)}
+        except Exception:
+            continue
+    return None
 
 
 def baseline_metric():
@@ -641,7 +678,7 @@ def main():
     if args.other_configs == "auto" and args.config == "metric" and world == 1 and not args.no_inflight_leg:
         others = {}
         t_end = time.perf_counter() + args.other_budget
-        keys = ["c2", "c3", "c5t", "c5"]
+        keys = ["c2", "c3", "c4", "c5t", "c5"]
         for i, key in enumerate(keys):
             left = t_end - time.perf_counter()
             if left < 4.0:
@@ -704,6 +741,8 @@ def main():
             "config": {"workload": cfg["name"], "config_key": args.config,
                        "frames_per_step_per_gpu": nframes, "frames_per_encode_call": int(per_call),
                        "distinct_frames": int(nframes // repeats),
+                       "value_definition": "device-resident (this line's `value`); SURVEY 8d / BASELINE.md section 3 define the metric from pinned host "
+                                           "pixels to JPEG bytes in host memory: that number is `value_host_inclusive`",
                        "input": "resident in HBM", "output": "complete JPEG files in HBM",
                        "parallelism": "images sharded, 1 process per GPU, no collective"},
             "bit_exact": bitexact,
@@ -722,6 +761,12 @@ def main():
                          "kernel_ms_per_call(untimed pass, every kernel bracketed)":
                              {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])}},
         }
+        issue = dominant_issue(args.config, dom, per_call, dom_ms)
+        if issue is not None:
+            out["roofline"]["valu_issue"] = issue      # (the interval is VALU-issue bound, not HBM bound: this is the ceiling it is near)
+        if elapsed < 1.0:
+            out["timed_region_warning"] = ("the timed region is %.2f s (%d steps): one noisy box moves it by percent -- the default run "
+                                           "(no --steps) times 3-5 s" % (elapsed, args.steps))
         if others is not None:
             out["other_configs"] = others
         if pipelined is not None:

@@ -486,6 +486,10 @@ static int check_supported(const mjh_params *p)
         return fail(MJH_EUNSUPPORTED, "optimize_scans needs the jpeg_search_progression script");
     }
     bool dc_seen[MJH_MAX_COMPS] = { false, false, false, false };
+    // the successive-approximation bookkeeping of validate_script (jcmaster.c:364-384): Al of the last scan that carried a
+    // coefficient, -1 = not sent yet; a script with the scan search on is not validated at all (:286-292)
+    int last_bitpos[MJH_MAX_COMPS][64];
+    for (int c = 0; c < MJH_MAX_COMPS; c++) for (int k = 0; k < 64; k++) last_bitpos[c][k] = -1;
     for (int si = 0; si < p->num_scans; si++) {
       const mjh_scan &sc = p->scan_info[si];
       if (sc.comps_in_scan < 1 || sc.comps_in_scan > p->num_components) return fail(MJH_EINVAL, "scan %d: component count", si);
@@ -500,8 +504,18 @@ static int check_supported(const mjh_params *p)
       for (int ci = 0; ci < sc.comps_in_scan; ci++) {
         if (sc.Ss == 0) dc_seen[sc.component_index[ci]] = true;
         else if (!dc_seen[sc.component_index[ci]] && !p->optimize_scans) return fail(MJH_EINVAL, "scan %d: AC before DC", si);
+        if (!p->optimize_scans)
+          for (int k = sc.Ss; k <= sc.Se; k++) {
+            int &lb = last_bitpos[sc.component_index[ci]][k];
+            if (lb < 0 ? sc.Ah != 0 : (sc.Ah != lb || sc.Al != sc.Ah - 1))
+              return fail(MJH_EINVAL, "scan %d: a first scan with Ah != 0, or a refinement that does not continue at the bit the last scan of the coefficient left (JERR_BAD_PROG_SCRIPT, jcmaster.c:371-381)", si);
+            lb = sc.Al;
+          }
       }
     }
+    if (!p->optimize_scans)
+      for (int c = 0; c < p->num_components; c++)
+        if (!dc_seen[c]) return fail(MJH_EINVAL, "the script sends no DC data for component %d (JERR_MISSING_DATA, jcmaster.c:420-432)", c);
   }
   if (p->restart_interval > 65535u || p->restart_in_rows < 0) return fail(MJH_EINVAL, "bad restart interval");
   if (p->arith_code) {

@@ -44,9 +44,11 @@ def test_random_libjpeg_calls(index):
     want = run(cmd)
     import json
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "goldens_calls.json")))["api_fuzz 2026 %d" % index]      # (made by the reference: make_goldens.py --calls)
-    if want.returncode != 0:
+    if want.returncode != 0:      # the reference itself refuses this draw (an ERREXIT of its own): so must the libraries under test
         assert golden is None
-        pytest.skip("the reference itself refuses this draw")
+        for kw in (dict(preload=SHIM), dict(libpath=STANDALONE_DIR)):
+            assert run(cmd, **kw).returncode != 0, kw
+        return
     assert want.stdout.decode() == golden
     for kw in (dict(preload=SHIM), dict(libpath=STANDALONE_DIR)):
         got = run(cmd, **kw)

@@ -7,7 +7,7 @@ db() { find "$O" -name "$1_results.db" | head -1; }
 tail -1 "$O/bench_default.log" > "${P}_bench_batch$BATCH.json"
 python tools/rocprof_summary.py "$(db stats)" > "${P}_kernel_stats_batch$BATCH.csv"
 python tools/pmc_traffic.py "$(db fetch)" "$(db write)" "$BATCH" $((3840*2160*3)) > "${P}_pmc_hbm_traffic_batch$BATCH.json"
-python tools/pmc_sq.py "$(db sq)" $(db sq2) > "${P}_pmc_sq_batch$BATCH.json" 2>/dev/null
+python tools/pmc_sq.py "$(db sq)" $(db sq2) --frames=$BATCH > "${P}_pmc_sq_batch$BATCH.json" 2>/dev/null
 if [ -f "$O/bench_c3.log" ]; then
   tail -1 "$O/bench_c3.log" > "${P}_c3_bench_batch32.json"
   python tools/rocprof_summary.py "$(db c3_stats)" > "${P}_c3_kernel_stats_batch32.csv"

@@ -22,6 +22,18 @@ def main():
                 continue
             out.setdefault(short, {})[cname] = round(avg, 1)
             out[short]["launches"] = n
+    # which machine code the passes were taken on (bench.py quotes the counters only for kernels that still compile to it)
+    try:
+        import os
+        import subprocess
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        isa = json.load(open(os.path.join(root, "mozjpeg_amd", "kernel_isa.json")))
+        frames = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--frames=")]
+        out["_meta"] = {"kernel_isa": {k: v["sha"] for k, v in isa["kernels"].items() if k in out},
+                        "profile_head": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=root, stdout=subprocess.PIPE).stdout.decode().strip(),
+                        "frames_per_launch": int(frames[0]) if frames else None}
+    except Exception:
+        pass
     print(json.dumps(out, indent=1, sort_keys=True))
 
 
