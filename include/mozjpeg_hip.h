@@ -148,7 +148,7 @@ typedef struct {
   uint8_t huff_vals[8][256];
   /* cinfo->dct_method (jpeglib.h:456): 0 = JDCT_ISLOW (jfdctint.c), 1 = JDCT_IFAST (jfdctfst.c: AA&N with 8-bit constants,
    * its scale factors folded into the divisors, jcdctmgr.c:291-345) -- what the legacy TurboJPEG calls select below quality 96
-   * (turbojpeg.c:522-527) and `cjpeg -dct fast`.  8-bit samples only. */
+   * (turbojpeg.c:522-527) and `cjpeg -dct fast`.  8- and 12-bit samples. */
   int dct_method;
 } mjh_params;
 

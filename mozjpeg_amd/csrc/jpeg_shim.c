@@ -622,7 +622,6 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
   if (cinfo->master->lossless) return "lossless mode";
   p->smoothing_factor = cinfo->smoothing_factor;   /* cjpeg -smooth N; ignored for raw data / coefficients like in the reference */
   if (cinfo->dct_method == JDCT_IFAST) {
-    if (cinfo->data_precision != 8) return "JDCT_IFAST with 12-bit samples";
     p->dct_method = 1;      /* jfdctfst.c: what TurboJPEG's legacy calls select below quality 96, `cjpeg -dct fast` */
   } else if (cinfo->dct_method != JDCT_ISLOW) return "dct_method JDCT_FLOAT (floating point: not a bit-exact path, SURVEY F5)";
   {

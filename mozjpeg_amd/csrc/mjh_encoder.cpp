@@ -552,7 +552,6 @@ static int check_supported(const mjh_params *p)
         return fail(MJH_EUNSUPPORTED, "no Huffman table in slot 2 / 3 (the Annex K tables exist for table numbers 0 and 1; others come through huff_tables_given; JERR_NO_HUFF_TABLE)");
   }
   if (p->dct_method != 0 && p->dct_method != 1) return fail(MJH_EUNSUPPORTED, "dct_method %d (0 = JDCT_ISLOW, 1 = JDCT_IFAST; the float DCT is outside the bit-exact path)", p->dct_method);
-  if (p->dct_method == 1 && p->data_precision == 12) return fail(MJH_EUNSUPPORTED, "JDCT_IFAST with 12-bit samples");
   if (p->trellis_stats_Ah < 0 || p->trellis_stats_Ah > 13 || p->trellis_stats_Al < 0 || p->trellis_stats_Al > 13) return fail(MJH_EINVAL, "trellis_stats_Ah / Al %d / %d", p->trellis_stats_Ah, p->trellis_stats_Al);
   return MJH_OK;
 }
@@ -1021,7 +1020,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
                                      21407, 29692, 27969, 25172, 21407, 16819, 11585, 5906, 19266, 26722, 25172, 22654, 19266, 15137, 10426, 5315,
                                      16384, 22725, 21407, 19266, 16384, 12873, 8867, 4520, 12873, 17855, 16819, 15137, 12873, 10114, 6967, 3552,
                                      8867, 12299, 11585, 10426, 8867, 6967, 4799, 2446, 4520, 6270, 5906, 5315, 4520, 3552, 2446, 1247 };
-        const int dc = p->dct_method == 1 ? (int)((((long)q * aan[kZZ[k]] + 1024L) >> 11) & 0xFFFF)
+        const int dc = p->dct_method == 1 ? (C.precision == 12 ? (int)(((long)q * aan[kZZ[k]] + 1024L) >> 11) : (int)((((long)q * aan[kZZ[k]] + 1024L) >> 11) & 0xFFFF))
                                           : C.precision == 12 ? 8 * q : (int)((8u * (unsigned)q) & 0xFFFFu);
         if (dc == 0)      // q = 8192, 16384, 24576: compute_reciprocal(0) divides by zero -- the reference dies
           for (int i = 0; i < C.ncomp; i++) if (p->quant_tbl_no[i] == t) e->fdct_div_zero = true;

@@ -611,7 +611,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
   }
   // IFAST with the trellis: the raw coefficients as the trellis reads them (natural order; the quantizer below keeps the scaled ones)
   int du[IFAST ? 64 : 1];
-  if (IFAST) aan_unscale_all(d, du);
+  if (IFAST && !W12) aan_unscale_all(d, du);      // (12-bit samples have no trellis: nothing reads the copy)
 
   float lambda_blk = 0.0f;
   if (!W12 && C.trellis) {
@@ -718,6 +718,13 @@ k_dct_quant_ifast(MjhConst C, const MjhQuant *__restrict__ Q, const uint8_t *__r
                   int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out, uint8_t *__restrict__ nq8_out)
 {
   dct_quant_body<uint8_t, false, false, true>(C, Q, planes, coef_uq, coef_q, lambda_out, nullptr, 0, make_int4(0, 0, 0, 0), nq8_out);
+}
+
+__global__ void __launch_bounds__(64)
+k_dct_quant_ifast12(MjhConst C, const MjhQuant *__restrict__ Q, const uint16_t *__restrict__ planes,
+                    int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q, float *__restrict__ lambda_out, uint8_t *__restrict__ nq8_out)
+{
+  dct_quant_body<uint16_t, false, false, true>(C, Q, planes, coef_uq, coef_q, lambda_out, nullptr, 0, make_int4(0, 0, 0, 0), nq8_out);
 }
 
 // =============================================================================================
@@ -3541,7 +3548,8 @@ void mjh_launch_dct(const MjhConst &C, const MjhQuant *Q, const void *planes, vo
   const int nb = (stat_tabs && C.precision != 12) ? DCTQ_NB : 1;      // (= the kernel's NB: the STATS instantiations)
   dim3 grid(((max_nblk(C) + 63) / 64 + nb - 1) / nb, C.ncomp, n);
   const int4 sl = stat_tabs ? make_int4(stat_slot[0], stat_slot[1], stat_slot[2], stat_slot[3]) : make_int4(0, 0, 0, 0);
-  if (ifast) hipLaunchKernelGGL(k_dct_quant_ifast, grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, nq8);   // (8-bit samples, no fused statistics: the caller's business)
+  if (ifast && C.precision == 12) hipLaunchKernelGGL(k_dct_quant_ifast12, grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, nq8);
+  else if (ifast) hipLaunchKernelGGL(k_dct_quant_ifast, grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, nq8);   // (no fused statistics: the caller's business)
   else if (C.precision == 12) hipLaunchKernelGGL((k_dct_quant<uint16_t, false>), grid, dim3(64), 0, s, C, Q, (const uint16_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else if (stat_tabs && fastdiv) hipLaunchKernelGGL((k_dct_quant<uint8_t, true, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);
   else if (stat_tabs) hipLaunchKernelGGL((k_dct_quant<uint8_t, true>), grid, dim3(64), 0, s, C, Q, (const uint8_t *)planes, (int16_t *)uq, (int16_t *)q, lambda, stat_tabs, spi, sl, nq8);

@@ -13,7 +13,7 @@
  * density.  Exactly these are mapped onto mjh_params; the output is the byte stream the reference TurboJPEG produces.
  * The LEGACY tjCompress2 selects the fast DCT (JDCT_IFAST, jfdctfst.c) unless quality >= 96 or TJFLAG_ACCURATEDCT is given
  * (processFlags turbojpeg.c:522-527), the 3.x API through TJPARAM_FASTDCT: mjh_params.dct_method, coded bit-exactly like the
- * accurate one.  Outside the GPU path (an ERROR, never a CPU fallback): CMYK / YCCK, lossless, the fast DCT on 12-bit samples.
+ * accurate one, 8- and 12-bit samples.  Outside the GPU path (an ERROR, never a CPU fallback): CMYK / YCCK, lossless.
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -264,7 +264,6 @@ static int build_params(tjs *t, const char *fn, int width, int height, int pixel
 {
   int subsamp = t->subsamp, gray_out, in_comps = 3;
   if (t->lossless) return fail(t, fn, "lossless mode is outside the GPU path (no CPU fallback)");
-  if (t->fast_dct && precision == 12) return fail(t, fn, "the fast DCT on 12-bit samples is outside the GPU path (no CPU fallback)");
   if (pixelFormat == TJPF_CMYK || t->colorspace == TJCS_CMYK || t->colorspace == TJCS_YCCK) return fail(t, fn, "CMYK / YCCK are outside the GPU path (no CPU fallback)");
   if (pixelFormat == TJPF_GRAY) in_comps = 1;
   gray_out = t->colorspace == TJCS_GRAY || (t->colorspace < 0 && subsamp == TJSAMP_GRAY) || in_comps == 1;

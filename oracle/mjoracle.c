@@ -600,6 +600,8 @@ static const short kAanScales[64] = {
   8867, 12299, 11585, 10426, 8867, 6967, 4799, 2446, 4520, 6270, 5906, 5315, 4520, 3552, 2446, 1247 };
 /* the divisor of natural-order position i: quantval * aanscale * 8 / 2^14, rounded (:327-335), as compute_reciprocal's UINT16 argument */
 int mjo_ifast_divisor(int quantval, int i) { return (int)((((long)quantval * kAanScales[i] + 1024L) >> 11) & 0xFFFF); }
+/* 12-bit samples: the same product kept as a DCTELEM (an int), divided by directly (jcdctmgr.c:337-341, quantize :655-684) */
+static int ifast_divisor12(int quantval, int i) { return (int)(((long)quantval * kAanScales[i] + 1024L) >> 11); }
 
 /* ------------------------------------------------------------------------------------------
  * a4,a7,a8  convsamp jcdctmgr.c:576, quantize :611 (the reciprocal form there is, for d = 8*q,
@@ -653,7 +655,7 @@ static void forward16(const mjo_params *p, uint16_t *const planes[MJO_MAX_COMPS]
            * wraps -- q = 8450 (quality 1) divides by 67600 mod 65536 = 2064; the 12-bit build keeps the value (:284).  (A wrapped
            * divisor of 0 makes the reference divide by zero: mjo_encode refuses such tables.)  The reciprocal form equals this
            * rounding division for every divisor 8 .. 65528 and |x| <= 32767 (checked exhaustively). */
-          int d = p->dct_method == 1 ? mjo_ifast_divisor(qt[i], i) : P == 12 ? 8 * qt[i] : (int)((8u * (unsigned)qt[i]) & 0xFFFFu), x = ws[i], v;
+          int d = p->dct_method == 1 ? (P == 12 ? ifast_divisor12(qt[i], i) : mjo_ifast_divisor(qt[i], i)) : P == 12 ? 8 * qt[i] : (int)((8u * (unsigned)qt[i]) & 0xFFFFu), x = ws[i], v;
           uq[i] = (int16_t)x;   /* (12-bit: may wrap; only the 8-bit trellis reads it) */
           if (p->dct_method == 1) {   /* what the trellis gets to see: the AA&N factors taken out again, forward_DCT jcdctmgr.c:745-750 (C division: towards zero) */
             const int sc = kAanScales[i];

@@ -77,7 +77,7 @@ typedef struct {
   int ycc_input;                  /* in_color_space = JCS_YCbCr with jpeg_color_space = JCS_YCbCr: the three input samples are Y, Cb, Cr already
                                    * (jinit_color_converter jccolor.c:687-692 -> null_convert :479); everything else is an ordinary YCbCr file */
   int dct_method;                 /* cinfo->dct_method: 0 JDCT_ISLOW, 1 JDCT_IFAST (cjpeg -dct fast; jfdctfst.c, divisors jcdctmgr.c:291-345,
-                                   * the trellis' copy of the raw coefficients rescaled :731-750); 8-bit samples */
+                                   * the trellis' copy of the raw coefficients rescaled :731-750) */
 } mjo_params;
 /* jpeg_set_colorspace(cinfo, JCS_RGB) (jcparam.c:611-619): three 1x1 components 'R' 'G' 'B', tables 0, no JFIF marker */
 void mjo_set_rgb_output(mjo_params *p);

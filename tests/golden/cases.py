@@ -240,6 +240,10 @@ CASES12 = [
     # 12-bit samples through the arithmetic coder (magnitude categories up to 15 bits)
     ("p12_arith_base_q90_444", dict(precision=12, arithmetic=True, baseline=True, notrellis=True, quality=90, sample=(1, 1)), True),
     ("p12_arith_progressive", dict(precision=12, arithmetic=True, notrellis=True), True),
+    # JDCT_IFAST on 12-bit samples (jfdctfst.c; the divisors stay full-width DCTELEMs, jcdctmgr.c:337-341)
+    ("p12_ifast_revert", dict(precision=12, revert=True, dct="fast"), True),
+    ("p12_ifast_base_q90_444", dict(precision=12, baseline=True, notrellis=True, quality=90, sample=(1, 1), dct="fast"), True),
+    ("p12_ifast_fastcrush_q1", dict(precision=12, notrellis=True, fastcrush=True, quality=1, dct="fast"), True),
 ]
 
 # constants the REFERENCE itself pins for this path (CMakeLists.txt:1347-1420), cjpeg -revert ... testorig.ppm

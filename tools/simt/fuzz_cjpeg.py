@@ -316,7 +316,7 @@ def main():
                 continue
             if not transcode:
                 # (a generator of its own for the DCT method: the cases of older seeds keep their other switches)
-                dct = "fast" if (not twelve and np.random.default_rng(seed * 7919 + i).random() < 0.25) else "int"
+                dct = "fast" if np.random.default_rng(seed * 7919 + i).random() < 0.25 else "int"
                 def cmd_of(out, a=a, src=src, dct=dct):
                     return [CJPEG, "-dct", dct] + a + ["-outfile", out, src]
                 what = " ".join((["-dct", "fast"] if dct == "fast" else []) + a)
