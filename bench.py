@@ -179,6 +179,8 @@ def other_config_line(M, torch, key, device, budget_s, t_end):
         be = verify_frames(frames, jp, w, h, kw, nver)
         be["repeats_identical_to_first_copy"] = all(jp[i] == jp[i % distinct] for i in range(len(jp)))
         be["ok"] = bool(be["ok"] and be["repeats_identical_to_first_copy"])
+        # the dominant interval ONE BATCH AT A TIME (its kernels alone on the chip: what the roofline fraction is about) ...
+        enc.set_inflight(1)
         enc.set_profiling(1)
         enc.encode_tensor(d, stream="own"); enc.sync()          # creates the events
         enc.set_profiling(1)
@@ -186,6 +188,17 @@ def other_config_line(M, torch, key, device, budget_s, t_end):
         kt = {k: v for k, v in dict(enc.kernel_times()).items() if "side stream" not in k and not k.startswith("join(")}
         focus = max(kt, key=kt.get) if kt else None
         enc.set_profiling(2, focus=focus)
+        for _ in range(6):
+            enc.encode_tensor(d, stream="own")
+        enc.sync()
+        dom = dict(enc.kernel_times())
+        dom_ms = dom.get(focus) if focus else None
+        enc.set_profiling(0)
+        # ... and the throughput as the library runs consecutive device-resident batches: two in flight (mjh_set_inflight)
+        enc.set_inflight(2)
+        for _ in range(2):
+            enc.encode_tensor(d, stream="own")
+        enc.sync()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         steps = 0
@@ -196,8 +209,6 @@ def other_config_line(M, torch, key, device, budget_s, t_end):
             steps += 1
         enc.sync()
         dt = (time.perf_counter() - t0) / steps
-        dom = dict(enc.kernel_times())
-        dom_ms = dom.get(focus) if focus else None
         algo = float(batch.nbytes) + float(sum(len(j) for j in jp))
         out = {"workload": cfg["name"], "frames_per_step": int(len(batch)) * calls_per_step, "steps": steps, "ms_per_step": round(dt * 1e3, 3),
                "value": round(float(w) * h * len(batch) * calls_per_step / dt / 1e6, 1), "unit": "Mpixels/s", "bit_exact": be}
@@ -205,7 +216,8 @@ def other_config_line(M, torch, key, device, budget_s, t_end):
             out["encode_calls_per_step"] = calls_per_step
         if dom_ms:
             out["roofline"] = {"kernel": focus, "kernel_ms": round(dom_ms, 4), "achieved": round(algo / (dom_ms * 1e-3) / 1e9, 1),
-                               "unit": "GB/s", "frac": round(algo / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                               "unit": "GB/s", "frac": round(algo / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                               "kernel_ms_is": "the interval with one batch at a time on the chip (mjh_set_inflight 1); `value` is with two batches in flight"}
         return out
     finally:
         enc.close()
@@ -475,7 +487,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of host CPU work for the cpu_baseline leg")
     ap.add_argument("--no-host-leg", action="store_true")
-    ap.add_argument("--no-inflight-leg", action="store_true", help="skip the three-batches-in-flight measurement (extra information)")
+    ap.add_argument("--no-inflight-leg", action="store_true", help="(kept for the scripts of earlier rounds: the extra legs it switched off are gone or folded into the line)")
     ap.add_argument("--host-seconds", type=float, default=3.0)
     ap.add_argument("--host-batch", type=int, default=16)
     ap.add_argument("--verify", default="all", help="frames per batch to compare with the reference: all | N")
@@ -626,49 +638,29 @@ def main():
     dom_times = dict(enc.kernel_times())          # average ms per encode call over the timed region
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
 
-    # Untimed extra pass with every kernel bracketed (level 1) for the per-kernel breakdown
+    # Untimed extra pass with every kernel bracketed (level 1) for the per-kernel breakdown, one batch at a time (with two in
+    # flight an interval between two events on one stream also holds the other batch's kernels)
+    enc.set_inflight(1)
     enc.set_profiling(1)
     for _ in range(min(args.steps, 5)):
         step()
     ktimes = dict(enc.kernel_times())
+    # ... and the reference figures of the same steps one batch at a time (never `value`)
+    enc.set_profiling(2, focus=focus)
+    ksteps = max(3, min(args.steps, 40))
+    barrier()
+    t0s = time.perf_counter()
+    for _ in range(ksteps):
+        step()
+    barrier()
+    serial_ms = (time.perf_counter() - t0s) / ksteps * 1e3
+    serial_dom = dict(enc.kernel_times())
     enc.set_profiling(0)
+    enc.set_inflight(2)
 
-    # Extra information, never `value`: the same steps with three batches in flight (three encoders, each on its own
-    # streams, taken round-robin), which is how a service keeps the device busy across the tails and the differently
-    # bound kernels of consecutive batches.  The contract line above stays the one-batch-at-a-time figure, so that the
-    # dominant kernel's event-timed duration is not inflated by concurrent launches.
+    # (Rounds 2-5 measured here what three encoders taken round-robin gain over one: since round 6 the encoder itself keeps two
+    # batches in flight -- mjh_set_inflight -- and `value` is that; the one-batch-at-a-time figures are in `one_batch_at_a_time`.)
     pipelined = None
-    if not args.no_inflight_leg and world == 1:
-        extra = []
-        try:
-            extra = [M.Encoder(params, max_batch=B, device=local_rank) for _ in range(2)]
-            ring = [enc] + extra
-            same = True
-            for e2 in extra:
-                e2.encode_tensor(d_frames[0:calls[0][1]], stream="own")
-                e2.sync()
-                same = same and e2.get_jpeg(0) == jpegs[0]
-            ksteps = max(3, min(args.steps, 60))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            k = 0
-            for _ in range(ksteps):
-                for s0, cnt in calls:
-                    ring[k % 3].encode_tensor(d_frames[s0:s0 + cnt], stream="own")
-                    k += 1
-            for e2 in ring:
-                e2.sync()
-            dt = (time.perf_counter() - t0) / ksteps
-            pipelined = {"encoders_in_flight": 3, "steps": ksteps, "ms_per_step": round(dt * 1e3, 3),
-                         "value": round(float(w) * h * nframes / dt / 1e6, 2), "unit": "Mpixels/s",
-                         "files_identical_to_the_single_encoder_run": bool(same)}
-        except Exception as exc:   # extra information only: the contract line must still come out
-            pipelined = {"error": str(exc)}
-        for e2 in extra:
-            try:
-                e2.close()
-            except Exception:
-                pass
     enc.close()
     del d_frames
 
@@ -743,6 +735,7 @@ def main():
                        "distinct_frames": int(nframes // repeats),
                        "value_definition": "device-resident (this line's `value`); SURVEY 8d / BASELINE.md section 3 define the metric from pinned host "
                                            "pixels to JPEG bytes in host memory: that number is `value_host_inclusive`",
+                       "batches_in_flight": 2,
                        "input": "resident in HBM", "output": "complete JPEG files in HBM",
                        "parallelism": "images sharded, 1 process per GPU, no collective"},
             "bit_exact": bitexact,
@@ -761,6 +754,10 @@ def main():
                          "kernel_ms_per_call(untimed pass, every kernel bracketed)":
                              {k: round(v, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1])}},
         }
+        out["one_batch_at_a_time"] = {"ms_per_step": round(serial_ms, 3), "steps": ksteps, "kernel": dom,
+                                      "kernel_ms": round(serial_dom.get(dom, 0.0), 4),
+                                      "frac": round(algo_bytes / (serial_dom[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if serial_dom.get(dom) else None,
+                                      "what": "the same steps with mjh_set_inflight(1): every kernel alone on the chip (rounds 1-5 measured this way)"}
         issue = dominant_issue(args.config, dom, per_call, dom_ms)
         if issue is not None:
             out["roofline"]["valu_issue"] = issue      # (the interval is VALU-issue bound, not HBM bound: this is the ceiling it is near)

@@ -225,6 +225,14 @@ const char *mjh_pool_last_error(const mjh_pool *pool);
  * mjh_encoder_sync() or any later synchronising call. */
 int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t row_pitch, size_t image_stride,
                       int n, void *stream);
+/* Batches in flight on the encoder's own stream (stream == NULL above): 2 (the default; MJH_INFLIGHT in the environment) -- consecutive
+ * mjh_encode_device calls alternate between two complete sets of working buffers and streams inside the encoder, so that the
+ * latency- and memory-bound kernels of one batch (colour conversion, final statistics, bit lengths, prefix sums, byte stuffing) run
+ * next to the other batch's, while the VALU-bound ones (AC trellis, FDCT, bit writer) keep the chip to themselves; the results of
+ * call k stay valid until call k + 2, and every accessor (mjh_get_jpeg, mjh_get_output_device, taps, ...) refers to the most recent
+ * call.  1 -- one batch at a time on one buffer set (half the device memory).  A caller's stream, debug taps and the memory checker
+ * always run one batch at a time.  The files are the same either way. */
+int mjh_set_inflight(mjh_encoder *e, int batches);
 /* Same with host pixels -- the whole-image form of jpeg_write_scanlines (jcapistd.c:90) + jpeg_finish_compress
  * (jcapimin.c:176) for a batch.  ASYNCHRONOUS and double-buffered: the call queues the host->device copy, the kernel
  * schedule and the hand-over of the finished files to pinned host memory, and returns; the copy of batch k+1 overlaps

@@ -90,6 +90,7 @@ def lib():
         L.mjh_encode_coefficients_device.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
         L.mjh_encode_coefficients_host.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int]
         L.mjh_encoder_sync.argtypes = [C.c_void_p]
+        L.mjh_set_inflight.argtypes = [C.c_void_p, C.c_int]
         L.mjh_encoder_params.argtypes = [C.c_void_p]
         L.mjh_encoder_params.restype = C.POINTER(Params)
         L.mjh_pool_create.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
@@ -402,6 +403,10 @@ class Encoder:
         _chk(lib().mjh_encode_coefficients_device(self._h, (C.c_void_p * 4)(*pad([t.data_ptr() for t in coefs], None)),
                                                   (C.c_size_t * 4)(*pad([t.shape[2] for t in coefs], 0)),
                                                   (C.c_size_t * 4)(*pad([t.stride(0) * 2 for t in coefs], 0)), n, stream))
+
+    def set_inflight(self, batches):
+        """device-resident batches in flight inside the encoder: 2 (default) or 1 (mjh_set_inflight)"""
+        _chk(lib().mjh_set_inflight(self._h, batches))
 
     def sync(self):
         _chk(lib().mjh_encoder_sync(self._h))

@@ -18,6 +18,7 @@
 #include <string>
 #include <thread>
 #include <memory>
+#include <chrono>
 #include <vector>
 
 #include "../../include/mozjpeg_hip.h"
@@ -370,6 +371,19 @@ struct mjh_encoder {
   bool sizes_valid = false;
   bool coef_input = false;         // last batch came in through mjh_encode_coefficients_*: d_meta[].bad_coef is meaningful
   hipStream_t last_stream = nullptr;   // the stream the last batch was queued on (mjh_encoder_sync waits for it)
+  // Two batches in flight (mjh_encode_device on the encoder's own stream): consecutive calls alternate between this encoder's
+  // buffers and streams and those of a TWIN (a second set, made at the first such call), so that the latency-bound tail of
+  // batch k (final statistics, bit lengths, prefix sums, bit writing, stuffing) and the front end of batch k+1 (colour, FDCT)
+  // share the chip, while the VALU-bound AC trellis of either batch has it for itself (events below).
+  mjh_params p_created;               // the parameters the caller passed to mjh_encoder_create (p is what the encoder made of them)
+  mjh_encoder *twin = nullptr;        // primary only
+  mjh_encoder *owner = nullptr;       // twin only
+  mjh_encoder *last = nullptr;        // primary only: who ran the most recent batch (nullptr = this encoder)
+  int inflight = 2, inflight_mode = 1;   // MJH_INFLIGHT (1 = one batch at a time), MJH_INFLIGHT_MODE (0 = no ordering between the two, 1 = the AC trellis alone)
+  unsigned dev_calls = 0;
+  bool high_priority_streams = false; // twin: its streams come from the high-priority queue pool, never the primary's hardware queues
+  hipEvent_t ev_done = nullptr, ev_tier1 = nullptr;   // end of this encoder's last pipeline / of its tile-sorted AC trellis kernel
+  bool ev_done_set = false, ev_tier1_set = false;
   hipEvent_t ev_null_in = nullptr;
   // arithmetic coding (mjh_arith.hip): the scans to code (the script, or one synthetic whole-block scan for a sequential file),
   // phase lists in d_lists (pl_phase[].scan_off / nscan), the rate table of quantize_trellis_arith
@@ -772,7 +786,9 @@ static void fill_std_table(MjhHuffTable *T, const uint8_t *bits, const uint8_t *
 static void free_all(mjh_encoder *e)
 {
   if (!e) return;
+  if (e->twin) { mjh_encoder *t = e->twin; e->twin = nullptr; free_all(t); }
   (void)hipSetDevice(e->device);
+  for (hipEvent_t ev : { e->ev_done, e->ev_tier1 }) if (ev) (void)hipEventDestroy(ev);
   if (e->ev_null_in) (void)hipEventDestroy(e->ev_null_in);
   void *ptrs[] = { e->d_pixb[0], e->d_pixb[1], e->d_plin, e->d_cfin, e->d_prog_mpos, e->d_prog_ffsums, e->d_prog_chunks, e->pe.len16, e->pe.run16, e->pe.tail16, e->pe.be16, e->pe.off32, e->pe.sums, e->pe.totals, e->pe.T32, e->pe.tsums, e->pe.ttotals, e->pe.ne_bits, e->pe.ne2_bits, e->pe.e_bits, e->pe.info, e->pe.chist, e->pe.rmask, e->d_planes, e->d_uq, e->d_q, e->d_q0, e->d_quant, e->d_quant_init, e->d_tabs, e->d_tabs_init, e->d_lambda, e->d_back, e->d_eob_cost, e->d_eob_has, e->d_qsums, e->d_nzmask, e->d_nq8, e->d_dense, e->d_worklist, e->d_worklist2, e->d_prog_scans, e->d_prog_ctl, e->d_lists, e->d_pool, e->d_outpool, e->d_frame_hdr, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos,
                    e->d_len16, e->d_off32, e->d_sums, e->d_totals, e->d_ffsums, e->d_fftotals, e->d_stream, e->d_out, e->d_sizes,
@@ -832,6 +848,27 @@ static MjhConst scan_view(const MjhConst &C, const mjh_params &p, const int *com
   return V;
 }
 
+// Do two streams run concurrently?  The HIP runtime deals streams over a few hardware queues (4 per priority level unless
+// GPU_MAX_HW_QUEUES says otherwise), round-robin; two streams on one queue are served in turn, whatever the kernels.  A busy wave on
+// each (150 us) takes 150 us when they overlap and 300 when they share a queue.  -1: could not tell (HIP error).
+static int mjh_streams_overlap(hipStream_t a, hipStream_t b)
+{
+  if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
+  int votes = 0;
+  for (int rep = 0; rep < 3; rep++) {
+    const auto t0 = std::chrono::steady_clock::now();
+    mjh_launch_spin(15000ull, a);
+    mjh_launch_spin(15000ull, b);
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    votes += us < 240.0;
+  }
+  return votes >= 2;
+}
+
+static thread_local bool g_create_twin = false;
+static thread_local hipStream_t g_twin_avoid[2] = { nullptr, nullptr };   // make_twin: the primary's main and side stream     // mjh_encoder_create is making the second buffer set of an encoder (make_twin)
+
 extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device, mjh_encoder **out)
 {
   if (!p || !out || max_batch < 1) return fail(MJH_EINVAL, "bad arguments");
@@ -882,6 +919,8 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   if (device < 0 || device >= ndev) return fail(MJH_EINVAL, "device %d out of range (%d devices)", device, ndev);
   mjh_encoder *e = new mjh_encoder();
   e->p = *p;
+  e->p_created = *p;
+  e->high_priority_streams = g_create_twin;
   if (p->num_components == 1 && (p->h_samp_factor[0] != 1 || p->v_samp_factor[0] != 1)) {   // (check_supported: only the SOF byte differs)
     e->sof_hv0 = (p->h_samp_factor[0] << 4) + p->v_samp_factor[0];
     e->dc_chain_v = p->v_samp_factor[0];
@@ -899,7 +938,33 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   e->nbands = p->trellis_quant && p->use_scans_in_trellis ? 2 : 1;          // jcmaster.c:451-460
   e->freq_split = p->trellis_freq_split > 0 ? p->trellis_freq_split : 8;   // jcparam.c:512
   HIPCHK_E(hipSetDevice(device));
-  HIPCHK_E(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  if (e->high_priority_streams) {
+    // The twin's main and side stream must not share a hardware queue with the primary's, or the two batches take turns instead of
+    // overlapping.  Streams of the same priority (another priority level has queues of its own, but its kernels are then dispatched
+    // first and the sharing turns into alternation: measured, 4.68 against 4.43 ms) are made until two are found that overlap with
+    // both of the primary's and with each other; the others are destroyed again.
+    std::vector<hipStream_t> made;
+    for (int tries = 0; tries < 12 && !e->side_stream; tries++) {
+      hipStream_t c = nullptr;
+      HIPCHK_E(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+      made.push_back(c);
+      bool free_queue = true;
+      for (hipStream_t other : { g_twin_avoid[0], g_twin_avoid[1], e->stream })
+        if (other && mjh_streams_overlap(c, other) == 0) { free_queue = false; break; }
+      if (!free_queue) continue;
+      if (!e->stream) e->stream = c; else e->side_stream = c;
+    }
+    for (hipStream_t c : made) if (c != e->stream && c != e->side_stream) (void)hipStreamDestroy(c);
+    if (!e->stream) HIPCHK_E(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));           // (fewer queues than streams: share)
+    if (!e->side_stream) HIPCHK_E(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+  } else {
+    HIPCHK_E(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIPCHK_E(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));     // (right behind the main stream: adjacent creations never share a hardware queue)
+  }
+  HIPCHK_E(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+  HIPCHK_E(hipEventCreateWithFlags(&e->ev_tier1, hipEventDisableTiming));
+  if (const char *v = getenv("MJH_INFLIGHT")) { e->inflight = atoi(v); if (e->inflight < 1 || e->inflight > 2) e->inflight = 2; }
+  if (const char *v = getenv("MJH_INFLIGHT_MODE")) { e->inflight_mode = atoi(v); if (e->inflight_mode < 0 || e->inflight_mode > 2) e->inflight_mode = 1; }
   {
     // (copy and hand-over streams at the greatest priority, i.e. in a hardware-queue pool of their own, were measured in round 3
     // with 16 libjpeg client threads: no gain with the coalescing shim, a loss without it -- default priority)
@@ -907,7 +972,6 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     HIPCHK_E(hipStreamCreateWithPriority(&e->copy_stream, hipStreamNonBlocking, e->copy_prio));
   }
   HIPCHK_E(hipEventCreateWithFlags(&e->copy_done, hipEventDisableTiming));
-  HIPCHK_E(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
   HIPCHK_E(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   HIPCHK_E(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
   HIPCHK_E(hipEventCreate(&e->ev_side0));
@@ -1450,6 +1514,15 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   e->res_buf = -1;
   e->coef_input = coef_src != nullptr;
   e->last_stream = s;
+  if (!e->owner) e->last = nullptr;      // (mjh_encode_device names the twin afterwards when it ran the batch)
+  // two batches in flight: the other buffer set's AC trellis kernel has the chip for itself -- nothing of this batch starts before it has ended
+  mjh_encoder *const peer = e->owner ? e->owner : e->twin;
+  const int if_mode = peer ? (e->owner ? e->owner : e)->inflight_mode : 0;      // 1: nothing next to the other set's AC trellis; 2: only the memory- / latency-bound kernels
+  const bool ordered = if_mode >= 1;
+  if (if_mode == 1 && peer->ev_tier1_set) HIPCHK(hipStreamWaitEvent(s, peer->ev_tier1, 0));
+  e->ev_tier1_set = false;
+  const bool peer_done_set = peer && peer->ev_done_set;
+  if (if_mode == 2) e->ev_done_set = false;
   Prof pr{ e, s };
   if (e->profiling && e->prof_calls < 256) {
     pr.enabled = true;
@@ -1528,6 +1601,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     HIPCHK(hipMemsetAsync(e->d_qsums, 0, (size_t)n * 4 * 64 * 2 * sizeof(long long), s));
   }
   if (!coef_src) {
+    if (if_mode == 2 && peer->ev_tier1_set) HIPCHK(hipStreamWaitEvent(s, peer->ev_tier1, 0));     // (the colour kernel is bound by HBM: it may run next to the trellis)
     pr.mark("dct_quant");
     mjh_launch_dct(C, e->d_quant, e->d_planes, e->d_uq, e->d_q, e->d_lambda, fuse_pre ? e->d_tabs : nullptr, spi, tr_ac, e->d_nq8, n, s, e->fastdiv_all, p.dct_method == 1);
   }
@@ -1691,13 +1765,17 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     }
     const bool extended = nbands > 1 || ext_eob || qstride != 0;
     if (!extended) { const int rc = adapt_first_tier(); if (rc != MJH_OK) return rc; }
-    pr.mark("trellis_ac");
     const bool v3 = nzm && e->d_nq8 && e->trellis_v3 > 0 && e->trellis_variant <= 4 && !extended;     // the tile-sorted first tier (plain compact pass)
+    // ... and this batch's AC trellis waits for the tail of the other set's batch (queued before this call)
+    const bool excl = ordered && v3 && !e->progressive;
+    if (excl && peer_done_set) HIPCHK(hipStreamWaitEvent(s, peer->ev_done, 0));
+    pr.mark("trellis_ac");
     mjh_launch_trellis_ac(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap,
                           e->trellis_variant,
                           Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, nzm, qstride, n, s,
                           e->d_nq8, v3 ? ((size_t)n * C.total_real_blocks < e->small_batch ? 1 : e->trellis_v3) : 0,   // (a small batch: one pass per tile -- four times the workgroups, a quarter of their length: latency matters more than the sorting)
-                          e->fastdiv_all, dc_late ? e->ev_side0 : nullptr);
+                          e->fastdiv_all, dc_late ? e->ev_side0 : nullptr, excl ? e->ev_tier1 : nullptr);
+    if (excl) e->ev_tier1_set = true;
     if (dc_late) {
       if (!v3) return fail(MJH_EINVAL, "internal: the late DC chains need the tile-sorted trellis' event");
       HIPCHK(hipStreamWaitEvent(e->side_stream, e->ev_side0, 0));
@@ -1874,6 +1952,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     pr.mark("huff_encode");
     mjh_launch_encode(C, e->d_q, nzm, e->d_tabs, spi, fin_dc, fin_ac, e->d_len16, e->d_off32, e->d_sums, e->chunks, e->d_totals,
                       e->d_stream, e->stream_words, e->d_meta, e->d_seg_x, e->d_seg_E, e->d_seg_sums, e->d_seg_totals, e->d_mpos, e->nseg, n, s);
+    if (if_mode == 2) { HIPCHK(hipEventRecord(e->ev_done, s)); e->ev_done_set = true; }      // (the bit writer is the tail's last VALU-bound kernel)
     pr.mark("byte_stuff");
     mjh_launch_stuff(e->d_stream, e->stream_words, e->d_totals, e->d_ffsums, e->ff_chunks, e->d_fftotals, e->d_out, e->out_stride,
                      e->d_meta, e->d_sizes, e->d_mpos, e->nseg, n, s);
@@ -1885,11 +1964,39 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
   }
   pr.mark(nullptr);
   pr.finish();
+  if (peer && !(if_mode == 2 && e->ev_done_set)) { HIPCHK(hipEventRecord(e->ev_done, s)); e->ev_done_set = true; }
   HIPCHK(hipGetLastError());
   return MJH_OK;
 }
 
 extern "C" const mjh_params *mjh_encoder_params(const mjh_encoder *e) { return e ? &e->p : nullptr; }
+
+// the encoder whose buffers hold the most recent batch: the twin, when it ran the last device-resident call
+static mjh_encoder *cur(mjh_encoder *e) { return e && e->last ? e->last : e; }
+
+// 1: every device-resident batch runs on the encoder's own buffer set, one after the other; 2 (the default, MJH_INFLIGHT): two sets take turns
+extern "C" int mjh_set_inflight(mjh_encoder *e, int batches)
+{
+  if (!e || batches < 1 || batches > 2) return fail(MJH_EINVAL, "batches in flight: 1 or 2");
+  e->inflight = batches;
+  return MJH_OK;
+}
+
+// the second buffer set of an encoder with two batches in flight: a complete encoder of its own on streams of the other queue pool
+static int make_twin(mjh_encoder *e)
+{
+  mjh_encoder *t = nullptr;
+  g_create_twin = true;
+  g_twin_avoid[0] = e->stream; g_twin_avoid[1] = e->side_stream;
+  const int rc = mjh_encoder_create(&e->p_created, e->max_batch, e->device, &t);
+  g_create_twin = false;
+  if (rc) return rc;
+  t->owner = e;
+  t->inflight = 1;
+  t->profiling = e->profiling; t->prof_focus_name = e->prof_focus_name; t->prof_focus = e->prof_focus;
+  e->twin = t;
+  return MJH_OK;
+}
 
 // An entry other than mjh_encode_host behind a mjh_encode_host call: that batch's files may still be on their way out of
 // the (single) output buffers on the D2H stream -- nothing of the new batch may run before they have left
@@ -1951,7 +2058,17 @@ extern "C" int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t ro
     HIPCHK(hipStreamWaitEvent(s, e->ev_null_in, 0));
   }
   { const int rcw = wait_pending_pack(e, s); if (rcw) return rcw; }
-  return run_pipeline(e, d_pixels, row_pitch, image_stride, n, s);
+  // Two batches in flight: on the encoder's own stream consecutive calls alternate between the two buffer sets (the results of
+  // call k stay where they are until call k + 2).  Debug taps, the memory checker and a caller's stream keep to one set.
+  mjh_encoder *t = e;
+  if (e->inflight > 1 && !stream && !e->debug_taps && mjh_guard_mode() == 0 && !e->owner) {
+    if (!e->twin) { const int rt = make_twin(e); if (rt) return rt; }
+    if (e->dev_calls++ & 1u) t = e->twin;
+    if (t != e) s = t->stream;
+  }
+  const int rc = run_pipeline(t, d_pixels, row_pitch, image_stride, n, s);
+  e->last = t == e ? nullptr : t;
+  return rc;
 }
 
 // ---- host entry: pixels in host memory -> JPEG files in host memory ----------------------------------
@@ -2437,6 +2554,7 @@ extern "C" int mjh_encoder_sync(mjh_encoder *e)
   if (!e) return fail(MJH_EINVAL, "null encoder");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->last_stream ? e->last_stream : e->stream));
+  if (e->twin) HIPCHK(hipStreamSynchronize(e->twin->last_stream ? e->twin->last_stream : e->twin->stream));
   return guard_verify();
 }
 
@@ -2480,6 +2598,7 @@ static int fetch_sizes(mjh_encoder *e)
 
 extern "C" int mjh_get_jpeg_size(mjh_encoder *e, int i, size_t *size)
 {
+  e = cur(e);
   if (!e || !size || i < 0 || i >= e->last_n) return fail(MJH_EINVAL, "bad image index");
   int rc = fetch_sizes(e);
   if (rc) return rc;
@@ -2489,6 +2608,7 @@ extern "C" int mjh_get_jpeg_size(mjh_encoder *e, int i, size_t *size)
 
 extern "C" int mjh_get_jpeg(mjh_encoder *e, int i, void *dst, size_t cap, size_t *size)
 {
+  e = cur(e);
   if (!e || !dst || i < 0 || i >= e->last_n) return fail(MJH_EINVAL, "bad image index");
   int rc = fetch_sizes(e);
   if (rc) return rc;
@@ -2506,6 +2626,7 @@ extern "C" int mjh_get_jpeg(mjh_encoder *e, int i, void *dst, size_t cap, size_t
 
 extern "C" int mjh_get_output_device(mjh_encoder *e, void **d_base, size_t *stride, void **d_sizes)
 {
+  e = cur(e);
   if (!e) return fail(MJH_EINVAL, "null encoder");
   if (d_base) *d_base = e->d_out;
   if (stride) *stride = e->out_stride;
@@ -2518,6 +2639,7 @@ extern "C" int mjh_set_profiling(mjh_encoder *e, int on)
 {
   if (!e) return fail(MJH_EINVAL, "null encoder");
   if (on < 0 || on > 2) return fail(MJH_EINVAL, "profiling level must be 0, 1 or 2");
+  if (e->twin) { e->twin->prof_focus_name = e->prof_focus_name; (void)mjh_set_profiling(e->twin, on); }
   e->profiling = on;
   e->prof_calls = 0;
   if (e->prof_focus_name.empty()) e->prof_focus = e->p.trellis_quant && !e->progressive ? "trellis_ac" : "dct_quant";
@@ -2541,8 +2663,20 @@ extern "C" int mjh_get_kernel_times(mjh_encoder *e, const char *const **names, c
   if (!e || !count) return fail(MJH_EINVAL, "bad arguments");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipDeviceSynchronize());
+  const int calls_e = e->prof_calls;
   const int rc = kernel_times_one(e);
   if (rc) return rc;
+  if (e->twin && e->twin->prof_calls > 0) {     // two buffer sets took turns: the averages of both, weighted by their calls
+    const int calls_t = e->twin->prof_calls;
+    const int rt = kernel_times_one(e->twin);
+    if (rt) return rt;
+    if (calls_e == 0) { e->prof_cnames = e->twin->prof_cnames; e->prof_ms = e->twin->prof_ms; }
+    else
+      for (size_t i = 0; i < e->prof_cnames.size(); i++)
+        for (size_t j = 0; j < e->twin->prof_cnames.size(); j++)
+          if (!strcmp(e->prof_cnames[i], e->twin->prof_cnames[j]))
+            e->prof_ms[i] = (e->prof_ms[i] * (float)calls_e + e->twin->prof_ms[j] * (float)calls_t) / (float)(calls_e + calls_t);
+  }
   if (names) *names = e->prof_cnames.data();
   if (ms) *ms = e->prof_ms.data();
   *count = (int)e->prof_cnames.size();
@@ -2594,6 +2728,7 @@ extern "C" int mjh_component_geometry(const mjh_encoder *e, int c, int *wib, int
 // table slots what the LAST CODED scan put there (jpeg_gen_optimal_table writes into cinfo->dc / ac_huff_tbl_ptrs, jchuff.c:1092-1105).
 extern "C" int mjh_get_scan_table(mjh_encoder *e, int image, int scan, int tblno, uint8_t bits[17], uint8_t vals[256])
 {
+  e = cur(e);
   if (!e || !bits || !vals || image < 0 || image >= e->last_n) return fail(MJH_EINVAL, "bad arguments");
   if (!e->progressive || e->arith || scan < 0 || scan >= e->nscans || tblno < 0 || tblno > 1) return fail(MJH_EINVAL, "no such scan table");
   const mjh_scan &sc = e->p.scan_info[scan];
@@ -2609,6 +2744,7 @@ extern "C" int mjh_get_scan_table(mjh_encoder *e, int image, int scan, int tblno
 
 extern "C" int mjh_read_tap(mjh_encoder *e, int what, int image, int comp, void *dst, size_t cap, size_t *size)
 {
+  e = cur(e);
   if (!e || !dst || image < 0 || image >= e->last_n) return fail(MJH_EINVAL, "bad arguments");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipDeviceSynchronize());

@@ -3594,7 +3594,7 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
-                           uint8_t *nq8, int v3_passes, int fastdiv, hipEvent_t after_first_tier)
+                           uint8_t *nq8, int v3_passes, int fastdiv, hipEvent_t after_first_tier, hipEvent_t after_first_tier2)
 {
   // band-limited pass (use_scans_in_trellis), the per-block outputs of trellis_eob_opt, per-image tables (trellis_q_opt):
   // the EXT instantiations
@@ -3638,6 +3638,7 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     else switch (np) { case 8: LV3(16, 8, true); break; case 4: LV3(16, 4, true); break; case 2: LV3(16, 2, true); break; default: LV3(16, 1, true); break; }
 #undef LV3
     if (after_first_tier) (void)hipEventRecord(after_first_tier, s);      // (what only waits for the big kernel starts here, next to the general tiers)
+    if (after_first_tier2) (void)hipEventRecord(after_first_tier2, s);    // (the other buffer set of an encoder with two batches in flight)
     const int qd_grid = 2048;     // (1024 ... 8192 workgroups: no difference beyond noise, gpurun_out/r5j)
     if (variant >= 3) LD(63, false, true, qd_grid, worklist, (unsigned *)nullptr);   // what is left has more than 32 records or a magnitude >= 16: one general tier that takes everything
     else { LD(32, false, true, qd_grid, worklist, worklist2); LD(63, false, true, 1024, worklist2, (unsigned *)nullptr); }
@@ -3725,6 +3726,17 @@ void mjh_launch_encode(const MjhConst &C, const void *q, const unsigned long lon
   hipLaunchKernelGGL(k_finish_bits, dim3((n + 63) / 64), dim3(64), 0, s, totals, rst ? (const unsigned *)seg_totals : (const unsigned *)nullptr, stream,
                      stream_words_per_image, (MjhImageMeta *)meta, n);
 }
+
+// One wave that keeps its hardware queue busy for `ticks` of the 100 MHz clock: mjh_streams_overlap (mjh_encoder.cpp) finds out with
+// two of them whether two streams were dealt the same hardware queue
+__global__ void __launch_bounds__(64) k_spin(unsigned long long ticks, unsigned *sink)
+{
+  const unsigned long long t0 = wall_clock64();
+  unsigned n = 0;
+  while (wall_clock64() - t0 < ticks) n++;
+  if (sink && threadIdx.x == 0 && n == 0xFFFFFFFFu) *sink = n;
+}
+void mjh_launch_spin(unsigned long long ticks, hipStream_t s) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, ticks, (unsigned *)nullptr); }
 
 void mjh_launch_header(const void *prefix, int prefix_len, const void *sos, int sos_len, const MjhHuffTable *tabs, int spi,
                        const int dht_slots[8], const int dht_ids[8], int ndht, int multi_dht, void *out, size_t out_stride, void *meta, int n, hipStream_t s,

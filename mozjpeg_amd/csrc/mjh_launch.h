@@ -17,7 +17,7 @@ void mjh_launch_gen_tables(MjhHuffTable *tabs, int spi, const int *slots, int ns
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
-                           uint8_t *nq8 = nullptr, int v3_passes = 0, int fastdiv = 0, hipEvent_t after_first_tier = nullptr);   // after_first_tier: recorded behind the tile-sorted kernel, in front of the general tiers   // v3_passes > 0 (plain compact pass): the tile-sorted kernel with that many passes per tile
+                           uint8_t *nq8 = nullptr, int v3_passes = 0, int fastdiv = 0, hipEvent_t after_first_tier = nullptr, hipEvent_t after_first_tier2 = nullptr);   // after_first_tier: recorded behind the tile-sorted kernel, in front of the general tiers   // v3_passes > 0 (plain compact pass): the tile-sorted kernel with that many passes per tile
 // trellis_eob_opt: the block-row pass behind a (band-limited) AC trellis; eob_cost / eob_has as written by mjh_launch_trellis_ac
 void mjh_launch_trellis_eob_chain(const MjhConst &C, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const void *eob_cost, const int *eob_has,
                                   int Ss, int Se, int n, hipStream_t s);
@@ -42,6 +42,7 @@ void mjh_launch_stuff(const unsigned *stream, size_t stream_words_per_image, con
                       unsigned *ff_totals, void *out, size_t out_stride, void *meta, unsigned *sizes, const unsigned *mpos, int nseg, int n, hipStream_t s);
 void mjh_launch_pack_results(const void *out, size_t out_stride, const unsigned *sizes, const void *meta, const void *prog_ctl, int n,
                              void *dst, size_t cap, void *table, hipStream_t s);
+void mjh_launch_spin(unsigned long long ticks_100mhz, hipStream_t s);   // one wave busy for that long (hardware-queue probe)
 void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots, int nslots, int n, hipStream_t s);
 // progressive mode (mjh_prog.hip)
 void mjh_launch_prog_reset(void *ctl, int nscans, int n, hipStream_t s);

@@ -10,7 +10,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else cfg["batch"]
 w, h, kw = cfg["w"], cfg["h"], cfg["kw"]
 frames = bench.make_frames(w, h, [1234 + i for i in range(B)], False, 1)
 d = torch.from_numpy(frames).cuda()
-for nenc in (1, 2, 3):
+for nenc in [int(v) for v in os.environ.get("INFLIGHT", "1,2,3").split(",")]:
     encs = [M.Encoder(M.make_params(w, h, **kw), max_batch=B) for _ in range(nenc)]
     for e in encs:
         e.encode_tensor(d, stream="own"); e.sync()
