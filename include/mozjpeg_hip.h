@@ -227,8 +227,8 @@ int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t row_pitch, si
                       int n, void *stream);
 /* Batches in flight on the encoder's own stream (stream == NULL above): 2 (the default; MJH_INFLIGHT in the environment) -- consecutive
  * mjh_encode_device calls alternate between two complete sets of working buffers and streams inside the encoder, so that the
- * latency- and memory-bound kernels of one batch (colour conversion, final statistics, bit lengths, prefix sums, byte stuffing) run
- * next to the other batch's, while the VALU-bound ones (AC trellis, FDCT, bit writer) keep the chip to themselves; the results of
+ * front end of one batch (colour conversion, FDCT) runs next to the tail of the other (final statistics, bit lengths, prefix sums,
+ * bit writing, byte stuffing), while the VALU-bound AC trellis of either keeps the chip to itself; the results of
  * call k stay valid until call k + 2, and every accessor (mjh_get_jpeg, mjh_get_output_device, taps, ...) refers to the most recent
  * call.  1 -- one batch at a time on one buffer set (half the device memory).  A caller's stream, debug taps and the memory checker
  * always run one batch at a time.  The files are the same either way. */

@@ -379,7 +379,7 @@ struct mjh_encoder {
   mjh_encoder *twin = nullptr;        // primary only
   mjh_encoder *owner = nullptr;       // twin only
   mjh_encoder *last = nullptr;        // primary only: who ran the most recent batch (nullptr = this encoder)
-  int inflight = 2, inflight_mode = 1;   // MJH_INFLIGHT (1 = one batch at a time), MJH_INFLIGHT_MODE (0 = no ordering between the two, 1 = the AC trellis alone)
+  int inflight = 2, inflight_mode = 1;   // MJH_INFLIGHT (1 = one batch at a time), MJH_INFLIGHT_MODE (0 = no ordering between the two sets, 1 = nothing next to a set's AC trellis kernel, 2 = only the colour kernel and the byte stuffing)
   unsigned dev_calls = 0;
   bool high_priority_streams = false; // twin: its streams come from the high-priority queue pool, never the primary's hardware queues
   hipEvent_t ev_done = nullptr, ev_tier1 = nullptr;   // end of this encoder's last pipeline / of its tile-sorted AC trellis kernel
@@ -2062,8 +2062,8 @@ extern "C" int mjh_encode_device(mjh_encoder *e, const void *d_pixels, size_t ro
   // call k stay where they are until call k + 2).  Debug taps, the memory checker and a caller's stream keep to one set.
   mjh_encoder *t = e;
   if (e->inflight > 1 && !stream && !e->debug_taps && mjh_guard_mode() == 0 && !e->owner) {
-    if (!e->twin) { const int rt = make_twin(e); if (rt) return rt; }
-    if (e->dev_calls++ & 1u) t = e->twin;
+    if (!e->twin && make_twin(e) != MJH_OK) e->inflight = 1;      // (no room for a second set: one batch at a time)
+    if (e->twin && (e->dev_calls++ & 1u)) t = e->twin;
     if (t != e) s = t->stream;
   }
   const int rc = run_pipeline(t, d_pixels, row_pitch, image_stride, n, s);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# two batches in flight inside the encoder: the metric line per setting; usage: gpu_r6_inflight.sh TAG [config]
+# two batches in flight inside the encoder: the metric line per setting; usage: gpu_inflight.sh TAG [config]
 TAG=${1:-r06if}; CFG=${2:-metric}
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/$TAG; mkdir -p "$O"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counter passes of the C3 chain and of the metric's kernels in one call (each pass its own rocprofv3 run, --kernel-trace only); usage: gpu_r6_sq.sh TAG
+# SQ counter passes of the C3 chain and of the metric's kernels in one call (each pass its own rocprofv3 run, --kernel-trace only); usage: gpu_sq_all.sh TAG
 TAG=${1:-r06sq}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
