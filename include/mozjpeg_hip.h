@@ -310,7 +310,7 @@ int mjh_get_output_device(mjh_encoder *e, void **d_base, size_t *stride, void **
 
 /* The Huffman table entry `scan` of the scan script was coded with in image `image` of the last batch: bits[0..16] (counts per
  * code length) and the symbols in code order.  Progressive encoders only; tblno selects the DC table of a DC scan (the number its
- * components carry in dc_tbl_no, 0 or 1) and is ignored for AC scans.  A scan search codes all its candidates, also those the file
+ * components carry in dc_tbl_no) and is ignored for AC scans.  A scan search codes all its candidates, also those the file
  * leaves out: the libjpeg drop-in keeps the object's table slots as the reference's last coded scans leave them
  * (jpeg_gen_optimal_table writes into cinfo->dc_huff_tbl_ptrs / ac_huff_tbl_ptrs, jchuff.c:1092-1105).  Synchronises. */
 int mjh_get_scan_table(mjh_encoder *e, int image, int scan, int tblno, uint8_t bits[17], uint8_t vals[256]);

@@ -46,7 +46,7 @@ typedef struct shim_state {
   struct batcher *bt;        /* pixel input: the batcher of this parameter set (concurrent clients are coalesced, below) */
   int reading_arena;         /* >= 0: this object's file lies in that result arena of the batch encoder until it has been handed over */
   int end_dc;                /* scan search: bit t = end_dc_bits / vals[t] is the DC table the search's last coded DC scan left in slot t */
-  unsigned char end_dc_bits[2][17], end_dc_vals[2][256];
+  unsigned char end_dc_bits[NUM_HUFF_TBLS][17], end_dc_vals[NUM_HUFF_TBLS][256];
   struct shim_state *next;
 } shim_state;
 
@@ -201,7 +201,7 @@ static void fetch_end_tables(shim_state *s, mjh_encoder *enc, int index)
   int si, k, t;
   s->end_dc = 0;
   if (!s->p.optimize_scans || s->p.arith_code) return;
-  for (t = 0; t < 2; t++) {
+  for (t = 0; t < NUM_HUFF_TBLS; t++) {
     int last = -1;
     for (si = 0; si < s->p.num_scans; si++) {
       const mjh_scan *sc = &s->p.scan_info[si];
@@ -209,14 +209,6 @@ static void fetch_end_tables(shim_state *s, mjh_encoder *enc, int index)
       for (k = 0; k < sc->comps_in_scan; k++) if (s->p.dc_tbl_no[sc->component_index[k]] == t) last = si;
     }
     if (last >= 0 && mjh_get_scan_table(enc, index, last, t, s->end_dc_bits[t], s->end_dc_vals[t]) == MJH_OK) s->end_dc |= 1 << t;
-  }
-  if (getenv("SHIM_DEBUG_TABLES")) {
-    static const int cand[4] = { 0, 23, 24, 25 };
-    for (k = 0; k < 4; k++) for (t = 0; t < 2; t++) {
-      unsigned char b[17], v[256]; int j;
-      if (mjh_get_scan_table(enc, index, cand[k], t, b, v) != MJH_OK) continue;
-      fprintf(stderr, "scan %d t %d:", cand[k], t); for (j = 0; j < 17; j++) fprintf(stderr, " %d", b[j]); fprintf(stderr, " |"); for (j = 0; j < 12; j++) fprintf(stderr, " %d", v[j]); fprintf(stderr, "\n");
-    }
   }
 }
 
@@ -566,7 +558,7 @@ static void hand_over_file(j_compress_ptr cinfo, const shim_state *s, const unsi
       p = e;
     }
   }
-  for (k = 0; k < 2; k++)
+  for (k = 0; k < NUM_HUFF_TBLS; k++)
     if (s->end_dc >> k & 1) {
       JHUFF_TBL **slot = &cinfo->dc_huff_tbl_ptrs[k];
       if (*slot == NULL) *slot = jpeg_alloc_huff_table((j_common_ptr)cinfo);

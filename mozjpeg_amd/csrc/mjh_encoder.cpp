@@ -486,8 +486,12 @@ static int check_supported(const mjh_params *p)
     // progressive mode: the checks of validate_script (jcmaster.c:269-432) that matter here
     if (!p->optimize_coding && !p->arith_code) return fail(MJH_EUNSUPPORTED, "progressive mode forces optimize_coding (jcmaster.c:1091-1094)");
 
+    // the progressive kernels keep two DC table classes per scan, told apart by the low bit of the table number: any AC table
+    // numbers, and DC table numbers as long as two different ones of the image do not share that bit (0 with 2, 1 with 3)
     for (int i = 0; i < p->num_components; i++)
-      if (p->dc_tbl_no[i] > 1 || p->ac_tbl_no[i] > 1) return fail(MJH_EUNSUPPORTED, "progressive mode: table numbers 0/1 only");
+      for (int j = 0; j < i; j++)
+        if (p->dc_tbl_no[i] != p->dc_tbl_no[j] && ((p->dc_tbl_no[i] ^ p->dc_tbl_no[j]) & 1) == 0 && !p->arith_code)
+          return fail(MJH_EUNSUPPORTED, "progressive mode: DC table numbers %d and %d in one image (the kernels tell two DC tables per scan apart by the low bit of the number)", p->dc_tbl_no[j], p->dc_tbl_no[i]);
     if (p->optimize_scans) {
       mjh_scan ref[MJH_MAX_SCANS];
       // scan 0 is whatever dc_scan_opt_mode was when the script was built (all components, or the luma alone,
@@ -1327,10 +1331,10 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
         d.ta[ci] = ms.Se ? p->ac_tbl_no[c] : 0;
         if (ms.Ss == 0) {
           if (ms.Ah == 0) {
-            const int t = p->dc_tbl_no[c];
-            if (d.slot[t] < 0) {
-              d.slot[t] = SLOT_PROG + 2 * si + t;
-              d.dht_slot[d.ndht] = d.slot[t]; d.dht_id[d.ndht] = t; d.ndht++;
+            const int t = p->dc_tbl_no[c], cls = t & 1;     // (check_supported: distinct table numbers of an image have distinct classes)
+            if (d.slot[cls] < 0) {
+              d.slot[cls] = SLOT_PROG + 2 * si + cls;
+              d.dht_slot[d.ndht] = d.slot[cls]; d.dht_id[d.ndht] = t; d.ndht++;
             }
           }
         } else {
@@ -2730,7 +2734,8 @@ extern "C" int mjh_get_scan_table(mjh_encoder *e, int image, int scan, int tblno
 {
   e = cur(e);
   if (!e || !bits || !vals || image < 0 || image >= e->last_n) return fail(MJH_EINVAL, "bad arguments");
-  if (!e->progressive || e->arith || scan < 0 || scan >= e->nscans || tblno < 0 || tblno > 1) return fail(MJH_EINVAL, "no such scan table");
+  if (!e->progressive || e->arith || scan < 0 || scan >= e->nscans || tblno < 0 || tblno > 3) return fail(MJH_EINVAL, "no such scan table");
+  tblno &= 1;      // (the table class of a DC scan: see check_supported)
   const mjh_scan &sc = e->p.scan_info[scan];
   if (sc.Ss == 0 && sc.Ah != 0) return fail(MJH_EINVAL, "a DC refinement scan has no table");
   HIPCHK(hipSetDevice(e->device));
