@@ -306,8 +306,8 @@ def dominant_issue(config, dom, frames_per_call, dom_ms):
     """What bounds the dominant interval when it is not the memory system: VALU issue.  From the newest committed SQ counter
     passes of this configuration (profiles/r*_pmc_sq_batch*.json, tools/pmc_sq.py): wave-instructions per launch of the interval's
     kernels, scaled to this batch; a SIMD issues one wave64 VALU instruction per 4 cycles (1024 SIMDs x 2.4 GHz,
-    MI355X_MICROARCH.md), so issue_frac = instructions x 4 / (1024 x 2.4e9 x the interval's measured time).  lanes_per_inst =
-    SQ_THREAD_CYCLES_VALU / (4 SQ_ACTIVE_INST_VALU).  None when the interval's kernels are not the profiled machine code."""
+    MI355X_MICROARCH.md), so issue_frac = instructions x 4 / (1024 x 2.4e9 x the interval's measured time).  lanes_per_instruction =
+    SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU.  None when the interval's kernels are not the profiled machine code."""
     if config != "metric":
         return None
     prefixes = INTERVAL_KERNELS.get(dom, ())
@@ -325,7 +325,7 @@ def dominant_issue(config, dom, frames_per_call, dom_ms):
             thr = sum(v.get("SQ_THREAD_CYCLES_VALU", 0.0) for v in mine.values())
             act = sum(v.get("SQ_ACTIVE_INST_VALU", 0.0) for v in mine.values())
             return {"valu_wave_instructions_per_launch": int(insts), "issue_frac": round(insts * 4.0 / (1024 * 2.4e9 * dom_ms * 1e-3), 4),
-                    "lanes_per_instruction": round(thr / (4.0 * act), 1) if act else None,
+                    "lanes_per_instruction": round(thr / act, 1) if act else None,
                     "source": "%s (SQ_INSTS_VALU per launch, scaled to this batch; machine code of the interval's kernels identical to the profiled tree's)" % os.path.relpath(path, ROOT)}
         except Exception:
             continue
