@@ -10,6 +10,7 @@
 #define MJH_DIVERGENT_SCOPE
 #define MJH_WAVE_GROUPS(n) ((void)0)
 #define MJH_WAVE_SYNC() ((void)0)
+#define MJH_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)      // the instruction scheduler moves nothing across (the emulator: nothing)
 #endif
 // MJH_WAVE_SYNC(): the lanes of a wave execute in lock step, so "every lane reads an LDS word, then lane 0 overwrites it" needs
 // no barrier on the device; the emulator runs the lanes one after the other between cross-lane operations and needs the point

@@ -302,6 +302,8 @@ struct mjh_encoder {
   int dc_late = 1;                   // large sequential batches: the DC chains of components >= dc_late (1: both chroma components, 2: Cr only) run behind the AC kernel, under the tail of small kernels (MJH_DC_LATE=0: all next to it)
   int dc_stats_side = 1;             // the final DC statistics run on the side stream behind the DC trellis (MJH_DC_STATS_SIDE=0: main stream)
   int dc_window_ok = 0;              // every component's DC quantizer step 8q >= 40: the DC trellis may use its sliding-window kernel
+  int trellis_chunks = 0;            // image ranges of the tile-sorted first tier (MJH_TRELLIS_CHUNKS; 0 = by batch size): the general tiers of range c run next to the first tier of range c + 1
+  hipEvent_t ev_chunk[4] = { nullptr, nullptr, nullptr, nullptr };
   int trellis_v3 = 4;                // passes per tile of the tile-sorted first tier (MJH_TRELLIS_V3; 0 = the general kernel)
   int dqt_off[4] = { -1, -1, -1, -1 };      // file offset of the first entry of every 8-bit DQT table
   int dqt_tabs[4] = { 0, 0, 0, 0 }, dqt_ntab = 0;   // quantization tables in DQT marker order (first use by a component)
@@ -813,7 +815,7 @@ static void free_all(mjh_encoder *e)
   for (hipEvent_t ev : e->prof_events) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : e->side_events) (void)hipEventDestroy(ev);
   if (e->copy_done) (void)hipEventDestroy(e->copy_done);
-  for (hipEvent_t ev : { e->ev_fork, e->ev_join, e->ev_side0, e->ev_side1 }) if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : { e->ev_fork, e->ev_join, e->ev_side0, e->ev_side1, e->ev_chunk[0], e->ev_chunk[1], e->ev_chunk[2], e->ev_chunk[3] }) if (ev) (void)hipEventDestroy(ev);
   if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
@@ -1027,6 +1029,9 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
   if (const char *v = getenv("MJH_TRELLIS_VARIANT")) { e->trellis_variant = atoi(v); e->trellis_adapt = false; }
   HIPCHK_E(hipHostMalloc((void **)&e->h_defer, 64, hipHostMallocDefault));
   if (const char *v = getenv("MJH_TRELLIS_V3")) e->trellis_v3 = atoi(v);
+  if (const char *v = getenv("MJH_SMALL_BATCH")) e->small_batch = (size_t)atoll(v);      // tests: the large-batch schedule on small images
+  if (const char *v = getenv("MJH_TRELLIS_CHUNKS")) { e->trellis_chunks = atoi(v); if (e->trellis_chunks < 0 || e->trellis_chunks > 4) e->trellis_chunks = 0; }
+  for (int i = 0; i < 4; i++) HIPCHK_E(hipEventCreateWithFlags(&e->ev_chunk[i], hipEventDisableTiming));
   if (const char *v = getenv("MJH_DC_LATE")) { e->dc_late = atoi(v); if (e->dc_late < 0 || e->dc_late > 2) e->dc_late = 1; }   // A/B knob
   e->dc_window_ok = 1;
   for (int i = 0; i < C.ncomp; i++) if (p->quantval[p->quant_tbl_no[i]][0] < 5) e->dc_window_ok = 0;
@@ -1081,6 +1086,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
       hq.q[t][k] = (uint16_t)q;
       hq.dq8[t][k] = 8 * q;
       hq.rcp8q[t][k] = 1.0f / (float)(8 * q);
+      hq.thr8[t][k] = (float)(8 * q - ((8 * q) >> 1));
       hq.lambda_tbl[t][k] = (float)(1.0 / (double)(q * q));   // jcdctmgr.c:1017-1021
       {   // the conventional quantizer's divisor: a UINT16 argument in the reference's 8-bit build (see MjhQuant)
         // JDCT_IFAST: quantval x the AA&N scale factors of the position (natural order) x 8, rounded at 11 bits (jcdctmgr.c:291-345)
@@ -1773,12 +1779,20 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     // ... and this batch's AC trellis waits for the tail of the other set's batch (queued before this call)
     const bool excl = ordered && v3 && !e->progressive;
     if (excl && peer_done_set) HIPCHK(hipStreamWaitEvent(s, peer->ev_done, 0));
+    // Image ranges of the first tier (mjh_launch_trellis_ac): measured per 64 4K frames, two ranges shorten the trellis interval
+    // from 1.72 to 1.61 ms at the same step time; 128 1080p frames: 0.97 -> 0.92 ms; 64 1080p frames lose 6 % (each range's
+    // launch drains before the next starts), a progressive batch gains nothing (profiles/r06f_chunks.md): two ranges from six
+    // million blocks of a sequential batch on, one otherwise
+    const int trellis_ranges = !v3 || e->debug_taps || (size_t)n * C.total_real_blocks < e->small_batch ? 1
+                               : e->trellis_chunks > 0 ? e->trellis_chunks
+                               : !e->progressive && (size_t)n * C.total_real_blocks >= (size_t)6000000 ? 2 : 1;
     pr.mark("trellis_ac");
     mjh_launch_trellis_ac(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap,
                           e->trellis_variant,
                           Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, nzm, qstride, n, s,
                           e->d_nq8, v3 ? ((size_t)n * C.total_real_blocks < e->small_batch ? 1 : e->trellis_v3) : 0,   // (a small batch: one pass per tile -- four times the workgroups, a quarter of their length: latency matters more than the sorting)
-                          e->fastdiv_all, dc_late ? e->ev_side0 : nullptr, excl ? e->ev_tier1 : nullptr);
+                          e->fastdiv_all, dc_late ? e->ev_side0 : nullptr, excl ? e->ev_tier1 : nullptr,
+                          trellis_ranges, e->side_stream, e->ev_chunk);
     if (excl) e->ev_tier1_set = true;
     if (dc_late) {
       if (!v3) return fail(MJH_EINVAL, "internal: the late DC chains need the tile-sorted trellis' event");

@@ -102,6 +102,9 @@ struct MjhQuant {
   // above, and with them the machine code of the kernels that do not quantize conventionally, stay what they were.)
   int dqc8[4][64];
   float rcpc8q[4][64];
+  // the smallest |x| the trellis' conventional quantization (jcdctmgr.c:1011-1015 applied to 8q) turns into a non-zero value:
+  // x + (8q >> 1) >= 8q  <=>  x >= 8q - (8q >> 1), as a float (exact: 8q < 2^24) for a compare on the converted coefficient
+  float thr8[4][64];
 };
 
 // per-image bookkeeping written by the encode kernels

@@ -1742,6 +1742,7 @@ k_qopt_update(long long *__restrict__ sums, MjhQuant *__restrict__ Q)
   Qi->q[t][k] = (uint16_t)q;
   Qi->dq8[t][k] = 8 * q;
   Qi->rcp8q[t][k] = 1.0f / (float)(8 * q);
+  Qi->thr8[t][k] = (float)(8 * q - ((8 * q) >> 1));
   Qi->dqc8[t][k] = 8 * q;                       // (q <= 254: nothing wraps)
   Qi->rcpc8q[t][k] = 1.0f / (float)(8 * q);
   Qi->lambda_tbl[t][k] = (float)(1.0 / (double)(q * q));
@@ -1825,9 +1826,12 @@ k_qopt_fix(const MjhQuant *__restrict__ Q, uint8_t *__restrict__ out, size_t out
   }
 }
 
-__global__ void k_zero_counters(unsigned *__restrict__ a, unsigned *__restrict__ b)
+// the 16-byte headers of up to four work-list pairs (one pair per image range of a chunked AC trellis), `step` words apart
+__global__ void k_zero_counters(unsigned *__restrict__ a, unsigned *__restrict__ b, int4 off)
 {
-  if (threadIdx.x < 4) { a[threadIdx.x] = 0; b[threadIdx.x] = 0; }
+  const int t = threadIdx.x & 3, c = threadIdx.x >> 2;
+  const int o = c == 0 ? off.x : c == 1 ? off.y : c == 2 ? off.z : off.w;
+  if (threadIdx.x < 16 && o >= 0) { a[o + t] = 0; b[o + t] = 0; }
 }
 
 // work-list entries: 3 words per deferred block at [4 + 3i]: image, component << 28 | block, slot of its dense copy
@@ -2052,33 +2056,53 @@ __device__ __forceinline__ float4 v3_rate(const float4 *rate_rows, int run)
   return rate_rows[run & 15];
 }
 
-// one step of the walk: the two newest live entries not looked at yet (e-1, e-2).  Entry e lives in slot e; entry 0, the
-// virtual start (position 0, no distortion, no cost), is a slot like the others, written before the walk -- a step has no
-// special case for it (until round 5 it was not stored and every step selected around it: ~10 of its 58 instructions)
+// The scan of one record: pair steps over the live entries, newest first -- two entries (e-1, e-2) per step.  Entry e lives in
+// slot e; entry 0, the virtual start (position 0, no distortion, no cost), is a slot like the others, written before the walk
+// -- a step has no special case for it (until round 5 it was not stored and every step selected around it: ~10 of its 58
+// instructions).
+// SOFTWARE PIPELINE (round 6).  The kernel turned out to be as sensitive to occupancy as a latency-bound one (14 / 10 / 6 waves
+// per CU: 1.47 / 1.85 / 2.46 ms, profiles/r06g_occupancy.md), and a step used to be two LDS round trips one behind the other:
+// entries + info words, then -- addressed by the run lengths the info words give -- the rate rows.  The entries and info
+// words of the NEXT step are now requested at the top of a step, so that a step waits for its rate rows only.  Same loads,
+// same operations on the same values in the same order per lane: the files do not change.  (Indices past the oldest entry are
+// clamped to 0: a harmless repeat, read only if the scan goes on.)
 template <int QN, int NC>
-__device__ __forceinline__ void v3_pair(const uint2 (*col)[64], const unsigned short (*info)[64], const float4 *rate_rows, int lane, int e, int im1,
+__device__ __forceinline__ void v3_scan(const uint2 (*col)[64], const unsigned short (*info)[64], const float4 *rate_rows, int lane, int e, int im1,
                                         float azd_prev, float f0f, float d0, float d1, float d2, float d3,
-                                        float &best, int &beste, int &bestk, float &gap_old)
+                                        float &best, int &beste, int &bestk)
 {
-  const int ea = e - 1, eb = e >= 2 ? e - 2 : 0;        // (e == 1: b repeats a, the same entry: harmless)
-  const uint2 va = col[ea][lane], vb = col[eb][lane];
-  const unsigned ia = info[ea][lane], ib = info[eb][lane];
-  const float azd_a = __uint_as_float(va.x), acc_a = __uint_as_float(va.y);
-  const float azd_b = __uint_as_float(vb.x), acc_b = __uint_as_float(vb.y);
-  const int run_a = im1 - (int)(ia & 63u), run_b = im1 - (int)(ib & 63u);
-  const float4 ra = v3_rate<NC>(rate_rows, run_a), rb4 = v3_rate<NC>(rate_rows, run_b);
-  const float rba = (float)(run_a >> 4) * f0f, rbb = (float)(run_b >> 4) * f0f;
-  const float gap_a = azd_prev - azd_a, gap_b = azd_prev - azd_b;
-  const float rhs_a = gap_a + acc_a, rhs_b = gap_b + acc_b;
-  float lba, lbb;
-  int lka, lkb;
-  v3_eval<NC>(ra, rba, rhs_a, d0, d1, d2, d3, lba, lka);
-  v3_eval<NC>(rb4, rbb, rhs_b, d0, d1, d2, d3, lbb, lkb);
-  // newest first, '<=': on equal cost the OLDER predecessor wins, as in the reference's oldest-first strict '<' scan (a cost
-  // without a Huffman code is >= 3e38 and never reaches the initial 1e38)
-  if (lba <= best) { best = lba; beste = ea; bestk = lka; }
-  if (lbb <= best) { best = lbb; beste = eb; bestk = lkb; }
-  gap_old = gap_b;
+  int ea = e - 1, eb = e >= 2 ? e - 2 : 0;        // (e == 1: b repeats a, the same entry: harmless)
+  uint2 va = col[ea][lane], vb = col[eb][lane];
+  unsigned ia = info[ea][lane], ib = info[eb][lane];
+  float gap_old;
+  do {
+    // this step's rate rows first (their addresses come from info words that are in registers), then the next step's entries:
+    // LDS answers in order, so the step waits for the rate rows while the prefetch is still on its way
+    const int run_a = im1 - (int)(ia & 63u), run_b = im1 - (int)(ib & 63u);
+    const float4 ra = v3_rate<NC>(rate_rows, run_a), rb4 = v3_rate<NC>(rate_rows, run_b);
+    const int ea_n = e >= 3 ? e - 3 : 0, eb_n = e >= 4 ? e - 4 : 0;
+    const uint2 va_n = col[ea_n][lane], vb_n = col[eb_n][lane];
+    const unsigned ia_n = info[ea_n][lane], ib_n = info[eb_n][lane];
+    MJH_SCHED_BARRIER();
+    const float azd_a = __uint_as_float(va.x), acc_a = __uint_as_float(va.y);
+    const float azd_b = __uint_as_float(vb.x), acc_b = __uint_as_float(vb.y);
+    const float rba = (float)(run_a >> 4) * f0f, rbb = (float)(run_b >> 4) * f0f;
+    const float gap_a = azd_prev - azd_a, gap_b = azd_prev - azd_b;
+    const float rhs_a = gap_a + acc_a, rhs_b = gap_b + acc_b;
+    float lba, lbb;
+    int lka, lkb;
+    v3_eval<NC>(ra, rba, rhs_a, d0, d1, d2, d3, lba, lka);
+    v3_eval<NC>(rb4, rbb, rhs_b, d0, d1, d2, d3, lbb, lkb);
+    // newest first, '<=': on equal cost the OLDER predecessor wins, as in the reference's oldest-first strict '<' scan (a cost
+    // without a Huffman code is >= 3e38 and never reaches the initial 1e38)
+    if (lba <= best) { best = lba; beste = ea; bestk = lka; }
+    if (lbb <= best) { best = lbb; beste = eb; bestk = lkb; }
+    gap_old = gap_b;
+    e -= 2;
+    ea = ea_n; eb = eb_n; va = va_n; vb = vb_n; ia = ia_n; ib = ib_n;
+    // cost >= rhs >= gap in float arithmetic, and the gap only grows towards older entries: once it exceeds the best cost
+    // no older predecessor can win or tie
+  } while (e > 0 && !(gap_old > best));
 }
 
 // (Round 3 also counted the AC symbol statistics of the final coefficients in this kernel's back-track, MJH_FUSE bit 4: the
@@ -2088,16 +2112,20 @@ __global__ void __launch_bounds__(64)
 k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q,
                 const MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 ac_slot_of_comp, int4 tile0_of_comp,
                 const float *__restrict__ lambda_in, uint8_t *__restrict__ nq8, unsigned *__restrict__ worklist,
-                int16_t *__restrict__ dense, unsigned dense_cap, unsigned long long *__restrict__ nzmask)
+                int16_t *__restrict__ dense, unsigned dense_cap, unsigned long long *__restrict__ nzmask, int img0, unsigned *__restrict__ counts)
 {
   static_assert(QN >= 16 && QN <= 63 && NPASS >= 1 && NPASS <= 8, "queue capacity / passes");
   constexpr int TILE = 64 * NPASS;
   __shared__ uint2 col[QN + 1][64];      // tile sort scratch; per pass: queue records (record r in slot r) -> live entries {azd, acc} (entry e in slot e; 0 = the virtual start) -> value column
   __shared__ unsigned short info[QN + 1][64];   // live entry e at [e]: position | back entry << 6 | magnitude (< 16) << 12 (the signs: one bit per position in a register)
   __shared__ float4 rate_rows[16];
+#ifdef MJH_V3_PAD   // occupancy experiments (tools/build_variant.sh): LDS nobody uses
+  __shared__ unsigned v3_pad[MJH_V3_PAD / 4];
+  if (lambda_in == nullptr) v3_pad[threadIdx.x] = 1u;
+#endif
   typedef unsigned __attribute__((may_alias)) u_alias;
   typedef unsigned short __attribute__((may_alias)) us_alias;
-  const int img = blockIdx.y, tl = blockIdx.x, lane = threadIdx.x;
+  const int img = blockIdx.y + img0, tl = blockIdx.x, lane = threadIdx.x;      // (img0: first image of this launch's range of the batch)
   const int comp = tl >= tile0_of_comp.w ? 3 : tl >= tile0_of_comp.z ? 2 : tl >= tile0_of_comp.y ? 1 : 0;
   const int t0 = comp == 0 ? 0 : comp == 1 ? tile0_of_comp.y : comp == 2 ? tile0_of_comp.z : tile0_of_comp.w;
   const MjhComp cc = C.c[comp];
@@ -2172,7 +2200,7 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
       constexpr int QCH = 8;
       int dq_c[QCH], sdiv_c[QCH];
       unsigned mdiv_c[QCH];
-      float lt_c[QCH], rcp_c[QCH];
+      float lt_c[QCH], rcp_c[QCH], thr_c[QCH];
       float azd = 0.0f;
 #pragma unroll
       for (int k = 1; k < 64; k++) {
@@ -2182,29 +2210,35 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
             const int kk = (k / QCH) * QCH + j;
             dq_c[j] = Q->dq8[cc.qtbl][kk];
             lt_c[j] = Q->lambda_tbl[cc.qtbl][kk];
+            thr_c[j] = Q->thr8[cc.qtbl][kk];
             if (FD) { sdiv_c[j] = Q->sdiv[cc.qtbl][kk]; mdiv_c[j] = Q->mdiv[cc.qtbl][kk]; }
             else rcp_c[j] = Q->rcp8q[cc.qtbl][kk];
           }
         }
+        // The position's share of the all-zero distortion needs x^2 only: from the SIGNED coefficient converted to float -- xf * xf is
+        // the correctly rounded x^2, which is what (float)(x * x) is (one rounding of the same exact integer either way) -- and
+        // "quantizes to non-zero" is a compare of |xf| (a source modifier) with the table's float threshold: six VALU instructions per
+        // position instead of nine; |x| as an integer exists only inside the branch few positions take.
         const int xsg = xs[k];
-        const int x = xsg < 0 ? -xsg : xsg;
-        const int dq = dq_c[k % QCH];
-        float t = (float)mul24(x, x) * lambda;
+        const float xf = (float)xsg;
+        float t = (xf * xf) * lambda;
         t = t * lt_c[k % QCH];
         const float azd_cur = t + azd;
-        if (x + (dq >> 1) >= dq) {
+        if (__builtin_fabsf(xf) >= thr_c[k % QCH]) {
+          const int x = (int)__builtin_fabsf(xf);      // (one conversion with a source modifier)
+          const int dq = dq_c[k % QCH];
           int qval = FD ? udiv_mh(x + (dq >> 1), sdiv_c[k % QCH], mdiv_c[k % QCH]) : udiv_exact(x + (dq >> 1), dq, rcp_c[k % QCH]);
           if (qval >= 1024) qval = 1023;
           qmax = qval > qmax ? qval : qmax;
           // (a block with more than QN records is deferred: what its surplus records overwrite in the last slot is never read)
-          col[nq < QN ? nq : QN - 1][lane] = make_uint2((unsigned)k | (xsg < 0 ? 64u : 0u) | ((unsigned)qval << 7) | ((unsigned)x << 17), __float_as_uint(azd));
+          col[nq < QN ? nq : QN - 1][lane] = make_uint2((unsigned)k | ((__float_as_uint(xf) >> 25) & 64u) | ((unsigned)qval << 7) | ((unsigned)x << 17), __float_as_uint(azd));      // (the sign: the float's)
           nq++;
         }
         azd = azd_cur;
       }
       azd63 = azd;
       defer_blocks(inside && (nq > QN || qmax >= 16), worklist, (unsigned)img, ((unsigned)comp << 28) | (unsigned)blk, 0u, xs, dense, dense_cap, true, lane);
-      count_heavy(worklist, inside, nq, lane);
+      count_heavy(counts, inside, nq, lane);      // (the whole batch's counts: the first range's header)
     }
     const bool work = inside && nq <= QN && qmax < 16;
 
@@ -2238,7 +2272,7 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
       azd_prev = __uint_as_float(rec.y);
       const int dq = dq_n;
       const float lti = lt_n;
-      float t = (float)mul24(x, x) * lambda;
+      float t = squaref(x) * lambda;      // ((float)x * (float)x == (float)(x * x): one rounding of the same exact integer)
       t = t * lti;
       azd_cur = t + azd_prev;
       ncd = bitlen((unsigned)qval);
@@ -2248,7 +2282,7 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
         if (k >= 2 && !wide) break;      // uniform
         const int cand = (k < ncd - 1) ? (2 << k) - 1 : qval;
         const int delta = mul24(cand, dq) - x;
-        const float d = (float)mul24(delta, delta) * lambda;      // (|delta| <= x < 2^15)
+        const float d = squaref(delta) * lambda;      // (|delta| <= x < 2^15)
         dd[k] = k < ncd ? d * lti : 3e38f;
       }
       d0 = dd[0]; d1 = dd[1]; d2 = dd[2]; d3 = dd[3];
@@ -2268,14 +2302,8 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
         // (a plain divergent loop: lanes whose scan has ended wait masked until the last one is done.  Written as
         // `while (ballot(scan)) if (scan) {..}` until late in round 5, the loop carried its state through a bypass block: eight
         // register copies plus a flag materialised and re-tested per pair step, 10 of its ~75 instructions)
-        float gap_old;
-        do {
-          if (!wide) v3_pair<QN, 2>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk, gap_old);
-          else v3_pair<QN, 4>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk, gap_old);
-          e -= 2;
-          // cost >= rhs >= gap in float arithmetic, and the gap only grows towards older entries: once it exceeds the best cost
-          // no older predecessor can win or tie
-        } while (e > 0 && !(gap_old > best));
+        if (!wide) v3_scan<QN, 2>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk);
+        else v3_scan<QN, 4>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk);
       }
       lookup();
       const bool wide_n = next_wide();
@@ -3594,7 +3622,8 @@ void mjh_launch_gen_tables_list(MjhHuffTable *tabs, int spi, const int *d_slots,
 void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq, void *q, MjhHuffTable *tabs, int spi, const int ac_slot[4], const float *lambda,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
-                           uint8_t *nq8, int v3_passes, int fastdiv, hipEvent_t after_first_tier, hipEvent_t after_first_tier2)
+                           uint8_t *nq8, int v3_passes, int fastdiv, hipEvent_t after_first_tier, hipEvent_t after_first_tier2,
+                           int chunks, hipStream_t side, hipEvent_t *ev_chunk)
 {
   // band-limited pass (use_scans_in_trellis), the per-block outputs of trellis_eob_opt, per-image tables (trellis_q_opt):
   // the EXT instantiations
@@ -3602,7 +3631,14 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   MjhTrellisExt ext;
   ext.Ss = Ss; ext.Se = Se; ext.eob_cost = (float2 *)eob_cost; ext.eob_has = eob_has; ext.nzmask = nzmask; ext.qstride = qstride;
   const int4 sl = make_int4(ac_slot[0], ac_slot[1], ac_slot[2], ac_slot[3]);
-  hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, worklist, worklist2);   // (a 16-byte hipMemsetAsync costs ~80 us of stream time)
+  const bool sorted = !extended && nzmask && nq8 && v3_passes > 0 && variant <= 4;
+  // Image ranges of the tile-sorted tier (see below): range c owns the work-list pair at word offset wo[c] (its own 16-byte
+  // header; room for every block of its images) and its share of the dense copies
+  const int nch = sorted && chunks > 1 && chunks <= 4 && side && ev_chunk && n >= 2 * chunks ? chunks : 1;
+  int n0[5], wo[4] = { 0, -1, -1, -1 };
+  for (int c = 0; c <= nch; c++) n0[c] = (int)((long long)c * n / nch);
+  for (int c = 0; c < nch; c++) wo[c] = 4 * c + 3 * n0[c] * C.total_real_blocks;
+  hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, worklist, worklist2, make_int4(wo[0], wo[1], wo[2], wo[3]));   // (a 16-byte hipMemsetAsync costs ~80 us of stream time)
   int w0[5] = { 0, 0, 0, 0, 0 };
   for (int i = 0; i < 4; i++) w0[i + 1] = w0[i] + (i < C.ncomp ? (C.c[i].nblk + 63) / 64 : 0);
   dim3 gridq(w0[C.ncomp], n);
@@ -3610,12 +3646,13 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   const int4 wv = make_int4(w0[0], w0[1], w0[2], w0[3]);
   // the general tiers behind a first tier: blocks with more than its capacity (then 32) queue records, from their dense copies
 #define LQ(QN, EXTV, CMP) hipLaunchKernelGGL((k_trellis_ac_q<QN, EXTV, CMP>), gridq, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, wv, lambda, worklist, (int16_t *)dense, dense_cap, ext)
-#define LD(QN, EXTV, CMP, GRID, WL, WLN) hipLaunchKernelGGL((k_trellis_ac_qd<QN, EXTV, CMP>), dim3(GRID), dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda, (const unsigned *)WL, WLN, (const int16_t *)dense, dense_cap, ext)
+#define LDX(QN, EXTV, CMP, GRID, WL, WLN, ST, DN, DCAP) hipLaunchKernelGGL((k_trellis_ac_qd<QN, EXTV, CMP>), dim3(GRID), dim3(64), 0, ST, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, lambda, (const unsigned *)WL, WLN, (const int16_t *)DN, DCAP, ext)
+#define LD(QN, EXTV, CMP, GRID, WL, WLN) LDX(QN, EXTV, CMP, GRID, WL, WLN, s, dense, dense_cap)
   if (extended) {   // the rarely used options take one fixed tiering (16 -> 32 -> 63)
     LQ(16, true, false);
     LD(32, true, false, 2048, worklist, worklist2);
     LD(63, true, false, 1024, worklist2, (unsigned *)nullptr);
-  } else if (nzmask && nq8 && v3_passes > 0 && variant <= 4) {
+  } else if (sorted) {
     // MJH_TRELLIS_VARIANT: queue capacity of the first tier: 0 = 16, 1 / 2 = 24, 3 = 32, 4 = 48 (all bit-identical).
     // The tile-sorted kernel: first tier of the plain compact pass; its work list (more records than its capacity, or a
     // magnitude >= 16) goes through the general tiers below.
@@ -3626,22 +3663,45 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
     const int np = small24 ? 1 : (!fastdiv || variant > 0) ? 4 : v3_passes >= 8 ? 8 : v3_passes >= 4 ? 4 : v3_passes >= 2 ? 2 : 1;
     int t0[5] = { 0, 0, 0, 0, 0 };
     for (int i = 0; i < 4; i++) t0[i + 1] = t0[i] + (i < C.ncomp ? (C.c[i].nblk + 64 * np - 1) / (64 * np) : 0);
-    dim3 gridt(t0[C.ncomp], n);
+    const int ntiles = t0[C.ncomp];
     for (int i = C.ncomp; i < 4; i++) t0[i] = 0x7FFFFFFF;
     const int4 tv = make_int4(t0[0], t0[1], t0[2], t0[3]);
-#define LV3(QN, NP, FDV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, NP, FDV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, worklist, (int16_t *)dense, dense_cap, nzmask)
-    if (small24) LV3(24, 1, true);
-    else if (variant >= 4) { if (fastdiv) LV3(48, 4, true); else LV3(48, 4, false); }      // q90 and up: 32 / 48 records (21 / 31 KB of LDS per wave)
-    else if (variant == 3) { if (fastdiv) LV3(32, 4, true); else LV3(32, 4, false); }
-    else if (variant > 0) { if (fastdiv) LV3(24, 4, true); else LV3(24, 4, false); }       // more records per block (higher qualities)
-    else if (!fastdiv) LV3(16, 4, false);
-    else switch (np) { case 8: LV3(16, 8, true); break; case 4: LV3(16, 4, true); break; case 2: LV3(16, 2, true); break; default: LV3(16, 1, true); break; }
-#undef LV3
-    if (after_first_tier) (void)hipEventRecord(after_first_tier, s);      // (what only waits for the big kernel starts here, next to the general tiers)
-    if (after_first_tier2) (void)hipEventRecord(after_first_tier2, s);    // (the other buffer set of an encoder with two batches in flight)
+    // IMAGE RANGES (round 6).  The general tiers are bound by latency (7 waves per CU at 32 records: 0.25 ms for 0.04 ms of
+    // instructions per 64 4K frames) and used to start when the whole first tier had finished.  With `chunks` > 1 the first tier
+    // runs as that many launches over consecutive image ranges, each with its own work list; the general tiers of range c go to
+    // the side stream and run next to the first tier of range c + 1 (disjoint blocks, disjoint lists); only the last range's
+    // general tiers stay behind the first tier on `s`, which then joins the side stream (ev_chunk[chunks - 1]).
+    const unsigned capc = dense_cap / (unsigned)nch;
     const int qd_grid = 2048;     // (1024 ... 8192 workgroups: no difference beyond noise, gpurun_out/r5j)
-    if (variant >= 3) LD(63, false, true, qd_grid, worklist, (unsigned *)nullptr);   // what is left has more than 32 records or a magnitude >= 16: one general tier that takes everything
-    else { LD(32, false, true, qd_grid, worklist, worklist2); LD(63, false, true, 1024, worklist2, (unsigned *)nullptr); }
+    for (int c = 0; c < nch; c++) {
+      const dim3 gridt(ntiles, n0[c + 1] - n0[c]);
+      unsigned *wl = worklist + wo[c], *wl2 = worklist2 + wo[c];
+      int16_t *dn = (int16_t *)dense + (size_t)c * capc * 64;
+      const int img0 = n0[c];
+#define LV3(QN, NP, FDV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, NP, FDV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, wl, dn, capc, nzmask, img0, worklist)
+      if (small24) LV3(24, 1, true);
+      else if (variant >= 4) { if (fastdiv) LV3(48, 4, true); else LV3(48, 4, false); }      // q90 and up: 32 / 48 records (21 / 31 KB of LDS per wave)
+      else if (variant == 3) { if (fastdiv) LV3(32, 4, true); else LV3(32, 4, false); }
+      else if (variant > 0) { if (fastdiv) LV3(24, 4, true); else LV3(24, 4, false); }       // more records per block (higher qualities)
+      else if (!fastdiv) LV3(16, 4, false);
+      else switch (np) { case 8: LV3(16, 8, true); break; case 4: LV3(16, 4, true); break; case 2: LV3(16, 2, true); break; default: LV3(16, 1, true); break; }
+#undef LV3
+      const bool last = c == nch - 1;
+      hipStream_t st = last ? s : side;
+      if (last) {
+        if (after_first_tier) (void)hipEventRecord(after_first_tier, s);      // (what only waits for the big kernel starts here, next to the general tiers)
+        if (after_first_tier2) (void)hipEventRecord(after_first_tier2, s);    // (the other buffer set of an encoder with two batches in flight)
+      } else {
+        (void)hipEventRecord(ev_chunk[c], s);
+        (void)hipStreamWaitEvent(side, ev_chunk[c], 0);
+      }
+      if (variant >= 3) LDX(63, false, true, qd_grid, wl, (unsigned *)nullptr, st, dn, capc);   // what is left has more than 32 records or a magnitude >= 16: one general tier that takes everything
+      else { LDX(32, false, true, qd_grid, wl, wl2, st, dn, capc); LDX(63, false, true, 1024, wl2, (unsigned *)nullptr, st, dn, capc); }
+    }
+    if (nch > 1) {
+      (void)hipEventRecord(ev_chunk[nch - 1], side);
+      (void)hipStreamWaitEvent(s, ev_chunk[nch - 1], 0);
+    }
   } else if (nzmask) {   // compact records out of the general first tier (the caller guarantees: plain pass)
     if (variant > 3) variant = 3;   // (the general first tier stops at 32 records)
     switch (variant) { case 1: LQ(20, false, true); break; case 2: LQ(24, false, true); break; case 3: LQ(32, false, true); break; default: LQ(16, false, true); break; }
@@ -3655,6 +3715,7 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   }
 #undef LQ
 #undef LD
+#undef LDX
 }
 
 // exclusive prefix sum of 16-bit lengths, `npairs` independent arrays of n_per entries (the progressive path's

@@ -104,6 +104,32 @@ def test_emulated_batch_of_1080p_frames_matches_the_oracle(simt):
         assert got[i] == O.encode(po, frames[i]), i
 
 
+@pytest.mark.parametrize("chunks", ["2", "4"])
+def test_emulated_image_ranges_of_the_ac_trellis_match_the_oracle(simt, chunks):
+    """MJH_TRELLIS_CHUNKS: the tile-sorted AC trellis over image ranges with a work list each (the large-batch schedule forced
+    onto small frames with MJH_SMALL_BATCH; late DC chains included); a tiny dense-copy budget sends part of every range's
+    deferred blocks through the planes"""
+    w, h = 227, 149
+    frames = np.stack([O.synthetic_frame(w, h, 900 + i) for i in range(9)])
+    po = O.make_params(w, h, baseline=True, quality=92)
+    want = [O.encode(po, frames[i]) for i in range(9)]
+    for dense in (None, "13"):
+        try:
+            os.environ["MJH_TRELLIS_CHUNKS"] = chunks
+            os.environ["MJH_SMALL_BATCH"] = "1"
+            os.environ["MJH_TRELLIS_VARIANT"] = "0"       # 16 records at q92: many deferred blocks, both general tiers
+            if dense:
+                os.environ["MJH_DENSE_CAP"] = dense
+            enc = M.Encoder(M.make_params(w, h, baseline=True, quality=92), max_batch=9)
+            got = enc.encode_host(frames)
+            enc.close()
+        finally:
+            for k in ("MJH_TRELLIS_CHUNKS", "MJH_SMALL_BATCH", "MJH_TRELLIS_VARIANT", "MJH_DENSE_CAP"):
+                os.environ.pop(k, None)
+        for i in range(9):
+            assert got[i] == want[i], (chunks, dense, i)
+
+
 def test_the_emulator_itself(tmp_path):
     """tools/simt/selftest.cpp: cross-lane operations against their documented results (shuffles, ballots under divergence with
     and without MJH_DIVERGENT_SCOPE, DPP row shifts / broadcasts with bound_ctrl, independent rows of 16, __syncthreads_or,

@@ -23,6 +23,7 @@ if __name__ == "__main__":
     ap.add_argument("--env", default="MJH_TRELLIS_VARIANT")
     ap.add_argument("--config", default="metric")
     ap.add_argument("--prof", type=int, default=0, help="profiling level inside the timed loop (0 off, 2 = the dominant interval bracketed)")
+    ap.add_argument("--focus", default="trellis_ac", help="with --prof 2: the interval bracketed in every step of the timed loop")
     a = ap.parse_args()
     cfg = bench.CONFIGS[a.config]
     w, h, kw = cfg["w"], cfg["h"], cfg["kw"]
@@ -36,18 +37,27 @@ if __name__ == "__main__":
         files = [enc.get_jpeg(i) for i in range(a.batch)]
         if base is None:
             base = files
-        enc.set_profiling(a.prof)
+        if a.prof == 2:
+            enc.set_profiling(2, focus=a.focus)
+        else:
+            enc.set_profiling(a.prof)
+        for _ in range(4):
+            enc.encode_tensor(d, stream="own")
+        enc.sync()
+        if a.prof == 2:
+            enc.set_profiling(2, focus=a.focus)      # (start the averages over: the first bracketed step creates the events)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             enc.encode_tensor(d, stream="own")
         enc.sync()
         dt = (time.perf_counter() - t0) / a.steps
+        live = dict(enc.kernel_times()).get(a.focus) if a.prof == 2 else None
         enc.set_profiling(1)
         for _ in range(3):
             enc.encode_tensor(d, stream="own")
         kt = dict(enc.kernel_times())
         print(json.dumps({"variant": "%s=%s" % (a.env, v), "ms_per_batch": round(dt * 1e3, 3), "mpix_per_s": round(w * h * a.batch / dt / 1e6, 1),
-                          "identical_to_first": files == base,
+                          "identical_to_first": files == base, "focus_ms_live": None if live is None else round(live, 4),
                           "kernel_ms": {k: round(x, 3) for k, x in sorted(kt.items(), key=lambda kv: -kv[1])[:8]}}), flush=True)
         enc.close()

@@ -73,6 +73,7 @@ inline DivergentScope::~DivergentScope() { cur->depth--; }
 #define MJH_WAVE_GROUPS(n) (simt::cur->width = (n))
 // lock-step order inside a wave that the device gets for free (all lanes read an LDS word, then one lane overwrites it)
 #define MJH_WAVE_SYNC() ((void)simt::exchange(0, "wave_sync", __FILE__, __LINE__))
+#define MJH_SCHED_BARRIER() ((void)0)
 #define threadIdx (simt::cur->tid)
 #define blockIdx (simt::cur->bid)
 #define blockDim (simt::cur->bdim)
