@@ -316,6 +316,7 @@ struct mjh_encoder {
   unsigned *d_worklist = nullptr, *d_worklist2 = nullptr;   // deferred trellis blocks: [0] = count, [4+3i..6+3i] = (image, comp<<28|block, dense slot)
   int trellis_variant = 0;           // first-tier queue capacity of the AC trellis: 0 = 16, 1 = 20, 2 = 24, 3 = 32, 4 = 48 (all bit-identical)
   bool trellis_adapt = true;         // no MJH_TRELLIS_VARIANT given: follow the share of deferred blocks of the previous batches
+  int defer_scale = 1;               // the counts of that pass come from one tile in defer_scale
   unsigned *h_defer = nullptr;       // pinned: work-list counters of an earlier trellis pass (count_heavy), read back asynchronously
   hipEvent_t ev_defer = nullptr; bool defer_pending = false; int defer_frames = 0;   // ... valid once ev_defer has completed; the frames they were counted over
   int spi = SLOTS_BASE;             // table slots per image (16 + 2 per progressive scan)
@@ -1593,7 +1594,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     if (qs == hipErrorNotReady) { (void)hipGetLastError(); return MJH_OK; }
     HIPCHK(qs);
     e->defer_pending = false;
-    const double blocks = (double)e->defer_frames * (double)C.total_real_blocks + 1.0;
+    const double blocks = ((double)e->defer_frames * (double)C.total_real_blocks + 1.0) / (double)e->defer_scale;
     const double s16 = e->h_defer[1] / blocks, s24 = e->h_defer[2] / blocks, s32 = e->h_defer[3] / blocks;
     const int cur = e->trellis_variant == 1 ? 2 : e->trellis_variant;
     auto level_for = [&](double slack) { return s16 < 0.06 * slack ? 0 : s24 < 0.06 * slack ? 2 : s32 < 0.10 * slack ? 3 : 4; };
@@ -1786,13 +1787,15 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     const int trellis_ranges = !v3 || e->debug_taps || (size_t)n * C.total_real_blocks < e->small_batch ? 1
                                : e->trellis_chunks > 0 ? e->trellis_chunks
                                : !e->progressive && (size_t)n * C.total_real_blocks >= (size_t)6000000 ? 2 : 1;
+    // the record counts the first tier's capacity is chosen by: from one tile in eight of a large batch (scaled back below)
+    const int count_mask = v3 && (size_t)n * C.total_real_blocks >= (size_t)2000000 ? 7 : 0;
     pr.mark("trellis_ac");
     mjh_launch_trellis_ac(CV, e->d_quant, e->d_uq, e->d_q, e->d_tabs, spi, sl_ac, e->d_lambda, e->d_worklist, e->d_worklist2, e->d_dense, e->dense_cap,
                           e->trellis_variant,
                           Ss, Se, ext_eob ? e->d_eob_cost : nullptr, ext_eob ? e->d_eob_has : nullptr, nzm, qstride, n, s,
                           e->d_nq8, v3 ? ((size_t)n * C.total_real_blocks < e->small_batch ? 1 : e->trellis_v3) : 0,   // (a small batch: one pass per tile -- four times the workgroups, a quarter of their length: latency matters more than the sorting)
                           e->fastdiv_all, dc_late ? e->ev_side0 : nullptr, excl ? e->ev_tier1 : nullptr,
-                          trellis_ranges, e->side_stream, e->ev_chunk);
+                          trellis_ranges, e->side_stream, e->ev_chunk, count_mask);
     if (excl) e->ev_tier1_set = true;
     if (dc_late) {
       if (!v3) return fail(MJH_EINVAL, "internal: the late DC chains need the tile-sorted trellis' event");
@@ -1806,6 +1809,7 @@ static int run_pipeline(mjh_encoder *e, const void *d_pixels, size_t row_pitch, 
     if (e->trellis_adapt && !extended && first_pass && !e->defer_pending) {   // (one read-back in flight at a time; its frame count travels with it)
       if (!e->ev_defer) HIPCHK(hipEventCreateWithFlags(&e->ev_defer, hipEventDisableTiming));
       e->defer_frames = n;
+      e->defer_scale = count_mask + 1;
       HIPCHK(hipMemcpyAsync(&e->h_defer[0], e->d_worklist, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
       HIPCHK(hipEventRecord(e->ev_defer, s));
       e->defer_pending = true;

@@ -620,7 +620,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
     // from the host libm.  Both trellis kernels consume it.
     float norm = 0.0f;
 #pragma unroll
-    for (int n = 1; n < 64; n++) { const int rc = IFAST ? du[IFAST ? n : 0] : d[n]; norm = norm + (float)mul24(rc, rc); }   // |raw coefficient| <= 2^15
+    for (int n = 1; n < 64; n++) { const int rc = IFAST ? du[IFAST ? n : 0] : d[n]; norm = norm + squaref(rc); }   // |raw coefficient| <= 2^15: (float)rc * (float)rc == (float)(rc * rc)
     norm = (float)((double)norm / 63.0);
     float lambda;
     if (C.lambda_log_scale2 > 0.0f) lambda = (float)(C.pow_scale1 * 1.0 / (C.pow_scale2 + (double)norm));
@@ -638,26 +638,29 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
   constexpr int QCH = 8;
   int dq_c[QCH], sdiv_c[QCH];
   unsigned mdiv_c[QCH];
-  float rcp_c[QCH];
+  float rcp_c[QCH], thr_c[QCH];
 #pragma unroll
   for (int k = 0; k < 64; k++) {
     if ((k % QCH) == 0) {
 #pragma unroll
       for (int j = 0; j < QCH; j++) {
         // (FD: every step <= 255, nothing wraps; otherwise the conventional quantizer's own divisor -- MjhQuant.dqc8)
-        if (FD) { dq_c[j] = Q->dq8[cc.qtbl][k + j]; sdiv_c[j] = Q->sdiv[cc.qtbl][k + j]; mdiv_c[j] = Q->mdiv[cc.qtbl][k + j]; }
+        if (FD) { dq_c[j] = Q->dq8[cc.qtbl][k + j]; sdiv_c[j] = Q->sdiv[cc.qtbl][k + j]; mdiv_c[j] = Q->mdiv[cc.qtbl][k + j]; if (STATS) thr_c[j] = Q->thr8[cc.qtbl][k + j]; }
         else { dq_c[j] = Q->dqc8[cc.qtbl][k + j]; rcp_c[j] = Q->rcpc8q[cc.qtbl][k + j]; }
       }
     }
     const int x = d[kZZ.v[k]];
     const int dq = dq_c[k % QCH];
-    const int ax = x < 0 ? -x : x;
     if (FD && STATS && k > 0) {
       // statistics of the conventionally quantized block only (the trellis recomputes the values): magnitude category of
-      // min(floor((|x| + 4q) / 8q), 1023) -- the signed clamp to +-1023 (jcdctmgr.c:761-770) leaves the category of 1023
+      // min(floor((|x| + 4q) / 8q), 1023) -- the signed clamp to +-1023 (jcdctmgr.c:761-770) leaves the category of 1023.
+      // "Quantizes to non-zero" (|x| + 4q >= 8q) is one conversion + one compare of |(float)x| with MjhQuant.thr8 (exact: both
+      // are integers below 2^24); |x| as an integer only where the division happens
       uq[(size_t)k * cc.kstride] = (int16_t)x;
       if (valid) {
-        if (ax + (dq >> 1) >= dq) {
+        const float xf = (float)x;
+        if (__builtin_fabsf(xf) >= thr_c[k % QCH]) {
+          const int ax = (int)__builtin_fabsf(xf);
           int qa = udiv_mh(ax + (dq >> 1), sdiv_c[k % QCH], mdiv_c[k % QCH]);
           if (clampq) qa = min(qa, 1023);
           nzc++;
@@ -668,6 +671,7 @@ __device__ __forceinline__ void dct_quant_body(const MjhConst &C, const MjhQuant
       }
       continue;
     }
+    const int ax = x < 0 ? -x : x;
     int v = FD ? udiv_mh(ax + (dq >> 1), sdiv_c[k % QCH], mdiv_c[k % QCH]) : udiv_exact(ax + (dq >> 1), dq, rcp_c[k % QCH]);
     if (x < 0) v = -v;
     if (clampq) v = W12 ? max(-16383, min(16383, v)) : max(-1023, min(1023, v));
@@ -2112,17 +2116,13 @@ __global__ void __launch_bounds__(64)
 k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restrict__ coef_uq, int16_t *__restrict__ coef_q,
                 const MjhHuffTable *__restrict__ tabs, int slots_per_image, int4 ac_slot_of_comp, int4 tile0_of_comp,
                 const float *__restrict__ lambda_in, uint8_t *__restrict__ nq8, unsigned *__restrict__ worklist,
-                int16_t *__restrict__ dense, unsigned dense_cap, unsigned long long *__restrict__ nzmask, int img0, unsigned *__restrict__ counts)
+                int16_t *__restrict__ dense, unsigned dense_cap, unsigned long long *__restrict__ nzmask, int img0, unsigned *__restrict__ counts, int count_mask)
 {
   static_assert(QN >= 16 && QN <= 63 && NPASS >= 1 && NPASS <= 8, "queue capacity / passes");
   constexpr int TILE = 64 * NPASS;
   __shared__ uint2 col[QN + 1][64];      // tile sort scratch; per pass: queue records (record r in slot r) -> live entries {azd, acc} (entry e in slot e; 0 = the virtual start) -> value column
   __shared__ unsigned short info[QN + 1][64];   // live entry e at [e]: position | back entry << 6 | magnitude (< 16) << 12 (the signs: one bit per position in a register)
   __shared__ float4 rate_rows[16];
-#ifdef MJH_V3_PAD   // occupancy experiments (tools/build_variant.sh): LDS nobody uses
-  __shared__ unsigned v3_pad[MJH_V3_PAD / 4];
-  if (lambda_in == nullptr) v3_pad[threadIdx.x] = 1u;
-#endif
   typedef unsigned __attribute__((may_alias)) u_alias;
   typedef unsigned short __attribute__((may_alias)) us_alias;
   const int img = blockIdx.y + img0, tl = blockIdx.x, lane = threadIdx.x;      // (img0: first image of this launch's range of the batch)
@@ -2238,7 +2238,10 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
       }
       azd63 = azd;
       defer_blocks(inside && (nq > QN || qmax >= 16), worklist, (unsigned)img, ((unsigned)comp << 28) | (unsigned)blk, 0u, xs, dense, dense_cap, true, lane);
-      count_heavy(counts, inside, nq, lane);      // (the whole batch's counts: the first range's header)
+      // (the whole batch's counts: the first range's header.  A large batch counts in every (count_mask + 1)-th tile only -- the host
+      // scales: three more atomics per pass on the line of the work-list counter, which one word's ~88 operations per microsecond make
+      // ~1.3 % of the kernel, profiles/r06g_occupancy.md)
+      if ((tl & count_mask) == 0) count_heavy(counts, inside, nq, lane);
     }
     const bool work = inside && nq <= QN && qmax < 16;
 
@@ -3623,7 +3626,7 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
                            uint8_t *nq8, int v3_passes, int fastdiv, hipEvent_t after_first_tier, hipEvent_t after_first_tier2,
-                           int chunks, hipStream_t side, hipEvent_t *ev_chunk)
+                           int chunks, hipStream_t side, hipEvent_t *ev_chunk, int count_mask)
 {
   // band-limited pass (use_scans_in_trellis), the per-block outputs of trellis_eob_opt, per-image tables (trellis_q_opt):
   // the EXT instantiations
@@ -3678,7 +3681,7 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
       unsigned *wl = worklist + wo[c], *wl2 = worklist2 + wo[c];
       int16_t *dn = (int16_t *)dense + (size_t)c * capc * 64;
       const int img0 = n0[c];
-#define LV3(QN, NP, FDV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, NP, FDV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, wl, dn, capc, nzmask, img0, worklist)
+#define LV3(QN, NP, FDV) hipLaunchKernelGGL((k_trellis_ac_v3<QN, NP, FDV>), gridt, dim3(64), 0, s, C, Q, (const int16_t *)uq, (int16_t *)q, (const MjhHuffTable *)tabs, spi, sl, tv, lambda, nq8, wl, dn, capc, nzmask, img0, worklist, count_mask)
       if (small24) LV3(24, 1, true);
       else if (variant >= 4) { if (fastdiv) LV3(48, 4, true); else LV3(48, 4, false); }      // q90 and up: 32 / 48 records (21 / 31 KB of LDS per wave)
       else if (variant == 3) { if (fastdiv) LV3(32, 4, true); else LV3(32, 4, false); }

@@ -18,7 +18,7 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
                            unsigned *worklist, unsigned *worklist2, void *dense, unsigned dense_cap, int variant,
                            int Ss, int Se, void *eob_cost, int *eob_has, unsigned long long *nzmask, int qstride, int n, hipStream_t s,
                            uint8_t *nq8 = nullptr, int v3_passes = 0, int fastdiv = 0, hipEvent_t after_first_tier = nullptr, hipEvent_t after_first_tier2 = nullptr,
-                           int chunks = 1, hipStream_t side = nullptr, hipEvent_t *ev_chunk = nullptr);   // chunks > 1: the tile-sorted tier over that many image ranges, the general tiers of all but the last on `side` (ev_chunk[chunks] events)   // after_first_tier: recorded behind the tile-sorted kernel, in front of the general tiers   // v3_passes > 0 (plain compact pass): the tile-sorted kernel with that many passes per tile
+                           int chunks = 1, hipStream_t side = nullptr, hipEvent_t *ev_chunk = nullptr, int count_mask = 0);   // count_mask: the heavy-block counts come from the tiles with (tile & count_mask) == 0   // chunks > 1: the tile-sorted tier over that many image ranges, the general tiers of all but the last on `side` (ev_chunk[chunks] events)   // after_first_tier: recorded behind the tile-sorted kernel, in front of the general tiers   // v3_passes > 0 (plain compact pass): the tile-sorted kernel with that many passes per tile
 // trellis_eob_opt: the block-row pass behind a (band-limited) AC trellis; eob_cost / eob_has as written by mjh_launch_trellis_ac
 void mjh_launch_trellis_eob_chain(const MjhConst &C, void *q, const MjhHuffTable *tabs, int spi, const int ac_slot[4], const void *eob_cost, const int *eob_has,
                                   int Ss, int Se, int n, hipStream_t s);
