@@ -17,6 +17,10 @@ SOURCES = ["mjh_kernels.hip", "mjh_prog.hip", "mjh_arith.hip", "mjh_encoder.cpp"
 # -ffp-contract=off: the trellis / deringing float recipes must not be fused into FMAs
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
+# per source: the SLP vectoriser pairs the trellis' and the colour kernel's float adds into v_pk_add_f32 and pays for it with
+# v_mov shuffles (packed f32 issues at half rate on gfx950, profiles/r04a_valu_rate_summary.md): without it the metric's step with
+# two batches in flight is 3.90 instead of 4.00 ms (profiles/r06p_noslp.md); the float recipes are untouched (no reassociation either way)
+EXTRA_FLAGS = {"mjh_kernels.hip": ["-fno-slp-vectorize"]}
 
 
 def _newer(target, deps):
@@ -33,13 +37,13 @@ def build(force=False, verbose=False):
         [os.path.join(HERE, "..", "include", "mozjpeg_hip.h")]
     # one object per source, rebuilt when its source or any shared header / .inc is newer; the translation units compile
     # side by side (the five kernel files take ~40-60 s each)
-    hdrs = [d for d in deps if d not in srcs]
+    hdrs = [d for d in deps if d not in srcs] + [os.path.abspath(__file__)]      # (the flags live in this file)
     objs, jobs = [], []
     for s in srcs:
         o = os.path.join(CSRC, os.path.splitext(os.path.basename(s))[0] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-x", "hip", "-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-x", "hip", "-c", s, "-o", o])
     if jobs:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:

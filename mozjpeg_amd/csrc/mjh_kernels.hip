@@ -3640,6 +3640,15 @@ void mjh_launch_trellis_ac(const MjhConst &C, const MjhQuant *Q, const void *uq,
   const int nch = sorted && chunks > 1 && chunks <= 4 && side && ev_chunk && n >= 2 * chunks ? chunks : 1;
   int n0[5], wo[4] = { 0, -1, -1, -1 };
   for (int c = 0; c <= nch; c++) n0[c] = (int)((long long)c * n / nch);
+  // two ranges: the first one larger -- its general tiers hide under the second range's first tier either way, and the second
+  // range's, which nothing hides, shrink with it (MJH_TRELLIS_FRONT: per mille of the images in the first range)
+  if (nch == 2) {
+    const char *fv = getenv("MJH_TRELLIS_FRONT");
+    const int front = fv ? atoi(fv) : 625;      // (metric: interval 1.59 -> 1.55 ms against an even split, step -0.8 %; 750 the same, profiles/r06f_chunks.md)
+    n0[1] = (int)((long long)n * front / 1000);
+    if (n0[1] < 1) n0[1] = 1;
+    if (n0[1] > n - 1) n0[1] = n - 1;
+  }
   for (int c = 0; c < nch; c++) wo[c] = 4 * c + 3 * n0[c] * C.total_real_blocks;
   hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, worklist, worklist2, make_int4(wo[0], wo[1], wo[2], wo[3]));   // (a 16-byte hipMemsetAsync costs ~80 us of stream time)
   int w0[5] = { 0, 0, 0, 0, 0 };

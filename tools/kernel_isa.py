@@ -106,12 +106,18 @@ def fingerprints(tree, jobs=3):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     tmp = tempfile.mkdtemp(prefix="kisa_")
     procs = []
+    extra = {}
+    try:        # the per-source flags of THAT tree's build (mozjpeg_amd/build.py: EXTRA_FLAGS), so that the fingerprints are the shipped code's
+        import runpy
+        extra = runpy.run_path(os.path.join(tree, "mozjpeg_amd", "build.py"), run_name="kernel_isa_probe").get("EXTRA_FLAGS", {})
+    except Exception:
+        extra = {}
     for u in UNITS:
         src = os.path.join(tree, "mozjpeg_amd", "csrc", u)
         if not os.path.exists(src):
             continue
         o = os.path.join(tmp, u + ".s")
-        procs.append((u, o, subprocess.Popen([hipcc] + FLAGS + ["-I" + os.path.join(tree, "include"), src, "-o", o])))
+        procs.append((u, o, subprocess.Popen([hipcc] + FLAGS + list(extra.get(u, [])) + ["-I" + os.path.join(tree, "include"), src, "-o", o])))
     res = {}
     for u, o, p in procs:
         if p.wait() != 0:
@@ -143,6 +149,9 @@ def source_stamp(tree=ROOT):
         if name.endswith((".hip", ".h", ".inc")):
             hsh.update(name.encode())
             hsh.update(open(os.path.join(src, name), "rb").read())
+    bp = os.path.join(tree, "mozjpeg_amd", "build.py")       # (the compile flags live there)
+    if os.path.exists(bp):
+        hsh.update(open(bp, "rb").read())
     return hsh.hexdigest()[:16]
 
 
