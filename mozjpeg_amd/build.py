@@ -13,14 +13,17 @@ LIB = os.path.join(HERE, "libmozjpeg_hip.so")
 SHIM = os.path.join(HERE, "libmozjpeg_hip_jpeg62.so")
 STANDALONE = os.path.join(HERE, "standalone", "libjpeg.so.62")
 TJSHIM = os.path.join(HERE, "libmozjpeg_hip_turbojpeg.so")
-SOURCES = ["mjh_kernels.hip", "mjh_prog.hip", "mjh_arith.hip", "mjh_encoder.cpp", "mjh_pool.cpp", "mjh_guard.cpp", "mjh_numa.cpp"]
+SOURCES = ["mjh_kernels.hip", "mjh_trellis.hip", "mjh_prog.hip", "mjh_arith.hip", "mjh_encoder.cpp", "mjh_pool.cpp", "mjh_guard.cpp", "mjh_numa.cpp"]
 # -ffp-contract=off: the trellis / deringing float recipes must not be fused into FMAs
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
 # per source: the SLP vectoriser pairs the trellis' and the colour kernel's float adds into v_pk_add_f32 and pays for it with
 # v_mov shuffles (packed f32 issues at half rate on gfx950, profiles/r04a_valu_rate_summary.md): without it the metric's step with
 # two batches in flight is 3.90 instead of 4.00 ms (profiles/r06p_noslp.md); the float recipes are untouched (no reassociation either way)
-EXTRA_FLAGS = {"mjh_kernels.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"mjh_kernels.hip": ["-fno-slp-vectorize"],
+               # the AC trellis' walks (dependent LDS look-ups + float adds): the max-ILP scheduling strategy; it costs the bit writers
+               # and the FDCT kernel more than it buys them, hence a translation unit of its own (profiles/r06q_sched.md)
+               "mjh_trellis.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _newer(target, deps):

@@ -30,7 +30,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-UNITS = ["mjh_kernels.hip", "mjh_prog.hip", "mjh_arith.hip"]
+UNITS = ["mjh_kernels.hip", "mjh_trellis.hip", "mjh_prog.hip", "mjh_arith.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-fast-math", "-w",
          "--cuda-device-only", "-S", "-x", "hip"]
 OUT = os.path.join(ROOT, "mozjpeg_amd", "kernel_isa.json")

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "mozjpeg_amd", "csrc")
 OUT = os.environ.get("SIMT_BUILD_DIR") or os.path.join(HERE, "_build")     # (a second directory lets a build go on while tests run from the first)
 LIB = os.path.join(OUT, "libmozjpeg_hip_simt.so")
-SOURCES = ["mjh_kernels.hip", "mjh_prog.hip", "mjh_arith.hip", "mjh_encoder.cpp", "mjh_pool.cpp", "mjh_guard.cpp", "mjh_numa.cpp"]
+SOURCES = ["mjh_kernels.hip", "mjh_trellis.hip", "mjh_prog.hip", "mjh_arith.hip", "mjh_encoder.cpp", "mjh_pool.cpp", "mjh_guard.cpp", "mjh_numa.cpp"]
 # the same floating-point contract as the device build (mozjpeg_amd/build.py): no FMA contraction
 FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-g1", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-fno-strict-aliasing",
          "-I" + os.path.join(HERE, "include"), "-I" + CSRC]
