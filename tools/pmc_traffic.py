@@ -36,11 +36,20 @@ def main():
     if color:
         factor = (in_bytes * frames) / (fetch[color[0]][0] * 1024.0)
     kernels = {}
+    # a kernel may run more than once per encode call (round 6: the AC trellis over two image ranges): bytes are per CALL = the
+    # average launch x the launches per call, counted against the colour kernel's one launch per call
+    calls_f = fetch[color[0]][1] if color else 0
+    calls_w = write[color[0]][1] if color and color[0] in write else 0
     for k in sorted(set(fetch) | set(write)):
-        f = fetch.get(k, (0.0, 0))[0] * 1024.0 * factor
-        w = write.get(k, (0.0, 0))[0] * 1024.0
+        lf = fetch.get(k, (0.0, 0))[1] / calls_f if calls_f else 1.0
+        lw = write.get(k, (0.0, 0))[1] / calls_w if calls_w else 1.0
+        if 0.9 < lf < 1.1: lf = 1.0
+        if 0.9 < lw < 1.1: lw = 1.0
+        f = fetch.get(k, (0.0, 0))[0] * 1024.0 * factor * max(lf, 1.0)
+        w = write.get(k, (0.0, 0))[0] * 1024.0 * max(lw, 1.0)
         kernels[k] = {"fetch_bytes_corrected": int(f), "write_bytes": int(w), "hbm_bytes": int(f + w),
-                      "hbm_bytes_per_frame": int((f + w) / frames), "launches_sampled": fetch.get(k, (0, 0))[1]}
+                      "hbm_bytes_per_frame": int((f + w) / frames), "launches_sampled": fetch.get(k, (0, 0))[1],
+                      "launches_per_call": round(max(lf, 1.0), 2)}
     kernels = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes"]))
     # which tree the passes belong to: bench.py quotes a summary only while the kernel sources still hash to this stamp
     sys.path.insert(0, ROOT)
@@ -56,8 +65,8 @@ def main():
     print(json.dumps({
         "profile_head": head, "kernel_source_stamp": bench.kernel_source_stamp(),
         "kernel_isa": {k: now[k] for k in kernels if k in now},
-        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate --kernel-trace passes; bytes per launch "
-                "(%d frames); fetch scaled by the factor calibrated on k_color's known input bytes" % frames,
+        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate --kernel-trace passes; bytes per encode call "
+                "(%d frames; a kernel launched more than once per call: all its launches); fetch scaled by the factor calibrated on k_color's known input bytes" % frames,
         "frames_per_launch": frames, "fetch_calibration_factor": round(factor, 4), "kernels": kernels}, indent=1))
 
 
