@@ -138,7 +138,8 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 grayin=False, quant_table=-1, lambda1=None, lambda2=None, restart=None,
                 progressive=False, fastcrush=False, precision=8, trellis_loops=1, smooth=0, rgb=False,
                 dc_scan_opt=None, dc_ver_weight=None, use_scans_in_trellis=False, trellis_freq_split=0,
-                trellis_eob_opt=False, trellis_q_opt=False, arithmetic=False, arith_cond=None, scans=None, gray_sample=None, yccin=False, dct=None):
+                trellis_eob_opt=False, trellis_q_opt=False, arithmetic=False, arith_cond=None, scans=None, gray_sample=None, yccin=False, dct=None,
+                dc_tbl=None, ac_tbl=None):
     """Parameters with cjpeg's switch vocabulary (cjpeg.c:371-714).  Without `baseline` or
     `revert` this is cjpeg's default: progressive with scan search (`fastcrush`: fixed 9-scan script)."""
     p = Params()
@@ -153,6 +154,23 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
     if gray_sample is not None and p.num_components == 1:   # (h, v) of a gray image's one component: cjpeg sets 2x1 for qualities 80..89 (rdswitch.c:566-570)
         p.h_samp_factor[0], p.v_samp_factor[0] = gray_sample
     _chk(L.mjh_params_set_quality(C.byref(p), quality, 1 if baseline else 0, quant_table))
+    for i in range(p.num_components):      # table numbers of the application's own (cinfo->comp_info[i].dc_tbl_no / ac_tbl_no)
+        if dc_tbl is not None:
+            p.dc_tbl_no[i] = dc_tbl[i]
+        if ac_tbl is not None:
+            p.ac_tbl_no[i] = ac_tbl[i]
+        # slots 2 / 3 are empty until the application defines them (the reference aborts on an empty slot): like oracle/refenc.c,
+        # a copy of the standard table of the same parity
+        for is_ac, t in ((0, p.dc_tbl_no[i]), (1, p.ac_tbl_no[i])):
+            if t > 1 and (dc_tbl is not None or ac_tbl is not None):
+                bits, vals, nv = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint8)(), C.c_int()
+                _chk(L.mjh_std_huffman_table(is_ac, t & 1, C.byref(bits), C.byref(vals), C.byref(nv)))
+                k = 2 * t + is_ac
+                for j in range(17):
+                    p.huff_bits[k][j] = bits[j]
+                for j in range(nv.value):
+                    p.huff_vals[k][j] = vals[j]
+                p.huff_tables_given |= 1 << k
     if optimize:
         p.optimize_coding = 1
     if notrellis:

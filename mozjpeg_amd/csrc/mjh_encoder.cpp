@@ -419,6 +419,21 @@ static int arith_qopt_updates(const mjh_params *p) { return arith_qopt_passes(p)
 // refused here rather than answered with a file of either kind.  comps: the components of one whole-block scan, in scan order.
 // dseen / aseen: the tables seen in this scan or sent by an earlier one (optimal tables are made anew for every scan, the Annex K
 // tables are sent once: jchuff.c finish_pass_gather / emit_dht's sent_table).
+// Class of component c's DC table inside a progressive image: the progressive kernels keep two DC tables per scan, so the image's
+// distinct DC table numbers are numbered in order of first use (0, 1; 2 and up: refused by check_supported).  Until round 6 the class
+// was the low bit of the number, which refused 0 with 2 and 1 with 3.
+static int dc_class(const mjh_params *p, int c)
+{
+  int seen[4], n = 0;
+  for (int i = 0; i <= c; i++) {
+    int k = 0;
+    while (k < n && seen[k] != p->dc_tbl_no[i]) k++;
+    if (k == n) seen[n++] = p->dc_tbl_no[i];
+    if (i == c) return k;
+  }
+  return 0;
+}
+
 static bool dht_writer_would_corrupt(const mjh_params *p, const int *comps, int k, bool dseen[4], bool aseen[4])
 {
   for (int j = 0; j < k; j++) {
@@ -489,12 +504,11 @@ static int check_supported(const mjh_params *p)
     // progressive mode: the checks of validate_script (jcmaster.c:269-432) that matter here
     if (!p->optimize_coding && !p->arith_code) return fail(MJH_EUNSUPPORTED, "progressive mode forces optimize_coding (jcmaster.c:1091-1094)");
 
-    // the progressive kernels keep two DC table classes per scan, told apart by the low bit of the table number: any AC table
-    // numbers, and DC table numbers as long as two different ones of the image do not share that bit (0 with 2, 1 with 3)
-    for (int i = 0; i < p->num_components; i++)
-      for (int j = 0; j < i; j++)
-        if (p->dc_tbl_no[i] != p->dc_tbl_no[j] && ((p->dc_tbl_no[i] ^ p->dc_tbl_no[j]) & 1) == 0 && !p->arith_code)
-          return fail(MJH_EUNSUPPORTED, "progressive mode: DC table numbers %d and %d in one image (the kernels tell two DC tables per scan apart by the low bit of the number)", p->dc_tbl_no[j], p->dc_tbl_no[i]);
+    // the progressive kernels keep two DC tables per scan (dc_class): any AC table numbers, and any two DC table numbers per image
+    if (!p->arith_code)
+      for (int i = 0; i < p->num_components; i++)
+        if (dc_class(p, i) > 1)
+          return fail(MJH_EUNSUPPORTED, "progressive mode: more than two different DC table numbers in one image (the kernels keep two DC tables per scan)");
     if (p->optimize_scans) {
       mjh_scan ref[MJH_MAX_SCANS];
       // scan 0 is whatever dc_scan_opt_mode was when the script was built (all components, or the luma alone,
@@ -610,7 +624,7 @@ static void build_const(const mjh_params *p, MjhConst *C)
     c.pw = c.wib * 8; c.ph = c.hib * 8;
     c.nblk = c.wib * c.hib;
     c.kstride = (c.nblk + 63) & ~63;
-    c.qtbl = p->quant_tbl_no[i]; c.dctbl = p->dc_tbl_no[i]; c.actbl = p->ac_tbl_no[i];
+    c.qtbl = p->quant_tbl_no[i]; c.dctbl = p->dc_tbl_no[i] | (dc_class(p, i) << 8); c.actbl = p->ac_tbl_no[i];
     c.mcu_blk0 = mcu_blk0; mcu_blk0 += c.h * c.v;
     c.plane_off = plane_off; plane_off += (long long)c.pw * c.ph;
     c.coef_off = coef_off; coef_off += (long long)c.kstride * 64;
@@ -1338,7 +1352,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
         d.ta[ci] = ms.Se ? p->ac_tbl_no[c] : 0;
         if (ms.Ss == 0) {
           if (ms.Ah == 0) {
-            const int t = p->dc_tbl_no[c], cls = t & 1;     // (check_supported: distinct table numbers of an image have distinct classes)
+            const int t = p->dc_tbl_no[c], cls = dc_class(p, c);     // (check_supported: at most two distinct table numbers per image)
             if (d.slot[cls] < 0) {
               d.slot[cls] = SLOT_PROG + 2 * si + cls;
               d.dht_slot[d.ndht] = d.slot[cls]; d.dht_id[d.ndht] = t; d.ndht++;
@@ -2753,8 +2767,13 @@ extern "C" int mjh_get_scan_table(mjh_encoder *e, int image, int scan, int tblno
   e = cur(e);
   if (!e || !bits || !vals || image < 0 || image >= e->last_n) return fail(MJH_EINVAL, "bad arguments");
   if (!e->progressive || e->arith || scan < 0 || scan >= e->nscans || tblno < 0 || tblno > 3) return fail(MJH_EINVAL, "no such scan table");
-  tblno &= 1;      // (the table class of a DC scan: see check_supported)
   const mjh_scan &sc = e->p.scan_info[scan];
+  {   // the table's class inside the image (dc_class): the class of the first component that names it
+    int cls = -1;
+    for (int i = 0; i < e->p.num_components && cls < 0; i++) if (e->p.dc_tbl_no[i] == tblno) cls = dc_class(&e->p, i);
+    if (sc.Ss == 0 && cls < 0) return fail(MJH_EINVAL, "no component uses DC table %d", tblno);
+    tblno = cls < 0 ? 0 : cls;
+  }
   if (sc.Ss == 0 && sc.Ah != 0) return fail(MJH_EINVAL, "a DC refinement scan has no table");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));

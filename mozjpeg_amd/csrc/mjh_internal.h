@@ -32,7 +32,8 @@ struct MjhComp {
   int pw, ph;             // sample plane = wib*8 x hib*8
   int nblk;               // wib*hib
   int kstride;            // elements between consecutive zig-zag planes (nblk rounded up to 64)
-  int qtbl, dctbl, actbl; // table numbers
+  int qtbl, dctbl, actbl; // table numbers; dctbl: number | class << 8 -- the progressive kernels keep two DC tables per scan, class = which of the
+                          // image's (at most two) distinct DC table numbers this is, in order of first use
   int mcu_blk0;           // index of this component's first block inside an interleaved MCU
   long long plane_off;    // sample offset of this component's plane inside one image's plane set
   long long coef_off;     // element offset of this component's coefficient planes inside one image's set

@@ -178,7 +178,7 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
           for (int ci = 0; ci < sc.ncomp; ci++) {
             const MjhComp cc = C.c[scans[sidx].comp[ci]];
             const int16_t *q0 = qimg + cc.coef_off;
-            const int tb = cc.dctbl & 1;
+            const int tb = (cc.dctbl >> 8) & 1;      // the DC table's class (MjhComp)
             const int mh = inter ? cc.v : 1, mw = inter ? cc.h : 1;
             for (int yi = 0; yi < mh; yi++)
               for (int xi = 0; xi < mw; xi++) {
@@ -870,7 +870,7 @@ k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
       for (int ci = 0; ci < sc.ncomp; ci++) {
         const MjhComp cc = C.c[sc.comp[ci]];
         const int16_t *q0 = qimg + cc.coef_off;
-        const int tb = cc.dctbl & 1;
+        const int tb = (cc.dctbl >> 8) & 1;      // the DC table's class (MjhComp)
         const int mh = inter ? cc.v : 1, mw = inter ? cc.h : 1;
         for (int yi = 0; yi < mh; yi++)
           for (int xi = 0; xi < mw; xi++) {
@@ -1211,7 +1211,7 @@ __device__ __forceinline__ unsigned pp_dc_unit(const MjhConst &C, const MjhProgS
   for (int ci = 0; ci < sc.ncomp; ci++) {
     const MjhComp cc = C.c[sc.comp[ci]];
     const int16_t *q0 = qimg + cc.coef_off;
-    const int tb = cc.dctbl & 1;
+    const int tb = (cc.dctbl >> 8) & 1;      // the DC table's class (MjhComp)
     const int mh = inter ? cc.v : 1, mw = inter ? cc.h : 1;
     for (int yi = 0; yi < mh; yi++)
       for (int xi = 0; xi < mw; xi++) {

@@ -2209,6 +2209,10 @@ static size_t encode_core(const mjo_params *p_in, const plane_source *ps, uint8_
   memcpy(e.dc[1].bits, STD_DC_C_BITS, 17); memcpy(e.dc[1].huffval, STD_DC_VAL, 12);
   memcpy(e.ac[0].bits, STD_AC_L_BITS, 17); memcpy(e.ac[0].huffval, STD_AC_L_VAL, 162);
   memcpy(e.ac[1].bits, STD_AC_C_BITS, 17); memcpy(e.ac[1].huffval, STD_AC_C_VAL, 162);
+  /* slots 2 / 3: empty in the library until the application defines them, and a component that names an empty slot aborts
+   * (JERR_NO_HUFF_TABLE); this restatement has no notion of application tables, so it assumes what oracle/refenc.c does for
+   * -dctbl / -actbl and what the test harness hands the GPU library: copies of the standard tables of the same parity */
+  e.dc[2] = e.dc[0]; e.dc[3] = e.dc[1]; e.ac[2] = e.ac[0]; e.ac[3] = e.ac[1];
 
   if (ps->coef) {
     /* jpeg_write_coefficients jctrans.c:44: the caller's quantized blocks (width_in_blocks x height_in_blocks per

@@ -63,6 +63,8 @@ int main(int argc, char **argv)
 {
   int quality = 75, baseline = 0, revert = 0, optimize = 0, progressive = 0, fastcrush = 0;
   int notrellis = 0, notrellis_dc = 0, noovershoot = 0, gray = 0, rgbout = 0, grayin = 0, qtbl = -1;
+  const char *dctbl = NULL, *actbl = NULL;
+  int no_optimize = 0;
   int ghs = 0, gvs = 0, yccin = 0;
   int hs = 2, vs = 2, hs1 = 1, vs1 = 1, hs2 = 1, vs2 = 1, nsamp = 2, restart = 0, restart_blocks = 0, reps = 1, rawW = 0, rawH = 0;
   double l1 = -1e9, l2 = -1e9;
@@ -121,6 +123,9 @@ int main(int argc, char **argv)
     else if (!strcmp(a, "-scanspec")) scanspec = argv[++i];   /* a scan script (cjpeg -scans file, read_scan_script rdswitch.c) on the command line: "c[,c..]:Ss-Se:Ah:Al;..." */
     else if (!strcmp(a, "-dct")) dct_fast = !strcmp(argv[++i], "fast");
     else if (!strcmp(a, "-arith-cond")) arith_cond = argv[++i];   /* L0,U0,K0,L1,U1,K1: cinfo->arith_dc_L / arith_dc_U / arith_ac_K of tables 0 and 1 (API-only fields, jpeglib.h:447-449) */
+    else if (!strcmp(a, "-no-optimize")) no_optimize = 1;   /* cinfo->optimize_coding = FALSE by hand, whatever the profile set (API-only) */
+    else if (!strcmp(a, "-dctbl")) dctbl = argv[++i];   /* a,b,c: cinfo->comp_info[i].dc_tbl_no (API-only; jpeg_set_colorspace assigns 0,1,1) */
+    else if (!strcmp(a, "-actbl")) actbl = argv[++i];
     else if (!strcmp(a, "-yuvin")) yuvin = 1;   /* -raw W H input holds component planes: jpeg_write_raw_data */
     else if (!in) in = a;
     else out = a;
@@ -204,6 +209,28 @@ int main(int argc, char **argv)
       if (nsamp == 6) {
         cinfo.comp_info[1].h_samp_factor = hs1; cinfo.comp_info[1].v_samp_factor = vs1;
         cinfo.comp_info[2].h_samp_factor = hs2; cinfo.comp_info[2].v_samp_factor = vs2;
+      }
+    }
+    if (no_optimize) cinfo.optimize_coding = FALSE;
+    if (dctbl || actbl) {   /* table numbers of the application's own */
+      int t[4] = { 0, 0, 0, 0 }, ci;
+      if (dctbl) { sscanf(dctbl, "%d,%d,%d,%d", &t[0], &t[1], &t[2], &t[3]); for (ci = 0; ci < cinfo.num_components; ci++) cinfo.comp_info[ci].dc_tbl_no = t[ci]; }
+      if (actbl) { sscanf(actbl, "%d,%d,%d,%d", &t[0], &t[1], &t[2], &t[3]); for (ci = 0; ci < cinfo.num_components; ci++) cinfo.comp_info[ci].ac_tbl_no = t[ci]; }
+      /* slots 2 / 3 are empty after jpeg_set_defaults and the library insists on a table in every slot a component names
+       * (JERR_NO_HUFF_TABLE, also where it only needs rates): what an application would do -- a copy of the standard table of the
+       * same parity */
+      for (ci = 0; ci < cinfo.num_components; ci++) {
+        const int d = cinfo.comp_info[ci].dc_tbl_no, a = cinfo.comp_info[ci].ac_tbl_no;
+        if (d > 1 && cinfo.dc_huff_tbl_ptrs[d] == NULL) {
+          cinfo.dc_huff_tbl_ptrs[d] = jpeg_alloc_huff_table((j_common_ptr)&cinfo);
+          *cinfo.dc_huff_tbl_ptrs[d] = *cinfo.dc_huff_tbl_ptrs[d & 1];
+          cinfo.dc_huff_tbl_ptrs[d]->sent_table = FALSE;
+        }
+        if (a > 1 && cinfo.ac_huff_tbl_ptrs[a] == NULL) {
+          cinfo.ac_huff_tbl_ptrs[a] = jpeg_alloc_huff_table((j_common_ptr)&cinfo);
+          *cinfo.ac_huff_tbl_ptrs[a] = *cinfo.ac_huff_tbl_ptrs[a & 1];
+          cinfo.ac_huff_tbl_ptrs[a]->sent_table = FALSE;
+        }
       }
     }
     if (restart) {

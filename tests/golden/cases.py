@@ -207,6 +207,13 @@ CASES = [
     ("ifast_base_q92_444_notrellis_dc", dict(baseline=True, dct="fast", quality=92, sample=(1, 1), notrellis_dc=True), True),
     ("ifast_arith_base", dict(arithmetic=True, baseline=True, dct="fast"), True),
     ("ifast_base_trellis_q_opt", dict(baseline=True, dct="fast", trellis_q_opt=True), True),
+    # table numbers of the application's own (API-only): any two DC table numbers in a progressive image (round 6; until then two
+    # numbers with the same low bit were refused), any AC table numbers
+    ("prog_dctbl_022", dict(dc_tbl=(0, 2, 2)), True),
+    ("prog_dctbl_133_actbl_203", dict(dc_tbl=(1, 3, 3), ac_tbl=(2, 0, 3), fastcrush=True), True),
+    ("prog_dctbl_313_revert", dict(dc_tbl=(3, 1, 3), revert=True, progressive=True), True),
+    ("prog_dctbl_200_restart1", dict(dc_tbl=(2, 0, 0), fastcrush=True, restart=1), True),
+    ("revert_opt_dctbl_232", dict(dc_tbl=(2, 3, 2), ac_tbl=(1, 3, 0), revert=True, optimize=True), True),
 ]
 
 

@@ -76,7 +76,8 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 noovershoot=False, sample=(2, 2), restart=None, gray=False, grayin=False,
                 quant_table=-1, lambda1=None, lambda2=None, precision=8, trellis_loops=1, smooth=0, trellis_q_opt=False,
                 trellis_eob_opt=False, use_scans_in_trellis=False, trellis_freq_split=0, rgb=False,
-                dc_scan_opt=None, dc_ver_weight=None, arithmetic=False, arith_cond=None, scans=None, gray_sample=None, yccin=False, dct=None):
+                dc_scan_opt=None, dc_ver_weight=None, arithmetic=False, arith_cond=None, scans=None, gray_sample=None, yccin=False, dct=None,
+                dc_tbl=None, ac_tbl=None):
     """Same switch vocabulary as cjpeg / oracle/refenc.c.  Default (no switch) is cjpeg's default:
     max-compression profile, progressive with scan search."""
     p = Params()
@@ -90,6 +91,11 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
             p.h_samp[i], p.v_samp[i] = sample[i]
     if gray_sample is not None and p.num_components == 1:      # (h, v) of a gray image's one component (cjpeg: 2x1 for qualities 80..89)
         p.h_samp[0], p.v_samp[0] = gray_sample
+    for i in range(p.num_components):          # table numbers of the application's own (cinfo->comp_info[i].dc_tbl_no / ac_tbl_no)
+        if dc_tbl is not None:
+            p.dc_tbl_no[i] = dc_tbl[i]
+        if ac_tbl is not None:
+            p.ac_tbl_no[i] = ac_tbl[i]
     if optimize:
         p.optimize_coding = 1
     if notrellis:
@@ -364,6 +370,10 @@ def ref_switches(**kw):
         sw += ["-dct", kw["dct"]]
     if kw.get("scans") is not None:           # (refenc's own switch: cjpeg reads the script from a file)
         sw += ["-scanspec", ";".join("%s:%d-%d:%d:%d" % (",".join(str(c) for c in comps), ss, se, ah, al) for comps, ss, se, ah, al in kw["scans"])]
+    if kw.get("dc_tbl") is not None:          # (refenc's own switches: the table numbers are API-only)
+        sw += ["-dctbl", ",".join(str(v) for v in kw["dc_tbl"])]
+    if kw.get("ac_tbl") is not None:
+        sw += ["-actbl", ",".join(str(v) for v in kw["ac_tbl"])]
     if kw.get("arith_cond") is not None:      # (refenc's own switch: the API fields cinfo->arith_dc_L / arith_dc_U / arith_ac_K have no cjpeg switch)
         sw += ["-arith-cond", ",".join(str(v) for t in kw["arith_cond"] for v in t)]
     return sw

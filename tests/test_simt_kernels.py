@@ -130,6 +130,27 @@ def test_emulated_image_ranges_of_the_ac_trellis_match_the_oracle(simt, chunks):
             assert got[i] == want[i], (chunks, dense, i)
 
 
+@pytest.mark.parametrize("dc", [(0, 2, 2), (1, 3, 3), (2, 0, 0), (3, 1, 3), (0, 2, 0), (2, 3, 2), (1, 1, 0)])
+def test_emulated_progressive_images_with_any_two_dc_table_numbers_match_the_oracle(simt, dc):
+    """a progressive image may use any two of the four DC table numbers (until round 6: only two with different low bits);
+    the interleaved DC scan of the default script codes all three components, each with its table's class"""
+    w, h = 83, 61
+    img = O.synthetic_frame(w, h, 4242)
+    for kw in (dict(quality=80), dict(quality=80, fastcrush=True), dict(quality=70, revert=True, progressive=True)):
+        pm, po = M.make_params(w, h, dc_tbl=dc, **kw), O.make_params(w, h, dc_tbl=dc, **kw)
+        enc = M.Encoder(pm)
+        got = enc.encode_host(img)[0]
+        enc.close()
+        assert got == O.encode(po, img), (dc, kw)
+
+
+def test_three_dc_table_numbers_in_a_progressive_image_are_refused_with_the_reason(simt):
+    pm = M.make_params(64, 64, quality=80, dc_tbl=(0, 1, 2))
+    with pytest.raises(M.MjhError) as ei:
+        M.Encoder(pm)
+    assert ei.value.code == M.EUNSUPPORTED and "two" in str(ei.value)
+
+
 def test_the_emulator_itself(tmp_path):
     """tools/simt/selftest.cpp: cross-lane operations against their documented results (shuffles, ballots under divergence with
     and without MJH_DIVERGENT_SCOPE, DPP row shifts / broadcasts with bound_ctrl, independent rows of 16, __syncthreads_or,
