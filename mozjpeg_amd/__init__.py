@@ -139,7 +139,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 progressive=False, fastcrush=False, precision=8, trellis_loops=1, smooth=0, rgb=False,
                 dc_scan_opt=None, dc_ver_weight=None, use_scans_in_trellis=False, trellis_freq_split=0,
                 trellis_eob_opt=False, trellis_q_opt=False, arithmetic=False, arith_cond=None, scans=None, gray_sample=None, yccin=False, dct=None,
-                dc_tbl=None, ac_tbl=None):
+                dc_tbl=None, ac_tbl=None, no_optimize=False):
     """Parameters with cjpeg's switch vocabulary (cjpeg.c:371-714).  Without `baseline` or
     `revert` this is cjpeg's default: progressive with scan search (`fastcrush`: fixed 9-scan script)."""
     p = Params()
@@ -173,6 +173,8 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 p.huff_tables_given |= 1 << k
     if optimize:
         p.optimize_coding = 1
+    if no_optimize:
+        p.optimize_coding = 0               # by hand, whatever the profile set
     if notrellis:
         p.trellis_quant = 0
     if notrellis_dc:

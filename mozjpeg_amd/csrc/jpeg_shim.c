@@ -714,7 +714,14 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
      * tables a progressive image's DC trellis takes its rates from (jccoefct.c:388-389).  A slot that holds the Annex K
      * table travels as "not given". */
     const int progressive = p->num_scans > 0 && (p->optimize_scans || !(p->scan_info[0].Ss == 0 && p->scan_info[0].Se == 63));
-    int coding = !p->optimize_coding && !p->arith_code, own = 0;
+    int coding, own = 0;
+    /* the trellis with optimize_coding switched off by hand, ONE component: the reference's passes are then the schedule of
+     * optimize_coding itself (statistics, trellis pass(es), output with the tables the last pass left in the slots) and its file the
+     * same bytes (mjh_encoder.cpp: check_supported); cinfo->optimize_coding stays what the application set */
+    if (p->trellis_quant && !p->optimize_coding && !p->arith_code && p->num_components == 1 && p->num_scans == 0 && !p->use_scans_in_trellis &&
+        !(p->trellis_q_opt && p->trellis_num_loops > 1))
+      p->optimize_coding = 1;
+    coding = !p->optimize_coding && !p->arith_code;
     const int dc_rates = progressive && !p->arith_code && p->trellis_quant && p->trellis_quant_dc;
     if (coding || dc_rates)
       for (ci = 0; ci < cinfo->num_components; ci++) {
@@ -740,7 +747,7 @@ static const char *capture_params(j_compress_ptr cinfo, mjh_params *p, int no_pi
       }
     if (coding && cinfo->data_precision == 12 && !own) p->optimize_coding = 1, coding = 0;   /* (and nothing of the slots is read) */
   }
-  if (p->trellis_quant && !p->optimize_coding && !p->arith_code)
+  if (p->trellis_quant && !p->optimize_coding && !p->arith_code)      /* (one component: coded, see above) */
     return "trellis without optimize_coding (the reference codes such an image with tables no pass made for it: its own djpeg rejects the colour files)";
   if (p->num_scans > 0 && p->optimize_coding && p->trellis_quant && no_pixels != 2) { p->trellis_stats_Ah = cinfo->Ah; p->trellis_stats_Al = cinfo->Al; }   /* SURVEY T15 */
   p->write_JFIF_header = cinfo->write_JFIF_header;

@@ -434,6 +434,12 @@ static int dc_class(const mjh_params *p, int c)
   return 0;
 }
 
+// see check_supported
+static bool trellis_without_optimize_is_optimize(const mjh_params *p)
+{
+  return p->num_components == 1 && p->num_scans == 0 && !p->use_scans_in_trellis && !(p->trellis_q_opt && p->trellis_num_loops > 1);
+}
+
 static bool dht_writer_would_corrupt(const mjh_params *p, const int *comps, int k, bool dseen[4], bool aseen[4])
 {
   for (int j = 0; j < k; j++) {
@@ -562,7 +568,14 @@ static int check_supported(const mjh_params *p)
         return fail(MJH_EINVAL, "arithmetic conditioning of table %d: L %d, U %d, K %d (0 <= L <= U <= 15, 1 <= K <= 63: T.81 B.2.4.3)", t, p->arith_dc_L[t], p->arith_dc_U[t], p->arith_ac_K[t]);
     }
   }
-  if (p->trellis_quant && !p->optimize_coding && !p->arith_code) return fail(MJH_EUNSUPPORTED, "trellis_quant requires optimize_coding (jcmaster.c:686-702 never selects a component otherwise)");
+  // The trellis with optimize_coding switched off by hand: the reference's passes below pass_number_scan_opt_base select ONE
+  // component each, pass_number / (2 loops), written for the (statistics, trellis) pairs of optimize_coding (jcmaster.c:451-466,
+  // :1128-1139); every one of them gathers statistics and leaves optimal tables in the slots.  For ONE component that is the
+  // schedule of optimize_coding itself -- main pass (statistics), trellis pass(es), output with the tables the last pass made:
+  // the same bytes (trellis_without_optimize_is_optimize; checked against the reference on 50 parameter sets) -- so it is coded
+  // that way.  With more components the last one is never quantized and coded with another component's tables: refused.
+  if (p->trellis_quant && !p->optimize_coding && !p->arith_code && !trellis_without_optimize_is_optimize(p))
+    return fail(MJH_EUNSUPPORTED, "trellis_quant requires optimize_coding (jcmaster.c:686-702 never selects a component otherwise)");
   if (p->huff_tables_given & ~0xFF) return fail(MJH_EINVAL, "huff_tables_given 0x%x", p->huff_tables_given);
   for (int k = 0; k < 8; k++) {
     if (!(p->huff_tables_given >> k & 1)) continue;
@@ -947,6 +960,7 @@ extern "C" int mjh_encoder_create(const mjh_params *p, int max_batch, int device
     e->dc_chain_v = p->v_samp_factor[0];
     e->p.h_samp_factor[0] = e->p.v_samp_factor[0] = 1;
   }
+  if (p->trellis_quant && !p->optimize_coding && !p->arith_code) e->p.optimize_coding = 1, e->p.huff_tables_given = 0;   // (check_supported: one component; the slots' tables are overwritten before anything reads them)
   if (p->data_precision == 12 && !p->huff_tables_given) e->p.optimize_coding = 1;   // standard tables are 8-bit only (jcparam.c:452-453, jcmaster.c:1102-1105: tables of the caller's own are kept)
   p = &e->p;     // (everything below reads the parameters as the encoder runs them: a 12-bit sequential scan script sends its scans' tables with every scan)
   e->device = device;

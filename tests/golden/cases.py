@@ -214,6 +214,12 @@ CASES = [
     ("prog_dctbl_313_revert", dict(dc_tbl=(3, 1, 3), revert=True, progressive=True), True),
     ("prog_dctbl_200_restart1", dict(dc_tbl=(2, 0, 0), fastcrush=True, restart=1), True),
     ("revert_opt_dctbl_232", dict(dc_tbl=(2, 3, 2), ac_tbl=(1, 3, 0), revert=True, optimize=True), True),
+    # the trellis with optimize_coding switched off by hand (API-only), one component: the reference's passes are the schedule of
+    # optimize_coding, its file the same bytes (round 6; colour images stay refused: the reference's own djpeg rejects its files)
+    ("base_gray_no_optimize", dict(baseline=True, gray=True, no_optimize=True), True),
+    ("base_gray_q90_loops3_no_optimize", dict(baseline=True, gray=True, quality=90, trellis_loops=3, no_optimize=True), True),
+    ("base_gray_restart1_eob_opt_no_optimize", dict(baseline=True, gray=True, restart=1, trellis_eob_opt=True, no_optimize=True), True),
+    ("base_gray_ifast_q_opt_no_optimize", dict(baseline=True, gray=True, dct="fast", trellis_q_opt=True, no_optimize=True), True),
 ]
 
 

@@ -77,7 +77,7 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
                 quant_table=-1, lambda1=None, lambda2=None, precision=8, trellis_loops=1, smooth=0, trellis_q_opt=False,
                 trellis_eob_opt=False, use_scans_in_trellis=False, trellis_freq_split=0, rgb=False,
                 dc_scan_opt=None, dc_ver_weight=None, arithmetic=False, arith_cond=None, scans=None, gray_sample=None, yccin=False, dct=None,
-                dc_tbl=None, ac_tbl=None):
+                dc_tbl=None, ac_tbl=None, no_optimize=False):
     """Same switch vocabulary as cjpeg / oracle/refenc.c.  Default (no switch) is cjpeg's default:
     max-compression profile, progressive with scan search."""
     p = Params()
@@ -98,6 +98,11 @@ def make_params(width, height, *, quality=75, baseline=False, revert=False, opti
             p.ac_tbl_no[i] = ac_tbl[i]
     if optimize:
         p.optimize_coding = 1
+    if no_optimize:
+        # optimize_coding switched off by hand with the trellis on, ONE component: the reference's passes are the schedule of
+        # optimize_coding and its file the same bytes (jcmaster.c:451-466, :975-1010; pinned by the *_no_optimize goldens): the
+        # restatement keeps the flag on
+        assert p.num_components == 1 and p.trellis_quant
     if notrellis:
         p.trellis_quant = 0
     if notrellis_dc:
@@ -370,6 +375,8 @@ def ref_switches(**kw):
         sw += ["-dct", kw["dct"]]
     if kw.get("scans") is not None:           # (refenc's own switch: cjpeg reads the script from a file)
         sw += ["-scanspec", ";".join("%s:%d-%d:%d:%d" % (",".join(str(c) for c in comps), ss, se, ah, al) for comps, ss, se, ah, al in kw["scans"])]
+    if kw.get("no_optimize"):                 # (refenc's own switch: cinfo->optimize_coding = FALSE by hand)
+        sw.append("-no-optimize")
     if kw.get("dc_tbl") is not None:          # (refenc's own switches: the table numbers are API-only)
         sw += ["-dctbl", ",".join(str(v) for v in kw["dc_tbl"])]
     if kw.get("ac_tbl") is not None:

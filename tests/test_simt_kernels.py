@@ -144,6 +144,29 @@ def test_emulated_progressive_images_with_any_two_dc_table_numbers_match_the_ora
         assert got == O.encode(po, img), (dc, kw)
 
 
+def test_emulated_gray_trellis_without_optimize_coding_is_the_optimize_schedule(simt, goldens):
+    """optimize_coding switched off by hand with the trellis on: one component = the reference's optimize_coding schedule, the same
+    bytes (reference-made goldens *_no_optimize, byte-identical to their optimize_coding twins); colour: refused (test_abi)"""
+    from cases import images
+    for cname in ("base_gray_no_optimize", "base_gray_q90_loops3_no_optimize", "base_gray_restart1_eob_opt_no_optimize", "base_gray_ifast_q_opt_no_optimize"):
+        kw = [k for c, k, _ in CASES if c == cname][0]
+        for iname, img in images().items():
+            h, w = img.shape[:2]
+            if w * h > 250 * 190:
+                continue
+            pm = M.make_params(w, h, **kw)
+            assert pm.optimize_coding == 0 and pm.trellis_quant == 1
+            enc = M.Encoder(pm)
+            data = enc.encode_host(img)[0]
+            enc.close()
+            g = goldens["%s/%s" % (iname, cname)]
+            assert (len(data), O.md5(data)) == (g["bytes"], g["md5"]), (iname, cname)
+    pm = M.make_params(64, 64, baseline=True, gray=True, use_scans_in_trellis=True, no_optimize=True)     # two bands per component: not the same schedule
+    with pytest.raises(M.MjhError) as ei:
+        M.Encoder(pm)
+    assert ei.value.code == M.EUNSUPPORTED
+
+
 def test_three_dc_table_numbers_in_a_progressive_image_are_refused_with_the_reason(simt):
     pm = M.make_params(64, 64, quality=80, dc_tbl=(0, 1, 2))
     with pytest.raises(M.MjhError) as ei:
