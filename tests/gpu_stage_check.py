@@ -58,10 +58,14 @@ def check_case(img, kw, verbose=True):
     bits = enc.read_tap(M.TAP_HUFF_BITS, 0)
     vals = enc.read_tap(M.TAP_HUFF_VALS, 0)
     if pg.optimize_coding and pg.num_scans == 0 and not kw.get("arithmetic"):   # (the arithmetic coder has no tables)
-        used = sorted({pg.dc_tbl_no[i] for i in range(pg.num_components)})   # tables a component refers to (RGB output: only 0)
-        for t in used:
-            for nm, gb, gv, ob, ov in (("dc", bits[2 * t], vals[2 * t], taps["dc_bits"][t], taps["dc_vals"][t]),
-                                       ("ac", bits[2 * t + 1], vals[2 * t + 1], taps["ac_bits"][t], taps["ac_vals"][t])):
+        # tables a component refers to (RGB output: only 0; table numbers of the application's own: any of the four, DC and AC apart)
+        used_dc = sorted({pg.dc_tbl_no[i] for i in range(pg.num_components)})
+        used_ac = sorted({pg.ac_tbl_no[i] for i in range(pg.num_components)})
+        for nm, used, off, tb, tv in (("dc", used_dc, 0, taps["dc_bits"], taps["dc_vals"]), ("ac", used_ac, 1, taps["ac_bits"], taps["ac_vals"])):
+            for t in used:
+                if t >= len(tb) or 2 * t + off >= len(bits):
+                    continue      # (the taps hold table numbers 0 and 1; the bytes below cover the rest)
+                gb, gv, ob, ov = bits[2 * t + off], vals[2 * t + off], tb[t], tv[t]
                 n = int(ob[1:].sum())
                 if not (np.array_equal(gb[1:], ob[1:]) and np.array_equal(gv[:n], ov[:n])):
                     status.append("%s-table%d DIFF" % (nm, t))
