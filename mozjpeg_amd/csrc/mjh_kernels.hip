@@ -1410,27 +1410,44 @@ template <int CTRL> __device__ __forceinline__ float dpp_f0(float v)
 // itself, and each costs a 4-cycle issue slot): SHL = row_shl:n (lane i reads lane i + n of its row) with lanes that have no source reading 0.0, BC = row_newbcast:n.
 // Same IEEE add as the two-instruction form.  `first`: the source may have been written by the instruction before (DPP read
 // hazard: 2 wait states), which the hazard recognizer cannot see across inline asm.
+#ifdef MJH_SIMT_HOST   // (tools/simt: the same three operations spelled with builtins)
 template <int SHL> __device__ __forceinline__ float add_shl(float v, float d, bool first = false)
 {
-#ifdef MJH_SIMT_HOST   // (tools/simt: the same operation spelled with the builtin)
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + SHL, 0xF, 0xF, true)) + d;
+}
+template <int BC> __device__ __forceinline__ float add_bcast(float v, float d, bool first = false)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + BC, 0xF, 0xF, false)) + d;
+}
+__device__ __forceinline__ float min3_f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 #else
+template <int SHL> __device__ __forceinline__ float add_shl(float v, float d, bool first = false)
+{
   float r;
   if (first) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_shl:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(d), "n"(SHL));
   else asm volatile("v_add_f32_dpp %0, %1, %2 row_shl:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(d), "n"(SHL));
   return r;
-#endif
 }
 template <int BC> __device__ __forceinline__ float add_bcast(float v, float d, bool first = false)
 {
-#ifdef MJH_SIMT_HOST
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + BC, 0xF, 0xF, false)) + d;
-#else
   float r;
   if (first) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(d), "n"(BC));
   else asm volatile("v_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(d), "n"(BC));
   return r;
+}
+// The minimum of three costs in ONE instruction.  fminf() on values that come out of inline assembly costs a v_max_f32 x, x each
+// (the compiler quiets a NaN it cannot rule out) in front of every v_min_f32: the nine-way minimum of a DC step was 8 + 6 + 2
+// instructions; costs are never NaN (3e38 stands for "no candidate"), the minimum of the same nine floats is the same float.
+__device__ __forceinline__ float min3_f(float a, float b, float c)
+{
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 #endif
+__device__ __forceinline__ float min9_f(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8)
+{
+  return min3_f(min3_f(a0, a1, a2), min3_f(a3, a4, a5), min3_f(a6, a7, a8));
 }
 
 __global__ void __launch_bounds__(64)
@@ -1517,8 +1534,10 @@ k_trellis_dc3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restr
           const float c_6 = add_bcast<6>(prev_cost, add_shl<1>(Rj, dist));
           const float c_7 = add_bcast<7>(prev_cost, Rj + dist);
           const float c_8 = add_bcast<8>(prev_cost, dpp_f<0x111>(R0, Rj) + dist);     // row_shr:1; lane 0 keeps R0
-          const float m = fminf(fminf(fminf(c_0, c_1), fminf(c_2, c_3)), fminf(fminf(fminf(c_4, c_5), fminf(c_6, c_7)), c_8));
+          const float m = min9_f(c_0, c_1, c_2, c_3, c_4, c_5, c_6, c_7, c_8);
           // first minimum in CANDIDATE order of the predecessor (:1100-1106): lanes of invalid candidates hold 3e38
+          // (tried in round 6: the mask shifted in by an add-with-carry behind each compare, 18 instead of ~26 instructions -- a
+          // chain of nine dependent adds through vcc, 0.3 % slower than the select / or tree)
           unsigned e = (c_0 == m ? 1u : 0u) | (c_1 == m ? 2u : 0u) | (c_2 == m ? 4u : 0u) | (c_3 == m ? 8u : 0u) | (c_4 == m ? 16u : 0u) |
                        (c_5 == m ? 32u : 0u) | (c_6 == m ? 64u : 0u) | (c_7 == m ? 128u : 0u) | (c_8 == m ? 256u : 0u);
           bb = prev_neg ? ncand - 1 - (31 - __clz((int)e)) : __ffs((int)e) - 1;
@@ -1537,7 +1556,7 @@ k_trellis_dc3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__restr
       const float p0 = row_bcast_f<0>(prev_cost), p1 = row_bcast_f<1>(prev_cost), p2 = row_bcast_f<2>(prev_cost), p3 = row_bcast_f<3>(prev_cost),
                   p4 = row_bcast_f<4>(prev_cost), p5 = row_bcast_f<5>(prev_cost), p6 = row_bcast_f<6>(prev_cost), p7 = row_bcast_f<7>(prev_cost),
                   p8 = row_bcast_f<8>(prev_cost);
-      const float m = fminf(fminf(fminf(p0, p1), fminf(p2, p3)), fminf(fminf(fminf(p4, p5), fminf(p6, p7)), p8));
+      const float m = min9_f(p0, p1, p2, p3, p4, p5, p6, p7, p8);
       const unsigned e = (p0 == m ? 1u : 0u) | (p1 == m ? 2u : 0u) | (p2 == m ? 4u : 0u) | (p3 == m ? 8u : 0u) | (p4 == m ? 16u : 0u) |
                          (p5 == m ? 32u : 0u) | (p6 == m ? 64u : 0u) | (p7 == m ? 128u : 0u) | (p8 == m ? 256u : 0u);
       j = prev_neg ? ncand - 1 - (31 - __clz((int)e)) : __ffs((int)e) - 1;
@@ -1686,7 +1705,7 @@ k_trellis_dc3_fwd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__r
         const float c_6 = add_bcast<6>(prev_cost, add_shl<1>(Rj, dist));
         const float c_7 = add_bcast<7>(prev_cost, Rj + dist);
         const float c_8 = add_bcast<8>(prev_cost, dpp_f<0x111>(R0, Rj) + dist);
-        const float m = fminf(fminf(fminf(c_0, c_1), fminf(c_2, c_3)), fminf(fminf(fminf(c_4, c_5), fminf(c_6, c_7)), c_8));
+        const float m = min9_f(c_0, c_1, c_2, c_3, c_4, c_5, c_6, c_7, c_8);
         unsigned e = (c_0 == m ? 1u : 0u) | (c_1 == m ? 2u : 0u) | (c_2 == m ? 4u : 0u) | (c_3 == m ? 8u : 0u) | (c_4 == m ? 16u : 0u) |
                      (c_5 == m ? 32u : 0u) | (c_6 == m ? 64u : 0u) | (c_7 == m ? 128u : 0u) | (c_8 == m ? 256u : 0u);
         bb = prev_neg ? ncand - 1 - (31 - __clz((int)e)) : __ffs((int)e) - 1;
@@ -1703,7 +1722,7 @@ k_trellis_dc3_fwd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__r
     const float p0 = row_bcast_f<0>(prev_cost), p1 = row_bcast_f<1>(prev_cost), p2 = row_bcast_f<2>(prev_cost), p3 = row_bcast_f<3>(prev_cost),
                 p4 = row_bcast_f<4>(prev_cost), p5 = row_bcast_f<5>(prev_cost), p6 = row_bcast_f<6>(prev_cost), p7 = row_bcast_f<7>(prev_cost),
                 p8 = row_bcast_f<8>(prev_cost);
-    const float m = fminf(fminf(fminf(p0, p1), fminf(p2, p3)), fminf(fminf(fminf(p4, p5), fminf(p6, p7)), p8));
+    const float m = min9_f(p0, p1, p2, p3, p4, p5, p6, p7, p8);
     const unsigned e = (p0 == m ? 1u : 0u) | (p1 == m ? 2u : 0u) | (p2 == m ? 4u : 0u) | (p3 == m ? 8u : 0u) | (p4 == m ? 16u : 0u) |
                        (p5 == m ? 32u : 0u) | (p6 == m ? 64u : 0u) | (p7 == m ? 128u : 0u) | (p8 == m ? 256u : 0u);
     int j = prev_neg ? ncand - 1 - (31 - __clz((int)e)) : __ffs((int)e) - 1;
