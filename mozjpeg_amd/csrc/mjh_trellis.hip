@@ -900,8 +900,8 @@ __device__ __forceinline__ float4 v3_rate(const float4 *rate_rows, int run)
 // words of the NEXT step are now requested at the top of a step, so that a step waits for its rate rows only.  Same loads,
 // same operations on the same values in the same order per lane: the files do not change.  (Indices past the oldest entry are
 // clamped to 0: a harmless repeat, read only if the scan goes on.)
-template <int QN, int NC>
-__device__ __forceinline__ void v3_scan(const uint2 (*col)[64], const unsigned short (*info)[64], const float4 *rate_rows, int lane, int e, int im1,
+template <int QN, int NC, typename IT>
+__device__ __forceinline__ void v3_scan(const uint2 (*col)[64], const IT (*info)[64], const float4 *rate_rows, int lane, int e, int im1,
                                         float azd_prev, float f0f, float d0, float d1, float d2, float d3,
                                         float &best, int &beste, int &bestk)
 {
@@ -912,7 +912,8 @@ __device__ __forceinline__ void v3_scan(const uint2 (*col)[64], const unsigned s
   do {
     // this step's rate rows first (their addresses come from info words that are in registers), then the next step's entries:
     // LDS answers in order, so the step waits for the rate rows while the prefetch is still on its way
-    const int run_a = im1 - (int)(ia & 63u), run_b = im1 - (int)(ib & 63u);
+    // (a one-byte info word IS the position: nothing to mask)
+    const int run_a = im1 - (int)(sizeof(IT) == 1 ? ia : ia & 63u), run_b = im1 - (int)(sizeof(IT) == 1 ? ib : ib & 63u);
     const float4 ra = v3_rate<NC>(rate_rows, run_a), rb4 = v3_rate<NC>(rate_rows, run_b);
     const int ea_n = e >= 3 ? e - 3 : 0, eb_n = e >= 4 ? e - 4 : 0;
     const uint2 va_n = col[ea_n][lane], vb_n = col[eb_n][lane];
@@ -951,7 +952,14 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
   static_assert(QN >= 16 && QN <= 63 && NPASS >= 1 && NPASS <= 8, "queue capacity / passes");
   constexpr int TILE = 64 * NPASS;
   __shared__ uint2 col[QN + 1][64];      // tile sort scratch; per pass: queue records (record r in slot r) -> live entries {azd, acc} (entry e in slot e; 0 = the virtual start) -> value column
-  __shared__ unsigned short info[QN + 1][64];   // live entry e at [e]: position | back entry << 6 | magnitude (< 16) << 12 (the signs: one bit per position in a register)
+  // live entry e at [e]: position | back entry << 6 | magnitude (< 16) << 12 (the signs: one bit per position in a register).
+  // SLIM (up to 16 records): the word keeps the position only -- ONE byte -- and the back entry (< 16) and the magnitude (< 16) of
+  // entry e are nibble e - 1 of two 64-bit registers.  17 slots of 9 instead of 10 bytes per lane + the rate rows = 10 048 bytes:
+  // 16 waves per CU instead of 14 (the kernel follows its occupancy, profiles/r06g_occupancy.md: T(w) ~ 0.52 + 13.3 / w), and the
+  // scan loop loses the two masks of its position fields.  Same operations on the same values per lane: the files do not change.
+  constexpr bool SLIM = QN <= 16;
+  typedef typename std::conditional<SLIM, unsigned char, unsigned short>::type info_t;
+  __shared__ info_t info[QN + 1][64];
   __shared__ float4 rate_rows[16];
   typedef unsigned __attribute__((may_alias)) u_alias;
   typedef unsigned short __attribute__((may_alias)) us_alias;
@@ -1084,7 +1092,8 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     float end_best = azd63 + eobf;
     uint2 rec_n = col[0][lane];
     col[0][lane] = make_uint2(0u, 0u);     // record 0 is in registers: its slot becomes entry 0, the virtual start (position 0, azd 0, cost 0)
-    info[0][lane] = (unsigned short)0;
+    info[0][lane] = (info_t)0;
+    unsigned long long back4 = 0ull, mag4 = 0ull;      // SLIM: nibble e - 1 = back entry / magnitude of live entry e
     // quantizer constants of the NEXT record's position: lane k holds entry k of the component's rows, fetched with ds_bpermute
     // at a point where every lane of the wave is enabled (a disabled source lane would read as 0)
     int dq_n = 1;
@@ -1135,8 +1144,8 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
         // (a plain divergent loop: lanes whose scan has ended wait masked until the last one is done.  Written as
         // `while (ballot(scan)) if (scan) {..}` until late in round 5, the loop carried its state through a bypass block: eight
         // register copies plus a flag materialised and re-tested per pair step, 10 of its ~75 instructions)
-        if (!wide) v3_scan<QN, 2>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk);
-        else v3_scan<QN, 4>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk);
+        if (!wide) v3_scan<QN, 2, info_t>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk);
+        else v3_scan<QN, 4, info_t>(col, info, rate_rows, lane, e, i - 1, azd_prev, f0f, d0, d1, d2, d3, best, beste, bestk);
       }
       lookup();
       const bool wide_n = next_wide();
@@ -1144,7 +1153,13 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
         if (beste >= 0) {
           const int mag = (bestk < ncd - 1) ? (2 << bestk) - 1 : qval;
           col[nlive][lane] = make_uint2(__float_as_uint(azd_cur), __float_as_uint(best));     // live entry nlive
-          info[nlive][lane] = (unsigned short)((unsigned)i | ((unsigned)beste << 6) | ((unsigned)mag << 12));
+          if (SLIM) {
+            info[nlive][lane] = (info_t)i;
+            const int sh = 4 * (nlive - 1);      // (nlive >= 1; beste < nlive <= 16)
+            back4 |= (unsigned long long)(unsigned)beste << sh;
+            mag4 |= (unsigned long long)(unsigned)mag << sh;
+          } else
+          info[nlive][lane] = (info_t)((unsigned)i | ((unsigned)beste << 6) | ((unsigned)mag << 12));
           neg |= (unsigned long long)sgn << i;
           // end-of-block choice (jcdctmgr.c:1187-1207): entries appear in position order, strict '<' keeps the first minimum
           float c = best + azd63;
@@ -1165,12 +1180,13 @@ k_trellis_ac_v3(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
     while (__builtin_amdgcn_ballot_w64(e2 > 0) != 0ull) {
       if (e2 > 0) {
         const unsigned inf = info[e2][lane];
-        const int mag = (int)(inf >> 12), pos = (int)(inf & 63u);
+        const int sh = 4 * (e2 - 1);
+        const int mag = SLIM ? (int)((mag4 >> sh) & 15ull) : (int)(inf >> 12), pos = SLIM ? (int)inf : (int)(inf & 63u);
         const int v = ((neg >> pos) & 1ull) ? -mag : mag;
         colh[((cnt >> 2) * 64 + lane) * 4 + (cnt & 3)] = (unsigned short)v;
         pmask |= 1ull << pos;
         cnt++;
-        e2 = (int)((inf >> 6) & 63u);
+        e2 = SLIM ? (int)((back4 >> sh) & 15ull) : (int)((inf >> 6) & 63u);
       }
     }
     if (work) nzmask[gblk] = pmask;
