@@ -48,14 +48,18 @@ PCIE_PEAK_GBS = 63.0   # PCIe Gen5 x16 per GPU (MI355X_MICROARCH.md)
 
 # BASELINE.json configs (SURVEY 8d "Config -> concrete runs").  batch = frames per step per GPU.
 CONFIGS = {
-    "metric": dict(w=3840, h=2160, kw=dict(quality=75, baseline=True), batch=64, steps=500,
+    # (96 frames per encode call since the round's third session: 64 / 96 / 128 frames = 140.1 / 144.1 / 144.3 Gpixels/s -- every
+    # launch of the schedule drains once per call, gpurun_out/r06x)
+    "metric": dict(w=3840, h=2160, kw=dict(quality=75, baseline=True), batch=96, steps=400,
                    name="3840x2160 synthetic RGB, q75 4:2:0 baseline, trellis+deringing+optimal Huffman (cjpeg -quality 75 -baseline)"),
-    "c2": dict(w=1920, h=1080, kw=dict(quality=75, baseline=True), batch=64, steps=1500,
+    # (frames per encode call, third session of round 6: c2 64 / 128 / 256 / 512 = 108.8 / 124.7 / 134.3 / 135.1 Gpixels/s; c3 32 / 48 / 64 =
+    # 25.5 / 26.1 / 26.3; c5t 1 / 2 / 4 / 8 images = 23.7 / 26.3 / 25.8 / 27.1 and c5 1 / 4 / 8 = 40.4 / 41.8 / 42.1: one image stays the case)
+    "c2": dict(w=1920, h=1080, kw=dict(quality=75, baseline=True), batch=256, steps=600,
                name="C2: 1920x1080 synthetic RGB, q75 4:2:0 baseline, trellis on (cjpeg -quality 75 -baseline)"),
-    "c3": dict(w=3840, h=2160, kw=dict(quality=85, sample=(2, 2)), batch=32, steps=150,
+    "c3": dict(w=3840, h=2160, kw=dict(quality=85, sample=(2, 2)), batch=64, steps=100,
                name="C3: 3840x2160 synthetic RGB, q85 4:2:0 progressive + scan search (cjpeg -quality 85 -sample 2x2)"),
-    "c4": dict(w=1920, h=1080, kw=dict(quality=75, baseline=True), batch=128, total=1024, steps=150,
-               name="C4: batch of 1024 x 1920x1080 frames, q75 trellis baseline, sharded over the GPUs (128 per encode call)"),
+    "c4": dict(w=1920, h=1080, kw=dict(quality=75, baseline=True), batch=256, total=1024, steps=150,
+               name="C4: batch of 1024 x 1920x1080 frames, q75 trellis baseline, sharded over the GPUs (256 per encode call)"),
     "c5": dict(w=8192, h=8192, kw=dict(precision=12, baseline=True, notrellis=True, quality=90, sample=(1, 1), restart=1), batch=1, steps=600,
                name="C5: 8192x8192 12-bit, q90 4:4:4, restart interval = MCU row, -notrellis (the reference aborts on 12-bit + trellis, SURVEY F1)"),
     # SURVEY 8f row 4 (completeness path, not a throughput path: an adaptive coder is one dependent chain per scan)
@@ -158,7 +162,7 @@ def other_config_line(M, torch, key, device, budget_s, t_end):
     cfg = CONFIGS[key]
     w, h, kw = cfg["w"], cfg["h"], cfg["kw"]
     twelve = kw.get("precision", 8) == 12
-    B = min(cfg["batch"], 32 if w * h > 4000000 else 64)
+    B = cfg["batch"]
     calls_per_step = 1
     if cfg.get("total"):                       # C4: the whole job of `total` frames = total / batch encode calls of `batch` frames
         B = cfg["batch"]

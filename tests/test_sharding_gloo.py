@@ -90,8 +90,8 @@ def _worker8(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mine = shard.shard_indices(1024, rank, world)          # BASELINE config 4: 1024 frames over the ranks
-    # what bench.py --config c4 does with its share: encode calls of at most 128 frames, seeds 1234 + frame index
-    calls = [(s, min(128, len(mine) - s)) for s in range(0, len(mine), 128)]
+    # what bench.py --config c4 does with its share: encode calls of at most 256 frames (128 = one call at N = 8), seeds 1234 + frame index
+    calls = [(s, min(256, len(mine) - s)) for s in range(0, len(mine), 256)]
     seeds = [1234 + i for i in mine]
     worst = shard.max_over_ranks(0.5 + 0.01 * rank, dist, torch.device("cpu"))
     gathered = [None] * world
