@@ -9,12 +9,12 @@ python tools/rocprof_summary.py "$(db stats)" > "${P}_kernel_stats_batch$BATCH.c
 python tools/pmc_traffic.py "$(db fetch)" "$(db write)" "$BATCH" $((3840*2160*3)) > "${P}_pmc_hbm_traffic_batch$BATCH.json"
 python tools/pmc_sq.py "$(db sq)" $(db sq2) --frames=$BATCH > "${P}_pmc_sq_batch$BATCH.json" 2>/dev/null
 if [ -f "$O/bench_c3.log" ]; then
-  tail -1 "$O/bench_c3.log" > "${P}_c3_bench_batch32.json"
-  python tools/rocprof_summary.py "$(db c3_stats)" > "${P}_c3_kernel_stats_batch32.csv"
-  python tools/pmc_traffic.py "$(db c3_fetch)" "$(db c3_write)" 32 $((3840*2160*3)) > "${P}_c3_pmc_hbm_traffic_batch32.json"
+  tail -1 "$O/bench_c3.log" > "${P}_c3_bench_batch64.json"
+  python tools/rocprof_summary.py "$(db c3_stats)" > "${P}_c3_kernel_stats_batch64.csv"
+  python tools/pmc_traffic.py "$(db c3_fetch)" "$(db c3_write)" 64 $((3840*2160*3)) > "${P}_c3_pmc_hbm_traffic_batch64.json"
 fi
 # traffic of the other configurations: frames per encode call, input bytes per frame (the calibration kernel's input)
-for spec in "c2 64 $((1920*1080*3))" "c4 128 $((1920*1080*3))" "c5 1 $((8192*8192*6))" "c5t 1 $((8192*8192*3))"; do
+for spec in "c2 256 $((1920*1080*3))" "c4 256 $((1920*1080*3))" "c5 1 $((8192*8192*6))" "c5t 1 $((8192*8192*3))"; do
   set -- $spec
   [ -n "$(db $1_fetch)" ] && [ -n "$(db $1_write)" ] && python tools/pmc_traffic.py "$(db $1_fetch)" "$(db $1_write)" $2 $3 > "${P}_$1_pmc_hbm_traffic_batch$2.json"
 done
