@@ -861,7 +861,7 @@ k_trellis_ac_qd(MjhConst C, const MjhQuant *__restrict__ Q, const int16_t *__res
 //    are created in position order, strict '<' keeps the first minimum); the back-track follows entry indices.
 //    Blocks with a quantized magnitude >= 16 (more than 4 candidates) or more than QN queue records go to the work list
 //    of the general kernels above.
-// LDS per wave: QN * (8 + 2) * 64 + 256 bytes (10.25 KB at QN = 16: 15 waves per CU); quantizer rows travel through ds_bpermute.
+// LDS per wave: (QN + 1) * (8 + 2) * 64 + 256 bytes; up to 16 records: (QN + 1) * (8 + 1) * 64 + 256 = 10 048 bytes, 16 waves per CU (SLIM below); quantizer rows travel through ds_bpermute.
 // =============================================================================================
 template <int NC>
 __device__ __forceinline__ void v3_eval(const float4 &rr, float rb, float rhs, float d0, float d1, float d2, float d3, float &lb, int &lk)
