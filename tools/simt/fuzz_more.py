@@ -4,7 +4,7 @@ oracle (development aid: correctness only).  The generator is test_gpu_fuzz.py's
 arithmetic coding (conditioning values, trellis_q_opt with several loops), round 5's sampling-factor sets and scan scripts,
 and, on a share of the cases, the encoder's remaining plan knobs (first-tier capacity and passes of the AC trellis, dense-copy
 capacity, where the DC chains run, the speculative DC rows) -- every plan has to give the same bytes.
-usage: python tools/simt/fuzz_more.py SEED COUNT [--knob-share 0.5] [--ref]        prints one line per failure and a summary
+usage: python tools/simt/fuzz_more.py SEED COUNT [--knob-share 0.5] [--ref] [--gpu]        prints one line per failure and a summary
 (--ref: also the oracle against the reference binary oracle/_ref/refenc on every case)"""
 import os
 import sys
@@ -16,10 +16,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, HERE)
 import numpy as np  # noqa: E402
-import build_simt  # noqa: E402
 import mozjpeg_amd as M  # noqa: E402
-M.LIB_PATH = build_simt.build()
-os.environ.setdefault("SIMT_STRICT", "1")
+if "--gpu" in sys.argv:      # the shipped library on the chip instead of the emulator (run through gpurun): the same cases, the same checks
+    pass
+else:
+    import build_simt  # noqa: E402
+    M.LIB_PATH = build_simt.build()
+    os.environ.setdefault("SIMT_STRICT", "1")
 import oracle_lib as O  # noqa: E402
 
 SAMPLINGS = [(1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (1, 4), (4, 2), (2, 4)]
