@@ -88,7 +88,7 @@ k_prog_scan(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__rest
   // dispatched first and the short chroma scans fill in behind them
   const int img = blockIdx.x;
   const int sidx = scan_list[blockIdx.y];
-  const MjhProgScan sc = scans[sidx];
+  const MjhProgScan &sc = scans[sidx];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
   MjhProgCtl *ct = ctl + img;
   if (prog_skip(sc, ct)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -739,8 +739,15 @@ __device__ __forceinline__ PPRefine pp_refine_block_compact(const int16_t *__res
   R.newm = R.nzm = R.corrm = R.posm = R.tailm = 0; R.own = 0;
   pp_band_nonzeros(qb, kstride, mask, Ss, Se, active, [&](int k, int v) {
     const int a = (v < 0 ? -v : v) >> Al;
-    if (a == 1) { R.newm |= 1ull << k; if (v >= 0) R.posm |= 1ull << k; }
-    else if (a > 1) { R.nzm |= 1ull << k; if (a & 1) R.corrm |= 1ull << k; }
+    // (selects, not branches: `if (a == 1) R.newm |= .. else if (a > 1) R.nzm |= ..` became ONE read-modify-write through a selected
+    // ADDRESS -- the two masks as an array in scratch memory, a scratch load + store per visited coefficient, found in the third
+    // session of round 6 by the kernels' .private_segment_fixed_size)
+    const unsigned long long bit = 1ull << k;
+    const bool one = a == 1, big = a > 1;
+    R.newm |= one ? bit : 0ull;
+    R.posm |= (one && v >= 0) ? bit : 0ull;
+    R.nzm |= big ? bit : 0ull;
+    R.corrm |= (big && (a & 1)) ? bit : 0ull;
   });
   return pp_refine_finish<COUNT>(R, Ss, Se, s_size, hist);
 }
@@ -843,7 +850,7 @@ k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
   const int img = blockIdx.z, li = li0 + blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;   // scans li0.. of the list
   const size_t pair = (size_t)li * gridDim.z + img;   // (the pairs of a scan are contiguous: image index fastest)
   const int sidx = scan_list[li];
-  const MjhProgScan sc = scans[sidx];
+  const MjhProgScan &sc = scans[sidx];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
   const int kind = pp_kind(sc);
   if (SEL == 1 && kind != PP_AC_FIRST) return;
   if (SEL == 2 && kind == PP_AC_FIRST) return;
@@ -1044,7 +1051,7 @@ k_pp_carry(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
   const int img = blockIdx.y, li = blockIdx.x;
   if (threadIdx.x != 0) return;
   const size_t pair = (size_t)li * gridDim.y + img;
-  const MjhProgScan sc = scans[scan_list[li]];
+  const MjhProgScan &sc = scans[scan_list[li]];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
   if (prog_skip(sc, ctl + img)) return;
   const int kind = pp_kind(sc);
   if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) return;
@@ -1066,7 +1073,7 @@ k_pp_cuts(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restri
   __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64], e_bits[MJH_PSTAT_BLOCKS / 64];
   const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const size_t pair = (size_t)li * gridDim.z + img;
-  const MjhProgScan sc = scans[scan_list[li]];
+  const MjhProgScan &sc = scans[scan_list[li]];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
   if (prog_skip(sc, ctl + img)) return;
   const int kind = pp_kind(sc);
   if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) return;
@@ -1098,7 +1105,7 @@ k_pp_resolve(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
 {
   const int img = blockIdx.y, li = blockIdx.x, lane = threadIdx.x;
   const size_t pair = (size_t)li * gridDim.y + img;
-  const MjhProgScan sc = scans[scan_list[li]];
+  const MjhProgScan &sc = scans[scan_list[li]];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
   if (prog_skip(sc, ctl + img)) return;
   const int kind = pp_kind(sc);
   if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) return;
@@ -1157,7 +1164,7 @@ k_pp_runs(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restri
   __shared__ unsigned hist[16];       // EOBRUN symbols: (nbits - 1) << 4, nbits - 1 = 0..14
   const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const size_t pair = (size_t)li * gridDim.z + img;
-  const MjhProgScan sc = scans[scan_list[li]];
+  const MjhProgScan &sc = scans[scan_list[li]];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
   if (prog_skip(sc, ctl + img)) return;
   const int kind = pp_kind(sc);
   if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) return;
@@ -1259,7 +1266,7 @@ k_pp_len(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restric
   const int img = blockIdx.z, li = li0 + blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;   // scans li0.. of the list
   const size_t pair = (size_t)li * gridDim.z + img;   // (the pairs of a scan are contiguous: image index fastest)
   const int sidx = scan_list[li];
-  const MjhProgScan sc = scans[sidx];
+  const MjhProgScan &sc = scans[sidx];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
   const int kind = pp_kind(sc);
   if (SEL == 1 && kind != PP_AC_FIRST) return;
   if (SEL == 2 && kind == PP_AC_FIRST) return;
@@ -1398,7 +1405,7 @@ k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
   const int img = blockIdx.z, li = li0 + blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;   // scans li0.. of the list
   const size_t pair = (size_t)li * gridDim.z + img;   // (the pairs of a scan are contiguous: image index fastest)
   const int sidx = scan_list[li];
-  const MjhProgScan sc = scans[sidx];
+  const MjhProgScan &sc = scans[sidx];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
   const int kind = pp_kind(sc);
   if (SEL == 1 && kind != PP_AC_FIRST) return;
   if (SEL == 2 && kind == PP_AC_FIRST) return;
@@ -1632,7 +1639,7 @@ k_pp_chunk_bits(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__
   __shared__ unsigned sh[4];
   const int img = blockIdx.y, li = blockIdx.x, tid = threadIdx.x;
   const size_t pair = (size_t)li * gridDim.y + img;
-  const MjhProgScan sc = scans[scan_list[li]];
+  const MjhProgScan &sc = scans[scan_list[li]];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
   if (prog_skip(sc, ctl + img)) return;
   const MjhComp cc = C.c[sc.comp[0]];
   const int nchunks = (cc.nblk + MJH_PSTAT_BLOCKS - 1) / MJH_PSTAT_BLOCKS;
@@ -1743,7 +1750,7 @@ k_pp_emit(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restri
   const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;   // the list starts with these scans
   const size_t pair = (size_t)li * gridDim.z + img;
   const int sidx = scan_list[li];
-  const MjhProgScan sc = scans[sidx];
+  const MjhProgScan &sc = scans[sidx];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
   const MjhProgCtl *ct = ctl + img;
   if (prog_skip(sc, ct)) return;
   const MjhComp cc = C.c[sc.comp[0]];
@@ -1792,7 +1799,7 @@ k_pp_finish(const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_
   const int img = blockIdx.y, li = blockIdx.x;
   const size_t pair = (size_t)li * gridDim.y + img;
   const int sidx = scan_list[li];
-  const MjhProgScan sc = scans[sidx];
+  const MjhProgScan &sc = scans[sidx];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
   MjhProgCtl *ct = ctl + img;
   if (ct->error) return;
   if (prog_skip(sc, ct)) return;
@@ -1836,7 +1843,7 @@ k_prog_alloc(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
   MjhProgCtl *ct = ctl + img;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int li = wave; li < nlist; li += 4) {
-    const MjhProgScan sc = scans[scan_list[li]];
+    const MjhProgScan &sc = scans[scan_list[li]];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
     if (prog_skip(sc, ct)) { if (lane == 0) s_bits[li] = 0ull; continue; }   // not coded for this image: an empty stream
     unsigned long long bits = 0;
     if (sc.Ss == 0) {
@@ -1913,7 +1920,7 @@ k_prog_header(const MjhProgScan *__restrict__ scans, const int *__restrict__ sca
 {
   const int img = blockIdx.y;
   const int sidx = scan_list[blockIdx.x];
-  const MjhProgScan sc = scans[sidx];
+  const MjhProgScan &sc = scans[sidx];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
   MjhProgCtl *ct = ctl + img;
   const int lane = threadIdx.x;
   if (ct->error) return;
