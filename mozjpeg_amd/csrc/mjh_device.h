@@ -151,6 +151,20 @@ struct BitWriter {
       nacc -= 32;
     }
   }
+  // a symbol's code (e = size << 16 | code) and its nbits value bits in ONE accumulator step (size + nbits <= 16 + 16): the same bits in
+  // the same order as put(code, size); put(val, nbits) -- half the shifts / compares, and half the dependent chain through acc
+  __device__ __forceinline__ void put_sym(unsigned e, unsigned val, int nbits)
+  {
+    const int n = (int)(e >> 16) + nbits;
+    acc = (acc << n) | (unsigned long long)(((e & 0xFFFFu) << nbits) | (val & ((1u << nbits) - 1u)));
+    nacc += n;
+    if (nacc >= 32) {
+      const unsigned w = (unsigned)(acc >> (nacc - 32));
+      atomicOr(&words[widx], __builtin_bswap32(w));
+      widx++;
+      nacc -= 32;
+    }
+  }
   __device__ __forceinline__ void flush()
   {
     if (nacc > 0) {
@@ -207,6 +221,20 @@ struct BitSink {
   __device__ __forceinline__ void put(unsigned code, int n)
   {
     acc = (acc << n) | (unsigned long long)(code & ((1u << n) - 1u));
+    nacc += n;
+    if (nacc >= 32) {
+      const unsigned w = (unsigned)(acc >> (nacc - 32));
+      atomicOr(&words[widx], __builtin_bswap32(w));
+      widx++;
+      nacc -= 32;
+    }
+  }
+  // a symbol's code (e = size << 16 | code) and its nbits value bits in ONE accumulator step (size + nbits <= 16 + 16): the same bits in
+  // the same order as put(code, size); put(val, nbits) -- half the shifts / compares, and half the dependent chain through acc
+  __device__ __forceinline__ void put_sym(unsigned e, unsigned val, int nbits)
+  {
+    const int n = (int)(e >> 16) + nbits;
+    acc = (acc << n) | (unsigned long long)(((e & 0xFFFFu) << nbits) | (val & ((1u << nbits) - 1u)));
     nacc += n;
     if (nacc >= 32) {
       const unsigned w = (unsigned)(acc >> (nacc - 32));

@@ -2026,8 +2026,7 @@ __device__ __forceinline__ void enc_write_block(const MjhConst &C, const MjhComp
       const int a = v < 0 ? -v : v;
       const int nbv = bitlen((unsigned)a);
       const unsigned e = s_ac[(run << 4) + nbv];
-      bw.put(e & 0xFFFF, (int)(e >> 16));
-      bw.put((unsigned)(v < 0 ? v - 1 : v), nbv);
+      bw.put_sym(e, (unsigned)(v < 0 ? v - 1 : v), nbv);
     });
     if (!real || prev < 63) { const unsigned e = s_ac[0]; bw.put(e & 0xFFFF, (int)(e >> 16)); }
   } else {
@@ -2045,8 +2044,7 @@ __device__ __forceinline__ void enc_write_block(const MjhConst &C, const MjhComp
           const int a = v < 0 ? -v : v;
           const int nb = bitlen((unsigned)a);
           const unsigned e = s_ac[(run << 4) + nb];
-          bw.put(e & 0xFFFF, (int)(e >> 16));
-          bw.put((unsigned)(v < 0 ? v - 1 : v), nb);
+          bw.put_sym(e, (unsigned)(v < 0 ? v - 1 : v), nb);
           run = 0;
         }
       }

@@ -1500,8 +1500,7 @@ k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
         while (r > 15) { const unsigned e = s_tab[0xF0]; bw.put(e & 0xFFFF, (int)(e >> 16)); r -= 16; }
         const int nbits = bitlen((unsigned)a);
         const unsigned e = s_tab[(r << 4) + nbits];
-        bw.put(e & 0xFFFF, (int)(e >> 16));
-        bw.put((unsigned)(v < 0 ? ~a : a), nbits);
+        bw.put_sym(e, (unsigned)(v < 0 ? ~a : a), nbits);
       });
       if (wr) bw.flush();
       continue;
@@ -1538,8 +1537,7 @@ k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
             while (r > 15) { const unsigned e = s_tab[0xF0]; bw.put(e & 0xFFFF, (int)(e >> 16)); r -= 16; }
             const int nbits = bitlen((unsigned)a);
             const unsigned e = s_tab[(r << 4) + nbits];
-            bw.put(e & 0xFFFF, (int)(e >> 16));
-            bw.put((unsigned)(v < 0 ? ~a : a), nbits);
+            bw.put_sym(e, (unsigned)(v < 0 ? ~a : a), nbits);
             r = 0;
           }
         }
@@ -1585,8 +1583,7 @@ k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
         }
         if ((R.nzm >> k) & 1ull) continue;
         const unsigned e = s_tab[(r << 4) + 1];
-        bw.put(e & 0xFFFF, (int)(e >> 16));
-        bw.put((unsigned)((R.posm >> k) & 1ull), 1);
+        bw.put_sym(e, (unsigned)((R.posm >> k) & 1ull), 1);
         put_corr(fb, k);
         fb = k + 1; r = 0;
       }
@@ -1727,8 +1724,7 @@ __device__ __forceinline__ void pp_emit_rounds(unsigned *dst, unsigned bit0, uns
         while (r > 15) { bw.put(zrl & 0xFFFF, (int)(zrl >> 16)); r -= 16; }
         const int nbits = bitlen((unsigned)a);
         const unsigned e = s_tab[(r << 4) + nbits];
-        bw.put(e & 0xFFFF, (int)(e >> 16));
-        bw.put((unsigned)(v < 0 ? ~a : a), nbits);
+        bw.put_sym(e, (unsigned)(v < 0 ? ~a : a), nbits);
       });
     }
     if (blen) bw.flush();
