@@ -850,7 +850,7 @@ k_pp_stats(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
   const int img = blockIdx.z, li = li0 + blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;   // scans li0.. of the list
   const size_t pair = (size_t)li * gridDim.z + img;   // (the pairs of a scan are contiguous: image index fastest)
   const int sidx = scan_list[li];
-  const MjhProgScan &sc = scans[sidx];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
+  const MjhProgScan &sc = scans[sidx];
   const int kind = pp_kind(sc);
   if (SEL == 1 && kind != PP_AC_FIRST) return;
   if (SEL == 2 && kind == PP_AC_FIRST) return;
@@ -1051,7 +1051,7 @@ k_pp_carry(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
   const int img = blockIdx.y, li = blockIdx.x;
   if (threadIdx.x != 0) return;
   const size_t pair = (size_t)li * gridDim.y + img;
-  const MjhProgScan &sc = scans[scan_list[li]];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
+  const MjhProgScan &sc = scans[scan_list[li]];
   if (prog_skip(sc, ctl + img)) return;
   const int kind = pp_kind(sc);
   if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) return;
@@ -1073,7 +1073,7 @@ k_pp_cuts(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restri
   __shared__ unsigned long long ne_bits[MJH_PSTAT_BLOCKS / 64], e_bits[MJH_PSTAT_BLOCKS / 64];
   const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const size_t pair = (size_t)li * gridDim.z + img;
-  const MjhProgScan &sc = scans[scan_list[li]];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
+  const MjhProgScan &sc = scans[scan_list[li]];
   if (prog_skip(sc, ctl + img)) return;
   const int kind = pp_kind(sc);
   if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) return;
@@ -1105,7 +1105,7 @@ k_pp_resolve(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
 {
   const int img = blockIdx.y, li = blockIdx.x, lane = threadIdx.x;
   const size_t pair = (size_t)li * gridDim.y + img;
-  const MjhProgScan &sc = scans[scan_list[li]];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
+  const MjhProgScan &sc = scans[scan_list[li]];
   if (prog_skip(sc, ctl + img)) return;
   const int kind = pp_kind(sc);
   if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) return;
@@ -1164,7 +1164,7 @@ k_pp_runs(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restri
   __shared__ unsigned hist[16];       // EOBRUN symbols: (nbits - 1) << 4, nbits - 1 = 0..14
   const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const size_t pair = (size_t)li * gridDim.z + img;
-  const MjhProgScan &sc = scans[scan_list[li]];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
+  const MjhProgScan &sc = scans[scan_list[li]];
   if (prog_skip(sc, ctl + img)) return;
   const int kind = pp_kind(sc);
   if (kind == PP_DC_FIRST || kind == PP_DC_REFINE) return;
@@ -1266,7 +1266,7 @@ k_pp_len(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restric
   const int img = blockIdx.z, li = li0 + blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;   // scans li0.. of the list
   const size_t pair = (size_t)li * gridDim.z + img;   // (the pairs of a scan are contiguous: image index fastest)
   const int sidx = scan_list[li];
-  const MjhProgScan &sc = scans[sidx];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
+  const MjhProgScan &sc = scans[sidx];
   const int kind = pp_kind(sc);
   if (SEL == 1 && kind != PP_AC_FIRST) return;
   if (SEL == 2 && kind == PP_AC_FIRST) return;
@@ -1405,7 +1405,7 @@ k_pp_write(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restr
   const int img = blockIdx.z, li = li0 + blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;   // scans li0.. of the list
   const size_t pair = (size_t)li * gridDim.z + img;   // (the pairs of a scan are contiguous: image index fastest)
   const int sidx = scan_list[li];
-  const MjhProgScan &sc = scans[sidx];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
+  const MjhProgScan &sc = scans[sidx];
   const int kind = pp_kind(sc);
   if (SEL == 1 && kind != PP_AC_FIRST) return;
   if (SEL == 2 && kind == PP_AC_FIRST) return;
@@ -1636,7 +1636,7 @@ k_pp_chunk_bits(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__
   __shared__ unsigned sh[4];
   const int img = blockIdx.y, li = blockIdx.x, tid = threadIdx.x;
   const size_t pair = (size_t)li * gridDim.y + img;
-  const MjhProgScan &sc = scans[scan_list[li]];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
+  const MjhProgScan &sc = scans[scan_list[li]];
   if (prog_skip(sc, ctl + img)) return;
   const MjhComp cc = C.c[sc.comp[0]];
   const int nchunks = (cc.nblk + MJH_PSTAT_BLOCKS - 1) / MJH_PSTAT_BLOCKS;
@@ -1746,7 +1746,7 @@ k_pp_emit(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__restri
   const int img = blockIdx.z, li = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;   // the list starts with these scans
   const size_t pair = (size_t)li * gridDim.z + img;
   const int sidx = scan_list[li];
-  const MjhProgScan &sc = scans[sidx];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
+  const MjhProgScan &sc = scans[sidx];
   const MjhProgCtl *ct = ctl + img;
   if (prog_skip(sc, ct)) return;
   const MjhComp cc = C.c[sc.comp[0]];
@@ -1795,7 +1795,7 @@ k_pp_finish(const MjhProgScan *__restrict__ scans, const int *__restrict__ scan_
   const int img = blockIdx.y, li = blockIdx.x;
   const size_t pair = (size_t)li * gridDim.y + img;
   const int sidx = scan_list[li];
-  const MjhProgScan &sc = scans[sidx];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
+  const MjhProgScan &sc = scans[sidx];
   MjhProgCtl *ct = ctl + img;
   if (ct->error) return;
   if (prog_skip(sc, ct)) return;
@@ -1839,7 +1839,7 @@ k_prog_alloc(MjhConst C, const MjhProgScan *__restrict__ scans, const int *__res
   MjhProgCtl *ct = ctl + img;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int li = wave; li < nlist; li += 4) {
-    const MjhProgScan &sc = scans[scan_list[li]];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
+    const MjhProgScan &sc = scans[scan_list[li]];
     if (prog_skip(sc, ct)) { if (lane == 0) s_bits[li] = 0ull; continue; }   // not coded for this image: an empty stream
     unsigned long long bits = 0;
     if (sc.Ss == 0) {
@@ -1916,7 +1916,7 @@ k_prog_header(const MjhProgScan *__restrict__ scans, const int *__restrict__ sca
 {
   const int img = blockIdx.y;
   const int sidx = scan_list[blockIdx.x];
-  const MjhProgScan &sc = scans[sidx];      // (a reference: a local copy whose arrays are indexed dynamically lives in scratch)
+  const MjhProgScan &sc = scans[sidx];
   MjhProgCtl *ct = ctl + img;
   const int lane = threadIdx.x;
   if (ct->error) return;

@@ -17,9 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, HERE)
 import numpy as np  # noqa: E402
 import mozjpeg_amd as M  # noqa: E402
-if "--gpu" in sys.argv:      # the shipped library on the chip instead of the emulator (run through gpurun): the same cases, the same checks
-    pass
-else:
+if "--gpu" not in sys.argv:      # (--gpu: the shipped library on the chip instead of the emulator, run through gpurun: the same cases, the same checks)
     import build_simt  # noqa: E402
     M.LIB_PATH = build_simt.build()
     os.environ.setdefault("SIMT_STRICT", "1")
