@@ -582,38 +582,28 @@ def main():
         torch.cuda.synchronize()
         enc.sync()
 
-    # warm-up; its first steps run with every kernel bracketed (profiling level 1) so that the DOMINANT interval of the
-    # schedule is measured on this workload, not assumed: the timed region then brackets exactly that one (level 2)
-    nprobe = min(3, max(0, args.warmup - 2))
+    # Warm-up: W untimed steps, ordered so that the chip is in the timed region's state when the clock starts (round 6, third
+    # session: the files used to be fetched and compared with the reference BETWEEN the warm-up and the timed region -- seconds of
+    # host work with an idle GPU right in front of a region that lasts 0.1 s at the driver's --steps 20; and no warm-up step ran
+    # with two batches in flight).
+    #   step 1      fetches every file; the comparison with the reference follows at once (outside every timed region)
+    #   nprobe      steps with every kernel bracketed (profiling level 1): the DOMINANT interval of the schedule is measured on
+    #               this workload, not assumed; the timed region then brackets exactly that one (level 2)
+    #   the rest    exactly like the timed steps: back to back, two batches in flight, the dominant interval bracketed
+    W = args.warmup
+    nprobe = 2 if W >= 4 else 0            # (the first bracketed step creates the events: two are the least)
     focus, probe = None, {}
-    for _ in range(max(0, args.warmup - 1 - nprobe)):
-        step()
-        enc.sync()     # (the encoder tunes itself from what the previous batch reported: let every warm-up batch finish)
-    if nprobe:
-        enc.set_profiling(1)
-        for i in range(nprobe):
-            if i == 1:
-                enc.set_profiling(1)   # the first bracketed step creates the events: its intervals include that; start over
-            step()
-            enc.sync()
-        probe = dict(enc.kernel_times())
-        main_stream = {k: v for k, v in probe.items() if "side stream" not in k and not k.startswith("join(")}
-        if main_stream:
-            focus = max(main_stream, key=main_stream.get)
-        enc.set_profiling(0)
     jpegs = []
-    late_probe = focus is None and args.warmup >= 1
+    late_probe = nprobe == 0
     if late_probe:
-        # a warm-up too short for the probe steps above (configurations whose step takes seconds): the last warm-up step is
-        # the bracketed one -- its intervals include the creation of the events, which does not change which one is largest
+        # a warm-up too short for probe steps (configurations whose step takes seconds, or --warmup 0: the one step below is then
+        # an extra untimed one): the file-fetching step is the bracketed one -- its intervals include the creation of the events,
+        # which does not change which one is largest
         enc.set_profiling(1)
-    step(keep=jpegs)                       # the last warm-up step also fetches every file for the check below
+    step(keep=jpegs)
     barrier()
     if late_probe:
         probe = dict(enc.kernel_times())
-        main_stream = {k: v for k, v in probe.items() if "side stream" not in k and not k.startswith("join(")}
-        if main_stream:
-            focus = max(main_stream, key=main_stream.get)
         enc.set_profiling(0)
     jpeg_bytes = sum(len(j) for j in jpegs)
     # bit-exactness of EVERY frame against the real reference (outside the timed region)
@@ -627,6 +617,22 @@ def main():
             bitexact["ok"] = bool(bitexact["ok"] and same)
         else:
             bitexact = verify_frames(frames, jpegs, w, h, kw, lim)
+    barrier()              # (every rank waits for rank 0's comparison, so that the remaining warm-up steps run right before the clock starts on all of them)
+    if nprobe:
+        enc.set_profiling(1)
+        for i in range(nprobe):
+            if i == 1:
+                enc.set_profiling(1)   # the first bracketed step creates the events: its intervals include that; start over
+            step()
+            enc.sync()     # (the encoder tunes itself from what the previous batch reported: let every probe batch finish)
+        probe = dict(enc.kernel_times())
+        enc.set_profiling(0)
+    main_stream = {k: v for k, v in probe.items() if "side stream" not in k and not k.startswith("join(")}
+    if main_stream:
+        focus = max(main_stream, key=main_stream.get)
+    enc.set_profiling(2, focus=focus)
+    for _ in range(max(0, W - 1 - nprobe)):
+        step()
 
     # Timed region: K steps back to back.  HIP events bracket only the dominant kernel here (profiling
     # level 2: two events per step on the encoder's stream, read once after the loop), so the event
