@@ -279,6 +279,27 @@ def test_traffic_figures_are_quoted_only_for_the_kernels_they_were_measured_on(m
         assert len(j.get("kernel_source_stamp", "")) == 16 and j.get("profile_head"), p
 
 
+def test_no_kernel_of_a_throughput_path_uses_scratch_memory():
+    """mozjpeg_amd/kernel_isa.json carries every kernel's descriptor resources (tools/kernel_isa.py, rewritten by build()).  Scratch
+    (.amdhsa_private_segment_fixed_size) in a kernel is either a register spill or -- what round 6's third session found in the
+    progressive kernels after four rounds -- a local array / struct the compiler could not keep in registers (a struct copy whose
+    member arrays are indexed dynamically; an if / else-if on two struct members turned into a read-modify-write through a selected
+    address): memory traffic per lane on the hot path that no profile names.  Every kernel outside the two cold ones below stays at 0."""
+    import json
+    real = json.load(open(os.path.join(ROOT, "mozjpeg_amd", "kernel_isa.json")))
+    allowed = {"k_trellis_arith": 1024,       # per-lane DP arrays of the arithmetic coder's trellis (a completeness path, DESIGN 4 K11)
+               "k_prog_scan<1>": 64}          # spills in the walk of progressive scans WITH restart intervals
+    seen = 0
+    for name, k in real["kernels"].items():
+        assert k.get("scratch") is not None and k.get("vgpr"), "kernel_isa.json without resources: run python tools/kernel_isa.py"
+        seen += 1
+        assert k["scratch"] <= allowed.get(name, 0), "%s uses %d bytes of scratch memory" % (name, k["scratch"])
+    assert seen > 100
+    # the metric's dominant kernel keeps the occupancy its design counts on: 16 waves per CU = at most 10 240 bytes of LDS and 128 VGPRs
+    v3 = real["kernels"]["k_trellis_ac_v3<16, 4, true>"]
+    assert v3["lds"] <= 10240 and v3["vgpr"] <= 128
+
+
 def test_kernel_fingerprints_ignore_labels_and_comments_but_not_code():
     """tools/kernel_isa.py: the per-kernel text that gets hashed"""
     import sys
